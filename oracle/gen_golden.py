@@ -1,0 +1,156 @@
+"""Generate golden vectors from the imported reference (run in the build container only).
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+Fixtures are plain float64/complex128 arrays (inputs + expected outputs) produced by *running*
+/root/reference; no reference source is stored.  See SURVEY.md 8(c) for the list (G1..G8).
+"""
+import os
+import sys
+import numpy as np
+
+from ._refimport import import_reference
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1e3))
+
+
+def gen_pk_eh(cp):
+    cosmo = cp.Cosmology()
+    fo = cp.Fourier(cosmo, engine='eisenstein_hu')
+    interp = fo.pk_interpolator()
+    out = {}
+    for n in (1024, 2048):
+        k = np.logspace(-5, 2, n)
+        out['k%d' % n] = k
+        out['pk%d' % n] = interp(k, z=0)
+    save('pk_eh_default', **out)
+    return out
+
+
+def _tables(f, every=1):
+    # 'every' > 1: strided spot samples (keeps the fixture set small); y/u strided by every//4
+    ev4 = max(every // 4, 1)
+    return dict(delta=np.asarray(f.delta), lnxy=np.asarray(f.lnxy), y=np.asarray(f.y)[..., ::ev4], u=np.asarray(f.padded_u)[..., ::ev4],
+                pre=np.asarray(f.padded_prefactor)[..., ::every], post=np.asarray(f.padded_postfactor)[..., ::every],
+                sizes=np.array([f.padded_size, f.padded_size_in_left, f.padded_size_in_right, f.padded_size_out_left, f.padded_size_out_right]))
+
+
+def gen_fftlog_tables(cp):
+    """G1: tables of every FFTlog subclass at N in {1024, 2048} (+ the test_pad case)."""
+    from cosmoprimo import fftlog as fl
+    out = {}
+    for n in (1024, 2048):
+        k = np.logspace(-5, 2, n)
+        cases = {
+            'p2c_l0': fl.PowerToCorrelation(k, ell=0),
+            'p2c_multi': fl.PowerToCorrelation(k, ell=[0, 1, 2, 3, 4]),
+            'p2c_multi_cplx': fl.PowerToCorrelation(k, ell=[0, 1, 2, 3, 4], complex=True),
+            'c2p_l0': fl.CorrelationToPower(k, ell=0),
+            'c2p_l2_q': fl.CorrelationToPower(k, ell=2, q=0.5),
+            'tophat': fl.TophatVariance(k),
+            'gauss': fl.GaussianVariance(k),
+            'hankel_nu0_q1': fl.HankelTransform(k, nu=0, q=1),
+            'hankel_nu2': fl.HankelTransform(k, nu=[0, 2], q=1),
+            'p2c_nolowring': fl.PowerToCorrelation(k, ell=0, lowring=False, xy=1.),
+        }
+        for name, f in cases.items():
+            every = 1 if name in ('p2c_l0', 'tophat') else 16
+            for key, val in _tables(f, every).items():
+                out['n%d_%s_%s' % (n, name, key)] = val
+    x = np.logspace(-3, 3, num=7, endpoint=True)   # reference tests/test_fftlog.py:40-45
+    f = fl.HankelTransform(x, minfolds=3, xy=1, lowring=False)
+    for key, val in _tables(f).items():
+        out['pad7_%s' % key] = val
+    out['pad7_padded_x'], out['pad7_padded_y'] = f.padded_x, f.padded_y
+    # raw FFTlog with generic kernels (TophatKernel, TophatSqKernel ndim=1,2, GaussianKernel, BesselJKernel)
+    x = np.logspace(-4, 3, 200)
+    gen = {
+        'tophat1': fl.TophatKernel(ndim=1), 'tophat3': fl.TophatKernel(ndim=3), 'tophatsq1': fl.TophatSqKernel(ndim=1),
+        'tophatsq2': fl.TophatSqKernel(ndim=2), 'gaussian': fl.GaussianKernel(), 'besselj1': fl.BesselJKernel(1.5),
+        'sphbesselj3': fl.SphericalBesselJKernel(3),
+    }
+    for name, kern in gen.items():
+        f = fl.FFTlog(x, kern, q=0.7, minfolds=3)
+        for key, val in _tables(f).items():
+            out['gen200_%s_%s' % (name, key)] = val
+    save('fftlog_tables', **out)
+
+
+def gen_loggamma():
+    """G2: scipy loggamma/gamma on the arguments the kernels use + a stress grid."""
+    from scipy.special import loggamma, gamma
+    rng = np.random.default_rng(42)
+    re = np.concatenate([rng.uniform(-2.5, 3., 1500), np.linspace(-2.45, 2.95, 100)])
+    im = np.concatenate([rng.uniform(0., 450., 1000), rng.uniform(0., 3., 500), np.zeros(50), rng.uniform(-450, 0., 50)])
+    z = re + 1j * im
+    # exact arguments of the N=2048 p2c ell=0 u-table: 0.5*(nu + q + i t) and 0.5*(3 + nu - q - i t)
+    d = np.log(1e7) / 2047
+    t = 2 * np.pi / 4096 / d * np.arange(2049)
+    zz = np.concatenate([0.5 * (1.5 + 1j * t), 0.5 * (1.5 - 1j * t), 0.5 * (1.5 - 4 + 1j * t), 0.5 * (5 - 1.5 - 1j * t)])
+    z = np.concatenate([z, zz])
+    zg = np.concatenate([rng.uniform(0.05, 3., 200) + 1j * rng.uniform(-40., 40., 200), 0.5 * (1.5 + 1j * t[::8])])
+    save('loggamma', z=z, loggamma=loggamma(z), zg=zg, gamma=gamma(zg))
+
+
+def gen_fftlog_transforms(cp, pks):
+    """G3: transforms of the default EH P(k) (configs 1 and 2) + config-2 batch rows + analytic Hankel pair."""
+    from cosmoprimo import fftlog as fl
+    from .workloads import config2_rows
+    out = {}
+    for n in (1024, 2048):
+        k, pk = pks['k%d' % n], pks['pk%d' % n]
+        f = fl.PowerToCorrelation(k, ell=0, lowring=True)
+        for name, extrap in [('zero', 0), ('edge', 'edge'), ('log', 'log'), ('mixed', ('log', 0.)), ('const', (1.5, 'edge'))]:
+            s, xi = f(pk, extrap=extrap)
+            out['n%d_p2c_l0_%s' % (n, name)] = xi
+        out['n%d_p2c_l0_s' % n] = s
+        out['n%d_p2c_l0_keep' % n] = f(pk, extrap='log', keep_padding=True)[1]
+        fm = fl.PowerToCorrelation(k, ell=[0, 2, 4], lowring=True)
+        out['n%d_p2c_l024' % n] = fm(pk)[1]
+        out['n%d_p2c_l024_s' % n] = fm(pk)[0]
+        ft = fl.TophatVariance(k)
+        out['n%d_tophat' % n] = ft(pk)[1]
+        out['n%d_tophat_r' % n] = ft(pk)[0]
+        fc = fl.CorrelationToPower(s, ell=0, lowring=True)
+        out['n%d_c2p_l0' % n] = fc(out['n%d_p2c_l0_zero' % n])[1]
+        out['n%d_c2p_l0_k' % n] = fc(out['n%d_p2c_l0_zero' % n])[0]
+    # config-2 batch rows 0, 1, 49999, 99999
+    k, pk = pks['k2048'], pks['pk2048']
+    f = fl.PowerToCorrelation(k, ell=0, lowring=True)
+    idx = np.array([0, 1, 49999, 99999])
+    rows = np.concatenate([config2_rows(k, pk, i, i + 1) for i in idx])
+    out['config2_idx'] = idx
+    out['config2_xi'] = f(rows)[1]
+    # analytic Hankel pair (reference tests/test_fftlog.py:58-81), incl. inv() and batched input
+    x = np.logspace(-3, 3, num=60, endpoint=False)
+    fx = 1 / (1 + x**2)**1.5
+    hf = fl.HankelTransform(x, nu=0, q=1, lowring=True)
+    y, g = hf(fx, extrap='log')
+    out['hankel60_x'], out['hankel60_f'], out['hankel60_y'], out['hankel60_g'] = x, fx, y, g
+    hf.inv()
+    x2, f2 = hf(g, extrap='log')
+    out['hankel60_inv_x'], out['hankel60_inv_f'] = x2, f2
+    for key, val in _tables(hf).items():
+        out['hankel60_inv_%s' % key] = val
+    save('fftlog_transforms', **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cp = import_reference()
+    which = sys.argv[1:] or ['fftlog']
+    if 'fftlog' in which:
+        pks = gen_pk_eh(cp)
+        gen_fftlog_tables(cp)
+        gen_loggamma()
+        gen_fftlog_transforms(cp, pks)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(GOLDEN, name + '.npz')))
+        return cache[name]
+    return load
+
+
+def tilted_err(g, ref, y, q):
+    """Tilted-space norm-wise error max|d(g y^q)|/max|g y^q| (SURVEY.md 8(d) tolerance (i))."""
+    w = np.asarray(y) ** q
+    return np.abs((g - ref) * w).max() / np.abs(ref * w).max()
