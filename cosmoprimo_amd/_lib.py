@@ -1,0 +1,109 @@
+"""ctypes binding of libcosmoprimo_amd.so (C ABI declared in include/cosmoprimo_amd.h).
+
+The library is the product: there is no Python/CPU fallback.  If it is missing (or its ABI does
+not match) importing any compute entry point raises, loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcosmoprimo_amd.so')
+ABI_VERSION = 1
+
+CP_OK, CP_EINVAL, CP_EUNSUPPORTED, CP_EDEVICE, CP_ENOMEM = range(5)
+EXTRAP_CONSTANT, EXTRAP_EDGE, EXTRAP_LOGLOG = range(3)
+(KERNEL_BESSEL_J, KERNEL_SPHERICAL_BESSEL_J, KERNEL_TOPHAT, KERNEL_TOPHAT_SQ, KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_SQ) = range(6)
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); every symbol of include/cosmoprimo_amd.h
+SIGNATURES = {
+    'cp_abi_version': (ctypes.c_int, []),
+    'cp_last_error': (ctypes.c_char_p, []),
+    'cp_device_count': (ctypes.c_int, []),
+    'cp_loggamma': (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_longlong]),
+    'cp_gamma': (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_longlong]),
+    'cp_kernel_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_longlong]),
+    'cp_fftlog_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                            _c_double_p, _c_double_p, ctypes.c_int]),
+    'cp_fftlog_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double,
+                                        ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]),
+    'cp_fftlog_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_fftlog_plan_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, _c_int_p, _c_int_p, _c_int_p]),
+}
+
+_lib = None
+
+
+class LibraryError(RuntimeError):
+    """The HIP library is missing or unusable."""
+
+
+def load():
+    """Load (once) and return the shared library; raise :class:`LibraryError` if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise LibraryError('{} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+                           '`make -C cosmoprimo_amd/csrc -j8` (hipcc, gfx950). There is no CPU fallback.'.format(LIB_PATH))
+    try:
+        # torch ships its own libamdhip64.so.7; import it first so the HIP runtime is shared with torch's allocator/streams
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise LibraryError('{} does not export {} (stale build?)'.format(LIB_PATH, name))
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.cp_abi_version() != ABI_VERSION:
+        raise LibraryError('ABI version mismatch: library {}, bindings {}'.format(lib.cp_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status):
+    """Map a status code onto the exception class the reference raises for the same condition."""
+    if status == CP_OK:
+        return
+    msg = load().cp_last_error().decode('utf-8', 'replace')
+    if status == CP_EINVAL:
+        raise ValueError(msg)
+    if status == CP_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if status == CP_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+def as_double_p(array):
+    return array.ctypes.data_as(_c_double_p)
+
+
+def _complex_map(fn_name, z, *head):
+    z = np.ascontiguousarray(z, dtype='c16')
+    out = np.empty_like(z)
+    fn = getattr(load(), fn_name)
+    check(fn(*head, as_double_p(z.view('f8')), as_double_p(out.view('f8')), z.size))
+    return out
+
+
+def loggamma(z):
+    """Principal branch of log Gamma on complex ``z`` (host; replaces scipy.special.loggamma in table setup)."""
+    return _complex_map('cp_loggamma', z)
+
+
+def gamma(z):
+    return _complex_map('cp_gamma', z)
+
+
+def kernel_eval(kind, param, z):
+    """Mellin kernel U_K(z) (reference cosmoprimo/fftlog.py:666-766) on complex ``z``."""
+    return _complex_map('cp_kernel_eval', z, int(kind), float(param))

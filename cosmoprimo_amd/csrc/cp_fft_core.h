@@ -1,0 +1,298 @@
+// cp_fft_core.h -- in-register radix butterflies and the pass structure of the fused FFTLog kernel.
+//
+// This header is device code for gfx950 (included by cp_fftlog.hip).  Every function is also a
+// valid host function so that tests/host_emu can run the *same* index / twiddle / digit-order
+// logic thread-by-thread on the CPU (no GPU in the build container).  The host emulation is a
+// unit-test harness only; it is not part of libcosmoprimo_amd.so.
+//
+// Math (reference cosmoprimo/fftlog.py:228-241, 538-544):
+//   g = irfft(conj(rfft(a * pre) * u), n=Np) * post
+// irfft(conj X)[n] = irfft(X)[-n], so with U the Hermitian extension of u (DC and Nyquist bins
+// real, as numpy's c2r assumes) g = FFT(FFT(a * pre) * U) / Np -- two *forward* complex FFTs and a
+// complex-linear map.  Two real rows a, b are therefore packed as z = a + i b and transformed
+// together: Re -> g_a, Im -> g_b, with no real-FFT split/merge step.
+// FFT #1 is decimation-in-frequency (natural in, digit-reversed out), U is stored in that
+// digit-reversed order, FFT #2 is the transposed (decimation-in-time) network: no reordering pass,
+// and the last DIF pass / first DIT pass share registers (no LDS round trip in the middle).
+#pragma once
+
+#if defined(__HIPCC__)
+#define CP_HD __host__ __device__ __forceinline__
+#else
+#define CP_HD inline
+#endif
+
+namespace cpfft {
+
+struct cplx {
+    double re, im;
+};
+
+CP_HD cplx cmul(const cplx a, const cplx b) {
+    cplx r;
+    r.re = a.re * b.re - a.im * b.im;
+    r.im = a.re * b.im + a.im * b.re;
+    return r;
+}
+
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+
+// Pass plan: radices R_0 = P, then min(P, remaining) until the product is NP.
+// len(i) = sub-FFT length handled by pass i (L_0 = NP), radix(i) = R_i, M_i = L_i / R_i.
+template <int NP, int P>
+struct Plan {
+    static_assert((NP & (NP - 1)) == 0 && (P & (P - 1)) == 0 && P <= NP && P >= 2, "powers of two");
+    static constexpr int T = NP / P;  // threads per packed pair of rows
+    static constexpr int count() {
+        int n = 0, rem = NP;
+        while (rem > 1) {
+            rem /= cmin(P, rem);
+            ++n;
+        }
+        return n;
+    }
+    static constexpr int NPASS = count();
+    static constexpr int len(int i) {
+        int rem = NP;
+        for (int k = 0; k < i; ++k) rem /= cmin(P, rem);
+        return rem;
+    }
+    static constexpr int radix(int i) { return cmin(P, len(i)); }
+    // offset of pass i in the concatenated twiddle table (pass i holds len(i) entries [s][j])
+    static constexpr int tw_offset(int i) {
+        int off = 0;
+        for (int k = 0; k < i; ++k) off += len(k);
+        return off;
+    }
+    static constexpr int TW_TOTAL = tw_offset(NPASS);
+};
+
+// LDS slot swizzle: XOR the low 4 bits of the element index with bits 4..7.  With 16-byte complex
+// slots this makes the radix-16 access patterns of all three pass shapes (stride 1, stride 16 in
+// blocks of 256, 16 contiguous per lane) conflict-free for ds_read_b128 / ds_write_b128.
+template <int NP>
+CP_HD int swz(int p) {
+    if (NP >= 256) return p ^ ((p >> 4) & 15);
+    return p;
+}
+
+// ---- small DFTs, forward sign exp(-2 pi i r s / R), natural order in and out -------------------
+template <int R>
+struct Dft;
+
+template <>
+struct Dft<2> {
+    static CP_HD void run(cplx* x) {
+        const cplx a = x[0], b = x[1];
+        x[0].re = a.re + b.re;
+        x[0].im = a.im + b.im;
+        x[1].re = a.re - b.re;
+        x[1].im = a.im - b.im;
+    }
+};
+
+CP_HD void dft4(cplx& x0, cplx& x1, cplx& x2, cplx& x3) {
+    const double s0r = x0.re + x2.re, s0i = x0.im + x2.im;
+    const double d0r = x0.re - x2.re, d0i = x0.im - x2.im;
+    const double s1r = x1.re + x3.re, s1i = x1.im + x3.im;
+    const double d1r = x1.re - x3.re, d1i = x1.im - x3.im;
+    x0.re = s0r + s1r;
+    x0.im = s0i + s1i;
+    x2.re = s0r - s1r;
+    x2.im = s0i - s1i;
+    x1.re = d0r + d1i;  // d0 - i d1
+    x1.im = d0i - d1r;
+    x3.re = d0r - d1i;  // d0 + i d1
+    x3.im = d0i + d1r;
+}
+
+template <>
+struct Dft<4> {
+    static CP_HD void run(cplx* x) { dft4(x[0], x[1], x[2], x[3]); }
+};
+
+// multiply by w_16^K = exp(-2 pi i K / 16), K compile-time
+template <int K>
+CP_HD void mul_w16(cplx& a) {
+    constexpr double C1 = 0.92387953251128673848;  // cos(pi/8)
+    constexpr double S1 = 0.38268343236508978178;  // sin(pi/8)
+    constexpr double H = 0.70710678118654752440;   // sqrt(1/2)
+    const double r = a.re, i = a.im;
+    if (K == 0) {
+    } else if (K == 1) {  // (C1, -S1)
+        a.re = r * C1 + i * S1;
+        a.im = i * C1 - r * S1;
+    } else if (K == 2) {  // (H, -H)
+        a.re = (r + i) * H;
+        a.im = (i - r) * H;
+    } else if (K == 3) {  // (S1, -C1)
+        a.re = r * S1 + i * C1;
+        a.im = i * S1 - r * C1;
+    } else if (K == 4) {  // -i
+        a.re = i;
+        a.im = -r;
+    } else if (K == 6) {  // (-H, -H)
+        a.re = (i - r) * H;
+        a.im = -(r + i) * H;
+    } else if (K == 9) {  // (-C1, S1)
+        a.re = -(r * C1 + i * S1);
+        a.im = r * S1 - i * C1;
+    }
+}
+
+template <>
+struct Dft<8> {
+    // 8 = 2 x 4: r = r0 + 2 r1, s = s0 + 4 s1;  X[s0 + 4 s1] = sum_r0 w8^(r0 s0) w2^(r0 s1) sum_r1 x[r0 + 2 r1] w4^(r1 s0)
+    static CP_HD void run(cplx* x) {
+        cplx e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+        cplx o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+        dft4(e0, e1, e2, e3);
+        dft4(o0, o1, o2, o3);
+        mul_w16<2>(o1);  // w8^1
+        mul_w16<4>(o2);  // w8^2
+        mul_w16<6>(o3);  // w8^3
+        x[0].re = e0.re + o0.re; x[0].im = e0.im + o0.im; x[4].re = e0.re - o0.re; x[4].im = e0.im - o0.im;
+        x[1].re = e1.re + o1.re; x[1].im = e1.im + o1.im; x[5].re = e1.re - o1.re; x[5].im = e1.im - o1.im;
+        x[2].re = e2.re + o2.re; x[2].im = e2.im + o2.im; x[6].re = e2.re - o2.re; x[6].im = e2.im - o2.im;
+        x[3].re = e3.re + o3.re; x[3].im = e3.im + o3.im; x[7].re = e3.re - o3.re; x[7].im = e3.im - o3.im;
+    }
+};
+
+// inner DFT4 with first and last input structurally zero: (0, x1, x2, 0) -> y0..y3 written to the four slots
+CP_HD void dft4_mid(cplx& x0, cplx& x1, cplx& x2, cplx& x3) {
+    const cplx a = x1, b = x2;
+    x0.re = b.re + a.re;
+    x0.im = b.im + a.im;
+    x2.re = b.re - a.re;
+    x2.im = b.im - a.im;
+    x1.re = a.im - b.re;  // -b - i a
+    x1.im = -b.im - a.re;
+    x3.re = -b.re - a.im;  // -b + i a
+    x3.im = a.re - b.im;
+}
+
+// 16 = 4 x 4: r = r0 + 4 r1, s = s0 + 4 s1;
+// X[s0 + 4 s1] = sum_r0 w16^(r0 s0) w4^(r0 s1) sum_r1 x[r0 + 4 r1] w4^(r1 s0)
+// After the inner DFT4s (over r1, one per r0) slot x[r0 + 4 s0] holds the partial sum for (r0, s0).
+CP_HD void dft16_outer(cplx* x) {
+    // twiddles w16^(r0 s0) on x[r0 + 4 s0]
+    mul_w16<1>(x[1 + 4]);
+    mul_w16<2>(x[1 + 8]);
+    mul_w16<3>(x[1 + 12]);
+    mul_w16<2>(x[2 + 4]);
+    mul_w16<4>(x[2 + 8]);
+    mul_w16<6>(x[2 + 12]);
+    mul_w16<3>(x[3 + 4]);
+    mul_w16<6>(x[3 + 8]);
+    mul_w16<9>(x[3 + 12]);
+    // outer DFT4 over r0 for each s0 (in place on x[4 s0 + r0], slot r0 := s1)
+    dft4(x[0], x[1], x[2], x[3]);
+    dft4(x[4], x[5], x[6], x[7]);
+    dft4(x[8], x[9], x[10], x[11]);
+    dft4(x[12], x[13], x[14], x[15]);
+    // x[4 s0 + s1] holds X[s0 + 4 s1]: 4x4 transpose (register renaming after unrolling)
+    cplx t;
+    t = x[1]; x[1] = x[4]; x[4] = t;
+    t = x[2]; x[2] = x[8]; x[8] = t;
+    t = x[3]; x[3] = x[12]; x[12] = t;
+    t = x[6]; x[6] = x[9]; x[9] = t;
+    t = x[7]; x[7] = x[13]; x[13] = t;
+    t = x[11]; x[11] = x[14]; x[14] = t;
+}
+
+template <>
+struct Dft<16> {
+    static CP_HD void run(cplx* x) {
+        dft4(x[0], x[4], x[8], x[12]);
+        dft4(x[1], x[5], x[9], x[13]);
+        dft4(x[2], x[6], x[10], x[14]);
+        dft4(x[3], x[7], x[11], x[15]);
+        dft16_outer(x);
+    }
+};
+
+// radix-16 butterfly whose points 0..3 and 12..15 are structural zeros (zero-padded FFTLog input,
+// n = NP/2): every inner DFT4 sees (0, x1, x2, 0) and costs 8 instead of 16 additions.
+struct Dft16ZeroPadded {
+    static CP_HD void run(cplx* x) {
+        dft4_mid(x[0], x[4], x[8], x[12]);
+        dft4_mid(x[1], x[5], x[9], x[13]);
+        dft4_mid(x[2], x[6], x[10], x[14]);
+        dft4_mid(x[3], x[7], x[11], x[15]);
+        dft16_outer(x);
+    }
+};
+
+// ---- one pass over the thread's P points ---------------------------------------------------------
+// Pass I works on sub-FFTs of length L = len(I) with radix R: butterfly beta = (block b, offset j),
+// j < M = L / R, touches elements b L + j + M r, r < R.  A thread owns butterflies t + T i.
+// Twiddle w_L^(j s) sits at tw[s * M + j] (pass-local table).  DIF: butterfly then twiddle on
+// outputs; DIT (the transposed network): twiddle on inputs then butterfly.
+template <int NP, int P, int I>
+struct Pass {
+    using PL = Plan<NP, P>;
+    static constexpr int R = PL::radix(I);
+    static constexpr int L = PL::len(I);
+    static constexpr int M = L / R;
+    static constexpr int NB = P / R;
+    static constexpr int T = PL::T;
+
+    static CP_HD int elem(int t, int i, int r) {
+        const int beta = t + T * i;
+        const int b = beta / M, j = beta % M;
+        return b * L + j + M * r;
+    }
+    static CP_HD int joff(int t, int i) { return (t + T * i) % M; }
+
+    static CP_HD void load_lds(int t, const cplx* lds, cplx* x) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) x[i * R + r] = lds[swz<NP>(elem(t, i, r))];
+    }
+    static CP_HD void store_lds(int t, cplx* lds, const cplx* x) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int r = 0; r < R; ++r) lds[swz<NP>(elem(t, i, r))] = x[i * R + r];
+    }
+    static CP_HD void twiddle(int t, const cplx* tw, cplx* x) {
+        if (M == 1) return;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = joff(t, i);
+#pragma unroll
+            for (int s = 1; s < R; ++s) x[i * R + s] = cmul(x[i * R + s], tw[s * M + j]);
+        }
+    }
+    static CP_HD void butterflies(cplx* x) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Dft<R>::run(x + i * R);
+    }
+    static CP_HD void dif(int t, const cplx* tw, cplx* x) {
+        butterflies(x);
+        twiddle(t, tw + PL::tw_offset(I), x);
+    }
+    static CP_HD void dit(int t, const cplx* tw, cplx* x) {
+        twiddle(t, tw + PL::tw_offset(I), x);
+        butterflies(x);
+    }
+};
+
+// Frequency index held at LDS position pos after the full DIF network (digit reversal for the
+// mixed-radix plan).  Host-side only (used to lay out U).
+template <int NP, int P>
+inline int dif_freq_of_pos(int pos) {
+    using PL = Plan<NP, P>;
+    int k = 0, mult = 1, rem = pos;
+    for (int i = 0; i < PL::NPASS; ++i) {
+        const int R = PL::radix(i), M = PL::len(i) / R;
+        const int s = rem / M;
+        rem = rem % M;
+        k += s * mult;
+        mult *= R;
+    }
+    return k;
+}
+
+}  // namespace cpfft

@@ -1,0 +1,202 @@
+// cp_fftlog_body.h -- the per-thread phases of the fused FFTLog kernel (device code for gfx950;
+// also host-compilable for tests/host_emu, see cp_fft_core.h).
+//
+// One workgroup of T = NP/P threads transforms one *pair* of rows (z = a + i b) per iteration:
+//   phase 0            : HBM -> registers (pad + extrapolate + x prefactor), DIF pass 0, -> LDS
+//   phases 1..NPASS-2  : LDS -> DIF pass I -> LDS (in place)
+//   phase NPASS-1      : LDS -> last DIF pass, x U (digit-reversed table), first DIT pass -> LDS
+//   phases ..2NPASS-3  : LDS -> DIT pass I -> LDS
+//   phase 2NPASS-2     : LDS -> DIT pass 0, x postfactor, crop, registers -> HBM
+// Reference semantics: cosmoprimo/fftlog.py:198-241 (FFTlog.__call__) and :436-505 (pad).
+#pragma once
+#include <math.h>
+
+#include "cp_fft_core.h"
+
+namespace cpfft {
+
+enum { CP_EXTRAP_CONST = 0, CP_EXTRAP_EDGE = 1, CP_EXTRAP_LOG = 2 };
+
+// Input front ends (how phase 0 pads the row):
+//   IN_GENERIC   any n / NP, constant or edge padding: clamped (always valid) loads + selects, branch-free
+//   IN_LOG       IN_GENERIC plus 'log' extrapolation (a pow() per padded element)
+//   IN_HALF      n == NP/2 and P == 16: the row occupies exactly r in [4, 12) of every thread's 16
+//                points (in_left = NP/4 = 4T, fftlog.py:149-153 with minfolds=2 and n a power of two);
+//                constant or edge padding
+//   IN_HALF_ZERO IN_HALF with zero padding (the reference default extrap=0): padded points are never formed
+// Output back ends:
+//   OUT_GENERIC  bounds-checked crop (any out_off / n_out, incl. keep_padding)
+//   OUT_HALF     n == NP/2, cropped output: exactly s in [4, 12) (out_left = NP/4)
+enum { IN_GENERIC = 0, IN_LOG = 1, IN_HALF = 2, IN_HALF_ZERO = 3 };
+enum { OUT_GENERIC = 0, OUT_HALF = 1 };
+
+struct FftlogArgs {
+    const double* in;   // (nbatch, nker, n) row-major
+    double* out;        // (nbatch, nker, n_out)
+    long long nbatch;   // batch items; each holds nker rows
+    int nker;           // transforms "in parallel" (reference FFTlog.nparallel)
+    int n;              // input row length
+    int in_left;        // left padding of the input (fftlog.py:152)
+    int out_off;        // first padded output index kept (fftlog.py:235), 0 when keep_padding
+    int n_out;          // output row length (n or NP)
+    int ext_l, ext_r;   // CP_EXTRAP_*
+    double val_l, val_r;
+    const double* pre;  // (nker, NP) padded prefactor
+    const double* post; // (nker, NP) padded postfactor
+    const cplx* u;      // (nker, NP) Hermitian-extended u / NP in thread layout [(i R + s) T + t]
+    const cplx* tw;     // concatenated per-pass twiddles, Plan::tw_offset
+};
+
+template <int NP, int P, int IN_MODE = IN_LOG, int OUT_MODE = OUT_GENERIC>
+struct Fftlog {
+    using PL = Plan<NP, P>;
+    static constexpr int T = PL::T;
+    static constexpr int NPASS = PL::NPASS;
+    static constexpr int NPH = 2 * NPASS - 1;  // phases separated by workgroup barriers
+    static constexpr int LAST = NPASS - 1;
+    static constexpr bool HALF_IN = IN_MODE == IN_HALF || IN_MODE == IN_HALF_ZERO;
+    static_assert((!HALF_IN && OUT_MODE != OUT_HALF) || (P == 16 && NPASS > 1), "HALF modes need P == 16 and NP > 16");
+
+    // padded input element j of one row (reference pad(): fftlog.py:483-505); branch-free for constant / edge
+    static CP_HD double fetch(const double* __restrict__ a, int j, const FftlogArgs& A) {
+        const int idx = j - A.in_left;
+        const int cl = idx < 0 ? 0 : (idx >= A.n ? A.n - 1 : idx);
+        double v = a[cl];  // in range: the sample; out of range: the edge value
+        if (idx < 0) {
+            if (A.ext_l == CP_EXTRAP_CONST) v = A.val_l;
+            if (IN_MODE == IN_LOG && A.ext_l == CP_EXTRAP_LOG) v = v * pow(a[1] / v, (double)idx);
+        } else if (idx >= A.n) {
+            if (A.ext_r == CP_EXTRAP_CONST) v = A.val_r;
+            if (IN_MODE == IN_LOG && A.ext_r == CP_EXTRAP_LOG) v = v / pow(a[A.n - 2] / v, (double)(idx - A.n + 1));
+        }
+        return v;
+    }
+
+    // phase 0 front end: x[r] = (a[j], b[j]) * pre[j], j = t + T r  (pass 0: R = P, M = T)
+    static CP_HD void load_input(int t, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
+                                 const double* __restrict__ pre, cplx* x) {
+        if constexpr (HALF_IN) {
+            double va[8], vb[8], f[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                va[r] = ra[t + T * r];
+                vb[r] = rb[t + T * r];
+                f[r] = pre[t + T * (r + 4)];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                x[r + 4].re = va[r] * f[r];
+                x[r + 4].im = has_b ? vb[r] * f[r] : 0.;
+            }
+            if constexpr (IN_MODE == IN_HALF) {
+                const double la = A.ext_l == CP_EXTRAP_CONST ? A.val_l : ra[0];
+                const double lb = A.ext_l == CP_EXTRAP_CONST ? A.val_l : rb[0];
+                const double ha = A.ext_r == CP_EXTRAP_CONST ? A.val_r : ra[A.n - 1];
+                const double hb = A.ext_r == CP_EXTRAP_CONST ? A.val_r : rb[A.n - 1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double fl = pre[t + T * r], fh = pre[t + T * (r + 12)];
+                    x[r].re = la * fl;
+                    x[r].im = has_b ? lb * fl : 0.;
+                    x[r + 12].re = ha * fh;
+                    x[r + 12].im = has_b ? hb * fh : 0.;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[r] = x[r + 12] = cplx{0., 0.};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const int j = t + T * r;
+                const double f = pre[j];
+                x[r].re = fetch(ra, j, A) * f;
+                x[r].im = has_b ? fetch(rb, j, A) * f : 0.;
+            }
+        }
+    }
+
+    // last phase back end: natural-order outputs n = t + T s -> crop, x post, split Re/Im to the two rows
+    static CP_HD void store_output(int t, const FftlogArgs& A, double* __restrict__ oa, double* __restrict__ ob, bool has_b,
+                                   const double* __restrict__ post, const cplx* x) {
+        if constexpr (OUT_MODE == OUT_HALF) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const double f = post[t + T * (s + 4)];
+                oa[t + T * s] = x[s + 4].re * f;
+                if (has_b) ob[t + T * s] = x[s + 4].im * f;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const int nidx = t + T * s;
+                const int o = nidx - A.out_off;
+                if (o >= 0 && o < A.n_out) {
+                    const double f = post[nidx];
+                    oa[o] = x[s].re * f;
+                    if (has_b) ob[o] = x[s].im * f;
+                }
+            }
+        }
+    }
+
+    static CP_HD void mul_u(int t, const cplx* __restrict__ u, cplx* x) {
+#pragma unroll
+        for (int e = 0; e < P; ++e) x[e] = cmul(x[e], u[e * T + t]);
+    }
+
+    // one phase for thread t; lds holds NP complex slots (unused when NPASS == 1).
+    // rb / ob always point at valid rows (the caller aliases them to row a when the pair is incomplete).
+    template <int PH>
+    static CP_HD void phase(int t, const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b, int ker,
+                            cplx* lds) {
+        cplx x[P];
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Launder the thread index once per phase: stops the compiler from sharing (and keeping
+        // live, or hoisting out of the persistent loop) the per-phase LDS / table addresses across
+        // phases, which otherwise costs >100 VGPRs and spills.  Addresses are cheap to recompute.
+        asm volatile("" : "+v"(t));
+#endif
+        const double* pre = A.pre + (long long)ker * NP;
+        const double* post = A.post + (long long)ker * NP;
+        const cplx* u = A.u + (long long)ker * NP;
+        if constexpr (NPASS == 1) {
+            load_input(t, A, ra, rb, has_b, pre, x);
+            Pass<NP, P, 0>::butterflies(x);
+            mul_u(t, u, x);
+            Pass<NP, P, 0>::butterflies(x);
+            store_output(t, A, oa, ob, has_b, post, x);
+        } else if constexpr (PH == 0) {
+            load_input(t, A, ra, rb, has_b, pre, x);
+            if constexpr (IN_MODE == IN_HALF_ZERO) {
+                Dft16ZeroPadded::run(x);  // points 0..3 and 12..15 are structural zeros
+            } else {
+                Pass<NP, P, 0>::butterflies(x);
+            }
+            Pass<NP, P, 0>::twiddle(t, A.tw + PL::tw_offset(0), x);
+            Pass<NP, P, 0>::store_lds(t, lds, x);
+        } else if constexpr (PH < LAST) {
+            constexpr int I = (PH < LAST) ? PH : 0;
+            Pass<NP, P, I>::load_lds(t, lds, x);
+            Pass<NP, P, I>::dif(t, A.tw, x);
+            Pass<NP, P, I>::store_lds(t, lds, x);
+        } else if constexpr (PH == LAST) {
+            Pass<NP, P, LAST>::load_lds(t, lds, x);
+            Pass<NP, P, LAST>::butterflies(x);  // M == 1: no twiddles
+            mul_u(t, u, x);
+            Pass<NP, P, LAST>::butterflies(x);
+            Pass<NP, P, LAST>::store_lds(t, lds, x);
+        } else if constexpr (PH < NPH - 1) {
+            constexpr int I = (PH > LAST && PH < NPH - 1) ? (NPH - 1 - PH) : 0;
+            Pass<NP, P, I>::load_lds(t, lds, x);
+            Pass<NP, P, I>::dit(t, A.tw, x);
+            Pass<NP, P, I>::store_lds(t, lds, x);
+        } else {
+            Pass<NP, P, 0>::load_lds(t, lds, x);
+            Pass<NP, P, 0>::dit(t, A.tw, x);
+            store_output(t, A, oa, ob, has_b, post, x);
+        }
+    }
+};
+
+}  // namespace cpfft

@@ -1,0 +1,229 @@
+"""GPU parity tests of the fused HIP FFTLog kernel (through the C ABI) against the oracle and the reference's golden
+vectors.  Tolerances: (i) tilted-space norm-wise max|d(g y^q)| / max|g y^q| <= 1e-13; (ii) pointwise
+relative <= 1e-10 for s in [1e-2, 2e2] Mpc/h; outside that range values are 16 decades below peak and are not gated."""
+import numpy as np
+import pytest
+
+from conftest import tilted_err
+from oracle import fftlog as ofl
+
+pytestmark = pytest.mark.gpu
+
+TOL_NORM = 1e-13
+TOL_POINT = 1e-10
+
+
+@pytest.fixture(scope='module')
+def cp():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    import cosmoprimo_amd
+    return cosmoprimo_amd
+
+
+def pointwise(g, ref, s, lo=1e-2, hi=2e2):
+    m = (s > lo) & (s < hi)
+    return np.abs(g[..., m] / ref[..., m] - 1.).max()
+
+
+@pytest.mark.parametrize('n', [1024, 2048])
+def test_golden_transforms(cp, golden, n):
+    """G3: default-cosmology EH P(k) (configs 1 and 2 grids), every extrap mode, keep_padding, multi-ell, tophat, xi->P."""
+    g = golden('fftlog_transforms')
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k%d' % n], pkd['pk%d' % n]
+    f = cp.PowerToCorrelation(k, ell=0, lowring=True)
+    for name, extrap in [('zero', 0), ('edge', 'edge'), ('log', 'log'), ('mixed', ('log', 0.)), ('const', (1.5, 'edge'))]:
+        s, xi = f(pk, extrap=extrap)
+        ref = g['n%d_p2c_l0_%s' % (n, name)]
+        assert xi.shape == (n,) and xi.dtype == np.float64
+        np.testing.assert_allclose(s, g['n%d_p2c_l0_s' % n], rtol=1e-14)
+        # 'edge' / constant padding put the largest tilted samples in the padding: conditioning ~1e2 worse (see oracle test)
+        tol = TOL_NORM if name in ('zero', 'log', 'mixed') else 1e-11
+        assert tilted_err(xi, ref, s, 1.5) < tol, name
+        if name in ('zero', 'log', 'mixed'):
+            assert pointwise(xi, ref, s) < TOL_POINT, name
+    y, keep = f(pk, extrap='log', keep_padding=True)
+    assert keep.shape == (2 * n,) and y.shape == (2 * n,)
+    assert tilted_err(keep, g['n%d_p2c_l0_keep' % n], y, 1.5) < TOL_NORM
+    fm = cp.PowerToCorrelation(k, ell=[0, 2, 4], lowring=True)
+    s3, xi3 = fm(pk)   # 1-D input broadcast against 3 kernels
+    assert xi3.shape == (3, n) and s3.shape == (3, n)
+    for i in range(3):
+        assert tilted_err(xi3[i], g['n%d_p2c_l024' % n][i], s3[i], 1.5) < TOL_NORM
+    r, var = cp.TophatVariance(k)(pk)
+    assert tilted_err(var, g['n%d_tophat' % n], r, 1.5) < TOL_NORM
+    assert pointwise(var, g['n%d_tophat' % n], r, 1e-1, 1e2) < TOL_POINT
+    k2, pk2 = cp.CorrelationToPower(g['n%d_p2c_l0_s' % n], ell=0, lowring=True)(g['n%d_p2c_l0_zero' % n])
+    assert tilted_err(pk2, g['n%d_c2p_l0' % n], k2, 1.5) < 1e-12
+
+
+def test_config2_golden_rows(cp, golden):
+    from oracle.workloads import config2_rows
+    g = golden('fftlog_transforms')
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k2048'], pkd['pk2048']
+    f = cp.PowerToCorrelation(k, ell=0)
+    rows = np.concatenate([config2_rows(k, pk, i, i + 1) for i in g['config2_idx']])
+    s, xi = f(rows)
+    for a, b in zip(xi, g['config2_xi']):
+        assert tilted_err(a, b, s, 1.5) < TOL_NORM
+        assert pointwise(a, b, s) < TOL_POINT
+
+
+def test_hankel_pair(cp, golden):
+    """Analytic pair f=(1+x^2)^-1.5 <-> g=exp(-y) incl. inv() and batched input; reference tests/test_fftlog.py:56-89."""
+    def ffun(x):
+        return 1 / (1 + x**2)**1.5
+
+    def gfun(y):
+        return np.exp(-y)
+
+    g = golden('fftlog_transforms')
+    for kwargs in [{'engine': 'numpy'}, {'engine': 'fftw', 'plan': 'estimate'}, {'engine': 'mi355x'}]:
+        x = np.logspace(-3, 3, num=60, endpoint=False)
+        f = ffun(x)
+        hf = cp.HankelTransform(x, nu=0, q=1, lowring=True, **kwargs)
+        y, gg = hf(f, extrap='log')
+        assert np.allclose(gg, gfun(y), rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(gg, g['hankel60_g'], rtol=1e-11, atol=1e-14)
+        hf.inv()
+        x2, f2 = hf(gg, extrap='log')
+        assert np.allclose(f2, f, rtol=1e-7, atol=1e-7)
+        np.testing.assert_allclose(f2, g['hankel60_inv_f'], rtol=1e-10, atol=1e-13)
+
+        y = np.logspace(-4, 2, num=60, endpoint=False)
+        gy = gfun(y)
+        hg = cp.HankelTransform(y, nu=0, q=1, lowring=True, **kwargs)
+        x, f = hg(gy, extrap='log')
+        assert np.allclose(f, ffun(x), rtol=1e-10, atol=1e-10)
+
+        y = np.array([np.logspace(-4, 2, num=60, endpoint=False)] * 3)
+        scales = np.linspace(1., 3., 3)
+        gy = gfun(y)
+        x, f = hg(gy * scales[:, None], extrap='log')
+        assert x.shape == (60, )
+        assert f.shape == (3, 60)
+        assert np.allclose(f / scales[:, None], ffun(x), rtol=1e-10, atol=1e-10)
+
+
+def test_power_to_correlation_roundtrip(cp, golden):
+    """reference tests/test_fftlog.py:92-109 with the golden EH P(k) as input."""
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k1024'], pkd['pk1024']
+    multipoles = []
+    ells = [0, 1, 2, 3, 4]
+    for ell in ells:
+        s, xi = cp.PowerToCorrelation(k, ell=ell, lowring=True, complex=False)(pk)
+        assert xi.shape == (1024, )
+        k2, pk2 = cp.CorrelationToPower(s, ell=ell, lowring=True, complex=False)(xi)
+        idx = (1e-2 < k2) & (k2 < 10.)
+        assert np.allclose(pk2[idx], np.interp(np.log(k2[idx]), np.log(k), pk), rtol=1e-2)
+        multipoles.append(xi)
+    assert np.allclose(cp.PowerToCorrelation(k, ell=ells, lowring=True, q=0, complex=False)(pk)[-1], multipoles)
+    s, xi = cp.PowerToCorrelation(k, ell=0, lowring=False)(pk)
+    assert np.allclose(s[::-1] * k, 1.)
+    s, xi1 = cp.PowerToCorrelation(k, ell=1)(pk)
+    assert np.abs(xi1).max() > 0.
+    # complex=True: (-i)^ell phases, complex128 output
+    sc, xic = cp.PowerToCorrelation(k, ell=ells, complex=True)(pk)
+    assert xic.dtype == np.complex128
+    t = ofl.power_to_correlation(k, ell=ells)
+    ref = ofl.apply(t, pk) * ((-1.) ** (np.array(ells) // 2))[:, None] * ((-1j) ** np.array(ells))[:, None]
+    for i in range(5):
+        assert np.abs((xic[i] - ref[i]) * sc[i]**1.5).max() / np.abs(ref[i] * sc[i]**1.5).max() < TOL_NORM
+
+
+@pytest.mark.parametrize('n', [2, 3, 5, 8, 13, 30, 60, 100, 250, 256, 500, 512, 1000, 1024, 2048, 3000, 4096])
+def test_sizes_and_modes_vs_oracle(cp, n):
+    """Every kernel size / variant, odd batches (incomplete pair), multi-kernel, keep_padding, all extrap modes."""
+    rng = np.random.default_rng(n)
+    k = np.logspace(-3, 2, n)
+    t = ofl.power_to_correlation(k, ell=[0, 2])
+    f = cp.PowerToCorrelation(k, ell=[0, 2])
+    fun = rng.uniform(0.95, 1.05, size=(5, 2, n)) * k**-1.2
+    modes = [(0, False), (0, True), ('edge', False), ((1.5, 'edge'), False), ((0., 'edge'), True)]
+    if n >= 3 and n <= 2048:
+        modes += [('log', True), (('log', 0.3), False), ((0.2, 'log'), False)]
+    with np.errstate(all='ignore'):
+        for extrap, keep in modes:
+            ref = ofl.apply(t, fun, extrap=extrap, keep_padding=keep)
+            y, got = f(fun, extrap=extrap, keep_padding=keep)
+            assert got.shape == ref.shape
+            scale = np.abs(ofl.pad(fun, (t.in_left, t.in_right), extrap) * t.pre).max(axis=-1)
+            scale = np.maximum(scale, scale[[1, 0, 3, 2, 4]])  # rows b and b^1 share one complex FFT
+            post = np.abs(t.post[:, t.out_left:t.out_left + t.n] if not keep else t.post)
+            err = np.abs(got - ref) / post / scale[..., None]
+            assert err.max() < 1e-14, (n, extrap, keep, err.max())
+
+
+def test_shapes_dtypes_devices(cp):
+    import torch
+    n = 128
+    k = np.logspace(-3, 2, n)
+    pk = k**-1.5
+    f1 = cp.PowerToCorrelation(k, ell=0)
+    f3 = cp.PowerToCorrelation(k, ell=[0, 2, 4])
+    t1 = ofl.power_to_correlation(k, ell=0)
+    s, xi = f1(pk)
+    assert s.shape == (n,) and xi.shape == (n,)
+    s, xi = f1(np.tile(pk, (7, 3, 1)))
+    assert xi.shape == (7, 3, n)
+    assert np.allclose(xi, ofl.apply(t1, pk)[0], rtol=1e-12)
+    s, xi = f3(np.tile(pk, (7, 3, 1)))
+    assert s.shape == (3, n) and xi.shape == (7, 3, n)
+    s, xi = f3(np.tile(pk, (7, 1, 1)))       # (7, 1, n) broadcasts against 3 kernels
+    assert xi.shape == (7, 3, n)
+    s, xi = f1(pk.astype('f4'))              # f4 in -> f8 out
+    assert xi.dtype == np.float64
+    s, xi = f1(np.zeros((0, n)))             # empty batch
+    assert xi.shape == (0, n)
+    s, xi = f1(pk, keep_padding=True)
+    assert s.shape == (2 * n,) and xi.shape == (2 * n,)
+    # torch in -> torch out on the same device, no host round trip
+    tpk = torch.as_tensor(np.tile(pk, (5, 1)), device='cuda')
+    ts, txi = f1(tpk)
+    assert isinstance(txi, torch.Tensor) and txi.is_cuda and txi.shape == (5, n) and txi.dtype == torch.float64
+    assert np.allclose(txi.cpu().numpy(), ofl.apply(t1, pk)[0], rtol=1e-12)
+    # a side stream is honoured
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ts, txi2 = f1(tpk)
+    st.synchronize()
+    assert torch.equal(txi, txi2)
+    with pytest.raises(ValueError):
+        f1(np.ones(n + 1))
+    with pytest.raises(ValueError):
+        f1(pk, extrap='nope')
+
+
+def test_full_size_batch_properties(cp, golden):
+    """BASELINE config 2 at full size (100k x 2048): sampled rows against the oracle, linearity over the whole batch,
+    and determinism (bitwise identical reruns)."""
+    import torch
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k2048'], pkd['pk2048']
+    nb = 100000
+    rng = np.random.default_rng(0)
+    amp, dn = rng.uniform(0.5, 2., nb), rng.uniform(-0.1, 0.1, nb)
+    dev = torch.device('cuda')
+    tk, tpk = torch.as_tensor(k, device=dev), torch.as_tensor(pk, device=dev)
+    rows = torch.as_tensor(amp, device=dev)[:, None] * (tk[None, :] / 0.05) ** torch.as_tensor(dn, device=dev)[:, None] * tpk[None, :]
+    f = cp.PowerToCorrelation(k, ell=0)
+    t = ofl.power_to_correlation(k, ell=0)
+    s, xi = f(rows)
+    s, xi2 = f(rows)
+    assert torch.equal(xi, xi2)
+    idx = np.unique(np.concatenate([[0, 1, nb - 2, nb - 1], rng.integers(0, nb, 60)]))
+    sub_in = rows[torch.as_tensor(idx, device=dev)].cpu().numpy()
+    sub_out = xi[torch.as_tensor(idx, device=dev)].cpu().numpy()
+    ref = ofl.apply(t, sub_in[:, None, :])[:, 0]
+    sn = s.cpu().numpy()
+    for a, b in zip(sub_out, ref):
+        assert tilted_err(a, b, sn, 1.5) < TOL_NORM
+        assert pointwise(a, b, sn) < TOL_POINT
+    # linearity: sum over the batch of the outputs == transform of the summed input
+    total_in = rows.sum(dim=0).cpu().numpy()
+    total_out = xi.sum(dim=0).cpu().numpy()
+    ref_total = ofl.apply(t, total_in)[0]
+    assert tilted_err(total_out, ref_total, sn, 1.5) < 1e-12

@@ -1,0 +1,167 @@
+"""CPU: host-side FFTlog logic (tables, shapes, errors) against golden vectors, and the host emulation of the
+HIP kernel's per-thread phases (tests/host_emu) against the oracle."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, tilted_err
+import cosmoprimo_amd as cp
+from cosmoprimo_amd import fftlog as fl
+from oracle import fftlog as ofl
+
+CASES = {
+    'p2c_l0': lambda k: cp.PowerToCorrelation(k, ell=0),
+    'p2c_multi': lambda k: cp.PowerToCorrelation(k, ell=[0, 1, 2, 3, 4]),
+    'p2c_multi_cplx': lambda k: cp.PowerToCorrelation(k, ell=[0, 1, 2, 3, 4], complex=True),
+    'c2p_l0': lambda k: cp.CorrelationToPower(k, ell=0),
+    'c2p_l2_q': lambda k: cp.CorrelationToPower(k, ell=2, q=0.5),
+    'tophat': lambda k: cp.TophatVariance(k),
+    'gauss': lambda k: cp.GaussianVariance(k),
+    'hankel_nu0_q1': lambda k: cp.HankelTransform(k, nu=0, q=1),
+    'hankel_nu2': lambda k: cp.HankelTransform(k, nu=[0, 2], q=1),
+    'p2c_nolowring': lambda k: cp.PowerToCorrelation(k, ell=0, lowring=False, xy=1.),
+}
+
+
+def check_tables(f, g, prefix, every):
+    ev4 = max(every // 4, 1)
+    assert np.array_equal(g[prefix + 'sizes'], [f.padded_size, f.padded_size_in_left, f.padded_size_in_right, f.padded_size_out_left, f.padded_size_out_right])
+    np.testing.assert_allclose(f.delta, g[prefix + 'delta'], rtol=1e-15)
+    np.testing.assert_allclose(f.lnxy, g[prefix + 'lnxy'], rtol=1e-12, atol=1e-17)
+    np.testing.assert_allclose(f.y[..., ::ev4], g[prefix + 'y'], rtol=1e-14)
+    u, uref = f.padded_u[..., ::ev4], g[prefix + 'u']
+    assert np.all(np.abs(u - uref) <= 2e-13 * np.abs(uref) + 1e-300)   # phase of loggamma at |Im z| ~ 400 carries ~1e-13
+    np.testing.assert_allclose(f.padded_prefactor[..., ::every], g[prefix + 'pre'], rtol=1e-13)
+    np.testing.assert_allclose(f.padded_postfactor[..., ::every], g[prefix + 'post'], rtol=1e-13)
+
+
+@pytest.mark.parametrize('n', [1024, 2048])
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_tables_vs_reference(golden, n, name):
+    g = golden('fftlog_tables')
+    f = CASES[name](np.logspace(-5, 2, n))
+    check_tables(f, g, 'n%d_%s_' % (n, name), 1 if name in ('p2c_l0', 'tophat') else 16)
+
+
+def test_generic_kernels_vs_reference(golden):
+    g = golden('fftlog_tables')
+    x = np.logspace(-4, 3, 200)
+    kern = {'tophat1': fl.TophatKernel(ndim=1), 'tophat3': fl.TophatKernel(ndim=3), 'tophatsq1': fl.TophatSqKernel(ndim=1),
+            'tophatsq2': fl.TophatSqKernel(ndim=2), 'gaussian': fl.GaussianKernel(), 'besselj1': fl.BesselJKernel(1.5),
+            'sphbesselj3': fl.SphericalBesselJKernel(3)}
+    for name, k in kern.items():
+        check_tables(cp.FFTlog(x, k, q=0.7, minfolds=3), g, 'gen200_%s_' % name, 1)
+
+
+def test_pad():
+    # reference tests/test_fftlog.py:26-53
+    a = b = np.ones((6, 6))
+    padded_a = np.zeros((13, 6))
+    padded_a[3: 9, :] = 1
+    padded_b = np.ones((6, 13))
+    c = np.array([(i + 1) * np.logspace(-3, 3, num=6, endpoint=False) for i in range(3)]).T
+    padded_c = np.array([(i + 1) * np.logspace(-12, 12, num=24, endpoint=False) for i in range(3)]).T
+    assert np.allclose(cp.pad(a, (3, 4), extrap=0, axis=0), padded_a)
+    assert np.allclose(cp.pad(b, (4, 3), extrap='edge', axis=1), padded_b)
+    assert np.allclose(cp.pad(c, (9, 9), extrap='log', axis=0), padded_c)
+    x = np.logspace(-3, 3, num=7, endpoint=True)
+    padded_x = np.logspace(-15, 16, num=32, endpoint=True)
+    y = np.logspace(-3, 3, num=7, endpoint=True)
+    padded_y = np.logspace(-16, 15, num=32, endpoint=True)
+    fftlog = cp.HankelTransform(x, minfolds=3, xy=1, lowring=False)
+    assert np.allclose(fftlog.padded_x, padded_x)
+    assert np.allclose(fftlog.padded_y, padded_y)
+    assert np.allclose(cp.pad(x, (fftlog.padded_size_in_left, fftlog.padded_size_in_right), extrap='log'), padded_x)
+    assert np.allclose(cp.pad(y, (fftlog.padded_size_out_left, fftlog.padded_size_out_right), extrap='log'), padded_y)
+    assert np.allclose(fftlog.padded_x[0, fftlog.padded_size_in_left: fftlog.padded_size_in_left + fftlog.size], x)
+    assert np.allclose(fftlog.padded_y[0, fftlog.padded_size_out_left: fftlog.padded_size_out_left + fftlog.size], y)
+
+
+def test_lowring_false_grid():
+    # reference tests/test_fftlog.py:108-109
+    k = np.logspace(-5, 2, 1000)
+    f = cp.PowerToCorrelation(k, ell=0, lowring=False)
+    assert np.allclose(f.y[0][::-1] * k, 1.)
+
+
+def test_inv_tables(golden):
+    g = golden('fftlog_transforms')
+    hf = cp.HankelTransform(g['hankel60_x'], nu=0, q=1, lowring=True)
+    hf.inv()
+    check_tables(hf, g, 'hankel60_inv_', 1)
+
+
+def test_errors():
+    k = np.logspace(-3, 3, 64)
+    with pytest.raises(ValueError):
+        cp.FFTlog(k, fl.BesselJKernel(0), engine='nope')
+    with pytest.raises(ValueError):
+        cp.FFTlog(np.linspace(1., 2., 64), fl.BesselJKernel(0), check_level=1)
+    with pytest.raises(ValueError):
+        cp.FFTlog(np.tile(k, (2, 1)), [fl.BesselJKernel(0)] * 3, check_level=1)
+    for engine in ('numpy', 'fftw', 'mi355x'):
+        assert cp.FFTlog(k, fl.BesselJKernel(0), engine=engine)._engine.size == 128
+
+
+# ---- host emulation of the kernel phases ---------------------------------------------------------
+@pytest.fixture(scope='module')
+def emu():
+    src = os.path.join(ROOT, 'tests', 'host_emu', 'emu_fftlog.cpp')
+    out = os.path.join(ROOT, 'tests', 'host_emu', 'libemu_fftlog.so')
+    deps = [src] + [os.path.join(ROOT, 'cosmoprimo_amd', 'csrc', h) for h in ('cp_fft_core.h', 'cp_fftlog_body.h', 'cp_fftlog_tables.h', 'cp_fftlog_dispatch.h')]
+    if not os.path.isfile(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(['g++', '-O1', '-std=c++17', '-shared', '-fPIC', '-o', out, src])
+    lib = ctypes.CDLL(out)
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.emu_fftlog.argtypes = [ctypes.c_int] * 3 + [dp] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_double, ctypes.c_int]
+
+    def run(t, fun, ext=(0, 0., 0, 0.), keep=False):
+        fun = np.ascontiguousarray(fun, dtype='f8')
+        nb = fun.size // (t.nker * t.n)
+        out = np.full((nb, t.nker, t.npad if keep else t.n), np.nan)
+        pre, post, u = np.ascontiguousarray(t.pre), np.ascontiguousarray(np.real(t.post)), np.ascontiguousarray(t.u).view('f8')
+        P = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+        assert lib.emu_fftlog(t.n, t.npad, t.nker, P(pre), P(post), P(u), P(fun), P(out), nb, ext[0], ext[1], ext[2], ext[3], int(keep)) == 0
+        return out
+    run.lib = lib
+    return run
+
+
+@pytest.mark.parametrize('r', [2, 4, 8, 16])
+def test_emu_butterflies(emu, r):
+    rng = np.random.default_rng(r)
+    z = rng.normal(size=r) + 1j * rng.normal(size=r)
+    buf = np.ascontiguousarray(np.stack([z.real, z.imag], -1).ravel())
+    emu.lib.emu_dft(r, buf.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    assert np.abs(buf[0::2] + 1j * buf[1::2] - np.fft.fft(z)).max() < 1e-14
+
+
+@pytest.mark.parametrize('n', [2, 3, 8, 13, 60, 250, 256, 500, 512, 1000, 1024, 2048, 4096])
+def test_emu_kernel_phases_vs_oracle(emu, n):
+    """Every kernel variant (generic, log, half, half-zero), odd batch (incomplete pair), multi-kernel, keep_padding."""
+    rng = np.random.default_rng(n)
+    k = np.logspace(-3, 2, n)
+    t = ofl.power_to_correlation(k, ell=[0, 2])
+    fun = rng.uniform(0.95, 1.05, size=(3, 2, n)) * k**-1.2
+    modes = [((0, 0., 0, 0.), 0, False), ((0, 0., 0, 0.), 0, True), ((1, 0., 1, 0.), 'edge', False), ((0, 1.5, 1, 0.), (1.5, 'edge'), False)]
+    if n <= 2048:
+        modes += [((2, 0., 2, 0.), 'log', True), ((2, 0., 0, 0.3), ('log', 0.3), False)]
+    with np.errstate(all='ignore'):
+        for ext, oext, keep in modes:
+            ref = ofl.apply(t, fun, extrap=oext, keep_padding=keep)
+            got = emu(t, fun, ext, keep)
+            assert not np.isnan(got).any()
+            yy = t.padded_y if keep else t.y
+            # error relative to the largest tilted *input* sample (padding with edge / constants makes that the scale)
+            scale = np.abs(ofl.pad(fun, (t.in_left, t.in_right), oext) * t.pre).max(axis=-1)
+            # two batch rows share one complex FFT (z = a + i b): rounding is relative to the larger row of the pair
+            scale[0] = scale[1] = np.maximum(scale[0], scale[1])
+            post = np.abs(t.post[:, t.out_left:t.out_left + t.n] if not keep else t.post)
+            err = np.abs(got - ref) / post / scale[..., None]
+            assert err.max() < 5e-15, (n, ext, err.max())
+            if oext == 0:
+                for i in range(2):
+                    assert tilted_err(got[:, i], ref[:, i], yy[i], 1.5) < 2e-15

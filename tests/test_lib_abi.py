@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cosmoprimo_amd.h declares (no compute calls)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from cosmoprimo_amd import _lib
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'cosmoprimo_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(cp_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_header():
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 10
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in _lib.SIGNATURES, 'binding missing for {}'.format(name)
+    assert lib.cp_abi_version() == _lib.ABI_VERSION
+
+
+def test_error_mapping():
+    lib = _lib.load()
+    import ctypes
+    handle = ctypes.c_void_p()
+    pre = np.ones(8)
+    with pytest.raises(ValueError):   # npad not a power of two -> CP_EINVAL -> ValueError (reference fftlog.py:155-159)
+        _lib.check(lib.cp_fftlog_plan_create(ctypes.byref(handle), 3, 6, 1, _lib.as_double_p(pre), _lib.as_double_p(pre), _lib.as_double_p(pre), 0))
+    assert b'power of two' in lib.cp_last_error()
+    with pytest.raises(NotImplementedError):  # beyond the LDS-resident range -> CP_EUNSUPPORTED
+        _lib.check(lib.cp_fftlog_plan_create(ctypes.byref(handle), 10000, 32768, 1, _lib.as_double_p(pre), _lib.as_double_p(pre), _lib.as_double_p(pre), 0))
+    with pytest.raises(ValueError):
+        _lib.kernel_eval(99, 0., np.ones(2, dtype='c16'))
+
+
+def test_loggamma_vs_scipy_golden(golden):
+    # G2: scipy.special.loggamma / gamma on the kernels' arguments + stress grid
+    g = golden('loggamma')
+    out = _lib.loggamma(g['z'])
+    ref = g['loggamma']
+    assert np.all(np.abs(out - ref) <= 4e-16 * np.maximum(np.abs(ref), 1.))
+    outg = _lib.gamma(g['zg'])
+    assert np.all(np.abs(outg - g['gamma']) <= 2e-15 * np.abs(g['gamma']))
+
+
+def test_loggamma_special_points():
+    from scipy.special import loggamma
+    z = np.array([1., 2., 0.5, 1.05 + 0.02j, 2.1 - 0.05j, -0.5 + 1e-3j, -3.3 - 2j, 6.9 + 6.9j, 7.1 + 0.1j, 0.05 + 0.01j, -2.5 + 0j, 30. + 0j,
+                  1e-8 + 0j, -1e-8 + 1e-9j, 3 + 1e-300j])
+    out = _lib.loggamma(z)
+    ref = loggamma(z)
+    assert np.all(np.abs(out - ref) <= 1e-15 * np.maximum(np.abs(ref), 1.)), np.abs(out - ref)
+    assert np.all(np.isnan(_lib.loggamma(np.array([0., -1., -2.])).real))  # poles
