@@ -33,8 +33,8 @@ BYTES_PER_ROW = 2 * 8 * N_K   # read N f64 + write N f64 (tables are batch-share
 
 
 def _cpu_chunk(args):
-    """One worker: time `reps` oracle transforms of a (rows, N) chunk (numpy rfft/irfft path, reference fftlog.py:228-241)."""
-    seed, rows, reps = args
+    """One worker: run oracle transforms of a (rows, N) chunk until `deadline` (numpy rfft/irfft path, reference fftlog.py:228-241)."""
+    seed, rows, seconds = args
     os.environ['OMP_NUM_THREADS'] = '1'
     from oracle import fftlog as ofl
     from oracle.workloads import pk_eh_default, config2_rows
@@ -42,28 +42,39 @@ def _cpu_chunk(args):
     t = ofl.power_to_correlation(k, ell=0)
     x = config2_rows(k, pk, seed * rows, (seed + 1) * rows)[:, None, :]
     ofl.apply(t, x[:64])
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
         ofl.apply(t, x)
-    return rows * reps, time.perf_counter() - t0
+        done += rows
+    return done, time.perf_counter() - t0
 
 
-def cpu_baseline(target_seconds=12.):
-    """Oracle ("port" of the reference's numpy path) on all host cores; bounded to about `target_seconds` of wall time."""
-    import multiprocessing as mp
+def _host_cores():
+    """Usable host cores: scheduler affinity capped by the cgroup CPU quota (containers often expose more CPUs than they may use)."""
     cores = len(os.sched_getaffinity(0))
-    rows = 256   # 256 x 4096 f64 temporaries stay in cache (faster per core than 2048-row chunks)
-    n0, t0 = _cpu_chunk((0, 256, 1))
-    per_row = t0 / n0
-    reps = max(1, int(target_seconds / (per_row * rows)))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = max(1, min(cores, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def cpu_baseline(seconds=10.):
+    """Oracle ("port" of the reference's numpy path) on all usable host cores for about `seconds` of wall time."""
+    import multiprocessing as mp
+    cores = _host_cores()
+    rows = 256   # 256 x 4096 f64 temporaries stay in cache (faster per core than larger chunks)
     ctx = mp.get_context('fork')   # before any GPU initialisation in this process
     with ctx.Pool(cores) as pool:
         tic = time.perf_counter()
-        res = pool.map(_cpu_chunk, [(i, rows, reps) for i in range(cores)])
+        res = pool.map(_cpu_chunk, [(i % 300, rows, seconds) for i in range(cores)])
         wall = time.perf_counter() - tic
     total = sum(r[0] for r in res)
     return {'value': total / wall, 'unit': 'transforms/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d rows x %d reps per core of the config-2 batch (N=%d), numpy oracle, %d processes' % (rows, reps, N_K, cores),
+            'sample': '%d-row chunks of the config-2 batch (N=%d) repeated for %.0f s on each of %d processes, numpy oracle (%d transforms)'
+                      % (rows, N_K, seconds, cores, total),
             'per_core_value': float(np.mean([r[0] / r[1] for r in res]))}
 
 
@@ -82,9 +93,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     distributed = world > 1
 
+    def log(msg):
+        if rank == 0:
+            print('[bench %.1fs] %s' % (time.perf_counter() - T0, msg), file=sys.stderr, flush=True)
+
+    T0 = time.perf_counter()
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        log('cpu baseline on %d cores ...' % _host_cores())
         cpu = cpu_baseline()   # before the GPU is touched (fork-safe)
+        log('cpu baseline: %.0f transforms/s' % cpu['value'])
 
     import torch
     import torch.distributed as dist
@@ -103,6 +121,7 @@ def main():
     tk, tpk = torch.as_tensor(k, device=dev), torch.as_tensor(pk, device=dev)
     rows = (torch.as_tensor(amp, device=dev)[:, None] * (tk[None, :] / 0.05) ** torch.as_tensor(dn, device=dev)[:, None] * tpk[None, :]).contiguous()
     f = cp.PowerToCorrelation(k, ell=0, device=dev)
+    log('inputs resident: %d x %d f64' % (nb, N_K))
 
     # product call path = FFTlog.__call__ -> cp_fftlog_execute; for timing, call the C ABI directly on preallocated buffers
     from cosmoprimo_amd import _lib
@@ -117,6 +136,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
+    log('warmup done')
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
