@@ -22,6 +22,13 @@
 #define CP_HD inline
 #endif
 
+// scheduling fence: the compiler may not move instructions across it (device only; no code is emitted)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CP_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define CP_SCHED_FENCE() ((void)0)
+#endif
+
 namespace cpfft {
 
 struct cplx {
@@ -264,6 +271,24 @@ struct Pass {
 #pragma unroll
             for (int s = 1; s < R; ++s) x[i * R + s] = cmul(x[i * R + s], tw[s * M + j]);
         }
+    }
+    // the same in two steps (w holds P entries; slot i R + s), so that a caller can order the table loads
+    // against other memory operations
+    static CP_HD void twiddle_load(int t, const cplx* tw, cplx* w) {
+        if (M == 1) return;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = joff(t, i);
+#pragma unroll
+            for (int s = 1; s < R; ++s) w[i * R + s] = tw[s * M + j];
+        }
+    }
+    static CP_HD void twiddle_apply(const cplx* w, cplx* x) {
+        if (M == 1) return;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int s = 1; s < R; ++s) x[i * R + s] = cmul(x[i * R + s], w[i * R + s]);
     }
     static CP_HD void butterflies(cplx* x) {
 #pragma unroll

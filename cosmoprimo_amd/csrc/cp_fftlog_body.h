@@ -72,47 +72,78 @@ struct Fftlog {
         return v;
     }
 
-    // phase 0 front end: x[r] = (a[j], b[j]) * pre[j], j = t + T r  (pass 0: R = P, M = T)
-    static CP_HD void load_input(int t, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
-                                 const double* __restrict__ pre, cplx* x) {
-        if constexpr (HALF_IN) {
-            double va[8], vb[8], f[8];
+    // HALF front end, split in two so the HBM loads of the NEXT pair are issued a whole pair ahead
+    // (prefetch registers va / vb live across the phases): issue ...
+    static CP_HD void prefetch_rows(int t, const double* __restrict__ ra, const double* __restrict__ rb, double* va, double* vb) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                va[r] = ra[t + T * r];
-                vb[r] = rb[t + T * r];
-                f[r] = pre[t + T * (r + 4)];
-            }
+        for (int r = 0; r < 8; ++r) {
+            va[r] = ra[t + T * r];
+            vb[r] = rb[t + T * r];
+        }
+    }
+
+    // ... and consume: x[r + 4] = (va[r], vb[r]) * pre[t + T (r + 4)]; padded points from the constant / edge value
+    template <class ST>
+    static CP_HD void load_input_half(int t, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
+                                      const double* __restrict__ pre, const ST& st, cplx* x) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                x[r + 4].re = va[r] * f[r];
-                x[r + 4].im = has_b ? vb[r] * f[r] : 0.;
-            }
-            if constexpr (IN_MODE == IN_HALF) {
-                const double la = A.ext_l == CP_EXTRAP_CONST ? A.val_l : ra[0];
-                const double lb = A.ext_l == CP_EXTRAP_CONST ? A.val_l : rb[0];
-                const double ha = A.ext_r == CP_EXTRAP_CONST ? A.val_r : ra[A.n - 1];
-                const double hb = A.ext_r == CP_EXTRAP_CONST ? A.val_r : rb[A.n - 1];
+        for (int r = 0; r < 8; ++r) {
+            x[r + 4].re = st.va[r] * st.fpre[r];
+            x[r + 4].im = has_b ? st.vb[r] * st.fpre[r] : 0.;
+        }
+        if constexpr (IN_MODE == IN_HALF) {
+            const double la = A.ext_l == CP_EXTRAP_CONST ? A.val_l : ra[0];
+            const double lb = A.ext_l == CP_EXTRAP_CONST ? A.val_l : rb[0];
+            const double ha = A.ext_r == CP_EXTRAP_CONST ? A.val_r : ra[A.n - 1];
+            const double hb = A.ext_r == CP_EXTRAP_CONST ? A.val_r : rb[A.n - 1];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double fl = pre[t + T * r], fh = pre[t + T * (r + 12)];
-                    x[r].re = la * fl;
-                    x[r].im = has_b ? lb * fl : 0.;
-                    x[r + 12].re = ha * fh;
-                    x[r + 12].im = has_b ? hb * fh : 0.;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) x[r] = x[r + 12] = cplx{0., 0.};
+            for (int r = 0; r < 4; ++r) {
+                const double fl = pre[t + T * r], fh = pre[t + T * (r + 12)];
+                x[r].re = la * fl;
+                x[r].im = has_b ? lb * fl : 0.;
+                x[r + 12].re = ha * fh;
+                x[r + 12].im = has_b ? hb * fh : 0.;
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const int j = t + T * r;
-                const double f = pre[j];
-                x[r].re = fetch(ra, j, A) * f;
-                x[r].im = has_b ? fetch(rb, j, A) * f : 0.;
-            }
+            for (int r = 0; r < 4; ++r) x[r] = x[r + 12] = cplx{0., 0.};
+        }
+    }
+
+    // generic phase 0 front end: x[r] = (a[j], b[j]) * pre[j], j = t + T r  (pass 0: R = P, M = T)
+    static CP_HD void load_input(int t, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
+                                 const double* __restrict__ pre, cplx* x) {
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const int j = t + T * r;
+            const double f = pre[j];
+            x[r].re = fetch(ra, j, A) * f;
+            x[r].im = has_b ? fetch(rb, j, A) * f : 0.;
+        }
+    }
+
+    // OUT_HALF back end with the postfactors already in registers: the 16 stores go out back to back
+    // nker > 1: the factors of the NEXT pair (kernel index nxt_ker) are loaded between the last use of fpost and the
+    // stores, so that no load is ever issued behind a store (vmcnt retires in order).
+    template <class ST>
+    static CP_HD void store_output_half(int t, const FftlogArgs& A, double* __restrict__ oa, double* __restrict__ ob, bool has_b, int nxt_ker,
+                                        ST& st, const cplx* x) {
+        double ya[8], yb[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            ya[s] = x[s + 4].re * st.fpost[s];
+            yb[s] = x[s + 4].im * st.fpost[s];
+        }
+        if (A.nker > 1) {
+            CP_SCHED_FENCE();
+            load_factors_half(t, A, nxt_ker, st);
+            CP_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) oa[t + T * s] = ya[s];
+        if (has_b) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) ob[t + T * s] = yb[s];
         }
     }
 
@@ -120,12 +151,7 @@ struct Fftlog {
     static CP_HD void store_output(int t, const FftlogArgs& A, double* __restrict__ oa, double* __restrict__ ob, bool has_b,
                                    const double* __restrict__ post, const cplx* x) {
         if constexpr (OUT_MODE == OUT_HALF) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const double f = post[t + T * (s + 4)];
-                oa[t + T * s] = x[s + 4].re * f;
-                if (has_b) ob[t + T * s] = x[s + 4].im * f;
-            }
+            static_assert(OUT_MODE != OUT_HALF, "OUT_HALF goes through store_output_half");
         } else {
 #pragma unroll
             for (int s = 0; s < P; ++s) {
@@ -140,16 +166,72 @@ struct Fftlog {
         }
     }
 
-    static CP_HD void mul_u(int t, const cplx* __restrict__ u, cplx* x) {
+    // ---- registers that live across phases (and pairs) -------------------------------------------------------
+    // w     : the tables (twiddles or U) of the NEXT phase, loaded one phase ahead: the loads are issued right after
+    //         the LDS writes of the previous phase, BEFORE the workgroup barrier, when x[] is dead -- so the L2
+    //         latency overlaps the barrier and the LDS reads instead of sitting on the critical path of every phase.
+    //         After the last phase w still holds the pass-0 twiddles, which are what the next pair's phase 0 needs.
+    // fpre / fpost, va / vb : HALF modes only: pre / postfactors of the thread's 8 in-range points (pair-invariant
+    //         when nker == 1) and the pair's rows, prefetched one whole pair ahead.
+    struct State {
+        cplx w[P];
+        double fpre[8], fpost[8];
+        double va[8], vb[8];
+    };
+
+    template <int I>
+    static CP_HD void load_twiddles(int t, const FftlogArgs& A, cplx* w) {
+        Pass<NP, P, I>::twiddle_load(t, A.tw + PL::tw_offset(I), w);
+    }
+
+    static CP_HD void load_u(int t, const FftlogArgs& A, int ker, cplx* w) {
+        const cplx* __restrict__ u = A.u + (long long)ker * NP;
 #pragma unroll
-        for (int e = 0; e < P; ++e) x[e] = cmul(x[e], u[e * T + t]);
+        for (int e = 0; e < P; ++e) w[e] = u[e * T + t];
+    }
+
+    static CP_HD void load_factors_half(int t, const FftlogArgs& A, int ker, State& st) {
+        const double* __restrict__ pre = A.pre + (long long)ker * NP;
+        const double* __restrict__ post = A.post + (long long)ker * NP;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            st.fpre[r] = pre[t + T * (r + 4)];
+            st.fpost[r] = post[t + T * (r + 4)];
+        }
+    }
+
+    // before the first pair of a workgroup
+    static CP_HD void init_state(int t, const FftlogArgs& A, const double* ra, const double* rb, int ker, State& st) {
+        if constexpr (NPASS > 1) load_twiddles<0>(t, A, st.w);
+        if constexpr (HALF_IN) {
+            load_factors_half(t, A, ker, st);
+            prefetch_rows(t, ra, rb, st.va, st.vb);
+        }
+    }
+
+    // tables of phase PHN into w (called at the end of phase PHN - 1)
+    template <int PHN>
+    static CP_HD void load_tables_for(int t, const FftlogArgs& A, int ker, cplx* w) {
+        if constexpr (PHN < LAST) {
+            load_twiddles<(PHN < LAST ? PHN : 0)>(t, A, w);
+        } else if constexpr (PHN == LAST) {
+            load_u(t, A, ker, w);
+        } else if constexpr (PHN < NPH) {
+            load_twiddles<(PHN > LAST && PHN < NPH ? NPH - 1 - PHN : 0)>(t, A, w);
+        }
+    }
+
+    static CP_HD void mul_w(const cplx* w, cplx* x) {
+#pragma unroll
+        for (int e = 0; e < P; ++e) x[e] = cmul(x[e], w[e]);
     }
 
     // one phase for thread t; lds holds NP complex slots (unused when NPASS == 1).
     // rb / ob always point at valid rows (the caller aliases them to row a when the pair is incomplete).
+    // nra / nrb / nxt_ker: rows and kernel index of the pair this workgroup handles next (the current ones on its last pair).
     template <int PH>
     static CP_HD void phase(int t, const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b, int ker,
-                            cplx* lds) {
+                            cplx* lds, const double* nra, const double* nrb, int nxt_ker, State& st) {
         cplx x[P];
 #if defined(__HIP_DEVICE_COMPILE__)
         // Launder the thread index once per phase: stops the compiler from sharing (and keeping
@@ -159,42 +241,65 @@ struct Fftlog {
 #endif
         const double* pre = A.pre + (long long)ker * NP;
         const double* post = A.post + (long long)ker * NP;
-        const cplx* u = A.u + (long long)ker * NP;
         if constexpr (NPASS == 1) {
             load_input(t, A, ra, rb, has_b, pre, x);
             Pass<NP, P, 0>::butterflies(x);
-            mul_u(t, u, x);
+            load_u(t, A, ker, st.w);
+            mul_w(st.w, x);
             Pass<NP, P, 0>::butterflies(x);
             store_output(t, A, oa, ob, has_b, post, x);
         } else if constexpr (PH == 0) {
-            load_input(t, A, ra, rb, has_b, pre, x);
+            if constexpr (HALF_IN) {
+                load_input_half(t, A, ra, rb, has_b, pre, st, x);
+            } else {
+                load_input(t, A, ra, rb, has_b, pre, x);
+            }
             if constexpr (IN_MODE == IN_HALF_ZERO) {
                 Dft16ZeroPadded::run(x);  // points 0..3 and 12..15 are structural zeros
             } else {
                 Pass<NP, P, 0>::butterflies(x);
             }
-            Pass<NP, P, 0>::twiddle(t, A.tw + PL::tw_offset(0), x);
+            Pass<NP, P, 0>::twiddle_apply(st.w, x);
             Pass<NP, P, 0>::store_lds(t, lds, x);
+            load_tables_for<1>(t, A, ker, st.w);
         } else if constexpr (PH < LAST) {
             constexpr int I = (PH < LAST) ? PH : 0;
             Pass<NP, P, I>::load_lds(t, lds, x);
-            Pass<NP, P, I>::dif(t, A.tw, x);
+            Pass<NP, P, I>::butterflies(x);
+            Pass<NP, P, I>::twiddle_apply(st.w, x);
             Pass<NP, P, I>::store_lds(t, lds, x);
+            load_tables_for<PH + 1>(t, A, ker, st.w);
         } else if constexpr (PH == LAST) {
             Pass<NP, P, LAST>::load_lds(t, lds, x);
             Pass<NP, P, LAST>::butterflies(x);  // M == 1: no twiddles
-            mul_u(t, u, x);
+            mul_w(st.w, x);                     // U, digit-reversed order, 1/NP folded in
             Pass<NP, P, LAST>::butterflies(x);
             Pass<NP, P, LAST>::store_lds(t, lds, x);
+            load_tables_for<PH + 1>(t, A, ker, st.w);
         } else if constexpr (PH < NPH - 1) {
             constexpr int I = (PH > LAST && PH < NPH - 1) ? (NPH - 1 - PH) : 0;
             Pass<NP, P, I>::load_lds(t, lds, x);
-            Pass<NP, P, I>::dit(t, A.tw, x);
+            Pass<NP, P, I>::twiddle_apply(st.w, x);
+            Pass<NP, P, I>::butterflies(x);
             Pass<NP, P, I>::store_lds(t, lds, x);
+            load_tables_for<PH + 1>(t, A, ker, st.w);
         } else {
             Pass<NP, P, 0>::load_lds(t, lds, x);
-            Pass<NP, P, 0>::dit(t, A.tw, x);
-            store_output(t, A, oa, ob, has_b, post, x);
+            // Memory-operation order matters because vmcnt retires in order: the NEXT pair's rows (consumed a whole
+            // pair later, never waited for here) are issued before this pair's stores, and nothing is loaded after
+            // the stores (w keeps the pass-0 twiddles for the next pair's phase 0).
+            if constexpr (HALF_IN) {
+                CP_SCHED_FENCE();
+                prefetch_rows(t, nra, nrb, st.va, st.vb);
+                CP_SCHED_FENCE();
+            }
+            Pass<NP, P, 0>::twiddle_apply(st.w, x);
+            Pass<NP, P, 0>::butterflies(x);
+            if constexpr (HALF_IN && OUT_MODE == OUT_HALF) {
+                store_output_half(t, A, oa, ob, has_b, nxt_ker, st, x);
+            } else {
+                store_output(t, A, oa, ob, has_b, post, x);
+            }
         }
     }
 };

@@ -30,13 +30,37 @@ bool find_launcher_g4(int npad, Launcher* out);
 #if defined(__HIPCC__)
 template <int NP, int P, int IM, int OM, int PH>
 __device__ __forceinline__ void run_phases(int t, const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b,
-                                           int ker, cplx* lds) {
+                                           int ker, cplx* lds, const double* nra, const double* nrb, int nxt_ker,
+                                           typename Fftlog<NP, P, IM, OM>::State& st) {
     using F = Fftlog<NP, P, IM, OM>;
-    F::template phase<PH>(t, A, ra, rb, oa, ob, has_b, ker, lds);
+    F::template phase<PH>(t, A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st);
     if constexpr (PH + 1 < F::NPH) {
         __syncthreads();
-        run_phases<NP, P, IM, OM, PH + 1>(t, A, ra, rb, oa, ob, has_b, ker, lds);
+        run_phases<NP, P, IM, OM, PH + 1>(t, A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st);
     }
+}
+
+// rows of pair p: batch items (2 q, 2 q + 1) of kernel `ker`; an incomplete last pair aliases row b to row a
+struct PairRows {
+    const double* ra;
+    const double* rb;
+    double* oa;
+    double* ob;
+    int ker;
+    int has_b;  // int, not bool: no padding bytes (a padded struct copy goes through scratch memory)
+};
+
+__device__ __forceinline__ PairRows pair_rows(const FftlogArgs& A, long long p) {
+    PairRows r;
+    r.ker = (int)(p % A.nker);
+    const long long b0 = 2 * (p / A.nker);
+    r.has_b = b0 + 1 < A.nbatch;
+    const long long b1 = r.has_b ? b0 + 1 : b0;
+    r.ra = A.in + (b0 * A.nker + r.ker) * A.n;
+    r.rb = A.in + (b1 * A.nker + r.ker) * A.n;
+    r.oa = A.out + (b0 * A.nker + r.ker) * A.n_out;
+    r.ob = A.out + (b1 * A.nker + r.ker) * A.n_out;
+    return r;
 }
 
 // One workgroup = T threads = one packed pair of rows per loop iteration (persistent over pairs).
@@ -50,17 +74,20 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
     const int t = threadIdx.x;
     const long long nhalf = (A.nbatch + 1) / 2;
     const long long npairs = nhalf * A.nker;
-    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
-        const int ker = (int)(p % A.nker);
-        const long long b0 = 2 * (p / A.nker);
-        const bool has_b = b0 + 1 < A.nbatch;
-        const long long b1 = has_b ? b0 + 1 : b0;  // incomplete pair: alias row b to row a (its results are dropped)
-        const double* ra = A.in + (b0 * A.nker + ker) * A.n;
-        const double* rb = A.in + (b1 * A.nker + ker) * A.n;
-        double* oa = A.out + (b0 * A.nker + ker) * A.n_out;
-        double* ob = A.out + (b1 * A.nker + ker) * A.n_out;
-        run_phases<NP, P, IM, OM, 0>(t, A, ra, rb, oa, ob, has_b, ker, lds);
+    typename F::State st;  // tables loaded one phase ahead + prefetched rows (cp_fftlog_body.h)
+    long long p = blockIdx.x;
+    if (p >= npairs) return;
+    PairRows cur = pair_rows(A, p);
+    F::init_state(t, A, cur.ra, cur.rb, cur.ker, st);
+    for (;;) {
+        const long long pn = p + gridDim.x;
+        const bool more = pn < npairs;
+        const PairRows nxt = more ? pair_rows(A, pn) : cur;
+        run_phases<NP, P, IM, OM, 0>(t, A, cur.ra, cur.rb, cur.oa, cur.ob, cur.has_b, cur.ker, lds, nxt.ra, nxt.rb, nxt.ker, st);
+        if (!more) break;
         if (F::NPASS > 1) __syncthreads();  // LDS is reused by the next pair
+        p = pn;
+        cur = nxt;
     }
 }
 

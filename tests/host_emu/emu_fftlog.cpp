@@ -12,11 +12,24 @@
 
 using namespace cpfft;
 
+// per-thread register state (tables loaded one phase ahead, prefetched rows) persists across phases and pairs
 template <int NP, int P, int IM, int OM, int PH>
-static void run_phases(const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b, int ker, cplx* lds) {
+static void run_phases(const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b, int ker, cplx* lds,
+                       const double* nra, const double* nrb, int nxt_ker, typename Fftlog<NP, P, IM, OM>::State* st) {
     using F = Fftlog<NP, P, IM, OM>;
-    for (int t = 0; t < F::T; ++t) F::template phase<PH>(t, A, ra, rb, oa, ob, has_b, ker, lds);
-    if constexpr (PH + 1 < F::NPH) run_phases<NP, P, IM, OM, PH + 1>(A, ra, rb, oa, ob, has_b, ker, lds);
+    for (int t = 0; t < F::T; ++t) F::template phase<PH>(t, A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st[t]);
+    if constexpr (PH + 1 < F::NPH) run_phases<NP, P, IM, OM, PH + 1>(A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st);
+}
+
+template <int NP, int P, int IM, int OM>
+static void run_pair(const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b, int ker, cplx* lds,
+                     const double* nra, const double* nrb, int nxt_ker, void* state, bool first) {
+    using F = Fftlog<NP, P, IM, OM>;
+    static_assert(sizeof(typename F::State) <= (16 * P + 32 * 8), "state slot too small");
+    auto* st = reinterpret_cast<typename F::State*>(state);
+    if (first)
+        for (int t = 0; t < F::T; ++t) F::init_state(t, A, ra, rb, ker, st[t]);
+    run_phases<NP, P, IM, OM, 0>(A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st);
 }
 
 template <int NP, int P>
@@ -34,22 +47,34 @@ static int emulate(int n, int nker, const double* pre, const double* post, const
     A.ext_l = ext_l; A.ext_r = ext_r; A.val_l = val_l; A.val_r = val_r;
     A.pre = pre; A.post = post; A.u = u.data(); A.tw = tw.data();
     const long long nhalf = (nbatch + 1) / 2, npairs = nhalf * nker;
-    for (long long p = 0; p < npairs; ++p) {
-        const int ker = (int)(p % nker);
+    std::vector<char> pfv((size_t)(16 * P + 32 * 8) * Plan<NP, P>::T);  // State is the same size for every variant of (NP, P)
+    void* pf = pfv.data();
+    auto rows = [&](long long p, const double*& ra, const double*& rb, double*& oa, double*& ob, bool& has_b, int& ker) {
+        ker = (int)(p % nker);
         const long long b0 = 2 * (p / nker), b1 = b0 + 1;
-        const double* ra = in + (b0 * nker + ker) * n;
-        double* oa = out + (b0 * nker + ker) * A.n_out;
-        const bool has_b = b1 < nbatch;
-        const double* rb = has_b ? in + (b1 * nker + ker) * n : ra;
-        double* ob = has_b ? out + (b1 * nker + ker) * A.n_out : oa;
+        ra = in + (b0 * nker + ker) * n;
+        oa = out + (b0 * nker + ker) * A.n_out;
+        has_b = b1 < nbatch;
+        rb = has_b ? in + (b1 * nker + ker) * n : ra;
+        ob = has_b ? out + (b1 * nker + ker) * A.n_out : oa;
+    };
+    // one emulated workgroup walks all pairs (grid = 1), prefetching the next pair's rows like the kernel does
+    for (long long p = 0; p < npairs; ++p) {
+        const double *ra, *rb, *nra, *nrb;
+        double *oa, *ob, *noa, *nob;
+        bool has_b, nhas_b;
+        int ker, nker_;
+        rows(p, ra, rb, oa, ob, has_b, ker);
+        rows(p + 1 < npairs ? p + 1 : p, nra, nrb, noa, nob, nhas_b, nker_);
+        const bool first = p == 0;
         // same variant selection as the library (cp_fftlog.hip: select_variant)
         const int v = select_variant(NP, P, n, ext_l, val_l, ext_r, val_r, keep_padding);
         if constexpr (P == 16 && (NP > 16)) {
-            if (v == VAR_HALF_ZERO) { run_phases<NP, P, IN_HALF_ZERO, OUT_HALF, 0>(A, ra, rb, oa, ob, has_b, ker, lds.data()); continue; }
-            if (v == VAR_HALF) { run_phases<NP, P, IN_HALF, OUT_HALF, 0>(A, ra, rb, oa, ob, has_b, ker, lds.data()); continue; }
+            if (v == VAR_HALF_ZERO) { run_pair<NP, P, IN_HALF_ZERO, OUT_HALF>(A, ra, rb, oa, ob, has_b, ker, lds.data(), nra, nrb, nker_, pf, first); continue; }
+            if (v == VAR_HALF) { run_pair<NP, P, IN_HALF, OUT_HALF>(A, ra, rb, oa, ob, has_b, ker, lds.data(), nra, nrb, nker_, pf, first); continue; }
         }
-        if (v == VAR_LOG) run_phases<NP, P, IN_LOG, OUT_GENERIC, 0>(A, ra, rb, oa, ob, has_b, ker, lds.data());
-        else run_phases<NP, P, IN_GENERIC, OUT_GENERIC, 0>(A, ra, rb, oa, ob, has_b, ker, lds.data());
+        if (v == VAR_LOG) run_pair<NP, P, IN_LOG, OUT_GENERIC>(A, ra, rb, oa, ob, has_b, ker, lds.data(), nra, nrb, nker_, pf, first);
+        else run_pair<NP, P, IN_GENERIC, OUT_GENERIC>(A, ra, rb, oa, ob, has_b, ker, lds.data(), nra, nrb, nker_, pf, first);
     }
     return 0;
 }
