@@ -29,6 +29,13 @@
 #define CP_SCHED_FENCE() ((void)0)
 #endif
 
+// Diagnostic builds only (tools/fftlog_microbench.hip): a bit mask that removes one cost at a time so that timing
+// differences show what the kernel is waiting on.  Results are wrong when any bit is set; the library is built with 0.
+//   1 no LDS traffic   2 no workgroup barriers   4 no table loads   8 no HBM row loads   16 no HBM stores   32 no butterflies
+#ifndef CP_ABLATE
+#define CP_ABLATE 0
+#endif
+
 namespace cpfft {
 
 struct cplx {
@@ -255,13 +262,22 @@ struct Pass {
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int r = 0; r < R; ++r) x[i * R + r] = lds[swz<NP>(elem(t, i, r))];
+            for (int r = 0; r < R; ++r) {
+                if (CP_ABLATE & 1) x[i * R + r] = cplx{1e-3 * t + r, 1. + i};
+                else x[i * R + r] = lds[swz<NP>(elem(t, i, r))];
+            }
     }
     static CP_HD void store_lds(int t, cplx* lds, const cplx* x) {
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int r = 0; r < R; ++r) lds[swz<NP>(elem(t, i, r))] = x[i * R + r];
+            for (int r = 0; r < R; ++r) {
+                if (CP_ABLATE & 1) {
+                    if (x[i * R + r].re == 1.2345e301) lds[t] = x[i * R + r];  // keeps x alive, never taken
+                } else {
+                    lds[swz<NP>(elem(t, i, r))] = x[i * R + r];
+                }
+            }
     }
     static CP_HD void twiddle(int t, const cplx* tw, cplx* x) {
         if (M == 1) return;
@@ -280,17 +296,42 @@ struct Pass {
         for (int i = 0; i < NB; ++i) {
             const int j = joff(t, i);
 #pragma unroll
-            for (int s = 1; s < R; ++s) w[i * R + s] = tw[s * M + j];
+            for (int s = 1; s < R; ++s) {
+                if (CP_ABLATE & 4) w[i * R + s] = cplx{1. + 1e-9 * t, 0.5 + s};
+                else w[i * R + s] = tw[s * M + j];
+            }
+        }
+    }
+    // twiddles of the middle passes come from a copy of the pass table in LDS (a few KB, loaded once per
+    // workgroup): ~10x lower latency than L2 and no traffic on the vector-memory path
+    static CP_HD void twiddle_apply_lds(int t, const cplx* ltw, cplx* x) {
+        if (M == 1) return;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = joff(t, i);
+#pragma unroll
+            for (int s = 1; s < R; ++s) {
+                cplx w;
+                if (CP_ABLATE & 4) w = cplx{1. + 1e-9 * t, 0.5 + s};
+                else w = ltw[s * M + j];
+                if (CP_ABLATE & 32) x[i * R + s].re += w.re + w.im;
+                else x[i * R + s] = cmul(x[i * R + s], w);
+            }
         }
     }
     static CP_HD void twiddle_apply(const cplx* w, cplx* x) {
         if (M == 1) return;
+        if (CP_ABLATE & 32) {
+            x[1].re += w[1].re + w[R - 1].im;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
             for (int s = 1; s < R; ++s) x[i * R + s] = cmul(x[i * R + s], w[i * R + s]);
     }
     static CP_HD void butterflies(cplx* x) {
+        if (CP_ABLATE & 32) return;
 #pragma unroll
         for (int i = 0; i < NB; ++i) Dft<R>::run(x + i * R);
     }

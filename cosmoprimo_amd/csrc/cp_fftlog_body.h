@@ -45,6 +45,9 @@ struct FftlogArgs {
     const double* post; // (nker, NP) padded postfactor
     const cplx* u;      // (nker, NP) Hermitian-extended u / NP in thread layout [(i R + s) T + t]
     const cplx* tw;     // concatenated per-pass twiddles, Plan::tw_offset
+#if defined(CP_STAMPS)
+    double* val_stamp;  // diagnostic builds: per-wave cycle sums
+#endif
 };
 
 template <int NP, int P, int IN_MODE = IN_LOG, int OUT_MODE = OUT_GENERIC>
@@ -55,6 +58,13 @@ struct Fftlog {
     static constexpr int NPH = 2 * NPASS - 1;  // phases separated by workgroup barriers
     static constexpr int LAST = NPASS - 1;
     static constexpr bool HALF_IN = IN_MODE == IN_HALF || IN_MODE == IN_HALF_ZERO;
+    // LDS: NP complex slots of data, then the twiddle tables of passes >= 1 (Plan::tw_offset order)
+    static constexpr int LDS_TW_ENTRIES = NPASS > 1 ? PL::TW_TOTAL - NP : 0;
+    static constexpr int LDS_BYTES = NPASS > 1 ? (NP + LDS_TW_ENTRIES) * (int)sizeof(cplx) : 0;
+    template <int I>
+    static CP_HD const cplx* lds_tw(const cplx* lds) {
+        return lds + NP + (PL::tw_offset(I) - NP);
+    }
     static_assert((!HALF_IN && OUT_MODE != OUT_HALF) || (P == 16 && NPASS > 1), "HALF modes need P == 16 and NP > 16");
 
     // padded input element j of one row (reference pad(): fftlog.py:483-505); branch-free for constant / edge
@@ -77,8 +87,13 @@ struct Fftlog {
     static CP_HD void prefetch_rows(int t, const double* __restrict__ ra, const double* __restrict__ rb, double* va, double* vb) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            va[r] = ra[t + T * r];
-            vb[r] = rb[t + T * r];
+            if (CP_ABLATE & 8) {
+                va[r] = 1e-3 * t + r;
+                vb[r] = 2e-3 * t - r;
+            } else {
+                va[r] = ra[t + T * r];
+                vb[r] = rb[t + T * r];
+            }
         }
     }
 
@@ -139,6 +154,13 @@ struct Fftlog {
             load_factors_half(t, A, nxt_ker, st);
             CP_SCHED_FENCE();
         }
+        if (CP_ABLATE & 16) {
+            double acc = 0.;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc += ya[s] * yb[s];
+            if (acc == 1.2345e301) oa[t] = acc;  // keeps the results alive, never taken
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) oa[t + T * s] = ya[s];
         if (has_b) {
@@ -187,7 +209,10 @@ struct Fftlog {
     static CP_HD void load_u(int t, const FftlogArgs& A, int ker, cplx* w) {
         const cplx* __restrict__ u = A.u + (long long)ker * NP;
 #pragma unroll
-        for (int e = 0; e < P; ++e) w[e] = u[e * T + t];
+        for (int e = 0; e < P; ++e) {
+            if (CP_ABLATE & 4) w[e] = cplx{1. + 1e-9 * t, 0.5 + e};
+            else w[e] = u[e * T + t];
+        }
     }
 
     static CP_HD void load_factors_half(int t, const FftlogArgs& A, int ker, State& st) {
@@ -200,6 +225,11 @@ struct Fftlog {
         }
     }
 
+    // once per workgroup: thread t copies its share of the middle-pass twiddle tables into LDS (a barrier follows)
+    static CP_HD void fill_lds_tables(int t, const FftlogArgs& A, cplx* lds) {
+        for (int i = t; i < LDS_TW_ENTRIES; i += T) lds[NP + i] = A.tw[NP + i];
+    }
+
     // before the first pair of a workgroup
     static CP_HD void init_state(int t, const FftlogArgs& A, const double* ra, const double* rb, int ker, State& st) {
         if constexpr (NPASS > 1) load_twiddles<0>(t, A, st.w);
@@ -209,19 +239,22 @@ struct Fftlog {
         }
     }
 
-    // tables of phase PHN into w (called at the end of phase PHN - 1)
+    // global tables of phase PHN into w (called at the end of phase PHN - 1): U for the middle phase, the pass-0
+    // twiddles for the last phase (they then stay in w for the next pair's phase 0); the middle passes read LDS tables
     template <int PHN>
     static CP_HD void load_tables_for(int t, const FftlogArgs& A, int ker, cplx* w) {
-        if constexpr (PHN < LAST) {
-            load_twiddles<(PHN < LAST ? PHN : 0)>(t, A, w);
-        } else if constexpr (PHN == LAST) {
+        if constexpr (PHN == LAST) {
             load_u(t, A, ker, w);
-        } else if constexpr (PHN < NPH) {
-            load_twiddles<(PHN > LAST && PHN < NPH ? NPH - 1 - PHN : 0)>(t, A, w);
+        } else if constexpr (PHN == NPH - 1) {
+            load_twiddles<0>(t, A, w);
         }
     }
 
     static CP_HD void mul_w(const cplx* w, cplx* x) {
+        if (CP_ABLATE & 32) {
+            x[1].re += w[1].re + w[P - 1].im;
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < P; ++e) x[e] = cmul(x[e], w[e]);
     }
@@ -266,7 +299,7 @@ struct Fftlog {
             constexpr int I = (PH < LAST) ? PH : 0;
             Pass<NP, P, I>::load_lds(t, lds, x);
             Pass<NP, P, I>::butterflies(x);
-            Pass<NP, P, I>::twiddle_apply(st.w, x);
+            Pass<NP, P, I>::twiddle_apply_lds(t, lds_tw<I>(lds), x);
             Pass<NP, P, I>::store_lds(t, lds, x);
             load_tables_for<PH + 1>(t, A, ker, st.w);
         } else if constexpr (PH == LAST) {
@@ -279,7 +312,7 @@ struct Fftlog {
         } else if constexpr (PH < NPH - 1) {
             constexpr int I = (PH > LAST && PH < NPH - 1) ? (NPH - 1 - PH) : 0;
             Pass<NP, P, I>::load_lds(t, lds, x);
-            Pass<NP, P, I>::twiddle_apply(st.w, x);
+            Pass<NP, P, I>::twiddle_apply_lds(t, lds_tw<I>(lds), x);
             Pass<NP, P, I>::butterflies(x);
             Pass<NP, P, I>::store_lds(t, lds, x);
             load_tables_for<PH + 1>(t, A, ker, st.w);

@@ -28,15 +28,38 @@ bool find_launcher_g3(int npad, Launcher* out);
 bool find_launcher_g4(int npad, Launcher* out);
 
 #if defined(__HIPCC__)
+#if defined(CP_STAMPS)
+// diagnostic build (tools/fftlog_microbench.hip -DCP_STAMPS): per-wave cycle sums of each phase's work and barrier wait
+__device__ __forceinline__ unsigned long long cp_stamp() {
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define CP_STAMP_DECL , unsigned long long* cp_stamp_acc
+#define CP_STAMP_ARG , cp_stamp_acc
+#else
+#define CP_STAMP_DECL
+#define CP_STAMP_ARG
+#endif
 template <int NP, int P, int IM, int OM, int PH>
 __device__ __forceinline__ void run_phases(int t, const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b,
                                            int ker, cplx* lds, const double* nra, const double* nrb, int nxt_ker,
-                                           typename Fftlog<NP, P, IM, OM>::State& st) {
+                                           typename Fftlog<NP, P, IM, OM>::State& st CP_STAMP_DECL) {
     using F = Fftlog<NP, P, IM, OM>;
+#if defined(CP_STAMPS)
+    const unsigned long long s0 = cp_stamp();
+#endif
     F::template phase<PH>(t, A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st);
+#if defined(CP_STAMPS)
+    const unsigned long long s1 = cp_stamp();
+    cp_stamp_acc[2 * PH] += s1 - s0;
+#endif
     if constexpr (PH + 1 < F::NPH) {
-        __syncthreads();
-        run_phases<NP, P, IM, OM, PH + 1>(t, A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st);
+        if (!(CP_ABLATE & 2)) __syncthreads();
+#if defined(CP_STAMPS)
+        cp_stamp_acc[2 * PH + 1] += cp_stamp() - s1;
+#endif
+        run_phases<NP, P, IM, OM, PH + 1>(t, A, ra, rb, oa, ob, has_b, ker, lds, nra, nrb, nxt_ker, st CP_STAMP_ARG);
     }
 }
 
@@ -77,18 +100,52 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
     typename F::State st;  // tables loaded one phase ahead + prefetched rows (cp_fftlog_body.h)
     long long p = blockIdx.x;
     if (p >= npairs) return;
+#if defined(CP_EXP_PRIO)
+    // experiment: break the lockstep of the two co-resident workgroups of a CU with a static wave priority
+    if (CP_EXP_PRIO == 1 && blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(2);
+    if (CP_EXP_PRIO == 2 && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(2);
+    if (CP_EXP_PRIO == 3 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(2);
+    if (CP_EXP_PRIO == 4 && blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < 60; ++i) __builtin_amdgcn_s_sleep(127);  // ~60 x 127 x 64 clk ~ 0.2 ms... start stagger
+    }
+    if (CP_EXP_PRIO == 5 && blockIdx.x >= gridDim.x / 2) {
+        for (int i = 0; i < 1; ++i) __builtin_amdgcn_s_sleep(100);  // ~6400 clk ~ 3 us start stagger
+    }
+#endif
     PairRows cur = pair_rows(A, p);
     F::init_state(t, A, cur.ra, cur.rb, cur.ker, st);
+    if constexpr (F::NPASS > 1) {
+        F::fill_lds_tables(t, A, lds);
+        __syncthreads();
+    }
+#if defined(CP_STAMPS)
+    unsigned long long cp_stamp_acc[2 * F::NPH] = {0};
+    const unsigned long long cp_t_begin = cp_stamp();
+#endif
     for (;;) {
         const long long pn = p + gridDim.x;
         const bool more = pn < npairs;
         const PairRows nxt = more ? pair_rows(A, pn) : cur;
-        run_phases<NP, P, IM, OM, 0>(t, A, cur.ra, cur.rb, cur.oa, cur.ob, cur.has_b, cur.ker, lds, nxt.ra, nxt.rb, nxt.ker, st);
+        run_phases<NP, P, IM, OM, 0>(t, A, cur.ra, cur.rb, cur.oa, cur.ob, cur.has_b, cur.ker, lds, nxt.ra, nxt.rb, nxt.ker, st CP_STAMP_ARG);
         if (!more) break;
-        if (F::NPASS > 1) __syncthreads();  // LDS is reused by the next pair
+#if defined(CP_STAMPS)
+        const unsigned long long sb = cp_stamp();
+#endif
+        if (F::NPASS > 1 && !(CP_ABLATE & 2)) __syncthreads();  // LDS is reused by the next pair
+#if defined(CP_STAMPS)
+        cp_stamp_acc[2 * F::NPH - 1] += cp_stamp() - sb;
+#endif
         p = pn;
         cur = nxt;
     }
+#if defined(CP_STAMPS)
+    if ((threadIdx.x & 63) == 0) {  // the stamp buffer is aliased onto the (unused) tail of A.post by the microbench
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<double*>(A.val_stamp)) +
+                                  ((size_t)blockIdx.x * (NP / P / 64) + threadIdx.x / 64) * (2 * F::NPH + 1);
+        for (int i = 0; i < 2 * F::NPH; ++i) dst[i] = cp_stamp_acc[i];
+        dst[2 * F::NPH] = cp_stamp() - cp_t_begin;
+    }
+#endif
 }
 
 template <int NP, int P>
@@ -99,7 +156,7 @@ constexpr bool has_half() {
 template <int NP, int P>
 void launch_impl(int variant, const FftlogArgs& A, int grid, hipStream_t stream) {
     constexpr int T = Plan<NP, P>::T;
-    constexpr int lds = Plan<NP, P>::NPASS > 1 ? NP * (int)sizeof(cplx) : 0;
+    constexpr int lds = Fftlog<NP, P>::LDS_BYTES;
     if constexpr (has_half<NP, P>()) {
         if (variant == VAR_HALF_ZERO) {
             hipLaunchKernelGGL((fftlog_kernel<NP, P, IN_HALF_ZERO, OUT_HALF>), dim3(grid), dim3(T), lds, stream, A);
@@ -130,7 +187,7 @@ Launcher make_launcher() {
     l.np = NP;
     l.p = P;
     l.block = Plan<NP, P>::T;
-    l.lds_bytes = Plan<NP, P>::NPASS > 1 ? NP * (int)sizeof(cplx) : 0;
+    l.lds_bytes = Fftlog<NP, P>::LDS_BYTES;
     l.build_tw = &build_twiddles<NP, P>;
     l.build_u = &build_u_layout<NP, P>;
     return l;

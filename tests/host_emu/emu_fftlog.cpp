@@ -35,7 +35,7 @@ static void run_pair(const FftlogArgs& A, const double* ra, const double* rb, do
 template <int NP, int P>
 static int emulate(int n, int nker, const double* pre, const double* post, const double* u_re_im, const double* in, double* out,
                    long long nbatch, int ext_l, double val_l, int ext_r, double val_r, int keep_padding) {
-    std::vector<cplx> tw, u((size_t)nker * NP), lds(NP);
+    std::vector<cplx> tw, u((size_t)nker * NP), lds(NP + Fftlog<NP, P>::LDS_TW_ENTRIES + 1);
     build_twiddles<NP, P>(tw);
     for (int k = 0; k < nker; ++k) build_u_layout<NP, P>(u_re_im + (size_t)k * 2 * (NP / 2 + 1), u.data() + (size_t)k * NP);
     FftlogArgs A;
@@ -46,6 +46,7 @@ static int emulate(int n, int nker, const double* pre, const double* post, const
     A.n_out = keep_padding ? NP : n;
     A.ext_l = ext_l; A.ext_r = ext_r; A.val_l = val_l; A.val_r = val_r;
     A.pre = pre; A.post = post; A.u = u.data(); A.tw = tw.data();
+    for (int t = 0; t < Plan<NP, P>::T; ++t) Fftlog<NP, P>::fill_lds_tables(t, A, lds.data());
     const long long nhalf = (nbatch + 1) / 2, npairs = nhalf * nker;
     std::vector<char> pfv((size_t)(16 * P + 32 * 8) * Plan<NP, P>::T);  // State is the same size for every variant of (NP, P)
     void* pf = pfv.data();
