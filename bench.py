@@ -186,6 +186,13 @@ def main():
         block = __import__('ctypes').c_int()
         lds = __import__('ctypes').c_int()
         lib.cp_fftlog_plan_info(plan.handle, nb, grid, block, lds)
+        traffic, traffic_src = None, None
+        import glob
+        prof = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))
+        if prof and nb == ROWS_PER_GPU:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            with open(prof[-1]) as fh:
+                traffic = json.load(fh)['hbm_bytes_per_launch']['total']
+            traffic_src = os.path.relpath(prof[-1], ROOT)
         line = {
             'metric': 'batched FFTLog P(k)->xi(r) transforms/sec (N=2048)', 'value': value, 'unit': 'transforms/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -194,7 +201,7 @@ def main():
                        'rows_per_gpu': nb, 'n_k': N_K, 'padded_size': 4096, 'parallelism': 'rows sharded over %d GPU(s), no collective' % world,
                        'grid': grid.value, 'block': block.value, 'lds_bytes': lds.value},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'kernel': 'fftlog_kernel<4096,16,IN_HALF_ZERO,OUT_HALF>', 'kernel_ms': kernel_ms,
+                         'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'fftlog_kernel<4096,16,IN_HALF_ZERO,OUT_HALF>', 'kernel_ms': kernel_ms,
                          'algorithmic_bytes_per_launch': BYTES_PER_ROW * nb},
             'parity_spot_check_tilted_err': err,
         }
