@@ -33,7 +33,20 @@ SIGNATURES = {
                                         ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]),
     'cp_fftlog_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_fftlog_plan_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, _c_int_p, _c_int_p, _c_int_p]),
+    'cp_background_distance': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cp_background_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
 }
+
+
+class cp_param(ctypes.Structure):
+    """A per-cosmology parameter: device array (ptr) or broadcast value (include/cosmoprimo_amd.h)."""
+    _fields_ = [('ptr', ctypes.c_void_p), ('value', ctypes.c_double)]
+
+
+BG_PARAMS = ('h', 'Omega_cdm', 'Omega_b', 'Omega_k', 'T_cmb', 'N_ur', 'w0_fld', 'wa_fld')
+BG_KINDS = {'comoving_radial_distance': 0, 'comoving_transverse_distance': 1, 'angular_diameter_distance': 2, 'luminosity_distance': 3,
+            'efunc': 4, 'hubble_function': 5}
 
 _lib = None
 

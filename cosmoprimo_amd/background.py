@@ -1,0 +1,105 @@
+"""
+Background E(z) and distances on MI355X for batches of cosmologies: the data-parallel core behind
+``DefaultBackground`` (reference cosmoprimo/cosmology.py:1954-2042, 1855-1912, 1751-1759).
+
+:func:`distance` is the batch entry point (one HIP thread per (cosmology, z) sample, ``cp_background_distance``);
+the section class :class:`cosmoprimo_amd.cosmology.DefaultBackground` wraps it with the reference's method names.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+KINDS = tuple(_lib.BG_KINDS)
+DEFAULTS = dict(h=0.7, Omega_cdm=0.25, Omega_b=0.05, Omega_k=0., T_cmb=2.7255, N_ur=3.044, w0_fld=-1., wa_fld=0.)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith('torch')
+
+
+def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=None):
+    """
+    Evaluate ``kind`` (one of :data:`KINDS`: 'comoving_radial_distance', 'comoving_transverse_distance',
+    'angular_diameter_distance', 'luminosity_distance' [Mpc/h], 'efunc', 'hubble_function' [km/s/Mpc]).
+
+    params : dict of ``h, Omega_cdm, Omega_b, Omega_k, T_cmb, N_ur, w0_fld, wa_fld``; each a float (shared) or an array /
+        torch CUDA tensor of shape (ncosmo,).  Missing entries take the reference defaults (cosmology.py:730-733).
+    Omega_m : float or array, optional; replaces ``Omega_cdm`` (Omega_cdm = Omega_m - Omega_b, cosmology.py:1163-1165).
+    z : array or torch tensor.  ``per_cosmology_z=False``: any shape, shared by all cosmologies -> output (ncosmo,) + z.shape
+        (or z.shape for scalar parameters).  ``per_cosmology_z=True``: shape (ncosmo, ...) -> output of the same shape.
+
+    Returns numpy for numpy / float inputs, a torch tensor on the same device if ``z`` is a torch tensor.  float32 ``z`` gives
+    float32 output (reference utils.flatarray, utils.py:98-138); computation is float64.
+    """
+    import torch
+    if kind not in _lib.BG_KINDS:
+        raise ValueError('unknown quantity {}; choose one of {}'.format(kind, KINDS))
+    params = dict(params or {})
+    for name in params:
+        if name not in _lib.BG_PARAMS:
+            raise ValueError('unknown background parameter {}'.format(name))
+    if Omega_m is not None:
+        params['Omega_cdm'] = Omega_m
+    z_torch = _is_torch(z)
+    if device is None:
+        if z_torch and z.is_cuda:
+            device = z.device
+        else:
+            for v in params.values():
+                if _is_torch(v) and v.is_cuda:
+                    device = v.device
+                    break
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError('cosmoprimo_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path')
+        device = torch.device('cuda', torch.cuda.current_device())
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    out_dtype = None
+    if z_torch:
+        out_dtype = z.dtype if z.dtype in (torch.float32, torch.float64) else torch.float64
+        tz = z.to(device=device, dtype=torch.float64)
+    else:
+        z = np.asarray(z)
+        np_dtype = z.dtype if z.dtype in (np.float32, np.float64) else np.float64
+        tz = torch.from_numpy(np.ascontiguousarray(z, dtype='f8')).to(device).reshape(z.shape)  # ascontiguousarray promotes 0-d to 1-d
+    ncosmo, batched = 1, False
+    tensors = {}
+    cparams = (_lib.cp_param * len(_lib.BG_PARAMS))()
+    for i, name in enumerate(_lib.BG_PARAMS):
+        v = params.get(name, DEFAULTS[name])
+        if np.ndim(v) == 0 and not _is_torch(v):
+            cparams[i].ptr, cparams[i].value = None, float(v)
+            continue
+        t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else torch.from_numpy(np.ascontiguousarray(v, dtype='f8')).to(device)
+        t = t.reshape(-1).contiguous()
+        if t.numel() == 1 and not batched and np.ndim(v) == 0:
+            cparams[i].ptr, cparams[i].value = None, float(t)
+            continue
+        if batched and t.numel() != ncosmo:
+            raise ValueError('parameter arrays must share one length, got {} and {}'.format(ncosmo, t.numel()))
+        ncosmo, batched = t.numel(), True
+        tensors[name] = t
+        cparams[i].ptr, cparams[i].value = t.data_ptr(), 0.
+    zshape = tuple(tz.shape)
+    if per_cosmology_z:
+        if not batched or len(zshape) < 1 or zshape[0] != ncosmo:
+            raise ValueError('per_cosmology_z needs z of shape (ncosmo, ...) = ({:d}, ...), got {}'.format(ncosmo, zshape))
+        nz = int(np.prod(zshape[1:], dtype=np.int64))
+        oshape = zshape
+    else:
+        nz = int(np.prod(zshape, dtype=np.int64))
+        oshape = ((ncosmo,) if batched else ()) + zshape
+    tz = tz.reshape(-1).contiguous()
+    out = torch.empty(ncosmo * nz, dtype=torch.float64, device=device)
+    if ncosmo * nz:
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(_lib.load().cp_background_distance(ncosmo, nz, ctypes.cast(cparams, ctypes.c_void_p), int(Omega_m is not None), tz.data_ptr(),
+                                                      int(not per_cosmology_z), out.data_ptr(), _lib.BG_KINDS[kind], device.index, stream))
+    out = out.reshape(oshape)
+    if z_torch:
+        return out.to(out_dtype)
+    return out.cpu().numpy().astype(np_dtype)

@@ -1,0 +1,280 @@
+// cp_background.hip -- background E(z) and distances for batches of cosmologies (gfx950) + C ABI.
+//
+// Replaces DefaultBackground.comoving_radial_distance and the distances derived from it
+// (reference cosmoprimo/cosmology.py:2027-2042, 1855-1912) together with everything they call:
+// BaseBackground.efunc / rho_* (:1680-1754), jax.odeint 'rk4' on the 119-knot grid (jax.py:672-716,
+// cosmology.py:1940-1951), the natural cubic spline of Interpolator1D (jax.py:169-175) and the per-cosmology
+// derived density parameters (cosmology.py:355-397).
+//
+// One thread per (cosmology, z) sample, no per-sample storage:
+//  * the RK4 of the reference has a y-independent integrand, i.e. it is Simpson with midpoints on each knot
+//    interval: inc_i = h_i/6 (f(z_i) + 2 f(mid) + 2 f(mid) + f(z_{i+1})), T_{i+1} = T_i + inc_i;
+//  * the natural-spline system for the knot derivatives is tridiagonal with a matrix that depends on the grid
+//    only.  The value at z in [z_k, z_{k+1}] needs just s_k and s_{k+1}: eliminate forward from knot 0 up to k and
+//    backward from knot 118 down to k+1 (all pivots are host-precomputed constants) and solve the remaining 2x2.
+//    Every interval is integrated exactly once, in the order the thread needs it (forward up to k, then from the
+//    top down), so the 237 E(z) evaluations of the reference are all that is computed.
+// ALU-bound (pow, exp, sqrt per E(z)); HBM traffic is 8 bytes per parameter array + 8 in + 8 out per sample.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <limits>
+#include <vector>
+
+#include "../../include/cosmoprimo_amd.h"
+#include "cp_error.h"
+
+namespace {
+
+constexpr int NK = 119;  // knots of get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949
+
+// physical constants as cosmoprimo/constants.py (scipy.constants CODATA 2018 values)
+constexpr double kC = 299792458.0;
+constexpr double kStefanBoltzmann = 5.6703744191844314e-08;  // scipy.constants.Stefan_Boltzmann (derived to full precision)
+constexpr double kParsec = 3.085677581491367e16;
+constexpr double kG = 6.6743e-11;
+constexpr double kPi = 3.141592653589793;
+constexpr double kMpc = 1e6 * kParsec;
+constexpr double kMsun = 1.98847 * 1e30;
+constexpr double kRhoCritKg = 3.0 * (100. * 1e3 / kMpc) * (100. * 1e3 / kMpc) / (8 * kPi * kG);  // h^2 kg/m^3
+constexpr double kRhoCrit = kRhoCritKg / (1e10 * kMsun) * kMpc * kMpc * kMpc;                      // 1e10 Msun/h / (Mpc/h)^3
+constexpr double kCkms = kC / 1e3;
+
+struct Tables {
+    double zc[NK], dx[NK], l[NK], u[NK], idf[NK], idb[NK], cp[NK], bq[NK], ra[NK], rb[NK];
+};
+
+struct Param {
+    const double* ptr;  // per-cosmology array, or nullptr ->
+    double value;       // broadcast value
+};
+
+struct Args {
+    long long ncosmo, nz;
+    Param p[CP_BG_NPARAMS];
+    int second_is_omega_m;  // parameter 1 holds Omega_m (Omega_cdm = Omega_m - Omega_b, cosmology.py:1163-1165)
+    const double* z;
+    int z_shared;  // z has nz entries shared by all cosmologies, else ncosmo * nz
+    double* out;
+    int kind;
+    const Tables* tab;
+};
+
+struct Cosmo {
+    double Omega_cdm, Omega_b, Omega_g, Omega_ur, Omega_de, Omega_k, w0, wa, h;
+};
+
+__device__ __forceinline__ double efunc(const Cosmo& c, double z) {
+    // operation order of BaseBackground.rho_tot / rho_crit / efunc, cosmology.py:1723-1754
+    const double zp1 = 1. + z;
+    const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0.;
+    const double r = c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit;
+    const double de = c.Omega_de * pow(zp1, 3. * (c.w0 + c.wa)) * exp(3. * c.wa * (1. / zp1 - 1.)) * kRhoCrit;
+    const double rho_crit = (m + r + de) + c.Omega_k / zp1 * kRhoCrit;
+    return sqrt(rho_crit * (zp1 * zp1 * zp1) / kRhoCrit);
+}
+
+__global__ __launch_bounds__(256) void bg_kernel(const Args A) {
+    __shared__ Tables T;
+    {
+        const double* src = reinterpret_cast<const double*>(A.tab);
+        double* dst = reinterpret_cast<double*>(&T);
+        for (int i = threadIdx.x; i < (int)(sizeof(Tables) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const long long nsamp = A.ncosmo * A.nz;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsamp) return;
+    const long long ic = i / A.nz, iz = i - ic * A.nz;
+    double v[CP_BG_NPARAMS];
+#pragma unroll
+    for (int k = 0; k < CP_BG_NPARAMS; ++k) v[k] = A.p[k].ptr ? A.p[k].ptr[ic] : A.p[k].value;
+    Cosmo c;
+    c.h = v[0];
+    c.Omega_b = v[2];
+    c.Omega_cdm = A.second_is_omega_m ? v[1] - v[2] : v[1];
+    c.Omega_k = v[3];
+    const double T_cmb = v[4], N_ur = v[5];
+    c.w0 = v[6];
+    c.wa = v[7];
+    // derived density parameters, cosmology.py:355-383
+    const double h2rc = c.h * c.h * kRhoCritKg;
+    c.Omega_g = (T_cmb * T_cmb * T_cmb * T_cmb) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
+    const double T_ur = T_cmb * 0.7137658555036082;  // (4/11)^(1/3)
+    c.Omega_ur = N_ur * 7. / 8. * (T_ur * T_ur * T_ur * T_ur) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
+    c.Omega_de = 1. - (c.Omega_cdm + c.Omega_b + c.Omega_g + c.Omega_ur + 0. + c.Omega_k);
+    const double z = A.z[A.z_shared ? iz : i];
+    const double nan = __builtin_nan("");
+    if (A.kind == CP_BG_EFUNC || A.kind == CP_BG_HUBBLE) {
+        const double e = efunc(c, z);
+        A.out[i] = A.kind == CP_BG_EFUNC ? e : e * (c.h * 100.);
+        return;
+    }
+    if (!(z >= T.zc[0] && z <= T.zc[NK - 1])) {  // NaN outside the interpolation range (jax.py:200), also for NaN input
+        A.out[i] = nan;
+        return;
+    }
+    // interval k: zc[k] <= z < zc[k+1] (last interval closed), binary search
+    int lo = 0, hi = NK - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (z >= T.zc[mid]) lo = mid;
+        else hi = mid;
+    }
+    const int k = lo;
+    const double f_first = kCkms / (100. * efunc(c, T.zc[0]));
+    const double f_last = kCkms / (100. * efunc(c, T.zc[NK - 1]));
+    double fprev = f_first;     // integrand at the shared end of the previous interval
+    double tk = 0.;             // T_k = sum of inc_i, i < k, accumulated in knot order like the reference's scan
+    double inc_prev = 0.;       // inc of the previously processed interval (idx - 1 going up, idx + 1 going down)
+    double inc_k = 0.;          // inc of interval k (needed by both eliminations)
+    double dp = 0., dq = 0.;    // running right-hand sides of the forward / backward eliminations
+    for (int it = 0; it < NK - 1; ++it) {
+        const bool fwd = it <= k;
+        const int idx = fwd ? it : (NK - 1) - it + k;  // k+1 .. 117 visited top down
+        if (it == k + 1) {                              // direction switch: restart from the last knot
+            fprev = f_last;
+            inc_prev = 0.;
+        }
+        const double x0 = T.zc[idx], x1 = T.zc[idx + 1], h = T.dx[idx];
+        const double fm = kCkms / (100. * efunc(c, x0 + h / 2));
+        const double fe = kCkms / (100. * efunc(c, fwd ? x1 : x0));
+        const double k1 = fwd ? fprev : fe, k4 = fwd ? fe : fprev;
+        const double inc = h / 6. * (k1 + 2 * fm + 2 * fm + k4);  // jax.py:709 with k2 == k3
+        fprev = fe;
+        if (fwd) {
+            // knot idx: d = ra * inc_{idx-1} + rb * inc_idx
+            const double d = T.ra[idx] * inc_prev + T.rb[idx] * inc;
+            dp = (d - T.l[idx] * dp) * T.idf[idx];
+            if (idx < k) tk = tk + inc;
+            if (idx == k) inc_k = inc;
+        } else {
+            // knot idx + 1: d = ra * inc_idx + rb * inc_{idx+1}
+            const double d = T.ra[idx + 1] * inc + T.rb[idx + 1] * inc_prev;
+            dq = (d - T.u[idx + 1] * dq) * T.idb[idx + 1];
+        }
+        inc_prev = inc;
+    }
+    {   // knot k + 1 closes the backward elimination: intervals k (from the forward sweep) and k + 1
+        const double inc_up = (k == NK - 2) ? 0. : inc_prev;  // inc_{k+1}: the last interval visited going down
+        const double d = T.ra[k + 1] * inc_k + T.rb[k + 1] * inc_up;
+        dq = (d - T.u[k + 1] * dq) * T.idb[k + 1];
+    }
+    // s_k + cp_k s_{k+1} = dp ;  s_{k+1} + bq_{k+1} s_k = dq
+    const double cpk = T.cp[k], bqk = T.bq[k + 1];
+    const double sk = (dp - cpk * dq) / (1. - cpk * bqk);
+    const double sk1 = dq - bqk * sk;
+    const double hk = T.dx[k];
+    const double slope = inc_k / hk;
+    const double tt = (sk + sk1 - 2. * slope) / hk;
+    const double c3 = tt / hk, c2 = (slope - sk) / hk - tt;
+    const double dz = z - T.zc[k];
+    double chi = tk + dz * (sk + dz * (c2 + dz * c3));
+    if (A.kind != CP_BG_COMOVING_RADIAL) {
+        const double K = -(100. * 100.) / (kCkms * kCkms) * c.Omega_k;  // (h/Mpc)^2, cosmology.py:397
+        if (K > 0.) chi = sin(sqrt(K) * chi) / sqrt(K);
+        else if (K < 0.) chi = sinh(sqrt(-K) * chi) / sqrt(-K);
+        const double da = chi / (1. + z);  // cosmology.py:1868
+        chi = A.kind == CP_BG_ANGULAR_DIAMETER ? da : (A.kind == CP_BG_COMOVING_TRANSVERSE ? da * (1. + z) : da * ((1. + z) * (1. + z)));
+    }
+    A.out[i] = chi;
+}
+
+void build_tables(Tables& t) {
+    // knots: concatenate(linspace(0, 0.3, 20)[:-1], 1 / geomspace(1e-4, 1/1.3, 100)[::-1] - 1), cosmology.py:1947-1949
+    const double zm = 0.3;
+    for (int i = 0; i < 19; ++i) t.zc[i] = 0. + i * ((zm - 0.) / 19.);  // numpy.linspace: start + i * step
+    const double la = std::log10(1e-4), lb = std::log10(1. / (1. + zm));
+    double g[100];
+    for (int i = 0; i < 100; ++i) g[i] = std::pow(10., la + i * ((lb - la) / 99.));  // numpy.geomspace via logspace
+    g[0] = 1e-4;
+    g[99] = 1. / (1. + zm);  // geomspace pins its end points
+    for (int i = 0; i < 100; ++i) t.zc[19 + i] = 1. / g[99 - i] - 1.;
+    const int n = NK;
+    for (int i = 0; i < n - 1; ++i) t.dx[i] = t.zc[i + 1] - t.zc[i];
+    t.dx[n - 1] = 0.;
+    std::vector<double> b(n);
+    t.l[0] = 0.; b[0] = 2. * t.dx[0]; t.u[0] = t.dx[0]; t.ra[0] = 0.; t.rb[0] = 3.;
+    for (int i = 1; i < n - 1; ++i) {
+        t.l[i] = t.dx[i];
+        b[i] = 2. * (t.dx[i - 1] + t.dx[i]);
+        t.u[i] = t.dx[i - 1];
+        t.ra[i] = 3. * t.dx[i] / t.dx[i - 1];
+        t.rb[i] = 3. * t.dx[i - 1] / t.dx[i];
+    }
+    t.l[n - 1] = t.dx[n - 2]; b[n - 1] = 2. * t.dx[n - 2]; t.u[n - 1] = 0.; t.ra[n - 1] = 3.; t.rb[n - 1] = 0.;
+    t.idf[0] = 1. / b[0];
+    t.cp[0] = t.u[0] * t.idf[0];
+    for (int i = 1; i < n; ++i) {
+        t.idf[i] = 1. / (b[i] - t.l[i] * t.cp[i - 1]);
+        t.cp[i] = t.u[i] * t.idf[i];
+    }
+    t.idb[n - 1] = 1. / b[n - 1];
+    t.bq[n - 1] = t.l[n - 1] * t.idb[n - 1];
+    for (int i = n - 2; i >= 0; --i) {
+        t.idb[i] = 1. / (b[i] - t.u[i] * t.bq[i + 1]);
+        t.bq[i] = t.l[i] * t.idb[i];
+    }
+}
+
+// one device copy of the grid tables per device, created on first use
+Tables* device_tables(int device) {
+    static Tables* cache[64] = {nullptr};
+    if (device < 0 || device >= 64) return nullptr;
+    if (!cache[device]) {
+        Tables h;
+        build_tables(h);
+        Tables* d = nullptr;
+        if (hipMalloc(&d, sizeof(Tables)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, &h, sizeof(Tables), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        cache[device] = d;
+    }
+    return cache[device];
+}
+
+}  // namespace
+
+extern "C" int cp_background_knots(double* zc_out, int n) {
+    if (!zc_out || n != NK) return cp::fail(CP_EINVAL, "cp_background_knots: need a buffer of %d doubles", NK);
+    Tables t;
+    build_tables(t);
+    for (int i = 0; i < NK; ++i) zc_out[i] = t.zc[i];
+    return CP_OK;
+}
+
+extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const double* d_z,
+                                      int z_shared, double* d_out, int kind, int device, void* stream) {
+    if (ncosmo < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_background_distance: negative size");
+    if (ncosmo == 0 || nz == 0) return CP_OK;
+    if (!params || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_background_distance: null pointer");
+    if (kind < CP_BG_COMOVING_RADIAL || kind > CP_BG_HUBBLE) return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: cannot select device %d", device);
+    Tables* tab = device_tables(device);
+    if (!tab) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return cp::fail(CP_ENOMEM, "cp_background_distance: cannot allocate the knot tables on device %d", device);
+    }
+    Args A;
+    A.ncosmo = ncosmo;
+    A.nz = nz;
+    for (int k = 0; k < CP_BG_NPARAMS; ++k) {
+        A.p[k].ptr = params[k].ptr;
+        A.p[k].value = params[k].value;
+    }
+    A.second_is_omega_m = second_is_omega_m;
+    A.z = d_z;
+    A.z_shared = z_shared;
+    A.out = d_out;
+    A.kind = kind;
+    A.tab = tab;
+    const long long nsamp = ncosmo * nz;
+    const int block = 256;
+    const long long grid = (nsamp + block - 1) / block;
+    hipLaunchKernelGGL(bg_kernel, dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

@@ -70,6 +70,34 @@ int cp_fftlog_plan_destroy(cp_fftlog_plan* plan);
 /* introspection for the bench / tests: workgroups launched per execute for `nbatch`, threads per workgroup, LDS bytes */
 int cp_fftlog_plan_info(const cp_fftlog_plan* plan, long long nbatch, int* grid, int* block, int* lds_bytes);
 
+/* ---- background E(z) and distances for batches of cosmologies (replaces DefaultBackground.comoving_radial_distance,
+ *      cosmology.py:2027-2042 -- jax.odeint rk4 on the 119-knot grid + natural cubic spline, jax.py:672-716, 169-175 -- the
+ *      derived distances cosmology.py:1855-1912, efunc :1751-1754 and the derived density parameters :355-397).
+ *      Massless neutrinos only (the reference default, m_ncdm empty). ---- */
+enum cp_bg_param {   /* index into the cp_param array */
+    CP_BG_H = 0, CP_BG_OMEGA_CDM = 1 /* or Omega_m, see second_is_omega_m */, CP_BG_OMEGA_B = 2, CP_BG_OMEGA_K = 3, CP_BG_T_CMB = 4,
+    CP_BG_N_UR = 5, CP_BG_W0_FLD = 6, CP_BG_WA_FLD = 7, CP_BG_NPARAMS = 8
+};
+enum cp_bg_kind {
+    CP_BG_COMOVING_RADIAL = 0,     /* comoving_radial_distance      cosmology.py:2027 */
+    CP_BG_COMOVING_TRANSVERSE = 1, /* comoving_transverse_distance  cosmology.py:1893 */
+    CP_BG_ANGULAR_DIAMETER = 2,    /* angular_diameter_distance     cosmology.py:1855 */
+    CP_BG_LUMINOSITY = 3,          /* luminosity_distance           cosmology.py:1904 */
+    CP_BG_EFUNC = 4,               /* efunc                         cosmology.py:1751 */
+    CP_BG_HUBBLE = 5               /* hubble_function               cosmology.py:1756 */
+};
+/* a per-cosmology parameter: device array of ncosmo doubles, or (ptr == NULL) one value for all cosmologies */
+typedef struct cp_param {
+    const double* ptr;
+    double value;
+} cp_param;
+/* Sample (ic, iz) = cosmology ic evaluated at z[ic * nz + iz] (or z[iz] when z_shared); d_out has ncosmo * nz doubles
+ * (Mpc/h for distances).  z outside [0, 9999] gives NaN as in the reference.  Asynchronous on `stream` of `device`. */
+int cp_background_distance(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const double* d_z, int z_shared,
+                           double* d_out, int kind, int device, void* stream);
+/* the 119 interpolation knots (host), get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949 */
+int cp_background_knots(double* zc_out, int n);
+
 #ifdef __cplusplus
 }
 #endif

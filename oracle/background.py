@@ -1,0 +1,112 @@
+"""Oracle: numpy restatement of cosmoprimo's background densities / E(z) / distance path (TEST INFRASTRUCTURE ONLY).
+
+Follows /root/reference/cosmoprimo/cosmology.py (BaseBackground :1627-1759, distances :1855-1912,
+DefaultBackground.comoving_radial_distance :2027-2042, get_default_z_interp :1940-1951, derived parameters
+:355-397), cosmoprimo/jax.py (odeint rk4 :672-716, Interpolator1D natural cubic :135-196) and
+cosmoprimo/constants.py.  Massless neutrinos only (m_ncdm empty, the reference default).
+Vectorised over a leading batch of cosmologies.
+
+Parity status: PINNED by tests/golden/background.npz (G8: 119-knot table, E(z), D_C/D_M/D_A/D_L from the reference).
+"""
+import numpy as np
+from scipy import constants as sc
+from scipy.interpolate import CubicSpline
+
+# cosmoprimo/constants.py:9-21
+megaparsec_over_m = 1e6 * sc.parsec
+msun_over_kg = 1.98847 * 1e30
+rho_crit_over_kgph_per_mph3 = 3.0 * (100. * 1e3 / megaparsec_over_m)**2 / (8 * sc.pi * sc.gravitational_constant)
+rho_crit_over_Msunph_per_Mpcph3 = rho_crit_over_kgph_per_mph3 / (1e10 * msun_over_kg) * megaparsec_over_m**3
+TCMB, NEFF = 2.7255, 3.044
+C_KMS = sc.c / 1e3
+
+
+def derived(h=0.7, Omega_cdm=0.25, Omega_b=0.05, Omega_k=0., T_cmb=TCMB, N_ur=NEFF, w0_fld=-1., wa_fld=0., Omega_m=None):
+    """Density parameters the background needs (cosmology.py:355-397, 1163-1165); arrays broadcast."""
+    h, Omega_b, Omega_k, T_cmb, N_ur, w0_fld, wa_fld = (np.asarray(v, dtype='f8') for v in (h, Omega_b, Omega_k, T_cmb, N_ur, w0_fld, wa_fld))
+    if Omega_m is not None:   # Omega_cdm = Omega_m - Omega_b (no massive neutrinos)  cosmology.py:1163-1165
+        Omega_cdm = np.asarray(Omega_m, dtype='f8') - Omega_b
+    Omega_cdm = np.asarray(Omega_cdm, dtype='f8')
+    rho_g = T_cmb**4 * 4. / sc.c**3 * sc.Stefan_Boltzmann                         # :356
+    Omega_g = rho_g / (h**2 * rho_crit_over_kgph_per_mph3)                        # :357
+    T_ur = T_cmb * (4. / 11.)**(1. / 3.)                                           # :359
+    rho_ur = N_ur * 7. / 8. * T_ur**4 * 4. / sc.c**3 * sc.Stefan_Boltzmann        # :363
+    Omega_ur = rho_ur / (h**2 * rho_crit_over_kgph_per_mph3)                      # :364
+    Omega_de = 1. - (Omega_cdm + Omega_b + Omega_g + Omega_ur + 0. + Omega_k)     # :383 (sum in that order)
+    K = -100.**2 / C_KMS**2 * Omega_k                                             # :397
+    names = ['h', 'Omega_cdm', 'Omega_b', 'Omega_k', 'Omega_g', 'Omega_ur', 'Omega_de', 'w0_fld', 'wa_fld', 'K']
+    vals = np.broadcast_arrays(h, Omega_cdm, Omega_b, Omega_k, Omega_g, Omega_ur, Omega_de, w0_fld, wa_fld, K)
+    return dict(zip(names, vals))
+
+
+def efunc(z, p):
+    """E(z) = H(z)/H0 (cosmology.py:1680-1754); z broadcast against the parameter arrays."""
+    rc = rho_crit_over_Msunph_per_Mpcph3
+    z = np.asarray(z, dtype='f8')
+    m = p['Omega_cdm'] * np.ones_like(z) * rc + p['Omega_b'] * np.ones_like(z) * rc + 0.          # :1733
+    r = p['Omega_g'] * (1 + z) * rc + p['Omega_ur'] * (1 + z) * rc                                 # :1734
+    de = p['Omega_de'] * (1 + z) ** (3. * (p['w0_fld'] + p['wa_fld'])) * np.exp(3. * p['wa_fld'] * (1. / (1 + z) - 1)) * rc   # :1728
+    rho_crit = (m + r + de) + p['Omega_k'] / (1 + z) * rc                                          # :1736, 1705, 1749
+    return np.sqrt(rho_crit * (1 + z)**3 / rc)                                                     # :1754
+
+
+def z_knots():
+    """119 interpolation knots of comoving_radial_distance (cosmology.py:1947-1949)."""
+    zm = 0.3
+    return np.concatenate([np.linspace(0., zm, 20)[:-1], 1. / np.geomspace(1e-4, 1. / (1 + zm), 100)[::-1] - 1.])
+
+
+def distance_table(p):
+    """T_i = D_C(zc_i): the reference's RK4 with a y-independent integrand (jax.py:700-710, cosmology.py:2036-2040)."""
+    zc = z_knots()
+    pb = {k: np.asarray(v)[..., None] for k, v in p.items()}
+
+    def f(z):
+        return C_KMS / (100. * efunc(z, pb))
+
+    t_last, t = zc[:-1], zc[1:]
+    h = t - t_last
+    k1, k2, k4 = f(t_last), f(t_last + h / 2), f(t)
+    inc = h / 6. * (k1 + 2 * k2 + 2 * k2 + k4)
+    # sequential accumulation y = y + inc (same rounding as the scan); first knot: h = 0 -> 0
+    tab = np.concatenate([np.zeros(inc.shape[:-1] + (1,)), np.cumsum(inc, axis=-1)], axis=-1)
+    return zc, tab
+
+
+def comoving_radial_distance(z, p):
+    """Natural cubic spline through (zc, T) (jax.py:172), NaN outside [0, zc[-1]]; z has the batch shape + trailing axes."""
+    zc, tab = distance_table(p)
+    z = np.asarray(z, dtype='f8')
+    tab2 = tab.reshape(-1, zc.size)
+    zz = np.broadcast_to(z, np.broadcast_shapes(z.shape, tab.shape[:-1] + (1,) * (z.ndim - (tab.ndim - 1)))) if tab.ndim > 1 else z
+    if tab.ndim == 1:
+        out = CubicSpline(zc, tab, bc_type='natural', extrapolate=False)(z)
+        return np.where((z >= zc[0]) & (z <= zc[-1]), out, np.nan)
+    zf = zz.reshape(tab2.shape[0], -1)
+    out = np.empty_like(zf)
+    for i in range(tab2.shape[0]):
+        o = CubicSpline(zc, tab2[i], bc_type='natural', extrapolate=False)(zf[i])
+        out[i] = np.where((zf[i] >= zc[0]) & (zf[i] <= zc[-1]), o, np.nan)
+    return out.reshape(zz.shape)
+
+
+def _sk(chi, K):
+    """S_K(chi) (cosmology.py:1862-1868)."""
+    K = np.broadcast_to(K, chi.shape) if np.ndim(K) else np.full(chi.shape, K)
+    out = chi.copy()
+    pos, neg = K > 0, K < 0
+    with np.errstate(invalid='ignore'):
+        out[pos] = np.sin(np.sqrt(K[pos]) * chi[pos]) / np.sqrt(K[pos])
+        out[neg] = np.sinh(np.sqrt(-K[neg]) * chi[neg]) / np.sqrt(-K[neg])
+    return out
+
+
+def distances(z, p):
+    """dict of D_C, D_M, D_A, D_L in Mpc/h (cosmology.py:1855-1912); z shape = batch shape + trailing axes."""
+    dc = comoving_radial_distance(z, p)
+    K = np.asarray(p['K'])
+    Kb = K.reshape(K.shape + (1,) * (dc.ndim - K.ndim)) if K.ndim else K
+    z = np.asarray(z, dtype='f8')
+    da = _sk(dc, np.broadcast_to(Kb, dc.shape)) / (1 + z)      # :1868
+    return {'comoving_radial_distance': dc, 'angular_diameter_distance': da, 'comoving_transverse_distance': da * (1. + z),
+            'luminosity_distance': da * (1. + z)**2}

@@ -141,6 +141,38 @@ def gen_fftlog_transforms(cp, pks):
     save('fftlog_transforms', **out)
 
 
+def gen_background(cp):
+    """G8: 32 cosmologies (Omega_m, w0, wa, Omega_k, h): the 119-knot D_C table, E(z) and D_C/D_M/D_A/D_L at 64 z."""
+    import warnings
+    rng = np.random.default_rng(8)
+    n = 32
+    par = dict(Omega_m=rng.uniform(0.1, 0.5, n), w0_fld=rng.uniform(-1.5, -0.5, n), wa_fld=rng.uniform(-1., 0.5, n),
+               Omega_k=np.where(np.arange(n) % 3 == 0, 0., rng.uniform(-0.1, 0.1, n)), h=rng.uniform(0.6, 0.8, n), Omega_b=np.full(n, 0.05))
+    par['w0_fld'][0], par['wa_fld'][0] = -1., 0.    # one plain LCDM
+    z = np.concatenate([[0., 1e-4, 5e-3], np.linspace(0.01, 3., 56), [10., 100., 1100., 5000., 9999.]])
+    out = {k: v for k, v in par.items()}
+    out['z'] = z
+    tabs, es, ds = [], [], {name: [] for name in ['comoving_radial_distance', 'comoving_transverse_distance', 'angular_diameter_distance', 'luminosity_distance']}
+    for i in range(n):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            cosmo = cp.Cosmology(engine='bbks', **{k: float(v[i]) for k, v in par.items()})
+            ba = cosmo.get_background()
+            for name in ds:
+                ds[name].append(getattr(ba, name)(z))
+            es.append(ba.efunc(z))
+            tabs.append(np.asarray(ba._cache['comoving_radial_distance']._fun))
+            if i == 0:
+                out['zc'] = np.asarray(ba._cache['comoving_radial_distance']._x)
+                out['nan_outside'] = ba.comoving_radial_distance(np.array([-0.1, 1e4]))
+                out['f4'] = ba.comoving_radial_distance(np.linspace(0., 2., 5).astype('f4'))
+    out['table'] = np.array(tabs)
+    out['efunc'] = np.array(es)
+    for name, v in ds.items():
+        out[name] = np.array(v)
+    save('background', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -150,6 +182,8 @@ def main():
         gen_fftlog_tables(cp)
         gen_loggamma()
         gen_fftlog_transforms(cp, pks)
+    if 'background' in which:
+        gen_background(cp)
 
 
 if __name__ == '__main__':

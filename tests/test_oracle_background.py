@@ -1,0 +1,36 @@
+"""Pin the numpy background oracle against golden vectors from the reference (G8)."""
+import numpy as np
+
+from oracle import background as ob
+
+
+def params_of(g):
+    return ob.derived(h=g['h'], Omega_m=g['Omega_m'], Omega_b=g['Omega_b'], Omega_k=g['Omega_k'], w0_fld=g['w0_fld'], wa_fld=g['wa_fld'])
+
+
+def test_knots_and_table(golden):
+    g = golden('background')
+    p = params_of(g)
+    zc, tab = ob.distance_table(p)
+    assert zc.size == 119 and np.array_equal(zc, g['zc'])
+    np.testing.assert_allclose(tab, g['table'], rtol=1e-15, atol=0)
+
+
+def test_efunc_and_distances(golden):
+    g = golden('background')
+    p = params_of(g)
+    z = g['z']
+    np.testing.assert_allclose(ob.efunc(z[None, :], {k: v[:, None] for k, v in p.items()}), g['efunc'], rtol=1e-15)
+    d = ob.distances(np.broadcast_to(z, (32, z.size)), p)
+    for name in ['comoving_radial_distance', 'comoving_transverse_distance', 'angular_diameter_distance', 'luminosity_distance']:
+        np.testing.assert_allclose(d[name], g[name], rtol=1e-14, atol=1e-12)
+    out = ob.comoving_radial_distance(np.array([-0.1, 1e4]), {k: v[0] for k, v in p.items()})
+    assert np.isnan(out).all() and np.isnan(g['nan_outside']).all()
+
+
+def test_closed_form_lcdm_flat_matter_only():
+    # Einstein-de Sitter-like check of the quadrature + spline: E = (1+z)^1.5 when Omega_m = 1 -> D_C = 2 c/H0 (1 - 1/sqrt(1+z))
+    p = ob.derived(h=0.7, Omega_cdm=0.95, Omega_b=0.05, T_cmb=1e-8, N_ur=0.)
+    z = np.linspace(0.2, 5., 20)
+    dc = ob.comoving_radial_distance(z, p)
+    np.testing.assert_allclose(dc, 2 * ob.C_KMS / 100. * (1 - 1 / np.sqrt(1 + z)), rtol=1e-5)
