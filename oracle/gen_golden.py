@@ -173,6 +173,90 @@ def gen_background(cp):
     save('background', **out)
 
 
+POWER_PARAMS = dict(Omega_m=[0.31, 0.25, 0.40, 0.28, 0.35, 0.30, 0.27, 0.33], Omega_b=[0.045, 0.04, 0.06, 0.05, 0.055, 0.048, 0.042, 0.05],
+                    h=[0.68, 0.6, 0.8, 0.7, 0.72, 0.65, 0.75, 0.67], n_s=[0.97, 0.92, 1.0, 0.96, 0.95, 0.98, 0.93, 0.965],
+                    sigma8=[0.81, 0.8, 0.8, 0.75, 0.9, 0.8, 0.85, 0.8], alpha_s=[0.01, 0., 0., -0.02, 0., 0., 0., 0.],
+                    w0_fld=[-1., -1., -0.9, -1., -1.1, -1., -1., -0.8], wa_fld=[0., 0., 0.2, 0., -0.3, 0., 0., 0.1])
+
+
+def gen_power(cp):
+    """G7: 8 cosmologies x 3 analytic engines: scalars, transfer_k, pk_k, P(k, z), growth factor / rate, sigma8 rescale factor."""
+    import warnings
+    k = np.concatenate([np.logspace(-7, 2, 46), [1e-5, 0.05, 0.1, 1.]])
+    z = np.array([0., 0.5, 1., 2., 3.])
+    out = {name: np.array(v, dtype='f8') for name, v in POWER_PARAMS.items()}
+    out['k'], out['z'] = k, z
+    n = len(POWER_PARAMS['h'])
+    names_sc = ['z_eq', 'k_eq', 'z_drag', 'r_drag', 'r_eq', 'rs_drag', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b']
+    for eng in ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks']:
+        acc = {key: [] for key in ['transfer', 'pk_prim', 'pkz', 'growth_factor', 'growth_factor_znorm0', 'growth_rate', 'rsigma8', 'A_s', 'sigma8_m']}
+        sc = {key: [] for key in names_sc + ['alpha_gamma', 'gamma', 'rs_drag_h', 'z_drag_th']}
+        for i in range(n):
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                cosmo = cp.Cosmology(engine=eng, **{name: float(v[i]) for name, v in POWER_PARAMS.items()})
+                fo, tr, pm, ba = cosmo.get_fourier(), cosmo.get_transfer(), cosmo.get_primordial(), cosmo.get_background()
+                acc['transfer'].append(tr.transfer_k(k))
+                acc['pk_prim'].append(pm.pk_k(k))
+                acc['pkz'].append(fo.pk_interpolator()(k, z))
+                acc['growth_factor'].append(ba.growth_factor(z))
+                acc['growth_factor_znorm0'].append(ba.growth_factor(z, znorm=0.))
+                acc['growth_rate'].append(ba.growth_rate(z))
+                acc['rsigma8'].append(cosmo._engine._rsigma8)
+                acc['A_s'].append(pm.A_s)
+                acc['sigma8_m'].append(fo.sigma8_m)
+                eng_obj = cosmo._engine
+                for key in sc:
+                    if key == 'rs_drag_h':
+                        sc[key].append(cosmo.get_thermodynamics().rs_drag if eng != 'bbks' else np.nan)
+                    elif key == 'z_drag_th':
+                        sc[key].append(cosmo.get_thermodynamics().z_drag if eng != 'bbks' else np.nan)
+                    else:
+                        sc[key].append(getattr(eng_obj, key, np.nan))
+        for key, v in {**acc, **sc}.items():
+            out['%s_%s' % (eng, key)] = np.array(v, dtype='f8')
+    save('power', **out)
+
+
+def gen_sigma(cp):
+    """G4: sigma_rz / sigma_dz / sigma8 of the EH callable interpolator and of a 500 x 30 table; fftlog and simpson methods; to_xi."""
+    import warnings
+    out = {}
+    r = np.geomspace(1., 100., 256)
+    z = np.linspace(0., 3., 64)
+    out['r'], out['z'] = r, z
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu')
+        fo = cosmo.get_fourier()
+        interp = fo.pk_interpolator()
+        out['eh_sigma_rz'] = interp.sigma_rz(r, z)
+        out['eh_sigma_rz_simpson'] = interp.sigma_rz(r[::16], z[::8], method='simpson')
+        out['eh_sigma_dz'] = interp.sigma_dz(z)
+        out['eh_sigma8_z'] = interp.sigma8_z(z)
+        i1 = interp.to_1d(z=0.)
+        out['eh_sigma_r_1d'] = i1.sigma_r(r)
+        out['eh_sigma_d_1d'] = i1.sigma_d()
+        xi = interp.to_xi()
+        out['eh_xi_s'], out['eh_xi'] = np.asarray(xi.s), np.asarray(xi.xi)[..., ::8]
+        xi1 = i1.to_xi()
+        out['eh_xi1_s'], out['eh_xi1'] = np.asarray(xi1.s), np.asarray(xi1.xi)
+        # table input (config 3 B): k = logspace(-4, 2, 500), z = linspace(0, 3, 30)
+        kt, zt = np.logspace(-4, 2, 500), np.linspace(0., 3., 30)
+        pkt = interp(kt, zt)
+        out['table_k'], out['table_z'], out['table_pk'] = kt, zt, pkt
+        tab = cp.PowerSpectrumInterpolator2D(kt, zt, pkt)
+        out['table_sigma_rz'] = tab.sigma_rz(r, z)
+        ke = np.geomspace(1e-7, 1e2, 64)
+        out['table_eval_k'] = ke
+        out['table_eval'] = tab(ke, z[::4])
+        tab1 = cp.PowerSpectrumInterpolator1D(kt, pkt[:, 0])
+        out['table1d_eval'] = tab1(ke)
+        out['table1d_sigma_r'] = tab1.sigma_r(r[::8])
+        out['table1d_sigma8'] = tab1.sigma8()
+    save('sigma', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -184,6 +268,10 @@ def main():
         gen_fftlog_transforms(cp, pks)
     if 'background' in which:
         gen_background(cp)
+    if 'power' in which:
+        gen_power(cp)
+    if 'sigma' in which:
+        gen_sigma(cp)
 
 
 if __name__ == '__main__':
