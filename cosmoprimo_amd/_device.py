@@ -1,0 +1,85 @@
+"""Small helpers shared by the host-side modules: device resolution, numpy <-> torch plumbing, cp_param packing."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def torch():
+    import torch as _torch
+    return _torch
+
+
+def is_torch(x):
+    return type(x).__module__.startswith('torch')
+
+
+def resolve_device(device=None, *tensors):
+    """torch.device to run on: explicit ``device``, else the device of the first CUDA tensor, else the current CUDA device."""
+    t = torch()
+    if device is None:
+        for x in tensors:
+            if is_torch(x) and x.is_cuda:
+                device = x.device
+                break
+    if device is None:
+        if not t.cuda.is_available():
+            raise RuntimeError('cosmoprimo_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path')
+        device = t.device('cuda', t.cuda.current_device())
+    device = t.device(device if not isinstance(device, int) else 'cuda:{:d}'.format(device))
+    if device.type != 'cuda':
+        raise ValueError('cosmoprimo_amd runs on a GPU; got device {}'.format(device))
+    if device.index is None:
+        device = t.device('cuda', t.cuda.current_device())
+    return device
+
+
+def to_device(x, device):
+    """float64 contiguous tensor on ``device`` from a number / numpy array / tensor (shape preserved)."""
+    t = torch()
+    if is_torch(x):
+        return x.to(device=device, dtype=t.float64).contiguous()
+    a = np.asarray(x, dtype='f8')
+    return t.from_numpy(np.ascontiguousarray(a)).to(device).reshape(a.shape)
+
+
+def stream_of(device):
+    return torch().cuda.current_stream(device).cuda_stream
+
+
+def float_dtype(*args):
+    """Reference utils._bcast_dtype (utils.py:88-95): float32 only if every array input is float32, else float64."""
+    t = torch()
+    dts = []
+    for a in args:
+        if is_torch(a):
+            dts.append({t.float32: np.float32, t.float64: np.float64}.get(a.dtype, np.float64))
+        elif hasattr(a, 'dtype'):
+            dts.append(a.dtype)
+    if not dts:
+        return np.dtype('f8')
+    out = np.result_type(*dts)
+    return out if np.issubdtype(out, np.floating) else np.dtype('f8')
+
+
+def pack_params(names, params, defaults, device):
+    """(ctypes cp_param array, ncosmo or None, keepalive list) for per-cosmology parameters given as floats or (ncosmo,) arrays."""
+    carr = (_lib.cp_param * len(names))()
+    keep, ncosmo = [], None
+    for i, name in enumerate(names):
+        v = params.get(name, defaults[name])
+        if not is_torch(v) and np.ndim(v) == 0:
+            carr[i].ptr, carr[i].value = None, float(v)
+            continue
+        tv = to_device(v, device).reshape(-1)
+        if ncosmo is not None and tv.numel() != ncosmo:
+            raise ValueError('parameter arrays must share one length, got {} and {}'.format(ncosmo, tv.numel()))
+        ncosmo = tv.numel()
+        keep.append(tv)
+        carr[i].ptr, carr[i].value = tv.data_ptr(), 0.
+    return carr, ncosmo, keep
+
+
+def as_void_p(carr):
+    return ctypes.cast(carr, ctypes.c_void_p)

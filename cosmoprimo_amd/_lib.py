@@ -36,6 +36,17 @@ SIGNATURES = {
     'cp_background_distance': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_background_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
+    'cp_power_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong,
+                                    ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'cp_eh_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'cp_spline_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    'cp_linop_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int]),
+    'cp_spline_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+    'cp_spline_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_spline_plan_info': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, _c_int_p]),
+    'cp_spline_operator': (ctypes.c_int, [ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                         _c_int_p]),
 }
 
 
@@ -45,8 +56,14 @@ class cp_param(ctypes.Structure):
 
 
 BG_PARAMS = ('h', 'Omega_cdm', 'Omega_b', 'Omega_k', 'T_cmb', 'N_ur', 'w0_fld', 'wa_fld')
+SPLINE_BC = {'natural': 0, 'clamped': 1, 'not-a-knot': 2}
+PK_PARAMS = ('A_s', 'n_s', 'alpha_s', 'beta_s', 'k_pivot')
+ENGINES = {'eisenstein_hu': 0, 'eisenstein_hu_nowiggle': 1, 'bbks': 2}
+PK_WHAT = {'matter': 0, 'transfer': 1, 'primordial': 2}
+EH_SCALARS = ('rs_drag', 'z_drag', 'z_eq', 'k_eq', 'r_drag', 'r_eq', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b', 'alpha_gamma',
+              'gamma')
 BG_KINDS = {'comoving_radial_distance': 0, 'comoving_transverse_distance': 1, 'angular_diameter_distance': 2, 'luminosity_distance': 3,
-            'efunc': 4, 'hubble_function': 5}
+            'efunc': 4, 'hubble_function': 5, 'growth_cpt': 6, 'growth_rate': 7, 'rho_crit': 8, 'Omega_m': 9, 'Omega_de': 10}
 
 _lib = None
 

@@ -1,0 +1,18 @@
+"""BBKS engine on MI355X (reference cosmoprimo/bbks.py; the polynomial is reproduced as coded there)."""
+import warnings
+
+from .eisenstein_hu import EisensteinHuEngine, Background, Primordial, Transfer, Fourier  # noqa: F401
+
+
+class BBKSEngine(EisensteinHuEngine):
+    """BBKS no-wiggle analytic formulae (reference bbks.py:10-38)."""
+    name = 'bbks'
+    _transfer = 'bbks'
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self.batch_size is None:
+            if self['Omega_k'] != 0.:
+                warnings.warn('{} cannot cope with non-zero curvature'.format(self.__class__.__name__))
+            if self._has_fld:
+                warnings.warn('{} cannot cope with non-constant dark energy'.format(self.__class__.__name__))

@@ -1,0 +1,439 @@
+"""
+Cosmology container, engine registry and the analytic engines on MI355X, behind the reference's API
+(cosmoprimo/cosmology.py: ``Cosmology``, ``BaseEngine`` + metaclass registry :459-503, ``get_engine`` :574-633, section
+getters :636-705, ``BaseBackground`` :1627-1933, ``DefaultBackground`` :1954-2093; engines eisenstein_hu.py,
+eisenstein_hu_nowiggle.py, bbks.py).
+
+Scope: the parameters the analytic engines and the background use (h / H0, Omega_cdm / omega_cdm /
+Omega_m / omega_m, Omega_b / omega_b, Omega_k, sigma8 / A_s / logA, n_s, alpha_s, beta_s, k_pivot, T_cmb, N_eff / N_ur,
+w0_fld, wa_fld, tau_reio ...).  Massive neutrinos, ``solve`` and persistence are outside this path and raise / are absent.
+
+Extension for the GPU: every numerical parameter may be an array (or torch tensor) of shape (B,): a *batch* of cosmologies.
+All section methods then return results with a leading (B,) axis.
+"""
+import sys
+
+import numpy as np
+
+from . import _lib, background as bgmod, power as pwmod
+from . import _device as dv
+from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, _host, _finish
+
+TCMB, NEFF, TNCDM_OVER_CMB = 2.7255, 3.044, 0.71611   # cosmoprimo/constants.py
+
+
+class CosmologyError(Exception):
+    """Generic exception raised when an error related to cosmology arises (reference cosmology.py:38)."""
+
+
+class CosmologyInputError(CosmologyError):
+    """Exception raised when error in input parameters."""
+
+
+class CosmologyComputationError(CosmologyError):
+    """Exception raised when error in cosmology computation."""
+
+
+_default_cosmological_parameters = dict(h=0.7, Omega_cdm=0.25, Omega_b=0.05, Omega_k=0., sigma8=0.8, k_pivot=0.05, n_s=0.96, alpha_s=0., beta_s=0.,
+                                        T_cmb=TCMB, m_ncdm=None, T_ncdm_over_cmb=TNCDM_OVER_CMB, N_eff=NEFF, tau_reio=0.06, w0_fld=-1., wa_fld=0.,
+                                        cs2_fld=1.)
+_conflict_parameters = [('h', 'H0'), ('Omega_b', 'omega_b'), ('Omega_cdm', 'omega_cdm', 'Omega_c', 'omega_c', 'Omega_m', 'omega_m'),
+                        ('Omega_k', 'omega_k'), ('N_ur', 'N_eff'), ('A_s', 'logA', 'sigma8')]
+_alias_parameters = {'omega_b': ('ombh2',), 'omega_cdm': ('omch2',), 'Omega_k': ('omk', 'Omega0_k'), 'N_eff': ('nnu',), 'n_s': ('ns',), 'alpha_s': ('nrun',),
+                     'beta_s': ('nrunrun',), 'tau_reio': ('tau',), 'Omega_m': ('Omega0_m',), 'Omega_cdm': ('Omega0_cdm', 'Omega_c'), 'omega_c': (),
+                     'Omega_b': ('Omega0_b',), 'T_cmb': ('T0_cmb',), 'logA': ('ln10^10A_s', 'ln10^{10}A_s', 'ln_A_s_1e10'), 'w0_fld': ('w',),
+                     'wa_fld': ('wa',), 'm_ncdm': ('mnu',)}
+
+
+def _is_array(v):
+    return dv.is_torch(v) or np.ndim(v) > 0
+
+
+def _compile_params(args):
+    """Input parameters -> the canonical set (a reduced restatement of reference Cosmology._compile_params, cosmology.py:874-1217)."""
+    params = {}
+    for name, value in args.items():   # aliases
+        for canon, aliases in _alias_parameters.items():
+            if name in aliases:
+                name = canon
+        params[name] = value
+    for group in _conflict_parameters:
+        found = [name for name in group if name in params]
+        if len(found) > 1:
+            raise CosmologyInputError('Conflicting parameters: {}'.format(found))
+    out = {k: v for k, v in _default_cosmological_parameters.items()}
+    for group in _conflict_parameters:   # a provided member removes the defaults of its group
+        if any(name in params for name in group):
+            for name in group:
+                out.pop(name, None)
+    out.update(params)
+    m_ncdm = out.pop('m_ncdm', None)
+    if m_ncdm is not None and np.size(m_ncdm) and np.any(np.asarray(m_ncdm) > 0.):
+        raise NotImplementedError('massive neutrinos are outside the MI355X hot path (SURVEY.md 8(f) f3)')
+    if 'H0' in out:
+        out['h'] = out.pop('H0') / 100.
+    h = out['h']
+    for name in ['b', 'cdm', 'c', 'm', 'k']:
+        if 'omega_' + name in out:
+            out['Omega_' + name] = out.pop('omega_' + name) / h**2
+    if 'Omega_c' in out:
+        out['Omega_cdm'] = out.pop('Omega_c')
+    if 'Omega_m' in out:   # Omega_cdm = Omega_m - Omega_b (no massive neutrinos), cosmology.py:1163-1165
+        out['Omega_cdm'] = out.pop('Omega_m') - out['Omega_b']
+    if 'N_ur' not in out:  # no massive species: N_ur = N_eff, cosmology.py:1108-1140
+        out['N_ur'] = out.pop('N_eff')
+    if 'logA' in out:
+        out['A_s'] = np.exp(out.pop('logA')) * 1e-10 if not dv.is_torch(out['logA']) else dv.torch().exp(out.pop('logA')) * 1e-10
+    w0, wa = out['w0_fld'], out['wa_fld']
+    if not _is_array(w0) and not _is_array(wa) and w0 + wa >= 1. / 3.:   # cosmology.py:1171-1177
+        raise CosmologyInputError('w0_fld + wa_fld must be < 1/3')
+    return out
+
+
+class BaseCosmoParams(object):
+
+    """Parameter access shared by :class:`Cosmology` and engines (reference BaseCosmoParams, cosmology.py:231-457)."""
+
+    def __getitem__(self, name):
+        return self.get(name)
+
+    def __contains__(self, name):
+        try:
+            self.get(name)
+            return True
+        except CosmologyError:
+            return False
+
+    def get(self, *args, **kwargs):
+        """Return an input (or easily derived) parameter (reference cosmology.py:331-415)."""
+        if len(args) == 1:
+            name, has_default, default = args[0], 'default' in kwargs, kwargs.get('default', None)
+        else:
+            (name, default), has_default = args, True
+        params = self._params
+        c, sb, rck = bgmod_constants()
+        if name in params:
+            return params[name]
+        if name.startswith('omega'):
+            return self.get('O' + name[1:]) * params['h']**2
+        if name == 'H0':
+            return params['h'] * 100
+        if name in ['logA', 'ln10^{10}A_s', 'ln10^10A_s', 'ln_A_s_1e10'] and 'A_s' in params:
+            return np.log(1e10 * params['A_s'])
+        if name == 'Omega_g':
+            return params['T_cmb']**4 * 4. / c**3 * sb / (params['h']**2 * rck)
+        if name == 'T_ur':
+            return params['T_cmb'] * (4. / 11.)**(1. / 3.)
+        if name == 'Omega_ur':
+            return params['N_ur'] * 7. / 8. * self.get('T_ur')**4 * 4. / c**3 * sb / (params['h']**2 * rck)
+        if name == 'Omega_r':
+            return self.get('Omega_g') + self.get('Omega_ur')
+        if name in ('m_ncdm_tot', 'Omega_ncdm_tot', 'Omega_pncdm_tot', 'N_ncdm'):
+            return 0 if name == 'N_ncdm' else 0.
+        if name in ('m_ncdm', 'Omega_ncdm', 'Omega_pncdm'):
+            return []
+        if name == 'Omega_m':
+            return params['Omega_b'] + params['Omega_cdm'] + 0. - 0.
+        if name == 'Omega_de':
+            return 1. - (params['Omega_cdm'] + params['Omega_b'] + self.get('Omega_g') + self.get('Omega_ur') + 0. + params['Omega_k'])
+        if name == 'Omega_Lambda':
+            return 0. if self._has_fld else self.get('Omega_de')
+        if name == 'Omega_fld':
+            return self.get('Omega_de') if self._has_fld else 0.
+        if name == 'K':
+            return - 100.**2 / (c / 1e3)**2 * params['Omega_k']
+        if name == 'N_eff':
+            return params['N_ur']
+        if has_default:
+            return default
+        raise CosmologyError('Parameter {} not found.'.format(name))
+
+    @property
+    def _has_fld(self):
+        p = self._params
+        if any(_is_array(p[n]) for n in ('w0_fld', 'wa_fld', 'cs2_fld')):
+            return True
+        return (p['w0_fld'] != -1) or (p['wa_fld'] != 0) or (p['cs2_fld'] != 1.)
+
+    @property
+    def batch_size(self):
+        """Number of cosmologies when parameters are arrays, else None."""
+        for v in self._params.values():
+            if _is_array(v):
+                return int(np.size(v)) if not dv.is_torch(v) else int(v.numel())
+        return None
+
+    def bg_params(self):
+        """The background parameter block of the kernels."""
+        return {name: self._params[name] for name in _lib.BG_PARAMS}
+
+
+def bgmod_constants():
+    c, sb = 299792458.0, 5.6703744191844314e-08   # scipy.constants.c, Stefan_Boltzmann
+    mpc = 1e6 * 3.085677581491367e16
+    rck = 3.0 * (100. * 1e3 / mpc)**2 / (8 * np.pi * 6.6743e-11)   # constants.rho_crit_over_kgph_per_mph3
+    return c, sb, rck
+
+
+_Sections = ['Background', 'Thermodynamics', 'Primordial', 'Transfer', 'Fourier']
+
+
+class RegisteredEngine(type):
+
+    """Metaclass registering :class:`BaseEngine`-derived classes by their ``name`` (reference cosmology.py:459-468)."""
+    _registry = {}
+
+    def __new__(meta, name, bases, class_dict):
+        cls = super().__new__(meta, name, bases, class_dict)
+        meta._registry[cls.name] = cls
+        return cls
+
+
+class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
+
+    """Base engine for cosmological calculation (reference cosmology.py:471-571)."""
+    name = 'base'
+
+    def __init__(self, cosmo, device=None, **extra_params):
+        self._params = dict(cosmo._params)
+        self._extra_params = extra_params
+        self._rsigma8 = None
+        self.device = dv.resolve_device(device if device is not None else getattr(cosmo, '_device', None), *self._params.values())
+        self._Sections = {}
+        module = sys.modules[self.__class__.__module__]
+        for name in _Sections:   # sections are module-level classes of the engine's module, discovered by name (reference :497-502)
+            Section = getattr(module, name, None)
+            if Section is not None:
+                self._Sections[name.lower()] = Section
+        self._sections = {}
+
+    def _get_A_s_fid(self):
+        """First guess for A_s given sigma8 (reference cosmology.py:505-510)."""
+        if 'A_s' in self._params:
+            return self._params['A_s']
+        return 2.43e-9 * (self['sigma8'] / 0.87659)**2
+
+    def _rescale_sigma8(self):
+        """Rescale perturbative quantities to match input sigma8 (reference eisenstein_hu.py:94-103)."""
+        if getattr(self, '_rsigma8', None) is not None:
+            return self._rsigma8
+        self._rsigma8 = 1.
+        if 'sigma8' in self._params:
+            fo = self.get_fourier()
+            sigma8 = self['sigma8']
+            s8m = fo._sigma8_m_device()
+            self._rsigma8 = dv.to_device(sigma8, self.device) / s8m
+            if self.batch_size is None:
+                self._rsigma8 = float(self._rsigma8)
+            self._sections.clear()
+        return self._rsigma8
+
+    def __getattr__(self, name):
+        if name.startswith('get_'):
+            section = name[4:]
+            if section in self.__dict__.get('_Sections', {}):
+                def getter():
+                    if section not in self._sections:
+                        self._sections[section] = self._Sections[section](self)
+                    return self._sections[section]
+                return getter
+        raise AttributeError('{} has no attribute {}'.format(self.__class__.__name__, name))
+
+
+def get_engine(engine):
+    """Return the engine class for a name / class (reference cosmology.py:574-633)."""
+    if isinstance(engine, str):
+        engine = engine.lower()
+        if engine not in RegisteredEngine._registry:
+            raise CosmologyError('Unknown engine {}; available on the MI355X path: {}'.format(engine, sorted(n for n in RegisteredEngine._registry if n != 'base')))
+        return RegisteredEngine._registry[engine]
+    return engine
+
+
+class Cosmology(BaseCosmoParams):
+
+    """Cosmology, defined as a set of parameters (and possibly a current engine attached to it) (reference cosmology.py:724-1477)."""
+
+    def __init__(self, engine=None, extra_params=None, device=None, **params):
+        self._input_params = dict(params)
+        self._params = _compile_params(params)
+        self._device = device
+        self._engine = None
+        if engine is not None:
+            self.set_engine(engine, **(extra_params or {}))
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def set_engine(self, engine, set_engine=True, **extra_params):
+        """Set engine for cosmological calculation (reference cosmology.py:636-668)."""
+        if isinstance(engine, BaseEngine):
+            new = engine
+        else:
+            new = get_engine(engine)(self, **extra_params)
+        if set_engine:
+            self._engine = new
+        return new
+
+    def clone(self, base='input', engine=None, extra_params=None, **params):
+        """Clone with updated parameters."""
+        new_params = dict(self._input_params if base == 'input' else {})
+        for group in _conflict_parameters:
+            if any(name in params for name in group):
+                for name in group:
+                    new_params.pop(name, None)
+        new_params.update(params)
+        if engine is None and self._engine is not None:
+            engine = self._engine.name
+        return self.__class__(engine=engine, extra_params=extra_params, device=self._device, **new_params)
+
+    def __getattr__(self, name):
+        if name.startswith('get_') and name[4:] in [s.lower() for s in _Sections]:
+            def getter(engine=None, set_engine=True, **extra_params):
+                return _get_section(self, name[4:], engine=engine, set_engine=set_engine, **extra_params)
+            return getter
+        if name in ('rs_drag', 'z_drag'):
+            return getattr(self.get_thermodynamics(), name)
+        raise AttributeError('{} has no attribute {}'.format(self.__class__.__name__, name))
+
+
+def _get_section(cosmo, section, engine=None, set_engine=True, **extra_params):
+    if engine is None:
+        if cosmo._engine is None:
+            raise CosmologyError('Please provide an engine')
+        eng = cosmo._engine
+    else:
+        eng = cosmo.set_engine(engine, set_engine=set_engine, **extra_params)
+    return getattr(eng, 'get_' + section)()
+
+
+def _make_section_getter(section):
+    def getter(cosmo, engine=None, set_engine=True, **extra_params):
+        return _get_section(cosmo, section, engine=engine, set_engine=set_engine, **extra_params)
+    getter.__name__ = section.capitalize()
+    getter.__doc__ = 'Return the {} section of ``cosmo`` for ``engine`` (reference cosmology.py:671-705).'.format(section)
+    return getter
+
+
+Background = _make_section_getter('background')
+Thermodynamics = _make_section_getter('thermodynamics')
+Primordial = _make_section_getter('primordial')
+Transfer = _make_section_getter('transfer')
+Fourier = _make_section_getter('fourier')
+
+
+class BaseSection(object):
+
+    """Base section (reference cosmology.py:1480-1540)."""
+
+    def __init__(self, engine):
+        self._engine = engine
+        self.device = engine.device
+        self._h = engine['h']
+
+    @property
+    def h(self):
+        return self._h
+
+
+def _out(t, like, dtype=None):
+    """Device tensor -> numpy (default) or torch if ``like`` is a torch tensor."""
+    dtype = dtype if dtype is not None else dv.float_dtype(like)
+    return _finish(t, dtype, dv.is_torch(like))
+
+
+class BaseBackground(BaseSection):
+
+    """Background densities, E(z) and distances (reference BaseBackground, cosmology.py:1627-1933), evaluated by ``cp_background_distance``."""
+
+    def __init__(self, engine):
+        super().__init__(engine)
+        for name in ['H0', 'h', 'N_ur', 'N_ncdm', 'm_ncdm', 'm_ncdm_tot', 'N_eff', 'w0_fld', 'wa_fld', 'cs2_fld', 'K']:
+            setattr(self, '_{}'.format(name), engine[name])
+        self._T0_cmb = engine['T_cmb']
+        for name in ['cdm', 'b', 'k', 'g', 'ur', 'r', 'ncdm_tot', 'pncdm_tot', 'm', 'Lambda', 'fld', 'de']:
+            setattr(self, '_Omega0_{}'.format(name), engine['Omega_{}'.format(name)])
+        self._bg = engine.bg_params()
+
+    def __getattr__(self, name):
+        # properties H0, h, Omega0_x, ... (reference utils.addproperty, cosmology.py:1627-1630)
+        if not name.startswith('_') and '_' + name in self.__dict__:
+            return self.__dict__['_' + name]
+        raise AttributeError(name)
+
+    def _eval(self, kind, z):
+        return bgmod.distance(kind, z, self._bg, device=self.device)
+
+    def efunc(self, z):
+        r"""E(z) = H(z) / H0, unitless (cosmology.py:1751-1754)."""
+        return self._eval('efunc', z)
+
+    def hubble_function(self, z):
+        """Hubble function, in km/s/Mpc (cosmology.py:1756-1759)."""
+        return self._eval('hubble_function', z)
+
+    def rho_crit(self, z):
+        """Comoving critical density excluding curvature, in 1e10 Msun/h / (Mpc/h)^3 (cosmology.py:1738-1749)."""
+        return self._eval('rho_crit', z)
+
+    def Omega_m(self, z):
+        """Density parameter of matter at z (cosmology.py:1796)."""
+        return self._eval('Omega_m', z)
+
+    def Omega_de(self, z):
+        """Density parameter of dark energy at z (cosmology.py:1850)."""
+        return self._eval('Omega_de', z)
+
+    def comoving_radial_distance(self, z):
+        """Comoving radial distance, in Mpc/h (cosmology.py:2027-2042)."""
+        return self._eval('comoving_radial_distance', z)
+
+    def angular_diameter_distance(self, z):
+        """Proper angular diameter distance, in Mpc/h (cosmology.py:1855-1868)."""
+        return self._eval('angular_diameter_distance', z)
+
+    def comoving_transverse_distance(self, z):
+        """Comoving transverse distance, in Mpc/h (cosmology.py:1893-1900)."""
+        return self._eval('comoving_transverse_distance', z)
+
+    comoving_angular_distance = comoving_transverse_distance
+
+    def luminosity_distance(self, z):
+        """Luminosity distance, in Mpc/h (cosmology.py:1904-1912)."""
+        return self._eval('luminosity_distance', z)
+
+    def angular_diameter_distance_2(self, z1, z2):
+        """Angular diameter distance of an object at z2 seen from z1 (cosmology.py:1870-1890); scalar cosmologies."""
+        if np.any(_host(z2) < _host(z1)):
+            import warnings
+            warnings.warn('Second redshift(s) z2 ({}) is less than first redshift(s) z1 ({}).'.format(z2, z1))
+        torch = dv.torch()
+        like, dtype = (z1 if dv.is_torch(z1) else z2), dv.float_dtype(z1, z2)
+        chi = dv.to_device(self.comoving_radial_distance(dv.to_device(z2, self.device)), self.device) - \
+            dv.to_device(self.comoving_radial_distance(dv.to_device(z1, self.device)), self.device)
+        K = dv.to_device(self._K, self.device)
+        K = K.reshape(K.shape + (1,) * (chi.ndim - K.ndim))
+        sq = torch.sqrt(torch.abs(K))
+        safe = torch.where(sq > 0, sq, torch.ones_like(sq))
+        sk = torch.where(K > 0, torch.sin(safe * chi) / safe, torch.where(K < 0, torch.sinh(safe * chi) / safe, chi))
+        return _out(sk / (1 + dv.to_device(z2, self.device)), like, dtype)
+
+
+class DefaultBackground(BaseBackground):
+
+    """Background of the analytic engines (reference DefaultBackground + eisenstein_hu.Background, eisenstein_hu.py:106-152)."""
+
+    def growth_factor(self, z, znorm=None):
+        """CPT92 approximation of the growth factor (eisenstein_hu.py:115-140)."""
+        growthz = self._eval('growth_cpt', z)
+        if znorm is not None:
+            return (1. + znorm) * growthz
+        g0 = self._eval('growth_cpt', np.zeros(()))
+        if np.ndim(g0) and np.ndim(growthz) > np.ndim(g0):
+            g0 = g0.reshape(g0.shape + (1,) * (np.ndim(growthz) - np.ndim(g0)))
+        return growthz / g0
+
+    def growth_rate(self, z):
+        """Approximation of the growth rate Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))) (eisenstein_hu.py:143-152)."""
+        return self._eval('growth_rate', z)

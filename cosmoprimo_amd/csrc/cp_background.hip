@@ -22,31 +22,17 @@
 #include <vector>
 
 #include "../../include/cosmoprimo_amd.h"
+#include "cp_cosmo_common.h"
 #include "cp_error.h"
 
 namespace {
 
-constexpr int NK = 119;  // knots of get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949
+using namespace cpcosmo;
 
-// physical constants as cosmoprimo/constants.py (scipy.constants CODATA 2018 values)
-constexpr double kC = 299792458.0;
-constexpr double kStefanBoltzmann = 5.6703744191844314e-08;  // scipy.constants.Stefan_Boltzmann (derived to full precision)
-constexpr double kParsec = 3.085677581491367e16;
-constexpr double kG = 6.6743e-11;
-constexpr double kPi = 3.141592653589793;
-constexpr double kMpc = 1e6 * kParsec;
-constexpr double kMsun = 1.98847 * 1e30;
-constexpr double kRhoCritKg = 3.0 * (100. * 1e3 / kMpc) * (100. * 1e3 / kMpc) / (8 * kPi * kG);  // h^2 kg/m^3
-constexpr double kRhoCrit = kRhoCritKg / (1e10 * kMsun) * kMpc * kMpc * kMpc;                      // 1e10 Msun/h / (Mpc/h)^3
-constexpr double kCkms = kC / 1e3;
+constexpr int NK = 119;  // knots of get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949
 
 struct Tables {
     double zc[NK], dx[NK], l[NK], u[NK], idf[NK], idb[NK], cp[NK], bq[NK], ra[NK], rb[NK];
-};
-
-struct Param {
-    const double* ptr;  // per-cosmology array, or nullptr ->
-    double value;       // broadcast value
 };
 
 struct Args {
@@ -60,20 +46,6 @@ struct Args {
     const Tables* tab;
 };
 
-struct Cosmo {
-    double Omega_cdm, Omega_b, Omega_g, Omega_ur, Omega_de, Omega_k, w0, wa, h;
-};
-
-__device__ __forceinline__ double efunc(const Cosmo& c, double z) {
-    // operation order of BaseBackground.rho_tot / rho_crit / efunc, cosmology.py:1723-1754
-    const double zp1 = 1. + z;
-    const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0.;
-    const double r = c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit;
-    const double de = c.Omega_de * pow(zp1, 3. * (c.w0 + c.wa)) * exp(3. * c.wa * (1. / zp1 - 1.)) * kRhoCrit;
-    const double rho_crit = (m + r + de) + c.Omega_k / zp1 * kRhoCrit;
-    return sqrt(rho_crit * (zp1 * zp1 * zp1) / kRhoCrit);
-}
-
 __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     __shared__ Tables T;
     {
@@ -86,28 +58,30 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsamp) return;
     const long long ic = i / A.nz, iz = i - ic * A.nz;
-    double v[CP_BG_NPARAMS];
-#pragma unroll
-    for (int k = 0; k < CP_BG_NPARAMS; ++k) v[k] = A.p[k].ptr ? A.p[k].ptr[ic] : A.p[k].value;
-    Cosmo c;
-    c.h = v[0];
-    c.Omega_b = v[2];
-    c.Omega_cdm = A.second_is_omega_m ? v[1] - v[2] : v[1];
-    c.Omega_k = v[3];
-    const double T_cmb = v[4], N_ur = v[5];
-    c.w0 = v[6];
-    c.wa = v[7];
-    // derived density parameters, cosmology.py:355-383
-    const double h2rc = c.h * c.h * kRhoCritKg;
-    c.Omega_g = (T_cmb * T_cmb * T_cmb * T_cmb) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
-    const double T_ur = T_cmb * 0.7137658555036082;  // (4/11)^(1/3)
-    c.Omega_ur = N_ur * 7. / 8. * (T_ur * T_ur * T_ur * T_ur) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
-    c.Omega_de = 1. - (c.Omega_cdm + c.Omega_b + c.Omega_g + c.Omega_ur + 0. + c.Omega_k);
+    const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m);
     const double z = A.z[A.z_shared ? iz : i];
     const double nan = __builtin_nan("");
     if (A.kind == CP_BG_EFUNC || A.kind == CP_BG_HUBBLE) {
         const double e = efunc(c, z);
         A.out[i] = A.kind == CP_BG_EFUNC ? e : e * (c.h * 100.);
+        return;
+    }
+    if (A.kind == CP_BG_GROWTH_CPT) {  // eisenstein_hu.py:134-136
+        A.out[i] = growth_cpt(c, z);
+        return;
+    }
+    if (A.kind == CP_BG_RHO_CRIT || A.kind == CP_BG_OMEGA_M_Z || A.kind == CP_BG_OMEGA_DE_Z) {  // cosmology.py:1738-1749, 1796, 1850
+        const double zp1 = 1. + z;
+        const double rc = rho_crit(c, zp1);
+        A.out[i] = A.kind == CP_BG_RHO_CRIT ? rc
+                 : (A.kind == CP_BG_OMEGA_M_Z ? (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rc : rho_de(c, zp1) / rc);
+        return;
+    }
+    if (A.kind == CP_BG_GROWTH_RATE) {  // Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))), eisenstein_hu.py:151-152
+        const double zp1 = 1. + z;
+        const double Om = (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rho_crit(c, zp1);
+        const double wz1 = c.w0 + (1. - 0.5) * c.wa;
+        A.out[i] = pow(Om, 0.55 + 0.05 * (1 + wz1));
         return;
     }
     if (!(z >= T.zc[0] && z <= T.zc[NK - 1])) {  // NaN outside the interpolation range (jax.py:200), also for NaN input
@@ -247,7 +221,7 @@ extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_p
     if (ncosmo < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_background_distance: negative size");
     if (ncosmo == 0 || nz == 0) return CP_OK;
     if (!params || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_background_distance: null pointer");
-    if (kind < CP_BG_COMOVING_RADIAL || kind > CP_BG_HUBBLE) return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
+    if (kind < CP_BG_COMOVING_RADIAL || kind > CP_BG_OMEGA_DE_Z) return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: cannot select device %d", device);

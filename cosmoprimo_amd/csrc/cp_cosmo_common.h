@@ -1,0 +1,79 @@
+// cp_cosmo_common.h -- constants and the per-cosmology parameter block shared by the background and P(k) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/cosmoprimo_amd.h"
+
+namespace cpcosmo {
+
+// physical constants as cosmoprimo/constants.py (scipy.constants values, scipy 1.15)
+constexpr double kC = 299792458.0;
+constexpr double kStefanBoltzmann = 5.6703744191844314e-08;  // scipy.constants.Stefan_Boltzmann (derived to full precision)
+constexpr double kParsec = 3.085677581491367e16;
+constexpr double kG = 6.6743e-11;
+constexpr double kPi = 3.141592653589793;
+constexpr double kE = 2.718281828459045;
+constexpr double kMpc = 1e6 * kParsec;
+constexpr double kMsun = 1.98847 * 1e30;
+constexpr double kRhoCritKg = 3.0 * (100. * 1e3 / kMpc) * (100. * 1e3 / kMpc) / (8 * kPi * kG);  // h^2 kg/m^3
+constexpr double kRhoCrit = kRhoCritKg / (1e10 * kMsun) * kMpc * kMpc * kMpc;                      // 1e10 Msun/h / (Mpc/h)^3
+constexpr double kCkms = kC / 1e3;
+
+struct Param {
+    const double* ptr;  // per-cosmology array, or nullptr ->
+    double value;       // broadcast value
+};
+
+struct Cosmo {
+    double h, Omega_cdm, Omega_b, Omega_k, T_cmb, N_ur, w0, wa;  // inputs
+    double Omega_g, Omega_ur, Omega_de;                            // derived, cosmology.py:355-383
+};
+
+// load the 8 background parameters of cosmology ic and derive the radiation / dark-energy densities
+__device__ __forceinline__ Cosmo load_cosmo(const Param* p, long long ic, int second_is_omega_m) {
+    double v[CP_BG_NPARAMS];
+#pragma unroll
+    for (int k = 0; k < CP_BG_NPARAMS; ++k) v[k] = p[k].ptr ? p[k].ptr[ic] : p[k].value;
+    Cosmo c;
+    c.h = v[CP_BG_H];
+    c.Omega_b = v[CP_BG_OMEGA_B];
+    c.Omega_cdm = second_is_omega_m ? v[CP_BG_OMEGA_CDM] - v[CP_BG_OMEGA_B] : v[CP_BG_OMEGA_CDM];  // cosmology.py:1163-1165
+    c.Omega_k = v[CP_BG_OMEGA_K];
+    c.T_cmb = v[CP_BG_T_CMB];
+    c.N_ur = v[CP_BG_N_UR];
+    c.w0 = v[CP_BG_W0_FLD];
+    c.wa = v[CP_BG_WA_FLD];
+    const double h2rc = c.h * c.h * kRhoCritKg;
+    c.Omega_g = (c.T_cmb * c.T_cmb * c.T_cmb * c.T_cmb) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
+    const double T_ur = c.T_cmb * 0.7137658555036082;  // (4/11)^(1/3)
+    c.Omega_ur = c.N_ur * 7. / 8. * (T_ur * T_ur * T_ur * T_ur) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
+    c.Omega_de = 1. - (c.Omega_cdm + c.Omega_b + c.Omega_g + c.Omega_ur + 0. + c.Omega_k);
+    return c;
+}
+
+// comoving critical density rho_crit(z) / rho_c0 pieces, operation order of BaseBackground (cosmology.py:1723-1749)
+__device__ __forceinline__ double rho_de(const Cosmo& c, double zp1) {
+    return c.Omega_de * pow(zp1, 3. * (c.w0 + c.wa)) * exp(3. * c.wa * (1. / zp1 - 1.)) * kRhoCrit;
+}
+
+__device__ __forceinline__ double rho_crit(const Cosmo& c, double zp1) {
+    const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0.;
+    const double r = c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit;
+    return (m + r + rho_de(c, zp1)) + c.Omega_k / zp1 * kRhoCrit;
+}
+
+__device__ __forceinline__ double efunc(const Cosmo& c, double z) {
+    const double zp1 = 1. + z;
+    return sqrt(rho_crit(c, zp1) * (zp1 * zp1 * zp1) / kRhoCrit);  // cosmology.py:1754
+}
+
+// CPT92 growth(z) of the analytic engines, un-normalised (eisenstein_hu.py:134-136)
+__device__ __forceinline__ double growth_cpt(const Cosmo& c, double z) {
+    const double zp1 = 1. + z;
+    const double rc = rho_crit(c, zp1);
+    const double Om = (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rc;  // rho_m / rho_crit, cosmology.py:1701, 1796
+    const double Ode = rho_de(c, zp1) / rc;
+    return 1. / zp1 * 5 * Om / 2. / (pow(Om, 4. / 7.) - Ode + (1. + Om / 2.) * (1 + Ode / 70.));
+}
+
+}  // namespace cpcosmo

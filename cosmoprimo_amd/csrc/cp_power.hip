@@ -1,0 +1,261 @@
+// cp_power.hip -- analytic matter power spectra for batches of cosmologies (gfx950) + C ABI.
+//
+// Replaces, for the engines 'eisenstein_hu', 'eisenstein_hu_nowiggle' and 'bbks':
+//   EisensteinHuEngine._set_rsdrag / compute          eisenstein_hu.py:34-92     (scalars per cosmology)
+//   Transfer.transfer_k                               eisenstein_hu.py:241-283, eisenstein_hu_nowiggle.py:34-51, bbks.py:50-64
+//   Primordial.pk_k                                   eisenstein_hu.py:189-215
+//   Fourier.pk_interpolator: pk_callable x growth^2   eisenstein_hu.py:315-324, growth eisenstein_hu.py:115-140
+// One thread per (cosmology, k); the ~15 fit coefficients are recomputed per thread (a few pow / log, cheaper than a
+// second kernel and a round trip through HBM).  Output layout (ncosmo, nz, nk), k fastest: rows are ready for the FFTLog
+// kernel.  Elementwise and ALU-bound (pow, log, exp); HBM traffic is the 8 nk nz output bytes per cosmology.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/cosmoprimo_amd.h"
+#include "cp_cosmo_common.h"
+#include "cp_error.h"
+
+namespace {
+
+using namespace cpcosmo;
+
+struct EhScalars {
+    double omega_b, omega_m, frac_b, theta_cmb, z_eq, k_eq, z_drag, r_drag, r_eq, rs_drag, k_silk, alpha_c, beta_c, alpha_b, beta_node, beta_b,
+        alpha_gamma;
+};
+
+// eisenstein_hu.py:34-92 (+ eisenstein_hu_nowiggle.py:21), operation for operation
+__device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, double Omega_b, double T_cmb, bool full) {
+    EhScalars s;
+    s.omega_b = Omega_b * (h * h);
+    s.omega_m = Omega_cdm * (h * h) + Omega_b * (h * h);
+    s.frac_b = s.omega_b / s.omega_m;
+    s.theta_cmb = T_cmb / 2.7;
+    const double th2 = s.theta_cmb * s.theta_cmb, thm4 = 1. / (th2 * th2), thm2 = 1. / th2;
+    s.z_eq = 2.5e4 * s.omega_m * thm4 - 1.;
+    s.k_eq = 0.0746 * s.omega_m * thm2;
+    const double b1 = 0.313 * pow(s.omega_m, -0.419) * (1 + 0.607 * pow(s.omega_m, 0.674));
+    const double b2 = 0.238 * pow(s.omega_m, 0.223);
+    s.z_drag = 1345 * pow(s.omega_m, 0.251) / (1. + 0.659 * pow(s.omega_m, 0.828)) * (1. + b1 * pow(s.omega_b, b2));  // HS96 prefactor
+    s.r_drag = 31.5 * s.omega_b * thm4 * (1000. / (1 + s.z_drag));
+    s.r_eq = 31.5 * s.omega_b * thm4 * (1000. / (1 + s.z_eq));
+    s.rs_drag = 2. / (3. * s.k_eq) * sqrt(6. / s.r_eq) * log((sqrt(1 + s.r_drag) + sqrt(s.r_drag + s.r_eq)) / (1 + sqrt(s.r_eq)));
+    s.alpha_gamma = 1. - 0.328 * log(431. * s.omega_m) * s.frac_b + 0.38 * log(22.3 * s.omega_m) * (s.frac_b * s.frac_b);
+    if (full) {
+        s.k_silk = 1.6 * pow(s.omega_b, 0.52) * pow(s.omega_m, 0.73) * (1 + pow(10.4 * s.omega_m, -0.95));
+        const double a1 = pow(46.9 * s.omega_m, 0.670) * (1 + pow(32.1 * s.omega_m, -0.532));
+        const double a2 = pow(12.0 * s.omega_m, 0.424) * (1 + pow(45.0 * s.omega_m, -0.582));
+        s.alpha_c = pow(a1, -s.frac_b) * pow(a2, -(s.frac_b * s.frac_b * s.frac_b));
+        const double bb1 = 0.944 / (1 + pow(458 * s.omega_m, -0.708));
+        const double bb2 = 0.395 * pow(s.omega_m, -0.0266);
+        s.beta_c = 1. / (1 + bb1 * (pow(1 - s.frac_b, bb2)) - 1);
+        const double y = (1 + s.z_eq) / (1 + s.z_drag);
+        const double G = y * (-6. * sqrt(1 + y) + (2. + 3. * y) * log((sqrt(1 + y) + 1) / (sqrt(1 + y) - 1)));
+        s.alpha_b = 2.07 * s.k_eq * s.rs_drag * pow(1 + s.r_drag, -0.75) * G;
+        s.beta_node = 8.41 * pow(s.omega_m, 0.435);
+        s.beta_b = 0.5 + s.frac_b + (3. - 2. * s.frac_b) * sqrt((17.2 * s.omega_m) * (17.2 * s.omega_m) + 1);
+    } else {
+        s.k_silk = s.alpha_c = s.beta_c = s.alpha_b = s.beta_node = s.beta_b = 0.;
+    }
+    return s;
+}
+
+__device__ __forceinline__ double sinc_pi(double x) {  // numpy.sinc(x / pi) = sin(x) / x
+    return x == 0. ? 1. : sin(x) / x;
+}
+
+__device__ __forceinline__ double transfer_eh(const EhScalars& s, double h, double kh) {  // eisenstein_hu.py:252-283
+    const double k = kh * h;
+    const double q = k / (13.41 * s.k_eq);
+    const double ks = k * s.rs_drag;
+    const double ln_beta = log(kE + 1.8 * s.beta_c * q);
+    const double ln_nobeta = log(kE + 1.8 * q);
+    const double q108 = pow(q, 1.08);
+    const double C_alpha = 14.2 / s.alpha_c + 386. / (1 + 69.9 * q108);
+    const double C_noalpha = 14.2 + 386. / (1 + 69.9 * q108);
+    const double ks54 = ks / 5.4;
+    const double T_c_f = 1. / (1. + (ks54 * ks54) * (ks54 * ks54));
+    const double q2 = q * q;
+    const double T_c = T_c_f * (ln_beta / (ln_beta + C_noalpha * q2)) + (1 - T_c_f) * (ln_beta / (ln_beta + C_alpha * q2));
+    const double bn = s.beta_node / ks;
+    const double s_tilde = s.rs_drag * pow(1 + bn * bn * bn, -1. / 3.);
+    const double ks_tilde = k * s_tilde;
+    const double T_b_T0 = ln_nobeta / (ln_nobeta + C_noalpha * q2);
+    const double T_b_1 = T_b_T0 / (1 + (ks / 5.2) * (ks / 5.2));
+    const double bb = s.beta_b / ks;
+    const double T_b_2 = s.alpha_b / (1 + bb * bb * bb) * exp(-pow(k / s.k_silk, 1.4));
+    const double T_b = sinc_pi(ks_tilde) * (T_b_1 + T_b_2);
+    return s.frac_b * T_b + (1 - s.frac_b) * T_c;
+}
+
+__device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h, double kh) {  // eisenstein_hu_nowiggle.py:45-51
+    const double k = kh * h;
+    const double ks = k * s.rs_drag;
+    const double x = 0.43 * ks;
+    const double gamma_eff = s.omega_m * (s.alpha_gamma + (1 - s.alpha_gamma) / (1 + (x * x) * (x * x)));
+    const double q = k * (s.theta_cmb * s.theta_cmb) / gamma_eff;
+    const double L0 = log(2 * kE + 1.8 * q);
+    const double C0 = 14.2 + 731.0 / (1 + 62.5 * q);
+    return L0 / (L0 + C0 * (q * q));
+}
+
+__device__ __forceinline__ double transfer_bbks(double h, double Omega_cdm, double Omega_b, double kh) {  // bbks.py:34-38, 62-64
+    const double Omega_m = Omega_b + Omega_cdm;
+    const double gamma = Omega_m * (h * h) * exp(-Omega_b * (1. + sqrt(2. * h) / Omega_m));
+    const double q = kh * h / gamma;
+    const double x = 2.34 * q;
+    const double a = 16.2 * q, b = 5.47 * q, c = 6.71 * q;
+    // as coded in the reference: 3.89 q (16.2 q)^2, not 3.89 q + (16.2 q)^2
+    return log(1 + x) / x * pow(1. + 3.89 * q * (a * a) + b * b * b + (c * c) * (c * c), -0.25);
+}
+
+struct Args {
+    long long ncosmo;
+    Param bg[CP_BG_NPARAMS];
+    Param pw[CP_PK_NPARAMS];
+    int second_is_omega_m;
+    int engine, what;
+    long long nk, nz;
+    const double* k;  // (nk) shared, h/Mpc
+    const double* z;  // (nz) shared (what == CP_PK_MATTER with nz > 0), else unused
+    double* out;      // (ncosmo, max(nz, 1), nk)
+};
+
+__global__ __launch_bounds__(256) void power_kernel(const Args A) {
+    const long long ik = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ic = blockIdx.y;
+    if (ik >= A.nk) return;
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
+    double pw[CP_PK_NPARAMS];
+#pragma unroll
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
+    const double kh = A.k[ik];
+    const long long nrow = A.nz > 0 ? A.nz : 1;
+    double* out = A.out + ic * nrow * A.nk + ik;
+    double T = 1.;
+    if (A.what != CP_PK_PRIMORDIAL) {
+        if (A.engine == CP_ENGINE_BBKS) {
+            T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+        } else {
+            const EhScalars s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
+            T = A.engine == CP_ENGINE_EH ? transfer_eh(s, c.h, kh) : transfer_nowiggle(s, c.h, kh);
+        }
+    }
+    if (A.what == CP_PK_TRANSFER) {
+        out[0] = T;
+        return;
+    }
+    // Primordial.pk_k, eisenstein_hu.py:214-215
+    const double A_s = pw[CP_PK_A_S], n_s = pw[CP_PK_N_S], alpha_s = pw[CP_PK_ALPHA_S], beta_s = pw[CP_PK_BETA_S];
+    const double kp = pw[CP_PK_K_PIVOT] / c.h;
+    const double lnkkp = log(kh / kp);
+    const double prim = (c.h * c.h * c.h) * A_s * pow(kh / kp, n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp));
+    if (A.what == CP_PK_PRIMORDIAL) {
+        out[0] = prim;
+        return;
+    }
+    // pk_callable, eisenstein_hu.py:321-324
+    const double Omega0_m = c.Omega_b + c.Omega_cdm + 0. - 0.;  // cosmology.py:381
+    const double p2d_base = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (kh * kh));
+    const double potential_to_density = 1. / (p2d_base * p2d_base);
+    const double curvature_to_potential = 9. / 25. * 2. * (kPi * kPi) / (kh * kh * kh) / (c.h * c.h * c.h);
+    const double p0 = (T * T) * potential_to_density * curvature_to_potential * prim;
+    if (A.nz <= 0) {
+        out[0] = p0;
+        return;
+    }
+    for (long long iz = 0; iz < A.nz; ++iz) {
+        const double g = growth_cpt(c, A.z[iz]);  // growth_factor(z, znorm=0), eisenstein_hu.py:317
+        out[iz * A.nk] = p0 * (g * g);
+    }
+}
+
+struct ScalArgs {
+    long long ncosmo;
+    Param bg[CP_BG_NPARAMS];
+    int second_is_omega_m;
+    double* out;  // (ncosmo, CP_EH_NSCALARS)
+};
+
+__global__ __launch_bounds__(256) void eh_scalars_kernel(const ScalArgs A) {
+    const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ic >= A.ncosmo) return;
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
+    const EhScalars s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, true);
+    double* o = A.out + ic * CP_EH_NSCALARS;
+    o[CP_EH_RS_DRAG] = s.rs_drag;
+    o[CP_EH_Z_DRAG] = s.z_drag;
+    o[CP_EH_Z_EQ] = s.z_eq;
+    o[CP_EH_K_EQ] = s.k_eq;
+    o[CP_EH_R_DRAG] = s.r_drag;
+    o[CP_EH_R_EQ] = s.r_eq;
+    o[CP_EH_K_SILK] = s.k_silk;
+    o[CP_EH_ALPHA_C] = s.alpha_c;
+    o[CP_EH_BETA_C] = s.beta_c;
+    o[CP_EH_ALPHA_B] = s.alpha_b;
+    o[CP_EH_BETA_NODE] = s.beta_node;
+    o[CP_EH_BETA_B] = s.beta_b;
+    o[CP_EH_ALPHA_GAMMA] = s.alpha_gamma;
+    const double Omega_m = c.Omega_b + c.Omega_cdm;
+    o[CP_EH_BBKS_GAMMA] = Omega_m * (c.h * c.h) * exp(-c.Omega_b * (1. + sqrt(2. * c.h) / Omega_m));
+}
+
+int select_device(int device, int* prev) {
+    *prev = -1;
+    if (hipGetDevice(prev) != hipSuccess) *prev = -1;
+    if (*prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cannot select device %d", device);
+    return CP_OK;
+}
+
+}  // namespace
+
+extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
+                             long long nk, const double* d_k, long long nz, const double* d_z, double* d_out, int device, void* stream) {
+    if (engine < CP_ENGINE_EH || engine > CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_power_eval: unknown engine %d", engine);
+    if (what < CP_PK_MATTER || what > CP_PK_PRIMORDIAL) return cp::fail(CP_EINVAL, "cp_power_eval: unknown quantity %d", what);
+    if (ncosmo < 0 || nk < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_power_eval: negative size");
+    if (ncosmo == 0 || nk == 0) return CP_OK;
+    if (!bg_params || !pk_params || !d_k || !d_out || (nz > 0 && !d_z)) return cp::fail(CP_EINVAL, "cp_power_eval: null pointer");
+    if (ncosmo > 65535) return cp::fail(CP_EUNSUPPORTED, "cp_power_eval: at most 65535 cosmologies per call (got %lld); split the batch", ncosmo);
+    int prev;
+    int st = select_device(device, &prev);
+    if (st != CP_OK) return st;
+    Args A;
+    A.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) A.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) A.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};
+    A.second_is_omega_m = second_is_omega_m;
+    A.engine = engine;
+    A.what = what;
+    A.nk = nk;
+    A.nz = what == CP_PK_MATTER ? nz : 0;
+    A.k = d_k;
+    A.z = d_z;
+    A.out = d_out;
+    const int block = 256;
+    hipLaunchKernelGGL(power_kernel, dim3((unsigned)((nk + block - 1) / block), (unsigned)ncosmo), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+extern "C" int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, double* d_out, int device, void* stream) {
+    if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_eh_scalars: negative size");
+    if (ncosmo == 0) return CP_OK;
+    if (!bg_params || !d_out) return cp::fail(CP_EINVAL, "cp_eh_scalars: null pointer");
+    int prev;
+    int st = select_device(device, &prev);
+    if (st != CP_OK) return st;
+    ScalArgs A;
+    A.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) A.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
+    A.second_is_omega_m = second_is_omega_m;
+    A.out = d_out;
+    hipLaunchKernelGGL(eh_scalars_kernel, dim3((unsigned)((ncosmo + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_eh_scalars: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

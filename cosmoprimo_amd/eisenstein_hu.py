@@ -1,0 +1,159 @@
+"""
+Eisenstein & Hu 1998 engine on MI355X (reference cosmoprimo/eisenstein_hu.py): fit coefficients, transfer function,
+primordial spectrum, P(k, z) and the sigma8 normalisation, all evaluated by the HIP kernels of ``cp_power.hip`` /
+``cp_fftlog*.hip`` / ``cp_spline.hip`` for one cosmology or a batch.
+"""
+import warnings
+
+import numpy as np
+
+from . import _device as dv
+from . import power as pwmod
+from .cosmology import BaseEngine, BaseSection, DefaultBackground, _out
+from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, integrate_sigma_r2, _host
+
+
+class EisensteinHuEngine(BaseEngine):
+
+    """Eisenstein & Hu analytic formulae, https://arxiv.org/abs/astro-ph/9709112 (reference eisenstein_hu.py:11-103)."""
+    name = 'eisenstein_hu'
+    _transfer = 'eisenstein_hu'
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if self['N_ncdm']:
+            warnings.warn('{} cannot cope with massive neutrinos'.format(self.__class__.__name__))
+        self.compute()
+        self._A_s = self._get_A_s_fid()
+
+    def compute(self):
+        """Fit coefficients (eisenstein_hu.py:34-92) as attributes: rs_drag [Mpc], z_drag, k_eq, alpha_c, ... (floats or (B,) tensors)."""
+        sc = pwmod.eh_scalars(self.bg_params(), device=self.device)
+        for name, v in sc.items():
+            setattr(self, name, float(v) if v.ndim == 0 else v)
+
+    def pk_params(self, rsigma8=None):
+        rs = self._rsigma8 if rsigma8 is None else rsigma8
+        if rs is None:
+            rs = 1.
+        A_s = self._A_s * rs**2 if not dv.is_torch(rs) else dv.to_device(self._A_s, self.device) * rs**2
+        return dict(A_s=A_s, n_s=self['n_s'], alpha_s=self['alpha_s'], beta_s=self['beta_s'], k_pivot=self['k_pivot'])
+
+
+class Background(DefaultBackground):
+    """Background quantities; does not treat neutrinos (reference eisenstein_hu.py:106-152)."""
+
+
+class Thermodynamics(BaseSection):
+
+    """rs_drag [Mpc/h] and z_drag (reference eisenstein_hu.py:155-162)."""
+
+    def __init__(self, engine):
+        super().__init__(engine)
+        self.rs_drag = engine.rs_drag * engine['h'] if not dv.is_torch(engine.rs_drag) else engine.rs_drag * dv.to_device(engine['h'], engine.device)
+        self.z_drag = engine.z_drag
+
+
+class Primordial(BaseSection):
+
+    """Primordial power spectrum (reference eisenstein_hu.py:165-230)."""
+
+    def __init__(self, engine):
+        super().__init__(engine)
+        self._rsigma8 = engine._rescale_sigma8()
+        self.n_s, self.alpha_s, self.beta_s = engine['n_s'], engine['alpha_s'], engine['beta_s']
+        self.k_pivot = engine['k_pivot'] / self._h
+
+    @property
+    def A_s(self):
+        r"""Scalar amplitude of the primordial power spectrum at :math:`k_\mathrm{pivot}`, unitless."""
+        return self._engine._A_s * self._rsigma8**2
+
+    @property
+    def ln_1e10_A_s(self):
+        return np.log(1e10 * self.A_s) if not dv.is_torch(self.A_s) else dv.torch().log(1e10 * self.A_s)
+
+    def pk_k(self, k, mode='scalar'):
+        r"""Primordial spectrum of curvature perturbations at ``k`` [h/Mpc], in (Mpc/h)^3 (eisenstein_hu.py:189-215)."""
+        ['scalar'].index(mode)
+        kh = _host(k)
+        out = pwmod.analytic(self._engine._transfer, 'primordial', kh.ravel(), bg=self._engine.bg_params(), pk=self._engine.pk_params(), device=self.device)
+        return _out(out.reshape(out.shape[:-1] + kh.shape), k)
+
+    def pk_interpolator(self, mode='scalar'):
+        return PowerSpectrumInterpolator1D.from_callable(pk_callable=lambda k: self.pk_k(dv.torch().as_tensor(k, device=self.device), mode=mode).T
+                                                         if self._engine.batch_size else self.pk_k(dv.torch().as_tensor(k, device=self.device), mode=mode),
+                                                         device=self.device)
+
+
+class Transfer(BaseSection):
+
+    """Matter transfer function (reference eisenstein_hu.py:233-283)."""
+
+    def transfer_k(self, k):
+        kh = _host(k)
+        out = pwmod.analytic(self._engine._transfer, 'transfer', kh.ravel(), bg=self._engine.bg_params(), pk=self._engine.pk_params(rsigma8=1.),
+                             device=self.device)
+        return _out(out.reshape(out.shape[:-1] + kh.shape), k)
+
+
+class Fourier(BaseSection):
+
+    """Matter power spectrum (reference eisenstein_hu.py:286-342)."""
+
+    def __init__(self, engine):
+        super().__init__(engine)
+        self.pm = engine.get_primordial()   # triggers the sigma8 normalisation, as in the reference
+        self.tr = engine.get_transfer()
+        self.ba = engine.get_background()
+
+    def _pk0_device(self, kh):
+        """P(k, z) without growth: device tensor (batch..., nk)."""
+        e = self._engine
+        return pwmod.analytic(e._transfer, 'matter', kh, bg=e.bg_params(), pk=e.pk_params(), device=self.device)
+
+    def pk_interpolator(self, of='delta_m', **kwargs):
+        """:class:`PowerSpectrumInterpolator2D` of the pair ``of`` ('delta_m', 'theta_m'), built from callables (eisenstein_hu.py:295-329)."""
+        if isinstance(of, str):
+            of = (of,)
+        of = list(of)
+        of = of + [of[0]] * (2 - len(of))
+        ntheta = sum(of_.startswith('theta_') for of_ in of)
+        ba, device = self.ba, self.device
+
+        def growth_factor_sq(z):
+            zt = dv.to_device(z, device)
+            g = dv.to_device(ba.growth_factor(zt, znorm=0.), device)**2
+            if ntheta:
+                g = g * dv.to_device(ba.growth_rate(zt), device)**ntheta
+            return g
+
+        def pk_callable(k):
+            return self._pk0_device(np.asarray(k, dtype='f8'))
+
+        return PowerSpectrumInterpolator2D.from_callable(pk_callable=pk_callable, growth_factor_sq=growth_factor_sq, device=device, **kwargs)
+
+    def sigma_rz(self, r, z, of='delta_m', **kwargs):
+        r"""R.m.s. of `of` perturbations in spheres of :math:`r` Mpc/h."""
+        return self.pk_interpolator(of=of, **kwargs).sigma_rz(r, z)
+
+    def sigma8_z(self, z, of='delta_m'):
+        r"""R.m.s. of `of` perturbations in spheres of 8 Mpc/h."""
+        return self.sigma_rz(8., z, of=of)
+
+    @property
+    def sigma8_m(self):
+        r"""Current r.m.s. of matter perturbations in a sphere of 8 Mpc/h, unitless."""
+        out = self.sigma8_z(0., of='delta_m')
+        return out
+
+    def _sigma8_m_device(self):
+        """sigma8 of the current normalisation as a device tensor (batch...,): P(k) -> TophatVariance FFTLog -> natural spline at r = 8."""
+        g0 = dv.to_device(self.ba.growth_factor(np.zeros(()), znorm=0.), self.device)**2
+
+        def rows(kh):
+            p0 = self._pk0_device(kh)
+            return p0 * (g0[..., None] if g0.ndim else g0)
+
+        e = self._engine
+        return integrate_sigma_r2(8., rows, kmin=1e-7, kmax=1e2, device=self.device)[..., 0]**0.5

@@ -1,0 +1,640 @@
+"""
+Power spectrum interpolators on MI355X: :class:`PowerSpectrumInterpolator1D`, :class:`PowerSpectrumInterpolator2D` with
+the constructor / ``from_callable`` / ``__call__`` / ``sigma_*`` / ``to_xi`` / ``to_1d`` contracts of the reference
+(cosmoprimo/interpolator.py:412-987), and the low-level :class:`Interpolator1D` / :class:`Interpolator2D`
+(cosmoprimo/jax.py:135-287).
+
+Data path (all on the GPU, through the C ABI of libcosmoprimo_amd.so):
+  * spline fits + evaluations are banded linear operators applied to rows (``cp_spline_*``): natural cubic for
+    Interpolator1D (jax.py:172), separable not-a-knot cubic for Interpolator2D (== RectBivariateSpline(kx=ky=3, s=0),
+    SURVEY.md App. C5);
+  * sigma_r / sigma_rz (default ``method='fftlog'``): P(k) rows on geomspace(kmin, kmax, nk) -> TophatVariance FFTLog
+    (fused kernel) -> natural spline in (s, var) at r -> sqrt (interpolator.py:285-291);
+  * ``method='simpson'`` and sigma_d: the composite-Simpson weights (jax.py:365-507) times the integrand kernel form a
+    fixed operator applied to the P(k) rows (``cp_linop_*``).
+Host side (numpy): grids, log-padding (:func:`_pad_log`), masks / NaN / ``bounds_error`` / dtype rules.
+Inputs may be numpy (results come back as numpy) or torch CUDA tensors (results stay on the device).
+"""
+import inspect
+
+import numpy as np
+
+from . import _device as dv
+from .fftlog import PowerToCorrelation, TophatVariance
+from .spline import LinearOperator, dense_operator
+
+
+def get_default_k_callable():
+    """Default k grid of interpolators built from callables (reference interpolator.py:18-27)."""
+    return np.concatenate([np.logspace(-5, -4, num=20, endpoint=False), np.logspace(-4, -3, num=40, endpoint=False),
+                           np.logspace(-3, -2, num=60, endpoint=False), np.logspace(-2, -1, num=80, endpoint=False),
+                           np.logspace(-1, 0, num=100, endpoint=False), np.logspace(0, 2, num=240, endpoint=True)])
+
+
+def get_default_z_callable():
+    """Default z grid (reference interpolator.py:34-35)."""
+    return np.linspace(0., 10.**0.5, 30)**2
+
+
+_default_extrap_kmin = 1e-7
+_default_extrap_kmax = 1e2
+
+
+def _pad_log(k, pk, extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax):
+    """Pad (k, pk) with two log-log linearly extrapolated points on each side (reference interpolator.py:42-87). Host numpy; axis 0 = k."""
+    logk = np.log10(k)
+    logpk = np.log10(pk)
+    log_extrap_kmin = np.log10(np.minimum(extrap_kmin, k[0] * (1 - 1e-9)))
+    log_extrap_kmax = np.log10(np.maximum(extrap_kmax, k[-1] * (1 + 1e-9)))
+    dlogpkdlogk = (logpk[-1] - logpk[-2]) / (logk[-1] - logk[-2])
+    padhighk = np.array([logk[-1] * 0.1 + log_extrap_kmax * 0.9, log_extrap_kmax])
+    padhighpk = np.array([logpk[-1] + dlogpkdlogk * (padhighk[0] - logk[-1]), logpk[-1] + dlogpkdlogk * (padhighk[1] - logk[-1])])
+    dlogpkdlogk = (logpk[1] - logpk[0]) / (logk[1] - logk[0])
+    padlowk = np.array([log_extrap_kmin, logk[0] * 0.1 + log_extrap_kmin * 0.9])
+    padlowpk = np.array([logpk[0] + dlogpkdlogk * (padlowk[0] - logk[0]), logpk[0] + dlogpkdlogk * (padlowk[1] - logk[0])])
+    return np.concatenate([padlowk, logk, padhighk], axis=0), np.concatenate([padlowpk, logpk, padhighpk], axis=0)
+
+
+def _mask_bounds(x, xlim, bounds_error=False):
+    """Masks of in-range values; ``bounds_error`` raises ValueError like the reference (jax.py:120-131). Host numpy."""
+    masks = [(xx >= lim[0]) & (xx <= lim[1]) for xx, lim in zip(x, xlim)]
+    if bounds_error:
+        for mask, xx, lim in zip(masks, x, xlim):
+            if not mask.all():
+                raise ValueError('input outside of extrapolation range (min: {} vs. {}; max: {} vs. {})'.format(xx.min(), lim[0], xx.max(), lim[1]))
+    return masks
+
+
+def _host(x):
+    """numpy float64 copy of a number / array / tensor (query coordinates are small and define host-built operators)."""
+    if dv.is_torch(x):
+        return x.detach().cpu().numpy().astype('f8')
+    return np.asarray(x, dtype='f8')
+
+
+def _finish(t, dtype, like_torch, shape=None):
+    """Device tensor -> caller's container (numpy unless any input was a torch tensor) with the reference's dtype rule."""
+    torch = dv.torch()
+    if shape is not None:
+        t = t.reshape(shape)
+    if like_torch:
+        return t.to(torch.float32 if dtype == np.float32 else torch.float64)
+    return t.cpu().numpy().astype(dtype)
+
+
+def _simpson_weights(x):
+    """Weights w with simpson(y, x) == w @ y for the reference's rule (jax.py:365-507: scipy v1.0.0 simpson, even='avg'). Host numpy."""
+    n = x.size
+
+    def pairs(xx):
+        h = np.diff(xx)
+        h0, h1 = h[0::2], h[1::2]
+        hsum, hprod, ratio = h0 + h1, h0 * h1, h0 / h1
+        w = np.zeros(xx.size)
+        np.add.at(w, np.arange(0, xx.size - 2, 2), hsum / 6.0 * (2 - 1.0 / ratio))
+        np.add.at(w, np.arange(1, xx.size - 1, 2), hsum / 6.0 * hsum * hsum / hprod)
+        np.add.at(w, np.arange(2, xx.size, 2), hsum / 6.0 * (2 - ratio))
+        return w
+
+    if n % 2 == 1:
+        return pairs(x)
+    w = np.zeros(n)
+    w[:-1] += pairs(x[:-1]) / 2.0
+    w[1:] += pairs(x[1:]) / 2.0
+    w[-1] += 0.25 * (x[-1] - x[-2])
+    w[-2] += 0.25 * (x[-1] - x[-2])
+    w[0] += 0.25 * (x[1] - x[0])
+    w[1] += 0.25 * (x[1] - x[0])
+    return w
+
+
+def kernel_tophat2(x):
+    """W(x)^2, W = 3 (sin x - x cos x) / x^3 with the Maclaurin series below 0.1 (reference interpolator.py:90-120). Host numpy."""
+    x = np.asarray(x, dtype='f8')
+    x2 = x**2
+    low = 1. + x2 * (-1.0 / 10.0 + x2 * (1.0 / 280.0 + x2 * (-1.0 / 15120.0 + x2 * (1.0 / 1330560.0 + x2 * (-1.0 / 172972800.0)))))
+    with np.errstate(all='ignore'):
+        high = 3. * (np.sin(x) - x * np.cos(x)) / x**3
+    return np.where(x < 0.1, low, high)**2
+
+
+_tophat_cache = {}
+_op_cache = {}
+
+
+def _cached_operator(key, build):
+    if key not in _op_cache:
+        if len(_op_cache) > 64:
+            _op_cache.clear()
+        _op_cache[key] = build()
+    return _op_cache[key]
+
+
+def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None):
+    r"""
+    :math:`\sigma_r^2 = \frac{1}{2\pi^2}\int dk\,k^2 P(k) W^2(kr)` (reference interpolator.py:200-292) for rows of P(k).
+
+    pk_rows : callable k (numpy, (nk,)) -> device tensor (..., nk): the power spectra sampled at k, k fastest.
+    method : 'fftlog' (default) or 'simpson'.  Returns a device tensor (..., nr) holding :math:`\sigma_r^2`.
+    """
+    device = dv.resolve_device(device)
+    rr = _host(r).ravel()
+    if nk is None:
+        nk = 1024
+    if method == 'fftlog':
+        k = np.geomspace(kmin, kmax, nk)
+        key = (float(kmin), float(kmax), int(nk), device.index)
+        if key not in _tophat_cache:
+            _tophat_cache[key] = TophatVariance(k, device=device)
+        fft = _tophat_cache[key]
+        rows = pk_rows(k)
+        s, var = fft(rows)
+        s = fft.y[0]
+        op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
+        # tmp = (2 pi^2) spline(var)(r); sigma^2 = tmp / (2 pi^2)  (interpolator.py:289-291)
+        return op(var)
+    if method == 'simpson':
+        limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
+        logk = np.linspace(*limits, nk)
+        k = np.exp(logk)
+
+        def build():
+            w = _simpson_weights(logk)
+            return LinearOperator.dense(1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * w)[None, :], device=device)
+
+        op = _cached_operator(('simpson_r', float(kmin), float(kmax), int(nk), rr.tobytes(), device.index), build)
+        return op(pk_rows(k))
+    raise NotImplementedError('integrate_sigma_r2 method {} is not available on the GPU path (use "fftlog" or "simpson")'.format(method))
+
+
+def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, device=None):
+    r""":math:`\sigma_d^2 = \frac{1}{6\pi^2}\int dk\,P(k)` (reference interpolator.py:123-197, default 'simpson'); device tensor (...,)."""
+    device = dv.resolve_device(device)
+    if method != 'simpson':
+        raise NotImplementedError('integrate_sigma_d2 method {} is not available on the GPU path (use "simpson")'.format(method))
+    if nk is None:
+        nk = 1024
+    limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
+    logk = np.linspace(*limits, nk)
+    k = np.exp(logk)
+    op = _cached_operator(('simpson_d', float(kmin), float(kmax), int(nk), device.index),
+                          lambda: LinearOperator.dense((1. / (6. * np.pi**2) * k * _simpson_weights(logk))[None, :], device=device))
+    return op(pk_rows(k))[..., 0]
+
+
+class Interpolator1D(object):
+
+    """1D interpolation along axis 0 of ``fun`` (n, ...) in lin or log10 space; natural cubic spline (reference jax.py:135-209)."""
+
+    def __init__(self, x, fun, k=3, interp_x='lin', interp_fun='lin', extrap=False, assume_sorted=False, device=None):
+        if int(k) != 3:
+            raise NotImplementedError('only cubic (k=3) interpolation is implemented on the GPU path')
+        self.device = dv.resolve_device(device, fun)
+        self.interp_x, self.interp_fun, self.extrap = str(interp_x), str(interp_fun), bool(extrap)
+        x = _host(x).ravel()
+        fun = dv.to_device(fun, self.device)
+        self.shape = tuple(fun.shape[1:])
+        if not assume_sorted:
+            ix = np.argsort(x)
+            x = x[ix]
+            fun = fun[dv.torch().as_tensor(ix, device=self.device)]
+        self.xmin, self.xmax = x[0], x[-1]
+        self._x = np.log10(x) if self.interp_x == 'log' else x
+        fun = fun.reshape(x.size, -1)
+        if self.interp_fun == 'log':
+            fun = dv.torch().log10(fun)
+        self._rows = fun.T.contiguous()   # (ncol, n): one spline per row
+        # any NaN in a column (e.g. log of a negative P) makes that whole column NaN, without raising (reference jax.py:161-172)
+        self._nan_rows = dv.torch().isnan(self._rows).any(dim=1)
+
+    def __call__(self, x, bounds_error=False, dx=0):
+        like_torch = dv.is_torch(x)
+        dtype = dv.float_dtype(x)
+        xh = _host(x)
+        shape = xh.shape + self.shape
+        xh = xh.ravel()
+        _mask_bounds([xh], [(self.xmin, self.xmax)], bounds_error=bounds_error)
+        xq = np.log10(xh) if self.interp_x == 'log' else xh
+        op = _cached_operator(('i1d', self._x.tobytes(), xq.tobytes(), int(dx), self.extrap, self.device.index),
+                              lambda: LinearOperator.spline(self._x, xq, bc='natural', nu=dx, extrapolate=self.extrap, device=self.device))
+        out = op(self._rows)   # (ncol, nq); NaN outside [xmin, xmax] unless extrap
+        if bool(self._nan_rows.any()):
+            out = dv.torch().where(self._nan_rows[:, None], dv.torch().full_like(out, float('nan')), out)
+        if self.interp_fun == 'log':
+            out = 10**out
+        return _finish(out.T, dtype, like_torch, shape)
+
+
+class Interpolator2D(object):
+
+    """2D grid interpolation, == RectBivariateSpline(kx=ky=3, s=0): separable not-a-knot cubic splines (reference jax.py:213-287)."""
+
+    def __init__(self, x, y, fun, kx=3, ky=3, interp_x='lin', interp_fun='lin', extrap=False, assume_sorted=False, device=None):
+        if int(kx) != 3 or int(ky) != 3:
+            raise NotImplementedError('only bicubic (kx=ky=3) interpolation is implemented on the GPU path')
+        torch = dv.torch()
+        self.device = dv.resolve_device(device, fun)
+        self.interp_x, self.interp_fun, self.extrap = str(interp_x), str(interp_fun), bool(extrap)
+        x, y = _host(x).ravel(), _host(y).ravel()
+        fun = dv.to_device(fun, self.device)
+        if not assume_sorted:
+            ix, iy = np.argsort(x), np.argsort(y)
+            x, y = x[ix], y[iy]
+            fun = fun[torch.as_tensor(ix, device=self.device)][:, torch.as_tensor(iy, device=self.device)]
+        self.xmin, self.xmax, self.ymin, self.ymax = x[0], x[-1], y[0], y[-1]
+        self._x = np.log10(x) if self.interp_x == 'log' else x
+        self._y = y
+        if self.interp_fun == 'log':
+            fun = torch.log10(fun)
+        self._fun = fun.contiguous()    # (nx, ny)
+
+    def __call__(self, x, y, grid=True, bounds_error=False):
+        torch = dv.torch()
+        like_torch = dv.is_torch(x) or dv.is_torch(y)
+        dtype = dv.float_dtype(x, y)
+        xh, yh = _host(x), _host(y)
+        shape = xh.shape + yh.shape if grid else xh.shape
+        xh, yh = xh.ravel(), yh.ravel()
+        mask_x, mask_y = _mask_bounds([xh, yh], [(self.xmin, self.xmax), (self.ymin, self.ymax)], bounds_error=bounds_error)
+        xq = np.log10(xh) if self.interp_x == 'log' else xh
+        if grid:
+            opx = _cached_operator(('i2x', self._x.tobytes(), xq.tobytes(), self.device.index),
+                                   lambda: LinearOperator.spline(self._x, xq, bc='not-a-knot', extrapolate=True, device=self.device))
+            opy = _cached_operator(('i2y', self._y.tobytes(), yh.tobytes(), self.device.index),
+                                   lambda: LinearOperator.spline(self._y, yh, bc='not-a-knot', extrapolate=True, device=self.device))
+            tmp = opx(self._fun.T.contiguous())     # rows = y knots: (ny, nxq)
+            out = opy(tmp.T.contiguous())           # rows = x queries: (nxq, nyq)
+            mask = mask_x[:, None] & mask_y
+        else:
+            wx = torch.as_tensor(dense_operator(self._x, xq, bc='not-a-knot', extrapolate=True), device=self.device)   # (nq, nx)
+            wy = torch.as_tensor(dense_operator(self._y, yh, bc='not-a-knot', extrapolate=True), device=self.device)   # (nq, ny)
+            out = ((wx @ self._fun) * wy).sum(dim=-1)
+            mask = mask_x & mask_y
+        if self.interp_fun == 'log':
+            out = 10**out
+        if not self.extrap:
+            out = torch.where(torch.as_tensor(mask, device=self.device), out, torch.full_like(out, float('nan')))
+        return _finish(out, dtype, like_torch, shape)
+
+
+def _get_default_kwargs(func, start=0, remove=()):
+    """Default parameters of ``func`` as a dictionary (reference interpolator.py:296-325)."""
+    parameters = inspect.signature(func).parameters
+    default_params = {}
+    for iname, (name, param) in enumerate(parameters.items()):
+        if iname >= start:
+            default_params[name] = param.default
+    for rm in remove:
+        default_params.pop(rm)
+    return default_params
+
+
+class _BasePowerSpectrumInterpolator(object):
+
+    """Base class for power spectrum interpolators (reference interpolator.py:327-407)."""
+
+    def _prepare(self, k, pk, z=None, interp_k='log', extrap_pk='log', extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax):
+        self.k = _host(k).ravel()
+        self._pk = _host(pk)
+        if self._pk.ndim > 1 or z is not None:
+            self._pk = self._pk.reshape(self.k.shape + (-1,))
+        ix = np.argsort(self.k)
+        self.k, self._pk = self.k[ix], self._pk[ix]
+        if z is not None:
+            self.z = _host(z).ravel()
+            ix = np.argsort(self.z)
+            self.z, self._pk = self.z[ix], self._pk[:, ix]
+        self.interp_k = str(interp_k)
+        self.extrap_pk = str(extrap_pk)
+        k, pk = self.k, self._pk
+        self.extrap_kmin, self.extrap_kmax = k[0], k[-1]
+        if self.extrap_pk == 'log':
+            if self.interp_k != 'log':
+                raise ValueError('log-log extrapolation requires log-x interpolation')
+            self.extrap_kmin, self.extrap_kmax = extrap_kmin, extrap_kmax
+            with np.errstate(all='ignore'):   # negative P -> NaN everywhere, without raising (reference tests/test_interpolator.py:328-337)
+                k, pk = _pad_log(k, pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
+                k, pk = 10**k, 10**pk
+        return k, pk
+
+    def params(self):
+        """Return interpolator parameter dictionary."""
+        return {name: getattr(self, name) for name in self.default_params}
+
+    def as_dict(self):
+        """Return interpolator as a dictionary."""
+        state = self.params()
+        for name in ['k', 'pk']:
+            state[name] = getattr(self, name)
+        if hasattr(self, 'z'):
+            state['z'] = self.z
+        return state
+
+    def clone(self, **kwargs):
+        """Clone interpolator, i.e. return a deepcopy with (possibly) other attributes in ``kwargs``."""
+        return self.__class__(**{**self.as_dict(), **kwargs})
+
+    def deepcopy(self):
+        """Deep copy interpolator (interpolators built from callables are re-tabulated at ``k``, as in the reference)."""
+        return self.__class__(**self.as_dict())
+
+    @property
+    def kmin(self):
+        """Minimum (interpolated) ``k`` value."""
+        return self.k[0]
+
+    @property
+    def kmax(self):
+        """Maximum (interpolated) ``k`` value."""
+        return self.k[-1]
+
+
+class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
+
+    """1D power spectrum interpolator with ``sigma_r``, ``sigma_d``, ``to_xi`` (reference interpolator.py:412-605)."""
+
+    def __init__(self, k, pk, interp_k='log', extrap_pk='log', extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax, interp_order_k=3,
+                 device=None):
+        self._rsigma8sq = 1.
+        self.device = dv.resolve_device(device, pk)
+        k, pk = self._prepare(k, pk, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
+        self.interp_order_k = int(interp_order_k)
+        self._interp = Interpolator1D(k, pk, k=self.interp_order_k, interp_x=self.interp_k, interp_fun=self.extrap_pk, assume_sorted=True, device=self.device)
+        self.is_from_callable = False
+
+    default_params = _get_default_kwargs(__init__, start=3, remove=('device',))
+
+    @property
+    def pk(self):
+        """Power spectrum array (evaluated at ``k`` if built from a callable), with normalisation."""
+        if self.is_from_callable:
+            return self(self.k)
+        return self._pk * self._rsigma8sq
+
+    @classmethod
+    def from_callable(cls, k=None, pk_callable=None, extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax, device=None):
+        """Build from ``pk_callable(k)`` -> array / device tensor of shape (nk,) or (nk, ncol) (reference interpolator.py:462-493)."""
+        if k is None:
+            k = get_default_k_callable()
+        self = cls.__new__(cls)
+        self.__dict__.update(self.default_params)
+        self._rsigma8sq = 1.
+        self.device = dv.resolve_device(device)
+        self.k = np.sort(_host(k).ravel())
+        self.extrap_kmin, self.extrap_kmax = extrap_kmin, extrap_kmax
+        self.is_from_callable = True
+        self._interp = pk_callable
+        return self
+
+    def _eval_device(self, kh, bounds_error=False):
+        """P(k) at host wavenumbers ``kh`` (flat) as a device tensor (nk,) + trailing column shape."""
+        torch = dv.torch()
+        if self.is_from_callable:
+            mask_k, = _mask_bounds([kh], [(self.extrap_kmin, self.extrap_kmax)], bounds_error=bounds_error)
+            out = dv.to_device(self._interp(kh), self.device)
+            mask = torch.as_tensor(mask_k, device=self.device).reshape((-1,) + (1,) * (out.ndim - 1))
+            out = torch.where(mask, out, torch.full_like(out, float('nan')))
+        else:
+            out = self._interp(torch.as_tensor(kh, device=self.device), bounds_error=bounds_error)
+        return out * self._rsigma8sq
+
+    def __call__(self, k, bounds_error=False):
+        """Evaluate the power spectrum at wavenumbers ``k``; NaN outside [extrap_kmin, extrap_kmax] (``bounds_error`` raises)."""
+        like_torch = dv.is_torch(k)
+        dtype = dv.float_dtype(k)
+        kh = _host(k)
+        out = self._eval_device(kh.ravel(), bounds_error=bounds_error)
+        return _finish(out, dtype, like_torch, kh.shape + tuple(out.shape[1:]))
+
+    def _rows(self, kh):
+        """P(k) as rows (ncol..., nk) for the sigma integrals."""
+        out = self._eval_device(kh)
+        return out.reshape(kh.size, -1).T.contiguous() if out.ndim > 1 else out[None, :]
+
+    def _colshape(self):
+        return tuple(self._eval_device(np.array([self.k[0]])).shape[1:])
+
+    def sigma_d(self, **kwargs):
+        r"""R.m.s. of the displacement field :math:`\sqrt{\frac{1}{6\pi^2}\int dk P(k)}` (reference interpolator.py:523-545)."""
+        cs = self._colshape()
+        out = integrate_sigma_d2(self._rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+        return _finish(out, np.dtype('f8'), False, cs)
+
+    def sigma_r(self, r, **kwargs):
+        r"""R.m.s. of perturbations in a sphere of radius :math:`r` (reference interpolator.py:547-573); shape r.shape (+ columns)."""
+        like_torch = dv.is_torch(r)
+        dtype = dv.float_dtype(r)
+        rh = _host(r)
+        cs = self._colshape()
+        out = integrate_sigma_r2(rh, self._rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5   # (ncol, nr)
+        return _finish(out.T, dtype, like_torch, rh.shape + cs)
+
+    def sigma8(self, **kwargs):
+        """R.m.s. of perturbations in a sphere of 8."""
+        return self.sigma_r(8., **kwargs)
+
+    def rescale_sigma8(self, sigma8=1.):
+        """Rescale power spectrum to the provided ``sigma8`` normalisation."""
+        self._rsigma8sq = 1.
+        self._rsigma8sq = sigma8**2 / self.sigma8()**2
+
+    def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
+        """Transform into a correlation function with FFTLog (reference interpolator.py:584-605): returns ``(s, xi)`` arrays (xi shape (nk,) + columns)."""
+        k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
+        s, xi = PowerToCorrelation(k, complex=False, device=self.device, **(fftlog_kwargs or {}))(self._rows(k))
+        cs = self._colshape()
+        return s.cpu().numpy(), xi.T.reshape((nk,) + cs).cpu().numpy()
+
+
+class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
+
+    """2D power spectrum interpolator with ``sigma_rz``, ``sigma_dz``, ``to_1d``, ``to_xi`` (reference interpolator.py:609-987)."""
+
+    def __init__(self, k, z, pk, interp_k='log', extrap_pk='log', extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax,
+                 interp_order_k=3, interp_order_z=3, growth_factor_sq=None, device=None):
+        self._rsigma8sq = 1.
+        self.growth_factor_sq = growth_factor_sq
+        self.device = dv.resolve_device(device, pk)
+        self._batch = None
+        k, pk = self._prepare(k, pk, z=z, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
+        self.interp_order_k, self.interp_order_z = int(interp_order_k), int(interp_order_z)
+        is2d = self._pk.shape[1] > 1
+        if is2d:
+            self._interp = Interpolator2D(k, self.z, pk, kx=self.interp_order_k, ky=self.interp_order_z, interp_x=self.interp_k, interp_fun=self.extrap_pk,
+                                          assume_sorted=True, device=self.device)
+        else:
+            if self.growth_factor_sq is None:
+                raise ValueError('provide either 2D pk array or growth_factor_sq')
+            self._interp = Interpolator1D(k, pk[:, 0], k=self.interp_order_k, interp_x=self.interp_k, interp_fun=self.extrap_pk, assume_sorted=True,
+                                          device=self.device)
+        self.is_from_callable = False
+
+    default_params = _get_default_kwargs(__init__, start=4, remove=('device',))
+
+    @property
+    def pk(self):
+        """Power spectrum array (evaluated on (k, z) if built from a callable), without growth factor, with normalisation."""
+        if self.is_from_callable:
+            kwargs = {'ignore_growth': True} if self.growth_factor_sq is not None else {}
+            return self(self.k, self.z, **kwargs)
+        return self._pk * self._rsigma8sq
+
+    @property
+    def zmin(self):
+        """Minimum (spline-interpolated) redshift."""
+        return self.z[0]
+
+    @property
+    def zmax(self):
+        """Maximum (spline-interpolated) redshift."""
+        return self.z[-1]
+
+    @classmethod
+    def from_callable(cls, k=None, z=None, pk_callable=None, growth_factor_sq=None, extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax,
+                      device=None):
+        """
+        Build from callables (reference interpolator.py:696-739).  ``pk_callable(k)`` -> (..., nk) and ``growth_factor_sq(z)`` ->
+        (..., nz) device tensors / arrays (leading dimensions = a batch of cosmologies), or ``pk_callable(k, z, grid=True)`` -> (..., nk, nz).
+        """
+        if k is None:
+            k = get_default_k_callable()
+        if z is None:
+            z = get_default_z_callable()
+        self = cls.__new__(cls)
+        self.__dict__.update(self.default_params)
+        self._rsigma8sq = 1.
+        self.device = dv.resolve_device(device)
+        self.k, self.z = np.sort(_host(k).ravel()), np.sort(_host(z).ravel())
+        self.growth_factor_sq = growth_factor_sq
+        self.extrap_kmin, self.extrap_kmax = extrap_kmin, extrap_kmax
+        self.is_from_callable = True
+        self._interp = pk_callable
+        return self
+
+    def _eval_device(self, kh, zh, grid=True, ignore_growth=False, bounds_error=False):
+        """P(k, z) at flat host coordinates as a device tensor (batch..., nk, nz) (grid) or (batch..., nk) (pairs)."""
+        torch = dv.torch()
+        if self.is_from_callable:
+            mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
+            mask = mask_k[:, None] & mask_z if grid else mask_k & mask_z
+            if self.growth_factor_sq is not None:
+                tmp = dv.to_device(self._interp(kh), self.device)                     # (..., nk)
+                if not ignore_growth:
+                    growth = dv.to_device(self.growth_factor_sq(zh), self.device)     # (..., nz)
+                    tmp = tmp[..., :, None] * growth[..., None, :] if grid else tmp * growth
+                elif grid:
+                    tmp = tmp[..., :, None].expand(tmp.shape + (zh.size,))
+            else:
+                tmp = dv.to_device(self._interp(kh, zh, grid=grid), self.device)
+            out = torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+        else:
+            is2d = self._pk.shape[1] > 1
+            mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
+            if not is2d:
+                mask_z = mask_z | True    # ignore input z
+            mask = mask_k[:, None] & mask_z if grid else mask_k & mask_z
+            if is2d:
+                interp = self._interp
+                saved = interp.extrap
+                interp.extrap = True      # the P(k, z) mask below uses the extrapolation range, as the reference does
+                tmp = interp(torch.as_tensor(kh, device=self.device), torch.as_tensor(zh, device=self.device), grid=grid)
+                interp.extrap = saved
+            else:
+                tmp = self._interp(torch.as_tensor(kh, device=self.device))
+                if grid:
+                    tmp = tmp[:, None].expand(kh.size, zh.size)
+            if self.growth_factor_sq is not None and not ignore_growth:
+                tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
+            out = torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+        return out * self._rsigma8sq
+
+    def __call__(self, k, z, grid=True, ignore_growth=False, bounds_error=False):
+        """Evaluate at wavenumbers ``k`` and redshifts ``z``: shape (batch...) + k.shape + z.shape (``grid``) or + k.shape (pairs)."""
+        like_torch = dv.is_torch(k) or dv.is_torch(z)
+        dtype = dv.float_dtype(k, z)
+        kh, zh = _host(k), _host(z)
+        out = self._eval_device(kh.ravel(), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error)
+        nlead = out.ndim - (2 if grid else 1)
+        shape = tuple(out.shape[:nlead]) + (kh.shape + zh.shape if grid else kh.shape)
+        return _finish(out, dtype, like_torch, shape)
+
+    def _rows_z(self, zh, ignore_growth=False):
+        """Callable k -> rows (batch..., nz, nk) of P(k, z) for the sigma integrals."""
+        def rows(kh):
+            return self._eval_device(kh, zh, grid=True, ignore_growth=ignore_growth).transpose(-1, -2).contiguous()
+        return rows
+
+    def sigma_dz(self, z, **kwargs):
+        r""":math:`\sigma_d(z) = \sqrt{\frac{1}{6\pi^2}\int dk P(k, z)}` (reference interpolator.py:819-844); shape (batch...) + z.shape."""
+        like_torch = dv.is_torch(z)
+        dtype = dv.float_dtype(z)
+        zh = _host(z)
+        out = integrate_sigma_d2(self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+        return _finish(out, dtype, like_torch, tuple(out.shape[:-1]) + zh.shape)
+
+    def sigma_rz(self, r, z, **kwargs):
+        r"""
+        R.m.s. of perturbations in spheres of radius :math:`r` at redshifts :math:`z` (reference interpolator.py:846-875):
+        shape (batch...) + r.shape + z.shape.
+        """
+        like_torch = dv.is_torch(r) or dv.is_torch(z)
+        dtype = dv.float_dtype(r, z)
+        rh, zh = _host(r), _host(z)
+        out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+        out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
+        return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
+
+    def sigma8_z(self, z=0, **kwargs):
+        """R.m.s. of perturbations in a sphere of 8."""
+        return self.sigma_rz(8., z=z, **kwargs)
+
+    def rescale_sigma8(self, sigma8=1.):
+        """Rescale power spectrum to the provided ``sigma8`` normalisation at z = 0."""
+        self._rsigma8sq = 1.
+        self._rsigma8sq = sigma8**2 / self.sigma8_z(z=0)**2
+
+    def growth_rate_rz(self, r, z, dz=1e-3, **kwargs):
+        r""":math:`f(r, z) = d\ln\sigma_r(z) / d\ln a` by finite differences in z (reference interpolator.py:886-936)."""
+        hdz = dz / 2.
+        dtype = dv.float_dtype(r, z)
+        rh, zh = _host(r), _host(z)
+        shape = rh.shape + zh.shape
+        if not all(shape):
+            return np.zeros(shape, dtype=dtype)
+        zf = zh.ravel()
+
+        def fun(zz):
+            return np.log(np.asarray(self.sigma_rz(rh.ravel(), zz, **kwargs), dtype='f8'))
+
+        feval = [f.reshape(f.shape[:-2] + (-1, zf.size)) for f in [fun(zf - dz), fun(zf - hdz), fun(zf), fun(zf + hdz), fun(zf + dz)]]
+        toret = np.where(zf < self.zmin + hdz, -feval[4] + 4 * feval[3] - 3 * feval[2], feval[3] - feval[1])
+        toret = np.where(zf > self.zmax - hdz, -(-feval[0] + 4 * feval[1] - 3 * feval[2]), toret)
+        dsigdlna = -(toret / dz) * (1 + zf)
+        return dsigdlna.astype(dtype).reshape(dsigdlna.shape[:-2] + shape)
+
+    def to_1d(self, z, **kwargs):
+        """:class:`PowerSpectrumInterpolator1D` at redshift(s) ``z`` (reference interpolator.py:938-963)."""
+        if self.is_from_callable:
+            zh = _host(z)
+
+            def pk_callable(kh):
+                out = self._eval_device(np.asarray(kh, dtype='f8').ravel(), zh.ravel(), grid=True) / self._rsigma8sq
+                out = out.reshape(out.shape[:-1] + zh.shape) if zh.ndim else out[..., 0]
+                return out * self._rsigma8sq
+
+            return PowerSpectrumInterpolator1D.from_callable(self.k, pk_callable=pk_callable, extrap_kmin=self.extrap_kmin, extrap_kmax=self.extrap_kmax,
+                                                             device=self.device)
+        default_params = dict(extrap_pk=self.extrap_pk, extrap_kmin=self.extrap_kmin, extrap_kmax=self.extrap_kmax, interp_order_k=self.interp_order_k)
+        default_params.update(kwargs)
+        self.extrap_kmin, self.extrap_kmax = -np.inf, np.inf    # in case self.k > self.extrap_kmax
+        pk = self(self.k, z=z)
+        self.extrap_kmin, self.extrap_kmax = default_params['extrap_kmin'], default_params['extrap_kmax']
+        return PowerSpectrumInterpolator1D(self.k, pk, device=self.device, **default_params)
+
+    def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
+        """FFTLog transform to the correlation function on the (s, z) grid, growth factor left out as in the reference
+        (interpolator.py:965-987, ``ignore_growth=True``): returns ``(s, z, xi)`` with xi (batch..., nk, nz)."""
+        k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
+        rows = self._rows_z(self.z, ignore_growth=True)(k)     # (batch..., nz, nk)
+        s, xi = PowerToCorrelation(k, complex=False, device=self.device, **(fftlog_kwargs or {}))(rows)
+        return s.cpu().numpy(), self.z, xi.transpose(-1, -2).cpu().numpy()

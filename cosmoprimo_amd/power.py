@@ -1,0 +1,72 @@
+"""
+Analytic matter power spectra on MI355X for batches of cosmologies: the data-parallel core behind the engines
+'eisenstein_hu', 'eisenstein_hu_nowiggle' and 'bbks' (reference eisenstein_hu.py, eisenstein_hu_nowiggle.py, bbks.py).
+"""
+import numpy as np
+
+from . import _lib
+from . import _device as dv
+from .background import DEFAULTS as BG_DEFAULTS
+
+PK_DEFAULTS = dict(A_s=2.43e-9 * (0.8 / 0.87659)**2, n_s=0.96, alpha_s=0., beta_s=0., k_pivot=0.05)
+
+
+def A_s_fid(sigma8):
+    """First guess for A_s given sigma8 (reference BaseEngine._get_A_s_fid, cosmology.py:505-510)."""
+    return 2.43e-9 * (sigma8 / 0.87659)**2
+
+
+def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=None):
+    """
+    ``what`` in ('matter', 'transfer', 'primordial') for engine in ('eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks').
+
+    k : (nk,) wavenumbers [h/Mpc] (numpy or torch), shared by the batch; z : (nz,) redshifts or None (no growth factor).
+    bg : background parameters (see :func:`cosmoprimo_amd.background.distance`), pk : ``A_s, n_s, alpha_s, beta_s, k_pivot``;
+    floats or arrays of shape (ncosmo,).
+
+    Returns a torch tensor on the device of shape (ncosmo,) (if batched) + ((nz,) if z is given) + (nk,), k fastest.
+    """
+    torch = dv.torch()
+    bg, pk = dict(bg or {}), dict(pk or {})
+    if Omega_m is not None:
+        bg['Omega_cdm'] = Omega_m
+    device = dv.resolve_device(device, k, z, *bg.values(), *pk.values())
+    cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, BG_DEFAULTS, device)
+    cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, device)
+    if n1 is not None and n2 is not None and n1 != n2:
+        raise ValueError('parameter arrays must share one length, got {} and {}'.format(n1, n2))
+    batched = n1 is not None or n2 is not None
+    ncosmo = n1 or n2 or 1
+    tk = dv.to_device(k, device).reshape(-1)
+    nk = tk.numel()
+    with_z = z is not None and what == 'matter'
+    tz = dv.to_device(z, device).reshape(-1) if with_z else None
+    nz = tz.numel() if with_z else 0
+    out = torch.empty((ncosmo, max(nz, 1), nk), dtype=torch.float64, device=device)
+    lib = _lib.load()
+    for start in range(0, ncosmo, 32768):   # the kernel indexes cosmologies with gridDim.y
+        stop = min(ncosmo, start + 32768)
+        sub_bg, sub_pk = (_lib.cp_param * len(_lib.BG_PARAMS))(), (_lib.cp_param * len(_lib.PK_PARAMS))()
+        for src, dst in ((cbg, sub_bg), (cpk, sub_pk)):
+            for i in range(len(dst)):
+                dst[i].ptr = (src[i].ptr + 8 * start) if src[i].ptr else None
+                dst[i].value = src[i].value
+        _lib.check(lib.cp_power_eval(_lib.ENGINES[engine], _lib.PK_WHAT[what], stop - start, dv.as_void_p(sub_bg), int(Omega_m is not None),
+                                     dv.as_void_p(sub_pk), nk, tk.data_ptr(), nz, tz.data_ptr() if with_z else None,
+                                     out[start:stop].data_ptr(), device.index, dv.stream_of(device)))
+    shape = ((ncosmo,) if batched else ()) + ((nz,) if with_z else ()) + (nk,)
+    return out.reshape(shape)
+
+
+def eh_scalars(bg=None, Omega_m=None, device=None):
+    """dict of the EH / no-wiggle / BBKS fit coefficients (reference eisenstein_hu.py:34-92), torch tensors of shape (ncosmo,) or ()."""
+    torch = dv.torch()
+    bg = dict(bg or {})
+    if Omega_m is not None:
+        bg['Omega_cdm'] = Omega_m
+    device = dv.resolve_device(device, *bg.values())
+    cbg, n, keep = dv.pack_params(_lib.BG_PARAMS, bg, BG_DEFAULTS, device)
+    ncosmo = n or 1
+    out = torch.empty((ncosmo, len(_lib.EH_SCALARS)), dtype=torch.float64, device=device)
+    _lib.check(_lib.load().cp_eh_scalars(ncosmo, dv.as_void_p(cbg), int(Omega_m is not None), out.data_ptr(), device.index, dv.stream_of(device)))
+    return {name: (out[:, i] if n is not None else out[0, i]) for i, name in enumerate(_lib.EH_SCALARS)}

@@ -1,0 +1,76 @@
+"""
+Cubic splines (and any fixed linear map) from fixed knots to fixed query points, applied on the GPU to batches of rows
+(``cp_spline_*`` / ``cp_linop_*``).  The operator is built once per (knots, queries, boundary condition) on the host.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import _device as dv
+
+
+class LinearOperator(object):
+
+    """out[..., q] = post(scale * sum_j W[q, j] y[..., j]) with W banded; owns a ``cp_spline_plan``."""
+
+    def __init__(self, handle, n, nq, device):
+        self._handle, self.n, self.nq, self.device = handle, n, nq, device
+
+    @classmethod
+    def spline(cls, x, xq, bc='natural', nu=0, extrapolate=False, device=None):
+        """Cubic spline through knots ``x`` evaluated (derivative order ``nu``) at ``xq``; bc in 'natural', 'clamped', 'not-a-knot'."""
+        device = dv.resolve_device(device)
+        x = np.ascontiguousarray(x, dtype='f8').ravel()
+        xq = np.ascontiguousarray(xq, dtype='f8').ravel()
+        handle = ctypes.c_void_p()
+        _lib.check(_lib.load().cp_spline_plan_create(ctypes.byref(handle), x.size, _lib.as_double_p(x), xq.size, _lib.as_double_p(xq),
+                                                     _lib.SPLINE_BC[bc], int(nu), int(bool(extrapolate)), device.index))
+        return cls(handle, x.size, xq.size, device)
+
+    @classmethod
+    def dense(cls, w, device=None):
+        """Any dense (nq, n) operator (e.g. quadrature weights)."""
+        device = dv.resolve_device(device)
+        w = np.ascontiguousarray(w, dtype='f8')
+        handle = ctypes.c_void_p()
+        _lib.check(_lib.load().cp_linop_plan_create(ctypes.byref(handle), w.shape[1], w.shape[0], _lib.as_double_p(w), device.index))
+        return cls(handle, w.shape[1], w.shape[0], device)
+
+    @property
+    def bandwidth(self):
+        bw = ctypes.c_int()
+        _lib.check(_lib.load().cp_spline_plan_info(self._handle, None, None, ctypes.byref(bw)))
+        return bw.value
+
+    def __call__(self, y, sqrt=False, scale=1.):
+        """y : torch tensor (..., n) on the operator's device -> (..., nq)."""
+        torch = dv.torch()
+        y = dv.to_device(y, self.device)
+        if y.shape[-1] != self.n:
+            raise ValueError('last dimension must be {:d}, got {}'.format(self.n, tuple(y.shape)))
+        lead = tuple(y.shape[:-1])
+        nrows = int(np.prod(lead, dtype=np.int64))
+        out = torch.empty(lead + (self.nq,), dtype=torch.float64, device=self.device)
+        if nrows:
+            _lib.check(_lib.load().cp_spline_apply(self._handle, y.data_ptr(), out.data_ptr(), nrows, int(bool(sqrt)), float(scale),
+                                                   dv.stream_of(self.device)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.load().cp_spline_plan_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+def dense_operator(x, xq, bc='natural', nu=0, extrapolate=False):
+    """The dense (nq, n) spline operator on the host (numpy); rows of out-of-range queries are NaN unless ``extrapolate``."""
+    x = np.ascontiguousarray(x, dtype='f8').ravel()
+    xq = np.ascontiguousarray(xq, dtype='f8').ravel()
+    w = np.empty((xq.size, x.size))
+    _lib.check(_lib.load().cp_spline_operator(x.size, _lib.as_double_p(x), xq.size, _lib.as_double_p(xq), _lib.SPLINE_BC[bc], int(nu),
+                                              int(bool(extrapolate)), _lib.as_double_p(w), None))
+    return w

@@ -84,7 +84,12 @@ enum cp_bg_kind {
     CP_BG_ANGULAR_DIAMETER = 2,    /* angular_diameter_distance     cosmology.py:1855 */
     CP_BG_LUMINOSITY = 3,          /* luminosity_distance           cosmology.py:1904 */
     CP_BG_EFUNC = 4,               /* efunc                         cosmology.py:1751 */
-    CP_BG_HUBBLE = 5               /* hubble_function               cosmology.py:1756 */
+    CP_BG_HUBBLE = 5,              /* hubble_function               cosmology.py:1756 */
+    CP_BG_GROWTH_CPT = 6,          /* un-normalised CPT92 growth(z) of the analytic engines, eisenstein_hu.py:134-136 */
+    CP_BG_GROWTH_RATE = 7,         /* growth_rate of the analytic engines, eisenstein_hu.py:143-152 */
+    CP_BG_RHO_CRIT = 8,            /* rho_crit(z), 1e10 Msun/h / (Mpc/h)^3   cosmology.py:1738-1749 */
+    CP_BG_OMEGA_M_Z = 9,           /* Omega_m(z)                    cosmology.py:1796 */
+    CP_BG_OMEGA_DE_Z = 10          /* Omega_de(z)                   cosmology.py:1850 */
 };
 /* a per-cosmology parameter: device array of ncosmo doubles, or (ptr == NULL) one value for all cosmologies */
 typedef struct cp_param {
@@ -97,6 +102,50 @@ int cp_background_distance(long long ncosmo, long long nz, const cp_param* param
                            double* d_out, int kind, int device, void* stream);
 /* the 119 interpolation knots (host), get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949 */
 int cp_background_knots(double* zc_out, int n);
+
+/* ---- analytic matter power spectra for batches of cosmologies (replaces Transfer.transfer_k, Primordial.pk_k and the
+ *      pk_callable x growth_factor_sq of Fourier.pk_interpolator in eisenstein_hu.py:189-215, 241-283, 315-324,
+ *      eisenstein_hu_nowiggle.py:34-51, bbks.py:50-64, with the per-cosmology fit coefficients of eisenstein_hu.py:34-92) ---- */
+enum cp_engine { CP_ENGINE_EH = 0, CP_ENGINE_EH_NOWIGGLE = 1, CP_ENGINE_BBKS = 2 };
+enum cp_pk_what {
+    CP_PK_MATTER = 0,    /* P(k, z) = T^2 x potential_to_density x curvature_to_potential x P_R x growth(z)^2 ; nz = 0: without growth */
+    CP_PK_TRANSFER = 1,  /* transfer_k */
+    CP_PK_PRIMORDIAL = 2 /* Primordial.pk_k */
+};
+enum cp_pk_param { CP_PK_A_S = 0, CP_PK_N_S = 1, CP_PK_ALPHA_S = 2, CP_PK_BETA_S = 3, CP_PK_K_PIVOT = 4 /* 1/Mpc */, CP_PK_NPARAMS = 5 };
+/* bg_params: the CP_BG_NPARAMS background parameters (cp_bg_param); pk_params: CP_PK_NPARAMS primordial parameters.
+ * d_k : (nk) wavenumbers in h/Mpc shared by the batch; d_z : (nz) redshifts shared by the batch (CP_PK_MATTER only).
+ * d_out : (ncosmo, max(nz, 1), nk), k fastest, (Mpc/h)^3. */
+int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
+                  long long nk, const double* d_k, long long nz, const double* d_z, double* d_out, int device, void* stream);
+enum cp_eh_scalar {
+    CP_EH_RS_DRAG = 0 /* Mpc */, CP_EH_Z_DRAG = 1, CP_EH_Z_EQ = 2, CP_EH_K_EQ = 3, CP_EH_R_DRAG = 4, CP_EH_R_EQ = 5, CP_EH_K_SILK = 6,
+    CP_EH_ALPHA_C = 7, CP_EH_BETA_C = 8, CP_EH_ALPHA_B = 9, CP_EH_BETA_NODE = 10, CP_EH_BETA_B = 11, CP_EH_ALPHA_GAMMA = 12,
+    CP_EH_BBKS_GAMMA = 13, CP_EH_NSCALARS = 14
+};
+/* d_out : (ncosmo, CP_EH_NSCALARS) fit coefficients of eisenstein_hu.py:34-92, eisenstein_hu_nowiggle.py:21, bbks.py:38 */
+int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, double* d_out, int device, void* stream);
+
+/* ---- cubic splines from fixed knots to fixed queries, applied to batches of rows as a banded linear operator
+ *      (replaces scipy.interpolate.CubicSpline / RectBivariateSpline where the grids are shared by the batch:
+ *      Interpolator1D jax.py:169-175 as used by integrate_sigma_r2, interpolator.py:285-289; Interpolator2D jax.py:241-271;
+ *      the clamped second-derivative splines of wallish2018, bao_filter.py:377-382) ---- */
+enum cp_spline_bc { CP_SPLINE_NATURAL = 0 /* y'' = 0 */, CP_SPLINE_CLAMPED = 1 /* y' = 0 */, CP_SPLINE_NOT_A_KNOT = 2 /* scipy default, == FITPACK s=0 */ };
+enum cp_spline_post { CP_SPLINE_POST_NONE = 0, CP_SPLINE_POST_SQRT = 1 };
+typedef struct cp_spline_plan cp_spline_plan;
+/* x : n strictly increasing knots (host), xq : nq query points (host), nu : derivative order 0..2;
+ * extrapolate = 0: queries outside [x[0], x[n-1]] give NaN (Interpolator1D, jax.py:200). */
+int cp_spline_plan_create(cp_spline_plan** plan, int n, const double* x, int nq, const double* xq, int bc, int nu, int extrapolate, int device);
+/* d_out[row, q] = post_op(scale * sum_j W[q, j] d_y[row, j]);  d_y : (nrows, n), d_out : (nrows, nq), device, row-major */
+int cp_spline_apply(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nrows, int post_op, double scale, void* stream);
+/* the same machinery for any fixed linear map of rows given densely (w_dense : nq x n row-major, host; a row starting with NaN
+ * marks a query that evaluates to NaN): the composite-Simpson weights of integrate_sigma_r2 / integrate_sigma_d2 method 'simpson'
+ * (interpolator.py:190-196, 280-284 with jax.py:365-507) are applied this way */
+int cp_linop_plan_create(cp_spline_plan** plan, int n, int nq, const double* w_dense, int device);
+int cp_spline_plan_destroy(cp_spline_plan* plan);
+int cp_spline_plan_info(const cp_spline_plan* plan, int* n, int* nq, int* bandwidth);
+/* the dense operator W (nq x n, row-major, host) and per-query inside-range flags: what the plan is built from */
+int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc, int nu, int extrapolate, double* w_out, int* inside_out);
 
 #ifdef __cplusplus
 }
