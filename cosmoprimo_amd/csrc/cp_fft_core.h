@@ -42,6 +42,47 @@ struct cplx {
     double re, im;
 };
 
+// ---- global-memory access through buffer instructions -----------------------------------------------------------
+// base is wave-uniform (a kernel argument or a per-pair row pointer, i.e. SGPRs), `voff` the per-lane byte offset and
+// `soff` a uniform byte offset: one `buffer_load_dwordx4 v, voff, s[rsrc], soff offen` with NO per-access 64-bit VALU
+// address arithmetic (the plain-pointer form costs 2-4 integer VALU instructions per access on a VALU-bound kernel).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef int cp_v4i __attribute__((ext_vector_type(4)));
+typedef int cp_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cp_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ cplx ld_cplx(const void* base, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(cplx, __builtin_amdgcn_raw_buffer_load_b128(cp_rsrc(base), (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ double ld_f64(const void* base, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cp_rsrc(base), (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void st_f64(void* base, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_v2i, v), cp_rsrc(base), (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ void st_cplx(void* base, unsigned voff, unsigned soff, cplx v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cp_v4i, v), cp_rsrc(base), (int)voff, (int)soff, 0);
+}
+// value of the neighbouring lane (lane ^ 1): a DPP quad permute, no LDS
+__device__ __forceinline__ double lane_swap1(double v) {
+    cp_v2i w = __builtin_bit_cast(cp_v2i, v);
+    w.x = __builtin_amdgcn_mov_dpp(w.x, 0xB1, 0xF, 0xF, true);  // quad_perm:[1,0,3,2]
+    w.y = __builtin_amdgcn_mov_dpp(w.y, 0xB1, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, w);
+}
+#else
+inline cplx ld_cplx(const void* base, unsigned voff, unsigned soff) {
+    return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + voff + soff);
+}
+inline double ld_f64(const void* base, unsigned voff, unsigned soff) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + voff + soff);
+}
+inline void st_f64(void* base, unsigned voff, unsigned soff, double v) {
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + voff + soff) = v;
+}
+#endif
+
 CP_HD cplx cmul(const cplx a, const cplx b) {
     cplx r;
     r.re = a.re * b.re - a.im * b.im;
@@ -258,26 +299,54 @@ struct Pass {
     }
     static CP_HD int joff(int t, int i) { return (t + T * i) % M; }
 
+    // Byte offset of the swizzled slot of element (t, i, r).  The radix-16 shapes reduce to ONE integer instruction per
+    // access (or none): the swizzle XORs bits 4..7 of the slot index into bits 0..3, and
+    //   M % 256 == 0 : bits 4..7 come from j only           -> base(t, i) + r * 16 M        (an immediate offset)
+    //   M == R == 16 : bits 4..7 of the slot are r          -> base(t, i) ^ (r * 0x110)
+    //   M == 1, R 16 : bits 4..7 are beta & 15              -> base(t, i) ^ (r * 16)
+    static CP_HD unsigned lds_base(int t, int i) {
+        const unsigned beta = (unsigned)(t + T * i);
+        if (NP >= 256 && M % 256 == 0) {
+            const unsigned b = beta / M, j = beta % M;
+            return (b * L + (j ^ ((j >> 4) & 15u))) * 16u;
+        } else if (NP >= 256 && M == 16 && R == 16) {
+            const unsigned b = beta / M, j = beta % M;
+            return b * (L * 16u) + j * 16u;
+        } else if (NP >= 256 && M == 1 && R == 16) {
+            return beta * 256u + (beta & 15u) * 16u;
+        }
+        return 0u;
+    }
+    static CP_HD unsigned lds_off(int t, int i, int r, unsigned base) {
+        if (NP >= 256 && M % 256 == 0) return base + (unsigned)r * (M * 16u);
+        if (NP >= 256 && M == 16 && R == 16) return base ^ ((unsigned)r * 0x110u);
+        if (NP >= 256 && M == 1 && R == 16) return base ^ ((unsigned)r * 16u);
+        return (unsigned)swz<NP>(elem(t, i, r)) * 16u;
+    }
     static CP_HD void load_lds(int t, const cplx* lds, cplx* x) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i) {
+            const unsigned base = lds_base(t, i);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (CP_ABLATE & 1) x[i * R + r] = cplx{1e-3 * t + r, 1. + i};
-                else x[i * R + r] = lds[swz<NP>(elem(t, i, r))];
+                else x[i * R + r] = *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(lds) + lds_off(t, i, r, base));
             }
+        }
     }
     static CP_HD void store_lds(int t, cplx* lds, const cplx* x) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
+        for (int i = 0; i < NB; ++i) {
+            const unsigned base = lds_base(t, i);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (CP_ABLATE & 1) {
                     if (x[i * R + r].re == 1.2345e301) lds[t] = x[i * R + r];  // keeps x alive, never taken
                 } else {
-                    lds[swz<NP>(elem(t, i, r))] = x[i * R + r];
+                    *reinterpret_cast<cplx*>(reinterpret_cast<char*>(lds) + lds_off(t, i, r, base)) = x[i * R + r];
                 }
             }
+        }
     }
     static CP_HD void twiddle(int t, const cplx* tw, cplx* x) {
         if (M == 1) return;
@@ -298,7 +367,7 @@ struct Pass {
 #pragma unroll
             for (int s = 1; s < R; ++s) {
                 if (CP_ABLATE & 4) w[i * R + s] = cplx{1. + 1e-9 * t, 0.5 + s};
-                else w[i * R + s] = tw[s * M + j];
+                else w[i * R + s] = ld_cplx(tw, (unsigned)j * 16u, (unsigned)(s * M) * 16u);
             }
         }
     }

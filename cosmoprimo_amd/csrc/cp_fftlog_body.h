@@ -85,14 +85,33 @@ struct Fftlog {
     // HALF front end, split in two so the HBM loads of the NEXT pair are issued a whole pair ahead
     // (prefetch registers va / vb live across the phases): issue ...
     static CP_HD void prefetch_rows(int t, const double* __restrict__ ra, const double* __restrict__ rb, double* va, double* vb) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CP_NO_WIDE_IO)
+        // 16-byte accesses: the even lane of each pair loads (a[n], a[n+1]) from row a, the odd lane (b[n], b[n+1]) from row b
+        // (n = the even lane's sample), then they trade one double through a DPP lane swap so that every lane holds its own
+        // (a[n], b[n]).  Halves the vector-memory instructions; 8-byte-per-lane accesses issue at about half the rate.
+        if (T >= 2 && !(CP_ABLATE & 8)) {
+            // The trade itself is done when the rows are consumed (unpack_rows, phase 0 of the next pair): any ALU work on
+            // the loaded registers here would make this phase wait for the HBM round trip.
+            const bool odd = t & 1;
+            const long long drow = reinterpret_cast<const char*>(rb) - reinterpret_cast<const char*>(ra);
+            const unsigned voff = (unsigned)(t & ~1) * 8u + (odd ? (unsigned)drow : 0u);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const cplx v = ld_cplx(ra, voff, (unsigned)(T * r) * 8u);  // (lo, hi) = samples n, n + 1 of this lane's row
+                va[r] = v.re;
+                vb[r] = v.im;
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             if (CP_ABLATE & 8) {
                 va[r] = 1e-3 * t + r;
                 vb[r] = 2e-3 * t - r;
             } else {
-                va[r] = ra[t + T * r];
-                vb[r] = rb[t + T * r];
+                va[r] = ld_f64(ra, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
+                vb[r] = ld_f64(rb, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
             }
         }
     }
@@ -103,8 +122,17 @@ struct Fftlog {
                                       const double* __restrict__ pre, const ST& st, cplx* x) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            x[r + 4].re = st.va[r] * st.fpre[r];
-            x[r + 4].im = has_b ? st.vb[r] * st.fpre[r] : 0.;
+            double a = st.va[r], b = st.vb[r];
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CP_NO_WIDE_IO)
+            if (T >= 2 && !(CP_ABLATE & 8)) {  // (va, vb) hold (row[n], row[n+1]) of this lane's row: trade with the neighbour lane
+                const bool odd = t & 1;
+                const double recv = lane_swap1(odd ? a : b);
+                a = odd ? recv : st.va[r];
+                b = odd ? st.vb[r] : recv;
+            }
+#endif
+            x[r + 4].re = a * st.fpre[r];
+            x[r + 4].im = has_b ? b * st.fpre[r] : 0.;
         }
         if constexpr (IN_MODE == IN_HALF) {
             const double la = A.ext_l == CP_EXTRAP_CONST ? A.val_l : ra[0];
@@ -161,11 +189,32 @@ struct Fftlog {
             if (acc == 1.2345e301) oa[t] = acc;  // keeps the results alive, never taken
             return;
         }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CP_NO_WIDE_IO)
+        if (T >= 2) {
+            // 16-byte stores, mirror image of prefetch_rows: even lanes write (g_a[n], g_a[n+1]) to row a, odd lanes
+            // (g_b[n], g_b[n+1]) to row b
+            const bool odd = t & 1;
+            const long long drow = reinterpret_cast<char*>(ob) - reinterpret_cast<char*>(oa);
+            const unsigned voff = (unsigned)(t & ~1) * 8u + (odd ? (unsigned)drow : 0u);
+            cplx v[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) oa[t + T * s] = ya[s];
+            for (int s = 0; s < 8; ++s) {
+                const double recv = lane_swap1(odd ? ya[s] : yb[s]);
+                v[s].re = odd ? recv : ya[s];
+                v[s].im = odd ? yb[s] : recv;
+            }
+            if (has_b || !odd) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) st_cplx(oa, voff, (unsigned)(T * s) * 8u, v[s]);
+            }
+            return;
+        }
+#endif
+#pragma unroll
+        for (int s = 0; s < 8; ++s) st_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
         if (has_b) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) ob[t + T * s] = yb[s];
+            for (int s = 0; s < 8; ++s) st_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
         }
     }
 
@@ -211,7 +260,7 @@ struct Fftlog {
 #pragma unroll
         for (int e = 0; e < P; ++e) {
             if (CP_ABLATE & 4) w[e] = cplx{1. + 1e-9 * t, 0.5 + e};
-            else w[e] = u[e * T + t];
+            else w[e] = ld_cplx(u, (unsigned)t * 16u, (unsigned)(e * T) * 16u);
         }
     }
 
@@ -220,8 +269,8 @@ struct Fftlog {
         const double* __restrict__ post = A.post + (long long)ker * NP;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            st.fpre[r] = pre[t + T * (r + 4)];
-            st.fpost[r] = post[t + T * (r + 4)];
+            st.fpre[r] = ld_f64(pre, (unsigned)t * 8u, (unsigned)(T * (r + 4)) * 8u);
+            st.fpost[r] = ld_f64(post, (unsigned)t * 8u, (unsigned)(T * (r + 4)) * 8u);
         }
     }
 
@@ -284,6 +333,12 @@ struct Fftlog {
         } else if constexpr (PH == 0) {
             if constexpr (HALF_IN) {
                 load_input_half(t, A, ra, rb, has_b, pre, st, x);
+                // The NEXT pair's rows are requested right here, as soon as the prefetch registers are free: a whole pair
+                // before they are consumed, ahead of every other memory operation of this pair (vmcnt retires in order, so
+                // the U / twiddle waits of phases 2 and 4 also retire them) and never behind this pair's stores.
+                CP_SCHED_FENCE();
+                prefetch_rows(t, nra, nrb, st.va, st.vb);
+                CP_SCHED_FENCE();
             } else {
                 load_input(t, A, ra, rb, has_b, pre, x);
             }
@@ -318,14 +373,8 @@ struct Fftlog {
             load_tables_for<PH + 1>(t, A, ker, st.w);
         } else {
             Pass<NP, P, 0>::load_lds(t, lds, x);
-            // Memory-operation order matters because vmcnt retires in order: the NEXT pair's rows (consumed a whole
-            // pair later, never waited for here) are issued before this pair's stores, and nothing is loaded after
-            // the stores (w keeps the pass-0 twiddles for the next pair's phase 0).
-            if constexpr (HALF_IN) {
-                CP_SCHED_FENCE();
-                prefetch_rows(t, nra, nrb, st.va, st.vb);
-                CP_SCHED_FENCE();
-            }
+            // Nothing is loaded after this pair's stores (w keeps the pass-0 twiddles for the next pair's phase 0), so the
+            // stores stay in flight while the next pair starts.
             Pass<NP, P, 0>::twiddle_apply(st.w, x);
             Pass<NP, P, 0>::butterflies(x);
             if constexpr (HALF_IN && OUT_MODE == OUT_HALF) {

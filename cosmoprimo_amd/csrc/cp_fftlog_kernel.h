@@ -118,6 +118,10 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
         F::fill_lds_tables(t, A, lds);
         __syncthreads();
     }
+    // Drain the one-off loads here.  Otherwise the compiler's wait-count merge at the loop head must also cover this
+    // entry path (where the row prefetch is the YOUNGEST operation) and emits vmcnt(0) at the top of every pair, which
+    // makes each pair wait for the previous pair's stores to be acknowledged by memory.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
 #if defined(CP_STAMPS)
     unsigned long long cp_stamp_acc[2 * F::NPH] = {0};
     const unsigned long long cp_t_begin = cp_stamp();
