@@ -1,0 +1,122 @@
+"""Oracle: numpy/scipy restatement of cosmoprimo's wallish2018 and brieden2022 BAO filters (TEST INFRASTRUCTURE ONLY).
+
+Follows /root/reference/cosmoprimo/bao_filter.py: base class set_k / set_pk (:81-102), Wallish2018 _compute / _tophat
+(:361-431), Brieden2022 _prepare / _interp / _compute (:461-509), and utils.LeastSquareSolver (utils.py:144-272).
+Inputs are callables pk(k) -> (nk, ncol) so that the oracle is independent of the interpolator classes.
+
+Parity status: PINNED by tests/golden/bao.npz (G6).
+"""
+import numpy as np
+from scipy import fftpack, interpolate, signal
+
+
+def filter_k(extrap_kmin=1e-7, extrap_kmax=1e2, nk=1024):
+    return np.geomspace(extrap_kmin, extrap_kmax, nk)      # bao_filter.py:81-90
+
+
+def _tophat(k, kmax=1, scale=1):
+    tophat = np.ones_like(k)
+    mask = k > kmax
+    tophat[mask] *= np.exp(-scale**2 * (k[mask] / kmax - 1.)**2)   # :426-431
+    return tophat
+
+
+def wallish2018(pk, extrap_kmin=1e-7, extrap_kmax=1e2, nk=1024, return_intermediates=False):
+    """pk : callable k -> (len(k), ncol).  Returns pknow (nk, ncol) on filter_k (bao_filter.py:361-424)."""
+    kf = filter_k(extrap_kmin, extrap_kmax, nk)
+    pkf = pk(kf)
+    k = np.linspace(extrap_kmin, 2., 4096)
+    p = pk(k)
+    kpk = np.log(k[:, None] * p)
+    kpkffted = fftpack.dst(kpk, type=2, axis=0, norm='ortho')
+    even, odd = kpkffted[::2].copy(), kpkffted[1::2].copy()
+    xeven, xodd = 1 + np.arange(even.shape[0]), 1 + np.arange(odd.shape[0])
+    dd_even = interpolate.CubicSpline(xeven, even, axis=0, bc_type='clamped', extrapolate=False)(xeven, nu=2)
+    dd_odd = interpolate.CubicSpline(xodd, odd, axis=0, bc_type='clamped', extrapolate=False)(xodd, nu=2)
+    margin_first, margin_second, offset = 20, 5, (-10, 20)
+    boxes = []
+
+    def smooth(y, dd, x):
+        argmax = dd[margin_first:-margin_first].argmax() + margin_first
+        ibox = (argmax + offset[0], argmax + margin_second + dd[argmax + margin_second:-margin_first].argmax() + offset[1])
+        mask = np.ones_like(y, dtype=np.bool_)
+        mask[ibox[0]:ibox[1] + 1] = False
+        boxes.append(ibox)
+        spline = interpolate.CubicSpline(x[mask], y[mask] * x[mask]**2, axis=-1, bc_type='clamped', extrapolate=False)
+        return spline(x) / x**2
+
+    for iz in range(p.shape[-1]):
+        even[:, iz] = smooth(even[:, iz], dd_even[:, iz], xeven)
+        odd[:, iz] = smooth(odd[:, iz], dd_odd[:, iz], xodd)
+    merged = np.empty_like(kpkffted)
+    merged[::2], merged[1::2] = even, odd
+    kpknow = fftpack.idst(merged, type=2, axis=0, norm='ortho')
+    pknow = np.exp(kpknow) / k[..., None]
+    mask = (k > 1e-2) & (k < 1.5)
+    mask_left, mask_right = kf < 5e-4, kf > 2.
+    kk = np.concatenate([kf[mask_left], k[mask], kf[mask_right]], axis=0)
+    pp = np.concatenate([pkf[mask_left], pknow[mask], pkf[mask_right]], axis=0)
+    pknow = interpolate.CubicSpline(kk, pp, axis=0, bc_type='clamped', extrapolate=False)(kf)
+    wiggles = (pkf / pknow - 1.) * _tophat(kf, kmax=1., scale=20.)[..., None] + 1.
+    out = pkf / wiggles
+    if return_intermediates:
+        return out, dict(dd_even=dd_even, dd_odd=dd_odd, even_now=even, odd_now=odd, boxes=boxes, kpkffted=kpkffted)
+    return out
+
+
+def least_squares_constrained(gradient, precision, constraint_gradient, delta, constraint):
+    """LeastSquareSolver(gradient, precision (1D), constraint_gradient, compute_inverse=False)(delta, constraint) -> model (utils.py:161-272)."""
+    hv = gradient * precision
+    invfisher = hv.dot(gradient.T)
+    nc = constraint_gradient.shape[-1]
+    invfisher = np.block([[invfisher, -constraint_gradient], [constraint_gradient.T, np.zeros((nc, nc))]])
+    hv = np.block([[hv, np.zeros(constraint_gradient.shape)], [np.zeros((nc, gradient.shape[-1])), np.eye(nc)]])
+    d = np.concatenate([delta, np.atleast_1d(constraint)], axis=-1)
+    params = np.linalg.solve(invfisher, hv.dot(d.T)).T[..., :gradient.shape[0]]
+    return params.dot(gradient)
+
+
+def _interp_envelopes(ixh, ixl, x, y, kind=2):
+    toret = 0.
+    for ix in [ixh, ixl]:
+        toret = toret + interpolate.interp1d(x[ix], y[ix], kind=kind, axis=0, fill_value='extrapolate', assume_sorted=True)(x)   # :483-488
+    return toret / 2.
+
+
+def brieden2022_prepare(pk_fid, pknow_fid, extrap_kmin=1e-7, extrap_kmax=1e2, nk=1024):
+    """pk_fid, pknow_fid : callables k -> (nk,) of the fiducial cosmology (its engine / its EH no-wiggle engine), z = 0 (bao_filter.py:461-480)."""
+    kf = filter_k(extrap_kmin, extrap_kmax, nk)
+    kmask_fid = (kf >= 1e-3) & (kf <= 1.)
+    k_fid = kf[kmask_fid]
+    ratio = pk_fid(k_fid) / pknow_fid(k_fid)
+    gradient = np.array([k_fid**(i - 1) for i in range(4)])
+    cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+    model = least_squares_constrained(gradient, k_fid**2, cg, ratio, [ratio[..., 0], ratio[..., 1] - ratio[..., 0], ratio[..., -1], ratio[..., -2] - ratio[..., -1]])
+    pknow_correction = model[:, None]
+    ratio_fid = ratio[:, None] / pknow_correction
+    ik0 = np.searchsorted(k_fid, 0.02, side='right') + 1
+    peaks = []
+    for si in [1., -1.]:
+        ix = signal.find_peaks(si * ratio_fid[ik0:, 0])[0] + ik0
+        ix = np.concatenate([[0]] * int(ix[0] > 0) + [ix] + [[-1]] * int(ix[-1] < k_fid.size - 1), axis=0)
+        peaks.append(ix)
+    ratio_now_fid = _interp_envelopes(*peaks, k_fid, ratio_fid)
+    return dict(kmask_fid=kmask_fid, k_fid=k_fid, pknow_correction=pknow_correction, ratio_fid=ratio_fid, peaks=peaks, ratio_now_fid=ratio_now_fid)
+
+
+def brieden2022_compute(prep, pk, pknow_cosmo, rescale, clone_eval, extrap_kmin=1e-7, extrap_kmax=1e2, nk=1024):
+    """
+    pk : callable k -> (nk, ncol) input spectrum; pknow_cosmo : callable k -> (nk,) EH no-wiggle P(k, z=0) of `cosmo`;
+    rescale = rs_drag(cosmo) / rs_drag(cosmo_fid); clone_eval(k_knots, pk_knots, k_eval) -> the input interpolator cloned on
+    (k_knots, pk_knots) and evaluated at k_eval (bao_filter.py:490-509).
+    """
+    kf = filter_k(extrap_kmin, extrap_kmax, nk)
+    k_fid = prep['k_fid']
+    p = pk(k_fid / rescale)
+    p = p.reshape(p.shape[0], -1)
+    pknow = pknow_cosmo(k_fid * rescale)[:, None] * prep['pknow_correction']
+    ratio = p / pknow / prep['ratio_fid']
+    pknow = _interp_envelopes(*prep['peaks'], k_fid, ratio) * pknow * prep['ratio_now_fid']
+    out = pk(kf).reshape(kf.size, -1).copy()
+    out[prep['kmask_fid']] = clone_eval(k_fid / rescale, pknow, k_fid).reshape(k_fid.size, -1)
+    return out

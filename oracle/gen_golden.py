@@ -257,6 +257,52 @@ def gen_sigma(cp):
     save('sigma', **out)
 
 
+BAO_PARAMS = [dict(), dict(Omega_m=0.27, Omega_b=0.045, h=0.72, n_s=0.95), dict(Omega_m=0.36, Omega_b=0.055, h=0.64, n_s=0.98, sigma8=0.85),
+              dict(Omega_m=0.31, Omega_b=0.049, h=0.6766, n_s=0.9665, sigma8=0.81)]
+
+
+def gen_bao(cp):
+    """G6: wallish2018 and brieden2022 on the EH98 P(k) of 4 cosmologies (1D callable input), a 4-column tabulated 2D input,
+    wallish intermediates and brieden _prepare products."""
+    import warnings
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fid = cp.Cosmology(engine='eisenstein_hu')
+        for i, par in enumerate(BAO_PARAMS):
+            cosmo = cp.Cosmology(engine='eisenstein_hu', **par)
+            interp = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+            w = cp.PowerSpectrumBAOFilter(interp, engine='wallish2018', cosmo=cosmo, cosmo_fid=fid)
+            out['c%d_wallish_pknow' % i] = w.pknow
+            out['c%d_pk' % i] = w.pk
+            if i == 0:
+                out['k'] = w.k
+                for name in ['_even', '_odd', '_dd_even', '_dd_odd', '_even_now', '_odd_now']:
+                    out['c0_wallish' + name] = getattr(w, name)
+            b = cp.PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid)
+            out['c%d_brieden_pknow' % i] = b.pknow
+            out['c%d_rs_drag_ratio' % i] = b.rs_drag_ratio()
+            if i == 0:
+                out['brieden_k_fid'] = b.k_fid
+                out['brieden_pknow_correction'] = b.pknow_correction
+                out['brieden_ratio_fid'] = b.ratio_fid
+                out['brieden_ratio_now_fid'] = b.ratio_now_fid
+                out['brieden_peaks_high'], out['brieden_peaks_low'] = [np.asarray(ix) for ix in b.ik_fid_peaks]
+            # no cosmo given: rs_drag_ratio = 1
+            if i == 1:
+                out['c1_brieden_pknow_nocosmo'] = cp.PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo_fid=fid).pknow
+                out['c1_wallish_pknow_nocosmo'] = cp.PowerSpectrumBAOFilter(interp, engine='wallish2018').pknow
+        # tabulated 2D input with 4 redshifts (columns differ)
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **BAO_PARAMS[3])
+        interp2 = cosmo.get_fourier().pk_interpolator()
+        kt, zt = np.logspace(-5, 1.5, 400), np.array([0., 0.5, 1., 1.5])
+        tab = cp.PowerSpectrumInterpolator2D(kt, zt, interp2(kt, zt))
+        out['tab_k'], out['tab_z'], out['tab_pk'] = kt, zt, interp2(kt, zt)
+        out['tab_wallish_pknow'] = cp.PowerSpectrumBAOFilter(tab, engine='wallish2018', cosmo=cosmo, cosmo_fid=fid).pknow
+        out['tab_brieden_pknow'] = cp.PowerSpectrumBAOFilter(tab, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid).pknow
+    save('bao', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -272,6 +318,8 @@ def main():
         gen_power(cp)
     if 'sigma' in which:
         gen_sigma(cp)
+    if 'bao' in which:
+        gen_bao(cp)
 
 
 if __name__ == '__main__':

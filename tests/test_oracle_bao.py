@@ -1,0 +1,78 @@
+"""Pin the BAO-filter oracle (oracle/bao.py) against golden vectors produced by the reference (G6)."""
+import numpy as np
+from scipy.interpolate import CubicSpline
+
+from oracle import background as ob, bao as obao, power as op, sigma as osg
+from oracle.gen_golden import BAO_PARAMS
+
+
+def eh_pk(par, engine='eisenstein_hu'):
+    """Normalised P(k, z=0) callable of an analytic engine for reference-style parameters (oracle power + sigma pipeline)."""
+    par = dict(par)
+    h, Ob = par.get('h', 0.7), par.get('Omega_b', 0.05)
+    Ocdm = par['Omega_m'] - Ob if 'Omega_m' in par else 0.25
+    s8, ns = par.get('sigma8', 0.8), par.get('n_s', 0.96)
+    p = ob.derived(h=h, Omega_cdm=Ocdm, Omega_b=Ob)
+    D0 = op.growth_factor(0., p, znorm=0.)
+
+    def raw(k):
+        return op.pk_z0(k, engine, h=h, Omega_cdm=Ocdm, Omega_b=Ob, sigma8=s8, n_s=ns) * D0**2
+
+    rs = s8 / np.sqrt(osg.sigma_r2(8., raw))
+    return (lambda k: np.where((k >= 1e-7) & (k <= 1e2), raw(k) * rs**2, np.nan)), op.eh_scalars(h, Ocdm, Ob)['rs_drag'] * h
+
+
+def pad_log_natural_eval(kk, pp, ke):
+    """PowerSpectrumInterpolator1D(kk, pp)(ke): _pad_log + natural cubic spline in log10-log10 (interpolator.py:42-87, 419-451; jax.py:172)."""
+    logk, logp = np.log10(kk), np.log10(pp)
+    lmin, lmax = np.log10(np.minimum(1e-7, kk[0] * (1 - 1e-9))), np.log10(np.maximum(1e2, kk[-1] * (1 + 1e-9)))
+    sl = (logp[-1] - logp[-2]) / (logk[-1] - logk[-2])
+    hk = np.array([logk[-1] * 0.1 + lmax * 0.9, lmax])
+    hp = np.array([logp[-1] + sl * (hk[0] - logk[-1]), logp[-1] + sl * (hk[1] - logk[-1])])
+    sl = (logp[1] - logp[0]) / (logk[1] - logk[0])
+    lk = np.array([lmin, logk[0] * 0.1 + lmin * 0.9])
+    lp = np.array([logp[0] + sl * (lk[0] - logk[0]), logp[0] + sl * (lk[1] - logk[0])])
+    x, y = np.concatenate([lk, logk, hk]), np.concatenate([lp, logp, hp])
+    return 10**CubicSpline(x, y, axis=0, bc_type='natural')(np.log10(ke))
+
+
+def test_wallish(golden):
+    g = golden('bao')
+    for i, par in enumerate(BAO_PARAMS):
+        pk, _ = eh_pk(par)
+        out, inter = obao.wallish2018(lambda k: pk(k)[:, None], return_intermediates=True)
+        np.testing.assert_allclose(out[:, 0], g['c%d_wallish_pknow' % i], rtol=1e-9)
+        if i == 0:
+            np.testing.assert_allclose(inter['even_now'], g['c0_wallish_even_now'], rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(inter['dd_odd'], g['c0_wallish_dd_odd'], rtol=1e-8, atol=1e-10)
+            print('boxes', inter['boxes'])
+
+
+def test_brieden(golden):
+    g = golden('bao')
+    pk_fid, rs_fid = eh_pk({})
+    pknow_fid, _ = eh_pk({}, 'eisenstein_hu_nowiggle')
+    prep = obao.brieden2022_prepare(pk_fid, pknow_fid)
+    np.testing.assert_allclose(prep['k_fid'], g['brieden_k_fid'], rtol=1e-15)
+    np.testing.assert_allclose(prep['pknow_correction'], g['brieden_pknow_correction'], rtol=1e-10)
+    np.testing.assert_allclose(prep['ratio_fid'], g['brieden_ratio_fid'], rtol=1e-10)
+    # The envelope knots come from find_peaks on ratio_fid, which the fit constraints pin to 1 +- 1 ulp at the last samples:
+    # the reference's list contains a rounding-noise "peak" at index 339 (ratio_fid[339] = 1, ratio_fid[340] = 1 - 2.2e-16).
+    # Any knot at >= 335 is therefore not reproducible; the physical knots must agree, and the reference list is used below.
+    def physical(ix):
+        return [i for i in ix if 0 < i < 335]
+    assert physical(prep['peaks'][0]) == physical(g['brieden_peaks_high']) and physical(prep['peaks'][1]) == physical(g['brieden_peaks_low'])
+    prep['peaks'] = [g['brieden_peaks_high'], g['brieden_peaks_low']]
+    prep['ratio_now_fid'] = obao._interp_envelopes(*prep['peaks'], prep['k_fid'], prep['ratio_fid'])
+    np.testing.assert_allclose(prep['ratio_now_fid'], g['brieden_ratio_now_fid'], rtol=1e-10)
+    for i, par in enumerate(BAO_PARAMS):
+        pk, rs = eh_pk(par)
+        pknow_c, _ = eh_pk(par, 'eisenstein_hu_nowiggle')
+        rescale = rs / rs_fid
+        np.testing.assert_allclose(rescale, g['c%d_rs_drag_ratio' % i], rtol=1e-13)
+
+        def clone_eval(kk, pp, ke):
+            return pad_log_natural_eval(kk, pp[:, 0], ke)
+
+        out = obao.brieden2022_compute(prep, lambda k: pk(k)[:, None], pknow_c, rescale, clone_eval)
+        np.testing.assert_allclose(out[:, 0], g['c%d_brieden_pknow' % i], rtol=1e-9)
