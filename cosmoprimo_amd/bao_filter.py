@@ -1,0 +1,339 @@
+"""
+BAO filters on MI355X: ``wallish2018`` and ``brieden2022`` behind the reference's registry / factory
+(cosmoprimo/bao_filter.py: metaclass registry :22-31, base class :34-169, Wallish2018 :345-431, Brieden2022 :434-509,
+factory :912-921).
+
+Data path (device, through the C ABI): the input interpolator evaluated as rows ``(ncol, nk)``; for wallish2018 the fused
+``log(k P)`` -> batched DST-II (``cp_dst``), clamped-spline second derivatives (``cp_spline`` operator), per-column peak box
+(arg-max reductions), gap spline (``cp_gap_spline``), batched DST-III with fused ``exp(.)/k``, final clamped splice as a
+fixed operator; for brieden2022 the envelope interpolation and the re-sampling are fixed operators applied to all columns.
+Host side (numpy, small, once per filter): grids, masks, the least-squares fit and the peak search of ``_prepare`` (341 samples
+of ONE fiducial cosmology), construction of the operators.
+"""
+import numpy as np
+
+from . import _lib
+from . import _device as dv
+from .cosmology import Cosmology, Fourier
+from .dst import DST
+from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D
+from .spline import LinearOperator
+
+
+class RegisteredPowerSpectrumBAOFilter(type):
+
+    """Metaclass registering :class:`BasePowerSpectrumBAOFilter`-derived classes by ``name`` (reference bao_filter.py:22-31)."""
+    _registry = {}
+
+    def __new__(meta, name, bases, class_dict):
+        cls = super().__new__(meta, name, bases, class_dict)
+        meta._registry[cls.name] = cls
+        return cls
+
+
+class BasePowerSpectrumBAOFilter(object, metaclass=RegisteredPowerSpectrumBAOFilter):
+
+    """Base BAO filter for power spectrum (reference bao_filter.py:34-169)."""
+    name = 'base'
+
+    def __init__(self, pk_interpolator, cosmo=None, cosmo_fid=None, **kwargs):
+        self._cosmo_fid = cosmo_fid
+        self._cosmo = cosmo
+        self.pk_interpolator = pk_interpolator
+        self.device = pk_interpolator.device
+        self.set_k(**kwargs)
+        self.set_pk(pk_interpolator, cosmo=cosmo)
+        self._prepare()
+        self._compute()
+        self._finalize()
+
+    def _prepare(self):
+        """Anything that can be done once."""
+
+    def set_k(self, nk=1024):
+        """Wavenumbers where the power spectrum is evaluated (reference bao_filter.py:81-90)."""
+        self.k = np.geomspace(self.pk_interpolator.extrap_kmin, self.pk_interpolator.extrap_kmax, nk)
+
+    def _rows(self, k):
+        """The input power spectrum at ``k`` as device rows (ncol, nk) + the reference output shape (nk, ...)."""
+        interp = self.pk_interpolator
+        if isinstance(interp, PowerSpectrumInterpolator2D):
+            rows = interp._rows_z(interp.z, ignore_growth=True)(np.asarray(k, dtype='f8'))      # (batch..., nz, nk)
+        else:
+            rows = interp._rows(np.asarray(k, dtype='f8'))                                       # (ncol, nk)
+        lead = tuple(rows.shape[:-1])
+        return rows.reshape(-1, rows.shape[-1]), lead
+
+    def set_pk(self, pk_interpolator, cosmo=None):
+        """Set input power spectrum to remove BAO wiggles from (reference bao_filter.py:92-102)."""
+        if cosmo is not None:
+            self._cosmo = cosmo
+        self.pk_interpolator = pk_interpolator
+        self._pk_rows, self._lead = self._rows(self.k)
+        if isinstance(pk_interpolator, PowerSpectrumInterpolator2D):
+            self.shape = (self.k.size,) + self._lead[-1:] if len(self._lead) == 1 else self._lead[:-1] + (self.k.size, self._lead[-1])
+        else:
+            cs = pk_interpolator._colshape()
+            self.shape = (self.k.size,) + cs
+
+    def _finalize(self):
+        """Device rows -> ``pk`` / ``pknow`` arrays of the reference's shape (k first, then columns)."""
+        def host(rows):
+            a = rows.cpu().numpy()
+            if isinstance(self.pk_interpolator, PowerSpectrumInterpolator2D) and len(self._lead) > 1:
+                return np.moveaxis(a.reshape(self._lead + (self.k.size,)), -1, -2)
+            return a.T.reshape(self.shape)
+        self.pk, self.pknow = host(self._pk_rows), host(self._pknow_rows)
+
+    def __call__(self, pk_interpolator, cosmo=None):
+        self.set_pk(pk_interpolator, cosmo=cosmo)
+        self._compute()
+        self._finalize()
+        return self
+
+    @property
+    def wiggles(self):
+        """Extracted wiggles."""
+        return self.pk / self.pknow
+
+    def smooth_pk_interpolator(self, **kwargs):
+        """Smooth (no-wiggle) power spectrum interpolator (reference bao_filter.py:115-129)."""
+        return self.pk_interpolator.clone(k=self.k, pk=self.pknow, **kwargs)
+
+    def smooth_xi_interpolator(self, **kwargs):
+        """Smooth correlation function through FFTLog (reference bao_filter.py:131-146): the ``to_xi`` output of the smooth interpolator."""
+        return self.smooth_pk_interpolator().to_xi(**kwargs)
+
+    @property
+    def cosmo(self):
+        """Cosmology."""
+        if self._cosmo is None:
+            self._cosmo = Cosmology(engine='eisenstein_hu', device=self.device)
+        return self._cosmo
+
+    @property
+    def cosmo_fid(self):
+        """Reference cosmology."""
+        if self._cosmo_fid is None:
+            self._cosmo_fid = Cosmology(engine='eisenstein_hu', device=self.device)
+        return self._cosmo_fid
+
+    def rs_drag_ratio(self):
+        """Ratio of ``cosmo.rs_drag`` to the fiducial one, 1 if no ``cosmo`` (reference bao_filter.py:161-169, hard-coded fiducial included)."""
+        if self._cosmo is None:
+            return 1.
+        if self._cosmo_fid is None:
+            rs_drag_fid = 100.91463132327911
+        else:
+            rs_drag_fid = self.cosmo_fid.rs_drag
+        return self.cosmo.rs_drag / rs_drag_fid
+
+
+class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
+
+    """
+    Sine-transform the power spectrum to real space, cut the BAO peak, re-interpolate with a spline (reference bao_filter.py:345-431;
+    https://arxiv.org/pdf/1810.02800.pdf App. D), with the reference's hand-tuned margins.
+    """
+    name = 'wallish2018'
+    _nlin = 4096
+    _margin_first, _margin_second, _offset = 20, 5, (-10, 20)
+
+    def _operators(self):
+        """Plans that depend on the grids only (built once per filter)."""
+        if getattr(self, '_ops', None) is not None:
+            return self._ops
+        kmin = self.pk_interpolator.extrap_kmin
+        klin = np.linspace(kmin, 2., self._nlin)
+        x = 1. + np.arange(self._nlin // 2)
+        dd = LinearOperator.spline(x, x, bc='clamped', nu=2, device=self.device)               # bao_filter.py:377-382
+        mask = (klin > 1e-2) & (klin < 1.5)                                                   # :415
+        mask_left, mask_right = self.k < 5e-4, self.k > 2.                                    # :417
+        knots = np.concatenate([self.k[mask_left], klin[mask], self.k[mask_right]], axis=0)
+        splice = LinearOperator.spline(knots, self.k, bc='clamped', device=self.device)       # :420
+        tophat = np.ones_like(self.k)
+        m = self.k > 1.
+        tophat[m] *= np.exp(-20.**2 * (self.k[m] / 1. - 1.)**2)                                # :426-431
+        self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=dd, splice=splice, mask=mask, mask_left=mask_left,
+                         mask_right=mask_right, tophat=dv.to_device(tophat, self.device))
+        return self._ops
+
+    def _box(self, dd):
+        """Per-column index box to cut, from the two maxima of the second derivative (reference bao_filter.py:390-394). dd : (ncol, n)."""
+        torch = dv.torch()
+        mf, ms, off = self._margin_first, self._margin_second, self._offset
+        n = dd.shape[-1]
+        argmax = dd[:, mf:n - mf].argmax(dim=1) + mf
+        # second maximum in [argmax + margin_second, n - margin_first): masked arg-max keeps the first maximal index like ndarray.argmax
+        idx = torch.arange(n, device=dd.device)[None, :]
+        valid = (idx >= (argmax + ms)[:, None]) & (idx < n - mf)
+        second = torch.where(valid, dd, torch.full_like(dd, float('-inf'))).argmax(dim=1)
+        return torch.stack([argmax + off[0], second + off[1]], dim=1).to(torch.int32).contiguous()
+
+    def _compute(self):
+        torch = dv.torch()
+        ops = self._operators()
+        lib = _lib.load()
+        rows, _ = self._rows(ops['klin'])                                 # P(k_lin), (ncol, 4096)
+        ffted = ops['dst'](rows, fused=True)                              # dst(log(k P)), type 2, ortho
+        even, odd = ffted[:, 0::2].contiguous(), ffted[:, 1::2].contiguous()
+        halves = []
+        self._dd, self._boxes = [], []
+        for y in (even, odd):
+            dd = ops['dd'](y)
+            box = self._box(dd)
+            out = torch.empty_like(y)
+            _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index,
+                                         dv.stream_of(self.device)))
+            halves.append(out)
+            self._dd.append(dd)
+            self._boxes.append(box)
+        self._even_now, self._odd_now = halves
+        merged = torch.empty_like(ffted)
+        merged[:, 0::2], merged[:, 1::2] = halves
+        pknow_lin = ops['dst'](merged, inverse=True, fused=True)          # exp(idst(.)) / k_lin
+        pk = self._pk_rows
+        mask, ml, mr = (torch.as_tensor(ops[name], device=self.device) for name in ('mask', 'mask_left', 'mask_right'))
+        vals = torch.cat([pk[:, ml], pknow_lin[:, mask], pk[:, mr]], dim=1).contiguous()
+        pknow = ops['splice'](vals)                                       # clamped CubicSpline on the spliced knots at self.k
+        wiggles = (pk / pknow - 1.) * ops['tophat'] + 1.
+        self._pknow_rows = pk / wiggles
+
+
+def _local_maxima(x):
+    """Indices of strict local maxima, plateaus reported at their midpoint (what scipy.signal.find_peaks returns without conditions)."""
+    out, i, n = [], 1, x.size
+    while i < n - 1:
+        if x[i - 1] < x[i]:
+            j = i
+            while j < n - 1 and x[j + 1] == x[i]:
+                j += 1
+            if j < n - 1 and x[j + 1] < x[i]:
+                out.append((i + j) // 2)
+            i = j + 1
+        else:
+            i += 1
+    return np.array(out, dtype=int)
+
+
+def _bspline_basis(t, k, x):
+    """Dense (len(x), len(t) - k - 1) matrix of B-spline basis values B_j(x) (Cox-de Boor), with polynomial extrapolation of the end pieces."""
+    n = t.size - k - 1
+    out = np.zeros((x.size, n))
+    for ix, xv in enumerate(x):
+        ell = np.searchsorted(t, xv, side='right') - 1
+        ell = min(max(ell, k), n - 1)          # interval [t_ell, t_ell+1); clamped: extrapolate with the end polynomial
+        b = np.zeros(k + 1)
+        b[0] = 1.
+        for d in range(1, k + 1):
+            saved = 0.
+            for r in range(d):
+                left, right = t[ell + r + 1 - d], t[ell + r + 1]
+                tmp = b[r] / (right - left)
+                b[r] = saved + (right - xv) * tmp
+                saved = (xv - left) * tmp
+            b[d] = saved
+        out[ix, ell - k:ell + 1] = b
+    return out
+
+
+def _quadratic_interp_operator(xk, xq):
+    """Dense operator of ``interp1d(xk, ., kind=2, fill_value='extrapolate')(xq)`` (scipy make_interp_spline(k=2))."""
+    k = 2
+    mid = (xk[1:] + xk[:-1]) / 2.
+    t = np.concatenate([(xk[0],) * (k + 1), mid[1:-1], (xk[-1],) * (k + 1)])
+    colloc = _bspline_basis(t, k, xk)
+    return _bspline_basis(t, k, xq).dot(np.linalg.inv(colloc))
+
+
+class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
+
+    """
+    Average the minima and maxima envelopes of the wiggles (reference bao_filter.py:434-509; https://arxiv.org/abs/2204.11868 App. D).
+    ``cosmo_fid`` must be provided, with an engine.
+    """
+    name = 'brieden2022'
+
+    @property
+    def cosmo_fid(self):
+        """Reference cosmology."""
+        if self._cosmo_fid is None:
+            raise ValueError('cosmo_fid must be provided, with an engine')
+        return self._cosmo_fid
+
+    def _prepare(self):
+        """Fiducial products (reference bao_filter.py:461-480): host numpy on 341 samples of the fiducial cosmology."""
+        self.kmask_fid = (self.k >= 1e-3) & (self.k <= 1.)
+        self.k_fid = self.k[self.kmask_fid]
+        pk_fid = np.asarray(Fourier(self.cosmo_fid).pk_interpolator()(self.k_fid, z=0.), dtype='f8')
+        pknow_fid = np.asarray(Fourier(self.cosmo_fid, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(self.k_fid, z=0.), dtype='f8')
+        ratio = pk_fid / pknow_fid
+        gradient = np.array([self.k_fid**(i - 1) for i in range(4)])
+        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+        constraint = [ratio[..., 0], ratio[..., 1] - ratio[..., 0], ratio[..., -1], ratio[..., -2] - ratio[..., -1]]
+        # utils.LeastSquareSolver(gradient, precision=k^2, constraint_gradient, compute_inverse=False) (utils.py:161-272)
+        hv = gradient * self.k_fid**2
+        invfisher = np.block([[hv.dot(gradient.T), -cg], [cg.T, np.zeros((4, 4))]])
+        hv = np.block([[hv, np.zeros(cg.shape)], [np.zeros((4, gradient.shape[-1])), np.eye(4)]])
+        params = np.linalg.solve(invfisher, hv.dot(np.concatenate([ratio, constraint]).T)).T[..., :4]
+        self.pknow_correction = params.dot(gradient)[:, None]
+        self.ratio_fid = ratio[:, None] / self.pknow_correction
+        ik0 = np.searchsorted(self.k_fid, 0.02, side='right') + 1
+        self.ik_fid_peaks = []
+        for si in [1., -1.]:
+            ix = _local_maxima(si * self.ratio_fid[ik0:, 0]) + ik0
+            ix = np.concatenate([[0]] * int(ix[0] > 0) + [ix] + [[-1]] * int(ix[-1] < self.k_fid.size - 1), axis=0)
+            self.ik_fid_peaks.append(ix)
+        self._set_envelope_operator()
+
+    def _set_envelope_operator(self):
+        """``_interp`` (reference bao_filter.py:482-488) is linear in y for fixed peak indices: one dense (341 x 341) operator."""
+        n = self.k_fid.size
+        M = np.zeros((n, n))
+        for ix in self.ik_fid_peaks:
+            ix = np.asarray(ix) % n
+            M[:, ix] += 0.5 * _quadratic_interp_operator(self.k_fid[ix], self.k_fid)
+        self._envelope = LinearOperator.dense(M, device=self.device)
+        self.ratio_now_fid = M.dot(self.ratio_fid)
+
+    def _compute(self):
+        torch = dv.torch()
+        rescale = self.rs_drag_ratio()
+        if dv.is_torch(rescale) or np.ndim(rescale):
+            raise NotImplementedError('brieden2022 with one rs_drag ratio per column (batched cosmologies) is not available yet')
+        rescale = float(rescale)
+        rows, _ = self._rows(self.k_fid / rescale)                                               # (ncol, 341)
+        pknow = Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(self.k_fid * rescale, z=0.)
+        pknow = dv.to_device(np.asarray(pknow, dtype='f8') * self.pknow_correction[:, 0], self.device)      # (341,)
+        ratio = rows / pknow / dv.to_device(self.ratio_fid[:, 0], self.device)
+        pknow_cols = self._envelope(ratio) * pknow * dv.to_device(self.ratio_now_fid[:, 0], self.device)   # (ncol, 341)
+        # the input interpolator cloned on (k_fid / rescale, pknow) and evaluated at k_fid (reference bao_filter.py:503-509)
+        interp = self.pk_interpolator
+        knots = self.k_fid / rescale
+        if isinstance(interp, PowerSpectrumInterpolator2D):
+            z = interp.z
+            pk2 = pknow_cols.reshape(self._lead + (knots.size,))
+            if pk2.ndim != 2:
+                raise NotImplementedError('brieden2022 on batched 2D interpolators is not available yet')
+            clone = PowerSpectrumInterpolator2D(knots, z, pk2.T, interp_k=interp.interp_k, extrap_pk=interp.extrap_pk, extrap_kmin=interp.extrap_kmin,
+                                                extrap_kmax=interp.extrap_kmax, interp_order_k=interp.interp_order_k, interp_order_z=interp.interp_order_z,
+                                                growth_factor_sq=interp.growth_factor_sq, device=self.device)
+            new = clone._rows_z(z, ignore_growth=True)(self.k_fid).reshape(-1, self.k_fid.size)
+        else:
+            clone = PowerSpectrumInterpolator1D(knots, pknow_cols.T, interp_k=interp.interp_k, extrap_pk=interp.extrap_pk, extrap_kmin=interp.extrap_kmin,
+                                                extrap_kmax=interp.extrap_kmax, interp_order_k=interp.interp_order_k, device=self.device)
+            new = clone._rows(self.k_fid)
+        out = self._pk_rows.clone()
+        out[:, torch.as_tensor(self.kmask_fid, device=self.device)] = new
+        self._pknow_rows = out
+
+
+def PowerSpectrumBAOFilter(pk_interpolator, engine='wallish2018', cosmo=None, cosmo_fid=None, **kwargs):
+    """
+    Run power spectrum BAO filter ``engine`` (reference bao_filter.py:912-921); available here: 'wallish2018', 'brieden2022'.
+    """
+    engine = engine.lower()
+    if engine not in RegisteredPowerSpectrumBAOFilter._registry or engine == 'base':
+        raise ValueError('BAO filter {} is not available on the MI355X path; choose one of {}'.format(
+            engine, sorted(name for name in RegisteredPowerSpectrumBAOFilter._registry if name != 'base')))
+    return RegisteredPowerSpectrumBAOFilter._registry[engine](pk_interpolator, cosmo=cosmo, cosmo_fid=cosmo_fid, **kwargs)

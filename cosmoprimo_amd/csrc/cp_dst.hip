@@ -1,0 +1,273 @@
+// cp_dst.hip -- batched orthonormal DST-II / DST-III of rows (gfx950) + C ABI.
+//
+// Replaces scipy.fftpack.dst / idst (type=2, norm='ortho') of the wallish2018 BAO filter
+// (reference cosmoprimo/bao_filter.py:371-372, 412):
+//   Y_k = f_k sum_n x_n sin(pi (k+1) (2n+1) / (2N)),  f_k = sqrt(2/N) (k < N-1), sqrt(1/N) (k = N-1);  inverse = transpose.
+// With x'_n = (-1)^n x_n the DST-II is the DCT-II of x' read backwards (Y_k = f_k C'_{N-1-k}), and the DCT-II comes from ONE
+// N-point complex FFT of the reordered sequence v_m = x'_{2m}, v_{N-1-m} = x'_{2m+1} (Makhoul 1980):
+// C'_k = Re(e^{-i pi k / 2N} V_k).  Two real rows are packed as v_a + i v_b and separated after the FFT through
+// V_a[k] = (V[k] + conj V[N-k]) / 2, V_b[k] = (V[k] - conj V[N-k]) / 2i.  The inverse runs the same network backwards:
+// Hermitian-symmetrised spectra H = H_a + i H_b, v = conj(FFT(conj H)).
+// The FFT reuses the pass machinery of the FFTLog kernel (cp_fft_core.h): radix-16 butterflies in registers, swizzled
+// LDS exchanges, middle-pass twiddles resident in LDS.  Optional fused elementwise maps for the filter:
+// forward input log(k_n x_n), inverse output exp(y_n) / k_n.  HBM traffic: 16 N bytes per row (read + write), HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "../../include/cosmoprimo_amd.h"
+#include "cp_error.h"
+#include "cp_fft_core.h"
+#include "cp_fftlog_tables.h"
+
+namespace {
+
+using namespace cpfft;
+
+struct Args {
+    const double* in;   // (nrows, N)
+    double* out;        // (nrows, N)
+    long long nrows;
+    const cplx* tw;     // Plan twiddles
+    const cplx* rot;    // (N) e^{-i pi k / (2N)} = (cos, -sin)
+    const double* kx;   // (N) optional abscissa for the fused maps, or nullptr
+    int fused;          // forward: x_n := log(kx_n * in_n); inverse: out_n := exp(y_n) / kx_n
+};
+
+// LDS position of frequency k after the full DIF network (digit reversal of the mixed-radix plan)
+template <int N, int P>
+__device__ __forceinline__ int pos_of_freq(int k) {
+    using PL = Plan<N, P>;
+    int pos = 0;
+#pragma unroll
+    for (int i = 0; i < PL::NPASS; ++i) {
+        const int R = PL::radix(i), M = PL::len(i) / R;
+        pos += (k % R) * M;
+        k /= R;
+    }
+    return pos;
+}
+
+template <int N, int P>
+__device__ __forceinline__ cplx lds_at(const cplx* lds, int pos) {
+    return lds[swz<N>(pos)];
+}
+
+// all DIF passes; pass 0 takes x from registers, the result is left in LDS in digit-reversed order
+template <int N, int P, int I>
+__device__ __forceinline__ void dif_rest(int t, const Args& A, cplx* lds, const cplx* ltw) {
+    using PL = Plan<N, P>;
+    if constexpr (I < PL::NPASS) {
+        cplx x[P];
+        __syncthreads();
+        asm volatile("" : "+v"(t));  // no address sharing across passes (register pressure, see cp_fftlog_body.h)
+        Pass<N, P, I>::load_lds(t, lds, x);
+        Pass<N, P, I>::butterflies(x);
+        Pass<N, P, I>::twiddle_apply_lds(t, ltw + (PL::tw_offset(I) - N), x);
+        Pass<N, P, I>::store_lds(t, lds, x);
+        dif_rest<N, P, I + 1>(t, A, lds, ltw);
+    }
+}
+
+template <int N, int P>
+__device__ __forceinline__ void dif_all(int t, const Args& A, cplx* x, cplx* lds, const cplx* ltw) {
+    using PL = Plan<N, P>;
+    Pass<N, P, 0>::butterflies(x);
+    cplx w[P];
+    Pass<N, P, 0>::twiddle_load(t, A.tw + PL::tw_offset(0), w);
+    Pass<N, P, 0>::twiddle_apply(w, x);
+    Pass<N, P, 0>::store_lds(t, lds, x);
+    dif_rest<N, P, 1>(t, A, lds, ltw);
+    __syncthreads();
+}
+
+template <int N, int P, bool INVERSE>
+__global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
+    using PL = Plan<N, P>;
+    constexpr int T = PL::T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* lds = reinterpret_cast<cplx*>(smem);
+    cplx* ltw = lds + N;
+    const int t = threadIdx.x;
+    for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = A.tw[N + i];
+    const long long npairs = (A.nrows + 1) / 2;
+    const double fn = sqrt(2. / N), fl = sqrt(1. / N);
+    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const bool has_b = 2 * p + 1 < A.nrows;
+        const double* ra = A.in + 2 * p * N;
+        const double* rb = has_b ? ra + N : ra;
+        double* oa = A.out + 2 * p * N;
+        double* ob = has_b ? oa + N : oa;
+        cplx x[P];
+        __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        if constexpr (!INVERSE) {
+            // Makhoul reordering with the (-1)^n sign folded in
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const int m = tt + T * r;
+                const bool lower = m < N / 2;
+                const int n = lower ? 2 * m : 2 * (N - 1 - m) + 1;
+                double a = ra[n], b = rb[n];
+                if (A.fused) {
+                    const double kk = A.kx[n];
+                    a = log(kk * a);
+                    b = log(kk * b);
+                }
+                x[r].re = lower ? a : -a;
+                x[r].im = has_b ? (lower ? b : -b) : 0.;
+            }
+            dif_all<N, P>(tt, A, x, lds, ltw);
+            asm volatile("" : "+v"(tt));
+            // separate the two rows, rotate, scale; frequency k -> output index N - 1 - k
+#pragma unroll 4
+            for (int s = 0; s < P; ++s) {
+                const int k = tt + T * s;
+                const cplx v = lds_at<N, P>(lds, pos_of_freq<N, P>(k));
+                const cplx u = lds_at<N, P>(lds, pos_of_freq<N, P>((N - k) % N));
+                const cplx rot = A.rot[k];  // (cos, -sin)
+                const double f = k == 0 ? fl : fn;
+                // V_a = ((p + r)/2, (q - s)/2), V_b = ((q + s)/2, (r - p)/2);  C' = cos * re + sin * im
+                const double ya = 0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im));
+                const double yb = 0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re));
+                oa[N - 1 - k] = f * ya;
+                if (has_b) ob[N - 1 - k] = f * yb;
+            }
+        } else {
+            // Hermitian-symmetrised, conjugated spectrum of the pair
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const int k = tt + T * r;
+                const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
+                const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
+                const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
+                const double Aa = fa * ra[ia], Ab = fa * rb[ia];
+                const double Ba = (k == 0 ? fa : fb) * ra[ib], Bb = (k == 0 ? fa : fb) * rb[ib];
+                const cplx rot = A.rot[k];
+                const double cs = rot.re, sn = -rot.im;
+                cplx Ha, Hb;
+                if (k == 0) {
+                    Ha = cplx{Aa, 0.};
+                    Hb = cplx{Ab, 0.};
+                } else {
+                    Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
+                    Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
+                }
+                if (!has_b) Hb = cplx{0., 0.};
+                // conj(H_a + i H_b)
+                x[r].re = Ha.re - Hb.im;
+                x[r].im = -(Ha.im + Hb.re);
+            }
+            dif_all<N, P>(tt, A, x, lds, ltw);
+            asm volatile("" : "+v"(tt));
+            // LDS holds (v_a[m], -v_b[m]) at pos(m); undo the reordering and the (-1)^n sign
+#pragma unroll 4
+            for (int s = 0; s < P; ++s) {
+                const int n = tt + T * s;
+                const bool even = (n & 1) == 0;
+                const int m = even ? n / 2 : N - 1 - (n - 1) / 2;
+                const cplx g = lds_at<N, P>(lds, pos_of_freq<N, P>(m));
+                double ya = even ? g.re : -g.re;
+                double yb = even ? -g.im : g.im;
+                if (A.fused) {
+                    const double kk = A.kx[n];
+                    ya = exp(ya) / kk;
+                    yb = exp(yb) / kk;
+                }
+                oa[n] = ya;
+                if (has_b) ob[n] = yb;
+            }
+        }
+    }
+}
+
+template <int N>
+void launch(bool inverse, const Args& A, int grid, hipStream_t stream) {
+    constexpr int P = 16, T = N / P;
+    constexpr int lds = (Plan<N, P>::TW_TOTAL) * (int)sizeof(cplx);
+    if (lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS (once per process would do; the call is cheap)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dst_kernel<N, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dst_kernel<N, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    if (inverse) hipLaunchKernelGGL((dst_kernel<N, P, true>), dim3(grid), dim3(T), lds, stream, A);
+    else hipLaunchKernelGGL((dst_kernel<N, P, false>), dim3(grid), dim3(T), lds, stream, A);
+}
+
+}  // namespace
+
+struct cp_dst_plan {
+    int n, device;
+    cplx* d_tw;
+    cplx* d_rot;
+    double* d_kx;
+};
+
+extern "C" int cp_dst_plan_destroy(cp_dst_plan* p) {
+    if (!p) return CP_OK;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device) (void)hipSetDevice(p->device);
+    if (p->d_tw) (void)hipFree(p->d_tw);
+    if (p->d_rot) (void)hipFree(p->d_rot);
+    if (p->d_kx) (void)hipFree(p->d_kx);
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    delete p;
+    return CP_OK;
+}
+
+extern "C" int cp_dst_plan_create(cp_dst_plan** out, int n, const double* kx, int device) {
+    if (!out) return cp::fail(CP_EINVAL, "cp_dst_plan_create: null plan pointer");
+    *out = nullptr;
+    if (n != 256 && n != 1024 && n != 4096) return cp::fail(CP_EUNSUPPORTED, "cp_dst_plan_create: length %d not instantiated (256, 1024, 4096)", n);
+    std::vector<cplx> tw, rot(n);
+    if (n == 256) build_twiddles<256, 16>(tw);
+    else if (n == 1024) build_twiddles<1024, 16>(tw);
+    else build_twiddles<4096, 16>(tw);
+    for (int k = 0; k < n; ++k) rot[k] = unit_root(k, 4LL * n);  // e^{-2 pi i k / 4N} = e^{-i pi k / 2N}
+    cp_dst_plan* p = new (std::nothrow) cp_dst_plan();
+    if (!p) return cp::fail(CP_ENOMEM, "cp_dst_plan_create: host allocation failed");
+    p->n = n; p->device = device; p->d_tw = nullptr; p->d_rot = nullptr; p->d_kx = nullptr;
+    int prev = -1, status = CP_OK;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: cannot select device %d", device);
+    if (status == CP_OK && (hipMalloc(&p->d_tw, tw.size() * sizeof(cplx)) != hipSuccess || hipMalloc(&p->d_rot, n * sizeof(cplx)) != hipSuccess ||
+                            (kx && hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess)))
+        status = cp::fail(CP_ENOMEM, "cp_dst_plan_create: device allocation failed");
+    if (status == CP_OK && (hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->d_rot, rot.data(), n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
+                            (kx && hipMemcpy(p->d_kx, kx, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)))
+        status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: upload failed");
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (status != CP_OK) {
+        cp_dst_plan_destroy(p);
+        return status;
+    }
+    *out = p;
+    return CP_OK;
+}
+
+extern "C" int cp_dst_execute(const cp_dst_plan* p, const double* d_in, double* d_out, long long nrows, int inverse, int fused, void* stream) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_dst_execute: null plan");
+    if (nrows < 0) return cp::fail(CP_EINVAL, "cp_dst_execute: negative row count");
+    if (nrows == 0) return CP_OK;
+    if (!d_in || !d_out) return cp::fail(CP_EINVAL, "cp_dst_execute: null device pointer");
+    if (fused && !p->d_kx) return cp::fail(CP_EINVAL, "cp_dst_execute: the fused log / exp maps need the abscissa given at plan creation");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_execute: cannot select device %d", p->device);
+    Args A;
+    A.in = d_in; A.out = d_out; A.nrows = nrows; A.tw = p->d_tw; A.rot = p->d_rot; A.kx = p->d_kx; A.fused = fused;
+    const long long npairs = (nrows + 1) / 2;
+    const int grid = (int)(npairs < 512 ? npairs : 512);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p->n == 256) launch<256>(inverse != 0, A, grid, s);
+    else if (p->n == 1024) launch<1024>(inverse != 0, A, grid, s);
+    else launch<4096>(inverse != 0, A, grid, s);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_execute: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

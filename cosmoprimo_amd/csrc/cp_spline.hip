@@ -312,7 +312,8 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_spline_apply: null device pointer");
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
     const size_t lds = (size_t)ROWS * p->n * sizeof(double);
-    if (lds > 64 * 1024) return cp::fail(CP_EUNSUPPORTED, "cp_spline_apply: %d knots exceed the LDS staging buffer (max %d)", p->n, 64 * 1024 / 8 / ROWS);
+    if (lds > 160 * 1024) return cp::fail(CP_EUNSUPPORTED, "cp_spline_apply: %d knots exceed the LDS staging buffer (max %d)", p->n, 160 * 1024 / 8 / ROWS);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_apply_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: cannot select device %d", p->device);
@@ -325,5 +326,105 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+
+// ---- clamped cubic spline through uniformly spaced knots with one run of knots removed -------------------------------------
+// wallish2018 (reference bao_filter.py:387-405): per column the DST coefficients y_i (positions x_i = i + 1) are multiplied by
+// x^2, the knots of a data-dependent box [a, b] are dropped, a clamped CubicSpline through the remaining knots is evaluated at ALL
+// positions and divided by x^2.  At a kept knot the spline returns the datum, so only the box interior is interpolated, and that
+// needs just the knot derivatives at the two knots bounding the gap.  The tridiagonal system is eliminated from both sides
+// towards the gap (two-sided elimination, no storage).  Its off-diagonal coupling decays as (2 - sqrt 3)^distance = 0.268^d, so
+// the sweeps start WINDOW = 64 knots away from the gap (true clamped end conditions if the array end is closer, a centred
+// difference otherwise; the error of that start value is damped by 0.268^64 ~ 1e-37).
+namespace {
+
+constexpr int GAP_WINDOW = 64;
+
+__global__ __launch_bounds__(64) void gap_spline_kernel(const double* __restrict__ y, const int* __restrict__ box, double* __restrict__ out,
+                                                        long long ncol, int n) {
+    const long long col = blockIdx.x;
+    if (col >= ncol) return;
+    const double* yc = y + col * n;
+    double* oc = out + col * n;
+    for (int i = threadIdx.x; i < n; i += 64) oc[i] = yc[i];
+    const int a = box[2 * col], b = box[2 * col + 1];
+    if (a < 1 || b > n - 2 || b < a) return;  // nothing removed (or an invalid box): identity
+    const int L = a - 1, R = b + 1;
+    const double g = (double)(R - L);
+    auto z = [&](int i) { const double x = (double)(i + 1); return yc[i] * (x * x); };
+    // forward sweep up to L: s_L + cpL s_R = dpL
+    double cp, dp;
+    const int i0 = L - GAP_WINDOW > 0 ? L - GAP_WINDOW : 0;
+    if (i0 == 0) {
+        cp = 0.; dp = 0.;  // clamped: s_0 = 0
+    } else {
+        cp = 0.; dp = 0.5 * (z(i0 + 1) - z(i0 - 1));
+    }
+    double cpL, dpL;
+    if (L == i0) {
+        cpL = cp; dpL = dp;
+    } else {
+        for (int i = i0 + 1; i < L; ++i) {
+            const double d = 3. * (z(i + 1) - z(i - 1));
+            const double den = 4. - cp;
+            cp = 1. / den;
+            dp = (d - dp) / den;
+        }
+        const double d = 3. * (g * (z(L) - z(L - 1)) + (z(R) - z(L)) / g);
+        const double den = 2. * (1. + g) - g * cp;
+        cpL = 1. / den;
+        dpL = (d - g * dp) / den;
+    }
+    // backward sweep down to R: s_R + bqR s_L = dqR
+    double bq, dq;
+    const int i1 = R + GAP_WINDOW < n - 1 ? R + GAP_WINDOW : n - 1;
+    if (i1 == n - 1) {
+        bq = 0.; dq = 0.;  // clamped: s_{n-1} = 0
+    } else {
+        bq = 0.; dq = 0.5 * (z(i1 + 1) - z(i1 - 1));
+    }
+    double bqR, dqR;
+    if (R == i1) {
+        bqR = bq; dqR = dq;
+    } else {
+        for (int i = i1 - 1; i > R; --i) {
+            const double d = 3. * (z(i + 1) - z(i - 1));
+            const double den = 4. - bq;
+            bq = 1. / den;
+            dq = (d - dq) / den;
+        }
+        const double d = 3. * ((z(R) - z(L)) / g + g * (z(R + 1) - z(R)));
+        const double den = 2. * (g + 1.) - g * bq;
+        bqR = 1. / den;
+        dqR = (d - g * dq) / den;
+    }
+    const double sL = (dpL - cpL * dqR) / (1. - cpL * bqR);
+    const double sR = dqR - bqR * sL;
+    const double zL = z(L), zR = z(R);
+    const double slope = (zR - zL) / g;
+    const double tt = (sL + sR - 2. * slope) / g;
+    const double c3 = tt / g, c2 = (slope - sL) / g - tt;
+    for (int i = a + threadIdx.x; i <= b; i += 64) {
+        const double u = (double)(i - L), x = (double)(i + 1);
+        oc[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_gap_spline(const double* d_y, const int* d_box, double* d_out, long long ncol, int n, int device, void* stream) {
+    if (ncol < 0 || n < 4) return cp::fail(CP_EINVAL, "cp_gap_spline: bad sizes");
+    if (ncol == 0) return CP_OK;
+    if (!d_y || !d_box || !d_out) return cp::fail(CP_EINVAL, "cp_gap_spline: null device pointer");
+    if (ncol > 2147483647LL) return cp::fail(CP_EUNSUPPORTED, "cp_gap_spline: too many columns for one launch");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_gap_spline: cannot select device %d", device);
+    hipLaunchKernelGGL(gap_spline_kernel, dim3((unsigned)ncol), dim3(64), 0, static_cast<hipStream_t>(stream), d_y, d_box, d_out, ncol, n);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_gap_spline: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }

@@ -1,0 +1,46 @@
+"""Batched orthonormal DST-II / DST-III of rows on the GPU (``cp_dst_*``): the scipy.fftpack.dst / idst(type=2, norm='ortho') of the
+wallish2018 BAO filter (reference bao_filter.py:371-372, 412)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from . import _device as dv
+
+
+class DST(object):
+
+    """Plan for rows of length ``n`` (256, 1024 or 4096); ``kx``: optional abscissa for the fused log(kx x) / exp(y)/kx maps."""
+
+    def __init__(self, n, kx=None, device=None):
+        self.device = dv.resolve_device(device)
+        self.n = int(n)
+        self._handle = ctypes.c_void_p()
+        kxp = None
+        if kx is not None:
+            kx = np.ascontiguousarray(kx, dtype='f8')
+            if kx.size != self.n:
+                raise ValueError('kx must have length {:d}'.format(self.n))
+            kxp = _lib.as_double_p(kx)
+        _lib.check(_lib.load().cp_dst_plan_create(ctypes.byref(self._handle), self.n, kxp, self.device.index))
+
+    def __call__(self, x, inverse=False, fused=False):
+        """x : (..., n) -> (..., n) device tensor: dst (or idst) type 2, norm='ortho', along the last axis."""
+        torch = dv.torch()
+        x = dv.to_device(x, self.device)
+        if x.shape[-1] != self.n:
+            raise ValueError('last dimension must be {:d}, got {}'.format(self.n, tuple(x.shape)))
+        out = torch.empty_like(x)
+        nrows = x.numel() // self.n
+        if nrows:
+            _lib.check(_lib.load().cp_dst_execute(self._handle, x.data_ptr(), out.data_ptr(), nrows, int(bool(inverse)), int(bool(fused)),
+                                                  dv.stream_of(self.device)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.load().cp_dst_plan_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass

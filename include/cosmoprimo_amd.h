@@ -147,6 +147,21 @@ int cp_spline_plan_info(const cp_spline_plan* plan, int* n, int* nq, int* bandwi
 /* the dense operator W (nq x n, row-major, host) and per-query inside-range flags: what the plan is built from */
 int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc, int nu, int extrapolate, double* w_out, int* inside_out);
 
+/* clamped cubic spline through uniformly spaced knots (positions 1..n) of x^2-weighted data with the knots of a per-column box
+ * [box[2c], box[2c+1]] removed, evaluated at all positions and divided by x^2 (wallish2018 peak removal, bao_filter.py:387-405).
+ * d_y, d_out : (ncol, n); d_box : (ncol, 2) int32. */
+int cp_gap_spline(const double* d_y, const int* d_box, double* d_out, long long ncol, int n, int device, void* stream);
+
+/* ---- batched orthonormal DST-II / DST-III of rows (replaces scipy.fftpack.dst / idst(type=2, norm='ortho') of the
+ *      wallish2018 filter, bao_filter.py:371-372, 412) ---- */
+typedef struct cp_dst_plan cp_dst_plan;
+/* n in {256, 1024, 4096}; kx : optional (n) host abscissa for the fused maps of cp_dst_execute, or NULL */
+int cp_dst_plan_create(cp_dst_plan** plan, int n, const double* kx, int device);
+/* d_in, d_out : (nrows, n) device.  inverse = 0: Y = dst2_ortho(x); 1: x = idst2_ortho(Y).
+ * fused = 1: forward transforms log(kx_n * in_n) (bao_filter.py:371), inverse returns exp(x_n) / kx_n (bao_filter.py:413). */
+int cp_dst_execute(const cp_dst_plan* plan, const double* d_in, double* d_out, long long nrows, int inverse, int fused, void* stream);
+int cp_dst_plan_destroy(cp_dst_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif
