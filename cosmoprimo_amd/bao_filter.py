@@ -139,9 +139,15 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
     _nlin = 4096
     _margin_first, _margin_second, _offset = 20, 5, (-10, 20)
 
+    _ops_cache = {}
+
     def _operators(self):
-        """Plans that depend on the grids only (built once per filter)."""
+        """Plans that depend on the grids only (built once per (k range, nk, device) and shared by all filter instances)."""
         if getattr(self, '_ops', None) is not None:
+            return self._ops
+        key = (float(self.pk_interpolator.extrap_kmin), float(self.pk_interpolator.extrap_kmax), self.k.size, self.device.index)
+        if key in self._ops_cache:
+            self._ops = self._ops_cache[key]
             return self._ops
         kmin = self.pk_interpolator.extrap_kmin
         klin = np.linspace(kmin, 2., self._nlin)
@@ -156,6 +162,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         tophat[m] *= np.exp(-20.**2 * (self.k[m] / 1. - 1.)**2)                                # :426-431
         self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=dd, splice=splice, mask=mask, mask_left=mask_left,
                          mask_right=mask_right, tophat=dv.to_device(tophat, self.device))
+        self._ops_cache[key] = self._ops
         return self._ops
 
     def _box(self, dd):

@@ -1,0 +1,91 @@
+"""
+Secondary measurements: BASELINE.json configs 3, 4 (wallish2018, one GPU's share) and 5 on ONE MI355X, inputs resident in HBM.
+Prints one JSON line per config (not the driver's bench contract: that is bench.py, config 2).
+
+    python tools/bench_configs.py [--scale 1.0]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, reps, torch):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--scale', type=float, default=1.)
+    args = ap.parse_args()
+    import torch
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import background
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    warnings.simplefilter('ignore')
+    dev = torch.device('cuda:0')
+
+    # config 3: sigma_rz on 256 r x 64 z, batch of EH cosmologies
+    nb = int(10000 * args.scale)
+    rng = np.random.default_rng(1)
+    par = dict(Omega_m=rng.uniform(.25, .40, nb), Omega_b=rng.uniform(.04, .06, nb), h=rng.uniform(.6, .8, nb), n_s=rng.uniform(.92, 1., nb), sigma8=0.8)
+    r, z = np.geomspace(1, 100, 256), np.linspace(0, 3, 64)
+    t0 = time.perf_counter()
+    cosmo = cp.Cosmology(engine='eisenstein_hu', **{k: (torch.as_tensor(v, device=dev) if np.ndim(v) else v) for k, v in par.items()})
+    interp = cosmo.get_fourier().pk_interpolator()
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t0
+    rt, zt = torch.as_tensor(r, device=dev), torch.as_tensor(z, device=dev)
+    dt = timed(lambda: interp.sigma_rz(rt, zt), 3, torch)
+    out_bytes = nb * 256 * 64 * 8
+    print(json.dumps({'config': 3, 'workload': 'sigma_rz 256 r x 64 z, %d EH cosmologies (method fftlog, nk=1024; one FFTLog per (cosmology, z) as the reference does)' % nb,
+                      'value': nb / dt, 'unit': 'cosmologies/s', 'ms': dt * 1e3, 'setup_incl_sigma8_normalisation_ms': t_setup * 1e3,
+                      'algorithmic_GBps': (out_bytes + nb * 80) / dt / 1e9}))
+    del interp, cosmo
+    torch.cuda.empty_cache()
+
+    # config 4 (one GPU's share of 1M vectors): wallish2018 on EH P(k) vectors, chunks of 16384 cosmologies
+    nb = int(125000 * args.scale)
+    rng = np.random.default_rng(2)
+    par = dict(Omega_m=rng.uniform(.25, .40, nb), Omega_b=rng.uniform(.04, .06, nb), h=rng.uniform(.6, .8, nb), n_s=rng.uniform(.92, 1., nb))
+    chunk = 16384
+    t0 = time.perf_counter()
+    done = 0
+    for start in range(0, nb, chunk):
+        sl = slice(start, min(nb, start + chunk))
+        cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{k: torch.as_tensor(v[sl], device=dev) for k, v in par.items()})
+        interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+        f = PowerSpectrumBAOFilter(interp, engine='wallish2018')
+        done += f.pknow.shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({'config': 4, 'workload': 'wallish2018 on %d EH98 P(k) vectors (nk=1024), incl. P(k) generation + sigma8 normalisation + D2H of pknow' % nb,
+                      'value': done / dt, 'unit': 'vectors/s', 'ms': dt * 1e3, 'algorithmic_GBps': done * 16384 / dt / 1e9}))
+    torch.cuda.empty_cache()
+
+    # config 5 (one GPU's share of 10M samples): comoving_radial_distance for (Omega_m, w0, wa, z) samples
+    nb = int(1250000 * args.scale)
+    rng = np.random.default_rng(3)
+    om, w0, wa, zz = (torch.as_tensor(v, device=dev) for v in (rng.uniform(0.1, 0.5, nb), rng.uniform(-1.5, -0.5, nb), rng.uniform(-1., 0.5, nb),
+                                                               rng.uniform(0., 3., nb)))
+    dt = timed(lambda: background.distance('comoving_radial_distance', zz[:, None], dict(w0_fld=w0, wa_fld=wa), Omega_m=om, per_cosmology_z=True), 5, torch)
+    print(json.dumps({'config': 5, 'workload': 'comoving_radial_distance, %d (Omega_m, w0, wa, z) samples, one fresh cosmology per sample' % nb,
+                      'value': nb / dt, 'unit': 'samples/s', 'ms': dt * 1e3, 'algorithmic_GBps': nb * 40 / dt / 1e9,
+                      'E_evaluations_per_s': nb * 237 / dt}))
+
+
+if __name__ == '__main__':
+    main()
