@@ -307,7 +307,7 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         torch = dv.torch()
         rescale = self.rs_drag_ratio()
         if dv.is_torch(rescale) or np.ndim(rescale):
-            raise NotImplementedError('brieden2022 with one rs_drag ratio per column (batched cosmologies) is not available yet')
+            return self._compute_batched(dv.to_device(rescale, self.device).reshape(-1))
         rescale = float(rescale)
         rows, _ = self._rows(self.k_fid / rescale)                                               # (ncol, 341)
         pknow = Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(self.k_fid * rescale, z=0.)
@@ -333,6 +333,51 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         out = self._pk_rows.clone()
         out[:, torch.as_tensor(self.kmask_fid, device=self.device)] = new
         self._pknow_rows = out
+
+
+def _brieden_compute_batched(self, rescale):
+    """
+    One rs_drag ratio per cosmology (``cosmo`` is a batch): same steps as :meth:`Brieden2022PowerSpectrumBAOFilter._compute`, with the
+    spectra evaluated at per-cosmology wavenumbers in one launch (``kscale``) and the final re-sampling -- a log-log natural spline on the
+    per-cosmology knots k_fid / rescale, extended by ``_pad_log`` -- done by the per-column spline kernel (``cp_spline_columns``).
+    Input: the 2D interpolator of a batched analytic engine built with a single redshift, e.g. ``Fourier(cosmo).pk_interpolator(z=[0.])``.
+    """
+    torch = dv.torch()
+    interp = self.pk_interpolator
+    if not (isinstance(interp, PowerSpectrumInterpolator2D) and hasattr(interp, '_pk_scaled') and interp.z.size == 1):
+        raise NotImplementedError('brieden2022 over a batch of cosmologies needs the pk_interpolator(z=[z0]) of a batched analytic engine')
+    nb, n = rescale.numel(), self.k_fid.size
+    rows = interp._pk_scaled(self.k_fid, 1. / rescale)                                           # P_c(k_fid / r_c), (B, 341)
+    now = Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator(z=np.array([0.]))
+    g0 = dv.to_device(now.growth_factor_sq(np.array([0.])), self.device).reshape(nb, 1)
+    pknow = now._pk_scaled(self.k_fid, rescale) * g0 * dv.to_device(self.pknow_correction[:, 0], self.device)
+    ratio = rows / pknow / dv.to_device(self.ratio_fid[:, 0], self.device)
+    pknow_cols = self._envelope(ratio) * pknow * dv.to_device(self.ratio_now_fid[:, 0], self.device)   # (B, 341)
+    # _pad_log (interpolator.py:42-87) on per-cosmology knots, knot-major (345, B)
+    logk = torch.log10(dv.to_device(self.k_fid, self.device)[:, None] / rescale[None, :])           # (341, B)
+    logp = torch.log10(pknow_cols).T.contiguous()
+    lmin = torch.log10(torch.minimum(torch.full_like(rescale, float(interp.extrap_kmin)), self.k_fid[0] / rescale * (1 - 1e-9)))
+    lmax = torch.log10(torch.maximum(torch.full_like(rescale, float(interp.extrap_kmax)), self.k_fid[-1] / rescale * (1 + 1e-9)))
+    sh = (logp[-1] - logp[-2]) / (logk[-1] - logk[-2])
+    hk = torch.stack([logk[-1] * 0.1 + lmax * 0.9, lmax])
+    hp = torch.stack([logp[-1] + sh * (hk[0] - logk[-1]), logp[-1] + sh * (hk[1] - logk[-1])])
+    sl = (logp[1] - logp[0]) / (logk[1] - logk[0])
+    lk = torch.stack([lmin, logk[0] * 0.1 + lmin * 0.9])
+    lp = torch.stack([logp[0] + sl * (lk[0] - logk[0]), logp[0] + sl * (lk[1] - logk[0])])
+    xk = torch.cat([lk, logk, hk], dim=0).contiguous()
+    yk = torch.cat([lp, logp, hp], dim=0).contiguous()
+    xq = dv.to_device(np.log10(self.k_fid), self.device)
+    out = torch.empty((n, nb), dtype=torch.float64, device=self.device)
+    scratch = torch.empty((2, xk.shape[0], nb), dtype=torch.float64, device=self.device)
+    _lib.check(_lib.load().cp_spline_columns(xk.data_ptr(), yk.data_ptr(), nb, xk.shape[0], xq.data_ptr(), n, out.data_ptr(), scratch.data_ptr(),
+                                             self.device.index, dv.stream_of(self.device)))
+    new = (10**out).T
+    res = self._pk_rows.clone()
+    res[:, torch.as_tensor(self.kmask_fid, device=self.device)] = new
+    self._pknow_rows = res
+
+
+Brieden2022PowerSpectrumBAOFilter._compute_batched = _brieden_compute_batched
 
 
 def PowerSpectrumBAOFilter(pk_interpolator, engine='wallish2018', cosmo=None, cosmo_fid=None, **kwargs):

@@ -118,6 +118,7 @@ struct Args {
     int engine, what;
     long long nk, nz;
     const double* k;  // (nk) shared, h/Mpc
+    const double* kscale;  // optional (ncosmo): cosmology ic is evaluated at k * kscale[ic] (brieden2022: k_fid / rescale, k_fid * rescale)
     const double* z;  // (nz) shared (what == CP_PK_MATTER with nz > 0), else unused
     double* out;      // (ncosmo, max(nz, 1), nk)
 };
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
-    const double kh = A.k[ik];
+    const double kh = A.kscale ? A.k[ik] * A.kscale[ic] : A.k[ik];
     const long long nrow = A.nz > 0 ? A.nz : 1;
     double* out = A.out + ic * nrow * A.nk + ik;
     double T = 1.;
@@ -211,7 +212,8 @@ int select_device(int device, int* prev) {
 }  // namespace
 
 extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                             long long nk, const double* d_k, long long nz, const double* d_z, double* d_out, int device, void* stream) {
+                             long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, int device,
+                             void* stream) {
     if (engine < CP_ENGINE_EH || engine > CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_power_eval: unknown engine %d", engine);
     if (what < CP_PK_MATTER || what > CP_PK_PRIMORDIAL) return cp::fail(CP_EINVAL, "cp_power_eval: unknown quantity %d", what);
     if (ncosmo < 0 || nk < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_power_eval: negative size");
@@ -231,6 +233,7 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     A.nk = nk;
     A.nz = what == CP_PK_MATTER ? nz : 0;
     A.k = d_k;
+    A.kscale = d_kscale;
     A.z = d_z;
     A.out = d_out;
     const int block = 256;

@@ -428,3 +428,79 @@ extern "C" int cp_gap_spline(const double* d_y, const int* d_box, double* d_out,
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_gap_spline: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
+
+
+// ---- natural cubic spline per column with per-column knots --------------------------------------------------------------------
+// brieden2022 re-samples its smooth spectrum through the input interpolator cloned on the knots k_fid / rescale (reference
+// bao_filter.py:503-509): with one rescale per column (batches of cosmologies) the knots differ per column and no fixed operator
+// exists.  One thread per column, arrays stored knot-major (n, ncol) so that lanes (columns) are coalesced: a Thomas sweep whose
+// modified coefficients go to a global scratch, then the back substitution with the (shared, ascending) queries evaluated on the
+// fly from the top interval down.  Queries outside a column's knots give NaN (Interpolator1D, jax.py:200).
+namespace {
+
+__global__ __launch_bounds__(256) void column_spline_kernel(const double* __restrict__ xk, const double* __restrict__ yk, long long ncol, int n,
+                                                           const double* __restrict__ xq, int nq, double* __restrict__ out,
+                                                           double* __restrict__ scratch) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncol) return;
+    double* cp = scratch + c;                 // (n, ncol)
+    double* dp = scratch + (long long)n * ncol + c;
+    auto X = [&](int i) { return xk[(long long)i * ncol + c]; };
+    auto Y = [&](int i) { return yk[(long long)i * ncol + c]; };
+    // forward elimination of the system for the knot derivatives (scipy CubicSpline, bc_type='natural')
+    double x0 = X(0), x1 = X(1), y0 = Y(0), y1 = Y(1);
+    double dxm = x1 - x0, slm = (y1 - y0) / dxm;   // left interval of knot 1
+    double cprev = 0.5, dprev = 3. * slm / 2.;     // row 0: 2 dx0 s0 + dx0 s1 = 3 dx0 slope0
+    cp[0] = cprev;
+    dp[0] = dprev;
+    for (int i = 1; i < n - 1; ++i) {
+        const double x2 = X(i + 1), y2 = Y(i + 1);
+        const double dxp = x2 - x1, slp = (y2 - y1) / dxp;
+        // dxp s_{i-1} + 2 (dxm + dxp) s_i + dxm s_{i+1} = 3 (dxp slm + dxm slp)
+        const double den = 2. * (dxm + dxp) - dxp * cprev;
+        cprev = dxm / den;
+        dprev = (3. * (dxp * slm + dxm * slp) - dxp * dprev) / den;
+        cp[(long long)i * ncol] = cprev;
+        dp[(long long)i * ncol] = dprev;
+        x1 = x2; y1 = y2; dxm = dxp; slm = slp;
+    }
+    // last row: dx s_{n-2} + 2 dx s_{n-1} = 3 dx slope
+    double s_hi = (3. * slm - dprev) / (2. - cprev);
+    const double nan = __builtin_nan("");
+    int iq = nq - 1;
+    const double xtop = x1;
+    while (iq >= 0 && xq[iq] > xtop) out[(long long)iq-- * ncol + c] = nan;
+    double xh = x1, yh = y1;   // upper knot of the current interval
+    for (int i = n - 2; i >= 0; --i) {
+        const double xl = X(i), yl = Y(i);
+        const double s_lo = dp[(long long)i * ncol] - cp[(long long)i * ncol] * s_hi;
+        const double h = xh - xl, slope = (yh - yl) / h;
+        const double tt = (s_lo + s_hi - 2. * slope) / h;
+        const double c3 = tt / h, c2 = (slope - s_lo) / h - tt;
+        while (iq >= 0 && xq[iq] >= xl) {
+            const double u = xq[iq] - xl;
+            out[(long long)iq * ncol + c] = yl + u * (s_lo + u * (c2 + u * c3));
+            --iq;
+        }
+        xh = xl; yh = yl; s_hi = s_lo;
+    }
+    while (iq >= 0) out[(long long)iq-- * ncol + c] = nan;
+}
+
+}  // namespace
+
+extern "C" int cp_spline_columns(const double* d_xk, const double* d_yk, long long ncol, int n, const double* d_xq, int nq, double* d_out,
+                                 double* d_scratch, int device, void* stream) {
+    if (ncol < 0 || n < 3 || nq < 0) return cp::fail(CP_EINVAL, "cp_spline_columns: bad sizes");
+    if (ncol == 0 || nq == 0) return CP_OK;
+    if (!d_xk || !d_yk || !d_xq || !d_out || !d_scratch) return cp::fail(CP_EINVAL, "cp_spline_columns: null device pointer");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_columns: cannot select device %d", device);
+    hipLaunchKernelGGL(column_spline_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_xk, d_yk, ncol, n,
+                       d_xq, nq, d_out, d_scratch);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_columns: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

@@ -107,10 +107,10 @@ class Fourier(BaseSection):
         self.tr = engine.get_transfer()
         self.ba = engine.get_background()
 
-    def _pk0_device(self, kh):
-        """P(k, z) without growth: device tensor (batch..., nk)."""
+    def _pk0_device(self, kh, kscale=None):
+        """P(k, z) without growth: device tensor (batch..., nk); ``kscale``: per-cosmology factors applied to k."""
         e = self._engine
-        return pwmod.analytic(e._transfer, 'matter', kh, bg=e.bg_params(), pk=e.pk_params(), device=self.device)
+        return pwmod.analytic(e._transfer, 'matter', kh, bg=e.bg_params(), pk=e.pk_params(), device=self.device, kscale=kscale)
 
     def pk_interpolator(self, of='delta_m', **kwargs):
         """:class:`PowerSpectrumInterpolator2D` of the pair ``of`` ('delta_m', 'theta_m'), built from callables (eisenstein_hu.py:295-329)."""
@@ -131,7 +131,10 @@ class Fourier(BaseSection):
         def pk_callable(k):
             return self._pk0_device(np.asarray(k, dtype='f8'))
 
-        return PowerSpectrumInterpolator2D.from_callable(pk_callable=pk_callable, growth_factor_sq=growth_factor_sq, device=device, **kwargs)
+        interp = PowerSpectrumInterpolator2D.from_callable(pk_callable=pk_callable, growth_factor_sq=growth_factor_sq, device=device, **kwargs)
+        # batched cosmologies: P_c(k * kscale_c) in one launch (used by the brieden2022 filter, one rs_drag ratio per cosmology)
+        interp._pk_scaled = lambda k, kscale: self._pk0_device(np.asarray(k, dtype='f8'), kscale=kscale) * interp._rsigma8sq
+        return interp
 
     def sigma_rz(self, r, z, of='delta_m', **kwargs):
         r"""R.m.s. of `of` perturbations in spheres of :math:`r` Mpc/h."""

@@ -16,13 +16,15 @@ def A_s_fid(sigma8):
     return 2.43e-9 * (sigma8 / 0.87659)**2
 
 
-def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=None):
+def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=None, kscale=None):
     """
     ``what`` in ('matter', 'transfer', 'primordial') for engine in ('eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks').
 
     k : (nk,) wavenumbers [h/Mpc] (numpy or torch), shared by the batch; z : (nz,) redshifts or None (no growth factor).
     bg : background parameters (see :func:`cosmoprimo_amd.background.distance`), pk : ``A_s, n_s, alpha_s, beta_s, k_pivot``;
     floats or arrays of shape (ncosmo,).
+
+    kscale : optional (ncosmo,) factors: cosmology i is evaluated at ``k * kscale[i]``.
 
     Returns a torch tensor on the device of shape (ncosmo,) (if batched) + ((nz,) if z is given) + (nk,), k fastest.
     """
@@ -43,6 +45,11 @@ def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=Non
     tz = dv.to_device(z, device).reshape(-1) if with_z else None
     nz = tz.numel() if with_z else 0
     out = torch.empty((ncosmo, max(nz, 1), nk), dtype=torch.float64, device=device)
+    tks = None
+    if kscale is not None:
+        tks = dv.to_device(kscale, device).reshape(-1)
+        if tks.numel() != ncosmo:
+            raise ValueError('kscale must have one entry per cosmology ({:d}), got {:d}'.format(ncosmo, tks.numel()))
     lib = _lib.load()
     for start in range(0, ncosmo, 32768):   # the kernel indexes cosmologies with gridDim.y
         stop = min(ncosmo, start + 32768)
@@ -52,7 +59,8 @@ def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=Non
                 dst[i].ptr = (src[i].ptr + 8 * start) if src[i].ptr else None
                 dst[i].value = src[i].value
         _lib.check(lib.cp_power_eval(_lib.ENGINES[engine], _lib.PK_WHAT[what], stop - start, dv.as_void_p(sub_bg), int(Omega_m is not None),
-                                     dv.as_void_p(sub_pk), nk, tk.data_ptr(), nz, tz.data_ptr() if with_z else None,
+                                     dv.as_void_p(sub_pk), nk, tk.data_ptr(), (tks.data_ptr() + 8 * start) if tks is not None else None, nz,
+                                     tz.data_ptr() if with_z else None,
                                      out[start:stop].data_ptr(), device.index, dv.stream_of(device)))
     shape = ((ncosmo,) if batched else ()) + ((nz,) if with_z else ()) + (nk,)
     return out.reshape(shape)

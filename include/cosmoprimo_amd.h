@@ -114,10 +114,12 @@ enum cp_pk_what {
 };
 enum cp_pk_param { CP_PK_A_S = 0, CP_PK_N_S = 1, CP_PK_ALPHA_S = 2, CP_PK_BETA_S = 3, CP_PK_K_PIVOT = 4 /* 1/Mpc */, CP_PK_NPARAMS = 5 };
 /* bg_params: the CP_BG_NPARAMS background parameters (cp_bg_param); pk_params: CP_PK_NPARAMS primordial parameters.
- * d_k : (nk) wavenumbers in h/Mpc shared by the batch; d_z : (nz) redshifts shared by the batch (CP_PK_MATTER only).
- * d_out : (ncosmo, max(nz, 1), nk), k fastest, (Mpc/h)^3. */
+ * d_k : (nk) wavenumbers in h/Mpc shared by the batch; d_kscale : NULL, or (ncosmo) per-cosmology factors applied to d_k
+ * (brieden2022 evaluates at k_fid / rescale and k_fid * rescale, bao_filter.py:493-499); d_z : (nz) redshifts shared by the batch
+ * (CP_PK_MATTER only).  d_out : (ncosmo, max(nz, 1), nk), k fastest, (Mpc/h)^3. */
 int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                  long long nk, const double* d_k, long long nz, const double* d_z, double* d_out, int device, void* stream);
+                  long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, int device,
+                  void* stream);
 enum cp_eh_scalar {
     CP_EH_RS_DRAG = 0 /* Mpc */, CP_EH_Z_DRAG = 1, CP_EH_Z_EQ = 2, CP_EH_K_EQ = 3, CP_EH_R_DRAG = 4, CP_EH_R_EQ = 5, CP_EH_K_SILK = 6,
     CP_EH_ALPHA_C = 7, CP_EH_BETA_C = 8, CP_EH_ALPHA_B = 9, CP_EH_BETA_NODE = 10, CP_EH_BETA_B = 11, CP_EH_ALPHA_GAMMA = 12,
@@ -151,6 +153,12 @@ int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc,
  * [box[2c], box[2c+1]] removed, evaluated at all positions and divided by x^2 (wallish2018 peak removal, bao_filter.py:387-405).
  * d_y, d_out : (ncol, n); d_box : (ncol, 2) int32. */
 int cp_gap_spline(const double* d_y, const int* d_box, double* d_out, long long ncol, int n, int device, void* stream);
+
+/* natural cubic spline per column with per-column knots (brieden2022 re-sampling with one rs_drag ratio per column, bao_filter.py:503-509):
+ * d_xk, d_yk : (n, ncol) knot-major; d_xq : (nq) ascending queries shared by all columns; d_out : (nq, ncol);
+ * d_scratch : 2 * n * ncol doubles.  Queries outside a column's knots give NaN. */
+int cp_spline_columns(const double* d_xk, const double* d_yk, long long ncol, int n, const double* d_xq, int nq, double* d_out, double* d_scratch,
+                      int device, void* stream);
 
 /* ---- batched orthonormal DST-II / DST-III of rows (replaces scipy.fftpack.dst / idst(type=2, norm='ortho') of the
  *      wallish2018 filter, bao_filter.py:371-372, 412) ---- */

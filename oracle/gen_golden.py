@@ -288,6 +288,11 @@ def gen_bao(cp):
                 out['brieden_ratio_fid'] = b.ratio_fid
                 out['brieden_ratio_now_fid'] = b.ratio_now_fid
                 out['brieden_peaks_high'], out['brieden_peaks_low'] = [np.asarray(ix) for ix in b.ik_fid_peaks]
+            # the same with the 2D interpolator built on a single redshift (no growth factor in the filter input, bao_filter.py:96-98):
+            # the input shape of batched runs
+            interp2d = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+            out['c%d_wallish_pknow_2d' % i] = cp.PowerSpectrumBAOFilter(interp2d, engine='wallish2018', cosmo=cosmo, cosmo_fid=fid).pknow
+            out['c%d_brieden_pknow_2d' % i] = cp.PowerSpectrumBAOFilter(interp2d, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid).pknow
             # no cosmo given: rs_drag_ratio = 1
             if i == 1:
                 out['c1_brieden_pknow_nocosmo'] = cp.PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo_fid=fid).pknow

@@ -97,3 +97,24 @@ def test_tabulated_2d_input(cp, golden):
     for iz in range(2):
         one = PowerSpectrumBAOFilter(tab.to_1d(z=g['tab_z'][iz]), engine='wallish2018', cosmo=cosmo, cosmo_fid=fid)
         assert np.allclose(one.pknow, w.pknow[:, iz], rtol=1e-6, atol=1e-6)   # reference tests/test_bao_filter.py:117-136
+
+
+def test_batched_cosmologies(cp, golden):
+    """BASELINE config 4 shape: the 4 golden cosmologies as ONE batched Cosmology; both filters run on all vectors at once
+    (brieden2022 with one rs_drag ratio per vector) and must reproduce the per-cosmology reference results."""
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    g = golden('bao')
+    fid = cp.Cosmology(engine='eisenstein_hu')
+    defaults = dict(Omega_m=0.3, Omega_b=0.05, h=0.7, n_s=0.96, sigma8=0.8)
+    par = {name: np.array([p.get(name, defaults[name]) for p in BAO_PARAMS]) for name in defaults}
+    cosmo = cp.Cosmology(engine='eisenstein_hu', **par)
+    interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+    w = PowerSpectrumBAOFilter(interp, engine='wallish2018', cosmo=cosmo, cosmo_fid=fid)
+    assert w.pknow.shape == (4, 1024, 1)
+    b = PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid)
+    b.ik_fid_peaks = [g['brieden_peaks_high'], g['brieden_peaks_low']]
+    b._set_envelope_operator()
+    b(interp, cosmo=cosmo)
+    for i in range(4):
+        np.testing.assert_allclose(w.pknow[i], g['c%d_wallish_pknow_2d' % i], rtol=RTOL)
+        np.testing.assert_allclose(b.pknow[i], g['c%d_brieden_pknow_2d' % i], rtol=RTOL)

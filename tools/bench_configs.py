@@ -72,7 +72,22 @@ def main():
         done += f.pknow.shape[0]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({'config': 4, 'workload': 'wallish2018 on %d EH98 P(k) vectors (nk=1024), incl. P(k) generation + sigma8 normalisation + D2H of pknow' % nb,
+    print(json.dumps({'config': 4, 'filter': 'wallish2018',
+                      'workload': 'wallish2018 on %d EH98 P(k) vectors (nk=1024), incl. P(k) generation + sigma8 normalisation + D2H of pknow' % nb,
+                      'value': done / dt, 'unit': 'vectors/s', 'ms': dt * 1e3, 'algorithmic_GBps': done * 16384 / dt / 1e9}))
+    fid = cp.Cosmology(engine='eisenstein_hu')
+    t0 = time.perf_counter()
+    done = 0
+    for start in range(0, nb, chunk):
+        sl = slice(start, min(nb, start + chunk))
+        cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{k: torch.as_tensor(v[sl], device=dev) for k, v in par.items()})
+        interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+        f = PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid)
+        done += f.pknow.shape[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({'config': 4, 'filter': 'brieden2022',
+                      'workload': 'brieden2022 on %d EH98 P(k) vectors (one rs_drag ratio each), incl. P(k) + no-wiggle template generation, both sigma8 normalisations, D2H' % nb,
                       'value': done / dt, 'unit': 'vectors/s', 'ms': dt * 1e3, 'algorithmic_GBps': done * 16384 / dt / 1e9}))
     torch.cuda.empty_cache()
 
