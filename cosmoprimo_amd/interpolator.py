@@ -141,6 +141,9 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
     rr = _host(r).ravel()
     if nk is None:
         nk = 1024
+    if rr.size == 0:
+        rows = pk_rows(np.geomspace(kmin, kmax, 4))
+        return rows.new_empty(tuple(rows.shape[:-1]) + (0,))
     if method == 'fftlog':
         k = np.geomspace(kmin, kmax, nk)
         key = (float(kmin), float(kmax), int(nk), device.index)
@@ -214,7 +217,10 @@ class Interpolator1D(object):
         shape = xh.shape + self.shape
         xh = xh.ravel()
         _mask_bounds([xh], [(self.xmin, self.xmax)], bounds_error=bounds_error)
-        xq = np.log10(xh) if self.interp_x == 'log' else xh
+        if xh.size == 0:
+            return _finish(dv.torch().empty((0, self._rows.shape[0]), dtype=dv.torch().float64, device=self.device), dtype, like_torch, shape)
+        with np.errstate(all='ignore'):
+            xq = np.log10(xh) if self.interp_x == 'log' else xh
         op = _cached_operator(('i1d', self._x.tobytes(), xq.tobytes(), int(dx), self.extrap, self.device.index),
                               lambda: LinearOperator.spline(self._x, xq, bc='natural', nu=dx, extrapolate=self.extrap, device=self.device))
         out = op(self._rows)   # (ncol, nq); NaN outside [xmin, xmax] unless extrap
@@ -247,6 +253,8 @@ class Interpolator2D(object):
         if self.interp_fun == 'log':
             fun = torch.log10(fun)
         self._fun = fun.contiguous()    # (nx, ny)
+        # FITPACK propagates any NaN datum (e.g. the log of a negative P) to the whole surface (reference tests/test_interpolator.py:328-337)
+        self._has_nan = bool(torch.isnan(self._fun).any())
 
     def __call__(self, x, y, grid=True, bounds_error=False):
         torch = dv.torch()
@@ -256,7 +264,11 @@ class Interpolator2D(object):
         shape = xh.shape + yh.shape if grid else xh.shape
         xh, yh = xh.ravel(), yh.ravel()
         mask_x, mask_y = _mask_bounds([xh, yh], [(self.xmin, self.xmax), (self.ymin, self.ymax)], bounds_error=bounds_error)
-        xq = np.log10(xh) if self.interp_x == 'log' else xh
+        if xh.size == 0 or yh.size == 0 or self._has_nan:
+            n = (xh.size, yh.size) if grid else (xh.size,)
+            return _finish(torch.full(n, float('nan'), dtype=torch.float64, device=self.device), dtype, like_torch, shape)
+        with np.errstate(all='ignore'):
+            xq = np.log10(xh) if self.interp_x == 'log' else xh
         if grid:
             opx = _cached_operator(('i2x', self._x.tobytes(), xq.tobytes(), self.device.index),
                                    lambda: LinearOperator.spline(self._x, xq, bc='not-a-knot', extrapolate=True, device=self.device))

@@ -1,0 +1,99 @@
+"""GPU: the shape / dtype / ordering contracts the reference pins for its interpolators (tests/test_interpolator.py:8-32, 35-70,
+168-300): scalar, empty and n-d inputs, f4 in -> f4 out, order independence at atol=0, clone equality, NaN / bounds_error."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def check_shape_1d(interp, shape=()):
+    assert interp(0.1).shape == shape
+    assert interp([]).shape == (0,) + shape
+    assert interp([[0.1, 0.2]] * 3).shape == (3, 2) + shape
+    assert interp(np.array([[0.1, 0.2]] * 3, dtype='f4')).dtype.itemsize == 4
+    assert np.allclose(interp([0.2, 0.1]), interp([0.1, 0.2])[::-1], atol=0)
+
+
+def check_shape_2d(interp, grid=True):
+    assert interp(0.1, 0.1).shape == ()
+    if grid:
+        assert interp(np.array([]), np.array(0.1)).shape == (0, )
+        assert interp([], []).shape == (0, 0)
+        assert interp(0.1, [0.1, 0.1]).shape == (2, )
+        assert interp([[0.1, 0.2]] * 3, 0.1).shape == (3, 2)
+        assert interp([[0.1, 0.2]] * 3, [0.1]).shape == (3, 2, 1)
+        assert interp([[0.1, 0.2]] * 3, [[0.1, 0.1, 0.2]] * 3).shape == (3, 2, 3, 3)
+        assert interp(np.array([[0.1, 0.2]] * 3, dtype='f4'), np.array(0.1, dtype='f4')).dtype.itemsize == 4
+        assert np.allclose(interp([0.2, 0.1], [0.1, 0.]), interp([0.1, 0.2], [0., 0.1])[::-1, ::-1], atol=0)
+    else:
+        assert interp([], [], grid=False).shape == (0, )
+        assert interp([0.1, 0.2], [0.1, 0.2], grid=False).shape == (2, )
+        assert interp([[0.1, 0.2]] * 3, [[0.1, 0.2]] * 3, grid=False).shape == (3, 2)
+        assert np.allclose(interp([0.2, 0.1], [0.1, 0.], grid=False), interp([0.1, 0.2], [0., 0.1], grid=False)[::-1], atol=0)
+
+
+def test_power_spectrum_contracts():
+    import torch
+    assert torch.cuda.is_available()
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D
+    warnings.simplefilter('ignore')
+    cosmo = cp.Cosmology()
+    tr = cp.Transfer(cosmo, engine='eisenstein_hu')
+    k = np.logspace(-3, 1.5, 100)
+    pk = tr.transfer_k(k)**2 * k ** cosmo['n_s']
+    interp = PowerSpectrumInterpolator1D(k, pk)
+    check_shape_1d(interp)
+    interp2d = PowerSpectrumInterpolator2D(k, z=[0., 0.5, 1., 1.5], pk=np.repeat(pk[:, None], 4, axis=-1))
+    assert interp2d(k, z=0.).shape == (100,)
+    interp2 = interp.clone()
+    assert np.all(interp2(np.ones((4, 2))) == interp(np.ones((4, 2))))
+    check_shape_1d(interp.sigma_r)
+    interp = PowerSpectrumInterpolator2D(k, z=0, pk=pk, growth_factor_sq=lambda z: np.ones_like(z))
+    assert np.allclose(interp(k, z=np.random.uniform(0., 1., 10)), pk[:, None], atol=0, rtol=1e-5)
+    check_shape_2d(interp)
+    check_shape_2d(interp, grid=False)
+    interp2 = interp.clone()
+    assert np.all(interp2._pk == interp._pk)
+    assert np.allclose(interp2(k, z=[0] * 2), interp(k, z=[0] * 2), atol=1e-18, rtol=1e-18)
+    check_shape_2d(interp2d)
+    check_shape_2d(interp2d, grid=False)
+    # engine callables
+    fo = cp.Fourier(cosmo, engine='eisenstein_hu')
+    ic = fo.pk_interpolator()
+    check_shape_2d(ic)
+    check_shape_2d(ic, grid=False)
+    check_shape_1d(ic.to_1d(z=0.))
+    assert ic.sigma_rz(np.linspace(1., 10., 3), np.linspace(0., 1., 4)).shape == (3, 4)
+    assert ic.sigma_dz(np.linspace(0., 1., 4)).shape == (4,)
+
+
+def test_extrapolation_and_nan():
+    """reference tests/test_interpolator.py:168-300, 328-337"""
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D
+    k = np.logspace(-3, 1., 50)
+    pk = k**-1.5
+    for kwargs in [dict(), dict(extrap_kmin=1e-5, extrap_kmax=1e3)]:
+        interp = PowerSpectrumInterpolator1D(k, pk, **kwargs)
+        kmin, kmax = kwargs.get('extrap_kmin', 1e-7), kwargs.get('extrap_kmax', 1e2)
+        assert np.isnan(interp(kmin * 0.5)) and np.isnan(interp(kmax * 2.))
+        assert np.isfinite(interp(np.array([kmin, kmax]))).all()
+        assert np.allclose(interp(np.array([1e-4, 50.])), np.array([1e-4, 50.])**-1.5, rtol=1e-6)   # log-log extrapolation of a power law is exact
+        with pytest.raises(ValueError):
+            interp(kmax * 2., bounds_error=True)
+    interp = PowerSpectrumInterpolator1D(k, pk, extrap_pk='lin')
+    assert np.isnan(interp(5e-4)) and np.isfinite(interp(2e-3))
+    with pytest.raises(ValueError):
+        PowerSpectrumInterpolator1D(k, pk, interp_k='lin', extrap_pk='log')
+    z = np.linspace(0., 1., 5)
+    interp2 = PowerSpectrumInterpolator2D(k, z, pk[:, None] * (1 + z))
+    assert np.isnan(interp2(1., 1.5)) and np.isnan(interp2(1e3, 0.5)) and np.isfinite(interp2(1., 0.5))
+    with pytest.raises(ValueError):
+        interp2(1., 1.5, bounds_error=True)
+    bad = pk.copy()
+    bad[10] *= -1
+    assert np.isnan(PowerSpectrumInterpolator1D(k, bad)(k)).all()
+    assert np.isnan(PowerSpectrumInterpolator2D(k, z, bad[:, None] * (1 + z))(k, z)).all()
