@@ -87,7 +87,7 @@ template <int N, int P, bool INVERSE>
 __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     using PL = Plan<N, P>;
     constexpr int T = PL::T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(4096))) char smem[];  // 4096: see LdsView (cp_fft_core.h)
     cplx* lds = reinterpret_cast<cplx*>(smem);
     cplx* ltw = lds + N;
     const int t = threadIdx.x;

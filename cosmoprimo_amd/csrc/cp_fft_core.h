@@ -71,6 +71,27 @@ __device__ __forceinline__ double lane_swap1(double v) {
     w.y = __builtin_amdgcn_mov_dpp(w.y, 0xB1, 0xF, 0xF, true);
     return __builtin_bit_cast(double, w);
 }
+// 2x2 transpose between the lanes of a pair (lane, lane ^ 1): even lanes end with (own lo, neighbour lo), odd lanes with
+// (neighbour hi, own hi).  v_cndmask_b32_dpp does the neighbour read and the select in one instruction (4 VALU per pair
+// of doubles; the compiler does not form it from mov_dpp + select because the condition has to sit in VCC).
+// s_nop 1: the two wait states a DPP read needs after a VALU write of its source.
+__device__ __forceinline__ void lane_transpose2(double& lo, double& hi) {
+    const cp_v2i l = __builtin_bit_cast(cp_v2i, lo), h = __builtin_bit_cast(cp_v2i, hi);
+    cp_v2i a, b;
+    asm volatile(
+        "s_mov_b64 vcc, %8\n\t"
+        "s_nop 1\n\t"
+        "v_cndmask_b32_dpp %0, %4, %6, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %5, %7, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %2, %6, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(a.x), "=&v"(a.y), "=&v"(b.x), "=&v"(b.y)
+        : "v"(h.x), "v"(h.y), "v"(l.x), "v"(l.y), "s"(0x5555555555555555ull)
+        : "vcc");
+    lo = __builtin_bit_cast(double, a);
+    hi = __builtin_bit_cast(double, b);
+}
 #else
 inline cplx ld_cplx(const void* base, unsigned voff, unsigned soff) {
     return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + voff + soff);
@@ -81,6 +102,29 @@ inline double ld_f64(const void* base, unsigned voff, unsigned soff) {
 inline void st_f64(void* base, unsigned voff, unsigned soff, double v) {
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + voff + soff) = v;
 }
+#endif
+
+// LDS accesses by 32-bit byte address.  On the device the address is an integer in the LDS address space: the buffer's
+// own offset is added once per phase (to the thread's base) instead of once per access, which is what pointer arithmetic
+// on the generic pointer costs.  The XOR forms of Pass::lds_off rely on the buffer being 4096-byte aligned in LDS
+// ((base + l0) ^ k == (base ^ k) + l0 for k < 4096): the kernels declare it so.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) cplx cp_lds_cplx;
+struct LdsView {
+    unsigned l0;
+    __device__ __forceinline__ explicit LdsView(const void* lds)
+        : l0((unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)lds) {}
+    __device__ __forceinline__ cplx read(unsigned addr) const { return *(const cp_lds_cplx*)(unsigned long long)addr; }
+    __device__ __forceinline__ void write(unsigned addr, const cplx v) const { *(cp_lds_cplx*)(unsigned long long)addr = v; }
+};
+#else
+struct LdsView {
+    static constexpr unsigned l0 = 0u;
+    char* p;
+    explicit LdsView(const void* lds) : p(const_cast<char*>(static_cast<const char*>(lds))) {}
+    cplx read(unsigned addr) const { return *reinterpret_cast<const cplx*>(p + addr); }
+    void write(unsigned addr, const cplx v) const { *reinterpret_cast<cplx*>(p + addr) = v; }
+};
 #endif
 
 CP_HD cplx cmul(const cplx a, const cplx b) {
@@ -229,22 +273,62 @@ CP_HD void dft4_mid(cplx& x0, cplx& x1, cplx& x2, cplx& x3) {
 // 16 = 4 x 4: r = r0 + 4 r1, s = s0 + 4 s1;
 // X[s0 + 4 s1] = sum_r0 w16^(r0 s0) w4^(r0 s1) sum_r1 x[r0 + 4 r1] w4^(r1 s0)
 // After the inner DFT4s (over r1, one per r0) slot x[r0 + 4 s0] holds the partial sum for (r0, s0).
+//
+// The sqrt(1/2) of the w16^2 / w16^6 twiddles is not applied to the rotated element but folded into the additions that
+// consume it (a +- H u is one FMA each): 8 fewer fp64 instructions per radix-16 butterfly.
+constexpr double CP_SQRT_HALF = 0.70710678118654752440;
+// u = a * w16^2 / H = (re + im, im - re);  u = a * w16^6 / H = (im - re, -re - im)
+CP_HD cplx rot_w16_2_unscaled(const cplx a) { return cplx{a.re + a.im, a.im - a.re}; }
+CP_HD cplx rot_w16_6_unscaled(const cplx a) { return cplx{a.im - a.re, -a.re - a.im}; }
+// DFT4 of (x0, x1, H u2, x3)
+CP_HD void dft4_h2(cplx& x0, cplx& x1, cplx& u2, cplx& x3) {
+    constexpr double H = CP_SQRT_HALF;
+    const double s0r = __builtin_fma(H, u2.re, x0.re), s0i = __builtin_fma(H, u2.im, x0.im);
+    const double d0r = __builtin_fma(-H, u2.re, x0.re), d0i = __builtin_fma(-H, u2.im, x0.im);
+    const double s1r = x1.re + x3.re, s1i = x1.im + x3.im;
+    const double d1r = x1.re - x3.re, d1i = x1.im - x3.im;
+    x0.re = s0r + s1r;
+    x0.im = s0i + s1i;
+    u2.re = s0r - s1r;
+    u2.im = s0i - s1i;
+    x1.re = d0r + d1i;
+    x1.im = d0i - d1r;
+    x3.re = d0r - d1i;
+    x3.im = d0i + d1r;
+}
+// DFT4 of (x0, H u1, x2, H u3)
+CP_HD void dft4_h13(cplx& x0, cplx& u1, cplx& x2, cplx& u3) {
+    constexpr double H = CP_SQRT_HALF;
+    const double s0r = x0.re + x2.re, s0i = x0.im + x2.im;
+    const double d0r = x0.re - x2.re, d0i = x0.im - x2.im;
+    const double s1r = u1.re + u3.re, s1i = u1.im + u3.im;  // unscaled
+    const double d1r = u1.re - u3.re, d1i = u1.im - u3.im;
+    x0.re = __builtin_fma(H, s1r, s0r);
+    x0.im = __builtin_fma(H, s1i, s0i);
+    x2.re = __builtin_fma(-H, s1r, s0r);
+    x2.im = __builtin_fma(-H, s1i, s0i);
+    u1.re = __builtin_fma(H, d1i, d0r);
+    u1.im = __builtin_fma(-H, d1r, d0i);
+    u3.re = __builtin_fma(-H, d1i, d0r);
+    u3.im = __builtin_fma(H, d1r, d0i);
+}
+
 CP_HD void dft16_outer(cplx* x) {
     // twiddles w16^(r0 s0) on x[r0 + 4 s0]
     mul_w16<1>(x[1 + 4]);
-    mul_w16<2>(x[1 + 8]);
+    x[1 + 8] = rot_w16_2_unscaled(x[1 + 8]);
     mul_w16<3>(x[1 + 12]);
-    mul_w16<2>(x[2 + 4]);
+    x[2 + 4] = rot_w16_2_unscaled(x[2 + 4]);
     mul_w16<4>(x[2 + 8]);
-    mul_w16<6>(x[2 + 12]);
+    x[2 + 12] = rot_w16_6_unscaled(x[2 + 12]);
     mul_w16<3>(x[3 + 4]);
-    mul_w16<6>(x[3 + 8]);
+    x[3 + 8] = rot_w16_6_unscaled(x[3 + 8]);
     mul_w16<9>(x[3 + 12]);
     // outer DFT4 over r0 for each s0 (in place on x[4 s0 + r0], slot r0 := s1)
     dft4(x[0], x[1], x[2], x[3]);
-    dft4(x[4], x[5], x[6], x[7]);
-    dft4(x[8], x[9], x[10], x[11]);
-    dft4(x[12], x[13], x[14], x[15]);
+    dft4_h2(x[4], x[5], x[6], x[7]);
+    dft4_h13(x[8], x[9], x[10], x[11]);
+    dft4_h2(x[12], x[13], x[14], x[15]);
     // x[4 s0 + s1] holds X[s0 + 4 s1]: 4x4 transpose (register renaming after unrolling)
     cplx t;
     t = x[1]; x[1] = x[4]; x[4] = t;
@@ -317,33 +401,40 @@ struct Pass {
         }
         return 0u;
     }
-    static CP_HD unsigned lds_off(int t, int i, int r, unsigned base) {
+    // base = lds_base(t, i) + the buffer's LDS address l0
+    static CP_HD unsigned lds_off(int t, int i, int r, unsigned base, unsigned l0) {
         if (NP >= 256 && M % 256 == 0) return base + (unsigned)r * (M * 16u);
         if (NP >= 256 && M == 16 && R == 16) return base ^ ((unsigned)r * 0x110u);
         if (NP >= 256 && M == 1 && R == 16) return base ^ ((unsigned)r * 16u);
-        return (unsigned)swz<NP>(elem(t, i, r)) * 16u;
+        return (unsigned)swz<NP>(elem(t, i, r)) * 16u + l0;
     }
+    // order in which a radix-16 butterfly consumes its points: (0, 8, 4, 12), (1, 9, 5, 13), ...; the LDS reads are issued
+    // in that order so that the first additions can start after two of them
+    static CP_HD int consume_order(int k) { return R == 16 ? (k >> 2) + 8 * (k & 1) + 4 * ((k >> 1) & 1) : k; }
     static CP_HD void load_lds(int t, const cplx* lds, cplx* x) {
+        const LdsView v(lds);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const unsigned base = lds_base(t, i);
+            const unsigned base = lds_base(t, i) + v.l0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
+            for (int k = 0; k < R; ++k) {
+                const int r = consume_order(k);
                 if (CP_ABLATE & 1) x[i * R + r] = cplx{1e-3 * t + r, 1. + i};
-                else x[i * R + r] = *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(lds) + lds_off(t, i, r, base));
+                else x[i * R + r] = v.read(lds_off(t, i, r, base, v.l0));
             }
         }
     }
     static CP_HD void store_lds(int t, cplx* lds, const cplx* x) {
+        const LdsView v(lds);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const unsigned base = lds_base(t, i);
+            const unsigned base = lds_base(t, i) + v.l0;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (CP_ABLATE & 1) {
                     if (x[i * R + r].re == 1.2345e301) lds[t] = x[i * R + r];  // keeps x alive, never taken
                 } else {
-                    *reinterpret_cast<cplx*>(reinterpret_cast<char*>(lds) + lds_off(t, i, r, base)) = x[i * R + r];
+                    v.write(lds_off(t, i, r, base, v.l0), x[i * R + r]);
                 }
             }
         }
@@ -385,6 +476,20 @@ struct Pass {
                 else w = ltw[s * M + j];
                 if (CP_ABLATE & 32) x[i * R + s].re += w.re + w.im;
                 else x[i * R + s] = cmul(x[i * R + s], w);
+            }
+        }
+    }
+    // ... or in two steps like twiddle_load / twiddle_apply: all reads issued up front (behind the data reads of the
+    // phase), so that their latency hides under the butterflies instead of stalling every twiddle multiplication
+    static CP_HD void twiddle_load_lds(int t, const cplx* ltw, cplx* w) {
+        if (M == 1) return;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = joff(t, i);
+#pragma unroll
+            for (int s = 1; s < R; ++s) {
+                if (CP_ABLATE & 4) w[i * R + s] = cplx{1. + 1e-9 * t, 0.5 + s};
+                else w[i * R + s] = ltw[s * M + j];
             }
         }
     }

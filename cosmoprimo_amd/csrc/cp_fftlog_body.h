@@ -125,10 +125,7 @@ struct Fftlog {
             double a = st.va[r], b = st.vb[r];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CP_NO_WIDE_IO)
             if (T >= 2 && !(CP_ABLATE & 8)) {  // (va, vb) hold (row[n], row[n+1]) of this lane's row: trade with the neighbour lane
-                const bool odd = t & 1;
-                const double recv = lane_swap1(odd ? a : b);
-                a = odd ? recv : st.va[r];
-                b = odd ? st.vb[r] : recv;
+                lane_transpose2(a, b);
             }
 #endif
             x[r + 4].re = a * st.fpre[r];
@@ -199,9 +196,9 @@ struct Fftlog {
             cplx v[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const double recv = lane_swap1(odd ? ya[s] : yb[s]);
-                v[s].re = odd ? recv : ya[s];
-                v[s].im = odd ? yb[s] : recv;
+                v[s].re = ya[s];
+                v[s].im = yb[s];
+                lane_transpose2(v[s].re, v[s].im);
             }
             if (has_b || !odd) {
 #pragma unroll
@@ -352,9 +349,13 @@ struct Fftlog {
             load_tables_for<1>(t, A, ker, st.w);
         } else if constexpr (PH < LAST) {
             constexpr int I = (PH < LAST) ? PH : 0;
+            // st.w is free during the middle phases (their tables live in LDS): it takes the twiddles, read right behind
+            // the data so that the LDS latency hides under the butterflies
             Pass<NP, P, I>::load_lds(t, lds, x);
+            Pass<NP, P, I>::twiddle_load_lds(t, lds_tw<I>(lds), st.w);
+            CP_SCHED_FENCE();
             Pass<NP, P, I>::butterflies(x);
-            Pass<NP, P, I>::twiddle_apply_lds(t, lds_tw<I>(lds), x);
+            Pass<NP, P, I>::twiddle_apply(st.w, x);
             Pass<NP, P, I>::store_lds(t, lds, x);
             load_tables_for<PH + 1>(t, A, ker, st.w);
         } else if constexpr (PH == LAST) {
@@ -366,8 +367,10 @@ struct Fftlog {
             load_tables_for<PH + 1>(t, A, ker, st.w);
         } else if constexpr (PH < NPH - 1) {
             constexpr int I = (PH > LAST && PH < NPH - 1) ? (NPH - 1 - PH) : 0;
+            Pass<NP, P, I>::twiddle_load_lds(t, lds_tw<I>(lds), st.w);
             Pass<NP, P, I>::load_lds(t, lds, x);
-            Pass<NP, P, I>::twiddle_apply_lds(t, lds_tw<I>(lds), x);
+            CP_SCHED_FENCE();
+            Pass<NP, P, I>::twiddle_apply(st.w, x);
             Pass<NP, P, I>::butterflies(x);
             Pass<NP, P, I>::store_lds(t, lds, x);
             load_tables_for<PH + 1>(t, A, ker, st.w);

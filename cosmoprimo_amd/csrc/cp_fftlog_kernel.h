@@ -91,7 +91,7 @@ __device__ __forceinline__ PairRows pair_rows(const FftlogArgs& A, long long p) 
 // NP = 4096, i.e. 2 waves per SIMD, so the register budget is 256 VGPR+AGPR per lane.
 template <int NP, int P, int IM, int OM>
 __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(4096))) char smem[];  // 4096: see LdsView (cp_fft_core.h)
     cplx* lds = reinterpret_cast<cplx*>(smem);
     using F = Fftlog<NP, P, IM, OM>;
     const int t = threadIdx.x;
