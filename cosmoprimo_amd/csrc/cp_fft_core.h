@@ -29,6 +29,25 @@
 #define CP_SCHED_FENCE() ((void)0)
 #endif
 
+#if defined(CP_STAMPS) && defined(__HIPCC__)
+// diagnostic build: wave clock, with the LDS / scalar-memory counter drained on both sides
+__device__ __forceinline__ unsigned long long cp_stamp() {
+    unsigned long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define CP_FS_BEGIN(st) ((st).fs_last = cp_stamp())
+#define CP_FS(st, k)                               \
+    do {                                           \
+        const unsigned long long now_ = cp_stamp(); \
+        (st).fs[k] += now_ - (st).fs_last;         \
+        (st).fs_last = now_;                       \
+    } while (0)
+#else
+#define CP_FS_BEGIN(st) ((void)0)
+#define CP_FS(st, k) ((void)0)
+#endif
+
 // Diagnostic builds only (tools/fftlog_microbench.hip): a bit mask that removes one cost at a time so that timing
 // differences show what the kernel is waiting on.  Results are wrong when any bit is set; the library is built with 0.
 //   1 no LDS traffic   2 no workgroup barriers   4 no table loads   8 no HBM row loads   16 no HBM stores   32 no butterflies
@@ -166,11 +185,18 @@ struct Plan {
     static constexpr int TW_TOTAL = tw_offset(NPASS);
 };
 
-// LDS slot swizzle: XOR the low 4 bits of the element index with bits 4..7.  With 16-byte complex
-// slots this makes the radix-16 access patterns of all three pass shapes (stride 1, stride 16 in
-// blocks of 256, 16 contiguous per lane) conflict-free for ds_read_b128 / ds_write_b128.
-template <int NP>
+// LDS slot swizzle: XOR the low 4 bits of the element index with a GF(2)-linear function of the higher bits, chosen
+// per radix so that with 16-byte complex slots every pass shape of the plan is conflict-free for ds_read_b128 /
+// ds_write_b128 (16 lanes are served per LDS cycle and must hit 16 distinct slots mod 16):
+//   P = 16 (strides 1 | 16 in blocks of 256 | 16 contiguous per lane):  low4 ^= bits 4..7
+//   P = 8  (strides 1 | 8 in blocks of 64 | 8 contiguous per lane):     low3 ^= bits 3..5, bit 3 ^= bit 6
+//          (reads are served 16 lanes per cycle over 64 banks, 16-byte writes 8 contiguous lanes over 32 banks:
+//          MI355X_MICROARCH.md, LDS; tools/lds_conflict_model.py checks every pass shape against both rules)
+// Linearity (swz(a ^ b) == swz(a) ^ swz(b)) is what lets Pass::lds_off split an address into a per-thread base and a
+// compile-time per-point constant.
+template <int NP, int P = 16>
 CP_HD int swz(int p) {
+    if (NP >= 256 && P == 8) return p ^ ((p >> 3) & 7) ^ (((p >> 6) & 1) << 3);
     if (NP >= 256) return p ^ ((p >> 4) & 15);
     return p;
 }
@@ -313,22 +339,35 @@ CP_HD void dft4_h13(cplx& x0, cplx& u1, cplx& x2, cplx& u3) {
     u3.im = __builtin_fma(H, d1r, d0i);
 }
 
+// stage S0 of the outer half: twiddles w16^(r0 S0) on x[r0 + 4 S0], then the DFT4 over r0 in place
+// (afterwards x[4 S0 + s1] holds X[S0 + 4 s1])
+template <int S0>
+CP_HD void dft16_outer_stage(cplx* x) {
+    if (S0 == 0) {
+        dft4(x[0], x[1], x[2], x[3]);
+    } else if (S0 == 1) {
+        mul_w16<1>(x[4 + 1]);
+        x[4 + 2] = rot_w16_2_unscaled(x[4 + 2]);
+        mul_w16<3>(x[4 + 3]);
+        dft4_h2(x[4], x[5], x[6], x[7]);
+    } else if (S0 == 2) {
+        x[8 + 1] = rot_w16_2_unscaled(x[8 + 1]);
+        mul_w16<4>(x[8 + 2]);
+        x[8 + 3] = rot_w16_6_unscaled(x[8 + 3]);
+        dft4_h13(x[8], x[9], x[10], x[11]);
+    } else {
+        mul_w16<3>(x[12 + 1]);
+        x[12 + 2] = rot_w16_6_unscaled(x[12 + 2]);
+        mul_w16<9>(x[12 + 3]);
+        dft4_h2(x[12], x[13], x[14], x[15]);
+    }
+}
+
 CP_HD void dft16_outer(cplx* x) {
-    // twiddles w16^(r0 s0) on x[r0 + 4 s0]
-    mul_w16<1>(x[1 + 4]);
-    x[1 + 8] = rot_w16_2_unscaled(x[1 + 8]);
-    mul_w16<3>(x[1 + 12]);
-    x[2 + 4] = rot_w16_2_unscaled(x[2 + 4]);
-    mul_w16<4>(x[2 + 8]);
-    x[2 + 12] = rot_w16_6_unscaled(x[2 + 12]);
-    mul_w16<3>(x[3 + 4]);
-    x[3 + 8] = rot_w16_6_unscaled(x[3 + 8]);
-    mul_w16<9>(x[3 + 12]);
-    // outer DFT4 over r0 for each s0 (in place on x[4 s0 + r0], slot r0 := s1)
-    dft4(x[0], x[1], x[2], x[3]);
-    dft4_h2(x[4], x[5], x[6], x[7]);
-    dft4_h13(x[8], x[9], x[10], x[11]);
-    dft4_h2(x[12], x[13], x[14], x[15]);
+    dft16_outer_stage<0>(x);
+    dft16_outer_stage<1>(x);
+    dft16_outer_stage<2>(x);
+    dft16_outer_stage<3>(x);
     // x[4 s0 + s1] holds X[s0 + 4 s1]: 4x4 transpose (register renaming after unrolling)
     cplx t;
     t = x[1]; x[1] = x[4]; x[4] = t;
@@ -339,13 +378,24 @@ CP_HD void dft16_outer(cplx* x) {
     t = x[11]; x[11] = x[14]; x[14] = t;
 }
 
+CP_HD void dft16_inner(cplx* x) {
+    dft4(x[0], x[4], x[8], x[12]);
+    dft4(x[1], x[5], x[9], x[13]);
+    dft4(x[2], x[6], x[10], x[14]);
+    dft4(x[3], x[7], x[11], x[15]);
+}
+// points 0..3 and 12..15 structurally zero (zero-padded FFTLog input, n = NP/2): 8 instead of 16 additions each
+CP_HD void dft16_inner_zero_padded(cplx* x) {
+    dft4_mid(x[0], x[4], x[8], x[12]);
+    dft4_mid(x[1], x[5], x[9], x[13]);
+    dft4_mid(x[2], x[6], x[10], x[14]);
+    dft4_mid(x[3], x[7], x[11], x[15]);
+}
+
 template <>
 struct Dft<16> {
     static CP_HD void run(cplx* x) {
-        dft4(x[0], x[4], x[8], x[12]);
-        dft4(x[1], x[5], x[9], x[13]);
-        dft4(x[2], x[6], x[10], x[14]);
-        dft4(x[3], x[7], x[11], x[15]);
+        dft16_inner(x);
         dft16_outer(x);
     }
 };
@@ -354,11 +404,26 @@ struct Dft<16> {
 // n = NP/2): every inner DFT4 sees (0, x1, x2, 0) and costs 8 instead of 16 additions.
 struct Dft16ZeroPadded {
     static CP_HD void run(cplx* x) {
-        dft4_mid(x[0], x[4], x[8], x[12]);
-        dft4_mid(x[1], x[5], x[9], x[13]);
-        dft4_mid(x[2], x[6], x[10], x[14]);
-        dft4_mid(x[3], x[7], x[11], x[15]);
+        dft16_inner_zero_padded(x);
         dft16_outer(x);
+    }
+};
+
+// radix-8 butterfly whose points 0, 1, 6, 7 are structural zeros (zero-padded input at P = 8): both inner DFT4s
+// (even and odd points) see (0, a, b, 0)
+struct Dft8ZeroPadded {
+    static CP_HD void run(cplx* x) {
+        cplx e0 = x[0], e1 = x[2], e2 = x[4], e3 = x[6];
+        cplx o0 = x[1], o1 = x[3], o2 = x[5], o3 = x[7];
+        dft4_mid(e0, e1, e2, e3);
+        dft4_mid(o0, o1, o2, o3);
+        mul_w16<2>(o1);
+        mul_w16<4>(o2);
+        mul_w16<6>(o3);
+        x[0].re = e0.re + o0.re; x[0].im = e0.im + o0.im; x[4].re = e0.re - o0.re; x[4].im = e0.im - o0.im;
+        x[1].re = e1.re + o1.re; x[1].im = e1.im + o1.im; x[5].re = e1.re - o1.re; x[5].im = e1.im - o1.im;
+        x[2].re = e2.re + o2.re; x[2].im = e2.im + o2.im; x[6].re = e2.re - o2.re; x[6].im = e2.im - o2.im;
+        x[3].re = e3.re + o3.re; x[3].im = e3.im + o3.im; x[7].re = e3.re - o3.re; x[7].im = e3.im - o3.im;
     }
 };
 
@@ -390,7 +455,7 @@ struct Pass {
     //   M == 1, R 16 : bits 4..7 are beta & 15              -> base(t, i) ^ (r * 16)
     static CP_HD unsigned lds_base(int t, int i) {
         const unsigned beta = (unsigned)(t + T * i);
-        if (NP >= 256 && M % 256 == 0) {
+        if (NP >= 256 && P == 16 && M % 256 == 0) {
             const unsigned b = beta / M, j = beta % M;
             return (b * L + (j ^ ((j >> 4) & 15u))) * 16u;
         } else if (NP >= 256 && M == 16 && R == 16) {
@@ -399,14 +464,24 @@ struct Pass {
         } else if (NP >= 256 && M == 1 && R == 16) {
             return beta * 256u + (beta & 15u) * 16u;
         }
-        return 0u;
+        return (unsigned)swz<NP, P>(elem(t, i, 0)) * 16u;
     }
     // base = lds_base(t, i) + the buffer's LDS address l0
     static CP_HD unsigned lds_off(int t, int i, int r, unsigned base, unsigned l0) {
-        if (NP >= 256 && M % 256 == 0) return base + (unsigned)r * (M * 16u);
+        if (NP >= 256 && P == 16 && M % 256 == 0) return base + (unsigned)r * (M * 16u);
         if (NP >= 256 && M == 16 && R == 16) return base ^ ((unsigned)r * 0x110u);
         if (NP >= 256 && M == 1 && R == 16) return base ^ ((unsigned)r * 16u);
-        return (unsigned)swz<NP>(elem(t, i, r)) * 16u + l0;
+        // any other shape: element = elem(t, i, 0) | M r (disjoint bits), so by linearity of the swizzle the address is
+        // base ^ (low bits of a constant) + (its bits from 4096 up, which the swizzle leaves alone: an immediate offset)
+        PointConst c = point_const(r);
+        return (base ^ c.lo) + c.hi;
+    }
+    struct PointConst {
+        unsigned lo, hi;
+    };
+    static CP_HD PointConst point_const(int r) {
+        const unsigned c = (unsigned)swz<NP, P>(M * r) * 16u;
+        return PointConst{c & 0xFFFu, c & ~0xFFFu};
     }
     // order in which a radix-16 butterfly consumes its points: (0, 8, 4, 12), (1, 9, 5, 13), ...; the LDS reads are issued
     // in that order so that the first additions can start after two of them
@@ -508,6 +583,66 @@ struct Pass {
         if (CP_ABLATE & 32) return;
 #pragma unroll
         for (int i = 0; i < NB; ++i) Dft<R>::run(x + i * R);
+    }
+    // Butterflies (+ the DIF twiddles w on the outputs when TW) + the LDS writes, in four stages for the single radix-16
+    // shape: each outer DFT4 is followed at once by the twiddles and the writes of its four outputs, so the LDS pipe
+    // drains under the arithmetic of the next stage instead of in one burst in front of the barrier.
+    template <bool ZERO_PADDED, bool TW>
+    static CP_HD void butterflies_store(int t, const cplx* w, cplx* lds, cplx* x) {
+        if constexpr (R == 16 && NB == 1 && CP_ABLATE == 0) {
+            const LdsView v(lds);
+            const unsigned base = lds_base(t, 0) + v.l0;
+            if (ZERO_PADDED) dft16_inner_zero_padded(x);
+            else dft16_inner(x);
+            stage_store<0, TW>(t, w, v, base, x);
+            stage_store<1, TW>(t, w, v, base, x);
+            stage_store<2, TW>(t, w, v, base, x);
+            stage_store<3, TW>(t, w, v, base, x);
+        } else if constexpr (R == 8 && NB == 1 && CP_ABLATE == 0) {
+            // radix 8 = 2 x 4: outputs k and k + 4 come from e_k +- o_k; four stages of two writes
+            const LdsView v(lds);
+            const unsigned base = lds_base(t, 0) + v.l0;
+            cplx e[4] = {x[0], x[2], x[4], x[6]}, o[4] = {x[1], x[3], x[5], x[7]};
+            if (ZERO_PADDED) {
+                dft4_mid(e[0], e[1], e[2], e[3]);
+                dft4_mid(o[0], o[1], o[2], o[3]);
+            } else {
+                dft4(e[0], e[1], e[2], e[3]);
+                dft4(o[0], o[1], o[2], o[3]);
+            }
+            mul_w16<2>(o[1]);
+            mul_w16<4>(o[2]);
+            mul_w16<6>(o[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cplx lo{e[k].re + o[k].re, e[k].im + o[k].im}, hi{e[k].re - o[k].re, e[k].im - o[k].im};
+                if (TW && M > 1) {
+                    if (k > 0) lo = cmul(lo, w[k]);
+                    hi = cmul(hi, w[k + 4]);
+                }
+                v.write(lds_off(t, 0, k, base, v.l0), lo);
+                v.write(lds_off(t, 0, k + 4, base, v.l0), hi);
+                CP_SCHED_FENCE();
+            }
+        } else {
+            if (ZERO_PADDED && R == 16) Dft16ZeroPadded::run(x);
+            else if (ZERO_PADDED && R == 8) Dft8ZeroPadded::run(x);
+            else butterflies(x);
+            if (TW) twiddle_apply(w, x);
+            store_lds(t, lds, x);
+        }
+    }
+    template <int S0, bool TW>
+    static CP_HD void stage_store(int t, const cplx* w, const LdsView& v, unsigned base, cplx* x) {
+        dft16_outer_stage<S0>(x);
+#pragma unroll
+        for (int s1 = 0; s1 < 4; ++s1) {
+            const int s = S0 + 4 * s1;  // output index of slot 4 S0 + s1
+            cplx y = x[4 * S0 + s1];
+            if (TW && M > 1 && s > 0) y = cmul(y, w[s]);
+            v.write(lds_off(t, 0, s, base, v.l0), y);
+        }
+        CP_SCHED_FENCE();
     }
     static CP_HD void dif(int t, const cplx* tw, cplx* x) {
         butterflies(x);

@@ -20,13 +20,13 @@ enum { CP_EXTRAP_CONST = 0, CP_EXTRAP_EDGE = 1, CP_EXTRAP_LOG = 2 };
 // Input front ends (how phase 0 pads the row):
 //   IN_GENERIC   any n / NP, constant or edge padding: clamped (always valid) loads + selects, branch-free
 //   IN_LOG       IN_GENERIC plus 'log' extrapolation (a pow() per padded element)
-//   IN_HALF      n == NP/2 and P == 16: the row occupies exactly r in [4, 12) of every thread's 16
-//                points (in_left = NP/4 = 4T, fftlog.py:149-153 with minfolds=2 and n a power of two);
+//   IN_HALF      n == NP/2 and P in {8, 16}: the row occupies exactly r in [P/4, 3P/4) of every thread's P
+//                points (in_left = NP/4 = (P/4) T, fftlog.py:149-153 with minfolds=2 and n a power of two);
 //                constant or edge padding
 //   IN_HALF_ZERO IN_HALF with zero padding (the reference default extrap=0): padded points are never formed
 // Output back ends:
 //   OUT_GENERIC  bounds-checked crop (any out_off / n_out, incl. keep_padding)
-//   OUT_HALF     n == NP/2, cropped output: exactly s in [4, 12) (out_left = NP/4)
+//   OUT_HALF     n == NP/2, cropped output: exactly s in [P/4, 3P/4) (out_left = NP/4)
 enum { IN_GENERIC = 0, IN_LOG = 1, IN_HALF = 2, IN_HALF_ZERO = 3 };
 enum { OUT_GENERIC = 0, OUT_HALF = 1 };
 
@@ -65,7 +65,9 @@ struct Fftlog {
     static CP_HD const cplx* lds_tw(const cplx* lds) {
         return lds + NP + (PL::tw_offset(I) - NP);
     }
-    static_assert((!HALF_IN && OUT_MODE != OUT_HALF) || (P == 16 && NPASS > 1), "HALF modes need P == 16 and NP > 16");
+    static_assert((!HALF_IN && OUT_MODE != OUT_HALF) || ((P == 16 || P == 8) && NPASS > 1), "HALF modes need P in {8, 16} and NP > P");
+    // HALF modes: the row occupies points r in [Q, Q + H) of every thread's P (Q = P/4 padded points on either side)
+    static constexpr int H = P / 2, Q = P / 4;
 
     // padded input element j of one row (reference pad(): fftlog.py:483-505); branch-free for constant / edge
     static CP_HD double fetch(const double* __restrict__ a, int j, const FftlogArgs& A) {
@@ -96,7 +98,7 @@ struct Fftlog {
             const long long drow = reinterpret_cast<const char*>(rb) - reinterpret_cast<const char*>(ra);
             const unsigned voff = (unsigned)(t & ~1) * 8u + (odd ? (unsigned)drow : 0u);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
+            for (int r = 0; r < H; ++r) {
                 const cplx v = ld_cplx(ra, voff, (unsigned)(T * r) * 8u);  // (lo, hi) = samples n, n + 1 of this lane's row
                 va[r] = v.re;
                 vb[r] = v.im;
@@ -105,7 +107,7 @@ struct Fftlog {
         }
 #endif
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < H; ++r) {
             if (CP_ABLATE & 8) {
                 va[r] = 1e-3 * t + r;
                 vb[r] = 2e-3 * t - r;
@@ -116,20 +118,20 @@ struct Fftlog {
         }
     }
 
-    // ... and consume: x[r + 4] = (va[r], vb[r]) * pre[t + T (r + 4)]; padded points from the constant / edge value
+    // ... and consume: x[r + Q] = (va[r], vb[r]) * pre[t + T (r + 4)]; padded points from the constant / edge value
     template <class ST>
     static CP_HD void load_input_half(int t, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
                                       const double* __restrict__ pre, const ST& st, cplx* x) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < H; ++r) {
             double a = st.va[r], b = st.vb[r];
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CP_NO_WIDE_IO)
             if (T >= 2 && !(CP_ABLATE & 8)) {  // (va, vb) hold (row[n], row[n+1]) of this lane's row: trade with the neighbour lane
                 lane_transpose2(a, b);
             }
 #endif
-            x[r + 4].re = a * st.fpre[r];
-            x[r + 4].im = has_b ? b * st.fpre[r] : 0.;
+            x[r + Q].re = a * st.fpre[r];
+            x[r + Q].im = has_b ? b * st.fpre[r] : 0.;
         }
         if constexpr (IN_MODE == IN_HALF) {
             const double la = A.ext_l == CP_EXTRAP_CONST ? A.val_l : ra[0];
@@ -137,16 +139,16 @@ struct Fftlog {
             const double ha = A.ext_r == CP_EXTRAP_CONST ? A.val_r : ra[A.n - 1];
             const double hb = A.ext_r == CP_EXTRAP_CONST ? A.val_r : rb[A.n - 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double fl = pre[t + T * r], fh = pre[t + T * (r + 12)];
+            for (int r = 0; r < Q; ++r) {
+                const double fl = pre[t + T * r], fh = pre[t + T * (r + 3 * Q)];
                 x[r].re = la * fl;
                 x[r].im = has_b ? lb * fl : 0.;
-                x[r + 12].re = ha * fh;
-                x[r + 12].im = has_b ? hb * fh : 0.;
+                x[r + 3 * Q].re = ha * fh;
+                x[r + 3 * Q].im = has_b ? hb * fh : 0.;
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = x[r + 12] = cplx{0., 0.};
+            for (int r = 0; r < Q; ++r) x[r] = x[r + 3 * Q] = cplx{0., 0.};
         }
     }
 
@@ -168,11 +170,11 @@ struct Fftlog {
     template <class ST>
     static CP_HD void store_output_half(int t, const FftlogArgs& A, double* __restrict__ oa, double* __restrict__ ob, bool has_b, int nxt_ker,
                                         ST& st, const cplx* x) {
-        double ya[8], yb[8];
+        double ya[H], yb[H];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            ya[s] = x[s + 4].re * st.fpost[s];
-            yb[s] = x[s + 4].im * st.fpost[s];
+        for (int s = 0; s < H; ++s) {
+            ya[s] = x[s + Q].re * st.fpost[s];
+            yb[s] = x[s + Q].im * st.fpost[s];
         }
         if (A.nker > 1) {
             CP_SCHED_FENCE();
@@ -182,7 +184,7 @@ struct Fftlog {
         if (CP_ABLATE & 16) {
             double acc = 0.;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc += ya[s] * yb[s];
+            for (int s = 0; s < H; ++s) acc += ya[s] * yb[s];
             if (acc == 1.2345e301) oa[t] = acc;  // keeps the results alive, never taken
             return;
         }
@@ -193,25 +195,25 @@ struct Fftlog {
             const bool odd = t & 1;
             const long long drow = reinterpret_cast<char*>(ob) - reinterpret_cast<char*>(oa);
             const unsigned voff = (unsigned)(t & ~1) * 8u + (odd ? (unsigned)drow : 0u);
-            cplx v[8];
+            cplx v[H];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < H; ++s) {
                 v[s].re = ya[s];
                 v[s].im = yb[s];
                 lane_transpose2(v[s].re, v[s].im);
             }
             if (has_b || !odd) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) st_cplx(oa, voff, (unsigned)(T * s) * 8u, v[s]);
+                for (int s = 0; s < H; ++s) st_cplx(oa, voff, (unsigned)(T * s) * 8u, v[s]);
             }
             return;
         }
 #endif
 #pragma unroll
-        for (int s = 0; s < 8; ++s) st_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
+        for (int s = 0; s < H; ++s) st_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
         if (has_b) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) st_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
+            for (int s = 0; s < H; ++s) st_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
         }
     }
 
@@ -243,8 +245,11 @@ struct Fftlog {
     //         when nker == 1) and the pair's rows, prefetched one whole pair ahead.
     struct State {
         cplx w[P];
-        double fpre[8], fpost[8];
-        double va[8], vb[8];
+        double fpre[H], fpost[H];
+        double va[H], vb[H];
+#if defined(CP_STAMPS)
+        unsigned long long fs[8], fs_last;  // fine stamps: [PH] LDS reads landed (PH 1..4), [5] U applied, [6] last twiddles applied
+#endif
     };
 
     template <int I>
@@ -265,9 +270,9 @@ struct Fftlog {
         const double* __restrict__ pre = A.pre + (long long)ker * NP;
         const double* __restrict__ post = A.post + (long long)ker * NP;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            st.fpre[r] = ld_f64(pre, (unsigned)t * 8u, (unsigned)(T * (r + 4)) * 8u);
-            st.fpost[r] = ld_f64(post, (unsigned)t * 8u, (unsigned)(T * (r + 4)) * 8u);
+        for (int r = 0; r < H; ++r) {
+            st.fpre[r] = ld_f64(pre, (unsigned)t * 8u, (unsigned)(T * (r + Q)) * 8u);
+            st.fpost[r] = ld_f64(post, (unsigned)t * 8u, (unsigned)(T * (r + Q)) * 8u);
         }
     }
 
@@ -320,6 +325,7 @@ struct Fftlog {
 #endif
         const double* pre = A.pre + (long long)ker * NP;
         const double* post = A.post + (long long)ker * NP;
+        CP_FS_BEGIN(st);
         if constexpr (NPASS == 1) {
             load_input(t, A, ra, rb, has_b, pre, x);
             Pass<NP, P, 0>::butterflies(x);
@@ -339,13 +345,8 @@ struct Fftlog {
             } else {
                 load_input(t, A, ra, rb, has_b, pre, x);
             }
-            if constexpr (IN_MODE == IN_HALF_ZERO) {
-                Dft16ZeroPadded::run(x);  // points 0..3 and 12..15 are structural zeros
-            } else {
-                Pass<NP, P, 0>::butterflies(x);
-            }
-            Pass<NP, P, 0>::twiddle_apply(st.w, x);
-            Pass<NP, P, 0>::store_lds(t, lds, x);
+            // IN_HALF_ZERO: points 0..3 and 12..15 are structural zeros
+            Pass<NP, P, 0>::template butterflies_store<IN_MODE == IN_HALF_ZERO, true>(t, st.w, lds, x);
             load_tables_for<1>(t, A, ker, st.w);
         } else if constexpr (PH < LAST) {
             constexpr int I = (PH < LAST) ? PH : 0;
@@ -354,31 +355,40 @@ struct Fftlog {
             Pass<NP, P, I>::load_lds(t, lds, x);
             Pass<NP, P, I>::twiddle_load_lds(t, lds_tw<I>(lds), st.w);
             CP_SCHED_FENCE();
-            Pass<NP, P, I>::butterflies(x);
-            Pass<NP, P, I>::twiddle_apply(st.w, x);
-            Pass<NP, P, I>::store_lds(t, lds, x);
+            CP_FS(st, PH);
+            Pass<NP, P, I>::template butterflies_store<false, true>(t, st.w, lds, x);
             load_tables_for<PH + 1>(t, A, ker, st.w);
         } else if constexpr (PH == LAST) {
             Pass<NP, P, LAST>::load_lds(t, lds, x);
+            CP_FS(st, PH);
             Pass<NP, P, LAST>::butterflies(x);  // M == 1: no twiddles
             mul_w(st.w, x);                     // U, digit-reversed order, 1/NP folded in
-            Pass<NP, P, LAST>::butterflies(x);
-            Pass<NP, P, LAST>::store_lds(t, lds, x);
+            CP_FS(st, 5);
+            Pass<NP, P, LAST>::template butterflies_store<false, false>(t, st.w, lds, x);
             load_tables_for<PH + 1>(t, A, ker, st.w);
         } else if constexpr (PH < NPH - 1) {
             constexpr int I = (PH > LAST && PH < NPH - 1) ? (NPH - 1 - PH) : 0;
             Pass<NP, P, I>::twiddle_load_lds(t, lds_tw<I>(lds), st.w);
             Pass<NP, P, I>::load_lds(t, lds, x);
             CP_SCHED_FENCE();
+            CP_FS(st, PH);
             Pass<NP, P, I>::twiddle_apply(st.w, x);
-            Pass<NP, P, I>::butterflies(x);
-            Pass<NP, P, I>::store_lds(t, lds, x);
+            Pass<NP, P, I>::template butterflies_store<false, false>(t, st.w, lds, x);
             load_tables_for<PH + 1>(t, A, ker, st.w);
         } else {
             Pass<NP, P, 0>::load_lds(t, lds, x);
+#if defined(__HIP_DEVICE_COMPILE__)
+            // LDS is free for the next pair once every wave has its values: synchronising here, a few instructions behind
+            // the previous barrier, costs far less than at the end of the pair, where the waves have drifted apart by the
+            // arithmetic and the stores of a whole phase.  (The host emulation runs the phases of all threads in turn.)
+            CP_FS(st, PH);
+            if (!(CP_ABLATE & 2)) __syncthreads();
+            CP_FS(st, 7);
+#endif
             // Nothing is loaded after this pair's stores (w keeps the pass-0 twiddles for the next pair's phase 0), so the
             // stores stay in flight while the next pair starts.
             Pass<NP, P, 0>::twiddle_apply(st.w, x);
+            CP_FS(st, 6);
             Pass<NP, P, 0>::butterflies(x);
             if constexpr (HALF_IN && OUT_MODE == OUT_HALF) {
                 store_output_half(t, A, oa, ob, has_b, nxt_ker, st, x);

@@ -31,7 +31,7 @@ enum { VAR_GENERIC = 0, VAR_LOG = 1, VAR_HALF = 2, VAR_HALF_ZERO = 3, VAR_COUNT 
 
 inline int select_variant(int np, int p, int n, int ext_l, double val_l, int ext_r, double val_r, int keep_padding) {
     if (ext_l == 2 || ext_r == 2) return VAR_LOG;
-    if (p == 16 && np >= CP_FFTLOG_HALF_MIN_NP && 2 * n == np && !keep_padding) {
+    if ((p == 16 || p == 8) && np >= CP_FFTLOG_HALF_MIN_NP && 2 * n == np && !keep_padding) {
         if (ext_l == 0 && ext_r == 0 && val_l == 0. && val_r == 0.) return VAR_HALF_ZERO;
         return VAR_HALF;
     }

@@ -30,11 +30,7 @@ bool find_launcher_g4(int npad, Launcher* out);
 #if defined(__HIPCC__)
 #if defined(CP_STAMPS)
 // diagnostic build (tools/fftlog_microbench.hip -DCP_STAMPS): per-wave cycle sums of each phase's work and barrier wait
-__device__ __forceinline__ unsigned long long cp_stamp() {
-    unsigned long long t;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
+// (cp_stamp: cp_fft_core.h)
 #define CP_STAMP_DECL , unsigned long long* cp_stamp_acc
 #define CP_STAMP_ARG , cp_stamp_acc
 #else
@@ -124,6 +120,7 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
 #if defined(CP_STAMPS)
     unsigned long long cp_stamp_acc[2 * F::NPH] = {0};
+    for (int i = 0; i < 8; ++i) st.fs[i] = 0;
     const unsigned long long cp_t_begin = cp_stamp();
 #endif
     for (;;) {
@@ -135,7 +132,8 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
 #if defined(CP_STAMPS)
         const unsigned long long sb = cp_stamp();
 #endif
-        if (F::NPASS > 1 && !(CP_ABLATE & 2)) __syncthreads();  // LDS is reused by the next pair
+        // no barrier here: the one that protects LDS against the next pair's writes sits in the last phase, right behind
+        // its LDS reads (Fftlog::phase), where the waves have just left the previous barrier and are still in step
 #if defined(CP_STAMPS)
         cp_stamp_acc[2 * F::NPH - 1] += cp_stamp() - sb;
 #endif
@@ -145,16 +143,17 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
 #if defined(CP_STAMPS)
     if ((threadIdx.x & 63) == 0) {  // the stamp buffer is aliased onto the (unused) tail of A.post by the microbench
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<double*>(A.val_stamp)) +
-                                  ((size_t)blockIdx.x * (NP / P / 64) + threadIdx.x / 64) * (2 * F::NPH + 1);
+                                  ((size_t)blockIdx.x * (NP / P / 64) + threadIdx.x / 64) * (2 * F::NPH + 1 + 8);
         for (int i = 0; i < 2 * F::NPH; ++i) dst[i] = cp_stamp_acc[i];
         dst[2 * F::NPH] = cp_stamp() - cp_t_begin;
+        for (int i = 0; i < 8; ++i) dst[2 * F::NPH + 1 + i] = st.fs[i];
     }
 #endif
 }
 
 template <int NP, int P>
 constexpr bool has_half() {
-    return P == 16 && NP >= CP_FFTLOG_HALF_MIN_NP;
+    return (P == 16 || P == 8) && NP >= CP_FFTLOG_HALF_MIN_NP;
 }
 
 template <int NP, int P>

@@ -70,7 +70,7 @@ static int emulate(int n, int nker, const double* pre, const double* post, const
         const bool first = p == 0;
         // same variant selection as the library (cp_fftlog.hip: select_variant)
         const int v = select_variant(NP, P, n, ext_l, val_l, ext_r, val_r, keep_padding);
-        if constexpr (P == 16 && (NP > 16)) {
+        if constexpr ((P == 16 || P == 8) && (NP > 16)) {
             if (v == VAR_HALF_ZERO) { run_pair<NP, P, IN_HALF_ZERO, OUT_HALF>(A, ra, rb, oa, ob, has_b, ker, lds.data(), nra, nrb, nker_, pf, first); continue; }
             if (v == VAR_HALF) { run_pair<NP, P, IN_HALF, OUT_HALF>(A, ra, rb, oa, ob, has_b, ker, lds.data(), nra, nrb, nker_, pf, first); continue; }
         }

@@ -24,12 +24,18 @@ using namespace cpfft;
 #ifndef MB_NP
 #define MB_NP 4096
 #endif
+#ifndef MB_P
+#define MB_P 16
+#endif
+#ifndef MB_GENERIC  // 1: the generic front / back ends instead of the HALF_ZERO / HALF flagship variant
+#define MB_GENERIC 0
+#endif
 #ifndef MB_WGS_PER_CU
 #define MB_WGS_PER_CU 2
 #endif
 
 int main(int argc, char** argv) {
-    constexpr int NP = MB_NP, P = 16, N = NP / 2;
+    constexpr int NP = MB_NP, P = MB_P, N = NP / 2;
     const long long nbatch = argc > 1 ? atoll(argv[1]) : 100000;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
     std::vector<double> in((size_t)nbatch * N), pre(NP), post(NP), u(2 * (NP / 2 + 1));
@@ -66,7 +72,11 @@ int main(int argc, char** argv) {
     CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
     const int grid = ncu * MB_WGS_PER_CU;
     constexpr int T = Plan<NP, P>::T, lds = Fftlog<NP, P>::LDS_BYTES;
+#if MB_GENERIC
+    auto kern = fftlog_kernel<NP, P, IN_GENERIC, OUT_GENERIC>;
+#else
     auto kern = fftlog_kernel<NP, P, IN_HALF_ZERO, OUT_HALF>;
+#endif
     if (lds > 64 * 1024) CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -84,7 +94,7 @@ int main(int argc, char** argv) {
            nbatch * 16. * N / ms * 1e-6);
 #if defined(CP_STAMPS)
     {
-        constexpr int NPH = Fftlog<NP, P>::NPH, W = T / 64, K = 2 * NPH + 1;
+        constexpr int NPH = Fftlog<NP, P>::NPH, W = T / 64, K = 2 * NPH + 1 + 8;
         std::vector<unsigned long long> h((size_t)grid * W * K);
         CHECK(hipMemcpy(h.data(), d_stamp, h.size() * 8, hipMemcpyDeviceToHost));
         std::vector<double> avg(K, 0.);
@@ -93,7 +103,10 @@ int main(int argc, char** argv) {
         const double npw = (double)((nbatch + 1) / 2) / grid;  // pairs per workgroup
         printf("per pair per wave [s_memtime ticks]: ");
         for (int ph = 0; ph < NPH; ++ph) printf(" work%d=%.0f bar%d=%.0f |", ph, avg[2 * ph] / npw, ph, avg[2 * ph + 1] / npw);
-        printf(" total=%.0f (whole kernel %.0f ticks = %.4f ms -> %.1f MHz)\n", avg[K - 1] / npw, avg[K - 1], ms, avg[K - 1] / ms * 1e-3);
+        printf(" total=%.0f (whole kernel %.0f ticks = %.4f ms -> %.1f MHz)\n", avg[2 * NPH] / npw, avg[2 * NPH], ms, avg[2 * NPH] / ms * 1e-3);
+        printf("fine: reads landed ph1..4 = %.0f %.0f %.0f %.0f | U applied %.0f | last twiddles applied %.0f | barrier in last phase %.0f\n",
+               avg[2 * NPH + 2] / npw, avg[2 * NPH + 3] / npw, avg[2 * NPH + 4] / npw, avg[2 * NPH + 5] / npw, avg[2 * NPH + 6] / npw,
+               avg[2 * NPH + 7] / npw, avg[2 * NPH + 8] / npw);
     }
 #endif
     return 0;
