@@ -107,7 +107,7 @@ __device__ __forceinline__ void lane_transpose2(double& lo, double& hi) {
         "v_cndmask_b32_dpp %3, %7, %5, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
         : "=&v"(a.x), "=&v"(a.y), "=&v"(b.x), "=&v"(b.y)
         : "v"(h.x), "v"(h.y), "v"(l.x), "v"(l.y), "s"(0x5555555555555555ull)
-        : "vcc");
+        : "vcc", "scc");  // s_not_b64 writes SCC: without the clobber the compiler may keep a carry alive across the block
     lo = __builtin_bit_cast(double, a);
     hi = __builtin_bit_cast(double, b);
 }

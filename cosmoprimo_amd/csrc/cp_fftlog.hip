@@ -187,7 +187,12 @@ extern "C" int cp_fftlog_execute(const cp_fftlog_plan* p, const double* d_in, do
     DeviceGuard guard(p->device);
     if (!guard.ok) return cp::fail(CP_EDEVICE, "cp_fftlog_execute: cannot select device %d", p->device);
     const int variant = select_variant(p->npad, p->l.p, p->n, extrap_left, val_left, extrap_right, val_right, keep_padding);
-    p->l.launch(variant, A, grid_for(p, variant, nbatch), static_cast<hipStream_t>(stream));
+    const int grid = grid_for(p, variant, nbatch);
+    // the kernel walks the rows with 32-bit element steps (cp_fftlog_kernel.h: PairWalk): nker rows, and 2 grid rows, of
+    // the padded length must stay below 2^31 elements (Np <= 8192: nker < 262144)
+    if ((long long)p->nker * p->npad >= (1LL << 31) || 2LL * grid * p->npad >= (1LL << 31))
+        return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_execute: nker = %d kernels of padded size %d exceed the row-walk range", p->nker, p->npad);
+    p->l.launch(variant, A, grid, static_cast<hipStream_t>(stream));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_execute: launch failed: %s", hipGetErrorString(e));
     return CP_OK;

@@ -59,27 +59,61 @@ __device__ __forceinline__ void run_phases(int t, const FftlogArgs& A, const dou
     }
 }
 
-// rows of pair p: batch items (2 q, 2 q + 1) of kernel `ker`; an incomplete last pair aliases row b to row a
+// Rows of pair p = (q, ker): batch items (2 q, 2 q + 1) of kernel `ker`, p = q nker + ker; an incomplete last pair (odd nbatch,
+// q = nhalf - 1) aliases row b to row a.  A workgroup walks p, p + G, p + 2 G, ... (G = gridDim.x) incrementally: ker and the
+// element offsets of row a advance by constants computed once per workgroup.  The direct form costs a 64-bit division and six
+// 64-bit multiplications in scalar instructions per pair and per wave (~250 instructions); the walk is kept small (32-bit steps)
+// because scalar registers spilled to VGPR lanes inside the pair loop cost more than the arithmetic they save.
 struct PairRows {
-    const double* ra;
-    const double* rb;
-    double* oa;
-    double* ob;
+    long long in_off, out_off;  // element offsets of row a in `in` / `out`
     int ker;
     int has_b;  // int, not bool: no padding bytes (a padded struct copy goes through scratch memory)
 };
 
-__device__ __forceinline__ PairRows pair_rows(const FftlogArgs& A, long long p) {
-    PairRows r;
-    r.ker = (int)(p % A.nker);
-    const long long b0 = 2 * (p / A.nker);
-    r.has_b = b0 + 1 < A.nbatch;
-    const long long b1 = r.has_b ? b0 + 1 : b0;
-    r.ra = A.in + (b0 * A.nker + r.ker) * A.n;
-    r.rb = A.in + (b1 * A.nker + r.ker) * A.n;
-    r.oa = A.out + (b0 * A.nker + r.ker) * A.n_out;
-    r.ob = A.out + (b1 * A.nker + r.ker) * A.n_out;
-    return r;
+struct PairWalk {
+    PairRows cur;
+    long long p, p_last_q;              // pair index; first pair index with q = nhalf - 1
+    unsigned in_step, out_step;         // per step of G pairs, without the wrap of ker    (G (2 n) < 2^31: see cp_fftlog.hip)
+    unsigned in_b, out_b;               // row b - row a = nker rows; also the extra step when ker wraps around nker
+    int dker, odd;                      // G mod nker; nbatch odd
+};
+
+__device__ __forceinline__ void pair_walk_flags(const FftlogArgs& A, PairWalk& w) {
+    w.cur.has_b = !(w.odd && w.p >= w.p_last_q);
+}
+
+__device__ __forceinline__ PairWalk pair_walk_begin(const FftlogArgs& A, long long p, unsigned G) {
+    PairWalk w;
+    const long long q = p / A.nker;
+    const unsigned dq = G / (unsigned)A.nker;
+    w.p = p;
+    w.cur.ker = (int)(p - q * A.nker);
+    w.dker = (int)(G - dq * (unsigned)A.nker);
+    const long long row = 2 * q * A.nker + w.cur.ker;
+    const unsigned drow = 2u * dq * (unsigned)A.nker + (unsigned)w.dker;
+    w.cur.in_off = row * A.n;
+    w.cur.out_off = row * A.n_out;
+    w.in_step = drow * (unsigned)A.n;
+    w.out_step = drow * (unsigned)A.n_out;
+    w.in_b = (unsigned)A.nker * (unsigned)A.n;
+    w.out_b = (unsigned)A.nker * (unsigned)A.n_out;
+    w.odd = (int)(A.nbatch & 1);
+    w.p_last_q = ((A.nbatch + 1) / 2 - 1) * A.nker;
+    pair_walk_flags(A, w);
+    return w;
+}
+
+__device__ __forceinline__ void pair_walk_next(const FftlogArgs& A, PairWalk& w, unsigned G) {
+    w.p += G;
+    w.cur.ker += w.dker;
+    w.cur.in_off += w.in_step;
+    w.cur.out_off += w.out_step;
+    if (w.cur.ker >= A.nker) {  // q advances by one more: + 2 nker - nker rows
+        w.cur.ker -= A.nker;
+        w.cur.in_off += w.in_b;
+        w.cur.out_off += w.out_b;
+    }
+    pair_walk_flags(A, w);
 }
 
 // One workgroup = T threads = one packed pair of rows per loop iteration (persistent over pairs).
@@ -108,8 +142,12 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
         for (int i = 0; i < 1; ++i) __builtin_amdgcn_s_sleep(100);  // ~6400 clk ~ 3 us start stagger
     }
 #endif
-    PairRows cur = pair_rows(A, p);
-    F::init_state(t, A, cur.ra, cur.rb, cur.ker, st);
+    PairWalk walk = pair_walk_begin(A, p, gridDim.x);
+    PairRows cur = walk.cur;
+    {
+        const double* ra = A.in + cur.in_off;
+        F::init_state(t, A, ra, ra + (cur.has_b ? walk.in_b : 0u), cur.ker, st);
+    }
     if constexpr (F::NPASS > 1) {
         F::fill_lds_tables(t, A, lds);
         __syncthreads();
@@ -124,10 +162,14 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
     const unsigned long long cp_t_begin = cp_stamp();
 #endif
     for (;;) {
-        const long long pn = p + gridDim.x;
-        const bool more = pn < npairs;
-        const PairRows nxt = more ? pair_rows(A, pn) : cur;
-        run_phases<NP, P, IM, OM, 0>(t, A, cur.ra, cur.rb, cur.oa, cur.ob, cur.has_b, cur.ker, lds, nxt.ra, nxt.rb, nxt.ker, st CP_STAMP_ARG);
+        const bool more = walk.p + gridDim.x < npairs;
+        if (more) pair_walk_next(A, walk, gridDim.x);
+        const PairRows nxt = walk.cur;  // == cur on the last pair: its prefetch re-reads the rows it already has
+        const double* ra = A.in + cur.in_off;
+        double* oa = A.out + cur.out_off;
+        const double* nra = A.in + nxt.in_off;
+        run_phases<NP, P, IM, OM, 0>(t, A, ra, ra + (cur.has_b ? walk.in_b : 0u), oa, oa + (cur.has_b ? walk.out_b : 0u), cur.has_b, cur.ker,
+                                     lds, nra, nra + (nxt.has_b ? walk.in_b : 0u), nxt.ker, st CP_STAMP_ARG);
         if (!more) break;
 #if defined(CP_STAMPS)
         const unsigned long long sb = cp_stamp();
@@ -137,7 +179,6 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
 #if defined(CP_STAMPS)
         cp_stamp_acc[2 * F::NPH - 1] += cp_stamp() - sb;
 #endif
-        p = pn;
         cur = nxt;
     }
 #if defined(CP_STAMPS)

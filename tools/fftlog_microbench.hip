@@ -27,7 +27,7 @@ using namespace cpfft;
 #ifndef MB_P
 #define MB_P 16
 #endif
-#ifndef MB_GENERIC  // 1: the generic front / back ends instead of the HALF_ZERO / HALF flagship variant
+#ifndef MB_GENERIC  // 1: the generic front / back ends; 2: the HALF front end with 'edge' padding; 0: HALF_ZERO (flagship)
 #define MB_GENERIC 0
 #endif
 #ifndef MB_WGS_PER_CU
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice));
     FftlogArgs A;
     A.in = d_in; A.out = d_out; A.nbatch = nbatch; A.nker = 1; A.n = N; A.in_left = NP / 4; A.out_off = NP / 4; A.n_out = N;
-    A.ext_l = A.ext_r = 0; A.val_l = A.val_r = 0.; A.pre = d_pre; A.post = d_post; A.u = d_u; A.tw = d_tw;
+    A.ext_l = A.ext_r = MB_GENERIC == 2 ? 1 : 0; A.val_l = A.val_r = 0.; A.pre = d_pre; A.post = d_post; A.u = d_u; A.tw = d_tw;
 #if defined(CP_STAMPS)
     unsigned long long* d_stamp;
     const size_t nstamp = (size_t)2048 * 8 * 16;
@@ -72,7 +72,9 @@ int main(int argc, char** argv) {
     CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
     const int grid = ncu * MB_WGS_PER_CU;
     constexpr int T = Plan<NP, P>::T, lds = Fftlog<NP, P>::LDS_BYTES;
-#if MB_GENERIC
+#if MB_GENERIC == 2  // 'edge' padding through the HALF front end
+    auto kern = fftlog_kernel<NP, P, IN_HALF, OUT_HALF>;
+#elif MB_GENERIC
     auto kern = fftlog_kernel<NP, P, IN_GENERIC, OUT_GENERIC>;
 #else
     auto kern = fftlog_kernel<NP, P, IN_HALF_ZERO, OUT_HALF>;
