@@ -1,7 +1,8 @@
 """MI355X-native implementation of cosmoprimo's FFTLog / P(k) hot path (same API names as cosmoprimo)."""
 from .fftlog import (FFTlog, HankelTransform, PowerToCorrelation, CorrelationToPower, TophatVariance, GaussianVariance, pad,
                      BesselJKernel, SphericalBesselJKernel, TophatKernel, TophatSqKernel, GaussianKernel, GaussianSqKernel)
-from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D
+from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, CorrelationFunctionInterpolator1D,
+                           CorrelationFunctionInterpolator2D)
 from .cosmology import (Cosmology, Background, Thermodynamics, Primordial, Transfer, Fourier, CosmologyError, CosmologyInputError,
                         CosmologyComputationError)
 from . import eisenstein_hu, eisenstein_hu_nowiggle, bbks  # noqa: F401  (registers the engines)

@@ -20,7 +20,7 @@ import inspect
 import numpy as np
 
 from . import _device as dv
-from .fftlog import PowerToCorrelation, TophatVariance
+from .fftlog import CorrelationToPower, PowerToCorrelation, TophatVariance
 from .spline import LinearOperator, dense_operator
 
 
@@ -450,12 +450,19 @@ class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
         self._rsigma8sq = 1.
         self._rsigma8sq = sigma8**2 / self.sigma8()**2
 
-    def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
-        """Transform into a correlation function with FFTLog (reference interpolator.py:584-605): returns ``(s, xi)`` arrays (xi shape (nk,) + columns)."""
+    def to_xi_arrays(self, nk=1024, fftlog_kwargs=None):
+        """FFTLog transform to the correlation function on the FFTLog grid: ``(s, xi)`` arrays, xi of shape (nk,) + columns."""
         k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
         s, xi = PowerToCorrelation(k, complex=False, device=self.device, **(fftlog_kwargs or {}))(self._rows(k))
         cs = self._colshape()
         return s.cpu().numpy(), xi.T.reshape((nk,) + cs).cpu().numpy()
+
+    def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
+        """Transform into a :class:`CorrelationFunctionInterpolator1D` with FFTLog (reference interpolator.py:584-605)."""
+        s, xi = self.to_xi_arrays(nk=nk, fftlog_kwargs=fftlog_kwargs)
+        default_params = dict(interp_s='log', interp_order_s=self.interp_order_k)
+        default_params.update(kwargs)
+        return CorrelationFunctionInterpolator1D(s, xi=xi, device=self.device, **default_params)
 
 
 class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
@@ -643,10 +650,306 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         self.extrap_kmin, self.extrap_kmax = default_params['extrap_kmin'], default_params['extrap_kmax']
         return PowerSpectrumInterpolator1D(self.k, pk, device=self.device, **default_params)
 
-    def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
+    def to_xi_arrays(self, nk=1024, fftlog_kwargs=None):
         """FFTLog transform to the correlation function on the (s, z) grid, growth factor left out as in the reference
-        (interpolator.py:965-987, ``ignore_growth=True``): returns ``(s, z, xi)`` with xi (batch..., nk, nz)."""
+        (interpolator.py:965-987, ``ignore_growth=True``): ``(s, z, xi)`` arrays with xi (batch..., nk, nz)."""
         k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
         rows = self._rows_z(self.z, ignore_growth=True)(k)     # (batch..., nz, nk)
         s, xi = PowerToCorrelation(k, complex=False, device=self.device, **(fftlog_kwargs or {}))(rows)
         return s.cpu().numpy(), self.z, xi.transpose(-1, -2).cpu().numpy()
+
+    def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
+        """Transform into a :class:`CorrelationFunctionInterpolator2D` with FFTLog (reference interpolator.py:965-987).
+        A batch of cosmologies has no tabulated interpolator: use :meth:`to_xi_arrays`."""
+        s, z, xi = self.to_xi_arrays(nk=nk, fftlog_kwargs=fftlog_kwargs)
+        if xi.ndim > 2:
+            raise NotImplementedError('to_xi() of a batch of cosmologies: use to_xi_arrays()')
+        default_params = dict(interp_s='log', interp_order_s=self.interp_order_k, interp_order_z=self.interp_order_z, growth_factor_sq=self.growth_factor_sq)
+        default_params.update(kwargs)
+        return CorrelationFunctionInterpolator2D(s, z=z, xi=xi, device=self.device, **default_params)
+
+
+def get_default_s_callable():
+    """Default separations of interpolators built from callables (reference interpolator.py:30-31)."""
+    return np.logspace(-6., 2., 500)
+
+
+class _BaseCorrelationFunctionInterpolator(object):
+
+    """Base class for correlation function interpolators (reference interpolator.py:990-1071)."""
+
+    def _prepare(self, s, xi, z=None, interp_s='log'):
+        self.s = _host(s).ravel()
+        self._xi = _host(xi)
+        if self._xi.ndim > 1:
+            self._xi = self._xi.reshape(self.s.shape + (-1,))
+        ix = np.argsort(self.s)
+        self.s, self._xi = self.s[ix], self._xi[ix]
+        if z is not None:
+            self.z = _host(z).ravel()
+            ix = np.argsort(self.z)
+            self.z, self._xi = self.z[ix], self._xi[:, ix]
+        self.interp_s = str(interp_s)
+        return self.s, self._xi
+
+    def params(self):
+        """Return interpolator parameter dictionary."""
+        return {name: getattr(self, name) for name in self.default_params}
+
+    def as_dict(self):
+        """Return interpolator as a dictionary."""
+        state = self.params()
+        for name in ['s', 'xi']:
+            state[name] = getattr(self, name)
+        if hasattr(self, 'z'):
+            state['z'] = self.z
+        return state
+
+    def clone(self, **kwargs):
+        """Clone interpolator, i.e. return a deepcopy with (possibly) other attributes in ``kwargs``."""
+        return self.__class__(**{**self.as_dict(), **kwargs})
+
+    def deepcopy(self):
+        """Deep copy interpolator (interpolators built from callables are re-tabulated at ``s``, as in the reference)."""
+        return self.__class__(**self.as_dict())
+
+    @property
+    def smin(self):
+        """Minimum (interpolated) ``s`` value."""
+        return self.s[0]
+
+    @property
+    def smax(self):
+        """Maximum (interpolated) ``s`` value."""
+        return self.s[-1]
+
+    @property
+    def extrap_smin(self):
+        """Minimum (extrapolated) ``s`` value (same as minimum interpolated value)."""
+        return self.s[0]
+
+    @property
+    def extrap_smax(self):
+        """Maximum (extrapolated) ``s`` value (same as maximum interpolated value)."""
+        return self.s[-1]
+
+
+class CorrelationFunctionInterpolator1D(_BaseCorrelationFunctionInterpolator):
+
+    """1D correlation function interpolator: lin-y natural spline in (log) s, no extrapolation (reference interpolator.py:1074-1222)."""
+
+    def __init__(self, s, xi, interp_s='log', interp_order_s=3, device=None):
+        self._rsigma8sq = 1.
+        self.device = dv.resolve_device(device, xi)
+        s, xi = self._prepare(s, xi, interp_s=interp_s)
+        self.interp_order_s = int(interp_order_s)
+        self._interp = Interpolator1D(s, xi, k=self.interp_order_s, interp_x=self.interp_s, assume_sorted=True, device=self.device)
+        self.is_from_callable = False
+
+    default_params = _get_default_kwargs(__init__, start=3, remove=('device',))
+
+    @property
+    def xi(self):
+        """Correlation function array (evaluated at ``s`` if built from a callable), with normalisation."""
+        if self.is_from_callable:
+            return self(self.s)
+        return self._xi * self._rsigma8sq
+
+    @classmethod
+    def from_callable(cls, s=None, xi_callable=None, device=None):
+        """Build from ``xi_callable(s)`` -> array / device tensor of shape (ns,) or (ns, ncol) (reference interpolator.py:1109-1139)."""
+        if s is None:
+            s = get_default_s_callable()
+        self = cls.__new__(cls)
+        self.__dict__.update(self.default_params)
+        self._rsigma8sq = 1.
+        self.device = dv.resolve_device(device)
+        self.s = np.sort(_host(s).ravel())
+        self.is_from_callable = True
+        self._interp = xi_callable
+        return self
+
+    def _eval_device(self, sh, bounds_error=False):
+        """xi(s) at host separations ``sh`` (flat) as a device tensor (ns,) + trailing column shape."""
+        torch = dv.torch()
+        if self.is_from_callable:
+            mask_s, = _mask_bounds([sh], [(self.smin, self.smax)], bounds_error=bounds_error)
+            out = dv.to_device(self._interp(sh), self.device)
+            mask = torch.as_tensor(mask_s, device=self.device).reshape((-1,) + (1,) * (out.ndim - 1))
+            out = torch.where(mask, out, torch.full_like(out, float('nan')))
+        else:
+            out = self._interp(torch.as_tensor(sh, device=self.device), bounds_error=bounds_error)
+        return out * self._rsigma8sq
+
+    def __call__(self, s, bounds_error=False):
+        """Evaluate the correlation function at separations ``s``; NaN outside [smin, smax] (``bounds_error`` raises)."""
+        like_torch = dv.is_torch(s)
+        dtype = dv.float_dtype(s)
+        sh = _host(s)
+        out = self._eval_device(sh.ravel(), bounds_error=bounds_error)
+        return _finish(out, dtype, like_torch, sh.shape + tuple(out.shape[1:]))
+
+    def sigma_d(self, **kwargs):
+        """R.m.s. of the displacement field, through :meth:`to_pk` (reference interpolator.py:1169-1175)."""
+        return self.to_pk().sigma_d(**kwargs)
+
+    def sigma_r(self, r, **kwargs):
+        """R.m.s. of perturbations in a sphere of radius r, through :meth:`to_pk` (reference interpolator.py:1177-1183)."""
+        return self.to_pk().sigma_r(r, **kwargs)
+
+    def sigma8(self, **kwargs):
+        """R.m.s. of perturbations in a sphere of 8."""
+        return self.sigma_r(8., **kwargs)
+
+    def rescale_sigma8(self, sigma8=1.):
+        """Rescale the correlation function to the provided ``sigma8`` normalisation."""
+        self._rsigma8sq = 1.
+        self._rsigma8sq = sigma8**2 / self.sigma8()**2
+
+    def to_pk(self, ns=1024, fftlog_kwargs=None, **kwargs):
+        """Transform into a :class:`PowerSpectrumInterpolator1D` with FFTLog (reference interpolator.py:1201-1222)."""
+        s = np.geomspace(self.extrap_smin, self.extrap_smax, ns)
+        out = self._eval_device(s)
+        cs = tuple(out.shape[1:])
+        rows = out.reshape(ns, -1).T.contiguous() if out.ndim > 1 else out[None, :]
+        k, pk = CorrelationToPower(s, complex=False, device=self.device, **(fftlog_kwargs or {}))(rows)
+        default_params = dict(interp_k='log', interp_order_k=self.interp_order_s)
+        default_params.update(kwargs)
+        return PowerSpectrumInterpolator1D(k.cpu().numpy(), pk=pk.T.reshape((ns,) + cs), device=self.device, **default_params)
+
+
+class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
+
+    """2D correlation function interpolator (reference interpolator.py:1225-1498)."""
+
+    def __init__(self, s, z, xi=None, interp_s='log', interp_order_s=3, interp_order_z=None, growth_factor_sq=None, device=None):
+        self._rsigma8sq = 1.
+        self.growth_factor_sq = growth_factor_sq
+        self.device = dv.resolve_device(device, xi)
+        s, xi = self._prepare(s, xi, z=z, interp_s=interp_s)
+        is2d = self._xi.shape[1] > 1
+        # the reference does int(interp_order_z) on its own default None (TypeError); None means cubic here
+        self.interp_order_s, self.interp_order_z = int(interp_order_s), 3 if interp_order_z is None else int(interp_order_z)
+        if is2d:
+            self._interp = Interpolator2D(s, self.z, xi, kx=self.interp_order_s, ky=self.interp_order_z, interp_x=self.interp_s, assume_sorted=True,
+                                          device=self.device)
+        else:
+            if self.growth_factor_sq is None:
+                raise ValueError('provide either 2D pk array or growth_factor_sq')
+            self._interp = Interpolator1D(s, xi[:, 0], k=self.interp_order_s, interp_x=self.interp_s, assume_sorted=True, device=self.device)
+        self.is_from_callable = False
+
+    default_params = _get_default_kwargs(__init__, start=4, remove=('device',))
+
+    @property
+    def xi(self):
+        """Correlation function array (evaluated on (s, z) if built from a callable), without growth factor, with normalisation."""
+        if self.is_from_callable:
+            kwargs = {'ignore_growth': True} if self.growth_factor_sq is not None else {}
+            return self(self.s, self.z, **kwargs)
+        return self._xi * self._rsigma8sq
+
+    @property
+    def zmin(self):
+        """Minimum (spline-interpolated) redshift."""
+        return self.z[0]
+
+    @property
+    def zmax(self):
+        """Maximum (spline-interpolated) redshift."""
+        return self.z[-1]
+
+    @classmethod
+    def from_callable(cls, s=None, z=None, xi_callable=None, growth_factor_sq=None, device=None):
+        """Build from ``xi_callable(s)`` + ``growth_factor_sq(z)``, or ``xi_callable(s, z, grid=True)`` (reference interpolator.py:1300-1337)."""
+        if s is None:
+            s = get_default_s_callable()
+        if z is None:
+            z = get_default_z_callable()
+        self = cls.__new__(cls)
+        self.__dict__.update(self.default_params)
+        self._rsigma8sq = 1.
+        self.device = dv.resolve_device(device)
+        self.s, self.z = np.sort(_host(s).ravel()), np.sort(_host(z).ravel())
+        self.growth_factor_sq = growth_factor_sq
+        self.is_from_callable = True
+        self._interp = xi_callable
+        return self
+
+    def _eval_device(self, sh, zh, grid=True, ignore_growth=False, bounds_error=False):
+        """xi(s, z) at flat host coordinates as a device tensor (ns, nz) (grid) or (ns,) (pairs)."""
+        torch = dv.torch()
+        mask_s, mask_z = _mask_bounds([sh, zh], [(self.smin, self.smax), (self.zmin, self.zmax)], bounds_error=bounds_error)
+        if self.is_from_callable:
+            mask = mask_s[:, None] & mask_z if grid else mask_s & mask_z
+            if self.growth_factor_sq is not None:
+                tmp = dv.to_device(self._interp(sh), self.device)
+                if not ignore_growth:
+                    growth = dv.to_device(self.growth_factor_sq(zh), self.device)
+                    tmp = tmp[..., :, None] * growth[..., None, :] if grid else tmp * growth
+                elif grid:
+                    tmp = tmp[..., :, None].expand(tmp.shape + (zh.size,))
+            else:
+                tmp = dv.to_device(self._interp(sh, zh, grid=grid), self.device)
+        else:
+            is2d = self._xi.shape[1] > 1
+            if not is2d:
+                mask_z = mask_z | True    # ignore input z
+            mask = mask_s[:, None] & mask_z if grid else mask_s & mask_z
+            if is2d:
+                tmp = self._interp(torch.as_tensor(sh, device=self.device), torch.as_tensor(zh, device=self.device), grid=grid)
+            else:
+                tmp = self._interp(torch.as_tensor(sh, device=self.device))
+                if grid:
+                    tmp = tmp[:, None].expand(sh.size, zh.size)
+            if self.growth_factor_sq is not None and not ignore_growth:
+                tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
+        out = torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+        return out * self._rsigma8sq
+
+    def __call__(self, s, z, grid=True, ignore_growth=False, bounds_error=False):
+        """Evaluate at separations ``s`` and redshifts ``z``: shape s.shape + z.shape (``grid``) or s.shape (pairs)."""
+        like_torch = dv.is_torch(s) or dv.is_torch(z)
+        dtype = dv.float_dtype(s, z)
+        sh, zh = _host(s), _host(z)
+        out = self._eval_device(sh.ravel(), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error)
+        return _finish(out, dtype, like_torch, sh.shape + zh.shape if grid else sh.shape)
+
+    def sigma_dz(self, z, **kwargs):
+        """R.m.s. of the displacement field at ``z``, through :meth:`to_pk` (reference interpolator.py:1409-1415)."""
+        return self.to_pk().sigma_dz(z=z, **kwargs)
+
+    def sigma_rz(self, r, z, **kwargs):
+        """R.m.s. of perturbations in spheres of radius r at ``z``, through :meth:`to_pk` (reference interpolator.py:1417-1423)."""
+        return self.to_pk().sigma_rz(r, z=z, **kwargs)
+
+    def sigma8_z(self, z, **kwargs):
+        """R.m.s. of perturbations in a sphere of 8 at ``z``."""
+        return self.sigma_rz(8., z=z, **kwargs)
+
+    def rescale_sigma8(self, sigma8=1.):
+        """Rescale the correlation function to the provided ``sigma8`` normalisation at z = 0."""
+        self._rsigma8sq = 1.
+        self._rsigma8sq = sigma8**2 / self.sigma8_z(z=0)**2
+
+    def growth_rate_rz(self, r, z, **kwargs):
+        """Growth rate from the log-derivative of sigma_r(z), through :meth:`to_pk` (reference interpolator.py:1438-1444)."""
+        return self.to_pk().growth_rate_rz(r, z=z, **kwargs)
+
+    def to_1d(self, z, **kwargs):
+        """:class:`CorrelationFunctionInterpolator1D` at redshift ``z`` (reference interpolator.py:1446-1467)."""
+        if self.is_from_callable:
+            return CorrelationFunctionInterpolator1D.from_callable(self.s, lambda s, **kw: self(s, z=z, **kw), device=self.device)
+        default_params = dict(interp_order_s=self.interp_order_s)
+        default_params.update(kwargs)
+        return CorrelationFunctionInterpolator1D(self.s, self(self.s, z=z), device=self.device, **default_params)
+
+    def to_pk(self, ns=1024, fftlog_kwargs=None, **kwargs):
+        """Transform into a :class:`PowerSpectrumInterpolator2D` with FFTLog, growth factor left out (reference interpolator.py:1469-1498)."""
+        s = np.geomspace(self.extrap_smin, self.extrap_smax, ns)
+        rows = self._eval_device(s, self.z, grid=True, ignore_growth=True).T.contiguous()     # (nz, ns)
+        k, pk = CorrelationToPower(s, complex=False, device=self.device, **(fftlog_kwargs or {}))(rows)
+        default_params = dict(interp_k='log', extrap_pk='log', interp_order_k=self.interp_order_s, interp_order_z=self.interp_order_z,
+                              growth_factor_sq=self.growth_factor_sq)
+        default_params.update(kwargs)
+        return PowerSpectrumInterpolator2D(k.cpu().numpy(), z=self.z, pk=pk.T, device=self.device, **default_params)

@@ -308,6 +308,75 @@ def gen_bao(cp):
     save('bao', **out)
 
 
+def gen_xi(cp):
+    """f1 (xi side): CorrelationFunctionInterpolator1D/2D built by to_xi() of the EH interpolators and from tables; evaluation,
+    to_pk() round trip, sigma8 through to_pk; the 1D 'lin' variant."""
+    import warnings
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu')
+        interp = cosmo.get_fourier().pk_interpolator()
+        i1 = interp.to_1d(z=0.)
+        xi1 = i1.to_xi()
+        sq = np.geomspace(xi1.smin * 1.001, xi1.smax * 0.999, 96)
+        kq = np.geomspace(1e-4, 10., 64)
+        zq = np.array([0., 0.35, 1.1, 2.7])
+        out['sq'], out['kq'], out['zq'] = sq, kq, zq
+        out['xi1_s'], out['xi1_xi'] = np.asarray(xi1.s), np.asarray(xi1.xi)
+        out['xi1_eval'] = xi1(sq)
+        out['xi1_eval_oob'] = xi1(np.array([xi1.smin * 0.5, 1., xi1.smax * 2.]))
+        pk1 = xi1.to_pk()
+        out['xi1_to_pk_k'], out['xi1_to_pk_pk'] = np.asarray(pk1.k), np.asarray(pk1.pk)
+        out['xi1_to_pk_eval'] = pk1(kq)
+        out['xi1_sigma8'] = xi1.sigma8()
+        out['xi1_sigma_r'] = xi1.sigma_r(np.array([2., 8., 30.]))
+        out['xi1_sigma_d'] = xi1.sigma_d()
+        xi2 = interp.to_xi()
+        out['xi2_s'], out['xi2_z'] = np.asarray(xi2.s), np.asarray(xi2.z)
+        out['xi2_eval'] = xi2(sq, zq)
+        out['xi2_eval_nogrowth'] = xi2(sq, zq, ignore_growth=True)
+        out['xi2_eval_pts'] = xi2(sq[:4], zq, grid=False)
+        pk2 = xi2.to_pk()
+        out['xi2_to_pk_eval'] = pk2(kq, zq)
+        out['xi2_sigma8_z'] = xi2.sigma8_z(zq)
+        out['xi2_to_1d_eval'] = xi2.to_1d(z=0.35)(sq)
+        # the reference's own round trip (tests/test_interpolator.py:123-165) narrows the k range first: P(k) from the default
+        # range has negative ringing at the edges, whose log makes the whole interpolator NaN (kept above: that IS the behaviour)
+        c1 = i1.clone(extrap_kmin=1e-5, extrap_kmax=1e2)
+        out['c1_k'], out['c1_pk'] = np.asarray(c1.k), np.asarray(c1.pk)
+        xc1 = c1.to_xi()
+        out['xc1_s'], out['xc1_xi'] = np.asarray(xc1.s), np.asarray(xc1.xi)
+        pc1 = xc1.to_pk()
+        out['xc1_to_pk_k'], out['xc1_to_pk_pk'] = np.asarray(pc1.k), np.asarray(pc1.pk)
+        out['xc1_to_pk_eval'] = pc1(kq)
+        out['xc1_sigma8'], out['xc1_sigma_d'] = xc1.sigma8(), xc1.sigma_d()
+        out['xc1_sigma_r'] = xc1.sigma_r(np.array([2., 8., 30.]))
+        c2 = interp.clone(extrap_kmin=1e-5, extrap_kmax=1e2)
+        out['c2_k'], out['c2_z'], out['c2_pk'] = np.asarray(c2.k), np.asarray(c2.z), np.asarray(c2.pk)
+        out['c2_eval'] = c2(kq, zq)
+        xc2 = c2.to_xi()
+        out['xc2_s'] = np.asarray(xc2.s)
+        out['xc2_eval'] = xc2(sq, zq)
+        pc2 = xc2.to_pk()
+        out['xc2_to_pk_eval'] = pc2(kq, zq)
+        out['xc2_sigma8_z'], out['xc2_sigma_dz'] = xc2.sigma8_z(zq), xc2.sigma_dz(zq)
+        # tabulated: a (s, z) table of the same xi with its growth: 2D spline in both directions; and a 2-column 1D table
+        st = np.geomspace(1e-2, 2e2, 300)
+        zt = np.linspace(0., 2., 8)
+        tab = xi2(st, zt)
+        out['tab_s'], out['tab_z'], out['tab_xi'] = st, zt, tab
+        t2 = cp.CorrelationFunctionInterpolator2D(st, zt, tab, interp_order_z=3)
+        sq2 = np.geomspace(0.02, 150., 50)
+        out['tab_sq'] = sq2
+        out['tab2_eval'] = t2(sq2, np.array([0.1, 0.9, 1.7]))
+        t1 = cp.CorrelationFunctionInterpolator1D(st, tab[:, :2])
+        out['tab1_eval'] = t1(sq2)
+        t1l = cp.CorrelationFunctionInterpolator1D(st, tab[:, 0], interp_s='lin')
+        out['tab1_lin_eval'] = t1l(sq2)
+    save('xi', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -325,6 +394,8 @@ def main():
         gen_sigma(cp)
     if 'bao' in which:
         gen_bao(cp)
+    if 'xi' in which:
+        gen_xi(cp)
 
 
 if __name__ == '__main__':

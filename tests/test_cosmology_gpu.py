@@ -102,12 +102,12 @@ def test_sigma_eh_callable(cp, golden):
     i1 = interp.to_1d(z=0.)
     close(i1.sigma_r(r), g['eh_sigma_r_1d'])
     close(i1.sigma_d(), g['eh_sigma_d_1d'])
-    s, zz, xi = interp.to_xi()
+    s, zz, xi = interp.to_xi_arrays()
     close(s, g['eh_xi_s'], 1e-13)
     ref = g['eh_xi']
     w = s[:, None]**1.5
     assert np.abs((xi[..., ::8] - ref) * w).max() / np.abs(ref * w).max() < 1e-13
-    s1, xi1 = i1.to_xi()
+    s1, xi1 = i1.to_xi_arrays()
     assert np.abs((xi1 - g['eh_xi1']) * s1**1.5).max() / np.abs(g['eh_xi1'] * s1**1.5).max() < 1e-13
     # shapes / dtypes (reference tests/test_interpolator.py:8-32)
     assert interp.sigma_rz(8., 0.).shape == ()
