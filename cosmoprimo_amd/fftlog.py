@@ -197,7 +197,14 @@ class FFTlog(object):
 
         device : int, string, torch.device, default=None
             GPU holding the plan; defaults to the device of the first input (current CUDA device for numpy inputs).
+
+        rescale_rows : bool, default=False (``engine_kwargs``)
+            The kernel transforms two rows at a time packed as one complex sequence, so rounding is relative to the larger row
+            of a pair.  With ``rescale_rows=True`` every row is divided by the power of two next to its largest magnitude
+            before the transform and multiplied back afterwards (both exact), which makes the error of each row relative to its
+            own norm at the price of two more elementwise passes over the batch.  Only with zero / 'edge' / 'log' padding.
         """
+        self._rescale_rows = bool(engine_kwargs.pop('rescale_rows', False))
         self.inparallel = isinstance(kernel, (tuple, list))
         if not self.inparallel:
             kernel = [kernel]
@@ -355,19 +362,28 @@ class FFTlog(object):
             if len(fshape) == 1:
                 tfun = tfun[None, :]
         tin = tfun.expand(bshape).contiguous()
+        el, er = _split_pair(extrap)
+        (cl, vl), (cr, vr) = _extrap_code(el), _extrap_code(er)
+        scale = None
+        if self._rescale_rows and tin.numel():
+            if (cl == 0 and vl != 0.) or (cr == 0 and vr != 0.):
+                raise ValueError('rescale_rows cannot be combined with a non-zero constant padding value')
+            _, expo = torch.frexp(tin.abs().amax(dim=-1, keepdim=True))
+            scale = torch.ldexp(torch.ones_like(expo, dtype=torch.float64), expo)     # 2^e >= max|row| (1 for an all-zero row)
+            tin = tin / scale
         nbatch = 1
         for s in bshape[:-2] if nker > 1 else bshape[:-1]:
             nbatch *= s
         nout = npad if keep_padding else n
         oshape = bshape[:-1] + (nout,)
         tout = torch.empty(oshape, dtype=torch.float64, device=dev)
-        el, er = _split_pair(extrap)
-        (cl, vl), (cr, vr) = _extrap_code(el), _extrap_code(er)
         if nbatch > 0:
             plan = self._get_plan(dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(_lib.load().cp_fftlog_execute(plan.handle, tin.data_ptr(), tout.data_ptr(), nbatch, cl, vl, cr, vr, int(bool(keep_padding)),
                                                      stream))
+        if scale is not None:
+            tout = tout * scale
         if self._phase is not None:
             tout = tout * torch.as_tensor(self._phase, device=dev)[:, None]
         y = self.padded_y if keep_padding else self.y

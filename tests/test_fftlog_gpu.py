@@ -227,3 +227,23 @@ def test_full_size_batch_properties(cp, golden):
     total_out = xi.sum(dim=0).cpu().numpy()
     ref_total = ofl.apply(t, total_in)[0]
     assert tilted_err(total_out, ref_total, sn, 1.5) < 1e-12
+
+
+def test_rescale_rows(cp, golden):
+    """Packed pairs: rounding is relative to the larger row of a pair; rescale_rows=True makes it relative to each row."""
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k2048'], pkd['pk2048']
+    rows = np.stack([pk, 1e-12 * pk, 3e7 * pk, pk * 1e-3])
+    t = ofl.power_to_correlation(k)
+    ref = ofl.apply(t, rows[:, None, :])[:, 0]
+    s = t.y[0]
+    plain = cp.PowerToCorrelation(k)(rows)[1]
+    safe = cp.PowerToCorrelation(k, rescale_rows=True)(rows)[1]
+    err_plain = [tilted_err(plain[i], ref[i], s, 1.5) for i in range(4)]
+    err_safe = [tilted_err(safe[i], ref[i], s, 1.5) for i in range(4)]
+    assert max(err_safe) < TOL_NORM, err_safe
+    assert err_plain[0] < TOL_NORM and err_plain[2] < TOL_NORM          # the larger row of each pair is unaffected
+    assert err_plain[1] > 1e3 * err_safe[1]                             # the 1e-12 row next to an O(1) row is not
+    with pytest.raises(ValueError):
+        cp.PowerToCorrelation(k, rescale_rows=True)(rows, extrap=(1.5, 'edge'))
+    np.testing.assert_array_equal(cp.PowerToCorrelation(k, rescale_rows=True)(np.zeros((2, k.size)))[1], 0.)
