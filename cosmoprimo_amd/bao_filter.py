@@ -16,7 +16,8 @@ from . import _lib
 from . import _device as dv
 from .cosmology import Cosmology, Fourier
 from .dst import DST
-from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D
+from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, CorrelationFunctionInterpolator1D,
+                           CorrelationFunctionInterpolator2D)
 from .spline import LinearOperator
 
 
@@ -389,3 +390,135 @@ def PowerSpectrumBAOFilter(pk_interpolator, engine='wallish2018', cosmo=None, co
         raise ValueError('BAO filter {} is not available on the MI355X path; choose one of {}'.format(
             engine, sorted(name for name in RegisteredPowerSpectrumBAOFilter._registry if name != 'base')))
     return RegisteredPowerSpectrumBAOFilter._registry[engine](pk_interpolator, cosmo=cosmo, cosmo_fid=cosmo_fid, **kwargs)
+
+
+class RegisteredCorrelationFunctionBAOFilter(type):
+
+    """Metaclass registering :class:`BaseCorrelationFunctionBAOFilter`-derived classes by ``name`` (reference bao_filter.py:691-700)."""
+    _registry = {}
+
+    def __new__(meta, name, bases, class_dict):
+        cls = super().__new__(meta, name, bases, class_dict)
+        meta._registry[cls.name] = cls
+        return cls
+
+
+class BaseCorrelationFunctionBAOFilter(object, metaclass=RegisteredCorrelationFunctionBAOFilter):
+
+    """Base BAO filter for correlation function (reference bao_filter.py:703-832)."""
+    name = 'base'
+
+    def __init__(self, xi_interpolator, cosmo=None, cosmo_fid=None, **kwargs):
+        self._cosmo_fid = cosmo_fid
+        self.xi_interpolator = xi_interpolator
+        self.device = xi_interpolator.device
+        self.set_s(**kwargs)
+        self.set_xi(xi_interpolator, cosmo=cosmo)
+        self._prepare()
+        self._compute()
+        self._finalize()
+
+    def _prepare(self):
+        """Anything that can be done once."""
+
+    def set_s(self, ns=1024):
+        """Separations where the correlation function is evaluated (reference bao_filter.py:749-758)."""
+        self.s = np.geomspace(self.xi_interpolator.extrap_smin, self.xi_interpolator.extrap_smax, ns)
+
+    def set_xi(self, xi_interpolator, cosmo=None):
+        """Set the input correlation function (reference bao_filter.py:760-770): device rows (ncol, ns)."""
+        self._cosmo = cosmo
+        self.xi_interpolator = xi_interpolator
+        if isinstance(xi_interpolator, CorrelationFunctionInterpolator2D):
+            out = xi_interpolator._eval_device(self.s, xi_interpolator.z, grid=True, ignore_growth=True)   # (ns, nz)
+        else:
+            out = xi_interpolator._eval_device(self.s)                                                    # (ns,) + columns
+        self.shape = tuple(out.shape)
+        self._xi_rows = out.reshape(self.s.size, -1).T.contiguous()
+
+    def _finalize(self):
+        self.xi = self._xi_rows.cpu().numpy().T.reshape(self.shape)
+        self.xinow = self._xinow_rows.cpu().numpy().T.reshape(self.shape)
+
+    def __call__(self, xi_interpolator, cosmo=None):
+        self.set_xi(xi_interpolator, cosmo=cosmo)
+        self._compute()
+        self._finalize()
+        return self
+
+    def smooth_xi_interpolator(self, **kwargs):
+        """Smooth (no-peak) correlation function interpolator (reference bao_filter.py:778-792)."""
+        return self.xi_interpolator.clone(s=self.s, xi=self.xinow, **kwargs)
+
+    def smooth_pk_interpolator(self, **kwargs):
+        """Smooth (no-wiggle) power spectrum through FFTLog (reference bao_filter.py:794-808)."""
+        return self.smooth_xi_interpolator().to_pk(**kwargs)
+
+    @property
+    def cosmo(self):
+        """Cosmology."""
+        if self._cosmo is None:
+            self._cosmo = Cosmology()
+        return self._cosmo
+
+    @property
+    def cosmo_fid(self):
+        """Reference cosmology."""
+        if self._cosmo_fid is None:
+            self._cosmo_fid = Cosmology()
+        return self._cosmo_fid
+
+    rs_drag_ratio = BasePowerSpectrumBAOFilter.rs_drag_ratio
+
+
+class Kirkby2013CorrelationFunctionBAOFilter(BaseCorrelationFunctionBAOFilter):
+
+    """
+    Cut the BAO peak and bridge it with a polynomial in 1/s fitted on either side (reference bao_filter.py:835-909).
+    For fixed boxes the whole filter is ONE linear map of xi(s): it is built on the host (a weighted 5-parameter least-squares
+    projector on ~200 samples, blended with the identity) and applied to all columns on the device as a dense operator.
+    """
+    name = 'kirkby2013'
+
+    def __init__(self, xi_interpolator, srange_left=(50., 82.), srange_right=(150., 190.), rescale_sbox=True, cosmo=None, **kwargs):
+        self.srange_left = np.asarray(srange_left)
+        self.srange_right = np.asarray(srange_right)
+        self.rescale_sbox = rescale_sbox
+        super(Kirkby2013CorrelationFunctionBAOFilter, self).__init__(xi_interpolator, cosmo=cosmo, **kwargs)
+
+    def _prepare(self):
+        factor = 2.  # safety factor
+        self.smask = (self.s >= self.srange_left[0] / factor) & (self.s <= self.srange_right[1] * factor)
+        self.model = np.array([self.s**(1 - i) for i in range(5)])
+        frac = 1. / 100.
+        shift_center = (self.srange_right[0] - self.srange_left[1]) * frac
+        self.window = (np.concatenate([[self.srange_left[0] * (1. - frac)], self.srange_left,
+                                       [self.srange_left[1] + shift_center, self.srange_right[0] - shift_center],
+                                       self.srange_right, [self.srange_right[1] * (1. + frac)]], axis=0),
+                       np.array([0., 1., 1., 0., 0., 1., 1., 0.]))
+
+    def _operator(self, rescale):
+        """xinow = A xi with A = diag(1 - center) + diag(center) model^T (G W G^T)^-1 G W (restricted to ``smask`` columns)."""
+        precision = np.interp(self.s[self.smask] / rescale, self.window[0], self.window[1], left=0., right=0.)
+        center = np.interp(self.s / rescale, self.window[0][2:-2], 1. - self.window[1][2:-2], left=0., right=0.)
+        g = self.model[:, self.smask]
+        hv = g * precision
+        proj = np.linalg.solve(hv.dot(g.T), hv)               # (5, nmask): parameters = proj . xi[smask]
+        A = np.diag(1. - center)
+        A[:, self.smask] += center[:, None] * self.model.T.dot(proj)
+        return A
+
+    def _compute(self):
+        rescale = self.rs_drag_ratio() if self.rescale_sbox else 1.
+        key = float(rescale)
+        if getattr(self, '_op_key', None) != key:
+            self._op, self._op_key = LinearOperator.dense(self._operator(key), device=self.device), key
+        self._xinow_rows = self._op(self._xi_rows)
+
+
+def CorrelationFunctionBAOFilter(xi_interpolator, engine='kirkby2013', **kwargs):
+    """Run correlation function BAO filter ``engine`` (reference bao_filter.py:924-933); available here: 'kirkby2013'."""
+    engine = engine.lower()
+    if engine not in RegisteredCorrelationFunctionBAOFilter._registry or engine == 'base':
+        raise ValueError('Correlation function BAO filter {} is unknown'.format(engine))
+    return RegisteredCorrelationFunctionBAOFilter._registry[engine](xi_interpolator, **kwargs)

@@ -120,3 +120,29 @@ def brieden2022_compute(prep, pk, pknow_cosmo, rescale, clone_eval, extrap_kmin=
     out = pk(kf).reshape(kf.size, -1).copy()
     out[prep['kmask_fid']] = clone_eval(k_fid / rescale, pknow, k_fid).reshape(k_fid.size, -1)
     return out
+
+
+def kirkby2013(s, xi, rescale=1., srange_left=(50., 82.), srange_right=(150., 190.)):
+    """
+    Kirkby2013CorrelationFunctionBAOFilter._prepare / _compute (bao_filter.py:883-909): weighted fit of a_0 s + a_1 + a_2 / s +
+    a_3 / s^2 + a_4 / s^3 on the two side bands, blended into xi between them.  ``xi`` : (ns,) or (ns, ncol); ``rescale`` =
+    rs_drag ratio (:147-158, 896-898).  Returns xinow of the same shape.
+    """
+    s = np.asarray(s, dtype='f8')
+    xi = np.asarray(xi, dtype='f8')
+    shape = xi.shape
+    xi = xi.reshape(s.size, -1)
+    l, r = np.asarray(srange_left, dtype='f8'), np.asarray(srange_right, dtype='f8')
+    smask = (s >= l[0] / 2.) & (s <= r[1] * 2.)                                   # safety factor 2 (:884-885)
+    model = np.array([s**(1 - i) for i in range(5)])
+    frac = 1. / 100.
+    shift = (r[0] - l[1]) * frac
+    wx = np.concatenate([[l[0] * (1. - frac)], l, [l[1] + shift, r[0] - shift], r, [r[1] * (1. + frac)]])
+    wy = np.array([0., 1., 1., 0., 0., 1., 1., 0.])
+    precision = np.interp(s[smask] / rescale, wx, wy, left=0., right=0.)          # :900
+    center = np.interp(s / rescale, wx[2:-2], 1. - wy[2:-2], left=0., right=0.)   # :902
+    g = model[:, smask]
+    hv = g * precision                                                            # LeastSquareSolver without constraints (utils.py:161-272)
+    params = np.linalg.solve(hv.dot(g.T), hv.dot(xi[smask])).T                    # (ncol, 5)
+    fit = params.dot(model)                                                       # (ncol, ns)
+    return (xi.T * (1. - center) + fit * center).T.reshape(shape)

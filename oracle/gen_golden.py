@@ -361,6 +361,20 @@ def gen_xi(cp):
         pc2 = xc2.to_pk()
         out['xc2_to_pk_eval'] = pc2(kq, zq)
         out['xc2_sigma8_z'], out['xc2_sigma_dz'] = xc2.sigma8_z(zq), xc2.sigma_dz(zq)
+        # Kirkby2013 correlation-function BAO filter on the 1D and 2D xi above: default boxes, rescaled boxes (rs_drag ratio != 1)
+        from cosmoprimo.bao_filter import CorrelationFunctionBAOFilter
+        f1 = CorrelationFunctionBAOFilter(xc1, engine='kirkby2013')
+        out['kirkby_s'], out['kirkby1_xi'], out['kirkby1_xinow'] = np.asarray(f1.s), np.asarray(f1.xi), np.asarray(f1.xinow)
+        out['kirkby1_smooth_eval'] = f1.smooth_xi_interpolator()(sq)
+        other = cp.Cosmology(engine='eisenstein_hu', Omega_m=0.36, Omega_b=0.055, h=0.64, n_s=0.98, sigma8=0.85)
+        f1r = CorrelationFunctionBAOFilter(xc1, engine='kirkby2013', cosmo=other, cosmo_fid=cosmo)
+        out['kirkby1r_ratio'], out['kirkby1r_xinow'] = f1r.rs_drag_ratio(), np.asarray(f1r.xinow)
+        f1d = CorrelationFunctionBAOFilter(xc1, engine='kirkby2013', cosmo=other)     # hard-coded fiducial rs_drag
+        out['kirkby1d_ratio'], out['kirkby1d_xinow'] = f1d.rs_drag_ratio(), np.asarray(f1d.xinow)
+        f2 = CorrelationFunctionBAOFilter(xc2, engine='kirkby2013', srange_left=(45., 80.), srange_right=(155., 195.), rescale_sbox=False, cosmo=other)
+        out['kirkby2_xinow'] = np.asarray(f2.xinow)[:, ::6]
+        out['kirkby2_smooth_eval'] = f2.smooth_xi_interpolator()(sq, zq)
+        out['kirkby2_smooth_pk_eval'] = f2.smooth_pk_interpolator()(kq, zq)
         # tabulated: a (s, z) table of the same xi with its growth: 2D spline in both directions; and a 2-column 1D table
         st = np.geomspace(1e-2, 2e2, 300)
         zt = np.linspace(0., 2., 8)

@@ -104,3 +104,16 @@ def test_xi_2d(golden):
     np.testing.assert_allclose(pc2(g['kq'], zq), g['xc2_to_pk_eval'], rtol=1e-8)
     np.testing.assert_allclose(np.sqrt(osg.sigma_r2(8., lambda kk: pc2(kk, zq))), g['xc2_sigma8_z'], rtol=1e-9)
     np.testing.assert_allclose(np.sqrt(osg.sigma_d2(lambda kk: pc2(kk, zq))), g['xc2_sigma_dz'], rtol=1e-9)
+
+
+def test_kirkby2013(golden):
+    """oracle/bao.py: kirkby2013 against the reference filter (default boxes; boxes rescaled by the rs_drag ratio; 2D input)."""
+    from oracle import bao as obao
+    g = golden('xi')
+    s = g['kirkby_s']
+    np.testing.assert_allclose(obao.kirkby2013(s, g['kirkby1_xi']), g['kirkby1_xinow'], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(obao.kirkby2013(s, g['kirkby1_xi'], rescale=float(g['kirkby1r_ratio'])), g['kirkby1r_xinow'], rtol=1e-9, atol=1e-14)
+    np.testing.assert_allclose(obao.kirkby2013(s, g['kirkby1_xi'], rescale=float(g['kirkby1d_ratio'])), g['kirkby1d_xinow'], rtol=1e-9, atol=1e-14)
+    assert np.abs(g['kirkby1_xinow'] - g['kirkby1_xi']).max() > 1e-4          # the peak is really removed ...
+    m = (s < 80.) | (s > 155.)
+    np.testing.assert_array_equal(g['kirkby1_xinow'][m], g['kirkby1_xi'][m])   # ... and nothing else is touched

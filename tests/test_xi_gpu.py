@@ -116,3 +116,36 @@ def test_xi_tables(cp, golden):
     np.testing.assert_allclose(t2.clone()(sq2, zq), t2(sq2, zq), rtol=1e-13, atol=1e-16)
     with pytest.raises(ValueError):
         cp.CorrelationFunctionInterpolator2D(st, 0., tab[:, :1])     # single-column table without growth_factor_sq
+
+
+def test_kirkby2013(cp, golden):
+    """Correlation-function BAO filter (reference bao_filter.py:835-909) on 1D / 2D xi, default and rescaled boxes."""
+    from oracle import bao as obao
+    g = golden('xi')
+    sq, kq, zq = g['sq'], g['kq'], g['zq']
+    fid = cp.Cosmology(engine='eisenstein_hu')
+    interp = fid.get_fourier().pk_interpolator()
+    xc1 = interp.to_1d(z=0.).clone(extrap_kmin=1e-5, extrap_kmax=1e2).to_xi()
+    f1 = cp.CorrelationFunctionBAOFilter(xc1, engine='kirkby2013')
+    np.testing.assert_allclose(f1.s, g['kirkby_s'], rtol=1e-13)
+    np.testing.assert_allclose(f1.xi, g['kirkby1_xi'], rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(f1.xinow, g['kirkby1_xinow'], rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(f1.xinow, obao.kirkby2013(f1.s, f1.xi), rtol=1e-9, atol=1e-14)      # same input: operator == oracle
+    np.testing.assert_allclose(f1.smooth_xi_interpolator()(sq), g['kirkby1_smooth_eval'], rtol=1e-8, atol=1e-13, equal_nan=True)
+    other = cp.Cosmology(engine='eisenstein_hu', Omega_m=0.36, Omega_b=0.055, h=0.64, n_s=0.98, sigma8=0.85)
+    f1r = cp.CorrelationFunctionBAOFilter(xc1, engine='kirkby2013', cosmo=other, cosmo_fid=fid)
+    np.testing.assert_allclose(f1r.rs_drag_ratio(), g['kirkby1r_ratio'], rtol=1e-10)
+    np.testing.assert_allclose(f1r.xinow, g['kirkby1r_xinow'], rtol=1e-8, atol=1e-13)
+    f1d = cp.CorrelationFunctionBAOFilter(xc1, engine='kirkby2013', cosmo=other)
+    np.testing.assert_allclose(f1d.rs_drag_ratio(), g['kirkby1d_ratio'], rtol=1e-10)
+    np.testing.assert_allclose(f1d.xinow, g['kirkby1d_xinow'], rtol=1e-8, atol=1e-13)
+    xc2 = interp.clone(extrap_kmin=1e-5, extrap_kmax=1e2).to_xi()
+    f2 = cp.CorrelationFunctionBAOFilter(xc2, engine='kirkby2013', srange_left=(45., 80.), srange_right=(155., 195.), rescale_sbox=False, cosmo=other)
+    assert f2.xinow.shape == (1024, xc2.z.size)
+    np.testing.assert_allclose(f2.xinow[:, ::6], g['kirkby2_xinow'], rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(f2.smooth_xi_interpolator()(sq, zq), g['kirkby2_smooth_eval'], rtol=1e-8, atol=1e-13, equal_nan=True)
+    assert np.isnan(f2.smooth_pk_interpolator()(kq, zq)).all() and np.isnan(g['kirkby2_smooth_pk_eval']).all()
+    f1(xc1, cosmo=other)                      # re-run on new input (reference bao_filter.py:772-776)
+    np.testing.assert_allclose(f1.xinow, g['kirkby1d_xinow'], rtol=1e-8, atol=1e-13)
+    with pytest.raises(ValueError):
+        cp.CorrelationFunctionBAOFilter(xc1, engine='nope')
