@@ -383,13 +383,208 @@ Brieden2022PowerSpectrumBAOFilter._compute_batched = _brieden_compute_batched
 
 def PowerSpectrumBAOFilter(pk_interpolator, engine='wallish2018', cosmo=None, cosmo_fid=None, **kwargs):
     """
-    Run power spectrum BAO filter ``engine`` (reference bao_filter.py:912-921); available here: 'wallish2018', 'brieden2022'.
+    Run power spectrum BAO filter ``engine`` (reference bao_filter.py:912-921); every filter of the reference's registry except
+    'bspline' (which fails in the reference itself under numpy 2).
     """
     engine = engine.lower()
     if engine not in RegisteredPowerSpectrumBAOFilter._registry or engine == 'base':
         raise ValueError('BAO filter {} is not available on the MI355X path; choose one of {}'.format(
             engine, sorted(name for name in RegisteredPowerSpectrumBAOFilter._registry if name != 'base')))
     return RegisteredPowerSpectrumBAOFilter._registry[engine](pk_interpolator, cosmo=cosmo, cosmo_fid=cosmo_fid, **kwargs)
+
+
+# ---- remaining P(k) filters of the registry (SURVEY.md 8(f) f2) ------------------------------------------------------------
+# For a fixed cosmology each of them is a fixed linear map of a transformed spectrum (log10 P, log(k P), or the ratio to the
+# Eisenstein & Hu no-wiggle spectrum): the map is built once on the host (least-squares projectors / Savitzky-Golay weights /
+# products of spline operators: numpy on <= 1024 samples) and applied to all columns on the device by the dense operator kernel.
+
+def _constrained_lsq_operator(gradient, precision, constraint_gradient, constraint_matrix, inverse=False):
+    """
+    ``utils.LeastSquareSolver(gradient, precision (1D), constraint_gradient)`` (reference utils.py:161-272) followed by ``model()``,
+    as one (ndata, ndata) matrix A: model = A . delta, for constraints that are themselves linear in delta
+    (constraint = constraint_matrix . delta).  ``inverse`` = the reference's ``compute_inverse`` (explicit inverse vs solve).
+    """
+    nparams, ndata = gradient.shape
+    nc = constraint_gradient.shape[-1]
+    hv = gradient * precision
+    invfisher = np.block([[hv.dot(gradient.T), -constraint_gradient], [constraint_gradient.T, np.zeros((nc, nc))]])
+    hv = np.block([[hv, np.zeros(constraint_gradient.shape)], [np.zeros((nc, ndata)), np.eye(nc)]])
+    proj = np.linalg.inv(invfisher).dot(hv) if inverse else np.linalg.solve(invfisher, hv)      # (nparams + nc, ndata + nc)
+    to_params = proj[:nparams, :ndata] + proj[:nparams, ndata:].dot(constraint_matrix)          # (nparams, ndata)
+    return gradient.T.dot(to_params)
+
+
+def _end_constraints(n, order=2):
+    """Rows picking delta[0], delta[1] - delta[0] (, second difference) and the same at the other end (reference bao_filter.py:226-229, 335)."""
+    rows = []
+    for sign in (1, -1):
+        idx = [0, 1, 2] if sign > 0 else [-1, -2, -3]
+        r0 = np.zeros(n); r0[idx[0]] = 1.
+        r1 = np.zeros(n); r1[idx[1]] = 1.; r1[idx[0]] = -1.
+        rows += [r0, r1]
+        if order > 2:
+            r2 = np.zeros(n); r2[idx[2]] = 1.; r2[idx[1]] = -2.; r2[idx[0]] = 1.
+            rows.append(r2)
+    return np.array(rows)
+
+
+def _savgol_operator(n, window, polyorder=4):
+    """``scipy.signal.savgol_filter(x, window, polyorder, mode='interp')`` as an (n, n) matrix: the centre weights of a local
+    polynomial fit inside, and the polynomial fitted to the first / last ``window`` samples for the half-window at either end."""
+    h = window // 2
+    powers = np.arange(polyorder + 1)
+    x = np.arange(-h, h + 1, dtype='f8')
+    centre = np.linalg.pinv(x[:, None]**powers)[0]
+    S = np.zeros((n, n))
+    for i in range(h, n - h):
+        S[i, i - h:i + h + 1] = centre
+    V = x[:, None]**powers                               # edge fits on a centred abscissa (same polynomial, better conditioned)
+    fit = V.dot(np.linalg.pinv(V))                       # fitted values at the window's own samples
+    S[:h, :window] = fit[:h]
+    S[n - h:, n - window:] = fit[window - h:]
+    return S
+
+
+class _OperatorFilterMixin(object):
+
+    def _eh_nowiggle(self, k):
+        """Eisenstein & Hu no-wiggle P(k, z=0) of ``cosmo`` on the device (reference: Fourier(cosmo, engine='eisenstein_hu_nowiggle'))."""
+        pknow = np.asarray(Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k, z=0.), dtype='f8')
+        return dv.torch().as_tensor(pknow, device=self.device)
+
+
+class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
+
+    """High-degree polynomial fitted to the power spectrum in log-log space (reference bao_filter.py:172-241)."""
+    name = 'hinton2017'
+
+    def __init__(self, pk_interpolator, degree=12, sigma=0.5, weight=0.9, **kwargs):
+        self.degree, self.sigma, self.weight = degree, sigma, weight
+        super(Hinton2017PowerSpectrumBAOFilter, self).__init__(pk_interpolator, **kwargs)
+
+    def _prepare(self):
+        self.kmask = (self.k > 1e-4) & (self.k < 5.)
+        logk = np.log10(self.k[self.kmask])
+        logpk0 = np.log10(self._pk_rows[0].cpu().numpy()[self.kmask])       # the first column only ("approximation", :219)
+        maxk = logk[np.argmax(logpk0)]
+        w = 1. - self.weight * np.exp(-0.5 * ((logk - maxk) / self.sigma)**2)
+        gradient = np.array([((logk - np.mean(logk)) / np.std(logk))**i for i in range(self.degree + 1)])
+        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., 2] - 2. * gradient[..., 1] + gradient[..., 0],
+                              gradient[..., -1], gradient[..., -2] - gradient[..., -1], gradient[..., -3] - 2. * gradient[..., -2] + gradient[..., -1]])
+        A = _constrained_lsq_operator(gradient, w**2, cg, _end_constraints(logk.size, order=3), inverse=True)
+        self._op = LinearOperator.dense(A, device=self.device)
+
+    def _compute(self):
+        torch = dv.torch()
+        mask = torch.as_tensor(self.kmask, device=self.device)
+        res = self._pk_rows.clone()
+        res[:, mask] = 10**self._op(torch.log10(self._pk_rows[:, mask]).contiguous())
+        self._pknow_rows = res
+
+
+class SavGolPowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
+
+    """Savitzky-Golay smoothing of log(k P) along log k (reference bao_filter.py:244-266)."""
+    name = 'savgol'
+
+    def _prepare(self):
+        self.nfilter = int(np.ceil(np.log(7) / np.log(self.k[-1] / self.k[-2])) // 2 * 2 + 1)
+        self._op = LinearOperator.dense(_savgol_operator(self.k.size, self.nfilter), device=self.device)
+
+    def _compute(self):
+        torch = dv.torch()
+        kt = torch.as_tensor(self.k, device=self.device)
+        res = torch.exp(self._op(torch.log(kt * self._pk_rows))) / kt
+        h = self.nfilter // 2
+        res[:, -h:] = self._pk_rows[:, -h:]
+        self._pknow_rows = res
+
+
+class EHNoWiggleSavGolPowerSpectrumBAOFilter(_OperatorFilterMixin, SavGolPowerSpectrumBAOFilter):
+
+    """Savitzky-Golay smoothing of the ratio to the Eisenstein & Hu no-wiggle spectrum (reference bao_filter.py:269-286)."""
+    name = 'ehsavgol'
+
+    def _compute(self):
+        pknow = self._eh_nowiggle(self.k)
+        self._pknow_rows = self._op(self._pk_rows / pknow) * pknow
+
+
+class EHNoWigglePolyPowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumBAOFilter):
+
+    """Ratio to the Eisenstein & Hu no-wiggle spectrum emulated by a constrained polynomial in k (reference bao_filter.py:289-342)."""
+    name = 'ehpoly'
+
+    def __init__(self, pk_interpolator, krange=(1e-3, 1.), rescale_krange=True, cosmo=None, **kwargs):
+        self.krange = krange
+        self.rescale_krange = rescale_krange
+        super(EHNoWigglePolyPowerSpectrumBAOFilter, self).__init__(pk_interpolator, cosmo=cosmo, **kwargs)
+
+    def _compute(self):
+        torch = dv.torch()
+        krange = np.asarray(self.krange)
+        if self.rescale_krange:
+            krange = krange / self.rs_drag_ratio()
+        mask = (self.k >= krange[0]) & (self.k <= krange[1])
+        k = self.k[mask]
+        gradient = np.array([k**(i - 2) for i in range(6)])
+        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+        A = _constrained_lsq_operator(gradient, k**2, cg, _end_constraints(k.size, order=2))
+        pknow = self._eh_nowiggle(k)
+        tmask = torch.as_tensor(mask, device=self.device)
+        ratio = (self._pk_rows[:, tmask] / pknow).contiguous()
+        res = self._pk_rows.clone()
+        res[:, tmask] = LinearOperator.dense(A, device=self.device)(ratio) * pknow      # pk / (ratio / model)
+        self._pknow_rows = res
+
+
+class PeakAveragePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumBAOFilter):
+
+    """Average of the splines through the maxima and through the minima of the wiggles, at the fiducial positions moved by the
+    rs_drag ratio (reference bao_filter.py:512-580).  ``cosmo_fid`` is mandatory, with an engine."""
+    name = 'peakaverage'
+
+    @property
+    def cosmo_fid(self):
+        """Reference cosmology."""
+        if self._cosmo_fid is None:
+            raise ValueError('cosmo_fid must be provided, with an engine')
+        return self._cosmo_fid
+
+    def _prepare(self):
+        index = np.flatnonzero((self.k >= 1e-3) & (self.k <= 1.))
+        k_fid = self.k[index]
+        pk_fid = np.asarray(Fourier(self.cosmo_fid).pk_interpolator()(k_fid, z=0.), dtype='f8')
+        pknow_fid = np.asarray(Fourier(self.cosmo_fid, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k_fid, z=0.), dtype='f8')
+        ratio = pk_fid / pknow_fid
+        gradient = np.array([k_fid**(i - 1) for i in range(4)])
+        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+        pknow_correction = _constrained_lsq_operator(gradient, k_fid**2, cg, _end_constraints(k_fid.size, order=2)).dot(ratio)
+        ik0 = np.searchsorted(k_fid, 1e-2, side='right') + 1
+        self.k_peaks, self.pad_peaks = [], []
+        for si in [1., -1.]:
+            ik = _local_maxima(si * ratio[ik0:] / pknow_correction[ik0:]) + ik0
+            npadlow = index[0]
+            ik = ik + npadlow
+            ikmax = max(index[-1], ik[-1] + 1)
+            self.pad_peaks.append((npadlow, len(ik), self.k.size - ikmax))
+            self.k_peaks.append(self.k[np.concatenate([np.arange(npadlow), ik, np.arange(ikmax, self.k.size)], axis=0)])
+
+    def _operator(self, rescale):
+        """``_interp`` (reference bao_filter.py:565-574): natural splines in log10 k, data -> moved knots (extrapolating) -> all k."""
+        from .spline import dense_operator
+        logx = np.log10(self.k)
+        M = 0.
+        for kp, npad in zip(self.k_peaks, self.pad_peaks):
+            scale = np.concatenate([np.linspace(1., rescale, npad[0]), np.full(npad[1], rescale), np.linspace(rescale, 1., npad[2])])
+            logxx = np.log10(kp / scale)
+            M = M + 0.5 * dense_operator(logxx, logx, bc='natural').dot(dense_operator(logx, logxx, bc='natural', extrapolate=True))
+        return M
+
+    def _compute(self):
+        pknow = self._eh_nowiggle(self.k)
+        op = LinearOperator.dense(self._operator(float(self.rs_drag_ratio())), device=self.device)
+        self._pknow_rows = op(self._pk_rows / pknow) * pknow
 
 
 class RegisteredCorrelationFunctionBAOFilter(type):

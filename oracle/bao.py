@@ -4,7 +4,10 @@ Follows /root/reference/cosmoprimo/bao_filter.py: base class set_k / set_pk (:81
 (:361-431), Brieden2022 _prepare / _interp / _compute (:461-509), and utils.LeastSquareSolver (utils.py:144-272).
 Inputs are callables pk(k) -> (nk, ncol) so that the oracle is independent of the interpolator classes.
 
-Parity status: PINNED by tests/golden/bao.npz (G6).
+The remaining P(k) filters of the registry (hinton2017 :172-241, savgol :244-266, ehsavgol :269-286,
+ehpoly :289-342, peakaverage :512-580) are restated array-in / array-out further down.
+
+Parity status: PINNED by tests/golden/bao.npz (G6) and tests/golden/bao2.npz (f2).
 """
 import numpy as np
 from scipy import fftpack, interpolate, signal
@@ -146,3 +149,105 @@ def kirkby2013(s, xi, rescale=1., srange_left=(50., 82.), srange_right=(150., 19
     params = np.linalg.solve(hv.dot(g.T), hv.dot(xi[smask])).T                    # (ncol, 5)
     fit = params.dot(model)                                                       # (ncol, ns)
     return (xi.T * (1. - center) + fit * center).T.reshape(shape)
+
+
+def least_squares_projector(gradient, precision, constraint_gradient):
+    """LeastSquareSolver(..., compute_inverse=True).projector (utils.py:161-232): explicit inverse, as the reference computes it."""
+    hv = gradient * precision
+    invfisher = hv.dot(gradient.T)
+    nc = constraint_gradient.shape[-1]
+    invfisher = np.block([[invfisher, -constraint_gradient], [constraint_gradient.T, np.zeros((nc, nc))]])
+    hv = np.block([[hv, np.zeros(constraint_gradient.shape)], [np.zeros((nc, gradient.shape[-1])), np.eye(nc)]])
+    return np.linalg.inv(invfisher).dot(hv).T
+
+
+def hinton2017(k, pk, degree=12, sigma=0.5, weight=0.9):
+    """Hinton2017 (bao_filter.py:215-241): constrained degree-12 polynomial in log10 k fitted to log10 P on 1e-4 < k < 5.
+    ``pk`` (nk, ncol); the Gaussian down-weighting is centred on the maximum of the FIRST column (:219)."""
+    pk = pk.reshape(k.size, -1)
+    kmask = (k > 1e-4) & (k < 5.)
+    logk = np.log10(k[kmask])
+    logpk = np.log10(pk[kmask].T)
+    maxk = logk[np.argmax(logpk[0], axis=0)]
+    w = 1. - weight * np.exp(-0.5 * ((logk - maxk) / sigma)**2)
+    gradient = np.array([((logk - np.mean(logk)) / np.std(logk))**i for i in range(degree + 1)])
+    cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., 2] - 2. * gradient[..., 1] + gradient[..., 0],
+                          gradient[..., -1], gradient[..., -2] - gradient[..., -1], gradient[..., -3] - 2. * gradient[..., -2] + gradient[..., -1]])
+    constraint = np.column_stack([logpk[..., 0], logpk[..., 1] - logpk[..., 0], logpk[..., 2] - 2. * logpk[..., 1] + logpk[..., 0],
+                                  logpk[..., -1], logpk[..., -2] - logpk[..., -1], logpk[..., -3] - 2. * logpk[..., -2] + logpk[..., -1]])
+    params = np.concatenate([logpk, constraint], axis=-1).dot(least_squares_projector(gradient, w**2, cg))[..., :degree + 1]
+    out = pk.copy()
+    out[kmask] = 10**params.dot(gradient).T
+    return out
+
+
+def savgol_length(k):
+    return int(np.ceil(np.log(7) / np.log(k[-1] / k[-2])) // 2 * 2 + 1)     # :262, 283
+
+
+def savgol(k, pk):
+    """SavGol (bao_filter.py:258-266): Savitzky-Golay (order 4) on log(k P) along log k; the last half-window is left untouched."""
+    pk = pk.reshape(k.size, -1)
+    n = savgol_length(k)
+    out = (np.exp(signal.savgol_filter(np.log(k * pk.T), n, polyorder=4, axis=-1)) / k).T
+    out[-(n // 2):] = pk[-(n // 2):]
+    return out
+
+
+def ehsavgol(k, pk, pknow_eh):
+    """EHNoWiggleSavGol (bao_filter.py:278-286): Savitzky-Golay on the ratio to the EH no-wiggle P(k, z=0) ``pknow_eh`` (nk,)."""
+    pk = pk.reshape(k.size, -1)
+    return (signal.savgol_filter(pk.T / pknow_eh, savgol_length(k), polyorder=4, axis=-1) * pknow_eh).T
+
+
+def ehpoly(k, pk, pknow_eh, rs_ratio=1., krange=(1e-3, 1.)):
+    """EHNoWigglePoly (bao_filter.py:323-342): the ratio to EH no-wiggle emulated by sum_i a_i k^(i-2), i < 6, constrained at both ends."""
+    pk = pk.reshape(k.size, -1)
+    kr = np.asarray(krange) / rs_ratio
+    mask = (k >= kr[0]) & (k <= kr[1])
+    kk = k[mask]
+    ratio = pk[mask].T / pknow_eh[mask]
+    gradient = np.array([kk**(i - 2) for i in range(6)])
+    cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+    constraint = np.column_stack([ratio[..., 0], ratio[..., 1] - ratio[..., 0], ratio[..., -1], ratio[..., -2] - ratio[..., -1]])
+    model = np.stack([least_squares_constrained(gradient, kk**2, cg, ratio[i], constraint[i]) for i in range(ratio.shape[0])])
+    wiggles = np.ones_like(pk)
+    wiggles[mask] = (ratio / model).T
+    return pk / wiggles
+
+
+def peakaverage_prepare(k, pk_fid, pknow_fid):
+    """PeakAverage._prepare (bao_filter.py:536-563): ``pk_fid`` / ``pknow_fid`` callables of the fiducial cosmology at z = 0."""
+    index = np.flatnonzero((k >= 1e-3) & (k <= 1.))
+    k_fid = k[index]
+    ratio = pk_fid(k_fid) / pknow_fid(k_fid)
+    gradient = np.array([k_fid**(i - 1) for i in range(4)])
+    cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+    corr = least_squares_constrained(gradient, k_fid**2, cg, ratio, [ratio[..., 0], ratio[..., 1] - ratio[..., 0], ratio[..., -1], ratio[..., -2] - ratio[..., -1]])
+    ik0 = np.searchsorted(k_fid, 1e-2, side='right') + 1
+    k_peaks, pad_peaks = [], []
+    for si in [1., -1.]:
+        ik = signal.find_peaks(si * ratio[ik0:] / corr[ik0:])[0] + ik0
+        npadlow = index[0]
+        ik += npadlow
+        ikmax = max(index[-1], ik[-1] + 1)
+        pad_peaks.append((npadlow, len(ik), k.size - ikmax))
+        k_peaks.append(k[np.concatenate([np.arange(npadlow), ik, np.arange(ikmax, k.size)], axis=0)])
+    return k_peaks, pad_peaks
+
+
+def peakaverage(k, pk, pknow_eh, prep, rs_ratio=1.):
+    """PeakAverage._interp / _compute (bao_filter.py:565-580): mean of two natural splines (in log10 k) through the ratio to EH no-wiggle
+    sampled at the fiducial maxima / minima moved by the rs_drag ratio."""
+    from .interp import spline1d
+    pk = pk.reshape(k.size, -1)
+    k_peaks, pad_peaks = prep
+    y = pk / pknow_eh[:, None]
+    logx = np.log10(k)
+    first = spline1d(logx, y, extrap=True)
+    out = 0.
+    for kp, npad in zip(k_peaks, pad_peaks):
+        rescale = np.concatenate([np.linspace(1., rs_ratio, npad[0]), np.full(npad[1], rs_ratio), np.linspace(rs_ratio, 1., npad[2])])
+        logxx = np.log10(kp / rescale)
+        out = out + spline1d(logxx, first(logxx))(logx)
+    return out / 2. * pknow_eh[:, None]

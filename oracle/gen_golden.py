@@ -391,6 +391,40 @@ def gen_xi(cp):
     save('xi', **out)
 
 
+def gen_bao2(cp):
+    """f2: the remaining P(k) filters of the registry (hinton2017, savgol, ehsavgol, ehpoly, peakaverage) on the EH98 P(k) of the
+    BAO_PARAMS cosmologies (1D callable input) and on a 4-column table; EH no-wiggle P(k) and peakaverage _prepare products."""
+    import warnings
+    out = {}
+    engines = ['hinton2017', 'savgol', 'ehsavgol', 'ehpoly', 'peakaverage']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fid = cp.Cosmology(engine='eisenstein_hu')
+        for i, par in enumerate(BAO_PARAMS):
+            cosmo = cp.Cosmology(engine='eisenstein_hu', **par)
+            interp = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+            for eng in engines:
+                f = cp.PowerSpectrumBAOFilter(interp, engine=eng, cosmo=cosmo, cosmo_fid=fid)
+                out['c%d_%s_pknow' % (i, eng)] = np.asarray(f.pknow)
+            out['c%d_pk' % i] = np.asarray(f.pk)
+            out['c%d_pknow_eh' % i] = cp.Fourier(cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(f.k, z=0.)
+            out['c%d_rs_ratio' % i] = f.rs_drag_ratio()
+        out['k'] = np.asarray(f.k)
+        for j, kp in enumerate(f.k_peaks):
+            out['peakaverage_k_peaks%d' % j] = np.asarray(kp)
+            out['peakaverage_pad_peaks%d' % j] = np.asarray(f.pad_peaks[j])
+        # tabulated 2D input (columns = 4 redshifts) of the third cosmology; no cosmo given to hinton2017 / savgol (rs ratio 1)
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **BAO_PARAMS[2])
+        interp2 = cosmo.get_fourier().pk_interpolator()
+        kt, zt = np.logspace(-5, 1.5, 400), np.array([0., 0.5, 1., 2.])
+        tab = cp.PowerSpectrumInterpolator2D(kt, zt, interp2(kt, zt))
+        out['tab_k'], out['tab_z'], out['tab_pk'] = kt, zt, interp2(kt, zt)
+        for eng in engines:
+            kw = dict(cosmo=cosmo, cosmo_fid=fid) if eng in ('ehsavgol', 'ehpoly', 'peakaverage') else {}
+            out['tab_%s_pknow' % eng] = np.asarray(cp.PowerSpectrumBAOFilter(tab, engine=eng, **kw).pknow)
+    save('bao2', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -410,6 +444,8 @@ def main():
         gen_bao(cp)
     if 'xi' in which:
         gen_xi(cp)
+    if 'bao2' in which:
+        gen_bao2(cp)
 
 
 if __name__ == '__main__':
