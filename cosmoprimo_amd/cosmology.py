@@ -385,6 +385,48 @@ class BaseBackground(BaseSection):
         """Density parameter of dark energy at z (cosmology.py:1850)."""
         return self._eval('Omega_de', z)
 
+    def rho_tot(self, z):
+        """Comoving total density (matter + radiation + dark energy), in 1e10 Msun/h / (Mpc/h)^3 (cosmology.py:1731-1736)."""
+        return self._eval('rho_tot', z)
+
+    def T_cmb(self, z):
+        """CMB temperature at z, in K (cosmology.py:1762-1764)."""
+        return self._eval('T_cmb', z)
+
+    def _zeros_like(self, z):
+        return self._eval('rho_g', z) * 0.
+
+    def _de_split(self, which, form, z):
+        """rho_Lambda / rho_fld (cosmology.py:1714-1722): dark energy is either a cosmological constant or a fluid (Cosmology._has_fld)."""
+        has_fld = self._engine._has_fld
+        if np.ndim(has_fld):
+            raise NotImplementedError('{}(z) for a batch mixing cosmological-constant and fluid dark energy'.format(which))
+        if bool(has_fld) == (form == 'fld'):
+            return self._eval(which, z)
+        return self._zeros_like(z)
+
+    def rho_Lambda(self, z):
+        """Comoving density of the cosmological constant (cosmology.py:1714-1717)."""
+        return self._de_split('rho_Lambda', 'Lambda', z)
+
+    def rho_fld(self, z):
+        """Comoving density of the dark energy fluid (cosmology.py:1719-1722)."""
+        return self._de_split('rho_fld', 'fld', z)
+
+    def Omega_Lambda(self, z):
+        """Density parameter of the cosmological constant at z (cosmology.py:1841-1844)."""
+        return self._de_split('Omega_Lambda', 'Lambda', z)
+
+    def Omega_fld(self, z):
+        """Density parameter of the dark energy fluid at z (cosmology.py:1846-1849)."""
+        return self._de_split('Omega_fld', 'fld', z)
+
+    # no massive neutrinos on this path (N_ncdm = 0): their densities and pressures are identically zero (cosmology.py:1652-1678)
+    def rho_ncdm_tot(self, z):
+        return self._zeros_like(z)
+
+    p_ncdm_tot = Omega_ncdm_tot = Omega_pncdm_tot = rho_ncdm_tot
+
     def comoving_radial_distance(self, z):
         """Comoving radial distance, in Mpc/h (cosmology.py:2027-2042)."""
         return self._eval('comoving_radial_distance', z)
@@ -418,6 +460,26 @@ class BaseBackground(BaseSection):
         safe = torch.where(sq > 0, sq, torch.ones_like(sq))
         sk = torch.where(K > 0, torch.sin(safe * chi) / safe, torch.where(K < 0, torch.sinh(safe * chi) / safe, chi))
         return _out(sk / (1 + dv.to_device(z2, self.device)), like, dtype)
+
+
+def _add_density_methods():
+    docs = {'g': 'photons', 'b': 'baryons', 'ur': 'massless neutrinos', 'cdm': 'cold dark matter', 'k': 'curvature',
+            'r': 'radiation (photons + massless neutrinos)', 'm': 'matter (cdm + baryons)', 'de': 'dark energy (fluid + cosmological constant)'}
+
+    def make(kind, doc):
+        def method(self, z):
+            return self._eval(kind, z)
+        method.__name__ = kind
+        method.__doc__ = doc
+        return method
+
+    for name, what in docs.items():
+        setattr(BaseBackground, 'rho_' + name, make('rho_' + name, 'Comoving density of {}, in 1e10 Msun/h / (Mpc/h)^3 (cosmology.py:1680-1729).'.format(what)))
+        if name not in ('m', 'de'):    # Omega_m(z), Omega_de(z) are defined above
+            setattr(BaseBackground, 'Omega_' + name, make('Omega_' + name, 'Density parameter of {} at z, unitless (cosmology.py:1774-1853).'.format(what)))
+
+
+_add_density_methods()
 
 
 class DefaultBackground(BaseBackground):

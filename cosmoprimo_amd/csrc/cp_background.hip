@@ -77,6 +77,30 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
                  : (A.kind == CP_BG_OMEGA_M_Z ? (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rc : rho_de(c, zp1) / rc);
         return;
     }
+    if ((A.kind & ~CP_BG_AS_FRACTION) >= CP_BG_RHO_G) {  // BaseBackground.rho_x / Omega_x, cosmology.py:1680-1736, 1774-1853
+        const double zp1 = 1. + z;
+        const int what = A.kind & ~CP_BG_AS_FRACTION;
+        const double g = c.Omega_g * zp1 * kRhoCrit, ur = c.Omega_ur * zp1 * kRhoCrit;
+        const double b = c.Omega_b * 1. * kRhoCrit, cdm = c.Omega_cdm * 1. * kRhoCrit;
+        double v = nan;
+        switch (what) {
+            case CP_BG_RHO_G: v = g; break;
+            case CP_BG_RHO_B: v = b; break;
+            case CP_BG_RHO_UR: v = ur; break;
+            case CP_BG_RHO_CDM: v = cdm; break;
+            case CP_BG_RHO_K: v = c.Omega_k / zp1 * kRhoCrit; break;
+            case CP_BG_RHO_LAMBDA: v = c.Omega_de / (zp1 * zp1 * zp1) * kRhoCrit; break;
+            case CP_BG_RHO_FLD: v = c.Omega_de * pow(zp1, 3. * (1 + c.w0 + c.wa)) * exp(3. * c.wa * (1. / zp1 - 1)) * kRhoCrit / (zp1 * zp1 * zp1); break;
+            case CP_BG_RHO_DE: v = rho_de(c, zp1); break;
+            case CP_BG_RHO_TOT: v = (cdm + b + 0.) + (g + ur) + rho_de(c, zp1); break;
+            case CP_BG_RHO_M: v = cdm + b + 0. - 3. * 0.; break;
+            case CP_BG_RHO_R: v = g + ur + 3. * 0.; break;
+            case CP_BG_T_CMB_Z: v = c.T_cmb * zp1; break;
+        }
+        if (A.kind & CP_BG_AS_FRACTION) v = v / rho_crit(c, zp1);
+        A.out[i] = v;
+        return;
+    }
     if (A.kind == CP_BG_GROWTH_RATE) {  // Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))), eisenstein_hu.py:151-152
         const double zp1 = 1. + z;
         const double Om = (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rho_crit(c, zp1);
@@ -221,7 +245,11 @@ extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_p
     if (ncosmo < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_background_distance: negative size");
     if (ncosmo == 0 || nz == 0) return CP_OK;
     if (!params || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_background_distance: null pointer");
-    if (kind < CP_BG_COMOVING_RADIAL || kind > CP_BG_OMEGA_DE_Z) return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
+    {
+        const int base = kind & ~CP_BG_AS_FRACTION;
+        if (kind < 0 || base > CP_BG_KIND_LAST || ((kind & CP_BG_AS_FRACTION) && (base < CP_BG_RHO_G || base == CP_BG_T_CMB_Z)))
+            return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
+    }
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: cannot select device %d", device);

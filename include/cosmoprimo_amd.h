@@ -89,7 +89,23 @@ enum cp_bg_kind {
     CP_BG_GROWTH_RATE = 7,         /* growth_rate of the analytic engines, eisenstein_hu.py:143-152 */
     CP_BG_RHO_CRIT = 8,            /* rho_crit(z), 1e10 Msun/h / (Mpc/h)^3   cosmology.py:1738-1749 */
     CP_BG_OMEGA_M_Z = 9,           /* Omega_m(z)                    cosmology.py:1796 */
-    CP_BG_OMEGA_DE_Z = 10          /* Omega_de(z)                   cosmology.py:1850 */
+    CP_BG_OMEGA_DE_Z = 10,         /* Omega_de(z)                   cosmology.py:1850 */
+    /* comoving densities rho_x(z) in 1e10 Msun/h / (Mpc/h)^3 (BaseBackground.rho_*, cosmology.py:1680-1736); OR-ed with
+       CP_BG_AS_FRACTION they are divided by rho_crit(z): the density parameters Omega_x(z) (cosmology.py:1774-1853) */
+    CP_BG_RHO_G = 11,              /* photons                       cosmology.py:1680 */
+    CP_BG_RHO_B = 12,              /* baryons                       cosmology.py:1685 */
+    CP_BG_RHO_UR = 13,             /* massless neutrinos            cosmology.py:1690 */
+    CP_BG_RHO_CDM = 14,            /* cold dark matter              cosmology.py:1699 */
+    CP_BG_RHO_K = 15,              /* curvature                     cosmology.py:1709 */
+    CP_BG_RHO_LAMBDA = 16,         /* Omega0_de / (1+z)^3: the cosmological-constant form (the caller knows whether w = -1)  :1714 */
+    CP_BG_RHO_FLD = 17,            /* Omega0_de (1+z)^(3(1+w0+wa)) exp(3 wa (1/(1+z) - 1)) / (1+z)^3: the fluid form          :1719 */
+    CP_BG_RHO_DE = 18,             /* total dark energy             cosmology.py:1724 */
+    CP_BG_RHO_TOT = 19,            /* matter + radiation + dark energy  cosmology.py:1731 */
+    CP_BG_RHO_M = 20,              /* cdm + baryons (no massive neutrinos on this path)  cosmology.py:1704 */
+    CP_BG_RHO_R = 21,              /* photons + massless neutrinos  cosmology.py:1694 */
+    CP_BG_T_CMB_Z = 22,            /* T0_cmb (1+z), K               cosmology.py:1762 */
+    CP_BG_KIND_LAST = 22,
+    CP_BG_AS_FRACTION = 32
 };
 /* a per-cosmology parameter: device array of ncosmo doubles, or (ptr == NULL) one value for all cosmologies */
 typedef struct cp_param {

@@ -50,6 +50,32 @@ def efunc(z, p):
     return np.sqrt(rho_crit * (1 + z)**3 / rc)                                                     # :1754
 
 
+def densities(z, p, T_cmb=TCMB, has_fld=None):
+    """BaseBackground.rho_x(z) / Omega_x(z) / T_cmb(z) for N_ncdm = 0 (cosmology.py:1680-1736, 1762-1853): dict name -> array.
+    ``has_fld``: dark energy is a fluid (Cosmology._has_fld, :418-420), default (w0, wa) != (-1, 0)."""
+    rc = rho_crit_over_Msunph_per_Mpcph3
+    z = np.asarray(z, dtype='f8')
+    if has_fld is None:
+        has_fld = bool(np.any(p['w0_fld'] != -1.) or np.any(p['wa_fld'] != 0.))
+    d = {}
+    d['rho_g'] = p['Omega_g'] * (1 + z) * rc
+    d['rho_b'] = p['Omega_b'] * np.ones_like(z) * rc
+    d['rho_ur'] = p['Omega_ur'] * (1 + z) * rc
+    d['rho_cdm'] = p['Omega_cdm'] * np.ones_like(z) * rc
+    d['rho_k'] = p['Omega_k'] / (1 + z) * rc
+    d['rho_de'] = p['Omega_de'] * (1 + z) ** (3. * (p['w0_fld'] + p['wa_fld'])) * np.exp(3. * p['wa_fld'] * (1. / (1 + z) - 1)) * rc
+    d['rho_Lambda'] = (0. if has_fld else p['Omega_de']) / (1 + z)**3 * rc + 0. * z
+    d['rho_fld'] = (p['Omega_de'] if has_fld else 0.) * (1 + z) ** (3. * (1 + p['w0_fld'] + p['wa_fld'])) * np.exp(3. * p['wa_fld'] * (1. / (1 + z) - 1)) * rc / (1 + z)**3
+    d['rho_r'] = d['rho_g'] + d['rho_ur'] + 3. * 0.
+    d['rho_m'] = d['rho_cdm'] + d['rho_b'] + 0. - 3. * 0.
+    d['rho_tot'] = (d['rho_cdm'] + d['rho_b'] + 0.) + (d['rho_g'] + d['rho_ur']) + d['rho_de']
+    d['rho_crit'] = d['rho_tot'] + d['rho_k']
+    for name in ['g', 'b', 'ur', 'cdm', 'k', 'de', 'Lambda', 'fld', 'r', 'm']:
+        d['Omega_' + name] = d['rho_' + name] / d['rho_crit']
+    d['T_cmb'] = T_cmb * (1 + z)
+    return d
+
+
 def z_knots():
     """119 interpolation knots of comoving_radial_distance (cosmology.py:1947-1949)."""
     zm = 0.3

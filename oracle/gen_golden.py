@@ -425,6 +425,28 @@ def gen_bao2(cp):
     save('bao2', **out)
 
 
+DENSITY_NAMES = ['rho_g', 'rho_b', 'rho_ur', 'rho_cdm', 'rho_k', 'rho_de', 'rho_Lambda', 'rho_fld', 'rho_r', 'rho_m', 'rho_tot', 'rho_crit',
+                 'Omega_g', 'Omega_b', 'Omega_ur', 'Omega_cdm', 'Omega_k', 'Omega_de', 'Omega_Lambda', 'Omega_fld', 'Omega_r', 'Omega_m', 'T_cmb',
+                 'rho_ncdm_tot', 'p_ncdm_tot']
+DENSITY_PARAMS = [dict(), dict(Omega_m=0.27, Omega_b=0.045, h=0.72, Omega_k=0.05), dict(Omega_m=0.36, h=0.64, w0_fld=-0.9, wa_fld=0.2, T_cmb=2.6),
+                  dict(Omega_m=0.31, Omega_k=-0.03, w0_fld=-1.2, wa_fld=-0.4, N_ur=2.0328), dict(h=0.6766, w0_fld=-1., wa_fld=0., cs2_fld=0.9)]
+
+
+def gen_densities(cp):
+    """a19: every BaseBackground density / density parameter / T_cmb(z) for 5 cosmologies (flat LCDM, curved, w0-wa, cs2_fld != 1)."""
+    import warnings
+    z = np.concatenate([[0., 1e-3], np.linspace(0.05, 3., 10), [10., 100., 1100., 9999.]])
+    out = {'z': z}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for i, par in enumerate(DENSITY_PARAMS):
+            ba = cp.Cosmology(engine='eisenstein_hu', **par).get_background()
+            for name in DENSITY_NAMES:
+                out['c%d_%s' % (i, name)] = np.asarray(getattr(ba, name)(z), dtype='f8') + 0. * z
+            out['c%d_has_fld' % i] = float(ba.Omega0_fld != 0.)
+    save('densities', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -446,6 +468,8 @@ def main():
         gen_xi(cp)
     if 'bao2' in which:
         gen_bao2(cp)
+    if 'densities' in which:
+        gen_densities(cp)
 
 
 if __name__ == '__main__':

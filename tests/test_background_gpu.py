@@ -83,3 +83,26 @@ def test_every_interval_and_knot(bg):
             out = bg.distance(name, z, pars, Omega_m=om)
             m = ref[name] != 0
             assert np.abs(out[m] / ref[name][m] - 1).max() < RTOL, (name, pars)
+
+
+def test_densities(golden):
+    """a19: every BaseBackground density, density parameter and T_cmb(z) through the device kernel (new kinds of cp_background_distance)."""
+    import warnings
+    import cosmoprimo_amd as cp
+    from oracle.gen_golden import DENSITY_NAMES, DENSITY_PARAMS
+    g = golden('densities')
+    z = g['z']
+    for i, par in enumerate(DENSITY_PARAMS):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ba = cp.Cosmology(engine='eisenstein_hu', **par).get_background()
+        for name in DENSITY_NAMES:
+            out = getattr(ba, name)(z)
+            assert out.shape == z.shape and out.dtype == np.float64
+            np.testing.assert_allclose(out, g['c%d_%s' % (i, name)], rtol=1e-13, atol=1e-300, err_msg='%d %s' % (i, name))
+        assert ba.rho_g(z.astype('f4')).dtype == np.float32 and ba.Omega_k(0.).shape == ()
+    # a batch of cosmologies: leading axis
+    ba = cp.Cosmology(engine='eisenstein_hu', Omega_m=np.array([0.3, 0.36]), h=np.array([0.7, 0.64])).get_background()
+    out = ba.Omega_cdm(z)
+    assert out.shape == (2, z.size)
+    np.testing.assert_allclose(out[1], cp.Cosmology(engine='eisenstein_hu', Omega_m=0.36, h=0.64).get_background().Omega_cdm(z), rtol=1e-14)

@@ -34,3 +34,24 @@ def test_closed_form_lcdm_flat_matter_only():
     z = np.linspace(0.2, 5., 20)
     dc = ob.comoving_radial_distance(z, p)
     np.testing.assert_allclose(dc, 2 * ob.C_KMS / 100. * (1 - 1 / np.sqrt(1 + z)), rtol=1e-5)
+
+
+def test_densities(golden):
+    """a19: BaseBackground rho_x / Omega_x / T_cmb(z) (oracle/background.py: densities) against the reference, 5 cosmologies."""
+    from oracle.gen_golden import DENSITY_NAMES, DENSITY_PARAMS
+    g = golden('densities')
+    z = g['z']
+    for i, par in enumerate(DENSITY_PARAMS):
+        par = dict(par)
+        cs2 = par.pop('cs2_fld', 1.)
+        T_cmb = par.get('T_cmb', ob.TCMB)
+        p = ob.derived(**({'Omega_cdm': 0.25} if 'Omega_m' not in par else {}), **par)
+        has_fld = bool(g['c%d_has_fld' % i])
+        assert has_fld == ((par.get('w0_fld', -1.) != -1.) or (par.get('wa_fld', 0.) != 0.) or (cs2 != 1.))
+        d = ob.densities(z, p, T_cmb=T_cmb, has_fld=has_fld)
+        for name in DENSITY_NAMES:
+            ref = g['c%d_%s' % (i, name)]
+            if name in ('rho_ncdm_tot', 'p_ncdm_tot'):
+                assert (ref == 0.).all()
+                continue
+            np.testing.assert_allclose(d[name], ref, rtol=1e-13, atol=1e-300, err_msg='%d %s' % (i, name))
