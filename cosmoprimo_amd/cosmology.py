@@ -486,6 +486,16 @@ class DefaultBackground(BaseBackground):
 
     """Background of the analytic engines (reference DefaultBackground + eisenstein_hu.Background, eisenstein_hu.py:106-152)."""
 
+    def time(self, z):
+        """Proper time (age of the universe at z), in Gyr (reference DefaultBackground.time, cosmology.py:2000-2012): the RK4 scan on the
+        400-knot grid and its natural spline, evaluated by the same device kernel as the distances; NaN outside [0, 1e8 - 1]."""
+        return self._eval('time', z)
+
+    @property
+    def age(self):
+        """Current age of the universe, in Gyr (cosmology.py:2014-2025); one value per cosmology."""
+        return self._eval('age', np.zeros(()))
+
     def growth_factor(self, z, znorm=None):
         """CPT92 approximation of the growth factor (eisenstein_hu.py:115-140)."""
         growthz = self._eval('growth_cpt', z)

@@ -29,11 +29,14 @@ namespace {
 
 using namespace cpcosmo;
 
-constexpr int NK = 119;  // knots of get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949
+constexpr int NK_DIST = 119;  // knots of get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949
+constexpr int NK_TIME = 400;  // knots of get_default_z_interp('time' / 'age'), cosmology.py:1945-1946
 
-struct Tables {
+template <int NK>
+struct TablesN {
     double zc[NK], dx[NK], l[NK], u[NK], idf[NK], idb[NK], cp[NK], bq[NK], ra[NK], rb[NK];
 };
+using Tables = TablesN<NK_DIST>;
 
 struct Args {
     long long ncosmo, nz;
@@ -43,15 +46,18 @@ struct Args {
     int z_shared;  // z has nz entries shared by all cosmologies, else ncosmo * nz
     double* out;
     int kind;
-    const Tables* tab;
+    const void* tab;  // TablesN<NK> of the kernel instantiation
 };
 
+// TIME: the integrand carries 1 / (1 + z) and the result is (T_last - spline(z)) / h / (Gyr per Mpc): DefaultBackground.time / age
+// (cosmology.py:2000-2025), same RK4 == Simpson scan and natural spline as the distances, on the 400-knot grid.
+template <int NK, bool TIME>
 __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
-    __shared__ Tables T;
+    __shared__ TablesN<NK> T;
     {
         const double* src = reinterpret_cast<const double*>(A.tab);
         double* dst = reinterpret_cast<double*>(&T);
-        for (int i = threadIdx.x; i < (int)(sizeof(Tables) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < (int)(sizeof(TablesN<NK>) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
     const long long nsamp = A.ncosmo * A.nz;
@@ -61,23 +67,24 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m);
     const double z = A.z[A.z_shared ? iz : i];
     const double nan = __builtin_nan("");
-    if (A.kind == CP_BG_EFUNC || A.kind == CP_BG_HUBBLE) {
+    auto integrand = [&](double zz) { return TIME ? kCkms / (1. + zz) / (100. * efunc(c, zz)) : kCkms / (100. * efunc(c, zz)); };
+    if (!TIME && (A.kind == CP_BG_EFUNC || A.kind == CP_BG_HUBBLE)) {
         const double e = efunc(c, z);
         A.out[i] = A.kind == CP_BG_EFUNC ? e : e * (c.h * 100.);
         return;
     }
-    if (A.kind == CP_BG_GROWTH_CPT) {  // eisenstein_hu.py:134-136
+    if (!TIME && A.kind == CP_BG_GROWTH_CPT) {  // eisenstein_hu.py:134-136
         A.out[i] = growth_cpt(c, z);
         return;
     }
-    if (A.kind == CP_BG_RHO_CRIT || A.kind == CP_BG_OMEGA_M_Z || A.kind == CP_BG_OMEGA_DE_Z) {  // cosmology.py:1738-1749, 1796, 1850
+    if (!TIME && (A.kind == CP_BG_RHO_CRIT || A.kind == CP_BG_OMEGA_M_Z || A.kind == CP_BG_OMEGA_DE_Z)) {  // cosmology.py:1738-1749, 1796, 1850
         const double zp1 = 1. + z;
         const double rc = rho_crit(c, zp1);
         A.out[i] = A.kind == CP_BG_RHO_CRIT ? rc
                  : (A.kind == CP_BG_OMEGA_M_Z ? (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rc : rho_de(c, zp1) / rc);
         return;
     }
-    if ((A.kind & ~CP_BG_AS_FRACTION) >= CP_BG_RHO_G) {  // BaseBackground.rho_x / Omega_x, cosmology.py:1680-1736, 1774-1853
+    if (!TIME && (A.kind & ~CP_BG_AS_FRACTION) >= CP_BG_RHO_G) {  // BaseBackground.rho_x / Omega_x, cosmology.py:1680-1736, 1774-1853
         const double zp1 = 1. + z;
         const int what = A.kind & ~CP_BG_AS_FRACTION;
         const double g = c.Omega_g * zp1 * kRhoCrit, ur = c.Omega_ur * zp1 * kRhoCrit;
@@ -101,14 +108,14 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         A.out[i] = v;
         return;
     }
-    if (A.kind == CP_BG_GROWTH_RATE) {  // Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))), eisenstein_hu.py:151-152
+    if (!TIME && A.kind == CP_BG_GROWTH_RATE) {  // Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))), eisenstein_hu.py:151-152
         const double zp1 = 1. + z;
         const double Om = (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rho_crit(c, zp1);
         const double wz1 = c.w0 + (1. - 0.5) * c.wa;
         A.out[i] = pow(Om, 0.55 + 0.05 * (1 + wz1));
         return;
     }
-    if (!(z >= T.zc[0] && z <= T.zc[NK - 1])) {  // NaN outside the interpolation range (jax.py:200), also for NaN input
+    if (!(z >= T.zc[0] && z <= T.zc[NK - 1]) && !(TIME && A.kind == CP_BG_AGE)) {  // NaN outside the interpolation range (jax.py:200), also for NaN input
         A.out[i] = nan;
         return;
     }
@@ -120,8 +127,9 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         else hi = mid;
     }
     const int k = lo;
-    const double f_first = kCkms / (100. * efunc(c, T.zc[0]));
-    const double f_last = kCkms / (100. * efunc(c, T.zc[NK - 1]));
+    const double f_first = integrand(T.zc[0]);
+    const double f_last = integrand(T.zc[NK - 1]);
+    double total = 0.;          // TIME: T_last = sum of all increments
     double fprev = f_first;     // integrand at the shared end of the previous interval
     double tk = 0.;             // T_k = sum of inc_i, i < k, accumulated in knot order like the reference's scan
     double inc_prev = 0.;       // inc of the previously processed interval (idx - 1 going up, idx + 1 going down)
@@ -135,11 +143,12 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
             inc_prev = 0.;
         }
         const double x0 = T.zc[idx], x1 = T.zc[idx + 1], h = T.dx[idx];
-        const double fm = kCkms / (100. * efunc(c, x0 + h / 2));
-        const double fe = kCkms / (100. * efunc(c, fwd ? x1 : x0));
+        const double fm = integrand(x0 + h / 2);
+        const double fe = integrand(fwd ? x1 : x0);
         const double k1 = fwd ? fprev : fe, k4 = fwd ? fe : fprev;
         const double inc = h / 6. * (k1 + 2 * fm + 2 * fm + k4);  // jax.py:709 with k2 == k3
         fprev = fe;
+        if (TIME) total = total + inc;
         if (fwd) {
             // knot idx: d = ra * inc_{idx-1} + rb * inc_idx
             const double d = T.ra[idx] * inc_prev + T.rb[idx] * inc;
@@ -168,6 +177,12 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     const double c3 = tt / hk, c2 = (slope - sk) / hk - tt;
     const double dz = z - T.zc[k];
     double chi = tk + dz * (sk + dz * (c2 + dz * c3));
+    if (TIME) {
+        constexpr double kGigayearOverMegaparsec = 3.06601394e2;  // cosmoprimo/constants.py:21
+        const double age = total / c.h / kGigayearOverMegaparsec;               // (tmp[-1] - tmp[0]) / h / ..., cosmology.py:2024
+        A.out[i] = A.kind == CP_BG_AGE ? age : (total - chi) / c.h / kGigayearOverMegaparsec;   // cosmology.py:2011
+        return;
+    }
     if (A.kind != CP_BG_COMOVING_RADIAL) {
         const double K = -(100. * 100.) / (kCkms * kCkms) * c.Omega_k;  // (h/Mpc)^2, cosmology.py:397
         if (K > 0.) chi = sin(sqrt(K) * chi) / sqrt(K);
@@ -178,16 +193,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     A.out[i] = chi;
 }
 
-void build_tables(Tables& t) {
-    // knots: concatenate(linspace(0, 0.3, 20)[:-1], 1 / geomspace(1e-4, 1/1.3, 100)[::-1] - 1), cosmology.py:1947-1949
-    const double zm = 0.3;
-    for (int i = 0; i < 19; ++i) t.zc[i] = 0. + i * ((zm - 0.) / 19.);  // numpy.linspace: start + i * step
-    const double la = std::log10(1e-4), lb = std::log10(1. / (1. + zm));
-    double g[100];
-    for (int i = 0; i < 100; ++i) g[i] = std::pow(10., la + i * ((lb - la) / 99.));  // numpy.geomspace via logspace
-    g[0] = 1e-4;
-    g[99] = 1. / (1. + zm);  // geomspace pins its end points
-    for (int i = 0; i < 100; ++i) t.zc[19 + i] = 1. / g[99 - i] - 1.;
+template <int NK>
+void build_pivots(TablesN<NK>& t) {
     const int n = NK;
     for (int i = 0; i < n - 1; ++i) t.dx[i] = t.zc[i + 1] - t.zc[i];
     t.dx[n - 1] = 0.;
@@ -215,16 +222,39 @@ void build_tables(Tables& t) {
     }
 }
 
-// one device copy of the grid tables per device, created on first use
-Tables* device_tables(int device) {
-    static Tables* cache[64] = {nullptr};
+void build_tables(Tables& t) {
+    // knots: concatenate(linspace(0, 0.3, 20)[:-1], 1 / geomspace(1e-4, 1/1.3, 100)[::-1] - 1), cosmology.py:1947-1949
+    const double zm = 0.3;
+    for (int i = 0; i < 19; ++i) t.zc[i] = 0. + i * ((zm - 0.) / 19.);  // numpy.linspace: start + i * step
+    const double la = std::log10(1e-4), lb = std::log10(1. / (1. + zm));
+    double g[100];
+    for (int i = 0; i < 100; ++i) g[i] = std::pow(10., la + i * ((lb - la) / 99.));  // numpy.geomspace via logspace
+    g[0] = 1e-4;
+    g[99] = 1. / (1. + zm);  // geomspace pins its end points
+    for (int i = 0; i < 100; ++i) t.zc[19 + i] = 1. / g[99 - i] - 1.;
+    build_pivots(t);
+}
+
+void build_tables(TablesN<NK_TIME>& t) {
+    // knots: 1 / logspace(-8, 0, 400)[::-1] - 1, cosmology.py:1945-1946
+    double g[NK_TIME];
+    for (int i = 0; i < NK_TIME; ++i) g[i] = std::pow(10., -8. + i * ((0. - -8.) / (NK_TIME - 1)));  // numpy.logspace: 10 ** linspace
+    g[NK_TIME - 1] = std::pow(10., 0.);  // linspace pins its last sample
+    for (int i = 0; i < NK_TIME; ++i) t.zc[i] = 1. / g[NK_TIME - 1 - i] - 1.;
+    build_pivots(t);
+}
+
+// one device copy of the grid tables per device and grid, created on first use
+template <int NK>
+TablesN<NK>* device_tables(int device) {
+    static TablesN<NK>* cache[64] = {nullptr};
     if (device < 0 || device >= 64) return nullptr;
     if (!cache[device]) {
-        Tables h;
-        build_tables(h);
-        Tables* d = nullptr;
-        if (hipMalloc(&d, sizeof(Tables)) != hipSuccess) return nullptr;
-        if (hipMemcpy(d, &h, sizeof(Tables), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        std::vector<TablesN<NK>> h(1);
+        build_tables(h[0]);
+        TablesN<NK>* d = nullptr;
+        if (hipMalloc(&d, sizeof(TablesN<NK>)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h.data(), sizeof(TablesN<NK>), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
         cache[device] = d;
     }
     return cache[device];
@@ -233,10 +263,16 @@ Tables* device_tables(int device) {
 }  // namespace
 
 extern "C" int cp_background_knots(double* zc_out, int n) {
-    if (!zc_out || n != NK) return cp::fail(CP_EINVAL, "cp_background_knots: need a buffer of %d doubles", NK);
+    if (zc_out && n == NK_TIME) {  // the 400 knots of time / age
+        std::vector<TablesN<NK_TIME>> t(1);
+        build_tables(t[0]);
+        for (int i = 0; i < NK_TIME; ++i) zc_out[i] = t[0].zc[i];
+        return CP_OK;
+    }
+    if (!zc_out || n != NK_DIST) return cp::fail(CP_EINVAL, "cp_background_knots: need a buffer of %d (distances) or %d (time) doubles", NK_DIST, NK_TIME);
     Tables t;
     build_tables(t);
-    for (int i = 0; i < NK; ++i) zc_out[i] = t.zc[i];
+    for (int i = 0; i < NK_DIST; ++i) zc_out[i] = t.zc[i];
     return CP_OK;
 }
 
@@ -247,13 +283,14 @@ extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_p
     if (!params || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_background_distance: null pointer");
     {
         const int base = kind & ~CP_BG_AS_FRACTION;
-        if (kind < 0 || base > CP_BG_KIND_LAST || ((kind & CP_BG_AS_FRACTION) && (base < CP_BG_RHO_G || base == CP_BG_T_CMB_Z)))
+        if (kind < 0 || base > CP_BG_KIND_LAST || ((kind & CP_BG_AS_FRACTION) && (base < CP_BG_RHO_G || base >= CP_BG_T_CMB_Z)))
             return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
     }
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: cannot select device %d", device);
-    Tables* tab = device_tables(device);
+    const bool is_time = kind == CP_BG_TIME || kind == CP_BG_AGE;
+    const void* tab = is_time ? static_cast<const void*>(device_tables<NK_TIME>(device)) : static_cast<const void*>(device_tables<NK_DIST>(device));
     if (!tab) {
         if (prev >= 0) (void)hipSetDevice(prev);
         return cp::fail(CP_ENOMEM, "cp_background_distance: cannot allocate the knot tables on device %d", device);
@@ -274,7 +311,8 @@ extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_p
     const long long nsamp = ncosmo * nz;
     const int block = 256;
     const long long grid = (nsamp + block - 1) / block;
-    hipLaunchKernelGGL(bg_kernel, dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    if (is_time) hipLaunchKernelGGL((bg_kernel<NK_TIME, true>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    else hipLaunchKernelGGL((bg_kernel<NK_DIST, false>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
     hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: launch failed: %s", hipGetErrorString(e));

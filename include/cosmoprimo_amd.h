@@ -104,7 +104,9 @@ enum cp_bg_kind {
     CP_BG_RHO_M = 20,              /* cdm + baryons (no massive neutrinos on this path)  cosmology.py:1704 */
     CP_BG_RHO_R = 21,              /* photons + massless neutrinos  cosmology.py:1694 */
     CP_BG_T_CMB_Z = 22,            /* T0_cmb (1+z), K               cosmology.py:1762 */
-    CP_BG_KIND_LAST = 22,
+    CP_BG_TIME = 23,               /* proper time (age of the universe at z), Gyr   DefaultBackground.time, cosmology.py:2000-2012 */
+    CP_BG_AGE = 24,                /* age today, Gyr (z ignored)                     DefaultBackground.age,  cosmology.py:2014-2025 */
+    CP_BG_KIND_LAST = 24,
     CP_BG_AS_FRACTION = 32
 };
 /* a per-cosmology parameter: device array of ncosmo doubles, or (ptr == NULL) one value for all cosmologies */

@@ -116,6 +116,42 @@ def comoving_radial_distance(z, p):
     return out.reshape(zz.shape)
 
 
+GIGAYEAR_OVER_MEGAPARSEC = 3.06601394e2   # cosmoprimo/constants.py:21
+
+
+def time_knots():
+    """400 interpolation knots of time / age (cosmology.py:1945-1946)."""
+    return 1. / np.logspace(-8, 0., 400)[::-1] - 1.
+
+
+def time_table(p):
+    """Cumulative integral of c / (1 + z) / (100 E) over the time knots (cosmology.py:2005-2009; RK4 == Simpson with midpoints)."""
+    zc = time_knots()
+
+    def f(z):
+        return C_KMS / (1. + z) / (100. * efunc(z, p))
+
+    t_last, t = zc[:-1], zc[1:]
+    h = t - t_last
+    inc = h / 6. * (f(t_last) + 2 * f(t_last + h / 2) + 2 * f(t_last + h / 2) + f(t))
+    return zc, np.concatenate([[0.], np.cumsum(inc)])
+
+
+def time(z, p):
+    """DefaultBackground.time (cosmology.py:2000-2012), in Gyr; one cosmology; NaN outside the knots."""
+    zc, tab = time_table(p)
+    z = np.asarray(z, dtype='f8')
+    y = (tab[-1] - tab) / p['h'] / GIGAYEAR_OVER_MEGAPARSEC
+    out = CubicSpline(zc, y, bc_type='natural', extrapolate=False)(z)
+    return np.where((z >= zc[0]) & (z <= zc[-1]), out, np.nan)
+
+
+def age(p):
+    """DefaultBackground.age (cosmology.py:2014-2025), in Gyr."""
+    zc, tab = time_table(p)
+    return (tab[-1] - tab[0]) / p['h'] / GIGAYEAR_OVER_MEGAPARSEC
+
+
 def _sk(chi, K):
     """S_K(chi) (cosmology.py:1862-1868)."""
     K = np.broadcast_to(K, chi.shape) if np.ndim(K) else np.full(chi.shape, K)

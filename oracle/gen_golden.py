@@ -444,6 +444,10 @@ def gen_densities(cp):
             for name in DENSITY_NAMES:
                 out['c%d_%s' % (i, name)] = np.asarray(getattr(ba, name)(z), dtype='f8') + 0. * z
             out['c%d_has_fld' % i] = float(ba.Omega0_fld != 0.)
+            out['c%d_time' % i] = np.asarray(ba.time(z), dtype='f8')
+            out['c%d_age' % i] = float(ba.age)
+        out['time_knots'] = np.asarray(ba._cache['time']._x)
+        out['time_nan_outside'] = ba.time(np.array([-0.1, 1e8]))
     save('densities', **out)
 
 

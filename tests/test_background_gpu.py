@@ -101,8 +101,19 @@ def test_densities(golden):
             assert out.shape == z.shape and out.dtype == np.float64
             np.testing.assert_allclose(out, g['c%d_%s' % (i, name)], rtol=1e-13, atol=1e-300, err_msg='%d %s' % (i, name))
         assert ba.rho_g(z.astype('f4')).dtype == np.float32 and ba.Omega_k(0.).shape == ()
+        # time / age (cosmology.py:2000-2025) on the 400-knot grid: cancellation (T_last - T(z)) costs digits at high z
+        np.testing.assert_allclose(ba.time(z), g['c%d_time' % i], rtol=1e-9)
+        np.testing.assert_allclose(ba.time(z[:8]), g['c%d_time' % i][:8], rtol=1e-12)
+        np.testing.assert_allclose(ba.age, g['c%d_age' % i], rtol=1e-13)
+        assert np.ndim(ba.age) == 0 and np.isnan(ba.time(np.array([-0.1, 1e8]))).all()
     # a batch of cosmologies: leading axis
     ba = cp.Cosmology(engine='eisenstein_hu', Omega_m=np.array([0.3, 0.36]), h=np.array([0.7, 0.64])).get_background()
     out = ba.Omega_cdm(z)
     assert out.shape == (2, z.size)
     np.testing.assert_allclose(out[1], cp.Cosmology(engine='eisenstein_hu', Omega_m=0.36, h=0.64).get_background().Omega_cdm(z), rtol=1e-14)
+    np.testing.assert_allclose(ba.age, [cp.Cosmology(engine='eisenstein_hu', Omega_m=om, h=h).get_background().age for om, h in [(0.3, 0.7), (0.36, 0.64)]],
+                               rtol=1e-14)
+    kn = np.empty(400)
+    from cosmoprimo_amd import _lib
+    _lib.check(_lib.load().cp_background_knots(_lib.as_double_p(kn), 400))
+    np.testing.assert_allclose(kn, g['time_knots'], rtol=1e-15)

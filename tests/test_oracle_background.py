@@ -55,3 +55,8 @@ def test_densities(golden):
                 assert (ref == 0.).all()
                 continue
             np.testing.assert_allclose(d[name], ref, rtol=1e-13, atol=1e-300, err_msg='%d %s' % (i, name))
+        # time / age: DefaultBackground.time, .age (cosmology.py:2000-2025)
+        np.testing.assert_allclose(ob.time(z, p), g['c%d_time' % i], rtol=1e-11)
+        np.testing.assert_allclose(ob.age(p), g['c%d_age' % i], rtol=1e-13)
+    np.testing.assert_allclose(ob.time_knots(), g['time_knots'], rtol=1e-15)
+    assert np.isnan(g['time_nan_outside']).all()
