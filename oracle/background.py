@@ -172,3 +172,100 @@ def distances(z, p):
     da = _sk(dc, np.broadcast_to(Kb, dc.shape)) / (1 + z)      # :1868
     return {'comoving_radial_distance': dc, 'angular_diameter_distance': da, 'comoving_transverse_distance': da * (1. + z),
             'luminosity_distance': da * (1. + z)**2}
+
+
+# ---- massive neutrinos ---------------------------------------------------------------------------
+TNCDM_OVER_CMB = 0.71611                                  # cosmoprimo/constants.py:18
+_EV_OVER_JOULE = sc.electron_volt
+_MSUN = 1.98847 * 1e30                                     # constants.py: msun_over_kg
+_MPC = 1e6 * sc.parsec
+
+
+def ncdm_momenta(T_eff, m, z, out='rho'):
+    """_compute_ncdm_momenta, method='laguerre' (cosmology.py:74-137): phase-space integral by 100-point Gauss-Laguerre,
+    in 1e10 Msun / Mpc^3.  ``out``: 'rho' | 'p'."""
+    z = np.asarray(z, dtype='f8')
+    a = 1. / (1. + z)
+    over_T = _EV_OVER_JOULE / (sc.Boltzmann * (T_eff / a))
+    m2 = ((m * over_T)**2)[..., None]
+    ti, wi = np.polynomial.laguerre.laggauss(100)
+    if out == 'rho':
+        f = ti**2 * np.sqrt(ti**2 + m2) / (1. + np.exp(-ti))           # :59-60, exp_sign = -1
+    else:
+        f = 1. / 3. * ti**4 / np.sqrt(ti**2 + m2) / (1. + np.exp(-ti))  # :65-66
+    tot = np.sum(f * wi, axis=-1)
+    return 7. / 8. * 4 / sc.c**3 * sc.Stefan_Boltzmann * (T_eff / a)**4 * tot / (7. * np.pi**4 / 120.) / (1e10 * _MSUN) * _MPC**3
+
+
+def ncdm_knots():
+    """Interpolation knots of rho_ncdm / p_ncdm (cosmology.py:1941-1943)."""
+    zm = 1.
+    return np.concatenate([np.linspace(0., zm, 20)[:-1], 1. / np.geomspace(1e-8, 1. / (1 + zm), 100)[::-1] - 1.])
+
+
+def derived_ncdm(m_ncdm, h=0.7, Omega_cdm=0.25, Omega_b=0.05, Omega_k=0., T_cmb=TCMB, N_eff=NEFF, N_ur=None, T_ncdm_over_cmb=None,
+                 w0_fld=-1., wa_fld=0., Omega_m=None):
+    """``derived`` with massive species (cosmology.py:355-383, 1123-1165): N_ur from N_eff, Omega_ncdm, Omega_m -> Omega_cdm, Omega_de."""
+    m_ncdm = np.atleast_1d(np.asarray(m_ncdm, dtype='f8'))
+    T_over = np.full(m_ncdm.size, TNCDM_OVER_CMB if T_ncdm_over_cmb is None else T_ncdm_over_cmb, dtype='f8')
+    if N_ur is None:
+        N_ur = N_eff - sum(t**4 * (4. / 11.)**(-4. / 3.) for t in T_over)                  # :1127
+    rc = rho_crit_over_Msunph_per_Mpcph3
+    rho0 = np.array([ncdm_momenta(T_cmb * t, m, 0., 'rho') / 1.**3 / h**2 for t, m in zip(T_over, m_ncdm)])     # _get_ncdm, :441-442
+    p0 = np.array([ncdm_momenta(T_cmb * t, m, 0., 'p') / 1.**3 / h**2 for t, m in zip(T_over, m_ncdm)])
+    Omega_ncdm, Omega_pncdm = rho0 / rc, 3. * p0 / rc
+    if Omega_m is not None:
+        Omega_cdm = Omega_m - Omega_b - (sum(rho0) - 3 * sum(p0)) / rc                   # :1163-1165
+    p = derived(h=h, Omega_cdm=Omega_cdm, Omega_b=Omega_b, Omega_k=Omega_k, T_cmb=T_cmb, N_ur=N_ur, w0_fld=w0_fld, wa_fld=wa_fld)
+    p = {k: v for k, v in p.items()}
+    p['Omega_ncdm'], p['Omega_pncdm'] = Omega_ncdm, Omega_pncdm
+    p['Omega_de'] = 1. - (p['Omega_cdm'] + p['Omega_b'] + p['Omega_g'] + p['Omega_ur'] + sum(Omega_ncdm) + p['Omega_k'])      # :383
+    p['N_ur'], p['m_ncdm'], p['T_ncdm'] = N_ur, m_ncdm, T_over * T_cmb
+    p['T_cmb'] = T_cmb
+    return p
+
+
+def ncdm_tables(p):
+    """DefaultBackground caches (cosmology.py:1961-1998): rho and p of every species on the knots, (nspecies, 119) each."""
+    zc = ncdm_knots()
+    rho = np.array([ncdm_momenta(T, m, zc, 'rho') / (1 + zc)**3 / p['h']**2 for T, m in zip(p['T_ncdm'], p['m_ncdm'])])
+    pr = np.array([ncdm_momenta(T, m, zc, 'p') / (1 + zc)**3 / p['h']**2 for T, m in zip(p['T_ncdm'], p['m_ncdm'])])
+    return zc, rho, pr
+
+
+def ncdm_interp(p, z, out='rho'):
+    """DefaultBackground.rho_ncdm / p_ncdm (interpolated, natural cubic spline, NaN outside the knots): (nspecies,) + z.shape."""
+    zc, rho, pr = ncdm_tables(p)
+    z = np.asarray(z, dtype='f8')
+    tab = rho if out == 'rho' else pr
+    val = CubicSpline(zc, tab.T, axis=0, bc_type='natural', extrapolate=False)(z.ravel()).T
+    val = np.where((z.ravel() >= zc[0]) & (z.ravel() <= zc[-1]), val, np.nan)
+    return val.reshape((tab.shape[0],) + z.shape)
+
+
+def efunc_ncdm(z, p):
+    """E(z) with massive neutrinos (cosmology.py:1731-1754 with DefaultBackground.rho_ncdm): one cosmology."""
+    rc = rho_crit_over_Msunph_per_Mpcph3
+    z = np.asarray(z, dtype='f8')
+    ncdm = ncdm_interp(p, z, 'rho').sum(axis=0)
+    m = p['Omega_cdm'] * np.ones_like(z) * rc + p['Omega_b'] * np.ones_like(z) * rc + ncdm
+    r = p['Omega_g'] * (1 + z) * rc + p['Omega_ur'] * (1 + z) * rc
+    de = p['Omega_de'] * (1 + z) ** (3. * (p['w0_fld'] + p['wa_fld'])) * np.exp(3. * p['wa_fld'] * (1. / (1 + z) - 1)) * rc
+    rho_crit = (m + r + de) + p['Omega_k'] / (1 + z) * rc
+    return np.sqrt(rho_crit * (1 + z)**3 / rc)
+
+
+def comoving_radial_distance_ncdm(z, p):
+    """D_C with massive neutrinos: the same scan + natural spline as comoving_radial_distance, E(z) from efunc_ncdm."""
+    zc = z_knots()
+
+    def f(zz):
+        return C_KMS / (100. * efunc_ncdm(zz, p))
+
+    t_last, t = zc[:-1], zc[1:]
+    h = t - t_last
+    inc = h / 6. * (f(t_last) + 2 * f(t_last + h / 2) + 2 * f(t_last + h / 2) + f(t))
+    tab = np.concatenate([[0.], np.cumsum(inc)])
+    z = np.asarray(z, dtype='f8')
+    out = CubicSpline(zc, tab, bc_type='natural', extrapolate=False)(z)
+    return np.where((z >= zc[0]) & (z <= zc[-1]), out, np.nan)

@@ -451,6 +451,39 @@ def gen_densities(cp):
     save('densities', **out)
 
 
+NCDM_PARAMS = [dict(m_ncdm=0.06), dict(m_ncdm=[0.02, 0.03, 0.05], Omega_m=0.31, h=0.6766, w0_fld=-0.9, wa_fld=0.15),
+               dict(m_ncdm=[0.1, 0.4], Omega_k=0.02, T_cmb=2.6, N_eff=3.2), dict(m_ncdm=[0.06], T_ncdm_over_cmb=[0.7], Omega_cdm=0.26, N_ur=2.03)]
+
+
+def gen_ncdm(cp):
+    """a23: massive neutrinos: derived parameters, interpolated rho / p of every species, E(z), densities and density parameters,
+    distances and time for 4 cosmologies (one / three / two species; w0wa; curvature; explicit T_ncdm_over_cmb and N_ur)."""
+    import warnings
+    z = np.concatenate([[0., 1e-3], np.linspace(0.05, 3., 12), [10., 100., 1100., 9999.]])
+    out = {'z': z}
+    names = ['efunc', 'rho_ncdm_tot', 'p_ncdm_tot', 'rho_m', 'rho_r', 'rho_tot', 'rho_crit', 'Omega_m', 'Omega_r', 'Omega_ncdm_tot', 'Omega_pncdm_tot',
+             'Omega_de', 'comoving_radial_distance', 'angular_diameter_distance', 'luminosity_distance', 'time']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for i, par in enumerate(NCDM_PARAMS):
+            cosmo = cp.Cosmology(engine='eisenstein_hu', **par)
+            ba = cosmo.get_background()
+            for name in ['N_ur', 'N_eff', 'Omega_ncdm_tot', 'Omega_pncdm_tot', 'Omega_m', 'Omega_de', 'Omega_cdm', 'Omega_r', 'm_ncdm_tot']:
+                out['c%d_par_%s' % (i, name)] = float(cosmo[name])
+            out['c%d_par_Omega_ncdm' % i] = np.asarray(cosmo['Omega_ncdm'], dtype='f8')
+            out['c%d_par_T_ncdm' % i] = np.asarray(cosmo['T_ncdm'], dtype='f8')
+            for name in names:
+                out['c%d_%s' % (i, name)] = np.asarray(getattr(ba, name)(z), dtype='f8')
+            out['c%d_rho_ncdm' % i] = np.asarray(ba.rho_ncdm(z), dtype='f8')
+            out['c%d_p_ncdm' % i] = np.asarray(ba.p_ncdm(z), dtype='f8')
+            out['c%d_Omega_ncdm_z' % i] = np.asarray(ba.Omega_ncdm(z), dtype='f8')
+            out['c%d_T_ncdm_z' % i] = np.asarray(ba.T_ncdm(z), dtype='f8')
+            out['c%d_age' % i] = float(ba.age)
+        out['ncdm_knots'] = np.asarray(ba._cache['rho_ncdm']._x)
+        out['rho_ncdm_table'] = np.asarray(ba._cache['rho_ncdm']._fun)
+    save('ncdm', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -474,6 +507,8 @@ def main():
         gen_bao2(cp)
     if 'densities' in which:
         gen_densities(cp)
+    if 'ncdm' in which:
+        gen_ncdm(cp)
 
 
 if __name__ == '__main__':
