@@ -36,6 +36,10 @@ SIGNATURES = {
     'cp_background_distance': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_background_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
+    'cp_ncdm_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
+    'cp_ncdm_tables': None,        # filled below (takes cp_param by value)
+    'cp_background_eval': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_power_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_eh_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
@@ -61,6 +65,15 @@ class cp_param(ctypes.Structure):
     _fields_ = [('ptr', ctypes.c_void_p), ('value', ctypes.c_double)]
 
 
+class cp_ncdm(ctypes.Structure):
+    """Massive-neutrino spline tables of the background kernels (include/cosmoprimo_amd.h)."""
+    _fields_ = [('nspecies', ctypes.c_int), ('species', ctypes.c_int), ('tab', ctypes.c_void_p)]
+
+
+SIGNATURES['cp_ncdm_tables'] = (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, cp_param, cp_param, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                               _c_double_p, _c_double_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p])
+NCDM_NKNOTS = 119
+
 BG_PARAMS = ('h', 'Omega_cdm', 'Omega_b', 'Omega_k', 'T_cmb', 'N_ur', 'w0_fld', 'wa_fld')
 SPLINE_BC = {'natural': 0, 'clamped': 1, 'not-a-knot': 2}
 PK_PARAMS = ('A_s', 'n_s', 'alpha_s', 'beta_s', 'k_pivot')
@@ -71,10 +84,11 @@ EH_SCALARS = ('rs_drag', 'z_drag', 'z_eq', 'k_eq', 'r_drag', 'r_eq', 'k_silk', '
 BG_KINDS = {'comoving_radial_distance': 0, 'comoving_transverse_distance': 1, 'angular_diameter_distance': 2, 'luminosity_distance': 3,
             'efunc': 4, 'hubble_function': 5, 'growth_cpt': 6, 'growth_rate': 7, 'rho_crit': 8, 'Omega_m': 9, 'Omega_de': 10,
             'rho_g': 11, 'rho_b': 12, 'rho_ur': 13, 'rho_cdm': 14, 'rho_k': 15, 'rho_Lambda': 16, 'rho_fld': 17, 'rho_de': 18, 'rho_tot': 19,
-            'rho_m': 20, 'rho_r': 21, 'T_cmb': 22, 'time': 23, 'age': 24}
+            'rho_m': 20, 'rho_r': 21, 'T_cmb': 22, 'time': 23, 'age': 24, 'rho_ncdm': 25, 'p_ncdm': 26}
 BG_AS_FRACTION = 32
-for _name in ('g', 'b', 'ur', 'cdm', 'k', 'Lambda', 'fld', 'r'):     # Omega_x(z) = rho_x(z) / rho_crit(z)
+for _name in ('g', 'b', 'ur', 'cdm', 'k', 'Lambda', 'fld', 'r', 'ncdm'):     # Omega_x(z) = rho_x(z) / rho_crit(z)
     BG_KINDS['Omega_' + _name] = BG_KINDS['rho_' + _name] | BG_AS_FRACTION
+BG_KINDS['pfrac_ncdm'] = BG_KINDS['p_ncdm'] | BG_AS_FRACTION     # p_ncdm(z) / rho_crit(z)
 
 _lib = None
 

@@ -19,7 +19,54 @@ def _is_torch(x):
     return type(x).__module__.startswith('torch')
 
 
-def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=None):
+def _cparam(v, device, keep):
+    """cp_param of a float or a per-cosmology array / tensor (kept alive in ``keep``); returns (cp_param, length or None)."""
+    import torch
+    if np.ndim(v) == 0 and not _is_torch(v):
+        return _lib.cp_param(None, float(v)), None
+    t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else torch.from_numpy(np.ascontiguousarray(v, dtype='f8')).to(device)
+    t = t.reshape(-1).contiguous()
+    keep.append(t)
+    return _lib.cp_param(t.data_ptr(), 0.), t.numel()
+
+
+class NcdmTables(object):
+
+    """
+    Massive neutrinos for the background kernels (``cp_ncdm_tables``): per cosmology and species the natural cubic splines of the
+    comoving density and pressure on the reference's 119 knots (DefaultBackground.rho_ncdm / p_ncdm caches, cosmology.py:1961-1998,
+    built from _compute_ncdm_momenta :74-137 with numpy's 100-point Gauss-Laguerre rule).  ``m_ncdm`` [eV], ``T_ncdm_over_cmb``:
+    one entry per species, each a float or an array of shape (ncosmo,), like ``h`` and ``T_cmb``.
+    """
+    def __init__(self, m_ncdm, T_ncdm_over_cmb, h=DEFAULTS['h'], T_cmb=DEFAULTS['T_cmb'], ncosmo=1, device=None):
+        import torch
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.device = torch.device(device)
+        self.nspecies, self.ncosmo = len(m_ncdm), int(ncosmo)
+        if len(T_ncdm_over_cmb) != self.nspecies:
+            raise TypeError('T_ncdm_over_cmb and m_ncdm must be of same length, found {:d} != {:d}'.format(len(T_ncdm_over_cmb), self.nspecies))
+        self.tab = torch.zeros((self.ncosmo, self.nspecies, 4, _lib.NCDM_NKNOTS), dtype=torch.float64, device=self.device)
+        if not self.nspecies:
+            return
+        keep = []
+        ch, cT = _cparam(h, self.device, keep)[0], _cparam(T_cmb, self.device, keep)[0]
+        cm = (_lib.cp_param * self.nspecies)(*[_cparam(v, self.device, keep)[0] for v in m_ncdm])
+        ct = (_lib.cp_param * self.nspecies)(*[_cparam(v, self.device, keep)[0] for v in T_ncdm_over_cmb])
+        for t in keep:
+            if t.numel() != self.ncosmo:
+                raise ValueError('per-cosmology arrays must have length ncosmo = {:d}, got {:d}'.format(self.ncosmo, t.numel()))
+        nodes, weights = np.polynomial.laguerre.laggauss(100)
+        nodes, weights = np.ascontiguousarray(nodes, dtype='f8'), np.ascontiguousarray(weights, dtype='f8')
+        _lib.check(_lib.load().cp_ncdm_tables(self.ncosmo, self.nspecies, ch, cT, ctypes.cast(cm, ctypes.c_void_p), ctypes.cast(ct, ctypes.c_void_p), 100,
+                                              _lib.as_double_p(nodes), _lib.as_double_p(weights), self.tab.data_ptr(), self.device.index,
+                                              torch.cuda.current_stream(self.device).cuda_stream))
+
+    def struct(self, species=None):
+        return _lib.cp_ncdm(self.nspecies, -1 if species is None else int(species), self.tab.data_ptr())
+
+
+def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=None, ncdm=None, species=None):
     """
     Evaluate ``kind`` (one of :data:`KINDS`: 'comoving_radial_distance', 'comoving_transverse_distance',
     'angular_diameter_distance', 'luminosity_distance' [Mpc/h], 'efunc', 'hubble_function' [km/s/Mpc]).
@@ -97,8 +144,14 @@ def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=N
     out = torch.empty(ncosmo * nz, dtype=torch.float64, device=device)
     if ncosmo * nz:
         stream = torch.cuda.current_stream(device).cuda_stream
-        _lib.check(_lib.load().cp_background_distance(ncosmo, nz, ctypes.cast(cparams, ctypes.c_void_p), int(Omega_m is not None), tz.data_ptr(),
-                                                      int(not per_cosmology_z), out.data_ptr(), _lib.BG_KINDS[kind], device.index, stream))
+        cn = None
+        if ncdm is not None and ncdm.nspecies:
+            if ncdm.ncosmo != ncosmo:
+                raise ValueError('massive-neutrino tables hold {:d} cosmologies, the parameters {:d}'.format(ncdm.ncosmo, ncosmo))
+            cn = ncdm.struct(species)
+        _lib.check(_lib.load().cp_background_eval(ncosmo, nz, ctypes.cast(cparams, ctypes.c_void_p), int(Omega_m is not None),
+                                                  ctypes.byref(cn) if cn is not None else None, tz.data_ptr(), int(not per_cosmology_z), out.data_ptr(),
+                                                  _lib.BG_KINDS[kind], device.index, stream))
     out = out.reshape(oshape)
     if z_torch:
         return out.to(out_dtype)

@@ -49,6 +49,22 @@ def _is_array(v):
     return dv.is_torch(v) or np.ndim(v) > 0
 
 
+def _ncdm_momenta_z0(T_eff, m, out='rho'):
+    """Phase-space integral of one massive species today (reference _compute_ncdm_momenta, cosmology.py:74-137, 100-point
+    Gauss-Laguerre), in 1e10 Msun / Mpc^3: host-side parameter derivation (Omega_ncdm, Omega_m -> Omega_cdm), floats or (B,) arrays."""
+    T_eff, m = np.asarray(_host(T_eff), dtype='f8'), np.asarray(_host(m), dtype='f8')
+    over_T = 1.602176634e-19 / (1.380649e-23 * T_eff)
+    m2 = ((m * over_T)**2)[..., None]
+    ti, wi = np.polynomial.laguerre.laggauss(100)
+    if out == 'rho':
+        f = ti**2 * np.sqrt(ti**2 + m2) / (1. + np.exp(-ti))
+    else:
+        f = 1. / 3. * ti**4 / np.sqrt(ti**2 + m2) / (1. + np.exp(-ti))
+    c, sb, _ = bgmod_constants()
+    mpc, msun = 1e6 * 3.085677581491367e16, 1.98847 * 1e30
+    return 7. / 8. * 4 / c**3 * sb * T_eff**4 * np.sum(f * wi, axis=-1) / (7. * np.pi**4 / 120.) / (1e10 * msun) * mpc**3
+
+
 def _compile_params(args):
     """Input parameters -> the canonical set (a reduced restatement of reference Cosmology._compile_params, cosmology.py:874-1217)."""
     params = {}
@@ -67,9 +83,30 @@ def _compile_params(args):
             for name in group:
                 out.pop(name, None)
     out.update(params)
+    if out.pop('neutrino_hierarchy', None) is not None:
+        raise NotImplementedError('neutrino_hierarchy is not supported: give the list of masses m_ncdm')
+    if 'Omega_ncdm' in out or 'omega_ncdm' in out:
+        raise NotImplementedError('massive neutrinos are specified by their masses m_ncdm on this path (not Omega_ncdm)')
+    # massive neutrinos (reference cosmology.py:960-969, 1113-1140): one entry per species, each a float or a (B,) array
     m_ncdm = out.pop('m_ncdm', None)
-    if m_ncdm is not None and np.size(m_ncdm) and np.any(np.asarray(m_ncdm) > 0.):
-        raise NotImplementedError('massive neutrinos are outside the MI355X hot path (SURVEY.md 8(f) f3)')
+    if m_ncdm is None:
+        m_ncdm = []
+    elif isinstance(m_ncdm, (list, tuple)):
+        m_ncdm = list(m_ncdm)           # entries: a float, or a (B,) array for a batch of cosmologies
+    else:
+        m_ncdm = list(np.atleast_1d(_host(m_ncdm)))   # a scalar or a 1D array: the masses of the species
+    m_ncdm = [m if _is_array(m) else float(m) for m in m_ncdm]
+    T_over = out.pop('T_ncdm_over_cmb', None)
+    if T_over is None:
+        T_over = TNCDM_OVER_CMB
+    if np.ndim(T_over) == 0:
+        T_over = [T_over] * len(m_ncdm)
+    T_over = [float(t) for t in T_over]
+    if len(T_over) != len(m_ncdm):
+        raise TypeError('T_ncdm_over_cmb and m_ncdm must be of same length, found {:d} != {:d}'.format(len(T_over), len(m_ncdm)))
+    if 'N_ncdm' in out and out.pop('N_ncdm') not in (None, len(m_ncdm)):
+        raise ValueError('provided N_ncdm does not match len(m_ncdm) = {:d}'.format(len(m_ncdm)))
+    out['m_ncdm'], out['T_ncdm_over_cmb'] = m_ncdm, T_over
     if 'H0' in out:
         out['h'] = out.pop('H0') / 100.
     h = out['h']
@@ -78,10 +115,19 @@ def _compile_params(args):
             out['Omega_' + name] = out.pop('omega_' + name) / h**2
     if 'Omega_c' in out:
         out['Omega_cdm'] = out.pop('Omega_c')
-    if 'Omega_m' in out:   # Omega_cdm = Omega_m - Omega_b (no massive neutrinos), cosmology.py:1163-1165
-        out['Omega_cdm'] = out.pop('Omega_m') - out['Omega_b']
-    if 'N_ur' not in out:  # no massive species: N_ur = N_eff, cosmology.py:1108-1140
-        out['N_ur'] = out.pop('N_eff')
+    if 'Omega_m' in out:   # Omega_cdm = Omega_m - Omega_b - non-relativistic part of the massive neutrinos, cosmology.py:1163-1165
+        rck = bgmod_constants()[2] / (1e10 * 1.98847 * 1e30) * (1e6 * 3.085677581491367e16)**3     # rho_crit_over_Msunph_per_Mpcph3
+        nonrel = sum((_ncdm_momenta_z0(_host(out['T_cmb']) * t, m, 'rho') - 3 * _ncdm_momenta_z0(_host(out['T_cmb']) * t, m, 'p')) for t, m in zip(T_over, m_ncdm))
+        nonrel = nonrel / np.asarray(_host(h), dtype='f8')**2 / rck if m_ncdm else 0.
+        if np.ndim(nonrel) == 0:
+            nonrel = float(nonrel)
+        elif dv.is_torch(out['Omega_m']) or dv.is_torch(out['Omega_b']):
+            nonrel = dv.torch().as_tensor(nonrel, device=(out['Omega_m'] if dv.is_torch(out['Omega_m']) else out['Omega_b']).device)
+        out['Omega_cdm'] = out.pop('Omega_m') - out['Omega_b'] - nonrel
+    if 'N_ur' not in out:  # N_ur = N_eff - sum over massive species (T_ncdm / T_cmb)^4 (4/11)^(-4/3), cosmology.py:1123-1127
+        out['N_ur'] = out.pop('N_eff') - sum(t**4 * (4. / 11.)**(-4. / 3.) for t in T_over)
+    else:
+        out.pop('N_eff', None)
     if 'logA' in out:
         out['A_s'] = np.exp(out.pop('logA')) * 1e-10 if not dv.is_torch(out['logA']) else dv.torch().exp(out.pop('logA')) * 1e-10
     w0, wa = out['w0_fld'], out['wa_fld']
@@ -127,26 +173,45 @@ class BaseCosmoParams(object):
         if name == 'Omega_ur':
             return params['N_ur'] * 7. / 8. * self.get('T_ur')**4 * 4. / c**3 * sb / (params['h']**2 * rck)
         if name == 'Omega_r':
-            return self.get('Omega_g') + self.get('Omega_ur')
-        if name in ('m_ncdm_tot', 'Omega_ncdm_tot', 'Omega_pncdm_tot', 'N_ncdm'):
-            return 0 if name == 'N_ncdm' else 0.
-        if name in ('m_ncdm', 'Omega_ncdm', 'Omega_pncdm'):
-            return []
+            return self.get('Omega_g') + self.get('Omega_ur') + self._like(self.get('Omega_pncdm_tot'))
+        if name == 'N_ncdm':
+            return len(params['m_ncdm'])
+        if name == 'm_ncdm_tot':
+            return sum(params['m_ncdm']) if params['m_ncdm'] else 0.
+        if name == 'T_ncdm':
+            return np.array(params['T_ncdm_over_cmb']) * params['T_cmb'] if not _is_array(params['T_cmb']) else [t * params['T_cmb'] for t in params['T_ncdm_over_cmb']]
+        if name in ('Omega_ncdm', 'Omega_pncdm'):   # today's density / 3 x pressure of every species over rho_crit (cosmology.py:371-376)
+            rck = bgmod_constants()[2] / (1e10 * 1.98847 * 1e30) * (1e6 * 3.085677581491367e16)**3
+            fac = 1. if name == 'Omega_ncdm' else 3.
+            T_cmb, h = np.asarray(_host(params['T_cmb']), dtype='f8'), np.asarray(_host(params['h']), dtype='f8')
+            vals = [fac * _ncdm_momenta_z0(T_cmb * t, m, 'rho' if name == 'Omega_ncdm' else 'p') / h**2 / rck for t, m in zip(params['T_ncdm_over_cmb'], params['m_ncdm'])]
+            return np.array(vals) if all(np.ndim(v) == 0 for v in vals) else vals
+        if name in ('Omega_ncdm_tot', 'Omega_pncdm_tot'):
+            vals = self.get(name[:-4])
+            return sum(vals) if len(vals) else 0.
         if name == 'Omega_m':
-            return params['Omega_b'] + params['Omega_cdm'] + 0. - 0.
+            return params['Omega_b'] + params['Omega_cdm'] + self._like(self.get('Omega_ncdm_tot')) - self._like(self.get('Omega_pncdm_tot'))
         if name == 'Omega_de':
-            return 1. - (params['Omega_cdm'] + params['Omega_b'] + self.get('Omega_g') + self.get('Omega_ur') + 0. + params['Omega_k'])
+            return 1. - (params['Omega_cdm'] + params['Omega_b'] + self.get('Omega_g') + self.get('Omega_ur') + self._like(self.get('Omega_ncdm_tot'))
+                         + params['Omega_k'])
         if name == 'Omega_Lambda':
             return 0. if self._has_fld else self.get('Omega_de')
         if name == 'Omega_fld':
             return self.get('Omega_de') if self._has_fld else 0.
         if name == 'K':
             return - 100.**2 / (c / 1e3)**2 * params['Omega_k']
-        if name == 'N_eff':
-            return params['N_ur']
+        if name == 'N_eff':   # cosmology.py:402-403
+            return sum(t**4 * (4. / 11.)**(-4. / 3.) for t in params['T_ncdm_over_cmb']) + params['N_ur']
         if has_default:
             return default
         raise CosmologyError('Parameter {} not found.'.format(name))
+
+    def _like(self, v):
+        """Host value -> same kind as the (possibly torch) parameters it is combined with."""
+        if np.ndim(v) and any(dv.is_torch(x) for x in self._params.values()):
+            ref = next(x for x in self._params.values() if dv.is_torch(x))
+            return dv.torch().as_tensor(np.asarray(v, dtype='f8'), device=ref.device)
+        return v
 
     @property
     def _has_fld(self):
@@ -158,9 +223,10 @@ class BaseCosmoParams(object):
     @property
     def batch_size(self):
         """Number of cosmologies when parameters are arrays, else None."""
-        for v in self._params.values():
-            if _is_array(v):
-                return int(np.size(v)) if not dv.is_torch(v) else int(v.numel())
+        for name, v in self._params.items():
+            for x in (v if name in ('m_ncdm', 'T_ncdm_over_cmb') else [v]):
+                if _is_array(x):
+                    return int(np.size(x)) if not dv.is_torch(x) else int(x.numel())
         return None
 
     def bg_params(self):
@@ -233,6 +299,9 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
             section = name[4:]
             if section in self.__dict__.get('_Sections', {}):
                 def getter():
+                    if section != 'background' and self['N_ncdm']:
+                        raise NotImplementedError('with massive neutrinos only the background section is available on the MI355X path '
+                                                  '(the analytic P(k) engines "cannot cope with massive neutrinos" in the reference either)')
                     if section not in self._sections:
                         self._sections[section] = self._Sections[section](self)
                     return self._sections[section]
@@ -355,6 +424,11 @@ class BaseBackground(BaseSection):
         for name in ['cdm', 'b', 'k', 'g', 'ur', 'r', 'ncdm_tot', 'pncdm_tot', 'm', 'Lambda', 'fld', 'de']:
             setattr(self, '_Omega0_{}'.format(name), engine['Omega_{}'.format(name)])
         self._bg = engine.bg_params()
+        self._T0_ncdm = engine['T_ncdm']
+        self._ncdm = None
+        if self._N_ncdm:   # massive neutrinos: spline tables of density and pressure, built on the device once (cosmology.py:1961-1998)
+            self._ncdm = bgmod.NcdmTables(self._m_ncdm, engine['T_ncdm_over_cmb'], h=self._h, T_cmb=self._T0_cmb, ncosmo=engine.batch_size or 1,
+                                          device=self.device)
 
     def __getattr__(self, name):
         # properties H0, h, Omega0_x, ... (reference utils.addproperty, cosmology.py:1627-1630)
@@ -362,8 +436,8 @@ class BaseBackground(BaseSection):
             return self.__dict__['_' + name]
         raise AttributeError(name)
 
-    def _eval(self, kind, z):
-        return bgmod.distance(kind, z, self._bg, device=self.device)
+    def _eval(self, kind, z, species=None):
+        return bgmod.distance(kind, z, self._bg, device=self.device, ncdm=self._ncdm, species=species)
 
     def efunc(self, z):
         r"""E(z) = H(z) / H0, unitless (cosmology.py:1751-1754)."""
@@ -421,11 +495,58 @@ class BaseBackground(BaseSection):
         """Density parameter of the dark energy fluid at z (cosmology.py:1846-1849)."""
         return self._de_split('Omega_fld', 'fld', z)
 
-    # no massive neutrinos on this path (N_ncdm = 0): their densities and pressures are identically zero (cosmology.py:1652-1678)
-    def rho_ncdm_tot(self, z):
-        return self._zeros_like(z)
+    # massive neutrinos: interpolated tables as DefaultBackground (cosmology.py:1961-1998); identically zero without massive species
+    def _per_species(self, kind, z, species, scale=1.):
+        if species is not None:
+            return self._eval(kind, z, species=species) * scale if self._N_ncdm else self._zeros_like(z)
+        if not self._N_ncdm:
+            first = self._zeros_like(z)
+            return np.zeros((0,) + tuple(first.shape), dtype=first.dtype) if not dv.is_torch(first) else first.new_zeros((0,) + tuple(first.shape))
+        vals = [self._eval(kind, z, species=s) * scale for s in range(self._N_ncdm)]
+        return dv.torch().stack(vals) if dv.is_torch(vals[0]) else np.stack(vals)
 
-    p_ncdm_tot = Omega_ncdm_tot = Omega_pncdm_tot = rho_ncdm_tot
+    def _ncdm_tot(self, kind, z, scale=1.):
+        return self._eval(kind, z) * scale if self._N_ncdm else self._zeros_like(z)
+
+    def rho_ncdm(self, z, species=None):
+        """Comoving density of massive neutrinos, every species (N_ncdm,) + z.shape or one (cosmology.py:1961-1978)."""
+        return self._per_species('rho_ncdm', z, species)
+
+    def p_ncdm(self, z, species=None):
+        """Pressure of massive neutrinos (cosmology.py:1980-1998)."""
+        return self._per_species('p_ncdm', z, species)
+
+    def rho_ncdm_tot(self, z):
+        """Total comoving density of massive neutrinos (cosmology.py:1661-1663)."""
+        return self._ncdm_tot('rho_ncdm', z)
+
+    def p_ncdm_tot(self, z):
+        """Total pressure of massive neutrinos (cosmology.py:1675-1677)."""
+        return self._ncdm_tot('p_ncdm', z)
+
+    def Omega_ncdm(self, z, species=None):
+        """Density parameter of massive neutrinos at z (cosmology.py:1812-1819)."""
+        return self._per_species('Omega_ncdm', z, species)
+
+    def Omega_ncdm_tot(self, z):
+        """Total density parameter of massive neutrinos at z (cosmology.py:1821-1824)."""
+        return self._ncdm_tot('Omega_ncdm', z)
+
+    def Omega_pncdm(self, z, species=None):
+        """Density parameter of the pressure of massive neutrinos, 3 p / rho_crit (cosmology.py:1826-1833)."""
+        return self._per_species('pfrac_ncdm', z, species, scale=3)
+
+    def Omega_pncdm_tot(self, z):
+        """Total density parameter of the pressure of massive neutrinos (cosmology.py:1835-1838)."""
+        return self._ncdm_tot('pfrac_ncdm', z, scale=3)
+
+    def T_ncdm(self, z, species=None):
+        """Temperature of the massive neutrinos, K: (N_ncdm,) + z.shape, or one species (cosmology.py:1766-1772)."""
+        zp1 = self._eval('T_cmb', z) / self._T0_cmb
+        T0 = np.asarray(self._T0_ncdm, dtype='f8')
+        if species is not None:
+            return zp1 * T0[species]
+        return T0.reshape((-1,) + (1,) * np.ndim(zp1)) * zp1
 
     def comoving_radial_distance(self, z):
         """Comoving radial distance, in Mpc/h (cosmology.py:2027-2042)."""

@@ -47,6 +47,10 @@ struct Args {
     double* out;
     int kind;
     const void* tab;  // TablesN<NK> of the kernel instantiation
+    // massive neutrinos (cp_ncdm): spline tables (ncosmo, nsp, 4, CP_NCDM_NKNOTS), their knots (device), species selector
+    const double* ncdm_tab;
+    const double* ncdm_knots;
+    int nsp, species;
 };
 
 // TIME: the integrand carries 1 / (1 + z) and the result is (T_last - spline(z)) / h / (Gyr per Mpc): DefaultBackground.time / age
@@ -59,12 +63,15 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         double* dst = reinterpret_cast<double*>(&T);
         for (int i = threadIdx.x; i < (int)(sizeof(TablesN<NK>) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
     }
+    __shared__ double ncdm_knots[CP_NCDM_NKNOTS];
+    if (A.nsp)
+        for (int i = threadIdx.x; i < CP_NCDM_NKNOTS; i += blockDim.x) ncdm_knots[i] = A.ncdm_knots[i];
     __syncthreads();
     const long long nsamp = A.ncosmo * A.nz;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsamp) return;
     const long long ic = i / A.nz, iz = i - ic * A.nz;
-    const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m);
+    const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m, A.ncdm_tab, ncdm_knots, A.nsp);
     const double z = A.z[A.z_shared ? iz : i];
     const double nan = __builtin_nan("");
     auto integrand = [&](double zz) { return TIME ? kCkms / (1. + zz) / (100. * efunc(c, zz)) : kCkms / (100. * efunc(c, zz)); };
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         const double zp1 = 1. + z;
         const double rc = rho_crit(c, zp1);
         A.out[i] = A.kind == CP_BG_RHO_CRIT ? rc
-                 : (A.kind == CP_BG_OMEGA_M_Z ? (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rc : rho_de(c, zp1) / rc);
+                 : (A.kind == CP_BG_OMEGA_M_Z ? rho_m(c, zp1) / rc : rho_de(c, zp1) / rc);
         return;
     }
     if (!TIME && (A.kind & ~CP_BG_AS_FRACTION) >= CP_BG_RHO_G) {  // BaseBackground.rho_x / Omega_x, cosmology.py:1680-1736, 1774-1853
@@ -99,10 +106,12 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
             case CP_BG_RHO_LAMBDA: v = c.Omega_de / (zp1 * zp1 * zp1) * kRhoCrit; break;
             case CP_BG_RHO_FLD: v = c.Omega_de * pow(zp1, 3. * (1 + c.w0 + c.wa)) * exp(3. * c.wa * (1. / zp1 - 1)) * kRhoCrit / (zp1 * zp1 * zp1); break;
             case CP_BG_RHO_DE: v = rho_de(c, zp1); break;
-            case CP_BG_RHO_TOT: v = (cdm + b + 0.) + (g + ur) + rho_de(c, zp1); break;
-            case CP_BG_RHO_M: v = cdm + b + 0. - 3. * 0.; break;
-            case CP_BG_RHO_R: v = g + ur + 3. * 0.; break;
+            case CP_BG_RHO_TOT: v = (cdm + b + ncdm_eval(c, z, 0)) + (g + ur) + rho_de(c, zp1); break;
+            case CP_BG_RHO_M: v = cdm + b + ncdm_eval(c, z, 0) - 3. * ncdm_eval(c, z, 1); break;
+            case CP_BG_RHO_R: v = g + ur + 3. * ncdm_eval(c, z, 1); break;
             case CP_BG_T_CMB_Z: v = c.T_cmb * zp1; break;
+            case CP_BG_RHO_NCDM: v = ncdm_eval(c, z, 0, A.species); break;
+            case CP_BG_P_NCDM: v = ncdm_eval(c, z, 1, A.species); break;
         }
         if (A.kind & CP_BG_AS_FRACTION) v = v / rho_crit(c, zp1);
         A.out[i] = v;
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     }
     if (!TIME && A.kind == CP_BG_GROWTH_RATE) {  // Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))), eisenstein_hu.py:151-152
         const double zp1 = 1. + z;
-        const double Om = (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rho_crit(c, zp1);
+        const double Om = rho_m(c, zp1) / rho_crit(c, zp1);
         const double wz1 = c.w0 + (1. - 0.5) * c.wa;
         A.out[i] = pow(Om, 0.55 + 0.05 * (1 + wz1));
         return;
@@ -260,7 +269,160 @@ TablesN<NK>* device_tables(int device) {
     return cache[device];
 }
 
+// ---- massive neutrinos --------------------------------------------------------------------------------------------------------
+// knots: concatenate(linspace(0, 1, 20)[:-1], 1 / geomspace(1e-8, 1/2, 100)[::-1] - 1), cosmology.py:1941-1943
+void build_ncdm_knots(double* zc) {
+    const double zm = 1.;
+    for (int i = 0; i < 19; ++i) zc[i] = 0. + i * ((zm - 0.) / 19.);
+    const double la = std::log10(1e-8), lb = std::log10(1. / (1. + zm));
+    double g[100];
+    for (int i = 0; i < 100; ++i) g[i] = std::pow(10., la + i * ((lb - la) / 99.));
+    g[0] = 1e-8;
+    g[99] = 1. / (1. + zm);
+    for (int i = 0; i < 100; ++i) zc[19 + i] = 1. / g[99 - i] - 1.;
+}
+
+double* device_ncdm_knots(int device) {
+    static double* cache[64] = {nullptr};
+    if (device < 0 || device >= 64) return nullptr;
+    if (!cache[device]) {
+        double h[CP_NCDM_NKNOTS];
+        build_ncdm_knots(h);
+        double* d = nullptr;
+        if (hipMalloc(&d, sizeof(h)) != hipSuccess) return nullptr;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        cache[device] = d;
+    }
+    return cache[device];
+}
+
+constexpr int NCDM_MAX_SPECIES = 8;
+constexpr int NCDM_MAX_NQ = 128;
+
+struct NcdmArgs {
+    long long ncosmo;
+    int nsp, nq;
+    Param h, T_cmb, m[NCDM_MAX_SPECIES], T_over[NCDM_MAX_SPECIES];
+    const double* knots;
+    const double* rule;  // device, nodes then weights (2 nq)
+    double* tab;
+};
+
+// _compute_ncdm_momenta (cosmology.py:74-137, method 'laguerre') / (1 + z)^3 / h^2 (_get_ncdm, :441-442) on every knot:
+// one thread per (cosmology, species, knot) computes the density and the pressure
+__global__ __launch_bounds__(128) void ncdm_momenta_kernel(const NcdmArgs A) {
+    __shared__ double rule[2 * NCDM_MAX_NQ];
+    for (int i = threadIdx.x; i < 2 * A.nq; i += blockDim.x) rule[i] = A.rule[i];
+    __syncthreads();
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.ncosmo * A.nsp * CP_NCDM_NKNOTS) return;
+    const int k = (int)(i % CP_NCDM_NKNOTS);
+    const int s = (int)((i / CP_NCDM_NKNOTS) % A.nsp);
+    const long long ic = i / ((long long)CP_NCDM_NKNOTS * A.nsp);
+    const double h = A.h.ptr ? A.h.ptr[ic] : A.h.value;
+    const double T_cmb = A.T_cmb.ptr ? A.T_cmb.ptr[ic] : A.T_cmb.value;
+    const double m = A.m[s].ptr ? A.m[s].ptr[ic] : A.m[s].value;
+    const double T_eff = T_cmb * (A.T_over[s].ptr ? A.T_over[s].ptr[ic] : A.T_over[s].value);
+    constexpr double kEv = 1.602176634e-19, kBoltzmann = 1.380649e-23;  // scipy.constants (exact SI values)
+    const double z = A.knots[k];
+    const double a = 1. / (1. + z);
+    const double over_T = kEv / (kBoltzmann * (T_eff / a));
+    const double m2 = (m * over_T) * (m * over_T);
+    double rho = 0., pr = 0.;
+    for (int q = 0; q < A.nq; ++q) {
+        const double t = rule[q], w = rule[A.nq + q];
+        const double e = sqrt(t * t + m2), f = 1. + exp(-1. * t);
+        rho += t * t * e / f * w;
+        pr += 1. / 3. * (t * t) * (t * t) / e / f * w;
+    }
+    const double Ta = T_eff / a;
+    const double pref = 7. / 8. * 4 / (kC * kC * kC) * kStefanBoltzmann * (Ta * Ta * Ta * Ta);
+    const double norm = (7. * (kPi * kPi * kPi * kPi) / 120.) * (1e10 * kMsun);
+    const double zp1 = 1. + z;
+    const double scale = (kMpc * kMpc * kMpc) / (zp1 * zp1 * zp1) / (h * h);
+    double* t0 = A.tab + ((ic * A.nsp + s) * 4) * (long long)CP_NCDM_NKNOTS;
+    t0[k] = pref * rho / norm * scale;
+    t0[2 * CP_NCDM_NKNOTS + k] = pref * pr / norm * scale;
+}
+
+// second derivatives of the natural cubic splines through the tabulated values: one thread per (cosmology, species, rho | p)
+__global__ __launch_bounds__(64) void ncdm_spline_kernel(const NcdmArgs A) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.ncosmo * A.nsp * 2) return;
+    double* y = A.tab + (i / 2 * 4 + (i & 1) * 2) * (long long)CP_NCDM_NKNOTS;
+    double* m = y + CP_NCDM_NKNOTS;
+    const double* x = A.knots;
+    constexpr int n = CP_NCDM_NKNOTS;
+    double cp[n], dp[n];  // Thomas algorithm on h_{i-1} m_{i-1} + 2 (h_{i-1} + h_i) m_i + h_i m_{i+1} = 6 (slope_i - slope_{i-1})
+    cp[0] = 0.;
+    dp[0] = 0.;
+    for (int j = 1; j < n - 1; ++j) {
+        const double h0 = x[j] - x[j - 1], h1 = x[j + 1] - x[j];
+        const double rhs = 6. * ((y[j + 1] - y[j]) / h1 - (y[j] - y[j - 1]) / h0);
+        const double den = 2. * (h0 + h1) - h0 * cp[j - 1];
+        cp[j] = h1 / den;
+        dp[j] = (rhs - h0 * dp[j - 1]) / den;
+    }
+    m[n - 1] = 0.;
+    for (int j = n - 2; j >= 1; --j) m[j] = dp[j] - cp[j] * m[j + 1];
+    m[0] = 0.;
+}
+
 }  // namespace
+
+extern "C" int cp_ncdm_knots(double* zc_out, int n) {
+    if (!zc_out || n != CP_NCDM_NKNOTS) return cp::fail(CP_EINVAL, "cp_ncdm_knots: need a buffer of %d doubles", CP_NCDM_NKNOTS);
+    build_ncdm_knots(zc_out);
+    return CP_OK;
+}
+
+extern "C" int cp_ncdm_tables(long long ncosmo, int nspecies, cp_param h, cp_param T_cmb, const cp_param* m_ncdm, const cp_param* T_ncdm_over_cmb,
+                              int nq, const double* nodes, const double* weights, double* d_tab, int device, void* stream) {
+    if (ncosmo < 0 || nspecies < 0) return cp::fail(CP_EINVAL, "cp_ncdm_tables: negative size");
+    if (ncosmo == 0 || nspecies == 0) return CP_OK;
+    if (nspecies > NCDM_MAX_SPECIES) return cp::fail(CP_EUNSUPPORTED, "cp_ncdm_tables: at most %d massive species", NCDM_MAX_SPECIES);
+    if (nq < 1 || nq > NCDM_MAX_NQ) return cp::fail(CP_EINVAL, "cp_ncdm_tables: quadrature size must be in [1, %d]", NCDM_MAX_NQ);
+    if (!m_ncdm || !T_ncdm_over_cmb || !nodes || !weights || !d_tab) return cp::fail(CP_EINVAL, "cp_ncdm_tables: null pointer");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_ncdm_tables: cannot select device %d", device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    NcdmArgs A;
+    A.ncosmo = ncosmo;
+    A.nsp = nspecies;
+    A.nq = nq;
+    A.h.ptr = h.ptr; A.h.value = h.value;
+    A.T_cmb.ptr = T_cmb.ptr; A.T_cmb.value = T_cmb.value;
+    for (int s = 0; s < nspecies; ++s) {
+        A.m[s].ptr = m_ncdm[s].ptr; A.m[s].value = m_ncdm[s].value;
+        A.T_over[s].ptr = T_ncdm_over_cmb[s].ptr; A.T_over[s].value = T_ncdm_over_cmb[s].value;
+    }
+    A.knots = device_ncdm_knots(device);
+    A.tab = d_tab;
+    double* d_rule = nullptr;
+    int rc = CP_OK;
+    if (!A.knots || hipMalloc(&d_rule, 2 * nq * sizeof(double)) != hipSuccess) {
+        rc = cp::fail(CP_ENOMEM, "cp_ncdm_tables: cannot allocate on device %d", device);
+    } else {
+        std::vector<double> rule(2 * nq);
+        for (int q = 0; q < nq; ++q) rule[q] = nodes[q], rule[nq + q] = weights[q];
+        if (hipMemcpyAsync(d_rule, rule.data(), 2 * nq * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {  // `rule` is a local: the copy must have left it
+            rc = cp::fail(CP_EDEVICE, "cp_ncdm_tables: cannot upload the quadrature rule");
+        } else {
+            A.rule = d_rule;
+            const long long n1 = ncosmo * nspecies * CP_NCDM_NKNOTS, n2 = ncosmo * nspecies * 2;
+            hipLaunchKernelGGL(ncdm_momenta_kernel, dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, st, A);
+            hipLaunchKernelGGL(ncdm_spline_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, A);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(st);  // d_rule is freed below
+            if (e != hipSuccess) rc = cp::fail(CP_EDEVICE, "cp_ncdm_tables: launch failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (d_rule) (void)hipFree(d_rule);
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
 
 extern "C" int cp_background_knots(double* zc_out, int n) {
     if (zc_out && n == NK_TIME) {  // the 400 knots of time / age
@@ -278,12 +440,20 @@ extern "C" int cp_background_knots(double* zc_out, int n) {
 
 extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const double* d_z,
                                       int z_shared, double* d_out, int kind, int device, void* stream) {
+    return cp_background_eval(ncosmo, nz, params, second_is_omega_m, nullptr, d_z, z_shared, d_out, kind, device, stream);
+}
+
+extern "C" int cp_background_eval(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const cp_ncdm* ncdm,
+                                  const double* d_z, int z_shared, double* d_out, int kind, int device, void* stream) {
     if (ncosmo < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_background_distance: negative size");
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_background_eval: bad massive-neutrino tables");
+    if (nsp > 0 && (ncdm->species < -1 || ncdm->species >= nsp)) return cp::fail(CP_EINVAL, "cp_background_eval: species %d of %d", ncdm->species, nsp);
     if (ncosmo == 0 || nz == 0) return CP_OK;
     if (!params || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_background_distance: null pointer");
     {
         const int base = kind & ~CP_BG_AS_FRACTION;
-        if (kind < 0 || base > CP_BG_KIND_LAST || ((kind & CP_BG_AS_FRACTION) && (base < CP_BG_RHO_G || base >= CP_BG_T_CMB_Z)))
+        if (kind < 0 || base > CP_BG_KIND_LAST || ((kind & CP_BG_AS_FRACTION) && (base < CP_BG_RHO_G || (base >= CP_BG_T_CMB_Z && base <= CP_BG_AGE))))
             return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
     }
     int prev = -1;
@@ -308,6 +478,14 @@ extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_p
     A.out = d_out;
     A.kind = kind;
     A.tab = tab;
+    A.nsp = nsp;
+    A.species = nsp ? ncdm->species : -1;
+    A.ncdm_tab = nsp ? ncdm->tab : nullptr;
+    A.ncdm_knots = nsp ? device_ncdm_knots(device) : nullptr;
+    if (nsp && !A.ncdm_knots) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return cp::fail(CP_ENOMEM, "cp_background_eval: cannot allocate the massive-neutrino knots on device %d", device);
+    }
     const long long nsamp = ncosmo * nz;
     const int block = 256;
     const long long grid = (nsamp + block - 1) / block;

@@ -27,10 +27,42 @@ struct Param {
 struct Cosmo {
     double h, Omega_cdm, Omega_b, Omega_k, T_cmb, N_ur, w0, wa;  // inputs
     double Omega_g, Omega_ur, Omega_de;                            // derived, cosmology.py:355-383
+    // massive neutrinos: spline tables of this cosmology (nsp, 4, CP_NCDM_NKNOTS) + the shared knots; nsp == 0: none
+    const double* ncdm_tab;
+    const double* ncdm_knots;
+    int nsp;
 };
 
+// natural cubic spline (values y, second derivatives m on the knots x) at z inside [x[0], x[n-1]]
+__device__ __forceinline__ double spline_m_eval(const double* x, const double* y, const double* m, int n, double z) {
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (z >= x[mid]) lo = mid;
+        else hi = mid;
+    }
+    const double hh = x[lo + 1] - x[lo];
+    const double a = (x[lo + 1] - z) / hh, b = (z - x[lo]) / hh;
+    return a * y[lo] + b * y[lo + 1] + ((a * a * a - a) * m[lo] + (b * b * b - b) * m[lo + 1]) * (hh * hh) / 6.;
+}
+
+// sum over species (or one species) of the interpolated comoving density (which = 0) or pressure (which = 1) of massive neutrinos:
+// DefaultBackground.rho_ncdm / p_ncdm (cosmology.py:1961-1998); NaN outside the knots as Interpolator1D without extrapolation
+__device__ __forceinline__ double ncdm_eval(const Cosmo& c, double z, int which, int species = -1) {
+    if (c.nsp == 0) return 0.;
+    if (!(z >= c.ncdm_knots[0] && z <= c.ncdm_knots[CP_NCDM_NKNOTS - 1])) return __builtin_nan("");
+    double tot = 0.;
+    for (int s = 0; s < c.nsp; ++s) {
+        if (species >= 0 && s != species) continue;
+        const double* t = c.ncdm_tab + ((long long)s * 4 + 2 * which) * CP_NCDM_NKNOTS;
+        tot = tot + spline_m_eval(c.ncdm_knots, t, t + CP_NCDM_NKNOTS, CP_NCDM_NKNOTS, z);
+    }
+    return tot;
+}
+
 // load the 8 background parameters of cosmology ic and derive the radiation / dark-energy densities
-__device__ __forceinline__ Cosmo load_cosmo(const Param* p, long long ic, int second_is_omega_m) {
+__device__ __forceinline__ Cosmo load_cosmo(const Param* p, long long ic, int second_is_omega_m, const double* ncdm_tab = nullptr,
+                                            const double* ncdm_knots = nullptr, int nsp = 0) {
     double v[CP_BG_NPARAMS];
 #pragma unroll
     for (int k = 0; k < CP_BG_NPARAMS; ++k) v[k] = p[k].ptr ? p[k].ptr[ic] : p[k].value;
@@ -47,7 +79,20 @@ __device__ __forceinline__ Cosmo load_cosmo(const Param* p, long long ic, int se
     c.Omega_g = (c.T_cmb * c.T_cmb * c.T_cmb * c.T_cmb) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
     const double T_ur = c.T_cmb * 0.7137658555036082;  // (4/11)^(1/3)
     c.Omega_ur = c.N_ur * 7. / 8. * (T_ur * T_ur * T_ur * T_ur) * 4. / (kC * kC * kC) * kStefanBoltzmann / h2rc;
-    c.Omega_de = 1. - (c.Omega_cdm + c.Omega_b + c.Omega_g + c.Omega_ur + 0. + c.Omega_k);
+    c.nsp = nsp;
+    c.ncdm_knots = ncdm_knots;
+    c.ncdm_tab = nsp ? ncdm_tab + ic * (long long)nsp * 4 * CP_NCDM_NKNOTS : nullptr;
+    double Omega_ncdm_tot = 0.;
+    if (nsp) {  // z = 0 is the first knot: the tabulated values are the reference's _get_ncdm(z=0) (cosmology.py:371-376)
+        double rho0 = 0., p0 = 0.;
+        for (int s = 0; s < nsp; ++s) {
+            rho0 = rho0 + c.ncdm_tab[((long long)s * 4 + 0) * CP_NCDM_NKNOTS];
+            p0 = p0 + c.ncdm_tab[((long long)s * 4 + 2) * CP_NCDM_NKNOTS];
+        }
+        Omega_ncdm_tot = rho0 / kRhoCrit;
+        if (second_is_omega_m) c.Omega_cdm = c.Omega_cdm - (rho0 - 3 * p0) / kRhoCrit;  // cosmology.py:1163-1165
+    }
+    c.Omega_de = 1. - (c.Omega_cdm + c.Omega_b + c.Omega_g + c.Omega_ur + Omega_ncdm_tot + c.Omega_k);
     return c;
 }
 
@@ -57,7 +102,7 @@ __device__ __forceinline__ double rho_de(const Cosmo& c, double zp1) {
 }
 
 __device__ __forceinline__ double rho_crit(const Cosmo& c, double zp1) {
-    const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0.;
+    const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + ncdm_eval(c, zp1 - 1., 0);
     const double r = c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit;
     return (m + r + rho_de(c, zp1)) + c.Omega_k / zp1 * kRhoCrit;
 }
@@ -67,11 +112,16 @@ __device__ __forceinline__ double efunc(const Cosmo& c, double z) {
     return sqrt(rho_crit(c, zp1) * (zp1 * zp1 * zp1) / kRhoCrit);  // cosmology.py:1754
 }
 
+// rho_m(z) = cdm + b + ncdm - 3 p_ncdm (cosmology.py:1704-1707)
+__device__ __forceinline__ double rho_m(const Cosmo& c, double zp1) {
+    return c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + ncdm_eval(c, zp1 - 1., 0) - 3. * ncdm_eval(c, zp1 - 1., 1);
+}
+
 // CPT92 growth(z) of the analytic engines, un-normalised (eisenstein_hu.py:134-136)
 __device__ __forceinline__ double growth_cpt(const Cosmo& c, double z) {
     const double zp1 = 1. + z;
     const double rc = rho_crit(c, zp1);
-    const double Om = (c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + 0. - 0.) / rc;  // rho_m / rho_crit, cosmology.py:1701, 1796
+    const double Om = rho_m(c, zp1) / rc;  // rho_m / rho_crit, cosmology.py:1701, 1796
     const double Ode = rho_de(c, zp1) / rc;
     return 1. / zp1 * 5 * Om / 2. / (pow(Om, 4. / 7.) - Ode + (1. + Om / 2.) * (1 + Ode / 70.));
 }

@@ -106,7 +106,9 @@ enum cp_bg_kind {
     CP_BG_T_CMB_Z = 22,            /* T0_cmb (1+z), K               cosmology.py:1762 */
     CP_BG_TIME = 23,               /* proper time (age of the universe at z), Gyr   DefaultBackground.time, cosmology.py:2000-2012 */
     CP_BG_AGE = 24,                /* age today, Gyr (z ignored)                     DefaultBackground.age,  cosmology.py:2014-2025 */
-    CP_BG_KIND_LAST = 24,
+    CP_BG_RHO_NCDM = 25,           /* massive neutrinos: comoving density of species cp_ncdm.species (-1: all)  DefaultBackground.rho_ncdm, cosmology.py:1961-1978 */
+    CP_BG_P_NCDM = 26,             /* ... and pressure                                                          DefaultBackground.p_ncdm,   cosmology.py:1980-1998 */
+    CP_BG_KIND_LAST = 26,
     CP_BG_AS_FRACTION = 32
 };
 /* a per-cosmology parameter: device array of ncosmo doubles, or (ptr == NULL) one value for all cosmologies */
@@ -118,8 +120,30 @@ typedef struct cp_param {
  * (Mpc/h for distances).  z outside [0, 9999] gives NaN as in the reference.  Asynchronous on `stream` of `device`. */
 int cp_background_distance(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const double* d_z, int z_shared,
                            double* d_out, int kind, int device, void* stream);
-/* the 119 interpolation knots (host), get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949 */
+/* the 119 interpolation knots (host), get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949 (n = 119),
+ * or the 400 knots of time / age, cosmology.py:1945-1946 (n = 400) */
 int cp_background_knots(double* zc_out, int n);
+
+/* ---- massive neutrinos (reference cosmology.py:74-137 _compute_ncdm_momenta, :1961-1998 DefaultBackground.rho_ncdm / p_ncdm) ----
+ * The reference tabulates, per species, the comoving density and pressure on 119 redshift knots (get_default_z_interp('rho_ncdm'),
+ * cosmology.py:1941-1943) by 100-point Gauss-Laguerre quadrature of the frozen Fermi-Dirac distribution and interpolates them with
+ * natural cubic splines wherever E(z) is needed.  cp_ncdm_tables builds those tables (values and spline second derivatives) on the
+ * device for a batch of cosmologies; cp_background_eval is cp_background_distance with the tables added to every density. */
+#define CP_NCDM_NKNOTS 119
+typedef struct cp_ncdm {
+    int nspecies;       /* number of massive species (0: none) */
+    int species;        /* CP_BG_RHO_NCDM / CP_BG_P_NCDM only: which species, -1 = sum over species */
+    const double* tab;  /* device, (ncosmo, nspecies, 4, CP_NCDM_NKNOTS): rho, rho'', p, p'' in 1e10 Msun/h / (Mpc/h)^3 */
+} cp_ncdm;
+int cp_ncdm_knots(double* zc_out, int n);
+/* m_ncdm[s] (eV) and T_ncdm_over_cmb[s], s < nspecies: per-cosmology parameters like h and T_cmb; nodes / weights: the nq-point
+ * Gauss-Laguerre rule (host arrays; the reference uses numpy.polynomial.laguerre.laggauss(100)); d_tab as in cp_ncdm.tab */
+int cp_ncdm_tables(long long ncosmo, int nspecies, cp_param h, cp_param T_cmb, const cp_param* m_ncdm, const cp_param* T_ncdm_over_cmb, int nq,
+                   const double* nodes, const double* weights, double* d_tab, int device, void* stream);
+/* cp_background_distance with massive neutrinos (ncdm may be NULL or have nspecies == 0).  With `second_is_omega_m` the non-relativistic
+ * part of the neutrinos at z = 0 is taken out of Omega_m as well (cosmology.py:1163-1165). */
+int cp_background_eval(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const cp_ncdm* ncdm, const double* d_z,
+                       int z_shared, double* d_out, int kind, int device, void* stream);
 
 /* ---- analytic matter power spectra for batches of cosmologies (replaces Transfer.transfer_k, Primordial.pk_k and the
  *      pk_callable x growth_factor_sq of Fourier.pk_interpolator in eisenstein_hu.py:189-215, 241-283, 315-324,

@@ -1,0 +1,86 @@
+"""GPU parity of the massive-neutrino background: cp_ncdm_tables + cp_background_eval through the Cosmology /
+Background API against golden vectors from the reference (tests/golden/ncdm.npz) and the oracle.  Tolerances: parameters 1e-13;
+tables and E(z) 1e-12; distances and time 1e-10 (1e-9 for time at z >= 10: T_last - T(z) cancels)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import background as ob
+from oracle.gen_golden import NCDM_PARAMS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def cp():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    import cosmoprimo_amd
+    return cosmoprimo_amd
+
+
+@pytest.mark.parametrize('ic', range(len(NCDM_PARAMS)))
+def test_ncdm_background(cp, golden, ic):
+    g = golden('ncdm')
+    z = g['z']
+    pre = 'c%d_' % ic
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **NCDM_PARAMS[ic])
+        ba = cosmo.get_background()
+    for name in ['N_ur', 'N_eff', 'Omega_ncdm_tot', 'Omega_pncdm_tot', 'Omega_m', 'Omega_de', 'Omega_cdm', 'Omega_r', 'm_ncdm_tot']:
+        np.testing.assert_allclose(cosmo[name], g[pre + 'par_' + name], rtol=1e-13, err_msg=name)
+    np.testing.assert_allclose(cosmo['Omega_ncdm'], g[pre + 'par_Omega_ncdm'], rtol=1e-13)
+    np.testing.assert_allclose(cosmo['T_ncdm'], g[pre + 'par_T_ncdm'], rtol=1e-15)
+    assert ba.N_ncdm == len(np.atleast_1d(NCDM_PARAMS[ic]['m_ncdm']))
+    np.testing.assert_allclose(ba.rho_ncdm(z), g[pre + 'rho_ncdm'], rtol=1e-12)
+    np.testing.assert_allclose(ba.p_ncdm(z), g[pre + 'p_ncdm'], rtol=1e-12)
+    np.testing.assert_allclose(ba.rho_ncdm(z, species=0), g[pre + 'rho_ncdm'][0], rtol=1e-12)
+    np.testing.assert_allclose(ba.Omega_ncdm(z), g[pre + 'Omega_ncdm_z'], rtol=1e-12)
+    np.testing.assert_allclose(ba.T_ncdm(z), g[pre + 'T_ncdm_z'], rtol=1e-14)
+    for name in ['efunc', 'rho_ncdm_tot', 'p_ncdm_tot', 'rho_m', 'rho_r', 'rho_tot', 'rho_crit', 'Omega_m', 'Omega_r', 'Omega_ncdm_tot', 'Omega_pncdm_tot', 'Omega_de']:
+        np.testing.assert_allclose(getattr(ba, name)(z), g[pre + name], rtol=1e-12, err_msg=name)
+    for name in ['comoving_radial_distance', 'angular_diameter_distance', 'luminosity_distance']:
+        np.testing.assert_allclose(getattr(ba, name)(z), g[pre + name], rtol=1e-10, atol=1e-300, err_msg=name)
+    np.testing.assert_allclose(ba.time(z)[:14], g[pre + 'time'][:14], rtol=1e-10)
+    np.testing.assert_allclose(ba.time(z), g[pre + 'time'], rtol=1e-9)
+    np.testing.assert_allclose(ba.age, g[pre + 'age'], rtol=1e-12)
+    # same inputs through the oracle: E(z) and D_C
+    par = dict(NCDM_PARAMS[ic])
+    m = par.pop('m_ncdm')
+    t = par.pop('T_ncdm_over_cmb', None)
+    p = ob.derived_ncdm(m, T_ncdm_over_cmb=None if t is None else np.asarray(t, dtype='f8'), **par)
+    np.testing.assert_allclose(ba.efunc(z), ob.efunc_ncdm(z, p), rtol=1e-12)
+    np.testing.assert_allclose(ba.comoving_radial_distance(z), ob.comoving_radial_distance_ncdm(z, p), rtol=1e-10, atol=1e-300)
+    assert np.isnan(ba.rho_ncdm_tot(np.array([-0.5, 1e9]))).all()
+    with pytest.raises(NotImplementedError):
+        cosmo.get_fourier()
+
+
+def test_ncdm_tables_and_batch(cp, golden):
+    g = golden('ncdm')
+    from cosmoprimo_amd import _lib, background as bg
+    kn = np.empty(119)
+    _lib.check(_lib.load().cp_ncdm_knots(_lib.as_double_p(kn), 119))
+    np.testing.assert_allclose(kn, g['ncdm_knots'], rtol=1e-15)
+    par = NCDM_PARAMS[-1]
+    tabs = bg.NcdmTables(par['m_ncdm'], par['T_ncdm_over_cmb'], h=0.7, T_cmb=2.7255)
+    np.testing.assert_allclose(tabs.tab[0, 0, 0].cpu().numpy(), g['rho_ncdm_table'][:, 0], rtol=1e-13)
+    # a batch of cosmologies (h, Omega_m, one mass per cosmology) equals the cosmologies taken one by one
+    z = g['z'][:14]
+    hs, oms, ms = np.array([0.7, 0.64, 0.72]), np.array([0.3, 0.36, 0.27]), np.array([0.06, 0.1, 0.2])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        bb = cp.Cosmology(engine='eisenstein_hu', h=hs, Omega_m=oms, m_ncdm=[ms, 0.05]).get_background()
+        out = bb.comoving_radial_distance(z)
+        assert out.shape == (3, z.size) and bb.rho_ncdm(z).shape == (2, 3, z.size)
+        for i in range(3):
+            one = cp.Cosmology(engine='eisenstein_hu', h=hs[i], Omega_m=oms[i], m_ncdm=[ms[i], 0.05]).get_background()
+            np.testing.assert_allclose(out[i], one.comoving_radial_distance(z), rtol=1e-13, atol=1e-300)
+            np.testing.assert_allclose(bb.Omega_m(z)[i], one.Omega_m(z), rtol=1e-13)
+    # no massive species: empty per-species arrays, zero totals (cosmology.py:1969-1970)
+    b0 = cp.Cosmology(engine='eisenstein_hu').get_background()
+    assert b0.rho_ncdm(z).shape == (0, z.size) and (b0.rho_ncdm_tot(z) == 0.).all() and b0.N_ncdm == 0
+    with pytest.raises(NotImplementedError):
+        cp.Cosmology(m_ncdm=0.06, neutrino_hierarchy='normal')
