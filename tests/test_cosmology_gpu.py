@@ -137,3 +137,16 @@ def test_tabulated_interpolators(cp, golden):
     bad = pkt[:, 0].copy()
     bad[100] = -1.
     assert np.isnan(cp.PowerSpectrumInterpolator1D(kt, bad)(kk)).all()
+
+
+def test_distance_to_redshift(cp):
+    """DistanceToRedshift (reference utils.py:275-316, tests/test_utils.py:63-75): spline inversion of D_C(z)."""
+    from cosmoprimo_amd.utils import DistanceToRedshift
+    ba = cp.Cosmology(engine='eisenstein_hu').get_background()
+    zmax = 10.
+    d2z = DistanceToRedshift(ba.comoving_radial_distance, zmax=zmax, nz=4096)
+    z = np.random.default_rng(0).uniform(0., 2., 1000)
+    assert np.allclose(d2z(ba.comoving_radial_distance(z)), z, atol=1e-6)
+    with pytest.raises(ValueError):
+        d2z(ba.comoving_radial_distance(np.array([zmax * 1.5])))
+    assert np.isnan(d2z(ba.comoving_radial_distance(np.array([zmax * 1.5])), bounds_error=False)).all()
