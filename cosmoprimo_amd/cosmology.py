@@ -299,9 +299,10 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
             section = name[4:]
             if section in self.__dict__.get('_Sections', {}):
                 def getter():
-                    if section != 'background' and self['N_ncdm']:
+                    if section != 'background' and self['N_ncdm'] and not getattr(self, '_copes_with_ncdm', False):
                         raise NotImplementedError('with massive neutrinos only the background section is available on the MI355X path '
-                                                  '(the analytic P(k) engines "cannot cope with massive neutrinos" in the reference either)')
+                                                  '(these analytic engines "cannot cope with massive neutrinos" in the reference either: use '
+                                                  "engine='eisenstein_hu_nowiggle_variants')")
                     if section not in self._sections:
                         self._sections[section] = self._Sections[section](self)
                     return self._sections[section]

@@ -370,6 +370,8 @@ __global__ __launch_bounds__(64) void ncdm_spline_kernel(const NcdmArgs A) {
 
 }  // namespace
 
+const double* cpcosmo::ncdm_knots_device(int device) { return device_ncdm_knots(device); }
+
 extern "C" int cp_ncdm_knots(double* zc_out, int n) {
     if (!zc_out || n != CP_NCDM_NKNOTS) return cp::fail(CP_EINVAL, "cp_ncdm_knots: need a buffer of %d doubles", CP_NCDM_NKNOTS);
     build_ncdm_knots(zc_out);

@@ -126,4 +126,7 @@ __device__ __forceinline__ double growth_cpt(const Cosmo& c, double z) {
     return 1. / zp1 * 5 * Om / 2. / (pow(Om, 4. / 7.) - Ode + (1. + Om / 2.) * (1 + Ode / 70.));
 }
 
+// device copy of the CP_NCDM_NKNOTS massive-neutrino knots (cp_background.hip), nullptr on failure
+const double* ncdm_knots_device(int device);
+
 }  // namespace cpcosmo

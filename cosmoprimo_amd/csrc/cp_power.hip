@@ -202,6 +202,105 @@ __global__ __launch_bounds__(256) void eh_scalars_kernel(const ScalArgs A) {
     o[CP_EH_BBKS_GAMMA] = Omega_m * (c.h * c.h) * exp(-c.Omega_b * (1. + sqrt(2. * c.h) / Omega_m));
 }
 
+// ---- eisenstein_hu_nowiggle_variants: Eisenstein & Hu 1997 with massive neutrinos (reference eisenstein_hu_nowiggle_variants.py) ----
+struct VarArgs {
+    long long ncosmo;
+    Param bg[CP_BG_NPARAMS];
+    Param pw[CP_PK_NPARAMS];
+    int second_is_omega_m;
+    int what, of;
+    long long nk, nz;
+    const double* k;
+    const double* z;
+    double* out;  // (ncosmo, nz, nk)
+    const double* ncdm_tab;
+    const double* ncdm_knots;
+    int nsp;
+};
+
+__global__ __launch_bounds__(256) void variants_kernel(const VarArgs A) {
+    __shared__ double knots[CP_NCDM_NKNOTS];
+    if (A.nsp)
+        for (int i = threadIdx.x; i < CP_NCDM_NKNOTS; i += blockDim.x) knots[i] = A.ncdm_knots[i];
+    __syncthreads();
+    const long long ik = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long ic = blockIdx.y;
+    if (ik >= A.nk) return;
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, knots, A.nsp);
+    // engine scalars, _set_rsdrag / compute (:32-76)
+    const double h2 = c.h * c.h;
+    double Omega_ncdm = 0., Omega_pncdm = 0.;
+    for (int s = 0; s < c.nsp; ++s) {
+        Omega_ncdm += c.ncdm_tab[((long long)s * 4 + 0) * CP_NCDM_NKNOTS] / kRhoCrit;
+        Omega_pncdm += 3. * c.ncdm_tab[((long long)s * 4 + 2) * CP_NCDM_NKNOTS] / kRhoCrit;
+    }
+    const double omega_b = c.Omega_b * h2;
+    const double omega_m = c.Omega_cdm * h2 + c.Omega_b * h2 + Omega_ncdm * h2 - Omega_pncdm * h2;
+    const double frac_b = omega_b / omega_m, frac_cdm = c.Omega_cdm * h2 / omega_m;
+    const double frac_cb = frac_cdm + frac_b, frac_ncdm = 1. - frac_cb;
+    const double N = (double)c.nsp;
+    const double theta_cmb = c.T_cmb / 2.7;
+    const double z_eq = 2.5e4 * omega_m * pow(theta_cmb, -4.) - 1.;
+    const double b1 = 0.313 * pow(omega_m, -0.419) * (1 + 0.607 * pow(omega_m, 0.674));
+    const double b2 = 0.238 * pow(omega_m, 0.223);
+    const double z_drag = 1291 * pow(omega_m, 0.251) / (1. + 0.659 * pow(omega_m, 0.828)) * (1. + b1 * pow(omega_b, b2));
+    const double rs_drag = 44.5 * log(9.83 / omega_m) / sqrt(1. + 10. * pow(omega_b, 0.75));
+    const double fbn = frac_b + frac_ncdm;
+    const double p_c = (5. - sqrt(1 + 24 * frac_cdm)) / 4., p_cb = (5. - sqrt(1 + 24. * frac_cb)) / 4.;
+    const double y_drag = (1 + z_eq) / (1 + z_drag);
+    const double alpha = frac_cdm / frac_cb * (5. - 2. * (p_c + p_cb)) / (5. - 4. * p_cb) * pow(1 + y_drag, p_cb - p_c) *
+                         (1 + fbn * (-0.553 + 0.126 * (fbn * fbn))) / (1 - 0.193 * sqrt(frac_ncdm * N) + 0.169 * frac_ncdm * pow(N, 0.2)) *
+                         (1 + (p_c - p_cb) / 2 * (1 + 1 / (3. - 4. * p_c) / (7. - 4. * p_cb)) / (1 + y_drag));
+    const double gamma_ncdm = sqrt(alpha);
+    const double beta_c = 1 / (1 - 0.949 * fbn);
+    // transfer_kz (:114-154): the z-independent part
+    const double khm = A.k[ik];          // h/Mpc
+    const double k = khm * c.h;          // 1/Mpc
+    const double q = k / omega_m * (theta_cmb * theta_cmb);
+    const double kr = k * rs_drag * 0.43;
+    const double gamma_eff = omega_m * (gamma_ncdm + (1 - gamma_ncdm) / (1 + (kr * kr) * (kr * kr)));
+    const double q_eff = q * omega_m / gamma_eff;
+    const double TL = log(kE + 1.84 * beta_c * gamma_ncdm * q_eff);
+    const double TC = 14.4 + 325. / (1 + 60.5 * pow(q_eff, 1.08));
+    double T_sup = TL / (TL + TC * (q_eff * q_eff));
+    double yfs = 0.;
+    if (c.nsp) {
+        const double qn = 3.92 * q * sqrt(N / frac_ncdm);
+        T_sup *= 1 + 1.24 * pow(frac_ncdm, 0.64) * pow(N, 0.3 + 0.6 * frac_ncdm) / (pow(qn, -1.6) + pow(qn, 0.8));
+        const double nq = N * q / frac_ncdm;
+        yfs = 17.2 * frac_ncdm * (1 + 0.488 * pow(frac_ncdm, -7. / 6.)) * (nq * nq);
+    }
+    // primordial spectrum and the potential -> density factors (Fourier.pk_interpolator :178-185, eisenstein_hu.py:214-215)
+    double pdd = 0.;
+    if (A.what == CP_PK_MATTER) {
+        double pw[CP_PK_NPARAMS];
+#pragma unroll
+        for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
+        const double kp = pw[CP_PK_K_PIVOT] / c.h;
+        const double lnkkp = log(khm / kp);
+        const double prim = (c.h * c.h * c.h) * pw[CP_PK_A_S] *
+                            pow(khm / kp, pw[CP_PK_N_S] - 1. + 1. / 2. * pw[CP_PK_ALPHA_S] * lnkkp + 1. / 6. * pw[CP_PK_BETA_S] * (lnkkp * lnkkp));
+        const double Omega0_m = c.Omega_b + c.Omega_cdm + Omega_ncdm - Omega_pncdm;  // cosmology.py:381
+        const double p2d = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (khm * khm));
+        pdd = 1. / (p2d * p2d) * (9. / 25. * 2. * (kPi * kPi) / (khm * khm * khm) / (c.h * c.h * c.h)) * prim;
+    }
+    double* out = A.out + ic * A.nz * A.nk + ik;
+    for (long long iz = 0; iz < A.nz; ++iz) {
+        const double z = A.z[iz];
+        const double g = growth_cpt(c, z);  // Background.growth_factor(z, znorm): (1 + znorm) x this, eisenstein_hu.py:134-139
+        double ratio = 1.;                 // growth / growth_k0 (:119-134)
+        if (c.nsp) {
+            const double gk0 = (1. + z_eq) * g;
+            const double t1 = pow(gk0, 1. - p_cb);
+            const double t2 = pow(gk0 / (1 + yfs), 0.7);
+            const double growth = A.of == 1 ? pow(1. + t2, p_cb / 0.7) * t1 : pow(pow(frac_cb, 0.7 / p_cb) + t2, p_cb / 0.7) * t1;
+            ratio = growth / gk0;
+        }
+        const double T = T_sup * ratio;
+        out[iz * A.nk] = A.what == CP_PK_TRANSFER ? T : (T * T) * (g * g) * pdd;
+    }
+}
+
 int select_device(int device, int* prev) {
     *prev = -1;
     if (hipGetDevice(prev) != hipSuccess) *prev = -1;
@@ -241,6 +340,47 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+extern "C" int cp_power_eval_variants(int what, int of, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                                      const cp_param* pk_params, long long nk, const double* d_k, long long nz, const double* d_z, double* d_out,
+                                      int device, void* stream) {
+    if (what != CP_PK_MATTER && what != CP_PK_TRANSFER) return cp::fail(CP_EINVAL, "cp_power_eval_variants: unknown quantity %d", what);
+    if (of != 0 && of != 1) return cp::fail(CP_EINVAL, "cp_power_eval_variants: of must be 0 (delta_m) or 1 (delta_cb)");
+    if (ncosmo < 0 || nk < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_power_eval_variants: negative size");
+    if (ncosmo == 0 || nk == 0 || nz == 0) return CP_OK;
+    if (!bg_params || !pk_params || !d_k || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_power_eval_variants: null pointer");
+    if (ncosmo > 65535) return cp::fail(CP_EUNSUPPORTED, "cp_power_eval_variants: at most 65535 cosmologies per call (got %lld); split the batch", ncosmo);
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_power_eval_variants: bad massive-neutrino tables");
+    int prev;
+    int st = select_device(device, &prev);
+    if (st != CP_OK) return st;
+    VarArgs A;
+    A.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) A.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) A.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};
+    A.second_is_omega_m = second_is_omega_m;
+    A.what = what;
+    A.of = of;
+    A.nk = nk;
+    A.nz = nz;
+    A.k = d_k;
+    A.z = d_z;
+    A.out = d_out;
+    A.nsp = nsp;
+    A.ncdm_tab = nsp ? ncdm->tab : nullptr;
+    A.ncdm_knots = nsp ? cpcosmo::ncdm_knots_device(device) : nullptr;
+    if (nsp && !A.ncdm_knots) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return cp::fail(CP_ENOMEM, "cp_power_eval_variants: cannot allocate the massive-neutrino knots on device %d", device);
+    }
+    const int block = 256;
+    hipLaunchKernelGGL(variants_kernel, dim3((unsigned)((nk + block - 1) / block), (unsigned)ncosmo), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval_variants: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
 

@@ -78,3 +78,34 @@ def eh_scalars(bg=None, Omega_m=None, device=None):
     out = torch.empty((ncosmo, len(_lib.EH_SCALARS)), dtype=torch.float64, device=device)
     _lib.check(_lib.load().cp_eh_scalars(ncosmo, dv.as_void_p(cbg), int(Omega_m is not None), out.data_ptr(), device.index, dv.stream_of(device)))
     return {name: (out[:, i] if n is not None else out[0, i]) for i, name in enumerate(_lib.EH_SCALARS)}
+
+
+def variants(what, k, z, of='delta_m', bg=None, pk=None, ncdm=None, device=None):
+    """
+    ``what`` in ('matter', 'transfer') of the 'eisenstein_hu_nowiggle_variants' engine (reference eisenstein_hu_nowiggle_variants.py:
+    Eisenstein & Hu 1997 with massive neutrinos) through ``cp_power_eval_variants``.  ``ncdm``: :class:`cosmoprimo_amd.background.NcdmTables`
+    of the same cosmologies, or None.  Returns a device tensor (ncosmo,) (if batched) + (nz, nk).
+    """
+    import ctypes
+    torch = dv.torch()
+    bg, pk = dict(bg or {}), dict(pk or {})
+    device = dv.resolve_device(device, k, z, *bg.values(), *pk.values())
+    cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, BG_DEFAULTS, device)
+    cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, device)
+    if n1 is not None and n2 is not None and n1 != n2:
+        raise ValueError('parameter arrays must share one length, got {} and {}'.format(n1, n2))
+    batched = n1 is not None or n2 is not None
+    ncosmo = n1 or n2 or 1
+    if ncosmo > 32768:
+        raise NotImplementedError('at most 32768 cosmologies per call')
+    tk, tz = dv.to_device(k, device).reshape(-1), dv.to_device(z, device).reshape(-1)
+    out = torch.empty((ncosmo, tz.numel(), tk.numel()), dtype=torch.float64, device=device)
+    cn = None
+    if ncdm is not None and ncdm.nspecies:
+        if ncdm.ncosmo != ncosmo:
+            raise ValueError('massive-neutrino tables hold {:d} cosmologies, the parameters {:d}'.format(ncdm.ncosmo, ncosmo))
+        cn = ncdm.struct()
+    _lib.check(_lib.load().cp_power_eval_variants(_lib.PK_WHAT[what], {'delta_m': 0, 'delta_cb': 1}[of], ncosmo, dv.as_void_p(cbg), 0,
+                                                  ctypes.byref(cn) if cn is not None else None, dv.as_void_p(cpk), tk.numel(), tk.data_ptr(), tz.numel(),
+                                                  tz.data_ptr(), out.data_ptr(), device.index, dv.stream_of(device)))
+    return out if batched else out[0]

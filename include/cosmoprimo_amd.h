@@ -168,6 +168,14 @@ enum cp_eh_scalar {
     CP_EH_BBKS_GAMMA = 13, CP_EH_NSCALARS = 14
 };
 /* d_out : (ncosmo, CP_EH_NSCALARS) fit coefficients of eisenstein_hu.py:34-92, eisenstein_hu_nowiggle.py:21, bbks.py:38 */
+/* eisenstein_hu_nowiggle_variants (reference eisenstein_hu_nowiggle_variants.py: Eisenstein & Hu 1997 with massive neutrinos,
+ * scale-dependent growth): Transfer.transfer_kz (:87-154) or the matter power spectrum of Fourier.pk_interpolator (:159-193),
+ * T(k, z)^2 x growth_factor(z, znorm=0)^2 x potential_to_density x curvature_to_potential x P_R(k).
+ * what: CP_PK_TRANSFER | CP_PK_MATTER; of: 0 'delta_m', 1 'delta_cb'; ncdm as for cp_background_eval (NULL: no massive species);
+ * d_out: (ncosmo, nz, nk), k fastest.  nz >= 1. */
+int cp_power_eval_variants(int what, int of, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                           const cp_param* pk_params, long long nk, const double* d_k, long long nz, const double* d_z, double* d_out, int device,
+                           void* stream);
 int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, double* d_out, int device, void* stream);
 
 /* ---- cubic splines from fixed knots to fixed queries, applied to batches of rows as a banded linear operator

@@ -484,6 +484,40 @@ def gen_ncdm(cp):
     save('ncdm', **out)
 
 
+VARIANTS_PARAMS = [dict(), dict(m_ncdm=0.06), dict(m_ncdm=[0.02, 0.03, 0.05], Omega_m=0.31, h=0.6766, n_s=0.9665, sigma8=0.81),
+                   dict(m_ncdm=[0.1, 0.4], Omega_b=0.045, T_cmb=2.6, A_s=2.2e-9)]
+
+
+def gen_variants(cp):
+    """f3: eisenstein_hu_nowiggle_variants: engine scalars, transfer_kz (delta_m, delta_cb), P(k, z), sigma8 and the rescaling factor for 4
+    cosmologies without / with one / three / two massive species."""
+    import warnings
+    k = np.concatenate([np.logspace(-5, 2, 36), [0.05, 0.1, 1.]])
+    z = np.array([0., 0.5, 1.5, 4.])
+    out = {'k': k, 'z': z}
+    names = ['omega_b', 'omega_m', 'frac_b', 'frac_cdm', 'frac_cb', 'frac_ncdm', 'theta_cmb', 'z_eq', 'k_eq', 'z_drag', 'rs_drag', 'p_c', 'p_cb',
+             'gamma_ncdm', 'beta_c']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for i, par in enumerate(VARIANTS_PARAMS):
+            cosmo = cp.Cosmology(engine='eisenstein_hu_nowiggle_variants', **par)
+            eng = cosmo._engine if hasattr(cosmo, '_engine') else cosmo.engine
+            for name in names:
+                out['c%d_%s' % (i, name)] = float(getattr(eng, name))
+            tr, fo, ba = cosmo.get_transfer(), cosmo.get_fourier(), cosmo.get_background()
+            out['c%d_growth_k0' % i] = np.asarray(ba.growth_factor(z, znorm=eng.z_eq))
+            for of in ['delta_m', 'delta_cb']:
+                out['c%d_transfer_%s' % (i, of)] = np.asarray(tr.transfer_kz(k, z, of=of))
+                out['c%d_pk_%s' % (i, of)] = np.asarray(fo.pk_interpolator(of=of)(k, z))
+            out['c%d_pk_theta' % i] = np.asarray(fo.pk_interpolator(of='theta_m')(k, z))
+            out['c%d_sigma8_m' % i] = float(fo.sigma8_m)
+            out['c%d_sigma8_z' % i] = np.asarray(fo.sigma8_z(z))
+            out['c%d_rsigma8' % i] = float(eng._rsigma8)
+            out['c%d_A_s' % i] = float(cosmo.get_primordial().A_s)
+            out['c%d_rs_drag_th' % i] = float(cosmo.get_thermodynamics().rs_drag)
+    save('variants', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -509,6 +543,8 @@ def main():
         gen_densities(cp)
     if 'ncdm' in which:
         gen_ncdm(cp)
+    if 'variants' in which:
+        gen_variants(cp)
 
 
 if __name__ == '__main__':

@@ -164,3 +164,65 @@ def pk_z0(k, engine='eisenstein_hu', h=0.7, Omega_cdm=0.25, Omega_b=0.05, T_cmb=
         tr = transfer_eh(k, h, s) if engine == 'eisenstein_hu' else transfer_nowiggle(k, h, s)
     Omega_m = np.asarray(Omega_b, dtype='f8') + np.asarray(Omega_cdm, dtype='f8')
     return pk_callable(k, tr, Omega_m, h, primordial_pk(k, h, A, n_s, alpha_s, beta_s, k_pivot))
+
+
+# ---- eisenstein_hu_nowiggle_variants: Eisenstein & Hu 1997 (astro-ph/9710252) with massive neutrinos -------
+def variants_scalars(p):
+    """EisensteinHuNoWiggleVariantsEngine._set_rsdrag / compute (eisenstein_hu_nowiggle_variants.py:32-76).  ``p`` = oracle/background.py
+    derived() or derived_ncdm() (+ 'T_cmb'); returns the engine's attributes as a dict."""
+    h2 = p['h']**2
+    s = {}
+    s['omega_b'] = p['Omega_b'] * h2
+    ncdm = (np.sum(p['Omega_ncdm']) - np.sum(p['Omega_pncdm'])) if 'Omega_ncdm' in p else 0.
+    s['omega_m'] = p['Omega_cdm'] * h2 + p['Omega_b'] * h2 + ncdm * h2                      # :36 (omega_ncdm_tot - omega_pncdm_tot)
+    s['frac_b'] = s['omega_b'] / s['omega_m']
+    s['frac_cdm'] = p['Omega_cdm'] * h2 / s['omega_m']
+    s['frac_cb'] = s['frac_cdm'] + s['frac_b']
+    s['frac_ncdm'] = 1. - s['frac_cb']
+    s['N_ncdm'] = len(p['m_ncdm']) if 'm_ncdm' in p else 0
+    s['theta_cmb'] = p.get('T_cmb', ob.TCMB) / 2.7
+    om, ob_ = s['omega_m'], s['omega_b']
+    s['z_eq'] = 2.5e4 * om * s['theta_cmb'] ** (-4) - 1.
+    s['k_eq'] = 0.0746 * om * s['theta_cmb'] ** (-2)
+    b1 = 0.313 * om ** (-0.419) * (1 + 0.607 * om ** 0.674)
+    b2 = 0.238 * om ** 0.223
+    s['z_drag'] = 1291 * om ** 0.251 / (1. + 0.659 * om ** 0.828) * (1. + b1 * ob_ ** b2)            # 1291 here, 1345 in eisenstein_hu.py:53
+    s['rs_drag'] = 44.5 * np.log(9.83 / om) / np.sqrt(1. + 10. * ob_ ** 0.75)
+    fbn = s['frac_b'] + s['frac_ncdm']
+    s['p_c'] = (5. - np.sqrt(1 + 24 * s['frac_cdm'])) / 4.
+    s['p_cb'] = (5. - np.sqrt(1 + 24. * s['frac_cb'])) / 4.
+    y_drag = (1 + s['z_eq']) / (1 + s['z_drag'])
+    N = s['N_ncdm']
+    alpha = s['frac_cdm'] / s['frac_cb'] * (5. - 2. * (s['p_c'] + s['p_cb'])) / (5. - 4. * s['p_cb']) * (1 + y_drag) ** (s['p_cb'] - s['p_c']) \
+        * (1 + fbn * (-0.553 + 0.126 * fbn ** 2)) \
+        / (1 - 0.193 * np.sqrt(s['frac_ncdm'] * N) + 0.169 * s['frac_ncdm'] * N ** 0.2) \
+        * (1 + (s['p_c'] - s['p_cb']) / 2 * (1 + 1 / (3. - 4. * s['p_c']) / (7. - 4. * s['p_cb'])) / (1 + y_drag))
+    s['gamma_ncdm'] = np.sqrt(alpha)
+    s['beta_c'] = 1 / (1 - 0.949 * fbn)
+    return s
+
+
+def variants_transfer_kz(k, z, p, s, growth_k0, of='delta_m'):
+    """Transfer.transfer_kz, grid=True (eisenstein_hu_nowiggle_variants.py:87-154): (nk, nz).  ``growth_k0`` = growth_factor(z, znorm=z_eq)."""
+    k = np.asarray(k, dtype='f8')[:, None] * p['h']
+    q = k / s['omega_m'] * s['theta_cmb'] ** 2
+    N, f = s['N_ncdm'], s['frac_ncdm']
+    if N:
+        yfs = 17.2 * f * (1 + 0.488 * f ** (-7. / 6.)) * (N * q / f) ** 2
+        t1 = growth_k0 ** (1. - s['p_cb'])
+        t2 = (growth_k0 / (1 + yfs)) ** 0.7
+        if of == 'delta_cb':
+            growth = (1. + t2) ** (s['p_cb'] / 0.7) * t1
+        else:
+            growth = (s['frac_cb'] ** (0.7 / s['p_cb']) + t2) ** (s['p_cb'] / 0.7) * t1
+    else:
+        growth = growth_k0 = np.ones_like(np.asarray(z, dtype='f8'))
+    gamma_eff = s['omega_m'] * (s['gamma_ncdm'] + (1 - s['gamma_ncdm']) / (1 + (k * s['rs_drag'] * 0.43) ** 4))
+    q_eff = q * s['omega_m'] / gamma_eff
+    TL = np.log(np.e + 1.84 * s['beta_c'] * s['gamma_ncdm'] * q_eff)
+    TC = 14.4 + 325. / (1 + 60.5 * q_eff ** 1.08)
+    T = TL / (TL + TC * q_eff ** 2)
+    if N:
+        qn = 3.92 * q * np.sqrt(N / f)
+        T = T * (1 + 1.24 * f ** 0.64 * N ** (0.3 + 0.6 * f) / (qn ** (-1.6) + qn ** 0.8))
+    return T * growth / growth_k0
