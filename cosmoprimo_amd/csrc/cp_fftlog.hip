@@ -13,6 +13,7 @@
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
 #include "cp_fftlog_kernel.h"
+#include "cp_fftlog_large.h"
 
 using namespace cpfft;
 
@@ -46,6 +47,7 @@ struct cp_fftlog_plan {
     double* d_post;
     cplx* d_u;
     cplx* d_tw;
+    cp_fftlog_large* large;  // Np > CP_FFTLOG_MAX_NP: the general-size path (cp_fftlog_large.hip), everything above unused
 };
 
 #define CP_HIP(call)                                                                               \
@@ -76,12 +78,33 @@ extern "C" int cp_fftlog_plan_create(cp_fftlog_plan** out, int n, int npad, int 
     if (npad < n || (npad & (npad - 1)) != 0)
         return cp::fail(CP_EINVAL, "cp_fftlog_plan_create: padded size %d must be a power of two >= n=%d (fftlog.py:149-159)", npad, n);
     Launcher l;
-    if (npad > CP_FFTLOG_MAX_NP || !find_launcher(npad, &l))
+    if (npad > (1 << 24)) return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_plan_create: padded size %d is beyond the supported range (2^24)", npad);
+    if (npad > CP_FFTLOG_MAX_NP) {  // one packed pair no longer fits the LDS: elementwise kernels around a library FFT
+        cp_fftlog_plan* p = new (std::nothrow) cp_fftlog_plan();
+        if (!p) return cp::fail(CP_ENOMEM, "cp_fftlog_plan_create: host allocation failed");
+        p->n = n; p->npad = npad; p->nker = nker; p->device = device;
+        p->in_left = (npad - n) / 2;
+        p->out_left = (npad - n) - (npad - n) / 2;
+        p->d_pre = p->d_post = nullptr;
+        p->d_u = p->d_tw = nullptr;
+        p->large = nullptr;
+        DeviceGuard guard(device);
+        int st = guard.ok ? cp_fftlog_large_create(&p->large, n, npad, nker, pre, post, u_re_im, device)
+                          : cp::fail(CP_EDEVICE, "cp_fftlog_plan_create: cannot select device %d", device);
+        if (st != CP_OK) {
+            delete p;
+            return st;
+        }
+        *out = p;
+        return CP_OK;
+    }
+    if (!find_launcher(npad, &l))
         return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_plan_create: padded size %d outside the LDS-resident kernel range [4, %d]", npad,
                         CP_FFTLOG_MAX_NP);
     int status = CP_OK;
     cp_fftlog_plan* p = new (std::nothrow) cp_fftlog_plan();
     if (!p) return cp::fail(CP_ENOMEM, "cp_fftlog_plan_create: host allocation failed");
+    p->large = nullptr;
     p->n = n;
     p->npad = npad;
     p->nker = nker;
@@ -141,6 +164,7 @@ extern "C" int cp_fftlog_plan_destroy(cp_fftlog_plan* p) {
         if (p->d_post) (void)hipFree(p->d_post);
         if (p->d_u) (void)hipFree(p->d_u);
         if (p->d_tw) (void)hipFree(p->d_tw);
+        cp_fftlog_large_destroy(p->large);
     }
     delete p;
     return CP_OK;
@@ -153,6 +177,12 @@ static int grid_for(const cp_fftlog_plan* p, int variant, long long nbatch) {
 
 extern "C" int cp_fftlog_plan_info(const cp_fftlog_plan* p, long long nbatch, int* grid, int* block, int* lds_bytes) {
     if (!p) return cp::fail(CP_EINVAL, "cp_fftlog_plan_info: null plan");
+    if (p->large) {  // no persistent kernel on the general-size path
+        if (grid) *grid = 0;
+        if (block) *block = 0;
+        if (lds_bytes) *lds_bytes = 0;
+        return CP_OK;
+    }
     if (grid) *grid = grid_for(p, select_variant(p->npad, p->l.p, p->n, 0, 0., 0, 0., 0), nbatch);
     if (block) *block = p->l.block;
     if (lds_bytes) *lds_bytes = p->l.lds_bytes;
@@ -167,6 +197,12 @@ extern "C" int cp_fftlog_execute(const cp_fftlog_plan* p, const double* d_in, do
     if (!d_in || !d_out) return cp::fail(CP_EINVAL, "cp_fftlog_execute: null device pointer");
     if (extrap_left < CP_EXTRAP_CONSTANT || extrap_left > CP_EXTRAP_LOGLOG || extrap_right < CP_EXTRAP_CONSTANT || extrap_right > CP_EXTRAP_LOGLOG)
         return cp::fail(CP_EINVAL, "cp_fftlog_execute: unknown extrapolation mode (%d, %d)", extrap_left, extrap_right);
+    if (p->large) {
+        DeviceGuard guard(p->device);
+        if (!guard.ok) return cp::fail(CP_EDEVICE, "cp_fftlog_execute: cannot select device %d", p->device);
+        return cp_fftlog_large_execute(p->large, d_in, d_out, nbatch, extrap_left, val_left, extrap_right, val_right, keep_padding,
+                                       static_cast<hipStream_t>(stream));
+    }
     FftlogArgs A;
     A.in = d_in;
     A.out = d_out;

@@ -247,3 +247,29 @@ def test_rescale_rows(cp, golden):
     with pytest.raises(ValueError):
         cp.PowerToCorrelation(k, rescale_rows=True)(rows, extrap=(1.5, 'edge'))
     np.testing.assert_array_equal(cp.PowerToCorrelation(k, rescale_rows=True)(np.zeros((2, k.size)))[1], 0.)
+
+
+@pytest.mark.parametrize('n', [5000, 8192, 20000])
+def test_large_sizes(cp, n):
+    """Padded sizes beyond the LDS-resident kernel (Np = 16384, 16384, 65536): the general-size path (elementwise kernels + hipFFT)
+    follows the same reference arithmetic: every extrap mode, keep_padding, multi-kernel, odd batch."""
+    rng = np.random.default_rng(n)
+    k = np.logspace(-4, 2, n)
+    t = ofl.power_to_correlation(k, ell=[0, 2])
+    f = cp.PowerToCorrelation(k, ell=[0, 2])
+    assert f.padded_size > 8192
+    fun = rng.uniform(0.95, 1.05, size=(3, 2, n)) * k**-1.2
+    with np.errstate(all='ignore'):
+        modes = [(0, False), (0, True), ('edge', False), ((1.5, 'edge'), False)]
+        if n <= 8192:    # the geometric continuation of noisy rows over > 20000 padded samples overflows (in the reference as well)
+            modes += [('log', True), (('log', 0.3), False)]
+        for extrap, keep in modes:
+            ref = ofl.apply(t, fun, extrap=extrap, keep_padding=keep)
+            y, got = f(fun, extrap=extrap, keep_padding=keep)
+            assert got.shape == ref.shape
+            scale = np.abs(ofl.pad(fun, (t.in_left, t.in_right), extrap) * t.pre).max(axis=-1)
+            post = np.abs(t.post[:, t.out_left:t.out_left + t.n] if not keep else t.post)
+            err = np.abs(got - ref) / post / scale[..., None]
+            assert err.max() < 1e-13, (n, extrap, keep, err.max())
+    s, xi = cp.PowerToCorrelation(k, ell=0)(fun[0, 0])
+    assert xi.shape == (n,) and tilted_err(xi, ofl.apply(ofl.power_to_correlation(k, ell=0), fun[0, 0])[0], s, 1.5) < TOL_NORM

@@ -33,8 +33,8 @@ def test_error_mapping():
     with pytest.raises(ValueError):   # npad not a power of two -> CP_EINVAL -> ValueError (reference fftlog.py:155-159)
         _lib.check(lib.cp_fftlog_plan_create(ctypes.byref(handle), 3, 6, 1, _lib.as_double_p(pre), _lib.as_double_p(pre), _lib.as_double_p(pre), 0))
     assert b'power of two' in lib.cp_last_error()
-    with pytest.raises(NotImplementedError):  # beyond the LDS-resident range -> CP_EUNSUPPORTED
-        _lib.check(lib.cp_fftlog_plan_create(ctypes.byref(handle), 10000, 32768, 1, _lib.as_double_p(pre), _lib.as_double_p(pre), _lib.as_double_p(pre), 0))
+    with pytest.raises(NotImplementedError):  # beyond the supported range (2^24) -> CP_EUNSUPPORTED
+        _lib.check(lib.cp_fftlog_plan_create(ctypes.byref(handle), 10000, 1 << 25, 1, _lib.as_double_p(pre), _lib.as_double_p(pre), _lib.as_double_p(pre), 0))
     with pytest.raises(ValueError):
         _lib.kernel_eval(99, 0., np.ones(2, dtype='c16'))
 
