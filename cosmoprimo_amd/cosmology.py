@@ -65,6 +65,43 @@ def _ncdm_momenta_z0(T_eff, m, out='rho'):
     return 7. / 8. * 4 / c**3 * sb * T_eff**4 * np.sum(f * wi, axis=-1) / (7. * np.pi**4 / 120.) / (1e10 * msun) * mpc**3
 
 
+def _split_neutrino_masses(sum_ncdm, hierarchy):
+    """Three masses adding up to ``sum_ncdm`` [eV] under the 'normal', 'inverted' or 'degenerate' hierarchy, by Newton's method on the
+    lightest mass with the squared-mass splittings of arXiv:1907.12598 (reference cosmology.py:1047-1104)."""
+    if sum_ncdm < 0.:
+        raise CosmologyInputError('Parameter {} should be positive, found {}'.format('m_ncdm', sum_ncdm))
+    deltam21sq = 7.39e-5
+
+    def newton(m, d21, d31):
+        m = list(m)
+        check = sum(m)
+        for _ in range(1000):
+            if not abs(sum_ncdm - check) > 1e-15:
+                break
+            m[0] = m[0] + (sum_ncdm - check) / (1. + m[0] / m[1] + m[0] / m[2])
+            m[1] = np.sqrt(m[0]**2 + d21)
+            m[2] = np.sqrt(m[0]**2 + d31)
+            check = sum(m)
+        return [float(x) for x in m]
+
+    if hierarchy == 'normal':
+        deltam31sq = 2.525e-3
+        if sum_ncdm**2 < deltam21sq + deltam31sq:
+            raise CosmologyInputError('If neutrino_hierarchy is normal, we are using the normal hierarchy and so m_ncdm must be greater than '
+                                      '(~)0.0592, found {:.2f}'.format(sum_ncdm))
+        return newton([0., deltam21sq, deltam31sq], deltam21sq, deltam31sq)
+    if hierarchy == 'inverted':
+        deltam32sq = -2.512e-3
+        deltam31sq = deltam32sq + deltam21sq
+        if sum_ncdm**2 < -deltam31sq - deltam32sq:
+            raise CosmologyInputError('If neutrino_hierarchy is inverted, we are using the inverted hierarchy and so m_ncdm must be greater than '
+                                      '(~)0.0978, found {:.2f}'.format(sum_ncdm))
+        return newton([np.sqrt(-deltam31sq), np.sqrt(-deltam32sq), 1e-5], deltam21sq, deltam31sq)
+    if hierarchy == 'degenerate':
+        return [sum_ncdm / 3.] * 3
+    raise CosmologyInputError('Unkown neutrino mass type {}'.format(hierarchy))
+
+
 def _compile_params(args):
     """Input parameters -> the canonical set (a reduced restatement of reference Cosmology._compile_params, cosmology.py:874-1217)."""
     params = {}
@@ -83,8 +120,7 @@ def _compile_params(args):
             for name in group:
                 out.pop(name, None)
     out.update(params)
-    if out.pop('neutrino_hierarchy', None) is not None:
-        raise NotImplementedError('neutrino_hierarchy is not supported: give the list of masses m_ncdm')
+    hierarchy = out.pop('neutrino_hierarchy', None)
     if 'Omega_ncdm' in out or 'omega_ncdm' in out:
         raise NotImplementedError('massive neutrinos are specified by their masses m_ncdm on this path (not Omega_ncdm)')
     # massive neutrinos (reference cosmology.py:960-969, 1113-1140): one entry per species, each a float or a (B,) array
@@ -97,6 +133,13 @@ def _compile_params(args):
         m_ncdm = list(np.atleast_1d(_host(m_ncdm)))   # a scalar or a 1D array: the masses of the species
     m_ncdm = [m if _is_array(m) else float(m) for m in m_ncdm]
     T_over = out.pop('T_ncdm_over_cmb', None)
+    if hierarchy is not None:   # the sum of masses split into three species (reference cosmology.py:1030-1106)
+        single = np.ndim(params.get('m_ncdm', None)) == 0 and params.get('m_ncdm', None) is not None
+        if not single or len(m_ncdm) != 1 or _is_array(m_ncdm[0]):
+            raise CosmologyInputError('neutrino_hierarchy {} cannot be passed with a list for m_ncdm, only with a sum.'.format(hierarchy))
+        m_ncdm = _split_neutrino_masses(m_ncdm[0], hierarchy)
+        if T_over is not None and np.ndim(T_over) > 0:
+            T_over = [list(T_over)[0]] * 3
     if T_over is None:
         T_over = TNCDM_OVER_CMB
     if np.ndim(T_over) == 0:

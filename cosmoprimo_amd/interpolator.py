@@ -139,6 +139,7 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
     """
     device = dv.resolve_device(device)
     rr = _host(r).ravel()
+    nk_leggauss = 100 if nk is None else nk
     if nk is None:
         nk = 1024
     if rr.size == 0:
@@ -167,17 +168,36 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
 
         op = _cached_operator(('simpson_r', float(kmin), float(kmax), int(nk), rr.tobytes(), device.index), build)
         return op(pk_rows(k))
-    raise NotImplementedError('integrate_sigma_r2 method {} is not available on the GPU path (use "fftlog" or "simpson")'.format(method))
+    if method == 'leggauss':   # "not accurate" in the reference's own words (interpolator.py:274-280); nk = 100 nodes by default
+        nl = nk_leggauss
+        limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
+        x, wx = np.polynomial.legendre.leggauss(nl)
+        logk = (limits[1] - limits[0]) / 2. * (1. + x) + limits[0]
+        k = np.exp(logk)
+        w = (limits[1] - limits[0]) / 2. * wx
+        op = _cached_operator(('leggauss_r', float(kmin), float(kmax), int(nl), rr.tobytes(), device.index),
+                              lambda: LinearOperator.dense(1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * w)[None, :], device=device))
+        return op(pk_rows(k))
+    raise NotImplementedError('integrate_sigma_r2 method {} is not available on the GPU path (use "fftlog", "simpson" or "leggauss")'.format(method))
 
 
 def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, device=None):
     r""":math:`\sigma_d^2 = \frac{1}{6\pi^2}\int dk\,P(k)` (reference interpolator.py:123-197, default 'simpson'); device tensor (...,)."""
     device = dv.resolve_device(device)
+    limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
+    if method == 'leggauss':   # interpolator.py:183-189
+        nl = 100 if nk is None else nk
+        x, wx = np.polynomial.legendre.leggauss(nl)
+        logk = (limits[1] - limits[0]) / 2. * (1. + x) + limits[0]
+        k = np.exp(logk)
+        w = (limits[1] - limits[0]) / 2. * wx
+        op = _cached_operator(('leggauss_d', float(kmin), float(kmax), int(nl), device.index),
+                              lambda: LinearOperator.dense((1. / (6. * np.pi**2) * k * w)[None, :], device=device))
+        return op(pk_rows(k))[..., 0]
     if method != 'simpson':
-        raise NotImplementedError('integrate_sigma_d2 method {} is not available on the GPU path (use "simpson")'.format(method))
+        raise NotImplementedError('integrate_sigma_d2 method {} is not available on the GPU path (use "simpson" or "leggauss")'.format(method))
     if nk is None:
         nk = 1024
-    limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
     logk = np.linspace(*limits, nk)
     k = np.exp(logk)
     op = _cached_operator(('simpson_d', float(kmin), float(kmax), int(nk), device.index),
@@ -185,13 +205,28 @@ def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, 
     return op(pk_rows(k))[..., 0]
 
 
+def _linear_interp_operator(x, xq, extrap=False):
+    """(nq, n) matrix of piecewise-linear interpolation on the knots ``x`` (scipy interp1d kind='linear', reference jax.py:176-177):
+    linear continuation of the end intervals if ``extrap``, else NaN rows outside [x[0], x[-1]].  Host numpy."""
+    i = np.clip(np.searchsorted(x, xq, side='right') - 1, 0, x.size - 2)
+    t = (xq - x[i]) / (x[i + 1] - x[i])
+    w = np.zeros((xq.size, x.size))
+    rows = np.arange(xq.size)
+    w[rows, i] = 1. - t
+    w[rows, i + 1] = t
+    if not extrap:
+        w[~((xq >= x[0]) & (xq <= x[-1]))] = np.nan
+    return w
+
+
 class Interpolator1D(object):
 
     """1D interpolation along axis 0 of ``fun`` (n, ...) in lin or log10 space; natural cubic spline (reference jax.py:135-209)."""
 
     def __init__(self, x, fun, k=3, interp_x='lin', interp_fun='lin', extrap=False, assume_sorted=False, device=None):
-        if int(k) != 3:
-            raise NotImplementedError('only cubic (k=3) interpolation is implemented on the GPU path')
+        if int(k) not in (1, 3):
+            raise NotImplementedError('only linear (k=1) and cubic (k=3) interpolation are implemented on the GPU path')
+        self.k = int(k)
         self.device = dv.resolve_device(device, fun)
         self.interp_x, self.interp_fun, self.extrap = str(interp_x), str(interp_fun), bool(extrap)
         x = _host(x).ravel()
@@ -221,8 +256,14 @@ class Interpolator1D(object):
             return _finish(dv.torch().empty((0, self._rows.shape[0]), dtype=dv.torch().float64, device=self.device), dtype, like_torch, shape)
         with np.errstate(all='ignore'):
             xq = np.log10(xh) if self.interp_x == 'log' else xh
-        op = _cached_operator(('i1d', self._x.tobytes(), xq.tobytes(), int(dx), self.extrap, self.device.index),
-                              lambda: LinearOperator.spline(self._x, xq, bc='natural', nu=dx, extrapolate=self.extrap, device=self.device))
+        if self.k == 1:
+            if dx:
+                raise TypeError('derivatives are available for cubic interpolation only')
+            op = _cached_operator(('i1d-lin', self._x.tobytes(), xq.tobytes(), self.extrap, self.device.index),
+                                  lambda: LinearOperator.dense(_linear_interp_operator(self._x, xq, self.extrap), device=self.device))
+        else:
+            op = _cached_operator(('i1d', self._x.tobytes(), xq.tobytes(), int(dx), self.extrap, self.device.index),
+                                  lambda: LinearOperator.spline(self._x, xq, bc='natural', nu=dx, extrapolate=self.extrap, device=self.device))
         out = op(self._rows)   # (ncol, nq); NaN outside [xmin, xmax] unless extrap
         if bool(self._nan_rows.any()):
             out = dv.torch().where(self._nan_rows[:, None], dv.torch().full_like(out, float('nan')), out)

@@ -69,6 +69,14 @@ def sigma_r2(r, pk, kmin=1e-7, kmax=1e2, method='fftlog', nk=1024):
         p = pk(k).reshape(k.shape + (-1,))
         y = kernel_tophat2(k[:, None] * rr)[:, :, None] * (k[:, None]**3 * p)[:, None, :]   # :244
         tmp = simpson(y, logk)
+    elif method == 'leggauss':                                                      # :274-280 ("not accurate")
+        limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
+        x, wx = np.polynomial.legendre.leggauss(100 if nk == 1024 else nk)
+        logk = (limits[1] - limits[0]) / 2. * (1. + x) + limits[0]
+        k = np.exp(logk)
+        p = pk(k).reshape(k.shape + (-1,))
+        y = kernel_tophat2(k[:, None] * rr)[:, :, None] * (k[:, None]**3 * p)[:, None, :]
+        tmp = np.sum(y * ((limits[1] - limits[0]) / 2. * wx)[:, None, None], axis=0)
     else:
         raise ValueError(method)
     return (1. / (2. * np.pi**2) * tmp).reshape(rshape + pshape)                    # :290-291

@@ -150,3 +150,29 @@ def test_distance_to_redshift(cp):
     with pytest.raises(ValueError):
         d2z(ba.comoving_radial_distance(np.array([zmax * 1.5])))
     assert np.isnan(d2z(ba.comoving_radial_distance(np.array([zmax * 1.5])), bounds_error=False)).all()
+
+
+def test_leggauss_and_hierarchy(cp):
+    """integrate_sigma_*(method='leggauss') (reference interpolator.py:183-189, 274-280) against the oracle; neutrino_hierarchy splitting
+    (reference cosmology.py:1030-1106): the three masses add up to the sum and obey the squared-mass differences."""
+    from oracle import sigma as osg
+    from test_oracle_power_sigma import eh_default_callable
+    i1 = cp.Cosmology(engine='eisenstein_hu').get_fourier().pk_interpolator().to_1d(z=0.)
+    r = np.array([2., 8., 30.])
+    np.testing.assert_allclose(i1.sigma_r(r, method='leggauss'), np.sqrt(osg.sigma_r2(r, eh_default_callable(0.), method='leggauss')), rtol=1e-10)
+    assert abs(i1.sigma_r(8., method='leggauss') / i1.sigma_r(8.) - 1.) < 5e-2          # "not accurate", but the same integral
+    assert abs(i1.sigma_d(method='leggauss') / i1.sigma_d() - 1.) < 5e-2
+    with pytest.raises(NotImplementedError):
+        i1.sigma_r(8., method='quad')
+    for hierarchy, d31 in [('normal', 2.525e-3), ('inverted', -2.512e-3 + 7.39e-5)]:
+        m = cp.Cosmology(m_ncdm=0.12, neutrino_hierarchy=hierarchy)['m_ncdm']
+        assert len(m) == 3 and abs(sum(m) - 0.12) < 1e-14
+        ref = {'normal': [0.030108750535617665, 0.031311928379070764, 0.05857932108531181],
+               'inverted': [0.05180653277664962, 0.05251492014978287, 0.015678547073567483]}[hierarchy]     # the reference, run in this container
+        np.testing.assert_allclose(m, ref, rtol=1e-14)
+        assert abs(m[1]**2 - m[0]**2 - 7.39e-5) < 1e-12 and abs(m[2]**2 - m[0]**2 - d31) < 1e-12
+    assert cp.Cosmology(m_ncdm=0.12, neutrino_hierarchy='degenerate')['m_ncdm'] == [0.04] * 3
+    with pytest.raises(cp.CosmologyInputError):
+        cp.Cosmology(m_ncdm=0.01, neutrino_hierarchy='normal')
+    with pytest.raises(cp.CosmologyInputError):
+        cp.Cosmology(m_ncdm=[0.06, 0.06], neutrino_hierarchy='normal')

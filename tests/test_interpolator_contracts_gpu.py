@@ -97,3 +97,24 @@ def test_extrapolation_and_nan():
     bad[10] *= -1
     assert np.isnan(PowerSpectrumInterpolator1D(k, bad)(k)).all()
     assert np.isnan(PowerSpectrumInterpolator2D(k, z, bad[:, None] * (1 + z))(k, z)).all()
+
+
+def test_linear_order():
+    """k = 1 (reference jax.py:176-177: scipy interp1d 'linear'): values, NaN outside, linear extrapolation, columns, log axes."""
+    import cosmoprimo_amd.interpolator as it
+    from scipy.interpolate import interp1d
+    rng = np.random.default_rng(3)
+    x = np.sort(rng.uniform(0.1, 10., 40))
+    fun = rng.uniform(1., 2., (40, 3))
+    xq = np.concatenate([[0.05, 20.], rng.uniform(0.1, 10., 30), x[[0, -1, 7]]])
+    for extrap in (False, True):
+        ref = interp1d(x, fun, kind='linear', axis=0, bounds_error=False, fill_value='extrapolate' if extrap else np.nan, assume_sorted=True)(xq)
+        got = it.Interpolator1D(x, fun, k=1, extrap=extrap)(xq)
+        np.testing.assert_allclose(got, ref, rtol=1e-13, equal_nan=True)
+    xin = np.clip(xq[2:], x[0], x[-1])
+    ref = 10**interp1d(np.log10(x), np.log10(fun[:, 0]), kind='linear')(np.log10(xin))
+    np.testing.assert_allclose(it.Interpolator1D(x, fun[:, 0], k=1, interp_x='log', interp_fun='log')(xin), ref, rtol=1e-12)
+    pk = it.PowerSpectrumInterpolator1D(x, fun[:, 0], interp_order_k=1)
+    assert np.isfinite(pk(np.array([1e-6, 1., 50.]))).all()
+    with pytest.raises(NotImplementedError):
+        it.Interpolator1D(x, fun, k=2)

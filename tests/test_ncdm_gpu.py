@@ -83,4 +83,4 @@ def test_ncdm_tables_and_batch(cp, golden):
     b0 = cp.Cosmology(engine='eisenstein_hu').get_background()
     assert b0.rho_ncdm(z).shape == (0, z.size) and (b0.rho_ncdm_tot(z) == 0.).all() and b0.N_ncdm == 0
     with pytest.raises(NotImplementedError):
-        cp.Cosmology(m_ncdm=0.06, neutrino_hierarchy='normal')
+        cp.Cosmology(Omega_ncdm=0.001)
