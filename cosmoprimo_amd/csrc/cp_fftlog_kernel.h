@@ -130,18 +130,6 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
     typename F::State st;  // tables loaded one phase ahead + prefetched rows (cp_fftlog_body.h)
     long long p = blockIdx.x;
     if (p >= npairs) return;
-#if defined(CP_EXP_PRIO)
-    // experiment: break the lockstep of the two co-resident workgroups of a CU with a static wave priority
-    if (CP_EXP_PRIO == 1 && blockIdx.x >= gridDim.x / 2) __builtin_amdgcn_s_setprio(2);
-    if (CP_EXP_PRIO == 2 && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(2);
-    if (CP_EXP_PRIO == 3 && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_setprio(2);
-    if (CP_EXP_PRIO == 4 && blockIdx.x >= gridDim.x / 2) {
-        for (int i = 0; i < 60; ++i) __builtin_amdgcn_s_sleep(127);  // ~60 x 127 x 64 clk ~ 0.2 ms... start stagger
-    }
-    if (CP_EXP_PRIO == 5 && blockIdx.x >= gridDim.x / 2) {
-        for (int i = 0; i < 1; ++i) __builtin_amdgcn_s_sleep(100);  // ~6400 clk ~ 3 us start stagger
-    }
-#endif
     PairWalk walk = pair_walk_begin(A, p, gridDim.x);
     PairRows cur = walk.cur;
     {

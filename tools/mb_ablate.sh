@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build and run the ablation variants of tools/fftlog_microbench.hip (on the GPU box): bash tools/run_microbench.sh "0 1 2 4 ..."
+# Build and run the ablation variants of tools/fftlog_microbench.hip (on the GPU box): bash tools/mb_ablate.sh "0 1 2 4 ..."
 masks=${1:-"0 1 2 4 8 16 32 24 28 31 63"}
 mkdir -p /tmp/mb
 for m in $masks; do

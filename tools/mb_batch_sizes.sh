@@ -1,4 +1,5 @@
 #!/bin/bash
+# batch-size sweep of the flagship kernel (launch overhead / tail effects) and the no-HBM ablation at two sizes
 mkdir -p /tmp/mb
 build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 "$@" tools/fftlog_microbench.hip 2>/dev/null || echo "build failed $*"; }
 build -o /tmp/mb/p0 &
