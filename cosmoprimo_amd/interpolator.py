@@ -624,12 +624,40 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             return self._eval_device(kh, zh, grid=True, ignore_growth=ignore_growth).transpose(-1, -2).contiguous()
         return rows
 
+    def _separable(self):
+        """P(k, z) = P(k) x growth_factor_sq(z) exactly: interpolators built from (callable or one tabulated column) + growth factor."""
+        if self.growth_factor_sq is None:
+            return False
+        return self.is_from_callable or self._pk.shape[1] == 1
+
+    def _sigma2_separable(self, integrate, zh):
+        """sigma^2(..., z) = growth_factor_sq(z) x sigma^2 of the z-independent spectrum: the k integral is linear in P, so ONE transform
+        per cosmology replaces one per (cosmology, z) -- same numbers as the reference's per-z integrals to rounding.  Returns
+        (batch..., nz, n) like the per-z path."""
+        torch = dv.torch()
+        z0 = np.array([self.z[0]])                                 # any redshift inside the table: the growth factor is left out
+
+        def rows(kh):
+            return self._eval_device(kh, z0, grid=True, ignore_growth=True).transpose(-1, -2).contiguous()      # (batch..., 1, nk)
+
+        base = integrate(rows)                                     # (batch..., 1, n)
+        growth = dv.to_device(self.growth_factor_sq(zh), self.device)          # (batch..., nz)
+        out = base * growth[..., :, None]
+        if self.is_from_callable:                                  # NaN outside the redshift range (tabulated single columns ignore z)
+            _, mask_z = _mask_bounds([z0, zh], [(self.zmin, self.zmax)] * 2)
+            out = torch.where(torch.as_tensor(mask_z, device=self.device)[:, None], out, torch.full_like(out, float('nan')))
+        return out
+
     def sigma_dz(self, z, **kwargs):
         r""":math:`\sigma_d(z) = \sqrt{\frac{1}{6\pi^2}\int dk P(k, z)}` (reference interpolator.py:819-844); shape (batch...) + z.shape."""
         like_torch = dv.is_torch(z)
         dtype = dv.float_dtype(z)
         zh = _host(z)
-        out = integrate_sigma_d2(self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+        if self._separable():
+            out = self._sigma2_separable(lambda rows: integrate_sigma_d2(rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
+                                                                         **kwargs)[..., None], zh.ravel())[..., 0]**0.5
+        else:
+            out = integrate_sigma_d2(self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
         return _finish(out, dtype, like_torch, tuple(out.shape[:-1]) + zh.shape)
 
     def sigma_rz(self, r, z, **kwargs):
@@ -640,7 +668,11 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         like_torch = dv.is_torch(r) or dv.is_torch(z)
         dtype = dv.float_dtype(r, z)
         rh, zh = _host(r), _host(z)
-        out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+        if self._separable():
+            out = self._sigma2_separable(lambda rows: integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
+                                                                         **kwargs), zh.ravel())**0.5
+        else:
+            out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
         out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
         return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
 
