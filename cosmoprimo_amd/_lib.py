@@ -86,7 +86,7 @@ EH_SCALARS = ('rs_drag', 'z_drag', 'z_eq', 'k_eq', 'r_drag', 'r_eq', 'k_silk', '
 BG_KINDS = {'comoving_radial_distance': 0, 'comoving_transverse_distance': 1, 'angular_diameter_distance': 2, 'luminosity_distance': 3,
             'efunc': 4, 'hubble_function': 5, 'growth_cpt': 6, 'growth_rate': 7, 'rho_crit': 8, 'Omega_m': 9, 'Omega_de': 10,
             'rho_g': 11, 'rho_b': 12, 'rho_ur': 13, 'rho_cdm': 14, 'rho_k': 15, 'rho_Lambda': 16, 'rho_fld': 17, 'rho_de': 18, 'rho_tot': 19,
-            'rho_m': 20, 'rho_r': 21, 'T_cmb': 22, 'time': 23, 'age': 24, 'rho_ncdm': 25, 'p_ncdm': 26}
+            'rho_m': 20, 'rho_r': 21, 'T_cmb': 22, 'time': 23, 'age': 24, 'rho_ncdm': 25, 'p_ncdm': 26, 'rs': 27, 'rs_cosmomc': 28}
 BG_AS_FRACTION = 32
 for _name in ('g', 'b', 'ur', 'cdm', 'k', 'Lambda', 'fld', 'r', 'ncdm'):     # Omega_x(z) = rho_x(z) / rho_crit(z)
     BG_KINDS['Omega_' + _name] = BG_KINDS['rho_' + _name] | BG_AS_FRACTION

@@ -243,6 +243,17 @@ class BaseCosmoParams(object):
             return self.get('Omega_de') if self._has_fld else 0.
         if name == 'K':
             return - 100.**2 / (c / 1e3)**2 * params['Omega_k']
+        if name == 'theta_cosmomc':   # sound horizon over angular distance at last scattering, CosmoMC approximation (cosmology.py:202-228, 404-408)
+            ba = self.get_background()
+            omega_b, omega_m = self.get('omega_b'), self.get('omega_m')
+            zstar = 1048 * (1 + 0.00124 * omega_b**(-0.738)) * (1 + (0.0783 * omega_b**(-0.238) / (1 + 39.5 * omega_b**0.763))
+                                                               * omega_m**(0.560 / (1 + 21.1 * omega_b**1.81)))
+            rs = ba._eval_per_cosmology('rs_cosmomc', zstar)
+            if bool((rs != rs).any()):
+                raise CosmologyComputationError('precision not achieved in the sound horizon integral')
+            return rs * _host(ba.h) / ba._eval_per_cosmology('comoving_transverse_distance', zstar)
+        if name == 'theta_MC_100':
+            return self.get('theta_cosmomc') * 100.
         if name == 'N_eff':   # cosmology.py:402-403
             return sum(t**4 * (4. / 11.)**(-4. / 3.) for t in params['T_ncdm_over_cmb']) + params['N_ur']
         if has_default:
@@ -502,6 +513,22 @@ class BaseBackground(BaseSection):
     def Omega_de(self, z):
         """Density parameter of dark energy at z (cosmology.py:1850)."""
         return self._eval('Omega_de', z)
+
+    def rs(self, z):
+        """Comoving sound horizon at z, in Mpc/h (cosmology.py:1914-1933): the reference's fixed-depth Romberg rule (15 refinements) of
+        c_s dtau/da from a = 1e-8, one wave per sample.  Like the reference it fails (CosmologyComputationError) where that rule misses
+        its 1e-7 tolerance, e.g. at z = 0."""
+        out = self._eval('rs', z)
+        if bool((out != out).any()):
+            raise CosmologyComputationError('precision not achieved in the sound horizon integral')
+        return out
+
+    def _eval_per_cosmology(self, kind, z):
+        """``kind`` at one redshift per cosmology (z: float, or (B,) for a batch)."""
+        if self._engine.batch_size is None:
+            return self._eval(kind, z)
+        zt = dv.to_device(z, self.device).reshape(-1, 1)
+        return bgmod.distance(kind, zt, self._bg, device=self.device, ncdm=self._ncdm, per_cosmology_z=True)[:, 0].cpu().numpy()
 
     def rho_tot(self, z):
         """Comoving total density (matter + radiation + dark energy), in 1e10 Msun/h / (Mpc/h)^3 (cosmology.py:1731-1736)."""

@@ -269,6 +269,58 @@ TablesN<NK>* device_tables(int device) {
     return cache[device];
 }
 
+// ---- sound horizon: the reference's fixed-depth Romberg rule (jax.py:519-660, divmax = 15: 2^15 + 1 integrand evaluations) ----
+// One wave per (cosmology, z) sample: the lanes stride the new ordinates of every refinement level, a butterfly reduction adds them.
+__global__ __launch_bounds__(64) void rs_kernel(const Args A) {
+    __shared__ double ncdm_knots[CP_NCDM_NKNOTS];
+    if (A.nsp)
+        for (int i = threadIdx.x; i < CP_NCDM_NKNOTS; i += blockDim.x) ncdm_knots[i] = A.ncdm_knots[i];
+    __syncthreads();
+    const long long i = blockIdx.x;
+    const long long ic = i / A.nz, iz = i - ic * A.nz;
+    const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m, A.ncdm_tab, ncdm_knots, A.nsp);
+    const double z = A.z[A.z_shared ? iz : i];
+    const bool cosmomc = A.kind == CP_BG_RS_COSMOMC;
+    const double omega_b = c.Omega_b * (c.h * c.h);
+    auto f = [&](double a) {  // dsoundda (cosmology.py:1920-1927) / dsoundda_approx (:215-222)
+        const double dtauda = 1. / (a * a * (efunc(c, 1 / a - 1.) * (c.h * 100.)) / kCkms);
+        const double R = cosmomc ? 3e4 * a * omega_b : 3 / 4. * a * c.Omega_b / c.Omega_g;
+        return dtauda * pow(3 * (1 + R), -0.5);
+    };
+    const double lo = 1e-8, hi = 1. / (1 + z);
+    const double intrange = hi - lo;
+    double ordsum = 0.5 * (f(lo) + f(hi));
+    constexpr int DIVMAX = 15;
+    double row[DIVMAX + 1];
+    row[0] = intrange * ordsum;
+    double err = 0.;
+    int n = 1;
+    for (int lev = 1; lev <= DIVMAX; ++lev) {
+        n *= 2;
+        const int numtosum = n / 2;
+        const double h = (hi - lo) * 1. / numtosum;
+        const double lox = lo + 0.5 * h;
+        double s = 0.;
+        for (int j = threadIdx.x; j < numtosum; j += 64) s += f(lox + h * j);
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        ordsum += s;
+        double x = intrange * ordsum / n;
+        double prev = row[0];  // the new row, left to right: x_{k+1} = (4^(k+1) x_k - y_k) / (4^(k+1) - 1)
+        row[0] = x;
+        double p4 = 1.;
+        for (int k = 0; k < lev; ++k) {
+            p4 *= 4.;
+            x = (p4 * x - prev) / (p4 - 1.0);
+            if (k == lev - 1) err = fabs(prev - x);  // |last_row[lev - 1] - row[lev]| (jax.py:648)
+            prev = row[k + 1];
+            row[k + 1] = x;
+        }
+    }
+    // precision not achieved (epsabs = epsrel = 1e-7): the reference raises; NaN here, turned into the exception by the caller
+    const double res = (err < 1e-7 && err < fabs(row[DIVMAX]) * 1e-7) ? row[DIVMAX] : __builtin_nan("");
+    if (threadIdx.x == 0) A.out[i] = cosmomc ? res : res * c.h;
+}
+
 // ---- massive neutrinos --------------------------------------------------------------------------------------------------------
 // knots: concatenate(linspace(0, 1, 20)[:-1], 1 / geomspace(1e-8, 1/2, 100)[::-1] - 1), cosmology.py:1941-1943
 void build_ncdm_knots(double* zc) {
@@ -455,7 +507,7 @@ extern "C" int cp_background_eval(long long ncosmo, long long nz, const cp_param
     if (!params || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_background_distance: null pointer");
     {
         const int base = kind & ~CP_BG_AS_FRACTION;
-        if (kind < 0 || base > CP_BG_KIND_LAST || ((kind & CP_BG_AS_FRACTION) && (base < CP_BG_RHO_G || (base >= CP_BG_T_CMB_Z && base <= CP_BG_AGE))))
+        if (kind < 0 || base > CP_BG_KIND_LAST || ((kind & CP_BG_AS_FRACTION) && (base < CP_BG_RHO_G || (base >= CP_BG_T_CMB_Z && base <= CP_BG_AGE) || base >= CP_BG_RS)))
             return cp::fail(CP_EINVAL, "cp_background_distance: unknown kind %d", kind);
     }
     int prev = -1;
@@ -491,7 +543,8 @@ extern "C" int cp_background_eval(long long ncosmo, long long nz, const cp_param
     const long long nsamp = ncosmo * nz;
     const int block = 256;
     const long long grid = (nsamp + block - 1) / block;
-    if (is_time) hipLaunchKernelGGL((bg_kernel<NK_TIME, true>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    if (kind == CP_BG_RS || kind == CP_BG_RS_COSMOMC) hipLaunchKernelGGL(rs_kernel, dim3((unsigned)nsamp), dim3(64), 0, static_cast<hipStream_t>(stream), A);
+    else if (is_time) hipLaunchKernelGGL((bg_kernel<NK_TIME, true>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
     else hipLaunchKernelGGL((bg_kernel<NK_DIST, false>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
     hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);

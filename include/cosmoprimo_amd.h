@@ -108,7 +108,9 @@ enum cp_bg_kind {
     CP_BG_AGE = 24,                /* age today, Gyr (z ignored)                     DefaultBackground.age,  cosmology.py:2014-2025 */
     CP_BG_RHO_NCDM = 25,           /* massive neutrinos: comoving density of species cp_ncdm.species (-1: all)  DefaultBackground.rho_ncdm, cosmology.py:1961-1978 */
     CP_BG_P_NCDM = 26,             /* ... and pressure                                                          DefaultBackground.p_ncdm,   cosmology.py:1980-1998 */
-    CP_BG_KIND_LAST = 26,
+    CP_BG_RS = 27,                 /* comoving sound horizon at z, Mpc/h: Romberg (15 levels) of c_s dtau/da from a = 1e-8   BaseBackground.rs, cosmology.py:1914-1933 */
+    CP_BG_RS_COSMOMC = 28,         /* the same with CosmoMC's R = 3e4 a omega_b, proper Mpc                       _compute_rs_cosmomc, cosmology.py:202-228 */
+    CP_BG_KIND_LAST = 28,
     CP_BG_AS_FRACTION = 32
 };
 /* a per-cosmology parameter: device array of ncosmo doubles, or (ptr == NULL) one value for all cosmologies */

@@ -269,3 +269,42 @@ def comoving_radial_distance_ncdm(z, p):
     z = np.asarray(z, dtype='f8')
     out = CubicSpline(zc, tab, bc_type='natural', extrapolate=False)(z)
     return np.where((z >= zc[0]) & (z <= zc[-1]), out, np.nan)
+
+
+def romberg(f, a, b, divmax=15):
+    """The reference's fixed-depth Romberg rule (jax.py:519-660): all ``divmax`` refinements, last entry of the last row."""
+    n, intrange = 1, b - a
+    ordsum = 0.5 * (f(a) + f(b))
+    last_row = np.array([intrange * ordsum])
+    for i in range(1, divmax + 1):
+        n *= 2
+        numtosum = n // 2
+        h = (b - a) * 1. / numtosum
+        ordsum = ordsum + np.sum(f(a + 0.5 * h + h * np.arange(numtosum)), axis=0)
+        x = intrange * ordsum / n
+        row = [x]
+        for k, y in enumerate(last_row[:i]):
+            x = (4.0**(k + 1) * x - y) / (4.0**(k + 1) - 1.0)
+            row.append(x)
+        last_row = np.array(row)
+    return last_row[divmax]
+
+
+def rs(z, p, efunc_fn=None, cosmomc=False):
+    """BaseBackground.rs (cosmology.py:1914-1933), Mpc/h, or with ``cosmomc`` the sound horizon of _compute_rs_cosmomc (:202-228), proper Mpc;
+    scalar z, one cosmology.  ``efunc_fn``: E(z) callable (default: no massive neutrinos)."""
+    efunc_fn = efunc_fn or (lambda zz: efunc(zz, p))
+    omega_b = p['Omega_b'] * p['h']**2
+
+    def f(a):
+        dtauda = 1. / (a**2 * (efunc_fn(1 / a - 1.) * (p['h'] * 100.)) / C_KMS)
+        R = 3e4 * a * omega_b if cosmomc else 3 / 4. * a * p['Omega_b'] / p['Omega_g']
+        return dtauda * (3 * (1 + R))**(-0.5)
+
+    out = romberg(f, 1e-8, 1. / (1 + z))
+    return out if cosmomc else out * p['h']
+
+
+def zstar_cosmomc(omega_b, omega_m):
+    """Hu & Sugiyama fit of the redshift of last scattering as used by CosmoMC (cosmology.py:208-210)."""
+    return 1048 * (1 + 0.00124 * omega_b**(-0.738)) * (1 + (0.0783 * omega_b**(-0.238) / (1 + 39.5 * omega_b**0.763)) * omega_m**(0.560 / (1 + 21.1 * omega_b**1.81)))

@@ -428,6 +428,7 @@ def gen_bao2(cp):
 DENSITY_NAMES = ['rho_g', 'rho_b', 'rho_ur', 'rho_cdm', 'rho_k', 'rho_de', 'rho_Lambda', 'rho_fld', 'rho_r', 'rho_m', 'rho_tot', 'rho_crit',
                  'Omega_g', 'Omega_b', 'Omega_ur', 'Omega_cdm', 'Omega_k', 'Omega_de', 'Omega_Lambda', 'Omega_fld', 'Omega_r', 'Omega_m', 'T_cmb',
                  'rho_ncdm_tot', 'p_ncdm_tot']
+RS_Z = [10., 1059.94, 1089.8]      # ba.rs(0.) raises in the reference (the fixed-depth Romberg rule misses its 1e-7 tolerance)
 DENSITY_PARAMS = [dict(), dict(Omega_m=0.27, Omega_b=0.045, h=0.72, Omega_k=0.05), dict(Omega_m=0.36, h=0.64, w0_fld=-0.9, wa_fld=0.2, T_cmb=2.6),
                   dict(Omega_m=0.31, Omega_k=-0.03, w0_fld=-1.2, wa_fld=-0.4, N_ur=2.0328), dict(h=0.6766, w0_fld=-1., wa_fld=0., cs2_fld=0.9)]
 
@@ -444,6 +445,9 @@ def gen_densities(cp):
             for name in DENSITY_NAMES:
                 out['c%d_%s' % (i, name)] = np.asarray(getattr(ba, name)(z), dtype='f8') + 0. * z
             out['c%d_has_fld' % i] = float(ba.Omega0_fld != 0.)
+            out['c%d_rs' % i] = np.array([float(ba.rs(zz)) for zz in RS_Z])
+            cosmo_i = cp.Cosmology(engine='eisenstein_hu', **par)
+            out['c%d_theta_cosmomc' % i] = float(cosmo_i['theta_cosmomc'])
             out['c%d_time' % i] = np.asarray(ba.time(z), dtype='f8')
             out['c%d_age' % i] = float(ba.age)
         out['time_knots'] = np.asarray(ba._cache['time']._x)

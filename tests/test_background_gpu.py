@@ -106,6 +106,14 @@ def test_densities(golden):
         np.testing.assert_allclose(ba.time(z[:8]), g['c%d_time' % i][:8], rtol=1e-12)
         np.testing.assert_allclose(ba.age, g['c%d_age' % i], rtol=1e-13)
         assert np.ndim(ba.age) == 0 and np.isnan(ba.time(np.array([-0.1, 1e8]))).all()
+        # sound horizon: fixed-depth Romberg, one wave per sample (cosmology.py:1914-1933); theta_cosmomc (:202-228, 404-408)
+        from oracle.gen_golden import RS_Z
+        np.testing.assert_allclose(ba.rs(np.array(RS_Z)), g['c%d_rs' % i], rtol=1e-10)
+        cosmo_i = cp.Cosmology(engine='eisenstein_hu', **par)
+        np.testing.assert_allclose(cosmo_i['theta_cosmomc'], g['c%d_theta_cosmomc' % i], rtol=1e-10)
+        np.testing.assert_allclose(cosmo_i['theta_MC_100'], 100. * g['c%d_theta_cosmomc' % i], rtol=1e-10)
+        with pytest.raises(cp.CosmologyComputationError):
+            ba.rs(0.)        # the reference fails there as well: its rule misses the 1e-7 tolerance
     # a batch of cosmologies: leading axis
     ba = cp.Cosmology(engine='eisenstein_hu', Omega_m=np.array([0.3, 0.36]), h=np.array([0.7, 0.64])).get_background()
     out = ba.Omega_cdm(z)
@@ -117,3 +125,6 @@ def test_densities(golden):
     from cosmoprimo_amd import _lib
     _lib.check(_lib.load().cp_background_knots(_lib.as_double_p(kn), 400))
     np.testing.assert_allclose(kn, g['time_knots'], rtol=1e-15)
+    both = cp.Cosmology(engine='eisenstein_hu', Omega_m=np.array([0.3, 0.36]), h=np.array([0.7, 0.64]))
+    np.testing.assert_allclose(both['theta_cosmomc'], [cp.Cosmology(engine='eisenstein_hu', Omega_m=om, h=h)['theta_cosmomc'] for om, h in [(0.3, 0.7), (0.36, 0.64)]],
+                               rtol=1e-13)

@@ -58,5 +58,12 @@ def test_densities(golden):
         # time / age: DefaultBackground.time, .age (cosmology.py:2000-2025)
         np.testing.assert_allclose(ob.time(z, p), g['c%d_time' % i], rtol=1e-11)
         np.testing.assert_allclose(ob.age(p), g['c%d_age' % i], rtol=1e-13)
+        # sound horizon (fixed-depth Romberg): rs(z) and theta_cosmomc (cosmology.py:202-228, 404-408, 1914-1933)
+        from oracle.gen_golden import RS_Z
+        np.testing.assert_allclose([ob.rs(zz, p) for zz in RS_Z], g['c%d_rs' % i], rtol=1e-11)
+        h2 = p['h']**2
+        zstar = ob.zstar_cosmomc(p['Omega_b'] * h2, (p['Omega_cdm'] + p['Omega_b']) * h2)
+        theta = ob.rs(zstar, p, cosmomc=True) * p['h'] / ob.distances(np.array([zstar]), p)['comoving_transverse_distance'][0]
+        np.testing.assert_allclose(theta, g['c%d_theta_cosmomc' % i], rtol=1e-10)
     np.testing.assert_allclose(ob.time_knots(), g['time_knots'], rtol=1e-15)
     assert np.isnan(g['time_nan_outside']).all()
