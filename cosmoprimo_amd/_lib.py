@@ -37,6 +37,9 @@ SIGNATURES = {
                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_background_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
     'cp_ncdm_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
+    'cp_growth_ode_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
+    'cp_growth_ode_tables': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_void_p]),
     'cp_ncdm_tables': None,        # filled below (takes cp_param by value)
     'cp_background_eval': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -75,6 +78,7 @@ class cp_ncdm(ctypes.Structure):
 SIGNATURES['cp_ncdm_tables'] = (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, cp_param, cp_param, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                _c_double_p, _c_double_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p])
 NCDM_NKNOTS = 119
+GROWTH_NKNOTS = 201
 
 BG_PARAMS = ('h', 'Omega_cdm', 'Omega_b', 'Omega_k', 'T_cmb', 'N_ur', 'w0_fld', 'wa_fld')
 SPLINE_BC = {'natural': 0, 'clamped': 1, 'not-a-knot': 2}

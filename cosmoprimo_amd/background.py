@@ -66,6 +66,29 @@ class NcdmTables(object):
         return _lib.cp_ncdm(self.nspecies, -1 if species is None else int(species), self.tab.data_ptr())
 
 
+def growth_ode_tables(params=None, mass='m', ncdm=None, ncosmo=1, device=None):
+    """Linear growth D and D'/D on the 201 knots of the reference's ODE solution (``cp_growth_ode_tables``; DefaultBackground.growth_factor,
+    cosmology.py:2044-2093): returns (knots (201,) numpy, ascending z; device tensor (ncosmo, 2, 201))."""
+    import torch
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    device = torch.device(device)
+    params = dict(params or {})
+    keep = []
+    cparams = (_lib.cp_param * len(_lib.BG_PARAMS))()
+    for i, name in enumerate(_lib.BG_PARAMS):
+        cparams[i], n = _cparam(params.get(name, DEFAULTS[name]), device, keep)
+        if n is not None and n != ncosmo:
+            raise ValueError('per-cosmology arrays must have length ncosmo = {:d}, got {:d}'.format(ncosmo, n))
+    tab = torch.empty((ncosmo, 2, _lib.GROWTH_NKNOTS), dtype=torch.float64, device=device)
+    cn = ncdm.struct() if ncdm is not None and ncdm.nspecies else None
+    _lib.check(_lib.load().cp_growth_ode_tables(ncosmo, ctypes.cast(cparams, ctypes.c_void_p), 0, ctypes.byref(cn) if cn is not None else None,
+                                                {'m': 0, 'cb': 1}[mass], tab.data_ptr(), device.index, torch.cuda.current_stream(device).cuda_stream))
+    knots = np.empty(_lib.GROWTH_NKNOTS)
+    _lib.check(_lib.load().cp_growth_ode_knots(_lib.as_double_p(knots), knots.size))
+    return knots, tab
+
+
 def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=None, ncdm=None, species=None):
     """
     Evaluate ``kind`` (one of :data:`KINDS`: 'comoving_radial_distance', 'comoving_transverse_distance',

@@ -676,7 +676,9 @@ _add_density_methods()
 
 class DefaultBackground(BaseBackground):
 
-    """Background of the analytic engines (reference DefaultBackground + eisenstein_hu.Background, eisenstein_hu.py:106-152)."""
+    """Background with the quantities that need a quadrature or an ODE (reference DefaultBackground, cosmology.py:1954-2093): interpolated
+    massive neutrinos, time / age, comoving radial distance (in :class:`BaseBackground` here: same kernels) and the linear growth from
+    its ODE.  The analytic engines override the growth with closed forms (``eisenstein_hu.Background``), as in the reference."""
 
     def time(self, z):
         """Proper time (age of the universe at z), in Gyr (reference DefaultBackground.time, cosmology.py:2000-2012): the RK4 scan on the
@@ -688,16 +690,33 @@ class DefaultBackground(BaseBackground):
         """Current age of the universe, in Gyr (cosmology.py:2014-2025); one value per cosmology."""
         return self._eval('age', np.zeros(()))
 
-    def growth_factor(self, z, znorm=None):
-        """CPT92 approximation of the growth factor (eisenstein_hu.py:115-140)."""
-        growthz = self._eval('growth_cpt', z)
-        if znorm is not None:
-            return (1. + znorm) * growthz
-        g0 = self._eval('growth_cpt', np.zeros(()))
-        if np.ndim(g0) and np.ndim(growthz) > np.ndim(g0):
-            g0 = g0.reshape(g0.shape + (1,) * (np.ndim(growthz) - np.ndim(g0)))
-        return growthz / g0
+    def _growth_tables(self, mass):
+        if mass not in ('m', 'cb'):
+            raise ValueError("mass must be one of ['m', 'cb']")
+        cache = self.__dict__.setdefault('_growth_cache', {})
+        if mass not in cache:   # 200 RK4 steps per cosmology on the device (cp_growth_ode_tables), once per section
+            cache[mass] = bgmod.growth_ode_tables(self._bg, mass=mass, ncdm=self._ncdm, ncosmo=self._engine.batch_size or 1, device=self.device)
+        return cache[mass]
 
-    def growth_rate(self, z):
-        """Approximation of the growth rate Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))) (eisenstein_hu.py:143-152)."""
-        return self._eval('growth_rate', z)
+    def _growth_eval(self, which, z, mass):
+        """Natural spline (as Interpolator1D) through row ``which`` (0: D, 1: D'/D) of the ODE tables at z and at 0: device (ncosmo, nq + 1)."""
+        from .spline import LinearOperator
+        knots, tab = self._growth_tables(mass)
+        zq = np.concatenate([_host(z).ravel(), [0.]])
+        return LinearOperator.spline(knots, zq, bc='natural', device=self.device)(tab[:, which].contiguous())
+
+    def growth_factor(self, z, mass='m', znorm=None):
+        """Linear growth factor from its ODE in ln a (reference cosmology.py:2044-2087): normalised to 1 at z = 0, or to (1 + znorm) / (1 + z)
+        deep in matter domination if ``znorm`` is given; ``mass``: 'm' or 'cb'.  NaN outside the solved range z <= e^6 - 1."""
+        out = self._growth_eval(0, z, mass)
+        out = (1. + znorm) * out[:, :-1] if znorm is not None else out[:, :-1] / out[:, -1:]
+        zshape = tuple(np.shape(_host(z)))
+        shape = ((out.shape[0],) if self._engine.batch_size is not None else ()) + zshape
+        return _out(out.reshape(shape), z)
+
+    def growth_rate(self, z, mass='m'):
+        """Linear growth rate d ln D / d ln a from the same ODE (reference cosmology.py:2089-2094)."""
+        out = self._growth_eval(1, z, mass)[:, :-1]
+        zshape = tuple(np.shape(_host(z)))
+        shape = ((out.shape[0],) if self._engine.batch_size is not None else ()) + zshape
+        return _out(out.reshape(shape), z)

@@ -321,6 +321,63 @@ __global__ __launch_bounds__(64) void rs_kernel(const Args A) {
     if (threadIdx.x == 0) A.out[i] = cosmomc ? res : res * c.h;
 }
 
+// ---- linear growth ODE (DefaultBackground.growth_factor / growth_rate, cosmology.py:2044-2093) -------------------------------------------
+struct GrowthArgs {
+    long long ncosmo;
+    Param p[CP_BG_NPARAMS];
+    int second_is_omega_m, mass;
+    const double* ncdm_tab;
+    const double* ncdm_knots;
+    int nsp;
+    double* tab;  // (ncosmo, 2, CP_GROWTH_NKNOTS)
+};
+
+__device__ __forceinline__ void growth_rhs(const Cosmo& c, int mass, double D, double Dp, double eta, double& dD, double& dDp) {
+    const double z = exp(-eta) - 1.;
+    const double zp1 = 1. + z;
+    const double rc = rho_crit(c, zp1);
+    const double Ok = c.Omega_k / zp1 * kRhoCrit / rc;
+    const double Or = (c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit + 3. * ncdm_eval(c, z, 1)) / rc;
+    const double Ode = rho_de(c, zp1) / rc;
+    const double Om = mass == 0 ? rho_m(c, zp1) / rc : c.Omega_cdm * 1. * kRhoCrit / rc + c.Omega_b * 1. * kRhoCrit / rc;
+    const double w_fld = c.w0 + z / (1. + z) * c.wa;
+    const double f1 = -1. - (-1. / 2. * (1. - Ok + Or + 3 * w_fld * Ode));
+    const double f2 = 3. / 2. * Om;
+    dD = Dp;
+    dDp = f2 * D + f1 * Dp;
+}
+
+// one thread per cosmology: 200 RK4 steps (jax.py:700-710), results stored in ascending z
+__global__ __launch_bounds__(64) void growth_ode_kernel(const GrowthArgs A) {
+    __shared__ double ncdm_knots[CP_NCDM_NKNOTS];
+    if (A.nsp)
+        for (int i = threadIdx.x; i < CP_NCDM_NKNOTS; i += blockDim.x) ncdm_knots[i] = A.ncdm_knots[i];
+    __syncthreads();
+    const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ic >= A.ncosmo) return;
+    const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m, A.ncdm_tab, ncdm_knots, A.nsp);
+    constexpr int n = CP_GROWTH_NKNOTS;
+    double* tD = A.tab + ic * 2 * n;
+    double* tF = tD + n;
+    const double eta0 = -6., step = (0. - -6.) / (n - 1);
+    double D = exp(eta0), Dp = D;
+    double t_last = eta0;
+    for (int i = 0; i < n; ++i) {
+        const double t = i == n - 1 ? 0. : eta0 + i * step;  // numpy.linspace
+        const double h = t - t_last;
+        double a1, b1, a2, b2, a3, b3, a4, b4;
+        growth_rhs(c, A.mass, D, Dp, t_last, a1, b1);
+        growth_rhs(c, A.mass, D + h * a1 / 2, Dp + h * b1 / 2, t_last + h / 2, a2, b2);
+        growth_rhs(c, A.mass, D + h * a2 / 2, Dp + h * b2 / 2, t_last + h / 2, a3, b3);
+        growth_rhs(c, A.mass, D + h * a3, Dp + h * b3, t, a4, b4);
+        D = D + h / 6. * (a1 + 2 * a2 + 2 * a3 + a4);
+        Dp = Dp + h / 6. * (b1 + 2 * b2 + 2 * b3 + b4);
+        t_last = t;
+        tD[n - 1 - i] = D;
+        tF[n - 1 - i] = Dp / D;
+    }
+}
+
 // ---- massive neutrinos --------------------------------------------------------------------------------------------------------
 // knots: concatenate(linspace(0, 1, 20)[:-1], 1 / geomspace(1e-8, 1/2, 100)[::-1] - 1), cosmology.py:1941-1943
 void build_ncdm_knots(double* zc) {
@@ -423,6 +480,51 @@ __global__ __launch_bounds__(64) void ncdm_spline_kernel(const NcdmArgs A) {
 }  // namespace
 
 const double* cpcosmo::ncdm_knots_device(int device) { return device_ncdm_knots(device); }
+
+extern "C" int cp_growth_ode_knots(double* zc_out, int n) {
+    if (!zc_out || n != CP_GROWTH_NKNOTS) return cp::fail(CP_EINVAL, "cp_growth_ode_knots: need a buffer of %d doubles", CP_GROWTH_NKNOTS);
+    for (int i = 0; i < n; ++i) {  // z = exp(-eta) - 1, eta = linspace(-6, 0, 201), reversed to ascending z
+        const int j = n - 1 - i;
+        const double eta = j == n - 1 ? 0. : -6. + j * ((0. - -6.) / (n - 1));
+        zc_out[i] = std::exp(-eta) - 1.;
+    }
+    return CP_OK;
+}
+
+extern "C" int cp_growth_ode_tables(long long ncosmo, const cp_param* params, int second_is_omega_m, const cp_ncdm* ncdm, int mass, double* d_tab,
+                                    int device, void* stream) {
+    if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_growth_ode_tables: negative size");
+    if (ncosmo == 0) return CP_OK;
+    if (!params || !d_tab) return cp::fail(CP_EINVAL, "cp_growth_ode_tables: null pointer");
+    if (mass != 0 && mass != 1) return cp::fail(CP_EINVAL, "cp_growth_ode_tables: mass must be 0 ('m') or 1 ('cb')");
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_growth_ode_tables: bad massive-neutrino tables");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_growth_ode_tables: cannot select device %d", device);
+    GrowthArgs A;
+    A.ncosmo = ncosmo;
+    for (int k = 0; k < CP_BG_NPARAMS; ++k) {
+        A.p[k].ptr = params[k].ptr;
+        A.p[k].value = params[k].value;
+    }
+    A.second_is_omega_m = second_is_omega_m;
+    A.mass = mass;
+    A.nsp = nsp;
+    A.ncdm_tab = nsp ? ncdm->tab : nullptr;
+    A.ncdm_knots = nsp ? device_ncdm_knots(device) : nullptr;
+    A.tab = d_tab;
+    int rc = CP_OK;
+    if (nsp && !A.ncdm_knots) {
+        rc = cp::fail(CP_ENOMEM, "cp_growth_ode_tables: cannot allocate the massive-neutrino knots on device %d", device);
+    } else {
+        hipLaunchKernelGGL(growth_ode_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), A);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = cp::fail(CP_EDEVICE, "cp_growth_ode_tables: launch failed: %s", hipGetErrorString(e));
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
+}
 
 extern "C" int cp_ncdm_knots(double* zc_out, int n) {
     if (!zc_out || n != CP_NCDM_NKNOTS) return cp::fail(CP_EINVAL, "cp_ncdm_knots: need a buffer of %d doubles", CP_NCDM_NKNOTS);

@@ -41,7 +41,21 @@ class EisensteinHuEngine(BaseEngine):
 
 
 class Background(DefaultBackground):
-    """Background quantities; does not treat neutrinos (reference eisenstein_hu.py:106-152)."""
+    """Background quantities with closed-form growth (reference eisenstein_hu.py:106-152)."""
+
+    def growth_factor(self, z, znorm=None):
+        """CPT92 approximation of the growth factor (eisenstein_hu.py:115-140)."""
+        growthz = self._eval('growth_cpt', z)
+        if znorm is not None:
+            return (1. + znorm) * growthz
+        g0 = self._eval('growth_cpt', np.zeros(()))
+        if np.ndim(g0) and np.ndim(growthz) > np.ndim(g0):
+            g0 = g0.reshape(g0.shape + (1,) * (np.ndim(growthz) - np.ndim(g0)))
+        return growthz / g0
+
+    def growth_rate(self, z):
+        """Approximation of the growth rate Omega_m(z)^(0.55 + 0.05 (1 + w(z=1))) (eisenstein_hu.py:143-152)."""
+        return self._eval('growth_rate', z)
 
 
 class Thermodynamics(BaseSection):

@@ -138,6 +138,15 @@ typedef struct cp_ncdm {
     const double* tab;  /* device, (ncosmo, nspecies, 4, CP_NCDM_NKNOTS): rho, rho'', p, p'' in 1e10 Msun/h / (Mpc/h)^3 */
 } cp_ncdm;
 int cp_ncdm_knots(double* zc_out, int n);
+
+/* Linear growth from the ODE D'' = f2 D + f1 D' in eta = ln a (reference DefaultBackground.growth_factor / growth_rate,
+ * cosmology.py:2044-2093: jax.odeint 'rk4' on eta = linspace(-6, 0, 201), initial conditions D = D' = e^-6): d_tab (ncosmo, 2, 201) receives
+ * D and D'/D on the knots z = exp(-eta) - 1 in ASCENDING z (cp_growth_ode_knots), ready for the natural splines the reference builds on them.
+ * mass: 0 'm' (Omega_m incl. massive neutrinos), 1 'cb' (Omega_cdm + Omega_b). */
+#define CP_GROWTH_NKNOTS 201
+int cp_growth_ode_knots(double* zc_out, int n);
+int cp_growth_ode_tables(long long ncosmo, const cp_param* params, int second_is_omega_m, const cp_ncdm* ncdm, int mass, double* d_tab, int device,
+                         void* stream);
 /* m_ncdm[s] (eV) and T_ncdm_over_cmb[s], s < nspecies: per-cosmology parameters like h and T_cmb; nodes / weights: the nq-point
  * Gauss-Laguerre rule (host arrays; the reference uses numpy.polynomial.laguerre.laggauss(100)); d_tab as in cp_ncdm.tab */
 int cp_ncdm_tables(long long ncosmo, int nspecies, cp_param h, cp_param T_cmb, const cp_param* m_ncdm, const cp_param* T_ncdm_over_cmb, int nq,

@@ -308,3 +308,49 @@ def rs(z, p, efunc_fn=None, cosmomc=False):
 def zstar_cosmomc(omega_b, omega_m):
     """Hu & Sugiyama fit of the redshift of last scattering as used by CosmoMC (cosmology.py:208-210)."""
     return 1048 * (1 + 0.00124 * omega_b**(-0.738)) * (1 + (0.0783 * omega_b**(-0.238) / (1 + 39.5 * omega_b**0.763)) * omega_m**(0.560 / (1 + 21.1 * omega_b**1.81)))
+
+
+def growth_ode_tables(p, mass='m', efunc_parts=None):
+    """DefaultBackground.growth_factor / growth_rate caches (cosmology.py:2044-2093): RK4 (jax.py:700-710) of D'' = f2 D + f1 D' in
+    eta = ln a on linspace(-6, 0, 201).  Returns (zc ascending, D, D'/D) on those knots; one cosmology without massive neutrinos."""
+    rc = rho_crit_over_Msunph_per_Mpcph3
+
+    def omegas(z):
+        d = densities(z, p)
+        return d['Omega_k'], d['Omega_r'], d['Omega_de'], (d['Omega_m'] if mass == 'm' else d['Omega_cdm'] + d['Omega_b'])
+
+    def deriv(y, eta):
+        z = np.exp(-eta) - 1.
+        Ok, Or, Ode, Om = omegas(z)
+        w_fld = p['w0_fld'] + z / (1. + z) * p['wa_fld']
+        f1 = -1. - (-1. / 2. * (1. - Ok + Or + 3 * w_fld * Ode))
+        f2 = 3. / 2. * Om
+        return np.array([y[1], f2 * y[0] + f1 * y[1]])
+
+    eta = np.linspace(-6., 0., 201)
+    y = np.array([np.exp(eta[0]), np.exp(eta[0])])
+    out, t_last = [], eta[0]
+    for t in eta:
+        h = t - t_last
+        k1 = deriv(y, t_last)
+        k2 = deriv(y + h * k1 / 2, t_last + h / 2)
+        k3 = deriv(y + h * k2 / 2, t_last + h / 2)
+        k4 = deriv(y + h * k3, t)
+        y = y + h / 6. * (k1 + 2 * k2 + 2 * k3 + k4)
+        out.append(y)
+        t_last = t
+    out = np.array(out)
+    zc = np.exp(-eta) - 1.
+    return zc[::-1], out[::-1, 0], out[::-1, 1] / out[::-1, 0]
+
+
+def growth_factor_ode(z, p, mass='m', znorm=None):
+    zc, D, _ = growth_ode_tables(p, mass=mass)
+    spl = CubicSpline(zc, D, bc_type='natural', extrapolate=False)
+    g = spl(np.asarray(z, dtype='f8'))
+    return (1. + znorm) * g if znorm is not None else g / spl(0.)
+
+
+def growth_rate_ode(z, p, mass='m'):
+    zc, _, f = growth_ode_tables(p, mass=mass)
+    return CubicSpline(zc, f, bc_type='natural', extrapolate=False)(np.asarray(z, dtype='f8'))

@@ -448,6 +448,14 @@ def gen_densities(cp):
             out['c%d_rs' % i] = np.array([float(ba.rs(zz)) for zz in RS_Z])
             cosmo_i = cp.Cosmology(engine='eisenstein_hu', **par)
             out['c%d_theta_cosmomc' % i] = float(cosmo_i['theta_cosmomc'])
+            from cosmoprimo.cosmology import DefaultBackground
+            bd = DefaultBackground(cosmo_i.engine if hasattr(cosmo_i, 'engine') else cosmo_i._engine)
+            zg = np.concatenate([[0., 1e-3], np.linspace(0.05, 3., 10), [10., 100., 400.]])
+            out['zg'] = zg
+            out['c%d_growth_factor_ode' % i] = np.asarray(bd.growth_factor(zg))
+            out['c%d_growth_factor_ode_znorm' % i] = np.asarray(bd.growth_factor(zg, znorm=10.))
+            out['c%d_growth_factor_ode_cb' % i] = np.asarray(bd.growth_factor(zg, mass='cb'))
+            out['c%d_growth_rate_ode' % i] = np.asarray(bd.growth_rate(zg))
             out['c%d_time' % i] = np.asarray(ba.time(z), dtype='f8')
             out['c%d_age' % i] = float(ba.age)
         out['time_knots'] = np.asarray(ba._cache['time']._x)

@@ -114,6 +114,18 @@ def test_densities(golden):
         np.testing.assert_allclose(cosmo_i['theta_MC_100'], 100. * g['c%d_theta_cosmomc' % i], rtol=1e-10)
         with pytest.raises(cp.CosmologyComputationError):
             ba.rs(0.)        # the reference fails there as well: its rule misses the 1e-7 tolerance
+        # linear growth from its ODE (DefaultBackground, cosmology.py:2044-2093); the analytic engines' own Background keeps the CPT92 form
+        from cosmoprimo_amd.cosmology import DefaultBackground
+        bd = DefaultBackground(cosmo_i.engine)
+        zg = g['zg']
+        np.testing.assert_allclose(bd.growth_factor(zg), g['c%d_growth_factor_ode' % i], rtol=1e-10)
+        np.testing.assert_allclose(bd.growth_factor(zg, znorm=10.), g['c%d_growth_factor_ode_znorm' % i], rtol=1e-10)
+        np.testing.assert_allclose(bd.growth_factor(zg, mass='cb'), g['c%d_growth_factor_ode_cb' % i], rtol=1e-10)
+        np.testing.assert_allclose(bd.growth_rate(zg), g['c%d_growth_rate_ode' % i], rtol=1e-10)
+        np.testing.assert_allclose(bd.growth_factor(zg), ob.growth_factor_ode(zg, ob.derived(**{k: v for k, v in par.items() if k != 'cs2_fld'},
+                                                                                             **({'Omega_cdm': 0.25} if 'Omega_m' not in par else {}))), rtol=1e-10)
+        assert bd.growth_factor(0.).shape == () and np.isnan(bd.growth_factor(np.array([500.]))).all() and abs(bd.growth_factor(0.) - 1.) < 1e-15
+        assert abs(ba.growth_factor(1.) / bd.growth_factor(1.) - 1.) < 0.1       # CPT92 closed form vs ODE: a few % with curvature or w0-wa
     # a batch of cosmologies: leading axis
     ba = cp.Cosmology(engine='eisenstein_hu', Omega_m=np.array([0.3, 0.36]), h=np.array([0.7, 0.64])).get_background()
     out = ba.Omega_cdm(z)
@@ -128,3 +140,7 @@ def test_densities(golden):
     both = cp.Cosmology(engine='eisenstein_hu', Omega_m=np.array([0.3, 0.36]), h=np.array([0.7, 0.64]))
     np.testing.assert_allclose(both['theta_cosmomc'], [cp.Cosmology(engine='eisenstein_hu', Omega_m=om, h=h)['theta_cosmomc'] for om, h in [(0.3, 0.7), (0.36, 0.64)]],
                                rtol=1e-13)
+    from cosmoprimo_amd.cosmology import DefaultBackground
+    gb = DefaultBackground(both.engine).growth_factor(g['zg'])
+    assert gb.shape == (2, g['zg'].size)
+    np.testing.assert_allclose(gb[1], DefaultBackground(cp.Cosmology(engine='eisenstein_hu', Omega_m=0.36, h=0.64).engine).growth_factor(g['zg']), rtol=1e-13)

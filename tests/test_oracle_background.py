@@ -65,5 +65,11 @@ def test_densities(golden):
         zstar = ob.zstar_cosmomc(p['Omega_b'] * h2, (p['Omega_cdm'] + p['Omega_b']) * h2)
         theta = ob.rs(zstar, p, cosmomc=True) * p['h'] / ob.distances(np.array([zstar]), p)['comoving_transverse_distance'][0]
         np.testing.assert_allclose(theta, g['c%d_theta_cosmomc' % i], rtol=1e-10)
+        # ODE growth of DefaultBackground (cosmology.py:2044-2093)
+        zg = g['zg']
+        np.testing.assert_allclose(ob.growth_factor_ode(zg, p), g['c%d_growth_factor_ode' % i], rtol=1e-11)
+        np.testing.assert_allclose(ob.growth_factor_ode(zg, p, znorm=10.), g['c%d_growth_factor_ode_znorm' % i], rtol=1e-11)
+        np.testing.assert_allclose(ob.growth_factor_ode(zg, p, mass='cb'), g['c%d_growth_factor_ode_cb' % i], rtol=1e-11)
+        np.testing.assert_allclose(ob.growth_rate_ode(zg, p), g['c%d_growth_rate_ode' % i], rtol=1e-11)
     np.testing.assert_allclose(ob.time_knots(), g['time_knots'], rtol=1e-15)
     assert np.isnan(g['time_nan_outside']).all()
