@@ -58,6 +58,8 @@ def _ncdm_momenta_z0(T_eff, m, out='rho'):
     ti, wi = np.polynomial.laguerre.laggauss(100)
     if out == 'rho':
         f = ti**2 * np.sqrt(ti**2 + m2) / (1. + np.exp(-ti))
+    elif out == 'drhodm':      # derivative of the density w.r.t. the mass (per eV), for the Newton solve of Omega_ncdm -> m_ncdm
+        f = (m * over_T**2)[..., None] * ti**2 / np.sqrt(ti**2 + m2) / (1. + np.exp(-ti))
     else:
         f = 1. / 3. * ti**4 / np.sqrt(ti**2 + m2) / (1. + np.exp(-ti))
     c, sb, _ = bgmod_constants()
@@ -121,8 +123,30 @@ def _compile_params(args):
                 out.pop(name, None)
     out.update(params)
     hierarchy = out.pop('neutrino_hierarchy', None)
-    if 'Omega_ncdm' in out or 'omega_ncdm' in out:
-        raise NotImplementedError('massive neutrinos are specified by their masses m_ncdm on this path (not Omega_ncdm)')
+    if 'omega_ncdm' in out:
+        out['Omega_ncdm'] = np.asarray(out.pop('omega_ncdm'), dtype='f8') / np.asarray(_host(out.get('h', out.get('H0', 70.) / 100.)), dtype='f8')**2
+    if 'Omega_ncdm' in out:   # densities instead of masses: Newton's method on every mass (reference cosmology.py:975-1014); scalar cosmologies
+        if out.get('m_ncdm', None) is not None:
+            raise CosmologyInputError('Conflicting parameters: m_ncdm and Omega_ncdm')
+        Omega_ncdm = out.pop('Omega_ncdm')
+        Omega_ncdm = [] if Omega_ncdm is None else list(np.atleast_1d(np.asarray(Omega_ncdm, dtype='f8')))
+        T_in = out.get('T_ncdm_over_cmb', None)
+        T_list = [TNCDM_OVER_CMB if T_in is None else t for t in (np.broadcast_to(np.asarray(TNCDM_OVER_CMB if T_in is None else T_in, dtype='f8'), (len(Omega_ncdm),)))]
+        hh = float(_host(out['H0'] / 100. if 'H0' in out else out['h']))
+        rck = bgmod_constants()[2] / (1e10 * 1.98847 * 1e30) * (1e6 * 3.085677581491367e16)**3
+        masses = []
+        for Om, t in zip(Omega_ncdm, T_list):
+            omega, T_eff = Om * hh**2, float(_host(out['T_cmb'])) * t
+            m = omega * 93.14
+            if Om != 0.:
+                check = _ncdm_momenta_z0(T_eff, m, 'rho') / rck
+                for _ in range(1000):
+                    if not abs(omega - check) > 1e-15:
+                        break
+                    m = m + (omega - check) / (_ncdm_momenta_z0(T_eff, m, 'drhodm') / rck)
+                    check = _ncdm_momenta_z0(T_eff, m, 'rho') / rck
+            masses.append(float(m))
+        out['m_ncdm'] = masses
     # massive neutrinos (reference cosmology.py:960-969, 1113-1140): one entry per species, each a float or a (B,) array
     m_ncdm = out.pop('m_ncdm', None)
     if m_ncdm is None:

@@ -82,5 +82,4 @@ def test_ncdm_tables_and_batch(cp, golden):
     # no massive species: empty per-species arrays, zero totals (cosmology.py:1969-1970)
     b0 = cp.Cosmology(engine='eisenstein_hu').get_background()
     assert b0.rho_ncdm(z).shape == (0, z.size) and (b0.rho_ncdm_tot(z) == 0.).all() and b0.N_ncdm == 0
-    with pytest.raises(NotImplementedError):
-        cp.Cosmology(Omega_ncdm=0.001)
+    np.testing.assert_allclose(cp.Cosmology(Omega_ncdm=0.0014)['Omega_ncdm_tot'], 0.0014, rtol=1e-12)
