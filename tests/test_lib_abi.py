@@ -57,3 +57,19 @@ def test_loggamma_special_points():
     ref = loggamma(z)
     assert np.all(np.abs(out - ref) <= 1e-15 * np.maximum(np.abs(ref), 1.)), np.abs(out - ref)
     assert np.all(np.isnan(_lib.loggamma(np.array([0., -1., -2.])).real))  # poles
+
+
+@pytest.mark.gpu
+def test_c_consumer(tmp_path):
+    """A consumer of the C ABI without Python or torch in the data path (tests/abi/consumer.cpp): HIP-runtime buffers, plain pointers; checked
+    against a direct O(N^2) evaluation of the reference arithmetic inside the program."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'consumer')
+    libdir = os.path.join(root, 'cosmoprimo_amd')
+    subprocess.run(['hipcc', '--offload-arch=gfx950', '-O2', '-I', os.path.join(root, 'include'), '-o', exe, os.path.join(root, 'tests', 'abi', 'consumer.cpp'),
+                    '-L', libdir, '-lcosmoprimo_amd', '-Wl,-rpath,' + libdir], check=True, capture_output=True, timeout=300)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert 'OK (ABI' in res.stdout
