@@ -30,11 +30,24 @@ class DST(object):
         x = dv.to_device(x, self.device)
         if x.shape[-1] != self.n:
             raise ValueError('last dimension must be {:d}, got {}'.format(self.n, tuple(x.shape)))
-        out = torch.empty_like(x)
         nrows = x.numel() // self.n
+        # the kernel transforms rows in pairs (one complex FFT): a row that is not finite (or, for the fused log map, not positive) would
+        # spread its NaN to its partner, which scipy's row-by-row transform does not do; such rows go in as a harmless constant and come out NaN
+        ok = None
+        if nrows:
+            ok = torch.isfinite(x).all(dim=-1, keepdim=True)
+            if fused and not inverse:
+                ok = ok & (x > 0.).all(dim=-1, keepdim=True)
+            if bool(ok.all()):
+                ok = None
+            else:
+                x = torch.where(ok, x, torch.ones_like(x)).contiguous()
+        out = torch.empty_like(x)
         if nrows:
             _lib.check(_lib.load().cp_dst_execute(self._handle, x.data_ptr(), out.data_ptr(), nrows, int(bool(inverse)), int(bool(fused)),
                                                   dv.stream_of(self.device)))
+        if ok is not None:
+            out = torch.where(ok, out, torch.full_like(out, float('nan')))
         return out
 
     def __del__(self):

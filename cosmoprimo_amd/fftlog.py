@@ -364,6 +364,16 @@ class FFTlog(object):
         tin = tfun.expand(bshape).contiguous()
         el, er = _split_pair(extrap)
         (cl, vl), (cr, vr) = _extrap_code(el), _extrap_code(er)
+        # Two rows share one complex transform in the kernel, so a NaN / Inf in one row would spread to its pair partner, which the
+        # reference's row-by-row FFTs do not do: such rows are transformed as zeros and filled with NaN afterwards (all of numpy's output
+        # for them is NaN as well).  One pass over the input and one host read of a flag; the C ABI itself leaves this to its caller.
+        finite = None
+        if tin.numel():
+            finite = torch.isfinite(tin).all(dim=-1, keepdim=True)
+            if bool(finite.all()):
+                finite = None
+            else:
+                tin = torch.where(finite, tin, torch.zeros_like(tin))
         scale = None
         if self._rescale_rows and tin.numel():
             if (cl == 0 and vl != 0.) or (cr == 0 and vr != 0.):
@@ -384,6 +394,8 @@ class FFTlog(object):
                                                      stream))
         if scale is not None:
             tout = tout * scale
+        if finite is not None:
+            tout = torch.where(finite, tout, torch.full_like(tout, float('nan')))
         if self._phase is not None:
             tout = tout * torch.as_tensor(self._phase, device=dev)[:, None]
         y = self.padded_y if keep_padding else self.y

@@ -63,7 +63,10 @@ typedef struct cp_fftlog_plan cp_fftlog_plan;
 int cp_fftlog_plan_create(cp_fftlog_plan** plan, int n, int npad, int nker, const double* pre, const double* post,
                           const double* u_re_im, int device);
 /* d_in : device (nbatch, nker, n) float64 C-contiguous;  d_out : device (nbatch, nker, n or npad).
- * extrap_*: cp_extrap, val_* used for CP_EXTRAP_CONSTANT.  keep_padding as in fftlog.py:233-237. */
+ * extrap_*: cp_extrap, val_* used for CP_EXTRAP_CONSTANT.  keep_padding as in fftlog.py:233-237.
+ * Batch items 2q and 2q + 1 of a kernel are transformed as the real and imaginary parts of ONE complex sequence: rounding is relative to
+ * the larger of the two rows, and a NaN / Inf in one of them reaches the other.  A caller that may hold such rows (or rows of very
+ * different magnitude) masks / rescales them first, as the Python class does (FFTlog.__call__; rescale_rows). */
 int cp_fftlog_execute(const cp_fftlog_plan* plan, const double* d_in, double* d_out, long long nbatch, int extrap_left,
                       double val_left, int extrap_right, double val_right, int keep_padding, void* stream);
 int cp_fftlog_plan_destroy(cp_fftlog_plan* plan);

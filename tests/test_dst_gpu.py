@@ -27,3 +27,24 @@ def test_dst_roundtrip_and_scipy(n):
     assert np.abs(yf - reff).max() < 1e-13 * np.abs(reff).max()
     pb = plan(reff, inverse=True, fused=True).cpu().numpy()
     assert np.abs(pb / p - 1).max() < 1e-12
+
+
+def test_nonfinite_rows_stay_isolated():
+    """Rows are transformed in pairs: a NaN row (or a non-positive one under the fused log map) must not reach its partner."""
+    import torch
+    from cosmoprimo_amd.dst import DST
+    from scipy import fftpack
+    rng = np.random.default_rng(5)
+    x = rng.uniform(0.5, 2., (4, 1024))
+    x[1, 3] = np.nan
+    d = DST(1024)
+    out = d(torch.as_tensor(x, device='cuda')).cpu().numpy()
+    assert np.isnan(out[1]).all()
+    for i in (0, 2, 3):
+        np.testing.assert_allclose(out[i], fftpack.dst(x[i], type=2, norm='ortho'), rtol=1e-11, atol=1e-12)
+    kx = np.linspace(1e-3, 2., 1024)
+    x[1, 3], x[2, 10] = 1., -1.
+    out = DST(1024, kx=kx)(torch.as_tensor(x, device='cuda'), fused=True).cpu().numpy()
+    assert np.isnan(out[2]).all()
+    for i in (0, 1, 3):
+        np.testing.assert_allclose(out[i], fftpack.dst(np.log(kx * x[i]), type=2, norm='ortho'), rtol=1e-10, atol=1e-11)

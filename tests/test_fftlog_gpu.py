@@ -273,3 +273,22 @@ def test_large_sizes(cp, n):
             assert err.max() < 1e-13, (n, extrap, keep, err.max())
     s, xi = cp.PowerToCorrelation(k, ell=0)(fun[0, 0])
     assert xi.shape == (n,) and tilted_err(xi, ofl.apply(ofl.power_to_correlation(k, ell=0), fun[0, 0])[0], s, 1.5) < TOL_NORM
+
+
+def test_nonfinite_rows_stay_isolated(cp, golden):
+    """A NaN / Inf row gives a NaN row and leaves its neighbours alone, as numpy's row-by-row FFT does (the kernel packs rows in pairs)."""
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k1024'], pkd['pk1024']
+    rows = np.tile(pk, (5, 1))
+    rows[1, 17] = np.nan
+    rows[2, 900] = np.inf
+    f = cp.PowerToCorrelation(k)
+    s, xi = f(rows)
+    ref = ofl.apply(ofl.power_to_correlation(k), pk)[0]
+    assert np.isnan(xi[1]).all() and np.isnan(xi[2]).all()
+    for i in (0, 3, 4):
+        assert tilted_err(xi[i], ref, s, 1.5) < TOL_NORM
+    import torch
+    t = torch.as_tensor(rows, device='cuda')
+    xi_t = f(t)[1]
+    assert bool(torch.isnan(xi_t[1]).all()) and bool(torch.isfinite(xi_t[0]).all())
