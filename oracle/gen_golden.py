@@ -9,7 +9,7 @@ import os
 import sys
 import numpy as np
 
-from ._refimport import import_reference
+from ._refimport import import_reference, REFERENCE_ROOT
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
 
@@ -530,6 +530,14 @@ def gen_variants(cp):
     save('variants', **out)
 
 
+def gen_desi_table():
+    """161 of the 40 002 rows of the reference's tabulated DESI fiducial (cosmoprimo/data/desi.dat: z, E(z), D_C(z) [Mpc/h], computed with
+    a Boltzmann code): a data file of the reference kept as a fixture, the z = 0 row plus 160 rows evenly spaced in log z."""
+    table = np.loadtxt(os.path.join(REFERENCE_ROOT, "cosmoprimo", "data", "desi.dat"), comments='#')
+    idx = np.r_[0, np.linspace(1, len(table) - 1, 160).astype(int)]
+    save('desi_table', z=table[idx, 0], efunc=table[idx, 1], comoving_radial_distance=table[idx, 2])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -557,6 +565,8 @@ def main():
         gen_ncdm(cp)
     if 'variants' in which:
         gen_variants(cp)
+    if 'desi_table' in which:
+        gen_desi_table()
 
 
 if __name__ == '__main__':
