@@ -7,6 +7,7 @@ Fixtures are plain float64/complex128 arrays (inputs + expected outputs) produce
 """
 import os
 import sys
+import warnings
 import numpy as np
 
 from ._refimport import import_reference, REFERENCE_ROOT
@@ -530,6 +531,30 @@ def gen_variants(cp):
     save('variants', **out)
 
 
+CALCULATOR_CASES = [('eisenstein_hu', {}, dict(Omega_m=0.3)), ('eisenstein_hu', {}, dict(h=0.65, n_s=0.95, w0_fld=-0.9)),
+                    ('eisenstein_hu_nowiggle_variants', dict(m_ncdm=[0.06]), dict(Omega_m=0.28)), ('bbks', {}, dict(Omega_b=0.045))]
+CALCULATOR_PK_STRIDE = (8, 3)
+
+
+def gen_calculator(cp):
+    """The reference's batch driver (emulators/__init__.py:11-60) on its analytic engines; its calculator drops the power spectra of these
+    engines (swallowed keyword error), so the pairs are taken from ``Fourier.pk_interpolator`` directly, on a sub-grid of the default (k, z)."""
+    from cosmoprimo.emulators import get_calculator
+    from cosmoprimo.emulators.emulated import get_default_k_callable, get_default_z_callable
+    out = {}
+    k, z = get_default_k_callable()[::CALCULATOR_PK_STRIDE[0]], get_default_z_callable()[::CALCULATOR_PK_STRIDE[1]]
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for i, (engine, base, params) in enumerate(CALCULATOR_CASES):
+            cosmo = cp.Cosmology(engine=engine, **base)
+            for name, value in get_calculator(cosmo)(**params).items():
+                out['c%d:%s' % (i, name)] = np.asarray(value, dtype='f8')
+            fo = cosmo.clone(**params).get_fourier()
+            for of in ([('delta_m', 'delta_m'), ('delta_m', 'theta_m'), ('theta_m', 'theta_m')] if 'variants' not in engine else [('delta_m', 'delta_m')]):
+                out['c%d:fourier.pk.%s.%s' % ((i,) + of)] = np.asarray(fo.pk_interpolator(of=of)(k, z))
+    save('calculator', **out)
+
+
 def gen_desi_table():
     """161 of the 40 002 rows of the reference's tabulated DESI fiducial (cosmoprimo/data/desi.dat: z, E(z), D_C(z) [Mpc/h], computed with
     a Boltzmann code): a data file of the reference kept as a fixture, the z = 0 row plus 160 rows evenly spaced in log z."""
@@ -565,6 +590,8 @@ def main():
         gen_ncdm(cp)
     if 'variants' in which:
         gen_variants(cp)
+    if 'calculator' in which:
+        gen_calculator(cp)
     if 'desi_table' in which:
         gen_desi_table()
 

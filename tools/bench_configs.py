@@ -105,6 +105,22 @@ def main():
                       'value': nb / dt, 'unit': 'samples/s', 'ms': dt * 1e3, 'algorithmic_GBps': nb * 40 / dt / 1e9,
                       'E_evaluations_per_s': nb * 237 / dt}))
 
+    # f4: the batch driver (emulators.get_calculator): params -> every section's arrays on the reference's default grids, D2H included
+    from cosmoprimo_amd.emulators import get_calculator
+    nb = int(8192 * args.scale)
+    rng = np.random.default_rng(4)
+    par = dict(Omega_m=rng.uniform(.25, .40, nb), Omega_b=rng.uniform(.04, .06, nb), h=rng.uniform(.6, .8, nb), n_s=rng.uniform(.92, 1., nb))
+    calc = get_calculator(cp.Cosmology(engine='eisenstein_hu'))
+    calc(**{k: v[:64] for k, v in par.items()})
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = calc(**par)
+    dt = time.perf_counter() - t0
+    nbytes = sum(v.nbytes for v in out.values())
+    print(json.dumps({'config': 'f4', 'workload': 'get_calculator(eisenstein_hu)(%d cosmologies): background (256 z) + thermodynamics + primordial + 3 P(k, z) pairs (422 k x 30 z), results on the host' % nb,
+                      'value': nb / dt, 'unit': 'cosmologies/s', 'ms': dt * 1e3, 'output_GB': nbytes / 1e9,
+                      'reference_cpu_note': 'the reference calculator takes 0.67 s per cosmology in the build container (without the P(k) pairs, which it drops)'}))
+
 
 if __name__ == '__main__':
     main()
