@@ -44,6 +44,25 @@ def to_device(x, device):
     return t.from_numpy(np.ascontiguousarray(a)).to(device).reshape(a.shape)
 
 
+def to_host(x):
+    """numpy array from a device tensor.  Results of a few MB and more (batches of filtered spectra, P(k, z) tables) go through a page-locked
+    staging buffer of torch's caching host allocator: the copy then runs at the PCIe rate instead of the pageable-memory rate."""
+    t = torch()
+    if not is_torch(x):
+        return np.asarray(x)
+    x = x.detach()
+    if x.is_cuda and x.numel() * x.element_size() >= (1 << 22):
+        try:
+            buf = t.empty(x.shape, dtype=x.dtype, pin_memory=True)
+        except RuntimeError:    # no page-locked memory left: the pageable copy below is the same result, slower
+            buf = None
+        if buf is not None:
+            buf.copy_(x, non_blocking=True)
+            t.cuda.current_stream(x.device).synchronize()
+            return buf.numpy()
+    return x.cpu().numpy()
+
+
 def stream_of(device):
     return torch().cuda.current_stream(device).cuda_stream
 

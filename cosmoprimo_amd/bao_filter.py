@@ -78,13 +78,34 @@ class BasePowerSpectrumBAOFilter(object, metaclass=RegisteredPowerSpectrumBAOFil
             self.shape = (self.k.size,) + cs
 
     def _finalize(self):
-        """Device rows -> ``pk`` / ``pknow`` arrays of the reference's shape (k first, then columns)."""
-        def host(rows):
-            a = rows.cpu().numpy()
+        """The host copies are made when ``pk`` / ``pknow`` are first read: a caller that keeps working on the device (``pknow_rows``) or
+        wants ``pknow`` only does not pay for two device-to-host copies of the batch."""
+        self._host = {}
+
+    def _to_host(self, name):
+        """Device rows -> array of the reference's shape (k first, then columns)."""
+        if name not in self._host:
+            a = dv.to_host(getattr(self, '_{}_rows'.format(name)))
             if isinstance(self.pk_interpolator, PowerSpectrumInterpolator2D) and len(self._lead) > 1:
-                return np.moveaxis(a.reshape(self._lead + (self.k.size,)), -1, -2)
-            return a.T.reshape(self.shape)
-        self.pk, self.pknow = host(self._pk_rows), host(self._pknow_rows)
+                self._host[name] = np.moveaxis(a.reshape(self._lead + (self.k.size,)), -1, -2)
+            else:
+                self._host[name] = a.T.reshape(self.shape)
+        return self._host[name]
+
+    @property
+    def pk(self):
+        """Input power spectrum at :attr:`k`."""
+        return self._to_host('pk')
+
+    @property
+    def pknow(self):
+        """Power spectrum without BAO wiggles at :attr:`k`."""
+        return self._to_host('pknow')
+
+    @property
+    def pknow_rows(self):
+        """:attr:`pknow` as it sits in HBM: tensor (ncolumns, nk), one row per input power spectrum."""
+        return self._pknow_rows
 
     def __call__(self, pk_interpolator, cosmo=None):
         self.set_pk(pk_interpolator, cosmo=cosmo)

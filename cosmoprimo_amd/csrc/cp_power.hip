@@ -121,54 +121,72 @@ struct Args {
     const double* kscale;  // optional (ncosmo): cosmology ic is evaluated at k * kscale[ic] (brieden2022: k_fid / rescale, k_fid * rescale)
     const double* z;  // (nz) shared (what == CP_PK_MATTER with nz > 0), else unused
     double* out;      // (ncosmo, max(nz, 1), nk)
+    long long kchunks, kspan;  // a workgroup evaluates kspan consecutive k of ONE cosmology; kchunks = ceil(nk / kspan) workgroups per cosmology
 };
 
+// One workgroup = one cosmology x kspan wavenumbers.  Everything that depends on the cosmology alone -- the ~25 pow() of the EH98 fit
+// coefficients, growth(z)^2 of every output redshift -- is evaluated ONCE per workgroup (one lane for the coefficients, one lane per
+// redshift) and shared through LDS; the lanes then walk the wavenumbers with the per-k part only (9 transcendentals).  Evaluated per lane,
+// as the first version did, the coefficients were 3/4 of the kernel's time.
 __global__ __launch_bounds__(256) void power_kernel(const Args A) {
-    const long long ik = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long ic = blockIdx.y;
-    if (ik >= A.nk) return;
+    __shared__ EhScalars sh_s;
+    __shared__ double sh_g2[256];
+    const int tid = threadIdx.x;
+    const long long ic = blockIdx.x / A.kchunks;
+    const long long k0 = (long long)(blockIdx.x % A.kchunks) * A.kspan;
+    const long long k1 = k0 + A.kspan < A.nk ? k0 + A.kspan : A.nk;
     const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
-    const double kh = A.kscale ? A.k[ik] * A.kscale[ic] : A.k[ik];
-    const long long nrow = A.nz > 0 ? A.nz : 1;
-    double* out = A.out + ic * nrow * A.nk + ik;
-    double T = 1.;
-    if (A.what != CP_PK_PRIMORDIAL) {
-        if (A.engine == CP_ENGINE_BBKS) {
-            T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-        } else {
-            const EhScalars s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
-            T = A.engine == CP_ENGINE_EH ? transfer_eh(s, c.h, kh) : transfer_nowiggle(s, c.h, kh);
-        }
-    }
-    if (A.what == CP_PK_TRANSFER) {
-        out[0] = T;
-        return;
-    }
+    const bool eh = A.what != CP_PK_PRIMORDIAL && A.engine != CP_ENGINE_BBKS;
+    const bool with_z = A.what == CP_PK_MATTER && A.nz > 0;
+    const long long nzs = with_z ? A.nz : 1;
+    const double kfac = A.kscale ? A.kscale[ic] : 1.;
     // Primordial.pk_k, eisenstein_hu.py:214-215
     const double A_s = pw[CP_PK_A_S], n_s = pw[CP_PK_N_S], alpha_s = pw[CP_PK_ALPHA_S], beta_s = pw[CP_PK_BETA_S];
     const double kp = pw[CP_PK_K_PIVOT] / c.h;
-    const double lnkkp = log(kh / kp);
-    const double prim = (c.h * c.h * c.h) * A_s * pow(kh / kp, n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp));
-    if (A.what == CP_PK_PRIMORDIAL) {
-        out[0] = prim;
-        return;
-    }
-    // pk_callable, eisenstein_hu.py:321-324
     const double Omega0_m = c.Omega_b + c.Omega_cdm + 0. - 0.;  // cosmology.py:381
-    const double p2d_base = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (kh * kh));
-    const double potential_to_density = 1. / (p2d_base * p2d_base);
-    const double curvature_to_potential = 9. / 25. * 2. * (kPi * kPi) / (kh * kh * kh) / (c.h * c.h * c.h);
-    const double p0 = (T * T) * potential_to_density * curvature_to_potential * prim;
-    if (A.nz <= 0) {
-        out[0] = p0;
-        return;
-    }
-    for (long long iz = 0; iz < A.nz; ++iz) {
-        const double g = growth_cpt(c, A.z[iz]);  // growth_factor(z, znorm=0), eisenstein_hu.py:317
-        out[iz * A.nk] = p0 * (g * g);
+    for (long long z0 = 0; z0 < nzs; z0 += 256) {
+        if (z0) __syncthreads();  // the previous block of redshifts has been written
+        if (with_z && z0 + tid < A.nz) {
+            const double g = growth_cpt(c, A.z[z0 + tid]);  // growth_factor(z, znorm=0), eisenstein_hu.py:317
+            sh_g2[tid] = g * g;
+        }
+        if (z0 == 0 && eh && tid == 255) sh_s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
+        __syncthreads();
+        const int nzi = with_z ? (int)(A.nz - z0 < 256 ? A.nz - z0 : 256) : 1;
+        for (long long ik = k0 + tid; ik < k1; ik += 256) {
+            const double kh = A.kscale ? A.k[ik] * kfac : A.k[ik];
+            double* out = A.out + (ic * nzs + z0) * A.nk + ik;
+            double T = 1.;
+            if (A.what != CP_PK_PRIMORDIAL) {
+                if (A.engine == CP_ENGINE_BBKS)
+                    T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+                else
+                    T = A.engine == CP_ENGINE_EH ? transfer_eh(sh_s, c.h, kh) : transfer_nowiggle(sh_s, c.h, kh);
+            }
+            if (A.what == CP_PK_TRANSFER) {
+                out[0] = T;
+                continue;
+            }
+            const double lnkkp = log(kh / kp);
+            const double prim = (c.h * c.h * c.h) * A_s * pow(kh / kp, n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp));
+            if (A.what == CP_PK_PRIMORDIAL) {
+                out[0] = prim;
+                continue;
+            }
+            // pk_callable, eisenstein_hu.py:321-324
+            const double p2d_base = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (kh * kh));
+            const double potential_to_density = 1. / (p2d_base * p2d_base);
+            const double curvature_to_potential = 9. / 25. * 2. * (kPi * kPi) / (kh * kh * kh) / (c.h * c.h * c.h);
+            const double p0 = (T * T) * potential_to_density * curvature_to_potential * prim;
+            if (!with_z) {
+                out[0] = p0;
+                continue;
+            }
+            for (int iz = 0; iz < nzi; ++iz) out[iz * A.nk] = p0 * sh_g2[iz];
+        }
     }
 }
 
@@ -216,88 +234,119 @@ struct VarArgs {
     const double* ncdm_tab;
     const double* ncdm_knots;
     int nsp;
+    long long kchunks, kspan;  // as in power_kernel's Args
 };
 
-__global__ __launch_bounds__(256) void variants_kernel(const VarArgs A) {
-    __shared__ double knots[CP_NCDM_NKNOTS];
-    if (A.nsp)
-        for (int i = threadIdx.x; i < CP_NCDM_NKNOTS; i += blockDim.x) knots[i] = A.ncdm_knots[i];
-    __syncthreads();
-    const long long ik = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long ic = blockIdx.y;
-    if (ik >= A.nk) return;
-    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, knots, A.nsp);
-    // engine scalars, _set_rsdrag / compute (:32-76)
+struct VarScalars {
+    double Omega_ncdm, Omega_pncdm, omega_m, frac_cb, frac_ncdm, theta_cmb, z_eq, rs_drag, p_cb, gamma_ncdm, beta_c;
+};
+
+// engine scalars, _set_rsdrag / compute (eisenstein_hu_nowiggle_variants.py:32-76)
+__device__ __forceinline__ VarScalars variants_scalars(const Cosmo& c) {
+    VarScalars v;
     const double h2 = c.h * c.h;
-    double Omega_ncdm = 0., Omega_pncdm = 0.;
+    v.Omega_ncdm = 0.;
+    v.Omega_pncdm = 0.;
     for (int s = 0; s < c.nsp; ++s) {
-        Omega_ncdm += c.ncdm_tab[((long long)s * 4 + 0) * CP_NCDM_NKNOTS] / kRhoCrit;
-        Omega_pncdm += 3. * c.ncdm_tab[((long long)s * 4 + 2) * CP_NCDM_NKNOTS] / kRhoCrit;
+        v.Omega_ncdm += c.ncdm_tab[((long long)s * 4 + 0) * CP_NCDM_NKNOTS] / kRhoCrit;
+        v.Omega_pncdm += 3. * c.ncdm_tab[((long long)s * 4 + 2) * CP_NCDM_NKNOTS] / kRhoCrit;
     }
     const double omega_b = c.Omega_b * h2;
-    const double omega_m = c.Omega_cdm * h2 + c.Omega_b * h2 + Omega_ncdm * h2 - Omega_pncdm * h2;
+    v.omega_m = c.Omega_cdm * h2 + c.Omega_b * h2 + v.Omega_ncdm * h2 - v.Omega_pncdm * h2;
+    const double omega_m = v.omega_m;
     const double frac_b = omega_b / omega_m, frac_cdm = c.Omega_cdm * h2 / omega_m;
-    const double frac_cb = frac_cdm + frac_b, frac_ncdm = 1. - frac_cb;
+    v.frac_cb = frac_cdm + frac_b;
+    v.frac_ncdm = 1. - v.frac_cb;
+    const double frac_cb = v.frac_cb, frac_ncdm = v.frac_ncdm;
     const double N = (double)c.nsp;
-    const double theta_cmb = c.T_cmb / 2.7;
-    const double z_eq = 2.5e4 * omega_m * pow(theta_cmb, -4.) - 1.;
+    v.theta_cmb = c.T_cmb / 2.7;
+    v.z_eq = 2.5e4 * omega_m * pow(v.theta_cmb, -4.) - 1.;
     const double b1 = 0.313 * pow(omega_m, -0.419) * (1 + 0.607 * pow(omega_m, 0.674));
     const double b2 = 0.238 * pow(omega_m, 0.223);
     const double z_drag = 1291 * pow(omega_m, 0.251) / (1. + 0.659 * pow(omega_m, 0.828)) * (1. + b1 * pow(omega_b, b2));
-    const double rs_drag = 44.5 * log(9.83 / omega_m) / sqrt(1. + 10. * pow(omega_b, 0.75));
+    v.rs_drag = 44.5 * log(9.83 / omega_m) / sqrt(1. + 10. * pow(omega_b, 0.75));
     const double fbn = frac_b + frac_ncdm;
-    const double p_c = (5. - sqrt(1 + 24 * frac_cdm)) / 4., p_cb = (5. - sqrt(1 + 24. * frac_cb)) / 4.;
-    const double y_drag = (1 + z_eq) / (1 + z_drag);
+    const double p_c = (5. - sqrt(1 + 24 * frac_cdm)) / 4.;
+    v.p_cb = (5. - sqrt(1 + 24. * frac_cb)) / 4.;
+    const double p_cb = v.p_cb;
+    const double y_drag = (1 + v.z_eq) / (1 + z_drag);
     const double alpha = frac_cdm / frac_cb * (5. - 2. * (p_c + p_cb)) / (5. - 4. * p_cb) * pow(1 + y_drag, p_cb - p_c) *
                          (1 + fbn * (-0.553 + 0.126 * (fbn * fbn))) / (1 - 0.193 * sqrt(frac_ncdm * N) + 0.169 * frac_ncdm * pow(N, 0.2)) *
                          (1 + (p_c - p_cb) / 2 * (1 + 1 / (3. - 4. * p_c) / (7. - 4. * p_cb)) / (1 + y_drag));
-    const double gamma_ncdm = sqrt(alpha);
-    const double beta_c = 1 / (1 - 0.949 * fbn);
-    // transfer_kz (:114-154): the z-independent part
-    const double khm = A.k[ik];          // h/Mpc
-    const double k = khm * c.h;          // 1/Mpc
-    const double q = k / omega_m * (theta_cmb * theta_cmb);
-    const double kr = k * rs_drag * 0.43;
-    const double gamma_eff = omega_m * (gamma_ncdm + (1 - gamma_ncdm) / (1 + (kr * kr) * (kr * kr)));
-    const double q_eff = q * omega_m / gamma_eff;
-    const double TL = log(kE + 1.84 * beta_c * gamma_ncdm * q_eff);
-    const double TC = 14.4 + 325. / (1 + 60.5 * pow(q_eff, 1.08));
-    double T_sup = TL / (TL + TC * (q_eff * q_eff));
-    double yfs = 0.;
-    if (c.nsp) {
-        const double qn = 3.92 * q * sqrt(N / frac_ncdm);
-        T_sup *= 1 + 1.24 * pow(frac_ncdm, 0.64) * pow(N, 0.3 + 0.6 * frac_ncdm) / (pow(qn, -1.6) + pow(qn, 0.8));
-        const double nq = N * q / frac_ncdm;
-        yfs = 17.2 * frac_ncdm * (1 + 0.488 * pow(frac_ncdm, -7. / 6.)) * (nq * nq);
-    }
-    // primordial spectrum and the potential -> density factors (Fourier.pk_interpolator :178-185, eisenstein_hu.py:214-215)
-    double pdd = 0.;
-    if (A.what == CP_PK_MATTER) {
-        double pw[CP_PK_NPARAMS];
+    v.gamma_ncdm = sqrt(alpha);
+    v.beta_c = 1 / (1 - 0.949 * fbn);
+    return v;
+}
+
+// Same shape as power_kernel: one workgroup = one cosmology x kspan wavenumbers; the engine scalars (one lane) and the CPT growth of every
+// redshift (one lane each) are evaluated once per workgroup and shared through LDS.
+__global__ __launch_bounds__(256) void variants_kernel(const VarArgs A) {
+    __shared__ double knots[CP_NCDM_NKNOTS];
+    __shared__ VarScalars sh_v;
+    __shared__ double sh_g[256];
+    const int tid = threadIdx.x;
+    if (A.nsp)
+        for (int i = tid; i < CP_NCDM_NKNOTS; i += blockDim.x) knots[i] = A.ncdm_knots[i];
+    __syncthreads();
+    const long long ic = blockIdx.x / A.kchunks;
+    const long long k0 = (long long)(blockIdx.x % A.kchunks) * A.kspan;
+    const long long k1 = k0 + A.kspan < A.nk ? k0 + A.kspan : A.nk;
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, knots, A.nsp);
+    double pw[CP_PK_NPARAMS];
 #pragma unroll
-        for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
-        const double kp = pw[CP_PK_K_PIVOT] / c.h;
-        const double lnkkp = log(khm / kp);
-        const double prim = (c.h * c.h * c.h) * pw[CP_PK_A_S] *
-                            pow(khm / kp, pw[CP_PK_N_S] - 1. + 1. / 2. * pw[CP_PK_ALPHA_S] * lnkkp + 1. / 6. * pw[CP_PK_BETA_S] * (lnkkp * lnkkp));
-        const double Omega0_m = c.Omega_b + c.Omega_cdm + Omega_ncdm - Omega_pncdm;  // cosmology.py:381
-        const double p2d = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (khm * khm));
-        pdd = 1. / (p2d * p2d) * (9. / 25. * 2. * (kPi * kPi) / (khm * khm * khm) / (c.h * c.h * c.h)) * prim;
-    }
-    double* out = A.out + ic * A.nz * A.nk + ik;
-    for (long long iz = 0; iz < A.nz; ++iz) {
-        const double z = A.z[iz];
-        const double g = growth_cpt(c, z);  // Background.growth_factor(z, znorm): (1 + znorm) x this, eisenstein_hu.py:134-139
-        double ratio = 1.;                 // growth / growth_k0 (:119-134)
-        if (c.nsp) {
-            const double gk0 = (1. + z_eq) * g;
-            const double t1 = pow(gk0, 1. - p_cb);
-            const double t2 = pow(gk0 / (1 + yfs), 0.7);
-            const double growth = A.of == 1 ? pow(1. + t2, p_cb / 0.7) * t1 : pow(pow(frac_cb, 0.7 / p_cb) + t2, p_cb / 0.7) * t1;
-            ratio = growth / gk0;
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
+    const double N = (double)c.nsp;
+    for (long long z0 = 0; z0 < A.nz; z0 += 256) {
+        if (z0) __syncthreads();
+        if (z0 + tid < A.nz) sh_g[tid] = growth_cpt(c, A.z[z0 + tid]);  // Background.growth_factor(z, znorm): (1 + znorm) x this, eisenstein_hu.py:134-139
+        if (z0 == 0 && tid == 255) sh_v = variants_scalars(c);
+        __syncthreads();
+        const VarScalars& v = sh_v;
+        const int nzi = (int)(A.nz - z0 < 256 ? A.nz - z0 : 256);
+        for (long long ik = k0 + tid; ik < k1; ik += 256) {
+            // transfer_kz (:114-154): the z-independent part
+            const double khm = A.k[ik];          // h/Mpc
+            const double k = khm * c.h;          // 1/Mpc
+            const double q = k / v.omega_m * (v.theta_cmb * v.theta_cmb);
+            const double kr = k * v.rs_drag * 0.43;
+            const double gamma_eff = v.omega_m * (v.gamma_ncdm + (1 - v.gamma_ncdm) / (1 + (kr * kr) * (kr * kr)));
+            const double q_eff = q * v.omega_m / gamma_eff;
+            const double TL = log(kE + 1.84 * v.beta_c * v.gamma_ncdm * q_eff);
+            const double TC = 14.4 + 325. / (1 + 60.5 * pow(q_eff, 1.08));
+            double T_sup = TL / (TL + TC * (q_eff * q_eff));
+            double yfs = 0.;
+            if (c.nsp) {
+                const double qn = 3.92 * q * sqrt(N / v.frac_ncdm);
+                T_sup *= 1 + 1.24 * pow(v.frac_ncdm, 0.64) * pow(N, 0.3 + 0.6 * v.frac_ncdm) / (pow(qn, -1.6) + pow(qn, 0.8));
+                const double nq = N * q / v.frac_ncdm;
+                yfs = 17.2 * v.frac_ncdm * (1 + 0.488 * pow(v.frac_ncdm, -7. / 6.)) * (nq * nq);
+            }
+            // primordial spectrum and the potential -> density factors (Fourier.pk_interpolator :178-185, eisenstein_hu.py:214-215)
+            double pdd = 0.;
+            if (A.what == CP_PK_MATTER) {
+                const double kp = pw[CP_PK_K_PIVOT] / c.h;
+                const double lnkkp = log(khm / kp);
+                const double prim = (c.h * c.h * c.h) * pw[CP_PK_A_S] *
+                                    pow(khm / kp, pw[CP_PK_N_S] - 1. + 1. / 2. * pw[CP_PK_ALPHA_S] * lnkkp + 1. / 6. * pw[CP_PK_BETA_S] * (lnkkp * lnkkp));
+                const double Omega0_m = c.Omega_b + c.Omega_cdm + v.Omega_ncdm - v.Omega_pncdm;  // cosmology.py:381
+                const double p2d = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (khm * khm));
+                pdd = 1. / (p2d * p2d) * (9. / 25. * 2. * (kPi * kPi) / (khm * khm * khm) / (c.h * c.h * c.h)) * prim;
+            }
+            double* out = A.out + (ic * A.nz + z0) * A.nk + ik;
+            for (int iz = 0; iz < nzi; ++iz) {
+                const double g = sh_g[iz];
+                double ratio = 1.;                 // growth / growth_k0 (:119-134)
+                if (c.nsp) {
+                    const double gk0 = (1. + v.z_eq) * g;
+                    const double t1 = pow(gk0, 1. - v.p_cb);
+                    const double t2 = pow(gk0 / (1 + yfs), 0.7);
+                    const double growth = A.of == 1 ? pow(1. + t2, v.p_cb / 0.7) * t1 : pow(pow(v.frac_cb, 0.7 / v.p_cb) + t2, v.p_cb / 0.7) * t1;
+                    ratio = growth / gk0;
+                }
+                const double T = T_sup * ratio;
+                out[iz * A.nk] = A.what == CP_PK_TRANSFER ? T : (T * T) * (g * g) * pdd;
+            }
         }
-        const double T = T_sup * ratio;
-        out[iz * A.nk] = A.what == CP_PK_TRANSFER ? T : (T * T) * (g * g) * pdd;
     }
 }
 
@@ -318,7 +367,6 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     if (ncosmo < 0 || nk < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_power_eval: negative size");
     if (ncosmo == 0 || nk == 0) return CP_OK;
     if (!bg_params || !pk_params || !d_k || !d_out || (nz > 0 && !d_z)) return cp::fail(CP_EINVAL, "cp_power_eval: null pointer");
-    if (ncosmo > 65535) return cp::fail(CP_EUNSUPPORTED, "cp_power_eval: at most 65535 cosmologies per call (got %lld); split the batch", ncosmo);
     int prev;
     int st = select_device(device, &prev);
     if (st != CP_OK) return st;
@@ -335,8 +383,17 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     A.kscale = d_kscale;
     A.z = d_z;
     A.out = d_out;
-    const int block = 256;
-    hipLaunchKernelGGL(power_kernel, dim3((unsigned)((nk + block - 1) / block), (unsigned)ncosmo), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    // wavenumbers per workgroup: all of a cosmology's when the batch alone fills the chip (>= 8 workgroups per CU), fewer for small batches
+    const long long block = 256;
+    long long kiter = (nk + block - 1) / block;
+    while (kiter > 1 && ncosmo * ((nk + block * kiter - 1) / (block * kiter)) < 2048) kiter = (kiter + 1) / 2;
+    A.kspan = block * kiter;
+    A.kchunks = (nk + A.kspan - 1) / A.kspan;
+    if (ncosmo * A.kchunks > 2147483647LL) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return cp::fail(CP_EUNSUPPORTED, "cp_power_eval: %lld cosmologies x %lld wavenumbers exceed one launch; split the batch", ncosmo, nk);
+    }
+    hipLaunchKernelGGL(power_kernel, dim3((unsigned)(ncosmo * A.kchunks)), dim3((unsigned)block), 0, static_cast<hipStream_t>(stream), A);
     hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval: launch failed: %s", hipGetErrorString(e));
@@ -351,7 +408,6 @@ extern "C" int cp_power_eval_variants(int what, int of, long long ncosmo, const 
     if (ncosmo < 0 || nk < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_power_eval_variants: negative size");
     if (ncosmo == 0 || nk == 0 || nz == 0) return CP_OK;
     if (!bg_params || !pk_params || !d_k || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_power_eval_variants: null pointer");
-    if (ncosmo > 65535) return cp::fail(CP_EUNSUPPORTED, "cp_power_eval_variants: at most 65535 cosmologies per call (got %lld); split the batch", ncosmo);
     const int nsp = ncdm ? ncdm->nspecies : 0;
     if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_power_eval_variants: bad massive-neutrino tables");
     int prev;
@@ -376,8 +432,16 @@ extern "C" int cp_power_eval_variants(int what, int of, long long ncosmo, const 
         if (prev >= 0) (void)hipSetDevice(prev);
         return cp::fail(CP_ENOMEM, "cp_power_eval_variants: cannot allocate the massive-neutrino knots on device %d", device);
     }
-    const int block = 256;
-    hipLaunchKernelGGL(variants_kernel, dim3((unsigned)((nk + block - 1) / block), (unsigned)ncosmo), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    const long long block = 256;
+    long long kiter = (nk + block - 1) / block;
+    while (kiter > 1 && ncosmo * ((nk + block * kiter - 1) / (block * kiter)) < 2048) kiter = (kiter + 1) / 2;
+    A.kspan = block * kiter;
+    A.kchunks = (nk + A.kspan - 1) / A.kspan;
+    if (ncosmo * A.kchunks > 2147483647LL) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return cp::fail(CP_EUNSUPPORTED, "cp_power_eval_variants: %lld cosmologies x %lld wavenumbers exceed one launch; split the batch", ncosmo, nk);
+    }
+    hipLaunchKernelGGL(variants_kernel, dim3((unsigned)(ncosmo * A.kchunks)), dim3((unsigned)block), 0, static_cast<hipStream_t>(stream), A);
     hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval_variants: launch failed: %s", hipGetErrorString(e));

@@ -51,17 +51,9 @@ def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=Non
         if tks.numel() != ncosmo:
             raise ValueError('kscale must have one entry per cosmology ({:d}), got {:d}'.format(ncosmo, tks.numel()))
     lib = _lib.load()
-    for start in range(0, ncosmo, 32768):   # the kernel indexes cosmologies with gridDim.y
-        stop = min(ncosmo, start + 32768)
-        sub_bg, sub_pk = (_lib.cp_param * len(_lib.BG_PARAMS))(), (_lib.cp_param * len(_lib.PK_PARAMS))()
-        for src, dst in ((cbg, sub_bg), (cpk, sub_pk)):
-            for i in range(len(dst)):
-                dst[i].ptr = (src[i].ptr + 8 * start) if src[i].ptr else None
-                dst[i].value = src[i].value
-        _lib.check(lib.cp_power_eval(_lib.ENGINES[engine], _lib.PK_WHAT[what], stop - start, dv.as_void_p(sub_bg), int(Omega_m is not None),
-                                     dv.as_void_p(sub_pk), nk, tk.data_ptr(), (tks.data_ptr() + 8 * start) if tks is not None else None, nz,
-                                     tz.data_ptr() if with_z else None,
-                                     out[start:stop].data_ptr(), device.index, dv.stream_of(device)))
+    _lib.check(lib.cp_power_eval(_lib.ENGINES[engine], _lib.PK_WHAT[what], ncosmo, dv.as_void_p(cbg), int(Omega_m is not None), dv.as_void_p(cpk), nk,
+                                 tk.data_ptr(), tks.data_ptr() if tks is not None else None, nz, tz.data_ptr() if with_z else None, out.data_ptr(),
+                                 device.index, dv.stream_of(device)))
     shape = ((ncosmo,) if batched else ()) + ((nz,) if with_z else ()) + (nk,)
     return out.reshape(shape)
 
@@ -96,8 +88,6 @@ def variants(what, k, z, of='delta_m', bg=None, pk=None, ncdm=None, device=None)
         raise ValueError('parameter arrays must share one length, got {} and {}'.format(n1, n2))
     batched = n1 is not None or n2 is not None
     ncosmo = n1 or n2 or 1
-    if ncosmo > 32768:
-        raise NotImplementedError('at most 32768 cosmologies per call')
     tk, tz = dv.to_device(k, device).reshape(-1), dv.to_device(z, device).reshape(-1)
     out = torch.empty((ncosmo, tz.numel(), tk.numel()), dtype=torch.float64, device=device)
     cn = None

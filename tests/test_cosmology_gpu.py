@@ -71,6 +71,26 @@ def test_power_batched_cosmologies(cp, golden, eng):
             close(getattr(cosmo._engine, name).cpu().numpy(), g[eng + '_' + name])
 
 
+@pytest.mark.parametrize('eng', ['eisenstein_hu', 'eisenstein_hu_nowiggle_variants'])
+def test_power_launch_shapes(cp, golden, eng):
+    """The power kernels give one workgroup a span of wavenumbers of one cosmology, the span depending on the batch: the same numbers must come
+    out of every launch shape -- 70 000 cosmologies in one call (more than a grid's y extent), ragged k counts, many redshifts (> 256)."""
+    g = golden('power')
+    base = {n: g[n] for n in PNAMES}
+    extra = dict(m_ncdm=[0.06]) if 'variants' in eng else {}
+    small = cp.Cosmology(engine=eng, **base, **extra).get_fourier().pk_interpolator()
+    k = np.geomspace(1e-4, 10., 1237)
+    z = np.linspace(0., 3., 300)
+    ref = small(k, z)                                                    # (8, 1237, 300)
+    for sl in (slice(0, 100), slice(100, 1237)):                          # other spans per workgroup, same numbers
+        assert np.array_equal(small(k[sl], z[:5]), ref[:, sl, :5])
+    big = cp.Cosmology(engine=eng, **{n: np.tile(v, 8750) for n, v in base.items()}, **extra)
+    assert big.batch_size == 70000
+    out = big.get_fourier().pk_interpolator()(k[::10], z[:2])
+    assert out.shape == (70000, 124, 2)
+    np.testing.assert_allclose(out.reshape(8750, 8, 124, 2), np.broadcast_to(ref[:, ::10, :2], (8750, 8, 124, 2)), rtol=1e-13, atol=0.)
+
+
 def test_background_through_cosmology_api(cp, golden):
     g = golden('background')
     z = g['z']
