@@ -10,6 +10,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
+from . import _device as dv
 
 KINDS = tuple(_lib.BG_KINDS)
 DEFAULTS = dict(h=0.7, Omega_cdm=0.25, Omega_b=0.05, Omega_k=0., T_cmb=2.7255, N_ur=3.044, w0_fld=-1., wa_fld=0.)
@@ -178,4 +179,4 @@ def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=N
     out = out.reshape(oshape)
     if z_torch:
         return out.to(out_dtype)
-    return out.cpu().numpy().astype(np_dtype)
+    return dv.to_host(out).astype(np_dtype, copy=False)

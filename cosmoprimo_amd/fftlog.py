@@ -14,6 +14,7 @@ stay on the device).  There is no CPU compute path.
 import numpy as np
 
 from . import _lib
+from . import _device as dv
 
 
 # ---------------------------------------------------------------------------------------------
@@ -404,7 +405,7 @@ class FFTlog(object):
             tout = tout.reshape(fshape[:-1] + (nout,))
         if is_torch:
             return torch.as_tensor(y, device=dev), tout
-        return y, tout.cpu().numpy()
+        return y, dv.to_host(tout)
 
     def inv(self):
         """Inverse the transform, in place (reference fftlog.py:243-248, including its padded_x / padded_y quirk)."""

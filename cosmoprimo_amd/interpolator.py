@@ -68,7 +68,7 @@ def _mask_bounds(x, xlim, bounds_error=False):
 def _host(x):
     """numpy float64 copy of a number / array / tensor (query coordinates are small and define host-built operators)."""
     if dv.is_torch(x):
-        return x.detach().cpu().numpy().astype('f8')
+        return dv.to_host(x).astype('f8', copy=False)
     return np.asarray(x, dtype='f8')
 
 
@@ -79,7 +79,7 @@ def _finish(t, dtype, like_torch, shape=None):
         t = t.reshape(shape)
     if like_torch:
         return t.to(torch.float32 if dtype == np.float32 else torch.float64)
-    return t.cpu().numpy().astype(dtype)
+    return dv.to_host(t).astype(dtype, copy=False)
 
 
 def _simpson_weights(x):
