@@ -6,7 +6,8 @@ eisenstein_hu_nowiggle.py, bbks.py).
 
 Scope: the parameters the analytic engines and the background use (h / H0, Omega_cdm / omega_cdm /
 Omega_m / omega_m, Omega_b / omega_b, Omega_k, sigma8 / A_s / logA, n_s, alpha_s, beta_s, k_pivot, T_cmb, N_eff / N_ur,
-w0_fld, wa_fld, tau_reio ...).  Massive neutrinos, ``solve`` and persistence are outside this path and raise / are absent.
+w0_fld, wa_fld, tau_reio ..., massive neutrinos through m_ncdm / Omega_ncdm / neutrino_hierarchy), the calculation parameters of the
+Boltzmann engines carried but unread, ``clone`` in both bases, ``solve``, json / npy persistence and the section shortcuts.
 
 Extension for the GPU: every numerical parameter may be an array (or torch tensor) of shape (B,): a *batch* of cosmologies.
 All section methods then return results with a leading (B,) axis.
@@ -35,18 +36,114 @@ class CosmologyComputationError(CosmologyError):
 
 
 _default_cosmological_parameters = dict(h=0.7, Omega_cdm=0.25, Omega_b=0.05, Omega_k=0., sigma8=0.8, k_pivot=0.05, n_s=0.96, alpha_s=0., beta_s=0.,
-                                        T_cmb=TCMB, m_ncdm=None, T_ncdm_over_cmb=TNCDM_OVER_CMB, N_eff=NEFF, tau_reio=0.06, w0_fld=-1., wa_fld=0.,
-                                        cs2_fld=1.)
-_conflict_parameters = [('h', 'H0'), ('Omega_b', 'omega_b'), ('Omega_cdm', 'omega_cdm', 'Omega_c', 'omega_c', 'Omega_m', 'omega_m'),
-                        ('Omega_k', 'omega_k'), ('N_ur', 'N_eff'), ('A_s', 'logA', 'sigma8')]
-_alias_parameters = {'omega_b': ('ombh2',), 'omega_cdm': ('omch2',), 'Omega_k': ('omk', 'Omega0_k'), 'N_eff': ('nnu',), 'n_s': ('ns',), 'alpha_s': ('nrun',),
-                     'beta_s': ('nrunrun',), 'tau_reio': ('tau',), 'Omega_m': ('Omega0_m',), 'Omega_cdm': ('Omega0_cdm', 'Omega_c'), 'omega_c': (),
-                     'Omega_b': ('Omega0_b',), 'T_cmb': ('T0_cmb',), 'logA': ('ln10^10A_s', 'ln10^{10}A_s', 'ln_A_s_1e10'), 'w0_fld': ('w',),
-                     'wa_fld': ('wa',), 'm_ncdm': ('mnu',)}
+                                        r=0., n_t='scc', alpha_t='scc', T_cmb=TCMB, m_ncdm=None, neutrino_hierarchy=None, T_ncdm_over_cmb=TNCDM_OVER_CMB,
+                                        N_eff=NEFF, tau_reio=0.06, reionization_width=0.5, A_L=1.0, w0_fld=-1., wa_fld=0., cs2_fld=1.)
+# accepted and carried for the Boltzmann engines of the reference; the analytic engines of this package do not read them (cosmology.py:734)
+_default_calculation_parameters = dict(non_linear='', modes='s', lensing=False, z_pk=None, kmax_pk=10., ellmax_cl=2500, YHe='BBN', use_ppf=True)
+_conflict_parameters_no_alias = [('h', 'H0'), ('T_cmb', 'Omega_g', 'omega_g'), ('Omega_b', 'omega_b'),
+                                 ('Omega_cdm', 'omega_cdm', 'Omega_c', 'omega_c', 'Omega_m', 'omega_m'), ('Omega_k', 'omega_k'),
+                                 ('N_ur', 'Omega_ur', 'omega_ur', 'N_eff'), ('m_ncdm', 'Omega_ncdm', 'omega_ncdm'), ('A_s', 'logA', 'sigma8'),
+                                 ('tau_reio', 'z_reio')]
+_alias_parameters = {'omega_b': ('ombh2',), 'omega_cdm': ('omch2',), 'Omega_k': ('omk', 'Omega0_k'), 'm_ncdm': ('mnu',), 'N_eff': ('nnu',), 'n_s': ('ns',),
+                     'alpha_s': ('nrun',), 'beta_s': ('nrunrun',), 'tau_reio': ('tau',), 'Omega_m': ('Omega0_m',), 'Omega_cdm': ('Omega0_cdm', 'Omega_c'),
+                     'Omega_b': ('Omega0_b',), 'Omega_ur': ('Omega0_ur',), 'Omega_ncdm': ('Omega0_ncdm',), 'Omega_fld': ('Omega0_fld',),
+                     'T_cmb': ('T0_cmb',), 'Omega_g': ('Omega0_g',), 'logA': ('ln10^10A_s', 'ln10^{10}A_s', 'ln_A_s_1e10'), 'w0_fld': ('w',),
+                     'wa_fld': ('wa',)}
+
+
+def _all_conflicts():
+    """Groups of mutually exclusive input names: the physical groups extended by the aliases of their members, plus one group per remaining
+    aliased name (same rule as reference cosmology.py:1543-1558, so that e.g. ``tau`` and ``tau_reio`` together are refused)."""
+    groups = []
+    for group in _conflict_parameters_no_alias:
+        group = list(group)
+        for name in list(group):
+            group += [alias for alias in _alias_parameters.get(name, ()) if alias not in group]
+        groups.append(tuple(group))
+    for name, aliases in _alias_parameters.items():
+        if not any(name in group for group in _conflict_parameters_no_alias):
+            groups.append((name,) + tuple(aliases))
+    return groups
+
+
+_conflict_parameters = _all_conflicts()
+
+
+def find_conflicts(name, conflicts=None):
+    """The group of input names ``name`` excludes (itself included), () if none (reference cosmology.py:1606-1624)."""
+    for group in (_conflict_parameters if conflicts is None else conflicts):
+        if name in group:
+            return group
+    return ()
+
+
+def check_params(args, conflicts=None):
+    """Raise :class:`CosmologyInputError` if two names of ``args`` exclude each other (reference cosmology.py:1592-1603)."""
+    for name in args:
+        found = [other for other in find_conflicts(name, conflicts) if other != name and other in args]
+        if found:
+            raise CosmologyInputError('Conflicting parameters are given: {}'.format([name] + found))
+
+
+def merge_params(args, moreargs, conflicts=None):
+    """``moreargs`` into ``args`` (in place): a new name first removes everything it excludes (reference cosmology.py:1561-1589)."""
+    for name in moreargs:
+        for other in find_conflicts(name, conflicts):
+            args.pop(other, None)
+    args.update(moreargs)
+    return args
 
 
 def _is_array(v):
     return dv.is_torch(v) or np.ndim(v) > 0
+
+
+class _class_or_instancemethod(classmethod):
+
+    """A method bound to the instance when called on one, to the class otherwise."""
+
+    def __get__(self, instance, owner):
+        return (super().__get__ if instance is None else self.__func__.__get__)(instance, owner)
+
+
+def _deepeq(a, b):
+    """Deep equality of parameter containers (dicts, sequences, arrays, device tensors, scalars)."""
+    if type(a) is not type(b):
+        return False
+    if isinstance(a, dict):
+        return a.keys() == b.keys() and all(_deepeq(a[name], b[name]) for name in a)
+    if isinstance(a, (tuple, list)):
+        return len(a) == len(b) and all(_deepeq(x, y) for x, y in zip(a, b))
+    if dv.is_torch(a):
+        return a.shape == b.shape and bool((a == b).all())
+    if isinstance(a, np.ndarray):
+        return a.shape == b.shape and bool(np.all(a == b))
+    return a == b
+
+
+def _to_json(obj):
+    """State dictionary -> JSON-serialisable (arrays and device tensors as tagged lists)."""
+    if isinstance(obj, dict):
+        return {name: _to_json(value) for name, value in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_to_json(value) for value in obj]
+    if dv.is_torch(obj):
+        obj = dv.to_host(obj)
+    if isinstance(obj, np.ndarray):
+        return {'__array__': obj.tolist(), 'dtype': str(obj.dtype)}
+    if isinstance(obj, np.generic):
+        return obj.item()
+    return obj
+
+
+def _from_json(obj):
+    if isinstance(obj, dict):
+        if '__array__' in obj:
+            return np.array(obj['__array__'], dtype=obj['dtype'])
+        return {name: _from_json(value) for name, value in obj.items()}
+    if isinstance(obj, list):
+        return [_from_json(value) for value in obj]
+    return obj
 
 
 def _ncdm_momenta_z0(T_eff, m, out='rho'):
@@ -106,22 +203,14 @@ def _split_neutrino_masses(sum_ncdm, hierarchy):
 
 def _compile_params(args):
     """Input parameters -> the canonical set (a reduced restatement of reference Cosmology._compile_params, cosmology.py:874-1217)."""
+    check_params(args)
     params = {}
     for name, value in args.items():   # aliases
         for canon, aliases in _alias_parameters.items():
             if name in aliases:
                 name = canon
         params[name] = value
-    for group in _conflict_parameters:
-        found = [name for name in group if name in params]
-        if len(found) > 1:
-            raise CosmologyInputError('Conflicting parameters: {}'.format(found))
-    out = {k: v for k, v in _default_cosmological_parameters.items()}
-    for group in _conflict_parameters:   # a provided member removes the defaults of its group
-        if any(name in params for name in group):
-            for name in group:
-                out.pop(name, None)
-    out.update(params)
+    out = merge_params(dict(_default_cosmological_parameters, **_default_calculation_parameters), params)   # a given name removes the defaults it excludes
     hierarchy = out.pop('neutrino_hierarchy', None)
     if 'omega_ncdm' in out:
         out['Omega_ncdm'] = np.asarray(out.pop('omega_ncdm'), dtype='f8') / np.asarray(_host(out.get('h', out.get('H0', 70.) / 100.)), dtype='f8')**2
@@ -177,11 +266,18 @@ def _compile_params(args):
     if 'H0' in out:
         out['h'] = out.pop('H0') / 100.
     h = out['h']
-    for name in ['b', 'cdm', 'c', 'm', 'k']:
+    for name in ['b', 'cdm', 'c', 'm', 'k', 'g', 'ur']:
         if 'omega_' + name in out:
             out['Omega_' + name] = out.pop('omega_' + name) / h**2
     if 'Omega_c' in out:
         out['Omega_cdm'] = out.pop('Omega_c')
+    if 'Omega_g' in out:     # photon density -> temperature (cosmology.py:952-953)
+        c, sb, rck = bgmod_constants()
+        out['T_cmb'] = (out.pop('Omega_g') * h**2 * rck / (4. / c**3 * sb))**0.25
+    if 'Omega_ur' in out:    # density of the massless species -> their number (cosmology.py:1110-1113)
+        c, sb, rck = bgmod_constants()
+        out['N_ur'] = out.pop('Omega_ur') / (7. / 8. * 4. / c**3 * sb * (out['T_cmb'] * (4. / 11.)**(1. / 3.))**4 / (h**2 * rck))
+        out.pop('N_eff', None)
     if 'Omega_m' in out:   # Omega_cdm = Omega_m - Omega_b - non-relativistic part of the massive neutrinos, cosmology.py:1163-1165
         rck = bgmod_constants()[2] / (1e10 * 1.98847 * 1e30) * (1e6 * 3.085677581491367e16)**3     # rho_crit_over_Msunph_per_Mpcph3
         nonrel = sum((_ncdm_momenta_z0(_host(out['T_cmb']) * t, m, 'rho') - 3 * _ncdm_momenta_z0(_host(out['T_cmb']) * t, m, 'p')) for t, m in zip(T_over, m_ncdm))
@@ -199,13 +295,89 @@ def _compile_params(args):
         out['A_s'] = np.exp(out.pop('logA')) * 1e-10 if not dv.is_torch(out['logA']) else dv.torch().exp(out.pop('logA')) * 1e-10
     w0, wa = out['w0_fld'], out['wa_fld']
     if not _is_array(w0) and not _is_array(wa) and w0 + wa >= 1. / 3.:   # cosmology.py:1171-1177
-        raise CosmologyInputError('w0_fld + wa_fld must be < 1/3')
+        raise CosmologyInputError('w(a -> 0) = w0_fld + wa_fld > 1 / 3 (found {:.2f}), violates radiation domination at early time'.format(w0 + wa))
+    # calculation parameters (cosmology.py:1150-1161): carried, not read by the analytic engines
+    if out.get('z_pk', None) is None:
+        out['z_pk'] = np.linspace(0., 10.**0.5, 30)**2     # interpolator.get_default_z_callable of the reference
+    if out.get('modes', None) is None:
+        out['modes'] = ['s']
+    for name in ['modes', 'z_pk']:
+        if np.ndim(out[name]) == 0:
+            out[name] = [out[name]]
+    out['z_pk'] = np.sort(np.asarray(out['z_pk'], dtype='f8'))
+    if 0. not in out['z_pk']:
+        out['z_pk'] = np.insert(out['z_pk'], 0, 0.)
+    out['use_ppf'] = bool(out.get('use_ppf', True))
+    for name in ['Omega_cdm', 'Omega_b', 'T_cmb', 'h', 'A_s', 'sigma8', 'm_ncdm', 'T_ncdm_over_cmb']:   # cosmology.py:1182-1192
+        values = out.get(name, None)
+        for value in (values if isinstance(values, (list, tuple)) else [values]):
+            if value is not None and not dv.is_torch(value) and bool(np.any(np.asarray(value, dtype='f8') < 0.)):   # device batches are not read back
+                raise CosmologyInputError('Parameter {} should be positive, found {}'.format(name, value))
+    for name, allowed in [('YHe', ('BBN',)), ('n_t', ('SCC',)), ('alpha_t', ('SCC',))]:   # a float or the named rule (cosmology.py:1194-1209)
+        value = out.get(name, None)
+        value = allowed[0] if value is None else value
+        if isinstance(value, str):
+            if value.upper() not in allowed:
+                raise CosmologyInputError('Parameter {} should be either a float or one of {}'.format(name, allowed))
+            value = value.upper()
+        out[name] = value
+    r, n_s = out['r'], out['n_s']
+    if isinstance(out['n_t'], str):        # single-field slow-roll consistency (cosmology.py:1212-1215)
+        out['n_t'] = - r / 8.0 * (2.0 - n_s - r / 8.0)
+    if isinstance(out['alpha_t'], str):
+        out['alpha_t'] = r / 8.0 * (r / 8.0 + n_s - 1)
     return out
 
 
 class BaseCosmoParams(object):
 
     """Parameter access shared by :class:`Cosmology` and engines (reference BaseCosmoParams, cosmology.py:231-457)."""
+
+    @classmethod
+    def get_default_params(cls, of=None, include_conflicts=True):
+        """Default input parameters ``of`` 'cosmology', 'calculation' or both (None); with ``include_conflicts`` every accepted name appears,
+        the excluded alternatives carrying the value of the default they exclude (reference cosmology.py:250-288)."""
+        if of is None:
+            toret = cls.get_default_params(of='cosmology', include_conflicts=include_conflicts)
+            toret.update(cls.get_default_params(of='calculation', include_conflicts=include_conflicts))
+            return toret
+        if of not in ('cosmology', 'calculation'):
+            raise CosmologyInputError('No default parameters for {}'.format(of))
+        toret = dict(_default_cosmological_parameters if of == 'cosmology' else _default_calculation_parameters)
+        if include_conflicts:
+            for name in list(toret):
+                for other in find_conflicts(name):
+                    toret[other] = toret[name]
+        return toret
+
+    @classmethod
+    def get_default_parameters(cls, **kwargs):
+        import warnings
+        warnings.warn('get_default_parameters is deprecated, use get_default_params')
+        return cls.get_default_params(**kwargs)
+
+    def get_params(self, of='base'):
+        """Parameters ``of`` 'base' (compiled), 'cosmology', 'calculation', 'derived', 'extra' (engine) or 'all' (reference cosmology.py:290-320)."""
+        if of == 'derived':
+            return dict(getattr(self, '_derived', {}))
+        if of == 'extra':
+            return dict(getattr(self, '_extra_params', {}))
+        toret = dict(self._params)
+        if of == 'base':
+            return toret
+        if of in ('cosmology', 'calculation'):
+            return {name: toret.get(name, value) for name, value in self.get_default_params(of=of).items()}
+        if of == 'all':
+            toret.update(self.get_params(of='derived'))
+            toret.update(self.get_params(of='extra'))
+            return toret
+        raise CosmologyInputError('No parameters for {}'.format(of))
+
+    def __eq__(self, other):
+        """Same parameters (and engine parameters)? (reference cosmology.py:454-456)"""
+        return type(other) == type(self) and _deepeq(other._params, self._params) and _deepeq(getattr(other, '_extra_params', {}), getattr(self, '_extra_params', {}))
+
+    __hash__ = object.__hash__
 
     def __getitem__(self, name):
         return self.get(name)
@@ -302,6 +474,8 @@ class BaseCosmoParams(object):
     def batch_size(self):
         """Number of cosmologies when parameters are arrays, else None."""
         for name, v in self._params.items():
+            if name in _default_calculation_parameters:   # z_pk, modes ...: arrays that are not batches
+                continue
             for x in (v if name in ('m_ncdm', 'T_ncdm_over_cmb') else [v]):
                 if _is_array(x):
                     return int(np.size(x)) if not dv.is_torch(x) else int(x.numel())
@@ -403,10 +577,12 @@ class Cosmology(BaseCosmoParams):
     """Cosmology, defined as a set of parameters (and possibly a current engine attached to it) (reference cosmology.py:724-1477)."""
 
     def __init__(self, engine=None, extra_params=None, device=None, **params):
-        self._input_params = dict(params)
-        self._params = _compile_params(params)
-        self._device = device
+        check_params(params)
+        self._derived = {}
         self._engine = None
+        self._device = device
+        self._input_params = merge_params(self.get_default_params(include_conflicts=False), params)
+        self._params = _compile_params(self._input_params)
         if engine is not None:
             self.set_engine(engine, **(extra_params or {}))
 
@@ -415,7 +591,7 @@ class Cosmology(BaseCosmoParams):
         return self._engine
 
     def set_engine(self, engine, set_engine=True, **extra_params):
-        """Set engine for cosmological calculation (reference cosmology.py:636-668)."""
+        """Set engine for cosmological calculation (reference cosmology.py:636-668, 1219-1235)."""
         if isinstance(engine, BaseEngine):
             new = engine
         else:
@@ -425,25 +601,216 @@ class Cosmology(BaseCosmoParams):
         return new
 
     def clone(self, base='input', engine=None, extra_params=None, **params):
-        """Clone with updated parameters."""
-        new_params = dict(self._input_params if base == 'input' else {})
-        for group in _conflict_parameters:
-            if any(name in params for name in group):
-                for name in group:
-                    new_params.pop(name, None)
-        new_params.update(params)
+        r"""
+        Copy with updated engine and parameters (reference cosmology.py:1237-1290).  ``base='input'``: update the input parameters (with input
+        :math:`h, \omega_b, \omega_{cdm}`, a new ``h`` keeps the physical densities); ``base='internal'`` (or None): update the compiled
+        :math:`h, \Omega_b, \Omega_{cdm}` basis (a new ``h`` keeps the density parameters).
+        """
+        check_params(params)
+        if base == 'input':
+            base_params = dict(self._input_params)
+        elif base in ('internal', None):
+            base_params = dict(self._params)
+        else:
+            raise CosmologyInputError('Unknown parameter base {}'.format(base))
         if engine is None and self._engine is not None:
-            engine = self._engine.name
-        return self.__class__(engine=engine, extra_params=extra_params, device=self._device, **new_params)
+            engine = self._engine.__class__
+        if extra_params is None:   # the current engine's, if the engine class is unchanged
+            same = engine is not None and self._engine is not None and get_engine(engine).name == self._engine.name
+            extra_params = dict(self._engine._extra_params) if same else {}
+        return self.__class__(engine=engine, extra_params=extra_params, device=self._device, **merge_params(base_params, params))
+
+    def solve(self, param, func, target=0., limits=None, init=None, xtol=1e-6, maxiter=25):
+        """
+        Cosmology with ``func(cosmo) == target``, varying input parameter ``param`` (one scalar cosmology; reference cosmology.py:1292-1376).
+
+        func : callable on a :class:`Cosmology`, or a parameter name: 'theta_MC_100' as in the reference (any name ``cosmo[name]`` knows works).
+        limits : bracket for ``param``; else the bracket is searched from ``init`` = x0 or (x0, dx) (default: the current value; for 'h' / 'H0'
+        matched to 'theta_MC_100' the fitting formula of class_public's shooting gives the start).  xtol : absolute tolerance on ``param``.
+        """
+        from scipy import optimize
+        if func is None:
+            raise CosmologyInputError('Provide func')
+        name = func if isinstance(func, str) else None
+        if name is not None:
+            def func(cosmo):
+                return cosmo[name]
+
+        def f(value):
+            try:
+                return float(np.asarray(_host(func(self.clone(base='input', **{param: value}))))) - target
+            except CosmologyError:
+                raise ValueError('cosmology could not be computed for {} = {}'.format(param, value))
+
+        def fail(exc, limits):
+            values = []
+            for x in limits:
+                try:
+                    values.append(f(x) + target)
+                except ValueError:
+                    values.append(np.nan)
+            raise CosmologyInputError('Could not find proper {} value in the interval that matches target = {:.4f} with [f({:.3f}), f({:.3f})] = [{:.4f}, {:.4f}]'
+                                      .format(param, target, *limits, *values)) from exc
+
+        if limits is None:
+            scale = {'h': 1., 'H0': 100.}.get(param, None)
+            if init is None and name == 'theta_MC_100' and scale is not None:
+                init = (scale * (3.54 * target**2 - 5.455 * target + 2.548), scale * 0.02)
+            if init is None:
+                init = self[param]
+            if np.ndim(init) == 0:
+                if scale is None:
+                    raise ValueError('provide either init tuple (x0, dx) = (initial value, typical variation), or parameter limits')
+                init = (init, 0.1 * scale)
+            x0, dx = float(init[0]), abs(float(init[1]))
+            # widen [x0 - w, x0 + w] until f changes sign; a side where the cosmology cannot be computed stops growing
+            lo = hi = x0
+            flo = fhi = f(x0)
+            found = flo == 0.
+            for it in range(maxiter):
+                if found:
+                    break
+                for side in (-1, 1):
+                    x = (lo if side < 0 else hi) + side * dx
+                    try:
+                        fx = f(x)
+                    except ValueError:
+                        continue
+                    if side < 0:
+                        if fx * flo <= 0.:
+                            lo, hi, found = x, lo, True
+                            break
+                        lo, flo = x, fx
+                    else:
+                        if fx * fhi <= 0.:
+                            lo, hi, found = hi, x, True
+                            break
+                        hi, fhi = x, fx
+                dx *= 1.5
+            if not found:
+                fail(ValueError('no sign change'), (lo, hi))
+            limits = (lo, hi)
+        limits = tuple(float(x) for x in limits)
+        try:
+            value = optimize.brentq(f, *limits, xtol=xtol, rtol=4 * np.finfo(float).eps, maxiter=max(4 * maxiter, 100))
+        except (ValueError, RuntimeError) as exc:
+            fail(exc, limits)
+        return self.clone(base='input', **{param: value})
+
+    def __getstate__(self):
+        """State dictionary: compiled, input and derived parameters, engine name and extra parameters (reference cosmology.py:1390-1397)."""
+        state = {'engine': None}
+        for name in ['params', 'input_params', 'derived']:
+            state[name] = getattr(self, '_{}'.format(name))
+        if getattr(self, '_engine', None) is not None:
+            state['engine'] = {'name': self._engine.name, 'extra_params': self._engine._extra_params}
+        return state
+
+    def __setstate__(self, state):
+        for name in ['params', 'input_params', 'derived']:
+            setattr(self, '_{}'.format(name), state.get(name, {}))
+        self._device, self._engine = None, None
+        if state.get('engine', None) is not None:
+            self.set_engine(state['engine']['name'], **state['engine']['extra_params'])
+
+    @classmethod
+    def from_state(cls, state):
+        new = cls.__new__(cls)
+        new.__setstate__(state)
+        return new
+
+    @classmethod
+    def read(cls, filename):
+        """Read from disk: '.json' or numpy '.npy' (reference cosmology.py:1406-1416)."""
+        import json
+        filename = str(filename)
+        if filename.endswith('.json'):
+            with open(filename, 'r') as file:
+                state = _from_json(json.load(file))
+        else:
+            state = np.load(filename, allow_pickle=True)[()]
+        return cls.from_state(state)
+
+    def write(self, filename):
+        """Write to disk: '.json' or numpy '.npy' (reference cosmology.py:1425-1434); batches held on the device are written as arrays."""
+        import json
+        import os
+        filename = str(filename)
+        dirname = os.path.dirname(filename)
+        if dirname:
+            os.makedirs(dirname, exist_ok=True)
+        state = _to_json(self.__getstate__())
+        if filename.endswith('.json'):
+            with open(filename, 'w') as file:
+                json.dump(state, file)
+        else:
+            np.save(filename, _from_json(state), allow_pickle=True)
+
+    @classmethod
+    def load(cls, filename):
+        import warnings
+        warnings.warn('load() is deprecated, use read() instead.', DeprecationWarning, stacklevel=2)
+        return cls.read(filename)
+
+    def save(self, filename):
+        import warnings
+        warnings.warn('save() is deprecated, use write() instead.', DeprecationWarning, stacklevel=2)
+        return self.write(filename)
+
+    @_class_or_instancemethod
+    def get_default_params(self=None, of=None, include_conflicts=True):
+        """Class or instance method: with an engine set, its defaults are added (reference cosmology.py:823-847)."""
+        toret = BaseCosmoParams.get_default_params(of=of, include_conflicts=include_conflicts)
+        engine = getattr(self, '_engine', None) if isinstance(self, Cosmology) else None
+        if engine is not None:
+            toret.update(engine.get_default_params(of=of, include_conflicts=include_conflicts))
+        return toret
+
+    def get_params(self, of='base'):
+        toret = super().get_params(of=of)
+        if self._engine is not None:
+            toret.update(self._engine.get_params(of=of))
+        return toret
+
+    def __dir__(self):
+        """Members plus those found in exactly one section of the engine (reference cosmology.py:1442-1457)."""
+        toret = list(super().__dir__())
+        if self._engine is None:
+            return toret
+        for Section in self._engine._Sections.values():
+            for item in _section_dir(Section):
+                if item in toret:
+                    toret.remove(item)
+                else:
+                    toret.append(item)
+        return toret
 
     def __getattr__(self, name):
+        """``cosmo.get_<section>()``, and the attributes of the engine's sections when one section only has them:
+        ``cosmo.comoving_radial_distance`` is ``cosmo.get_background().comoving_radial_distance`` (reference cosmology.py:1459-1473)."""
+        if name.startswith('__') or name in ('_engine', '_params', '_input_params', '_derived', '_device'):
+            raise AttributeError(name)
         if name.startswith('get_') and name[4:] in [s.lower() for s in _Sections]:
             def getter(engine=None, set_engine=True, **extra_params):
                 return _get_section(self, name[4:], engine=engine, set_engine=set_engine, **extra_params)
             return getter
-        if name in ('rs_drag', 'z_drag'):
-            return getattr(self.get_thermodynamics(), name)
-        raise AttributeError('{} has no attribute {}'.format(self.__class__.__name__, name))
+        if self._engine is None:
+            raise AttributeError('Attribute {} not found; try setting an engine ("set_engine")?'.format(name))
+        Sections = self._engine._Sections
+        owners = [section_name for section_name, Section in Sections.items() if name in _section_dir(Section)]
+        if len(owners) == 1:
+            return getattr(getattr(self._engine, 'get_{}'.format(owners[0]))(), name)
+        raise AttributeError("Attribute {} not found in any of {} engine's products (rejecting duplicates)".format(name, self._engine.__class__.__name__))
+
+    def __eq__(self, other):
+        return type(other) == type(self) and _deepeq(other._params, self._params) and other._engine == self._engine
+
+    __hash__ = object.__hash__
+
+
+def _section_dir(Section):
+    """Public names a section class offers: its class members and the per-instance quantities it declares in ``_shortcuts``."""
+    return [item for item in dir(Section) if not item.startswith('_')] + list(getattr(Section, '_shortcuts', ()))
 
 
 def _get_section(cosmo, section, engine=None, set_engine=True, **extra_params):
@@ -481,8 +848,8 @@ class BaseSection(object):
         self._h = engine['h']
 
     @property
-    def h(self):
-        return self._h
+    def engine(self):
+        return self._engine
 
 
 def _out(t, like, dtype=None):
@@ -494,13 +861,17 @@ def _out(t, like, dtype=None):
 class BaseBackground(BaseSection):
 
     """Background densities, E(z) and distances (reference BaseBackground, cosmology.py:1627-1933), evaluated by ``cp_background_distance``."""
+    # today's quantities, stored per instance as '_name' (the reference's utils.addproperty list, cosmology.py:1627-1630)
+    _shortcuts = ('H0', 'h', 'N_ur', 'N_ncdm', 'm_ncdm', 'm_ncdm_tot', 'N_eff', 'T0_cmb', 'T0_ncdm', 'w0_fld', 'wa_fld', 'cs2_fld', 'Omega0_cdm',
+                  'Omega0_b', 'Omega0_k', 'K', 'Omega0_g', 'Omega0_ur', 'Omega0_r', 'Omega0_pncdm', 'Omega0_pncdm_tot', 'Omega0_ncdm',
+                  'Omega0_ncdm_tot', 'Omega0_m', 'Omega0_Lambda', 'Omega0_fld', 'Omega0_de')
 
     def __init__(self, engine):
         super().__init__(engine)
         for name in ['H0', 'h', 'N_ur', 'N_ncdm', 'm_ncdm', 'm_ncdm_tot', 'N_eff', 'w0_fld', 'wa_fld', 'cs2_fld', 'K']:
             setattr(self, '_{}'.format(name), engine[name])
         self._T0_cmb = engine['T_cmb']
-        for name in ['cdm', 'b', 'k', 'g', 'ur', 'r', 'ncdm_tot', 'pncdm_tot', 'm', 'Lambda', 'fld', 'de']:
+        for name in ['cdm', 'b', 'k', 'g', 'ur', 'r', 'ncdm', 'pncdm', 'ncdm_tot', 'pncdm_tot', 'm', 'Lambda', 'fld', 'de']:
             setattr(self, '_Omega0_{}'.format(name), engine['Omega_{}'.format(name)])
         self._bg = engine.bg_params()
         self._T0_ncdm = engine['T_ncdm']

@@ -61,6 +61,7 @@ class Background(DefaultBackground):
 class Thermodynamics(BaseSection):
 
     """rs_drag [Mpc/h] and z_drag (reference eisenstein_hu.py:155-162)."""
+    _shortcuts = ('rs_drag', 'z_drag')
 
     def __init__(self, engine):
         super().__init__(engine)
@@ -71,6 +72,7 @@ class Thermodynamics(BaseSection):
 class Primordial(BaseSection):
 
     """Primordial power spectrum (reference eisenstein_hu.py:165-230)."""
+    _shortcuts = ('k_pivot', 'n_s', 'alpha_s', 'beta_s')
 
     def __init__(self, engine):
         super().__init__(engine)

@@ -555,6 +555,33 @@ def gen_calculator(cp):
     save('calculator', **out)
 
 
+def gen_cosmology_api(cp):
+    """Host-side behaviour of ``Cosmology`` the reference's tests/test_cosmology.py exercises: default-parameter names, ``solve``, clones."""
+    from cosmoprimo.fiducial import DESI
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        out['default_names'] = np.array(sorted(cp.Cosmology.get_default_params()))
+        out['default_names_noconflicts'] = np.array(sorted(cp.Cosmology.get_default_params(include_conflicts=False)))
+        out['default_cosmology_names'] = np.array(sorted(cp.Cosmology.get_default_params(of='cosmology')))
+        cosmo = cp.Cosmology(engine='eisenstein_hu')
+        out['z_pk'] = np.asarray(cosmo['z_pk'])
+        solved = cosmo.solve('h', 'theta_MC_100', 1.04092)
+        out['solve_h_theta_MC_100'] = float(solved['h'])
+        solved = DESI(engine='eisenstein_hu_nowiggle_variants').solve('h', lambda cosmo: 100. * cosmo['theta_cosmomc'], target=1.04, limits=[0.6, 0.9], xtol=1e-6)
+        out['solve_h_desi'] = float(solved['h'])
+        cosmo = cp.Cosmology(omega_cdm=0.2, engine='eisenstein_hu')
+        clone = cosmo.clone(base='internal', h=cosmo.h * 1.1)
+        out['clone_internal'] = np.array([clone.Omega0_m, clone.Omega0_cdm, clone['omega_cdm']], dtype='f8')
+        clone = cosmo.clone(base='input', h=cosmo.h * 1.1)
+        out['clone_input'] = np.array([clone.Omega0_m, clone.Omega0_cdm, clone['omega_cdm']], dtype='f8')
+        cosmo = cp.Cosmology(Omega_g=5e-5, omega_ur=1.7e-5)
+        out['from_Omega_g_ur'] = np.array([cosmo['T_cmb'], cosmo['N_ur'], cosmo['N_eff']], dtype='f8')
+        cosmo = cp.Cosmology(r=0.1)
+        out['tensor_defaults'] = np.array([cosmo['n_t'], cosmo['alpha_t']], dtype='f8')
+    save('cosmology_api', **out)
+
+
 def gen_desi_table():
     """161 of the 40 002 rows of the reference's tabulated DESI fiducial (cosmoprimo/data/desi.dat: z, E(z), D_C(z) [Mpc/h], computed with
     a Boltzmann code): a data file of the reference kept as a fixture, the z = 0 row plus 160 rows evenly spaced in log z."""
@@ -592,6 +619,8 @@ def main():
         gen_variants(cp)
     if 'calculator' in which:
         gen_calculator(cp)
+    if 'cosmology_api' in which:
+        gen_cosmology_api(cp)
     if 'desi_table' in which:
         gen_desi_table()
 

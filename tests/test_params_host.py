@@ -22,3 +22,71 @@ def test_ncdm_inputs():
         _compile_params(dict(m_ncdm=[0.06, 0.1], T_ncdm_over_cmb=[0.7]))
     with pytest.raises(CosmologyInputError):
         _compile_params(dict(w0_fld=-0.5, wa_fld=1.))
+
+
+def test_param_tables_and_conflicts(golden):
+    """Input names, defaults and exclusions (reference tests/test_cosmology.py::test_params, test_error) against the reference's own tables."""
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import Cosmology, CosmologyError, CosmologyInputError
+    g = golden('cosmology_api')
+    names = set(Cosmology.get_default_params())
+    # 'omk' is an alias the reference documents but loses (a duplicate key in its alias table); accepted here
+    assert names - set(g['default_names'].tolist()) == {'omk'} and set(g['default_names'].tolist()) <= names
+    assert set(Cosmology.get_default_params(include_conflicts=False)) == set(g['default_names_noconflicts'].tolist())
+    assert set(Cosmology.get_default_params(of='cosmology')) - {'omk'} == set(g['default_cosmology_names'].tolist())
+    with pytest.raises(CosmologyInputError):
+        Cosmology.get_default_params(of='nothing')
+    cosmo = Cosmology()
+    assert cosmo.get_default_params() == Cosmology.get_default_params()
+    for bad in [dict(sigma8=1., A_s=1e-9), dict(tau=0.05, tau_reio=0.06), dict(Omega_m=-0.1), dict(h=-0.7), dict(YHe='nope'), dict(w0_fld=0.5),
+                dict(H0=70., h=0.7), dict(omega_b=0.02, ombh2=0.02), dict(Omega_m=0.3, omch2=0.1)]:
+        with pytest.raises(CosmologyInputError):
+            Cosmology(**bad)
+    assert issubclass(CosmologyInputError, CosmologyError)
+    cosmo = Cosmology(Omega_cdm=0.3, Omega_b=0.02, h=0.8, n_s=0.96)
+    assert cosmo['omega_cdm'] == 0.3 * 0.8**2 and cosmo['sigma8'] == 0.8
+    assert len(cosmo['z_pk']) == 30 and np.array_equal(cosmo['z_pk'], g['z_pk'])
+    assert cosmo.batch_size is None      # the array of output redshifts is not a batch of cosmologies
+    assert np.allclose(Cosmology(z_pk=[1., 0.5])['z_pk'], [0., 0.5, 1.])
+    cosmo = Cosmology(ombh2=0.05, omch2=0.1)
+    assert np.allclose(cosmo['omega_b'], 0.05) and np.allclose(cosmo['omega_cdm'], 0.1)
+    cosmo = Cosmology(Omega_g=5e-5, omega_ur=1.7e-5)
+    np.testing.assert_allclose([cosmo['T_cmb'], cosmo['N_ur'], cosmo['N_eff']], g['from_Omega_g_ur'], rtol=1e-13)
+    cosmo = Cosmology(r=0.1)
+    np.testing.assert_allclose([cosmo['n_t'], cosmo['alpha_t']], g['tensor_defaults'], rtol=1e-13)
+    params = cosmo.get_params(of='cosmology')
+    assert params['r'] == 0.1 and 'kmax_pk' not in params and cosmo.get_params(of='calculation')['kmax_pk'] == 10.
+    assert cosmo.get_params(of='extra') == {} and set(cosmo.get_params()) == set(cosmo.get_params(of='all'))
+    assert cp.cosmology.find_conflicts('tau') == cp.cosmology.find_conflicts('z_reio') and cp.cosmology.find_conflicts('n_s') == ('n_s', 'ns')
+
+
+def test_clone_equality_persistence(tmp_path, golden):
+    """clone in both bases, equality, state round trips to json / npy (reference test_params, test_clone) -- no engine, host only."""
+    from cosmoprimo_amd import Cosmology, CosmologyInputError
+    g = golden('cosmology_api')
+    cosmo = Cosmology(omega_cdm=0.2)
+    for base, ref in [('internal', g['clone_internal']), ('input', g['clone_input'])]:
+        clone = cosmo.clone(base=base, h=cosmo['h'] * 1.1)
+        np.testing.assert_allclose([clone['Omega_m'], clone['Omega_cdm'], clone['omega_cdm']], ref, rtol=1e-13)
+    assert cosmo.clone(base=None, h=0.6)['Omega_cdm'] == cosmo['Omega_cdm']
+    with pytest.raises(CosmologyInputError):
+        cosmo.clone(base='other')
+    with pytest.raises(CosmologyInputError):
+        cosmo.clone(h=0.6, H0=60.)
+    assert cosmo.clone(sigma8=0.9)['sigma8'] == 0.9 and 'A_s' not in cosmo.clone(sigma8=0.9).get_params()
+    assert 'sigma8' not in cosmo.clone(A_s=2e-9).get_params()                # a new name removes what it excludes
+    assert cosmo == cosmo.clone() and cosmo != cosmo.clone(h=0.6) and cosmo != 1
+    m_ncdm = [0.01, 0.02, 0.05]
+    cosmo = Cosmology(m_ncdm=m_ncdm, Omega_m=np.array([0.3, 0.31]))
+    for name in ['cosmo.json', 'sub/cosmo.npy']:
+        fn = str(tmp_path / name)
+        cosmo.write(fn)
+        back = Cosmology.read(fn)
+        assert back == cosmo and np.allclose(back['m_ncdm'], m_ncdm) and back.engine is None and back.batch_size == 2
+    with pytest.warns(DeprecationWarning):
+        cosmo.save(str(tmp_path / 'old.npy'))
+    with pytest.warns(DeprecationWarning):
+        assert Cosmology.load(str(tmp_path / 'old.npy')) == cosmo
+    with pytest.raises(AttributeError):
+        cosmo.comoving_radial_distance
+    assert 'tau_reio' not in dir(cosmo) and 'comoving_radial_distance' not in dir(cosmo)

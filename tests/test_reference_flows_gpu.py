@@ -347,3 +347,80 @@ def test_fftlog_flows(cp):
     r2, sigmar2 = cp.TophatVariance(k, lowring=True)(pk)
     assert np.allclose(np.sqrt(interpolate.CubicSpline(r2, sigmar2)(r)), sigmar_ref, rtol=1e-5)
     assert np.allclose(pk_interp.sigma_r(r), sigmar_ref, rtol=1e-5)
+
+
+def test_cosmology_engine_clone_shortcut(cp, tmp_path):
+    """reference tests/test_cosmology.py::test_engine, test_clone, test_shortcut, test_params (engine part) with this package's engines."""
+    from cosmoprimo_amd import Cosmology, Background, Fourier
+    warnings.simplefilter('ignore')
+    cosmo = Cosmology(engine='eisenstein_hu')
+    cosmo.set_engine(engine='bbks')
+    cosmo.set_engine(engine=cosmo.engine)
+    ba = Background(cosmo)
+    assert ba._engine is cosmo.engine and ba.engine is cosmo.engine
+    ba = cosmo.get_background(engine='eisenstein_hu', set_engine=False)
+    ba = Background(cosmo, engine='eisenstein_hu', set_engine=False)
+    assert cosmo.engine is not ba._engine and cosmo.engine.name == 'bbks'
+    assert type(cosmo.get_background()) is type(cosmo.get_background(engine='eisenstein_hu'))
+    assert cosmo.engine.name == 'eisenstein_hu'
+
+    cosmo = Cosmology(omega_cdm=0.2, engine='eisenstein_hu')
+    engine = cosmo.engine
+    for factor in [1., 1.1]:
+        clone = cosmo.clone(omega_cdm=cosmo['omega_cdm'] * factor)
+        assert type(clone.engine) == type(engine) and clone.engine is not engine
+        z = np.linspace(0.5, 2., 100)
+        same = np.allclose(clone.get_background().comoving_radial_distance(z), cosmo.get_background().comoving_radial_distance(z))
+        assert same == (factor == 1)
+        clone = cosmo.clone(base='internal', sigma8=cosmo.sigma8_m * factor)
+        assert np.allclose(clone.get_fourier().sigma_rz(8, 0, of='delta_m'), cosmo.sigma8_m * factor, rtol=1e-4)
+        clone = cosmo.clone(base='internal', h=cosmo.h * factor)
+        assert np.allclose(clone.Omega0_m, cosmo.Omega0_m)
+        clone = cosmo.clone(base='input', h=cosmo.h * factor)
+        assert np.allclose(clone.Omega0_cdm, cosmo.Omega0_cdm / factor**2)
+
+    cosmo = Cosmology()
+    z = [0.1, 0.3]
+    with pytest.raises(AttributeError):
+        cosmo.comoving_radial_distance(z)
+    assert 'rs_drag' not in dir(cosmo)
+    cosmo.set_engine('eisenstein_hu')
+    assert 'rs_drag' in dir(cosmo) and 'comoving_radial_distance' in dir(cosmo) and 'Omega0_m' in dir(cosmo)
+    assert 'pk_interpolator' not in dir(cosmo)       # offered by two sections (primordial, fourier): rejected as ambiguous, as in the reference
+    assert 'pk_interpolator' in dir(Fourier(cosmo))
+    with pytest.raises(AttributeError):
+        cosmo.pk_interpolator
+    assert np.all(cosmo.comoving_radial_distance(z) == cosmo.get_background().comoving_radial_distance(z))
+    assert cosmo.rs_drag == cosmo.get_thermodynamics().rs_drag and cosmo.n_s == 0.96 and cosmo.h == 0.7
+    assert abs(cosmo.Omega0_r / 8.535876457678869e-05 - 1.) < 1e-12          # Omega0_r of the reference's default cosmology
+
+    cosmo = Cosmology(m_ncdm=[0.01, 0.02, 0.05], engine='eisenstein_hu_nowiggle_variants', Omega_m=np.array([0.3, 0.31]))
+    fn = str(tmp_path / 'cosmo.json')
+    cosmo.write(fn)
+    back = Cosmology.read(fn)
+    assert back == cosmo and back.engine.name == 'eisenstein_hu_nowiggle_variants'
+    assert np.array_equal(back.get_background().comoving_radial_distance(1.), cosmo.get_background().comoving_radial_distance(1.))
+
+
+def test_solve(cp, golden):
+    """reference test_bisect: h matching 100 theta_MC (CosmoMC's approximate sound-horizon angle), found to the tolerance asked for."""
+    from cosmoprimo_amd import Cosmology, CosmologyInputError
+    from cosmoprimo_amd.fiducial import DESI
+    warnings.simplefilter('ignore')
+    g = golden('cosmology_api')
+    solved = Cosmology(engine='eisenstein_hu').solve('h', 'theta_MC_100', 1.04092)
+    assert abs(solved['h'] - g['solve_h_theta_MC_100']) < 2e-6               # xtol = 1e-6 on both sides
+    assert abs(solved['theta_MC_100'] - 1.04092) < 5e-6 and solved.engine.name == 'eisenstein_hu'
+    solved = Cosmology(engine='eisenstein_hu').solve('H0', 'theta_MC_100', 1.04092, xtol=1e-4)
+    assert abs(solved['H0'] - 100. * g['solve_h_theta_MC_100']) < 2e-4
+    solved = DESI().solve('h', lambda cosmo: 100. * cosmo['theta_cosmomc'], target=1.04, limits=[0.6, 0.9], xtol=1e-6)
+    assert abs(solved['h'] - g['solve_h_desi']) < 2e-6
+    assert abs(solved['omega_cdm'] - 0.12) < 1e-15                           # base='input': physical densities kept
+    solved = Cosmology(engine='eisenstein_hu').solve('Omega_m', lambda cosmo: cosmo.get_background().comoving_radial_distance(1.), target=2300., init=(0.3, 0.05))
+    assert abs(solved.get_background().comoving_radial_distance(1.) - 2300.) < 1e-2
+    with pytest.raises(CosmologyInputError):
+        Cosmology(engine='eisenstein_hu').solve('h', 'theta_MC_100', 1.04092, limits=[0.3, 0.4])
+    with pytest.raises(CosmologyInputError):
+        Cosmology(engine='eisenstein_hu').solve('h', None)
+    with pytest.raises(ValueError):
+        Cosmology(engine='eisenstein_hu').solve('n_s', 'theta_MC_100', 1.04)
