@@ -843,8 +843,8 @@ class BaseSection(object):
     """Base section (reference cosmology.py:1480-1540)."""
 
     def __init__(self, engine):
-        self._engine = engine
-        self.device = engine.device
+        self._engine = engine    # an engine, or (DefaultBackground only, as in the reference's tests) a Cosmology without one
+        self.device = engine.device if hasattr(engine, 'device') else dv.resolve_device(getattr(engine, '_device', None), *engine._params.values())
         self._h = engine['h']
 
     @property

@@ -402,6 +402,23 @@ def test_cosmology_engine_clone_shortcut(cp, tmp_path):
     assert np.array_equal(back.get_background().comoving_radial_distance(1.), cosmo.get_background().comoving_radial_distance(1.))
 
 
+def test_default_background_without_engine(cp):
+    """reference test_default_background: ``DefaultBackground(cosmo)`` on a cosmology that has no engine."""
+    from cosmoprimo_amd.cosmology import DefaultBackground
+    from cosmoprimo_amd.fiducial import DESI
+    warnings.simplefilter('ignore')
+    z = np.linspace(0., 10., 100)
+    for params in [{'m_ncdm': 0.4}, {'m_ncdm': 0.4, 'w0_fld': -0.6, 'wa_fld': -1.}, {'m_ncdm': 5., 'w0_fld': -0.8, 'wa_fld': -0.5}]:
+        cosmo = DESI(**params, engine=None)
+        assert cosmo.engine is None
+        ba, ba_engine = DefaultBackground(cosmo), DESI(**params).get_background()
+        for name in ['time', 'comoving_radial_distance', 'Omega_ncdm', 'efunc']:
+            assert np.array_equal(getattr(ba, name)(z), getattr(ba_engine, name)(z)), name
+        growth = ba.growth_factor(z, mass='cb')
+        assert growth[0] == 1. and np.all(np.diff(growth) < 0.) and np.all(np.isfinite(ba.growth_rate(z)))
+        assert abs(DESI(**params, engine='bbks')['theta_cosmomc'] / DESI(**params)['theta_cosmomc'] - 1.) < 1e-12
+
+
 def test_solve(cp, golden):
     """reference test_bisect: h matching 100 theta_MC (CosmoMC's approximate sound-horizon angle), found to the tolerance asked for."""
     from cosmoprimo_amd import Cosmology, CosmologyInputError
