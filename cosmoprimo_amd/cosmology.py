@@ -963,12 +963,14 @@ class BaseBackground(BaseSection):
 
     # massive neutrinos: interpolated tables as DefaultBackground (cosmology.py:1961-1998); identically zero without massive species
     def _per_species(self, kind, z, species, scale=1.):
-        if species is not None:
-            return self._eval(kind, z, species=species) * scale if self._N_ncdm else self._zeros_like(z)
-        if not self._N_ncdm:
+        """One species (int): z.shape; several (None = all, or a sequence of indices): (nspecies,) + z.shape."""
+        if species is not None and np.ndim(species) == 0:
+            return self._eval(kind, z, species=int(species)) * scale if self._N_ncdm else self._zeros_like(z)
+        species = list(range(self._N_ncdm)) if species is None else [int(s) for s in species]
+        if not species:
             first = self._zeros_like(z)
             return np.zeros((0,) + tuple(first.shape), dtype=first.dtype) if not dv.is_torch(first) else first.new_zeros((0,) + tuple(first.shape))
-        vals = [self._eval(kind, z, species=s) * scale for s in range(self._N_ncdm)]
+        vals = [self._eval(kind, z, species=s) * scale for s in species]
         return dv.torch().stack(vals) if dv.is_torch(vals[0]) else np.stack(vals)
 
     def _ncdm_tot(self, kind, z, scale=1.):
@@ -1010,9 +1012,12 @@ class BaseBackground(BaseSection):
         """Temperature of the massive neutrinos, K: (N_ncdm,) + z.shape, or one species (cosmology.py:1766-1772)."""
         zp1 = self._eval('T_cmb', z) / self._T0_cmb
         T0 = np.asarray(self._T0_ncdm, dtype='f8')
-        if species is not None:
-            return zp1 * T0[species]
-        return T0.reshape((-1,) + (1,) * np.ndim(zp1)) * zp1
+        if species is not None and np.ndim(species) == 0:
+            return zp1 * float(T0[species])
+        T0 = T0 if species is None else T0[[int(s) for s in species]]
+        if dv.is_torch(zp1):
+            return dv.torch().as_tensor(T0, device=zp1.device, dtype=zp1.dtype).reshape((-1,) + (1,) * zp1.ndim) * zp1
+        return T0.astype(zp1.dtype).reshape((-1,) + (1,) * np.ndim(zp1)) * zp1
 
     def comoving_radial_distance(self, z):
         """Comoving radial distance, in Mpc/h (cosmology.py:2027-2042)."""

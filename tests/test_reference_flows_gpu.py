@@ -441,3 +441,64 @@ def test_solve(cp, golden):
         Cosmology(engine='eisenstein_hu').solve('h', None)
     with pytest.raises(ValueError):
         Cosmology(engine='eisenstein_hu').solve('n_s', 'theta_MC_100', 1.04)
+
+
+LIST_PARAMS = [{}, {'sigma8': 1., 'non_linear': 'mead'}, {'logA': 3., 'non_linear': 'mead'}, {'A_s': 2e-9, 'alpha_s': -0.2}, {'lensing': True},
+               {'m_ncdm': 0.1, 'neutrino_hierarchy': 'normal'}, {'Omega_k': 0.1}, {'w0_fld': -0.9, 'wa_fld': 0.1, 'cs2_fld': 0.9},
+               {'w0_fld': -1.1, 'wa_fld': 0.2}]      # reference tests/test_cosmology.py:60-63
+
+
+@pytest.mark.parametrize('params', LIST_PARAMS)
+def test_background_contracts(cp, params):
+    """reference test_background: today's quantities against the parameters, and the shape / dtype / species contract of every method,
+    for every engine of this package (the reference compares engines with each other; values are pinned by the golden tests)."""
+    from cosmoprimo_amd import Cosmology
+    warnings.simplefilter('ignore')
+    rng = np.random.RandomState(seed=42)
+    cosmo = Cosmology(**params)
+    ba_ref = None
+    for engine in ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'eisenstein_hu_nowiggle_variants', 'bbks']:
+        ba = cosmo.get_background(engine=engine)
+        for name in ['T0_cmb', 'T0_ncdm', 'Omega0_cdm', 'Omega0_b', 'Omega0_k', 'Omega0_g', 'Omega0_ur', 'Omega0_r', 'Omega0_pncdm', 'Omega0_pncdm_tot',
+                     'Omega0_ncdm', 'Omega0_ncdm_tot', 'Omega0_m', 'Omega0_Lambda', 'Omega0_fld', 'Omega0_de']:
+            assert np.allclose(getattr(ba, name), cosmo[name.replace('0', '')], atol=0, rtol=1e-3), name
+            assert np.allclose(getattr(ba, name), getattr(ba, name.replace('0', ''))(0.), atol=0, rtol=1e-3), name
+        for name in ['H0', 'h', 'N_ur', 'N_ncdm', 'm_ncdm', 'm_ncdm_tot', 'N_eff', 'w0_fld', 'wa_fld', 'cs2_fld', 'K']:
+            assert np.allclose(getattr(ba, name), cosmo[name], atol=1e-9, rtol=1e-8 if name not in ['N_eff'] else 1e-4), name
+
+        def check(name):
+            test = getattr(ba, name)
+            has_species = name.endswith('ncdm')
+            shape = (cosmo['N_ncdm'], ) if has_species else ()
+            z = rng.uniform(0., 3., 30)
+            if ba_ref is not None:     # the engines share the background kernels
+                assert np.allclose(test(z=z), getattr(ba_ref, name)(z), atol=0, rtol=1e-12), name
+            assert np.all(np.isfinite(test(z=z)))
+            assert test(0.).shape == shape, (name, test(0.).shape)
+            assert test([]).shape == shape + (0, ), name
+            z = np.array(0.)
+            assert test(z).dtype.itemsize == z.dtype.itemsize
+            z = np.array([0., 1.])
+            assert test(z).shape == shape + z.shape
+            z = np.array([[0., 1.]] * 4, dtype='f4')
+            assert test(z).shape == shape + z.shape
+            assert test(z).dtype.itemsize == z.dtype.itemsize, name
+            if has_species and cosmo['N_ncdm']:
+                assert test(0., species=0).shape == ()
+                assert test([], species=0).shape == (0, )
+                assert test([0., 1.], species=0).shape == (2, )
+                assert test([0., 1.], species=[0]).shape == (1, 2, )
+
+        names = ['T_cmb', 'T_ncdm', 'rho_crit', 'p_ncdm', 'p_ncdm_tot', 'Omega_pncdm', 'Omega_pncdm_tot', 'efunc', 'hubble_function', 'time',
+                 'comoving_radial_distance', 'luminosity_distance', 'angular_diameter_distance', 'comoving_angular_distance']
+        names += ['{}_{}'.format(density, species) for density in ['rho', 'Omega']
+                  for species in ['cdm', 'b', 'k', 'g', 'ur', 'r', 'ncdm', 'ncdm_tot', 'm', 'Lambda', 'fld', 'de']]
+        for name in names:
+            check(name)
+        if ba_ref is None:
+            ba_ref = ba
+        for name in ['growth_factor', 'growth_rate']:
+            test = getattr(ba, name)
+            assert test(0.).shape == () and test([]).shape == (0, ) and test(np.array([[0., 1.]] * 4, dtype='f4')).shape == (4, 2)
+        z1, z2 = rng.uniform(0., 1., 10), rng.uniform(0., 1., 10)
+        assert ba.angular_diameter_distance_2(z1, z2).shape == (10,) and np.ndim(ba.age) == 0 and np.ndim(ba.K) == 0
