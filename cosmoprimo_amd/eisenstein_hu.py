@@ -93,7 +93,7 @@ class Primordial(BaseSection):
         r"""Primordial spectrum of curvature perturbations at ``k`` [h/Mpc], in (Mpc/h)^3 (eisenstein_hu.py:189-215)."""
         ['scalar'].index(mode)
         kh = _host(k)
-        out = pwmod.analytic(self._engine._transfer, 'primordial', kh.ravel(), bg=self._engine.bg_params(), pk=self._engine.pk_params(), device=self.device)
+        out = pwmod.analytic(getattr(self._engine, '_transfer', 'eisenstein_hu'), 'primordial', kh.ravel(), bg=self._engine.bg_params(), pk=self._engine.pk_params(), device=self.device)
         return _out(out.reshape(out.shape[:-1] + kh.shape), k)
 
     def pk_interpolator(self, mode='scalar'):
