@@ -630,23 +630,23 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             return False
         return self.is_from_callable or self._pk.shape[1] == 1
 
-    def _sigma2_separable(self, integrate, zh):
+    def _sigma_separable(self, integrate, zh):
         """sigma^2(..., z) = growth_factor_sq(z) x sigma^2 of the z-independent spectrum: the k integral is linear in P, so ONE transform
-        per cosmology replaces one per (cosmology, z) -- same numbers as the reference's per-z integrals to rounding.  Returns
-        (batch..., nz, n) like the per-z path."""
+        per cosmology replaces one per (cosmology, z) -- same numbers as the reference's per-z integrals to rounding.  Returns the two
+        square roots, (batch..., n) and (batch..., nz) (NaN outside the redshift range), for the caller to multiply out in the layout
+        it returns: the (batch, n, nz) result is then written once instead of being multiplied, masked, rooted and transposed in four passes."""
         torch = dv.torch()
         z0 = np.array([self.z[0]])                                 # any redshift inside the table: the growth factor is left out
 
         def rows(kh):
             return self._eval_device(kh, z0, grid=True, ignore_growth=True).transpose(-1, -2).contiguous()      # (batch..., 1, nk)
 
-        base = integrate(rows)                                     # (batch..., 1, n)
+        base = integrate(rows)[..., 0, :]                          # (batch..., n)
         growth = dv.to_device(self.growth_factor_sq(zh), self.device)          # (batch..., nz)
-        out = base * growth[..., :, None]
         if self.is_from_callable:                                  # NaN outside the redshift range (tabulated single columns ignore z)
             _, mask_z = _mask_bounds([z0, zh], [(self.zmin, self.zmax)] * 2)
-            out = torch.where(torch.as_tensor(mask_z, device=self.device)[:, None], out, torch.full_like(out, float('nan')))
-        return out
+            growth = torch.where(torch.as_tensor(mask_z, device=self.device), growth, torch.full_like(growth, float('nan')))
+        return base.sqrt(), growth.sqrt()
 
     def sigma_dz(self, z, **kwargs):
         r""":math:`\sigma_d(z) = \sqrt{\frac{1}{6\pi^2}\int dk P(k, z)}` (reference interpolator.py:819-844); shape (batch...) + z.shape."""
@@ -654,8 +654,9 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         dtype = dv.float_dtype(z)
         zh = _host(z)
         if self._separable():
-            out = self._sigma2_separable(lambda rows: integrate_sigma_d2(rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
-                                                                         **kwargs)[..., None], zh.ravel())[..., 0]**0.5
+            base, growth = self._sigma_separable(lambda rows: integrate_sigma_d2(rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
+                                                                                 **kwargs)[..., None], zh.ravel())
+            out = base * growth                                    # (batch..., 1) x (batch..., nz)
         else:
             out = integrate_sigma_d2(self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
         return _finish(out, dtype, like_torch, tuple(out.shape[:-1]) + zh.shape)
@@ -669,11 +670,12 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         dtype = dv.float_dtype(r, z)
         rh, zh = _host(r), _host(z)
         if self._separable():
-            out = self._sigma2_separable(lambda rows: integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
-                                                                         **kwargs), zh.ravel())**0.5
+            base, growth = self._sigma_separable(lambda rows: integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
+                                                                                 **kwargs), zh.ravel())
+            out = base[..., :, None] * growth[..., None, :]        # (batch..., nr, nz), written once
         else:
             out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
-        out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
+            out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
         return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
 
     def sigma8_z(self, z=0, **kwargs):
