@@ -122,14 +122,22 @@ struct Args {
     const double* z;  // (nz) shared (what == CP_PK_MATTER with nz > 0), else unused
     double* out;      // (ncosmo, max(nz, 1), nk)
     long long kchunks, kspan;  // a workgroup evaluates kspan consecutive k of ONE cosmology; kchunks = ceil(nk / kspan) workgroups per cosmology
+    const EhScalars* scal;     // (ncosmo) fit coefficients from coefficients_kernel (EH98 / no-wiggle transfer), else unused
 };
 
-// One workgroup = one cosmology x kspan wavenumbers.  Everything that depends on the cosmology alone -- the ~25 pow() of the EH98 fit
-// coefficients, growth(z)^2 of every output redshift -- is evaluated ONCE per workgroup (one lane for the coefficients, one lane per
-// redshift) and shared through LDS; the lanes then walk the wavenumbers with the per-k part only (9 transcendentals).  Evaluated per lane,
-// as the first version did, the coefficients were 3/4 of the kernel's time.
+// The ~25 pow() of the EH98 / no-wiggle fit coefficients depend on the cosmology alone: one lane per cosmology here, read back by
+// power_kernel through scalar loads.  (Evaluated in every (cosmology, k) lane, as the first version did, they were 3/4 of the time; evaluated
+// by one lane of each power_kernel workgroup they still were half of it for 1024 wavenumbers per cosmology, all on one SIMD of the CU.)
+__global__ __launch_bounds__(64) void coefficients_kernel(const Args A, EhScalars* out) {
+    const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ic >= A.ncosmo) return;
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
+    out[ic] = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
+}
+
+// One workgroup = one cosmology x kspan wavenumbers: growth(z)^2 of every output redshift is evaluated once per workgroup (one lane per
+// redshift) and shared through LDS; the lanes then walk the wavenumbers with the per-k part only (9 transcendentals for EH98).
 __global__ __launch_bounds__(256) void power_kernel(const Args A) {
-    __shared__ EhScalars sh_s;
     __shared__ double sh_g2[256];
     const int tid = threadIdx.x;
     const long long ic = blockIdx.x / A.kchunks;
@@ -139,7 +147,8 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
-    const bool eh = A.what != CP_PK_PRIMORDIAL && A.engine != CP_ENGINE_BBKS;
+    EhScalars s{};
+    if (A.scal) s = A.scal[ic];
     const bool with_z = A.what == CP_PK_MATTER && A.nz > 0;
     const long long nzs = with_z ? A.nz : 1;
     const double kfac = A.kscale ? A.kscale[ic] : 1.;
@@ -153,7 +162,6 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
             const double g = growth_cpt(c, A.z[z0 + tid]);  // growth_factor(z, znorm=0), eisenstein_hu.py:317
             sh_g2[tid] = g * g;
         }
-        if (z0 == 0 && eh && tid == 255) sh_s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
         __syncthreads();
         const int nzi = with_z ? (int)(A.nz - z0 < 256 ? A.nz - z0 : 256) : 1;
         for (long long ik = k0 + tid; ik < k1; ik += 256) {
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
                 if (A.engine == CP_ENGINE_BBKS)
                     T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
                 else
-                    T = A.engine == CP_ENGINE_EH ? transfer_eh(sh_s, c.h, kh) : transfer_nowiggle(sh_s, c.h, kh);
+                    T = A.engine == CP_ENGINE_EH ? transfer_eh(s, c.h, kh) : transfer_nowiggle(s, c.h, kh);
             }
             if (A.what == CP_PK_TRANSFER) {
                 out[0] = T;
@@ -383,6 +391,7 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     A.kscale = d_kscale;
     A.z = d_z;
     A.out = d_out;
+    A.scal = nullptr;
     // wavenumbers per workgroup: all of a cosmology's when the batch alone fills the chip (>= 8 workgroups per CU), fewer for small batches
     const long long block = 256;
     long long kiter = (nk + block - 1) / block;
@@ -393,8 +402,20 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
         if (prev >= 0) (void)hipSetDevice(prev);
         return cp::fail(CP_EUNSUPPORTED, "cp_power_eval: %lld cosmologies x %lld wavenumbers exceed one launch; split the batch", ncosmo, nk);
     }
-    hipLaunchKernelGGL(power_kernel, dim3((unsigned)(ncosmo * A.kchunks)), dim3((unsigned)block), 0, static_cast<hipStream_t>(stream), A);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    EhScalars* scal = nullptr;   // stream-ordered scratch: concurrent calls on other streams have their own
+    if (what != CP_PK_PRIMORDIAL && engine != CP_ENGINE_BBKS) {
+        if (hipMallocAsync(reinterpret_cast<void**>(&scal), sizeof(EhScalars) * (size_t)ncosmo, hs) != hipSuccess) {
+            (void)hipGetLastError();
+            if (prev >= 0) (void)hipSetDevice(prev);
+            return cp::fail(CP_ENOMEM, "cp_power_eval: cannot allocate the fit coefficients of %lld cosmologies", ncosmo);
+        }
+        A.scal = scal;
+        hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, hs, A, scal);
+    }
+    hipLaunchKernelGGL(power_kernel, dim3((unsigned)(ncosmo * A.kchunks)), dim3((unsigned)block), 0, hs, A);
     hipError_t e = hipGetLastError();
+    if (scal) (void)hipFreeAsync(scal, hs);
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval: launch failed: %s", hipGetErrorString(e));
     return CP_OK;

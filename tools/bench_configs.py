@@ -27,9 +27,46 @@ def timed(fn, reps, torch):
     return (time.perf_counter() - t0) / reps
 
 
+def cpu_config3(par, r, z, n):
+    """The reference's path for one cosmology at a time (numpy port, oracle/): P(k, z) = P(k) growth^2(z) on 64 redshifts -> 64 FFTLogs
+    (TophatVariance) -> natural spline to r -> sqrt; seconds per cosmology on one core."""
+    from oracle import background as ob, power as op, sigma as osig
+    t0 = time.perf_counter()
+    for i in range(n):
+        Om, Ob, h, ns = (float(par[name][i]) for name in ('Omega_m', 'Omega_b', 'h', 'n_s'))
+        bg = ob.derived(h=h, Omega_b=Ob, Omega_m=Om)
+        g2 = op.growth_factor(z, bg, znorm=0.)**2
+        osig.sigma_r2(r, lambda k: op.pk_z0(k, 'eisenstein_hu', h=h, Omega_cdm=Om - Ob, Omega_b=Ob, n_s=ns)[:, None] * g2[None, :])**0.5
+    return (time.perf_counter() - t0) / n
+
+
+def cpu_config4(par, n):
+    """wallish2018 of the numpy port for one P(k) vector at a time; seconds per vector on one core."""
+    from oracle import bao as obao, power as op
+    t0 = time.perf_counter()
+    for i in range(n):
+        Om, Ob, h, ns = (float(par[name][i]) for name in ('Omega_m', 'Omega_b', 'h', 'n_s'))
+        obao.wallish2018(lambda k: op.pk_z0(k, 'eisenstein_hu', h=h, Omega_cdm=Om - Ob, Omega_b=Ob, n_s=ns)[:, None])
+    return (time.perf_counter() - t0) / n
+
+
+def cpu_config5(om, w0, wa, zz, n):
+    """comoving_radial_distance of the numpy port, one fresh cosmology (119-knot table + natural spline) per sample; seconds per sample."""
+    from oracle import background as ob
+    t0 = time.perf_counter()
+    for i in range(n):
+        ob.comoving_radial_distance(np.array([zz[i]]), ob.derived(Omega_m=om[i], w0_fld=w0[i], wa_fld=wa[i]))
+    return (time.perf_counter() - t0) / n
+
+
+def baseline(seconds_per_unit, unit, sample):
+    return {'value': 1. / seconds_per_unit, 'unit': unit, 'cores': 1, 'kind': 'port', 'sample': sample}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scale', type=float, default=1.)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
     import torch
     import cosmoprimo_amd as cp
@@ -53,7 +90,8 @@ def main():
     out_bytes = nb * 256 * 64 * 8
     print(json.dumps({'config': 3, 'workload': 'sigma_rz 256 r x 64 z, %d EH cosmologies (method fftlog, nk=1024; P(k, z) = P(k) x growth(z): one FFTLog per cosmology, growth applied to sigma^2)' % nb,
                       'value': nb / dt, 'unit': 'cosmologies/s', 'ms': dt * 1e3, 'setup_incl_sigma8_normalisation_ms': t_setup * 1e3,
-                      'algorithmic_GBps': (out_bytes + nb * 80) / dt / 1e9}))
+                      'algorithmic_GBps': (out_bytes + nb * 80) / dt / 1e9,
+                      'cpu_baseline': None if args.no_cpu_baseline else baseline(cpu_config3(par, r, z, 8), 'cosmologies/s', '8 cosmologies, one at a time')}))
     del interp, cosmo
     torch.cuda.empty_cache()
 
@@ -80,7 +118,8 @@ def main():
     dt = time.perf_counter() - t0
     print(json.dumps({'config': 4, 'filter': 'wallish2018',
                       'workload': 'wallish2018 on %d EH98 P(k) vectors (nk=1024), incl. P(k) generation + sigma8 normalisation + D2H of pknow' % nb,
-                      'value': done / dt, 'unit': 'vectors/s', 'ms': dt * 1e3, 'algorithmic_GBps': done * 16384 / dt / 1e9}))
+                      'value': done / dt, 'unit': 'vectors/s', 'ms': dt * 1e3, 'algorithmic_GBps': done * 16384 / dt / 1e9,
+                      'cpu_baseline': None if args.no_cpu_baseline else baseline(cpu_config4(par, 32), 'vectors/s', '32 vectors, one at a time, P(k) generation included')}))
     fid = cp.Cosmology(engine='eisenstein_hu')
     one_chunk(slice(0, min(nb, chunk)), 'brieden2022', cosmo_fid=fid)
     torch.cuda.synchronize()
@@ -98,12 +137,13 @@ def main():
     # config 5 (one GPU's share of 10M samples): comoving_radial_distance for (Omega_m, w0, wa, z) samples
     nb = int(1250000 * args.scale)
     rng = np.random.default_rng(3)
-    om, w0, wa, zz = (torch.as_tensor(v, device=dev) for v in (rng.uniform(0.1, 0.5, nb), rng.uniform(-1.5, -0.5, nb), rng.uniform(-1., 0.5, nb),
-                                                               rng.uniform(0., 3., nb)))
+    host5 = (rng.uniform(0.1, 0.5, nb), rng.uniform(-1.5, -0.5, nb), rng.uniform(-1., 0.5, nb), rng.uniform(0., 3., nb))
+    om, w0, wa, zz = (torch.as_tensor(v, device=dev) for v in host5)
     dt = timed(lambda: background.distance('comoving_radial_distance', zz[:, None], dict(w0_fld=w0, wa_fld=wa), Omega_m=om, per_cosmology_z=True), 5, torch)
     print(json.dumps({'config': 5, 'workload': 'comoving_radial_distance, %d (Omega_m, w0, wa, z) samples, one fresh cosmology per sample' % nb,
                       'value': nb / dt, 'unit': 'samples/s', 'ms': dt * 1e3, 'algorithmic_GBps': nb * 40 / dt / 1e9,
-                      'E_evaluations_per_s': nb * 237 / dt}))
+                      'E_evaluations_per_s': nb * 237 / dt,
+                      'cpu_baseline': None if args.no_cpu_baseline else baseline(cpu_config5(*host5, 2000), 'samples/s', '2000 samples, one cosmology each')}))
 
     # f4: the batch driver (emulators.get_calculator): params -> every section's arrays on the reference's default grids, D2H included
     from cosmoprimo_amd.emulators import get_calculator
