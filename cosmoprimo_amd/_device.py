@@ -63,6 +63,20 @@ def to_host(x):
     return x.cpu().numpy()
 
 
+def screen_rows(x, require_positive=False, with_scale=False):
+    """One pass over the rows of the contiguous device tensor ``x`` (..., n) (``cp_rows_screen``): ``ok`` (..., 1) bool, False for rows
+    holding a NaN / Inf (or a value <= 0 with ``require_positive``), and -- ``with_scale`` -- the power of two >= max |row| (..., 1)."""
+    t = torch()
+    n = x.shape[-1]
+    nrows = x.numel() // n if n else 0
+    ok = t.empty(tuple(x.shape[:-1]) + (1,), dtype=t.uint8, device=x.device)
+    scale = t.empty(tuple(x.shape[:-1]) + (1,), dtype=t.float64, device=x.device) if with_scale else None
+    _lib.check(_lib.load().cp_rows_screen(x.data_ptr(), nrows, n, int(bool(require_positive)), ok.data_ptr(), scale.data_ptr() if with_scale else None,
+                                          x.device.index, stream_of(x.device)))
+    ok = ok.to(t.bool)
+    return (ok, scale) if with_scale else ok
+
+
 def stream_of(device):
     return torch().cuda.current_stream(device).cuda_stream
 

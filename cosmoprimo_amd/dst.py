@@ -35,9 +35,7 @@ class DST(object):
         # spread its NaN to its partner, which scipy's row-by-row transform does not do; such rows go in as a harmless constant and come out NaN
         ok = None
         if nrows:
-            ok = torch.isfinite(x).all(dim=-1, keepdim=True)
-            if fused and not inverse:
-                ok = ok & (x > 0.).all(dim=-1, keepdim=True)
+            ok = dv.screen_rows(x, require_positive=fused and not inverse)
             if bool(ok.all()):
                 ok = None
             else:

@@ -368,20 +368,20 @@ class FFTlog(object):
         # Two rows share one complex transform in the kernel, so a NaN / Inf in one row would spread to its pair partner, which the
         # reference's row-by-row FFTs do not do: such rows are transformed as zeros and filled with NaN afterwards (all of numpy's output
         # for them is NaN as well).  One pass over the input and one host read of a flag; the C ABI itself leaves this to its caller.
-        finite = None
+        finite, scale = None, None
+        if self._rescale_rows and ((cl == 0 and vl != 0.) or (cr == 0 and vr != 0.)):
+            raise ValueError('rescale_rows cannot be combined with a non-zero constant padding value')
         if tin.numel():
-            finite = torch.isfinite(tin).all(dim=-1, keepdim=True)
+            if self._rescale_rows:
+                finite, scale = dv.screen_rows(tin, with_scale=True)                  # 2^e >= max|row| (1 for an all-zero row)
+            else:
+                finite = dv.screen_rows(tin)
             if bool(finite.all()):
                 finite = None
             else:
                 tin = torch.where(finite, tin, torch.zeros_like(tin))
-        scale = None
-        if self._rescale_rows and tin.numel():
-            if (cl == 0 and vl != 0.) or (cr == 0 and vr != 0.):
-                raise ValueError('rescale_rows cannot be combined with a non-zero constant padding value')
-            _, expo = torch.frexp(tin.abs().amax(dim=-1, keepdim=True))
-            scale = torch.ldexp(torch.ones_like(expo, dtype=torch.float64), expo)     # 2^e >= max|row| (1 for an all-zero row)
-            tin = tin / scale
+            if scale is not None:
+                tin = tin / scale
         nbatch = 1
         for s in bshape[:-2] if nker > 1 else bshape[:-1]:
             nbatch *= s

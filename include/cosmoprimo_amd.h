@@ -234,6 +234,12 @@ int cp_dst_plan_create(cp_dst_plan** plan, int n, const double* kx, int device);
 int cp_dst_execute(const cp_dst_plan* plan, const double* d_in, double* d_out, long long nrows, int inverse, int fused, void* stream);
 int cp_dst_plan_destroy(cp_dst_plan* plan);
 
+/* ---- row screening for the callers of cp_fftlog_execute / cp_dst_execute (two rows share one complex FFT there, so a non-finite row
+ *      would reach its pair partner, unlike the reference's row-by-row numpy.fft / scipy.fftpack calls, fftlog.py:540-560) ----
+ * d_x : (nrows, n) device.  d_ok[row] = 1 if every entry of the row is finite (and > 0 if require_positive: the fused log map of
+ * cp_dst_execute), else 0.  d_scale : optional (nrows) device, 2^e >= max |row| with e <= 1023 (1 for all-zero and non-finite rows), or NULL. */
+int cp_rows_screen(const double* d_x, long long nrows, long long n, int require_positive, unsigned char* d_ok, double* d_scale, int device, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

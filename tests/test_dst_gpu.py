@@ -48,3 +48,37 @@ def test_nonfinite_rows_stay_isolated():
     assert np.isnan(out[2]).all()
     for i in (0, 1, 3):
         np.testing.assert_allclose(out[i], fftpack.dst(np.log(kx * x[i]), type=2, norm='ortho'), rtol=1e-10, atol=1e-11)
+
+
+def test_rows_screen():
+    """cp_rows_screen (the one-pass row check the FFTLog / DST facades run before a paired transform) against the torch expressions it replaced."""
+    import torch
+    from cosmoprimo_amd import _device as dv
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(5)
+    for n in (1, 63, 256, 1000, 4096):
+        x = rng.standard_normal((37, n)) * 10.**rng.uniform(-300, 300, (37, 1))
+        x[3, n // 2] = np.nan
+        x[5, 0] = np.inf
+        x[7, n - 1] = -np.inf
+        x[11] = 0.
+        x[13] = np.abs(x[13]) + 1e-300
+        x[17] = 2.**-1074                      # subnormal
+        x[19] = np.nextafter(np.inf, 0.)       # largest finite value
+        t = torch.as_tensor(x, device=dev)
+        ok, scale = dv.screen_rows(t, with_scale=True)
+        finite = torch.isfinite(t).all(dim=-1, keepdim=True)
+        assert ok.shape == (37, 1) and torch.equal(ok, finite)
+        assert torch.equal(dv.screen_rows(t, require_positive=True), finite & (t > 0.).all(dim=-1, keepdim=True))
+        # 2^e >= max|row| with e from frexp, 1 for an all-zero row: an exact power of two (torch.ldexp, which the facade used before, goes
+        # through pow() and is one ulp off for some exponents, so that the "rescaling by powers of two" it stood for was not exact)
+        good = finite[:, 0].cpu().numpy()
+        amax = np.abs(x[good]).max(axis=1)
+        ref = np.ldexp(1., np.minimum(np.frexp(amax)[1], 1023))       # (2^1024 is not a double: the largest rows are scaled to < 2)
+        assert np.array_equal(scale.cpu().numpy()[good, 0], ref)
+        assert np.all(np.frexp(ref)[0] == 0.5) and np.all(ref >= amax / 2.) and np.all(ref[amax < 2.**1023] >= amax[amax < 2.**1023])
+    assert dv.screen_rows(torch.empty((0, 8), dtype=torch.float64, device=dev)).shape == (0, 1)
+    big = torch.as_tensor(rng.standard_normal((70000, 16)), device=dev)      # more rows than workgroups
+    big[69999, 3] = float('nan')
+    ok = dv.screen_rows(big)
+    assert bool(ok[:69999].all()) and not bool(ok[69999])
