@@ -5,7 +5,7 @@ from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolato
                            CorrelationFunctionInterpolator2D)
 from .cosmology import (Cosmology, Background, Thermodynamics, Primordial, Transfer, Fourier, CosmologyError, CosmologyInputError,
                         CosmologyComputationError)
-from . import eisenstein_hu, eisenstein_hu_nowiggle, eisenstein_hu_nowiggle_variants, bbks  # noqa: F401  (registers the engines)
+from . import eisenstein_hu, eisenstein_hu_nowiggle, eisenstein_hu_nowiggle_variants, bbks, tabulated  # noqa: F401  (registers the engines)
 from .bao_filter import PowerSpectrumBAOFilter, CorrelationFunctionBAOFilter
 from . import fiducial  # noqa: F401
 

@@ -48,6 +48,14 @@ def AbacusSummitBase(engine=_DEFAULT_ENGINE, precision=None, extra_params=None, 
 DESI = AbacusSummitBase
 
 
+def DESIDR2Flatw0waCDM(engine=_DEFAULT_ENGINE, precision=None, extra_params=None, **params):
+    """Best fit of flat w0waCDM to CMB + DESI DR2 BAO + DES-Y5 supernovae, arXiv:2503.14738 (reference fiducial.py:295-327): these values on
+    top of the AbacusSummit base cosmology."""
+    bestfit_params = {'Omega_m': 0.3191980194, 'omega_b': 0.02221485621, 'H0': 66.73428704, 'logA': 3.038847745, 'n_s': 0.9644215278,
+                      'tau_reio': 0.05271118001, 'w0_fld': -0.7536302620, 'wa_fld': -0.8574714585}
+    return AbacusSummit(engine=engine, precision=precision, extra_params=extra_params, **bestfit_params).clone(**params)
+
+
 def Uchuu(name='Planck2015', engine=_DEFAULT_ENGINE, extra_params=None, **params):
     """Cosmologies of the Uchuu simulations (reference fiducial.py:11-47)."""
     common = dict(Omega_k=0., m_ncdm=[0.06], neutrino_hierarchy=None, T_ncdm_over_cmb=TNCDM_OVER_CMB, N_eff=NEFF, A_L=1.0, k_pivot=0.05)
@@ -58,3 +66,40 @@ def Uchuu(name='Planck2015', engine=_DEFAULT_ENGINE, extra_params=None, **params
     if name not in table:
         raise NotImplementedError('Uchuu cosmology {} not implemented; available cosmologies are {}'.format(name, list(table)))
     return Cosmology(engine=engine, extra_params=extra_params, **table[name], **common).clone(**params)
+
+
+_desi_table = {}
+
+
+def _tabulate_DESI():
+    """(z, E(z), D_C(z) [Mpc/h]) of the DESI fiducial cosmology on the reference's grid, z = [0] + logspace(-8, 2, 40001) (fiducial.py:285-291).
+    E(z) comes from this package's background kernels (massive neutrino included); D_C(z) is the cumulated 8-point Gauss-Legendre integral of
+    c / (100 E) over every table interval -- not the 119-knot spline of ``comoving_radial_distance``, whose end condition costs 1e-3 below z = 0.1."""
+    import numpy as np
+    if not _desi_table:
+        ba = DESI().get_background()
+        z = np.concatenate([[0.], np.logspace(-8, 2, 40001)])
+        x, w = np.polynomial.legendre.leggauss(8)
+        lo, hi = z[:-1], z[1:]
+        nodes = 0.5 * (hi - lo)[:, None] * (x[None, :] + 1.) + lo[:, None]
+        integrand = 299792.458 / (100. * ba.efunc(nodes.ravel()).reshape(nodes.shape))
+        steps = 0.5 * (hi - lo) * (integrand * w[None, :]).sum(axis=1)
+        _desi_table.update(z=z, efunc=ba.efunc(z), comoving_radial_distance=np.concatenate([[0.], np.cumsum(steps)]))
+    return _desi_table
+
+
+def TabulatedDESI():
+    """
+    Tabulated DESI cosmology (reference fiducial.py:272-282): E(z) and D_C(z) interpolated linearly in a 40 002-row table over 0 <= z <= 100,
+    for whole catalogues of redshifts at once.  The reference ships the table as a data file computed with a Boltzmann code; here it is computed
+    on first use from :func:`DESI` (same parameters; E(z) within 2e-6 and D_C within 3e-6 of the reference's file, tests/test_fiducial_gpu.py).
+    """
+    return DESI(engine='tabulated', extra_params={'table': _tabulate_DESI()})
+
+
+def save_TabulatedDESI(filename):
+    """Write the table of :func:`TabulatedDESI` in the reference's file format (fiducial.py:285-291): readable by its 'tabulated' engine."""
+    import numpy as np
+    table = _tabulate_DESI()
+    header = 'z = [0] + np.logspace(-8, 2, 40001)\nz efunc(z) comoving_radial_distance(z) [Mpc/h]'
+    np.savetxt(filename, np.array([table['z'], table['efunc'], table['comoving_radial_distance']]).T, fmt='%.18e', header=header, comments='# ')

@@ -234,6 +234,11 @@ int cp_dst_plan_create(cp_dst_plan** plan, int n, const double* kx, int device);
 int cp_dst_execute(const cp_dst_plan* plan, const double* d_in, double* d_out, long long nrows, int inverse, int fused, void* stream);
 int cp_dst_plan_destroy(cp_dst_plan* plan);
 
+/* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
+ * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];
+ * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */
+int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const double* d_x, double* d_out, long long nx, int device, void* stream);
+
 /* ---- row screening for the callers of cp_fftlog_execute / cp_dst_execute (two rows share one complex FFT there, so a non-finite row
  *      would reach its pair partner, unlike the reference's row-by-row numpy.fft / scipy.fftpack calls, fftlog.py:540-560) ----
  * d_x : (nrows, n) device.  d_ok[row] = 1 if every entry of the row is finite (and > 0 if require_positive: the fused log map of

@@ -40,3 +40,59 @@ def test_desi_fiducial(golden):
     assert abs(DESI(h=0.7)['h'] - 0.7) < 1e-15
     with pytest.raises(NotImplementedError):
         AbacusSummit(name=1)
+    from cosmoprimo_amd.fiducial import DESIDR2Flatw0waCDM
+    dr2 = DESIDR2Flatw0waCDM()
+    assert abs(dr2['Omega_m'] - 0.3191980194) < 1e-12 and dr2['w0_fld'] == -0.7536302620 and abs(dr2['h'] - 0.6673428704) < 1e-15 and dr2['N_ncdm'] == 1
+    assert np.isfinite(dr2.comoving_radial_distance(1.))
+
+
+def test_tabulated(golden, tmp_path):
+    """The 'tabulated' engine (reference tabulated.py, tests/test_tabulated.py): bit-identical to numpy.interp on a table file; TabulatedDESI
+    against the reference's own table (161 of its rows, tests/golden/desi_table.npz)."""
+    import torch
+    from cosmoprimo_amd import Cosmology, CosmologyError
+    from cosmoprimo_amd.fiducial import DESI, TabulatedDESI, save_TabulatedDESI
+    warnings.simplefilter('ignore')
+    g = golden('desi_table')
+    fn = str(tmp_path / 'table.dat')
+    np.savetxt(fn, np.array([g['z'], g['efunc'], g['comoving_radial_distance']]).T, fmt='%.18e', header='z efunc comoving_radial_distance', comments='# ')
+    cosmo = DESI(engine='tabulated', extra_params={'filename': fn, 'names': ['efunc', 'comoving_radial_distance']})
+    table = np.loadtxt(fn, unpack=True)
+    rng = np.random.default_rng(3)
+    z = np.concatenate([10.**rng.uniform(-8, 2, 100000), table[0], [0., 100.], np.nextafter(table[0][1:], 0.), np.nextafter(table[0][:-1], 1e3)])
+    for name, column in [('efunc', table[1]), ('comoving_radial_distance', table[2])]:
+        out = getattr(cosmo.get_background(), name)(z)
+        assert np.array_equal(out, np.interp(z, table[0], column)), name          # same arithmetic as numpy.interp, bit for bit
+        assert getattr(cosmo, name)(0.5).shape == () and getattr(cosmo, name)(np.zeros((2, 3), dtype='f4')).dtype == np.float32
+    zt = torch.as_tensor(z, device='cuda:0')
+    out = cosmo.comoving_radial_distance(zt)
+    assert out.is_cuda and np.array_equal(out.cpu().numpy(), np.interp(z, table[0], table[2]))
+    for bad in (-1., 100.1, [0.5, 200.]):
+        with pytest.raises(CosmologyError):
+            cosmo.comoving_radial_distance(bad)
+    assert cosmo.comoving_radial_distance([]).shape == (0,)
+
+    tab = TabulatedDESI()                                             # reference test_tabulated.py::test_desi
+    fn = str(tmp_path / 'cosmo.json')
+    tab.write(fn)
+    back = Cosmology.read(fn)
+    assert np.allclose(back['omega_ncdm'], 0.0006442) and back['N_ncdm'] == 1 and back.engine.name == 'tabulated'
+    with pytest.raises(CosmologyError):
+        tab.comoving_radial_distance(-1)
+    rows = g['z'] <= 100.
+    assert np.allclose(tab.efunc(g['z'][rows]), g['efunc'][rows], rtol=2e-6, atol=0.)
+    # the reference's file (a Boltzmann code's own background table, interpolated) is off by up to 3e-5 below z = 1e-2: at z = 1e-8 it holds
+    # 2.99800696e-05 Mpc/h where c z / (100 km/s/Mpc) = 2.99792458e-05
+    dc, ref, zz = tab.comoving_radial_distance(g['z'][rows]), g['comoving_radial_distance'][rows], g['z'][rows]
+    assert np.allclose(dc[zz > 1e-2], ref[zz > 1e-2], rtol=3e-6, atol=0.) and np.allclose(dc, ref, rtol=5e-5, atol=1e-10)
+    assert abs(dc[1] / (299792.458 / 100. * 1e-8) - 1.) < 1e-7
+    z = np.linspace(0, 10, 100)
+    assert np.allclose(tab.comoving_radial_distance(z), DESI().comoving_radial_distance(z), rtol=2e-3, atol=1e-10)     # (the 119-knot spline below z = 0.1)
+    assert np.allclose(tab.comoving_radial_distance(z[2:]), DESI().comoving_radial_distance(z[2:]), rtol=3e-6)      # (the spline's own 1e-6)
+    z0, dz = np.linspace(0, 9.9, 100), 1e-6
+    dcdz = (tab.comoving_radial_distance(z0 + dz) - tab.comoving_radial_distance(z0)) / dz
+    assert np.allclose(dcdz, 299792.458 / (100. * tab.efunc(z0)), rtol=1e-2, atol=1e-10)
+    fn = str(tmp_path / 'desi.dat')
+    save_TabulatedDESI(fn)
+    again = DESI(engine='tabulated', extra_params={'filename': fn})
+    assert np.array_equal(again.comoving_radial_distance(z), tab.comoving_radial_distance(z)) and open(fn).readline().startswith('# z = [0] + np.logspace(-8, 2, 40001)')

@@ -145,6 +145,25 @@ def main():
                       'E_evaluations_per_s': nb * 237 / dt,
                       'cpu_baseline': None if args.no_cpu_baseline else baseline(cpu_config5(*host5, 2000), 'samples/s', '2000 samples, one cosmology each')}))
 
+    # tabulated engine: redshift -> comoving distance for a catalogue (fiducial.TabulatedDESI, linear interpolation in a 40 002-row table)
+    from cosmoprimo_amd.fiducial import TabulatedDESI
+    tab = TabulatedDESI()
+    nb = int(2e8 * args.scale)
+    zcat = torch.rand(nb, device=dev, dtype=torch.float64) * 3.
+    dt = timed(lambda: tab.comoving_radial_distance(zcat), 5, torch)
+    line = {'config': 'tabulated', 'workload': 'TabulatedDESI().comoving_radial_distance, %d redshifts resident in HBM (range check included)' % nb,
+            'value': nb / dt, 'unit': 'redshifts/s', 'ms': dt * 1e3, 'algorithmic_GBps': nb * 16 / dt / 1e9}
+    if not args.no_cpu_baseline:
+        table = tab.engine
+        zh = np.random.default_rng(5).uniform(0., 3., 2000000)
+        t0 = time.perf_counter()
+        np.interp(zh, table.z, table.comoving_radial_distance)
+        line['cpu_baseline'] = baseline((time.perf_counter() - t0) / zh.size, 'redshifts/s', 'numpy.interp, 2e6 redshifts (the reference\'s own call)')
+        line['cpu_baseline']['kind'] = 'reference'
+    print(json.dumps(line))
+    del zcat
+    torch.cuda.empty_cache()
+
     # f4: the batch driver (emulators.get_calculator): params -> every section's arrays on the reference's default grids, D2H included
     from cosmoprimo_amd.emulators import get_calculator
     nb = int(8192 * args.scale)
