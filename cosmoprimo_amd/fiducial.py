@@ -4,6 +4,8 @@ Fiducial cosmologies under the reference's names (cosmoprimo/fiducial.py): param
 'eisenstein_hu_nowiggle_variants', the analytic engine that handles the massive species these cosmologies have) instead of the reference's
 Boltzmann codes.
 """
+import os
+
 from .cosmology import Cosmology, TNCDM_OVER_CMB, NEFF
 
 _DEFAULT_ENGINE = 'eisenstein_hu_nowiggle_variants'
@@ -23,19 +25,49 @@ def BOSS(engine=_DEFAULT_ENGINE, extra_params=None, **params):
     return Cosmology(engine=engine, extra_params=extra_params, **default_params).clone(**params)
 
 
-# AbacusSummit c000 (https://github.com/abacusorg/AbacusSummit/tree/master/Cosmologies): Planck 2018 base_plikHM_TTTEEE_lowl_lowE_lensing mean
-_ABACUS_000 = dict(omega_b=0.02237, omega_cdm=0.1200, h=0.6736, A_s=2.0830e-9, n_s=0.9649, alpha_s=0.0, N_ur=2.0328, omega_ncdm=(0.00064420,),
-                   omega_k=0., tau_reio=0.0544, w0_fld=-1.0, wa_fld=0.0)
+_AbacusSummit_params_filename = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'abacus_cosmologies.json')
+
+
+def AbacusSummit_params(name=None, filename=_AbacusSummit_params_filename, params=None):
+    """
+    AbacusSummit cosmological parameters (https://github.com/abacusorg/AbacusSummit/tree/master/Cosmologies; reference fiducial.py:108-155):
+    the dictionary of cosmology ``name`` (e.g. ``0`` or ``'000'``), or the list for every cosmology; ``params``: the names to return, default
+    ['omega_b', 'omega_cdm', 'h', 'A_s', 'n_s', 'alpha_s', 'N_ur', 'omega_ncdm', 'omega_k', 'tau_reio', 'w0_fld', 'wa_fld'] ('root' is accepted).
+    The table is kept as JSON (``filename``), one entry per cosmology.
+    """
+    import json
+    import re
+    if name is not None and not isinstance(name, str):
+        name = '{:03d}'.format(name)
+    if params is None:
+        params = ['omega_b', 'omega_cdm', 'h', 'A_s', 'n_s', 'alpha_s', 'N_ur', 'omega_ncdm', 'omega_k', 'tau_reio', 'w0_fld', 'wa_fld']
+    default = {'tau_reio': 0.0544, 'omega_k': 0.}     # not in the table
+    with open(filename, 'r') as file:
+        table = json.load(file)
+    toret = []
+    for root, row in table.items():
+        tmp = {name_: value for name_, value in default.items() if name_ in params}      # these two come first, as in the reference
+        for param in params:
+            if param in default:
+                continue
+            value = root if param == 'root' else row[param]
+            tmp[param] = tuple(value) if isinstance(value, list) else value
+        if name is not None:
+            if re.match('[^0-9]*{}$'.format(name), root):
+                return tmp
+        else:
+            toret.append(tmp)
+    if name is not None:
+        raise ValueError('AbacusSummit cosmology {} not found'.format(name))
+    return toret
 
 
 def AbacusSummit(name=0, engine=_DEFAULT_ENGINE, precision=None, extra_params=None, **params):
-    """AbacusSummit cosmology ``name`` (reference fiducial.py:158-228); only the base cosmology c000 is tabulated here.  As in the
-    reference, ``N_ur`` is recast into ``N_eff`` so that later changes of the neutrino masses are continuous."""
-    if not isinstance(name, str):
-        name = '{:03d}'.format(name)
-    if name != '000':
-        raise NotImplementedError('AbacusSummit cosmology {} is not tabulated here (only the base cosmology 000)'.format(name))
-    cosmo = Cosmology(engine=engine, extra_params=extra_params, **_ABACUS_000)
+    """AbacusSummit cosmology ``name`` (reference fiducial.py:158-228).  As in the reference, ``N_ur`` is recast into ``N_eff`` so that later
+    changes of the neutrino masses are continuous.  ``precision`` (settings of the Boltzmann code there) is accepted and unused."""
+    default_params = dict(k_pivot=0.05, neutrino_hierarchy=None, T_ncdm_over_cmb=TNCDM_OVER_CMB, A_L=1.0)
+    default_params.update(AbacusSummit_params(name=name))
+    cosmo = Cosmology(engine=engine, extra_params=extra_params, **default_params)
     cosmo = cosmo.clone(base='input', N_eff=cosmo['N_eff'])
     return cosmo.clone(**params)
 

@@ -582,6 +582,33 @@ def gen_cosmology_api(cp):
     save('cosmology_api', **out)
 
 
+def gen_abacus_table(cp):
+    """The AbacusSummit cosmology table (https://github.com/abacusorg/AbacusSummit/tree/master/Cosmologies; the reference carries it as
+    data/abacus_cosmologies.csv) as read by the reference's ``AbacusSummit_params``: package data, cosmoprimo_amd/data/abacus_cosmologies.json."""
+    import json
+    from cosmoprimo.fiducial import AbacusSummit_params
+    names = ['root', 'omega_b', 'omega_cdm', 'h', 'A_s', 'n_s', 'alpha_s', 'N_ur', 'omega_ncdm', 'w0_fld', 'wa_fld']
+    table = {}
+    for row in AbacusSummit_params(params=names):
+        root = row.pop('root')
+        table[root] = {name: (list(value) if isinstance(value, tuple) else value) for name, value in row.items()}
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'cosmoprimo_amd', 'data', 'abacus_cosmologies.json')
+    os.makedirs(os.path.dirname(fn), exist_ok=True)
+    with open(fn, 'w') as file:
+        json.dump(table, file, indent=0)
+    print('wrote', fn, len(table), 'cosmologies')
+    # and what the reference derives for a few of them, as a fixture
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        from cosmoprimo.fiducial import AbacusSummit
+        for name in ['000', '009', '019', '130']:
+            cosmo = AbacusSummit(name, engine='eisenstein_hu_nowiggle_variants')
+            out['c%s' % name] = np.array([cosmo['h'], cosmo['Omega_m'], cosmo['N_ur'], cosmo['N_eff'], cosmo['m_ncdm_tot'], cosmo['N_ncdm'], cosmo['w0_fld'],
+                                          cosmo['wa_fld'], cosmo.get_primordial().A_s, cosmo.comoving_radial_distance(1.)], dtype='f8')
+    save('abacus', **out)
+
+
 def gen_desi_table():
     """161 of the 40 002 rows of the reference's tabulated DESI fiducial (cosmoprimo/data/desi.dat: z, E(z), D_C(z) [Mpc/h], computed with
     a Boltzmann code): a data file of the reference kept as a fixture, the z = 0 row plus 160 rows evenly spaced in log z."""
@@ -621,6 +648,8 @@ def main():
         gen_calculator(cp)
     if 'cosmology_api' in which:
         gen_cosmology_api(cp)
+    if 'abacus' in which:
+        gen_abacus_table(cp)
     if 'desi_table' in which:
         gen_desi_table()
 

@@ -38,8 +38,6 @@ def test_desi_fiducial(golden):
         assert c['N_ncdm'] == 1 and abs(c.get_fourier().sigma8_m / c['sigma8'] - 1.) < 1e-6
     assert Uchuu('Planck2018DDE')['w0_fld'] == -0.45 and abs(Uchuu()['Omega_m'] - 0.3089) < 1e-12
     assert abs(DESI(h=0.7)['h'] - 0.7) < 1e-15
-    with pytest.raises(NotImplementedError):
-        AbacusSummit(name=1)
     from cosmoprimo_amd.fiducial import DESIDR2Flatw0waCDM
     dr2 = DESIDR2Flatw0waCDM()
     assert abs(dr2['Omega_m'] - 0.3191980194) < 1e-12 and dr2['w0_fld'] == -0.7536302620 and abs(dr2['h'] - 0.6673428704) < 1e-15 and dr2['N_ncdm'] == 1
@@ -96,3 +94,35 @@ def test_tabulated(golden, tmp_path):
     save_TabulatedDESI(fn)
     again = DESI(engine='tabulated', extra_params={'filename': fn})
     assert np.array_equal(again.comoving_radial_distance(z), tab.comoving_radial_distance(z)) and open(fn).readline().startswith('# z = [0] + np.logspace(-8, 2, 40001)')
+
+
+def test_abacus(golden):
+    """reference tests/test_fiducial.py::test_abacus, test_planck, test_boss, test_uchuu with this package's default engine, and the derived
+    parameters the reference itself gets for four of the cosmologies (tests/golden/abacus.npz)."""
+    from cosmoprimo_amd import fiducial
+    from cosmoprimo_amd.fiducial import AbacusSummit_params, AbacusSummit
+    warnings.simplefilter('ignore')
+    assert fiducial.Planck2018FullFlatLCDM()['h'] == 0.6766 and fiducial.BOSS()['h'] == 0.676
+    cosmo = fiducial.Uchuu()
+    for name, value in {'Omega_m': 0.3089, 'h': 0.6774, 'sigma8': 0.8159, 'Omega_b': 0.0486, 'n_s': 0.9667}.items():
+        assert abs(cosmo[name] - value) < 1e-15, name
+    dcosmos = AbacusSummit_params(params=['root', 'omega_b', 'omega_cdm', 'h', 'A_s', 'n_s', 'alpha_s', 'N_ur', 'omega_ncdm', 'w0_fld', 'wa_fld'])
+    assert len(dcosmos) == 98
+    assert AbacusSummit_params(19)['omega_ncdm'] == (0.0006442, 0.0006442)
+    assert list(AbacusSummit_params(19, params=['h']).keys()) == ['h']
+    assert list(AbacusSummit_params(19, params=['omega_k', 'h']).keys()) == ['omega_k', 'h']
+    base = AbacusSummit()
+    for dcosmo in dcosmos:
+        cosmo = AbacusSummit(dcosmo['root'])
+        dcosmo.pop('root')
+        cosmo2 = base.clone(T_ncdm_over_cmb=None, **dcosmo)
+        assert np.allclose(cosmo2._params['N_ur'], cosmo._params['N_ur'])
+        assert cosmo == cosmo2.clone(N_eff=cosmo2['N_eff'])
+    with pytest.raises(ValueError):
+        AbacusSummit('0')
+    g = golden('abacus')
+    for name in ['000', '009', '019', '130']:
+        cosmo = AbacusSummit(name)
+        mine = [cosmo['h'], cosmo['Omega_m'], cosmo['N_ur'], cosmo['N_eff'], cosmo['m_ncdm_tot'], cosmo['N_ncdm'], cosmo['w0_fld'], cosmo['wa_fld'],
+                cosmo.get_primordial().A_s, cosmo.comoving_radial_distance(1.)]
+        np.testing.assert_allclose(np.array(mine, dtype='f8'), g['c' + name], rtol=1e-9, atol=1e-12, err_msg=name)
