@@ -204,23 +204,17 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         ops = self._operators()
         lib = _lib.load()
         rows, _ = self._rows(ops['klin'])                                 # P(k_lin), (ncol, 4096)
-        ffted = ops['dst'](rows, fused=True)                              # dst(log(k P)), type 2, ortho
-        even, odd = ffted[:, 0::2].contiguous(), ffted[:, 1::2].contiguous()
-        halves = []
-        self._dd, self._boxes = [], []
-        for y in (even, odd):
-            dd = ops['dd'](y)
-            box = self._box(dd)
-            out = torch.empty_like(y)
-            _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index,
-                                         dv.stream_of(self.device)))
-            halves.append(out)
-            self._dd.append(dd)
-            self._boxes.append(box)
-        self._even_now, self._odd_now = halves
-        merged = torch.empty_like(ffted)
-        merged[:, 0::2], merged[:, 1::2] = halves
-        pknow_lin = ops['dst'](merged, inverse=True, fused=True)          # exp(idst(.)) / k_lin
+        # dst(log(k P)), type 2, ortho, written as [even-indexed | odd-indexed] coefficients: seen as (2 ncol, 2048) the two sequences of
+        # every vector are consecutive rows, and share the operators (x_even = x_odd = 1 + arange(2048), bao_filter.py:374-375)
+        ffted = ops['dst'](rows, fused=True, split=True)
+        y = ffted.view(2 * ffted.shape[0], ffted.shape[1] // 2)
+        dd = ops['dd'](y)
+        box = self._box(dd)
+        out = torch.empty_like(y)
+        _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index, dv.stream_of(self.device)))
+        self._dd, self._boxes = [dd[0::2], dd[1::2]], [box[0::2], box[1::2]]
+        self._even_now, self._odd_now = out[0::2], out[1::2]
+        pknow_lin = ops['dst'](out.view(ffted.shape), inverse=True, fused=True, split=True)          # exp(idst(.)) / k_lin
         pk = self._pk_rows
         mask, ml, mr = (torch.as_tensor(ops[name], device=self.device) for name in ('mask', 'mask_left', 'mask_right'))
         vals = torch.cat([pk[:, ml], pknow_lin[:, mask], pk[:, mr]], dim=1).contiguous()

@@ -34,6 +34,7 @@ struct Args {
     const cplx* rot;    // (N) e^{-i pi k / (2N)} = (cos, -sin)
     const double* kx;   // (N) optional abscissa for the fused maps, or nullptr
     int fused;          // forward: x_n := log(kx_n * in_n); inverse: out_n := exp(y_n) / kx_n
+    int split;          // coefficients stored de-interleaved: Y_0, Y_2, ... in the first half of the row, Y_1, Y_3, ... in the second
 };
 
 // LDS position of frequency k after the full DIF network (digit reversal of the mixed-radix plan)
@@ -101,6 +102,9 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
         double* oa = A.out + 2 * p * N;
         double* ob = has_b ? oa + N : oa;
         cplx x[P];
+        // position of coefficient j in its row: the wallish2018 filter treats even- and odd-indexed coefficients as two sequences
+        // (bao_filter.py:373), so they can be written / read as two half rows instead of being gathered by separate copy kernels
+        auto at = [&](int j) { return A.split ? ((j & 1) * (N / 2) + (j >> 1)) : j; };
         __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
         int tt = t;
         asm volatile("" : "+v"(tt));
@@ -133,8 +137,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 // V_a = ((p + r)/2, (q - s)/2), V_b = ((q + s)/2, (r - p)/2);  C' = cos * re + sin * im
                 const double ya = 0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im));
                 const double yb = 0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re));
-                oa[N - 1 - k] = f * ya;
-                if (has_b) ob[N - 1 - k] = f * yb;
+                oa[at(N - 1 - k)] = f * ya;
+                if (has_b) ob[at(N - 1 - k)] = f * yb;
             }
         } else {
             // Hermitian-symmetrised, conjugated spectrum of the pair
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
                 const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
                 const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-                const double Aa = fa * ra[ia], Ab = fa * rb[ia];
-                const double Ba = (k == 0 ? fa : fb) * ra[ib], Bb = (k == 0 ? fa : fb) * rb[ib];
+                const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
+                const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
                 const cplx rot = A.rot[k];
                 const double cs = rot.re, sn = -rot.im;
                 cplx Ha, Hb;
@@ -249,7 +253,9 @@ extern "C" int cp_dst_plan_create(cp_dst_plan** out, int n, const double* kx, in
     return CP_OK;
 }
 
-extern "C" int cp_dst_execute(const cp_dst_plan* p, const double* d_in, double* d_out, long long nrows, int inverse, int fused, void* stream) {
+extern "C" int cp_dst_execute(const cp_dst_plan* p, const double* d_in, double* d_out, long long nrows, int inverse, int flags, void* stream) {
+    if (flags & ~(CP_DST_FUSED | CP_DST_SPLIT)) return cp::fail(CP_EINVAL, "cp_dst_execute: unknown flags %d", flags);
+    const int fused = flags & CP_DST_FUSED;
     if (!p) return cp::fail(CP_EINVAL, "cp_dst_execute: null plan");
     if (nrows < 0) return cp::fail(CP_EINVAL, "cp_dst_execute: negative row count");
     if (nrows == 0) return CP_OK;
@@ -259,7 +265,7 @@ extern "C" int cp_dst_execute(const cp_dst_plan* p, const double* d_in, double* 
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_execute: cannot select device %d", p->device);
     Args A;
-    A.in = d_in; A.out = d_out; A.nrows = nrows; A.tw = p->d_tw; A.rot = p->d_rot; A.kx = p->d_kx; A.fused = fused;
+    A.in = d_in; A.out = d_out; A.nrows = nrows; A.tw = p->d_tw; A.rot = p->d_rot; A.kx = p->d_kx; A.fused = fused; A.split = (flags & CP_DST_SPLIT) != 0;
     const long long npairs = (nrows + 1) / 2;
     const int grid = (int)(npairs < 512 ? npairs : 512);
     hipStream_t s = static_cast<hipStream_t>(stream);

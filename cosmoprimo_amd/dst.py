@@ -24,8 +24,9 @@ class DST(object):
             kxp = _lib.as_double_p(kx)
         _lib.check(_lib.load().cp_dst_plan_create(ctypes.byref(self._handle), self.n, kxp, self.device.index))
 
-    def __call__(self, x, inverse=False, fused=False):
-        """x : (..., n) -> (..., n) device tensor: dst (or idst) type 2, norm='ortho', along the last axis."""
+    def __call__(self, x, inverse=False, fused=False, split=False):
+        """x : (..., n) -> (..., n) device tensor: dst (or idst) type 2, norm='ortho', along the last axis.  ``split``: the coefficients are
+        stored de-interleaved, even-indexed ones in the first half of the row and odd-indexed ones in the second."""
         torch = dv.torch()
         x = dv.to_device(x, self.device)
         if x.shape[-1] != self.n:
@@ -42,7 +43,7 @@ class DST(object):
                 x = torch.where(ok, x, torch.ones_like(x)).contiguous()
         out = torch.empty_like(x)
         if nrows:
-            _lib.check(_lib.load().cp_dst_execute(self._handle, x.data_ptr(), out.data_ptr(), nrows, int(bool(inverse)), int(bool(fused)),
+            _lib.check(_lib.load().cp_dst_execute(self._handle, x.data_ptr(), out.data_ptr(), nrows, int(bool(inverse)), int(bool(fused)) | (2 if split else 0),
                                                   dv.stream_of(self.device)))
         if ok is not None:
             out = torch.where(ok, out, torch.full_like(out, float('nan')))

@@ -229,9 +229,13 @@ int cp_spline_columns(const double* d_xk, const double* d_yk, long long ncol, in
 typedef struct cp_dst_plan cp_dst_plan;
 /* n in {256, 1024, 4096}; kx : optional (n) host abscissa for the fused maps of cp_dst_execute, or NULL */
 int cp_dst_plan_create(cp_dst_plan** plan, int n, const double* kx, int device);
-/* d_in, d_out : (nrows, n) device.  inverse = 0: Y = dst2_ortho(x); 1: x = idst2_ortho(Y).
- * fused = 1: forward transforms log(kx_n * in_n) (bao_filter.py:371), inverse returns exp(x_n) / kx_n (bao_filter.py:413). */
-int cp_dst_execute(const cp_dst_plan* plan, const double* d_in, double* d_out, long long nrows, int inverse, int fused, void* stream);
+/* d_in, d_out : (nrows, n) device.  inverse = 0: Y = dst2_ortho(x); 1: x = idst2_ortho(Y).  flags:
+ * CP_DST_FUSED: forward transforms log(kx_n * in_n) (bao_filter.py:371), inverse returns exp(x_n) / kx_n (bao_filter.py:413);
+ * CP_DST_SPLIT: the coefficient side is de-interleaved, Y_0, Y_2, ... in the first half of each row and Y_1, Y_3, ... in the second
+ *               (the filter's even / odd sequences, bao_filter.py:373, 408-410, without gather / scatter copies). */
+#define CP_DST_FUSED 1
+#define CP_DST_SPLIT 2
+int cp_dst_execute(const cp_dst_plan* plan, const double* d_in, double* d_out, long long nrows, int inverse, int flags, void* stream);
 int cp_dst_plan_destroy(cp_dst_plan* plan);
 
 /* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----

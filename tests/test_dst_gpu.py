@@ -27,6 +27,12 @@ def test_dst_roundtrip_and_scipy(n):
     assert np.abs(yf - reff).max() < 1e-13 * np.abs(reff).max()
     pb = plan(reff, inverse=True, fused=True).cpu().numpy()
     assert np.abs(pb / p - 1).max() < 1e-12
+    # de-interleaved coefficient layout: [Y_0, Y_2, ... | Y_1, Y_3, ...], the same numbers
+    ys = plan(x, split=True).cpu().numpy()
+    assert np.array_equal(ys[:, :n // 2], y[:, 0::2]) and np.array_equal(ys[:, n // 2:], y[:, 1::2])
+    assert np.array_equal(plan(torch.as_tensor(ys, device='cuda'), inverse=True, split=True).cpu().numpy(), plan(torch.as_tensor(y, device='cuda'), inverse=True).cpu().numpy())
+    yfs = plan(p, fused=True, split=True).cpu().numpy()
+    assert np.array_equal(yfs[:, :n // 2], yf[:, 0::2]) and np.array_equal(yfs[:, n // 2:], yf[:, 1::2])
 
 
 def test_nonfinite_rows_stay_isolated():
