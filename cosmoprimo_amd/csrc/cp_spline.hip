@@ -10,7 +10,7 @@
 // derivative order).  W is built once per plan on the host with n tridiagonal solves (scipy CubicSpline's system for
 // the knot first derivatives + Hermite evaluation) and is exponentially banded (each query couples to ~30-40 knots
 // either side at 1e-17), so only the band is stored and applied: bandwidth x nq multiply-adds per row instead of a
-// tridiagonal solve per row.  The kernel stages, for up to 16 rows, the knots under a tile of 256 queries in LDS; every lane owns one query.
+// tridiagonal solve per row.  The kernel stages, for up to 16 rows, the knots under a tile of consecutive queries in LDS; every lane owns one query.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -24,7 +24,8 @@
 
 namespace {
 
-constexpr int TILE_Q = 256;  // queries per workgroup tile, one per lane
+constexpr int TILE_Q = 256;      // at most one query per lane
+constexpr int SPAN_CAP = 480;    // knots a tile may cover when it holds more than one query: 16 rows x 480 knots = 60 KB of LDS
 
 struct Args {
     const double* y;    // (nrows, n)
@@ -33,16 +34,17 @@ struct Args {
     int n, nq, bw;
     const double* wb;   // (bw, nq) band, query fastest
     const int* j0;      // (nq) first knot of each query's band; -1: query outside the knots -> NaN
-    const int* tile;    // (ntiles, 2): first knot and number of knots the bands of the tile's TILE_Q queries cover
+    const int* tile;    // (ntiles, 4): first query, number of queries (<= TILE_Q), first knot and number of knots their bands cover
     int ntiles, span_max;
     int post_op;
     double scale;
 };
 
-// One work item = R rows x one tile of TILE_Q queries.  The knots the tile's bands cover (for sorted queries: the knots under the tile plus one
-// bandwidth) are staged in LDS for R rows; every lane owns one query and streams its band weights once for the R rows (weights come from
-// L2: bw x nq doubles per plan, shared by all rows).  R = 16 cuts the weight traffic per output by 4 against the first version (4 rows,
-// whole rows in LDS), which ran at the L2 rate: 1.28 -> 0.4 ms for 16 384 rows of 2048 knots.
+// One work item = R rows x one tile of consecutive queries.  The knots the tile's bands cover are staged in LDS for the R rows; a lane owns
+// one query and streams its band weights once for the R rows (weights come from L2: bw x nq doubles per plan, shared by all rows).  With
+// R = 16 the weight traffic per output is a quarter of the first version's (4 rows, whole rows in LDS), which ran at the L2 rate.  Tiles are
+// cut where their knots would exceed SPAN_CAP, so operators that thin the knots out unevenly (log-spaced queries on 3666 linear knots: 83
+// knots per query at the top) get many narrow tiles there instead of one tile that forces whole rows into LDS.
 template <int R>
 __global__ __launch_bounds__(256) void spline_apply_kernel(const Args A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,15 +56,15 @@ __global__ __launch_bounds__(256) void spline_apply_kernel(const Args A) {
         const int t = (int)(it % A.ntiles);   // tiles of one row group run together: the group's rows are read from HBM once, the rest from L2
         const long long r0 = (it / A.ntiles) * R;
         const int nr = (int)((A.nrows - r0) < R ? (A.nrows - r0) : R);
-        const int tj0 = A.tile[2 * t], span = A.tile[2 * t + 1];
+        const int q0 = A.tile[4 * t], nqt = A.tile[4 * t + 1], tj0 = A.tile[4 * t + 2], span = A.tile[4 * t + 3];
         __syncthreads();
         for (int r = 0; r < R; ++r) {
             const double* yr = A.y + (r0 + (r < nr ? r : nr - 1)) * A.n + tj0;   // rows past the end repeat the last one (never stored)
             for (int i = tid; i < span; i += 256) ylds[r * A.span_max + i] = yr[i];
         }
         __syncthreads();
-        const int q = t * TILE_Q + tid;
-        if (q >= A.nq) continue;
+        if (tid >= nqt) continue;
+        const int q = q0 + tid;
         const int j0 = A.j0[q];
         double acc[R];
 #pragma unroll
@@ -286,23 +288,29 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
             if (j <= j1[q]) wb[(size_t)jj * nq + q] = w[(size_t)q * n + j];
         }
     }
-    // knots covered by the bands of each tile of TILE_Q queries
-    const int ntiles = (nq + TILE_Q - 1) / TILE_Q;
-    std::vector<int> tile(2 * (size_t)ntiles, 0);
+    // tiles of consecutive queries: as many as TILE_Q, cut earlier where the knots under their bands would exceed SPAN_CAP
+    std::vector<int> tile;
     int span_max = 1;
-    for (int t = 0; t < ntiles; ++t) {
-        int lo = n, hi = 0;
-        for (int q = t * TILE_Q; q < nq && q < (t + 1) * TILE_Q; ++q) {
-            if (j0[q] < 0) continue;
-            lo = j0[q] < lo ? j0[q] : lo;
-            const int end = j0[q] + bw < n ? j0[q] + bw : n;
-            hi = end > hi ? end : hi;
+    for (int q0 = 0; q0 < nq;) {
+        int lo = n, hi = 0, q = q0;
+        for (; q < nq && q - q0 < TILE_Q; ++q) {
+            int nlo = lo, nhi = hi;
+            if (j0[q] >= 0) {
+                nlo = j0[q] < lo ? j0[q] : lo;
+                const int end = j0[q] + bw < n ? j0[q] + bw : n;
+                nhi = end > hi ? end : hi;
+            }
+            if (q > q0 && nhi > nlo && nhi - nlo > SPAN_CAP) break;
+            lo = nlo;
+            hi = nhi;
         }
         if (hi <= lo) lo = 0, hi = 1;   // every query of the tile is outside the knots: nothing is read
-        tile[2 * t] = lo;
-        tile[2 * t + 1] = hi - lo;
+        const int entry[4] = {q0, q - q0, lo, hi - lo};
+        tile.insert(tile.end(), entry, entry + 4);
         span_max = hi - lo > span_max ? hi - lo : span_max;
+        q0 = q;
     }
+    const int ntiles = (int)(tile.size() / 4);
     cp_spline_plan* p = new (std::nothrow) cp_spline_plan();
     if (!p) return cp::fail(CP_ENOMEM, "cp_spline_plan_create: host allocation failed");
     p->n = n; p->nq = nq; p->bw = bw; p->device = device; p->d_wb = nullptr; p->d_j0 = nullptr; p->d_tile = nullptr;
@@ -364,8 +372,8 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     while (rows > 4 && ((size_t)rows * p->span_max * sizeof(double) > 64 * 1024 || rows / 2 >= nrows)) rows /= 2;
     const size_t lds = (size_t)rows * p->span_max * sizeof(double);
     if (lds > 160 * 1024)
-        return cp::fail(CP_EUNSUPPORTED, "cp_spline_apply: a tile of %d queries covers %d knots, more than the LDS staging buffer holds (max %d)", TILE_Q,
-                        p->span_max, 160 * 1024 / 8 / 4);
+        return cp::fail(CP_EUNSUPPORTED, "cp_spline_apply: one query couples to %d knots, more than the LDS staging buffer holds (max %d)", p->span_max,
+                        160 * 1024 / 8 / 4);
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: cannot select device %d", p->device);
