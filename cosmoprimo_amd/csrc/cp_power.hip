@@ -23,6 +23,7 @@ using namespace cpcosmo;
 struct EhScalars {
     double omega_b, omega_m, frac_b, theta_cmb, z_eq, k_eq, z_drag, r_drag, r_eq, rs_drag, k_silk, alpha_c, beta_c, alpha_b, beta_node, beta_b,
         alpha_gamma;
+    double ln_q_over_kh, ln_ksilk_over_kh;  // log(q / kh) = log(h / (13.41 k_eq)) and log((k / k_silk) / kh) = log(h / k_silk): see transfer_eh
 };
 
 // eisenstein_hu.py:34-92 (+ eisenstein_hu_nowiggle.py:21), operation for operation
@@ -55,8 +56,11 @@ __device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, doub
         s.alpha_b = 2.07 * s.k_eq * s.rs_drag * pow(1 + s.r_drag, -0.75) * G;
         s.beta_node = 8.41 * pow(s.omega_m, 0.435);
         s.beta_b = 0.5 + s.frac_b + (3. - 2. * s.frac_b) * sqrt((17.2 * s.omega_m) * (17.2 * s.omega_m) + 1);
+        s.ln_q_over_kh = log(h / (13.41 * s.k_eq));
+        s.ln_ksilk_over_kh = log(h / s.k_silk);
     } else {
         s.k_silk = s.alpha_c = s.beta_c = s.alpha_b = s.beta_node = s.beta_b = 0.;
+        s.ln_q_over_kh = s.ln_ksilk_over_kh = 0.;
     }
     return s;
 }
@@ -65,13 +69,16 @@ __device__ __forceinline__ double sinc_pi(double x) {  // numpy.sinc(x / pi) = s
     return x == 0. ? 1. : sin(x) / x;
 }
 
-__device__ __forceinline__ double transfer_eh(const EhScalars& s, double h, double kh) {  // eisenstein_hu.py:252-283
+// eisenstein_hu.py:252-283.  ln_kh = log(kh): the powers of q and k / k_silk go through it, x^p = exp(p (log kh + log(x / kh))), one log
+// shared by the three powers of k of a P(k) evaluation instead of a pow() each (pow is log + exp in extended precision: four of them were
+// 40 % of the kernel's instructions); the relative error of exp(p log x) is |p log x| eps < 2e-15 here.
+__device__ __forceinline__ double transfer_eh(const EhScalars& s, double h, double kh, double ln_kh) {
     const double k = kh * h;
     const double q = k / (13.41 * s.k_eq);
     const double ks = k * s.rs_drag;
     const double ln_beta = log(kE + 1.8 * s.beta_c * q);
     const double ln_nobeta = log(kE + 1.8 * q);
-    const double q108 = pow(q, 1.08);
+    const double q108 = exp(1.08 * (ln_kh + s.ln_q_over_kh));
     const double C_alpha = 14.2 / s.alpha_c + 386. / (1 + 69.9 * q108);
     const double C_noalpha = 14.2 + 386. / (1 + 69.9 * q108);
     const double ks54 = ks / 5.4;
@@ -79,12 +86,12 @@ __device__ __forceinline__ double transfer_eh(const EhScalars& s, double h, doub
     const double q2 = q * q;
     const double T_c = T_c_f * (ln_beta / (ln_beta + C_noalpha * q2)) + (1 - T_c_f) * (ln_beta / (ln_beta + C_alpha * q2));
     const double bn = s.beta_node / ks;
-    const double s_tilde = s.rs_drag * pow(1 + bn * bn * bn, -1. / 3.);
+    const double s_tilde = s.rs_drag * rcbrt(1 + bn * bn * bn);
     const double ks_tilde = k * s_tilde;
     const double T_b_T0 = ln_nobeta / (ln_nobeta + C_noalpha * q2);
     const double T_b_1 = T_b_T0 / (1 + (ks / 5.2) * (ks / 5.2));
     const double bb = s.beta_b / ks;
-    const double T_b_2 = s.alpha_b / (1 + bb * bb * bb) * exp(-pow(k / s.k_silk, 1.4));
+    const double T_b_2 = s.alpha_b / (1 + bb * bb * bb) * exp(-exp(1.4 * (ln_kh + s.ln_ksilk_over_kh)));
     const double T_b = sinc_pi(ks_tilde) * (T_b_1 + T_b_2);
     return s.frac_b * T_b + (1 - s.frac_b) * T_c;
 }
@@ -107,7 +114,7 @@ __device__ __forceinline__ double transfer_bbks(double h, double Omega_cdm, doub
     const double x = 2.34 * q;
     const double a = 16.2 * q, b = 5.47 * q, c = 6.71 * q;
     // as coded in the reference: 3.89 q (16.2 q)^2, not 3.89 q + (16.2 q)^2
-    return log(1 + x) / x * pow(1. + 3.89 * q * (a * a) + b * b * b + (c * c) * (c * c), -0.25);
+    return log(1 + x) / x / sqrt(sqrt(1. + 3.89 * q * (a * a) + b * b * b + (c * c) * (c * c)));
 }
 
 struct Args {
@@ -155,6 +162,7 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
     // Primordial.pk_k, eisenstein_hu.py:214-215
     const double A_s = pw[CP_PK_A_S], n_s = pw[CP_PK_N_S], alpha_s = pw[CP_PK_ALPHA_S], beta_s = pw[CP_PK_BETA_S];
     const double kp = pw[CP_PK_K_PIVOT] / c.h;
+    const double ln_kp = log(kp);
     const double Omega0_m = c.Omega_b + c.Omega_cdm + 0. - 0.;  // cosmology.py:381
     for (long long z0 = 0; z0 < nzs; z0 += 256) {
         if (z0) __syncthreads();  // the previous block of redshifts has been written
@@ -167,19 +175,20 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
         for (long long ik = k0 + tid; ik < k1; ik += 256) {
             const double kh = A.kscale ? A.k[ik] * kfac : A.k[ik];
             double* out = A.out + (ic * nzs + z0) * A.nk + ik;
+            const double ln_kh = log(kh);
             double T = 1.;
             if (A.what != CP_PK_PRIMORDIAL) {
                 if (A.engine == CP_ENGINE_BBKS)
                     T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
                 else
-                    T = A.engine == CP_ENGINE_EH ? transfer_eh(s, c.h, kh) : transfer_nowiggle(s, c.h, kh);
+                    T = A.engine == CP_ENGINE_EH ? transfer_eh(s, c.h, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
             }
             if (A.what == CP_PK_TRANSFER) {
                 out[0] = T;
                 continue;
             }
-            const double lnkkp = log(kh / kp);
-            const double prim = (c.h * c.h * c.h) * A_s * pow(kh / kp, n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp));
+            const double lnkkp = ln_kh - ln_kp;
+            const double prim = (c.h * c.h * c.h) * A_s * exp((n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp)) * lnkkp);
             if (A.what == CP_PK_PRIMORDIAL) {
                 out[0] = prim;
                 continue;
@@ -335,7 +344,7 @@ __global__ __launch_bounds__(256) void variants_kernel(const VarArgs A) {
                 const double kp = pw[CP_PK_K_PIVOT] / c.h;
                 const double lnkkp = log(khm / kp);
                 const double prim = (c.h * c.h * c.h) * pw[CP_PK_A_S] *
-                                    pow(khm / kp, pw[CP_PK_N_S] - 1. + 1. / 2. * pw[CP_PK_ALPHA_S] * lnkkp + 1. / 6. * pw[CP_PK_BETA_S] * (lnkkp * lnkkp));
+                                    exp((pw[CP_PK_N_S] - 1. + 1. / 2. * pw[CP_PK_ALPHA_S] * lnkkp + 1. / 6. * pw[CP_PK_BETA_S] * (lnkkp * lnkkp)) * lnkkp);
                 const double Omega0_m = c.Omega_b + c.Omega_cdm + v.Omega_ncdm - v.Omega_pncdm;  // cosmology.py:381
                 const double p2d = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (khm * khm));
                 pdd = 1. / (p2d * p2d) * (9. / 25. * 2. * (kPi * kPi) / (khm * khm * khm) / (c.h * c.h * c.h)) * prim;
