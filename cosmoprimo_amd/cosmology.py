@@ -329,6 +329,9 @@ def _compile_params(args):
     return out
 
 
+_missing = object()
+
+
 class BaseCosmoParams(object):
 
     """Parameter access shared by :class:`Cosmology` and engines (reference BaseCosmoParams, cosmology.py:231-457)."""
@@ -396,9 +399,24 @@ class BaseCosmoParams(object):
         else:
             (name, default), has_default = args, True
         params = self._params
-        c, sb, rck = bgmod_constants()
         if name in params:
             return params[name]
+        # derived values are kept: parameters do not change after construction, and sections read dozens of them (some cost a device read-back)
+        memo = self.__dict__.setdefault('_derived_memo', {})
+        if name in memo:
+            return memo[name]
+        found = self._derive(name)
+        if found is not _missing:
+            memo[name] = found
+            return found
+        if has_default:
+            return default
+        raise CosmologyError('Parameter {} not found.'.format(name))
+
+    def _derive(self, name):
+        """``name`` from the compiled parameters, ``_missing`` if it is not a derived parameter."""
+        params = self._params
+        c, sb, rck = bgmod_constants()
         if name.startswith('omega'):
             return self.get('O' + name[1:]) * params['h']**2
         if name == 'H0':
@@ -452,9 +470,7 @@ class BaseCosmoParams(object):
             return self.get('theta_cosmomc') * 100.
         if name == 'N_eff':   # cosmology.py:402-403
             return sum(t**4 * (4. / 11.)**(-4. / 3.) for t in params['T_ncdm_over_cmb']) + params['N_ur']
-        if has_default:
-            return default
-        raise CosmologyError('Parameter {} not found.'.format(name))
+        return _missing
 
     def _like(self, v):
         """Host value -> same kind as the (possibly torch) parameters it is combined with."""
@@ -543,7 +559,7 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
             self._rsigma8 = dv.to_device(sigma8, self.device) / s8m
             if self.batch_size is None:
                 self._rsigma8 = float(self._rsigma8)
-            self._sections.clear()
+            self._sections = {name: section for name, section in self._sections.items() if name in ('background', 'thermodynamics')}   # untouched by the rescaling
         return self._rsigma8
 
     def __getattr__(self, name):

@@ -37,6 +37,8 @@ def main():
     st = pstats.Stats(prof)
     st.sort_stats('cumulative').print_stats(45)
     st.sort_stats('tottime').print_stats(25)
+    st.print_callers('to_host')
+    st.print_callers("'cpu' of")
 
 
 if __name__ == '__main__':
