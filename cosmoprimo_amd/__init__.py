@@ -7,6 +7,6 @@ from .cosmology import (Cosmology, Background, Thermodynamics, Primordial, Trans
                         CosmologyComputationError)
 from . import eisenstein_hu, eisenstein_hu_nowiggle, eisenstein_hu_nowiggle_variants, bbks, tabulated  # noqa: F401  (registers the engines)
 from .bao_filter import PowerSpectrumBAOFilter, CorrelationFunctionBAOFilter
-from . import fiducial  # noqa: F401
+from . import fiducial, constants  # noqa: F401
 
 __version__ = '0.1.0'

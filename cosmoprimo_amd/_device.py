@@ -6,6 +6,15 @@ import numpy as np
 from . import _lib
 
 
+class Copyable(object):
+
+    """``copy()`` of the reference's BaseClass (utils.py): a shallow copy; device tables and plans are shared, not duplicated."""
+
+    def copy(self):
+        import copy
+        return copy.copy(self)
+
+
 def torch():
     import torch as _torch
     return _torch

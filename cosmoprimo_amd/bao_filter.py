@@ -32,7 +32,7 @@ class RegisteredPowerSpectrumBAOFilter(type):
         return cls
 
 
-class BasePowerSpectrumBAOFilter(object, metaclass=RegisteredPowerSpectrumBAOFilter):
+class BasePowerSpectrumBAOFilter(dv.Copyable, metaclass=RegisteredPowerSpectrumBAOFilter):
 
     """Base BAO filter for power spectrum (reference bao_filter.py:34-169)."""
     name = 'base'
@@ -613,7 +613,7 @@ class RegisteredCorrelationFunctionBAOFilter(type):
         return cls
 
 
-class BaseCorrelationFunctionBAOFilter(object, metaclass=RegisteredCorrelationFunctionBAOFilter):
+class BaseCorrelationFunctionBAOFilter(dv.Copyable, metaclass=RegisteredCorrelationFunctionBAOFilter):
 
     """Base BAO filter for correlation function (reference bao_filter.py:703-832)."""
     name = 'base'

@@ -332,7 +332,7 @@ def _compile_params(args):
 _missing = object()
 
 
-class BaseCosmoParams(object):
+class BaseCosmoParams(dv.Copyable):
 
     """Parameter access shared by :class:`Cosmology` and engines (reference BaseCosmoParams, cosmology.py:231-457)."""
 

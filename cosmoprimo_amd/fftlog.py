@@ -181,7 +181,7 @@ def _is_torch(x):
     return type(x).__module__.startswith('torch')
 
 
-class FFTlog(object):
+class FFTlog(dv.Copyable):
     r"""
     FFTLog algorithm (https://jila.colorado.edu/~ajsh/FFTLog/) for :math:`G(y) = \int_0^\infty x dx F(x) K(xy)`,
     same constructor and call contract as the reference (fftlog.py:31-248).

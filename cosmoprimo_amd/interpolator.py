@@ -219,7 +219,7 @@ def _linear_interp_operator(x, xq, extrap=False):
     return w
 
 
-class Interpolator1D(object):
+class Interpolator1D(dv.Copyable):
 
     """1D interpolation along axis 0 of ``fun`` (n, ...) in lin or log10 space; natural cubic spline (reference jax.py:135-209)."""
 
@@ -272,7 +272,7 @@ class Interpolator1D(object):
         return _finish(out.T, dtype, like_torch, shape)
 
 
-class Interpolator2D(object):
+class Interpolator2D(dv.Copyable):
 
     """2D grid interpolation, == RectBivariateSpline(kx=ky=3, s=0): separable not-a-knot cubic splines (reference jax.py:213-287)."""
 
@@ -342,7 +342,7 @@ def _get_default_kwargs(func, start=0, remove=()):
     return default_params
 
 
-class _BasePowerSpectrumInterpolator(object):
+class _BasePowerSpectrumInterpolator(dv.Copyable):
 
     """Base class for power spectrum interpolators (reference interpolator.py:327-407)."""
 
@@ -749,7 +749,7 @@ def get_default_s_callable():
     return np.logspace(-6., 2., 500)
 
 
-class _BaseCorrelationFunctionInterpolator(object):
+class _BaseCorrelationFunctionInterpolator(dv.Copyable):
 
     """Base class for correlation function interpolators (reference interpolator.py:990-1071)."""
 

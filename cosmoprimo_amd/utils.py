@@ -8,10 +8,11 @@ Utilities with the reference's names (cosmoprimo/utils.py): :class:`LeastSquareS
 """
 import numpy as np
 
+from ._device import Copyable as _Copyable
 from .interpolator import Interpolator1D
 
 
-class LeastSquareSolver(object):
+class LeastSquareSolver(_Copyable):
     r"""
     Solve :math:`d\chi^2 / d\mathbf{p} = 0` for
     :math:`\chi^2 = (\delta - \mathbf{p} \cdot \mathrm{grad})^T \mathbf{F} (\delta - \mathbf{p} \cdot \mathrm{grad})`, optionally
@@ -78,7 +79,7 @@ class LeastSquareSolver(object):
         return (delta.dot(self.precision) * delta).sum(axis=-1)
 
 
-class DistanceToRedshift(object):
+class DistanceToRedshift(_Copyable):
 
     """Distance -> redshift conversion by spline interpolation of a tabulated redshift -> distance relation (reference utils.py:275-316)."""
 
