@@ -54,13 +54,15 @@ def to_device(x, device):
 
 
 def to_host(x):
-    """numpy array from a device tensor.  Results of a few MB and more (batches of filtered spectra, P(k, z) tables) go through a page-locked
-    staging buffer of torch's caching host allocator: the copy then runs at the PCIe rate instead of the pageable-memory rate."""
+    """numpy array from a device tensor.  Results between 4 MiB and 1 GiB (batches of filtered spectra, P(k, z) tables) land in a page-locked
+    buffer of torch's caching host allocator, which the returned array keeps alive: the copy then runs at the PCIe rate instead of the
+    pageable-memory rate (which is a staged copy plus a host memcpy).  Larger results take the pageable path so that a caller holding
+    several of them does not pin gigabytes of host memory."""
     t = torch()
     if not is_torch(x):
         return np.asarray(x)
     x = x.detach()
-    if x.is_cuda and x.numel() * x.element_size() >= (1 << 22):
+    if x.is_cuda and (1 << 22) <= x.numel() * x.element_size() <= (1 << 30):
         try:
             buf = t.empty(x.shape, dtype=x.dtype, pin_memory=True)
         except RuntimeError:    # no page-locked memory left: the pageable copy below is the same result, slower
