@@ -107,6 +107,19 @@ __device__ __forceinline__ double rho_crit(const Cosmo& c, double zp1) {
     return (m + r + rho_de(c, zp1)) + c.Omega_k / zp1 * kRhoCrit;
 }
 
+// E(z) with log(1 + z) given (tabulated by the caller): (1 + z)^(3 (w0 + wa)) exp(3 wa (1 / (1 + z) - 1)) is one exp(); its relative error,
+// |exponent| eps < 1e-14, sits in the dark-energy term only, far below the 1e-10 the background is held to.  A cosmological constant
+// (w0 = -1, wa = 0) needs no transcendental function at all.
+__device__ __forceinline__ double efunc_ln(const Cosmo& c, double z, double lzp1) {
+    const double zp1 = 1. + z;
+    const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + ncdm_eval(c, z, 0);
+    const double r = c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit;
+    const double de = (c.w0 == -1. && c.wa == 0.) ? c.Omega_de / (zp1 * zp1 * zp1) * kRhoCrit
+                                                  : c.Omega_de * exp(3. * (c.w0 + c.wa) * lzp1 + 3. * c.wa * (1. / zp1 - 1.)) * kRhoCrit;
+    const double rc = (m + r + de) + c.Omega_k / zp1 * kRhoCrit;
+    return sqrt(rc * (zp1 * zp1 * zp1) / kRhoCrit);
+}
+
 __device__ __forceinline__ double efunc(const Cosmo& c, double z) {
     const double zp1 = 1. + z;
     return sqrt(rho_crit(c, zp1) * (zp1 * zp1 * zp1) / kRhoCrit);  // cosmology.py:1754
