@@ -35,7 +35,8 @@ constexpr int NK_TIME = 400;  // knots of get_default_z_interp('time' / 'age'), 
 template <int NK>
 struct TablesN {
     double zc[NK], dx[NK], l[NK], u[NK], idf[NK], idb[NK], cp[NK], bq[NK], ra[NK], rb[NK];
-    double lk[NK], lm[NK];  // log(1 + z) at the knots and at the interval midpoints zc + dx / 2: every integrand ordinate is one of them
+    // log(1 + z) and 1 / (1 + z) at the knots and at the interval midpoints zc + dx / 2: every integrand ordinate is one of them
+    double lk[NK], lm[NK], ik[NK], im[NK];
 };
 using Tables = TablesN<NK_DIST>;
 
@@ -76,9 +77,10 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     const double z = A.z[A.z_shared ? iz : i];
     const double nan = __builtin_nan("");
     // ordinates sit on the fixed grid, where log(1 + z) is tabulated: the dark-energy term of E(z) is then ONE exp() instead of pow() x exp()
-    auto integrand = [&](double zz, double lzp1) {
-        const double e = efunc_ln(c, zz, lzp1);
-        return TIME ? kCkms / (1. + zz) / (100. * e) : kCkms / (100. * e);
+    // and 1 / E(z) comes from rsqrt(E^2): no division, no sqrt per ordinate
+    auto integrand = [&](double zz, double lzp1, double izp1) {
+        const double ie = inv_efunc_ln(c, zz, lzp1, izp1);
+        return TIME ? (kCkms / 100.) * izp1 * ie : (kCkms / 100.) * ie;
     };
     if (!TIME && (A.kind == CP_BG_EFUNC || A.kind == CP_BG_HUBBLE)) {
         const double e = efunc(c, z);
@@ -141,8 +143,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         else hi = mid;
     }
     const int k = lo;
-    const double f_first = integrand(T.zc[0], T.lk[0]);
-    const double f_last = integrand(T.zc[NK - 1], T.lk[NK - 1]);
+    const double f_first = integrand(T.zc[0], T.lk[0], T.ik[0]);
+    const double f_last = integrand(T.zc[NK - 1], T.lk[NK - 1], T.ik[NK - 1]);
     double total = 0.;          // TIME: T_last = sum of all increments
     double fprev = f_first;     // integrand at the shared end of the previous interval
     double tk = 0.;             // T_k = sum of inc_i, i < k, accumulated in knot order like the reference's scan
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
             inc_prev = 0.;
         }
         const double x0 = T.zc[idx], x1 = T.zc[idx + 1], h = T.dx[idx];
-        const double fm = integrand(x0 + h / 2, T.lm[idx]);
-        const double fe = integrand(fwd ? x1 : x0, fwd ? T.lk[idx + 1] : T.lk[idx]);
+        const double fm = integrand(x0 + h / 2, T.lm[idx], T.im[idx]);
+        const double fe = integrand(fwd ? x1 : x0, fwd ? T.lk[idx + 1] : T.lk[idx], fwd ? T.ik[idx + 1] : T.ik[idx]);
         const double k1 = fwd ? fprev : fe, k4 = fwd ? fe : fprev;
         const double inc = h / 6. * (k1 + 2 * fm + 2 * fm + k4);  // jax.py:709 with k2 == k3
         fprev = fe;
@@ -215,6 +217,8 @@ void build_pivots(TablesN<NK>& t) {
     for (int i = 0; i < n; ++i) {
         t.lk[i] = std::log1p(t.zc[i]);
         t.lm[i] = std::log1p(t.zc[i] + t.dx[i] / 2);
+        t.ik[i] = 1. / (1. + t.zc[i]);
+        t.im[i] = 1. / (1. + (t.zc[i] + t.dx[i] / 2));
     }
     std::vector<double> b(n);
     t.l[0] = 0.; b[0] = 2. * t.dx[0]; t.u[0] = t.dx[0]; t.ra[0] = 0.; t.rb[0] = 3.;

@@ -120,6 +120,17 @@ __device__ __forceinline__ double efunc_ln(const Cosmo& c, double z, double lzp1
     return sqrt(rc * (zp1 * zp1 * zp1) / kRhoCrit);
 }
 
+// 1 / E(z) with log(1 + z) and 1 / (1 + z) given: rsqrt of E^2 (no division, no sqrt)
+__device__ __forceinline__ double inv_efunc_ln(const Cosmo& c, double z, double lzp1, double izp1) {
+    const double zp1 = 1. + z;
+    const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + ncdm_eval(c, z, 0);
+    const double r = c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit;
+    const double de = (c.w0 == -1. && c.wa == 0.) ? c.Omega_de * (izp1 * izp1 * izp1) * kRhoCrit
+                                                  : c.Omega_de * exp(3. * (c.w0 + c.wa) * lzp1 + 3. * c.wa * (izp1 - 1.)) * kRhoCrit;
+    const double rc = (m + r + de) + c.Omega_k * izp1 * kRhoCrit;
+    return rsqrt(rc * (zp1 * zp1 * zp1) * (1. / kRhoCrit));
+}
+
 __device__ __forceinline__ double efunc(const Cosmo& c, double z) {
     const double zp1 = 1. + z;
     return sqrt(rho_crit(c, zp1) * (zp1 * zp1 * zp1) / kRhoCrit);  // cosmology.py:1754
