@@ -191,13 +191,11 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         """Per-column index box to cut, from the two maxima of the second derivative (reference bao_filter.py:390-394). dd : (ncol, n)."""
         torch = dv.torch()
         mf, ms, off = self._margin_first, self._margin_second, self._offset
-        n = dd.shape[-1]
-        argmax = dd[:, mf:n - mf].argmax(dim=1) + mf
-        # second maximum in [argmax + margin_second, n - margin_first): masked arg-max keeps the first maximal index like ndarray.argmax
-        idx = torch.arange(n, device=dd.device)[None, :]
-        valid = (idx >= (argmax + ms)[:, None]) & (idx < n - mf)
-        second = torch.where(valid, dd, torch.full_like(dd, float('-inf'))).argmax(dim=1)
-        return torch.stack([argmax + off[0], second + off[1]], dim=1).to(torch.int32).contiguous()
+        dd = dd.contiguous()
+        box = torch.empty((dd.shape[0], 2), dtype=torch.int32, device=dd.device)
+        _lib.check(_lib.load().cp_wallish_box(dd.data_ptr(), dd.shape[0], dd.shape[1], mf, ms, off[0], off[1], box.data_ptr(), self.device.index,
+                                              dv.stream_of(self.device)))
+        return box
 
     def _compute(self):
         torch = dv.torch()

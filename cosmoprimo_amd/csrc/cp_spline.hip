@@ -489,6 +489,66 @@ extern "C" int cp_gap_spline(const double* d_y, const int* d_box, double* d_out,
 }
 
 
+// ---- the box of knots wallish2018 removes: between the two maxima of the second derivative (reference bao_filter.py:390-394) ----
+// argmax over [margin_first, n - margin_first), then the argmax over [argmax + margin_second, n - margin_first): first index of the maximum,
+// NaN counting as the largest value, as numpy / torch argmax do; an empty second range gives index 0 (the arg-max of an all -inf row).
+// One wave per column, one pass over its second derivatives (the torch version filled and masked a copy of the whole array).
+namespace {
+
+__device__ __forceinline__ void argmax_merge(double& v, int& i, double ov, int oi) {
+    const bool take = (ov > v && !(v != v)) || (ov != ov && !(v != v)) || (((ov == v) || (ov != ov && v != v)) && oi < i);
+    if (take) {
+        v = ov;
+        i = oi;
+    }
+}
+
+__device__ __forceinline__ int wave_argmax(const double* __restrict__ row, int lo, int hi, int lane) {
+    double v = -__builtin_inf();
+    int idx = 0x7fffffff;
+    for (int j = lo + lane; j < hi; j += 64) argmax_merge(v, idx, row[j], j);   // ascending j: ties keep the first
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        argmax_merge(v, idx, ov, oi);
+    }
+    return idx == 0x7fffffff ? 0 : idx;
+}
+
+__global__ __launch_bounds__(256) void wallish_box_kernel(const double* __restrict__ dd, long long ncol, int n, int margin_first, int margin_second,
+                                                          int off0, int off1, int* __restrict__ box) {
+    const long long col = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= ncol) return;
+    const int lane = threadIdx.x & 63;
+    const double* row = dd + col * n;
+    const int first = wave_argmax(row, margin_first, n - margin_first, lane);
+    const int second = wave_argmax(row, first + margin_second, n - margin_first, lane);
+    if (lane == 0) {
+        box[2 * col] = first + off0;
+        box[2 * col + 1] = second + off1;
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_wallish_box(const double* d_dd, long long ncol, int n, int margin_first, int margin_second, int offset_first, int offset_second,
+                              int* d_box, int device, void* stream) {
+    if (ncol < 0 || n < 1 || margin_first < 0 || 2 * margin_first >= n) return cp::fail(CP_EINVAL, "cp_wallish_box: bad sizes");
+    if (ncol == 0) return CP_OK;
+    if (!d_dd || !d_box) return cp::fail(CP_EINVAL, "cp_wallish_box: null device pointer");
+    if ((ncol + 3) / 4 > 2147483647LL) return cp::fail(CP_EUNSUPPORTED, "cp_wallish_box: too many columns for one launch");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_wallish_box: cannot select device %d", device);
+    hipLaunchKernelGGL(wallish_box_kernel, dim3((unsigned)((ncol + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), d_dd, ncol, n, margin_first,
+                       margin_second, offset_first, offset_second, d_box);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_wallish_box: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+
 // ---- natural cubic spline per column with per-column knots --------------------------------------------------------------------
 // brieden2022 re-samples its smooth spectrum through the input interpolator cloned on the knots k_fid / rescale (reference
 // bao_filter.py:503-509): with one rescale per column (batches of cosmologies) the knots differ per column and no fixed operator

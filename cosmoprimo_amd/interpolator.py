@@ -586,7 +586,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                     tmp = tmp[..., :, None].expand(tmp.shape + (zh.size,))
             else:
                 tmp = dv.to_device(self._interp(kh, zh, grid=grid), self.device)
-            out = torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+            out = tmp if mask.all() else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
         else:
             is2d = self._pk.shape[1] > 1
             mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
@@ -605,7 +605,9 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                     tmp = tmp[:, None].expand(kh.size, zh.size)
             if self.growth_factor_sq is not None and not ignore_growth:
                 tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
-            out = torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+            out = tmp if mask.all() else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+        if isinstance(self._rsigma8sq, float) and self._rsigma8sq == 1.:     # (nothing to rescale: no pass over the result)
+            return out
         return out * self._rsigma8sq
 
     def __call__(self, k, z, grid=True, ignore_growth=False, bounds_error=False):

@@ -217,6 +217,11 @@ int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc,
  * [box[2c], box[2c+1]] removed, evaluated at all positions and divided by x^2 (wallish2018 peak removal, bao_filter.py:387-405).
  * d_y, d_out : (ncol, n); d_box : (ncol, 2) int32. */
 int cp_gap_spline(const double* d_y, const int* d_box, double* d_out, long long ncol, int n, int device, void* stream);
+/* The box cp_gap_spline removes (bao_filter.py:390-394): d_dd (ncol, n) second derivatives -> d_box (ncol, 2) =
+ * [argmax over [margin_first, n - margin_first) + offset_first, argmax over [that argmax + margin_second, n - margin_first) + offset_second],
+ * first index of the maximum as ndarray.argmax (index 0 when the second range is empty). */
+int cp_wallish_box(const double* d_dd, long long ncol, int n, int margin_first, int margin_second, int offset_first, int offset_second, int* d_box,
+                   int device, void* stream);
 
 /* natural cubic spline per column with per-column knots (brieden2022 re-sampling with one rs_drag ratio per column, bao_filter.py:503-509):
  * d_xk, d_yk : (n, ncol) knot-major; d_xq : (nq) ascending queries shared by all columns; d_out : (nq, ncol);

@@ -118,3 +118,31 @@ def test_batched_cosmologies(cp, golden):
     for i in range(4):
         np.testing.assert_allclose(w.pknow[i], g['c%d_wallish_pknow_2d' % i], rtol=RTOL)
         np.testing.assert_allclose(b.pknow[i], g['c%d_brieden_pknow_2d' % i], rtol=RTOL)
+
+
+def test_wallish_box_kernel():
+    """cp_wallish_box against ndarray.argmax on the reference's ranges (bao_filter.py:390-394): first index on ties, NaN as the maximum, the
+    index-0 convention for an empty second range."""
+    import torch
+    from cosmoprimo_amd import _lib, _device as dv
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(11)
+    mf, ms, off = 20, 5, (-10, 20)
+    for n in (64, 257, 2048):
+        dd = rng.standard_normal((301, n))
+        dd[1, mf + 3] = dd[1, mf + 9] = 50.                  # tie: the first wins
+        dd[2, n - mf - 1] = 60.                              # maximum on the last admissible index: second range empty
+        dd[3, mf + 7] = np.nan                               # NaN is the maximum
+        dd[4, :] = 1.                                        # constant row
+        dd[5, 0] = dd[5, n - 1] = 1e9                        # outside the ranges: ignored
+        dd[6, mf + 1] = 70.; dd[6, mf + 1 + ms] = 65.; dd[6, mf + ms] = 66.     # the second range starts at argmax + margin_second
+        t = torch.as_tensor(dd, device=dev)
+        box = torch.empty((dd.shape[0], 2), dtype=torch.int32, device=dev)
+        _lib.check(_lib.load().cp_wallish_box(t.data_ptr(), dd.shape[0], n, mf, ms, off[0], off[1], box.data_ptr(), 0, dv.stream_of(dev)))
+        ref = np.empty((dd.shape[0], 2), dtype=np.int64)
+        for i, row in enumerate(dd):
+            first = row[mf:n - mf].argmax() + mf
+            tail = row[first + ms:n - mf]
+            second = first + ms + tail.argmax() if tail.size else 0
+            ref[i] = first + off[0], second + off[1]
+        assert np.array_equal(box.cpu().numpy(), ref), n
