@@ -16,6 +16,7 @@ from . import _lib
 from . import _device as dv
 from .cosmology import Cosmology, Fourier
 from .dst import DST
+from .interpolator import _quadratic_interp_operator  # noqa: F401
 from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, CorrelationFunctionInterpolator1D,
                            CorrelationFunctionInterpolator2D)
 from .spline import LinearOperator
@@ -235,36 +236,6 @@ def _local_maxima(x):
         else:
             i += 1
     return np.array(out, dtype=int)
-
-
-def _bspline_basis(t, k, x):
-    """Dense (len(x), len(t) - k - 1) matrix of B-spline basis values B_j(x) (Cox-de Boor), with polynomial extrapolation of the end pieces."""
-    n = t.size - k - 1
-    out = np.zeros((x.size, n))
-    for ix, xv in enumerate(x):
-        ell = np.searchsorted(t, xv, side='right') - 1
-        ell = min(max(ell, k), n - 1)          # interval [t_ell, t_ell+1); clamped: extrapolate with the end polynomial
-        b = np.zeros(k + 1)
-        b[0] = 1.
-        for d in range(1, k + 1):
-            saved = 0.
-            for r in range(d):
-                left, right = t[ell + r + 1 - d], t[ell + r + 1]
-                tmp = b[r] / (right - left)
-                b[r] = saved + (right - xv) * tmp
-                saved = (xv - left) * tmp
-            b[d] = saved
-        out[ix, ell - k:ell + 1] = b
-    return out
-
-
-def _quadratic_interp_operator(xk, xq):
-    """Dense operator of ``interp1d(xk, ., kind=2, fill_value='extrapolate')(xq)`` (scipy make_interp_spline(k=2))."""
-    k = 2
-    mid = (xk[1:] + xk[:-1]) / 2.
-    t = np.concatenate([(xk[0],) * (k + 1), mid[1:-1], (xk[-1],) * (k + 1)])
-    colloc = _bspline_basis(t, k, xk)
-    return _bspline_basis(t, k, xq).dot(np.linalg.inv(colloc))
 
 
 class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):

@@ -219,13 +219,47 @@ def _linear_interp_operator(x, xq, extrap=False):
     return w
 
 
+def _bspline_basis(t, k, x):
+    """Dense (len(x), len(t) - k - 1) matrix of B-spline basis values B_j(x) (Cox-de Boor), with polynomial extrapolation of the end pieces."""
+    n = t.size - k - 1
+    out = np.zeros((x.size, n))
+    for ix, xv in enumerate(x):
+        ell = np.searchsorted(t, xv, side='right') - 1
+        ell = min(max(ell, k), n - 1)          # interval [t_ell, t_ell+1); clamped: extrapolate with the end polynomial
+        b = np.zeros(k + 1)
+        b[0] = 1.
+        for d in range(1, k + 1):
+            saved = 0.
+            for r in range(d):
+                left, right = t[ell + r + 1 - d], t[ell + r + 1]
+                tmp = b[r] / (right - left)
+                b[r] = saved + (right - xv) * tmp
+                saved = (xv - left) * tmp
+            b[d] = saved
+        out[ix, ell - k:ell + 1] = b
+    return out
+
+
+def _quadratic_interp_operator(xk, xq, extrap=True):
+    """Dense operator of ``interp1d(xk, ., kind=2, fill_value='extrapolate')(xq)`` (scipy make_interp_spline(k=2); SURVEY.md App. C6);
+    NaN rows outside [xk[0], xk[-1]] unless ``extrap``."""
+    k = 2
+    mid = (xk[1:] + xk[:-1]) / 2.
+    t = np.concatenate([(xk[0],) * (k + 1), mid[1:-1], (xk[-1],) * (k + 1)])
+    colloc = _bspline_basis(t, k, xk)
+    w = _bspline_basis(t, k, xq).dot(np.linalg.inv(colloc))
+    if not extrap:
+        w[~((xq >= xk[0]) & (xq <= xk[-1]))] = np.nan
+    return w
+
+
 class Interpolator1D(dv.Copyable):
 
     """1D interpolation along axis 0 of ``fun`` (n, ...) in lin or log10 space; natural cubic spline (reference jax.py:135-209)."""
 
     def __init__(self, x, fun, k=3, interp_x='lin', interp_fun='lin', extrap=False, assume_sorted=False, device=None):
-        if int(k) not in (1, 3):
-            raise NotImplementedError('only linear (k=1) and cubic (k=3) interpolation are implemented on the GPU path')
+        if int(k) not in (1, 2, 3):
+            raise NotImplementedError('only linear (k=1), quadratic (k=2) and cubic (k=3) interpolation are implemented on the GPU path')
         self.k = int(k)
         self.device = dv.resolve_device(device, fun)
         self.interp_x, self.interp_fun, self.extrap = str(interp_x), str(interp_fun), bool(extrap)
@@ -256,11 +290,12 @@ class Interpolator1D(dv.Copyable):
             return _finish(dv.torch().empty((0, self._rows.shape[0]), dtype=dv.torch().float64, device=self.device), dtype, like_torch, shape)
         with np.errstate(all='ignore'):
             xq = np.log10(xh) if self.interp_x == 'log' else xh
-        if self.k == 1:
+        if self.k in (1, 2):     # scipy interp1d(kind='linear' / 'quadratic') of the reference (jax.py:176-177)
             if dx:
                 raise TypeError('derivatives are available for cubic interpolation only')
-            op = _cached_operator(('i1d-lin', self._x.tobytes(), xq.tobytes(), self.extrap, self.device.index),
-                                  lambda: LinearOperator.dense(_linear_interp_operator(self._x, xq, self.extrap), device=self.device))
+            build = _linear_interp_operator if self.k == 1 else _quadratic_interp_operator
+            op = _cached_operator(('i1d-k%d' % self.k, self._x.tobytes(), xq.tobytes(), self.extrap, self.device.index),
+                                  lambda: LinearOperator.dense(build(self._x, xq, self.extrap), device=self.device))
         else:
             op = _cached_operator(('i1d', self._x.tobytes(), xq.tobytes(), int(dx), self.extrap, self.device.index),
                                   lambda: LinearOperator.spline(self._x, xq, bc='natural', nu=dx, extrapolate=self.extrap, device=self.device))

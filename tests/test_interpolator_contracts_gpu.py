@@ -116,5 +116,17 @@ def test_linear_order():
     np.testing.assert_allclose(it.Interpolator1D(x, fun[:, 0], k=1, interp_x='log', interp_fun='log')(xin), ref, rtol=1e-12)
     pk = it.PowerSpectrumInterpolator1D(x, fun[:, 0], interp_order_k=1)
     assert np.isfinite(pk(np.array([1e-6, 1., 50.]))).all()
+    # k = 2: scipy interp1d 'quadratic' (make_interp_spline(k=2)), the other order the reference's Interpolator1D accepts
+    for extrap in (False, True):
+        ref = interp1d(x, fun, kind='quadratic', axis=0, bounds_error=False, fill_value='extrapolate' if extrap else np.nan, assume_sorted=True)(xq)
+        got = it.Interpolator1D(x, fun, k=2, extrap=extrap)(xq)
+        assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref))
+        np.testing.assert_allclose(got[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=1e-10, atol=1e-12 * np.abs(fun).max())
+    ref = 10**interp1d(np.log10(x), np.log10(fun[:, 0]), kind='quadratic')(np.log10(xin))
+    np.testing.assert_allclose(it.Interpolator1D(x, fun[:, 0], k=2, interp_x='log', interp_fun='log')(xin), ref, rtol=1e-10)
+    pk2 = it.PowerSpectrumInterpolator1D(x, fun[:, 0], interp_order_k=2)      # knots padded to (extrap_kmin, extrap_kmax) as in the reference
+    knots, values = pk2._interp._x, pk2._interp._rows.cpu().numpy()[0]
+    assert knots.size == x.size + 4 and np.allclose(knots[2:-2], np.log10(x))      # two log-extrapolated points on either side
+    np.testing.assert_allclose(pk2(xin), 10**interp1d(knots, values, kind='quadratic')(np.log10(xin)), rtol=1e-10)
     with pytest.raises(NotImplementedError):
-        it.Interpolator1D(x, fun, k=2)
+        it.Interpolator1D(x, fun, k=4)
