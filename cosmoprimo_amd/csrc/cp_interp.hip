@@ -12,16 +12,26 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void interp_linear_kernel(const double* __restrict__ xp, const double* __restrict__ fp, long long n,
-                                                            const double* __restrict__ x, double* __restrict__ out, long long nx) {
+// Every S-th knot sits in LDS: the first log2(n / S) bisection steps run there, the last log2(S) in one or two cache lines of the table.
+__global__ __launch_bounds__(256) void interp_linear_kernel(const double* __restrict__ xp, const double* __restrict__ fp, long long n, int stride,
+                                                            int ncoarse, const double* __restrict__ x, double* __restrict__ out, long long nx) {
+    extern __shared__ double coarse[];   // coarse[i] = xp[i * stride]
+    for (int i = threadIdx.x; i < ncoarse; i += 256) coarse[i] = xp[(long long)i * stride];
+    __syncthreads();
+    const double x0 = coarse[0], xn = xp[n - 1];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (long long)gridDim.x * blockDim.x) {
         const double v = x[i];
         double r = __builtin_nan("");
-        if (v >= xp[0] && v <= xp[n - 1]) {
-            if (v == xp[n - 1]) {
+        if (v >= x0 && v <= xn) {
+            if (v == xn) {
                 r = fp[n - 1];
             } else {
-                long long lo = 0, hi = n - 1;  // invariant: xp[lo] <= v < xp[hi]
+                int clo = 0, chi = ncoarse;   // coarse[clo] <= v, and v < coarse[chi] if chi < ncoarse
+                while (chi - clo > 1) {
+                    const int mid = (clo + chi) >> 1;
+                    if (coarse[mid] <= v) clo = mid; else chi = mid;
+                }
+                long long lo = (long long)clo * stride, hi = lo + stride < n - 1 ? lo + stride : n - 1;  // invariant: xp[lo] <= v < xp[hi]
                 while (hi - lo > 1) {
                     const long long mid = (lo + hi) >> 1;
                     if (xp[mid] <= v) lo = mid; else hi = mid;
@@ -53,9 +63,13 @@ extern "C" int cp_interp_linear(const double* d_xp, const double* d_fp, long lon
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_interp_linear: cannot select device %d", device);
+    int stride = 32;                                    // at most 4096 coarse knots (32 KB of LDS)
+    while ((n + stride - 1) / stride > 4096) stride *= 2;
+    const int ncoarse = (int)((n + stride - 1) / stride);
     const long long blocks = (nx + 255) / 256;
-    const unsigned grid = (unsigned)(blocks < 256 * 32 ? blocks : 256 * 32);
-    hipLaunchKernelGGL(interp_linear_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_xp, d_fp, n, d_x, d_out, nx);
+    const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+    hipLaunchKernelGGL(interp_linear_kernel, dim3(grid), dim3(256), ncoarse * sizeof(double), static_cast<hipStream_t>(stream), d_xp, d_fp, n, stride,
+                       ncoarse, d_x, d_out, nx);
     const hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_interp_linear: launch failed: %s", hipGetErrorString(e));
