@@ -37,6 +37,14 @@ def test_error_mapping():
         _lib.check(lib.cp_fftlog_plan_create(ctypes.byref(handle), 10000, 1 << 25, 1, _lib.as_double_p(pre), _lib.as_double_p(pre), _lib.as_double_p(pre), 0))
     with pytest.raises(ValueError):
         _lib.kernel_eval(99, 0., np.ones(2, dtype='c16'))
+    # argument checks of the entry points added later in the round come before any device call
+    for call in (lambda: lib.cp_interp_linear(None, None, 0, None, None, 4, 0, None), lambda: lib.cp_interp_linear(None, None, 8, None, None, 4, 0, None),
+                 lambda: lib.cp_rows_screen(None, -1, 8, 0, None, None, 0, None), lambda: lib.cp_rows_screen(None, 4, 8, 0, None, None, 0, None),
+                 lambda: lib.cp_wallish_box(None, 4, 64, 40, 5, -10, 20, None, 0, None), lambda: lib.cp_wallish_box(None, 4, 2048, 20, 5, -10, 20, None, 0, None),
+                 lambda: lib.cp_dst_execute(None, None, None, 4, 0, 0, None)):
+        with pytest.raises(ValueError):
+            _lib.check(call())
+    assert lib.cp_interp_linear(None, None, 8, None, None, 0, 0, None) == 0 and lib.cp_rows_screen(None, 0, 8, 0, None, None, 0, None) == 0     # nothing to do
 
 
 def test_loggamma_vs_scipy_golden(golden):
