@@ -67,6 +67,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--scale', type=float, default=1.)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--chunk', type=int, default=16384, help='cosmologies per call in config 4')
     args = ap.parse_args()
     import torch
     import cosmoprimo_amd as cp
@@ -99,7 +100,7 @@ def main():
     nb = int(125000 * args.scale)
     rng = np.random.default_rng(2)
     par = dict(Omega_m=rng.uniform(.25, .40, nb), Omega_b=rng.uniform(.04, .06, nb), h=rng.uniform(.6, .8, nb), n_s=rng.uniform(.92, 1., nb))
-    chunk = 16384
+    chunk = args.chunk
 
     filters = {}
 
