@@ -22,6 +22,11 @@ from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolato
 from .spline import LinearOperator
 
 
+def _host_value(x):
+    """float or numpy array from a float / array / device tensor."""
+    return dv.to_host(x) if dv.is_torch(x) else np.asarray(x, dtype='f8')
+
+
 class RegisteredPowerSpectrumBAOFilter(type):
 
     """Metaclass registering :class:`BasePowerSpectrumBAOFilter`-derived classes by ``name`` (reference bao_filter.py:22-31)."""
@@ -149,7 +154,16 @@ class BasePowerSpectrumBAOFilter(dv.Copyable, metaclass=RegisteredPowerSpectrumB
             rs_drag_fid = 100.91463132327911
         else:
             rs_drag_fid = self.cosmo_fid.rs_drag
-        return self.cosmo.rs_drag / rs_drag_fid
+        ratio = _host_value(self.cosmo.rs_drag) / _host_value(rs_drag_fid)
+        return float(ratio) if np.ndim(ratio) == 0 else ratio
+
+    def _scalar_rs_drag_ratio(self):
+        """The ratio for filters whose operator is built for ONE ratio (a dense matrix per value): a batch of cosmologies is refused."""
+        ratio = self.rs_drag_ratio()
+        if np.ndim(ratio):
+            raise NotImplementedError('{} builds one dense operator per rs_drag ratio: give it one cosmology at a time (wallish2018 and brieden2022 '
+                                      'take batches of cosmologies)'.format(self.__class__.__name__))
+        return float(ratio)
 
 
 class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
@@ -508,7 +522,7 @@ class EHNoWigglePolyPowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectr
         torch = dv.torch()
         krange = np.asarray(self.krange)
         if self.rescale_krange:
-            krange = krange / self.rs_drag_ratio()
+            krange = krange / self._scalar_rs_drag_ratio()
         mask = (self.k >= krange[0]) & (self.k <= krange[1])
         k = self.k[mask]
         gradient = np.array([k**(i - 2) for i in range(6)])
@@ -567,7 +581,7 @@ class PeakAveragePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumB
 
     def _compute(self):
         pknow = self._eh_nowiggle(self.k)
-        op = LinearOperator.dense(self._operator(float(self.rs_drag_ratio())), device=self.device)
+        op = LinearOperator.dense(self._operator(self._scalar_rs_drag_ratio()), device=self.device)
         self._pknow_rows = op(self._pk_rows / pknow) * pknow
 
 
@@ -648,6 +662,7 @@ class BaseCorrelationFunctionBAOFilter(dv.Copyable, metaclass=RegisteredCorrelat
         return self._cosmo_fid
 
     rs_drag_ratio = BasePowerSpectrumBAOFilter.rs_drag_ratio
+    _scalar_rs_drag_ratio = BasePowerSpectrumBAOFilter._scalar_rs_drag_ratio
 
 
 class Kirkby2013CorrelationFunctionBAOFilter(BaseCorrelationFunctionBAOFilter):
@@ -688,7 +703,7 @@ class Kirkby2013CorrelationFunctionBAOFilter(BaseCorrelationFunctionBAOFilter):
         return A
 
     def _compute(self):
-        rescale = self.rs_drag_ratio() if self.rescale_sbox else 1.
+        rescale = self._scalar_rs_drag_ratio() if self.rescale_sbox else 1.
         key = float(rescale)
         if getattr(self, '_op_key', None) != key:
             self._op, self._op_key = LinearOperator.dense(self._operator(key), device=self.device), key

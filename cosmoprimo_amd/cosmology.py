@@ -647,6 +647,8 @@ class Cosmology(BaseCosmoParams):
         from scipy import optimize
         if func is None:
             raise CosmologyInputError('Provide func')
+        if self.batch_size is not None:
+            raise NotImplementedError('solve() varies one parameter of one cosmology; call it per cosmology of a batch')
         name = func if isinstance(func, str) else None
         if name is not None:
             def func(cosmo):

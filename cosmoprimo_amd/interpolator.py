@@ -551,6 +551,9 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         self.growth_factor_sq = growth_factor_sq
         self.device = dv.resolve_device(device, pk)
         self._batch = None
+        if np.ndim(pk) > 2:
+            raise NotImplementedError('a tabulated PowerSpectrumInterpolator2D holds one (k, z) table: tables of a batch of cosmologies (pk of {:d} '
+                                      'dimensions) go in one at a time'.format(np.ndim(pk)))
         k, pk = self._prepare(k, pk, z=z, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
         self.interp_order_k, self.interp_order_z = int(interp_order_k), int(interp_order_z)
         is2d = self._pk.shape[1] > 1
@@ -750,6 +753,9 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
 
             def pk_callable(kh):
                 out = self._eval_device(np.asarray(kh, dtype='f8').ravel(), zh.ravel(), grid=True) / self._rsigma8sq
+                nbatch = out.ndim - 2
+                if nbatch:      # a batch of cosmologies becomes columns of the 1D interpolator: (nk, batch..., nz), as Primordial.pk_interpolator
+                    out = out.permute(nbatch, *range(nbatch), out.ndim - 1)
                 out = out.reshape(out.shape[:-1] + zh.shape) if zh.ndim else out[..., 0]
                 return out * self._rsigma8sq
 
