@@ -19,11 +19,17 @@ def main():
     par = dict(Omega_m=rng.uniform(.25, .40, nb), Omega_b=rng.uniform(.04, .06, nb), h=rng.uniform(.6, .8, nb), n_s=rng.uniform(.92, 1., nb))
     fid = cp.Cosmology(engine='eisenstein_hu')
 
+    filters = {}
+
     def chunk():
         cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{k: torch.as_tensor(v, device=dev) for k, v in par.items()})
         interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
         kw = dict(cosmo=cosmo, cosmo_fid=fid) if engine != 'wallish2018' else {}
-        out = cp.PowerSpectrumBAOFilter(interp, engine=engine, **kw).pknow
+        if engine not in filters:
+            filters[engine] = cp.PowerSpectrumBAOFilter(interp, engine=engine, **kw)
+        else:
+            filters[engine](interp, cosmo=cosmo if kw else None)
+        out = filters[engine].pknow
         torch.cuda.synchronize()
         return out
 
