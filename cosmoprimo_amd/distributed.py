@@ -53,3 +53,46 @@ def gather_rows(local, n_total=None, group=None):
     if n_total is not None and out.shape[0] != n_total:
         raise ValueError('gathered {} rows, expected {}'.format(out.shape[0], n_total))
     return out
+
+
+def shard_params(params, rank=None, world_size=None):
+    """
+    This rank's block of a batch of cosmologies: every array-valued parameter (numpy array or torch tensor with one entry per cosmology) is
+    cut to the rank's contiguous block, scalars and other values are passed through.  For the batch drivers::
+
+        calculator = get_calculator(Cosmology(engine='eisenstein_hu'))
+        mine = calculator(**shard_params(dict(Omega_m=Omega_m, h=h)))        # no communication
+        full = gather_arrays(mine, n_total=Omega_m.size)                     # optional: replicate the results
+    """
+    import numpy as np
+    sizes = {int(v.shape[0]) for v in params.values() if hasattr(v, 'shape') and len(v.shape) >= 1}
+    if len(sizes) > 1:
+        raise ValueError('array-valued parameters must share one length, got {}'.format(sorted(sizes)))
+    if not sizes:
+        return dict(params)
+    return {name: shard(v, rank=rank, world_size=world_size) if hasattr(v, 'shape') and len(v.shape) >= 1 else v for name, v in params.items()}
+
+
+def gather_arrays(local, n_total=None, batch_keys=None, device=None, group=None):
+    """
+    All-gather a dictionary of result arrays (as returned by a calculator on this rank's block) along the batch axis.  ``batch_keys``: the
+    entries that carry the batch axis (default: those whose leading dimension equals this rank's block size; grids shared by the batch such
+    as 'fourier.k' are returned as they are).  numpy in, numpy out: arrays travel through ``device`` (default: CPU for gloo, the current GPU
+    for nccl / RCCL).
+    """
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+    if batch_keys is None:
+        nloc = {int(np.shape(v)[0]) for v in local.values() if np.ndim(v) >= 1}
+        if n_total is None:
+            raise ValueError('give n_total or batch_keys')
+        start, stop = shard_range(n_total, dist.get_rank(group), dist.get_world_size(group))
+        batch_keys = [name for name, v in local.items() if np.ndim(v) >= 1 and np.shape(v)[0] == stop - start]
+    out = dict(local)
+    for name in sorted(batch_keys):      # same order on every rank
+        t = torch.as_tensor(np.ascontiguousarray(local[name])).to(device)
+        out[name] = gather_rows(t, n_total=n_total, group=group).cpu().numpy()
+    return out

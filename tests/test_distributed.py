@@ -24,7 +24,7 @@ WORKER = textwrap.dedent('''
     import os, sys
     import numpy as np, torch, torch.distributed as dist
     sys.path.insert(0, {root!r})
-    from cosmoprimo_amd.distributed import shard, shard_range, gather_rows
+    from cosmoprimo_amd.distributed import shard, shard_range, gather_rows, shard_params, gather_arrays
     dist.init_process_group('gloo')
     rank, world = dist.get_rank(), dist.get_world_size()
     n = 11                                  # odd: shards of 6 and 5 rows
@@ -35,6 +35,20 @@ WORKER = textwrap.dedent('''
     result = mine * 2. + 1.                 # stands for the per-row transform: no communication
     out = gather_rows(result, n_total=n)    # the one collective
     assert torch.equal(out, full * 2. + 1.), (rank, out)
+    # a batch of cosmologies through a (stand-in) calculator: parameters cut per rank, results gathered, shared grids left alone
+    Om, h = np.linspace(0.2, 0.4, n), np.linspace(0.6, 0.8, n)
+    mine = shard_params(dict(Omega_m=Om, h=torch.as_tensor(h), n_s=0.96))
+    assert mine['n_s'] == 0.96 and mine['Omega_m'].shape == (stop - start,) and torch.equal(mine['h'], torch.as_tensor(h)[start:stop])
+    zgrid = np.linspace(0., 1., 4)
+    local = {{'background.z': zgrid, 'background.d': np.outer(mine['Omega_m'] * mine['h'].numpy(), zgrid), 'thermodynamics.rs': mine['Omega_m'] * 100.}}
+    full = gather_arrays(local, n_total=n)
+    assert np.array_equal(full['background.z'], zgrid) and np.allclose(full['background.d'], np.outer(Om * h, zgrid))
+    assert np.allclose(full['thermodynamics.rs'], Om * 100.)
+    try:
+        shard_params(dict(a=np.zeros(3), b=np.zeros(4)))
+        raise SystemExit('no error for ragged parameters')
+    except ValueError:
+        pass
     dist.barrier()
     if rank == 0:
         print('OK', world)
