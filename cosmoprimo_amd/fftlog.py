@@ -234,6 +234,14 @@ class FFTlog(dv.Copyable):
         self._setup(kernel, q, minfolds=minfolds, lowring=lowring, xy=xy, check_level=check_level)
         self.set_fft_engine(engine, **engine_kwargs)
 
+    def _device_copy(self, name, array, dev):
+        """Device tensor of a host table of this plan (output coordinates, phases), copied once per device instead of on every call."""
+        cache = self.__dict__.setdefault('_device_tables', {})
+        key = (name, dev.index)
+        if key not in cache:
+            cache[key] = _torch().as_tensor(array, device=dev)
+        return cache[key]
+
     def set_fft_engine(self, engine='mi355x', **engine_kwargs):
         """Select the engine (reference fftlog.py:119-132); see :func:`get_fft_engine`."""
         self._engine = get_fft_engine(engine, size=self.padded_size, nparallel=self.nparallel, **engine_kwargs)
@@ -398,18 +406,19 @@ class FFTlog(dv.Copyable):
         if finite is not None:
             tout = torch.where(finite, tout, torch.full_like(tout, float('nan')))
         if self._phase is not None:
-            tout = tout * torch.as_tensor(self._phase, device=dev)[:, None]
+            tout = tout * self._device_copy('phase', self._phase, dev)[:, None]
         y = self.padded_y if keep_padding else self.y
         if not self.inparallel:
             y = y[0]
             tout = tout.reshape(fshape[:-1] + (nout,))
         if is_torch:
-            return torch.as_tensor(y, device=dev), tout
+            return self._device_copy('y_padded' if keep_padding else 'y' + ('' if self.inparallel else '0'), y, dev), tout
         return y, dv.to_host(tout)
 
     def inv(self):
         """Inverse the transform, in place (reference fftlog.py:243-248, including its padded_x / padded_y quirk)."""
         self.x, self.y = self.y, self.x
+        self.__dict__.pop('_device_tables', None)     # device copies of the output coordinates
         self.padded_x, self.padded_y = self.y, self.x
         self.padded_prefactor, self.padded_postfactor = 1 / self.padded_postfactor, 1 / self.padded_prefactor
         self.padded_u = 1 / self.padded_u.conj()
