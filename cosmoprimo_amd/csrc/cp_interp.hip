@@ -75,3 +75,80 @@ extern "C" int cp_interp_linear(const double* d_xp, const double* d_fp, long lon
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_interp_linear: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
+
+// ---- cubic splines at many points: one lane per query ------------------------------------------------------------------------------------
+// The operator form of cp_spline_apply (a band of weights per query, shared by all rows) suits thousands of rows on a fixed set of queries.
+// The opposite shape -- one or a few splines evaluated at 1e6-1e9 points, DistanceToRedshift for a catalogue (reference utils.py:275-316) --
+// is a search plus one cubic per point: Hermite form on the interval [x_k, x_k+1] from the values and the knot first derivatives
+// (the derivatives are cp_spline_apply with nu = 1 at the knots themselves, so any boundary condition of cp_spline_operator is available).
+namespace {
+
+__global__ __launch_bounds__(256) void spline_points_kernel(const double* __restrict__ xk, const double* __restrict__ y, const double* __restrict__ s,
+                                                            long long n, int ncol, int stride, int ncoarse, const double* __restrict__ xq,
+                                                            double* __restrict__ out, long long nq, int nu, int extrapolate) {
+    extern __shared__ double coarse[];   // coarse[i] = xk[i * stride]
+    for (int i = threadIdx.x; i < ncoarse; i += 256) coarse[i] = xk[(long long)i * stride];
+    __syncthreads();
+    const double x0 = coarse[0], xn = xk[n - 1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long long)gridDim.x * blockDim.x) {
+        const double v = xq[i];
+        const bool inside = v >= x0 && v <= xn;
+        if (!(inside || (extrapolate && v == v))) {   // outside without extrapolation, or NaN
+            for (int c = 0; c < ncol; ++c) out[(long long)c * nq + i] = __builtin_nan("");
+            continue;
+        }
+        long long lo;
+        if (v <= x0) lo = 0;
+        else if (v >= xn) lo = n - 2;
+        else {
+            int clo = 0, chi = ncoarse;
+            while (chi - clo > 1) {
+                const int mid = (clo + chi) >> 1;
+                if (coarse[mid] <= v) clo = mid; else chi = mid;
+            }
+            lo = (long long)clo * stride;
+            long long hi = lo + stride < n - 1 ? lo + stride : n - 1;
+            while (hi - lo > 1) {
+                const long long mid = (lo + hi) >> 1;
+                if (xk[mid] <= v) lo = mid; else hi = mid;
+            }
+        }
+        const double h = xk[lo + 1] - xk[lo], u = v - xk[lo];
+        for (int c = 0; c < ncol; ++c) {
+            const double* yc = y + (long long)c * n;
+            const double* sc = s + (long long)c * n;
+            // PPoly coefficients of the interval as scipy's CubicSpline forms them: t = (s_k + s_k+1 - 2 slope) / h
+            const double slope = (yc[lo + 1] - yc[lo]) / h;
+            const double t = (sc[lo] + sc[lo + 1] - 2. * slope) / h;
+            const double c3 = t / h, c2 = (slope - sc[lo]) / h - t, c1 = sc[lo], c0 = yc[lo];
+            double r;
+            if (nu == 0) r = c0 + u * (c1 + u * (c2 + u * c3));
+            else if (nu == 1) r = c1 + u * (2. * c2 + u * 3. * c3);
+            else r = 2. * c2 + 6. * c3 * u;
+            out[(long long)c * nq + i] = r;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_spline_points(const double* d_xk, const double* d_y, const double* d_s, long long n, int ncol, const double* d_xq, double* d_out,
+                                long long nq, int nu, int extrapolate, int device, void* stream) {
+    if (n < 2 || ncol < 0 || nq < 0 || nu < 0 || nu > 2) return cp::fail(CP_EINVAL, "cp_spline_points: need n >= 2, nu in {0, 1, 2} and non-negative counts");
+    if (nq == 0 || ncol == 0) return CP_OK;
+    if (!d_xk || !d_y || !d_s || !d_xq || !d_out) return cp::fail(CP_EINVAL, "cp_spline_points: null pointer");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_points: cannot select device %d", device);
+    int stride = 32;
+    while ((n + stride - 1) / stride > 4096) stride *= 2;
+    const int ncoarse = (int)((n + stride - 1) / stride);
+    const long long blocks = (nq + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+    hipLaunchKernelGGL(spline_points_kernel, dim3(grid), dim3(256), ncoarse * sizeof(double), static_cast<hipStream_t>(stream), d_xk, d_y, d_s, n, ncol, stride,
+                       ncoarse, d_xq, d_out, nq, nu, extrapolate);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_points: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

@@ -19,6 +19,7 @@ import inspect
 
 import numpy as np
 
+from . import _lib
 from . import _device as dv
 from .fftlog import CorrelationToPower, PowerToCorrelation, TophatVariance
 from .spline import LinearOperator, dense_operator
@@ -279,9 +280,44 @@ class Interpolator1D(dv.Copyable):
         # any NaN in a column (e.g. log of a negative P) makes that whole column NaN, without raising (reference jax.py:161-172)
         self._nan_rows = dv.torch().isnan(self._rows).any(dim=1)
 
+    # more queries than this go through the point-evaluation kernel instead of a (queries x knots) operator
+    _npoints_operator = 16384
+
+    def _call_points(self, x, bounds_error, dx):
+        """Few splines at very many points (``cp_spline_points``): the queries stay where they are (a device tensor is not read back), the
+        splines are given by their values and knot derivatives (the nu = 1 operator at the knots, applied once)."""
+        torch = dv.torch()
+        like_torch = dv.is_torch(x)
+        dtype = dv.float_dtype(x)
+        xq = dv.to_device(x, self.device)
+        shape = tuple(xq.shape) + self.shape
+        xq = xq.reshape(-1)
+        if bounds_error:
+            lo, hi = torch.aminmax(xq)
+            if bool((lo < self.xmin) | (hi > self.xmax)):
+                raise ValueError('input outside of extrapolation range ({}, {})'.format(self.xmin, self.xmax))
+        if self.interp_x == 'log':
+            xq = torch.log10(xq)
+        slopes = self.__dict__.get('_knot_slopes', None)
+        if slopes is None:
+            slopes = self._knot_slopes = LinearOperator.spline(self._x, self._x, bc='natural', nu=1, device=self.device)(self._rows).contiguous()
+            self._x_device = dv.to_device(self._x, self.device)
+        out = torch.empty((self._rows.shape[0], xq.numel()), dtype=torch.float64, device=self.device)
+        _lib.check(_lib.load().cp_spline_points(self._x_device.data_ptr(), self._rows.data_ptr(), slopes.data_ptr(), self._x.size, self._rows.shape[0],
+                                                xq.data_ptr(), out.data_ptr(), xq.numel(), int(dx), int(self.extrap), self.device.index,
+                                                dv.stream_of(self.device)))
+        if bool(self._nan_rows.any()):
+            out = torch.where(self._nan_rows[:, None], torch.full_like(out, float('nan')), out)
+        if self.interp_fun == 'log':
+            out = 10**out
+        out = out.T if out.shape[0] > 1 else out.reshape(-1, 1)
+        return _finish(out, dtype, like_torch, shape)
+
     def __call__(self, x, bounds_error=False, dx=0):
         like_torch = dv.is_torch(x)
         dtype = dv.float_dtype(x)
+        if self.k == 3 and (x.numel() if like_torch else np.size(x)) > self._npoints_operator:
+            return self._call_points(x, bounds_error, dx)
         xh = _host(x)
         shape = xh.shape + self.shape
         xh = xh.ravel()

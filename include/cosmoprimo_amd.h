@@ -248,6 +248,13 @@ int cp_dst_plan_destroy(cp_dst_plan* plan);
  * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */
 int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const double* d_x, double* d_out, long long nx, int device, void* stream);
 
+/* ---- cubic splines at many points (replaces Interpolator1D.__call__ = CubicSpline(x, fun)(xq) when there are few splines and 1e6-1e9 queries:
+ *      DistanceToRedshift, utils.py:275-316; jax.py:169-175) ----
+ * d_xk : (n) ascending knots; d_y, d_s : (ncol, n) values and first derivatives at the knots (cp_spline_apply with nu = 1 at the knots);
+ * d_xq : (nq) queries; d_out : (ncol, nq).  nu : derivative order 0, 1, 2.  Outside [xk[0], xk[n-1]]: the end polynomials if extrapolate, else NaN. */
+int cp_spline_points(const double* d_xk, const double* d_y, const double* d_s, long long n, int ncol, const double* d_xq, double* d_out, long long nq, int nu,
+                     int extrapolate, int device, void* stream);
+
 /* ---- row screening for the callers of cp_fftlog_execute / cp_dst_execute (two rows share one complex FFT there, so a non-finite row
  *      would reach its pair partner, unlike the reference's row-by-row numpy.fft / scipy.fftpack calls, fftlog.py:540-560) ----
  * d_x : (nrows, n) device.  d_ok[row] = 1 if every entry of the row is finite (and > 0 if require_positive: the fused log map of

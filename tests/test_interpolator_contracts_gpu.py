@@ -130,3 +130,46 @@ def test_linear_order():
     np.testing.assert_allclose(pk2(xin), 10**interp1d(knots, values, kind='quadratic')(np.log10(xin)), rtol=1e-10)
     with pytest.raises(NotImplementedError):
         it.Interpolator1D(x, fun, k=4)
+
+
+def test_many_points_path():
+    """Interpolator1D at more than 16 384 points takes the point-evaluation kernel (cp_spline_points) instead of a (queries x knots) operator:
+    same numbers, queries that live on the device stay there; DistanceToRedshift for a catalogue (reference tests/test_utils.py::test_redshift_array)."""
+    import torch
+    import cosmoprimo_amd.interpolator as it
+    from cosmoprimo_amd.utils import DistanceToRedshift
+    from cosmoprimo_amd.fiducial import DESI
+    from scipy.interpolate import CubicSpline
+    rng = np.random.default_rng(9)
+    x = np.sort(rng.uniform(0.1, 10., 300))
+    fun = rng.uniform(1., 2., (300, 3))
+    xq = np.concatenate([[0.05, 20.], rng.uniform(0.1, 10., 40000), x[[0, -1, 7]]])
+    for extrap in (False, True):
+        interp = it.Interpolator1D(x, fun, extrap=extrap)
+        got = interp(xq)
+        ref = CubicSpline(x, fun, axis=0, bc_type='natural', extrapolate=True)(xq)
+        if not extrap:
+            ref[(xq < x[0]) | (xq > x[-1])] = np.nan
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-13, equal_nan=True)
+        for nu in (1, 2):
+            refd = CubicSpline(x, fun, axis=0, bc_type='natural', extrapolate=True)(xq, nu=nu)
+            if not extrap:
+                refd[(xq < x[0]) | (xq > x[-1])] = np.nan
+            np.testing.assert_allclose(interp(xq, dx=nu), refd, rtol=1e-9, atol=1e-9, equal_nan=True)
+        saved, it.Interpolator1D._npoints_operator = it.Interpolator1D._npoints_operator, 10**9      # the operator path on the same queries
+        try:
+            np.testing.assert_allclose(got, interp(xq), rtol=1e-12, atol=1e-12, equal_nan=True)
+        finally:
+            it.Interpolator1D._npoints_operator = saved
+    loglog = it.Interpolator1D(x, fun[:, 0], interp_x='log', interp_fun='log')
+    xin = np.clip(xq, x[0], x[-1])
+    np.testing.assert_allclose(loglog(xin), 10**CubicSpline(np.log10(x), np.log10(fun[:, 0]), bc_type='natural')(np.log10(xin)), rtol=1e-11)
+    with pytest.raises(ValueError):
+        it.Interpolator1D(x, fun)(xq, bounds_error=True)
+    cosmo = DESI()
+    redshift = DistanceToRedshift(distance=cosmo.comoving_radial_distance, zmax=10., nz=4096)
+    z = torch.rand(2000000, device='cuda:0', dtype=torch.float64) * 2.
+    back = redshift(cosmo.comoving_radial_distance(z))
+    assert back.is_cuda and back.shape == z.shape and float((back - z).abs().max()) < 1e-6
+    zh = np.random.default_rng(1).uniform(0., 2., 10000)
+    assert np.allclose(redshift(cosmo.comoving_radial_distance(zh)), zh, atol=1e-6)

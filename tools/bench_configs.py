@@ -169,7 +169,15 @@ def main():
         line['cpu_baseline'] = baseline((time.perf_counter() - t0) / zh.size, 'redshifts/s', 'numpy.interp, 2e6 redshifts (the reference\'s own call)')
         line['cpu_baseline']['kind'] = 'reference'
     print(json.dumps(line))
-    del zcat
+    # and back: distance -> redshift for the same catalogue (utils.DistanceToRedshift: a cubic spline of z(D_C) at every distance)
+    from cosmoprimo_amd.utils import DistanceToRedshift
+    dcat = tab.comoving_radial_distance(zcat)
+    redshift = DistanceToRedshift(distance=tab.comoving_radial_distance, zmax=10., nz=4096)
+    dt = timed(lambda: redshift(dcat), 5, torch)
+    err = float((redshift(dcat) - zcat).abs().max())
+    print(json.dumps({'config': 'distance_to_redshift', 'workload': 'DistanceToRedshift (4096-knot natural spline) at %d resident distances' % nb,
+                      'value': nb / dt, 'unit': 'distances/s', 'ms': dt * 1e3, 'algorithmic_GBps': nb * 16 / dt / 1e9, 'max_abs_redshift_error': err}))
+    del zcat, dcat
     torch.cuda.empty_cache()
 
     # f4: the batch driver (emulators.get_calculator): params -> every section's arrays on the reference's default grids, D2H included
