@@ -1037,8 +1037,29 @@ class BaseBackground(BaseSection):
             return dv.torch().as_tensor(T0, device=zp1.device, dtype=zp1.dtype).reshape((-1,) + (1,) * zp1.ndim) * zp1
         return T0.astype(zp1.dtype).reshape((-1,) + (1,) * np.ndim(zp1)) * zp1
 
+    # one cosmology, more redshifts than this (a catalogue): the spline the kernel evaluates per sample is built once and evaluated per point
+    _ncatalogue = 16384
+
+    def _table_spline(self, kind):
+        """The reference's own representation of D_C(z) / time(z) (cosmology.py:2011, 2036-2042): the natural cubic spline through the values at
+        the interpolation knots.  The background kernel evaluates that spline per (cosmology, z) sample from a fresh quadrature -- the right
+        shape for batches of cosmologies; for ONE cosmology and a catalogue of redshifts the table is computed once (one launch on the knots)
+        and the spline evaluated per point (``cp_spline_points``): same numbers to rounding, 237 E(z) evaluations per redshift less."""
+        cache = self.__dict__.setdefault('_table_splines', {})
+        if kind not in cache:
+            from .interpolator import Interpolator1D
+            knots = np.empty(400 if kind == 'time' else 119)
+            _lib.check(_lib.load().cp_background_knots(_lib.as_double_p(knots), knots.size))
+            cache[kind] = Interpolator1D(knots, self._eval(kind, knots), k=3, extrap=False, assume_sorted=True, device=self.device)
+        return cache[kind]
+
+    def _is_catalogue(self, z):
+        return self._engine.batch_size is None and (z.numel() if dv.is_torch(z) else np.size(z)) > self._ncatalogue
+
     def comoving_radial_distance(self, z):
         """Comoving radial distance, in Mpc/h (cosmology.py:2027-2042)."""
+        if self._is_catalogue(z):
+            return self._table_spline('comoving_radial_distance')(z)
         return self._eval('comoving_radial_distance', z)
 
     def angular_diameter_distance(self, z):

@@ -144,3 +144,33 @@ def test_densities(golden):
     gb = DefaultBackground(both.engine).growth_factor(g['zg'])
     assert gb.shape == (2, g['zg'].size)
     np.testing.assert_allclose(gb[1], DefaultBackground(cp.Cosmology(engine='eisenstein_hu', Omega_m=0.36, h=0.64).engine).growth_factor(g['zg']), rtol=1e-13)
+
+
+def test_catalogue_path():
+    """One cosmology at more than 16 384 redshifts: the distance table is built once and splined per point (cp_spline_points) -- the same
+    natural spline the kernel evaluates per sample, so the same numbers; NaN outside the knots, dtype and container of the input kept."""
+    import torch
+    from cosmoprimo_amd.cosmology import BaseBackground
+    from cosmoprimo_amd.fiducial import DESI
+    rng = np.random.default_rng(12)
+    for cosmo in (cp_mod().Cosmology(engine='eisenstein_hu', Omega_k=0.05, w0_fld=-0.9, wa_fld=0.1), DESI()):
+        ba = cosmo.get_background()
+        z = np.concatenate([rng.uniform(0., 5., 50000), 10.**rng.uniform(-6, 3.9, 5000), [0., -0.1, 2e4]])
+        fast = ba.comoving_radial_distance(z)
+        saved, BaseBackground._ncatalogue = BaseBackground._ncatalogue, 10**9
+        try:
+            slow = ba.comoving_radial_distance(z)
+        finally:
+            BaseBackground._ncatalogue = saved
+        assert np.array_equal(np.isnan(fast), np.isnan(slow)) and np.isnan(fast[-2:]).all() and fast[-3] == 0.
+        np.testing.assert_allclose(fast, slow, rtol=1e-11, atol=1e-12 * np.nanmax(slow), equal_nan=True)
+        zt = torch.as_tensor(z[:40000], device='cuda:0', dtype=torch.float32)
+        out = ba.comoving_radial_distance(zt)
+        assert out.is_cuda and out.dtype == torch.float32 and out.shape == zt.shape
+        out = ba.comoving_radial_distance(z[:55000].reshape(5, 11000).astype('f4'))
+        assert out.dtype == np.float32 and out.shape == (5, 11000)
+
+
+def cp_mod():
+    import cosmoprimo_amd
+    return cosmoprimo_amd
