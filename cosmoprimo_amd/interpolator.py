@@ -316,7 +316,7 @@ class Interpolator1D(dv.Copyable):
     def __call__(self, x, bounds_error=False, dx=0):
         like_torch = dv.is_torch(x)
         dtype = dv.float_dtype(x)
-        if self.k == 3 and (x.numel() if like_torch else np.size(x)) > self._npoints_operator:
+        if self.k == 3 and self._rows.shape[0] <= 64 and (x.numel() if like_torch else np.size(x)) > self._npoints_operator:     # few splines, many points
             return self._call_points(x, bounds_error, dx)
         xh = _host(x)
         shape = xh.shape + self.shape
