@@ -280,7 +280,7 @@ class Interpolator1D(dv.Copyable):
         # any NaN in a column (e.g. log of a negative P) makes that whole column NaN, without raising (reference jax.py:161-172)
         self._nan_rows = dv.torch().isnan(self._rows).any(dim=1)
 
-    # more queries than this go through the point-evaluation kernel instead of a (queries x knots) operator
+    # more queries than this (or more than 4 M operator entries) go through the point-evaluation kernel instead of a (queries x knots) operator
     _npoints_operator = 16384
 
     def _call_points(self, x, bounds_error, dx):
@@ -316,7 +316,9 @@ class Interpolator1D(dv.Copyable):
     def __call__(self, x, bounds_error=False, dx=0):
         like_torch = dv.is_torch(x)
         dtype = dv.float_dtype(x)
-        if self.k == 3 and self._rows.shape[0] <= 64 and (x.numel() if like_torch else np.size(x)) > self._npoints_operator:     # few splines, many points
+        nq = x.numel() if like_torch else np.size(x)
+        if self.k == 3 and self._rows.shape[0] <= 64 and (nq > self._npoints_operator or (nq > 1024 and nq * self._x.size > (1 << 22))):
+            # few splines, and a (queries x knots) operator that would be large: evaluate point by point
             return self._call_points(x, bounds_error, dx)
         xh = _host(x)
         shape = xh.shape + self.shape
