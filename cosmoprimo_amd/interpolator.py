@@ -370,10 +370,51 @@ class Interpolator2D(dv.Copyable):
         # FITPACK propagates any NaN datum (e.g. the log of a negative P) to the whole surface (reference tests/test_interpolator.py:328-337)
         self._has_nan = bool(torch.isnan(self._fun).any())
 
+    def _call_many_x(self, x, y, bounds_error):
+        """Grid evaluation at very many x (a mesh of wavenumbers) and a few y: the y direction first (operator, few queries), then one spline
+        along x per requested y evaluated point by point (``cp_spline_points``); x may live on the device and is not read back."""
+        torch = dv.torch()
+        like_torch = dv.is_torch(x) or dv.is_torch(y)
+        dtype = dv.float_dtype(x, y)
+        yh = _host(y)
+        xq = dv.to_device(x, self.device)
+        shape = tuple(xq.shape) + yh.shape
+        xq, yh = xq.reshape(-1), yh.ravel()
+        mask_y, = _mask_bounds([yh], [(self.ymin, self.ymax)], bounds_error=bounds_error)
+        mask_x = (xq >= self.xmin) & (xq <= self.xmax)
+        if bounds_error and not bool(mask_x.all()):
+            raise ValueError('input outside of extrapolation range ({}, {})'.format(self.xmin, self.xmax))
+        if self._has_nan:
+            return _finish(torch.full((xq.numel(), yh.size), float('nan'), dtype=torch.float64, device=self.device), dtype, like_torch, shape)
+        if self.interp_x == 'log':
+            xq = torch.log10(xq)
+        opy = _cached_operator(('i2y', self._y.tobytes(), yh.tobytes(), self.device.index),
+                               lambda: LinearOperator.spline(self._y, yh, bc='not-a-knot', extrapolate=True, device=self.device))
+        rows = opy(self._fun).T.contiguous()                      # (nyq, nx): the surface along x at every requested y
+        slope_op = _cached_operator(('i2s', self._x.tobytes(), self.device.index),
+                                    lambda: LinearOperator.spline(self._x, self._x, bc='not-a-knot', nu=1, extrapolate=True, device=self.device))
+        slopes = slope_op(rows).contiguous()
+        xk = self.__dict__.get('_x_device', None)
+        if xk is None:
+            xk = self._x_device = dv.to_device(self._x, self.device)
+        out = torch.empty((rows.shape[0], xq.numel()), dtype=torch.float64, device=self.device)
+        _lib.check(_lib.load().cp_spline_points(xk.data_ptr(), rows.data_ptr(), slopes.data_ptr(), self._x.size, rows.shape[0], xq.data_ptr(), out.data_ptr(),
+                                                xq.numel(), 0, 1, self.device.index, dv.stream_of(self.device)))
+        out = out.T
+        if self.interp_fun == 'log':
+            out = 10**out
+        if not self.extrap:
+            mask = mask_x[:, None] & torch.as_tensor(mask_y, device=self.device)[None, :]
+            out = torch.where(mask, out, torch.full_like(out, float('nan')))
+        return _finish(out, dtype, like_torch, shape)
+
     def __call__(self, x, y, grid=True, bounds_error=False):
         torch = dv.torch()
         like_torch = dv.is_torch(x) or dv.is_torch(y)
         dtype = dv.float_dtype(x, y)
+        nxq, nyq = (v.numel() if dv.is_torch(v) else np.size(v) for v in (x, y))
+        if grid and 0 < nyq <= 64 and (nxq > Interpolator1D._npoints_operator or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
+            return self._call_many_x(x, y, bounds_error)
         xh, yh = _host(x), _host(y)
         shape = xh.shape + yh.shape if grid else xh.shape
         xh, yh = xh.ravel(), yh.ravel()

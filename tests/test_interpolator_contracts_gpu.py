@@ -173,3 +173,38 @@ def test_many_points_path():
     assert back.is_cuda and back.shape == z.shape and float((back - z).abs().max()) < 1e-6
     zh = np.random.default_rng(1).uniform(0., 2., 10000)
     assert np.allclose(redshift(cosmo.comoving_radial_distance(zh)), zh, atol=1e-6)
+
+
+def test_many_points_2d():
+    """Interpolator2D / tabulated PowerSpectrumInterpolator2D at a mesh of wavenumbers (more than 16 384) and a few redshifts: the y direction by
+    operator, the x direction point by point -- RectBivariateSpline's numbers, device-resident queries left on the device."""
+    import torch
+    import cosmoprimo_amd as cp
+    import cosmoprimo_amd.interpolator as it
+    from scipy.interpolate import RectBivariateSpline
+    rng = np.random.default_rng(4)
+    x, y = np.sort(rng.uniform(0., 5., 60)), np.linspace(0., 2., 12)
+    fun = np.sin(x)[:, None] * np.cos(y)[None, :] + 0.1 * rng.standard_normal((60, 12))
+    xq, yq = np.concatenate([rng.uniform(x[0], x[-1], 30000), [x[0], x[-1], -1., 7.]]), np.array([0., 0.33, 1.7, 2., 2.5])
+    order = np.argsort(xq)
+    ref = np.empty((xq.size, yq.size))
+    ref[order] = RectBivariateSpline(x, y, fun, kx=3, ky=3, s=0)(xq[order], yq, grid=True)
+    for extrap in (True, False):
+        interp = it.Interpolator2D(x, y, fun, extrap=extrap)
+        got = interp(xq, yq)
+        expected = ref.copy()
+        if not extrap:
+            expected[(xq < x[0]) | (xq > x[-1])] = np.nan
+            expected[:, (yq < y[0]) | (yq > y[-1])] = np.nan
+        assert got.shape == (xq.size, yq.size) and np.array_equal(np.isnan(got), np.isnan(expected))
+        keep = (xq >= x[0]) & (xq <= x[-1])        # (FITPACK clamps outside its knots; the reference masks there unless extrap)
+        np.testing.assert_allclose(got[keep][:, :4], expected[keep][:, :4], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(got[:20], interp(xq[:20], yq), rtol=1e-11, atol=1e-13, equal_nan=True)      # the operator path on a few of them
+    k, z = np.geomspace(1e-4, 10., 200), np.linspace(0., 2., 8)
+    table = cp.Cosmology(engine='eisenstein_hu').get_fourier().pk_interpolator()(k, z)
+    pk2d = cp.PowerSpectrumInterpolator2D(k, z, table)
+    kmesh = torch.as_tensor(10.**rng.uniform(-3.9, 0.9, 300000), device='cuda:0')
+    out = pk2d(kmesh, np.array([0.5, 1.]))
+    assert out.is_cuda and out.shape == (300000, 2)
+    some = kmesh[:50].cpu().numpy()
+    np.testing.assert_allclose(out[:50].cpu().numpy(), pk2d(some, np.array([0.5, 1.])), rtol=1e-10)
