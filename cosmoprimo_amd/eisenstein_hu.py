@@ -145,7 +145,7 @@ class Fourier(BaseSection):
             return g
 
         def pk_callable(k):
-            return self._pk0_device(np.asarray(k, dtype='f8'))
+            return self._pk0_device(k if dv.is_torch(k) else np.asarray(k, dtype='f8'))
 
         interp = PowerSpectrumInterpolator2D.from_callable(pk_callable=pk_callable, growth_factor_sq=growth_factor_sq, device=device, **kwargs)
         # batched cosmologies: P_c(k * kscale_c) in one launch (used by the brieden2022 filter, one rs_drag ratio per cosmology)

@@ -693,6 +693,8 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         torch = dv.torch()
         if self.is_from_callable:
             mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
+            if dv.is_torch(mask_k):      # wavenumbers that live on the device (a mesh): masks there too
+                mask_z = torch.as_tensor(mask_z, device=mask_k.device)
             mask = mask_k[:, None] & mask_z if grid else mask_k & mask_z
             if self.growth_factor_sq is not None:
                 tmp = dv.to_device(self._interp(kh), self.device)                     # (..., nk)
@@ -703,7 +705,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                     tmp = tmp[..., :, None].expand(tmp.shape + (zh.size,))
             else:
                 tmp = dv.to_device(self._interp(kh, zh, grid=grid), self.device)
-            out = tmp if mask.all() else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+            out = tmp if bool(mask.all()) else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
         else:
             is2d = self._pk.shape[1] > 1
             mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
@@ -731,8 +733,12 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         """Evaluate at wavenumbers ``k`` and redshifts ``z``: shape (batch...) + k.shape + z.shape (``grid``) or + k.shape (pairs)."""
         like_torch = dv.is_torch(k) or dv.is_torch(z)
         dtype = dv.float_dtype(k, z)
-        kh, zh = _host(k), _host(z)
-        out = self._eval_device(kh.ravel(), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error)
+        zh = _host(z)
+        if self.is_from_callable and self.growth_factor_sq is not None and dv.is_torch(k) and k.is_cuda and k.numel() > Interpolator1D._npoints_operator:
+            kh = k.to(dv.torch().float64)      # a mesh of wavenumbers on the device goes to the callable as it is (no copy to the host and back)
+        else:
+            kh = _host(k)
+        out = self._eval_device(kh.reshape(-1), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error)
         nlead = out.ndim - (2 if grid else 1)
         shape = tuple(out.shape[:nlead]) + (kh.shape + zh.shape if grid else kh.shape)
         return _finish(out, dtype, like_torch, shape)

@@ -208,3 +208,22 @@ def test_many_points_2d():
     assert out.is_cuda and out.shape == (300000, 2)
     some = kmesh[:50].cpu().numpy()
     np.testing.assert_allclose(out[:50].cpu().numpy(), pk2d(some, np.array([0.5, 1.])), rtol=1e-10)
+
+
+def test_device_mesh_through_callable():
+    """P(k, z) of an analytic engine at a mesh of wavenumbers that lives on the device: evaluated there (no copy of k to the host and back),
+    same numbers as for the host array, NaN outside the extrapolation range."""
+    import torch
+    import cosmoprimo_amd as cp
+    pk = cp.Cosmology(engine='eisenstein_hu').get_fourier().pk_interpolator()
+    rng = np.random.default_rng(6)
+    kh = np.concatenate([10.**rng.uniform(-6.5, 1.9, 100000), [1e-9, 1e3]])
+    z = np.array([0., 1.])
+    ref = pk(kh, z)
+    out = pk(torch.as_tensor(kh, device='cuda:0'), z)
+    assert out.is_cuda and out.shape == (kh.size, 2)
+    assert np.array_equal(out.cpu().numpy(), ref, equal_nan=True) and np.isnan(ref[-2:]).all() and np.isfinite(ref[:-2]).all()
+    mesh = torch.as_tensor(kh[:-2], device='cuda:0').reshape(100, 1000)
+    assert pk(mesh, 0.5).shape == (100, 1000) and pk(mesh.to(torch.float32), 0.5).dtype == torch.float32
+    with pytest.raises(ValueError):
+        pk(torch.as_tensor(kh, device='cuda:0'), z, bounds_error=True)
