@@ -489,6 +489,11 @@ class BaseCosmoParams(dv.Copyable):
     @property
     def batch_size(self):
         """Number of cosmologies when parameters are arrays, else None."""
+        if '_batch_size' not in self.__dict__:      # parameters do not change after construction
+            self.__dict__['_batch_size'] = self._find_batch_size()
+        return self.__dict__['_batch_size']
+
+    def _find_batch_size(self):
         for name, v in self._params.items():
             if name in _default_calculation_parameters:   # z_pk, modes ...: arrays that are not batches
                 continue
@@ -1037,13 +1042,12 @@ class BaseBackground(BaseSection):
             return dv.torch().as_tensor(T0, device=zp1.device, dtype=zp1.dtype).reshape((-1,) + (1,) * zp1.ndim) * zp1
         return T0.astype(zp1.dtype).reshape((-1,) + (1,) * np.ndim(zp1)) * zp1
 
-    # one cosmology, more redshifts than this (a catalogue): the spline the kernel evaluates per sample is built once and evaluated per point
-    _ncatalogue = 16384
+    _use_table_spline = True      # (tests switch it off to compare with the per-sample kernel)
 
     def _table_spline(self, kind):
         """The reference's own representation of D_C(z) / time(z) (cosmology.py:2011, 2036-2042): the natural cubic spline through the values at
         the interpolation knots.  The background kernel evaluates that spline per (cosmology, z) sample from a fresh quadrature -- the right
-        shape for batches of cosmologies; for ONE cosmology and a catalogue of redshifts the table is computed once (one launch on the knots)
+        shape for batches of cosmologies; for ONE cosmology (a few redshifts or a catalogue) the table is computed once (one launch on the knots)
         and the spline evaluated per point (``cp_spline_points``): same numbers to rounding, 237 E(z) evaluations per redshift less."""
         cache = self.__dict__.setdefault('_table_splines', {})
         if kind not in cache:
@@ -1051,14 +1055,12 @@ class BaseBackground(BaseSection):
             knots = np.empty(400 if kind == 'time' else 119)
             _lib.check(_lib.load().cp_background_knots(_lib.as_double_p(knots), knots.size))
             cache[kind] = Interpolator1D(knots, self._eval(kind, knots), k=3, extrap=False, assume_sorted=True, device=self.device)
+            cache[kind]._npoints_operator = 0      # always point by point: no operator per set of redshifts
         return cache[kind]
-
-    def _is_catalogue(self, z):
-        return self._engine.batch_size is None and (z.numel() if dv.is_torch(z) else np.size(z)) > self._ncatalogue
 
     def comoving_radial_distance(self, z):
         """Comoving radial distance, in Mpc/h (cosmology.py:2027-2042)."""
-        if self._is_catalogue(z):
+        if self._use_table_spline and self._engine.batch_size is None:     # one cosmology: its table once, then a cubic per redshift (a few or a catalogue of them)
             return self._table_spline('comoving_radial_distance')(z)
         return self._eval('comoving_radial_distance', z)
 

@@ -147,7 +147,7 @@ def test_densities(golden):
 
 
 def test_catalogue_path():
-    """One cosmology at more than 16 384 redshifts: the distance table is built once and splined per point (cp_spline_points) -- the same
+    """One cosmology (a few redshifts or a catalogue): the distance table is built once and splined per point (cp_spline_points) -- the same
     natural spline the kernel evaluates per sample, so the same numbers; NaN outside the knots, dtype and container of the input kept."""
     import torch
     from cosmoprimo_amd.cosmology import BaseBackground
@@ -157,11 +157,13 @@ def test_catalogue_path():
         ba = cosmo.get_background()
         z = np.concatenate([rng.uniform(0., 5., 50000), 10.**rng.uniform(-6, 3.9, 5000), [0., -0.1, 2e4]])
         fast = ba.comoving_radial_distance(z)
-        saved, BaseBackground._ncatalogue = BaseBackground._ncatalogue, 10**9
+        BaseBackground._use_table_spline = False
         try:
             slow = ba.comoving_radial_distance(z)
         finally:
-            BaseBackground._ncatalogue = saved
+            BaseBackground._use_table_spline = True
+        few = ba.comoving_radial_distance(z[:7])
+        assert few.shape == (7,) and np.allclose(few, slow[:7], rtol=1e-11) and ba.comoving_radial_distance(0.5).shape == ()
         assert np.array_equal(np.isnan(fast), np.isnan(slow)) and np.isnan(fast[-2:]).all() and fast[-3] == 0.
         np.testing.assert_allclose(fast, slow, rtol=1e-11, atol=1e-12 * np.nanmax(slow), equal_nan=True)
         zt = torch.as_tensor(z[:40000], device='cuda:0', dtype=torch.float32)
