@@ -176,3 +176,32 @@ def test_catalogue_path():
 def cp_mod():
     import cosmoprimo_amd
     return cosmoprimo_amd
+
+
+def test_distances_extreme_parameters():
+    """E(z) and D_C far from the fiducial region against the oracle (the quadrature takes 1 / E from rsqrt on tabulated log(1 + z)): curvature,
+    phantom / thawing dark energy, low and high matter density."""
+    import torch
+    from cosmoprimo_amd import background
+    from oracle import background as ob
+    rng = np.random.default_rng(22)
+    nb = 400
+    om, ok = 10.**rng.uniform(-1.5, 0., nb), rng.uniform(-0.3, 0.3, nb)
+    w0, wa, h = rng.uniform(-2.5, -0.34, nb), rng.uniform(-2., 0.6, nb), rng.uniform(0.3, 1.5, nb)
+    wa = np.where(w0 + wa >= 0.3, 0.25 - w0, wa)      # w(a -> 0) < 1/3
+    z = 10.**rng.uniform(-3., 3.5, (nb, 6))
+    dev = torch.device('cuda', 0)
+    t = lambda v: torch.as_tensor(v, device=dev)      # noqa: E731
+    params = dict(w0_fld=t(w0), wa_fld=t(wa), Omega_k=t(ok), h=t(h))
+    for kind in ('efunc', 'comoving_radial_distance'):
+        out = background.distance(kind, t(z), params, Omega_m=t(om), per_cosmology_z=True).cpu().numpy()
+        assert np.isfinite(out).mean() > 0.9
+        for i in range(0, nb, 3):      # (closed models with little matter have E^2 < 0 somewhere: NaN there in the reference as well)
+            p = ob.derived(Omega_m=om[i], Omega_k=ok[i], w0_fld=w0[i], wa_fld=wa[i], h=h[i])
+            with np.errstate(all='ignore'):
+                try:
+                    ref = ob.efunc(z[i], p) if kind == 'efunc' else ob.comoving_radial_distance(z[i], p)
+                except ValueError:      # scipy refuses the NaN table of such a model (so does the reference): every distance is NaN here
+                    assert np.isnan(out[i]).all()
+                    continue
+            np.testing.assert_allclose(out[i], ref, rtol=1e-10, equal_nan=True, err_msg='%s %d' % (kind, i))

@@ -196,3 +196,29 @@ def test_leggauss_and_hierarchy(cp):
         cp.Cosmology(m_ncdm=0.01, neutrino_hierarchy='normal')
     with pytest.raises(cp.CosmologyInputError):
         cp.Cosmology(m_ncdm=[0.06, 0.06], neutrino_hierarchy='normal')
+
+
+@pytest.mark.parametrize('eng', ENGINES)
+def test_power_extreme_parameters(cp, eng):
+    """Transfer functions and P(k) far from the fiducial region (the golden cosmologies sit near it) against the oracle: the kernels share one
+    log(k) between the powers of k and take 1 / E from rsqrt, rewrites that must hold for any parameter value."""
+    from oracle import power as op
+    rng = np.random.default_rng(21)
+    nb = 300
+    par = dict(h=rng.uniform(0.3, 1.5, nb), Omega_m=10.**rng.uniform(-1.3, 0., nb), n_s=rng.uniform(0.5, 1.5, nb))
+    par['Omega_b'] = par['Omega_m'] * 10.**rng.uniform(-3., -0.2, nb)
+    k = np.geomspace(1e-6, 1e2, 400)
+    cosmo = cp.Cosmology(engine=eng, A_s=2e-9, alpha_s=0.02, beta_s=-0.01, **par)
+    tr, pk = cosmo.get_transfer().transfer_k(k), cosmo.get_fourier().pk_interpolator()(k, 0.)
+    assert np.all(np.isfinite(tr)) and np.all(np.isfinite(pk))
+    for i in range(0, nb, 7):
+        h, Om, Ob, ns = (float(par[name][i]) for name in ('h', 'Omega_m', 'Omega_b', 'n_s'))
+        if eng == 'bbks':
+            ref_tr = op.transfer_bbks(k, h, op.bbks_gamma(h, Om - Ob, Ob))
+        else:
+            s = op.eh_scalars(h, Om - Ob, Ob)
+            ref_tr = op.transfer_eh(k, h, s) if eng == 'eisenstein_hu' else op.transfer_nowiggle(k, h, s)
+        np.testing.assert_allclose(tr[i], ref_tr, rtol=1e-10, atol=1e-300)
+        ref_pk = op.pk_z0(k, eng, h=h, Omega_cdm=Om - Ob, Omega_b=Ob, A_s=2e-9, n_s=ns, alpha_s=0.02, beta_s=-0.01)
+        # (growth at z = 0 is not 1 for these engines: compare shapes through the ratio to the first wavenumber)
+        np.testing.assert_allclose(pk[i] / pk[i][0], ref_pk / ref_pk[0], rtol=1e-9)
