@@ -123,6 +123,24 @@ _tophat_cache = {}
 _op_cache = {}
 
 
+_fftlog_cache = {}
+
+
+def _cached_fftlog(cls, x, device, fftlog_kwargs):
+    """FFTLog plan (tables on the device) of transform ``cls`` on abscissa ``x``: built once per (grid, options, device) instead of at every
+    ``to_xi`` / ``to_pk`` -- a likelihood calls them at every step with the same grid."""
+    try:
+        key = (cls.__name__, x.tobytes(), tuple(sorted((fftlog_kwargs or {}).items())), device.index)
+        hash(key)
+    except TypeError:       # an option that cannot be a key (an array ...): no caching
+        return cls(x, complex=False, device=device, **(fftlog_kwargs or {}))
+    if key not in _fftlog_cache:
+        if len(_fftlog_cache) > 16:
+            _fftlog_cache.clear()
+        _fftlog_cache[key] = cls(x, complex=False, device=device, **(fftlog_kwargs or {}))
+    return _fftlog_cache[key]
+
+
 def _cached_operator(key, build):
     if key not in _op_cache:
         if len(_op_cache) > 64:
@@ -608,7 +626,7 @@ class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
     def to_xi_arrays(self, nk=1024, fftlog_kwargs=None):
         """FFTLog transform to the correlation function on the FFTLog grid: ``(s, xi)`` arrays, xi of shape (nk,) + columns."""
         k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
-        s, xi = PowerToCorrelation(k, complex=False, device=self.device, **(fftlog_kwargs or {}))(self._rows(k))
+        s, xi = _cached_fftlog(PowerToCorrelation, k, self.device, fftlog_kwargs)(self._rows(k))
         cs = self._colshape()
         return s.cpu().numpy(), xi.T.reshape((nk,) + cs).cpu().numpy()
 
@@ -858,7 +876,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         (interpolator.py:965-987, ``ignore_growth=True``): ``(s, z, xi)`` arrays with xi (batch..., nk, nz)."""
         k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
         rows = self._rows_z(self.z, ignore_growth=True)(k)     # (batch..., nz, nk)
-        s, xi = PowerToCorrelation(k, complex=False, device=self.device, **(fftlog_kwargs or {}))(rows)
+        s, xi = _cached_fftlog(PowerToCorrelation, k, self.device, fftlog_kwargs)(rows)
         return s.cpu().numpy(), self.z, xi.transpose(-1, -2).cpu().numpy()
 
     def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
@@ -1015,7 +1033,7 @@ class CorrelationFunctionInterpolator1D(_BaseCorrelationFunctionInterpolator):
         out = self._eval_device(s)
         cs = tuple(out.shape[1:])
         rows = out.reshape(ns, -1).T.contiguous() if out.ndim > 1 else out[None, :]
-        k, pk = CorrelationToPower(s, complex=False, device=self.device, **(fftlog_kwargs or {}))(rows)
+        k, pk = _cached_fftlog(CorrelationToPower, s, self.device, fftlog_kwargs)(rows)
         default_params = dict(interp_k='log', interp_order_k=self.interp_order_s)
         default_params.update(kwargs)
         return PowerSpectrumInterpolator1D(k.cpu().numpy(), pk=pk.T.reshape((ns,) + cs), device=self.device, **default_params)
@@ -1151,7 +1169,7 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         """Transform into a :class:`PowerSpectrumInterpolator2D` with FFTLog, growth factor left out (reference interpolator.py:1469-1498)."""
         s = np.geomspace(self.extrap_smin, self.extrap_smax, ns)
         rows = self._eval_device(s, self.z, grid=True, ignore_growth=True).T.contiguous()     # (nz, ns)
-        k, pk = CorrelationToPower(s, complex=False, device=self.device, **(fftlog_kwargs or {}))(rows)
+        k, pk = _cached_fftlog(CorrelationToPower, s, self.device, fftlog_kwargs)(rows)
         default_params = dict(interp_k='log', extrap_pk='log', interp_order_k=self.interp_order_s, interp_order_z=self.interp_order_z,
                               growth_factor_sq=self.growth_factor_sq)
         default_params.update(kwargs)
