@@ -272,6 +272,28 @@ def _quadratic_interp_operator(xk, xq, extrap=True):
     return w
 
 
+def _natural_spline_slopes(x, y):
+    """First derivatives at the knots ``x`` of the natural cubic splines through the columns of ``y`` (n, ncol): the tridiagonal system of
+    scipy's CubicSpline(bc_type='natural'), solved with the same banded LAPACK routine.  Host numpy; a column holding NaN comes out NaN."""
+    from scipy.linalg import solve_banded
+    n = x.size
+    dx = np.diff(x)
+    slope = np.diff(y, axis=0) / dx[:, None]
+    ab = np.zeros((3, n))
+    ab[1, 1:-1] = 2. * (dx[:-1] + dx[1:])      # diagonal
+    ab[0, 2:] = dx[:-1]                          # upper
+    ab[2, :-2] = dx[1:]                          # lower
+    rhs = np.empty_like(y)
+    rhs[1:-1] = 3. * (dx[1:, None] * slope[:-1] + dx[:-1, None] * slope[1:])
+    ab[1, 0], ab[0, 1], rhs[0] = 2., 1., 3. * slope[0]
+    ab[1, -1], ab[2, -2], rhs[-1] = 2., 1., 3. * slope[-1]
+    finite = np.isfinite(rhs).all(axis=0)
+    out = np.full_like(y, np.nan)
+    if finite.any():
+        out[:, finite] = solve_banded((1, 1), ab, rhs[:, finite], overwrite_ab=False, overwrite_b=False, check_finite=False)
+    return out
+
+
 class Interpolator1D(dv.Copyable):
 
     """1D interpolation along axis 0 of ``fun`` (n, ...) in lin or log10 space; natural cubic spline (reference jax.py:135-209)."""
@@ -298,8 +320,10 @@ class Interpolator1D(dv.Copyable):
         # any NaN in a column (e.g. log of a negative P) makes that whole column NaN, without raising (reference jax.py:161-172)
         self._nan_rows = dv.torch().isnan(self._rows).any(dim=1)
 
-    # more queries than this (or more than 4 M operator entries) go through the point-evaluation kernel instead of a (queries x knots) operator
-    _npoints_operator = 16384
+    # With few splines (<= 64 columns) every evaluation goes point by point (cp_spline_points): no (queries x knots) operator to build on the
+    # host for each new set of queries -- what a likelihood calling with its own redshifts pays at every step.  Many columns on shared queries
+    # (batches of spectra) keep the operator form, unless the operator would be larger than this many queries / 4 M entries.
+    _npoints_operator = 0
 
     def _call_points(self, x, bounds_error, dx):
         """Few splines at very many points (``cp_spline_points``): the queries stay where they are (a device tensor is not read back), the
@@ -318,7 +342,13 @@ class Interpolator1D(dv.Copyable):
             xq = torch.log10(xq)
         slopes = self.__dict__.get('_knot_slopes', None)
         if slopes is None:
-            slopes = self._knot_slopes = LinearOperator.spline(self._x, self._x, bc='natural', nu=1, device=self.device)(self._rows).contiguous()
+            if self._x.size <= 512:     # a small (knots x knots) operator, shared by every spline on these knots
+                slope_op = _cached_operator(('i1s', self._x.tobytes(), self.device.index),
+                                            lambda: LinearOperator.spline(self._x, self._x, bc='natural', nu=1, device=self.device))
+                slopes = slope_op(self._rows).contiguous()
+            else:                       # many knots: the tridiagonal system itself, once per interpolator (few columns: a host solve)
+                slopes = dv.to_device(_natural_spline_slopes(self._x, dv.to_host(self._rows).T).T, self.device).contiguous()
+            self._knot_slopes = slopes
             self._x_device = dv.to_device(self._x, self.device)
         out = torch.empty((self._rows.shape[0], xq.numel()), dtype=torch.float64, device=self.device)
         _lib.check(_lib.load().cp_spline_points(self._x_device.data_ptr(), self._rows.data_ptr(), slopes.data_ptr(), self._x.size, self._rows.shape[0],
@@ -431,7 +461,7 @@ class Interpolator2D(dv.Copyable):
         like_torch = dv.is_torch(x) or dv.is_torch(y)
         dtype = dv.float_dtype(x, y)
         nxq, nyq = (v.numel() if dv.is_torch(v) else np.size(v) for v in (x, y))
-        if grid and 0 < nyq <= 64 and (nxq > Interpolator1D._npoints_operator or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
+        if grid and 0 < nyq <= 64 and (nxq > 16384 or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
             return self._call_many_x(x, y, bounds_error)
         xh, yh = _host(x), _host(y)
         shape = xh.shape + yh.shape if grid else xh.shape
@@ -752,7 +782,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         like_torch = dv.is_torch(k) or dv.is_torch(z)
         dtype = dv.float_dtype(k, z)
         zh = _host(z)
-        if self.is_from_callable and self.growth_factor_sq is not None and dv.is_torch(k) and k.is_cuda and k.numel() > Interpolator1D._npoints_operator:
+        if self.is_from_callable and self.growth_factor_sq is not None and dv.is_torch(k) and k.is_cuda and k.numel() > 16384:
             kh = k.to(dv.torch().float64)      # a mesh of wavenumbers on the device goes to the callable as it is (no copy to the host and back)
         else:
             kh = _host(k)
