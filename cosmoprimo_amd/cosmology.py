@@ -1064,19 +1064,39 @@ class BaseBackground(BaseSection):
             return self._table_spline('comoving_radial_distance')(z)
         return self._eval('comoving_radial_distance', z)
 
+    def _curved_distance(self, kind, z):
+        """Angular / transverse / luminosity distance of ONE cosmology from its radial-distance table (cosmology.py:1855-1912): the curvature
+        map and the powers of 1 + z applied on the device in float64, in the kernel's operation order; dtype and container of ``z`` kept."""
+        torch = dv.torch()
+        zt = dv.to_device(z, self.device)
+        chi = self._table_spline('comoving_radial_distance')(zt)       # float64 device tensor
+        K = float(self._K)
+        if K > 0.:
+            chi = torch.sin(np.sqrt(K) * chi) / np.sqrt(K)
+        elif K < 0.:
+            chi = torch.sinh(np.sqrt(-K) * chi) / np.sqrt(-K)
+        da = chi / (1. + zt)
+        out = da if kind == 'angular_diameter_distance' else (da * (1. + zt) if kind == 'comoving_transverse_distance' else da * ((1. + zt) * (1. + zt)))
+        return _out(out, z)
+
+    def _distance(self, kind, z):
+        if self._use_table_spline and self._engine.batch_size is None:
+            return self._curved_distance(kind, z)
+        return self._eval(kind, z)
+
     def angular_diameter_distance(self, z):
         """Proper angular diameter distance, in Mpc/h (cosmology.py:1855-1868)."""
-        return self._eval('angular_diameter_distance', z)
+        return self._distance('angular_diameter_distance', z)
 
     def comoving_transverse_distance(self, z):
         """Comoving transverse distance, in Mpc/h (cosmology.py:1893-1900)."""
-        return self._eval('comoving_transverse_distance', z)
+        return self._distance('comoving_transverse_distance', z)
 
     comoving_angular_distance = comoving_transverse_distance
 
     def luminosity_distance(self, z):
         """Luminosity distance, in Mpc/h (cosmology.py:1904-1912)."""
-        return self._eval('luminosity_distance', z)
+        return self._distance('luminosity_distance', z)
 
     def angular_diameter_distance_2(self, z1, z2):
         """Angular diameter distance of an object at z2 seen from z1 (cosmology.py:1870-1890); scalar cosmologies."""

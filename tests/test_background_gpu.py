@@ -157,16 +157,24 @@ def test_catalogue_path():
         ba = cosmo.get_background()
         z = np.concatenate([rng.uniform(0., 5., 50000), 10.**rng.uniform(-6, 3.9, 5000), [0., -0.1, 2e4]])
         fast = ba.comoving_radial_distance(z)
+        zt = torch.as_tensor(z[:40000], device='cuda:0', dtype=torch.float32)
         BaseBackground._use_table_spline = False
         try:
             slow = ba.comoving_radial_distance(z)
         finally:
             BaseBackground._use_table_spline = True
+        for name in ('angular_diameter_distance', 'comoving_transverse_distance', 'luminosity_distance'):      # through the same table
+            quick = getattr(ba, name)(z)
+            BaseBackground._use_table_spline = False
+            try:
+                np.testing.assert_allclose(quick, getattr(ba, name)(z), rtol=1e-11, atol=1e-12 * np.nanmax(slow), equal_nan=True, err_msg=name)
+            finally:
+                BaseBackground._use_table_spline = True
+            assert getattr(ba, name)(np.float32(0.5)).dtype == np.float32 and getattr(ba, name)(zt).dtype == torch.float32
         few = ba.comoving_radial_distance(z[:7])
         assert few.shape == (7,) and np.allclose(few, slow[:7], rtol=1e-11) and ba.comoving_radial_distance(0.5).shape == ()
         assert np.array_equal(np.isnan(fast), np.isnan(slow)) and np.isnan(fast[-2:]).all() and fast[-3] == 0.
         np.testing.assert_allclose(fast, slow, rtol=1e-11, atol=1e-12 * np.nanmax(slow), equal_nan=True)
-        zt = torch.as_tensor(z[:40000], device='cuda:0', dtype=torch.float32)
         out = ba.comoving_radial_distance(zt)
         assert out.is_cuda and out.dtype == torch.float32 and out.shape == zt.shape
         out = ba.comoving_radial_distance(z[:55000].reshape(5, 11000).astype('f4'))
