@@ -1,9 +1,11 @@
 """Generate golden vectors from the imported reference (run in the build container only).
 
-    python -m oracle.gen_golden            # writes tests/golden/*.npz
+    python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Fixtures are plain float64/complex128 arrays (inputs + expected outputs) produced by *running*
-/root/reference; no reference source is stored.  See SURVEY.md 8(c) for the list (G1..G8).
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, bao, xi, bao2, densities, ncdm, variants,
+calculator, cosmology_api, abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
+reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
+See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
 """
 import os
 import sys
