@@ -90,7 +90,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     constexpr int T = PL::T;
     extern __shared__ __attribute__((aligned(4096))) char smem[];  // 4096: see LdsView (cp_fft_core.h)
     cplx* lds = reinterpret_cast<cplx*>(smem);
-    cplx* ltw = lds + N;
+    cplx* ltw = lds + lds_data_slots(N, P);  // data slots of one packed pair (padded layout for N = 4096), then the tables
     const int t = threadIdx.x;
     for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = A.tw[N + i];
     const long long npairs = (A.nrows + 1) / 2;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
 template <int N>
 void launch(bool inverse, const Args& A, int grid, hipStream_t stream) {
     constexpr int P = 16, T = N / P;
-    constexpr int lds = (Plan<N, P>::TW_TOTAL) * (int)sizeof(cplx);
+    constexpr int lds = (lds_data_slots(N, P) + Plan<N, P>::TW_TOTAL - N) * (int)sizeof(cplx);
     if (lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS (once per process would do; the call is cheap)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dst_kernel<N, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dst_kernel<N, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -111,6 +111,78 @@ __device__ __forceinline__ void lane_transpose2(double& lo, double& hi) {
     lo = __builtin_bit_cast(double, a);
     hi = __builtin_bit_cast(double, b);
 }
+// the same for N = 2 or 3 (lo, hi) pairs in one block: VCC is set up once per block instead of once per pair (the kernel is
+// bound by instruction issue, scalar instructions included); an asm statement takes at most 30 operands, hence N <= 3
+__device__ __forceinline__ void lane_transpose2x2(double* lo, double* hi) {
+    cp_v2i l0 = __builtin_bit_cast(cp_v2i, lo[0]), h0 = __builtin_bit_cast(cp_v2i, hi[0]);
+    cp_v2i l1 = __builtin_bit_cast(cp_v2i, lo[1]), h1 = __builtin_bit_cast(cp_v2i, hi[1]);
+    cp_v2i a0, b0, a1, b1;
+    asm volatile(
+        "s_mov_b64 vcc, %16\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %0, %10, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %11, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %4, %14, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %5, %15, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %2, %8, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %9, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %6, %12, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %7, %13, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(a0.x), "=&v"(a0.y), "=&v"(b0.x), "=&v"(b0.y), "=&v"(a1.x), "=&v"(a1.y), "=&v"(b1.x), "=&v"(b1.y)
+        : "v"(l0.x), "v"(l0.y), "v"(h0.x), "v"(h0.y), "v"(l1.x), "v"(l1.y), "v"(h1.x), "v"(h1.y), "s"(0x5555555555555555ull)
+        : "vcc", "scc");
+    lo[0] = __builtin_bit_cast(double, a0);
+    hi[0] = __builtin_bit_cast(double, b0);
+    lo[1] = __builtin_bit_cast(double, a1);
+    hi[1] = __builtin_bit_cast(double, b1);
+}
+__device__ __forceinline__ void lane_transpose2x3(double* lo, double* hi) {
+    cp_v2i l0 = __builtin_bit_cast(cp_v2i, lo[0]), h0 = __builtin_bit_cast(cp_v2i, hi[0]);
+    cp_v2i l1 = __builtin_bit_cast(cp_v2i, lo[1]), h1 = __builtin_bit_cast(cp_v2i, hi[1]);
+    cp_v2i l2 = __builtin_bit_cast(cp_v2i, lo[2]), h2 = __builtin_bit_cast(cp_v2i, hi[2]);
+    cp_v2i a0, b0, a1, b1, a2, b2;
+    asm volatile(
+        "s_mov_b64 vcc, %24\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_dpp %0, %14, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %1, %15, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %4, %18, %16, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %5, %19, %17, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %8, %22, %20, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %9, %23, %21, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "v_cndmask_b32_dpp %2, %12, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %3, %13, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %6, %16, %18, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %7, %17, %19, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %10, %20, %22, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32_dpp %11, %21, %23, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "=&v"(a0.x), "=&v"(a0.y), "=&v"(b0.x), "=&v"(b0.y), "=&v"(a1.x), "=&v"(a1.y), "=&v"(b1.x), "=&v"(b1.y), "=&v"(a2.x), "=&v"(a2.y),
+          "=&v"(b2.x), "=&v"(b2.y)
+        : "v"(l0.x), "v"(l0.y), "v"(h0.x), "v"(h0.y), "v"(l1.x), "v"(l1.y), "v"(h1.x), "v"(h1.y), "v"(l2.x), "v"(l2.y), "v"(h2.x), "v"(h2.y),
+          "s"(0x5555555555555555ull)
+        : "vcc", "scc");
+    lo[0] = __builtin_bit_cast(double, a0);
+    hi[0] = __builtin_bit_cast(double, b0);
+    lo[1] = __builtin_bit_cast(double, a1);
+    hi[1] = __builtin_bit_cast(double, b1);
+    lo[2] = __builtin_bit_cast(double, a2);
+    hi[2] = __builtin_bit_cast(double, b2);
+}
+// N pairs, N a multiple of 2 or 3 ... in blocks of 3, 3, 2 for the 8 pairs of a P = 16 thread
+template <int N>
+__device__ __forceinline__ void lane_transpose2_all(double* lo, double* hi) {
+    if constexpr (N >= 3 && N != 4) {
+        lane_transpose2x3(lo, hi);
+        lane_transpose2_all<N - 3>(lo + 3, hi + 3);
+    } else if constexpr (N >= 2) {
+        lane_transpose2x2(lo, hi);
+        lane_transpose2_all<N - 2>(lo + 2, hi + 2);
+    } else if constexpr (N == 1) {
+        lane_transpose2(lo[0], hi[0]);
+    }
+}
 #else
 inline cplx ld_cplx(const void* base, unsigned voff, unsigned soff) {
     return *reinterpret_cast<const cplx*>(reinterpret_cast<const char*>(base) + voff + soff);
@@ -128,7 +200,7 @@ inline void st_f64(void* base, unsigned voff, unsigned soff, double v) {
 // on the generic pointer costs.  The XOR forms of Pass::lds_off rely on the buffer being 4096-byte aligned in LDS
 // ((base + l0) ^ k == (base ^ k) + l0 for k < 4096): the kernels declare it so.
 #if defined(__HIP_DEVICE_COMPILE__)
-typedef __attribute__((address_space(3))) cplx cp_lds_cplx;
+typedef __attribute__((address_space(3), aligned(16))) cplx cp_lds_cplx;  // 16-byte slots: ds_read_b128 / ds_write_b128
 struct LdsView {
     unsigned l0;
     __device__ __forceinline__ explicit LdsView(const void* lds)
@@ -194,8 +266,26 @@ struct Plan {
 //          MI355X_MICROARCH.md, LDS; tools/lds_conflict_model.py checks every pass shape against both rules)
 // Linearity (swz(a ^ b) == swz(a) ^ swz(b)) is what lets Pass::lds_off split an address into a per-thread base and a
 // compile-time per-point constant.
+// NP = 16^3, P = 16 (the benchmark shape): a digit-wise PADDED layout instead of the XOR swizzle.  Element (hi, mid, lo) (base-16
+// digits of its index) sits in slot lo + 17 mid + 272 hi.  In every pass one digit is the thread's point index r and the other
+// two come from the thread index, so an address is thread base + r * constant: the constant goes into the 16-bit offset field
+// of ds_read / ds_write and NO per-access address arithmetic is left (the XOR form costs one VALU instruction per access on a
+// kernel that is bound by instruction issue).  Bank behaviour (16-byte slots; reads are served 16 lanes at a time in the lane
+// groups of MI355X_MICROARCH.md, writes 8 contiguous lanes): the pass-1 and pass-2 shapes and the pass-0 writes are
+// conflict-free, and so is the pass-0 shape once the lanes are permuted (Fftlog::pass0_thread).
+// MEASURED (MI355X, 100 000 x 2048, tools/mb_variants.sh, round 2): 1.134-1.145 ms against 1.124 ms for the XOR swizzle on the
+// same box, although the main loop has 130 fewer VALU instructions -- the kernel is not bound by instruction count.  Kept as a
+// build option (-DCP_PADDED_LDS=1), off by default.
+#ifndef CP_PADDED_LDS
+#define CP_PADDED_LDS 0
+#endif
+constexpr bool padded_lds(int NP, int P) { return CP_PADDED_LDS && NP == 4096 && P == 16; }
+// complex slots of the data region of one packed pair
+constexpr int lds_data_slots(int NP, int P) { return padded_lds(NP, P) ? 16 * 272 : NP; }
+
 template <int NP, int P = 16>
 CP_HD int swz(int p) {
+    if (padded_lds(NP, P)) return (p & 15) + 17 * ((p >> 4) & 15) + 272 * (p >> 8);
     if (NP >= 256 && P == 8) return p ^ ((p >> 3) & 7) ^ (((p >> 6) & 1) << 3);
     if (NP >= 256) return p ^ ((p >> 4) & 15);
     return p;
@@ -453,9 +543,19 @@ struct Pass {
     //   M % 256 == 0 : bits 4..7 come from j only           -> base(t, i) + r * 16 M        (an immediate offset)
     //   M == R == 16 : bits 4..7 of the slot are r          -> base(t, i) ^ (r * 0x110)
     //   M == 1, R 16 : bits 4..7 are beta & 15              -> base(t, i) ^ (r * 16)
+    // The thread's base address goes through an empty asm so that the compiler cannot re-associate base + buffer address +
+    // point offset: the point offset stays the outermost constant addend and lands in the offset field of ds_read / ds_write.
+    static CP_HD unsigned opaque_base(unsigned base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(base));
+#endif
+        return base;
+    }
     static CP_HD unsigned lds_base(int t, int i) {
         const unsigned beta = (unsigned)(t + T * i);
-        if (NP >= 256 && P == 16 && M % 256 == 0) {
+        if (padded_lds(NP, P)) {
+            return (unsigned)swz<NP, P>(elem(t, i, 0)) * 16u;
+        } else if (NP >= 256 && P == 16 && M % 256 == 0) {
             const unsigned b = beta / M, j = beta % M;
             return (b * L + (j ^ ((j >> 4) & 15u))) * 16u;
         } else if (NP >= 256 && M == 16 && R == 16) {
@@ -468,6 +568,8 @@ struct Pass {
     }
     // base = lds_base(t, i) + the buffer's LDS address l0
     static CP_HD unsigned lds_off(int t, int i, int r, unsigned base, unsigned l0) {
+        // padded layout: the point index is a base-16 digit of its own, so its slot offset simply adds (an immediate)
+        if (padded_lds(NP, P)) return base + (unsigned)swz<NP, P>(M * r) * 16u;
         if (NP >= 256 && P == 16 && M % 256 == 0) return base + (unsigned)r * (M * 16u);
         if (NP >= 256 && M == 16 && R == 16) return base ^ ((unsigned)r * 0x110u);
         if (NP >= 256 && M == 1 && R == 16) return base ^ ((unsigned)r * 16u);
@@ -490,7 +592,7 @@ struct Pass {
         const LdsView v(lds);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const unsigned base = lds_base(t, i) + v.l0;
+            const unsigned base = opaque_base(lds_base(t, i) + v.l0);
 #pragma unroll
             for (int k = 0; k < R; ++k) {
                 const int r = consume_order(k);
@@ -503,7 +605,7 @@ struct Pass {
         const LdsView v(lds);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const unsigned base = lds_base(t, i) + v.l0;
+            const unsigned base = opaque_base(lds_base(t, i) + v.l0);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 if (CP_ABLATE & 1) {
@@ -591,7 +693,7 @@ struct Pass {
     static CP_HD void butterflies_store(int t, const cplx* w, cplx* lds, cplx* x) {
         if constexpr (R == 16 && NB == 1 && CP_ABLATE == 0) {
             const LdsView v(lds);
-            const unsigned base = lds_base(t, 0) + v.l0;
+            const unsigned base = opaque_base(lds_base(t, 0) + v.l0);
             if (ZERO_PADDED) dft16_inner_zero_padded(x);
             else dft16_inner(x);
             stage_store<0, TW>(t, w, v, base, x);
@@ -601,7 +703,7 @@ struct Pass {
         } else if constexpr (R == 8 && NB == 1 && CP_ABLATE == 0) {
             // radix 8 = 2 x 4: outputs k and k + 4 come from e_k +- o_k; four stages of two writes
             const LdsView v(lds);
-            const unsigned base = lds_base(t, 0) + v.l0;
+            const unsigned base = opaque_base(lds_base(t, 0) + v.l0);
             cplx e[4] = {x[0], x[2], x[4], x[6]}, o[4] = {x[1], x[3], x[5], x[7]};
             if (ZERO_PADDED) {
                 dft4_mid(e[0], e[1], e[2], e[3]);
@@ -653,6 +755,30 @@ struct Pass {
         butterflies(x);
     }
 };
+
+// True when every element a thread reads in pass IR was written (in pass IW, in place) by a thread of the SAME wave: the
+// exchange between the two passes then needs no workgroup barrier, because the LDS executes the instructions of one wave in
+// order.  (NP = 4096, P = 16: passes 1 <-> 2 trade data inside groups of 16 consecutive threads.)
+#ifndef CP_WAVE_LOCAL
+#define CP_WAVE_LOCAL 1
+#endif
+template <int NP, int P>
+constexpr bool exchange_is_wave_local(int iw, int ir) {
+    using PL = Plan<NP, P>;
+    if (!CP_WAVE_LOCAL) return false;
+    const int T = PL::T;
+    const int Lw = PL::len(iw), Mw = Lw / PL::radix(iw);
+    const int Lr = PL::len(ir), Rr = PL::radix(ir), Mr = Lr / Rr;
+    for (int t = 0; t < T; ++t)
+        for (int i = 0; i < P / Rr; ++i)
+            for (int r = 0; r < Rr; ++r) {
+                const int beta = t + T * i;
+                const int e = (beta / Mr) * Lr + beta % Mr + Mr * r;   // Pass<NP, P, ir>::elem(t, i, r)
+                const int writer = ((e / Lw) * Mw + e % Mw) % T;        // thread whose pass-iw butterfly holds e
+                if (writer / 64 != t / 64) return false;
+            }
+    return true;
+}
 
 // Frequency index held at LDS position pos after the full DIF network (digit reversal for the
 // mixed-radix plan).  Host-side only (used to lay out U).

@@ -51,7 +51,13 @@ __device__ __forceinline__ void run_phases(int t, const FftlogArgs& A, const dou
     cp_stamp_acc[2 * PH] += s1 - s0;
 #endif
     if constexpr (PH + 1 < F::NPH) {
-        if (!(CP_ABLATE & 2)) __syncthreads();
+        if constexpr (F::template barrier_free_after<PH>()) {
+            // the next phase reads only what this wave has just written (in place), and the LDS executes one wave's
+            // instructions in order: no barrier, the waves of the workgroup drift apart and spread their LDS bursts
+            asm volatile("" ::: "memory");
+        } else if (!(CP_ABLATE & 2)) {
+            __syncthreads();
+        }
 #if defined(CP_STAMPS)
         cp_stamp_acc[2 * PH + 1] += cp_stamp() - s1;
 #endif

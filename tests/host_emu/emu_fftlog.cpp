@@ -25,7 +25,7 @@ template <int NP, int P, int IM, int OM>
 static void run_pair(const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b, int ker, cplx* lds,
                      const double* nra, const double* nrb, int nxt_ker, void* state, bool first) {
     using F = Fftlog<NP, P, IM, OM>;
-    static_assert(sizeof(typename F::State) <= (16 * P + 32 * 8), "state slot too small");
+    static_assert(sizeof(typename F::State) <= (16 * P + 32 * 8 + 16), "state slot too small");
     auto* st = reinterpret_cast<typename F::State*>(state);
     if (first)
         for (int t = 0; t < F::T; ++t) F::init_state(t, A, ra, rb, ker, st[t]);
@@ -35,7 +35,7 @@ static void run_pair(const FftlogArgs& A, const double* ra, const double* rb, do
 template <int NP, int P>
 static int emulate(int n, int nker, const double* pre, const double* post, const double* u_re_im, const double* in, double* out,
                    long long nbatch, int ext_l, double val_l, int ext_r, double val_r, int keep_padding) {
-    std::vector<cplx> tw, u((size_t)nker * NP), lds(NP + Fftlog<NP, P>::LDS_TW_ENTRIES + 1);
+    std::vector<cplx> tw, u((size_t)nker * NP), lds(Fftlog<NP, P>::LDS_DATA + Fftlog<NP, P>::LDS_TW_ENTRIES + 1);
     build_twiddles<NP, P>(tw);
     for (int k = 0; k < nker; ++k) build_u_layout<NP, P>(u_re_im + (size_t)k * 2 * (NP / 2 + 1), u.data() + (size_t)k * NP);
     FftlogArgs A;
@@ -48,7 +48,7 @@ static int emulate(int n, int nker, const double* pre, const double* post, const
     A.pre = pre; A.post = post; A.u = u.data(); A.tw = tw.data();
     for (int t = 0; t < Plan<NP, P>::T; ++t) Fftlog<NP, P>::fill_lds_tables(t, A, lds.data());
     const long long nhalf = (nbatch + 1) / 2, npairs = nhalf * nker;
-    std::vector<char> pfv((size_t)(16 * P + 32 * 8) * Plan<NP, P>::T);  // State is the same size for every variant of (NP, P)
+    std::vector<char> pfv((size_t)(16 * P + 32 * 8 + 16) * Plan<NP, P>::T);  // State is the same size for every variant of (NP, P)
     void* pf = pfv.data();
     auto rows = [&](long long p, const double*& ra, const double*& rb, double*& oa, double*& ob, bool& has_b, int& ker) {
         ker = (int)(p % nker);
