@@ -111,6 +111,31 @@ __device__ __forceinline__ void lane_transpose2(double& lo, double& hi) {
     lo = __builtin_bit_cast(double, a);
     hi = __builtin_bit_cast(double, b);
 }
+// maxima of two unsigned values over the 64 lanes of a wave (results are wave-uniform): four DPP steps inside the rows of 16
+// lanes (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8), then one lane of each row
+__device__ __forceinline__ void wave_max2_u32(unsigned& a, unsigned& b) {
+#define CP_WAVE_MAX_STEP(CTRL)                                                                    \
+    {                                                                                             \
+        const unsigned pa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, CTRL, 0xf, 0xf, true); \
+        const unsigned pb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true); \
+        a = a > pa ? a : pa;                                                                      \
+        b = b > pb ? b : pb;                                                                      \
+    }
+    CP_WAVE_MAX_STEP(0xB1)
+    CP_WAVE_MAX_STEP(0x4E)
+    CP_WAVE_MAX_STEP(0x124)
+    CP_WAVE_MAX_STEP(0x128)
+#undef CP_WAVE_MAX_STEP
+    unsigned ra = 0, rb = 0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned xa = (unsigned)__builtin_amdgcn_readlane((int)a, 16 * row), xb = (unsigned)__builtin_amdgcn_readlane((int)b, 16 * row);
+        ra = ra > xa ? ra : xa;
+        rb = rb > xb ? rb : xb;
+    }
+    a = ra;
+    b = rb;
+}
 // the same for N = 2 or 3 (lo, hi) pairs in one block: VCC is set up once per block instead of once per pair (the kernel is
 // bound by instruction issue, scalar instructions included); an asm statement takes at most 30 operands, hence N <= 3
 __device__ __forceinline__ void lane_transpose2x2(double* lo, double* hi) {
@@ -226,6 +251,11 @@ CP_HD cplx cmul(const cplx a, const cplx b) {
 }
 
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
+
+// ---- row screening (cp_fftlog_body.h, "row independence") ----------------------------------------------------------------
+// high dword of |v|: an unsigned integer that orders finite doubles by magnitude, with Inf / NaN above every finite value;
+// bits 30..20 are the biased exponent
+CP_HD unsigned hi_abs(double v) { return (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32) & 0x7fffffffu; }
 
 // Pass plan: radices R_0 = P, then min(P, remaining) until the product is NP.
 // len(i) = sub-FFT length handled by pass i (L_0 = NP), radix(i) = R_i, M_i = L_i / R_i.

@@ -24,6 +24,23 @@ enum { CP_EXTRAP_CONST = 0, CP_EXTRAP_EDGE = 1, CP_EXTRAP_LOG = 2 };
 #ifndef CP_WIDE_IO  // 1: 16-byte row loads / stores shared by lane pairs through DPP lane transposes; 0: one 8-byte access per sample
 #define CP_WIDE_IO 0
 #endif
+// Row independence.  Two rows share one complex transform (z = a + i b), so without care a NaN / Inf in one row reaches its pair
+// partner and rounding is relative to the larger row of the pair -- numpy's row-by-row FFTs (reference fftlog.py:538-544) do
+// neither.  The kernel therefore finds, per row, the largest |sample| (its exponent field: 0 .. 2047, 2047 = Inf / NaN) and
+//   * transforms a non-finite row as zeros and stores NaN for it (all of numpy's output for such a row is NaN as well);
+//   * when the exponents of the two rows differ by more than CP_ROW_SCALE_SPREAD, scales each row by the power of two that
+//     brings its largest sample to [1, 2) (exact), and scales the results back (exact): rounding becomes relative to the row's
+//     own magnitude.  Within the spread nothing is done: the error is at most 2^spread times the row-relative one.
+// Magnitudes are those of the TILTED samples a_j * pre_j (what the FFT sees; with 'log' extrapolation the raw padded samples of
+// similar rows differ by orders of magnitude where the prefactor is tiny).  The zero-padded HALF variant takes them from the
+// prefetch registers a pair ahead and reduces over the workgroup through the barrier that precedes the last phase (no extra
+// barrier); the other variants reduce inside phase 0 (one extra barrier per pair).
+#ifndef CP_ROW_SCREEN
+#define CP_ROW_SCREEN 1
+#endif
+#ifndef CP_ROW_SCALE_SPREAD
+#define CP_ROW_SCALE_SPREAD 4
+#endif
 #ifndef CP_EARLY_TW1
 #define CP_EARLY_TW1 1
 #endif
@@ -52,6 +69,7 @@ struct FftlogArgs {
     int n_out;          // output row length (n or NP)
     int ext_l, ext_r;   // CP_EXTRAP_*
     double val_l, val_r;
+    unsigned pad_hi;    // max of hi_abs() of the constant padding values in use (0 when none): they count towards a row's magnitude
     const double* pre;  // (nker, NP) padded prefactor
     const double* post; // (nker, NP) padded postfactor
     const cplx* u;      // (nker, NP) Hermitian-extended u / NP in thread layout [(i R + s) T + t]
@@ -75,7 +93,21 @@ struct Fftlog {
     // (Plan::tw_offset order)
     static constexpr int LDS_DATA = lds_data_slots(NP, P);
     static constexpr int LDS_TW_ENTRIES = NPASS > 1 ? PL::TW_TOTAL - NP : 0;
-    static constexpr int LDS_BYTES = NPASS > 1 ? (LDS_DATA + LDS_TW_ENTRIES) * (int)sizeof(cplx) : 0;
+    // ... then the scratch of the row screening: one (max a, max b) pair of unsigned per wave
+    // (full waves: one slot per wave, filled after a DPP reduction; workgroups smaller than a wave: one slot per thread -- lane
+    // operations must not read the inactive lanes of a partial wave)
+    static constexpr int SCR_SLOTS = T >= 64 ? T / 64 : T;
+    static constexpr int LDS_SCR_BYTES = ((SCR_SLOTS * 8 + 15) / 16) * 16;
+    static constexpr int LDS_BYTES = NPASS > 1 ? (LDS_DATA + LDS_TW_ENTRIES) * (int)sizeof(cplx) + LDS_SCR_BYTES : 0;
+    static CP_HD unsigned* lds_scr(cplx* lds) { return reinterpret_cast<unsigned*>(lds + LDS_DATA + LDS_TW_ENTRIES); }
+    static constexpr bool SCREEN = CP_ROW_SCREEN && CP_ABLATE == 0;
+    // the zero-padded HALF variant (the reference's default extrap=0) screens a pair ahead, from the prefetch registers
+    static constexpr bool SCREEN_AHEAD = SCREEN && IN_MODE == 3 /* IN_HALF_ZERO */ && !CP_WIDE_IO;
+#if defined(__HIP_DEVICE_COMPILE__)
+    static constexpr bool SCREEN_AHEAD_DEVICE = SCREEN_AHEAD;
+#else
+    static constexpr bool SCREEN_AHEAD_DEVICE = false;  // the host emulation screens in phase 0
+#endif
     // Which pass-0 butterfly (j = the low 8 bits of its elements' indices) thread t takes.  Identity except under the padded LDS
     // layout, where the lanes of each half wave are permuted so that the 16 lanes ds_read_b128 serves together (lane groups
     // {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31}: MI355X_MICROARCH.md) all hold the same middle digit: slot = lo + 17 mid + 272 hi
@@ -95,7 +127,11 @@ struct Fftlog {
     // no workgroup barrier is needed between phases PH and PH + 1 when that exchange stays inside single waves
     template <int PH>
     static constexpr bool barrier_free_after() {
-        if constexpr (NPASS > 1 && PH + 1 < NPH) return exchange_is_wave_local<NP, P>(write_pass(PH), read_pass(PH + 1));
+        if constexpr (NPASS > 1 && PH + 1 < NPH) {
+            // the barrier in front of the last phase also publishes the screening scratch of the next pair (HALF variants)
+            if (SCREEN_AHEAD && PH == NPH - 2 && T > 64) return false;
+            return exchange_is_wave_local<NP, P>(write_pass(PH), read_pass(PH + 1));
+        }
         return false;
     }
     template <int I>
@@ -119,6 +155,128 @@ struct Fftlog {
             if (IN_MODE == IN_LOG && A.ext_r == CP_EXTRAP_LOG) v = v / pow(a[A.n - 2] / v, (double)(idx - A.n + 1));
         }
         return v;
+    }
+
+    // ---- row screening (see CP_ROW_SCREEN above) -------------------------------------------------------------------------
+    // info = exponent field of row a | exponent field of row b << 16
+    struct RowFix {
+        int any, nan_a, nan_b, sh_a, sh_b;  // sh: power of two applied to the row on the way in (0: none), undone on the way out
+    };
+    static CP_HD RowFix decode_info(unsigned info) {
+        const int ea = (int)(info & 0xffffu), eb = (int)(info >> 16);
+        RowFix f;
+        f.nan_a = ea == 2047;
+        f.nan_b = eb == 2047;
+        const int d = ea - eb;
+        const int scale = !f.nan_a && !f.nan_b && ea != 0 && eb != 0 && (d > CP_ROW_SCALE_SPREAD || d < -CP_ROW_SCALE_SPREAD);
+        f.sh_a = scale ? 1023 - ea : 0;
+        f.sh_b = scale ? 1023 - eb : 0;
+        f.any = f.nan_a | f.nan_b | scale;
+        return f;
+    }
+    static CP_HD unsigned make_info(unsigned ma, unsigned mb) { return (ma >> 20) | ((mb >> 20) << 16); }
+    template <int N>
+    static CP_HD void fix_input(const RowFix& f, cplx* x) {
+        if (!f.any) return;  // wave-uniform on the device
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            if (f.nan_a) x[r].re = 0.;
+            else if (f.sh_a) x[r].re = ldexp(x[r].re, f.sh_a);
+            if (f.nan_b) x[r].im = 0.;
+            else if (f.sh_b) x[r].im = ldexp(x[r].im, f.sh_b);
+        }
+    }
+    template <int N>
+    static CP_HD void fix_output(const RowFix& f, double* ya, double* yb) {
+        if (!f.any) return;
+#pragma unroll
+        for (int s = 0; s < N; ++s) {
+            if (f.nan_a) ya[s] = __builtin_nan("");
+            else if (f.sh_a) ya[s] = ldexp(ya[s], -f.sh_a);
+            if (f.nan_b) yb[s] = __builtin_nan("");
+            else if (f.sh_b) yb[s] = ldexp(yb[s], -f.sh_b);
+        }
+    }
+    template <int N>
+    static CP_HD void thread_max(const double* a, const double* b, unsigned& ma, unsigned& mb) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const unsigned ha = hi_abs(a[r]), hb = hi_abs(b[r]);
+            ma = ma > ha ? ma : ha;
+            mb = mb > hb ? mb : hb;
+        }
+    }
+    template <int N>
+    static CP_HD void thread_max(const cplx* x, unsigned& ma, unsigned& mb) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const unsigned ha = hi_abs(x[r].re), hb = hi_abs(x[r].im);
+            ma = ma > ha ? ma : ha;
+            mb = mb > hb ? mb : hb;
+        }
+    }
+    // phase 0 of the variants that do not screen ahead: the thread's tilted points x[0..N) -> reduction over the workgroup (one
+    // barrier) -> the pair's exponent fields in `info`, fix-up applied.  Host emulation: magnitudes straight from the rows.
+    template <int N>
+    static CP_HD void screen_in_phase0(int t, const FftlogArgs& A, const double* ra, const double* rb, const double* pre, cplx* lds, unsigned& info,
+                                       cplx* x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned ma = 0, mb = 0;
+        thread_max<N>(x, ma, mb);
+        if constexpr (T > 1) {
+            screen_publish(t, lds, ma, mb);
+            __syncthreads();
+            info = screen_collect(lds);
+        } else {
+            info = make_info(ma, mb);
+        }
+#else
+        info = host_row_info(ra, rb, pre, A);
+#endif
+        fix_input<N>(decode_info(info), x);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // workgroup reduction of the per-thread maxima: wave maximum by DPP, one 8-byte LDS slot per wave, published by the next
+    // workgroup barrier (or by the in-order LDS of a single-wave workgroup), collected by every thread
+    static __device__ __forceinline__ void screen_publish(int t, cplx* lds, unsigned ma, unsigned mb) {
+        if constexpr (T >= 64) {
+            wave_max2_u32(ma, mb);
+            if ((t & 63) == 0) {
+                unsigned* scr = lds_scr(lds) + 2 * (t >> 6);
+                scr[0] = ma;
+                scr[1] = mb;
+            }
+        } else {
+            unsigned* scr = lds_scr(lds) + 2 * t;
+            scr[0] = ma;
+            scr[1] = mb;
+        }
+    }
+    static __device__ __forceinline__ unsigned screen_collect(cplx* lds) {
+        const unsigned* scr = lds_scr(lds);
+        unsigned ma = 0, mb = 0;
+#pragma unroll
+        for (int w = 0; w < SCR_SLOTS; ++w) {
+            ma = ma > scr[2 * w] ? ma : scr[2 * w];
+            mb = mb > scr[2 * w + 1] ? mb : scr[2 * w + 1];
+        }
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)make_info(ma, mb));
+    }
+#else
+    // host pass of the kernel source / host emulation: never called (the emulation takes the magnitudes from the rows)
+    static void screen_publish(int, cplx*, unsigned, unsigned) {}
+    static unsigned screen_collect(cplx*) { return 0u; }
+#endif
+    // host emulation: the magnitudes straight from the rows (the emulated threads run one after the other)
+    static CP_HD unsigned host_row_info(const double* __restrict__ ra, const double* __restrict__ rb, const double* __restrict__ pre,
+                                        const FftlogArgs& A) {
+        unsigned ma = 0, mb = 0;
+        for (int j = 0; j < NP; ++j) {
+            const unsigned ha = hi_abs(fetch(ra, j, A) * pre[j]), hb = hi_abs(fetch(rb, j, A) * pre[j]);
+            ma = ma > ha ? ma : ha;
+            mb = mb > hb ? mb : hb;
+        }
+        return make_info(ma, mb);
     }
 
     // HALF front end, split in two so the HBM loads of the NEXT pair are issued a whole pair ahead
@@ -155,10 +313,12 @@ struct Fftlog {
         }
     }
 
-    // ... and consume: x[r + Q] = (va[r], vb[r]) * pre[t + T (r + 4)]; padded points from the constant / edge value
+    // ... and consume: x[r + Q] = (va[r], vb[r]) * pre[t + T (r + 4)]; padded points from the constant / edge value.
+    // SCREEN_AHEAD: the products were formed when the rows were screened (screen_prefetched) and st.info_cur holds the verdict;
+    // otherwise the screening happens in here (`info` returns the pair's exponent fields).
     template <class ST>
-    static CP_HD void load_input_half(int t, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
-                                      const double* __restrict__ pre, const ST& st, cplx* x) {
+    static CP_HD void load_input_half(int t, int t_real, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb,
+                                      bool has_b, const double* __restrict__ pre, cplx* lds, ST& st, cplx* x) {
         double ia[H], ib[H];
 #pragma unroll
         for (int r = 0; r < H; ++r) ia[r] = st.va[r], ib[r] = st.vb[r];
@@ -166,10 +326,15 @@ struct Fftlog {
         // (va, vb) hold (row[n], row[n+1]) of this lane's row: trade with the neighbour lane
         if (T >= 2 && !(CP_ABLATE & 8)) lane_transpose2_all<H>(ia, ib);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+        constexpr bool tilted = SCREEN_AHEAD;
+#else
+        constexpr bool tilted = false;
+#endif
 #pragma unroll
         for (int r = 0; r < H; ++r) {
-            x[r + Q].re = ia[r] * st.fpre[r];
-            x[r + Q].im = ib[r] * st.fpre[r];  // an incomplete pair has row b aliased to row a (never stored): no select needed
+            x[r + Q].re = tilted ? ia[r] : ia[r] * st.fpre[r];
+            x[r + Q].im = tilted ? ib[r] : ib[r] * st.fpre[r];  // an incomplete pair has row b aliased to row a (never stored)
         }
         if constexpr (IN_MODE == IN_HALF) {
             const double la = A.ext_l == CP_EXTRAP_CONST ? A.val_l : ra[0];
@@ -180,26 +345,41 @@ struct Fftlog {
             for (int r = 0; r < Q; ++r) {
                 const double fl = pre[t + T * r], fh = pre[t + T * (r + 3 * Q)];
                 x[r].re = la * fl;
-                x[r].im = has_b ? lb * fl : 0.;
+                x[r].im = lb * fl;
                 x[r + 3 * Q].re = ha * fh;
-                x[r + 3 * Q].im = has_b ? hb * fh : 0.;
+                x[r + 3 * Q].im = hb * fh;
             }
         } else {
 #pragma unroll
             for (int r = 0; r < Q; ++r) x[r] = x[r + 3 * Q] = cplx{0., 0.};
         }
+        if constexpr (SCREEN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (SCREEN_AHEAD) {
+                fix_input<H>(decode_info(st.info_cur), x + Q);
+                return;
+            }
+#endif
+            if constexpr (IN_MODE == IN_HALF) {
+                screen_in_phase0<P>(t_real, A, ra, rb, pre, lds, st.info_cur, x);
+            } else {  // zero padding: only the H in-range points count
+                screen_in_phase0<H>(t_real, A, ra, rb, pre, lds, st.info_cur, x + Q);
+            }
+        }
     }
 
-    // generic phase 0 front end: x[r] = (a[j], b[j]) * pre[j], j = t + T r  (pass 0: R = P, M = T)
-    static CP_HD void load_input(int t, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
-                                 const double* __restrict__ pre, cplx* x) {
+    // generic phase 0 front end: x[r] = (a[j], b[j]) * pre[j], j = t + T r  (pass 0: R = P, M = T); the row screening reduces
+    // over the workgroup in here (`info` returns the pair's exponent fields)
+    static CP_HD void load_input(int t, int t_real, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
+                                 const double* __restrict__ pre, cplx* lds, unsigned& info, cplx* x) {
 #pragma unroll
         for (int r = 0; r < P; ++r) {
             const int j = t + T * r;
             const double f = pre[j];
             x[r].re = fetch(ra, j, A) * f;
-            x[r].im = has_b ? fetch(rb, j, A) * f : 0.;
+            x[r].im = fetch(rb, j, A) * f;  // an incomplete pair has row b aliased to row a (never stored)
         }
+        if constexpr (SCREEN) screen_in_phase0<P>(t_real, A, ra, rb, pre, lds, info, x);
     }
 
     // OUT_HALF back end with the postfactors already in registers: the 16 stores go out back to back
@@ -214,9 +394,10 @@ struct Fftlog {
             ya[s] = x[s + Q].re * st.fpost[s];
             yb[s] = x[s + Q].im * st.fpost[s];
         }
+        if constexpr (SCREEN) fix_output<H>(decode_info(st.info_cur), ya, yb);
         if (A.nker > 1) {
             CP_SCHED_FENCE();
-            load_factors_half(t, A, nxt_ker, st);
+            load_factors_half<!SCREEN_AHEAD_DEVICE>(t, A, nxt_ker, st);  // screen_prefetched has the next prefactors already
             CP_SCHED_FENCE();
         }
         if (CP_ABLATE & 16) {
@@ -251,7 +432,7 @@ struct Fftlog {
 
     // last phase back end: natural-order outputs n = t + T s -> crop, x post, split Re/Im to the two rows
     static CP_HD void store_output(int t, const FftlogArgs& A, double* __restrict__ oa, double* __restrict__ ob, bool has_b,
-                                   const double* __restrict__ post, const cplx* x) {
+                                   const double* __restrict__ post, const RowFix& fix, const cplx* x) {
         if constexpr (OUT_MODE == OUT_HALF) {
             static_assert(OUT_MODE != OUT_HALF, "OUT_HALF goes through store_output_half");
         } else {
@@ -261,8 +442,10 @@ struct Fftlog {
                 const int o = nidx - A.out_off;
                 if (o >= 0 && o < A.n_out) {
                     const double f = post[nidx];
-                    oa[o] = x[s].re * f;
-                    if (has_b) ob[o] = x[s].im * f;
+                    double ya = x[s].re * f, yb = x[s].im * f;
+                    if constexpr (SCREEN) fix_output<1>(fix, &ya, &yb);
+                    oa[o] = ya;
+                    if (has_b) ob[o] = yb;
                 }
             }
         }
@@ -277,6 +460,7 @@ struct Fftlog {
     //         when nker == 1) and the pair's rows, prefetched one whole pair ahead.
     struct State {
         int t0;  // pass0_thread(t)
+        unsigned info_cur, info_nxt;  // row screening of the current / the next (prefetched) pair, wave-uniform
         cplx w[P];
         double fpre[H], fpost[H];
         double va[H], vb[H];
@@ -299,12 +483,13 @@ struct Fftlog {
         }
     }
 
+    template <bool WITH_PRE = true>
     static CP_HD void load_factors_half(int t, const FftlogArgs& A, int ker, State& st) {
         const double* __restrict__ pre = A.pre + (long long)ker * NP;
         const double* __restrict__ post = A.post + (long long)ker * NP;
 #pragma unroll
         for (int r = 0; r < H; ++r) {
-            st.fpre[r] = ld_f64(pre, (unsigned)t * 8u, (unsigned)(T * (r + Q)) * 8u);
+            if (WITH_PRE) st.fpre[r] = ld_f64(pre, (unsigned)t * 8u, (unsigned)(T * (r + Q)) * 8u);
             st.fpost[r] = ld_f64(post, (unsigned)t * 8u, (unsigned)(T * (r + Q)) * 8u);
         }
     }
@@ -312,6 +497,30 @@ struct Fftlog {
     // once per workgroup: thread t copies its share of the middle-pass twiddle tables into LDS (a barrier follows)
     static CP_HD void fill_lds_tables(int t, const FftlogArgs& A, cplx* lds) {
         for (int i = t; i < LDS_TW_ENTRIES; i += T) lds[LDS_DATA + i] = A.tw[NP + i];
+    }
+
+    // SCREEN_AHEAD: tilt the rows in the prefetch registers (the NEXT pair; the products stay in va / vb for its phase 0) and
+    // publish their magnitudes for the reduction over the workgroup.  Called in the phase in front of the last barrier of a pair,
+    // where the prefetch (issued in phase 0, ahead of the U loads that phase LAST has already waited for) has long landed.
+    // With several kernels the next pair's prefactors are fetched here (the current ones are dead after phase 0).
+    static CP_HD void screen_prefetched(int t, int t0, const FftlogArgs& A, int nxt_ker, cplx* lds, State& st) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (SCREEN_AHEAD) {
+            if (A.nker > 1) {
+                const double* __restrict__ pre = A.pre + (long long)nxt_ker * NP;
+#pragma unroll
+                for (int r = 0; r < H; ++r) st.fpre[r] = ld_f64(pre, (unsigned)t0 * 8u, (unsigned)(T * (r + Q)) * 8u);
+            }
+#pragma unroll
+            for (int r = 0; r < H; ++r) {
+                st.va[r] *= st.fpre[r];
+                st.vb[r] *= st.fpre[r];
+            }
+            unsigned ma = 0, mb = 0;
+            thread_max<H>(st.va, st.vb, ma, mb);
+            screen_publish(t, lds, ma, mb);
+        }
+#endif
     }
 
     // before the first pair of a workgroup
@@ -365,15 +574,18 @@ struct Fftlog {
         const double* post = A.post + (long long)ker * NP;
         CP_FS_BEGIN(st);
         if constexpr (NPASS == 1) {
-            load_input(t0, A, ra, rb, has_b, pre, x);
+            load_input(t0, t, A, ra, rb, has_b, pre, lds, st.info_cur, x);
             Pass<NP, P, 0>::butterflies(x);
             load_u(t0, A, ker, st.w);
             mul_w(st.w, x);
             Pass<NP, P, 0>::butterflies(x);
-            store_output(t0, A, oa, ob, has_b, post, x);
+            store_output(t0, A, oa, ob, has_b, post, decode_info(st.info_cur), x);
         } else if constexpr (PH == 0) {
             if constexpr (HALF_IN) {
-                load_input_half(t0, A, ra, rb, has_b, pre, st, x);
+#if defined(__HIP_DEVICE_COMPILE__)
+                if constexpr (SCREEN_AHEAD) st.info_cur = st.info_nxt;  // found a pair ahead (screen_prefetched)
+#endif
+                load_input_half(t0, t, A, ra, rb, has_b, pre, lds, st, x);
                 // The NEXT pair's rows are requested right here, as soon as the prefetch registers are free: a whole pair
                 // before they are consumed, ahead of every other memory operation of this pair (vmcnt retires in order, so
                 // the U / twiddle waits of phases 2 and 4 also retire them) and never behind this pair's stores.
@@ -381,7 +593,7 @@ struct Fftlog {
                 prefetch_rows(t0, nra, nrb, st.va, st.vb);
                 CP_SCHED_FENCE();
             } else {
-                load_input(t0, A, ra, rb, has_b, pre, x);
+                load_input(t0, t, A, ra, rb, has_b, pre, lds, st.info_cur, x);
             }
             // IN_HALF_ZERO: points 0..3 and 12..15 are structural zeros
             Pass<NP, P, 0>::template butterflies_store<IN_MODE == IN_HALF_ZERO, true>(t0, st.w, lds, x);
@@ -400,6 +612,7 @@ struct Fftlog {
             Pass<NP, P, I>::template butterflies_store<false, true>(t, st.w, lds, x);
             load_tables_for<PH + 1>(t, t0, A, ker, st.w);
         } else if constexpr (PH == LAST) {
+            if constexpr (PH == NPH - 2) screen_prefetched(t, t0, A, nxt_ker, lds, st);
             Pass<NP, P, LAST>::load_lds(t, lds, x);
             CP_FS(st, PH);
             Pass<NP, P, LAST>::butterflies(x);  // M == 1: no twiddles
@@ -409,6 +622,7 @@ struct Fftlog {
             load_tables_for<PH + 1>(t, t0, A, ker, st.w);
         } else if constexpr (PH < NPH - 1) {
             constexpr int I = (PH > LAST && PH < NPH - 1) ? (NPH - 1 - PH) : 0;
+            if constexpr (PH == NPH - 2) screen_prefetched(t, t0, A, nxt_ker, lds, st);
             Pass<NP, P, I>::twiddle_load_lds(t, lds_tw<I>(lds), st.w);
             Pass<NP, P, I>::load_lds(t, lds, x);
             CP_SCHED_FENCE();
@@ -418,6 +632,9 @@ struct Fftlog {
             load_tables_for<PH + 1>(t, t0, A, ker, st.w);
         } else {
             Pass<NP, P, 0>::load_lds(t0, lds, x);
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (SCREEN_AHEAD) st.info_nxt = screen_collect(lds);  // published in front of the barrier that precedes this phase
+#endif
             // No barrier between this pair and the next: the slots read here are exactly the slots this same thread writes in
             // the next pair's phase 0 (pass-0 shape, in place), the LDS executes one wave's instructions in order, and no other
             // thread touches them before the barrier that follows phase 0.
@@ -434,7 +651,7 @@ struct Fftlog {
             if constexpr (HALF_IN && OUT_MODE == OUT_HALF) {
                 store_output_half(t0, A, oa, ob, has_b, nxt_ker, st, x);
             } else {
-                store_output(t0, A, oa, ob, has_b, post, x);
+                store_output(t0, A, oa, ob, has_b, post, decode_info(st.info_cur), x);
             }
         }
     }

@@ -144,7 +144,10 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
     }
     if constexpr (F::NPASS > 1) {
         F::fill_lds_tables(t, A, lds);
+        // row screening of the first pair (HALF variants; later pairs are screened a pair ahead inside the loop)
+        F::screen_prefetched(t, st.t0, A, cur.ker, lds, st);
         __syncthreads();
+        if constexpr (F::SCREEN_AHEAD) st.info_nxt = F::screen_collect(lds);
     }
     // Drain the one-off loads here.  Otherwise the compiler's wait-count merge at the loop head must also cover this
     // entry path (where the row prefetch is the YOUNGEST operation) and emits vmcnt(0) at the top of every pair, which

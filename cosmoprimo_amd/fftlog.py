@@ -199,13 +199,12 @@ class FFTlog(dv.Copyable):
         device : int, string, torch.device, default=None
             GPU holding the plan; defaults to the device of the first input (current CUDA device for numpy inputs).
 
-        rescale_rows : bool, default=False (``engine_kwargs``)
-            The kernel transforms two rows at a time packed as one complex sequence, so rounding is relative to the larger row
-            of a pair.  With ``rescale_rows=True`` every row is divided by the power of two next to its largest magnitude
-            before the transform and multiplied back afterwards (both exact), which makes the error of each row relative to its
-            own norm at the price of two more elementwise passes over the batch.  Only with zero / 'edge' / 'log' padding.
+        rescale_rows : bool (``engine_kwargs``)
+            Accepted for compatibility with earlier versions of this package and ignored: the kernel now always keeps the rounding
+            of a row relative to its own magnitude (rows that differ by more than a factor 32 from their pair partner are rescaled
+            by exact powers of two inside the kernel).
         """
-        self._rescale_rows = bool(engine_kwargs.pop('rescale_rows', False))
+        engine_kwargs.pop('rescale_rows', None)
         self.inparallel = isinstance(kernel, (tuple, list))
         if not self.inparallel:
             kernel = [kernel]
@@ -373,23 +372,9 @@ class FFTlog(dv.Copyable):
         tin = tfun.expand(bshape).contiguous()
         el, er = _split_pair(extrap)
         (cl, vl), (cr, vr) = _extrap_code(el), _extrap_code(er)
-        # Two rows share one complex transform in the kernel, so a NaN / Inf in one row would spread to its pair partner, which the
-        # reference's row-by-row FFTs do not do: such rows are transformed as zeros and filled with NaN afterwards (all of numpy's output
-        # for them is NaN as well).  One pass over the input and one host read of a flag; the C ABI itself leaves this to its caller.
-        finite, scale = None, None
-        if self._rescale_rows and ((cl == 0 and vl != 0.) or (cr == 0 and vr != 0.)):
-            raise ValueError('rescale_rows cannot be combined with a non-zero constant padding value')
-        if tin.numel():
-            if self._rescale_rows:
-                finite, scale = dv.screen_rows(tin, with_scale=True)                  # 2^e >= max|row| (1 for an all-zero row)
-            else:
-                finite = dv.screen_rows(tin)
-            if bool(finite.all()):
-                finite = None
-            else:
-                tin = torch.where(finite, tin, torch.zeros_like(tin))
-            if scale is not None:
-                tin = tin / scale
+        # Rows stay independent inside the kernel (non-finite rows give NaN rows, rows of very different magnitude are rescaled by exact
+        # powers of two: csrc/cp_fftlog_body.h, "row independence"), as with numpy's row-by-row FFTs: nothing to screen here, no extra
+        # pass over the batch, no host synchronisation.
         nbatch = 1
         for s in bshape[:-2] if nker > 1 else bshape[:-1]:
             nbatch *= s
@@ -401,10 +386,6 @@ class FFTlog(dv.Copyable):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(_lib.load().cp_fftlog_execute(plan.handle, tin.data_ptr(), tout.data_ptr(), nbatch, cl, vl, cr, vr, int(bool(keep_padding)),
                                                      stream))
-        if scale is not None:
-            tout = tout * scale
-        if finite is not None:
-            tout = torch.where(finite, tout, torch.full_like(tout, float('nan')))
         if self._phase is not None:
             tout = tout * self._device_copy('phase', self._phase, dev)[:, None]
         y = self.padded_y if keep_padding else self.y

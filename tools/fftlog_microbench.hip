@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice));
     FftlogArgs A;
     A.in = d_in; A.out = d_out; A.nbatch = nbatch; A.nker = 1; A.n = N; A.in_left = NP / 4; A.out_off = NP / 4; A.n_out = N;
-    A.ext_l = A.ext_r = MB_GENERIC == 2 ? 1 : 0; A.val_l = A.val_r = 0.; A.pre = d_pre; A.post = d_post; A.u = d_u; A.tw = d_tw;
+    A.ext_l = A.ext_r = MB_GENERIC == 2 ? 1 : 0; A.val_l = A.val_r = 0.; A.pad_hi = 0; A.pre = d_pre; A.post = d_post; A.u = d_u; A.tw = d_tw;
 #if defined(CP_STAMPS)
     unsigned long long* d_stamp;
     const size_t nstamp = (size_t)2048 * 8 * 16;
