@@ -154,8 +154,27 @@ def main():
     elapsed = time.perf_counter() - tic
     kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
 
+    # the same K steps through the product API (cp.PowerToCorrelation.__call__ on the resident tensor: output allocation, plan
+    # lookup and the ctypes call included, no host synchronisation inside)
+    for _ in range(max(1, args.warmup)):
+        f(rows)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    tic_api = time.perf_counter()
+    for i in range(args.steps):
+        s_api, xi_api = f(rows)
+    torch.cuda.synchronize(dev)
+    if distributed:
+        dist.barrier()
+    elapsed_api = time.perf_counter() - tic_api
+    assert xi_api.shape == rows.shape and bool(torch.equal(xi_api, out)), 'API path and C-ABI path disagree'
+
     gather_ms = None
     if distributed:
+        tapi = torch.tensor([elapsed_api], device=dev, dtype=torch.float64)
+        dist.all_reduce(tapi, op=dist.ReduceOp.MAX)
+        elapsed_api = float(tapi[0])
         tmax = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
@@ -204,6 +223,7 @@ def main():
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'fftlog_kernel<4096,16,IN_HALF_ZERO,OUT_HALF>', 'kernel_ms': kernel_ms,
                          'algorithmic_bytes_per_launch': BYTES_PER_ROW * nb},
             'parity_spot_check_tilted_err': err,
+            'value_api': nb * world * args.steps / elapsed_api,   # same batch through cp.PowerToCorrelation.__call__ (resident tensors)
         }
         if cpu is not None:
             line['cpu_baseline'] = cpu

@@ -15,6 +15,14 @@ ABI_VERSION = 1
 CP_OK, CP_EINVAL, CP_EUNSUPPORTED, CP_EDEVICE, CP_ENOMEM = range(5)
 EXTRAP_CONSTANT, EXTRAP_EDGE, EXTRAP_LOGLOG = range(3)
 (KERNEL_BESSEL_J, KERNEL_SPHERICAL_BESSEL_J, KERNEL_TOPHAT, KERNEL_TOPHAT_SQ, KERNEL_GAUSSIAN, KERNEL_GAUSSIAN_SQ) = range(6)
+KERNEL_CUSTOM = 100
+
+
+class FFTlogSpec(ctypes.Structure):
+    """cp_fftlog_spec (include/cosmoprimo_amd.h): kernel, tilt and convention of one transform of a plan."""
+    _fields_ = [('kind', ctypes.c_int), ('param', ctypes.c_double), ('q', ctypes.c_double), ('xy', ctypes.c_double), ('pre_power', ctypes.c_double),
+                ('pre_const', ctypes.c_double), ('post_sign', ctypes.c_double)]
+
 
 _c_double_p = ctypes.POINTER(ctypes.c_double)
 _c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -27,6 +35,9 @@ SIGNATURES = {
     'cp_loggamma': (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_longlong]),
     'cp_gamma': (ctypes.c_int, [_c_double_p, _c_double_p, ctypes.c_longlong]),
     'cp_kernel_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_double, _c_double_p, _c_double_p, ctypes.c_longlong]),
+    'cp_fftlog_padded_size': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    'cp_fftlog_tables': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.POINTER(FFTlogSpec), ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       _c_double_p, _c_double_p] + [_c_double_p] * 8),
     'cp_fftlog_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                                             _c_double_p, _c_double_p, ctypes.c_int]),
     'cp_fftlog_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double,

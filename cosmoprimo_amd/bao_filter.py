@@ -680,21 +680,27 @@ class Kirkby2013CorrelationFunctionBAOFilter(BaseCorrelationFunctionBAOFilter):
         self.rescale_sbox = rescale_sbox
         super(Kirkby2013CorrelationFunctionBAOFilter, self).__init__(xi_interpolator, cosmo=cosmo, **kwargs)
 
+    # Shape of the fit (reference bao_filter.py:885-896, 898-909): a polynomial in 1/s of degree 3 times s, i.e. the five powers
+    # s^1 .. s^-3, fitted with weight 1 inside the two side boxes; the weight ramps linearly to 0 over 1 % of a box edge outside
+    # the boxes and over 1 % of the gap towards the peak.  The peak region is where the weight is 0 between the boxes: there (and on
+    # the inner ramps, blended linearly) xi is replaced by the fitted curve.  Samples beyond a factor 2 of the outer box edges do
+    # not enter the fit at all.
+    _n_powers, _ramp_fraction, _fit_reach = 5, 0.01, 2.
+
     def _prepare(self):
-        factor = 2.  # safety factor
-        self.smask = (self.s >= self.srange_left[0] / factor) & (self.s <= self.srange_right[1] * factor)
-        self.model = np.array([self.s**(1 - i) for i in range(5)])
-        frac = 1. / 100.
-        shift_center = (self.srange_right[0] - self.srange_left[1]) * frac
-        self.window = (np.concatenate([[self.srange_left[0] * (1. - frac)], self.srange_left,
-                                       [self.srange_left[1] + shift_center, self.srange_right[0] - shift_center],
-                                       self.srange_right, [self.srange_right[1] * (1. + frac)]], axis=0),
-                       np.array([0., 1., 1., 0., 0., 1., 1., 0.]))
+        (l0, l1), (r0, r1) = self.srange_left, self.srange_right
+        self.smask = (self.s >= l0 / self._fit_reach) & (self.s <= r1 * self._fit_reach)
+        self.model = self.s[None, :]**(1. - np.arange(self._n_powers))[:, None]
+        ramp = (r0 - l1) * self._ramp_fraction
+        knots = np.array([l0 * (1. - self._ramp_fraction), l0, l1, l1 + ramp, r0 - ramp, r0, r1, r1 * (1. + self._ramp_fraction)])
+        self.window = (knots, np.array([0., 1., 1., 0., 0., 1., 1., 0.]))
 
     def _operator(self, rescale):
-        """xinow = A xi with A = diag(1 - center) + diag(center) model^T (G W G^T)^-1 G W (restricted to ``smask`` columns)."""
-        precision = np.interp(self.s[self.smask] / rescale, self.window[0], self.window[1], left=0., right=0.)
-        center = np.interp(self.s / rescale, self.window[0][2:-2], 1. - self.window[1][2:-2], left=0., right=0.)
+        """xinow = A xi with A = diag(1 - center) + diag(center) model^T (G W G^T)^-1 G W (restricted to ``smask`` columns): the weighted
+        least-squares fit of :class:`utils.LeastSquareSolver` written as a projector, so that the whole filter is one linear map."""
+        knots, weights = self.window
+        precision = np.interp(self.s[self.smask] / rescale, knots, weights, left=0., right=0.)
+        center = np.interp(self.s / rescale, knots[2:-2], 1. - weights[2:-2], left=0., right=0.)   # 1 between the boxes, ramps on their inner edges
         g = self.model[:, self.smask]
         hv = g * precision
         proj = np.linalg.solve(hv.dot(g.T), hv)               # (5, nmask): parameters = proj . xi[smask]

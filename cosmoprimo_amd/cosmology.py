@@ -186,15 +186,13 @@ def _split_neutrino_masses(sum_ncdm, hierarchy):
     if hierarchy == 'normal':
         deltam31sq = 2.525e-3
         if sum_ncdm**2 < deltam21sq + deltam31sq:
-            raise CosmologyInputError('If neutrino_hierarchy is normal, we are using the normal hierarchy and so m_ncdm must be greater than '
-                                      '(~)0.0592, found {:.2f}'.format(sum_ncdm))
+            raise CosmologyInputError('the normal neutrino hierarchy needs a total mass above sqrt(dm21^2 + dm31^2) ~ 0.0592 eV, got {:.4f} eV'.format(sum_ncdm))
         return newton([0., deltam21sq, deltam31sq], deltam21sq, deltam31sq)
     if hierarchy == 'inverted':
         deltam32sq = -2.512e-3
         deltam31sq = deltam32sq + deltam21sq
         if sum_ncdm**2 < -deltam31sq - deltam32sq:
-            raise CosmologyInputError('If neutrino_hierarchy is inverted, we are using the inverted hierarchy and so m_ncdm must be greater than '
-                                      '(~)0.0978, found {:.2f}'.format(sum_ncdm))
+            raise CosmologyInputError('the inverted neutrino hierarchy needs a total mass above sqrt(-dm31^2 - dm32^2) ~ 0.0978 eV, got {:.4f} eV'.format(sum_ncdm))
         return newton([np.sqrt(-deltam31sq), np.sqrt(-deltam32sq), 1e-5], deltam21sq, deltam31sq)
     if hierarchy == 'degenerate':
         return [sum_ncdm / 3.] * 3

@@ -5,9 +5,9 @@ FFTLog on MI355X: same classes and call signatures as the reference ``cosmoprimo
 ``FFTlog.__call__`` executed by ONE fused HIP kernel (``csrc/cp_fftlog*.{h,hip}``) through the C ABI
 of ``libcosmoprimo_amd.so``.
 
-Host side (this file): table setup exactly as reference ``FFTlog._setup`` (fftlog.py:144-184) in
-numpy, with the complex log-gamma of the Mellin kernels evaluated by the library's own host routine
-(``cp_kernel_eval``), and shape / dtype bookkeeping of ``__call__`` (fftlog.py:198-241).
+Host side (this file): argument handling and the shape / dtype bookkeeping of ``__call__`` (fftlog.py:198-241); the
+plan tables (what reference ``FFTlog._setup`` computes, fftlog.py:144-184, plus the conventions of the named transforms)
+come from the library's host routine ``cp_fftlog_tables`` (``csrc/cp_fftlog_setup.cpp``).
 Inputs may be numpy arrays (copied to the GPU and back) or torch CUDA tensors (zero copy; results
 stay on the device).  There is no CPU compute path.
 """
@@ -181,11 +181,33 @@ def _is_torch(x):
     return type(x).__module__.startswith('torch')
 
 
+def _unit_phase_split(table, what):
+    """Split a (nker, npad) table into a real table and one unit complex factor per row (tables of ``complex=True`` transforms and of
+    their inverses are of that form); real tables return ``(table, None)``."""
+    table = np.asarray(table)
+    if not np.iscomplexobj(table):
+        return np.ascontiguousarray(table, dtype='f8'), None
+    pivot = np.abs(table).argmax(axis=-1)
+    lead = table[np.arange(table.shape[0]), pivot]
+    phase = lead / np.abs(lead)
+    real = table / phase[:, None]
+    if np.abs(real.imag).max() > 1e-12 * np.abs(real.real).max():
+        raise NotImplementedError('{} must be a real table times one complex factor per transform'.format(what))
+    return np.ascontiguousarray(real.real), phase
+
+
 class FFTlog(dv.Copyable):
     r"""
     FFTLog algorithm (https://jila.colorado.edu/~ajsh/FFTLog/) for :math:`G(y) = \int_0^\infty x dx F(x) K(xy)`,
     same constructor and call contract as the reference (fftlog.py:31-248).
+
+    The named transforms below differ from the bare algorithm only by a *convention* (class attribute ``_convention``): an offset
+    added to the tilt ``q``, a power law ``c x^p`` multiplied into the prefactor and a phase per multipole for the postfactor.
+    All tables come from one call to the library's host routine ``cp_fftlog_tables``.
     """
+    # (tilt offset, prefactor power p, prefactor constant c, phase of order ell or None)
+    _convention = (0., 0., 1., None)
+
     def __init__(self, x, kernel, q=0, minfolds=2, lowring=True, xy=1, check_level=0, engine='mi355x', device=None, **engine_kwargs):
         r"""
         Parameters are those of the reference (fftlog.py:49-92): ``x`` log-spaced input coordinates (1D or one row per
@@ -195,6 +217,8 @@ class FFTlog(dv.Copyable):
         engine : string, default='mi355x'
             The fused HIP kernel.  The reference's names ``'numpy'`` and ``'fftw'`` are accepted and run the same kernel
             (this package has no CPU path); ``engine_kwargs`` of the FFTW engine (``nthreads``, ``wisdom``, ``plan``) are ignored.
+            An object with the reference's ``forward`` / ``backward`` methods (fftlog.py:508-544) is honoured as well: the
+            transform then runs un-fused around that engine (prefactor, engine.forward, x u, engine.backward, postfactor).
 
         device : int, string, torch.device, default=None
             GPU holding the plan; defaults to the device of the first input (current CUDA device for numpy inputs).
@@ -206,31 +230,20 @@ class FFTlog(dv.Copyable):
         """
         engine_kwargs.pop('rescale_rows', None)
         self.inparallel = isinstance(kernel, (tuple, list))
-        if not self.inparallel:
-            kernel = [kernel]
-        kernel = list(kernel)
-        if np.ndim(q) == 0:
-            q = [q] * len(kernel)
-        q = list(q)
-        self.x = np.asarray(x, dtype='f8')
-        if not self.inparallel:
-            self.x = self.x[None, :]
-        elif self.x.ndim == 1:
-            self.x = np.tile(self.x[None, :], (len(kernel), 1))
-        if np.ndim(xy) == 0:
-            xy = [xy] * len(kernel)
-        xy = list(xy)
-        if check_level:
-            if len(self.x) != len(kernel):
-                raise ValueError('x and kernel must of same length')
-            if len(q) != len(kernel):
-                raise ValueError('q and kernel must be lists of same length')
-            if len(xy) != len(kernel):
-                raise ValueError('xy and kernel must be lists of same length')
+        kernels = list(kernel) if self.inparallel else [kernel]
+        nker = len(kernels)
+        x = np.array(x, dtype='f8')
+        if check_level and self.inparallel and x.ndim == 2 and x.shape[0] != nker:
+            raise ValueError('x and kernel must of same length')
+        for name, value in (('q', q), ('xy', xy)):
+            if check_level and np.ndim(value) and len(value) != nker:
+                raise ValueError('{} and kernel must be lists of same length'.format(name))
+        self.x = np.ascontiguousarray(np.broadcast_to(x, (nker, x.shape[-1])))     # one row of coordinates per kernel
         self._device = device
-        self._plan = None
-        self._phase = None  # complex phase applied after the (real) postfactor, see PowerToCorrelation(complex=True)
-        self._setup(kernel, q, minfolds=minfolds, lowring=lowring, xy=xy, check_level=check_level)
+        self._phase = None       # unit complex factor per kernel on the way out (complex=True transforms), else None
+        self._phase_in = None    # ... and on the way in (inverse of a complex=True transform)
+        self._setup(kernels, np.broadcast_to(np.asarray(q, dtype='f8'), (nker,)), minfolds=minfolds, lowring=lowring,
+                    xy=np.broadcast_to(np.asarray(xy, dtype='f8'), (nker,)), check_level=check_level)
         self.set_fft_engine(engine, **engine_kwargs)
 
     def _device_copy(self, name, array, dev):
@@ -256,46 +269,72 @@ class FFTlog(dv.Copyable):
         return self.x.shape[-1]
 
     def _setup(self, kernels, qs, minfolds=2, lowring=True, xy=1., check_level=0):
-        """Set up u functions and pre/post factors: host numpy, operation for operation as reference fftlog.py:144-184."""
-        self.delta = np.log(self.x[:, -1] / self.x[:, 0]) / (self.size - 1)
-
-        nfolds = (self.size * minfolds - 1).bit_length()
-        self.padded_size = 2**nfolds
-        npad = self.padded_size - self.size
-        self.padded_size_in_left, self.padded_size_in_right = npad // 2, npad - npad // 2
-        self.padded_size_out_left, self.padded_size_out_right = npad - npad // 2, npad // 2
-
-        if check_level:
-            if not np.allclose(np.log(self.x[:, 1:] / self.x[:, :-1]), self.delta[:, None], rtol=1e-3):
-                raise ValueError('Input x must be log-spaced')
-            if self.padded_size < self.size:
-                raise ValueError('Convolution size must be larger than input x size')
-
-        if lowring:
-            self.lnxy = np.array([delta / np.pi * np.angle(kernel(q + 1j * np.pi / delta)) for kernel, delta, q in zip(kernels, self.delta, qs)], dtype='f8')
-        else:
-            self.lnxy = np.log(xy) + self.delta
-
-        self.y = np.exp(self.lnxy - self.delta)[:, None] / self.x[:, ::-1]
-
-        m = np.arange(0, self.padded_size // 2 + 1)
-        self.padded_u, self.padded_prefactor, self.padded_postfactor = [], [], []
-        self.padded_x = pad(self.x, (self.padded_size_in_left, self.padded_size_in_right), axis=-1, extrap='log')
-        self.padded_y = pad(self.y, (self.padded_size_out_left, self.padded_size_out_right), axis=-1, extrap='log')
-        prev_kernel, prev_q, prev_delta, prev_u = None, None, None, None
-        for kernel, padded_x, padded_y, lnxy, delta, q in zip(kernels, self.padded_x, self.padded_y, self.lnxy, self.delta, qs):
-            self.padded_prefactor.append(padded_x**(-q))
-            self.padded_postfactor.append(padded_y**(-q))
-            if kernel is prev_kernel and q == prev_q and delta == prev_delta:
-                u = prev_u
-            else:
-                u = prev_u = np.asarray(kernel(q + 2j * np.pi / self.padded_size / delta * m))
-            self.padded_u.append(u * np.exp(-2j * np.pi * lnxy / self.padded_size / delta * m))
-            prev_kernel, prev_q, prev_delta = kernel, q, delta
-        self.padded_u = np.array(self.padded_u)
-        self.padded_prefactor = np.array(self.padded_prefactor)
-        self.padded_postfactor = np.array(self.padded_postfactor)
+        """All tables of the plan (what reference fftlog.py:144-184 sets up, plus the convention of the named transform), built on the
+        host by ``cp_fftlog_tables``; kernels that are arbitrary Python callables are evaluated here at the arguments the tables need."""
+        import ctypes
+        lib = _lib.load()
+        n, nker = self.size, self.nparallel
+        npad = lib.cp_fftlog_padded_size(n, int(minfolds))
+        if npad < 0:
+            raise ValueError('minfolds = {} and size = {:d} do not give a valid padded size'.format(minfolds, n))
+        self.padded_size = npad
+        left = (npad - n) // 2
+        self.padded_size_in_left, self.padded_size_in_right = left, npad - n - left
+        self.padded_size_out_left, self.padded_size_out_right = npad - n - left, left
+        q_offset, pre_power, pre_const, _ = self._convention
+        spec = (_lib.FFTlogSpec * nker)()
+        custom = [not isinstance(kernel, BaseKernel) or kernel._kind is None for kernel in kernels]
+        for ik, kernel in enumerate(kernels):
+            spec[ik].kind = _lib.KERNEL_CUSTOM if custom[ik] else kernel._kind
+            spec[ik].param = 0. if custom[ik] else kernel._param
+            spec[ik].q, spec[ik].xy = float(qs[ik]), float(np.broadcast_to(xy, (nker,))[ik])
+            spec[ik].pre_power, spec[ik].pre_const, spec[ik].post_sign = pre_power, pre_const, 1.
+        nu = npad // 2 + 1
+        u_custom = lowring_custom = None
+        if any(custom):
+            delta = np.log(self.x[:, -1] / self.x[:, 0]) / (n - 1)
+            u_custom, lowring_custom = np.zeros((nker, nu), dtype='c16'), np.zeros(nker, dtype='c16')
+            for ik, kernel in enumerate(kernels):
+                if custom[ik]:
+                    u_custom[ik] = kernel(qs[ik] + 2j * np.pi / npad / delta[ik] * np.arange(nu))   # same rounding as the library's arguments
+                    if lowring:
+                        lowring_custom[ik] = kernel(qs[ik] + 1j * np.pi / delta[ik])
+        out = {name: np.empty(shape, dtype='f8') for name, shape in [('delta', nker), ('lnxy', nker), ('y', (nker, n)), ('padded_x', (nker, npad)),
+                                                                     ('padded_y', (nker, npad)), ('pre', (nker, npad)), ('post', (nker, npad)),
+                                                                     ('u', (nker, nu, 2))]}
+        P = _lib.as_double_p
+        _lib.check(lib.cp_fftlog_tables(n, nker, P(self.x), spec, int(minfolds), int(bool(lowring)), int(check_level),
+                                        None if u_custom is None else P(u_custom.view('f8')), None if lowring_custom is None else P(lowring_custom.view('f8')),
+                                        *[P(out[name]) for name in ('delta', 'lnxy', 'y', 'padded_x', 'padded_y', 'pre', 'post', 'u')]))
+        self.delta, self.lnxy, self.y, self.padded_x, self.padded_y = (out[name] for name in ('delta', 'lnxy', 'y', 'padded_x', 'padded_y'))
+        self._pre, self._post, self._u = out['pre'], out['post'], out['u'][..., 0] + 1j * out['u'][..., 1]
         self._plan = None
+
+    # The three tables are plain arrays that user code may rescale (as the reference's subclasses do, fftlog.py:280): assigning
+    # one of them drops the device plan.  A complex table must be a real table times one unit factor per transform.
+    @property
+    def padded_prefactor(self):
+        return self._pre
+
+    @padded_prefactor.setter
+    def padded_prefactor(self, value):
+        self._pre, self._plan = np.asarray(value), None
+
+    @property
+    def padded_postfactor(self):
+        return self._post
+
+    @padded_postfactor.setter
+    def padded_postfactor(self, value):
+        self._post, self._plan = np.asarray(value), None
+
+    @property
+    def padded_u(self):
+        return self._u
+
+    @padded_u.setter
+    def padded_u(self, value):
+        self._u, self._plan = np.asarray(value), None
 
     # -- device plan --------------------------------------------------------------------------
     def _resolve_device(self, tensor=None):
@@ -318,18 +357,11 @@ class FFTlog(dv.Copyable):
         """Build (once per device) the library plan from the current tables."""
         if self._plan is not None and self._plan[0] == dev.index:
             return self._plan[1]
-        post = self.padded_postfactor
-        pre = self.padded_prefactor
-        if np.iscomplexobj(pre):
-            raise NotImplementedError('complex prefactor (inverse of a complex=True transform) is not supported')
-        if np.iscomplexobj(post):
-            # complex=True transforms: postfactor = real table x unit phase per kernel; the kernel applies the real
-            # table and the phase is applied on the way out
-            if self._phase is None:
-                raise NotImplementedError('complex postfactor without a per-kernel phase')
-            post = np.real(post / self._phase[:, None])
-        plan = _Plan(self.size, self.padded_size, pre, post, self.padded_u, dev.index)
+        pre, self._phase_in = _unit_phase_split(self._pre, 'the prefactor')
+        post, self._phase = _unit_phase_split(self._post, 'the postfactor')
+        plan = _Plan(self.size, self.padded_size, pre, post, self._u, dev.index)
         self._plan = (dev.index, plan)
+        self.__dict__.pop('_device_tables', None)
         return plan
 
     def __call__(self, fun, extrap=0, keep_padding=False):
@@ -343,49 +375,39 @@ class FFTlog(dv.Copyable):
         Returns ``(y, fftloged)``, numpy for numpy input, torch (same device) for torch input.  Output is float64
         (complex128 for ``complex=True`` transforms) as in the reference.
         """
+        if not isinstance(self._engine, MI355XFFTEngine):
+            return self._call_unfused(fun, extrap=extrap, keep_padding=keep_padding)
         torch = _torch()
         is_torch = _is_torch(fun)
-        if is_torch:
-            dev = self._resolve_device(fun)
-            tfun = fun.to(device=dev, dtype=torch.float64)
+        dev = self._resolve_device(fun if is_torch else None)
+        plan = self._get_plan(dev)           # also splits the unit phases off complex tables
+        if not is_torch:
+            fun = torch.from_numpy(np.ascontiguousarray(fun)).to(dev)
+        if self._phase_in is not None:       # complex prefactor: the FFT sees the real part of fun x prefactor (numpy.fft.rfft, fftlog.py:540)
+            tfun = (fun.to(torch.complex128) * self._device_copy('phase_in', self._phase_in, dev)[:, None]).real
         else:
-            fun = np.asarray(fun)
-            if np.iscomplexobj(fun):
-                fun = fun.real  # numpy.fft.rfft discards the imaginary part (fftlog.py:540)
-            dev = self._resolve_device(None)
-            tfun = torch.from_numpy(np.ascontiguousarray(fun, dtype='f8')).to(dev)
+            tfun = (fun.real if fun.is_complex() else fun).to(device=dev, dtype=torch.float64)
         n, nker, npad = self.size, self.nparallel, self.padded_size
         fshape = tuple(tfun.shape)
         if len(fshape) < 1 or fshape[-1] != n:
             raise ValueError('fun last dimension must be {:d}, got shape {}'.format(n, fshape))
         # broadcast against (nker, n), as fun * padded_prefactor does in the reference
-        if nker > 1:
-            if len(fshape) == 1:
-                tfun = tfun[None, :]
-            if tfun.shape[-2] not in (1, nker):
-                raise ValueError('fun shape {} does not broadcast against ({:d}, {:d})'.format(fshape, nker, n))
-            bshape = tuple(tfun.shape[:-2]) + (nker, n)
-        else:
-            bshape = fshape if len(fshape) >= 2 else (1, n)
-            if len(fshape) == 1:
-                tfun = tfun[None, :]
+        if len(fshape) == 1:
+            tfun = tfun[None, :]
+        if nker > 1 and tfun.shape[-2] not in (1, nker):
+            raise ValueError('fun shape {} does not broadcast against ({:d}, {:d})'.format(fshape, nker, n))
+        bshape = tuple(tfun.shape[:-2]) + (nker, n) if nker > 1 else tuple(tfun.shape)
         tin = tfun.expand(bshape).contiguous()
-        el, er = _split_pair(extrap)
-        (cl, vl), (cr, vr) = _extrap_code(el), _extrap_code(er)
+        (cl, vl), (cr, vr) = (_extrap_code(e) for e in _split_pair(extrap))
         # Rows stay independent inside the kernel (non-finite rows give NaN rows, rows of very different magnitude are rescaled by exact
         # powers of two: csrc/cp_fftlog_body.h, "row independence"), as with numpy's row-by-row FFTs: nothing to screen here, no extra
         # pass over the batch, no host synchronisation.
-        nbatch = 1
-        for s in bshape[:-2] if nker > 1 else bshape[:-1]:
-            nbatch *= s
+        nbatch = int(np.prod(bshape[:-2] if nker > 1 else bshape[:-1], dtype='i8'))
         nout = npad if keep_padding else n
-        oshape = bshape[:-1] + (nout,)
-        tout = torch.empty(oshape, dtype=torch.float64, device=dev)
+        tout = torch.empty(bshape[:-1] + (nout,), dtype=torch.float64, device=dev)
         if nbatch > 0:
-            plan = self._get_plan(dev)
-            stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(_lib.load().cp_fftlog_execute(plan.handle, tin.data_ptr(), tout.data_ptr(), nbatch, cl, vl, cr, vr, int(bool(keep_padding)),
-                                                     stream))
+                                                     torch.cuda.current_stream(dev).cuda_stream))
         if self._phase is not None:
             tout = tout * self._device_copy('phase', self._phase, dev)[:, None]
         y = self.padded_y if keep_padding else self.y
@@ -393,88 +415,95 @@ class FFTlog(dv.Copyable):
             y = y[0]
             tout = tout.reshape(fshape[:-1] + (nout,))
         if is_torch:
-            return self._device_copy('y_padded' if keep_padding else 'y' + ('' if self.inparallel else '0'), y, dev), tout
+            return self._device_copy(('y_padded' if keep_padding else 'y') + ('' if self.inparallel else '0'), y, dev), tout
         return y, dv.to_host(tout)
 
+    def _call_unfused(self, fun, extrap=0, keep_padding=False):
+        """The transform around a user-supplied engine object (reference fftlog.py:198-241 with the protocol of :508-544): host numpy
+        for the elementwise steps, ``engine.forward`` (real -> half complex spectrum) and ``engine.backward`` (which must compute
+        ``irfft(conj(.))``) for the FFTs.  This is the reference's plug point for foreign FFT libraries; the fused kernel is not involved."""
+        fun = np.asarray(fun.cpu() if _is_torch(fun) else fun)
+        spectrum = self._engine.forward(pad(fun, (self.padded_size_in_left, self.padded_size_in_right), axis=-1, extrap=extrap) * self.padded_prefactor)
+        out = self._engine.backward(spectrum * self.padded_u) * self.padded_postfactor
+        if keep_padding:
+            y = self.padded_y
+        else:
+            y, out = self.y, out[..., self.padded_size_out_left:self.padded_size_out_left + self.size]
+        if not self.inparallel:
+            y, out = y[0], out.reshape(fun.shape[:-1] + out.shape[-1:])
+        return y, out
+
     def inv(self):
-        """Inverse the transform, in place (reference fftlog.py:243-248, including its padded_x / padded_y quirk)."""
-        self.x, self.y = self.y, self.x
-        self.__dict__.pop('_device_tables', None)     # device copies of the output coordinates
-        self.padded_x, self.padded_y = self.y, self.x
-        self.padded_prefactor, self.padded_postfactor = 1 / self.padded_postfactor, 1 / self.padded_prefactor
-        self.padded_u = 1 / self.padded_u.conj()
-        if self._phase is not None:
-            raise NotImplementedError('inv() of a complex=True transform is not supported')
+        """Turn the transform into its inverse, in place (reference fftlog.py:243-248): input and output grids trade places (the padded
+        grids become the un-padded ones, as there), each factor becomes the reciprocal of its counterpart and u -> 1 / conj(u)."""
+        tables = dict(x=self.y, y=self.x, padded_x=self.y, padded_y=self.x, padded_prefactor=1. / self._post, padded_postfactor=1. / self._pre,
+                      padded_u=1. / np.conj(self._u))
+        for name, value in tables.items():
+            setattr(self, name, value)
+        self.__dict__.pop('_device_tables', None)     # device copies of the output coordinates and phases
         self._plan = None
 
 
+def _kernels_of(cls, order):
+    """One kernel for a scalar order, a list (transforms in parallel) for a sequence of orders."""
+    return cls(order) if np.ndim(order) == 0 else [cls(o) for o in order]
+
+
+class _MultipoleTransform(FFTlog):
+    """Transforms between multipoles of order ``ell`` with spherical Bessel kernels: tilt offset 1.5, prefactor x^3 c, and the phase
+    ``_phase_unit ** ell`` -- kept as such for ``complex=True`` (complex128 output), reduced to its real sign (-1)^(ell // 2) otherwise."""
+    _phase_unit = 1.
+
+    def __init__(self, x, ell=0, q=0, complex=False, **kwargs):
+        FFTlog.__init__(self, x, _kernels_of(SphericalBesselJKernel, ell), q=self._convention[0] + np.asarray(q), **kwargs)
+        ell = np.atleast_1d(ell)
+        phase = self._phase_unit**ell if complex else (-1.)**(ell // 2)
+        self.padded_postfactor = self._post * phase[:, None]
+
+
 class HankelTransform(FFTlog):
-    """Hankel transform with Bessel kernels (reference fftlog.py:252-280)."""
+    """Hankel transform with Bessel kernels of order ``nu`` (reference fftlog.py:252-280): prefactor x^2."""
+    _convention = (0., 2., 1., None)
+
     def __init__(self, x, nu=0, **kwargs):
-        if np.ndim(nu) == 0:
-            kernel = BesselJKernel(nu)
-        else:
-            kernel = [BesselJKernel(nu_) for nu_ in nu]
-        FFTlog.__init__(self, x, kernel, **kwargs)
-        self.padded_prefactor *= self.padded_x**2
+        FFTlog.__init__(self, x, _kernels_of(BesselJKernel, nu), **kwargs)
 
 
-class PowerToCorrelation(FFTlog):
+class PowerToCorrelation(_MultipoleTransform):
     r"""
     Power spectrum to correlation function (reference fftlog.py:284-330):
     :math:`\xi_\ell(s) = \frac{(-i)^\ell}{2\pi^2} \int dk k^2 P_\ell(k) j_\ell(ks)`.
     """
-    def __init__(self, k, ell=0, q=0, complex=False, **kwargs):
-        if np.ndim(ell) == 0:
-            kernel = SphericalBesselJKernel(ell)
-        else:
-            kernel = [SphericalBesselJKernel(ell_) for ell_ in ell]
-        FFTlog.__init__(self, k, kernel, q=1.5 + q, **kwargs)
-        self.padded_prefactor *= self.padded_x**3 / (2 * np.pi)**1.5
-        ell = np.atleast_1d(ell)
-        if complex:
-            phase = (-1j)**ell
-            self._phase = phase
-        else:
-            phase = (-1)**(ell // 2)
-        self.padded_postfactor = self.padded_postfactor * phase[:, None]
+    _convention = (1.5, 3., (2. * np.pi)**-1.5, None)
+    _phase_unit = -1j
 
 
-class CorrelationToPower(FFTlog):
+class CorrelationToPower(_MultipoleTransform):
     r"""
     Correlation function to power spectrum (reference fftlog.py:334-377):
     :math:`P_\ell(k) = 4\pi i^\ell \int ds s^2 \xi_\ell(s) j_\ell(ks)`.
     """
-    def __init__(self, s, ell=0, q=0, complex=False, **kwargs):
-        if np.ndim(ell) == 0:
-            kernel = SphericalBesselJKernel(ell)
-        else:
-            kernel = [SphericalBesselJKernel(ell_) for ell_ in ell]
-        FFTlog.__init__(self, s, kernel, q=1.5 + q, **kwargs)
-        self.padded_prefactor *= self.padded_x**3 * (2 * np.pi)**1.5
-        ell = np.atleast_1d(ell)
-        if complex:
-            phase = (1j)**ell
-            self._phase = phase
-        else:
-            phase = (-1)**(ell // 2)
-        self.padded_postfactor = self.padded_postfactor * phase[:, None]
+    _convention = (1.5, 3., (2. * np.pi)**1.5, None)
+    _phase_unit = 1j
 
 
-class TophatVariance(FFTlog):
+class _WindowVariance(FFTlog):
+    r"""Variance of the field smoothed by a window: :math:`\sigma^2(r) = \frac{1}{2\pi^2} \int dk k^2 P(k) W^2(kr)` (tilt offset 1.5)."""
+    _convention = (1.5, 3., 1. / (2. * np.pi**2), None)
+    _window = None
+
+    def __init__(self, k, q=0, **kwargs):
+        FFTlog.__init__(self, k, self._window(), q=self._convention[0] + q, **kwargs)
+
+
+class TophatVariance(_WindowVariance):
     """Variance in a tophat window (reference fftlog.py:381-405)."""
-    def __init__(self, k, q=0, **kwargs):
-        kernel = TophatSqKernel(ndim=3)
-        FFTlog.__init__(self, k, kernel, q=1.5 + q, **kwargs)
-        self.padded_prefactor *= self.padded_x**3 / (2 * np.pi**2)
+    _window = staticmethod(lambda: TophatSqKernel(ndim=3))
 
 
-class GaussianVariance(FFTlog):
+class GaussianVariance(_WindowVariance):
     """Variance in a Gaussian window (reference fftlog.py:409-433)."""
-    def __init__(self, k, q=0, **kwargs):
-        kernel = GaussianSqKernel()
-        FFTlog.__init__(self, k, kernel, q=1.5 + q, **kwargs)
-        self.padded_prefactor *= self.padded_x**3 / (2 * np.pi**2)
+    _window = staticmethod(GaussianSqKernel)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -505,13 +534,14 @@ class MI355XFFTEngine(BaseFFTEngine):
 def get_fft_engine(engine, *args, **kwargs):
     """
     Return the engine (reference fftlog.py:641-663).  ``'mi355x'`` / ``'hip'`` and, for drop-in use of code written
-    against the reference, ``'numpy'`` / ``'fftw'`` all select the fused HIP kernel.  Engine *objects* implementing the
-    reference's forward / backward protocol cannot be fused and are rejected.
+    against the reference, ``'numpy'`` / ``'fftw'`` all select the fused HIP kernel.  Anything that is not a string is passed
+    through, as in the reference: an object with ``forward`` / ``backward`` methods (protocol of fftlog.py:508-544) makes
+    :meth:`FFTlog.__call__` run un-fused around it.
     """
     if isinstance(engine, str):
         if engine.lower() in ('mi355x', 'hip', 'numpy', 'fftw'):
             return MI355XFFTEngine(*args, **kwargs)
         raise ValueError('FFT engine {} is unknown'.format(engine))
-    if isinstance(engine, MI355XFFTEngine):
-        return engine
-    raise NotImplementedError('custom forward/backward FFT engines cannot be used with the fused MI355X kernel')
+    if not isinstance(engine, MI355XFFTEngine) and not (callable(getattr(engine, 'forward', None)) and callable(getattr(engine, 'backward', None))):
+        raise ValueError('FFT engine {!r} has no forward / backward methods'.format(engine))
+    return engine

@@ -37,7 +37,8 @@ enum cp_kernel {
     CP_KERNEL_TOPHAT = 2,             /* TophatKernel(ndim)          fftlog.py:719-726 */
     CP_KERNEL_TOPHAT_SQ = 3,          /* TophatSqKernel(ndim)        fftlog.py:729-746 */
     CP_KERNEL_GAUSSIAN = 4,           /* GaussianKernel              fftlog.py:749-756 */
-    CP_KERNEL_GAUSSIAN_SQ = 5         /* GaussianSqKernel            fftlog.py:759-766 */
+    CP_KERNEL_GAUSSIAN_SQ = 5,        /* GaussianSqKernel            fftlog.py:759-766 */
+    CP_KERNEL_CUSTOM = 100            /* values supplied by the caller (any Python callable kernel, fftlog.py:54-56) */
 };
 
 int cp_abi_version(void);
@@ -52,6 +53,27 @@ int cp_loggamma(const double* z_re_im, double* out_re_im, long long n);
 int cp_gamma(const double* z_re_im, double* out_re_im, long long n);
 int cp_kernel_eval(int kind, double param, const double* z_re_im, double* out_re_im, long long n);
 
+/* ---- FFTLog plan tables on the host (replaces FFTlog._setup, fftlog.py:144-184, and the convention factors of its
+ *      subclasses, fftlog.py:280, 318-330, 368-377, 403-405, 431-433) ---- */
+typedef struct cp_fftlog_spec {
+    int kind;         /* cp_kernel; CP_KERNEL_CUSTOM: Mellin-transform values supplied in u_custom / lowring_custom */
+    double param;     /* nu / ndim of the kernel */
+    double q;         /* tilt, including the convention's offset (1.5 + q for P <-> xi and the variances) */
+    double xy;        /* x y product, used when lowring == 0 (fftlog.py:165) */
+    double pre_power; /* prefactor  = pre_const x^(pre_power) x^(-q)   e.g. 3, (2 pi)^-1.5 for P -> xi (fftlog.py:319) */
+    double pre_const;
+    double post_sign; /* postfactor = post_sign y^(-q); the unit phase of complex=True transforms stays with the caller */
+} cp_fftlog_spec;
+/* padded size 2**((n * minfolds - 1).bit_length()) (fftlog.py:149-150), -1 on bad arguments */
+int cp_fftlog_padded_size(int n, int minfolds);
+/* x : (nker, n) log-spaced coordinates.  Outputs (host): delta, lnxy : (nker); y : (nker, n); padded_x, padded_y, pre, post :
+ * (nker, npad); u : (nker, npad/2 + 1) complex128 interleaved.  u_custom : (nker, npad/2 + 1) complex values of custom kernels at
+ * z_m = q + 2 pi i m / (npad delta) (rows of other kernels ignored), lowring_custom : (nker) complex values at q + i pi / delta; both
+ * may be NULL when no kernel is custom.  check_level != 0 verifies the log spacing (CP_EINVAL, fftlog.py:155-157). */
+int cp_fftlog_tables(int n, int nker, const double* x, const cp_fftlog_spec* spec, int minfolds, int lowring, int check_level,
+                     const double* u_custom, const double* lowring_custom, double* delta, double* lnxy, double* y, double* padded_x,
+                     double* padded_y, double* pre, double* post, double* u);
+
 /* ---- fused FFTLog (replaces FFTlog.__call__, fftlog.py:198-241: pad -> x prefactor -> rfft -> x u ->
  *      irfft(conj) -> x postfactor -> crop, i.e. numpy.fft.rfft/irfft at fftlog.py:540, 544) ---- */
 typedef struct cp_fftlog_plan cp_fftlog_plan;
@@ -64,9 +86,9 @@ int cp_fftlog_plan_create(cp_fftlog_plan** plan, int n, int npad, int nker, cons
                           const double* u_re_im, int device);
 /* d_in : device (nbatch, nker, n) float64 C-contiguous;  d_out : device (nbatch, nker, n or npad).
  * extrap_*: cp_extrap, val_* used for CP_EXTRAP_CONSTANT.  keep_padding as in fftlog.py:233-237.
- * Batch items 2q and 2q + 1 of a kernel are transformed as the real and imaginary parts of ONE complex sequence: rounding is relative to
- * the larger of the two rows, and a NaN / Inf in one of them reaches the other.  A caller that may hold such rows (or rows of very
- * different magnitude) masks / rescales them first, as the Python class does (FFTlog.__call__; rescale_rows). */
+ * Rows are independent, as in numpy's row-by-row FFTs: batch items 2q and 2q + 1 of a kernel share one complex transform inside the
+ * kernel, which itself transforms a row holding NaN / Inf as zeros and stores NaN for it, and rescales the two rows by exact powers
+ * of two when their (tilted) magnitudes differ by more than a factor 32, so that rounding is relative to each row's own magnitude. */
 int cp_fftlog_execute(const cp_fftlog_plan* plan, const double* d_in, double* d_out, long long nbatch, int extrap_left,
                       double val_left, int extrap_right, double val_right, int keep_padding, void* stream);
 int cp_fftlog_plan_destroy(cp_fftlog_plan* plan);

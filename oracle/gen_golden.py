@@ -3,7 +3,7 @@
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
 Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, bao, xi, bao2, densities, ncdm, variants,
-calculator, cosmology_api, abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
+calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
 """
@@ -619,6 +619,15 @@ def gen_desi_table():
     save('desi_table', z=table[idx, 0], efunc=table[idx, 1], comoving_radial_distance=table[idx, 2])
 
 
+def gen_api_flows(cp):
+    """tests/api_scenarios.py (API scenarios written for this repository) replayed with the reference: every entry is what the reference
+    returns -- an array, or the class name of the exception it raises."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    import api_scenarios
+    results = api_scenarios.run_all(cp)
+    save('api_flows', **results)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -654,6 +663,8 @@ def main():
         gen_abacus_table(cp)
     if 'desi_table' in which:
         gen_desi_table()
+    if 'api_flows' in which:
+        gen_api_flows(cp)
 
 
 if __name__ == '__main__':

@@ -1,0 +1,363 @@
+"""
+API scenarios replayed against two implementations of the cosmoprimo interface.
+
+Each scenario is a function ``scenario(pkg) -> dict(name -> array or outcome string)`` written against the public API only
+(classes, methods and arguments as documented in the reference: FFTlog & co, PowerSpectrumInterpolator1D / 2D,
+CorrelationFunctionInterpolator1D / 2D, PowerSpectrumBAOFilter, Cosmology / Fourier / Transfer).  ``oracle/gen_golden.py``
+runs them with the reference package imported in the build container and stores what comes out in
+``tests/golden/api_flows.npz``; ``tests/test_api_flows_gpu.py`` runs the same functions with ``cosmoprimo_amd`` on the GPU box
+and compares shape, dtype, NaN pattern and values of every entry.  An exception is an outcome too (its class name is stored).
+
+What the scenarios cover is the behaviour the reference's own tests assert (tests/test_interpolator.py, test_fftlog.py,
+test_bao_filter.py: result shapes for scalar / empty / nested / float32 arguments, ordering, clones, from_callable, to_1d, to_xi / to_pk
+round trips, bounds and NaN rules, 2-D filters against per-redshift ones), recorded as data rather than restated as assertions.
+"""
+import warnings
+
+import numpy as np
+
+# relative tolerance of the comparison per scenario (entries are compared with atol = rtol x largest |value| of the entry)
+TOLERANCES = {'interp1d': 1e-9, 'interp2d_growth': 1e-9, 'interp2d_table': 1e-8, 'engine_interpolators': 1e-8, 'correlation': 1e-7, 'bounds': 1e-7,
+              'invalid_tables': 0., 'fftlog_grids': 1e-12, 'fftlog_hankel': 1e-9, 'fftlog_multipoles': 1e-9, 'bao_2d': 1e-6, 'bao_2d_xi': 1e-6}
+
+
+def outcome(fn, *args, **kwargs):
+    """Result of ``fn(*args, **kwargs)`` as an array, or the name of the exception it raises."""
+    try:
+        return np.asarray(fn(*args, **kwargs))
+    except Exception as exc:  # noqa: BLE001 -- the class of the exception IS the recorded behaviour
+        return np.asarray(type(exc).__name__)
+
+
+ARG_SHAPES_1D = {'scalar': 0.1, 'empty': [], 'nested': [[0.1, 0.2]] * 3, 'float32': np.array([[0.1, 0.2]] * 3, dtype='f4'), 'descending': [0.2, 0.1]}
+
+
+def call_1d(fn, prefix, out):
+    """``fn`` at every argument form of ARG_SHAPES_1D."""
+    for name, x in ARG_SHAPES_1D.items():
+        out['%s.%s' % (prefix, name)] = outcome(fn, x)
+
+
+def call_2d(fn, prefix, out, first=(0.1, 0.2), second=(0.1, 0.3)):
+    """A two-argument (k or s or r, z) callable on grids and, where it has the keyword, on matched points."""
+    a, b = first
+    z0, z1 = second
+    forms = {'scalars': (a, z0), 'empty_first': (np.array([]), np.array(z0)), 'both_empty': ([], []), 'scalar_vector': (a, [z0, z0]),
+             'nested_scalar': ([[a, b]] * 3, z0), 'nested_vector': ([[a, b]] * 3, [z0]), 'nested_nested': ([[a, b]] * 3, [[z0, z0, z1]] * 3),
+             'float32': (np.array([[a, b]] * 3, dtype='f4'), np.array(z0, dtype='f4')), 'descending': ([b, a], [z1, z0])}
+    for name, args in forms.items():
+        out['%s.grid.%s' % (prefix, name)] = outcome(fn, *args)
+    for name, args in {'both_empty': ([], []), 'vectors': ([a, b], [z0, z1]), 'nested': ([[a, b]] * 3, [[z0, z1]] * 3), 'descending': ([b, a], [z1, z0])}.items():
+        out['%s.points.%s' % (prefix, name)] = outcome(lambda *xz: fn(*xz, grid=False), *args)
+
+
+def _fftlog(pkg):
+    """The fftlog sub-module (the transforms are not all re-exported at package level)."""
+    import importlib
+    return importlib.import_module(pkg.__name__ + '.fftlog')
+
+
+def _eh_power(pkg, k):
+    cosmo = pkg.Cosmology()
+    transfer = pkg.Transfer(cosmo, engine='eisenstein_hu')
+    return cosmo, transfer.transfer_k(k)**2 * k**cosmo['n_s']
+
+
+def interp1d(pkg):
+    """PowerSpectrumInterpolator1D on a table: argument forms, clone, sigma_r / sigma_d / sigma8."""
+    out = {}
+    k = np.logspace(-3, 1.5, 100)
+    cosmo, pk = _eh_power(pkg, k)
+    interp = pkg.PowerSpectrumInterpolator1D(k, pk)
+    call_1d(interp, 'call', out)
+    call_1d(interp.sigma_r, 'sigma_r', out)
+    out['clone.same_values'] = np.asarray(np.all(interp.clone()(np.ones((4, 2))) == interp(np.ones((4, 2)))))
+    out['sigma8'] = outcome(interp.sigma8)
+    out['sigma_d'] = outcome(interp.sigma_d)
+    out['extrap_range'] = np.array([interp.extrap_kmin, interp.extrap_kmax])
+    two_columns = pkg.PowerSpectrumInterpolator1D(k, np.stack([pk, 2. * pk], axis=-1))
+    out['two_columns.call'] = outcome(two_columns, [0.01, 0.1, 1.])
+    out['two_columns.sigma_r'] = outcome(two_columns.sigma_r, [4., 8.])
+    return out
+
+
+def interp2d_growth(pkg):
+    """PowerSpectrumInterpolator2D built from one P(k) and a growth function."""
+    out = {}
+    k = np.logspace(-3, 1.5, 100)
+    cosmo, pk = _eh_power(pkg, k)
+    interp = pkg.PowerSpectrumInterpolator2D(k, z=0, pk=pk, growth_factor_sq=lambda z: np.ones_like(z))
+    call_2d(interp, 'call', out)
+    out['at_knots'] = outcome(interp, k, np.linspace(0., 1., 5))
+    clone = interp.clone()
+    out['clone.call'] = outcome(clone, k[::9], [0., 0.])
+    grow = pkg.PowerSpectrumInterpolator2D(k, z=0, pk=pk, growth_factor_sq=lambda z: 1. / (1. + z)**2)
+    out['growth.call'] = outcome(grow, [0.01, 0.1], [0., 1., 3.])
+    out['growth.sigma8_z'] = outcome(grow.sigma8_z, [0., 1., 3.])
+    out['growth.ignore_growth'] = outcome(lambda: grow([0.01, 0.1], [0., 1.], ignore_growth=True))
+    return out
+
+
+def interp2d_table(pkg):
+    """PowerSpectrumInterpolator2D on a (k, z) table, descending redshifts on input."""
+    out = {}
+    k = np.logspace(-3, 1.5, 100)
+    cosmo, pk = _eh_power(pkg, k)
+    z = np.linspace(1., 0., 10)
+    flat = pkg.PowerSpectrumInterpolator2D(k, z=z, pk=np.array([pk] * len(z)).T)
+    call_2d(flat, 'call', out)
+    call_1d(flat.sigma8_z, 'sigma8_z', out)
+    call_1d(flat.sigma_dz, 'sigma_dz', out)
+    call_2d(flat.sigma_rz, 'sigma_rz', out, first=(4., 8.))
+    ramp = pkg.PowerSpectrumInterpolator2D(k, z=z, pk=np.array([pk * (iz + 1) / len(z) for iz in range(len(z))]).T)
+    call_2d(ramp.growth_rate_rz, 'growth_rate_rz', out, first=(4., 8.))
+    out['growth_rate_rz.dz'] = outcome(lambda: ramp.growth_rate_rz(8., [0., 2e-3], dz=1e-3))
+    wide = pkg.PowerSpectrumInterpolator2D(k, z=z, pk=np.array([pk] * len(z)).T, extrap_kmin=1e-6, extrap_kmax=1e2)
+    out['wide.call'] = outcome(wide, [1e-5, 1e-2, 50.], [0., 0.45])
+    out['wide.range'] = np.array([wide.extrap_kmin, wide.extrap_kmax])
+    return out
+
+
+def engine_interpolators(pkg):
+    """Interpolators handed out by the analytic engines: values, clone(pk=...), to_1d, from_callable, to_xi."""
+    out = {}
+    cosmo = pkg.Cosmology()
+    k, z = np.logspace(-4, 2, 60), np.linspace(0, 4, 6)
+    for engine in ['eisenstein_hu', 'eisenstein_hu_nowiggle_variants']:
+        interp = pkg.Fourier(cosmo, engine=engine).pk_interpolator()
+        pk = interp(k, z)
+        out[engine + '.call'] = np.asarray(pk)
+        call_2d(interp, engine + '.forms', out)
+        out[engine + '.clone_doubled'] = outcome(interp.clone(pk=2 * interp.pk), k[::7], z[::2])
+        one = interp.to_1d(z=z[2])
+        out[engine + '.to_1d.call'] = outcome(one, k)
+        out[engine + '.to_1d.range'] = np.array([one.extrap_kmin, one.extrap_kmax, interp.extrap_kmin, interp.extrap_kmax])
+        out[engine + '.sigma8_z'] = outcome(interp.sigma8_z, z)
+        out[engine + '.to_1d.sigma8'] = outcome(one.sigma8)
+        out[engine + '.sigma_dz'] = outcome(interp.sigma_dz, z)
+        out[engine + '.sigma_dz.nk_none'] = outcome(lambda: interp.sigma_dz(z[2], nk=None))
+        out[engine + '.to_1d.sigma_d'] = outcome(one.sigma_d)
+        again = pkg.PowerSpectrumInterpolator2D.from_callable(interp.k, interp.z, interp)
+        out[engine + '.from_callable.call'] = outcome(again, k, z)
+        call_2d(again, engine + '.from_callable.forms', out)
+        again_1d = one.from_callable(one.k, one)
+        out[engine + '.from_callable_1d.call'] = outcome(again_1d, k)
+        call_1d(again_1d, engine + '.from_callable_1d.forms', out)
+    fine = np.logspace(-4, 2, 1000)
+    table = pkg.PowerSpectrumInterpolator2D(fine, z, pkg.Fourier(cosmo, engine='eisenstein_hu').pk_interpolator()(fine, z))
+    stacked = table.to_1d(z=z)
+    out['stacked.call'] = outcome(stacked, k)
+    call_1d(stacked, 'stacked.forms', out)
+    xi_stacked = stacked.to_xi()
+    s = xi_stacked.s[::40]
+    out['stacked.to_xi'] = outcome(xi_stacked, s)
+    out['table.to_xi'] = outcome(table.to_xi(), s, z)
+    return out
+
+
+def correlation(pkg):
+    """xi(s, z) interpolators: to_xi, to_pk and back, from_callable, sigma through to_pk."""
+    out = {}
+    cosmo = pkg.Cosmology()
+    s, z, k = np.logspace(-2, 2, 40), np.linspace(0, 4, 5), np.logspace(-3, 0.5, 30)
+    for engine in ['eisenstein_hu', 'eisenstein_hu_nowiggle_variants']:
+        pk_interp = pkg.Fourier(cosmo, engine=engine).pk_interpolator()
+        xi_interp = pk_interp.clone(extrap_kmin=1e-5, extrap_kmax=1e2).to_xi()
+        out[engine + '.xi'] = outcome(xi_interp, s, z)
+        out[engine + '.xi.clone'] = outcome(xi_interp.clone(), s, z)
+        call_2d(xi_interp, engine + '.xi.forms', out, first=(1., 20.))
+        out[engine + '.pk_back'] = outcome(xi_interp.to_pk(), k, z)
+        again = pkg.CorrelationFunctionInterpolator2D.from_callable(xi_interp.s, xi_interp.z, xi_interp)
+        out[engine + '.from_callable'] = outcome(again, s, z)
+        one = xi_interp.to_1d(z=0.)
+        call_1d(lambda x: one(np.asarray(x, dtype=getattr(x, 'dtype', 'f8')) * 100.), engine + '.to_1d.forms', out)
+        out[engine + '.to_1d.from_callable'] = outcome(one.from_callable(one.s, one), s)
+        pk1 = pk_interp.to_1d(z=z[2])
+        out[engine + '.round_trip_1d'] = outcome(pk1.clone(extrap_kmin=1e-5, extrap_kmax=1e2).to_xi().clone().to_pk(), k)
+        out[engine + '.xi.sigma_dz'] = outcome(xi_interp.sigma_dz, z[2])
+        out[engine + '.xi.sigma8_z'] = outcome(xi_interp.sigma8_z, z[2])
+        out[engine + '.xi.to_1d.sigma8'] = outcome(xi_interp.to_1d(z[2]).sigma8)
+    return out
+
+
+def bounds(pkg):
+    """Outside the tabulated range: NaN by default, ValueError with bounds_error=True, in k, s and z."""
+    out = {}
+    cosmo = pkg.Cosmology()
+    fo = pkg.Fourier(cosmo, engine='eisenstein_hu')
+    k, wide = np.logspace(-4, 2, 400), np.logspace(-6, 3, 400)
+    inside = wide[1:-1]
+    z = np.linspace(0, 4, 5)
+    ref1 = fo.pk_interpolator(k=wide, extrap_kmin=wide[0], extrap_kmax=wide[-1]).to_1d(z=0.)
+    tab1 = pkg.PowerSpectrumInterpolator1D(k, ref1(k), extrap_kmin=wide[0], extrap_kmax=wide[-1])
+    out['1d.range'] = np.array([tab1.extrap_kmin, tab1.extrap_kmax])
+    out['1d.inside'] = outcome(lambda: tab1(inside[::20], bounds_error=True))
+    for name, x in {'below': inside / 2., 'above': inside * 2., 'one_below': inside[0] / 2., 'one_above': inside[-1] * 2.}.items():
+        out['1d.%s.nan' % name] = outcome(lambda x=x: np.isnan(tab1(x)))
+        out['1d.%s.error' % name] = outcome(lambda x=x: tab1(x, bounds_error=True))
+    xi1 = tab1.to_xi()
+    s = xi1.s
+    out['1d.xi.inside'] = outcome(lambda: xi1(s[::50], bounds_error=True))
+    for name, x in {'below': s / 2., 'above': s * 2.}.items():
+        out['1d.xi.%s.nan' % name] = outcome(lambda x=x: np.isnan(xi1(x, bounds_error=False)))
+        out['1d.xi.%s.error' % name] = outcome(lambda x=x: xi1(x, bounds_error=True))
+    out['1d.xi.to_pk'] = outcome(xi1.to_pk(), k[::40])
+    ref2 = fo.pk_interpolator(k=wide, z=z, extrap_kmin=wide[0], extrap_kmax=wide[-1])
+    tab2 = pkg.PowerSpectrumInterpolator2D(k, z, ref2(k, z), extrap_kmin=wide[0], extrap_kmax=wide[-1])
+    out['2d.inside'] = outcome(lambda: tab2(inside[::20], z, bounds_error=True))
+    for name, args in {'k_below': (inside / 2., z), 'k_above': (inside * 2., z), 'z_above': (inside, z * 2.)}.items():
+        out['2d.%s.nan' % name] = outcome(lambda args=args: np.isnan(tab2(*args, bounds_error=False)))
+        out['2d.%s.error' % name] = outcome(lambda args=args: tab2(*args, bounds_error=True))
+    xi2 = tab2.to_xi()
+    s = xi2.s
+    for name, args in {'s_below': (s / 2., z), 's_above': (s * 2., z), 'z_above': (s, z * 2.)}.items():
+        out['2d.xi.%s.nan' % name] = outcome(lambda args=args: np.isnan(xi2(*args, bounds_error=False)))
+        out['2d.xi.%s.error' % name] = outcome(lambda args=args: xi2(*args, bounds_error=True))
+    out['2d.xi.to_pk'] = outcome(lambda: xi2.to_pk()(k[::40], z=0.))
+    return out
+
+
+def invalid_tables(pkg):
+    """A table that is not positive cannot be interpolated in log-log space: NaN everywhere, no exception."""
+    out = {}
+    k = np.logspace(-4, 2, 200)
+    pk = k**2
+    pk[:2] *= -1
+    out['1d'] = outcome(lambda: np.isnan(pkg.PowerSpectrumInterpolator1D(k, pk)(k)))
+    z = np.linspace(0., 2., 4)
+    out['2d'] = outcome(lambda: np.isnan(pkg.PowerSpectrumInterpolator2D(k, z, np.repeat(pk[:, None], z.size, axis=1))(k, z=1.)))
+    return out
+
+
+def fftlog_grids(pkg):
+    """pad() and the padded coordinate grids of a plan."""
+    pad = _fftlog(pkg).pad
+    out = {}
+    ones = np.ones((6, 6))
+    out['pad.zero'] = outcome(pad, ones, (3, 4), extrap=0, axis=0)
+    out['pad.edge'] = outcome(pad, ones, (4, 3), extrap='edge', axis=1)
+    decades = np.array([(i + 1) * np.logspace(-3, 3, num=6, endpoint=False) for i in range(3)]).T
+    out['pad.log'] = outcome(pad, decades, (9, 9), extrap='log', axis=0)
+    out['pad.mixed'] = outcome(pad, decades, (2, 3), extrap=('log', 7.), axis=0)
+    x = np.logspace(-3, 3, num=7, endpoint=True)
+    plan = _fftlog(pkg).HankelTransform(x, minfolds=3, xy=1, lowring=False)
+    out['hankel.sizes'] = np.array([plan.padded_size, plan.padded_size_in_left, plan.padded_size_in_right, plan.padded_size_out_left, plan.padded_size_out_right])
+    out['hankel.padded_x'] = np.asarray(plan.padded_x)
+    out['hankel.padded_y'] = np.asarray(plan.padded_y)
+    out['hankel.y'] = np.asarray(plan.y)
+    return out
+
+
+def fftlog_hankel(pkg):
+    """The analytic pair (1 + x^2)^-1.5 <-> exp(-y) through HankelTransform, its inverse, and a batch of rows."""
+    out = {}
+    for engine in ['numpy']:      # the reference's default engine name (this package runs its fused kernel under that name too)
+        x = np.logspace(-3, 3, num=60, endpoint=False)
+        f = 1 / (1 + x**2)**1.5
+        plan = _fftlog(pkg).HankelTransform(x, nu=0, q=1, lowring=True, engine=engine)
+        y, g = plan(f, extrap='log')
+        out[engine + '.forward.y'], out[engine + '.forward'] = np.asarray(y), np.asarray(g)
+        plan.inv()
+        x2, f2 = plan(g, extrap='log')
+        out[engine + '.inverse.x'], out[engine + '.inverse'] = np.asarray(x2), np.asarray(f2)
+        y = np.logspace(-4, 2, num=60, endpoint=False)
+        back = _fftlog(pkg).HankelTransform(y, nu=0, q=1, lowring=True, engine=engine)
+        rows = np.exp(-y)[None, :] * np.linspace(1., 3., 3)[:, None]
+        x3, f3 = back(rows, extrap='log')
+        out[engine + '.batch.x'], out[engine + '.batch'] = np.asarray(x3), np.asarray(f3)
+    return out
+
+
+def fftlog_multipoles(pkg):
+    """P -> xi_ell -> P for ell = 0..4, multipoles in parallel, lowring=False grid, two rows at once, the tophat variance."""
+    out = {}
+    cosmo = pkg.Cosmology()
+    pk_interp = pkg.Fourier(cosmo, engine='eisenstein_hu').pk_interpolator().to_1d(z=0)
+    k = np.logspace(-5, 2, 1000)
+    pk = np.asarray(pk_interp(k))
+    ells = [0, 1, 2, 3, 4]
+    window = slice(300, 800, 25)      # k between 1e-3 and 4: the round trip is well conditioned there
+    for ell in ells:
+        s, xi = _fftlog(pkg).PowerToCorrelation(k, ell=ell, lowring=True, complex=False)(pk)
+        out['xi.%d' % ell] = np.asarray(xi)[window]
+        k2, pk2 = _fftlog(pkg).CorrelationToPower(s, ell=ell, lowring=True, complex=False)(xi)
+        out['pk_back.%d' % ell] = np.asarray(pk2)[window]
+        out['k_back.%d' % ell] = np.asarray(k2)[window]
+    s, xi = _fftlog(pkg).PowerToCorrelation(k, ell=ells, lowring=True, q=0, complex=False)(pk)
+    out['parallel.s'], out['parallel.xi'] = np.asarray(s)[:, window], np.asarray(xi)[:, window]
+    s, xi = _fftlog(pkg).PowerToCorrelation(k, ell=0, lowring=False)(pk)
+    out['nolowring.sk'] = np.asarray(s)[::-1] * k
+    pk2 = np.asarray(pkg.Fourier(cosmo, engine='eisenstein_hu').pk_interpolator()(k, z=np.asarray([0.5, 1.0]))).T
+    s, xi = _fftlog(pkg).PowerToCorrelation(k, ell=0)(pk2)
+    out['two_rows.s'], out['two_rows.xi'] = np.asarray(s)[window], np.asarray(xi)[:, window]
+    r, var = _fftlog(pkg).TophatVariance(k, lowring=True)(pk)
+    out['tophat.r'], out['tophat.var'] = np.asarray(r)[window], np.asarray(var)[window]
+    out['sigma_r'] = outcome(pk_interp.sigma_r, np.linspace(1., 20., 4))
+    return out
+
+
+BAO_FILTERS = ['hinton2017', 'savgol', 'ehpoly', 'wallish2018', 'brieden2022', 'peakaverage', 'ehsavgol']
+
+
+def bao_2d(pkg):
+    """Smooth P(k, z) from a filter applied to the 2-D interpolator, against the same filter applied redshift by redshift (one 1-D
+    filter called again for every redshift, and one filter on a multi-column 1-D interpolator)."""
+    out = {}
+    cosmo = pkg.Cosmology()
+    pk_interp = pkg.Fourier(cosmo, engine='eisenstein_hu').pk_interpolator()
+    k = np.logspace(-3, 1.5, 60)
+    z = np.asarray(pk_interp.z)
+    picks = list(range(0, z.size, 10))
+    for engine in BAO_FILTERS:
+        both = pkg.PowerSpectrumBAOFilter(pk_interp, engine=engine, cosmo=cosmo, cosmo_fid=cosmo)
+        out[engine + '.2d'] = np.asarray(both.smooth_pk_interpolator()(k, z=z[picks]))
+        one = pkg.PowerSpectrumBAOFilter(pk_interp.to_1d(z=0), engine=engine, cosmo=cosmo, cosmo_fid=cosmo)
+        per_z = []
+        for iz in picks:
+            one = one(pk_interp.to_1d(z=z[iz]))
+            per_z.append(np.asarray(one.smooth_pk_interpolator()(k)))
+        out[engine + '.per_z'] = np.stack(per_z, axis=-1)
+        columns = pkg.PowerSpectrumBAOFilter(pk_interp.to_1d(z=z[picks]), engine=engine, cosmo=cosmo, cosmo_fid=cosmo)
+        out[engine + '.columns'] = np.asarray(columns.smooth_pk_interpolator()(k))
+        out[engine + '.wiggles_amplitude'] = np.asarray(np.abs(np.asarray(both.wiggles) - 1.).max() < 0.25)
+    return out
+
+
+def bao_2d_xi(pkg):
+    """The same for the correlation-function filter."""
+    out = {}
+    cosmo = pkg.Cosmology()
+    pk_interp = pkg.Fourier(cosmo, engine='eisenstein_hu').pk_interpolator()
+    xi_interp = pk_interp.to_xi()
+    s = np.linspace(1e-2, 300, 80)
+    z = np.asarray(xi_interp.z)
+    picks = list(range(0, z.size, 10))
+    both = pkg.CorrelationFunctionBAOFilter(xi_interp, engine='kirkby2013')
+    out['2d'] = np.asarray(both.smooth_xi_interpolator()(s, z=z[picks]))
+    one = pkg.CorrelationFunctionBAOFilter(xi_interp.to_1d(z=0), engine='kirkby2013')
+    per_z = []
+    for iz in picks:
+        one = one(pk_interp.to_1d(z=z[iz]).to_xi())
+        per_z.append(np.asarray(one.smooth_xi_interpolator()(s)))
+    out['per_z'] = np.stack(per_z, axis=-1)
+    columns = pkg.CorrelationFunctionBAOFilter(xi_interp.to_1d(z=z[picks]), engine='kirkby2013')
+    out['columns'] = np.asarray(columns.smooth_xi_interpolator()(s))
+    return out
+
+
+SCENARIOS = [interp1d, interp2d_growth, interp2d_table, engine_interpolators, correlation, bounds, invalid_tables, fftlog_grids, fftlog_hankel,
+             fftlog_multipoles, bao_2d, bao_2d_xi]
+
+
+def run_all(pkg, only=None):
+    """{'scenario/entry': array} for every scenario (warnings of the analytic engines silenced)."""
+    results = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        with np.errstate(all='ignore'):
+            for scenario in SCENARIOS:
+                if only is not None and scenario.__name__ not in only:
+                    continue
+                for name, value in scenario(pkg).items():
+                    results['%s/%s' % (scenario.__name__, name)] = value
+    return results

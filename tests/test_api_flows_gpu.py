@@ -1,0 +1,83 @@
+"""The API scenarios of tests/api_scenarios.py run with this package on the GPU and compared, entry by entry, with what the
+reference returned for the very same calls (tests/golden/api_flows.npz, written by ``python -m oracle.gen_golden api_flows`` in the
+build container): same shape, same float width, same NaN pattern, same exception class, values within the scenario's tolerance."""
+import numpy as np
+import pytest
+
+import api_scenarios
+
+@pytest.fixture(scope='module')
+def cp():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    import cosmoprimo_amd
+    return cosmoprimo_amd
+
+
+# Where this package deliberately differs from the reference: entries compared with a looser rule, and why
+LOOSER = {
+    # wallish2018 is not scale covariant to 1e-6 in the reference either (its 2-D and per-redshift results differ by 4e-3 there): the
+    # detected peak box moves with the normalisation of the column
+    'bao_2d/wallish2018': 1e-2,
+    # brieden2022 / peakaverage: one rounding-noise knot of the reference's envelope-knot list differs (ratio_fid is 1 +- 1 ulp there)
+    'bao_2d/brieden2022': 1e-5, 'bao_2d/peakaverage': 1e-5,
+    # the reference forms the finite-difference stencil z +- dz (dz = 1e-3) in the float32 of its argument, which puts ~1e-4 of rounding
+    # noise on the derivative; here the stencil is float64 and only the result is cast
+    'interp2d_table/growth_rate_rz.grid.float32': 2e-3,
+}
+
+
+def compare(scenario, got, expected, looser=()):
+    """Differences between the entries of one scenario and the reference's, as a list of messages."""
+    names = [name for name in expected if name.startswith(scenario + '/')]
+    assert names and sorted(got) == sorted(names)
+    rtol = api_scenarios.TOLERANCES[scenario]
+    failures = []
+    for name in names:
+        ref, val = expected[name], np.asarray(got[name])
+        if ref.dtype.kind in 'US' or val.dtype.kind in 'US':      # an exception class name on either side
+            if str(ref) != str(val):
+                failures.append('%s: reference %s, here %s' % (name, ref, val))
+            continue
+        if ref.shape != val.shape:
+            failures.append('%s: shape %s, reference %s' % (name, val.shape, ref.shape))
+            continue
+        if ref.dtype.kind == 'f' and val.dtype.itemsize != ref.dtype.itemsize:
+            failures.append('%s: dtype %s, reference %s' % (name, val.dtype, ref.dtype))
+            continue
+        if ref.dtype.kind == 'b':
+            if not np.array_equal(ref, val):
+                failures.append('%s: flags differ' % name)
+            continue
+        if not np.array_equal(np.isnan(ref), np.isnan(val)):
+            failures.append('%s: NaN pattern differs (%d vs %d NaN)' % (name, np.isnan(val).sum(), np.isnan(ref).sum()))
+            continue
+        if ref.size == 0:
+            continue
+        tol = max([rtol] + [loose for prefix, loose in dict(looser).items() if name.startswith(prefix)])
+        if ref.dtype.itemsize == 4:
+            tol = max(tol, 2e-6)      # float32 in, float32 out
+        finite = ~np.isnan(ref)
+        err = np.abs(val[finite] - ref[finite]).max() / max(np.abs(ref[finite]).max(), 1e-300) if finite.any() else 0.
+        if not err <= tol:
+            failures.append('%s: relative difference %.2e > %.0e' % (name, err, tol))
+    return failures
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('scenario', [fn.__name__ for fn in api_scenarios.SCENARIOS])
+def test_scenario_matches_reference(cp, golden, scenario):
+    failures = compare(scenario, api_scenarios.run_all(cp, only=[scenario]), golden('api_flows'), LOOSER)
+    assert not failures, '\n'.join(failures)
+
+
+def test_golden_is_what_the_reference_returns(golden):
+    """Build container only (the reference tree is there): the scenarios replayed with the reference reproduce the committed fixture."""
+    from oracle import _refimport
+    if not _refimport.available():
+        pytest.skip('reference tree not present')
+    results = api_scenarios.run_all(_refimport.import_reference())
+    expected = golden('api_flows')
+    for fn in api_scenarios.SCENARIOS:
+        failures = compare(fn.__name__, {k: v for k, v in results.items() if k.startswith(fn.__name__ + '/')}, expected)
+        assert not failures, '\n'.join(failures)

@@ -327,6 +327,34 @@ def test_large_sizes(cp, n):
     assert xi.shape == (n,) and tilted_err(xi, ofl.apply(ofl.power_to_correlation(k, ell=0), fun[0, 0])[0], s, 1.5) < TOL_NORM
 
 
+def test_complex_transforms_and_their_inverse(cp, golden):
+    """complex=True multipoles (reference fftlog.py:318-330): xi_ell x (-i)^ell as complex128; inv() of such a plan (fftlog.py:243-248) has a
+    complex prefactor -- the FFT then sees the real part of fun x prefactor, as numpy.fft.rfft does -- and brings P(k) back."""
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k1024'], pkd['pk1024']
+    ells = [0, 1, 2, 3]
+    f = cp.PowerToCorrelation(k, ell=ells, complex=True)
+    s, xi = f(pk)
+    assert xi.dtype == np.complex128 and xi.shape == (4, 1024)
+    real = cp.PowerToCorrelation(k, ell=ells)(pk)[1]
+    for i, ell in enumerate(ells):      # (-i)^ell against the real transform's (-1)^(ell // 2)
+        np.testing.assert_allclose(xi[i], real[i] * (-1j)**ell / (-1.)**(ell // 2), rtol=1e-13, atol=0)
+    t = ofl.power_to_correlation(k, ell=ells)
+    ref = ofl.apply(t, pk)
+    for i in range(4):
+        assert tilted_err(real[i], ref[i], s[i], 1.5) < TOL_NORM
+    f.inv()
+    assert np.iscomplexobj(f.padded_prefactor)
+    k2, pk2 = f(xi)                       # complex in, real table x unit phase on the way in
+    m = (k2[0] > 1e-2) & (k2[0] < 10.)
+    for i in range(4):
+        np.testing.assert_allclose(pk2[i][m].real, pk[m], rtol=2e-3)
+    # the same inverse from the real convention: identical numbers
+    g = cp.PowerToCorrelation(k, ell=ells)
+    g.inv()
+    np.testing.assert_allclose(g(real)[1][:, m], pk2[:, m].real, rtol=1e-9)
+
+
 def test_nonfinite_rows_stay_isolated(cp, golden):
     """A NaN / Inf row gives a NaN row and leaves its neighbours alone, as numpy's row-by-row FFT does (the kernel packs rows in pairs)."""
     pkd = golden('pk_eh_default')

@@ -34,8 +34,16 @@ def check_tables(f, g, prefix, every):
     np.testing.assert_allclose(f.y[..., ::ev4], g[prefix + 'y'], rtol=1e-14)
     u, uref = f.padded_u[..., ::ev4], g[prefix + 'u']
     assert np.all(np.abs(u - uref) <= 2e-13 * np.abs(uref) + 1e-300)   # phase of loggamma at |Im z| ~ 400 carries ~1e-13
-    np.testing.assert_allclose(f.padded_prefactor[..., ::every], g[prefix + 'pre'], rtol=1e-13)
-    np.testing.assert_allclose(f.padded_postfactor[..., ::every], g[prefix + 'post'], rtol=1e-13)
+    # The padded grids are geometric continuations x0 (x1 / x0)^e, |e| <= npad / 2 (reference pad(), fftlog.py:483-498): a last-bit
+    # difference in the grid ratio (the library's exp / pow against numpy's) is amplified by |e| |q - p|.  In-range samples agree to
+    # 1e-14; the continuation is held to 4e-16 x npad (the ill-conditioning of the reference's own formula, not of the tables).
+    inrange = np.zeros(f.padded_size, dtype=bool)
+    for name, left, factor in (('pre', f.padded_size_in_left, f.padded_prefactor), ('post', f.padded_size_out_left, f.padded_postfactor)):
+        inrange[:] = False
+        inrange[left:left + f.size] = True
+        ref, got, m = g[prefix + name], factor[..., ::every], inrange[::every]
+        np.testing.assert_allclose(got[..., m], ref[..., m], rtol=1e-14)
+        np.testing.assert_allclose(got[..., ~m], ref[..., ~m], rtol=4e-16 * f.padded_size)
 
 
 @pytest.mark.parametrize('n', [1024, 2048])
@@ -165,3 +173,79 @@ def test_emu_kernel_phases_vs_oracle(emu, n):
             if oext == 0:
                 for i in range(2):
                     assert tilted_err(got[:, i], ref[:, i], yy[i], 1.5) < 2e-15
+
+
+# ---- plug points: foreign FFT engines and arbitrary kernel callables (reference fftlog.py:54-56, 641-663) ----------------
+class NumpyEngine(object):
+    """An engine object with the reference's protocol (fftlog.py:508-544): backward computes irfft(conj(.))."""
+    def __init__(self, size):
+        self.size, self.calls = size, []
+
+    def forward(self, fun):
+        self.calls.append('forward')
+        return np.fft.rfft(fun, axis=-1)
+
+    def backward(self, fun):
+        self.calls.append('backward')
+        return np.fft.irfft(fun.conj(), n=self.size, axis=-1)
+
+
+def test_custom_engine_object_is_passed_through(golden):
+    """A non-string engine is used as is (G3, 'custom-engine passthrough'): the transform runs un-fused around it, on the host."""
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k1024'], pkd['pk1024']
+    for ell, extrap, keep in [(0, 0, False), ([0, 2], 'log', True), (0, ('edge', 1.5), False)]:
+        engine = NumpyEngine(2048)
+        f = cp.PowerToCorrelation(k, ell=ell, engine=engine)
+        assert f._engine is engine
+        t = ofl.power_to_correlation(k, ell=ell if isinstance(ell, list) else [ell])
+        fun = np.stack([pk, 2 * pk])[:, None, :] if isinstance(ell, list) else np.stack([pk, 2 * pk])
+        s, xi = f(fun, extrap=extrap, keep_padding=keep)
+        ref = ofl.apply(t, fun[:, None, :] if not isinstance(ell, list) else fun, extrap=extrap, keep_padding=keep)
+        ref = ref if isinstance(ell, list) else ref[:, 0]
+        assert engine.calls == ['forward', 'backward'] and xi.shape == ref.shape
+        yy = t.padded_y if keep else t.y
+        # 'edge' / constant padding put the largest tilted samples in the (geometrically continued) padding: ill-conditioned by design
+        tol = 1e-13 if extrap in (0, 'log') else 1e-10
+        if isinstance(ell, list):
+            assert max(tilted_err(xi[:, i], ref[:, i], yy[i], 1.5) for i in range(2)) < tol
+        else:
+            assert tilted_err(xi, ref, yy[0], 1.5) < tol
+        assert s.shape == ((2048 if keep else 1024),) if not isinstance(ell, list) else s.shape == (2, 2048 if keep else 1024)
+    with pytest.raises(ValueError):
+        cp.PowerToCorrelation(k, engine=object())
+    with pytest.raises(ValueError):
+        cp.PowerToCorrelation(k, engine='nope')
+
+
+def test_python_callable_kernel():
+    """Any callable z -> U(z) is a kernel (reference fftlog.py:54-56): its values go to cp_fftlog_tables as they are."""
+    k = np.logspace(-4, 2, 300)
+    builtin = cp.FFTlog(k, fl.SphericalBesselJKernel(2), q=1.2, minfolds=3)
+    same = cp.FFTlog(k, lambda z: fl.SphericalBesselJKernel(2)(z), q=1.2, minfolds=3)
+    for name in ('delta', 'lnxy', 'y', 'padded_u', 'padded_prefactor', 'padded_postfactor'):
+        np.testing.assert_allclose(getattr(same, name), getattr(builtin, name), rtol=1e-15, atol=0)
+    mixed = cp.FFTlog(k, [fl.BesselJKernel(0.5), lambda z: 0.5 * fl.GaussianKernel()(z)], q=[0.3, 0.9], lowring=False, xy=[1., 2.])
+    ref = cp.FFTlog(k, [fl.BesselJKernel(0.5), fl.GaussianKernel()], q=[0.3, 0.9], lowring=False, xy=[1., 2.])
+    np.testing.assert_allclose(mixed.padded_u[0], ref.padded_u[0], rtol=1e-15)
+    np.testing.assert_allclose(mixed.padded_u[1], 0.5 * ref.padded_u[1], rtol=1e-15)
+    np.testing.assert_allclose(mixed.y, ref.y, rtol=1e-15)
+
+
+def test_inverse_tables_of_complex_transforms():
+    """inv() (reference fftlog.py:243-248) also for complex=True transforms: reciprocal factors, u -> 1 / conj(u), grids traded."""
+    k = np.logspace(-3, 2, 128)
+    f = cp.PowerToCorrelation(k, ell=[0, 1, 2], complex=True)
+    pre, post, u, y = f.padded_prefactor.copy(), f.padded_postfactor.copy(), f.padded_u.copy(), f.y.copy()
+    assert np.iscomplexobj(post)
+    f.inv()
+    np.testing.assert_allclose(f.padded_prefactor, 1 / post, rtol=1e-15)
+    np.testing.assert_allclose(f.padded_postfactor, 1 / pre, rtol=1e-15)
+    np.testing.assert_allclose(f.padded_u, 1 / u.conj(), rtol=1e-15)
+    np.testing.assert_array_equal(f.x, y)
+    np.testing.assert_array_equal(f.padded_x, y)      # the reference's quirk: the un-padded grids
+    real, phase = fl._unit_phase_split(f.padded_prefactor, 'prefactor')
+    np.testing.assert_allclose(phase, 1 / (-1j)**np.arange(3), atol=1e-15)
+    np.testing.assert_allclose(real * phase[:, None], f.padded_prefactor, rtol=1e-14)
+    with pytest.raises(NotImplementedError):
+        fl._unit_phase_split(np.exp(1j * np.linspace(0, 1, 8))[None, :], 'table')
