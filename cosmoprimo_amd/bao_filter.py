@@ -252,6 +252,45 @@ def _local_maxima(x):
     return np.array(out, dtype=int)
 
 
+def _fiducial_wiggles(cosmo_fid, k_fid):
+    """
+    Wiggles of the fiducial cosmology on ``k_fid`` (z = 0), as brieden2022 and peakaverage define them (reference bao_filter.py:461-472,
+    536-548): the ratio of its P(k) to its Eisenstein-Hu no-wiggle P(k), divided by a broad-band correction -- the cubic in k
+    times 1/k (powers k^-1 .. k^2) fitted to the ratio with weights k^2 and pinned to its value and first difference at both ends.
+    Returns ``(ratio, correction)``; ``ratio / correction`` oscillates around 1 and equals 1 (to rounding) at the two first and two
+    last samples.
+    """
+    pk = np.asarray(Fourier(cosmo_fid).pk_interpolator()(k_fid, z=0.), dtype='f8')
+    pknow = np.asarray(Fourier(cosmo_fid, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k_fid, z=0.), dtype='f8')
+    ratio = pk / pknow
+    powers = k_fid[None, :]**np.arange(-1., 3.)[:, None]                      # (4, n)
+    ends = _end_constraints(k_fid.size, order=2)                              # value and first difference at either end, as rows
+    correction = _constrained_lsq_operator(powers, k_fid**2, powers.dot(ends.T), ends).dot(ratio)
+    return ratio, correction
+
+
+def _wiggle_extrema(residual, start):
+    """
+    Indices of the local maxima and of the local minima of ``residual[start:]`` (what ``scipy.signal.find_peaks`` reports for the
+    series and for its negative), with the tie at the end of the series settled by rule instead of by rounding: the fit behind
+    ``residual`` pins its last two samples to the same value, so in exact arithmetic the series ends on a two-sample plateau,
+    and whether the first of the two counts as an extremum depends on the last bit of the fit (in the reference as well: its lists
+    for the default fiducial cosmology hold that sample as a maximum, tests/golden/bao.npz; the knot moves the smooth P(k) by up
+    to 4e-4 above k = 0.36 h/Mpc).  Here it is an extremum of the kind the series approaches the plateau from: a maximum when it
+    rises into it, a minimum when it falls into it -- which is what the reference finds for its default fiducial cosmology.
+    """
+    x = np.array(residual[start:], dtype='f8')
+    n = x.size
+    x[n - 2] = x[n - 1] = 0.5 * (x[n - 2] + x[n - 1])                          # the plateau the constraints impose
+    found = []
+    for sign in (1., -1.):
+        ix = _local_maxima(sign * x)
+        if sign * x[n - 3] < sign * x[n - 2]:
+            ix = np.append(ix, n - 2)
+        found.append(ix + start)
+    return found
+
+
 class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     """
@@ -268,28 +307,17 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         return self._cosmo_fid
 
     def _prepare(self):
-        """Fiducial products (reference bao_filter.py:461-480): host numpy on 341 samples of the fiducial cosmology."""
+        """Fiducial products (reference bao_filter.py:461-480), host numpy on the 341 samples of 1e-3 <= k <= 1: the wiggles of the
+        fiducial cosmology, the knots of their two envelopes (first and last sample added as end knots) and the envelope operator."""
         self.kmask_fid = (self.k >= 1e-3) & (self.k <= 1.)
         self.k_fid = self.k[self.kmask_fid]
-        pk_fid = np.asarray(Fourier(self.cosmo_fid).pk_interpolator()(self.k_fid, z=0.), dtype='f8')
-        pknow_fid = np.asarray(Fourier(self.cosmo_fid, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(self.k_fid, z=0.), dtype='f8')
-        ratio = pk_fid / pknow_fid
-        gradient = np.array([self.k_fid**(i - 1) for i in range(4)])
-        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
-        constraint = [ratio[..., 0], ratio[..., 1] - ratio[..., 0], ratio[..., -1], ratio[..., -2] - ratio[..., -1]]
-        # utils.LeastSquareSolver(gradient, precision=k^2, constraint_gradient, compute_inverse=False) (utils.py:161-272)
-        hv = gradient * self.k_fid**2
-        invfisher = np.block([[hv.dot(gradient.T), -cg], [cg.T, np.zeros((4, 4))]])
-        hv = np.block([[hv, np.zeros(cg.shape)], [np.zeros((4, gradient.shape[-1])), np.eye(4)]])
-        params = np.linalg.solve(invfisher, hv.dot(np.concatenate([ratio, constraint]).T)).T[..., :4]
-        self.pknow_correction = params.dot(gradient)[:, None]
-        self.ratio_fid = ratio[:, None] / self.pknow_correction
-        ik0 = np.searchsorted(self.k_fid, 0.02, side='right') + 1
-        self.ik_fid_peaks = []
-        for si in [1., -1.]:
-            ix = _local_maxima(si * self.ratio_fid[ik0:, 0]) + ik0
-            ix = np.concatenate([[0]] * int(ix[0] > 0) + [ix] + [[-1]] * int(ix[-1] < self.k_fid.size - 1), axis=0)
-            self.ik_fid_peaks.append(ix)
+        ratio, correction = _fiducial_wiggles(self.cosmo_fid, self.k_fid)
+        self.pknow_correction = correction[:, None]
+        self.ratio_fid = (ratio / correction)[:, None]
+        start = np.searchsorted(self.k_fid, 0.02, side='right') + 1            # extrema are looked for above k = 0.02 only
+        last = self.k_fid.size - 1
+        self.ik_fid_peaks = [np.concatenate([[0] if ix[0] > 0 else [], ix, [-1] if ix[-1] < last else []]).astype(int)
+                             for ix in _wiggle_extrema(self.ratio_fid[:, 0], start)]
         self._set_envelope_operator()
 
     def _set_envelope_operator(self):
@@ -550,23 +578,18 @@ class PeakAveragePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumB
         return self._cosmo_fid
 
     def _prepare(self):
+        """Knots of the two splines (reference bao_filter.py:536-563): the extrema of the fiducial wiggles above k = 0.01, with every
+        sample below k = 1e-3 and above the last extremum (at least all of k > 1) kept as knots on either side."""
         index = np.flatnonzero((self.k >= 1e-3) & (self.k <= 1.))
-        k_fid = self.k[index]
-        pk_fid = np.asarray(Fourier(self.cosmo_fid).pk_interpolator()(k_fid, z=0.), dtype='f8')
-        pknow_fid = np.asarray(Fourier(self.cosmo_fid, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k_fid, z=0.), dtype='f8')
-        ratio = pk_fid / pknow_fid
-        gradient = np.array([k_fid**(i - 1) for i in range(4)])
-        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
-        pknow_correction = _constrained_lsq_operator(gradient, k_fid**2, cg, _end_constraints(k_fid.size, order=2)).dot(ratio)
-        ik0 = np.searchsorted(k_fid, 1e-2, side='right') + 1
+        ratio, correction = _fiducial_wiggles(self.cosmo_fid, self.k[index])
+        start = np.searchsorted(self.k[index], 1e-2, side='right') + 1
+        first = index[0]
         self.k_peaks, self.pad_peaks = [], []
-        for si in [1., -1.]:
-            ik = _local_maxima(si * ratio[ik0:] / pknow_correction[ik0:]) + ik0
-            npadlow = index[0]
-            ik = ik + npadlow
-            ikmax = max(index[-1], ik[-1] + 1)
-            self.pad_peaks.append((npadlow, len(ik), self.k.size - ikmax))
-            self.k_peaks.append(self.k[np.concatenate([np.arange(npadlow), ik, np.arange(ikmax, self.k.size)], axis=0)])
+        for extrema in _wiggle_extrema(ratio / correction, start):
+            extrema = extrema + first
+            resume = max(index[-1], extrema[-1] + 1)
+            self.pad_peaks.append((first, len(extrema), self.k.size - resume))
+            self.k_peaks.append(np.concatenate([self.k[:first], self.k[extrema], self.k[resume:]]))
 
     def _operator(self, rescale):
         """``_interp`` (reference bao_filter.py:565-574): natural splines in log10 k, data -> moved knots (extrapolating) -> all k."""
