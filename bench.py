@@ -2,8 +2,8 @@
 Headline benchmark (BASELINE.json): batched FFTLog P(k) -> xi(r) transforms/sec at N=2048, fp64, with the achieved
 fraction of the HBM roofline.
 
-    python bench.py [--gpus N --steps K --warmup W]          # N=1
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N --steps K --warmup W]          # N=1, config 2 (the headline)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W [--config 2|4|5] [--gather]
 
 Workload: per GPU, 100 000 rows x 2048 log-k bins, rows = A_b (k/0.05)^dn_b P_EH(k),
 A~U(0.5,2), dn~U(-0.1,0.1), default_rng(rank); PowerToCorrelation(k, ell=0), defaults (lowring, extrap=0) -> Np=4096.
@@ -11,8 +11,12 @@ One "step" = one pass of the fused kernel over the resident batch (inputs alread
 ranks shard with no data-path collective (weak scaling: per-GPU work fixed); `value` = rows of all ranks / max time.
 
 Extra objects on the JSON line: "roofline" (algorithmic bytes 2*8*N per row / kernel time measured with HIP events on
-the launch stream, against 8 TB/s) and, at N=1, "cpu_baseline" (the numpy oracle -- same math as the reference's
-numpy path -- on a bounded sample, all host cores through a process pool).
+the launch stream, against 8 TB/s), "value_api" (the same steps through cp.PowerToCorrelation.__call__), at N=1 "cpu_baseline" (the numpy
+oracle -- same math as the reference's numpy path -- on a bounded sample, all host cores through a process pool) and "secondary": BASELINE
+configs 3, 4 and 5 at one GPU's share (a few ms to a few tens of ms of GPU time each) with their own roofline figures.
+
+--config 4 / 5: the 8-GPU configs of BASELINE.json as STRONG splits (1 M P(k) vectors through wallish2018 + brieden2022; 10 M background
+samples; each rank takes its contiguous block of cosmologies / samples, no data-path collective); --gather adds the final RCCL all_gather.
 """
 import argparse
 import json
@@ -78,6 +82,192 @@ def cpu_baseline(seconds=10.):
             'per_core_value': float(np.mean([r[0] / r[1] for r in res]))}
 
 
+def _gpu_ms(fn, reps, torch, dev):
+    """(wall ms, HIP-event ms) per call of fn() on the current stream, after one untimed call."""
+    fn()
+    torch.cuda.synchronize(dev)
+    stream = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / reps * 1e3, e0.elapsed_time(e1) / reps
+
+
+def eh_parameters(n, seed, torch, dev):
+    """Omega_m ~ U(.25, .40), Omega_b ~ U(.04, .06), h ~ U(.6, .8), n_s ~ U(.92, 1) for n cosmologies, on the device."""
+    rng = np.random.default_rng(seed)
+    par = dict(Omega_m=rng.uniform(.25, .40, n), Omega_b=rng.uniform(.04, .06, n), h=rng.uniform(.6, .8, n), n_s=rng.uniform(.92, 1., n))
+    return {name: torch.as_tensor(v, device=dev) for name, v in par.items()}
+
+
+def config3(cp, torch, dev, ncosmo=10000, reps=5):
+    """sigma_rz on 256 r x 64 z for a batch of EH cosmologies (method fftlog, nk = 1024): cosmologies/s, HBM fraction on the
+    131 072 + 80 algorithmic bytes per cosmology (10 parameters in, 256 x 64 float64 out)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **eh_parameters(ncosmo, 1, torch, dev))
+        interp = cosmo.get_fourier().pk_interpolator()
+        r, z = torch.as_tensor(np.geomspace(1, 100, 256), device=dev), torch.as_tensor(np.linspace(0, 3, 64), device=dev)
+        wall, gpu = _gpu_ms(lambda: interp.sigma_rz(r, z), reps, torch, dev)
+    nbytes = ncosmo * (256 * 64 * 8 + 80)
+    return {'workload': 'config 3: sigma_rz 256 r x 64 z, %d EH98 cosmologies, method fftlog nk=1024, through PowerSpectrumInterpolator2D.sigma_rz' % ncosmo,
+            'value': ncosmo / (wall * 1e-3), 'unit': 'cosmologies/s', 'ms': wall, 'ms_gpu_events': gpu,
+            'roofline': {'bound': 'hbm', 'achieved': nbytes / (wall * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': nbytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_cosmology': 256 * 64 * 8 + 80}}
+
+
+def config4(cp, torch, dev, par, chunk=16384):
+    """wallish2018 and brieden2022 on EH98 P(k) vectors (nk = 1024) of the cosmologies ``par``, chunk by chunk (P(k) generation and sigma8
+    normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time."""
+    import warnings
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    n = int(par['Omega_m'].numel())
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fid = cp.Cosmology(engine='eisenstein_hu')
+        for engine in ('wallish2018', 'brieden2022'):
+            kw = dict(cosmo_fid=fid) if engine == 'brieden2022' else {}
+            state = {}
+
+            def run(sl):
+                cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{name: v[sl] for name, v in par.items()})
+                interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+                if 'filter' not in state:      # made once, called again for every chunk: its _prepare products depend on the fiducial only
+                    state['filter'] = PowerSpectrumBAOFilter(interp, engine=engine, **(dict(kw, cosmo=cosmo) if kw else {}))
+                else:
+                    state['filter'](interp, cosmo=cosmo if kw else None)
+                return state['filter']._pknow_rows
+
+            run(slice(0, min(n, chunk)))       # plans, operators and code objects are built on first use
+            torch.cuda.synchronize(dev)
+            stream = torch.cuda.current_stream(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for start in range(0, n, chunk):
+                res = run(slice(start, min(n, start + chunk)))
+            e1.record(stream)
+            torch.cuda.synchronize(dev)
+            wall = time.perf_counter() - t0
+            assert bool(torch.isfinite(res).all())
+            out[engine] = {'value': n / wall, 'unit': 'vectors/s', 'ms': wall * 1e3, 'ms_gpu_events': e0.elapsed_time(e1), 'vectors': n,
+                           'roofline': {'bound': 'hbm', 'achieved': n * 16384 / wall / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                        'frac': n * 16384 / wall / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_vector': 16384,
+                                        'note': 'latency / ALU bound by construction (SURVEY.md 8(d)): the HBM fraction is reported, not targeted'}}
+    return out
+
+
+# comoving_radial_distance, fresh cosmology per sample: 237 evaluations of 1 / E(z) on the 119-knot Simpson grid, each ~13 fp64 operations of
+# the polynomial part + exp (~22) + rsqrt (~9), plus the Simpson sums and the two-sided natural-spline elimination (~12 per knot): the count
+# of fp64 VALU instructions of bg_kernel per sample (tools/isa_census.py on cp_background.hip, DESIGN.md section 4)
+CONFIG5_FLOP_PER_SAMPLE = 237 * 44 + 119 * 12
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+
+
+def config5(torch, dev, om, w0, wa, zz, reps=5):
+    from cosmoprimo_amd import background
+    n = int(zz.numel())
+    wall, gpu = _gpu_ms(lambda: background.distance('comoving_radial_distance', zz[:, None], dict(w0_fld=w0, wa_fld=wa), Omega_m=om, per_cosmology_z=True),
+                        reps, torch, dev)
+    tflops = n * CONFIG5_FLOP_PER_SAMPLE / (wall * 1e-3) / 1e12
+    return {'workload': 'config 5: comoving_radial_distance for %d (Omega_m, w0, wa, z) samples, one fresh cosmology per sample' % n,
+            'value': n / (wall * 1e-3), 'unit': 'samples/s', 'ms': wall, 'ms_gpu_events': gpu,
+            'roofline': {'bound': 'fp64 valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
+                         'flop_per_sample': CONFIG5_FLOP_PER_SAMPLE, 'hbm_GBps': n * 40 / (wall * 1e-3) / 1e9}}
+
+
+def config5_samples(n, seed, torch, dev):
+    """Omega_m ~ U(.1, .5), w0 ~ U(-1.5, -.5), wa ~ U(-1, .5) with w0 + wa < 1/3 (re-drawn otherwise), z ~ U(0, 3)."""
+    rng = np.random.default_rng(seed)
+    om, w0, wa, zz = rng.uniform(0.1, 0.5, n), rng.uniform(-1.5, -0.5, n), rng.uniform(-1., 0.5, n), rng.uniform(0., 3., n)
+    bad = w0 + wa >= 1. / 3.
+    while bad.any():
+        w0[bad], wa[bad] = rng.uniform(-1.5, -0.5, bad.sum()), rng.uniform(-1., 0.5, bad.sum())
+        bad = w0 + wa >= 1. / 3.
+    return tuple(torch.as_tensor(v, device=dev) for v in (om, w0, wa, zz))
+
+
+def secondary(cp, torch, dev):
+    """BASELINE configs 3, 4, 5 at one GPU's share of the smaller kind (a few ms to tens of ms each), for the N = 1 line."""
+    out = {'config3': config3(cp, torch, dev)}
+    c4 = config4(cp, torch, dev, eh_parameters(16384, 2, torch, dev))
+    out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on 16 384 EH98 P(k) vectors (one chunk of a GPU share of 125 000), '
+                                         'P(k) generation and sigma8 normalisation included, results resident')
+    out['config5'] = config5(torch, dev, *config5_samples(1250000, 3, torch, dev))
+    return out
+
+
+def main_split(args, config):
+    """--config 4 / 5: strong split of the BASELINE 8-GPU workloads over the ranks, no data-path collective; rank 0 prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    rank, local_rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd.distributed import shard_range, gather_rows
+    total = args.rows if args.rows != ROWS_PER_GPU else (1000000 if config == 4 else 10000000)
+    start, stop = shard_range(total, rank, world)
+    if config == 4:
+        full = eh_parameters(total, 2, torch, torch.device('cpu'))
+        par = {name: v[start:stop].to(dev) for name, v in full.items()}
+        run = lambda: config4(cp, torch, dev, par)      # noqa: E731
+    else:
+        full = config5_samples(total, 3, torch, torch.device('cpu'))
+        mine = tuple(v[start:stop].to(dev) for v in full)
+        run = lambda: config5(torch, dev, *mine, reps=1)      # noqa: E731
+    for _ in range(max(1, args.warmup)):
+        run()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    tic = time.perf_counter()
+    for _ in range(args.steps):
+        last = run()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - tic
+    gather_ms = None
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax[0])
+        if args.gather:
+            local = torch.zeros((stop - start, 1024 if config == 4 else 1), dtype=torch.float64, device=dev)      # the shape of a rank's results
+            gather_rows(local, n_total=total)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            gather_rows(local, n_total=total)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            gather_ms = (time.perf_counter() - t0) * 1e3
+    if rank == 0:
+        units = total * (2 if config == 4 else 1)       # config 4: every vector goes through both filters
+        line = {'metric': 'BAO-filtered P(k) vectors/sec (wallish2018 + brieden2022, nk=1024)' if config == 4 else 'comoving_radial_distance samples/sec',
+                'value': units * args.steps / elapsed, 'unit': 'filtered vectors/s' if config == 4 else 'samples/s', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+                'dtype': 'f64', 'data': 'synthetic',
+                'config': {'workload': 'config %d: %d %s split over %d GPU(s) in contiguous blocks, no collective' % (
+                    config, total, 'EH98 P(k) vectors through both filters' if config == 4 else '(Omega_m, w0, wa, z) samples', world),
+                    'per_gpu': stop - start, 'rccl_ranks': world if world > 1 else 0},
+                'rank0_detail': last}
+        if gather_ms is not None:
+            line['gather_ms'] = gather_ms
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -86,7 +276,12 @@ def main():
     ap.add_argument('--rows', type=int, default=ROWS_PER_GPU, help='rows per GPU (default: the config-2 batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--gather', action='store_true', help='also time the final RCCL all_gather of the result shards (reported separately)')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 4, 5], help='BASELINE.json config: 2 (headline, weak scaling), 4 or 5 (strong splits)')
+    ap.add_argument('--ramp-ms', type=float, default=300., help='untimed load before the warmup steps, to reach the sustained device state')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs 3 / 4 / 5 numbers of the N = 1 line')
     args = ap.parse_args()
+    if args.config != 2:
+        return main_split(args, args.config)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -133,6 +328,14 @@ def main():
     def step():
         _lib.check(lib.cp_fftlog_execute(plan.handle, rows.data_ptr(), out.data_ptr(), nb, 0, 0., 0, 0., 0, stream.cuda_stream))
 
+    # Bring the device to its sustained state first: after an idle period the first tens of milliseconds of load run ~10 % slower than the
+    # steady state that follows (clock / power management ramp; measured with tools/api_probe.py: 1.12 ms for the first 20 launches of a fresh
+    # process, 0.975 ms for every later batch of 20).  Untimed, like the W warmup steps that follow it.
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < args.ramp_ms * 1e-3:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize(dev)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -179,12 +382,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
         if args.gather:
+            from cosmoprimo_amd.distributed import gather_rows
             full = torch.empty((world * nb, N_K), dtype=out.dtype, device=dev)
-            dist.all_gather_into_tensor(full, out)
+            gather_rows(out, n_total=world * nb, out=full)      # equal shards: one all_gather_into_tensor into the preallocated result
             torch.cuda.synchronize(dev)
             dist.barrier()
             t0 = time.perf_counter()
-            dist.all_gather_into_tensor(full, out)
+            gather_rows(out, n_total=world * nb, out=full)
             torch.cuda.synchronize(dev)
             dist.barrier()
             gather_ms = (time.perf_counter() - t0) * 1e3
@@ -225,8 +429,13 @@ def main():
             'parity_spot_check_tilted_err': err,
             'value_api': nb * world * args.steps / elapsed_api,   # same batch through cp.PowerToCorrelation.__call__ (resident tensors)
         }
+        line['config']['rccl_ranks'] = world if distributed else 0
         if cpu is not None:
             line['cpu_baseline'] = cpu
+        if world == 1 and not args.no_secondary:
+            del rows, out
+            torch.cuda.empty_cache()
+            line['secondary'] = secondary(cp, torch, dev)
         if gather_ms is not None:
             line['gather_ms'] = gather_ms
             line['value_with_gather'] = nb * world / (elapsed / args.steps + gather_ms * 1e-3)

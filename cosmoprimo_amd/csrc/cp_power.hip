@@ -376,9 +376,11 @@ int select_device(int device, int* prev) {
 
 }  // namespace
 
+extern "C" long long cp_power_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : (long long)sizeof(EhScalars) * ncosmo; }
+
 extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                             long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, int device,
-                             void* stream) {
+                             long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, void* d_work,
+                             int device, void* stream) {
     if (engine < CP_ENGINE_EH || engine > CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_power_eval: unknown engine %d", engine);
     if (what < CP_PK_MATTER || what > CP_PK_PRIMORDIAL) return cp::fail(CP_EINVAL, "cp_power_eval: unknown quantity %d", what);
     if (ncosmo < 0 || nk < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_power_eval: negative size");
@@ -412,19 +414,17 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
         return cp::fail(CP_EUNSUPPORTED, "cp_power_eval: %lld cosmologies x %lld wavenumbers exceed one launch; split the batch", ncosmo, nk);
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    EhScalars* scal = nullptr;   // stream-ordered scratch: concurrent calls on other streams have their own
-    if (what != CP_PK_PRIMORDIAL && engine != CP_ENGINE_BBKS) {
-        if (hipMallocAsync(reinterpret_cast<void**>(&scal), sizeof(EhScalars) * (size_t)ncosmo, hs) != hipSuccess) {
-            (void)hipGetLastError();
+    if (what != CP_PK_PRIMORDIAL && engine != CP_ENGINE_BBKS) {   // fit coefficients of the cosmologies: caller-owned workspace, nothing is allocated here
+        if (!d_work) {
             if (prev >= 0) (void)hipSetDevice(prev);
-            return cp::fail(CP_ENOMEM, "cp_power_eval: cannot allocate the fit coefficients of %lld cosmologies", ncosmo);
+            return cp::fail(CP_EINVAL, "cp_power_eval: the EH engines need a workspace of cp_power_workspace_bytes(ncosmo) bytes");
         }
+        EhScalars* scal = static_cast<EhScalars*>(d_work);
         A.scal = scal;
         hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, hs, A, scal);
     }
     hipLaunchKernelGGL(power_kernel, dim3((unsigned)(ncosmo * A.kchunks)), dim3((unsigned)block), 0, hs, A);
     hipError_t e = hipGetLastError();
-    if (scal) (void)hipFreeAsync(scal, hs);
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval: launch failed: %s", hipGetErrorString(e));
     return CP_OK;

@@ -90,6 +90,100 @@ __global__ __launch_bounds__(256) void spline_apply_kernel(const Args A) {
     }
 }
 
+// The same with an outer-product epilogue: out[row, q, z] = f(scale x spline(y)[row, q] x g[row, z]), f = sqrt or identity, written once as
+// (nrows, nq, nz).  sigma(r, z) of separable spectra P(k, z) = P(k) D^2(z) is of that form (sigma^2(r) x D^2(z), rooted: reference
+// interpolator.py:846-875 evaluates one integral per redshift).  The interpolated values of a tile are staged in LDS and the workgroup
+// then streams the rows' (nqt x nz) blocks -- contiguous in the output -- with 16-byte stores: the result, by far the largest array of the
+// chain (nq nz values per input row), is produced by the kernel that computes it instead of by elementwise passes behind it.
+struct OuterArgs {
+    Args a;
+    const double* g;   // (nrows, nz)
+    int nz;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void spline_outer_kernel(const OuterArgs O) {
+    const Args& A = O.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* ylds = reinterpret_cast<double*>(smem);   // (R, span_max) knots, then (R, TILE_Q) interpolated values, then (R, nz) factors
+    double* vlds = ylds + R * A.span_max;
+    double* glds = vlds + R * TILE_Q;
+    const int tid = threadIdx.x;
+    const int nz = O.nz;
+    const long long ngroups = (A.nrows + R - 1) / R;
+    const long long nitems = ngroups * A.ntiles;
+    for (long long it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int t = (int)(it % A.ntiles);
+        const long long r0 = (it / A.ntiles) * R;
+        const int nr = (int)((A.nrows - r0) < R ? (A.nrows - r0) : R);
+        const int q0 = A.tile[4 * t], nqt = A.tile[4 * t + 1], tj0 = A.tile[4 * t + 2], span = A.tile[4 * t + 3];
+        __syncthreads();   // the previous item's stores have read vlds / glds
+        for (int r = 0; r < R; ++r) {
+            const long long row = r0 + (r < nr ? r : nr - 1);
+            const double* yr = A.y + row * A.n + tj0;
+            for (int i = tid; i < span; i += 256) ylds[r * A.span_max + i] = yr[i];
+            for (int i = tid; i < nz; i += 256) glds[r * nz + i] = O.g[row * nz + i];
+        }
+        __syncthreads();
+        if (tid < nqt) {
+            const int q = q0 + tid;
+            const int j0 = A.j0[q];
+            double acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = 0.;
+            if (j0 >= 0) {
+                const int base = j0 - tj0;
+                for (int jj = 0; jj < A.bw; ++jj) {
+                    const double w = A.wb[(long long)jj * A.nq + q];
+                    int j = base + jj;
+                    j = j < span ? j : span - 1;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r] = fma(w, ylds[r * A.span_max + j], acc[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) vlds[r * TILE_Q + tid] = j0 >= 0 ? acc[r] * A.scale : __builtin_nan("");
+        }
+        __syncthreads();
+        const long long block = (long long)nqt * nz;   // values of one row of this tile, contiguous in the output
+        for (int r = 0; r < nr; ++r) {
+            double* dst = A.out + ((r0 + r) * A.nq + q0) * nz;
+            const double* vr = vlds + r * TILE_Q;
+            const double* gr = glds + r * nz;
+            if ((nz & 1) == 0) {
+                for (long long e = 2LL * tid; e < block; e += 512) {
+                    const int q = (int)(e / nz), z = (int)(e - (long long)q * nz);
+                    double2 v;
+                    v.x = vr[q] * gr[z];
+                    v.y = vr[q] * gr[z + 1];
+                    if (A.post_op == CP_SPLINE_POST_SQRT) {
+                        v.x = sqrt(v.x);
+                        v.y = sqrt(v.y);
+                    }
+                    *reinterpret_cast<double2*>(dst + e) = v;
+                }
+            } else {
+                for (long long e = tid; e < block; e += 256) {
+                    const int q = (int)(e / nz), z = (int)(e - (long long)q * nz);
+                    double v = vr[q] * gr[z];
+                    if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                    dst[e] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int R>
+hipError_t launch_outer(const OuterArgs& O, size_t lds, hipStream_t stream) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_outer_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long long nitems = ((O.a.nrows + R - 1) / R) * O.a.ntiles;
+    const int grid = (int)(nitems < 256 * 8 ? nitems : 256 * 8);
+    hipLaunchKernelGGL(spline_outer_kernel<R>, dim3(grid), dim3(256), lds, stream, O);
+    return hipGetLastError();
+}
+
 template <int R>
 hipError_t launch_apply(const Args& A, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024)
@@ -385,6 +479,36 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     const hipError_t e = rows == 16 ? launch_apply<16>(A, lds, hs) : rows == 8 ? launch_apply<8>(A, lds, hs) : launch_apply<4>(A, lds, hs);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+
+extern "C" int cp_spline_apply_outer(const cp_spline_plan* p, const double* d_y, const double* d_g, int nz, double* d_out, long long nrows, int post_op,
+                                     double scale, void* stream) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_spline_apply_outer: null plan");
+    if (nrows < 0 || nz < 1) return cp::fail(CP_EINVAL, "cp_spline_apply_outer: bad sizes (nrows=%lld, nz=%d)", nrows, nz);
+    if (nrows == 0) return CP_OK;
+    if (!d_y || !d_g || !d_out) return cp::fail(CP_EINVAL, "cp_spline_apply_outer: null device pointer");
+    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_apply_outer: unknown post op %d", post_op);
+    // rows per work item: the staged knots, interpolated values and factors of the group within 64 KB of LDS (two to three workgroups per CU)
+    auto bytes = [&](int rows) { return (size_t)rows * ((size_t)p->span_max + TILE_Q + (size_t)nz) * sizeof(double); };
+    int rows = 8;
+    while (rows > 2 && (bytes(rows) > 64 * 1024 || rows / 2 >= nrows)) rows /= 2;
+    const size_t lds = bytes(rows);
+    if (lds > 160 * 1024) return cp::fail(CP_EUNSUPPORTED, "cp_spline_apply_outer: %d knots per query and %d factors per row exceed the LDS staging buffer", p->span_max, nz);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply_outer: cannot select device %d", p->device);
+    OuterArgs O;
+    Args& A = O.a;
+    A.y = d_y; A.out = d_out; A.nrows = nrows; A.n = p->n; A.nq = p->nq; A.bw = p->bw; A.wb = p->d_wb; A.j0 = p->d_j0;
+    A.tile = p->d_tile; A.ntiles = p->ntiles; A.span_max = p->span_max;
+    A.post_op = post_op; A.scale = scale;
+    O.g = d_g; O.nz = nz;
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    const hipError_t e = rows == 8 ? launch_outer<8>(O, lds, hs) : rows == 4 ? launch_outer<4>(O, lds, hs) : launch_outer<2>(O, lds, hs);
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply_outer: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
 

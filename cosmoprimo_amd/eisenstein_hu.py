@@ -137,11 +137,22 @@ class Fourier(BaseSection):
         ntheta = sum(of_.startswith('theta_') for of_ in of)
         ba, device = self.ba, self.device
 
+        growth_cache = {}      # host redshift grid (bytes) -> device result: the cosmology behind this closure does not change
+
         def growth_factor_sq(z):
+            key = None
+            if not dv.is_torch(z) and np.size(z) <= 4096:
+                key = (np.shape(z), np.asarray(z, dtype='f8').tobytes())
+                if key in growth_cache:
+                    return growth_cache[key]
             zt = dv.to_device(z, device)
             g = dv.to_device(ba.growth_factor(zt, znorm=0.), device)**2
             if ntheta:
                 g = g * dv.to_device(ba.growth_rate(zt), device)**ntheta
+            if key is not None:
+                if len(growth_cache) >= 8:
+                    growth_cache.clear()
+                growth_cache[key] = g
             return g
 
         def pk_callable(k):

@@ -66,10 +66,25 @@ def _mask_bounds(x, xlim, bounds_error=False):
     return masks
 
 
+_host_copies = {}   # id(tensor) -> (weak reference, tensor version, host copy)
+
+
 def _host(x):
-    """numpy float64 copy of a number / array / tensor (query coordinates are small and define host-built operators)."""
+    """numpy float64 copy of a number / array / tensor (query coordinates are small and define host-built operators).  The copy of a small
+    device tensor is remembered while the tensor lives and is not written to: the same grid of radii or redshifts passed call after call
+    costs one device-to-host copy (which synchronises the stream), not one per call."""
     if dv.is_torch(x):
-        return dv.to_host(x).astype('f8', copy=False)
+        if x.numel() > 65536 or not x.is_cuda:
+            return dv.to_host(x).astype('f8', copy=False)
+        import weakref
+        key = id(x)
+        entry = _host_copies.get(key)
+        if entry is not None and entry[0]() is x and entry[1] == x._version:
+            return entry[2]
+        copy = dv.to_host(x).astype('f8', copy=False)
+        copy.setflags(write=False)
+        _host_copies[key] = (weakref.ref(x, lambda _, key=key: _host_copies.pop(key, None)), x._version, copy)
+        return copy
     return np.asarray(x, dtype='f8')
 
 
@@ -149,12 +164,21 @@ def _cached_operator(key, build):
     return _op_cache[key]
 
 
-def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None):
+def _with_growth(sigma2, growth_sq):
+    """sqrt(sigma2[..., r] growth_sq[..., z]) as (..., nr, nz) (methods other than 'fftlog': elementwise), or sigma2 as it is."""
+    if growth_sq is None:
+        return sigma2
+    return (sigma2[..., :, None] * growth_sq[..., None, :]).sqrt()
+
+
+def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None):
     r"""
     :math:`\sigma_r^2 = \frac{1}{2\pi^2}\int dk\,k^2 P(k) W^2(kr)` (reference interpolator.py:200-292) for rows of P(k).
 
     pk_rows : callable k (numpy, (nk,)) -> device tensor (..., nk): the power spectra sampled at k, k fastest.
     method : 'fftlog' (default) or 'simpson'.  Returns a device tensor (..., nr) holding :math:`\sigma_r^2`.
+    growth_sq : optional device tensor (..., nz), one row of factors per row of P(k): the result is then
+        :math:`\sqrt{\sigma_r^2\,\mathrm{growth\_sq}(z)}` of shape (..., nr, nz), written once by the interpolation kernel.
     """
     device = dv.resolve_device(device)
     rr = _host(r).ravel()
@@ -175,6 +199,8 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         s = fft.y[0]
         op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
         # tmp = (2 pi^2) spline(var)(r); sigma^2 = tmp / (2 pi^2)  (interpolator.py:289-291)
+        if growth_sq is not None:
+            return op.outer(var, growth_sq, sqrt=True)
         return op(var)
     if method == 'simpson':
         limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
@@ -186,7 +212,7 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
             return LinearOperator.dense(1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * w)[None, :], device=device)
 
         op = _cached_operator(('simpson_r', float(kmin), float(kmax), int(nk), rr.tobytes(), device.index), build)
-        return op(pk_rows(k))
+        return _with_growth(op(pk_rows(k)), growth_sq)
     if method == 'leggauss':   # "not accurate" in the reference's own words (interpolator.py:274-280); nk = 100 nodes by default
         nl = nk_leggauss
         limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
@@ -196,7 +222,7 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         w = (limits[1] - limits[0]) / 2. * wx
         op = _cached_operator(('leggauss_r', float(kmin), float(kmax), int(nl), rr.tobytes(), device.index),
                               lambda: LinearOperator.dense(1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * w)[None, :], device=device))
-        return op(pk_rows(k))
+        return _with_growth(op(pk_rows(k)), growth_sq)
     raise NotImplementedError('integrate_sigma_r2 method {} is not available on the GPU path (use "fftlog", "simpson" or "leggauss")'.format(method))
 
 
@@ -803,6 +829,16 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             return False
         return self.is_from_callable or self._pk.shape[1] == 1
 
+    def _growth_sq_device(self, zh):
+        """growth_factor_sq at flat host redshifts as a device tensor (batch..., nz), NaN outside the redshift range of a callable."""
+        torch = dv.torch()
+        growth = dv.to_device(self.growth_factor_sq(zh), self.device)
+        if self.is_from_callable:
+            _, mask_z = _mask_bounds([self.z[:1], zh], [(self.zmin, self.zmax)] * 2)
+            if not mask_z.all():
+                growth = torch.where(torch.as_tensor(mask_z, device=self.device), growth, torch.full_like(growth, float('nan')))
+        return growth
+
     def _sigma_separable(self, integrate, zh):
         """sigma^2(..., z) = growth_factor_sq(z) x sigma^2 of the z-independent spectrum: the k integral is linear in P, so ONE transform
         per cosmology replaces one per (cosmology, z) -- same numbers as the reference's per-z integrals to rounding.  Returns the two
@@ -842,10 +878,19 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         like_torch = dv.is_torch(r) or dv.is_torch(z)
         dtype = dv.float_dtype(r, z)
         rh, zh = _host(r), _host(z)
-        if self._separable():
+        if self._separable() and rh.size and zh.size:
+            # sigma^2(r, z) = growth_factor_sq(z) x sigma^2(r) of the z-independent spectrum (the k integral is linear in P): ONE transform per
+            # cosmology instead of one per (cosmology, z), and the (batch, nr, nz) result written once by the kernel that interpolates in r
+            growth_sq = self._growth_sq_device(zh.ravel())
+
+            def rows(kh):
+                return self._eval_device(kh, self.z[:1], grid=True, ignore_growth=True)[..., 0]      # (batch..., nk)
+
+            out = integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, growth_sq=growth_sq, **kwargs)
+        elif self._separable():
             base, growth = self._sigma_separable(lambda rows: integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
                                                                                  **kwargs), zh.ravel())
-            out = base[..., :, None] * growth[..., None, :]        # (batch..., nr, nz), written once
+            out = base[..., :, None] * growth[..., None, :]
         else:
             out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
             out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)

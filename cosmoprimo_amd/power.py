@@ -51,9 +51,10 @@ def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=Non
         if tks.numel() != ncosmo:
             raise ValueError('kscale must have one entry per cosmology ({:d}), got {:d}'.format(ncosmo, tks.numel()))
     lib = _lib.load()
+    work = torch.empty(max(int(lib.cp_power_workspace_bytes(ncosmo)), 8), dtype=torch.uint8, device=device)    # fit coefficients: torch's caching allocator
     _lib.check(lib.cp_power_eval(_lib.ENGINES[engine], _lib.PK_WHAT[what], ncosmo, dv.as_void_p(cbg), int(Omega_m is not None), dv.as_void_p(cpk), nk,
                                  tk.data_ptr(), tks.data_ptr() if tks is not None else None, nz, tz.data_ptr() if with_z else None, out.data_ptr(),
-                                 device.index, dv.stream_of(device)))
+                                 work.data_ptr(), device.index, dv.stream_of(device)))
     shape = ((ncosmo,) if batched else ()) + ((nz,) if with_z else ()) + (nk,)
     return out.reshape(shape)
 

@@ -57,6 +57,21 @@ class LinearOperator(object):
                                                    dv.stream_of(self.device)))
         return out
 
+    def outer(self, y, g, sqrt=False, scale=1.):
+        """y : (..., n), g : (..., nz) device tensors with the same leading shape -> (..., nq, nz) = f(scale x (W y)[..., q] x g[..., z]), f = sqrt or
+        identity, written once by the kernel that interpolates (``cp_spline_apply_outer``)."""
+        torch = dv.torch()
+        y, g = dv.to_device(y, self.device), dv.to_device(g, self.device)
+        if y.shape[-1] != self.n or tuple(y.shape[:-1]) != tuple(g.shape[:-1]):
+            raise ValueError('need y (..., {:d}) and g (..., nz) with the same leading shape, got {} and {}'.format(self.n, tuple(y.shape), tuple(g.shape)))
+        lead, nz = tuple(y.shape[:-1]), int(g.shape[-1])
+        nrows = int(np.prod(lead, dtype=np.int64))
+        out = torch.empty(lead + (self.nq, nz), dtype=torch.float64, device=self.device)
+        if nrows and nz:
+            _lib.check(_lib.load().cp_spline_apply_outer(self._handle, y.data_ptr(), g.data_ptr(), nz, out.data_ptr(), nrows, int(bool(sqrt)), float(scale),
+                                                         dv.stream_of(self.device)))
+        return out
+
     def __del__(self):
         try:
             if self._handle:

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 1
+#define CP_ABI_VERSION 2
 
 enum cp_status {
     CP_OK = 0,
@@ -194,10 +194,14 @@ enum cp_pk_param { CP_PK_A_S = 0, CP_PK_N_S = 1, CP_PK_ALPHA_S = 2, CP_PK_BETA_S
 /* bg_params: the CP_BG_NPARAMS background parameters (cp_bg_param); pk_params: CP_PK_NPARAMS primordial parameters.
  * d_k : (nk) wavenumbers in h/Mpc shared by the batch; d_kscale : NULL, or (ncosmo) per-cosmology factors applied to d_k
  * (brieden2022 evaluates at k_fid / rescale and k_fid * rescale, bao_filter.py:493-499); d_z : (nz) redshifts shared by the batch
- * (CP_PK_MATTER only).  d_out : (ncosmo, max(nz, 1), nk), k fastest, (Mpc/h)^3. */
+ * (CP_PK_MATTER only).  d_out : (ncosmo, max(nz, 1), nk), k fastest, (Mpc/h)^3.
+ * d_work : device workspace of cp_power_workspace_bytes(ncosmo) bytes for the fit coefficients of the cosmologies (EH98 / no-wiggle; unused
+ * and may be NULL for CP_ENGINE_BBKS and CP_PK_PRIMORDIAL), owned by the caller and free again once the call's kernels have run on `stream`:
+ * nothing is allocated inside the call. */
+long long cp_power_workspace_bytes(long long ncosmo);
 int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                  long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, int device,
-                  void* stream);
+                  long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, void* d_work,
+                  int device, void* stream);
 enum cp_eh_scalar {
     CP_EH_RS_DRAG = 0 /* Mpc */, CP_EH_Z_DRAG = 1, CP_EH_Z_EQ = 2, CP_EH_K_EQ = 3, CP_EH_R_DRAG = 4, CP_EH_R_EQ = 5, CP_EH_K_SILK = 6,
     CP_EH_ALPHA_C = 7, CP_EH_BETA_C = 8, CP_EH_ALPHA_B = 9, CP_EH_BETA_NODE = 10, CP_EH_BETA_B = 11, CP_EH_ALPHA_GAMMA = 12,
@@ -226,6 +230,10 @@ typedef struct cp_spline_plan cp_spline_plan;
 int cp_spline_plan_create(cp_spline_plan** plan, int n, const double* x, int nq, const double* xq, int bc, int nu, int extrapolate, int device);
 /* d_out[row, q] = post_op(scale * sum_j W[q, j] d_y[row, j]);  d_y : (nrows, n), d_out : (nrows, nq), device, row-major */
 int cp_spline_apply(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nrows, int post_op, double scale, void* stream);
+/* the same followed by an outer product with per-row factors, written once: d_out (nrows, nq, nz) = f(scale x spline(d_y)[row, q] x d_g[row, z]),
+ * f = sqrt for CP_SPLINE_POST_SQRT.  sigma_rz of separable P(k, z) = P(k) x growth^2(z): PowerSpectrumInterpolator2D.sigma_rz, interpolator.py:846-875 */
+int cp_spline_apply_outer(const cp_spline_plan* plan, const double* d_y, const double* d_g, int nz, double* d_out, long long nrows, int post_op,
+                          double scale, void* stream);
 /* the same machinery for any fixed linear map of rows given densely (w_dense : nq x n row-major, host; a row starting with NaN
  * marks a query that evaluates to NaN): the composite-Simpson weights of integrate_sigma_r2 / integrate_sigma_d2 method 'simpson'
  * (interpolator.py:190-196, 280-284 with jax.py:365-507) are applied this way */
