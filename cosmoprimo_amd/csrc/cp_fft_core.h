@@ -111,30 +111,24 @@ __device__ __forceinline__ void lane_transpose2(double& lo, double& hi) {
     lo = __builtin_bit_cast(double, a);
     hi = __builtin_bit_cast(double, b);
 }
-// maxima of two unsigned values over the 64 lanes of a wave (results are wave-uniform): four DPP steps inside the rows of 16
-// lanes (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8), then one lane of each row
+// maxima of two unsigned values over the 64 lanes of a wave, valid in lane 63: four DPP steps inside the rows of 16 lanes (quad_perm
+// [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8: every lane of a row then holds the row maximum), then row_bcast:15 into rows 1 and 3 and
+// row_bcast:31 into rows 2 and 3 -- twelve v_max_u32_dpp, no lane reads and no scalar arithmetic
 __device__ __forceinline__ void wave_max2_u32(unsigned& a, unsigned& b) {
-#define CP_WAVE_MAX_STEP(CTRL)                                                                    \
-    {                                                                                             \
-        const unsigned pa = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, CTRL, 0xf, 0xf, true); \
-        const unsigned pb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true); \
-        a = a > pa ? a : pa;                                                                      \
-        b = b > pb ? b : pb;                                                                      \
+#define CP_WAVE_MAX_STEP(CTRL, ROWS)                                                                  \
+    {                                                                                                 \
+        const unsigned pa = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)a, CTRL, ROWS, 0xf, false); \
+        const unsigned pb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)b, CTRL, ROWS, 0xf, false); \
+        a = a > pa ? a : pa;                                                                          \
+        b = b > pb ? b : pb;                                                                          \
     }
-    CP_WAVE_MAX_STEP(0xB1)
-    CP_WAVE_MAX_STEP(0x4E)
-    CP_WAVE_MAX_STEP(0x124)
-    CP_WAVE_MAX_STEP(0x128)
+    CP_WAVE_MAX_STEP(0xB1, 0xf)
+    CP_WAVE_MAX_STEP(0x4E, 0xf)
+    CP_WAVE_MAX_STEP(0x124, 0xf)
+    CP_WAVE_MAX_STEP(0x128, 0xf)
+    CP_WAVE_MAX_STEP(0x142, 0xa)  // row_bcast:15 -> rows 1, 3
+    CP_WAVE_MAX_STEP(0x143, 0xc)  // row_bcast:31 -> rows 2, 3
 #undef CP_WAVE_MAX_STEP
-    unsigned ra = 0, rb = 0;
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        const unsigned xa = (unsigned)__builtin_amdgcn_readlane((int)a, 16 * row), xb = (unsigned)__builtin_amdgcn_readlane((int)b, 16 * row);
-        ra = ra > xa ? ra : xa;
-        rb = rb > xb ? rb : xb;
-    }
-    a = ra;
-    b = rb;
 }
 // the same for N = 2 or 3 (lo, hi) pairs in one block: VCC is set up once per block instead of once per pair (the kernel is
 // bound by instruction issue, scalar instructions included); an asm statement takes at most 30 operands, hence N <= 3

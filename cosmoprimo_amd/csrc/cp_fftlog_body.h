@@ -175,9 +175,12 @@ struct Fftlog {
         return f;
     }
     static CP_HD unsigned make_info(unsigned ma, unsigned mb) { return (ma >> 20) | ((mb >> 20) << 16); }
+    // The verdict is decoded once per pair: `gate` maps every info word that asks for nothing to 0, and the fix-ups test that word only.
+    static CP_HD unsigned gate(unsigned info) { return decode_info(info).any ? info : 0u; }
     template <int N>
-    static CP_HD void fix_input(const RowFix& f, cplx* x) {
-        if (!f.any) return;  // wave-uniform on the device
+    static CP_HD void fix_input(unsigned gated, cplx* x) {
+        if (gated == 0u) return;  // wave-uniform on the device
+        const RowFix f = decode_info(gated);
 #pragma unroll
         for (int r = 0; r < N; ++r) {
             if (f.nan_a) x[r].re = 0.;
@@ -187,8 +190,9 @@ struct Fftlog {
         }
     }
     template <int N>
-    static CP_HD void fix_output(const RowFix& f, double* ya, double* yb) {
-        if (!f.any) return;
+    static CP_HD void fix_output(unsigned gated, double* ya, double* yb) {
+        if (gated == 0u) return;
+        const RowFix f = decode_info(gated);
 #pragma unroll
         for (int s = 0; s < N; ++s) {
             if (f.nan_a) ya[s] = __builtin_nan("");
@@ -233,7 +237,8 @@ struct Fftlog {
 #else
         info = host_row_info(ra, rb, pre, A);
 #endif
-        fix_input<N>(decode_info(info), x);
+        info = gate(info);
+        fix_input<N>(info, x);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     // workgroup reduction of the per-thread maxima: wave maximum by DPP, one 8-byte LDS slot per wave, published by the next
@@ -241,7 +246,7 @@ struct Fftlog {
     static __device__ __forceinline__ void screen_publish(int t, cplx* lds, unsigned ma, unsigned mb) {
         if constexpr (T >= 64) {
             wave_max2_u32(ma, mb);
-            if ((t & 63) == 0) {
+            if ((t & 63) == 63) {      // the lane that holds the wave maxima
                 unsigned* scr = lds_scr(lds) + 2 * (t >> 6);
                 scr[0] = ma;
                 scr[1] = mb;
@@ -356,7 +361,7 @@ struct Fftlog {
         if constexpr (SCREEN) {
 #if defined(__HIP_DEVICE_COMPILE__)
             if constexpr (SCREEN_AHEAD) {
-                fix_input<H>(decode_info(st.info_cur), x + Q);
+                fix_input<H>(st.info_cur, x + Q);
                 return;
             }
 #endif
@@ -394,7 +399,7 @@ struct Fftlog {
             ya[s] = x[s + Q].re * st.fpost[s];
             yb[s] = x[s + Q].im * st.fpost[s];
         }
-        if constexpr (SCREEN) fix_output<H>(decode_info(st.info_cur), ya, yb);
+        if constexpr (SCREEN) fix_output<H>(st.info_cur, ya, yb);
         if (A.nker > 1) {
             CP_SCHED_FENCE();
             load_factors_half<!SCREEN_AHEAD_DEVICE>(t, A, nxt_ker, st);  // screen_prefetched has the next prefactors already
@@ -432,7 +437,7 @@ struct Fftlog {
 
     // last phase back end: natural-order outputs n = t + T s -> crop, x post, split Re/Im to the two rows
     static CP_HD void store_output(int t, const FftlogArgs& A, double* __restrict__ oa, double* __restrict__ ob, bool has_b,
-                                   const double* __restrict__ post, const RowFix& fix, const cplx* x) {
+                                   const double* __restrict__ post, unsigned fix, const cplx* x) {
         if constexpr (OUT_MODE == OUT_HALF) {
             static_assert(OUT_MODE != OUT_HALF, "OUT_HALF goes through store_output_half");
         } else {
@@ -579,11 +584,11 @@ struct Fftlog {
             load_u(t0, A, ker, st.w);
             mul_w(st.w, x);
             Pass<NP, P, 0>::butterflies(x);
-            store_output(t0, A, oa, ob, has_b, post, decode_info(st.info_cur), x);
+            store_output(t0, A, oa, ob, has_b, post, st.info_cur, x);
         } else if constexpr (PH == 0) {
             if constexpr (HALF_IN) {
 #if defined(__HIP_DEVICE_COMPILE__)
-                if constexpr (SCREEN_AHEAD) st.info_cur = st.info_nxt;  // found a pair ahead (screen_prefetched)
+                if constexpr (SCREEN_AHEAD) st.info_cur = gate(st.info_nxt);  // found a pair ahead (screen_prefetched); 0: nothing to fix
 #endif
                 load_input_half(t0, t, A, ra, rb, has_b, pre, lds, st, x);
                 // The NEXT pair's rows are requested right here, as soon as the prefetch registers are free: a whole pair
@@ -612,8 +617,12 @@ struct Fftlog {
             Pass<NP, P, I>::template butterflies_store<false, true>(t, st.w, lds, x);
             load_tables_for<PH + 1>(t, t0, A, ker, st.w);
         } else if constexpr (PH == LAST) {
-            if constexpr (PH == NPH - 2) screen_prefetched(t, t0, A, nxt_ker, lds, st);
             Pass<NP, P, LAST>::load_lds(t, lds, x);
+            if constexpr (PH == NPH - 2) {
+                CP_SCHED_FENCE();
+                screen_prefetched(t, t0, A, nxt_ker, lds, st);
+                CP_SCHED_FENCE();
+            }
             CP_FS(st, PH);
             Pass<NP, P, LAST>::butterflies(x);  // M == 1: no twiddles
             mul_w(st.w, x);                     // U, digit-reversed order, 1/NP folded in
@@ -622,9 +631,11 @@ struct Fftlog {
             load_tables_for<PH + 1>(t, t0, A, ker, st.w);
         } else if constexpr (PH < NPH - 1) {
             constexpr int I = (PH > LAST && PH < NPH - 1) ? (NPH - 1 - PH) : 0;
-            if constexpr (PH == NPH - 2) screen_prefetched(t, t0, A, nxt_ker, lds, st);
             Pass<NP, P, I>::twiddle_load_lds(t, lds_tw<I>(lds), st.w);
             Pass<NP, P, I>::load_lds(t, lds, x);
+            CP_SCHED_FENCE();
+            // the screening of the next pair's rows (register-only work) goes behind the LDS reads of this phase: it runs while they land
+            if constexpr (PH == NPH - 2) screen_prefetched(t, t0, A, nxt_ker, lds, st);
             CP_SCHED_FENCE();
             CP_FS(st, PH);
             Pass<NP, P, I>::twiddle_apply(st.w, x);
@@ -651,7 +662,7 @@ struct Fftlog {
             if constexpr (HALF_IN && OUT_MODE == OUT_HALF) {
                 store_output_half(t0, A, oa, ob, has_b, nxt_ker, st, x);
             } else {
-                store_output(t0, A, oa, ob, has_b, post, decode_info(st.info_cur), x);
+                store_output(t0, A, oa, ob, has_b, post, st.info_cur, x);
             }
         }
     }

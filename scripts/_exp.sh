@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2
-python bench.py --steps 20 --warmup 5 > gpurun_out/r2/bench_r2a.json 2> gpurun_out/r2/bench_r2a.err
-tail -2 gpurun_out/r2/bench_r2a.err
+( bash tools/mb_variants.sh "default:-DCP_X=0" "noscreen:-DCP_ROW_SCREEN=0" ) > gpurun_out/r2/exp11_mb.log 2>&1
+cat gpurun_out/r2/exp11_mb.log
+timeout 900 python -m pytest tests/test_fftlog_gpu.py -q -m gpu -p no:cacheprovider 2>&1 | tail -3

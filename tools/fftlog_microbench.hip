@@ -83,7 +83,8 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, 0, A);
+    // reach the sustained device state first: the first tens of milliseconds of load after an idle period run ~10 % slower (clock ramp)
+    for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, 0, A);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
     for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, 0, A);
