@@ -180,9 +180,10 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     def _operators(self):
         """Plans that depend on the grids only (built once per (k range, nk, device) and shared by all filter instances)."""
-        if getattr(self, '_ops', None) is not None:
-            return self._ops
         key = (float(self.pk_interpolator.extrap_kmin), float(self.pk_interpolator.extrap_kmax), self.k.size, self.device.index)
+        if getattr(self, '_ops', None) is not None and getattr(self, '_ops_key', None) == key:
+            return self._ops          # (a call with another interpolator may bring another k range: the reference takes it from the current one, :363)
+        self._ops_key = key
         if key in self._ops_cache:
             self._ops = self._ops_cache[key]
             return self._ops

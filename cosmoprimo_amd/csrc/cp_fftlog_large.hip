@@ -113,7 +113,9 @@ struct cp_fftlog_large {
     double* d_work;        // (chunk, npad)
     double2* d_cplx;       // (chunk, npad / 2 + 1)
     fft_handle d2z, z2d;
-    std::mutex lock;       // hipfftSetStream mutates the plan: one execute at a time
+    std::mutex lock;       // hipfftSetStream mutates the plan: one execute is ENQUEUED at a time ...
+    hipEvent_t done;       // ... and the scratch (d_work, d_cplx) is shared: an execute waits, on its own stream, for the event the previous
+    bool has_done;         // execute recorded behind its last kernel, so that executes of one plan on different streams cannot overlap on the device
 };
 
 int cp_fftlog_large_create(cp_fftlog_large** out, int n, int npad, int nker, const double* pre, const double* post, const double* u_re_im, int device) {
@@ -127,6 +129,8 @@ int cp_fftlog_large_create(cp_fftlog_large** out, int n, int npad, int nker, con
     p->d_pre = p->d_post = p->d_work = nullptr;
     p->d_u = p->d_cplx = nullptr;
     p->d2z = p->z2d = nullptr;
+    p->done = nullptr;
+    p->has_done = false;
     const int nh = npad / 2 + 1;
     long long chunk = (256LL << 20) / ((long long)npad * 24);   // ~256 MB of scratch
     if (chunk < 1) chunk = 1;
@@ -143,6 +147,11 @@ int cp_fftlog_large_create(cp_fftlog_large** out, int n, int npad, int nker, con
     if (!ok) {
         cp_fftlog_large_destroy(p);
         return cp::fail(CP_ENOMEM, "cp_fftlog_plan_create: cannot allocate the tables / scratch of the large-size path on device %d", device);
+    }
+    if (hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) {
+        p->done = nullptr;
+        cp_fftlog_large_destroy(p);
+        return cp::fail(CP_EDEVICE, "cp_fftlog_plan_create: cannot create the stream-ordering event of the large-size path");
     }
     if (api->plan1d(&p->d2z, npad, FFT_D2Z, (int)chunk) != FFT_SUCCESS || api->plan1d(&p->z2d, npad, FFT_Z2D, (int)chunk) != FFT_SUCCESS) {
         cp_fftlog_large_destroy(p);
@@ -162,6 +171,7 @@ void cp_fftlog_large_destroy(cp_fftlog_large* p) {
     if (p->d_u) (void)hipFree(p->d_u);
     if (p->d_work) (void)hipFree(p->d_work);
     if (p->d_cplx) (void)hipFree(p->d_cplx);
+    if (p->done) (void)hipEventDestroy(p->done);
     delete p;
 }
 
@@ -176,6 +186,8 @@ int cp_fftlog_large_execute(cp_fftlog_large* p, const double* d_in, double* d_ou
     std::lock_guard<std::mutex> guard(p->lock);
     if (api->set_stream(p->d2z, st) != FFT_SUCCESS || api->set_stream(p->z2d, st) != FFT_SUCCESS)
         return cp::fail(CP_EDEVICE, "cp_fftlog_execute: hipfftSetStream failed");
+    if (p->has_done && hipStreamWaitEvent(st, p->done, 0) != hipSuccess)   // the previous execute (any stream) is done with the scratch
+        return cp::fail(CP_EDEVICE, "cp_fftlog_execute: hipStreamWaitEvent failed");
     for (long long r0 = 0; r0 < nrows_total; r0 += p->chunk) {
         const long long nrows = nrows_total - r0 < p->chunk ? nrows_total - r0 : p->chunk;
         PadArgs A;
@@ -193,5 +205,7 @@ int cp_fftlog_large_execute(cp_fftlog_large* p, const double* d_in, double* d_ou
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_execute: launch failed: %s", hipGetErrorString(e));
+    if (hipEventRecord(p->done, st) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_execute: hipEventRecord failed");
+    p->has_done = true;
     return CP_OK;
 }

@@ -343,8 +343,15 @@ class Interpolator1D(dv.Copyable):
         if self.interp_fun == 'log':
             fun = dv.torch().log10(fun)
         self._rows = fun.T.contiguous()   # (ncol, n): one spline per row
-        # any NaN in a column (e.g. log of a negative P) makes that whole column NaN, without raising (reference jax.py:161-172)
-        self._nan_rows = dv.torch().isnan(self._rows).any(dim=1)
+        # NaN rule of the reference (jax.py:161-172): columns that are NaN throughout are set aside and stay NaN; if any OTHER column holds a
+        # NaN (e.g. the log of a negative P at a few knots) no spline is built at all and every column evaluates to NaN, without raising.
+        # +-Inf knots (the log of P = 0) make scipy's CubicSpline raise in the reference; here such a column evaluates to NaN.
+        torch = dv.torch()
+        nan = torch.isnan(self._rows)
+        all_nan, some_nan = nan.all(dim=1), nan.any(dim=1)
+        self._nan_rows = some_nan | ~torch.isfinite(self._rows).all(dim=1)
+        if self.k == 3 and bool((some_nan & ~all_nan).any()):
+            self._nan_rows = torch.ones_like(self._nan_rows)
 
     # With few splines (<= 64 columns) every evaluation goes point by point (cp_spline_points): no (queries x knots) operator to build on the
     # host for each new set of queries -- what a likelihood calling with its own redshifts pays at every step.  Many columns on shared queries

@@ -226,6 +226,11 @@ def invalid_tables(pkg):
     out['1d'] = outcome(lambda: np.isnan(pkg.PowerSpectrumInterpolator1D(k, pk)(k)))
     z = np.linspace(0., 2., 4)
     out['2d'] = outcome(lambda: np.isnan(pkg.PowerSpectrumInterpolator2D(k, z, np.repeat(pk[:, None], z.size, axis=1))(k, z=1.)))
+    # columns of one 1-D interpolator: a column that is NaN throughout stays on its own, a column with a few bad knots takes every column with it
+    good = k**-1.5
+    all_bad = np.full_like(good, np.nan)
+    out['1d.columns.one_all_nan'] = outcome(lambda: np.isnan(pkg.PowerSpectrumInterpolator1D(k, np.stack([good, all_bad, 2. * good], axis=-1))(k[::20])))
+    out['1d.columns.one_partly_bad'] = outcome(lambda: np.isnan(pkg.PowerSpectrumInterpolator1D(k, np.stack([good, pk, 2. * good], axis=-1))(k[::20])))
     return out
 
 

@@ -80,6 +80,59 @@ def test_config4_filters_full_chunk():
     assert np.median(dev) < 0.02 and dev.max() < 0.2
 
 
+def test_config4_one_gpu_share():
+    """Config 4 at the size one of 8 GPUs gets: 125 000 EH98 P(k) vectors through wallish2018 and brieden2022, chunk by chunk as bench.py
+    runs them (results kept on the device), sampled vectors of every chunk boundary against the oracle, every vector finite and positive."""
+    import torch
+    import cosmoprimo_amd as cp
+    import bench
+    import test_oracle_bao as tob
+    from oracle import bao as obao
+    warnings.simplefilter('ignore')
+    dev = torch.device('cuda', 0)
+    n, chunk = 125000, 16384
+    par = bench.eh_parameters(n, 2, torch, dev)
+    host = {name: v.cpu().numpy() for name, v in par.items()}
+    fid = cp.Cosmology(engine='eisenstein_hu')
+    rows, rsig = {}, []
+    for engine in ('wallish2018', 'brieden2022'):
+        flt, parts = None, []
+        for start in range(0, n, chunk):
+            sl = slice(start, min(n, start + chunk))
+            cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{name: v[sl] for name, v in par.items()})
+            interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+            kw = dict(cosmo=cosmo, cosmo_fid=fid) if engine == 'brieden2022' else {}
+            if flt is None:
+                flt = cp.PowerSpectrumBAOFilter(interp, engine=engine, **kw)
+            else:
+                flt(interp, cosmo=cosmo if kw else None)
+            parts.append(flt._pknow_rows.reshape(sl.stop - sl.start, -1).clone())
+            if engine == 'wallish2018':
+                rsig.append(cp.interpolator._host(cosmo._engine._rsigma8))
+        rows[engine] = torch.cat(parts)
+        assert rows[engine].shape == (n, 1024) and bool(torch.isfinite(rows[engine]).all()) and bool((rows[engine] > 0.).all())
+    # sampled vectors: first / last of the batch and both sides of chunk boundaries
+    pk_fid, rs_fid = tob.eh_pk({})
+    pknow_fid, _ = tob.eh_pk({}, 'eisenstein_hu_nowiggle')
+    prep = obao.brieden2022_prepare(pk_fid, pknow_fid)
+    prep['peaks'] = [np.asarray(ix) for ix in flt.ik_fid_peaks]      # the package's knot lists (= the reference's, tests/test_bao_gpu.py)
+    prep['ratio_now_fid'] = obao._interp_envelopes(*prep['peaks'], prep['k_fid'], prep['ratio_fid'])
+    rsig = np.concatenate(rsig)
+    from oracle import power as op
+    for i in (0, chunk - 1, chunk, 5 * chunk + 17, n - 1):
+        p = {name: float(v[i]) for name, v in host.items()}
+        _, rs = tob.eh_pk(p)                                         # rs_drag of the cosmology
+
+        def pk(k, p=p, i=i):      # the filters work on the growth-less P(k) of a 2-D interpolator (reference bao_filter.py:363, 493: ignore_growth=True)
+            return op.pk_z0(k, 'eisenstein_hu', h=p['h'], Omega_cdm=p['Omega_m'] - p['Omega_b'], Omega_b=p['Omega_b'], n_s=p['n_s'], rsigma8=float(rsig[i]))
+
+        ref = obao.wallish2018(lambda k: pk(k)[:, None])[:, 0]
+        np.testing.assert_allclose(rows['wallish2018'][i].cpu().numpy(), ref, rtol=1e-8, err_msg='wallish2018 %d' % i)
+        pknow_c, _ = tob.eh_pk(p, 'eisenstein_hu_nowiggle')
+        ref = obao.brieden2022_compute(prep, lambda k: pk(k)[:, None], pknow_c, rs / rs_fid, lambda kk, pp, ke: tob.pad_log_natural_eval(kk, pp[:, 0], ke))[:, 0]
+        np.testing.assert_allclose(rows['brieden2022'][i].cpu().numpy(), ref, rtol=1e-8, err_msg='brieden2022 %d' % i)
+
+
 def test_config5_distances_full_size():
     import torch
     from cosmoprimo_amd import background
