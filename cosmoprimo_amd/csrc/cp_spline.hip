@@ -184,6 +184,94 @@ hipError_t launch_outer(const OuterArgs& O, size_t lds, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---- dense operators on the matrix cores -------------------------------------------------------------------------------------------
+// out (nrows, nq) = Y (nrows, n) W^T for an operator W (nq, n) that is genuinely dense (quadrature weights, least-squares projectors, products
+// of spline operators: cp_linop_plan_create): a GEMM in float64, v_mfma_f64_16x16x4_f64.  Lane l of a wave supplies A[l & 15][k = l >> 4] =
+// Y[row][k] and B[k = l >> 4][l & 15] = W[q][k]; both matrices are row-major with k contiguous, so a lane loads FOUR consecutive k of its row
+// (32 bytes) and spends them on four MFMAs -- lane group g = l >> 4 then carries k = kb + 4 g + m in step m for A and for B alike.  The
+// results sit at D[row = (l >> 4) + 4 reg][col = l & 15] (cdna_hip_programming.md, fragment layout of the f64 form).
+// Wave tile 32 rows x 64 queries (2 x 4 accumulator tiles, 64 VGPRs); the four waves of a workgroup sit side by side in q on the same rows.
+// No LDS: W is small and lives in L2, a Y row segment is re-read by the four waves from L1 and nq / 256 times from L2 / HBM.
+typedef double cp_v4d __attribute__((ext_vector_type(4)));
+
+struct DenseArgs {
+    const double* y;
+    double* out;
+    long long nrows;
+    int n, nq, n_pad, nq_pad;
+    const double* w;   // (nq_pad, n_pad), zero padded
+    const int* j0;     // (nq): < 0 marks a query that evaluates to NaN
+    int post_op;
+    double scale;
+};
+
+__global__ __launch_bounds__(256) void linop_mfma_kernel(const DenseArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long long nrt = (A.nrows + 31) / 32;
+    const int nqt = (A.nq_pad + 255) / 256;
+    for (long long item = blockIdx.x; item < nrt * nqt; item += gridDim.x) {
+        const long long row0 = (item / nqt) * 32;   // consecutive items share their rows: Y comes from L2 for all but the first
+        const int q0 = (int)(item % nqt) * 256 + wave * 64;
+        if (q0 >= A.nq_pad) continue;
+        cp_v4d acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = cp_v4d{0., 0., 0., 0.};
+        const double* yr[2];
+        const double* wr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long long row = row0 + 16 * i + l15;
+            row = row < A.nrows ? row : A.nrows - 1;   // rows past the end repeat the last one (never stored)
+            yr[i] = A.y + row * A.n;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[j] = A.w + (long long)(q0 + 16 * j + l15) * A.n_pad;
+        for (int kb = 0; kb < A.n_pad; kb += 16) {
+            const int k = kb + 4 * g;
+            double a[2][4];
+            cp_v4d b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const cp_v4d*>(wr[j] + k);
+            if (kb + 16 <= A.n) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[i][m] = yr[i][k + m];
+            } else {   // last, partial chunk: W is zero there, but Y must not bring in the next row's values (0 x NaN)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[i][m] = k + m < A.n ? yr[i][k + m] : 0.;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + 16 * j + l15;
+            if (q >= A.nq) continue;
+            const bool nanq = A.j0[q] < 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long row = row0 + 16 * i + g + 4 * r;
+                    if (row >= A.nrows) continue;
+                    double v = nanq ? __builtin_nan("") : acc[i][j][r] * A.scale;
+                    if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                    A.out[row * A.nq + q] = v;
+                }
+        }
+    }
+}
+
 template <int R>
 hipError_t launch_apply(const Args& A, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024)
@@ -269,6 +357,8 @@ struct cp_spline_plan {
     int* d_j0;
     int* d_tile;
     int ntiles, span_max;
+    double* d_wdense;    // operators that are dense (band wider than half the knots): (nq_pad, n_pad) row-major, zero padded, for the MFMA kernel
+    int n_pad, nq_pad;
 };
 
 extern "C" int cp_spline_plan_destroy(cp_spline_plan* p) {
@@ -279,6 +369,7 @@ extern "C" int cp_spline_plan_destroy(cp_spline_plan* p) {
     if (p->d_wb) (void)hipFree(p->d_wb);
     if (p->d_j0) (void)hipFree(p->d_j0);
     if (p->d_tile) (void)hipFree(p->d_tile);
+    if (p->d_wdense) (void)hipFree(p->d_wdense);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     delete p;
     return CP_OK;
@@ -409,6 +500,17 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     if (!p) return cp::fail(CP_ENOMEM, "cp_spline_plan_create: host allocation failed");
     p->n = n; p->nq = nq; p->bw = bw; p->device = device; p->d_wb = nullptr; p->d_j0 = nullptr; p->d_tile = nullptr;
     p->ntiles = ntiles; p->span_max = span_max;
+    p->d_wdense = nullptr;
+    p->n_pad = (n + 15) / 16 * 16;
+    p->nq_pad = (nq + 63) / 64 * 64;
+    const bool dense = 2 * bw > n && n >= 16 && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
+    std::vector<double> wd;
+    if (dense) {
+        wd.assign((size_t)p->n_pad * p->nq_pad, 0.);
+        for (int q = 0; q < nq; ++q)
+            if (j0[q] >= 0)
+                for (int j = 0; j < n; ++j) wd[(size_t)q * p->n_pad + j] = w[(size_t)q * n + j];
+    }
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     int status = CP_OK;
@@ -420,6 +522,10 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
                             hipMemcpy(p->d_j0, j0.data(), nq * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(p->d_tile, tile.data(), tile.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
         status = cp::fail(CP_EDEVICE, "cp_spline_plan_create: upload failed");
+    if (status == CP_OK && dense &&
+        (hipMalloc(&p->d_wdense, wd.size() * sizeof(double)) != hipSuccess ||
+         hipMemcpy(p->d_wdense, wd.data(), wd.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess))
+        status = cp::fail(CP_ENOMEM, "cp_spline_plan_create: cannot upload the dense operator");
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (status != CP_OK) {
         cp_spline_plan_destroy(p);
@@ -460,7 +566,25 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     if (nrows < 0) return cp::fail(CP_EINVAL, "cp_spline_apply: negative row count");
     if (nrows == 0) return CP_OK;
     if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_spline_apply: null device pointer");
+    const int path = post_op & (CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
+    post_op &= ~(CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
+    if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the operator is banded, it has no matrix-core path");
+    if (p->d_wdense && path != CP_SPLINE_PATH_VALU && (nrows >= 16 || path == CP_SPLINE_PATH_MFMA)) {   // dense operator: GEMM on the matrix cores
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: cannot select device %d", p->device);
+        DenseArgs D;
+        D.y = d_y; D.out = d_out; D.nrows = nrows; D.n = p->n; D.nq = p->nq; D.n_pad = p->n_pad; D.nq_pad = p->nq_pad; D.w = p->d_wdense; D.j0 = p->d_j0;
+        D.post_op = post_op; D.scale = scale;
+        const long long items = ((nrows + 31) / 32) * ((p->nq_pad + 255) / 256);
+        const int grid = (int)(items < 256 * 4 ? items : 256 * 4);
+        hipLaunchKernelGGL(linop_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), D);
+        const hipError_t e = hipGetLastError();
+        if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+        if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: launch failed: %s", hipGetErrorString(e));
+        return CP_OK;
+    }
     // rows per work item: as many as keep the staged knots within 64 KB of LDS (two workgroups per CU), and no more than there are rows
     int rows = 16;
     while (rows > 4 && ((size_t)rows * p->span_max * sizeof(double) > 64 * 1024 || rows / 2 >= nrows)) rows /= 2;

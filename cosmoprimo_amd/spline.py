@@ -43,8 +43,11 @@ class LinearOperator(object):
         _lib.check(_lib.load().cp_spline_plan_info(self._handle, None, None, ctypes.byref(bw)))
         return bw.value
 
-    def __call__(self, y, sqrt=False, scale=1.):
-        """y : torch tensor (..., n) on the operator's device -> (..., nq)."""
+    _PATHS = {None: 0, 'valu': 16, 'mfma': 32}     # CP_SPLINE_PATH_*: force one kernel (measurements); default: the library's choice
+
+    def __call__(self, y, sqrt=False, scale=1., path=None):
+        """y : torch tensor (..., n) on the operator's device -> (..., nq).  Dense operators run as a float64 GEMM on the matrix cores,
+        banded ones (splines) on the vector ALUs; ``path`` = 'valu' / 'mfma' forces one of the two kernels."""
         torch = dv.torch()
         y = dv.to_device(y, self.device)
         if y.shape[-1] != self.n:
@@ -53,7 +56,7 @@ class LinearOperator(object):
         nrows = int(np.prod(lead, dtype=np.int64))
         out = torch.empty(lead + (self.nq,), dtype=torch.float64, device=self.device)
         if nrows:
-            _lib.check(_lib.load().cp_spline_apply(self._handle, y.data_ptr(), out.data_ptr(), nrows, int(bool(sqrt)), float(scale),
+            _lib.check(_lib.load().cp_spline_apply(self._handle, y.data_ptr(), out.data_ptr(), nrows, int(bool(sqrt)) | self._PATHS[path], float(scale),
                                                    dv.stream_of(self.device)))
         return out
 

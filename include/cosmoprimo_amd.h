@@ -223,7 +223,12 @@ int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_ome
  *      Interpolator1D jax.py:169-175 as used by integrate_sigma_r2, interpolator.py:285-289; Interpolator2D jax.py:241-271;
  *      the clamped second-derivative splines of wallish2018, bao_filter.py:377-382) ---- */
 enum cp_spline_bc { CP_SPLINE_NATURAL = 0 /* y'' = 0 */, CP_SPLINE_CLAMPED = 1 /* y' = 0 */, CP_SPLINE_NOT_A_KNOT = 2 /* scipy default, == FITPACK s=0 */ };
-enum cp_spline_post { CP_SPLINE_POST_NONE = 0, CP_SPLINE_POST_SQRT = 1 };
+enum cp_spline_post {
+    CP_SPLINE_POST_NONE = 0, CP_SPLINE_POST_SQRT = 1,
+    /* OR-ed into post_op of cp_spline_apply, for measurements: force the banded vector-ALU kernel / the dense matrix-core (MFMA f64) kernel; by
+     * default operators whose band is wider than half the knots (cp_linop_plan_create: quadrature weights, projectors) take the matrix cores */
+    CP_SPLINE_PATH_VALU = 16, CP_SPLINE_PATH_MFMA = 32
+};
 typedef struct cp_spline_plan cp_spline_plan;
 /* x : n strictly increasing knots (host), xq : nq query points (host), nu : derivative order 0..2;
  * extrapolate = 0: queries outside [x[0], x[n-1]] give NaN (Interpolator1D, jax.py:200). */

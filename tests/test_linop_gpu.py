@@ -1,0 +1,70 @@
+"""Dense linear operators (``cp_linop_plan_create`` + ``cp_spline_apply``): the float64 matrix-core kernel (v_mfma_f64_16x16x4_f64) against the
+vector-ALU kernel and against numpy, for shapes that exercise every edge of the 32 x 256 tiling; the fused outer-product epilogue of the spline
+operator (``cp_spline_apply_outer``) against its two-step form."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('n,nq,nrows', [(16, 1, 1), (17, 64, 16), (100, 65, 33), (341, 341, 1000), (1024, 256, 4097), (1000, 1030, 64)])
+def test_dense_operator_paths(n, nq, nrows):
+    import torch
+    from cosmoprimo_amd.spline import LinearOperator
+    rng = np.random.default_rng(n + nq)
+    w = rng.normal(size=(nq, n)) / np.sqrt(n)
+    if nq > 3:
+        w[3] = np.nan                     # a query marked as outside: NaN out
+    y = rng.normal(size=(nrows, n))
+    op = LinearOperator.dense(w)
+    ty = torch.as_tensor(y, device=op.device)
+    ref = y.dot(w.T)
+    scale = np.abs(y).max() * np.nanmax(np.abs(w)) * n
+    for path in ('valu', 'mfma', None):
+        got = op(ty, path=path).cpu().numpy()
+        assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref)), path
+        assert np.nanmax(np.abs(got - ref)) < 1e-14 * scale, (path, np.nanmax(np.abs(got - ref)) / scale)
+    both = op(ty.abs(), sqrt=True, scale=2., path='mfma').cpu().numpy()
+    ref2 = np.sqrt(2. * np.abs(y).dot(w.T))
+    keep = np.isfinite(ref2) & np.isfinite(both)       # (sums that cancel to ~0 may fall on either side of it)
+    np.testing.assert_allclose(both[keep]**2, ref2[keep]**2, rtol=0., atol=4e-14 * scale)
+    # a NaN row of Y stays in its row
+    y2 = y.copy()
+    y2[nrows // 2, n - 1] = np.nan
+    got = op(torch.as_tensor(y2, device=op.device), path='mfma').cpu().numpy()
+    cols = [c for c in range(nq) if c != 3]
+    bad = np.isnan(got[:, cols]).any(axis=1)
+    assert bad[nrows // 2] and bad.sum() == 1
+
+
+def test_banded_operator_has_no_matrix_path():
+    import torch
+    from cosmoprimo_amd.spline import LinearOperator
+    x = np.linspace(0., 1., 512)
+    op = LinearOperator.spline(x, np.linspace(0.01, 0.99, 300), bc='natural')
+    y = torch.as_tensor(np.sin(7 * x)[None, :], device=op.device)
+    assert op.bandwidth < 128
+    np.testing.assert_allclose(op(y).cpu().numpy()[0], np.sin(7 * np.linspace(0.01, 0.99, 300)), atol=1e-6)
+    with pytest.raises(ValueError):
+        op(y, path='mfma')
+
+
+def test_outer_epilogue():
+    import torch
+    from cosmoprimo_amd.spline import LinearOperator
+    rng = np.random.default_rng(3)
+    x = np.geomspace(1e-2, 1e2, 1024)
+    xq = np.geomspace(0.1, 50., 256)
+    op = LinearOperator.spline(np.log(x), np.log(xq), bc='natural')
+    for nrows, nz in [(1, 1), (5, 64), (37, 7), (200, 30)]:
+        y = torch.as_tensor(rng.uniform(0.5, 2., size=(nrows, 1024)) * x**-0.7, device=op.device)
+        g = torch.as_tensor(rng.uniform(0.1, 1., size=(nrows, nz)), device=op.device)
+        two_steps = (op(y)[:, :, None] * g[:, None, :]).sqrt()
+        fused = op.outer(y, g, sqrt=True)
+        assert fused.shape == (nrows, 256, nz)
+        assert torch.equal(fused, two_steps) or float(((fused - two_steps) / two_steps).abs().max()) < 4e-16
+        plain = op.outer(y, g, scale=3.)
+        np.testing.assert_allclose(plain.cpu().numpy(), (3. * op(y)[:, :, None] * g[:, None, :]).cpu().numpy(), rtol=1e-15)
+    outside = LinearOperator.spline(np.log(x), np.log(np.array([1e-3, 1., 1e3])), bc='natural')
+    res = outside.outer(y[:2], g[:2])
+    assert bool(torch.isnan(res[:, 0]).all()) and bool(torch.isnan(res[:, 2]).all()) and bool(torch.isfinite(res[:, 1]).all())
