@@ -359,6 +359,7 @@ struct cp_spline_plan {
     int ntiles, span_max;
     double* d_wdense;    // operators that are dense (band wider than half the knots): (nq_pad, n_pad) row-major, zero padded, for the MFMA kernel
     int n_pad, nq_pad;
+    bool prefer_dense;
 };
 
 extern "C" int cp_spline_plan_destroy(cp_spline_plan* p) {
@@ -446,7 +447,7 @@ extern "C" int cp_spline_operator(int n, const double* x, int nq, const double* 
 }
 
 // plan from a dense (nq x n) operator; rows whose first entry is NaN mark queries that evaluate to NaN
-static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w, int device) {
+static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w, int device, bool keep_dense) {
     std::vector<int> j0(nq), j1(nq);
     int bw = 1;
     for (int q = 0; q < nq; ++q) {
@@ -503,7 +504,10 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     p->d_wdense = nullptr;
     p->n_pad = (n + 15) / 16 * 16;
     p->nq_pad = (nq + 63) / 64 * 64;
-    const bool dense = 2 * bw > n && n >= 16 && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
+    // the dense copy is kept for operators given as dense matrices (cp_linop_plan_create); the matrix cores are the default for them when
+    // the band is wider than half the knots, and a measurement option otherwise (CP_SPLINE_PATH_MFMA)
+    const bool dense = keep_dense && n >= 16 && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
+    p->prefer_dense = dense && 2 * bw > n;
     std::vector<double> wd;
     if (dense) {
         wd.assign((size_t)p->n_pad * p->nq_pad, 0.);
@@ -543,14 +547,14 @@ extern "C" int cp_spline_plan_create(cp_spline_plan** out, int n, const double* 
     std::vector<double> w((size_t)nq * n);
     int st = cp_spline_operator(n, x, nq, xq, bc, nu, extrapolate, w.data(), nullptr);
     if (st != CP_OK) return st;
-    return plan_from_dense(out, n, nq, w.data(), device);
+    return plan_from_dense(out, n, nq, w.data(), device, false);
 }
 
 extern "C" int cp_linop_plan_create(cp_spline_plan** out, int n, int nq, const double* w_dense, int device) {
     if (!out) return cp::fail(CP_EINVAL, "cp_linop_plan_create: null plan pointer");
     *out = nullptr;
     if (n < 1 || nq < 1 || !w_dense) return cp::fail(CP_EINVAL, "cp_linop_plan_create: bad arguments");
-    return plan_from_dense(out, n, nq, w_dense, device);
+    return plan_from_dense(out, n, nq, w_dense, device, true);
 }
 
 extern "C" int cp_spline_plan_info(const cp_spline_plan* p, int* n, int* nq, int* bandwidth) {
@@ -570,7 +574,7 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     post_op &= ~(CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
     if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the operator is banded, it has no matrix-core path");
-    if (p->d_wdense && path != CP_SPLINE_PATH_VALU && (nrows >= 16 || path == CP_SPLINE_PATH_MFMA)) {   // dense operator: GEMM on the matrix cores
+    if (p->d_wdense && path != CP_SPLINE_PATH_VALU && ((p->prefer_dense && nrows >= 16) || path == CP_SPLINE_PATH_MFMA)) {   // dense operator: GEMM on the matrix cores
         int prev = -1;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: cannot select device %d", p->device);

@@ -437,19 +437,37 @@ class Interpolator2D(dv.Copyable):
         self.device = dv.resolve_device(device, fun)
         self.interp_x, self.interp_fun, self.extrap = str(interp_x), str(interp_fun), bool(extrap)
         x, y = _host(x).ravel(), _host(y).ravel()
-        fun = dv.to_device(fun, self.device)
+        fun = dv.to_device(fun, self.device)      # (nx, ny), or (batch..., nx, ny): one surface per batch entry on the shared (x, y) grid
         if not assume_sorted:
             ix, iy = np.argsort(x), np.argsort(y)
             x, y = x[ix], y[iy]
-            fun = fun[torch.as_tensor(ix, device=self.device)][:, torch.as_tensor(iy, device=self.device)]
+            fun = fun.index_select(-2, torch.as_tensor(ix, device=self.device)).index_select(-1, torch.as_tensor(iy, device=self.device))
         self.xmin, self.xmax, self.ymin, self.ymax = x[0], x[-1], y[0], y[-1]
         self._x = np.log10(x) if self.interp_x == 'log' else x
         self._y = y
         if self.interp_fun == 'log':
             fun = torch.log10(fun)
-        self._fun = fun.contiguous()    # (nx, ny)
+        self._fun = fun.contiguous()    # (batch..., nx, ny)
+        self._lead = tuple(self._fun.shape[:-2])
         # FITPACK propagates any NaN datum (e.g. the log of a negative P) to the whole surface (reference tests/test_interpolator.py:328-337)
-        self._has_nan = bool(torch.isnan(self._fun).any())
+        nan = torch.isnan(self._fun).flatten(-2).any(dim=-1)           # per surface
+        self._has_nan = bool(nan.all()) if self._lead else bool(nan)
+        self._nan_surfaces = nan if self._lead and bool(nan.any()) and not self._has_nan else None
+
+    def rows_y_major(self, xh, yh):
+        """The surfaces on the grid of flat host coordinates (xh, yh) as (batch..., ny, nx), x fastest -- the layout of rows of P(k) at every z --
+        evaluated y direction first: the y operator of a (k, z) table is dense (30 knots couple to every query: a GEMM on the matrix cores),
+        the x operator banded.  No mask, no back-transform of a log."""
+        with np.errstate(all='ignore'):
+            xq = np.log10(xh) if self.interp_x == 'log' else xh
+        opx = _cached_operator(('i2x', self._x.tobytes(), xq.tobytes(), self.device.index),
+                               lambda: LinearOperator.spline(self._x, xq, bc='not-a-knot', extrapolate=True, device=self.device))
+        opy = _cached_operator(('i2y', self._y.tobytes(), yh.tobytes(), self.device.index),
+                               lambda: LinearOperator.spline(self._y, yh, bc='not-a-knot', extrapolate=True, device=self.device))
+        out = opx(opy(self._fun).transpose(-1, -2).contiguous())       # (batch..., nx, nyq) -> (batch..., nyq, nx) -> (batch..., nyq, nxq)
+        if self._nan_surfaces is not None:
+            out = dv.torch().where(self._nan_surfaces[..., None, None], dv.torch().full_like(out, float('nan')), out)
+        return out
 
     def _call_many_x(self, x, y, bounds_error):
         """Grid evaluation at very many x (a mesh of wavenumbers) and a few y: the y direction first (operator, few queries), then one spline
@@ -465,6 +483,8 @@ class Interpolator2D(dv.Copyable):
         mask_x = (xq >= self.xmin) & (xq <= self.xmax)
         if bounds_error and not bool(mask_x.all()):
             raise ValueError('input outside of extrapolation range ({}, {})'.format(self.xmin, self.xmax))
+        if self._lead:
+            raise NotImplementedError('a mesh of x on a batch of surfaces: evaluate on a grid of at most 16 384 x')
         if self._has_nan:
             return _finish(torch.full((xq.numel(), yh.size), float('nan'), dtype=torch.float64, device=self.device), dtype, like_torch, shape)
         if self.interp_x == 'log':
@@ -497,11 +517,11 @@ class Interpolator2D(dv.Copyable):
         if grid and 0 < nyq <= 64 and (nxq > 16384 or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
             return self._call_many_x(x, y, bounds_error)
         xh, yh = _host(x), _host(y)
-        shape = xh.shape + yh.shape if grid else xh.shape
+        shape = self._lead + (xh.shape + yh.shape if grid else xh.shape)
         xh, yh = xh.ravel(), yh.ravel()
         mask_x, mask_y = _mask_bounds([xh, yh], [(self.xmin, self.xmax), (self.ymin, self.ymax)], bounds_error=bounds_error)
         if xh.size == 0 or yh.size == 0 or self._has_nan:
-            n = (xh.size, yh.size) if grid else (xh.size,)
+            n = self._lead + ((xh.size, yh.size) if grid else (xh.size,))
             return _finish(torch.full(n, float('nan'), dtype=torch.float64, device=self.device), dtype, like_torch, shape)
         with np.errstate(all='ignore'):
             xq = np.log10(xh) if self.interp_x == 'log' else xh
@@ -510,8 +530,8 @@ class Interpolator2D(dv.Copyable):
                                    lambda: LinearOperator.spline(self._x, xq, bc='not-a-knot', extrapolate=True, device=self.device))
             opy = _cached_operator(('i2y', self._y.tobytes(), yh.tobytes(), self.device.index),
                                    lambda: LinearOperator.spline(self._y, yh, bc='not-a-knot', extrapolate=True, device=self.device))
-            tmp = opx(self._fun.T.contiguous())     # rows = y knots: (ny, nxq)
-            out = opy(tmp.T.contiguous())           # rows = x queries: (nxq, nyq)
+            tmp = opx(self._fun.transpose(-1, -2).contiguous())     # rows = y knots: (batch..., ny, nxq)
+            out = opy(tmp.transpose(-1, -2).contiguous())           # rows = x queries: (batch..., nxq, nyq)
             mask = mask_x[:, None] & mask_y
         else:
             wx = torch.as_tensor(dense_operator(self._x, xq, bc='not-a-knot', extrapolate=True), device=self.device)   # (nq, nx)
@@ -520,8 +540,10 @@ class Interpolator2D(dv.Copyable):
             mask = mask_x & mask_y
         if self.interp_fun == 'log':
             out = 10**out
-        if not self.extrap:
+        if not self.extrap and not mask.all():
             out = torch.where(torch.as_tensor(mask, device=self.device), out, torch.full_like(out, float('nan')))
+        if self._nan_surfaces is not None:
+            out = torch.where(self._nan_surfaces.reshape(self._lead + (1,) * (out.ndim - len(self._lead))), torch.full_like(out, float('nan')), out)
         return _finish(out, dtype, like_torch, shape)
 
 
@@ -710,13 +732,16 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         self._rsigma8sq = 1.
         self.growth_factor_sq = growth_factor_sq
         self.device = dv.resolve_device(device, pk)
-        self._batch = None
-        if np.ndim(pk) > 2:
-            raise NotImplementedError('a tabulated PowerSpectrumInterpolator2D holds one (k, z) table: tables of a batch of cosmologies (pk of {:d} '
-                                      'dimensions) go in one at a time'.format(np.ndim(pk)))
-        k, pk = self._prepare(k, pk, z=z, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
+        self._tables_batched = len(pk.shape if hasattr(pk, 'shape') else np.shape(pk)) == 3
+        if self._tables_batched:
+            # (batch, nk, nz): one (k, z) table per cosmology on shared grids, kept on the device (extension of the reference's (nk, nz) table)
+            if growth_factor_sq is not None:
+                raise NotImplementedError('a batch of (k, z) tables and a growth factor')
+            k, pk = self._prepare_tables(k, z, pk, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
+        else:
+            k, pk = self._prepare(k, pk, z=z, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
         self.interp_order_k, self.interp_order_z = int(interp_order_k), int(interp_order_z)
-        is2d = self._pk.shape[1] > 1
+        is2d = self._is2d()
         if is2d:
             self._interp = Interpolator2D(k, self.z, pk, kx=self.interp_order_k, ky=self.interp_order_z, interp_x=self.interp_k, interp_fun=self.extrap_pk,
                                           assume_sorted=True, device=self.device)
@@ -729,12 +754,56 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
 
     default_params = _get_default_kwargs(__init__, start=4, remove=('device',))
 
+    def _is2d(self):
+        """A (k, z) table (or a batch of them), as opposed to one column of P(k) with a growth factor."""
+        return getattr(self, '_tables_batched', False) or self._pk.shape[1] > 1
+
+    def _prepare_tables(self, k, z, pk, interp_k='log', extrap_pk='log', extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax):
+        """``_prepare`` + ``_pad_log`` (reference interpolator.py:329-351, 42-87) for a batch of tables (batch, nk, nz), on the device: sorted grids,
+        and with log-log extrapolation two linearly extrapolated points of log10 P against log10 k on either side."""
+        torch = dv.torch()
+        self.k, self.z = _host(k).ravel(), _host(z).ravel()
+        pk = dv.to_device(pk, self.device)
+        if tuple(pk.shape[1:]) != (self.k.size, self.z.size):
+            raise ValueError('pk must be (batch, {:d}, {:d}), got {}'.format(self.k.size, self.z.size, tuple(pk.shape)))
+        ik, iz = np.argsort(self.k), np.argsort(self.z)
+        if np.any(ik[1:] < ik[:-1]) or np.any(iz[1:] < iz[:-1]):
+            pk = pk.index_select(1, torch.as_tensor(ik, device=self.device)).index_select(2, torch.as_tensor(iz, device=self.device))
+        self.k, self.z, self._pk = self.k[ik], self.z[iz], pk.contiguous()
+        self.interp_k, self.extrap_pk = str(interp_k), str(extrap_pk)
+        self.extrap_kmin, self.extrap_kmax = self.k[0], self.k[-1]
+        if self.extrap_pk != 'log':
+            return self.k, self._pk
+        if self.interp_k != 'log':
+            raise ValueError('log-log extrapolation requires log-x interpolation')
+        self.extrap_kmin, self.extrap_kmax = extrap_kmin, extrap_kmax
+        logk, logpk = np.log10(self.k), torch.log10(self._pk)            # negative P -> NaN for that table, without raising
+        lo, hi = np.log10(np.minimum(extrap_kmin, self.k[0] * (1 - 1e-9))), np.log10(np.maximum(extrap_kmax, self.k[-1] * (1 + 1e-9)))
+        knots_lo, knots_hi = np.array([lo, logk[0] * 0.1 + lo * 0.9]), np.array([logk[-1] * 0.1 + hi * 0.9, hi])
+        slope_lo = (logpk[:, 1] - logpk[:, 0]) / (logk[1] - logk[0])          # (batch, nz)
+        slope_hi = (logpk[:, -1] - logpk[:, -2]) / (logk[-1] - logk[-2])
+        pad_lo = torch.stack([logpk[:, 0] + slope_lo * float(kk - logk[0]) for kk in knots_lo], dim=1)
+        pad_hi = torch.stack([logpk[:, -1] + slope_hi * float(kk - logk[-1]) for kk in knots_hi], dim=1)
+        return 10**np.concatenate([knots_lo, logk, knots_hi]), 10**torch.cat([pad_lo, logpk, pad_hi], dim=1)
+
+    def _rescaled(self, out, nlead):
+        """``out`` (batch..., ...) times the sigma8 rescaling factor (a float, or one value per batch entry)."""
+        rs = self._rsigma8sq
+        if isinstance(rs, float) and rs == 1.:     # nothing to rescale: no pass over the result
+            return out
+        if np.ndim(rs) == 0 and not dv.is_torch(rs):
+            return out * float(rs)
+        rs = dv.to_device(rs, self.device)
+        return out * rs.reshape(tuple(rs.shape) + (1,) * (out.ndim - rs.ndim))
+
     @property
     def pk(self):
         """Power spectrum array (evaluated on (k, z) if built from a callable), without growth factor, with normalisation."""
         if self.is_from_callable:
             kwargs = {'ignore_growth': True} if self.growth_factor_sq is not None else {}
             return self(self.k, self.z, **kwargs)
+        if getattr(self, '_tables_batched', False):
+            return self._rescaled(self._pk, 1)
         return self._pk * self._rsigma8sq
 
     @property
@@ -788,7 +857,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                 tmp = dv.to_device(self._interp(kh, zh, grid=grid), self.device)
             out = tmp if bool(mask.all()) else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
         else:
-            is2d = self._pk.shape[1] > 1
+            is2d = self._is2d()
             mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
             if not is2d:
                 mask_z = mask_z | True    # ignore input z
@@ -806,6 +875,8 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             if self.growth_factor_sq is not None and not ignore_growth:
                 tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
             out = tmp if mask.all() else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+        if getattr(self, '_tables_batched', False):
+            return self._rescaled(out, 1)
         if isinstance(self._rsigma8sq, float) and self._rsigma8sq == 1.:     # (nothing to rescale: no pass over the result)
             return out
         return out * self._rsigma8sq
@@ -827,6 +898,20 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
     def _rows_z(self, zh, ignore_growth=False):
         """Callable k -> rows (batch..., nz, nk) of P(k, z) for the sigma integrals."""
         def rows(kh):
+            if not self.is_from_callable and self._is2d() and kh.size and zh.size:
+                # (k, z) tables: the surfaces come out of the two spline operators z-major already (z contraction first), no transposed copy
+                torch = dv.torch()
+                mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)])
+                out = self._interp.rows_y_major(kh, zh)
+                if self._interp.interp_fun == 'log':
+                    out = 10**out
+                mask = mask_z[:, None] & mask_k
+                if not mask.all():
+                    out = torch.where(torch.as_tensor(mask, device=self.device), out, torch.full_like(out, float('nan')))
+                if self.growth_factor_sq is not None and not ignore_growth:
+                    out = out * dv.to_device(self.growth_factor_sq(zh), self.device)[..., :, None]
+                return self._rescaled(out, out.ndim - 2) if getattr(self, '_tables_batched', False) else (
+                    out if isinstance(self._rsigma8sq, float) and self._rsigma8sq == 1. else out * self._rsigma8sq)
             return self._eval_device(kh, zh, grid=True, ignore_growth=ignore_growth).transpose(-1, -2).contiguous()
         return rows
 
@@ -834,7 +919,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         """P(k, z) = P(k) x growth_factor_sq(z) exactly: interpolators built from (callable or one tabulated column) + growth factor."""
         if self.growth_factor_sq is None:
             return False
-        return self.is_from_callable or self._pk.shape[1] == 1
+        return self.is_from_callable or not self._is2d()
 
     def _growth_sq_device(self, zh):
         """growth_factor_sq at flat host redshifts as a device tensor (batch..., nz), NaN outside the redshift range of a callable."""

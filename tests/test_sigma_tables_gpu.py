@@ -1,0 +1,79 @@
+"""Batches of tabulated P(k, z) (BASELINE config 3, variant B of SURVEY.md 8(d): one 500 x 30 table per cosmology): every entry of the batch
+must be what the single-table interpolator gives for that table -- whose numbers are pinned by the reference's (tests/golden/sigma.npz) --
+for evaluation on grids and at pairs, sigma_rz, sigma8_z, sigma_dz and the sigma8 rescaling; a table with a negative entry stays NaN alone."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def cp():
+    import torch
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    import cosmoprimo_amd
+    return cosmoprimo_amd
+
+
+def tables(g, nb, seed=0):
+    rng = np.random.default_rng(seed)
+    k, z, pk = g['table_k'], g['table_z'], g['table_pk']
+    amp, tilt, evol = rng.uniform(0.5, 2., nb), rng.uniform(-0.1, 0.1, nb), rng.uniform(-0.2, 0.2, nb)
+    amp[0], tilt[0], evol[0] = 1., 0., 0.                       # entry 0 is the golden table itself
+    batch = amp[:, None, None] * (k[None, :, None] / 0.05)**tilt[:, None, None] * (1. + z[None, None, :])**evol[:, None, None] * pk[None]
+    return k, z, batch
+
+
+def test_batch_of_tables_matches_single_tables(cp, golden):
+    import torch
+    g = golden('sigma')
+    k, z, batch = tables(g, 7)
+    r, zq = g['r'], g['z']
+    many = cp.PowerSpectrumInterpolator2D(k, z, torch.as_tensor(batch, device='cuda'))
+    out = many.sigma_rz(r, zq)
+    assert out.shape == (7, 256, 64)
+    np.testing.assert_allclose(out[0], g['table_sigma_rz'], rtol=1e-9)              # the reference's numbers for its table
+    kq, zz = g['table_eval_k'], np.linspace(0.1, 2.5, 16)
+    np.testing.assert_allclose(many(kq, zq[::4])[0], g['table_eval'], rtol=1e-10)               # ... and its values (64 k x 16 z)
+    pairs = many(kq[:16], zz, grid=False)
+    assert pairs.shape == (7, 16)
+    for i in range(7):
+        one = cp.PowerSpectrumInterpolator2D(k, z, batch[i])
+        np.testing.assert_allclose(out[i], one.sigma_rz(r, zq), rtol=1e-11)
+        np.testing.assert_allclose(many(kq, zz)[i], one(kq, zz), rtol=1e-12)
+        np.testing.assert_allclose(pairs[i], one(kq[:16], zz, grid=False), rtol=1e-12)
+        np.testing.assert_allclose(many.sigma8_z(zq[::9])[i], one.sigma8_z(zq[::9]), rtol=1e-11)
+        np.testing.assert_allclose(many.sigma_dz(zq[::9])[i], one.sigma_dz(zq[::9]), rtol=1e-11)
+    # outside the redshift range: NaN, and nowhere else
+    high = many.sigma_rz(r[:4], np.array([1., 3.5]))
+    assert np.isnan(high[..., 1]).all() and np.isfinite(high[..., 0]).all()
+    # grids given in any order
+    shuffled = cp.PowerSpectrumInterpolator2D(k[::-1], z[::-1], batch[:, ::-1, ::-1].copy())
+    np.testing.assert_allclose(shuffled(kq, zz), many(kq, zz), rtol=1e-14)
+    # one table with a negative entry: that cosmology is NaN, the others are what they were
+    bad = batch.copy()
+    bad[3, 100, 7] *= -1.
+    mixed = cp.PowerSpectrumInterpolator2D(k, z, bad)
+    res = mixed.sigma_rz(r[::16], zq[::8])
+    assert np.isnan(res[3]).all() and np.isfinite(np.delete(res, 3, axis=0)).all()
+    np.testing.assert_allclose(np.delete(res, 3, axis=0), np.delete(out[:, ::16, ::8], 3, axis=0), rtol=1e-12)
+    # sigma8 rescaling, one factor per table
+    many.rescale_sigma8(0.8)
+    np.testing.assert_allclose(many.sigma8_z(0.), 0.8, rtol=1e-10)
+    assert many.pk.shape == (7, 500, 30)
+
+
+def test_config3_variant_b_full_size(cp, golden):
+    """10 000 tables (500 k x 30 z) -> sigma_rz on 256 r x 64 z: finite, deterministic, falling with r and z, sampled entries against single tables."""
+    import torch
+    g = golden('sigma')
+    k, z, batch = tables(g, 10000, seed=1)
+    r, zq = torch.as_tensor(g['r'], device='cuda'), torch.as_tensor(g['z'], device='cuda')
+    many = cp.PowerSpectrumInterpolator2D(k, z, torch.as_tensor(batch, device='cuda'))
+    out = many.sigma_rz(r, zq)
+    assert tuple(out.shape) == (10000, 256, 64) and bool(torch.isfinite(out).all())
+    assert torch.equal(out, many.sigma_rz(r, zq))
+    assert bool((out[:, 1:] < out[:, :-1]).all())
+    for i in (0, 5000, 9999):
+        one = cp.PowerSpectrumInterpolator2D(k, z, batch[i])
+        np.testing.assert_allclose(out[i].cpu().numpy(), one.sigma_rz(g['r'], g['z']), rtol=1e-11)

@@ -35,5 +35,31 @@ def main():
         print(line)
 
 
+def spline_contraction():
+    """The k contraction of a (k, z) table (not-a-knot cubic spline from 504 log-k knots to the 1024 FFTLog wavenumbers, 64 redshifts x 10 000
+    cosmologies = 640 000 rows) as a banded operator on the vector ALUs and, forced dense, as a GEMM on the matrix cores."""
+    import torch
+    from cosmoprimo_amd.spline import LinearOperator, dense_operator
+    dev = torch.device('cuda', 0)
+    x, xq = np.linspace(-7., 2., 504), np.linspace(-7., 2., 1024)
+    banded = LinearOperator.spline(x, xq, bc='not-a-knot', device=dev)
+    dense = LinearOperator.dense(dense_operator(x, xq, bc='not-a-knot'), device=dev)
+    y = torch.as_tensor(np.random.default_rng(1).normal(size=(640000, 504)), device=dev)
+    line = '%-62s' % '(k, z) table, k contraction: 504 -> 1024, 640 000 rows'
+    for name, op, path in (('banded valu (bandwidth %d)' % banded.bandwidth, banded, None), ('dense mfma', dense, 'mfma')):
+        for _ in range(5):
+            out = op(y, path=path)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            out = op(y, path=path)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        line += '  %s %.3f ms' % (name, ms)
+    print(line)
+    print('   (difference of the two results: %.1e)' % float((banded(y[:1000]) - dense(y[:1000], path='mfma')).abs().max()))
+
+
 if __name__ == '__main__':
     main()
+    spline_contraction()
