@@ -574,7 +574,10 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     post_op &= ~(CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
     if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the operator is banded, it has no matrix-core path");
-    if (p->d_wdense && path != CP_SPLINE_PATH_VALU && ((p->prefer_dense && nrows >= 16) || path == CP_SPLINE_PATH_MFMA)) {   // dense operator: GEMM on the matrix cores
+    // the vector kernel stages the knots under a tile of queries in LDS, 4 rows at least: operators wider than that only have the dense route
+    const bool valu_fits = (size_t)4 * p->span_max * sizeof(double) <= 160 * 1024;
+    if (p->d_wdense && path != CP_SPLINE_PATH_VALU &&
+        ((p->prefer_dense && nrows >= 16) || path == CP_SPLINE_PATH_MFMA || !valu_fits)) {   // dense operator: GEMM on the matrix cores
         int prev = -1;
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: cannot select device %d", p->device);

@@ -171,12 +171,14 @@ def _with_growth(sigma2, growth_sq):
     return (sigma2[..., :, None] * growth_sq[..., None, :]).sqrt()
 
 
-def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None):
+def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None, epsabs=1e-5, epsrel=1e-5):
     r"""
     :math:`\sigma_r^2 = \frac{1}{2\pi^2}\int dk\,k^2 P(k) W^2(kr)` (reference interpolator.py:200-292) for rows of P(k).
 
     pk_rows : callable k (numpy, (nk,)) -> device tensor (..., nk): the power spectra sampled at k, k fastest.
-    method : 'fftlog' (default) or 'simpson'.  Returns a device tensor (..., nr) holding :math:`\sigma_r^2`.
+    method : 'fftlog' (default), 'simpson', 'leggauss' or 'quad'.  Returns a device tensor (..., nr) holding :math:`\sigma_r^2`.
+        'quad' meets ``epsabs`` / ``epsrel`` (the tolerances the reference hands to ``scipy.integrate.quad``, interpolator.py:255-273)
+        for every (row, r) by refining a composite Simpson rule in log k for the whole batch at once: see :func:`_refined_rule`.
     growth_sq : optional device tensor (..., nz), one row of factors per row of P(k): the result is then
         :math:`\sqrt{\sigma_r^2\,\mathrm{growth\_sq}(z)}` of shape (..., nr, nz), written once by the interpolation kernel.
     """
@@ -223,10 +225,44 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         op = _cached_operator(('leggauss_r', float(kmin), float(kmax), int(nl), rr.tobytes(), device.index),
                               lambda: LinearOperator.dense(1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * w)[None, :], device=device))
         return _with_growth(op(pk_rows(k)), growth_sq)
-    raise NotImplementedError('integrate_sigma_r2 method {} is not available on the GPU path (use "fftlog", "simpson" or "leggauss")'.format(method))
+    if method == 'quad':
+        limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
+
+        def rule(logk):
+            k = np.exp(logk)
+            return 1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * _simpson_weights(logk))[None, :]
+
+        return _with_growth(_refined_rule(rule, limits, pk_rows, epsabs / (2. * np.pi**2), epsrel, device, what='sigma_r2'), growth_sq)
+    raise NotImplementedError('integrate_sigma_r2 method {} is not available on the GPU path (use "fftlog", "simpson", "leggauss" or "quad")'.format(method))
 
 
-def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, device=None):
+def _refined_rule(rule, limits, pk_rows, epsabs, epsrel, device, what='integral', start=1025, stop=2**17 + 1):
+    """
+    ``method='quad'`` of the sigma integrals (reference interpolator.py:167-177, 255-273: one adaptive QUADPACK integration per
+    (r, column), sequential and data-dependent).  Here one composite Simpson rule in log k serves every row of the batch and is
+    refined globally: the number of intervals doubles until two successive estimates agree within ``max(epsabs, epsrel |I|)`` for
+    every (row, r) -- the error of the finer one is then about 1 / 15 of that, inside what ``quad`` promises.  One reduction and
+    one host synchronisation per level.
+
+    rule : logk (n,) -> (nout, n) weights of the rule (kernel and Jacobian included);  returns the device tensor (..., nout).
+    """
+    torch = dv.torch()
+    previous, n = None, start
+    while True:
+        logk = np.linspace(*limits, n)
+        current = LinearOperator.dense(rule(logk), device=device)(pk_rows(np.exp(logk)))
+        if previous is not None:
+            bound = torch.clamp(epsrel * current.abs(), min=epsabs)
+            if bool((((current - previous).abs() <= bound) | ~torch.isfinite(current)).all()):   # NaN / Inf entries cannot converge
+                return current
+        if n >= stop:
+            import warnings
+            warnings.warn('{}: requested accuracy not reached with {:d} Simpson nodes in log k'.format(what, n))
+            return current
+        previous, n = current, 2 * n - 1
+
+
+def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, device=None, epsabs=1e-5, epsrel=1e-5):
     r""":math:`\sigma_d^2 = \frac{1}{6\pi^2}\int dk\,P(k)` (reference interpolator.py:123-197, default 'simpson'); device tensor (...,)."""
     device = dv.resolve_device(device)
     limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
@@ -239,8 +275,14 @@ def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, 
         op = _cached_operator(('leggauss_d', float(kmin), float(kmax), int(nl), device.index),
                               lambda: LinearOperator.dense((1. / (6. * np.pi**2) * k * w)[None, :], device=device))
         return op(pk_rows(k))[..., 0]
+    if method == 'quad':   # interpolator.py:167-177
+
+        def rule(logk):
+            return (1. / (6. * np.pi**2) * np.exp(logk) * _simpson_weights(logk))[None, :]
+
+        return _refined_rule(rule, limits, pk_rows, epsabs / (6. * np.pi**2), epsrel, device, what='sigma_d2')[..., 0]
     if method != 'simpson':
-        raise NotImplementedError('integrate_sigma_d2 method {} is not available on the GPU path (use "simpson" or "leggauss")'.format(method))
+        raise NotImplementedError('integrate_sigma_d2 method {} is not available on the GPU path (use "simpson", "leggauss" or "quad")'.format(method))
     if nk is None:
         nk = 1024
     logk = np.linspace(*limits, nk)
@@ -296,6 +338,24 @@ def _quadratic_interp_operator(xk, xq, extrap=True):
     if not extrap:
         w[~((xq >= xk[0]) & (xq <= xk[-1]))] = np.nan
     return w
+
+
+def _fitpack_interp_operator(xk, xq, k):
+    """Dense (nq, n) operator of the interpolating spline of degree ``k`` (1...5) FITPACK builds with ``s=0`` (``RectBivariateSpline`` along
+    one axis, reference jax.py:241-242): interior knots at the data points for odd degrees, half-way between them for even ones (fpregr /
+    fpgrre); queries beyond the data are clamped to the end points, as ``bispev`` does."""
+    n = xk.size
+    if not 1 <= k <= 5:
+        raise ValueError('spline degrees 1 <= k <= 5 are supported')       # FITPACK's own limit
+    if n <= k:
+        raise ValueError('at least {:d} points are needed for degree {:d}'.format(k + 1, k))
+    if k % 2:
+        interior = xk[(k + 1) // 2:n - (k + 1) // 2]
+    else:
+        interior = ((xk[1:] + xk[:-1]) / 2.)[k // 2:n - 1 - k // 2]
+    t = np.concatenate([(xk[0],) * (k + 1), interior, (xk[-1],) * (k + 1)])
+    colloc = _bspline_basis(t, k, xk)
+    return np.linalg.solve(colloc.T, _bspline_basis(t, k, np.clip(xq, xk[0], xk[-1])).T).T
 
 
 def _natural_spline_slopes(x, y):
@@ -428,11 +488,14 @@ class Interpolator1D(dv.Copyable):
 
 class Interpolator2D(dv.Copyable):
 
-    """2D grid interpolation, == RectBivariateSpline(kx=ky=3, s=0): separable not-a-knot cubic splines (reference jax.py:213-287)."""
+    """2D grid interpolation, == RectBivariateSpline(kx, ky, s=0) (reference jax.py:213-287): separable interpolating splines, banded
+    not-a-knot cubic operators for degree 3 (the default), dense operators for the other degrees (1, 2, 4, 5)."""
 
     def __init__(self, x, y, fun, kx=3, ky=3, interp_x='lin', interp_fun='lin', extrap=False, assume_sorted=False, device=None):
-        if int(kx) != 3 or int(ky) != 3:
-            raise NotImplementedError('only bicubic (kx=ky=3) interpolation is implemented on the GPU path')
+        self.kx, self.ky = int(kx), int(ky)
+        for k in (self.kx, self.ky):
+            if not 1 <= k <= 5:
+                raise ValueError('spline degrees 1 <= kx, ky <= 5 are supported')       # as RectBivariateSpline
         torch = dv.torch()
         self.device = dv.resolve_device(device, fun)
         self.interp_x, self.interp_fun, self.extrap = str(interp_x), str(interp_fun), bool(extrap)
@@ -454,16 +517,27 @@ class Interpolator2D(dv.Copyable):
         self._has_nan = bool(nan.all()) if self._lead else bool(nan)
         self._nan_surfaces = nan if self._lead and bool(nan.any()) and not self._has_nan else None
 
+    def _operator(self, axis, q, dense=False):
+        """Operator from the knots of ``axis`` ('x': transformed coordinates, 'y') to the queries ``q`` (host, flat); queries outside the
+        knots are clamped to the end points (FITPACK's ``bispev``), which only shows with ``extrap=True``: the mask turns them NaN otherwise.
+        dense : return the (nq, n) weights on the host instead."""
+        knots, k = (self._x, self.kx) if axis == 'x' else (self._y, self.ky)
+        q = np.clip(q, knots[0], knots[-1])
+        if dense:
+            return dense_operator(knots, q, bc='not-a-knot', extrapolate=True) if k == 3 else _fitpack_interp_operator(knots, q, k)
+        if k == 3:
+            build = lambda: LinearOperator.spline(knots, q, bc='not-a-knot', extrapolate=True, device=self.device)
+        else:
+            build = lambda: LinearOperator.dense(_fitpack_interp_operator(knots, q, k), device=self.device)
+        return _cached_operator(('i2' + axis, k, knots.tobytes(), q.tobytes(), self.device.index), build)
+
     def rows_y_major(self, xh, yh):
         """The surfaces on the grid of flat host coordinates (xh, yh) as (batch..., ny, nx), x fastest -- the layout of rows of P(k) at every z --
         evaluated y direction first: the y operator of a (k, z) table is dense (30 knots couple to every query: a GEMM on the matrix cores),
         the x operator banded.  No mask, no back-transform of a log."""
         with np.errstate(all='ignore'):
             xq = np.log10(xh) if self.interp_x == 'log' else xh
-        opx = _cached_operator(('i2x', self._x.tobytes(), xq.tobytes(), self.device.index),
-                               lambda: LinearOperator.spline(self._x, xq, bc='not-a-knot', extrapolate=True, device=self.device))
-        opy = _cached_operator(('i2y', self._y.tobytes(), yh.tobytes(), self.device.index),
-                               lambda: LinearOperator.spline(self._y, yh, bc='not-a-knot', extrapolate=True, device=self.device))
+        opx, opy = self._operator('x', xq), self._operator('y', yh)
         out = opx(opy(self._fun).transpose(-1, -2).contiguous())       # (batch..., nx, nyq) -> (batch..., nyq, nx) -> (batch..., nyq, nxq)
         if self._nan_surfaces is not None:
             out = dv.torch().where(self._nan_surfaces[..., None, None], dv.torch().full_like(out, float('nan')), out)
@@ -489,8 +563,7 @@ class Interpolator2D(dv.Copyable):
             return _finish(torch.full((xq.numel(), yh.size), float('nan'), dtype=torch.float64, device=self.device), dtype, like_torch, shape)
         if self.interp_x == 'log':
             xq = torch.log10(xq)
-        opy = _cached_operator(('i2y', self._y.tobytes(), yh.tobytes(), self.device.index),
-                               lambda: LinearOperator.spline(self._y, yh, bc='not-a-knot', extrapolate=True, device=self.device))
+        opy = self._operator('y', yh)
         rows = opy(self._fun).T.contiguous()                      # (nyq, nx): the surface along x at every requested y
         slope_op = _cached_operator(('i2s', self._x.tobytes(), self.device.index),
                                     lambda: LinearOperator.spline(self._x, self._x, bc='not-a-knot', nu=1, extrapolate=True, device=self.device))
@@ -514,7 +587,7 @@ class Interpolator2D(dv.Copyable):
         like_torch = dv.is_torch(x) or dv.is_torch(y)
         dtype = dv.float_dtype(x, y)
         nxq, nyq = (v.numel() if dv.is_torch(v) else np.size(v) for v in (x, y))
-        if grid and 0 < nyq <= 64 and (nxq > 16384 or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
+        if grid and self.kx == 3 and not self.extrap and 0 < nyq <= 64 and (nxq > 16384 or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
             return self._call_many_x(x, y, bounds_error)
         xh, yh = _host(x), _host(y)
         shape = self._lead + (xh.shape + yh.shape if grid else xh.shape)
@@ -526,16 +599,13 @@ class Interpolator2D(dv.Copyable):
         with np.errstate(all='ignore'):
             xq = np.log10(xh) if self.interp_x == 'log' else xh
         if grid:
-            opx = _cached_operator(('i2x', self._x.tobytes(), xq.tobytes(), self.device.index),
-                                   lambda: LinearOperator.spline(self._x, xq, bc='not-a-knot', extrapolate=True, device=self.device))
-            opy = _cached_operator(('i2y', self._y.tobytes(), yh.tobytes(), self.device.index),
-                                   lambda: LinearOperator.spline(self._y, yh, bc='not-a-knot', extrapolate=True, device=self.device))
+            opx, opy = self._operator('x', xq), self._operator('y', yh)
             tmp = opx(self._fun.transpose(-1, -2).contiguous())     # rows = y knots: (batch..., ny, nxq)
             out = opy(tmp.transpose(-1, -2).contiguous())           # rows = x queries: (batch..., nxq, nyq)
             mask = mask_x[:, None] & mask_y
         else:
-            wx = torch.as_tensor(dense_operator(self._x, xq, bc='not-a-knot', extrapolate=True), device=self.device)   # (nq, nx)
-            wy = torch.as_tensor(dense_operator(self._y, yh, bc='not-a-knot', extrapolate=True), device=self.device)   # (nq, ny)
+            wx = torch.as_tensor(self._operator('x', xq, dense=True), device=self.device)   # (nq, nx)
+            wy = torch.as_tensor(self._operator('y', yh, dense=True), device=self.device)   # (nq, ny)
             out = ((wx @ self._fun) * wy).sum(dim=-1)
             mask = mask_x & mask_y
         if self.interp_fun == 'log':

@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, bao, xi, bao2, densities, ncdm, variants,
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, densities, ncdm, variants,
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -258,6 +258,35 @@ def gen_sigma(cp):
         out['table1d_sigma_r'] = tab1.sigma_r(r[::8])
         out['table1d_sigma8'] = tab1.sigma8()
     save('sigma', **out)
+
+
+def gen_sigma_quad(cp):
+    """The sigma integrals with method='quad' (scipy.integrate.quad per (r, column), interpolator.py:167-177, 255-273) on the G4 table."""
+    import warnings
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        interp = cp.Cosmology(engine='eisenstein_hu').get_fourier().pk_interpolator()
+        kt, zt = np.logspace(-4, 2, 500), np.linspace(0., 3., 30)
+        pkt = interp(kt, zt)
+        out['table_k'], out['table_z'], out['table_pk'] = kt, zt, pkt
+        out['r'], out['z'] = np.array([2., 8., 30.]), np.array([0., 1.45])
+        tab1 = cp.PowerSpectrumInterpolator1D(kt, pkt[:, 0])
+        out['sigma_r'] = tab1.sigma_r(out['r'], method='quad')
+        out['sigma_d'] = tab1.sigma_d(method='quad')
+        # the 2-D classes fail with method='quad' in the reference (interpolator.py:259 indexes p[:, i] on the 1-D pk(scalar k)):
+        # one 1-D interpolator per redshift stands for them
+        out['sigma_rz'] = np.stack([cp.PowerSpectrumInterpolator1D(kt, pkt[:, iz]).sigma_r(out['r'], method='quad') for iz in (0, 14)], axis=-1)
+        out['sigma_dz'] = np.array([cp.PowerSpectrumInterpolator1D(kt, pkt[:, iz]).sigma_d(method='quad') for iz in (0, 14)])
+        out['z'] = zt[[0, 14]]
+        out['sigma_r_tight'] = tab1.sigma_r(out['r'], method='quad', epsabs=1e-10, epsrel=1e-10)
+        # ... which stops at quad's default of 50 subintervals, 5e-6 short of the request; the same integrand with room to converge:
+        from scipy import integrate
+        from cosmoprimo.interpolator import kernel_tophat2
+        limits = (np.log(1e-7 * (1. + 1e-9)), np.log(1e2 * (1. - 1e-9)))
+        out['sigma_r_converged'] = np.array([(integrate.quad(lambda logk: kernel_tophat2(np.exp(logk) * rr) * np.exp(logk)**3 * tab1(np.exp(logk)), *limits,
+                                                             epsabs=1e-12, epsrel=1e-12, limit=4000)[0] / (2. * np.pi**2))**0.5 for rr in out['r']])
+    save('sigma_quad', **out)
 
 
 BAO_PARAMS = [dict(), dict(Omega_m=0.27, Omega_b=0.045, h=0.72, n_s=0.95), dict(Omega_m=0.36, Omega_b=0.055, h=0.64, n_s=0.98, sigma8=0.85),
@@ -643,6 +672,8 @@ def main():
         gen_power(cp)
     if 'sigma' in which:
         gen_sigma(cp)
+    if 'sigma_quad' in which:
+        gen_sigma_quad(cp)
     if 'bao' in which:
         gen_bao(cp)
     if 'xi' in which:

@@ -1,0 +1,126 @@
+// Sanitizer driver for the host side of the library (TEST HARNESS ONLY; built with
+//   g++ -fsanitize=address,undefined -fno-sanitize-recover=all
+// by tests/test_host_sanitizers.py).  It runs, on the CPU, the code of the product that is plain C++:
+//   * the special functions and the FFTLog table setup behind the C ABI (cp_special.cpp, cp_fftlog_setup.cpp),
+//   * the per-thread phases of the fused FFTLog kernel through the emulator (tests/host_emu/emu_fftlog.cpp): the kernel's LDS is a heap
+//     array of exactly the size the launch requests, its rows are heap arrays of exactly n samples, so an index of the kernel that leaves
+//     its LDS allocation or its rows is an AddressSanitizer report here (GPU sanitizers are not available on the pool).
+// Exit status 0 and a last line "ok" mean no report; numerical checks are the business of tests/test_fftlog_host.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <limits>
+#include <vector>
+
+#include "../../include/cosmoprimo_amd.h"
+
+extern "C" int emu_fftlog(int n, int np, int nker, const double* pre, const double* post, const double* u_re_im, const double* in,
+                          double* out, long long nbatch, int ext_l, double val_l, int ext_r, double val_r, int keep_padding);
+
+static int failures = 0;
+#define EXPECT(cond)                                                       \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            std::fprintf(stderr, "line %d: %s\n", __LINE__, #cond);        \
+            ++failures;                                                    \
+        }                                                                  \
+    } while (0)
+
+static void special_functions() {
+    std::vector<double> z, out;
+    for (double re = -6.5; re <= 30.; re += 0.73)
+        for (double im : {-250., -3.1, 0., 1e-9, 0.4, 17., 1e4}) { z.push_back(re); z.push_back(im); }
+    const long long n = (long long)z.size() / 2;
+    out.resize(z.size());
+    EXPECT(cp_loggamma(z.data(), out.data(), n) == CP_OK);
+    EXPECT(cp_gamma(z.data(), out.data(), n) == CP_OK);
+    for (int kind : {CP_KERNEL_BESSEL_J, CP_KERNEL_SPHERICAL_BESSEL_J, CP_KERNEL_TOPHAT, CP_KERNEL_TOPHAT_SQ, CP_KERNEL_GAUSSIAN, CP_KERNEL_GAUSSIAN_SQ})
+        for (double param : {0., 0.5, 2., 3., 4.})
+            EXPECT(cp_kernel_eval(kind, param, z.data(), out.data(), n) == CP_OK);
+    EXPECT(cp_kernel_eval(12345, 0., z.data(), out.data(), n) != CP_OK);
+    EXPECT(cp_loggamma(z.data(), out.data(), 0) == CP_OK);
+}
+
+struct Tables {
+    int n, npad, nker;
+    std::vector<double> x, delta, lnxy, y, px, py, pre, post, u;
+};
+
+static bool make_tables(Tables& t, int n, int nker, int kind, double param, double q, int minfolds, int lowring) {
+    t.n = n; t.nker = nker;
+    t.npad = cp_fftlog_padded_size(n, minfolds);
+    if (t.npad < n) return false;
+    t.x.resize((size_t)nker * n);
+    for (int k = 0; k < nker; ++k)
+        for (int i = 0; i < n; ++i) t.x[(size_t)k * n + i] = std::pow(10., -3. + (5. + k) * i / (n > 1 ? n - 1 : 1));
+    std::vector<cp_fftlog_spec> spec(nker);
+    for (int k = 0; k < nker; ++k) spec[k] = cp_fftlog_spec{kind, param + 2 * k, q, 1., 3., 0.0635, k % 2 ? -1. : 1.};
+    t.delta.resize(nker); t.lnxy.resize(nker); t.y.resize((size_t)nker * n);
+    t.px.resize((size_t)nker * t.npad); t.py = t.pre = t.post = t.px;
+    t.u.resize((size_t)nker * (t.npad / 2 + 1) * 2);
+    return cp_fftlog_tables(n, nker, t.x.data(), spec.data(), minfolds, lowring, 1, nullptr, nullptr, t.delta.data(), t.lnxy.data(), t.y.data(),
+                            t.px.data(), t.py.data(), t.pre.data(), t.post.data(), t.u.data()) == CP_OK;
+}
+
+static void table_setup_errors() {
+    EXPECT(cp_fftlog_padded_size(0, 2) < 0);
+    EXPECT(cp_fftlog_padded_size(1000, 2) == 2048);
+    Tables t;
+    EXPECT(make_tables(t, 64, 2, CP_KERNEL_BESSEL_J, 0., 0., 2, 1));
+    // not log-spaced with check_level
+    std::vector<double> x(64);
+    for (int i = 0; i < 64; ++i) x[i] = 1. + i;
+    cp_fftlog_spec spec{CP_KERNEL_BESSEL_J, 0., 0., 1., 0., 1., 1.};
+    std::vector<double> d(1), l(1), y(64), a(128), b(128), c(128), e(128), u(130);
+    EXPECT(cp_fftlog_tables(64, 1, x.data(), &spec, 2, 1, 1, nullptr, nullptr, d.data(), l.data(), y.data(), a.data(), b.data(), c.data(), e.data(),
+                            u.data()) != CP_OK);
+    // custom kernel without its samples
+    spec.kind = CP_KERNEL_CUSTOM;
+    for (int i = 0; i < 64; ++i) x[i] = std::pow(10., -2. + 4. * i / 63.);
+    EXPECT(cp_fftlog_tables(64, 1, x.data(), &spec, 2, 1, 0, nullptr, nullptr, d.data(), l.data(), y.data(), a.data(), b.data(), c.data(), e.data(),
+                            u.data()) != CP_OK);
+    // custom kernel with samples
+    std::vector<double> uc(130, 0.5), lr{1., 0.3};
+    EXPECT(cp_fftlog_tables(64, 1, x.data(), &spec, 2, 1, 0, uc.data(), lr.data(), d.data(), l.data(), y.data(), a.data(), b.data(), c.data(), e.data(),
+                            u.data()) == CP_OK);
+}
+
+static void kernel_phases() {
+    const double nan = std::numeric_limits<double>::quiet_NaN(), inf = std::numeric_limits<double>::infinity();
+    struct Mode { int el; double vl; int er; double vr; int keep; };
+    const Mode modes[] = {{0, 0., 0, 0., 0}, {0, 0., 0, 0., 1}, {1, 0., 1, 0., 0}, {0, 1.5, 1, 0., 1}, {2, 0., 2, 0., 0}, {2, 0., 0, 0.3, 1}};
+    for (int n : {2, 3, 8, 13, 60, 250, 256, 500, 1000, 1024, 2048, 4096})
+        for (int nker : {1, 3}) {
+            if (n > 1024 && nker > 1) continue;
+            Tables t;
+            EXPECT(make_tables(t, n, nker, CP_KERNEL_SPHERICAL_BESSEL_J, 0., 1.5, 2, 1));
+            for (long long nbatch : {1LL, 2LL, 5LL}) {
+                std::vector<double> in((size_t)nbatch * nker * n), out;
+                for (size_t i = 0; i < in.size(); ++i) in[i] = (1. + 0.1 * std::sin(0.37 * i)) * std::pow(t.x[i % n], -1.2);
+                // one row 1e-12 of its partner, one row with a NaN, one with an Inf: the screening and scaling branches
+                if (nbatch >= 2) for (int i = 0; i < n; ++i) in[(size_t)nker * n + i] *= 1e-12;
+                if (nbatch >= 5) { in[(size_t)2 * nker * n + n / 2] = nan; in[(size_t)3 * nker * n] = inf; }
+                for (const Mode& m : modes) {
+                    out.assign((size_t)nbatch * nker * (m.keep ? t.npad : n), -7.);
+                    EXPECT(emu_fftlog(n, t.npad, nker, t.pre.data(), t.post.data(), t.u.data(), in.data(), out.data(), nbatch, m.el, m.vl, m.er, m.vr,
+                                      m.keep) == 0);
+                    bool written = true;
+                    for (double v : out) written = written && v != -7.;
+                    EXPECT(written);
+                    if (nbatch >= 5 && m.el != 2) {    // row 0 of batch entry 4 is finite, the NaN row is NaN alone
+                        EXPECT(std::isfinite(out[(size_t)4 * nker * (m.keep ? t.npad : n)]));
+                        EXPECT(std::isnan(out[(size_t)2 * nker * (m.keep ? t.npad : n)]));
+                    }
+                }
+            }
+        }
+}
+
+int main() {
+    special_functions();
+    table_setup_errors();
+    kernel_phases();
+    if (failures) { std::fprintf(stderr, "%d expectation(s) failed\n", failures); return 1; }
+    std::puts("ok");
+    return 0;
+}

@@ -24,3 +24,19 @@ def test_local_maxima():
 
 def test_registry():
     assert {'wallish2018', 'brieden2022'} <= set(RegisteredPowerSpectrumBAOFilter._registry)
+
+
+def test_fitpack_interp_operator():
+    """Interpolating splines of degree 1...5 with FITPACK's knots (RectBivariateSpline(s=0) along one axis), clamped beyond the data."""
+    from cosmoprimo_amd.interpolator import _fitpack_interp_operator
+    rng = np.random.default_rng(2)
+    x = np.sort(rng.uniform(0., 4., 23))
+    fun = rng.normal(size=(23, 7))
+    xq = np.sort(np.concatenate([rng.uniform(x[0], x[-1], 50), x[:3], [x[0] - 0.5, x[-1] + 1.]]))
+    yk = np.arange(7.)
+    for k in range(1, 6):
+        ref = interpolate.RectBivariateSpline(x, yk, fun, kx=k, ky=1, s=0)(xq, yk, grid=True) if k > 1 else None
+        W = _fitpack_interp_operator(x, xq, k)
+        if ref is None:
+            ref = np.array([np.interp(xq, x, fun[:, j]) for j in range(7)]).T
+        assert np.abs(W.dot(fun) - ref).max() < 1e-12 * np.abs(fun).max(), k

@@ -183,7 +183,7 @@ def test_leggauss_and_hierarchy(cp):
     assert abs(i1.sigma_r(8., method='leggauss') / i1.sigma_r(8.) - 1.) < 5e-2          # "not accurate", but the same integral
     assert abs(i1.sigma_d(method='leggauss') / i1.sigma_d() - 1.) < 5e-2
     with pytest.raises(NotImplementedError):
-        i1.sigma_r(8., method='quad')
+        i1.sigma_r(8., method='romberg')      # raises IndexError in the reference itself
     for hierarchy, d31 in [('normal', 2.525e-3), ('inverted', -2.512e-3 + 7.39e-5)]:
         m = cp.Cosmology(m_ncdm=0.12, neutrino_hierarchy=hierarchy)['m_ncdm']
         assert len(m) == 3 and abs(sum(m) - 0.12) < 1e-14
