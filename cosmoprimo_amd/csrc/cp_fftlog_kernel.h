@@ -125,8 +125,11 @@ __device__ __forceinline__ void pair_walk_next(const FftlogArgs& A, PairWalk& w,
 // One workgroup = T threads = one packed pair of rows per loop iteration (persistent over pairs).
 // Occupancy target: the LDS footprint (16 NP bytes per workgroup) allows 2 workgroups per CU at
 // NP = 4096, i.e. 2 waves per SIMD, so the register budget is 256 VGPR+AGPR per lane.
+#ifndef CP_WAVES_PER_SIMD
+#define CP_WAVES_PER_SIMD 2
+#endif
 template <int NP, int P, int IM, int OM>
-__global__ __launch_bounds__(NP / P, 2) void fftlog_kernel(const FftlogArgs A) {
+__global__ __launch_bounds__(NP / P, CP_WAVES_PER_SIMD) void fftlog_kernel(const FftlogArgs A) {
     extern __shared__ __attribute__((aligned(4096))) char smem[];  // 4096: see LdsView (cp_fft_core.h)
     cplx* lds = reinterpret_cast<cplx*>(smem);
     using F = Fftlog<NP, P, IM, OM>;

@@ -1,5 +1,2 @@
-cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-mkdir -p gpurun_out/r2
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r2/prof_linop -- python3 tools/bench_linop.py > gpurun_out/r2/prof_linop.log 2>&1
-grep -v "amdgpu\|rocprofv3\|^W2026\|^E2026" gpurun_out/r2/prof_linop.log
+#!/bin/bash
+bash tools/mb_variants.sh "base:" "p8w4:-DMB_P=8 -DCP_WAVES_PER_SIMD=4" "p8w4ns:-DMB_P=8 -DCP_WAVES_PER_SIMD=4 -DCP_ROW_SCREEN=0" "p8w4bar:-DMB_P=8 -DCP_WAVES_PER_SIMD=4 -DCP_WAVE_LOCAL=0" "p8w3:-DMB_P=8 -DCP_WAVES_PER_SIMD=3 -DMB_WGS_PER_CU=1" 2>&1 | tee gpurun_out/exp_p8.txt
