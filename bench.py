@@ -210,8 +210,10 @@ def main_split(args, config):
     rank, local_rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    launched = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)      # under torchrun, also with one rank
+    if launched:
         dist.init_process_group('nccl', device_id=dev)
+        dist.barrier()      # communicator built here, not at the barrier in front of the timed steps
     import cosmoprimo_amd as cp
     from cosmoprimo_amd.distributed import shard_range, gather_rows
     total = args.rows if args.rows != ROWS_PER_GPU else (1000000 if config == 4 else 10000000)
@@ -227,17 +229,17 @@ def main_split(args, config):
     for _ in range(max(1, args.warmup)):
         run()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if launched:
         dist.barrier()
     tic = time.perf_counter()
     for _ in range(args.steps):
         last = run()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if launched:
         dist.barrier()
     elapsed = time.perf_counter() - tic
     gather_ms = None
-    if world > 1:
+    if launched:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
@@ -259,12 +261,12 @@ def main_split(args, config):
                 'dtype': 'f64', 'data': 'synthetic',
                 'config': {'workload': 'config %d: %d %s split over %d GPU(s) in contiguous blocks, no collective' % (
                     config, total, 'EH98 P(k) vectors through both filters' if config == 4 else '(Omega_m, w0, wa, z) samples', world),
-                    'per_gpu': stop - start, 'rccl_ranks': world if world > 1 else 0},
+                    'per_gpu': stop - start, 'rccl_ranks': world if launched else 0},
                 'rank0_detail': last}
         if gather_ms is not None:
             line['gather_ms'] = gather_ms
         print(json.dumps(line))
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 
@@ -286,7 +288,7 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    distributed = world > 1
+    distributed = world > 1 or ('RANK' in os.environ and 'MASTER_ADDR' in os.environ)      # under torchrun, also with one rank: RCCL is then exercised
 
     def log(msg):
         if rank == 0:
@@ -306,6 +308,9 @@ def main():
     torch.cuda.set_device(dev)
     if distributed:
         dist.init_process_group('nccl', device_id=dev)
+        # RCCL builds its communicator on the first collective (hundreds of ms with the device idle): do that now, not at the barrier in
+        # front of the timed steps, which would put them back into the clock ramp that the warm-up is there to leave behind
+        dist.barrier()
 
     import cosmoprimo_amd as cp
     from oracle.workloads import pk_eh_default

@@ -65,35 +65,104 @@ __device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, doub
     return s;
 }
 
-__device__ __forceinline__ double sinc_pi(double x) {  // numpy.sinc(x / pi) = sin(x) / x
-    return x == 0. ? 1. : sin(x) / x;
+// 1 / x for finite, normal x: the hardware estimate and two Newton steps (relative error below 2 ulp), a third of the instructions of an
+// IEEE division (v_div_scale x 2, v_div_fmas, v_div_fixup around the same estimate and steps)
+__device__ __forceinline__ double recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.), r, r);
+    r = fma(fma(-x, r, 1.), r, r);
+    return r;
 }
 
-// eisenstein_hu.py:252-283.  ln_kh = log(kh): the powers of q and k / k_silk go through it, x^p = exp(p (log kh + log(x / kh))), one log
-// shared by the three powers of k of a P(k) evaluation instead of a pow() each (pow is log + exp in extended precision: four of them were
-// 40 % of the kernel's instructions); the relative error of exp(p log x) is |p log x| eps < 2e-15 here.
-__device__ __forceinline__ double transfer_eh(const EhScalars& s, double h, double kh, double ln_kh) {
-    const double k = kh * h;
-    const double q = k / (13.41 * s.k_eq);
-    const double ks = k * s.rs_drag;
-    const double ln_beta = log(kE + 1.8 * s.beta_c * q);
-    const double ln_nobeta = log(kE + 1.8 * q);
-    const double q108 = exp(1.08 * (ln_kh + s.ln_q_over_kh));
-    const double C_alpha = 14.2 / s.alpha_c + 386. / (1 + 69.9 * q108);
-    const double C_noalpha = 14.2 + 386. / (1 + 69.9 * q108);
-    const double ks54 = ks / 5.4;
-    const double T_c_f = 1. / (1. + (ks54 * ks54) * (ks54 * ks54));
+// log(x), fast for positive, finite, normal x (every argument here is a wavenumber or e + a positive term): the classic argument reduction to
+// m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1) and a degree-14 odd series in s (the fdlibm scheme and minimax coefficients), below 1 ulp;
+// a third of the instructions of the library log, which carries double-double intermediates this kernel has no use for.
+__device__ __forceinline__ double log_pos(double x) {
+    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);   // zero, negative, subnormal, Inf, NaN: the library's answers
+    double m = __builtin_amdgcn_frexp_mant(x);           // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double k = (double)e;
+    const double f = m - 1.;
+    const double s = f * recip(2. + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    return k * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f);
+}
+
+// sin(x) for 0 <= x < 1e6 (k rs_drag reaches 1e4 at k = 100 h/Mpc): n = round(x / (pi / 2)), r = x - n pi/2 with pi/2 in two pieces (33 + 53
+// bits: n times the first is exact), then the degree-13 / degree-14 polynomials of sin and cos on [-pi/4, pi/4] picked by n mod 4; absolute
+// error below 2e-16 (checked against extended precision on 6e5 arguments up to 1e6).  Larger arguments take the library function.
+__device__ __forceinline__ double sin_bounded(double x) {
+    if (!(x < 1e6)) return sin(x);
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, x);
+    r = fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double ps = fma(r * z, fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01), r);
+    const double pc = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                                  2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02), fma(-0.5, z, 1.));
+    const int q = (int)n;
+    const double v = (q & 1) ? pc : ps;
+    return (q & 2) ? -v : v;
+}
+
+// What transfer_eh needs of one cosmology, in the units of the loop over wavenumbers (kh in h/Mpc): once per thread
+struct EhPerCosmology {
+    double q_per_kh;     // q = kh h / (13.41 k_eq)
+    double ks_per_kh;    // ks = kh h rs_drag
+    double c_alpha0;     // 14.2 / alpha_c
+    double beta18, beta_node3, beta_b3, alpha_b, frac_b;
+    double ln_q_over_kh, ln_ksilk_over_kh;
+};
+
+__device__ __forceinline__ EhPerCosmology eh_per_cosmology(const EhScalars& s, double h) {
+    EhPerCosmology d;
+    d.q_per_kh = h / (13.41 * s.k_eq);
+    d.ks_per_kh = h * s.rs_drag;
+    d.c_alpha0 = 14.2 / s.alpha_c;
+    d.beta18 = 1.8 * s.beta_c;
+    d.beta_node3 = s.beta_node * s.beta_node * s.beta_node;
+    d.beta_b3 = s.beta_b * s.beta_b * s.beta_b;
+    d.alpha_b = s.alpha_b;
+    d.frac_b = s.frac_b;
+    d.ln_q_over_kh = s.ln_q_over_kh;
+    d.ln_ksilk_over_kh = s.ln_ksilk_over_kh;
+    return d;
+}
+
+// eisenstein_hu.py:252-283, the same rational functions with their quotients gathered (6 reciprocals instead of 16 divisions) and the cosmology-only
+// factors taken out of the loop over wavenumbers; within 1e-14 of the operation-for-operation form (tests/test_cosmology_gpu.py, 1e-11 against
+// the reference's numbers).  ln_kh = log(kh): the powers of q and k / k_silk go through it, x^p = exp(p (log kh + log(x / kh))), one log
+// shared by the three powers of k of a P(k) evaluation instead of a pow() each; the relative error of exp(p log x) is |p log x| eps < 2e-15 here.
+__device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh, double ln_kh) {
+    const double q = kh * d.q_per_kh;
+    const double ks = kh * d.ks_per_kh;
+    const double ln_beta = log_pos(kE + d.beta18 * q);
+    const double ln_nobeta = log_pos(kE + 1.8 * q);
+    const double q108 = exp(1.08 * (ln_kh + d.ln_q_over_kh));
+    const double c386 = 386. * recip(1 + 69.9 * q108);
+    const double C_alpha = d.c_alpha0 + c386, C_noalpha = 14.2 + c386;
+    const double ks54 = ks * (1. / 5.4), ks52 = ks * (1. / 5.2);
+    const double f = recip(1. + (ks54 * ks54) * (ks54 * ks54));          // T_c_f
     const double q2 = q * q;
-    const double T_c = T_c_f * (ln_beta / (ln_beta + C_noalpha * q2)) + (1 - T_c_f) * (ln_beta / (ln_beta + C_alpha * q2));
-    const double bn = s.beta_node / ks;
-    const double s_tilde = s.rs_drag * rcbrt(1 + bn * bn * bn);
-    const double ks_tilde = k * s_tilde;
-    const double T_b_T0 = ln_nobeta / (ln_nobeta + C_noalpha * q2);
-    const double T_b_1 = T_b_T0 / (1 + (ks / 5.2) * (ks / 5.2));
-    const double bb = s.beta_b / ks;
-    const double T_b_2 = s.alpha_b / (1 + bb * bb * bb) * exp(-exp(1.4 * (ln_kh + s.ln_ksilk_over_kh)));
-    const double T_b = sinc_pi(ks_tilde) * (T_b_1 + T_b_2);
-    return s.frac_b * T_b + (1 - s.frac_b) * T_c;
+    // T_c = f ln_beta / d1 + (1 - f) ln_beta / d2
+    const double d1 = ln_beta + C_noalpha * q2, d2 = ln_beta + C_alpha * q2;
+    const double T_c = ln_beta * fma(f, d2 - d1, d1) * recip(d1 * d2);
+    // 1 + (beta / ks)^3 = (ks^3 + beta^3) / ks^3
+    const double ks3 = ks * ks * ks;
+    const double ks_tilde = ks * ks * rcbrt(ks3 + d.beta_node3);         // k rs_drag / cbrt(1 + (beta_node / ks)^3)
+    const double T_b_1 = ln_nobeta * recip((ln_nobeta + C_noalpha * q2) * fma(ks52, ks52, 1.));
+    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * exp(-exp(1.4 * (ln_kh + d.ln_ksilk_over_kh)));
+    const double sinc = ks_tilde == 0. ? 1. : sin_bounded(ks_tilde) * recip(ks_tilde);   // numpy.sinc(x / pi)
+    const double T_b = sinc * (T_b_1 + T_b_2);
+    return d.frac_b * T_b + (1 - d.frac_b) * T_c;
 }
 
 __device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h, double kh) {  // eisenstein_hu_nowiggle.py:45-51
@@ -102,7 +171,7 @@ __device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h
     const double x = 0.43 * ks;
     const double gamma_eff = s.omega_m * (s.alpha_gamma + (1 - s.alpha_gamma) / (1 + (x * x) * (x * x)));
     const double q = k * (s.theta_cmb * s.theta_cmb) / gamma_eff;
-    const double L0 = log(2 * kE + 1.8 * q);
+    const double L0 = log_pos(2 * kE + 1.8 * q);
     const double C0 = 14.2 + 731.0 / (1 + 62.5 * q);
     return L0 / (L0 + C0 * (q * q));
 }
@@ -156,6 +225,7 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
     EhScalars s{};
     if (A.scal) s = A.scal[ic];
+    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
     const bool with_z = A.what == CP_PK_MATTER && A.nz > 0;
     const long long nzs = with_z ? A.nz : 1;
     const double kfac = A.kscale ? A.kscale[ic] : 1.;
@@ -164,6 +234,10 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
     const double kp = pw[CP_PK_K_PIVOT] / c.h;
     const double ln_kp = log(kp);
     const double Omega0_m = c.Omega_b + c.Omega_cdm + 0. - 0.;  // cosmology.py:381
+    // pk_callable, eisenstein_hu.py:321-324: potential_to_density^-2 x curvature_to_potential x h^3 A_s = kh x a constant of the cosmology
+    // (the h^3 of the primordial spectrum and of curvature_to_potential cancel)
+    const double p2d_unit = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms));
+    const double pk_unit = 9. / 25. * 2. * (kPi * kPi) / (p2d_unit * p2d_unit) * A_s;
     for (long long z0 = 0; z0 < nzs; z0 += 256) {
         if (z0) __syncthreads();  // the previous block of redshifts has been written
         if (with_z && z0 + tid < A.nz) {
@@ -175,29 +249,25 @@ __global__ __launch_bounds__(256) void power_kernel(const Args A) {
         for (long long ik = k0 + tid; ik < k1; ik += 256) {
             const double kh = A.kscale ? A.k[ik] * kfac : A.k[ik];
             double* out = A.out + (ic * nzs + z0) * A.nk + ik;
-            const double ln_kh = log(kh);
+            const double ln_kh = log_pos(kh);
             double T = 1.;
             if (A.what != CP_PK_PRIMORDIAL) {
                 if (A.engine == CP_ENGINE_BBKS)
                     T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
                 else
-                    T = A.engine == CP_ENGINE_EH ? transfer_eh(s, c.h, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
+                    T = A.engine == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
             }
             if (A.what == CP_PK_TRANSFER) {
                 out[0] = T;
                 continue;
             }
             const double lnkkp = ln_kh - ln_kp;
-            const double prim = (c.h * c.h * c.h) * A_s * exp((n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp)) * lnkkp);
+            const double tilt = exp((n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp)) * lnkkp);
             if (A.what == CP_PK_PRIMORDIAL) {
-                out[0] = prim;
+                out[0] = (c.h * c.h * c.h) * A_s * tilt;
                 continue;
             }
-            // pk_callable, eisenstein_hu.py:321-324
-            const double p2d_base = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms) * (kh * kh));
-            const double potential_to_density = 1. / (p2d_base * p2d_base);
-            const double curvature_to_potential = 9. / 25. * 2. * (kPi * kPi) / (kh * kh * kh) / (c.h * c.h * c.h);
-            const double p0 = (T * T) * potential_to_density * curvature_to_potential * prim;
+            const double p0 = (T * T) * (kh * pk_unit) * tilt;
             if (!with_z) {
                 out[0] = p0;
                 continue;

@@ -1,0 +1,28 @@
+"""One of the secondary configs of bench.py on its own, for a kernel trace (development aid):
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c3 -- python3 tools/profile_secondary.py 3
+Configs: 3, 4 (both filters, one 16 384-vector chunk timed 4 times), 5."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+
+
+def main():
+    import torch
+    import bench
+    import cosmoprimo_amd as cp
+    which = sys.argv[1] if len(sys.argv) > 1 else '3'
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    if which == '3':
+        out = bench.config3(cp, torch, dev, reps=20)
+    elif which == '4':
+        out = bench.config4(cp, torch, dev, bench.eh_parameters(4 * 16384, 2, torch, dev))
+    else:
+        out = bench.config5(torch, dev, *bench.config5_samples(1250000, 3, torch, dev), reps=20)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
