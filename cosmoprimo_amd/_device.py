@@ -44,13 +44,33 @@ def resolve_device(device=None, *tensors):
     return device
 
 
+def upload(x, device):
+    """Tensor on ``device`` from a numpy array / number / tensor, dtype kept.  Host arrays up to 1 MiB (grids, masks, index lists, parameter
+    vectors) go through a page-locked block of torch's caching host allocator and an asynchronous copy: a copy from pageable memory blocks the
+    host until everything queued on the stream before it has run, i.e. every small upload in the middle of a pipeline is a device
+    synchronisation (21 of them per 16 384-vector chunk of the wallish2018 filter before this)."""
+    t = torch()
+    if is_torch(x):
+        return x.to(device=device)
+    shape = np.shape(x)
+    a = np.ascontiguousarray(x)
+    if a.dtype.byteorder not in '=|':
+        a = a.astype(a.dtype.newbyteorder('='))
+    h = t.from_numpy(a) if a.flags.writeable else t.from_numpy(a.copy())
+    if 0 < a.nbytes <= (1 << 20):
+        try:
+            return h.pin_memory().to(device, non_blocking=True).reshape(shape)
+        except RuntimeError:    # no page-locked memory left: the blocking copy below is the same result
+            pass
+    return h.to(device).reshape(shape)
+
+
 def to_device(x, device):
     """float64 contiguous tensor on ``device`` from a number / numpy array / tensor (shape preserved)."""
     t = torch()
     if is_torch(x):
         return x.to(device=device, dtype=t.float64).contiguous()
-    a = np.asarray(x, dtype='f8')
-    return t.from_numpy(np.ascontiguousarray(a)).to(device).reshape(a.shape)
+    return upload(np.asarray(x, dtype='f8'), device)
 
 
 def to_host(x):

@@ -230,7 +230,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         self._even_now, self._odd_now = out[0::2], out[1::2]
         pknow_lin = ops['dst'](out.view(ffted.shape), inverse=True, fused=True, split=True)          # exp(idst(.)) / k_lin
         pk = self._pk_rows
-        mask, ml, mr = (torch.as_tensor(ops[name], device=self.device) for name in ('mask', 'mask_left', 'mask_right'))
+        mask, ml, mr = (dv.upload(ops[name], self.device) for name in ('mask', 'mask_left', 'mask_right'))
         vals = torch.cat([pk[:, ml], pknow_lin[:, mask], pk[:, mr]], dim=1).contiguous()
         pknow = ops['splice'](vals)                                       # clamped CubicSpline on the spliced knots at self.k
         wiggles = (pk / pknow - 1.) * ops['tophat'] + 1.
@@ -359,7 +359,7 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
                                                 extrap_kmax=interp.extrap_kmax, interp_order_k=interp.interp_order_k, device=self.device)
             new = clone._rows(self.k_fid)
         out = self._pk_rows.clone()
-        out[:, torch.as_tensor(self.kmask_fid, device=self.device)] = new
+        out[:, dv.upload(self.kmask_fid, self.device)] = new
         self._pknow_rows = out
 
 
@@ -401,7 +401,7 @@ def _brieden_compute_batched(self, rescale):
                                              self.device.index, dv.stream_of(self.device)))
     new = (10**out).T
     res = self._pk_rows.clone()
-    res[:, torch.as_tensor(self.kmask_fid, device=self.device)] = new
+    res[:, dv.upload(self.kmask_fid, self.device)] = new
     self._pknow_rows = res
 
 
@@ -477,7 +477,7 @@ class _OperatorFilterMixin(object):
     def _eh_nowiggle(self, k):
         """Eisenstein & Hu no-wiggle P(k, z=0) of ``cosmo`` on the device (reference: Fourier(cosmo, engine='eisenstein_hu_nowiggle'))."""
         pknow = np.asarray(Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k, z=0.), dtype='f8')
-        return dv.torch().as_tensor(pknow, device=self.device)
+        return dv.upload(pknow, self.device)
 
 
 class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
@@ -503,7 +503,7 @@ class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     def _compute(self):
         torch = dv.torch()
-        mask = torch.as_tensor(self.kmask, device=self.device)
+        mask = dv.upload(self.kmask, self.device)
         res = self._pk_rows.clone()
         res[:, mask] = 10**self._op(torch.log10(self._pk_rows[:, mask]).contiguous())
         self._pknow_rows = res
@@ -520,7 +520,7 @@ class SavGolPowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     def _compute(self):
         torch = dv.torch()
-        kt = torch.as_tensor(self.k, device=self.device)
+        kt = dv.upload(self.k, self.device)
         res = torch.exp(self._op(torch.log(kt * self._pk_rows))) / kt
         h = self.nfilter // 2
         res[:, -h:] = self._pk_rows[:, -h:]
@@ -558,7 +558,7 @@ class EHNoWigglePolyPowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectr
         cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
         A = _constrained_lsq_operator(gradient, k**2, cg, _end_constraints(k.size, order=2))
         pknow = self._eh_nowiggle(k)
-        tmask = torch.as_tensor(mask, device=self.device)
+        tmask = dv.upload(mask, self.device)
         ratio = (self._pk_rows[:, tmask] / pknow).contiguous()
         res = self._pk_rows.clone()
         res[:, tmask] = LinearOperator.dense(A, device=self.device)(ratio) * pknow      # pk / (ratio / model)

@@ -95,6 +95,11 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = A.tw[N + i];
     const long long npairs = (A.nrows + 1) / 2;
     const double fn = sqrt(2. / N), fl = sqrt(1. / N);
+    // Rows stay independent although two of them share one complex FFT (scipy transforms row by row): a row holding a sample that is
+    // not finite -- or, for the fused log map, not positive -- goes into the transform as a harmless constant and is stored as NaN; its
+    // partner is untouched.  The flags of the pair are raised by whichever thread meets such a sample and read behind one barrier.
+    __shared__ int bad_row[2];
+    const double nan = __builtin_nan("");
     for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
         const bool has_b = 2 * p + 1 < A.nrows;
         const double* ra = A.in + 2 * p * N;
@@ -105,17 +110,21 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
         // position of coefficient j in its row: the wallish2018 filter treats even- and odd-indexed coefficients as two sequences
         // (bao_filter.py:373), so they can be written / read as two half rows instead of being gathered by separate copy kernels
         auto at = [&](int j) { return A.split ? ((j & 1) * (N / 2) + (j >> 1)) : j; };
+        if (t == 0) bad_row[0] = bad_row[1] = 0;
         __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
         int tt = t;
         asm volatile("" : "+v"(tt));
         if constexpr (!INVERSE) {
             // Makhoul reordering with the (-1)^n sign folded in
+            bool bad_a = false, bad_b = false;
 #pragma unroll
             for (int r = 0; r < P; ++r) {
                 const int m = tt + T * r;
                 const bool lower = m < N / 2;
                 const int n = lower ? 2 * m : 2 * (N - 1 - m) + 1;
                 double a = ra[n], b = rb[n];
+                bad_a |= !(fabs(a) <= 1.7976931348623157e308) || (A.fused && !(a > 0.));
+                bad_b |= !(fabs(b) <= 1.7976931348623157e308) || (A.fused && !(b > 0.));
                 if (A.fused) {
                     const double kk = A.kx[n];
                     a = log(kk * a);
@@ -123,6 +132,17 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 }
                 x[r].re = lower ? a : -a;
                 x[r].im = has_b ? (lower ? b : -b) : 0.;
+            }
+            if (bad_a) bad_row[0] = 1;
+            if (bad_b) bad_row[1] = 1;
+            __syncthreads();
+            const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
+            if (skip_a | skip_b) {
+#pragma unroll
+                for (int r = 0; r < P; ++r) {
+                    if (skip_a) x[r].re = 0.;
+                    if (skip_b) x[r].im = 0.;
+                }
             }
             dif_all<N, P>(tt, A, x, lds, ltw);
             asm volatile("" : "+v"(tt));
@@ -137,34 +157,46 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 // V_a = ((p + r)/2, (q - s)/2), V_b = ((q + s)/2, (r - p)/2);  C' = cos * re + sin * im
                 const double ya = 0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im));
                 const double yb = 0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re));
-                oa[at(N - 1 - k)] = f * ya;
-                if (has_b) ob[at(N - 1 - k)] = f * yb;
+                oa[at(N - 1 - k)] = skip_a ? nan : f * ya;
+                if (has_b) ob[at(N - 1 - k)] = skip_b ? nan : f * yb;
             }
         } else {
-            // Hermitian-symmetrised, conjugated spectrum of the pair
+            // Hermitian-symmetrised, conjugated spectrum of the pair; keep_a / keep_b: rows that take part
+            bool bad_a = false, bad_b = false;
+            auto spectrum = [&](bool keep_a, bool keep_b) {
 #pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const int k = tt + T * r;
-                const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
-                const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
-                const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-                const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
-                const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
-                const cplx rot = A.rot[k];
-                const double cs = rot.re, sn = -rot.im;
-                cplx Ha, Hb;
-                if (k == 0) {
-                    Ha = cplx{Aa, 0.};
-                    Hb = cplx{Ab, 0.};
-                } else {
-                    Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
-                    Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
+                for (int r = 0; r < P; ++r) {
+                    const int k = tt + T * r;
+                    const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
+                    const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
+                    const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
+                    const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
+                    const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
+                    bad_a |= !(fabs(Aa) <= 1.7976931348623157e308) || !(fabs(Ba) <= 1.7976931348623157e308);
+                    bad_b |= !(fabs(Ab) <= 1.7976931348623157e308) || !(fabs(Bb) <= 1.7976931348623157e308);
+                    const cplx rot = A.rot[k];
+                    const double cs = rot.re, sn = -rot.im;
+                    cplx Ha, Hb;
+                    if (k == 0) {
+                        Ha = cplx{Aa, 0.};
+                        Hb = cplx{Ab, 0.};
+                    } else {
+                        Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
+                        Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
+                    }
+                    if (!keep_a) Ha = cplx{0., 0.};
+                    if (!keep_b) Hb = cplx{0., 0.};
+                    // conj(H_a + i H_b)
+                    x[r].re = Ha.re - Hb.im;
+                    x[r].im = -(Ha.im + Hb.re);
                 }
-                if (!has_b) Hb = cplx{0., 0.};
-                // conj(H_a + i H_b)
-                x[r].re = Ha.re - Hb.im;
-                x[r].im = -(Ha.im + Hb.re);
-            }
+            };
+            spectrum(true, has_b);
+            if (bad_a) bad_row[0] = 1;
+            if (bad_b) bad_row[1] = 1;
+            __syncthreads();
+            const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
+            if (skip_a | skip_b) spectrum(!skip_a, has_b && !skip_b);   // rare: the spectrum again without the bad row
             dif_all<N, P>(tt, A, x, lds, ltw);
             asm volatile("" : "+v"(tt));
             // LDS holds (v_a[m], -v_b[m]) at pos(m); undo the reordering and the (-1)^n sign
@@ -181,8 +213,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                     ya = exp(ya) / kk;
                     yb = exp(yb) / kk;
                 }
-                oa[n] = ya;
-                if (has_b) ob[n] = yb;
+                oa[n] = skip_a ? nan : ya;
+                if (has_b) ob[n] = skip_b ? nan : yb;
             }
         }
     }

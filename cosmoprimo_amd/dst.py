@@ -32,21 +32,12 @@ class DST(object):
         if x.shape[-1] != self.n:
             raise ValueError('last dimension must be {:d}, got {}'.format(self.n, tuple(x.shape)))
         nrows = x.numel() // self.n
-        # the kernel transforms rows in pairs (one complex FFT): a row that is not finite (or, for the fused log map, not positive) would
-        # spread its NaN to its partner, which scipy's row-by-row transform does not do; such rows go in as a harmless constant and come out NaN
-        ok = None
-        if nrows:
-            ok = dv.screen_rows(x, require_positive=fused and not inverse)
-            if bool(ok.all()):
-                ok = None
-            else:
-                x = torch.where(ok, x, torch.ones_like(x)).contiguous()
+        # rows are independent, as in scipy's row-by-row transform: the kernel itself keeps a row that is not finite (or, for the fused log map,
+        # not positive) away from the row it shares a complex FFT with, and stores NaN for it
         out = torch.empty_like(x)
         if nrows:
             _lib.check(_lib.load().cp_dst_execute(self._handle, x.data_ptr(), out.data_ptr(), nrows, int(bool(inverse)), int(bool(fused)) | (2 if split else 0),
                                                   dv.stream_of(self.device)))
-        if ok is not None:
-            out = torch.where(ok, out, torch.full_like(out, float('nan')))
         return out
 
     def __del__(self):

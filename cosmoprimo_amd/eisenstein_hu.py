@@ -97,8 +97,8 @@ class Primordial(BaseSection):
         return _out(out.reshape(out.shape[:-1] + kh.shape), k)
 
     def pk_interpolator(self, mode='scalar'):
-        return PowerSpectrumInterpolator1D.from_callable(pk_callable=lambda k: self.pk_k(dv.torch().as_tensor(k, device=self.device), mode=mode).T
-                                                         if self._engine.batch_size else self.pk_k(dv.torch().as_tensor(k, device=self.device), mode=mode),
+        return PowerSpectrumInterpolator1D.from_callable(pk_callable=lambda k: self.pk_k(dv.upload(k, self.device), mode=mode).T
+                                                         if self._engine.batch_size else self.pk_k(dv.upload(k, self.device), mode=mode),
                                                          device=self.device)
 
 

@@ -251,7 +251,7 @@ class FFTlog(dv.Copyable):
         cache = self.__dict__.setdefault('_device_tables', {})
         key = (name, dev.index)
         if key not in cache:
-            cache[key] = _torch().as_tensor(array, device=dev)
+            cache[key] = dv.upload(array, dev)
         return cache[key]
 
     def set_fft_engine(self, engine='mi355x', **engine_kwargs):

@@ -396,7 +396,7 @@ class Interpolator1D(dv.Copyable):
         if not assume_sorted:
             ix = np.argsort(x)
             x = x[ix]
-            fun = fun[dv.torch().as_tensor(ix, device=self.device)]
+            fun = fun[dv.upload(ix, self.device)]
         self.xmin, self.xmax = x[0], x[-1]
         self._x = np.log10(x) if self.interp_x == 'log' else x
         fun = fun.reshape(x.size, -1)
@@ -504,7 +504,7 @@ class Interpolator2D(dv.Copyable):
         if not assume_sorted:
             ix, iy = np.argsort(x), np.argsort(y)
             x, y = x[ix], y[iy]
-            fun = fun.index_select(-2, torch.as_tensor(ix, device=self.device)).index_select(-1, torch.as_tensor(iy, device=self.device))
+            fun = fun.index_select(-2, dv.upload(ix, self.device)).index_select(-1, dv.upload(iy, self.device))
         self.xmin, self.xmax, self.ymin, self.ymax = x[0], x[-1], y[0], y[-1]
         self._x = np.log10(x) if self.interp_x == 'log' else x
         self._y = y
@@ -578,7 +578,7 @@ class Interpolator2D(dv.Copyable):
         if self.interp_fun == 'log':
             out = 10**out
         if not self.extrap:
-            mask = mask_x[:, None] & torch.as_tensor(mask_y, device=self.device)[None, :]
+            mask = mask_x[:, None] & dv.upload(mask_y, self.device)[None, :]
             out = torch.where(mask, out, torch.full_like(out, float('nan')))
         return _finish(out, dtype, like_torch, shape)
 
@@ -604,14 +604,14 @@ class Interpolator2D(dv.Copyable):
             out = opy(tmp.transpose(-1, -2).contiguous())           # rows = x queries: (batch..., nxq, nyq)
             mask = mask_x[:, None] & mask_y
         else:
-            wx = torch.as_tensor(self._operator('x', xq, dense=True), device=self.device)   # (nq, nx)
-            wy = torch.as_tensor(self._operator('y', yh, dense=True), device=self.device)   # (nq, ny)
+            wx = dv.upload(self._operator('x', xq, dense=True), self.device)   # (nq, nx)
+            wy = dv.upload(self._operator('y', yh, dense=True), self.device)   # (nq, ny)
             out = ((wx @ self._fun) * wy).sum(dim=-1)
             mask = mask_x & mask_y
         if self.interp_fun == 'log':
             out = 10**out
         if not self.extrap and not mask.all():
-            out = torch.where(torch.as_tensor(mask, device=self.device), out, torch.full_like(out, float('nan')))
+            out = torch.where(dv.upload(mask, self.device), out, torch.full_like(out, float('nan')))
         if self._nan_surfaces is not None:
             out = torch.where(self._nan_surfaces.reshape(self._lead + (1,) * (out.ndim - len(self._lead))), torch.full_like(out, float('nan')), out)
         return _finish(out, dtype, like_torch, shape)
@@ -732,10 +732,10 @@ class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
         if self.is_from_callable:
             mask_k, = _mask_bounds([kh], [(self.extrap_kmin, self.extrap_kmax)], bounds_error=bounds_error)
             out = dv.to_device(self._interp(kh), self.device)
-            mask = torch.as_tensor(mask_k, device=self.device).reshape((-1,) + (1,) * (out.ndim - 1))
+            mask = dv.upload(mask_k, self.device).reshape((-1,) + (1,) * (out.ndim - 1))
             out = torch.where(mask, out, torch.full_like(out, float('nan')))
         else:
-            out = self._interp(torch.as_tensor(kh, device=self.device), bounds_error=bounds_error)
+            out = self._interp(dv.upload(kh, self.device), bounds_error=bounds_error)
         return out * self._rsigma8sq
 
     def __call__(self, k, bounds_error=False):
@@ -838,7 +838,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             raise ValueError('pk must be (batch, {:d}, {:d}), got {}'.format(self.k.size, self.z.size, tuple(pk.shape)))
         ik, iz = np.argsort(self.k), np.argsort(self.z)
         if np.any(ik[1:] < ik[:-1]) or np.any(iz[1:] < iz[:-1]):
-            pk = pk.index_select(1, torch.as_tensor(ik, device=self.device)).index_select(2, torch.as_tensor(iz, device=self.device))
+            pk = pk.index_select(1, dv.upload(ik, self.device)).index_select(2, dv.upload(iz, self.device))
         self.k, self.z, self._pk = self.k[ik], self.z[iz], pk.contiguous()
         self.interp_k, self.extrap_pk = str(interp_k), str(extrap_pk)
         self.extrap_kmin, self.extrap_kmax = self.k[0], self.k[-1]
@@ -914,7 +914,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         if self.is_from_callable:
             mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
             if dv.is_torch(mask_k):      # wavenumbers that live on the device (a mesh): masks there too
-                mask_z = torch.as_tensor(mask_z, device=mask_k.device)
+                mask_z = dv.upload(mask_z, mask_k.device)
             mask = mask_k[:, None] & mask_z if grid else mask_k & mask_z
             if self.growth_factor_sq is not None:
                 tmp = dv.to_device(self._interp(kh), self.device)                     # (..., nk)
@@ -925,7 +925,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                     tmp = tmp[..., :, None].expand(tmp.shape + (zh.size,))
             else:
                 tmp = dv.to_device(self._interp(kh, zh, grid=grid), self.device)
-            out = tmp if bool(mask.all()) else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+            out = tmp if bool(mask.all()) else torch.where(dv.upload(mask, self.device), tmp, torch.full_like(tmp, float('nan')))
         else:
             is2d = self._is2d()
             mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
@@ -936,15 +936,15 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                 interp = self._interp
                 saved = interp.extrap
                 interp.extrap = True      # the P(k, z) mask below uses the extrapolation range, as the reference does
-                tmp = interp(torch.as_tensor(kh, device=self.device), torch.as_tensor(zh, device=self.device), grid=grid)
+                tmp = interp(dv.upload(kh, self.device), dv.upload(zh, self.device), grid=grid)
                 interp.extrap = saved
             else:
-                tmp = self._interp(torch.as_tensor(kh, device=self.device))
+                tmp = self._interp(dv.upload(kh, self.device))
                 if grid:
                     tmp = tmp[:, None].expand(kh.size, zh.size)
             if self.growth_factor_sq is not None and not ignore_growth:
                 tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
-            out = tmp if mask.all() else torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+            out = tmp if mask.all() else torch.where(dv.upload(mask, self.device), tmp, torch.full_like(tmp, float('nan')))
         if getattr(self, '_tables_batched', False):
             return self._rescaled(out, 1)
         if isinstance(self._rsigma8sq, float) and self._rsigma8sq == 1.:     # (nothing to rescale: no pass over the result)
@@ -977,7 +977,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                     out = 10**out
                 mask = mask_z[:, None] & mask_k
                 if not mask.all():
-                    out = torch.where(torch.as_tensor(mask, device=self.device), out, torch.full_like(out, float('nan')))
+                    out = torch.where(dv.upload(mask, self.device), out, torch.full_like(out, float('nan')))
                 if self.growth_factor_sq is not None and not ignore_growth:
                     out = out * dv.to_device(self.growth_factor_sq(zh), self.device)[..., :, None]
                 return self._rescaled(out, out.ndim - 2) if getattr(self, '_tables_batched', False) else (
@@ -998,7 +998,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         if self.is_from_callable:
             _, mask_z = _mask_bounds([self.z[:1], zh], [(self.zmin, self.zmax)] * 2)
             if not mask_z.all():
-                growth = torch.where(torch.as_tensor(mask_z, device=self.device), growth, torch.full_like(growth, float('nan')))
+                growth = torch.where(dv.upload(mask_z, self.device), growth, torch.full_like(growth, float('nan')))
         return growth
 
     def _sigma_separable(self, integrate, zh):
@@ -1016,7 +1016,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         growth = dv.to_device(self.growth_factor_sq(zh), self.device)          # (batch..., nz)
         if self.is_from_callable:                                  # NaN outside the redshift range (tabulated single columns ignore z)
             _, mask_z = _mask_bounds([z0, zh], [(self.zmin, self.zmax)] * 2)
-            growth = torch.where(torch.as_tensor(mask_z, device=self.device), growth, torch.full_like(growth, float('nan')))
+            growth = torch.where(dv.upload(mask_z, self.device), growth, torch.full_like(growth, float('nan')))
         return base.sqrt(), growth.sqrt()
 
     def sigma_dz(self, z, **kwargs):
@@ -1233,10 +1233,10 @@ class CorrelationFunctionInterpolator1D(_BaseCorrelationFunctionInterpolator):
         if self.is_from_callable:
             mask_s, = _mask_bounds([sh], [(self.smin, self.smax)], bounds_error=bounds_error)
             out = dv.to_device(self._interp(sh), self.device)
-            mask = torch.as_tensor(mask_s, device=self.device).reshape((-1,) + (1,) * (out.ndim - 1))
+            mask = dv.upload(mask_s, self.device).reshape((-1,) + (1,) * (out.ndim - 1))
             out = torch.where(mask, out, torch.full_like(out, float('nan')))
         else:
-            out = self._interp(torch.as_tensor(sh, device=self.device), bounds_error=bounds_error)
+            out = self._interp(dv.upload(sh, self.device), bounds_error=bounds_error)
         return out * self._rsigma8sq
 
     def __call__(self, s, bounds_error=False):
@@ -1355,14 +1355,14 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
                 mask_z = mask_z | True    # ignore input z
             mask = mask_s[:, None] & mask_z if grid else mask_s & mask_z
             if is2d:
-                tmp = self._interp(torch.as_tensor(sh, device=self.device), torch.as_tensor(zh, device=self.device), grid=grid)
+                tmp = self._interp(dv.upload(sh, self.device), dv.upload(zh, self.device), grid=grid)
             else:
-                tmp = self._interp(torch.as_tensor(sh, device=self.device))
+                tmp = self._interp(dv.upload(sh, self.device))
                 if grid:
                     tmp = tmp[:, None].expand(sh.size, zh.size)
             if self.growth_factor_sq is not None and not ignore_growth:
                 tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
-        out = torch.where(torch.as_tensor(mask, device=self.device), tmp, torch.full_like(tmp, float('nan')))
+        out = torch.where(dv.upload(mask, self.device), tmp, torch.full_like(tmp, float('nan')))
         return out * self._rsigma8sq
 
     def __call__(self, s, z, grid=True, ignore_growth=False, bounds_error=False):

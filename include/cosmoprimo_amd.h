@@ -272,7 +272,9 @@ int cp_dst_plan_create(cp_dst_plan** plan, int n, const double* kx, int device);
 /* d_in, d_out : (nrows, n) device.  inverse = 0: Y = dst2_ortho(x); 1: x = idst2_ortho(Y).  flags:
  * CP_DST_FUSED: forward transforms log(kx_n * in_n) (bao_filter.py:371), inverse returns exp(x_n) / kx_n (bao_filter.py:413);
  * CP_DST_SPLIT: the coefficient side is de-interleaved, Y_0, Y_2, ... in the first half of each row and Y_1, Y_3, ... in the second
- *               (the filter's even / odd sequences, bao_filter.py:373, 408-410, without gather / scatter copies). */
+ *               (the filter's even / odd sequences, bao_filter.py:373, 408-410, without gather / scatter copies)..
+ * Rows are independent, as in scipy's row-by-row transform, although two of them share one complex FFT inside the kernel: a row holding a
+ * sample that is not finite (or, with CP_DST_FUSED forward, not positive) is stored as NaN and leaves its partner untouched. */
 #define CP_DST_FUSED 1
 #define CP_DST_SPLIT 2
 int cp_dst_execute(const cp_dst_plan* plan, const double* d_in, double* d_out, long long nrows, int inverse, int flags, void* stream);
@@ -290,8 +292,8 @@ int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const 
 int cp_spline_points(const double* d_xk, const double* d_y, const double* d_s, long long n, int ncol, const double* d_xq, double* d_out, long long nq, int nu,
                      int extrapolate, int device, void* stream);
 
-/* ---- row screening for the callers of cp_fftlog_execute / cp_dst_execute (two rows share one complex FFT there, so a non-finite row
- *      would reach its pair partner, unlike the reference's row-by-row numpy.fft / scipy.fftpack calls, fftlog.py:540-560) ----
+/* ---- row screening utility (cp_fftlog_execute and cp_dst_execute screen their rows themselves; this pass is for callers that want
+ *      the flags, e.g. to count or report the rows a batch loses) ----
  * d_x : (nrows, n) device.  d_ok[row] = 1 if every entry of the row is finite (and > 0 if require_positive: the fused log map of
  * cp_dst_execute), else 0.  d_scale : optional (nrows) device, 2^e >= max |row| with e <= 1023 (1 for all-zero and non-finite rows), or NULL. */
 int cp_rows_screen(const double* d_x, long long nrows, long long n, int require_positive, unsigned char* d_ok, double* d_scale, int device, void* stream);
