@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void spline_apply_kernel(const Args A) {
             if (r < nr) {
                 double v = j0 >= 0 ? acc[r] * A.scale : __builtin_nan("");
                 if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                else if (A.post_op == CP_SPLINE_POST_EXP10) v = exp10(v);
                 A.out[(r0 + r) * A.nq + q] = v;
             }
         }
@@ -266,9 +267,106 @@ __global__ __launch_bounds__(256) void linop_mfma_kernel(const DenseArgs A) {
                     if (row >= A.nrows) continue;
                     double v = nanq ? __builtin_nan("") : acc[i][j][r] * A.scale;
                     if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                    else if (A.post_op == CP_SPLINE_POST_EXP10) v = exp10(v);
                     A.out[row * A.nq + q] = v;
                 }
         }
+    }
+}
+
+// The same contraction along the MIDDLE axis of (nbatch, n, ninner) arrays: out[b, q, c] = f(scale x sum_j W[q, j] y[b, j, c]), c contiguous --
+// the redshift interpolation of batches of (z, k) tables whose rows along k feed the FFTLog next (P(k, z) tables are splined in log10 P: f =
+// 10^x in the epilogue writes the spectra once, z-major, instead of interpolating, transposing and exponentiating in three passes).
+// Here the operator is the A matrix, A[m = l & 15][k = l >> 4] = W[q0 + m][j], and y the B matrix, B[k = l >> 4][n = l & 15] =
+// y[b, j, c0 + n]: per k step a lane group reads 16 consecutive doubles of one row j (128-byte segments, four adjacent ones for the four
+// column tiles of a wave).  Wave tile 64 queries x 64 columns (4 x 4 accumulator tiles); the four waves of a workgroup take adjacent columns.
+struct MidArgs {
+    const double* y;
+    double* out;
+    long long nbatch, ninner;
+    int n, nq, n_pad, nq_pad;
+    const double* w;   // (nq_pad, n_pad), zero padded
+    const int* j0;     // (nq): < 0 marks a query that evaluates to NaN
+    int post_op;
+    double scale;
+};
+
+__global__ __launch_bounds__(256) void linop_mid_mfma_kernel(const MidArgs A) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    const long long nct = (A.ninner + 255) / 256;     // column tiles of 256 (64 per wave)
+    const int nqt = A.nq_pad / 64;
+    const long long nitems = A.nbatch * nct * nqt;
+    // a small operator (one tile of 64 queries, at most 32 knots: the redshift grids of P(k, z) tables) stays in registers for all items
+    const bool resident = nqt == 1 && A.n_pad <= 32;
+    double wres[8][4];
+    if (resident) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wres[s][i] = 4 * s < A.n_pad ? A.w[(long long)(16 * i + l15) * A.n_pad + 4 * s + g] : 0.;
+    }
+    for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int qt = (int)(item % nqt);
+        const long long ct = (item / nqt) % nct, b = item / (nqt * nct);
+        const long long c0 = ct * 256 + wave * 64;
+        if (c0 >= A.ninner) continue;
+        const int q0 = qt * 64;
+        const double* yb = A.y + b * A.n * A.ninner;
+        cp_v4d acc[4][4];   // [query tile][column tile]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = cp_v4d{0., 0., 0., 0.};
+        long long col[4];
+        bool colok[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            col[j] = c0 + 16 * j + l15;
+            colok[j] = col[j] < A.ninner;
+            col[j] = colok[j] ? col[j] : A.ninner - 1;
+        }
+        auto step = [&](int kb, const double* a) {
+            const int jrow = kb + g;
+            double bv[4];
+            const bool rowok = jrow < A.n;     // W is zero in its padding, but y must not bring in another batch entry's values (0 x NaN)
+            const double* yr = yb + (long long)(rowok ? jrow : 0) * A.ninner;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = rowok ? yr[col[j]] : 0.;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
+        };
+        if (resident) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (4 * s < A.n_pad) step(4 * s, wres[s]);
+        } else {
+            for (int kb = 0; kb < A.n_pad; kb += 4) {
+                double a[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = A.w[(long long)(q0 + 16 * i + l15) * A.n_pad + kb + g];
+                step(kb, a);
+            }
+        }
+        double* ob = A.out + b * A.nq * A.ninner;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + 16 * i + g + 4 * r;
+                if (q >= A.nq) continue;
+                const bool nanq = A.j0[q] < 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!colok[j]) continue;
+                    double v = nanq ? __builtin_nan("") : acc[i][j][r] * A.scale;
+                    if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                    else if (A.post_op == CP_SPLINE_POST_EXP10) v = exp10(v);
+                    ob[(long long)q * A.ninner + col[j]] = v;
+                }
+            }
     }
 }
 
@@ -506,8 +604,8 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     p->nq_pad = (nq + 63) / 64 * 64;
     // the dense copy is kept for operators given as dense matrices (cp_linop_plan_create); the matrix cores are the default for them when
     // the band is wider than half the knots, and a measurement option otherwise (CP_SPLINE_PATH_MFMA)
-    const bool dense = keep_dense && n >= 16 && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
-    p->prefer_dense = dense && 2 * bw > n;
+    const bool dense = keep_dense && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
+    p->prefer_dense = dense && n >= 16 && 2 * bw > n;
     std::vector<double> wd;
     if (dense) {
         wd.assign((size_t)p->n_pad * p->nq_pad, 0.);
@@ -572,7 +670,8 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_spline_apply: null device pointer");
     const int path = post_op & (CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
     post_op &= ~(CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
-    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
+    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT && post_op != CP_SPLINE_POST_EXP10)
+        return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
     if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the operator is banded, it has no matrix-core path");
     // the vector kernel stages the knots under a tile of queries in LDS, 4 rows at least: operators wider than that only have the dense route
     const bool valu_fits = (size_t)4 * p->span_max * sizeof(double) <= 160 * 1024;
@@ -640,6 +739,31 @@ extern "C" int cp_spline_apply_outer(const cp_spline_plan* p, const double* d_y,
     const hipError_t e = rows == 8 ? launch_outer<8>(O, lds, hs) : rows == 4 ? launch_outer<4>(O, lds, hs) : launch_outer<2>(O, lds, hs);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply_outer: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+
+extern "C" int cp_linop_apply_mid(const cp_spline_plan* p, const double* d_y, double* d_out, long long nbatch, long long ninner, int post_op, double scale,
+                                  void* stream) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_linop_apply_mid: null plan");
+    if (nbatch < 0 || ninner < 0) return cp::fail(CP_EINVAL, "cp_linop_apply_mid: negative sizes");
+    if (nbatch == 0 || ninner == 0) return CP_OK;
+    if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_linop_apply_mid: null device pointer");
+    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT && post_op != CP_SPLINE_POST_EXP10)
+        return cp::fail(CP_EINVAL, "cp_linop_apply_mid: unknown post op %d", post_op);
+    if (!p->d_wdense) return cp::fail(CP_EUNSUPPORTED, "cp_linop_apply_mid: the plan holds no dense operator (create it with cp_linop_plan_create)");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_linop_apply_mid: cannot select device %d", p->device);
+    MidArgs M;
+    M.y = d_y; M.out = d_out; M.nbatch = nbatch; M.ninner = ninner; M.n = p->n; M.nq = p->nq; M.n_pad = p->n_pad; M.nq_pad = p->nq_pad;
+    M.w = p->d_wdense; M.j0 = p->d_j0; M.post_op = post_op; M.scale = scale;
+    const long long items = nbatch * ((ninner + 255) / 256) * (p->nq_pad / 64);
+    const int grid = (int)(items < 256 * 8 ? items : 256 * 8);
+    hipLaunchKernelGGL(linop_mid_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), M);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_linop_apply_mid: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
 

@@ -171,7 +171,7 @@ def _with_growth(sigma2, growth_sq):
     return (sigma2[..., :, None] * growth_sq[..., None, :]).sqrt()
 
 
-def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None, epsabs=1e-5, epsrel=1e-5):
+def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None, epsabs=1e-5, epsrel=1e-5, sqrt=False):
     r"""
     :math:`\sigma_r^2 = \frac{1}{2\pi^2}\int dk\,k^2 P(k) W^2(kr)` (reference interpolator.py:200-292) for rows of P(k).
 
@@ -181,6 +181,7 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         for every (row, r) by refining a composite Simpson rule in log k for the whole batch at once: see :func:`_refined_rule`.
     growth_sq : optional device tensor (..., nz), one row of factors per row of P(k): the result is then
         :math:`\sqrt{\sigma_r^2\,\mathrm{growth\_sq}(z)}` of shape (..., nr, nz), written once by the interpolation kernel.
+    sqrt : return :math:`\sigma_r` instead (the root taken by the kernel that interpolates to ``r``, method 'fftlog').
     """
     device = dv.resolve_device(device)
     rr = _host(r).ravel()
@@ -203,7 +204,10 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         # tmp = (2 pi^2) spline(var)(r); sigma^2 = tmp / (2 pi^2)  (interpolator.py:289-291)
         if growth_sq is not None:
             return op.outer(var, growth_sq, sqrt=True)
-        return op(var)
+        return op(var, sqrt=sqrt)
+    if sqrt:
+        return integrate_sigma_r2(r, pk_rows, kmin=kmin, kmax=kmax, method=method, nk=nk if method != 'leggauss' else nk_leggauss, device=device,
+                                  growth_sq=growth_sq, epsabs=epsabs, epsrel=epsrel).sqrt()
     if method == 'simpson':
         limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
         logk = np.linspace(*limits, nk)
@@ -531,14 +535,20 @@ class Interpolator2D(dv.Copyable):
             build = lambda: LinearOperator.dense(_fitpack_interp_operator(knots, q, k), device=self.device)
         return _cached_operator(('i2' + axis, k, knots.tobytes(), q.tobytes(), self.device.index), build)
 
-    def rows_y_major(self, xh, yh):
+    def rows_y_major(self, xh, yh, exp10=False):
         """The surfaces on the grid of flat host coordinates (xh, yh) as (batch..., ny, nx), x fastest -- the layout of rows of P(k) at every z --
-        evaluated y direction first: the y operator of a (k, z) table is dense (30 knots couple to every query: a GEMM on the matrix cores),
-        the x operator banded.  No mask, no back-transform of a log."""
+        in two passes: the x operator (banded spline kernel) on the table kept y-major, then the y operator along the middle axis as a GEMM on the
+        matrix cores whose epilogue applies 10^x when asked (tables splined in log10 P) and writes the result once.  No mask."""
         with np.errstate(all='ignore'):
             xq = np.log10(xh) if self.interp_x == 'log' else xh
-        opx, opy = self._operator('x', xq), self._operator('y', yh)
-        out = opx(opy(self._fun).transpose(-1, -2).contiguous())       # (batch..., nx, nyq) -> (batch..., nyq, nx) -> (batch..., nyq, nxq)
+        fun_t = self.__dict__.get('_fun_y_major', None)
+        if fun_t is None:
+            fun_t = self._fun_y_major = self._fun.transpose(-1, -2).contiguous()       # (batch..., ny, nx), once per object
+        knots, k = self._y, self.ky
+        yq = np.clip(yh, knots[0], knots[-1])
+        opy = _cached_operator(('i2y-dense', k, knots.tobytes(), yq.tobytes(), self.device.index),
+                               lambda: LinearOperator.dense(self._operator('y', yq, dense=True), device=self.device))
+        out = opy.mid(self._operator('x', xq)(fun_t), post='exp10' if exp10 else None)     # (batch..., ny, nxq) -> (batch..., nyq, nxq)
         if self._nan_surfaces is not None:
             out = dv.torch().where(self._nan_surfaces[..., None, None], dv.torch().full_like(out, float('nan')), out)
         return out
@@ -972,9 +982,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                 # (k, z) tables: the surfaces come out of the two spline operators z-major already (z contraction first), no transposed copy
                 torch = dv.torch()
                 mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)])
-                out = self._interp.rows_y_major(kh, zh)
-                if self._interp.interp_fun == 'log':
-                    out = 10**out
+                out = self._interp.rows_y_major(kh, zh, exp10=self._interp.interp_fun == 'log')
                 mask = mask_z[:, None] & mask_k
                 if not mask.all():
                     out = torch.where(dv.upload(mask, self.device), out, torch.full_like(out, float('nan')))
@@ -1054,7 +1062,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                                                                                  **kwargs), zh.ravel())
             out = base[..., :, None] * growth[..., None, :]
         else:
-            out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+            out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True, **kwargs)
             out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
         return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
 

@@ -60,6 +60,23 @@ class LinearOperator(object):
                                                    dv.stream_of(self.device)))
         return out
 
+    _POSTS = {None: 0, 'sqrt': 1, 'exp10': 2}       # CP_SPLINE_POST_*
+
+    def mid(self, y, post=None, scale=1.):
+        """y : (..., n, m) device tensor -> (..., nq, m) = post(scale x sum_j W[q, j] y[..., j, :]): the operator along the last-but-one axis, the
+        last axis left contiguous (``cp_linop_apply_mid``, matrix cores; operators built with :meth:`dense` only).  post : None, 'sqrt' or 'exp10'."""
+        torch = dv.torch()
+        y = dv.to_device(y, self.device)
+        if y.ndim < 2 or y.shape[-2] != self.n:
+            raise ValueError('last-but-one dimension must be {:d}, got {}'.format(self.n, tuple(y.shape)))
+        lead, m = tuple(y.shape[:-2]), int(y.shape[-1])
+        nb = int(np.prod(lead, dtype=np.int64))
+        out = torch.empty(lead + (self.nq, m), dtype=torch.float64, device=self.device)
+        if nb and m:
+            _lib.check(_lib.load().cp_linop_apply_mid(self._handle, y.data_ptr(), out.data_ptr(), nb, m, self._POSTS[post], float(scale),
+                                                      dv.stream_of(self.device)))
+        return out
+
     def outer(self, y, g, sqrt=False, scale=1.):
         """y : (..., n), g : (..., nz) device tensors with the same leading shape -> (..., nq, nz) = f(scale x (W y)[..., q] x g[..., z]), f = sqrt or
         identity, written once by the kernel that interpolates (``cp_spline_apply_outer``)."""

@@ -224,7 +224,7 @@ int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_ome
  *      the clamped second-derivative splines of wallish2018, bao_filter.py:377-382) ---- */
 enum cp_spline_bc { CP_SPLINE_NATURAL = 0 /* y'' = 0 */, CP_SPLINE_CLAMPED = 1 /* y' = 0 */, CP_SPLINE_NOT_A_KNOT = 2 /* scipy default, == FITPACK s=0 */ };
 enum cp_spline_post {
-    CP_SPLINE_POST_NONE = 0, CP_SPLINE_POST_SQRT = 1,
+    CP_SPLINE_POST_NONE = 0, CP_SPLINE_POST_SQRT = 1, CP_SPLINE_POST_EXP10 = 2 /* 10^x: tables splined in log10 P come out as P */,
     /* OR-ed into post_op of cp_spline_apply, for measurements: force the banded vector-ALU kernel / the dense matrix-core (MFMA f64) kernel; by
      * default operators whose band is wider than half the knots (cp_linop_plan_create: quadrature weights, projectors) take the matrix cores */
     CP_SPLINE_PATH_VALU = 16, CP_SPLINE_PATH_MFMA = 32
@@ -243,6 +243,11 @@ int cp_spline_apply_outer(const cp_spline_plan* plan, const double* d_y, const d
  * marks a query that evaluates to NaN): the composite-Simpson weights of integrate_sigma_r2 / integrate_sigma_d2 method 'simpson'
  * (interpolator.py:190-196, 280-284 with jax.py:365-507) are applied this way */
 int cp_linop_plan_create(cp_spline_plan** plan, int n, int nq, const double* w_dense, int device);
+/* a dense operator along the MIDDLE axis: d_out[b, q, c] = post_op(scale * sum_j W[q, j] d_y[b, j, c]);  d_y : (nbatch, n, ninner), d_out :
+ * (nbatch, nq, ninner), c contiguous.  The redshift interpolation of batches of (z, k) tables, written z-major for the FFTLog: the y direction of
+ * RectBivariateSpline (jax.py:241-271) in PowerSpectrumInterpolator2D.sigma_rz (interpolator.py:846-875).  Plans of cp_linop_plan_create only. */
+int cp_linop_apply_mid(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nbatch, long long ninner, int post_op, double scale,
+                       void* stream);
 int cp_spline_plan_destroy(cp_spline_plan* plan);
 int cp_spline_plan_info(const cp_spline_plan* plan, int* n, int* nq, int* bandwidth);
 /* the dense operator W (nq x n, row-major, host) and per-query inside-range flags: what the plan is built from */

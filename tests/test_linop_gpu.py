@@ -68,3 +68,38 @@ def test_outer_epilogue():
     outside = LinearOperator.spline(np.log(x), np.log(np.array([1e-3, 1., 1e3])), bc='natural')
     res = outside.outer(y[:2], g[:2])
     assert bool(torch.isnan(res[:, 0]).all()) and bool(torch.isnan(res[:, 2]).all()) and bool(torch.isfinite(res[:, 1]).all())
+
+
+@pytest.mark.parametrize('n,nq,m,nb', [(5, 1, 1, 1), (30, 64, 1024, 7), (33, 70, 300, 3), (16, 130, 257, 2), (30, 64, 64, 100)])
+def test_dense_operator_along_the_middle_axis(n, nq, m, nb):
+    """``cp_linop_apply_mid``: out[b, q, c] = post(scale sum_j W[q, j] y[b, j, c]) against numpy, every edge of the 64 x 256 tiling, the three
+    epilogues, NaN queries, and a NaN in one batch entry (or one column) staying where it is."""
+    import torch
+    from cosmoprimo_amd.spline import LinearOperator
+    rng = np.random.default_rng(n + nq + m)
+    w = rng.normal(size=(nq, n)) / np.sqrt(n)
+    if nq > 3:
+        w[3] = np.nan
+    y = rng.normal(size=(nb, n, m))
+    op = LinearOperator.dense(w)
+    ty = torch.as_tensor(y, device=op.device)
+    ref = np.einsum('qj,bjc->bqc', w, y)
+    scale = np.abs(y).max() * np.nanmax(np.abs(w)) * n
+    got = op.mid(ty).cpu().numpy()
+    assert got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.nanmax(np.abs(got - ref)) < 1e-14 * scale
+    np.testing.assert_allclose(op.mid(ty, post='exp10', scale=0.5).cpu().numpy(), 10**(0.5 * ref), rtol=1e-13)
+    both = op.mid(ty.abs(), post='sqrt', scale=2.).cpu().numpy()
+    ref2 = 2. * np.einsum('qj,bjc->bqc', w, np.abs(y))
+    keep = np.isfinite(both) & (ref2 > 0)
+    np.testing.assert_allclose(both[keep]**2, ref2[keep], rtol=0., atol=4e-14 * scale)
+    y2 = y.copy()
+    y2[nb // 2, n - 1, m // 2] = np.nan
+    got = op.mid(torch.as_tensor(y2, device=op.device)).cpu().numpy()
+    rows = [q for q in range(nq) if q != 3]
+    bad = np.isnan(got[:, rows])
+    assert bad[nb // 2, :, m // 2].all() and bad.sum() == len(rows)
+    with pytest.raises(ValueError):
+        op.mid(ty[:, :-1])
+    with pytest.raises(NotImplementedError):
+        LinearOperator.spline(np.linspace(0., 1., 40), np.linspace(0., 1., 7)).mid(torch.zeros((2, 40, 8), dtype=torch.float64, device=op.device))
