@@ -161,42 +161,46 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 if (has_b) ob[at(N - 1 - k)] = skip_b ? nan : f * yb;
             }
         } else {
-            // Hermitian-symmetrised, conjugated spectrum of the pair; keep_a / keep_b: rows that take part
+            // first the flags (the rows are read again below, from L1: keeping 64 samples in registers across the barrier would spill)
             bool bad_a = false, bad_b = false;
-            auto spectrum = [&](bool keep_a, bool keep_b) {
 #pragma unroll
-                for (int r = 0; r < P; ++r) {
-                    const int k = tt + T * r;
-                    const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
-                    const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
-                    const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-                    const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
-                    const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
-                    bad_a |= !(fabs(Aa) <= 1.7976931348623157e308) || !(fabs(Ba) <= 1.7976931348623157e308);
-                    bad_b |= !(fabs(Ab) <= 1.7976931348623157e308) || !(fabs(Bb) <= 1.7976931348623157e308);
-                    const cplx rot = A.rot[k];
-                    const double cs = rot.re, sn = -rot.im;
-                    cplx Ha, Hb;
-                    if (k == 0) {
-                        Ha = cplx{Aa, 0.};
-                        Hb = cplx{Ab, 0.};
-                    } else {
-                        Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
-                        Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
-                    }
-                    if (!keep_a) Ha = cplx{0., 0.};
-                    if (!keep_b) Hb = cplx{0., 0.};
-                    // conj(H_a + i H_b)
-                    x[r].re = Ha.re - Hb.im;
-                    x[r].im = -(Ha.im + Hb.re);
-                }
-            };
-            spectrum(true, has_b);
+            for (int r = 0; r < P; ++r) {
+                const int k = tt + T * r;
+                const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
+                bad_a |= !(fabs(ra[at(ia)]) <= 1.7976931348623157e308) || !(fabs(ra[at(ib)]) <= 1.7976931348623157e308);
+                bad_b |= !(fabs(rb[at(ia)]) <= 1.7976931348623157e308) || !(fabs(rb[at(ib)]) <= 1.7976931348623157e308);
+            }
             if (bad_a) bad_row[0] = 1;
             if (bad_b) bad_row[1] = 1;
             __syncthreads();
+            asm volatile("" : "+v"(tt));
             const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
-            if (skip_a | skip_b) spectrum(!skip_a, has_b && !skip_b);   // rare: the spectrum again without the bad row
+            const bool keep_a = !skip_a, keep_b = has_b && !skip_b;
+            // Hermitian-symmetrised, conjugated spectrum of the pair; a row that is skipped does not take part
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const int k = tt + T * r;
+                const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
+                const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
+                const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
+                const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
+                const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
+                const cplx rot = A.rot[k];
+                const double cs = rot.re, sn = -rot.im;
+                cplx Ha, Hb;
+                if (k == 0) {
+                    Ha = cplx{Aa, 0.};
+                    Hb = cplx{Ab, 0.};
+                } else {
+                    Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
+                    Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
+                }
+                if (!keep_a) Ha = cplx{0., 0.};
+                if (!keep_b) Hb = cplx{0., 0.};
+                // conj(H_a + i H_b)
+                x[r].re = Ha.re - Hb.im;
+                x[r].im = -(Ha.im + Hb.re);
+            }
             dif_all<N, P>(tt, A, x, lds, ltw);
             asm volatile("" : "+v"(tt));
             // LDS holds (v_a[m], -v_b[m]) at pos(m); undo the reordering and the (-1)^n sign

@@ -202,6 +202,7 @@ struct DenseArgs {
     int n, nq, n_pad, nq_pad;
     const double* w;   // (nq_pad, n_pad), zero padded
     const int* j0;     // (nq): < 0 marks a query that evaluates to NaN
+    const int* kwin;   // (nq_pad / 64, 2): the knots [lo, hi), multiples of 16, that the bands of each tile of 64 queries cover
     int post_op;
     double scale;
 };
@@ -230,7 +231,9 @@ __global__ __launch_bounds__(256) void linop_mfma_kernel(const DenseArgs A) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) wr[j] = A.w + (long long)(q0 + 16 * j + l15) * A.n_pad;
-        for (int kb = 0; kb < A.n_pad; kb += 16) {
+        // a banded operator (spline) is a block-banded GEMM: the wave's 64 queries only couple to the knots of their window
+        const int klo = A.kwin[2 * (q0 >> 6)], khi = A.kwin[2 * (q0 >> 6) + 1];
+        for (int kb = klo; kb < khi; kb += 16) {
             const int k = kb + 4 * g;
             double a[2][4];
             cp_v4d b[4];
@@ -456,6 +459,7 @@ struct cp_spline_plan {
     int* d_tile;
     int ntiles, span_max;
     double* d_wdense;    // operators that are dense (band wider than half the knots): (nq_pad, n_pad) row-major, zero padded, for the MFMA kernel
+    int* d_kwin;         // windows of knots per tile of 64 queries, for the matrix-core kernel
     int n_pad, nq_pad;
     bool prefer_dense;
 };
@@ -469,6 +473,7 @@ extern "C" int cp_spline_plan_destroy(cp_spline_plan* p) {
     if (p->d_j0) (void)hipFree(p->d_j0);
     if (p->d_tile) (void)hipFree(p->d_tile);
     if (p->d_wdense) (void)hipFree(p->d_wdense);
+    if (p->d_kwin) (void)hipFree(p->d_kwin);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     delete p;
     return CP_OK;
@@ -600,18 +605,38 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     p->n = n; p->nq = nq; p->bw = bw; p->device = device; p->d_wb = nullptr; p->d_j0 = nullptr; p->d_tile = nullptr;
     p->ntiles = ntiles; p->span_max = span_max;
     p->d_wdense = nullptr;
+    p->d_kwin = nullptr;
     p->n_pad = (n + 15) / 16 * 16;
     p->nq_pad = (nq + 63) / 64 * 64;
-    // the dense copy is kept for operators given as dense matrices (cp_linop_plan_create); the matrix cores are the default for them when
-    // the band is wider than half the knots, and a measurement option otherwise (CP_SPLINE_PATH_MFMA)
+    // A dense copy (zero outside the bands) serves the matrix-core kernel, which treats the operator as a block-banded GEMM: a tile of 64
+    // queries times the window of knots its bands cover.  That does (window / bandwidth) times the multiply-adds of the banded vector kernel
+    // but at about five times its rate (the vector kernel reads one LDS word per multiply-add): the matrix cores are the default up to a
+    // factor 3 -- dense operators (quadrature weights, projectors: factor 1), splines between grids of similar density (factor 1.5 for 504 ->
+    // 1024 knots of a P(k) table) -- and a measurement option otherwise (CP_SPLINE_PATH_MFMA; 1024 -> 256 radii: factor 5, and HBM-bound anyway).
     const bool dense = keep_dense && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
-    p->prefer_dense = dense && n >= 16 && 2 * bw > n;
     std::vector<double> wd;
+    std::vector<int> kwin((size_t)2 * (p->nq_pad / 64), 0);
     if (dense) {
         wd.assign((size_t)p->n_pad * p->nq_pad, 0.);
+        double work = 0.;
         for (int q = 0; q < nq; ++q)
             if (j0[q] >= 0)
-                for (int j = 0; j < n; ++j) wd[(size_t)q * p->n_pad + j] = w[(size_t)q * n + j];
+                for (int j = j0[q]; j <= j1[q]; ++j) wd[(size_t)q * p->n_pad + j] = w[(size_t)q * n + j];
+        for (int t = 0; t < p->nq_pad / 64; ++t) {
+            int lo = n, hi = 0;
+            for (int q = 64 * t; q < 64 * (t + 1) && q < nq; ++q)
+                if (j0[q] >= 0) {
+                    lo = j0[q] < lo ? j0[q] : lo;
+                    hi = j1[q] + 1 > hi ? j1[q] + 1 : hi;
+                }
+            if (hi <= lo) lo = hi = 0;
+            kwin[2 * t] = lo / 16 * 16;
+            kwin[2 * t + 1] = (hi + 15) / 16 * 16;
+            work += 64. * (kwin[2 * t + 1] - kwin[2 * t]);
+        }
+        p->prefer_dense = n >= 16 && work <= 3. * (double)nq * bw;
+    } else {
+        p->prefer_dense = false;
     }
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
@@ -626,7 +651,9 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
         status = cp::fail(CP_EDEVICE, "cp_spline_plan_create: upload failed");
     if (status == CP_OK && dense &&
         (hipMalloc(&p->d_wdense, wd.size() * sizeof(double)) != hipSuccess ||
-         hipMemcpy(p->d_wdense, wd.data(), wd.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess))
+         hipMemcpy(p->d_wdense, wd.data(), wd.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+         hipMalloc(&p->d_kwin, kwin.size() * sizeof(int)) != hipSuccess ||
+         hipMemcpy(p->d_kwin, kwin.data(), kwin.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess))
         status = cp::fail(CP_ENOMEM, "cp_spline_plan_create: cannot upload the dense operator");
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (status != CP_OK) {
@@ -645,7 +672,7 @@ extern "C" int cp_spline_plan_create(cp_spline_plan** out, int n, const double* 
     std::vector<double> w((size_t)nq * n);
     int st = cp_spline_operator(n, x, nq, xq, bc, nu, extrapolate, w.data(), nullptr);
     if (st != CP_OK) return st;
-    return plan_from_dense(out, n, nq, w.data(), device, false);
+    return plan_from_dense(out, n, nq, w.data(), device, true);
 }
 
 extern "C" int cp_linop_plan_create(cp_spline_plan** out, int n, int nq, const double* w_dense, int device) {
@@ -672,7 +699,7 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     post_op &= ~(CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT && post_op != CP_SPLINE_POST_EXP10)
         return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
-    if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the operator is banded, it has no matrix-core path");
+    if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the plan holds no dense copy of the operator (more than 256 MB), it has no matrix-core path");
     // the vector kernel stages the knots under a tile of queries in LDS, 4 rows at least: operators wider than that only have the dense route
     const bool valu_fits = (size_t)4 * p->span_max * sizeof(double) <= 160 * 1024;
     if (p->d_wdense && path != CP_SPLINE_PATH_VALU &&
@@ -682,7 +709,7 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
         if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: cannot select device %d", p->device);
         DenseArgs D;
         D.y = d_y; D.out = d_out; D.nrows = nrows; D.n = p->n; D.nq = p->nq; D.n_pad = p->n_pad; D.nq_pad = p->nq_pad; D.w = p->d_wdense; D.j0 = p->d_j0;
-        D.post_op = post_op; D.scale = scale;
+        D.kwin = p->d_kwin; D.post_op = post_op; D.scale = scale;
         const long long items = ((nrows + 31) / 32) * ((p->nq_pad + 255) / 256);
         const int grid = (int)(items < 256 * 4 ? items : 256 * 4);
         hipLaunchKernelGGL(linop_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), D);
