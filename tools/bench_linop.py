@@ -36,28 +36,30 @@ def main():
 
 
 def spline_contraction():
-    """The k contraction of a (k, z) table (not-a-knot cubic spline from 504 log-k knots to the 1024 FFTLog wavenumbers, 64 redshifts x 10 000
-    cosmologies = 640 000 rows) as a banded operator on the vector ALUs and, forced dense, as a GEMM on the matrix cores."""
+    """Spline operators of the package as banded operators on the vector ALUs and as block-banded GEMMs on the matrix cores (a tile of 64 queries
+    times the window of knots under its bands): the k contraction of (k, z) tables, the FFTLog grid to radii, the two operators of wallish2018."""
     import torch
-    from cosmoprimo_amd.spline import LinearOperator, dense_operator
+    from cosmoprimo_amd.spline import LinearOperator
     dev = torch.device('cuda', 0)
-    x, xq = np.linspace(-7., 2., 504), np.linspace(-7., 2., 1024)
-    banded = LinearOperator.spline(x, xq, bc='not-a-knot', device=dev)
-    dense = LinearOperator.dense(dense_operator(x, xq, bc='not-a-knot'), device=dev)
-    y = torch.as_tensor(np.random.default_rng(1).normal(size=(640000, 504)), device=dev)
-    line = '%-62s' % '(k, z) table, k contraction: 504 -> 1024, 640 000 rows'
-    for name, op, path in (('banded valu (bandwidth %d)' % banded.bandwidth, banded, None), ('dense mfma', dense, 'mfma')):
-        for _ in range(5):
-            out = op(y, path=path)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            out = op(y, path=path)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / 5 * 1e3
-        line += '  %s %.3f ms' % (name, ms)
-    print(line)
-    print('   (difference of the two results: %.1e)' % float((banded(y[:1000]) - dense(y[:1000], path='mfma')).abs().max()))
+    klin = np.linspace(1e-4, 10., 3666)
+    cases = [('(k, z) tables, k contraction: 504 -> 1024 log k, 640 000 rows', np.linspace(-7., 2., 504), np.linspace(-7., 2., 1024), 'not-a-knot', 0, 640000),
+             ('FFTLog grid -> radii: 1024 -> 256, 640 000 rows', np.linspace(-2., 7., 1024), np.linspace(0., 2., 256), 'natural', 0, 640000),
+             ('wallish2018 second derivatives: 2048 -> 2048, 32 768 rows', 1. + np.arange(2048.), 1. + np.arange(2048.), 'clamped', 2, 32768),
+             ('wallish2018 splice: 3666 linear knots -> 1024 log k, 16 384 rows', klin, np.geomspace(2e-4, 9.9, 1024), 'clamped', 0, 16384)]
+    for name, x, xq, bc, nu, nrows in cases:
+        op = LinearOperator.spline(x, xq, bc=bc, nu=nu, device=dev)
+        y = torch.as_tensor(np.random.default_rng(1).normal(size=(nrows, x.size)), device=dev)
+        line = '%-68s bandwidth %3d' % (name, op.bandwidth)
+        for path in ('valu', 'mfma', None):
+            for _ in range(5):
+                op(y, path=path)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                op(y, path=path)
+            torch.cuda.synchronize()
+            line += '  %s %.3f ms' % (path or 'default', (time.perf_counter() - t0) / 5 * 1e3)
+        print(line + '  (paths differ by %.1e)' % float((op(y[:1000], path='valu') - op(y[:1000], path='mfma')).abs().max()))
 
 
 if __name__ == '__main__':
