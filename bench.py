@@ -82,10 +82,24 @@ def cpu_baseline(seconds=10.):
             'per_core_value': float(np.mean([r[0] / r[1] for r in res]))}
 
 
-def _gpu_ms(fn, reps, torch, dev):
-    """(wall ms, HIP-event ms) per call of fn() on the current stream, after one untimed call."""
+RAMP_S = 0.3
+
+
+def _ramp(fn, torch, dev, seconds=None):
+    """Untimed load in front of a measurement: after an idle period (or lighter work) the first tens of milliseconds run ~10 % and more below the
+    sustained rate (see the ramp of the headline measurement in main()); every secondary config is timed behind ``seconds`` of its own work."""
+    seconds = RAMP_S if seconds is None else seconds
     fn()
     torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        fn()
+        torch.cuda.synchronize(dev)
+
+
+def _gpu_ms(fn, reps, torch, dev):
+    """(wall ms, HIP-event ms) per call of fn() on the current stream, behind the untimed ramp."""
+    _ramp(fn, torch, dev)
     stream = torch.cuda.current_stream(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -144,8 +158,7 @@ def config4(cp, torch, dev, par, chunk=16384):
                     state['filter'](interp, cosmo=cosmo if kw else None)
                 return state['filter']._pknow_rows
 
-            run(slice(0, min(n, chunk)))       # plans, operators and code objects are built on first use
-            torch.cuda.synchronize(dev)
+            _ramp(lambda: run(slice(0, min(n, chunk))), torch, dev)       # plans, operators and code objects are built on first use; clock ramp
             stream = torch.cuda.current_stream(dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
@@ -207,6 +220,8 @@ def main_split(args, config):
     """--config 4 / 5: strong split of the BASELINE 8-GPU workloads over the ranks, no data-path collective; rank 0 prints one JSON line."""
     import torch
     import torch.distributed as dist
+    global RAMP_S
+    RAMP_S = 0.     # the W untimed steps of this mode are whole passes over the rank's share (hundreds of ms each): they are the ramp
     rank, local_rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -279,7 +294,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--gather', action='store_true', help='also time the final RCCL all_gather of the result shards (reported separately)')
     ap.add_argument('--config', type=int, default=2, choices=[2, 4, 5], help='BASELINE.json config: 2 (headline, weak scaling), 4 or 5 (strong splits)')
-    ap.add_argument('--ramp-ms', type=float, default=300., help='untimed load before the warmup steps, to reach the sustained device state')
+    ap.add_argument('--ramp-ms', type=float, default=300., help='untimed load before the warmup steps (and before each secondary config), to reach the sustained device state')
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs 3 / 4 / 5 numbers of the N = 1 line')
     args = ap.parse_args()
     if args.config != 2:
@@ -438,6 +453,8 @@ def main():
         if cpu is not None:
             line['cpu_baseline'] = cpu
         if world == 1 and not args.no_secondary:
+            global RAMP_S
+            RAMP_S = args.ramp_ms * 1e-3
             del rows, out
             torch.cuda.empty_cache()
             line['secondary'] = secondary(cp, torch, dev)
