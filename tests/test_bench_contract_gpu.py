@@ -1,0 +1,48 @@
+"""GPU: bench.py's contract with the driver -- one JSON line with the agreed keys, at N = 1 directly and under torchrun with one rank (RCCL
+initialised, barriers, the optional gather) -- on a small batch so that the test takes seconds."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'}
+
+
+def run(cmd):
+    res = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [line for line in res.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def check(line, steps, warmup):
+    assert KEYS <= set(line), KEYS - set(line)
+    assert line['steps'] == steps and line['warmup'] == warmup and line['n_gpus'] == 1 and line['higher_is_better'] is True
+    assert line['dtype'] == 'f64' and line['data'] == 'synthetic' and line['vs_baseline'] is None and 'workload' in line['config']
+    assert line['value'] > 0 and line['ms_per_step'] > 0
+    roof = line['roofline']
+    assert {'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'} <= set(roof) and roof['bound'] == 'hbm' and roof['peak'] == 8000.
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-12
+    assert line['parity_spot_check_tilted_err'] < 1e-13
+
+
+def test_single_process_line():
+    line = run([sys.executable, 'bench.py', '--rows', '4000', '--steps', '3', '--warmup', '1', '--ramp-ms', '20', '--no-cpu-baseline', '--no-secondary'])
+    check(line, 3, 1)
+    assert line['scaling'] == 'weak' and line['config']['rccl_ranks'] == 0 and line['value_api'] > 0
+
+
+def test_one_rank_under_torchrun():
+    base = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1']
+    line = run(base + ['--master-port', '29541', 'bench.py', '--gpus', '1', '--rows', '4000', '--steps', '3', '--warmup', '1', '--ramp-ms', '20',
+                       '--no-cpu-baseline', '--no-secondary', '--gather'])
+    check(line, 3, 1)
+    assert line['config']['rccl_ranks'] == 1 and line['gather_ms'] > 0 and line['value_with_gather'] > 0
+    split = run(base + ['--master-port', '29542', 'bench.py', '--gpus', '1', '--config', '5', '--rows', '200000', '--steps', '2', '--warmup', '1', '--gather'])
+    assert split['scaling'] == 'strong' and split['config']['rccl_ranks'] == 1 and split['value'] > 0 and split['unit'] == 'samples/s'
