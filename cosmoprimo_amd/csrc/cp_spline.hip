@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void spline_outer_kernel(const OuterArgs O) {
             const long long row = r0 + (r < nr ? r : nr - 1);
             const double* yr = A.y + row * A.n + tj0;
             for (int i = tid; i < span; i += 256) ylds[r * A.span_max + i] = yr[i];
-            for (int i = tid; i < nz; i += 256) glds[r * nz + i] = O.g[row * nz + i];
+            // f = sqrt: sqrt(v g) is written as sqrt(v) sqrt(g) -- nq + nz roots per row instead of nq nz (both factors are >= 0 or the result is NaN either way)
+            for (int i = tid; i < nz; i += 256) glds[r * nz + i] = A.post_op == CP_SPLINE_POST_SQRT ? sqrt(O.g[row * nz + i]) : O.g[row * nz + i];
         }
         __syncthreads();
         if (tid < nqt) {
@@ -169,32 +170,35 @@ __global__ __launch_bounds__(256) void spline_outer_kernel(const OuterArgs O) {
                 }
             }
 #pragma unroll
-            for (int r = 0; r < R; ++r) vlds[r * TILE_Q + tid] = j0 >= 0 ? acc[r] * A.scale : __builtin_nan("");
+            for (int r = 0; r < R; ++r) {
+                const double v = j0 >= 0 ? acc[r] * A.scale : __builtin_nan("");
+                vlds[r * TILE_Q + tid] = A.post_op == CP_SPLINE_POST_SQRT ? sqrt(v) : v;
+            }
         }
         __syncthreads();
-        const long long block = (long long)nqt * nz;   // values of one row of this tile, contiguous in the output
+        const int block = nqt * nz;   // values of one row of this tile, contiguous in the output (nqt <= 256: well below 2^31 for any sensible nz)
+        // element e = q nz + z of the block; a thread walks e = e0 + stride i without dividing: (q, z) advance by (stride / nz, stride % nz)
+        const int stride = (nz & 1) == 0 ? 512 : 256, e0 = (nz & 1) == 0 ? 2 * tid : tid;
+        const int dq = stride / nz, dz = stride - dq * nz, q_first = e0 / nz, z_first = e0 - q_first * nz;
         for (int r = 0; r < nr; ++r) {
             double* dst = A.out + ((r0 + r) * A.nq + q0) * nz;
             const double* vr = vlds + r * TILE_Q;
             const double* gr = glds + r * nz;
+            int q = q_first, z = z_first;
             if ((nz & 1) == 0) {
-                for (long long e = 2LL * tid; e < block; e += 512) {
-                    const int q = (int)(e / nz), z = (int)(e - (long long)q * nz);
+                for (int e = e0; e < block; e += 512) {
                     double2 v;
                     v.x = vr[q] * gr[z];
                     v.y = vr[q] * gr[z + 1];
-                    if (A.post_op == CP_SPLINE_POST_SQRT) {
-                        v.x = sqrt(v.x);
-                        v.y = sqrt(v.y);
-                    }
                     *reinterpret_cast<double2*>(dst + e) = v;
+                    q += dq; z += dz;
+                    if (z >= nz) { z -= nz; ++q; }
                 }
             } else {
-                for (long long e = tid; e < block; e += 256) {
-                    const int q = (int)(e / nz), z = (int)(e - (long long)q * nz);
-                    double v = vr[q] * gr[z];
-                    if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
-                    dst[e] = v;
+                for (int e = e0; e < block; e += 256) {
+                    dst[e] = vr[q] * gr[z];
+                    q += dq; z += dz;
+                    if (z >= nz) { z -= nz; ++q; }
                 }
             }
         }
