@@ -121,9 +121,9 @@ __device__ __forceinline__ double efunc_ln(const Cosmo& c, double z, double lzp1
 }
 
 // exp(x) for the 237 ordinates of a distance: round(x / ln 2), ln 2 in two pieces, the degree-13 Taylor polynomial on |r| <= ln(2) / 2 (remainder
-// 4e-18), ldexp -- relative error below 2e-16, 20 instructions for the library's 35 (which also serves subnormal results and the overflow edge)
+// 4e-18), ldexp -- relative error below 2e-16, 20 instructions for the library's 35
 __device__ __forceinline__ double exp_mid(double x) {
-    if (!(fabs(x) < 700.)) return exp(x);
+    x = x < -746. ? -746. : (x > 710. ? 710. : x);   // 0 and Inf beyond the range of double through ldexp; NaN passes
     const double n = rint(x * 1.4426950408889634);
     double r = fma(-n, 0.6931471803691238, x);
     r = fma(-n, 1.9082149292705877e-10, r);

@@ -146,7 +146,7 @@ __device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh
     const double ks = kh * d.ks_per_kh;
     const double ln_beta = log_pos(kE + d.beta18 * q);
     const double ln_nobeta = log_pos(kE + 1.8 * q);
-    const double q108 = exp(1.08 * (ln_kh + d.ln_q_over_kh));
+    const double q108 = exp_mid(1.08 * (ln_kh + d.ln_q_over_kh));
     const double c386 = 386. * recip(1 + 69.9 * q108);
     const double C_alpha = d.c_alpha0 + c386, C_noalpha = 14.2 + c386;
     const double ks54 = ks * (1. / 5.4), ks52 = ks * (1. / 5.2);
@@ -159,7 +159,7 @@ __device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh
     const double ks3 = ks * ks * ks;
     const double ks_tilde = ks * ks * rcbrt(ks3 + d.beta_node3);         // k rs_drag / cbrt(1 + (beta_node / ks)^3)
     const double T_b_1 = ln_nobeta * recip((ln_nobeta + C_noalpha * q2) * fma(ks52, ks52, 1.));
-    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * exp(-exp(1.4 * (ln_kh + d.ln_ksilk_over_kh)));
+    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * exp_mid(-exp_mid(1.4 * (ln_kh + d.ln_ksilk_over_kh)));
     const double sinc = ks_tilde == 0. ? 1. : sin_bounded(ks_tilde) * recip(ks_tilde);   // numpy.sinc(x / pi)
     const double T_b = sinc * (T_b_1 + T_b_2);
     return d.frac_b * T_b + (1 - d.frac_b) * T_c;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
                 continue;
             }
             const double lnkkp = ln_kh - ln_kp;
-            const double tilt = exp((n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp)) * lnkkp);
+            const double tilt = exp_mid((n_s - 1. + 1. / 2. * alpha_s * lnkkp + 1. / 6. * beta_s * (lnkkp * lnkkp)) * lnkkp);
             if (A.what == CP_PK_PRIMORDIAL) {
                 out[0] = (c.h * c.h * c.h) * A_s * tilt;
                 continue;
