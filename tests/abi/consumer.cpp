@@ -1,6 +1,7 @@
 // tests/abi/consumer.cpp -- a consumer of the C ABI that is neither Python nor torch: plain HIP runtime allocations, plain pointers.
 // Builds a small plan from arbitrary tables, runs cp_fftlog_execute and checks the result against a direct O(N^2) evaluation of the
-// reference arithmetic irfft(conj(rfft(pad(f) * pre) * u), n=Np) * post, cropped (cosmoprimo/fftlog.py:228-241).
+// reference arithmetic irfft(conj(rfft(pad(f) * pre) * u), n=Np) * post, cropped (cosmoprimo/fftlog.py:228-241); then the whole P(k) -> xi(s) -> P(k)
+// path with the tables built behind the boundary (cp_fftlog_tables), against an analytic pair.
 //   hipcc --offload-arch=gfx950 -O2 -I include -o consumer tests/abi/consumer.cpp -L cosmoprimo_amd -lcosmoprimo_amd -Wl,-rpath,$PWD/cosmoprimo_amd
 #include <hip/hip_runtime.h>
 
@@ -92,6 +93,66 @@ int main() {
     }
     printf("worst relative error %.3g (n = %d)\n", worst, worst_n);
     if (!(worst < 1e-12)) return 2;
+    // ---- the whole path behind the boundary: log grid -> cp_fftlog_tables (P -> xi convention, fftlog.py:318-330) -> plan -> execute, checked
+    //      against the analytic pair P(k) = exp(-a^2 k^2) <-> xi(s) = exp(-s^2 / 4 a^2) / (8 pi^1.5 a^3), then back with the xi -> P tables
+    //      (fftlog.py:368-377); row 1 of the batch carries a NaN and must stay alone with it
+    {
+        const int n = 1024, nker = 1, nbatch = 3;
+        const double a = 2.;
+        std::vector<double> k(n);
+        for (int i = 0; i < n; ++i) k[i] = std::pow(10., -5. + 8. * i / (n - 1));
+        const int npad = cp_fftlog_padded_size(n, 2);
+        if (npad != 2048) return 4;
+        const int nh = npad / 2 + 1;
+        auto tables = [&](const std::vector<double>& x, double pre_const, std::vector<double>& y, std::vector<double>& pre, std::vector<double>& post,
+                          std::vector<double>& u) {
+            cp_fftlog_spec spec{CP_KERNEL_SPHERICAL_BESSEL_J, 0., 1.5, 1., 3., pre_const, 1.};
+            double delta, lnxy;
+            std::vector<double> px(npad), py(npad);
+            y.resize(n); pre.resize(npad); post.resize(npad); u.resize(2 * nh);
+            return cp_fftlog_tables(n, nker, x.data(), &spec, 2, 1, 1, nullptr, nullptr, &delta, &lnxy, y.data(), px.data(), py.data(), pre.data(),
+                                    post.data(), u.data());
+        };
+        std::vector<double> s, pre, post, u, k2, pre2, post2, u2;
+        CHECK_CP(tables(k, std::pow(2. * pi, -1.5), s, pre, post, u));
+        CHECK_CP(tables(s, std::pow(2. * pi, 1.5), k2, pre2, post2, u2));
+        cp_fftlog_plan *fwd = nullptr, *bwd = nullptr;
+        CHECK_CP(cp_fftlog_plan_create(&fwd, n, npad, nker, pre.data(), post.data(), u.data(), 0));
+        CHECK_CP(cp_fftlog_plan_create(&bwd, n, npad, nker, pre2.data(), post2.data(), u2.data(), 0));
+        std::vector<double> pk(nbatch * n), xi(nbatch * n), back(nbatch * n);
+        for (int b = 0; b < nbatch; ++b)
+            for (int i = 0; i < n; ++i) pk[b * n + i] = (1. + b) * std::exp(-a * a * k[i] * k[i]);
+        pk[1 * n + 17] = std::nan("");
+        double *d_a = nullptr, *d_b = nullptr, *d_c = nullptr;
+        CHECK_HIP(hipMalloc(&d_a, pk.size() * sizeof(double)));
+        CHECK_HIP(hipMalloc(&d_b, pk.size() * sizeof(double)));
+        CHECK_HIP(hipMalloc(&d_c, pk.size() * sizeof(double)));
+        CHECK_HIP(hipMemcpy(d_a, pk.data(), pk.size() * sizeof(double), hipMemcpyHostToDevice));
+        CHECK_CP(cp_fftlog_execute(fwd, d_a, d_b, nbatch, CP_EXTRAP_CONSTANT, 0., CP_EXTRAP_CONSTANT, 0., 0, nullptr));
+        CHECK_CP(cp_fftlog_execute(bwd, d_b, d_c, nbatch, CP_EXTRAP_CONSTANT, 0., CP_EXTRAP_CONSTANT, 0., 0, nullptr));
+        CHECK_HIP(hipDeviceSynchronize());
+        CHECK_HIP(hipMemcpy(xi.data(), d_b, xi.size() * sizeof(double), hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(back.data(), d_c, back.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double err_xi = 0., err_back = 0.;
+        for (int b = 0; b < nbatch; b += 2)
+            for (int i = 0; i < n; ++i) {
+                if (std::fabs(k2[i] / k[i] - 1.) > 1e-12) return 5;                       // the inverse transform lands on the input grid
+                if (s[i] > 1e-1 && s[i] < 1e1) {
+                    const double ref = (1. + b) * std::exp(-s[i] * s[i] / (4. * a * a)) / (8. * std::pow(pi, 1.5) * a * a * a);
+                    err_xi = std::fmax(err_xi, std::fabs(xi[b * n + i] / ref - 1.));
+                }
+                if (k[i] > 1e-2 && k[i] < 1.) err_back = std::fmax(err_back, std::fabs(back[b * n + i] / pk[b * n + i] - 1.));
+            }
+        for (int i = 0; i < n; ++i)
+            if (!std::isnan(xi[1 * n + i]) || !std::isnan(back[1 * n + i])) return 6;     // the NaN row is NaN, alone
+        printf("P -> xi against the analytic pair: %.2g; P -> xi -> P: %.2g\n", err_xi, err_back);
+        if (!(err_xi < 1e-9) || !(err_back < 1e-9)) return 7;
+        CHECK_CP(cp_fftlog_plan_destroy(fwd));
+        CHECK_CP(cp_fftlog_plan_destroy(bwd));
+        CHECK_HIP(hipFree(d_a));
+        CHECK_HIP(hipFree(d_b));
+        CHECK_HIP(hipFree(d_c));
+    }
     // error convention: status + message, no exception, no abort
     cp_fftlog_plan* plan = nullptr;
     double one = 1.;
