@@ -1,5 +1,7 @@
 """Small helpers shared by the host-side modules: device resolution, numpy <-> torch plumbing, cp_param packing."""
+import collections
 import ctypes
+import hashlib
 
 import numpy as np
 
@@ -44,11 +46,19 @@ def resolve_device(device=None, *tensors):
     return device
 
 
+_upload_cache = collections.OrderedDict()      # (device index, dtype, shape, digest of the bytes) -> device tensor, least recently used first
+_UPLOAD_CACHE_ENTRIES, _UPLOAD_CACHE_BYTES = 1024, 1 << 16
+
+
 def upload(x, device):
-    """Tensor on ``device`` from a numpy array / number / tensor, dtype kept.  Host arrays up to 1 MiB (grids, masks, index lists, parameter
-    vectors) go through a page-locked block of torch's caching host allocator and an asynchronous copy: a copy from pageable memory blocks the
-    host until everything queued on the stream before it has run, i.e. every small upload in the middle of a pipeline is a device
-    synchronisation (21 of them per 16 384-vector chunk of the wallish2018 filter before this)."""
+    """Tensor on ``device`` from a numpy array / number / tensor, dtype kept; the result is to be treated as read-only.
+
+    Host arrays up to 64 KiB (grids, masks, index lists, parameter vectors: what the pipelines upload again and again) are kept on the device,
+    keyed by their content: a second upload of the same values is a dictionary lookup, and a function that has run once can be recorded into a
+    HIP graph (``torch.cuda.graph``) without any copy in it.  Larger ones, up to 1 MiB, go through a page-locked block of torch's caching host
+    allocator and an asynchronous copy: a copy from pageable memory blocks the host until everything queued on the stream before it has run,
+    i.e. every small upload in the middle of a pipeline was a device synchronisation (21 of them per 16 384-vector chunk of the wallish2018
+    filter)."""
     t = torch()
     if is_torch(x):
         return x.to(device=device)
@@ -56,13 +66,30 @@ def upload(x, device):
     a = np.ascontiguousarray(x)
     if a.dtype.byteorder not in '=|':
         a = a.astype(a.dtype.newbyteorder('='))
+    key = None
+    if a.nbytes <= _UPLOAD_CACHE_BYTES:
+        key = (t.device(device).index, a.dtype.str, shape, hashlib.blake2b(a.tobytes(), digest_size=16).digest())
+        hit = _upload_cache.get(key)
+        if hit is not None:
+            _upload_cache.move_to_end(key)
+            return hit
+    if t.cuda.is_current_stream_capturing():
+        raise RuntimeError('a host array is uploaded while a HIP graph is being captured: call the function once before capturing it, so that its '
+                           'constants are on the device')
     h = t.from_numpy(a) if a.flags.writeable else t.from_numpy(a.copy())
+    out = None
     if 0 < a.nbytes <= (1 << 20):
         try:
-            return h.pin_memory().to(device, non_blocking=True).reshape(shape)
+            out = h.pin_memory().to(device, non_blocking=True).reshape(shape)
         except RuntimeError:    # no page-locked memory left: the blocking copy below is the same result
-            pass
-    return h.to(device).reshape(shape)
+            out = None
+    if out is None:
+        out = h.to(device).reshape(shape)
+    if key is not None:
+        _upload_cache[key] = out
+        if len(_upload_cache) > _UPLOAD_CACHE_ENTRIES:
+            _upload_cache.popitem(last=False)
+    return out
 
 
 def to_device(x, device):

@@ -25,7 +25,7 @@ def _cparam(v, device, keep):
     import torch
     if np.ndim(v) == 0 and not _is_torch(v):
         return _lib.cp_param(None, float(v)), None
-    t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else torch.from_numpy(np.ascontiguousarray(v, dtype='f8')).to(device)
+    t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else dv.upload(np.asarray(v, dtype='f8'), device)
     t = t.reshape(-1).contiguous()
     keep.append(t)
     return _lib.cp_param(t.data_ptr(), 0.), t.numel()
@@ -136,7 +136,7 @@ def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=N
     else:
         z = np.asarray(z)
         np_dtype = z.dtype if z.dtype in (np.float32, np.float64) else np.float64
-        tz = torch.from_numpy(np.ascontiguousarray(z, dtype='f8')).to(device).reshape(z.shape)  # ascontiguousarray promotes 0-d to 1-d
+        tz = dv.upload(np.asarray(z, dtype='f8'), device)
     ncosmo, batched = 1, False
     tensors = {}
     cparams = (_lib.cp_param * len(_lib.BG_PARAMS))()
@@ -145,7 +145,7 @@ def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=N
         if np.ndim(v) == 0 and not _is_torch(v):
             cparams[i].ptr, cparams[i].value = None, float(v)
             continue
-        t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else torch.from_numpy(np.ascontiguousarray(v, dtype='f8')).to(device)
+        t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else dv.upload(np.asarray(v, dtype='f8'), device)
         t = t.reshape(-1).contiguous()
         if t.numel() == 1 and not batched and np.ndim(v) == 0:
             cparams[i].ptr, cparams[i].value = None, float(t)

@@ -153,8 +153,14 @@ class BasePowerSpectrumBAOFilter(dv.Copyable, metaclass=RegisteredPowerSpectrumB
         if self._cosmo_fid is None:
             rs_drag_fid = 100.91463132327911
         else:
-            rs_drag_fid = self.cosmo_fid.rs_drag
-        ratio = _host_value(self.cosmo.rs_drag) / _host_value(rs_drag_fid)
+            key = id(self._cosmo_fid)           # one fiducial cosmology per filter object, as a rule: its sound horizon is read back once
+            if getattr(self, '_rs_drag_fid', (None, None))[0] != key:
+                self._rs_drag_fid = (key, _host_value(self.cosmo_fid.rs_drag))
+            rs_drag_fid = self._rs_drag_fid[1]
+        rs_drag = self.cosmo.rs_drag
+        if dv.is_torch(rs_drag) and rs_drag.ndim and np.ndim(rs_drag_fid) == 0:
+            return rs_drag / float(rs_drag_fid)     # a batch of cosmologies: one ratio per cosmology, left on the device
+        ratio = _host_value(rs_drag) / _host_value(rs_drag_fid)
         return float(ratio) if np.ndim(ratio) == 0 else ratio
 
     def _scalar_rs_drag_ratio(self):
@@ -198,8 +204,10 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         tophat = np.ones_like(self.k)
         m = self.k > 1.
         tophat[m] *= np.exp(-20.**2 * (self.k[m] / 1. - 1.)**2)                                # :426-431
-        self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=dd, splice=splice, mask=mask, mask_left=mask_left,
-                         mask_right=mask_right, tophat=dv.to_device(tophat, self.device))
+        # index lists instead of boolean masks: selecting with a mask makes torch count its entries on the host (a synchronisation per call)
+        index = {name: dv.upload(np.flatnonzero(m), self.device) for name, m in (('mask', mask), ('mask_left', mask_left), ('mask_right', mask_right))}
+        self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=dd, splice=splice, index=index,
+                         tophat=dv.to_device(tophat, self.device))
         self._ops_cache[key] = self._ops
         return self._ops
 
@@ -230,8 +238,9 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         self._even_now, self._odd_now = out[0::2], out[1::2]
         pknow_lin = ops['dst'](out.view(ffted.shape), inverse=True, fused=True, split=True)          # exp(idst(.)) / k_lin
         pk = self._pk_rows
-        mask, ml, mr = (dv.upload(ops[name], self.device) for name in ('mask', 'mask_left', 'mask_right'))
-        vals = torch.cat([pk[:, ml], pknow_lin[:, mask], pk[:, mr]], dim=1).contiguous()
+        index = ops['index']
+        vals = torch.cat([pk.index_select(1, index['mask_left']), pknow_lin.index_select(1, index['mask']), pk.index_select(1, index['mask_right'])],
+                         dim=1).contiguous()
         pknow = ops['splice'](vals)                                       # clamped CubicSpline on the spliced knots at self.k
         wiggles = (pk / pknow - 1.) * ops['tophat'] + 1.
         self._pknow_rows = pk / wiggles
@@ -321,6 +330,12 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
                              for ix in _wiggle_extrema(self.ratio_fid[:, 0], start)]
         self._set_envelope_operator()
 
+    def _kfid_index(self):
+        """Positions of ``k_fid`` in ``k`` as a device index list (a boolean mask would make torch count its entries on the host at every use)."""
+        if getattr(self, '_kfid_index_cache', None) is None:
+            self._kfid_index_cache = dv.upload(np.flatnonzero(self.kmask_fid), self.device)
+        return self._kfid_index_cache
+
     def _set_envelope_operator(self):
         """``_interp`` (reference bao_filter.py:482-488) is linear in y for fixed peak indices: one dense (341 x 341) operator."""
         n = self.k_fid.size
@@ -359,7 +374,7 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
                                                 extrap_kmax=interp.extrap_kmax, interp_order_k=interp.interp_order_k, device=self.device)
             new = clone._rows(self.k_fid)
         out = self._pk_rows.clone()
-        out[:, dv.upload(self.kmask_fid, self.device)] = new
+        out.index_copy_(1, self._kfid_index(), new)
         self._pknow_rows = out
 
 
@@ -401,7 +416,7 @@ def _brieden_compute_batched(self, rescale):
                                              self.device.index, dv.stream_of(self.device)))
     new = (10**out).T
     res = self._pk_rows.clone()
-    res[:, dv.upload(self.kmask_fid, self.device)] = new
+    res.index_copy_(1, self._kfid_index(), new.contiguous())
     self._pknow_rows = res
 
 

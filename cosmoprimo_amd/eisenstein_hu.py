@@ -179,7 +179,7 @@ class Fourier(BaseSection):
 
     def _sigma8_m_device(self):
         """sigma8 of the current normalisation as a device tensor (batch...,): P(k) -> TophatVariance FFTLog -> natural spline at r = 8."""
-        g0 = dv.to_device(self.ba.growth_factor(np.zeros(()), znorm=0.), self.device)**2
+        g0 = dv.to_device(self.ba.growth_factor(dv.torch().zeros((), dtype=dv.torch().float64, device=self.device), znorm=0.), self.device)**2   # device z: no trip to the host
 
         def rows(kh):
             p0 = self._pk0_device(kh)

@@ -382,7 +382,7 @@ class FFTlog(dv.Copyable):
         dev = self._resolve_device(fun if is_torch else None)
         plan = self._get_plan(dev)           # also splits the unit phases off complex tables
         if not is_torch:
-            fun = torch.from_numpy(np.ascontiguousarray(fun)).to(dev)
+            fun = dv.upload(fun, dev)
         if self._phase_in is not None:       # complex prefactor: the FFT sees the real part of fun x prefactor (numpy.fft.rfft, fftlog.py:540)
             tfun = (fun.to(torch.complex128) * self._device_copy('phase_in', self._phase_in, dev)[:, None]).real
         else:
