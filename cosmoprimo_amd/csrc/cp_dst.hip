@@ -99,6 +99,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     // not finite -- or, for the fused log map, not positive -- goes into the transform as a harmless constant and is stored as NaN; its
     // partner is untouched.  The flags of the pair are raised by whichever thread meets such a sample and read behind one barrier.
     __shared__ int bad_row[2];
+    __shared__ int pair_flag;   // inverse transform: some sample of the pair is not finite
     const double nan = __builtin_nan("");
     for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
         const bool has_b = 2 * p + 1 < A.nrows;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
         // position of coefficient j in its row: the wallish2018 filter treats even- and odd-indexed coefficients as two sequences
         // (bao_filter.py:373), so they can be written / read as two half rows instead of being gathered by separate copy kernels
         auto at = [&](int j) { return A.split ? ((j & 1) * (N / 2) + (j >> 1)) : j; };
-        if (t == 0) bad_row[0] = bad_row[1] = 0;
+        if (t == 0) bad_row[0] = bad_row[1] = pair_flag = 0;
         __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
         int tt = t;
         asm volatile("" : "+v"(tt));
@@ -161,45 +162,59 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 if (has_b) ob[at(N - 1 - k)] = skip_b ? nan : f * yb;
             }
         } else {
-            // first the flags (the rows are read again below, from L1: keeping 64 samples in registers across the barrier would spill)
-            bool bad_a = false, bad_b = false;
-#pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const int k = tt + T * r;
-                const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-                bad_a |= !(fabs(ra[at(ia)]) <= 1.7976931348623157e308) || !(fabs(ra[at(ib)]) <= 1.7976931348623157e308);
-                bad_b |= !(fabs(rb[at(ia)]) <= 1.7976931348623157e308) || !(fabs(rb[at(ib)]) <= 1.7976931348623157e308);
-            }
-            if (bad_a) bad_row[0] = 1;
-            if (bad_b) bad_row[1] = 1;
-            __syncthreads();
-            asm volatile("" : "+v"(tt));
-            const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
-            const bool keep_a = !skip_a, keep_b = has_b && !skip_b;
             // Hermitian-symmetrised, conjugated spectrum of the pair; a row that is skipped does not take part
+            auto spectrum = [&](bool keep_a, bool keep_b) {
 #pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const int k = tt + T * r;
-                const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
-                const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
-                const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-                const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
-                const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
-                const cplx rot = A.rot[k];
-                const double cs = rot.re, sn = -rot.im;
-                cplx Ha, Hb;
-                if (k == 0) {
-                    Ha = cplx{Aa, 0.};
-                    Hb = cplx{Ab, 0.};
-                } else {
-                    Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
-                    Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
+                for (int r = 0; r < P; ++r) {
+                    const int k = tt + T * r;
+                    const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
+                    const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
+                    const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
+                    const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
+                    const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
+                    const cplx rot = A.rot[k];
+                    const double cs = rot.re, sn = -rot.im;
+                    cplx Ha, Hb;
+                    if (k == 0) {
+                        Ha = cplx{Aa, 0.};
+                        Hb = cplx{Ab, 0.};
+                    } else {
+                        Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
+                        Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
+                    }
+                    if (!keep_a) Ha = cplx{0., 0.};
+                    if (!keep_b) Hb = cplx{0., 0.};
+                    // conj(H_a + i H_b)
+                    x[r].re = Ha.re - Hb.im;
+                    x[r].im = -(Ha.im + Hb.re);
                 }
-                if (!keep_a) Ha = cplx{0., 0.};
-                if (!keep_b) Hb = cplx{0., 0.};
-                // conj(H_a + i H_b)
-                x[r].re = Ha.re - Hb.im;
-                x[r].im = -(Ha.im + Hb.re);
+            };
+            spectrum(true, has_b);
+            // a sample that is not finite shows in the packed spectrum, though not which row it came from: the pair is flagged from the registers
+            // (no second pass over the rows), and only a flagged pair -- rare -- reads its rows again to tell the two apart and leave the bad one out
+            bool suspect = false;
+#pragma unroll
+            for (int r = 0; r < P; ++r) suspect |= !(fabs(x[r].re) <= 1.7976931348623157e308) || !(fabs(x[r].im) <= 1.7976931348623157e308);
+            if (suspect) pair_flag = 1;
+            __syncthreads();
+            bool skip_a = false, skip_b = false;
+            if (pair_flag) {     // uniform over the workgroup
+                bool bad_a = false, bad_b = false;
+                asm volatile("" : "+v"(tt));
+#pragma unroll 1
+                for (int r = 0; r < P; ++r) {
+                    const int k = tt + T * r;
+                    const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
+                    bad_a |= !(fabs(ra[at(ia)]) <= 1.7976931348623157e308) || !(fabs(ra[at(ib)]) <= 1.7976931348623157e308);
+                    bad_b |= !(fabs(rb[at(ia)]) <= 1.7976931348623157e308) || !(fabs(rb[at(ib)]) <= 1.7976931348623157e308);
+                }
+                if (bad_a) bad_row[0] = 1;
+                if (bad_b) bad_row[1] = 1;
+                __syncthreads();
+                skip_a = bad_row[0] != 0;
+                skip_b = bad_row[1] != 0;
+                // finite rows whose sum overflowed in the packing stay as they are (skip_a = skip_b = false): nothing to separate
+                if (skip_a | skip_b) spectrum(!skip_a, has_b && !skip_b);
             }
             dif_all<N, P>(tt, A, x, lds, ltw);
             asm volatile("" : "+v"(tt));
