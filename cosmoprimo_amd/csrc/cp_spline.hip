@@ -641,8 +641,9 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     // A dense copy (zero outside the bands) serves the matrix-core kernel, which treats the operator as a block-banded GEMM: a tile of 64
     // queries times the window of knots its bands cover.  That does (window / bandwidth) times the multiply-adds of the banded vector kernel
     // but at about five times its rate (the vector kernel reads one LDS word per multiply-add): the matrix cores are the default up to a
-    // factor 3 -- dense operators (quadrature weights, projectors: factor 1), splines between grids of similar density (factor 1.5 for 504 ->
-    // 1024 knots of a P(k) table) -- and a measurement option otherwise (CP_SPLINE_PATH_MFMA; 1024 -> 256 radii: factor 5, and HBM-bound anyway).
+    // factor 5 -- dense operators (quadrature weights, projectors: factor 1), splines between grids of similar density (factor 1.5 for 504 ->
+    // 1024 knots of a P(k) table), the wallish2018 splice from 3666 linear knots to 1024 log-spaced ones (factor 4.x: 0.98 against 1.18 ms) --
+    // and a measurement option otherwise (CP_SPLINE_PATH_MFMA).
     const bool dense = keep_dense && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
     std::vector<double> wd;
     std::vector<int> kwin((size_t)2 * (p->nq_pad / 64), 0);
@@ -664,7 +665,7 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
             kwin[2 * t + 1] = (hi + 15) / 16 * 16;
             work += 64. * (kwin[2 * t + 1] - kwin[2 * t]);
         }
-        p->prefer_dense = n >= 16 && work <= 3. * (double)nq * bw;
+        p->prefer_dense = n >= 16 && work <= 5. * (double)nq * bw;
     } else {
         p->prefer_dense = false;
     }
