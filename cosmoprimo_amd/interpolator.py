@@ -518,8 +518,13 @@ class Interpolator2D(dv.Copyable):
         self._lead = tuple(self._fun.shape[:-2])
         # FITPACK propagates any NaN datum (e.g. the log of a negative P) to the whole surface (reference tests/test_interpolator.py:328-337)
         nan = torch.isnan(self._fun).flatten(-2).any(dim=-1)           # per surface
-        self._has_nan = bool(nan.all()) if self._lead else bool(nan)
-        self._nan_surfaces = nan if self._lead and bool(nan.any()) and not self._has_nan else None
+        if self._lead:
+            # a batch of surfaces: the ones holding a NaN are made NaN throughout, on the device -- every interpolated value of theirs is then NaN
+            # by arithmetic (the operators are linear), with no flag to read back and no mask to apply to the results
+            self._fun = torch.where(nan[..., None, None], torch.full_like(self._fun, float('nan')), self._fun)
+            self._has_nan, self._nan_surfaces = False, None
+        else:
+            self._has_nan, self._nan_surfaces = bool(nan), None
 
     def _operator(self, axis, q, dense=False):
         """Operator from the knots of ``axis`` ('x': transformed coordinates, 'y') to the queries ``q`` (host, flat); queries outside the

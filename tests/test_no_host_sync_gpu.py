@@ -91,3 +91,16 @@ def test_fftlog_and_distances():
                                                                        zz=rng.uniform(0., 3., 5000)).items()}
     capture_and_compare(torch, lambda: background.distance('comoving_radial_distance', samples['zz'][:, None], dict(w0_fld=samples['w0']),
                                                            Omega_m=samples['om'], per_cosmology_z=True), samples, fresh)
+
+
+def test_sigma_rz_of_a_batch_of_tables(golden):
+    import torch
+    import cosmoprimo_amd as cp
+    dev = torch.device('cuda', 0)
+    g = golden('sigma')
+    k, z = g['table_k'], g['table_z']
+    rng = np.random.default_rng(6)
+    tables = {'pk': torch.as_tensor(rng.uniform(0.5, 2., (50, 1, 1)) * g['table_pk'][None], device=dev)}
+    fresh = {'pk': torch.as_tensor(rng.uniform(0.5, 2., (50, 1, 1)) * g['table_pk'][None], device=dev)}
+    r, zq = torch.as_tensor(np.geomspace(1., 100., 32), device=dev), torch.as_tensor(np.linspace(0.1, 2.5, 8), device=dev)
+    capture_and_compare(torch, lambda: cp.PowerSpectrumInterpolator2D(k, z, tables['pk']).sigma_rz(r, zq), tables, fresh)
