@@ -1009,16 +1009,32 @@ __global__ __launch_bounds__(256) void column_spline_kernel(const double* __rest
     double cprev = 0.5, dprev = 3. * slm / 2.;     // row 0: 2 dx0 s0 + dx0 s1 = 3 dx0 slope0
     cp[0] = cprev;
     dp[0] = dprev;
-    for (int i = 1; i < n - 1; ++i) {
-        const double x2 = X(i + 1), y2 = Y(i + 1);
-        const double dxp = x2 - x1, slp = (y2 - y1) / dxp;
-        // dxp s_{i-1} + 2 (dxm + dxp) s_i + dxm s_{i+1} = 3 (dxp slm + dxm slp)
-        const double den = 2. * (dxm + dxp) - dxp * cprev;
-        cprev = dxm / den;
-        dprev = (3. * (dxp * slm + dxm * slp) - dxp * dprev) / den;
-        cp[(long long)i * ncol] = cprev;
-        dp[(long long)i * ncol] = dprev;
-        x1 = x2; y1 = y2; dxm = dxp; slm = slp;
+    // the sweeps are chains of dependent divisions fed by one knot per step: with a handful of waves per CU nothing hides the latency of a load
+    // issued when its value is needed (1.5 us per knot), so the knots of the next CHUNK steps are fetched together, ahead of the arithmetic
+    constexpr int CHUNK = 8;
+    for (int i0 = 1; i0 < n - 1; i0 += CHUNK) {
+        double xs[CHUNK], ys[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int j = i0 + u + 1 < n ? i0 + u + 1 : n - 1;
+            xs[u] = X(j);
+            ys[u] = Y(j);
+        }
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int i = i0 + u;
+            if (i < n - 1) {
+                const double x2 = xs[u], y2 = ys[u];
+                const double dxp = x2 - x1, slp = (y2 - y1) / dxp;
+                // dxp s_{i-1} + 2 (dxm + dxp) s_i + dxm s_{i+1} = 3 (dxp slm + dxm slp)
+                const double den = 2. * (dxm + dxp) - dxp * cprev;
+                cprev = dxm / den;
+                dprev = (3. * (dxp * slm + dxm * slp) - dxp * dprev) / den;
+                cp[(long long)i * ncol] = cprev;
+                dp[(long long)i * ncol] = dprev;
+                x1 = x2; y1 = y2; dxm = dxp; slm = slp;
+            }
+        }
     }
     // last row: dx s_{n-2} + 2 dx s_{n-1} = 3 dx slope
     double s_hi = (3. * slm - dprev) / (2. - cprev);
@@ -1027,18 +1043,31 @@ __global__ __launch_bounds__(256) void column_spline_kernel(const double* __rest
     const double xtop = x1;
     while (iq >= 0 && xq[iq] > xtop) out[(long long)iq-- * ncol + c] = nan;
     double xh = x1, yh = y1;   // upper knot of the current interval
-    for (int i = n - 2; i >= 0; --i) {
-        const double xl = X(i), yl = Y(i);
-        const double s_lo = dp[(long long)i * ncol] - cp[(long long)i * ncol] * s_hi;
-        const double h = xh - xl, slope = (yh - yl) / h;
-        const double tt = (s_lo + s_hi - 2. * slope) / h;
-        const double c3 = tt / h, c2 = (slope - s_lo) / h - tt;
-        while (iq >= 0 && xq[iq] >= xl) {
-            const double u = xq[iq] - xl;
-            out[(long long)iq * ncol + c] = yl + u * (s_lo + u * (c2 + u * c3));
-            --iq;
+    for (int i0 = n - 2; i0 >= 0; i0 -= CHUNK) {
+        double xs[CHUNK], ys[CHUNK], cs[CHUNK], ds[CHUNK];
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int j = i0 - u >= 0 ? i0 - u : 0;
+            xs[u] = X(j);
+            ys[u] = Y(j);
+            cs[u] = cp[(long long)j * ncol];
+            ds[u] = dp[(long long)j * ncol];
         }
-        xh = xl; yh = yl; s_hi = s_lo;
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            if (i0 - u < 0) continue;
+            const double xl = xs[u], yl = ys[u];
+            const double s_lo = ds[u] - cs[u] * s_hi;
+            const double h = xh - xl, slope = (yh - yl) / h;
+            const double tt = (s_lo + s_hi - 2. * slope) / h;
+            const double c3 = tt / h, c2 = (slope - s_lo) / h - tt;
+            while (iq >= 0 && xq[iq] >= xl) {
+                const double v = xq[iq] - xl;
+                out[(long long)iq * ncol + c] = yl + v * (s_lo + v * (c2 + v * c3));
+                --iq;
+            }
+            xh = xl; yh = yl; s_hi = s_lo;
+        }
     }
     while (iq >= 0) out[(long long)iq-- * ncol + c] = nan;
 }
@@ -1053,7 +1082,7 @@ extern "C" int cp_spline_columns(const double* d_xk, const double* d_yk, long lo
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_columns: cannot select device %d", device);
-    hipLaunchKernelGGL(column_spline_kernel, dim3((unsigned)((ncol + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), d_xk, d_yk, ncol, n,
+    hipLaunchKernelGGL(column_spline_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), d_xk, d_yk, ncol, n,
                        d_xq, nq, d_out, d_scratch);
     hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
