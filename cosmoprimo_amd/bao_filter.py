@@ -232,7 +232,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         y = ffted.view(2 * ffted.shape[0], ffted.shape[1] // 2)
         dd = ops['dd'](y)
         box = self._box(dd)
-        out = torch.empty_like(y)
+        out = y      # in place: the kept coefficients stay where they are, only the boxes are rewritten
         _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index, dv.stream_of(self.device)))
         self._dd, self._boxes = [dd[0::2], dd[1::2]], [box[0::2], box[1::2]]
         self._even_now, self._odd_now = out[0::2], out[1::2]

@@ -255,7 +255,7 @@ int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc,
 
 /* clamped cubic spline through uniformly spaced knots (positions 1..n) of x^2-weighted data with the knots of a per-column box
  * [box[2c], box[2c+1]] removed, evaluated at all positions and divided by x^2 (wallish2018 peak removal, bao_filter.py:387-405).
- * d_y, d_out : (ncol, n); d_box : (ncol, 2) int32. */
+ * d_y, d_out : (ncol, n); d_box : (ncol, 2) int32.  d_out may be d_y (in place: only the boxes are rewritten, nothing is copied). */
 int cp_gap_spline(const double* d_y, const int* d_box, double* d_out, long long ncol, int n, int device, void* stream);
 /* The box cp_gap_spline removes (bao_filter.py:390-394): d_dd (ncol, n) second derivatives -> d_box (ncol, 2) =
  * [argmax over [margin_first, n - margin_first) + offset_first, argmax over [that argmax + margin_second, n - margin_first) + offset_second],
