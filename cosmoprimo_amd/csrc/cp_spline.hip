@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void linop_mfma_kernel(const DenseArgs A) {
 // 10^x in the epilogue writes the spectra once, z-major, instead of interpolating, transposing and exponentiating in three passes).
 // Here the operator is the A matrix, A[m = l & 15][k = l >> 4] = W[q0 + m][j], and y the B matrix, B[k = l >> 4][n = l & 15] =
 // y[b, j, c0 + n]: per k step a lane group reads 16 consecutive doubles of one row j (128-byte segments, four adjacent ones for the four
-// column tiles of a wave).  Wave tile 64 queries x 64 columns (4 x 4 accumulator tiles); the four waves of a workgroup take adjacent columns.
+// column tiles of a wave).  Wave tile 64 queries x 32 columns (4 x 2 accumulator tiles: with 4 x 4 the kernel needs 434 registers, one wave per SIMD, and runs at 2.2 TB/s); the four waves of a workgroup take adjacent columns.
 struct MidArgs {
     const double* y;
     double* out;
@@ -324,57 +324,67 @@ struct MidArgs {
     double scale;
 };
 
-__global__ __launch_bounds__(256) void linop_mid_mfma_kernel(const MidArgs A) {
+constexpr int MID_NT = 2;   // 16-column tiles per wave: 64 queries x 32 columns (4 x 2 accumulator tiles)
+constexpr int MID_WSTRIDE = 80;   // LDS row stride (doubles) of the resident operator, 64 queries + padding: lane groups fall on different banks
+
+// The kernel moves 3 bytes for every multiply-add: what it needs is memory operations in flight, i.e. waves -- four per SIMD (128 registers: the
+// accumulators of a 64 x 32 tile, the operator in LDS rather than in registers).
+__global__ __launch_bounds__(256, 4) void linop_mid_mfma_kernel(const MidArgs A) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l15 = lane & 15, g = lane >> 4;
-    const long long nct = (A.ninner + 255) / 256;     // column tiles of 256 (64 per wave)
+    constexpr int NT = MID_NT, WCOLS = 16 * NT, GCOLS = 4 * WCOLS;   // columns per wave and per workgroup
+    const long long nct = (A.ninner + GCOLS - 1) / GCOLS;
     const int nqt = A.nq_pad / 64;
     const long long nitems = A.nbatch * nct * nqt;
-    // a small operator (one tile of 64 queries, at most 32 knots: the redshift grids of P(k, z) tables) stays in registers for all items
+    // a small operator (one tile of 64 queries, at most 32 knots: the redshift grids of P(k, z) tables) stays in LDS for all items, knot-major
     const bool resident = nqt == 1 && A.n_pad <= 32;
-    double wres[8][4];
+    __shared__ double wl[32 * MID_WSTRIDE];
     if (resident) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wres[s][i] = 4 * s < A.n_pad ? A.w[(long long)(16 * i + l15) * A.n_pad + 4 * s + g] : 0.;
+        for (int e = threadIdx.x; e < 64 * A.n_pad; e += 256) {
+            const int q = e / A.n_pad, k = e - q * A.n_pad;
+            wl[k * MID_WSTRIDE + q] = A.w[e];
+        }
+        __syncthreads();
     }
     for (long long item = blockIdx.x; item < nitems; item += gridDim.x) {
         const int qt = (int)(item % nqt);
         const long long ct = (item / nqt) % nct, b = item / (nqt * nct);
-        const long long c0 = ct * 256 + wave * 64;
+        const long long c0 = ct * GCOLS + wave * WCOLS;
         if (c0 >= A.ninner) continue;
         const int q0 = qt * 64;
         const double* yb = A.y + b * A.n * A.ninner;
-        cp_v4d acc[4][4];   // [query tile][column tile]
+        cp_v4d acc[4][NT];   // [query tile][column tile]
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = cp_v4d{0., 0., 0., 0.};
-        long long col[4];
-        bool colok[4];
+            for (int j = 0; j < NT; ++j) acc[i][j] = cp_v4d{0., 0., 0., 0.};
+        long long col[NT];
+        bool colok[NT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NT; ++j) {
             col[j] = c0 + 16 * j + l15;
             colok[j] = col[j] < A.ninner;
             col[j] = colok[j] ? col[j] : A.ninner - 1;
         }
         auto step = [&](int kb, const double* a) {
             const int jrow = kb + g;
-            double bv[4];
+            double bv[NT];
             const bool rowok = jrow < A.n;     // W is zero in its padding, but y must not bring in another batch entry's values (0 x NaN)
             const double* yr = yb + (long long)(rowok ? jrow : 0) * A.ninner;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = rowok ? yr[col[j]] : 0.;
+            for (int j = 0; j < NT; ++j) bv[j] = rowok ? yr[col[j]] : 0.;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bv[j], acc[i][j], 0, 0, 0);
         };
         if (resident) {
+            for (int kb = 0; kb < A.n_pad; kb += 4) {
+                double a[4];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (4 * s < A.n_pad) step(4 * s, wres[s]);
+                for (int i = 0; i < 4; ++i) a[i] = wl[(kb + g) * MID_WSTRIDE + 16 * i + l15];
+                step(kb, a);
+            }
         } else {
             for (int kb = 0; kb < A.n_pad; kb += 4) {
                 double a[4];
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(256) void linop_mid_mfma_kernel(const MidArgs A) {
                 if (q >= A.nq) continue;
                 const bool nanq = A.j0[q] < 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     if (!colok[j]) continue;
                     double v = nanq ? __builtin_nan("") : acc[i][j][r] * A.scale;
                     if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
@@ -804,7 +814,7 @@ extern "C" int cp_spline_apply_outer(const cp_spline_plan* p, const double* d_y,
 extern "C" int cp_linop_apply_mid(const cp_spline_plan* p, const double* d_y, double* d_out, long long nbatch, long long ninner, int post_op, double scale,
                                   void* stream) {
     if (!p) return cp::fail(CP_EINVAL, "cp_linop_apply_mid: null plan");
-    if (nbatch < 0 || ninner < 0) return cp::fail(CP_EINVAL, "cp_linop_apply_mid: negative sizes");
+    if (nbatch < 0 || ninner < 0 || ninner > 2147483647LL - 1024) return cp::fail(CP_EINVAL, "cp_linop_apply_mid: bad sizes");
     if (nbatch == 0 || ninner == 0) return CP_OK;
     if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_linop_apply_mid: null device pointer");
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT && post_op != CP_SPLINE_POST_EXP10)
@@ -816,7 +826,7 @@ extern "C" int cp_linop_apply_mid(const cp_spline_plan* p, const double* d_y, do
     MidArgs M;
     M.y = d_y; M.out = d_out; M.nbatch = nbatch; M.ninner = ninner; M.n = p->n; M.nq = p->nq; M.n_pad = p->n_pad; M.nq_pad = p->nq_pad;
     M.w = p->d_wdense; M.j0 = p->d_j0; M.post_op = post_op; M.scale = scale;
-    const long long items = nbatch * ((ninner + 255) / 256) * (p->nq_pad / 64);
+    const long long items = nbatch * ((ninner + 64 * MID_NT - 1) / (64 * MID_NT)) * (p->nq_pad / 64);
     const int grid = (int)(items < 256 * 8 ? items : 256 * 8);
     hipLaunchKernelGGL(linop_mid_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), M);
     const hipError_t e = hipGetLastError();
