@@ -236,7 +236,8 @@ int cp_spline_plan_create(cp_spline_plan** plan, int n, const double* x, int nq,
 /* d_out[row, q] = post_op(scale * sum_j W[q, j] d_y[row, j]);  d_y : (nrows, n), d_out : (nrows, nq), device, row-major */
 int cp_spline_apply(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nrows, int post_op, double scale, void* stream);
 /* the same followed by an outer product with per-row factors, written once: d_out (nrows, nq, nz) = f(scale x spline(d_y)[row, q] x d_g[row, z]),
- * f = sqrt for CP_SPLINE_POST_SQRT.  sigma_rz of separable P(k, z) = P(k) x growth^2(z): PowerSpectrumInterpolator2D.sigma_rz, interpolator.py:846-875 */
+ * f = sqrt for CP_SPLINE_POST_SQRT, evaluated as sqrt(scale x spline) x sqrt(g): both factors are variances / squared growth factors (a negative one
+ * gives NaN).  sigma_rz of separable P(k, z) = P(k) x growth^2(z): PowerSpectrumInterpolator2D.sigma_rz, interpolator.py:846-875 */
 int cp_spline_apply_outer(const cp_spline_plan* plan, const double* d_y, const double* d_g, int nz, double* d_out, long long nrows, int post_op,
                           double scale, void* stream);
 /* the same machinery for any fixed linear map of rows given densely (w_dense : nq x n row-major, host; a row starting with NaN
