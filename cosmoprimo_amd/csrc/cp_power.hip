@@ -77,8 +77,11 @@ __device__ __forceinline__ double recip(double x) {
 // log(x), fast for positive, finite, normal x (every argument here is a wavenumber or e + a positive term): the classic argument reduction to
 // m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1) and a degree-14 odd series in s (the fdlibm scheme and minimax coefficients), below 1 ulp;
 // a third of the instructions of the library log, which carries double-double intermediates this kernel has no use for.
+__device__ __attribute__((noinline)) double log_any(double x) { return log(x); }
+__device__ __attribute__((noinline)) double sin_any(double x) { return sin(x); }
+
 __device__ __forceinline__ double log_pos(double x) {
-    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);   // zero, negative, subnormal, Inf, NaN: the library's answers
+    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log_any(x);   // zero, negative, subnormal, Inf, NaN: the library's answers (out of line)
     double m = __builtin_amdgcn_frexp_mant(x);           // [1/2, 1)
     int e = __builtin_amdgcn_frexp_exp(x);
     const bool low = m < 0.70710678118654752440;
@@ -99,7 +102,7 @@ __device__ __forceinline__ double log_pos(double x) {
 // bits: n times the first is exact), then the degree-13 / degree-14 polynomials of sin and cos on [-pi/4, pi/4] picked by n mod 4; absolute
 // error below 2e-16 (checked against extended precision on 6e5 arguments up to 1e6).  Larger arguments take the library function.
 __device__ __forceinline__ double sin_bounded(double x) {
-    if (!(x < 1e6)) return sin(x);
+    if (!(x < 1e6)) return sin_any(x);
     const double n = rint(x * 6.36619772367581382433e-01);
     double r = fma(-n, 1.57079632673412561417e+00, x);
     r = fma(-n, 6.07710050650619224932e-11, r);
