@@ -3,8 +3,12 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/cosmoprimo_amd.h"
+#include "cp_math.h"
 
 namespace cpcosmo {
+
+using cpmath::exp_mid;
+using cpmath::rsqrt_pos;
 
 // physical constants as cosmoprimo/constants.py (scipy.constants values, scipy 1.15)
 constexpr double kC = 299792458.0;
@@ -118,37 +122,6 @@ __device__ __forceinline__ double efunc_ln(const Cosmo& c, double z, double lzp1
                                                   : c.Omega_de * exp(3. * (c.w0 + c.wa) * lzp1 + 3. * c.wa * (1. / zp1 - 1.)) * kRhoCrit;
     const double rc = (m + r + de) + c.Omega_k / zp1 * kRhoCrit;
     return sqrt(rc * (zp1 * zp1 * zp1) / kRhoCrit);
-}
-
-// exp(x) for the 237 ordinates of a distance: round(x / ln 2), ln 2 in two pieces, the degree-13 Taylor polynomial on |r| <= ln(2) / 2 (remainder
-// 4e-18), ldexp -- relative error below 2e-16, 20 instructions for the library's 35
-__device__ __forceinline__ double exp_mid(double x) {
-    x = x < -746. ? -746. : (x > 710. ? 710. : x);   // 0 and Inf beyond the range of double through ldexp; NaN passes
-    const double n = rint(x * 1.4426950408889634);
-    double r = fma(-n, 0.6931471803691238, x);
-    r = fma(-n, 1.9082149292705877e-10, r);
-    double p = 1. / 6227020800.;
-    p = fma(p, r, 1. / 479001600.);
-    p = fma(p, r, 1. / 39916800.);
-    p = fma(p, r, 1. / 3628800.);
-    p = fma(p, r, 1. / 362880.);
-    p = fma(p, r, 1. / 40320.);
-    p = fma(p, r, 1. / 5040.);
-    p = fma(p, r, 1. / 720.);
-    p = fma(p, r, 1. / 120.);
-    p = fma(p, r, 1. / 24.);
-    p = fma(p, r, 1. / 6.);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.);
-    p = fma(p, r, 1.);
-    return ldexp(p, (int)n);
-}
-
-// 1 / sqrt(x) for positive, finite, normal x: the hardware estimate (2^-23) and one third-order correction y (1 + e / 2 + 3 e^2 / 8), e = 1 - x y^2
-__device__ __forceinline__ double rsqrt_pos(double x) {
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = fma(-x * y, y, 1.);
-    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 // 1 / E(z) with log(1 + z) and 1 / (1 + z) given: rsqrt of E^2 (no division, no sqrt)

@@ -21,6 +21,7 @@
 #include "cp_error.h"
 #include "cp_fft_core.h"
 #include "cp_fftlog_tables.h"
+#include "cp_math.h"
 
 namespace {
 
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 bad_b |= !(fabs(b) <= 1.7976931348623157e308) || (A.fused && !(b > 0.));
                 if (A.fused) {
                     const double kk = A.kx[n];
-                    a = log(kk * a);
-                    b = log(kk * b);
+                    a = cpmath::log_pos(kk * a);      // rows with a sample that is not positive are flagged above and left out
+                    b = cpmath::log_pos(kk * b);
                 }
                 x[r].re = lower ? a : -a;
                 x[r].im = has_b ? (lower ? b : -b) : 0.;
@@ -229,8 +230,9 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 double yb = even ? -g.im : g.im;
                 if (A.fused) {
                     const double kk = A.kx[n];
-                    ya = exp(ya) / kk;
-                    yb = exp(yb) / kk;
+                    const double ik = cpmath::recip(kk);
+                    ya = cpmath::exp_mid(ya) * ik;
+                    yb = cpmath::exp_mid(yb) * ik;
                 }
                 oa[n] = skip_a ? nan : ya;
                 if (has_b) ob[n] = skip_b ? nan : yb;

@@ -1,0 +1,118 @@
+// cp_math.h -- short forms of the transcendental functions the ALU-bound kernels spend their time in (device code, gfx950).
+// Each is the textbook argument reduction + polynomial of its function, accurate to 1-2 ulp (stated per function, checked against extended
+// precision), at a third to a half of the instructions of the library versions, which carry double-double intermediates and the handling of
+// subnormal / overflowing arguments that these kernels' arguments never need; out-of-range arguments go to the library functions out of line.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cpmath {
+
+// 1 / x for finite, normal x: the hardware estimate and two Newton steps (relative error below 2 ulp), a third of the instructions of an
+// IEEE division (v_div_scale x 2, v_div_fmas, v_div_fixup around the same estimate and steps)
+__device__ __forceinline__ double recip(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.), r, r);
+    r = fma(fma(-x, r, 1.), r, r);
+    return r;
+}
+
+// log(x), fast for positive, finite, normal x (every argument here is a wavenumber or e + a positive term): the classic argument reduction to
+// m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1) and a degree-14 odd series in s (the fdlibm scheme and minimax coefficients), below 1 ulp;
+// a third of the instructions of the library log, which carries double-double intermediates this kernel has no use for.
+static __device__ __attribute__((noinline)) double log_any(double x) { return log(x); }
+static __device__ __attribute__((noinline)) double sin_any(double x) { return sin(x); }
+
+__device__ __forceinline__ double log_pos(double x) {
+    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log_any(x);   // zero, negative, subnormal, Inf, NaN: the library's answers (out of line)
+    double m = __builtin_amdgcn_frexp_mant(x);           // [1/2, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool low = m < 0.70710678118654752440;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double k = (double)e;
+    const double f = m - 1.;
+    const double s = f * recip(2. + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t1 + t2;
+    const double hfsq = 0.5 * f * f;
+    return k * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f);
+}
+
+// sin(x) for 0 <= x < 1e6 (k rs_drag reaches 1e4 at k = 100 h/Mpc): n = round(x / (pi / 2)), r = x - n pi/2 with pi/2 in two pieces (33 + 53
+// bits: n times the first is exact), then the degree-13 / degree-14 polynomials of sin and cos on [-pi/4, pi/4] picked by n mod 4; absolute
+// error below 2e-16 (checked against extended precision on 6e5 arguments up to 1e6).  Larger arguments take the library function.
+__device__ __forceinline__ double sin_bounded(double x) {
+    if (!(x < 1e6)) return sin_any(x);
+    const double n = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, x);
+    r = fma(-n, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double ps = fma(r * z, fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01), r);
+    const double pc = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                                  2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02), fma(-0.5, z, 1.));
+    const int q = (int)n;
+    const double v = (q & 1) ? pc : ps;
+    return (q & 2) ? -v : v;
+}
+
+// exp(x) for the 237 ordinates of a distance: round(x / ln 2), ln 2 in two pieces, the degree-13 Taylor polynomial on |r| <= ln(2) / 2 (remainder
+// 4e-18), ldexp -- relative error below 2e-16, 20 instructions for the library's 35
+__device__ __forceinline__ double exp_mid(double x) {
+    x = x < -746. ? -746. : (x > 710. ? 710. : x);   // 0 and Inf beyond the range of double through ldexp; NaN passes
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(-n, 0.6931471803691238, x);
+    r = fma(-n, 1.9082149292705877e-10, r);
+    double p = 1. / 6227020800.;
+    p = fma(p, r, 1. / 479001600.);
+    p = fma(p, r, 1. / 39916800.);
+    p = fma(p, r, 1. / 3628800.);
+    p = fma(p, r, 1. / 362880.);
+    p = fma(p, r, 1. / 40320.);
+    p = fma(p, r, 1. / 5040.);
+    p = fma(p, r, 1. / 720.);
+    p = fma(p, r, 1. / 120.);
+    p = fma(p, r, 1. / 24.);
+    p = fma(p, r, 1. / 6.);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.);
+    p = fma(p, r, 1.);
+    return ldexp(p, (int)n);
+}
+
+// 1 / sqrt(x) for positive, finite, normal x: the hardware estimate (2^-23) and one third-order correction y (1 + e / 2 + 3 e^2 / 8), e = 1 - x y^2
+__device__ __forceinline__ double rsqrt_pos(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// 10^x for the epilogues (tables splined in log10 P): round(x log2 10), log10(2) in two pieces, 10^r = e^(r ln 10) by the degree-13 Taylor
+// polynomial on |r ln 10| <= ln(2) / 2, ldexp -- relative error 2e-16 (checked against 50-digit arithmetic), half the instructions of the
+// library's exp10, which matters where every lane of the GEMM epilogue takes 64 of them per tile
+__device__ __forceinline__ double exp10_mid(double x) {
+    if (!(fabs(x) < 300.)) return exp10(x);
+    const double n = rint(x * 3.321928094887362);
+    double r = fma(-n, 0.3010299955494702, x);
+    r = fma(-n, 1.1451100898021838e-10, r);
+    const double y = r * 2.302585092994046;
+    double p = 1. / 6227020800.;
+    p = fma(p, y, 1. / 479001600.);
+    p = fma(p, y, 1. / 39916800.);
+    p = fma(p, y, 1. / 3628800.);
+    p = fma(p, y, 1. / 362880.);
+    p = fma(p, y, 1. / 40320.);
+    p = fma(p, y, 1. / 5040.);
+    p = fma(p, y, 1. / 720.);
+    p = fma(p, y, 1. / 120.);
+    p = fma(p, y, 1. / 24.);
+    p = fma(p, y, 1. / 6.);
+    p = fma(p, y, 0.5);
+    p = fma(p, y, 1.);
+    p = fma(p, y, 1.);
+    return ldexp(p, (int)n);
+}
+
+}  // namespace cpmath

@@ -14,11 +14,13 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_cosmo_common.h"
+#include "cp_math.h"
 #include "cp_error.h"
 
 namespace {
 
 using namespace cpcosmo;
+using namespace cpmath;
 
 struct EhScalars {
     double omega_b, omega_m, frac_b, theta_cmb, z_eq, k_eq, z_drag, r_drag, r_eq, rs_drag, k_silk, alpha_c, beta_c, alpha_b, beta_node, beta_b,
@@ -63,57 +65,6 @@ __device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, doub
         s.ln_q_over_kh = s.ln_ksilk_over_kh = 0.;
     }
     return s;
-}
-
-// 1 / x for finite, normal x: the hardware estimate and two Newton steps (relative error below 2 ulp), a third of the instructions of an
-// IEEE division (v_div_scale x 2, v_div_fmas, v_div_fixup around the same estimate and steps)
-__device__ __forceinline__ double recip(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.), r, r);
-    r = fma(fma(-x, r, 1.), r, r);
-    return r;
-}
-
-// log(x), fast for positive, finite, normal x (every argument here is a wavenumber or e + a positive term): the classic argument reduction to
-// m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1) and a degree-14 odd series in s (the fdlibm scheme and minimax coefficients), below 1 ulp;
-// a third of the instructions of the library log, which carries double-double intermediates this kernel has no use for.
-__device__ __attribute__((noinline)) double log_any(double x) { return log(x); }
-__device__ __attribute__((noinline)) double sin_any(double x) { return sin(x); }
-
-__device__ __forceinline__ double log_pos(double x) {
-    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log_any(x);   // zero, negative, subnormal, Inf, NaN: the library's answers (out of line)
-    double m = __builtin_amdgcn_frexp_mant(x);           // [1/2, 1)
-    int e = __builtin_amdgcn_frexp_exp(x);
-    const bool low = m < 0.70710678118654752440;
-    m = low ? m + m : m;
-    e = low ? e - 1 : e;
-    const double k = (double)e;
-    const double f = m - 1.;
-    const double s = f * recip(2. + f);
-    const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
-    const double R = t1 + t2;
-    const double hfsq = 0.5 * f * f;
-    return k * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f);
-}
-
-// sin(x) for 0 <= x < 1e6 (k rs_drag reaches 1e4 at k = 100 h/Mpc): n = round(x / (pi / 2)), r = x - n pi/2 with pi/2 in two pieces (33 + 53
-// bits: n times the first is exact), then the degree-13 / degree-14 polynomials of sin and cos on [-pi/4, pi/4] picked by n mod 4; absolute
-// error below 2e-16 (checked against extended precision on 6e5 arguments up to 1e6).  Larger arguments take the library function.
-__device__ __forceinline__ double sin_bounded(double x) {
-    if (!(x < 1e6)) return sin_any(x);
-    const double n = rint(x * 6.36619772367581382433e-01);
-    double r = fma(-n, 1.57079632673412561417e+00, x);
-    r = fma(-n, 6.07710050650619224932e-11, r);
-    const double z = r * r;
-    const double ps = fma(r * z, fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01), r);
-    const double pc = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                                                  2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02), fma(-0.5, z, 1.));
-    const int q = (int)n;
-    const double v = (q & 1) ? pc : ps;
-    return (q & 2) ? -v : v;
 }
 
 // What transfer_eh needs of one cosmology, in the units of the loop over wavenumbers (kh in h/Mpc): once per thread

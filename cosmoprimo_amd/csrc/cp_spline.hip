@@ -21,37 +21,14 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
+#include "cp_math.h"
 
 namespace {
 
+using cpmath::exp10_mid;
+
 constexpr int TILE_Q = 256;      // at most one query per lane
 constexpr int SPAN_CAP = 480;    // knots a tile may cover when it holds more than one query: 16 rows x 480 knots = 60 KB of LDS
-
-// 10^x for the epilogues (tables splined in log10 P): round(x log2 10), log10(2) in two pieces, 10^r = e^(r ln 10) by the degree-13 Taylor
-// polynomial on |r ln 10| <= ln(2) / 2, ldexp -- relative error 2e-16 (checked against 50-digit arithmetic), half the instructions of the
-// library's exp10, which matters where every lane of the GEMM epilogue takes 64 of them per tile
-__device__ __forceinline__ double exp10_mid(double x) {
-    if (!(fabs(x) < 300.)) return exp10(x);
-    const double n = rint(x * 3.321928094887362);
-    double r = fma(-n, 0.3010299955494702, x);
-    r = fma(-n, 1.1451100898021838e-10, r);
-    const double y = r * 2.302585092994046;
-    double p = 1. / 6227020800.;
-    p = fma(p, y, 1. / 479001600.);
-    p = fma(p, y, 1. / 39916800.);
-    p = fma(p, y, 1. / 3628800.);
-    p = fma(p, y, 1. / 362880.);
-    p = fma(p, y, 1. / 40320.);
-    p = fma(p, y, 1. / 5040.);
-    p = fma(p, y, 1. / 720.);
-    p = fma(p, y, 1. / 120.);
-    p = fma(p, y, 1. / 24.);
-    p = fma(p, y, 1. / 6.);
-    p = fma(p, y, 0.5);
-    p = fma(p, y, 1.);
-    p = fma(p, y, 1.);
-    return ldexp(p, (int)n);
-}
 
 struct Args {
     const double* y;    // (nrows, n)
