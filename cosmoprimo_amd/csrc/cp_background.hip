@@ -57,7 +57,7 @@ struct Args {
 
 // TIME: the integrand carries 1 / (1 + z) and the result is (T_last - spline(z)) / h / (Gyr per Mpc): DefaultBackground.time / age
 // (cosmology.py:2000-2025), same RK4 == Simpson scan and natural spline as the distances, on the 400-knot grid.
-template <int NK, bool TIME>
+template <int NK, bool TIME, bool NCDM>   // NCDM = false: no massive species -- their table look-ups (one waterfall loop per ordinate) are not compiled in
 __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     __shared__ TablesN<NK> T;
     {
@@ -66,14 +66,14 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         for (int i = threadIdx.x; i < (int)(sizeof(TablesN<NK>) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
     }
     __shared__ double ncdm_knots[CP_NCDM_NKNOTS];
-    if (A.nsp)
+    if (NCDM && A.nsp)
         for (int i = threadIdx.x; i < CP_NCDM_NKNOTS; i += blockDim.x) ncdm_knots[i] = A.ncdm_knots[i];
     __syncthreads();
     const long long nsamp = A.ncosmo * A.nz;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsamp) return;
     const long long ic = i / A.nz, iz = i - ic * A.nz;
-    const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m, A.ncdm_tab, ncdm_knots, A.nsp);
+    const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m, A.ncdm_tab, ncdm_knots, NCDM ? A.nsp : 0);
     const double z = A.z[A.z_shared ? iz : i];
     const double nan = __builtin_nan("");
     // ordinates sit on the fixed grid, where log(1 + z) is tabulated: the dark-energy term of E(z) is then ONE exp() instead of pow() x exp()
@@ -659,8 +659,10 @@ extern "C" int cp_background_eval(long long ncosmo, long long nz, const cp_param
     const int block = 256;
     const long long grid = (nsamp + block - 1) / block;
     if (kind == CP_BG_RS || kind == CP_BG_RS_COSMOMC) hipLaunchKernelGGL(rs_kernel, dim3((unsigned)nsamp), dim3(64), 0, static_cast<hipStream_t>(stream), A);
-    else if (is_time) hipLaunchKernelGGL((bg_kernel<NK_TIME, true>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
-    else hipLaunchKernelGGL((bg_kernel<NK_DIST, false>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    else if (is_time && A.nsp) hipLaunchKernelGGL((bg_kernel<NK_TIME, true, true>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    else if (is_time) hipLaunchKernelGGL((bg_kernel<NK_TIME, true, false>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    else if (A.nsp) hipLaunchKernelGGL((bg_kernel<NK_DIST, false, true>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
+    else hipLaunchKernelGGL((bg_kernel<NK_DIST, false, false>), dim3((unsigned)grid), dim3(block), 0, static_cast<hipStream_t>(stream), A);
     hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: launch failed: %s", hipGetErrorString(e));
