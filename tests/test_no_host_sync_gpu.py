@@ -104,3 +104,30 @@ def test_sigma_rz_of_a_batch_of_tables(golden):
     fresh = {'pk': torch.as_tensor(rng.uniform(0.5, 2., (50, 1, 1)) * g['table_pk'][None], device=dev)}
     r, zq = torch.as_tensor(np.geomspace(1., 100., 32), device=dev), torch.as_tensor(np.linspace(0.1, 2.5, 8), device=dev)
     capture_and_compare(torch, lambda: cp.PowerSpectrumInterpolator2D(k, z, tables['pk']).sigma_rz(r, zq), tables, fresh)
+
+
+def test_upload_cache():
+    """Small host arrays are kept on the device by content (dtype and shape included); larger ones are copied every time."""
+    import torch
+    from cosmoprimo_amd import _device as dv
+    dev = torch.device('cuda', 0)
+    a = np.linspace(0., 1., 100)
+    t1, t2 = dv.upload(a, dev), dv.upload(a.copy(), dev)
+    assert t1.data_ptr() == t2.data_ptr() and t1.dtype == torch.float64 and tuple(t1.shape) == (100,)
+    assert dv.upload(a.reshape(10, 10), dev).data_ptr() != t1.data_ptr() and tuple(dv.upload(a.reshape(10, 10), dev).shape) == (10, 10)
+    assert dv.upload(a.astype('f4'), dev).dtype == torch.float32
+    mask = a > 0.5
+    tm = dv.upload(mask, dev)
+    assert tm.dtype == torch.bool and bool((tm.cpu().numpy() == mask).all())
+    idx = np.flatnonzero(mask)
+    assert dv.upload(idx, dev).dtype == torch.int64 and np.array_equal(dv.upload(idx, dev).cpu().numpy(), idx)
+    assert tuple(dv.upload(3.5, dev).shape) == () and float(dv.upload(3.5, dev)) == 3.5
+    b = a.copy()
+    b[3] = 7.
+    assert dv.upload(b, dev).data_ptr() != t1.data_ptr() and float(dv.upload(b, dev)[3]) == 7. and float(t1[3]) == a[3]
+    big = np.arange(100000.)
+    u1, u2 = dv.upload(big, dev), dv.upload(big, dev)
+    assert u1.data_ptr() != u2.data_ptr() and np.array_equal(u1.cpu().numpy(), big)
+    assert dv.to_device(np.arange(5), dev).dtype == torch.float64
+    t = torch.arange(4., device=dev)
+    assert dv.upload(t, dev) is t
