@@ -2,8 +2,9 @@
 Headline benchmark (BASELINE.json): batched FFTLog P(k) -> xi(r) transforms/sec at N=2048, fp64, with the achieved
 fraction of the HBM roofline.
 
-    python bench.py [--gpus N --steps K --warmup W]          # N=1, config 2 (the headline)
+    python bench.py [--gpus N --steps K --warmup W]          # config 2 (the headline); N > 1 without a launcher: bench.py starts its own N ranks
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W [--config 2|4|5] [--gather]
+(under a launcher WORLD_SIZE must equal --gpus: a mismatch exits non-zero)
 
 Workload: per GPU, 100 000 rows x 2048 log-k bins, rows = A_b (k/0.05)^dn_b P_EH(k),
 A~U(0.5,2), dn~U(-0.1,0.1), default_rng(rank); PowerToCorrelation(k, ell=0), defaults (lowring, extrap=0) -> Np=4096.
@@ -285,6 +286,34 @@ def main_split(args, config):
         dist.destroy_process_group()
 
 
+def _launch_ranks_if_needed(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks itself (one process per GPU through
+    ``python -m torch.distributed.run``, a CHILD process started before this one has made any GPU call), relay its output and exit with its
+    code.  Under a launcher the world size must be the --gpus that was asked for; anything else exits non-zero instead of printing a line
+    that claims N GPUs."""
+    world = int(os.environ.get('WORLD_SIZE', 1)) if 'RANK' in os.environ else None
+    if world is not None:
+        if world != args.gpus:
+            sys.exit('bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a line for %d GPU(s)'
+                     % (args.gpus, world, args.gpus))
+        return
+    if args.gpus <= 1 and not args.launcher:
+        return
+    import subprocess
+    import torch       # device_count() does not initialise the GPU runtime of this process
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.exit('bench.py: --gpus %d asked for, %d GPU(s) visible on this node; one rank per GPU is the only mode' % (args.gpus, have))
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -295,8 +324,10 @@ def main():
     ap.add_argument('--gather', action='store_true', help='also time the final RCCL all_gather of the result shards (reported separately)')
     ap.add_argument('--config', type=int, default=2, choices=[2, 4, 5], help='BASELINE.json config: 2 (headline, weak scaling), 4 or 5 (strong splits)')
     ap.add_argument('--ramp-ms', type=float, default=300., help='untimed load before the warmup steps (and before each secondary config), to reach the sustained device state')
+    ap.add_argument('--launcher', action='store_true', help='start the rank(s) through torch.distributed.run even for --gpus 1 (RCCL initialised); N > 1 always does')
     ap.add_argument('--no-secondary', action='store_true', help='skip the configs 3 / 4 / 5 numbers of the N = 1 line')
     args = ap.parse_args()
+    _launch_ranks_if_needed(args)
     if args.config != 2:
         return main_split(args, args.config)
 

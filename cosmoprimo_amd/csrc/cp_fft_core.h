@@ -80,6 +80,19 @@ __device__ __forceinline__ double ld_f64(const void* base, unsigned voff, unsign
 __device__ __forceinline__ void st_f64(void* base, unsigned voff, unsigned soff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_v2i, v), cp_rsrc(base), (int)voff, (int)soff, 0);
 }
+// the rows themselves (read once, written once): cache policy of the access as a build option (aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1)
+#ifndef CP_ROW_LOAD_AUX
+#define CP_ROW_LOAD_AUX 0
+#endif
+#ifndef CP_ROW_STORE_AUX
+#define CP_ROW_STORE_AUX 0
+#endif
+__device__ __forceinline__ double ld_row_f64(const void* base, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cp_rsrc(base), (int)voff, (int)soff, CP_ROW_LOAD_AUX));
+}
+__device__ __forceinline__ void st_row_f64(void* base, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_v2i, v), cp_rsrc(base), (int)voff, (int)soff, CP_ROW_STORE_AUX);
+}
 __device__ __forceinline__ void st_cplx(void* base, unsigned voff, unsigned soff, cplx v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cp_v4i, v), cp_rsrc(base), (int)voff, (int)soff, 0);
 }
@@ -212,6 +225,8 @@ inline double ld_f64(const void* base, unsigned voff, unsigned soff) {
 inline void st_f64(void* base, unsigned voff, unsigned soff, double v) {
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + voff + soff) = v;
 }
+inline double ld_row_f64(const void* base, unsigned voff, unsigned soff) { return ld_f64(base, voff, soff); }
+inline void st_row_f64(void* base, unsigned voff, unsigned soff, double v) { st_f64(base, voff, soff, v); }
 #endif
 
 // LDS accesses by 32-bit byte address.  On the device the address is an integer in the LDS address space: the buffer's

@@ -41,6 +41,9 @@ enum { CP_EXTRAP_CONST = 0, CP_EXTRAP_EDGE = 1, CP_EXTRAP_LOG = 2 };
 #ifndef CP_ROW_SCALE_SPREAD
 #define CP_ROW_SCALE_SPREAD 4
 #endif
+#ifndef CP_SCREEN_SUM  // 1: a thread's magnitude is the exponent of the sum of its |samples| instead of their maximum
+#define CP_SCREEN_SUM 0
+#endif
 #ifndef CP_EARLY_TW1
 #define CP_EARLY_TW1 1
 #endif
@@ -203,6 +206,20 @@ struct Fftlog {
     }
     template <int N>
     static CP_HD void thread_max(const double* a, const double* b, unsigned& ma, unsigned& mb) {
+#if CP_SCREEN_SUM
+        // magnitude of the thread's samples as the exponent of sum |a_r| (between the largest sample and N times it; NaN / Inf
+        // propagate): N fp64 additions with the absolute value as an operand modifier, instead of 2 N integer operations
+        double sa = 0., sb = 0.;
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            sa += __builtin_fabs(a[r]);
+            sb += __builtin_fabs(b[r]);
+        }
+        const unsigned ha = hi_abs(sa), hb = hi_abs(sb);
+        ma = ma > ha ? ma : ha;
+        mb = mb > hb ? mb : hb;
+        return;
+#endif
 #pragma unroll
         for (int r = 0; r < N; ++r) {
             const unsigned ha = hi_abs(a[r]), hb = hi_abs(b[r]);
@@ -312,8 +329,8 @@ struct Fftlog {
                 va[r] = 1e-3 * t + r;
                 vb[r] = 2e-3 * t - r;
             } else {
-                va[r] = ld_f64(ra, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
-                vb[r] = ld_f64(rb, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
+                va[r] = ld_row_f64(ra, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
+                vb[r] = ld_row_f64(rb, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
             }
         }
     }
@@ -428,10 +445,10 @@ struct Fftlog {
         }
 #endif
 #pragma unroll
-        for (int s = 0; s < H; ++s) st_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
+        for (int s = 0; s < H; ++s) st_row_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
         if (has_b) {
 #pragma unroll
-            for (int s = 0; s < H; ++s) st_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
+            for (int s = 0; s < H; ++s) st_row_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
         }
     }
 

@@ -46,3 +46,21 @@ def test_one_rank_under_torchrun():
     assert line['config']['rccl_ranks'] == 1 and line['gather_ms'] > 0 and line['value_with_gather'] > 0
     split = run(base + ['--master-port', '29542', 'bench.py', '--gpus', '1', '--config', '5', '--rows', '200000', '--steps', '2', '--warmup', '1', '--gather'])
     assert split['scaling'] == 'strong' and split['config']['rccl_ranks'] == 1 and split['value'] > 0 and split['unit'] == 'samples/s'
+
+
+def test_self_launch():
+    """`python bench.py --gpus N` without a launcher starts its own ranks: with --launcher also for N = 1 (RCCL then initialised); asking for more
+    GPUs than the node has, or a launcher whose world size is not --gpus, exits non-zero instead of printing a line."""
+    import torch
+    small = ['--rows', '4000', '--steps', '3', '--warmup', '1', '--ramp-ms', '20', '--no-cpu-baseline', '--no-secondary']
+    line = run([sys.executable, 'bench.py', '--gpus', '1', '--launcher'] + small)
+    check(line, 3, 1)
+    assert line['config']['rccl_ranks'] == 1
+    too_many = torch.cuda.device_count() + 1
+    res = subprocess.run([sys.executable, 'bench.py', '--gpus', str(too_many)] + small, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=600)
+    assert res.returncode != 0 and not any(ln.startswith('{') for ln in res.stdout.splitlines()) and 'GPU(s) visible' in res.stderr
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    res = subprocess.run([sys.executable, 'bench.py', '--gpus', '2'] + small, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=600)
+    assert res.returncode != 0 and not any(ln.startswith('{') for ln in res.stdout.splitlines()) and 'WORLD_SIZE' in res.stderr
