@@ -406,7 +406,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - tic
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in zip(starts, ends)]))
+    per_step = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    kernel_ms, kernel_ms_min = float(np.mean(per_step)), float(np.min(per_step))
 
     # the same K steps through the product API (cp.PowerToCorrelation.__call__ on the resident tensor: output allocation, plan
     # lookup and the ctypes call included, no host synchronisation inside)
@@ -467,6 +468,14 @@ def main():
             with open(prof[-1]) as fh:
                 traffic = json.load(fh)['hbm_bytes_per_launch']['total']
             traffic_src = os.path.relpath(prof[-1], ROOT)
+        # the committed rocprofv3 --kernel-trace summary of this same command (scripts/gpu_profile.sh, scripts/summarize_steady.py): steady-state
+        # dispatches only, next to the HIP-event time measured live above
+        rocprof = None
+        steady = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_headline_steady.json')))
+        if steady and nb == ROWS_PER_GPU:
+            with open(steady[-1]) as fh:
+                summ = json.load(fh)
+            rocprof = dict(summ['steady_state'], source=os.path.relpath(steady[-1], ROOT), kernel_ms_hip_events_same_run=(summ.get('same_run_bench_line') or {}).get('kernel_ms_hip_events'))
         line = {
             'metric': 'batched FFTLog P(k)->xi(r) transforms/sec (N=2048)', 'value': value, 'unit': 'transforms/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -476,7 +485,7 @@ def main():
                        'grid': grid.value, 'block': block.value, 'lds_bytes': lds.value},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'fftlog_kernel<4096,16,IN_HALF_ZERO,OUT_HALF>', 'kernel_ms': kernel_ms,
-                         'algorithmic_bytes_per_launch': BYTES_PER_ROW * nb},
+                         'kernel_ms_min': kernel_ms_min, 'rocprof_steady_state': rocprof, 'algorithmic_bytes_per_launch': BYTES_PER_ROW * nb},
             'parity_spot_check_tilted_err': err,
             'value_api': nb * world * args.steps / elapsed_api,   # same batch through cp.PowerToCorrelation.__call__ (resident tensors)
         }

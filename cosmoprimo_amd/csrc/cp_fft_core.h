@@ -80,18 +80,13 @@ __device__ __forceinline__ double ld_f64(const void* base, unsigned voff, unsign
 __device__ __forceinline__ void st_f64(void* base, unsigned voff, unsigned soff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_v2i, v), cp_rsrc(base), (int)voff, (int)soff, 0);
 }
-// the rows themselves (read once, written once): cache policy of the access as a build option (aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1)
-#ifndef CP_ROW_LOAD_AUX
-#define CP_ROW_LOAD_AUX 0
-#endif
-#ifndef CP_ROW_STORE_AUX
-#define CP_ROW_STORE_AUX 0
-#endif
-__device__ __forceinline__ double ld_row_f64(const void* base, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cp_rsrc(base), (int)voff, (int)soff, CP_ROW_LOAD_AUX));
+// the rows themselves, read once and written once: the same accesses with the non-temporal cache policy (aux bit 1 = nt), used when a launch
+// moves more bytes than the Infinity Cache holds (FftlogArgs::stream_rows) -- 1.5 % on the 100 000 x 2048 batch
+__device__ __forceinline__ double ld_row_f64_nt(const void* base, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cp_rsrc(base), (int)voff, (int)soff, 2));
 }
-__device__ __forceinline__ void st_row_f64(void* base, unsigned voff, unsigned soff, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_v2i, v), cp_rsrc(base), (int)voff, (int)soff, CP_ROW_STORE_AUX);
+__device__ __forceinline__ void st_row_f64_nt(void* base, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cp_v2i, v), cp_rsrc(base), (int)voff, (int)soff, 2);
 }
 __device__ __forceinline__ void st_cplx(void* base, unsigned voff, unsigned soff, cplx v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cp_v4i, v), cp_rsrc(base), (int)voff, (int)soff, 0);
@@ -225,8 +220,8 @@ inline double ld_f64(const void* base, unsigned voff, unsigned soff) {
 inline void st_f64(void* base, unsigned voff, unsigned soff, double v) {
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + voff + soff) = v;
 }
-inline double ld_row_f64(const void* base, unsigned voff, unsigned soff) { return ld_f64(base, voff, soff); }
-inline void st_row_f64(void* base, unsigned voff, unsigned soff, double v) { st_f64(base, voff, soff, v); }
+inline double ld_row_f64_nt(const void* base, unsigned voff, unsigned soff) { return ld_f64(base, voff, soff); }
+inline void st_row_f64_nt(void* base, unsigned voff, unsigned soff, double v) { st_f64(base, voff, soff, v); }
 #endif
 
 // LDS accesses by 32-bit byte address.  On the device the address is an integer in the LDS address space: the buffer's
@@ -666,13 +661,15 @@ struct Pass {
     }
     // the same in two steps (w holds P entries; slot i R + s), so that a caller can order the table loads
     // against other memory operations
+    // SKIP: the first SKIP twiddles (s = 1 .. SKIP) are held elsewhere (Fftlog::State::wpin) and not loaded
+    template <int SKIP = 0>
     static CP_HD void twiddle_load(int t, const cplx* tw, cplx* w) {
         if (M == 1) return;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int j = joff(t, i);
 #pragma unroll
-            for (int s = 1; s < R; ++s) {
+            for (int s = 1 + SKIP; s < R; ++s) {
                 if (CP_ABLATE & 4) w[i * R + s] = cplx{1. + 1e-9 * t, 0.5 + s};
                 else w[i * R + s] = ld_cplx(tw, (unsigned)j * 16u, (unsigned)(s * M) * 16u);
             }

@@ -216,11 +216,8 @@ extern "C" int cp_fftlog_execute(const cp_fftlog_plan* p, const double* d_in, do
     A.ext_r = extrap_right;
     A.val_l = val_left;
     A.val_r = val_right;
-    {
-        const unsigned hl = extrap_left == CP_EXTRAP_CONSTANT && p->in_left > 0 ? hi_abs(val_left) : 0u;
-        const unsigned hr = extrap_right == CP_EXTRAP_CONSTANT && p->npad - p->n - p->in_left > 0 ? hi_abs(val_right) : 0u;
-        A.pad_hi = hl > hr ? hl : hr;
-    }
+    // once-read / once-written rows bypass the caches when the launch moves more than the Infinity Cache (256 MB) can keep for a consumer
+    A.stream_rows = (double)nbatch * p->nker * ((double)p->n + A.n_out) * 8. > 512. * 1024. * 1024.;
     A.pre = p->d_pre;
     A.post = p->d_post;
     A.u = p->d_u;

@@ -44,6 +44,12 @@ enum { CP_EXTRAP_CONST = 0, CP_EXTRAP_EDGE = 1, CP_EXTRAP_LOG = 2 };
 #ifndef CP_SCREEN_SUM  // 1: a thread's magnitude is the exponent of the sum of its |samples| instead of their maximum
 #define CP_SCREEN_SUM 0
 #endif
+// The first CP_PIN_TW0 pass-0 twiddles of a thread stay in registers for the whole launch (HALF variants at NP = 4096 only): they are the same
+// for every pair, the kernel uses 225-238 of the 256 registers two waves per SIMD leave it, and every table load taken out pays (measured on
+// 100 000 x 2048, nt rows: 0 -> 0.972 ms, 3 -> 0.965, 6 -> 0.958, 7 -> 0.951, 8 -> 0.953 with all 256 registers taken).
+#ifndef CP_PIN_TW0
+#define CP_PIN_TW0 7
+#endif
 #ifndef CP_EARLY_TW1
 #define CP_EARLY_TW1 1
 #endif
@@ -72,7 +78,7 @@ struct FftlogArgs {
     int n_out;          // output row length (n or NP)
     int ext_l, ext_r;   // CP_EXTRAP_*
     double val_l, val_r;
-    unsigned pad_hi;    // max of hi_abs() of the constant padding values in use (0 when none): they count towards a row's magnitude
+    int stream_rows;    // != 0: the rows are moved with the non-temporal cache policy (launches larger than the Infinity Cache)
     const double* pre;  // (nker, NP) padded prefactor
     const double* post; // (nker, NP) padded postfactor
     const cplx* u;      // (nker, NP) Hermitian-extended u / NP in thread layout [(i R + s) T + t]
@@ -92,6 +98,8 @@ struct Fftlog {
     // phase 1 is a middle DIF phase with LDS twiddles (NPASS >= 3) whose table reads can be issued in phase 0
     static constexpr bool EARLY_TW1 = CP_EARLY_TW1 && NPASS >= 3 && CP_ABLATE == 0;
     static constexpr bool HALF_IN = IN_MODE == IN_HALF || IN_MODE == IN_HALF_ZERO;
+    // pass-0 twiddles s = 1 .. KPIN of the thread are loaded once per launch (State::wpin) instead of once per pair
+    static constexpr int KPIN = (HALF_IN && NP == 4096 && P == 16 && CP_ABLATE == 0) ? CP_PIN_TW0 : 0;
     // LDS: the data slots of one packed pair (NP, or more for a padded layout), then the twiddle tables of passes >= 1
     // (Plan::tw_offset order)
     static constexpr int LDS_DATA = lds_data_slots(NP, P);
@@ -303,7 +311,7 @@ struct Fftlog {
 
     // HALF front end, split in two so the HBM loads of the NEXT pair are issued a whole pair ahead
     // (prefetch registers va / vb live across the phases): issue ...
-    static CP_HD void prefetch_rows(int t, const double* __restrict__ ra, const double* __restrict__ rb, double* va, double* vb) {
+    static CP_HD void prefetch_rows(int t, const double* __restrict__ ra, const double* __restrict__ rb, double* va, double* vb, int stream_rows) {
 #if defined(__HIP_DEVICE_COMPILE__) && CP_WIDE_IO
         // 16-byte accesses: the even lane of each pair loads (a[n], a[n+1]) from row a, the odd lane (b[n], b[n+1]) from row b
         // (n = the even lane's sample), then they trade one double through a DPP lane swap so that every lane holds its own
@@ -323,14 +331,22 @@ struct Fftlog {
             return;
         }
 #endif
+        if (stream_rows && !(CP_ABLATE & 8)) {  // wave-uniform (a kernel argument)
+#pragma unroll
+            for (int r = 0; r < H; ++r) {
+                va[r] = ld_row_f64_nt(ra, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
+                vb[r] = ld_row_f64_nt(rb, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < H; ++r) {
             if (CP_ABLATE & 8) {
                 va[r] = 1e-3 * t + r;
                 vb[r] = 2e-3 * t - r;
             } else {
-                va[r] = ld_row_f64(ra, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
-                vb[r] = ld_row_f64(rb, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
+                va[r] = ld_f64(ra, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
+                vb[r] = ld_f64(rb, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
             }
         }
     }
@@ -444,11 +460,20 @@ struct Fftlog {
             return;
         }
 #endif
+        if (A.stream_rows) {  // wave-uniform (a kernel argument)
 #pragma unroll
-        for (int s = 0; s < H; ++s) st_row_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
+            for (int s = 0; s < H; ++s) st_row_f64_nt(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
+            if (has_b) {
+#pragma unroll
+                for (int s = 0; s < H; ++s) st_row_f64_nt(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
+            }
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < H; ++s) st_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
         if (has_b) {
 #pragma unroll
-            for (int s = 0; s < H; ++s) st_row_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
+            for (int s = 0; s < H; ++s) st_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
         }
     }
 
@@ -484,6 +509,7 @@ struct Fftlog {
         int t0;  // pass0_thread(t)
         unsigned info_cur, info_nxt;  // row screening of the current / the next (prefetched) pair, wave-uniform
         cplx w[P];
+        cplx wpin[KPIN > 0 ? KPIN : 1];
         double fpre[H], fpost[H];
         double va[H], vb[H];
 #if defined(CP_STAMPS)
@@ -493,7 +519,12 @@ struct Fftlog {
 
     template <int I>
     static CP_HD void load_twiddles(int t, const FftlogArgs& A, cplx* w) {
-        Pass<NP, P, I>::twiddle_load(t, A.tw + PL::tw_offset(I), w);
+        Pass<NP, P, I>::template twiddle_load<(I == 0 ? KPIN : 0)>(t, A.tw + PL::tw_offset(I), w);
+    }
+    template <class ST>
+    static CP_HD void merge_pinned(const ST& st, cplx* wl) {
+#pragma unroll
+        for (int s = 0; s < P; ++s) wl[s] = (s >= 1 && s <= KPIN) ? st.wpin[s - 1] : st.w[s];
     }
 
     static CP_HD void load_u(int t, const FftlogArgs& A, int ker, cplx* w) {
@@ -549,9 +580,14 @@ struct Fftlog {
     static CP_HD void init_state(int t, const FftlogArgs& A, const double* ra, const double* rb, int ker, State& st) {
         st.t0 = pass0_thread(t);
         if constexpr (NPASS > 1) load_twiddles<0>(st.t0, A, st.w);
+        if constexpr (KPIN > 0) {
+            const cplx* tw0 = A.tw + PL::tw_offset(0);
+#pragma unroll
+            for (int s = 1; s <= KPIN; ++s) st.wpin[s - 1] = ld_cplx(tw0, (unsigned)st.t0 * 16u, (unsigned)(s * T) * 16u);
+        }
         if constexpr (HALF_IN) {
             load_factors_half(st.t0, A, ker, st);
-            prefetch_rows(st.t0, ra, rb, st.va, st.vb);
+            prefetch_rows(st.t0, ra, rb, st.va, st.vb, A.stream_rows);
         }
     }
 
@@ -612,13 +648,19 @@ struct Fftlog {
                 // before they are consumed, ahead of every other memory operation of this pair (vmcnt retires in order, so
                 // the U / twiddle waits of phases 2 and 4 also retire them) and never behind this pair's stores.
                 CP_SCHED_FENCE();
-                prefetch_rows(t0, nra, nrb, st.va, st.vb);
+                prefetch_rows(t0, nra, nrb, st.va, st.vb, A.stream_rows);
                 CP_SCHED_FENCE();
             } else {
                 load_input(t0, t, A, ra, rb, has_b, pre, lds, st.info_cur, x);
             }
             // IN_HALF_ZERO: points 0..3 and 12..15 are structural zeros
-            Pass<NP, P, 0>::template butterflies_store<IN_MODE == IN_HALF_ZERO, true>(t0, st.w, lds, x);
+            if constexpr (KPIN > 0) {
+                cplx wl[P];
+                merge_pinned(st, wl);
+                Pass<NP, P, 0>::template butterflies_store<IN_MODE == IN_HALF_ZERO, true>(t0, wl, lds, x);
+            } else {
+                Pass<NP, P, 0>::template butterflies_store<IN_MODE == IN_HALF_ZERO, true>(t0, st.w, lds, x);
+            }
             load_tables_for<1>(t, t0, A, ker, st.w);
             // the LDS twiddles of phase 1 do not depend on the exchange: read them in front of the barrier (w is free), so
             // that only the 16 data reads are left for the burst behind it
@@ -673,7 +715,13 @@ struct Fftlog {
 #endif
             // Nothing is loaded after this pair's stores (w keeps the pass-0 twiddles for the next pair's phase 0), so the
             // stores stay in flight while the next pair starts.
-            Pass<NP, P, 0>::twiddle_apply(st.w, x);
+            if constexpr (KPIN > 0) {
+                cplx wl[P];
+                merge_pinned(st, wl);
+                Pass<NP, P, 0>::twiddle_apply(wl, x);
+            } else {
+                Pass<NP, P, 0>::twiddle_apply(st.w, x);
+            }
             CP_FS(st, 6);
             Pass<NP, P, 0>::butterflies(x);
             if constexpr (HALF_IN && OUT_MODE == OUT_HALF) {

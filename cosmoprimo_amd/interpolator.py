@@ -72,7 +72,9 @@ _host_copies = {}   # id(tensor) -> (weak reference, tensor version, host copy)
 def _host(x):
     """numpy float64 copy of a number / array / tensor (query coordinates are small and define host-built operators).  The copy of a small
     device tensor is remembered while the tensor lives and is not written to: the same grid of radii or redshifts passed call after call
-    costs one device-to-host copy (which synchronises the stream), not one per call."""
+    costs one device-to-host copy (which synchronises the stream), not one per call.  The copy is validated by the tensor's identity and torch
+    version counter: writes that bypass that counter (a foreign kernel writing through ``data_ptr()``, a HIP-graph replay into the tensor) are not
+    seen -- query grids are inputs, keep them constant or pass a new tensor.  Callers that store the result as a public attribute copy it."""
     if dv.is_torch(x):
         if x.numel() > 65536 or not x.is_cuda:
             return dv.to_host(x).astype('f8', copy=False)
@@ -633,15 +635,18 @@ class Interpolator2D(dv.Copyable):
 
 
 def _get_default_kwargs(func, start=0, remove=()):
-    """Default parameters of ``func`` as a dictionary (reference interpolator.py:296-325)."""
-    parameters = inspect.signature(func).parameters
-    default_params = {}
-    for iname, (name, param) in enumerate(parameters.items()):
-        if iname >= start:
-            default_params[name] = param.default
-    for rm in remove:
-        default_params.pop(rm)
-    return default_params
+    """``{argument: default}`` of ``func`` from its ``start``-th argument on, without the names in ``remove`` (what the reference keeps as
+    ``default_params`` of its interpolator classes, interpolator.py:296-325)."""
+    arguments = list(inspect.signature(func).parameters.values())[start:]
+    return {arg.name: arg.default for arg in arguments if arg.name not in remove}
+
+
+def _sorted_axis(values):
+    """A coordinate axis as a private ascending float64 vector (it becomes a public attribute of the interpolator: never the cached, shared host
+    copy of a device tensor) and the permutation that sorts it."""
+    axis = np.array(_host(values), dtype='f8').ravel()
+    order = np.argsort(axis)
+    return axis[order], order
 
 
 class _BasePowerSpectrumInterpolator(dv.Copyable):
@@ -649,28 +654,29 @@ class _BasePowerSpectrumInterpolator(dv.Copyable):
     """Base class for power spectrum interpolators (reference interpolator.py:327-407)."""
 
     def _prepare(self, k, pk, z=None, interp_k='log', extrap_pk='log', extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax):
-        self.k = _host(k).ravel()
-        self._pk = _host(pk)
-        if self._pk.ndim > 1 or z is not None:
-            self._pk = self._pk.reshape(self.k.shape + (-1,))
-        ix = np.argsort(self.k)
-        self.k, self._pk = self.k[ix], self._pk[ix]
+        """Sorted axes and table as attributes (``k``, ``z``, ``_pk`` of shape (k,) or (k, z)), the extrapolation range, and the (k, P) the splines
+        are built on: with log-log extrapolation the table continued as power laws down to ``extrap_kmin`` and up to ``extrap_kmax``
+        (reference interpolator.py:331-351)."""
+        self.interp_k, self.extrap_pk = str(interp_k), str(extrap_pk)
+        self.k, order_k = _sorted_axis(k)
+        table = np.asarray(_host(pk), dtype='f8')
+        if z is not None or table.ndim > 1:
+            table = table.reshape(self.k.size, -1)
+        table = table[order_k]
         if z is not None:
-            self.z = _host(z).ravel()
-            ix = np.argsort(self.z)
-            self.z, self._pk = self.z[ix], self._pk[:, ix]
-        self.interp_k = str(interp_k)
-        self.extrap_pk = str(extrap_pk)
-        k, pk = self.k, self._pk
-        self.extrap_kmin, self.extrap_kmax = k[0], k[-1]
-        if self.extrap_pk == 'log':
-            if self.interp_k != 'log':
-                raise ValueError('log-log extrapolation requires log-x interpolation')
-            self.extrap_kmin, self.extrap_kmax = extrap_kmin, extrap_kmax
-            with np.errstate(all='ignore'):   # negative P -> NaN everywhere, without raising (reference tests/test_interpolator.py:328-337)
-                k, pk = _pad_log(k, pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
-                k, pk = 10**k, 10**pk
-        return k, pk
+            self.z, order_z = _sorted_axis(z)
+            table = table[:, order_z]
+        self._pk = table
+        if self.extrap_pk != 'log':
+            self.extrap_kmin, self.extrap_kmax = self.k[0], self.k[-1]
+            return self.k, table
+        if self.interp_k != 'log':
+            self.extrap_kmin, self.extrap_kmax = self.k[0], self.k[-1]
+            raise ValueError('log-log extrapolation requires log-x interpolation')
+        self.extrap_kmin, self.extrap_kmax = extrap_kmin, extrap_kmax
+        with np.errstate(all='ignore'):   # negative P -> NaN everywhere, without raising (reference tests/test_interpolator.py:328-337)
+            logk, logpk = _pad_log(self.k, table, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
+            return 10**logk, 10**logpk
 
     def params(self):
         """Return interpolator parameter dictionary."""
@@ -847,7 +853,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         """``_prepare`` + ``_pad_log`` (reference interpolator.py:329-351, 42-87) for a batch of tables (batch, nk, nz), on the device: sorted grids,
         and with log-log extrapolation two linearly extrapolated points of log10 P against log10 k on either side."""
         torch = dv.torch()
-        self.k, self.z = _host(k).ravel(), _host(z).ravel()
+        self.k, self.z = np.array(_host(k), dtype='f8').ravel(), np.array(_host(z), dtype='f8').ravel()      # private copies: public attributes
         pk = dv.to_device(pk, self.device)
         if tuple(pk.shape[1:]) != (self.k.size, self.z.size):
             raise ValueError('pk must be (batch, {:d}, {:d}), got {}'.format(self.k.size, self.z.size, tuple(pk.shape)))
@@ -1150,14 +1156,14 @@ class _BaseCorrelationFunctionInterpolator(dv.Copyable):
     """Base class for correlation function interpolators (reference interpolator.py:990-1071)."""
 
     def _prepare(self, s, xi, z=None, interp_s='log'):
-        self.s = _host(s).ravel()
-        self._xi = _host(xi)
+        self.s = np.array(_host(s), dtype='f8').ravel()      # private copies: public attributes
+        self._xi = np.array(_host(xi), dtype='f8')
         if self._xi.ndim > 1:
             self._xi = self._xi.reshape(self.s.shape + (-1,))
         ix = np.argsort(self.s)
         self.s, self._xi = self.s[ix], self._xi[ix]
         if z is not None:
-            self.z = _host(z).ravel()
+            self.z = np.array(_host(z), dtype='f8').ravel()
             ix = np.argsort(self.z)
             self.z, self._xi = self.z[ix], self._xi[:, ix]
         self.interp_s = str(interp_s)

@@ -2,7 +2,7 @@
 # Usage (on the GPU box, from the repo root): bash scripts/gpu_profile.sh <tag>
 # Kernel trace + HBM / LDS / issue counters of the bench command (separate passes, program directly after `--`) and the calibration of
 # FETCH_SIZE / WRITE_SIZE for 8- and 16-byte accesses; summaries land in gpurun_out/prof_<tag>/.
-tag=${1:-r2}
+tag=${1:-r3}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -16,5 +16,6 @@ timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_grbm
 hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_cal tools/fetch_calibration.hip 2> $out/cal_build.log
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/cal_fetch -- /tmp/fetch_cal > $out/cal_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/cal_write -- /tmp/fetch_cal > $out/cal_write.log 2>&1
+python3 scripts/summarize_steady.py $tag > $out/steady.log 2>&1   # profiles/<tag>_headline_{kernel_stats.csv,steady.json}
 find $out -name "*.csv" | wc -l
 tail -2 $out/trace.log

@@ -1,0 +1,57 @@
+"""Steady-state summary of the headline kernel from a rocprofv3 --kernel-trace run of bench.py (written by scripts/gpu_profile.sh):
+
+    python scripts/summarize_steady.py <tag>     # gpurun_out/prof_<tag>/trace -> profiles/<tag>_headline_kernel_stats.csv, profiles/<tag>_headline_steady.json
+
+The bench loads the device for 300 ms before its warm-up and timed steps (the first tens of milliseconds after an idle period run ~10 % slower);
+the dispatches of that ramp are listed apart from the steady-state ones, which are what `roofline.achieved` of the bench line is measured on.
+The bench line printed by the SAME profiled run is kept beside the summary, so the HIP-event time and the profiler's time can be compared on
+one run (under the profiler both read about 1-3 % longer than in an unprofiled run)."""
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = 'gpurun_out/prof_%s' % tag
+RAMP_NS = 300e6
+ROWS, BYTES_PER_ROW, PEAK = 100000, 2 * 8 * 2048, 8e12
+
+stats = glob.glob(src + '/trace/**/*kernel_stats.csv', recursive=True)[0]
+shutil.copy(stats, 'profiles/%s_headline_kernel_stats.csv' % tag)
+trace = glob.glob(src + '/trace/**/*kernel_trace.csv', recursive=True)[0]
+disp = []
+for row in csv.DictReader(open(trace)):
+    if 'fftlog_kernel' in row['Kernel_Name']:
+        disp.append((int(row['Start_Timestamp']), int(row['End_Timestamp']), int(row['VGPR_Count']), int(row['Grid_Size_X']), int(row['LDS_Block_Size'])))
+disp.sort()
+t0 = disp[0][0]
+dur = lambda rows: [(e - s) * 1e-6 for s, e, *_ in rows]      # noqa: E731  (ms)
+ramp = [d for d in disp if d[0] - t0 < RAMP_NS]
+steady = [d for d in disp if d[0] - t0 >= RAMP_NS]
+
+
+def summary(rows):
+    d = dur(rows)
+    if not d:
+        return None
+    mean = sum(d) / len(d)
+    return {'n': len(d), 'mean_ms': mean, 'min_ms': min(d), 'max_ms': max(d), 'frac_of_hbm_peak_at_mean': ROWS * BYTES_PER_ROW / (mean * 1e-3) / PEAK}
+
+
+bench_line = None
+for line in open(src + '/trace.log'):
+    if line.startswith('{'):
+        bench_line = json.loads(line)
+out = {
+    'command': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary',
+    'kernel': 'cpfft::fftlog_kernel<4096, 16, 3, 1>', 'rows_per_launch': ROWS, 'algorithmic_bytes_per_launch': ROWS * BYTES_PER_ROW,
+    'vgpr_count': disp[0][2], 'grid': disp[0][3], 'lds_bytes': disp[0][4],
+    'all_dispatches': summary(disp), 'ramp_first_300ms': summary(ramp), 'steady_state': summary(steady),
+    'same_run_bench_line': None if bench_line is None else {'kernel_ms_hip_events': bench_line['roofline']['kernel_ms'], 'frac': bench_line['roofline']['frac'],
+                                                            'ms_per_step': bench_line['ms_per_step'], 'value': bench_line['value']},
+}
+if bench_line is not None and out['steady_state']:
+    out['events_over_rocprof_steady_mean'] = bench_line['roofline']['kernel_ms'] / out['steady_state']['mean_ms']
+json.dump(out, open('profiles/%s_headline_steady.json' % tag, 'w'), indent=1)
+print(json.dumps(out, indent=1))

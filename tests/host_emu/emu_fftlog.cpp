@@ -25,7 +25,7 @@ template <int NP, int P, int IM, int OM>
 static void run_pair(const FftlogArgs& A, const double* ra, const double* rb, double* oa, double* ob, bool has_b, int ker, cplx* lds,
                      const double* nra, const double* nrb, int nxt_ker, void* state, bool first) {
     using F = Fftlog<NP, P, IM, OM>;
-    static_assert(sizeof(typename F::State) <= (16 * P + 32 * 8 + 32), "state slot too small");
+    static_assert(sizeof(typename F::State) <= (16 * P + 32 * 8 + 32 + 16 * 8), "state slot too small");
     auto* st = reinterpret_cast<typename F::State*>(state);
     if (first)
         for (int t = 0; t < F::T; ++t) F::init_state(t, A, ra, rb, ker, st[t]);
@@ -45,11 +45,11 @@ static int emulate(int n, int nker, const double* pre, const double* post, const
     A.out_off = keep_padding ? 0 : npad - npad / 2;
     A.n_out = keep_padding ? NP : n;
     A.ext_l = ext_l; A.ext_r = ext_r; A.val_l = val_l; A.val_r = val_r;
-    A.pad_hi = 0;  // device-side reduction only; the emulation takes the magnitudes straight from the rows
+    A.stream_rows = 0;
     A.pre = pre; A.post = post; A.u = u.data(); A.tw = tw.data();
     for (int t = 0; t < Plan<NP, P>::T; ++t) Fftlog<NP, P>::fill_lds_tables(t, A, lds.data());
     const long long nhalf = (nbatch + 1) / 2, npairs = nhalf * nker;
-    std::vector<char> pfv((size_t)(16 * P + 32 * 8 + 32) * Plan<NP, P>::T);  // State is the same size for every variant of (NP, P)
+    std::vector<char> pfv((size_t)(16 * P + 32 * 8 + 32 + 16 * 8) * Plan<NP, P>::T);  // State is the same size for every variant of (NP, P)
     void* pf = pfv.data();
     auto rows = [&](long long p, const double*& ra, const double*& rb, double*& oa, double*& ob, bool& has_b, int& ker) {
         ker = (int)(p % nker);

@@ -30,6 +30,9 @@ using namespace cpfft;
 #ifndef MB_GENERIC  // 1: the generic front / back ends; 2: the HALF front end with 'edge' padding; 0: HALF_ZERO (flagship)
 #define MB_GENERIC 0
 #endif
+#ifndef MB_STREAM_ROWS  // non-temporal row accesses (what cp_fftlog_execute selects for launches of this size)
+#define MB_STREAM_ROWS 1
+#endif
 #ifndef MB_WGS_PER_CU
 #define MB_WGS_PER_CU 2
 #endif
@@ -60,7 +63,7 @@ int main(int argc, char** argv) {
     CHECK(hipMemcpy(d_tw, tw.data(), tw.size() * 16, hipMemcpyHostToDevice));
     FftlogArgs A;
     A.in = d_in; A.out = d_out; A.nbatch = nbatch; A.nker = 1; A.n = N; A.in_left = NP / 4; A.out_off = NP / 4; A.n_out = N;
-    A.ext_l = A.ext_r = MB_GENERIC == 2 ? 1 : 0; A.val_l = A.val_r = 0.; A.pad_hi = 0; A.pre = d_pre; A.post = d_post; A.u = d_u; A.tw = d_tw;
+    A.ext_l = A.ext_r = MB_GENERIC == 2 ? 1 : 0; A.val_l = A.val_r = 0.; A.stream_rows = MB_STREAM_ROWS; A.pre = d_pre; A.post = d_post; A.u = d_u; A.tw = d_tw;
 #if defined(CP_STAMPS)
     unsigned long long* d_stamp;
     const size_t nstamp = (size_t)2048 * 8 * 16;
