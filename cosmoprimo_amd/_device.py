@@ -46,19 +46,26 @@ def resolve_device(device=None, *tensors):
     return device
 
 
-_upload_cache = collections.OrderedDict()      # (device index, dtype, shape, digest of the bytes) -> device tensor, least recently used first
+_upload_cache = collections.OrderedDict()      # (device index, dtype, shape, digest of the bytes) -> (tensor, event, stream), least recently used first
+_upload_held = {}                              # entries a HIP graph was recorded on: never evicted (a replay reads their raw pointers)
 _UPLOAD_CACHE_ENTRIES, _UPLOAD_CACHE_BYTES = 1024, 1 << 16
 
 
-def upload(x, device):
-    """Tensor on ``device`` from a numpy array / number / tensor, dtype kept; the result is to be treated as read-only.
+def upload(x, device, cache=True):
+    """Tensor on ``device`` from a numpy array / number / tensor, dtype kept.
 
-    Host arrays up to 64 KiB (grids, masks, index lists, parameter vectors: what the pipelines upload again and again) are kept on the device,
-    keyed by their content: a second upload of the same values is a dictionary lookup, and a function that has run once can be recorded into a
-    HIP graph (``torch.cuda.graph``) without any copy in it.  Larger ones, up to 1 MiB, go through a page-locked block of torch's caching host
-    allocator and an asynchronous copy: a copy from pageable memory blocks the host until everything queued on the stream before it has run,
-    i.e. every small upload in the middle of a pipeline was a device synchronisation (21 of them per 16 384-vector chunk of the wallish2018
-    filter)."""
+    cache=True (grids, masks, index lists, weights: the constants pipelines upload again and again): host arrays up to 64 KiB are kept on the
+    device, keyed by their content; a second upload of the same values is a dictionary lookup and returns the SAME tensor -- it is read-only by
+    contract (an in-place write would change what every later upload of these values returns).  A function that has run once can then be recorded
+    into a HIP graph (``torch.cuda.graph``) without any copy in it; entries that are created or served while a graph is being captured are held
+    for the life of the process, because a replay reads their raw device pointers (the others are evicted least recently used first).  An entry
+    served on another stream than the one its copy was queued on is ordered behind that copy by an event.
+
+    cache=False (per-call parameter vectors): a private tensor, uploaded through a page-locked block and an asynchronous copy.
+
+    Arrays up to 1 MiB go through a page-locked block of torch's caching host allocator: a copy from pageable memory blocks the host until
+    everything queued on the stream before it has run, i.e. every small upload in the middle of a pipeline was a device synchronisation (21 of them
+    per 16 384-vector chunk of the wallish2018 filter)."""
     t = torch()
     if is_torch(x):
         return x.to(device=device)
@@ -66,16 +73,28 @@ def upload(x, device):
     a = np.ascontiguousarray(x)
     if a.dtype.byteorder not in '=|':
         a = a.astype(a.dtype.newbyteorder('='))
+    capturing = t.cuda.is_current_stream_capturing()
     key = None
-    if a.nbytes <= _UPLOAD_CACHE_BYTES:
+    if cache and a.nbytes <= _UPLOAD_CACHE_BYTES:
         key = (t.device(device).index, a.dtype.str, shape, hashlib.blake2b(a.tobytes(), digest_size=16).digest())
-        hit = _upload_cache.get(key)
+        hit = _upload_held.get(key)
+        if hit is None:
+            hit = _upload_cache.get(key)
+            if hit is not None:
+                if capturing:       # the graph being recorded will read this tensor at every replay: out of the evictable set
+                    _upload_held[key] = _upload_cache.pop(key)
+                else:
+                    _upload_cache.move_to_end(key)
         if hit is not None:
-            _upload_cache.move_to_end(key)
-            return hit
-    if t.cuda.is_current_stream_capturing():
+            tensor, event, stream = hit
+            if not capturing:
+                current = t.cuda.current_stream(tensor.device)
+                if current.cuda_stream != stream:
+                    current.wait_event(event)       # the copy was queued on another stream
+            return tensor
+    if capturing:
         raise RuntimeError('a host array is uploaded while a HIP graph is being captured: call the function once before capturing it, so that its '
-                           'constants are on the device')
+                           'constants are on the device (per-call values must be device tensors)')
     h = t.from_numpy(a) if a.flags.writeable else t.from_numpy(a.copy())
     out = None
     if 0 < a.nbytes <= (1 << 20):
@@ -86,18 +105,22 @@ def upload(x, device):
     if out is None:
         out = h.to(device).reshape(shape)
     if key is not None:
-        _upload_cache[key] = out
+        current = t.cuda.current_stream(out.device)
+        event = t.cuda.Event()
+        event.record(current)
+        _upload_cache[key] = (out, event, current.cuda_stream)
         if len(_upload_cache) > _UPLOAD_CACHE_ENTRIES:
             _upload_cache.popitem(last=False)
     return out
 
 
-def to_device(x, device):
-    """float64 contiguous tensor on ``device`` from a number / numpy array / tensor (shape preserved)."""
+def to_device(x, device, cache=True):
+    """float64 contiguous tensor on ``device`` from a number / numpy array / tensor (shape preserved).  Small host arrays come from the content-keyed
+    cache of :func:`upload` and are shared: treat the result as read-only, or pass ``cache=False`` for a private tensor (per-call parameters)."""
     t = torch()
     if is_torch(x):
         return x.to(device=device, dtype=t.float64).contiguous()
-    return upload(np.asarray(x, dtype='f8'), device)
+    return upload(np.asarray(x, dtype='f8'), device, cache=cache)
 
 
 def to_host(x):
@@ -163,7 +186,7 @@ def pack_params(names, params, defaults, device):
         if not is_torch(v) and np.ndim(v) == 0:
             carr[i].ptr, carr[i].value = None, float(v)
             continue
-        tv = to_device(v, device).reshape(-1)
+        tv = to_device(v, device, cache=False).reshape(-1)      # per-call parameter vectors: private, not cached
         if ncosmo is not None and tv.numel() != ncosmo:
             raise ValueError('parameter arrays must share one length, got {} and {}'.format(ncosmo, tv.numel()))
         ncosmo = tv.numel()

@@ -25,7 +25,7 @@ def _cparam(v, device, keep):
     import torch
     if np.ndim(v) == 0 and not _is_torch(v):
         return _lib.cp_param(None, float(v)), None
-    t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else dv.upload(np.asarray(v, dtype='f8'), device)
+    t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else dv.upload(np.asarray(v, dtype='f8'), device, cache=False)
     t = t.reshape(-1).contiguous()
     keep.append(t)
     return _lib.cp_param(t.data_ptr(), 0.), t.numel()
@@ -145,7 +145,7 @@ def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=N
         if np.ndim(v) == 0 and not _is_torch(v):
             cparams[i].ptr, cparams[i].value = None, float(v)
             continue
-        t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else dv.upload(np.asarray(v, dtype='f8'), device)
+        t = v.to(device=device, dtype=torch.float64) if _is_torch(v) else dv.upload(np.asarray(v, dtype='f8'), device, cache=False)
         t = t.reshape(-1).contiguous()
         if t.numel() == 1 and not batched and np.ndim(v) == 0:
             cparams[i].ptr, cparams[i].value = None, float(t)

@@ -474,7 +474,7 @@ class BaseCosmoParams(dv.Copyable):
         """Host value -> same kind as the (possibly torch) parameters it is combined with."""
         if np.ndim(v) and any(dv.is_torch(x) for x in self._params.values()):
             ref = next(x for x in self._params.values() if dv.is_torch(x))
-            return dv.upload(np.asarray(v, dtype='f8'), ref.device)
+            return dv.upload(np.asarray(v, dtype='f8'), ref.device, cache=False)
         return v
 
     @property
