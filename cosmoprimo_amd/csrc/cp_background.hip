@@ -426,15 +426,19 @@ struct NcdmArgs {
     int nsp, nq;
     Param h, T_cmb, m[NCDM_MAX_SPECIES], T_over[NCDM_MAX_SPECIES];
     const double* knots;
-    const double* rule;  // device, nodes then weights (2 nq)
     double* tab;
+};
+// the Gauss-Laguerre rule, nodes then weights (2 nq), travels by value in the kernel arguments (2 KB): no device buffer to allocate, fill
+// and free around the launch, so the call is asynchronous and can be recorded into a HIP graph like every other execute
+struct NcdmRule {
+    double v[2 * NCDM_MAX_NQ];
 };
 
 // _compute_ncdm_momenta (cosmology.py:74-137, method 'laguerre') / (1 + z)^3 / h^2 (_get_ncdm, :441-442) on every knot:
 // one thread per (cosmology, species, knot) computes the density and the pressure
-__global__ __launch_bounds__(128) void ncdm_momenta_kernel(const NcdmArgs A) {
+__global__ __launch_bounds__(128) void ncdm_momenta_kernel(const NcdmArgs A, const NcdmRule R) {
     __shared__ double rule[2 * NCDM_MAX_NQ];
-    for (int i = threadIdx.x; i < 2 * A.nq; i += blockDim.x) rule[i] = A.rule[i];
+    for (int i = threadIdx.x; i < 2 * A.nq; i += blockDim.x) rule[i] = R.v[i];
     __syncthreads();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.ncosmo * A.nsp * CP_NCDM_NKNOTS) return;
@@ -568,27 +572,19 @@ extern "C" int cp_ncdm_tables(long long ncosmo, int nspecies, cp_param h, cp_par
     }
     A.knots = device_ncdm_knots(device);
     A.tab = d_tab;
-    double* d_rule = nullptr;
     int rc = CP_OK;
-    if (!A.knots || hipMalloc(&d_rule, 2 * nq * sizeof(double)) != hipSuccess) {
-        rc = cp::fail(CP_ENOMEM, "cp_ncdm_tables: cannot allocate on device %d", device);
+    if (!A.knots) {
+        rc = cp::fail(CP_ENOMEM, "cp_ncdm_tables: cannot allocate the knots on device %d", device);
     } else {
-        std::vector<double> rule(2 * nq);
-        for (int q = 0; q < nq; ++q) rule[q] = nodes[q], rule[nq + q] = weights[q];
-        if (hipMemcpyAsync(d_rule, rule.data(), 2 * nq * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) {  // `rule` is a local: the copy must have left it
-            rc = cp::fail(CP_EDEVICE, "cp_ncdm_tables: cannot upload the quadrature rule");
-        } else {
-            A.rule = d_rule;
-            const long long n1 = ncosmo * nspecies * CP_NCDM_NKNOTS, n2 = ncosmo * nspecies * 2;
-            hipLaunchKernelGGL(ncdm_momenta_kernel, dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, st, A);
-            hipLaunchKernelGGL(ncdm_spline_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, A);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipStreamSynchronize(st);  // d_rule is freed below
-            if (e != hipSuccess) rc = cp::fail(CP_EDEVICE, "cp_ncdm_tables: launch failed: %s", hipGetErrorString(e));
-        }
+        NcdmRule R;
+        for (int q = 0; q < nq; ++q) R.v[q] = nodes[q], R.v[nq + q] = weights[q];
+        for (int q = 2 * nq; q < 2 * NCDM_MAX_NQ; ++q) R.v[q] = 0.;
+        const long long n1 = ncosmo * nspecies * CP_NCDM_NKNOTS, n2 = ncosmo * nspecies * 2;
+        hipLaunchKernelGGL(ncdm_momenta_kernel, dim3((unsigned)((n1 + 127) / 128)), dim3(128), 0, st, A, R);
+        hipLaunchKernelGGL(ncdm_spline_kernel, dim3((unsigned)((n2 + 63) / 64)), dim3(64), 0, st, A);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = cp::fail(CP_EDEVICE, "cp_ncdm_tables: launch failed: %s", hipGetErrorString(e));
     }
-    if (d_rule) (void)hipFree(d_rule);
     if (prev >= 0) (void)hipSetDevice(prev);
     return rc;
 }

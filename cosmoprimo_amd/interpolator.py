@@ -542,7 +542,7 @@ class Interpolator2D(dv.Copyable):
             build = lambda: LinearOperator.dense(_fitpack_interp_operator(knots, q, k), device=self.device)
         return _cached_operator(('i2' + axis, k, knots.tobytes(), q.tobytes(), self.device.index), build)
 
-    def rows_y_major(self, xh, yh, exp10=False, batch=None):
+    def rows_y_major(self, xh, yh, exp10=False):
         """The surfaces on the grid of flat host coordinates (xh, yh) as (batch..., ny, nx), x fastest -- the layout of rows of P(k) at every z --
         in two passes: the x operator (banded spline kernel) on the table kept y-major, then the y operator along the middle axis as a GEMM on the
         matrix cores whose epilogue applies 10^x when asked (tables splined in log10 P) and writes the result once.  No mask."""
@@ -555,8 +555,6 @@ class Interpolator2D(dv.Copyable):
         yq = np.clip(yh, knots[0], knots[-1])
         opy = _cached_operator(('i2y-dense', k, knots.tobytes(), yq.tobytes(), self.device.index),
                                lambda: LinearOperator.dense(self._operator('y', yq, dense=True), device=self.device))
-        if batch is not None:       # a slice of the (single) batch axis: the caller walks the tables in blocks (PowerSpectrumInterpolator2D.sigma_rz)
-            fun_t = fun_t[batch]
         out = opy.mid(self._operator('x', xq)(fun_t), post='exp10' if exp10 else None)     # (batch..., ny, nxq) -> (batch..., nyq, nxq)
         if self._nan_surfaces is not None:
             out = dv.torch().where(self._nan_surfaces[..., None, None], dv.torch().full_like(out, float('nan')), out)
@@ -988,23 +986,19 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         shape = tuple(out.shape[:nlead]) + (kh.shape + zh.shape if grid else kh.shape)
         return _finish(out, dtype, like_torch, shape)
 
-    def _rows_z(self, zh, ignore_growth=False, batch=None):
-        """Callable k -> rows (batch..., nz, nk) of P(k, z) for the sigma integrals; ``batch``: a slice of a batch of tables."""
+    def _rows_z(self, zh, ignore_growth=False):
+        """Callable k -> rows (batch..., nz, nk) of P(k, z) for the sigma integrals."""
         def rows(kh):
             if not self.is_from_callable and self._is2d() and kh.size and zh.size:
                 # (k, z) tables: the surfaces come out of the two spline operators z-major already (z contraction first), no transposed copy
                 torch = dv.torch()
                 mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)])
-                out = self._interp.rows_y_major(kh, zh, exp10=self._interp.interp_fun == 'log', batch=batch)
+                out = self._interp.rows_y_major(kh, zh, exp10=self._interp.interp_fun == 'log')
                 mask = mask_z[:, None] & mask_k
                 if not mask.all():
                     out = torch.where(dv.upload(mask, self.device), out, torch.full_like(out, float('nan')))
                 if self.growth_factor_sq is not None and not ignore_growth:
                     out = out * dv.to_device(self.growth_factor_sq(zh), self.device)[..., :, None]
-                if batch is not None:
-                    rs = self._rsigma8sq
-                    if dv.is_torch(rs) or np.ndim(rs) > 0:
-                        return out * dv.to_device(rs, self.device)[batch].reshape(-1, 1, 1)
                 return self._rescaled(out, out.ndim - 2) if getattr(self, '_tables_batched', False) else (
                     out if isinstance(self._rsigma8sq, float) and self._rsigma8sq == 1. else out * self._rsigma8sq)
             return self._eval_device(kh, zh, grid=True, ignore_growth=ignore_growth).transpose(-1, -2).contiguous()
@@ -1078,26 +1072,10 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             base, growth = self._sigma_separable(lambda rows: integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
                                                                                  **kwargs), zh.ravel())
             out = base[..., :, None] * growth[..., None, :]
-        elif getattr(self, '_tables_batched', False) and rh.size and zh.size and self._table_block(zh.size) < self._pk.shape[0]:
-            # A large batch of tables goes through the four passes (k-spline, z-contraction + 10^x, FFTLog, r-spline + sqrt) block by block: the
-            # spectra and variances between the passes -- 8 x the bytes of the tables and the result -- then stay in the Infinity Cache instead of
-            # making two round trips through HBM each, and the (nz, nr) -> (nr, nz) transposition is part of the copy into the result.
-            torch = dv.torch()
-            nb, block = self._pk.shape[0], self._table_block(zh.size)
-            out = torch.empty((nb, rh.size, zh.size), dtype=torch.float64, device=self.device)
-            for start in range(0, nb, block):
-                sl = slice(start, min(nb, start + block))
-                part = integrate_sigma_r2(rh, self._rows_z(zh.ravel(), batch=sl), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True, **kwargs)
-                out[sl].copy_(part.transpose(-1, -2))
         else:
             out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True, **kwargs)
             out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
         return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
-
-    _table_block_bytes = 96 << 20     # largest intermediate of a block of tables: (block, nz, 1024) float64 spectra
-
-    def _table_block(self, nz):
-        return max(1, int(self._table_block_bytes // (8 * 1024 * max(1, nz))))
 
     def sigma8_z(self, z=0, **kwargs):
         """R.m.s. of perturbations in a sphere of 8."""

@@ -81,7 +81,11 @@ typedef struct cp_fftlog_plan cp_fftlog_plan;
 /* Tables are HOST arrays as the reference's FFTlog._setup produces them (fftlog.py:144-184):
  *   pre, post : (nker, npad) float64  padded_prefactor / padded_postfactor (real part)
  *   u_re_im   : (nker, npad/2 + 1) complex128 padded_u, interleaved
- * npad must be the power of two 2**((n*minfolds-1).bit_length()); pad splits follow fftlog.py:152-153. */
+ * npad must be the power of two 2**((n*minfolds-1).bit_length()); pad splits follow fftlog.py:152-153.
+ * npad <= 8192 (every size the reference's own callers and BASELINE.json's configs use) runs the fused hand-written kernel.  Larger sizes, up to
+ * 2^24, are a LIBRARY FALLBACK outside the BASELINE configs: the same arithmetic as three elementwise kernels around hipFFT D2Z / Z2D batches
+ * (csrc/cp_fftlog_large.hip, hipFFT loaded on first use); it exists for completeness of FFTlog's size range, is not a native kernel, and no
+ * performance figure of this package refers to it. */
 int cp_fftlog_plan_create(cp_fftlog_plan** plan, int n, int npad, int nker, const double* pre, const double* post,
                           const double* u_re_im, int device);
 /* d_in : device (nbatch, nker, n) float64 C-contiguous;  d_out : device (nbatch, nker, n or npad).
@@ -173,7 +177,8 @@ int cp_growth_ode_knots(double* zc_out, int n);
 int cp_growth_ode_tables(long long ncosmo, const cp_param* params, int second_is_omega_m, const cp_ncdm* ncdm, int mass, double* d_tab, int device,
                          void* stream);
 /* m_ncdm[s] (eV) and T_ncdm_over_cmb[s], s < nspecies: per-cosmology parameters like h and T_cmb; nodes / weights: the nq-point
- * Gauss-Laguerre rule (host arrays; the reference uses numpy.polynomial.laguerre.laggauss(100)); d_tab as in cp_ncdm.tab */
+ * Gauss-Laguerre rule (host arrays, read before the call returns and passed to the kernel by value; the reference uses
+ * numpy.polynomial.laguerre.laggauss(100)); d_tab as in cp_ncdm.tab.  Like every execute: allocates nothing, asynchronous on `stream`. */
 int cp_ncdm_tables(long long ncosmo, int nspecies, cp_param h, cp_param T_cmb, const cp_param* m_ncdm, const cp_param* T_ncdm_over_cmb, int nq,
                    const double* nodes, const double* weights, double* d_tab, int device, void* stream);
 /* cp_background_distance with massive neutrinos (ncdm may be NULL or have nspecies == 0).  With `second_is_omega_m` the non-relativistic

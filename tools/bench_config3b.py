@@ -21,8 +21,6 @@ def main():
     r, zq = torch.as_tensor(g['r'], device='cuda'), torch.as_tensor(g['z'], device='cuda')
     t0 = time.perf_counter()
     interp = cp.PowerSpectrumInterpolator2D(k, z, batch)
-    if len(sys.argv) > 2:      # block size of the pass-by-pass walk in MiB of spectra (0: the whole batch at once)
-        type(interp)._table_block_bytes = (int(sys.argv[2]) << 20) if int(sys.argv[2]) else (1 << 60)
     torch.cuda.synchronize()
     print('setup (sort, log-log padding, log10): %.2f ms' % ((time.perf_counter() - t0) * 1e3))
     for _ in range(3):
