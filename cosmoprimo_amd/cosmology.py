@@ -565,12 +565,17 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
             self._sections = {name: section for name, section in self._sections.items() if name in ('background', 'thermodynamics')}   # untouched by the rescaling
         return self._rsigma8
 
+    def _any_mass(self):
+        masses = self['m_ncdm']
+        return any(bool((m > 0.).any()) if dv.is_torch(m) else bool(np.any(np.asarray(m) > 0.)) for m in (masses if isinstance(masses, (list, tuple)) else [masses]))
+
     def __getattr__(self, name):
         if name.startswith('get_'):
             section = name[4:]
             if section in self.__dict__.get('_Sections', {}):
                 def getter():
-                    if section != 'background' and self['N_ncdm'] and not getattr(self, '_copes_with_ncdm', False):
+                    # species of zero mass are radiation: nothing for the fits to cope with (the reference keeps them in N_ncdm as well, cosmology.py:1119-1121)
+                    if section != 'background' and self['N_ncdm'] and not getattr(self, '_copes_with_ncdm', False) and self._any_mass():
                         raise NotImplementedError('with massive neutrinos only the background section is available on the MI355X path '
                                                   '(these analytic engines "cannot cope with massive neutrinos" in the reference either: use '
                                                   "engine='eisenstein_hu_nowiggle_variants')")
