@@ -14,6 +14,7 @@
 #include "cp_error.h"
 #include "cp_fftlog_kernel.h"
 #include "cp_fftlog_large.h"
+#include "cp_internal.h"
 
 using namespace cpfft;
 
@@ -58,6 +59,12 @@ struct cp_fftlog_plan {
             goto done;                                                                             \
         }                                                                                          \
     } while (0)
+
+bool cp_fftlog_plan_view(const cp_fftlog_plan* p, cp_fftlog_tables_view* out) {
+    if (!p || p->large || !out) return false;
+    *out = cp_fftlog_tables_view{p->n, p->npad, p->nker, p->device, p->in_left, p->out_left, p->d_pre, p->d_post, p->d_u, p->d_tw};
+    return true;
+}
 
 extern "C" int cp_abi_version(void) { return CP_ABI_VERSION; }
 

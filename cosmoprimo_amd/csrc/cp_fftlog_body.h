@@ -61,10 +61,12 @@ enum { CP_EXTRAP_CONST = 0, CP_EXTRAP_EDGE = 1, CP_EXTRAP_LOG = 2 };
 //                points (in_left = NP/4 = (P/4) T, fftlog.py:149-153 with minfolds=2 and n a power of two);
 //                constant or edge padding
 //   IN_HALF_ZERO IN_HALF with zero padding (the reference default extrap=0): padded points are never formed
+//   IN_HALF_ZERO_GEN  IN_HALF_ZERO for a kernel that PRODUCES its rows itself (cp_sigma.hip evaluates P(k) into the row registers in front of
+//                phase 0): nothing is prefetched from memory, the rows are screened inside phase 0
 // Output back ends:
 //   OUT_GENERIC  bounds-checked crop (any out_off / n_out, incl. keep_padding)
 //   OUT_HALF     n == NP/2, cropped output: exactly s in [P/4, 3P/4) (out_left = NP/4)
-enum { IN_GENERIC = 0, IN_LOG = 1, IN_HALF = 2, IN_HALF_ZERO = 3 };
+enum { IN_GENERIC = 0, IN_LOG = 1, IN_HALF = 2, IN_HALF_ZERO = 3, IN_HALF_ZERO_GEN = 4 };
 enum { OUT_GENERIC = 0, OUT_HALF = 1 };
 
 struct FftlogArgs {
@@ -97,7 +99,9 @@ struct Fftlog {
     static constexpr int LAST = NPASS - 1;
     // phase 1 is a middle DIF phase with LDS twiddles (NPASS >= 3) whose table reads can be issued in phase 0
     static constexpr bool EARLY_TW1 = CP_EARLY_TW1 && NPASS >= 3 && CP_ABLATE == 0;
-    static constexpr bool HALF_IN = IN_MODE == IN_HALF || IN_MODE == IN_HALF_ZERO;
+    static constexpr bool HALF_IN = IN_MODE == IN_HALF || IN_MODE == IN_HALF_ZERO || IN_MODE == IN_HALF_ZERO_GEN;
+    static constexpr bool ZERO_PADDED_IN = IN_MODE == IN_HALF_ZERO || IN_MODE == IN_HALF_ZERO_GEN;
+    static constexpr bool ROWS_FROM_MEMORY = IN_MODE != IN_HALF_ZERO_GEN;
     // pass-0 twiddles s = 1 .. KPIN of the thread are loaded once per launch (State::wpin) instead of once per pair
     static constexpr int KPIN = (HALF_IN && NP == 4096 && P == 16 && CP_ABLATE == 0) ? CP_PIN_TW0 : 0;
     // LDS: the data slots of one packed pair (NP, or more for a padded layout), then the twiddle tables of passes >= 1
@@ -587,7 +591,7 @@ struct Fftlog {
         }
         if constexpr (HALF_IN) {
             load_factors_half(st.t0, A, ker, st);
-            prefetch_rows(st.t0, ra, rb, st.va, st.vb, A.stream_rows);
+            if constexpr (ROWS_FROM_MEMORY) prefetch_rows(st.t0, ra, rb, st.va, st.vb, A.stream_rows);
         }
     }
 
@@ -648,7 +652,7 @@ struct Fftlog {
                 // before they are consumed, ahead of every other memory operation of this pair (vmcnt retires in order, so
                 // the U / twiddle waits of phases 2 and 4 also retire them) and never behind this pair's stores.
                 CP_SCHED_FENCE();
-                prefetch_rows(t0, nra, nrb, st.va, st.vb, A.stream_rows);
+                if constexpr (ROWS_FROM_MEMORY) prefetch_rows(t0, nra, nrb, st.va, st.vb, A.stream_rows);
                 CP_SCHED_FENCE();
             } else {
                 load_input(t0, t, A, ra, rb, has_b, pre, lds, st.info_cur, x);
@@ -657,9 +661,9 @@ struct Fftlog {
             if constexpr (KPIN > 0) {
                 cplx wl[P];
                 merge_pinned(st, wl);
-                Pass<NP, P, 0>::template butterflies_store<IN_MODE == IN_HALF_ZERO, true>(t0, wl, lds, x);
+                Pass<NP, P, 0>::template butterflies_store<ZERO_PADDED_IN, true>(t0, wl, lds, x);
             } else {
-                Pass<NP, P, 0>::template butterflies_store<IN_MODE == IN_HALF_ZERO, true>(t0, st.w, lds, x);
+                Pass<NP, P, 0>::template butterflies_store<ZERO_PADDED_IN, true>(t0, st.w, lds, x);
             }
             load_tables_for<1>(t, t0, A, ker, st.w);
             // the LDS twiddles of phase 1 do not depend on the exchange: read them in front of the barrier (w is free), so

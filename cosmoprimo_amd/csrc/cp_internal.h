@@ -1,0 +1,33 @@
+// cp_internal.h -- what the translation units of libcosmoprimo_amd.so share with each other besides the public C ABI (not installed, not part
+// of the ABI): views of plan internals for kernels that fuse several stages (cp_sigma.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/cosmoprimo_amd.h"
+
+namespace cpfft {
+struct cplx;
+}
+
+// device tables of a fused-kernel FFTLog plan (npad <= 8192); false for plans of the general-size path
+struct cp_fftlog_tables_view {
+    int n, npad, nker, device, in_left, out_left;
+    const double* d_pre;
+    const double* d_post;
+    const cpfft::cplx* d_u;
+    const cpfft::cplx* d_tw;
+};
+bool cp_fftlog_plan_view(const cp_fftlog_plan* plan, cp_fftlog_tables_view* out);
+
+// band form of a spline / operator plan: wb (bw, nq) band-major weights (padded entries are zero), j0 (nq) first knot of each band, -1 for a
+// query outside the knots
+struct cp_spline_band_view {
+    int n, nq, bw, device;
+    const double* d_wb;
+    const int* d_j0;
+};
+bool cp_spline_plan_view(const cp_spline_plan* plan, cp_spline_band_view* out);
+
+// fit coefficients of the EH98 / no-wiggle engines for a batch of cosmologies into d_work (cp_power_workspace_bytes(ncosmo) bytes): the first
+// of the two kernels cp_power_eval launches
+int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, void* d_work, int device, void* stream);

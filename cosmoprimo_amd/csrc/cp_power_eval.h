@@ -1,0 +1,163 @@
+// cp_power_eval.h -- the per-cosmology fit coefficients and the per-wavenumber evaluation of the analytic engines (EH98, EH no-wiggle, BBKS) as
+// device functions, shared by the P(k) kernels (cp_power.hip) and by the fused sigma(r, z) kernel (cp_sigma.hip), which evaluates the spectra
+// in the front end of its FFTLog instead of reading them.  Reference: eisenstein_hu.py:34-92, 189-215, 241-283, 315-324;
+// eisenstein_hu_nowiggle.py:21-51; bbks.py:34-64.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "../../include/cosmoprimo_amd.h"
+#include "cp_cosmo_common.h"
+#include "cp_math.h"
+
+namespace cppower {
+
+using namespace cpcosmo;
+using namespace cpmath;
+
+struct EhScalars {
+    double omega_b, omega_m, frac_b, theta_cmb, z_eq, k_eq, z_drag, r_drag, r_eq, rs_drag, k_silk, alpha_c, beta_c, alpha_b, beta_node, beta_b,
+        alpha_gamma;
+    double ln_q_over_kh, ln_ksilk_over_kh;  // log(q / kh) = log(h / (13.41 k_eq)) and log((k / k_silk) / kh) = log(h / k_silk): see transfer_eh
+};
+
+// eisenstein_hu.py:34-92 (+ eisenstein_hu_nowiggle.py:21), operation for operation
+__device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, double Omega_b, double T_cmb, bool full) {
+    EhScalars s;
+    s.omega_b = Omega_b * (h * h);
+    s.omega_m = Omega_cdm * (h * h) + Omega_b * (h * h);
+    s.frac_b = s.omega_b / s.omega_m;
+    s.theta_cmb = T_cmb / 2.7;
+    const double th2 = s.theta_cmb * s.theta_cmb, thm4 = 1. / (th2 * th2), thm2 = 1. / th2;
+    s.z_eq = 2.5e4 * s.omega_m * thm4 - 1.;
+    s.k_eq = 0.0746 * s.omega_m * thm2;
+    const double b1 = 0.313 * pow(s.omega_m, -0.419) * (1 + 0.607 * pow(s.omega_m, 0.674));
+    const double b2 = 0.238 * pow(s.omega_m, 0.223);
+    s.z_drag = 1345 * pow(s.omega_m, 0.251) / (1. + 0.659 * pow(s.omega_m, 0.828)) * (1. + b1 * pow(s.omega_b, b2));  // HS96 prefactor
+    s.r_drag = 31.5 * s.omega_b * thm4 * (1000. / (1 + s.z_drag));
+    s.r_eq = 31.5 * s.omega_b * thm4 * (1000. / (1 + s.z_eq));
+    s.rs_drag = 2. / (3. * s.k_eq) * sqrt(6. / s.r_eq) * log((sqrt(1 + s.r_drag) + sqrt(s.r_drag + s.r_eq)) / (1 + sqrt(s.r_eq)));
+    s.alpha_gamma = 1. - 0.328 * log(431. * s.omega_m) * s.frac_b + 0.38 * log(22.3 * s.omega_m) * (s.frac_b * s.frac_b);
+    if (full) {
+        s.k_silk = 1.6 * pow(s.omega_b, 0.52) * pow(s.omega_m, 0.73) * (1 + pow(10.4 * s.omega_m, -0.95));
+        const double a1 = pow(46.9 * s.omega_m, 0.670) * (1 + pow(32.1 * s.omega_m, -0.532));
+        const double a2 = pow(12.0 * s.omega_m, 0.424) * (1 + pow(45.0 * s.omega_m, -0.582));
+        s.alpha_c = pow(a1, -s.frac_b) * pow(a2, -(s.frac_b * s.frac_b * s.frac_b));
+        const double bb1 = 0.944 / (1 + pow(458 * s.omega_m, -0.708));
+        const double bb2 = 0.395 * pow(s.omega_m, -0.0266);
+        s.beta_c = 1. / (1 + bb1 * (pow(1 - s.frac_b, bb2)) - 1);
+        const double y = (1 + s.z_eq) / (1 + s.z_drag);
+        const double G = y * (-6. * sqrt(1 + y) + (2. + 3. * y) * log((sqrt(1 + y) + 1) / (sqrt(1 + y) - 1)));
+        s.alpha_b = 2.07 * s.k_eq * s.rs_drag * pow(1 + s.r_drag, -0.75) * G;
+        s.beta_node = 8.41 * pow(s.omega_m, 0.435);
+        s.beta_b = 0.5 + s.frac_b + (3. - 2. * s.frac_b) * sqrt((17.2 * s.omega_m) * (17.2 * s.omega_m) + 1);
+        s.ln_q_over_kh = log(h / (13.41 * s.k_eq));
+        s.ln_ksilk_over_kh = log(h / s.k_silk);
+    } else {
+        s.k_silk = s.alpha_c = s.beta_c = s.alpha_b = s.beta_node = s.beta_b = 0.;
+        s.ln_q_over_kh = s.ln_ksilk_over_kh = 0.;
+    }
+    return s;
+}
+
+// What transfer_eh needs of one cosmology, in the units of the loop over wavenumbers (kh in h/Mpc): once per thread
+struct EhPerCosmology {
+    double q_per_kh;     // q = kh h / (13.41 k_eq)
+    double ks_per_kh;    // ks = kh h rs_drag
+    double c_alpha0;     // 14.2 / alpha_c
+    double beta18, beta_node3, beta_b3, alpha_b, frac_b;
+    double ln_q_over_kh, ln_ksilk_over_kh;
+};
+
+__device__ __forceinline__ EhPerCosmology eh_per_cosmology(const EhScalars& s, double h) {
+    EhPerCosmology d;
+    d.q_per_kh = h / (13.41 * s.k_eq);
+    d.ks_per_kh = h * s.rs_drag;
+    d.c_alpha0 = 14.2 / s.alpha_c;
+    d.beta18 = 1.8 * s.beta_c;
+    d.beta_node3 = s.beta_node * s.beta_node * s.beta_node;
+    d.beta_b3 = s.beta_b * s.beta_b * s.beta_b;
+    d.alpha_b = s.alpha_b;
+    d.frac_b = s.frac_b;
+    d.ln_q_over_kh = s.ln_q_over_kh;
+    d.ln_ksilk_over_kh = s.ln_ksilk_over_kh;
+    return d;
+}
+
+// eisenstein_hu.py:252-283, the same rational functions with their quotients gathered (6 reciprocals instead of 16 divisions) and the cosmology-only
+// factors taken out of the loop over wavenumbers; within 1e-14 of the operation-for-operation form (tests/test_cosmology_gpu.py, 1e-11 against
+// the reference's numbers).  ln_kh = log(kh): the powers of q and k / k_silk go through it, x^p = exp(p (log kh + log(x / kh))), one log
+// shared by the three powers of k of a P(k) evaluation instead of a pow() each; the relative error of exp(p log x) is |p log x| eps < 2e-15 here.
+__device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh, double ln_kh) {
+    const double q = kh * d.q_per_kh;
+    const double ks = kh * d.ks_per_kh;
+    const double ln_beta = log_pos(kE + d.beta18 * q);
+    const double ln_nobeta = log_pos(kE + 1.8 * q);
+    const double q108 = exp_mid(1.08 * (ln_kh + d.ln_q_over_kh));
+    const double c386 = 386. * recip(1 + 69.9 * q108);
+    const double C_alpha = d.c_alpha0 + c386, C_noalpha = 14.2 + c386;
+    const double ks54 = ks * (1. / 5.4), ks52 = ks * (1. / 5.2);
+    const double f = recip(1. + (ks54 * ks54) * (ks54 * ks54));          // T_c_f
+    const double q2 = q * q;
+    // T_c = f ln_beta / d1 + (1 - f) ln_beta / d2
+    const double d1 = ln_beta + C_noalpha * q2, d2 = ln_beta + C_alpha * q2;
+    const double T_c = ln_beta * fma(f, d2 - d1, d1) * recip(d1 * d2);
+    // 1 + (beta / ks)^3 = (ks^3 + beta^3) / ks^3
+    const double ks3 = ks * ks * ks;
+    const double ks_tilde = ks * ks * rcbrt(ks3 + d.beta_node3);         // k rs_drag / cbrt(1 + (beta_node / ks)^3)
+    const double T_b_1 = ln_nobeta * recip((ln_nobeta + C_noalpha * q2) * fma(ks52, ks52, 1.));
+    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * exp_mid(-exp_mid(1.4 * (ln_kh + d.ln_ksilk_over_kh)));
+    const double sinc = ks_tilde == 0. ? 1. : sin_bounded(ks_tilde) * recip(ks_tilde);   // numpy.sinc(x / pi)
+    const double T_b = sinc * (T_b_1 + T_b_2);
+    return d.frac_b * T_b + (1 - d.frac_b) * T_c;
+}
+
+__device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h, double kh) {  // eisenstein_hu_nowiggle.py:45-51
+    const double k = kh * h;
+    const double ks = k * s.rs_drag;
+    const double x = 0.43 * ks;
+    const double gamma_eff = s.omega_m * (s.alpha_gamma + (1 - s.alpha_gamma) / (1 + (x * x) * (x * x)));
+    const double q = k * (s.theta_cmb * s.theta_cmb) / gamma_eff;
+    const double L0 = log_pos(2 * kE + 1.8 * q);
+    const double C0 = 14.2 + 731.0 / (1 + 62.5 * q);
+    return L0 / (L0 + C0 * (q * q));
+}
+
+__device__ __forceinline__ double transfer_bbks(double h, double Omega_cdm, double Omega_b, double kh) {  // bbks.py:34-38, 62-64
+    const double Omega_m = Omega_b + Omega_cdm;
+    const double gamma = Omega_m * (h * h) * exp(-Omega_b * (1. + sqrt(2. * h) / Omega_m));
+    const double q = kh * h / gamma;
+    const double x = 2.34 * q;
+    const double a = 16.2 * q, b = 5.47 * q, c = 6.71 * q;
+    // as coded in the reference: 3.89 q (16.2 q)^2, not 3.89 q + (16.2 q)^2
+    return log(1 + x) / x / sqrt(sqrt(1. + 3.89 * q * (a * a) + b * b * b + (c * c) * (c * c)));
+}
+
+// What one P(k) evaluation needs of a cosmology besides its transfer function: primordial tilt and the constant that turns T^2 k into P
+// (Primordial.pk_k, eisenstein_hu.py:214-215; pk_callable, eisenstein_hu.py:321-324: potential_to_density^-2 x curvature_to_potential x
+// h^3 A_s = kh x a constant of the cosmology -- the h^3 of the primordial spectrum and of curvature_to_potential cancel)
+struct PkPerCosmology {
+    double n_s, alpha_s, beta_s, ln_kp, pk_unit, h3_A_s;
+};
+
+__device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const double* pw) {
+    PkPerCosmology p;
+    const double A_s = pw[CP_PK_A_S];
+    p.n_s = pw[CP_PK_N_S];
+    p.alpha_s = pw[CP_PK_ALPHA_S];
+    p.beta_s = pw[CP_PK_BETA_S];
+    p.ln_kp = log(pw[CP_PK_K_PIVOT] / c.h);
+    const double Omega0_m = c.Omega_b + c.Omega_cdm + 0. - 0.;  // cosmology.py:381
+    const double p2d_unit = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms));
+    p.pk_unit = 9. / 25. * 2. * (kPi * kPi) / (p2d_unit * p2d_unit) * A_s;
+    p.h3_A_s = (c.h * c.h * c.h) * A_s;
+    return p;
+}
+
+__device__ __forceinline__ double primordial_tilt(const PkPerCosmology& p, double ln_kh) {
+    const double lnkkp = ln_kh - p.ln_kp;
+    return exp_mid((p.n_s - 1. + 1. / 2. * p.alpha_s * lnkkp + 1. / 6. * p.beta_s * (lnkkp * lnkkp)) * lnkkp);
+}
+
+}  // namespace cppower

@@ -21,6 +21,7 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
+#include "cp_internal.h"
 #include "cp_math.h"
 
 namespace {
@@ -480,6 +481,12 @@ struct cp_spline_plan {
     int n_pad, nq_pad;
     bool prefer_dense;
 };
+
+bool cp_spline_plan_view(const cp_spline_plan* p, cp_spline_band_view* out) {
+    if (!p || !out || !p->d_wb || !p->d_j0) return false;
+    *out = cp_spline_band_view{p->n, p->nq, p->bw, p->device, p->d_wb, p->d_j0};
+    return true;
+}
 
 extern "C" int cp_spline_plan_destroy(cp_spline_plan* p) {
     if (!p) return CP_OK;

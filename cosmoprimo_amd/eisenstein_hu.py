@@ -158,6 +158,9 @@ class Fourier(BaseSection):
         def pk_callable(k):
             return self._pk0_device(k if dv.is_torch(k) else np.asarray(k, dtype='f8'))
 
+        # what the one-call sigma(r, z) pipeline of the library needs to evaluate the same spectra itself (cp_sigma_rz_analytic)
+        pk_callable.analytic_engine = lambda: (self._engine._transfer, self._engine.bg_params(), self._engine.pk_params())
+
         interp = PowerSpectrumInterpolator2D.from_callable(pk_callable=pk_callable, growth_factor_sq=growth_factor_sq, device=device, **kwargs)
         # batched cosmologies: P_c(k * kscale_c) in one launch (used by the brieden2022 filter, one rs_drag ratio per cosmology)
         interp._pk_scaled = lambda k, kscale: self._pk0_device(np.asarray(k, dtype='f8'), kscale=kscale) * interp._rsigma8sq

@@ -1063,6 +1063,9 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             # sigma^2(r, z) = growth_factor_sq(z) x sigma^2(r) of the z-independent spectrum (the k integral is linear in P): ONE transform per
             # cosmology instead of one per (cosmology, z), and the (batch, nr, nz) result written once by the kernel that interpolates in r
             growth_sq = self._growth_sq_device(zh.ravel())
+            out = self._sigma_rz_fused(rh, growth_sq, kwargs)
+            if out is not None:
+                return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
 
             def rows(kh):
                 return self._eval_device(kh, self.z[:1], grid=True, ignore_growth=True)[..., 0]      # (batch..., nk)
@@ -1076,6 +1079,48 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True, **kwargs)
             out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
         return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
+
+    _two_stream_min_bytes = 1 << 20        # results smaller than this take the three separate calls (a few microseconds of kernels either way)
+    _two_stream_blocks = 0       # 0: the fused kernel (cp_sigma.hip); n > 0: n blocks on two streams with the three separate kernels (measurements)
+
+    def _sigma_rz_fused(self, rh, growth_sq, kwargs):
+        """Batches of cosmologies built from an analytic engine's callable, default method: ONE library call, ``cp_sigma_rz_analytic``, which runs
+        the whole chain -- P(k) evaluated into the registers of the FFTLog, transform in LDS, spline to the radii out of LDS, product with the growth
+        factors, root, the (nr x nz) results written once -- as one kernel (csrc/cp_sigma.hip).  The ALU-bound and the store-bound stage then
+        overlap across workgroups instead of adding up as three launches, and the spectra and variances never leave the CU.  Same arithmetic in
+        the same order as the separate kernels.  Returns None when the conditions are not met (the caller takes the separate calls)."""
+        torch = dv.torch()
+        call = self._interp if self.is_from_callable else None
+        rs = self._rsigma8sq
+        if call is None or not hasattr(call, 'analytic_engine') or kwargs or growth_sq.ndim != 2 or not (isinstance(rs, float) and rs == 1.):
+            return None
+        nb, nz = growth_sq.shape
+        if nb * rh.size * nz * 8 < self._two_stream_min_bytes:
+            return None
+        engine, bg, pk = call.analytic_engine()
+        from .background import DEFAULTS as bg_defaults
+        from .power import PK_DEFAULTS
+        cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, self.device)
+        cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, self.device)
+        if {n for n in (n1, n2) if n is not None} - {nb}:
+            return None
+        nk = 1024
+        k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
+        rr = rh.ravel()
+        key = (float(self.extrap_kmin), float(self.extrap_kmax), nk, self.device.index)
+        if key not in _tophat_cache:
+            _tophat_cache[key] = TophatVariance(k, device=self.device)
+        fft = _tophat_cache[key]
+        s = fft.y[0]
+        op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), self.device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=self.device))
+        lib = _lib.load()
+        out = torch.empty((nb, rr.size, nz), dtype=torch.float64, device=self.device)
+        work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(nb, nk)), dtype=torch.uint8, device=self.device)
+        growth_sq = growth_sq.contiguous()
+        _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, self.device).data_ptr(),
+                                            fft._get_plan(self.device).handle, op._handle, growth_sq.data_ptr(), nz, out.data_ptr(), work.data_ptr(),
+                                            self._two_stream_blocks, self.device.index, dv.stream_of(self.device)))
+        return out
 
     def sigma8_z(self, z=0, **kwargs):
         """R.m.s. of perturbations in a sphere of 8."""

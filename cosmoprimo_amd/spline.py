@@ -77,7 +77,7 @@ class LinearOperator(object):
                                                       dv.stream_of(self.device)))
         return out
 
-    def outer(self, y, g, sqrt=False, scale=1.):
+    def outer(self, y, g, sqrt=False, scale=1., out=None):
         """y : (..., n), g : (..., nz) device tensors with the same leading shape -> (..., nq, nz) = f(scale x (W y)[..., q] x g[..., z]), f = sqrt or
         identity, written once by the kernel that interpolates (``cp_spline_apply_outer``)."""
         torch = dv.torch()
@@ -86,7 +86,10 @@ class LinearOperator(object):
             raise ValueError('need y (..., {:d}) and g (..., nz) with the same leading shape, got {} and {}'.format(self.n, tuple(y.shape), tuple(g.shape)))
         lead, nz = tuple(y.shape[:-1]), int(g.shape[-1])
         nrows = int(np.prod(lead, dtype=np.int64))
-        out = torch.empty(lead + (self.nq, nz), dtype=torch.float64, device=self.device)
+        if out is None:
+            out = torch.empty(lead + (self.nq, nz), dtype=torch.float64, device=self.device)
+        elif tuple(out.shape) != lead + (self.nq, nz) or not out.is_contiguous() or out.dtype != torch.float64:
+            raise ValueError('out must be a contiguous float64 tensor of shape {}'.format(lead + (self.nq, nz)))
         if nrows and nz:
             _lib.check(_lib.load().cp_spline_apply_outer(self._handle, y.data_ptr(), g.data_ptr(), nz, out.data_ptr(), nrows, int(bool(sqrt)), float(scale),
                                                          dv.stream_of(self.device)))

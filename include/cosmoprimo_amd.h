@@ -259,6 +259,23 @@ int cp_spline_plan_info(const cp_spline_plan* plan, int* n, int* nq, int* bandwi
 /* the dense operator W (nq x n, row-major, host) and per-query inside-range flags: what the plan is built from */
 int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc, int nu, int extrapolate, double* w_out, int* inside_out);
 
+/* ---- sigma(r, z) of a batch of analytic cosmologies in one call (PowerSpectrumInterpolator2D.sigma_rz, reference interpolator.py:846-875 with
+ *      integrate_sigma_r2 :200-292, for the interpolators the analytic engines build from a callable + growth factor, eisenstein_hu.py:295-329):
+ *      d_out[c, q, z] = sqrt(spline(TophatVariance FFTLog of P_c(k))(r_q) x growth_sq[c, z]).  The batch is walked in `nblocks` blocks: `stream`
+ *      evaluates P(k) (cp_power_eval) and transforms (cp_fftlog_execute) block after block while a second stream owned by the library stores the
+ *      (nr x nz) results of the block before (cp_spline_apply_outer) -- ALU-bound and HBM-write-bound kernels side by side; `stream` waits for the
+ *      last store before the call's work counts as done on it.  nblocks = 0 (what the package passes): ONE fused kernel instead -- P(k) evaluated
+ *      into the row registers, FFTLog in LDS, spline out of LDS, results written once (csrc/cp_sigma.hip) -- when the transform is the default
+ *      one (1024 samples padded to 2048: cp_sigma_rz_fused_available), else one block on `stream`.  fftlog: plan of the transform on d_k
+ *      (nker = 1, n = nk); spline: plan from the transform's output grid to the radii.  d_work: cp_sigma_rz_workspace_bytes(ncosmo, nk) bytes.
+ *      Allocates nothing, asynchronous. ---- */
+int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline);
+long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk);
+int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+                         const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
+                         double* d_out, void* d_work, int nblocks, int device, void* stream);
+
+
 /* clamped cubic spline through uniformly spaced knots (positions 1..n) of x^2-weighted data with the knots of a per-column box
  * [box[2c], box[2c+1]] removed, evaluated at all positions and divided by x^2 (wallish2018 peak removal, bao_filter.py:387-405).
  * d_y, d_out : (ncol, n); d_box : (ncol, 2) int32.  d_out may be d_y (in place: only the boxes are rewritten, nothing is copied). */

@@ -36,6 +36,15 @@ def test_config3_sigma_rz_full_size():
         norm = 0.8**2 / (float(osig.sigma_r2(np.array([8.]), pk0)[0]) * g2[0])       # sigma8 is set at z = 0, growth factor (not 1 there) included
         ref = (norm * osig.sigma_r2(r, lambda k: pk0(k)[:, None] * g2[None, :]))**0.5
         np.testing.assert_allclose(out[i], ref, rtol=1e-9)
+    # the batch took the fused kernel (cp_sigma.hip: P(k) -> FFTLog -> spline -> store in one launch); the three separate kernels do the same
+    # arithmetic in the same order
+    kind = type(interp)
+    assert nb * 256 * 64 * 8 >= kind._two_stream_min_bytes
+    saved, kind._two_stream_min_bytes = kind._two_stream_min_bytes, 1 << 60
+    try:
+        np.testing.assert_allclose(out, interp.sigma_rz(r, z), rtol=1e-13, atol=0)
+    finally:
+        kind._two_stream_min_bytes = saved
     # a cosmology gives the same numbers whatever batch it sits in
     sub = slice(1000, 1003)
     small = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{name: v[sub] for name, v in par.items()}).get_fourier().pk_interpolator().sigma_rz(r, z)

@@ -1,0 +1,97 @@
+"""GPU: the fused sigma(r, z) kernel (csrc/cp_sigma.hip, cp_sigma_rz_analytic with nblocks = 0) against the three separate kernels it replaces and
+against the oracle: every analytic engine, odd batches, odd numbers of radii / redshifts, a cosmology whose parameters give NaN next to good
+ones, the two-stream block walk of the same entry point."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def parameters(n, seed):
+    rng = np.random.default_rng(seed)
+    return dict(Omega_m=rng.uniform(.25, .40, n), Omega_b=rng.uniform(.04, .06, n), h=rng.uniform(.6, .8, n), n_s=rng.uniform(.92, 1., n))
+
+
+def both_routes(interp, r, z):
+    kind = type(interp)
+    saved = kind._two_stream_min_bytes
+    try:
+        kind._two_stream_min_bytes = 0
+        fused = interp.sigma_rz(r, z)
+        kind._two_stream_min_bytes = 1 << 60
+        separate = interp.sigma_rz(r, z)
+    finally:
+        kind._two_stream_min_bytes = saved
+    return fused, separate
+
+
+@pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
+def test_fused_matches_separate_kernels(engine):
+    import cosmoprimo_amd as cp
+    warnings.simplefilter('ignore')
+    for n, nr, nz in ((1, 5, 3), (7, 256, 64), (64, 130, 7), (301, 33, 16)):
+        interp = cp.Cosmology(engine=engine, sigma8=0.8, **parameters(n, n)).get_fourier().pk_interpolator()
+        r, z = np.geomspace(0.5, 150., nr), np.linspace(0., 2.5, nz)
+        fused, separate = both_routes(interp, r, z)
+        assert fused.shape == (n, nr, nz) and np.isfinite(fused).all()
+        np.testing.assert_allclose(fused, separate, rtol=1e-13, atol=0, err_msg=str((engine, n, nr, nz)))
+
+
+def test_fused_against_oracle():
+    import cosmoprimo_amd as cp
+    from oracle import background as ob, power as op, sigma as osig
+    warnings.simplefilter('ignore')
+    par = parameters(5, 11)
+    r, z = np.geomspace(1., 100., 40), np.linspace(0., 3., 6)
+    interp = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **par).get_fourier().pk_interpolator()
+    fused, _ = both_routes(interp, r, z)
+    for i in range(5):
+        Om, Ob, h, ns = (float(par[name][i]) for name in ('Omega_m', 'Omega_b', 'h', 'n_s'))
+        g2 = op.growth_factor(z, ob.derived(h=h, Omega_b=Ob, Omega_m=Om), znorm=0.)**2
+        pk0 = lambda k: op.pk_z0(k, 'eisenstein_hu', h=h, Omega_cdm=Om - Ob, Omega_b=Ob, n_s=ns)        # noqa: E731
+        norm = 0.8**2 / (float(osig.sigma_r2(np.array([8.]), pk0)[0]) * g2[0])
+        ref = (norm * osig.sigma_r2(r, lambda k: pk0(k)[:, None] * g2[None, :]))**0.5
+        np.testing.assert_allclose(fused[i], ref, rtol=1e-9)
+
+
+def test_rows_stay_independent_and_radii_outside_are_nan():
+    import torch
+    import cosmoprimo_amd as cp
+    warnings.simplefilter('ignore')
+    par = parameters(6, 5)
+    good = cp.Cosmology(engine='eisenstein_hu', **par).get_fourier().pk_interpolator()
+    r, z = np.geomspace(1., 100., 24), np.linspace(0., 1., 4)
+    ref, _ = both_routes(good, r, z)
+    bad = {name: torch.as_tensor(v, device='cuda') for name, v in par.items()}
+    bad['n_s'] = bad['n_s'].clone()
+    bad['n_s'][2] = float('nan')                   # cosmology 2 shares a transform with cosmology 3
+    mixed = cp.Cosmology(engine='eisenstein_hu', **bad).get_fourier().pk_interpolator()
+    fused, separate = both_routes(mixed, torch.as_tensor(r, device='cuda'), torch.as_tensor(z, device='cuda'))
+    fused, separate = fused.cpu().numpy(), separate.cpu().numpy()
+    assert np.isnan(fused[2]).all() and np.isnan(separate[2]).all()
+    keep = [0, 1, 3, 4, 5]
+    np.testing.assert_allclose(fused[keep], ref[keep], rtol=1e-12)
+    # radii outside the transform's output grid: NaN, as the spline returns them
+    wide = np.array([1e-3, 1., 10., 1e8])
+    fused, separate = both_routes(good, wide, z)
+    assert np.array_equal(np.isnan(fused), np.isnan(separate)) and np.isfinite(fused[:, 1:3]).all()
+
+
+def test_block_walk_on_two_streams():
+    """cp_sigma_rz_analytic with nblocks > 0: the three separate kernels, blocks of cosmologies, the store on a second stream."""
+    import cosmoprimo_amd as cp
+    warnings.simplefilter('ignore')
+    interp = cp.Cosmology(engine='eisenstein_hu', **parameters(203, 9)).get_fourier().pk_interpolator()
+    r, z = np.geomspace(1., 100., 64), np.linspace(0., 2., 9)
+    kind = type(interp)
+    fused, separate = both_routes(interp, r, z)
+    saved = kind._two_stream_min_bytes, kind._two_stream_blocks
+    try:
+        kind._two_stream_min_bytes = 0
+        for blocks in (1, 3, 16):
+            kind._two_stream_blocks = blocks
+            np.testing.assert_allclose(interp.sigma_rz(r, z), separate, rtol=1e-13, atol=0)      # (pairs of cosmologies differ at block edges)
+    finally:
+        kind._two_stream_min_bytes, kind._two_stream_blocks = saved
