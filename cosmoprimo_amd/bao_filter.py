@@ -19,7 +19,7 @@ from .dst import DST
 from .interpolator import _quadratic_interp_operator  # noqa: F401
 from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, CorrelationFunctionInterpolator1D,
                            CorrelationFunctionInterpolator2D)
-from .spline import LinearOperator
+from .spline import LinearOperator, dense_operator
 
 
 def _host_value(x):
@@ -200,13 +200,21 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         mask = (klin > 1e-2) & (klin < 1.5)                                                   # :415
         mask_left, mask_right = self.k < 5e-4, self.k > 2.                                    # :417
         knots = np.concatenate([self.k[mask_left], klin[mask], self.k[mask_right]], axis=0)
-        splice = LinearOperator.spline(knots, self.k, bc='clamped', device=self.device)       # :420
+        # The clamped spline through the spliced knots (:420) is linear in their values, which are contiguous pieces of two arrays that already
+        # sit in HBM: P at self.k (left and right pieces) and the smoothed spectrum on the linear grid (middle piece).  Written as one operator
+        # on each array -- the dense spline operator with its columns moved to the positions of those pieces, zero elsewhere (the plans keep
+        # bands only) -- the spline needs neither the three gathers nor the concatenation of the 3666 knot values of every vector.
+        w = dense_operator(knots, self.k, bc='clamped')                                        # (nk, nknots)
+        n_left, n_mid = int(mask_left.sum()), int(mask.sum())
+        w_pk, w_lin = np.zeros((self.k.size, self.k.size)), np.zeros((self.k.size, self._nlin))
+        w_pk[:, np.flatnonzero(mask_left)] = w[:, :n_left]
+        w_pk[:, np.flatnonzero(mask_right)] = w[:, n_left + n_mid:]
+        w_lin[:, np.flatnonzero(mask)] = w[:, n_left:n_left + n_mid]
+        splice = (LinearOperator.dense(w_pk, device=self.device), LinearOperator.dense(w_lin, device=self.device))
         tophat = np.ones_like(self.k)
         m = self.k > 1.
         tophat[m] *= np.exp(-20.**2 * (self.k[m] / 1. - 1.)**2)                                # :426-431
-        # index lists instead of boolean masks: selecting with a mask makes torch count its entries on the host (a synchronisation per call)
-        index = {name: dv.upload(np.flatnonzero(m), self.device) for name, m in (('mask', mask), ('mask_left', mask_left), ('mask_right', mask_right))}
-        self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=dd, splice=splice, index=index,
+        self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=dd, splice=splice,
                          tophat=dv.to_device(tophat, self.device))
         self._ops_cache[key] = self._ops
         return self._ops
@@ -237,13 +245,13 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         self._dd, self._boxes = [dd[0::2], dd[1::2]], [box[0::2], box[1::2]]
         self._even_now, self._odd_now = out[0::2], out[1::2]
         pknow_lin = ops['dst'](out.view(ffted.shape), inverse=True, fused=True, split=True)          # exp(idst(.)) / k_lin
-        pk = self._pk_rows
-        index = ops['index']
-        vals = torch.cat([pk.index_select(1, index['mask_left']), pknow_lin.index_select(1, index['mask']), pk.index_select(1, index['mask_right'])],
-                         dim=1).contiguous()
-        pknow = ops['splice'](vals)                                       # clamped CubicSpline on the spliced knots at self.k
-        wiggles = (pk / pknow - 1.) * ops['tophat'] + 1.
-        self._pknow_rows = pk / wiggles
+        pk = self._pk_rows.contiguous()
+        from_pk, from_lin = ops['splice'][0](pk), ops['splice'][1](pknow_lin)      # clamped CubicSpline on the spliced knots at self.k, in two parts
+        out = torch.empty_like(pk)
+        # pknow = from_pk + from_lin; wiggles = (pk / pknow - 1) tophat + 1; pk / wiggles (:421-431), one pass
+        _lib.check(lib.cp_wallish_finish(pk.data_ptr(), from_pk.data_ptr(), from_lin.data_ptr(), ops['tophat'].data_ptr(), out.data_ptr(), pk.shape[0],
+                                         pk.shape[1], self.device.index, dv.stream_of(self.device)))
+        self._pknow_rows = out
 
 
 def _local_maxima(x):
@@ -390,33 +398,37 @@ def _brieden_compute_batched(self, rescale):
     if not (isinstance(interp, PowerSpectrumInterpolator2D) and hasattr(interp, '_pk_scaled') and interp.z.size == 1):
         raise NotImplementedError('brieden2022 over a batch of cosmologies needs the pk_interpolator(z=[z0]) of a batched analytic engine')
     nb, n = rescale.numel(), self.k_fid.size
-    rows = interp._pk_scaled(self.k_fid, 1. / rescale)                                           # P_c(k_fid / r_c), (B, 341)
+    lib, stream = _lib.load(), dv.stream_of(self.device)
+    rescale = rescale.contiguous()
+    rows = interp._pk_scaled(self.k_fid, 1. / rescale).contiguous()                              # P_c(k_fid / r_c), (B, 341)
     now = Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator(z=np.array([0.]))
-    g0 = dv.to_device(now.growth_factor_sq(np.array([0.])), self.device).reshape(nb, 1)
-    pknow = now._pk_scaled(self.k_fid, rescale) * g0 * dv.to_device(self.pknow_correction[:, 0], self.device)
-    ratio = rows / pknow / dv.to_device(self.ratio_fid[:, 0], self.device)
-    pknow_cols = self._envelope(ratio) * pknow * dv.to_device(self.ratio_now_fid[:, 0], self.device)   # (B, 341)
-    # _pad_log (interpolator.py:42-87) on per-cosmology knots, knot-major (345, B)
-    logk = torch.log10(dv.to_device(self.k_fid, self.device)[:, None] / rescale[None, :])           # (341, B)
-    logp = torch.log10(pknow_cols).T.contiguous()
-    lmin = torch.log10(torch.minimum(torch.full_like(rescale, float(interp.extrap_kmin)), self.k_fid[0] / rescale * (1 - 1e-9)))
-    lmax = torch.log10(torch.maximum(torch.full_like(rescale, float(interp.extrap_kmax)), self.k_fid[-1] / rescale * (1 + 1e-9)))
-    sh = (logp[-1] - logp[-2]) / (logk[-1] - logk[-2])
-    hk = torch.stack([logk[-1] * 0.1 + lmax * 0.9, lmax])
-    hp = torch.stack([logp[-1] + sh * (hk[0] - logk[-1]), logp[-1] + sh * (hk[1] - logk[-1])])
-    sl = (logp[1] - logp[0]) / (logk[1] - logk[0])
-    lk = torch.stack([lmin, logk[0] * 0.1 + lmin * 0.9])
-    lp = torch.stack([logp[0] + sl * (lk[0] - logk[0]), logp[0] + sl * (lk[1] - logk[0])])
-    xk = torch.cat([lk, logk, hk], dim=0).contiguous()
-    yk = torch.cat([lp, logp, hp], dim=0).contiguous()
-    xq = dv.to_device(np.log10(self.k_fid), self.device)
+    g0 = dv.to_device(now.growth_factor_sq(np.array([0.])), self.device).reshape(nb).contiguous()
+    raw = now._pk_scaled(self.k_fid, rescale).contiguous()
+    const = self.__dict__.get('_device_constants')
+    if const is None:      # fiducial products and the k_fid range: uploaded once per filter object
+        first = int(np.flatnonzero(self.kmask_fid)[0])
+        assert np.array_equal(np.flatnonzero(self.kmask_fid), first + np.arange(n))      # 1e-3 <= k <= 1 is a contiguous range of k
+        const = self._device_constants = dict(correction=dv.to_device(self.pknow_correction[:, 0], self.device), ratio_fid=dv.to_device(self.ratio_fid[:, 0], self.device),
+                                              ratio_now_fid=dv.to_device(self.ratio_now_fid[:, 0], self.device), k_fid=dv.to_device(self.k_fid, self.device),
+                                              log_k_fid=dv.to_device(np.log10(self.k_fid), self.device), first=first)
+    # pknow = P_nowiggle x growth x correction; ratio = P / pknow / ratio_fid (reference bao_filter.py:493-499): one pass
+    pknow, ratio = torch.empty_like(rows), torch.empty_like(rows)
+    _lib.check(lib.cp_brieden_ratio(rows.data_ptr(), raw.data_ptr(), g0.data_ptr(), const['correction'].data_ptr(), const['ratio_fid'].data_ptr(),
+                                    pknow.data_ptr(), ratio.data_ptr(), nb, n, self.device.index, stream))
+    envelope = self._envelope(ratio)                                                                  # (B, 341)
+    # log10 of envelope x pknow x ratio_now_fid on the per-cosmology knots k_fid / rescale, knot-major (345, B), with the two extrapolated knots of
+    # _pad_log (interpolator.py:42-87) on either side: one pass
+    xk, yk = torch.empty((n + 4, nb), dtype=torch.float64, device=self.device), torch.empty((n + 4, nb), dtype=torch.float64, device=self.device)
+    _lib.check(lib.cp_brieden_knots(envelope.data_ptr(), pknow.data_ptr(), const['ratio_now_fid'].data_ptr(), const['k_fid'].data_ptr(), rescale.data_ptr(),
+                                    float(interp.extrap_kmin), float(interp.extrap_kmax), xk.data_ptr(), yk.data_ptr(), nb, n, self.device.index, stream))
     out = torch.empty((n, nb), dtype=torch.float64, device=self.device)
-    scratch = torch.empty((2, xk.shape[0], nb), dtype=torch.float64, device=self.device)
-    _lib.check(_lib.load().cp_spline_columns(xk.data_ptr(), yk.data_ptr(), nb, xk.shape[0], xq.data_ptr(), n, out.data_ptr(), scratch.data_ptr(),
-                                             self.device.index, dv.stream_of(self.device)))
-    new = (10**out).T
-    res = self._pk_rows.clone()
-    res.index_copy_(1, self._kfid_index(), new.contiguous())
+    scratch = torch.empty((2, n + 4, nb), dtype=torch.float64, device=self.device)
+    _lib.check(lib.cp_spline_columns(xk.data_ptr(), yk.data_ptr(), nb, n + 4, const['log_k_fid'].data_ptr(), n, out.data_ptr(), scratch.data_ptr(),
+                                     self.device.index, stream))
+    # the input spectra with 10^(re-sampled) written over the k_fid range (bao_filter.py:509): one pass
+    pk = self._pk_rows.contiguous()
+    res = torch.empty_like(pk)
+    _lib.check(lib.cp_brieden_finish(pk.data_ptr(), out.data_ptr(), res.data_ptr(), nb, pk.shape[1], const['first'], n, self.device.index, stream))
     self._pknow_rows = res
 
 

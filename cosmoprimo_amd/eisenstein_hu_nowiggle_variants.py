@@ -64,7 +64,13 @@ class EisensteinHuNoWiggleVariantsEngine(BaseEngine):
         rs = self._rsigma8 if rsigma8 is None else rsigma8
         if rs is None:
             rs = 1.
-        A_s = self._A_s * rs**2 if not dv.is_torch(rs) else dv.to_device(self._A_s, self.device) * rs**2
+        if dv.is_torch(rs):      # the normalised amplitudes of a batch: one product per normalisation, not one per evaluation of P(k)
+            cached = self.__dict__.get('_A_s_normalised')
+            if cached is None or cached[0] is not rs:
+                cached = self.__dict__['_A_s_normalised'] = (rs, dv.to_device(self._A_s, self.device) * rs**2)
+            A_s = cached[1]
+        else:
+            A_s = self._A_s * rs**2
         return dict(A_s=A_s, n_s=self['n_s'], alpha_s=self['alpha_s'], beta_s=self['beta_s'], k_pivot=self['k_pivot'])
 
 

@@ -286,6 +286,21 @@ int cp_gap_spline(const double* d_y, const int* d_box, double* d_out, long long 
 int cp_wallish_box(const double* d_dd, long long ncol, int n, int margin_first, int margin_second, int offset_first, int offset_second, int* d_box,
                    int device, void* stream);
 
+/* the elementwise stages of the two filters over (nrows, n) batches of spectra, one pass each (csrc/cp_bao.hip):
+ * cp_wallish_finish: pknow = d_a (+ d_b when not NULL: the spliced spline applied as two operators), wiggles = (pk / pknow - 1) tophat + 1,
+ *   out = pk / wiggles (bao_filter.py:421-431); d_tophat : (n).
+ * cp_brieden_ratio: pknow = now x g0[c] x correction[j], ratio = rows / pknow / ratio_fid[j] (bao_filter.py:493-499); (nb, n) rows.
+ * cp_brieden_knots: log10 of envelope x pknow x ratio_now_fid against log10(k_fid / rescale[c]) as knot-major (n + 4, nb) arrays with the two
+ *   log-log extrapolated knots of _pad_log (interpolator.py:42-87) on either side: the input of cp_spline_columns.
+ * cp_brieden_finish: out = pk (nb, nk) with columns [first, first + n) replaced by 10^resampled (knot-major (n, nb)) (bao_filter.py:509). */
+int cp_wallish_finish(const double* d_pk, const double* d_a, const double* d_b, const double* d_tophat, double* d_out, long long nrows, int n, int device,
+                      void* stream);
+int cp_brieden_ratio(const double* d_rows, const double* d_now, const double* d_g0, const double* d_correction, const double* d_ratio_fid, double* d_pknow,
+                     double* d_ratio, long long nb, int n, int device, void* stream);
+int cp_brieden_knots(const double* d_envelope, const double* d_pknow, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_rescale,
+                     double extrap_kmin, double extrap_kmax, double* d_xk, double* d_yk, long long nb, int n, int device, void* stream);
+int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_out, long long nb, int nk, int first, int n, int device, void* stream);
+
 /* natural cubic spline per column with per-column knots (brieden2022 re-sampling with one rs_drag ratio per column, bao_filter.py:503-509):
  * d_xk, d_yk : (n, ncol) knot-major; d_xq : (nq) ascending queries shared by all columns; d_out : (nq, ncol);
  * d_scratch : 2 * n * ncol doubles.  Queries outside a column's knots give NaN. */
