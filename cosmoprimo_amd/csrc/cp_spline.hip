@@ -585,6 +585,10 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
         }
         double mx = 0.;
         for (int j = 0; j < n; ++j) mx = std::fmax(mx, std::fabs(w[(size_t)q * n + j]));
+        if (mx == 0.) {  // a row of zeros (an operator that acts on part of its queries only): placed below
+            j0[q] = j1[q] = -2;
+            continue;
+        }
         const double thr = mx * 1e-18;  // band: entries above 1e-18 of the row maximum
         int a = 0, b = n - 1;
         while (a < b && std::fabs(w[(size_t)q * n + a]) <= thr) ++a;
@@ -592,6 +596,20 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
         j0[q] = a;
         j1[q] = b;
         if (b - a + 1 > bw) bw = b - a + 1;
+    }
+    // rows of zeros get a one-entry band (weight 0) next to the band of the nearest row that has one, so that they widen neither the tiles of the
+    // vector kernel nor the windows of the matrix-core kernel
+    {
+        int last = -1;
+        for (int q = 0; q < nq; ++q) {
+            if (j0[q] >= 0) last = j0[q];
+            else if (j0[q] == -2 && last >= 0) j0[q] = j1[q] = last;
+        }
+        last = -1;
+        for (int q = nq - 1; q >= 0; --q) {
+            if (j0[q] >= 0) last = j0[q];
+            else if (j0[q] == -2) j0[q] = j1[q] = last >= 0 ? last : 0;
+        }
     }
     std::vector<double> wb((size_t)bw * nq, 0.);
     for (int q = 0; q < nq; ++q) {
