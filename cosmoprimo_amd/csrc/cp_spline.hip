@@ -215,24 +215,32 @@ struct DenseArgs {
     double scale;
 };
 
-__global__ __launch_bounds__(256) void linop_mfma_kernel(const DenseArgs A) {
+// Round 3: wave tile 64 rows x 64 queries (4 x 4 accumulator tiles, 128 registers) instead of 32 x 64.  The kernel reads its operands straight from
+// L1 / L2 in the fragment layout, and what bounded the 32 x 64 tile was that path: per 16-knot chunk a wave fetched (32 + 64) x 16 doubles = 12 KB
+// for 32 MFMAs (512 matrix-core cycles), 24 B per cycle and wave, 96 B per cycle for the four SIMDs of a CU against the 64 B per cycle the L1
+// delivers -- 44-46 TFLOP/s = 58 % of the matrix peak, the ratio of the two.  A 64 x 64 tile fetches 16 KB for 64 MFMAs: 16 B per cycle and wave.
+// Two waves per SIMD (launch bound: 256 registers) alternate between fetching a chunk and multiplying one.
+constexpr int LINOP_MT = 4;   // 16-row tiles per wave
+
+__global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int l15 = lane & 15, g = lane >> 4;
-    const long long nrt = (A.nrows + 31) / 32;
+    constexpr int MT = LINOP_MT, ROWS = 16 * MT;
+    const long long nrt = (A.nrows + ROWS - 1) / ROWS;
     const int nqt = (A.nq_pad + 255) / 256;
     for (long long item = blockIdx.x; item < nrt * nqt; item += gridDim.x) {
-        const long long row0 = (item / nqt) * 32;   // consecutive items share their rows: Y comes from L2 for all but the first
+        const long long row0 = (item / nqt) * ROWS;   // consecutive items share their rows: Y comes from L2 for all but the first
         const int q0 = (int)(item % nqt) * 256 + wave * 64;
         if (q0 >= A.nq_pad) continue;
-        cp_v4d acc[2][4];
+        cp_v4d acc[MT][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = cp_v4d{0., 0., 0., 0.};
-        const double* yr[2];
+        const double* yr[MT];
         const double* wr[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             long long row = row0 + 16 * i + l15;
             row = row < A.nrows ? row : A.nrows - 1;   // rows past the end repeat the last one (never stored)
             yr[i] = A.y + row * A.n;
@@ -241,27 +249,28 @@ __global__ __launch_bounds__(256) void linop_mfma_kernel(const DenseArgs A) {
         for (int j = 0; j < 4; ++j) wr[j] = A.w + (long long)(q0 + 16 * j + l15) * A.n_pad;
         // a banded operator (spline) is a block-banded GEMM: the wave's 64 queries only couple to the knots of their window
         const int klo = A.kwin[2 * (q0 >> 6)], khi = A.kwin[2 * (q0 >> 6) + 1];
+#pragma unroll 1
         for (int kb = klo; kb < khi; kb += 16) {
             const int k = kb + 4 * g;
-            double a[2][4];
+            double a[MT][4];
             cp_v4d b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const cp_v4d*>(wr[j] + k);
             if (kb + 16 <= A.n) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) a[i][m] = yr[i][k + m];
             } else {   // last, partial chunk: W is zero there, but Y must not bring in the next row's values (0 x NaN)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) a[i][m] = k + m < A.n ? yr[i][k + m] : 0.;
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
         }
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(256) void linop_mfma_kernel(const DenseArgs A) {
             if (q >= A.nq) continue;
             const bool nanq = A.j0[q] < 0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long long row = row0 + 16 * i + g + 4 * r;
@@ -753,8 +762,8 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
         DenseArgs D;
         D.y = d_y; D.out = d_out; D.nrows = nrows; D.n = p->n; D.nq = p->nq; D.n_pad = p->n_pad; D.nq_pad = p->nq_pad; D.w = p->d_wdense; D.j0 = p->d_j0;
         D.kwin = p->d_kwin; D.post_op = post_op; D.scale = scale;
-        const long long items = ((nrows + 31) / 32) * ((p->nq_pad + 255) / 256);
-        const int grid = (int)(items < 256 * 4 ? items : 256 * 4);
+        const long long items = ((nrows + 16 * LINOP_MT - 1) / (16 * LINOP_MT)) * ((p->nq_pad + 255) / 256);
+        const int grid = (int)(items < 256 * 2 ? items : 256 * 2);
         hipLaunchKernelGGL(linop_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), D);
         const hipError_t e = hipGetLastError();
         if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
