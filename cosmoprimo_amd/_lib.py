@@ -63,6 +63,7 @@ SIGNATURES = {
     'cp_eh_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_sigma_rz_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
     'cp_sigma_rz_fused_available': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'cp_fftlog_spline_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
     'cp_sigma_rz_analytic': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_void_p]),

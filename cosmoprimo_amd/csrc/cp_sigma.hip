@@ -133,7 +133,7 @@ CP_HD void keep_variances(int t0, cplx* lds, const double* ya, const double* yb)
 // weights come from L2 (bw x nq doubles per plan): they are fetched CHUNK at a time ahead of the multiply-adds that use them, for the thread's
 // two queries q and q + T at once, so that the loop waits for memory once per chunk instead of once per weight.
 template <int T>
-CP_HD void spline_to_radii(int t, const cplx* lds, const double* __restrict__ wb, const int* __restrict__ j0s, int bw, int nq, double* roots_r) {
+CP_HD void spline_to_radii(int t, const cplx* lds, const double* __restrict__ wb, const int* __restrict__ j0s, int bw, int nq, double* roots_r, bool root = true) {
     constexpr int CHUNK = 8;
     const LdsView v(lds);
     for (int q = t; q < nq; q += 2 * T) {
@@ -163,11 +163,13 @@ CP_HD void spline_to_radii(int t, const cplx* lds, const double* __restrict__ wb
             }
         }
         const double nan = __builtin_nan("");
-        roots_r[q] = sqrt(j0a >= 0 ? acc[0] : nan);
-        roots_r[nq + q] = sqrt(j0a >= 0 ? acc[1] : nan);
+        if (j0a < 0) acc[0] = acc[1] = nan;
+        if (j0b < 0) acc[2] = acc[3] = nan;
+        roots_r[q] = root ? sqrt(acc[0]) : acc[0];
+        roots_r[nq + q] = root ? sqrt(acc[1]) : acc[1];
         if (q2 != q) {
-            roots_r[q2] = sqrt(j0b >= 0 ? acc[2] : nan);
-            roots_r[nq + q2] = sqrt(j0b >= 0 ? acc[3] : nan);
+            roots_r[q2] = root ? sqrt(acc[2]) : acc[2];
+            roots_r[nq + q2] = root ? sqrt(acc[3]) : acc[3];
         }
     }
 }
@@ -274,6 +276,81 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
     }
 }
 
+// ---- the same tail behind rows that come from memory: FFTLog of a batch of rows + natural spline of every output row to the radii (+ root), the
+// variances never written.  integrate_sigma_r2(method='fftlog') for tabulated spectra (interpolator.py:285-291): 640 000 rows of config 3B went
+// through fftlog_kernel (5.2 GB written), then through the spline kernel (5.2 GB read); here 1.3 GB of results leave the kernel.  Front end,
+// prefetch and row screening are those of fftlog_kernel<2048, 16, IN_HALF_ZERO, OUT_HALF> (cp_fftlog_kernel.h); out: (nrows, nq).
+struct RowsArgs {
+    FftlogArgs fft;
+    const double* wb;
+    const int* j0;
+    int bw, nq, post_sqrt;
+    double* out;   // (nbatch, nq)
+};
+
+__global__ __launch_bounds__(NP / P, 2) void fftlog_spline_kernel(const RowsArgs R) {
+    using F = Fftlog<NP, P, IN_HALF_ZERO, OUT_HALF>;
+    constexpr int T = F::T, H = F::H, Q = F::Q;
+    extern __shared__ __attribute__((aligned(4096))) char smem[];
+    cplx* lds = reinterpret_cast<cplx*>(smem);
+    double* roots_r = reinterpret_cast<double*>(smem + F::LDS_BYTES);   // (2, nq)
+    const int t = threadIdx.x;
+    const FftlogArgs& A = R.fft;
+    const long long npairs = (A.nbatch + 1) / 2;
+    long long p = blockIdx.x;
+    if (p >= npairs) return;
+    typename F::State st;
+    const long long n = A.n;
+    {
+        const double* ra = A.in + 2 * p * n;
+        F::init_state(t, A, ra, ra + (2 * p + 1 < A.nbatch ? n : 0), 0, st);
+    }
+    F::fill_lds_tables(t, A, lds);
+    F::screen_prefetched(t, st.t0, A, 0, lds, st);
+    __syncthreads();
+    st.info_nxt = F::screen_collect(lds);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see fftlog_kernel
+    const int t0 = st.t0;
+    for (; p < npairs; p += gridDim.x) {
+        const bool has_b = 2 * p + 1 < A.nbatch;
+        const long long pn = p + gridDim.x < npairs ? p + gridDim.x : p;      // the pair prefetched during this one (itself on the last round)
+        const double* nra = A.in + 2 * pn * n;
+        const double* nrb = nra + (2 * pn + 1 < A.nbatch ? n : 0);
+        // phases 0 .. NPH - 2 (phase 0 issues the next pair's row loads; the phase before the last one screens them)
+        {
+            F::template phase<0>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            __syncthreads();
+            F::template phase<1>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            if constexpr (!F::template barrier_free_after<1>()) __syncthreads();
+            F::template phase<2>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            if constexpr (!F::template barrier_free_after<2>()) __syncthreads();
+            static_assert(F::NPH == 5, "three passes");
+            F::template phase<3>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            __syncthreads();
+        }
+        cplx x[P];
+        Pass<NP, P, 0>::load_lds(t0, lds, x);
+        st.info_nxt = F::screen_collect(lds);      // verdict on the next pair's rows, published in front of the barrier above
+        __syncthreads();      // every thread has its inputs: the data region is free for the outputs
+        Pass<NP, P, 0>::twiddle_apply(st.w, x);
+        Pass<NP, P, 0>::butterflies(x);
+        {
+            double ya[H], yb[H];
+#pragma unroll
+            for (int s = 0; s < H; ++s) {
+                ya[s] = x[s + Q].re * st.fpost[s];
+                yb[s] = x[s + Q].im * st.fpost[s];
+            }
+            F::template fix_output<H>(st.info_cur, ya, yb);
+            keep_variances<T, H>(t0, lds, ya, yb);
+        }
+        __syncthreads();
+        spline_to_radii<T>(t, lds, R.wb, R.j0, R.bw, R.nq, roots_r, R.post_sqrt != 0);
+        __syncthreads();
+        for (int e = t; e < (has_b ? 2 : 1) * R.nq; e += T) R.out[2 * p * R.nq + e] = roots_r[e];      // rows 2 p and 2 p + 1 are adjacent: one contiguous block
+    }
+}
+
 template <int ENGINE>
 hipError_t launch(const SigmaArgs& S, int grid, size_t lds, hipStream_t stream) {
     static bool configured[64] = {false};      // per device: dynamic LDS above 64 KB needs the attribute once
@@ -346,5 +423,54 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     else e = launch<CP_ENGINE_BBKS>(S, grid, lds, hs);
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_fused: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+// FFTLog of (nbatch, n) rows followed by the spline of every output row to the plan's queries (root taken when post_op is CP_SPLINE_POST_SQRT), as one
+// kernel; d_out : (nbatch, nq).  Plans as for cp_sigma_rz_fused_available.
+extern "C" int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_in, double* d_out, long long nbatch,
+                                        int post_op, void* stream) {
+    if (nbatch < 0) return cp::fail(CP_EINVAL, "cp_fftlog_spline_execute: negative batch");
+    if (nbatch == 0) return CP_OK;
+    if (!d_in || !d_out) return cp::fail(CP_EINVAL, "cp_fftlog_spline_execute: null device pointer");
+    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_fftlog_spline_execute: unknown post op %d", post_op);
+    if (!cp_sigma_rz_fused_available(fftlog, spline)) return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_spline_execute: plans outside the fused kernel's shape (1024 samples padded to 2048, one kernel)");
+    cp_fftlog_tables_view f;
+    cp_spline_band_view b;
+    (void)cp_fftlog_plan_view(fftlog, &f);
+    (void)cp_spline_plan_view(spline, &b);
+    RowsArgs R{};
+    FftlogArgs& A = R.fft;
+    A.in = d_in; A.out = nullptr; A.nbatch = nbatch; A.nker = 1; A.n = f.n; A.in_left = f.in_left; A.out_off = f.out_left; A.n_out = f.n;
+    A.ext_l = A.ext_r = CP_EXTRAP_CONST; A.val_l = A.val_r = 0.;
+    A.stream_rows = (double)nbatch * f.n * 8. > 512. * 1024. * 1024.;
+    A.pre = f.d_pre; A.post = f.d_post; A.u = f.d_u; A.tw = f.d_tw;
+    R.wb = b.d_wb; R.j0 = b.d_j0; R.bw = b.bw; R.nq = b.nq; R.post_sqrt = post_op == CP_SPLINE_POST_SQRT;
+    R.out = d_out;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != f.device && hipSetDevice(f.device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_spline_execute: cannot select device %d", f.device);
+    using F = Fftlog<NP, P, IN_HALF_ZERO, OUT_HALF>;
+    const size_t lds = (size_t)F::LDS_BYTES + (size_t)(2 * b.nq) * sizeof(double);
+    if (lds > 160 * 1024) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_spline_execute: %d queries exceed the LDS staging", b.nq);
+    }
+    static bool configured[64] = {false};
+    if (lds > 64 * 1024 && f.device >= 0 && f.device < 64 && !configured[f.device]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fftlog_spline_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured[f.device] = true;
+    }
+    int ncu = 0;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, f.device);
+    const long long npairs = (nbatch + 1) / 2;
+    const size_t per_cu = (160 * 1024) / lds;
+    const long long resident = (long long)(ncu > 0 ? ncu : 256) * (long long)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    const long long rounds = (npairs + resident - 1) / resident;
+    const int grid = (int)((npairs + rounds - 1) / rounds);
+    hipLaunchKernelGGL(fftlog_spline_kernel, dim3(grid), dim3(NP / P), lds, static_cast<hipStream_t>(stream), R);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_spline_execute: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }

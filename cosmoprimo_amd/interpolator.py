@@ -166,6 +166,33 @@ def _cached_operator(key, build):
     return _op_cache[key]
 
 
+# The fused kernel reads a query's band of weights from L2 once per PAIR of rows (the separate spline kernel: once per 16 rows) and gives one
+# query to one thread: it pays for batches that are small enough to be launch / latency bound and wide enough in queries to keep its threads
+# busy (tools/bench_fused_spline.py); large batches (config 3B: 640 000 rows) and single radii (sigma8) take the two kernels.
+_FUSED_SPLINE_ROWS = (2, 8192)
+
+
+def _fftlog_then_spline(fft, op, rows, device, sqrt=False):
+    """The transform of ``rows`` (..., nk) and the spline of every transformed row to the operator's queries as ONE kernel
+    (``cp_fftlog_spline_execute``: the transformed rows stay on the CU), for the default transform (1024 samples); None when it does not apply."""
+    torch = dv.torch()
+    lib = _lib.load()
+    if not dv.is_torch(rows) or rows.dtype != torch.float64 or rows.shape[-1] != fft.size or fft.nparallel != 1:
+        return None
+    plan = fft._get_plan(device)
+    if getattr(fft, '_phase', None) is not None or getattr(fft, '_phase_in', None) is not None or not lib.cp_sigma_rz_fused_available(plan.handle, op._handle):
+        return None
+    rows = rows.contiguous()
+    lead = tuple(rows.shape[:-1])
+    nrows = int(np.prod(lead, dtype=np.int64))
+    if not _FUSED_SPLINE_ROWS[0] <= nrows <= _FUSED_SPLINE_ROWS[1] or op.nq < 32:
+        return None
+    out = torch.empty(lead + (op.nq,), dtype=torch.float64, device=device)
+    if nrows:
+        _lib.check(lib.cp_fftlog_spline_execute(plan.handle, op._handle, rows.data_ptr(), out.data_ptr(), nrows, int(bool(sqrt)), dv.stream_of(device)))
+    return out
+
+
 def _with_growth(sigma2, growth_sq):
     """sqrt(sigma2[..., r] growth_sq[..., z]) as (..., nr, nz) (methods other than 'fftlog': elementwise), or sigma2 as it is."""
     if growth_sq is None:
@@ -200,10 +227,13 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
             _tophat_cache[key] = TophatVariance(k, device=device)
         fft = _tophat_cache[key]
         rows = pk_rows(k)
-        s, var = fft(rows)
         s = fft.y[0]
         op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
         # tmp = (2 pi^2) spline(var)(r); sigma^2 = tmp / (2 pi^2)  (interpolator.py:289-291)
+        fused = _fftlog_then_spline(fft, op, rows, device, sqrt=sqrt) if growth_sq is None else None
+        if fused is not None:
+            return fused
+        var = fft(rows)[1]
         if growth_sq is not None:
             return op.outer(var, growth_sq, sqrt=True)
         return op(var, sqrt=sqrt)

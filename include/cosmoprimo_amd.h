@@ -270,6 +270,11 @@ int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc,
  *      (nker = 1, n = nk); spline: plan from the transform's output grid to the radii.  d_work: cp_sigma_rz_workspace_bytes(ncosmo, nk) bytes.
  *      Allocates nothing, asynchronous. ---- */
 int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline);
+/* FFTLog of (nbatch, n) rows followed by the spline of every output row to the spline plan's queries, root taken for CP_SPLINE_POST_SQRT, as one
+ * kernel: integrate_sigma_r2(method='fftlog') for spectra that sit in memory (interpolator.py:285-291); d_out : (nbatch, nq).  The transformed rows
+ * are never written.  Plans for which cp_sigma_rz_fused_available() is 1 (CP_EUNSUPPORTED otherwise: make the two calls). */
+int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_in, double* d_out, long long nbatch, int post_op,
+                             void* stream);
 long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk);
 int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
                          const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
