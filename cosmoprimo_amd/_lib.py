@@ -75,6 +75,8 @@ SIGNATURES = {
                                             ctypes.c_double, ctypes.c_void_p]),
     'cp_linop_apply_mid': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_double,
                                          ctypes.c_void_p]),
+    'cp_tables_rows_available': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    'cp_tables_rows': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     'cp_spline_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_spline_plan_info': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, _c_int_p]),
     'cp_spline_columns': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,

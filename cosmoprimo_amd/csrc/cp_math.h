@@ -93,8 +93,12 @@ __device__ __forceinline__ double rsqrt_pos(double x) {
 // polynomial on |r ln 10| <= ln(2) / 2, ldexp -- relative error 2e-16 (checked against 50-digit arithmetic), half the instructions of the
 // library's exp10, which matters where every lane of the GEMM epilogue takes 64 of them per tile
 __device__ __forceinline__ double exp10_mid(double x) {
-    if (!(fabs(x) < 300.)) return exp10(x);
-    const double n = rint(x * 3.321928094887362);
+    // branch-free over the whole line: the exponent is clamped (beyond +-1100 the result is 0 or Inf whatever the polynomial says), NaN goes
+    // through the arithmetic, and -Inf / +Inf (whose reduced argument is not finite) are settled by the two selects at the end.  An unrolled
+    // GEMM epilogue holds 64 copies of this function: a library call for the rare arguments would put 64 call sites, with their register
+    // spills, into it.
+    double n = rint(x * 3.321928094887362);
+    n = fmax(fmin(n, 1100.), -1100.);
     double r = fma(-n, 0.3010299955494702, x);
     r = fma(-n, 1.1451100898021838e-10, r);
     const double y = r * 2.302585092994046;
@@ -112,7 +116,10 @@ __device__ __forceinline__ double exp10_mid(double x) {
     p = fma(p, y, 0.5);
     p = fma(p, y, 1.);
     p = fma(p, y, 1.);
-    return ldexp(p, (int)n);
+    double v = ldexp(p, (int)n);
+    v = x < -400. ? 0. : v;
+    v = x > 400. ? __builtin_inf() : v;
+    return v;
 }
 
 }  // namespace cpmath

@@ -223,7 +223,7 @@ struct DenseArgs {
 constexpr int LINOP_MT = 4;   // 16-row tiles per wave
 
 __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (in a scalar register: what follows from it is wave-uniform for the compiler too)
     const int l15 = lane & 15, g = lane >> 4;
     constexpr int MT = LINOP_MT, ROWS = 16 * MT;
     const long long nrt = (A.nrows + ROWS - 1) / ROWS;
@@ -317,7 +317,7 @@ constexpr int MID_WSTRIDE = 80;   // LDS row stride (doubles) of the resident op
 // The kernel moves 3 bytes for every multiply-add: what it needs is memory operations in flight, i.e. waves -- four per SIMD (128 registers: the
 // accumulators of a 64 x 32 tile, the operator in LDS rather than in registers).
 __global__ __launch_bounds__(256, 4) void linop_mid_mfma_kernel(const MidArgs A) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (in a scalar register: what follows from it is wave-uniform for the compiler too)
     const int l15 = lane & 15, g = lane >> 4;
     constexpr int NT = MID_NT, WCOLS = 16 * NT, GCOLS = 4 * WCOLS;   // columns per wave and per workgroup
     const long long nct = (A.ninner + GCOLS - 1) / GCOLS;
@@ -846,6 +846,168 @@ extern "C" int cp_linop_apply_mid(const cp_spline_plan* p, const double* d_y, do
     return CP_OK;
 }
 
+
+// ---- batches of (z, k) tables -> rows of P(k, z): both spline operators of a table in ONE kernel ---------------------------------------------
+// PowerSpectrumInterpolator2D(k, z, pk)(k_out, z_out) for a batch of tables on shared grids (reference interpolator.py:667-672, jax.py:241-271:
+// RectBivariateSpline = spline along k, then spline along z): out[b, zq, q] = f(sum_zi Wz[zq, zi] sum_j Wk[q, j] T[b, zi, j]), f = 10^x for
+// tables splined in log10 P.  As two launches (k-spline, then the middle-axis GEMM) the k-splined tables (B, nz, nq) make a round trip through
+// HBM -- 2.5 GB written and read for 10 000 tables of 30 x 504 -> 1024, next to 1.2 GB of input and 5.2 GB of result.  Here they never exist:
+// a wave computes L = T[b] Wk^T for all (up to 32) input redshifts and 64 output wavenumbers as a block-banded GEMM, and its accumulators ARE the B
+// fragments of the second GEMM R = Wz L: in v_mfma_f64_16x16x4_f64 a lane holds D[row = (l >> 4) + 4 r][col = l & 15] in register r, and as a B
+// operand supplies B[k = l >> 4][n = l & 15] -- with rows = input redshifts, register r of row tile i is exactly the B fragment of the knots
+// z_in = 16 i + 4 r + (l >> 4), the chunk kk = 4 i + r of the second contraction.  No LDS, no shuffles, no intermediate.
+namespace {
+
+struct TablesArgs {
+    const double* t;     // (nbatch, nzin, n) tables, k fastest
+    double* out;         // (nbatch, nzq, nq)
+    long long nbatch;
+    int n, nq, n_pad, nq_pad, nzin, nzq;
+    const double* wk;    // (nq_pad, n_pad) k operator, zero padded
+    const int* kwin;     // windows of knots per 64 queries
+    const int* j0k;      // (nq) < 0: NaN query
+    const double* wz;    // (64, 32) z operator, zero padded
+    const int* j0z;      // (nzq)
+    int post_op;
+    double scale;
+};
+
+constexpr int TABLES_WSTRIDE = 80;
+
+template <int POST>
+__global__ __launch_bounds__(256, 2) void tables_rows_kernel(const TablesArgs A) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (in a scalar register: what follows from it is wave-uniform for the compiler too)
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqt = (A.nq_pad + 255) / 256;
+    // the z operator in LDS for the launch, knot-major with a skewed stride (the lanes of an A fragment, 16 queries x 4 knots, on different banks):
+    // A fragment of chunk kk and row tile mi = wl[(4 kk + (l >> 4)) * TABLES_WSTRIDE + 16 mi + (l & 15)]
+    __shared__ double wl[32 * TABLES_WSTRIDE];
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int q = e >> 5, kz = e & 31;
+        wl[kz * TABLES_WSTRIDE + q] = A.wz[e];
+    }
+    __syncthreads();
+    // output redshifts whose operator row is NaN, among the 16 this lane stores (zq = 16 mi + (l >> 4) + 4 r): one bit each, for the launch
+    unsigned nan_z = 0u;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int zq = 16 * mi + g + 4 * r;
+            if (zq < A.nzq && A.j0z[zq] < 0) nan_z |= 1u << (4 * mi + r);
+        }
+    for (long long item = blockIdx.x; item < A.nbatch * nqt; item += gridDim.x) {
+        const long long b = item / nqt;
+        const int q0 = (int)(item % nqt) * 256 + wave * 64;
+        if (q0 >= A.nq_pad) continue;
+        // ---- L = T[b] Wk^T: rows = input redshifts (2 tiles of 16), columns = the wave's 64 output wavenumbers ----
+        cp_v4d acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = cp_v4d{0., 0., 0., 0.};
+        const double* yr[2];
+        const double* wr[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = 16 * i + l15;
+            row = row < A.nzin ? row : A.nzin - 1;      // rows past the table repeat its last one: Wz is zero there
+            yr[i] = A.t + (b * A.nzin + row) * A.n;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[j] = A.wk + (long long)(q0 + 16 * j + l15) * A.n_pad;
+        const int klo = A.kwin[2 * (q0 >> 6)], khi = A.kwin[2 * (q0 >> 6) + 1];
+        for (int kb = klo; kb < khi; kb += 16) {
+            const int k = kb + 4 * g;
+            double a[2][4];
+            cp_v4d bw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[j] = *reinterpret_cast<const cp_v4d*>(wr[j] + k);
+            if (kb + 16 <= A.n) {      // (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[i][m] = yr[i][k + m];
+            } else {   // last, partial chunk: Wk is zero there, but the table must not bring in the next row's values (0 x NaN)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[i][m] = k + m < A.n ? yr[i][k + m] : 0.;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][m], bw[j][m], acc[i][j], 0, 0, 0);
+        }
+        // ---- R = Wz L, one column tile at a time (accumulators: 4 tiles of 16 output redshifts), f applied, rows of P(k, z) stored ----
+        double* ob = A.out + b * (long long)A.nzq * A.nq;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            cp_v4d r2[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) r2[mi] = cp_v4d{0., 0., 0., 0.};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    r2[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(4 * kk + g) * TABLES_WSTRIDE + 16 * mi + l15], acc[kk >> 2][jj][kk & 3], r2[mi], 0, 0, 0);
+            // the epilogue without divergent control flow: NaN queries by selects, one wave-uniform test for tiles that reach past the arrays
+            const bool full = q0 + 16 * (jj + 1) <= A.nq && A.nzq == 64;
+            const int q = q0 + 16 * jj + l15;
+            const int qc = q < A.nq ? q : A.nq - 1;
+            const bool nanq = A.j0k[qc] < 0;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int zq = 16 * mi + g + 4 * r;
+                    double v = r2[mi][r] * A.scale;
+                    if (POST == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                    else if (POST == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
+                    v = (nanq || ((nan_z >> (4 * mi + r)) & 1u)) ? __builtin_nan("") : v;
+                    if (full || (q < A.nq && zq < A.nzq)) ob[(long long)zq * A.nq + q] = v;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_tables_rows_available(const cp_spline_plan* kplan, const cp_spline_plan* zplan) {
+    return kplan && zplan && kplan->d_wdense && kplan->d_kwin && zplan->d_wdense && zplan->n <= 32 && zplan->nq <= 64 && zplan->n_pad == 32 &&
+           zplan->nq_pad == 64 && kplan->device == zplan->device;
+}
+
+extern "C" int cp_tables_rows(const cp_spline_plan* kplan, const cp_spline_plan* zplan, const double* d_tables, double* d_out, long long nbatch, int post_op,
+                              double scale, void* stream) {
+    if (!kplan || !zplan) return cp::fail(CP_EINVAL, "cp_tables_rows: null plan");
+    if (nbatch < 0) return cp::fail(CP_EINVAL, "cp_tables_rows: negative batch");
+    if (nbatch == 0) return CP_OK;
+    if (!d_tables || !d_out) return cp::fail(CP_EINVAL, "cp_tables_rows: null device pointer");
+    if (post_op < CP_SPLINE_POST_NONE || post_op > CP_SPLINE_POST_EXP10) return cp::fail(CP_EINVAL, "cp_tables_rows: unknown post op %d", post_op);
+    if (!cp_tables_rows_available(kplan, zplan))
+        return cp::fail(CP_EUNSUPPORTED, "cp_tables_rows: needs a k operator with a dense copy and a z operator of at most 32 knots and 64 queries");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != kplan->device && hipSetDevice(kplan->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_tables_rows: cannot select device %d", kplan->device);
+    TablesArgs T;
+    T.t = d_tables; T.out = d_out; T.nbatch = nbatch;
+    T.n = kplan->n; T.nq = kplan->nq; T.n_pad = kplan->n_pad; T.nq_pad = kplan->nq_pad; T.nzin = zplan->n; T.nzq = zplan->nq;
+    T.wk = kplan->d_wdense; T.kwin = kplan->d_kwin; T.j0k = kplan->d_j0; T.wz = zplan->d_wdense; T.j0z = zplan->d_j0;
+    T.post_op = post_op; T.scale = scale;
+    const long long items = nbatch * ((kplan->nq_pad + 255) / 256);
+    const int grid = (int)(items < 256 * 2 ? items : 256 * 2);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (post_op == CP_SPLINE_POST_EXP10) hipLaunchKernelGGL(tables_rows_kernel<CP_SPLINE_POST_EXP10>, dim3(grid), dim3(256), 0, hs, T);
+    else if (post_op == CP_SPLINE_POST_SQRT) hipLaunchKernelGGL(tables_rows_kernel<CP_SPLINE_POST_SQRT>, dim3(grid), dim3(256), 0, hs, T);
+    else hipLaunchKernelGGL(tables_rows_kernel<CP_SPLINE_POST_NONE>, dim3(grid), dim3(256), 0, hs, T);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != kplan->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_tables_rows: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
 
 // ---- clamped cubic spline through uniformly spaced knots with one run of knots removed -------------------------------------
 // wallish2018 (reference bao_filter.py:387-405): per column the DST coefficients y_i (positions x_i = i + 1) are multiplied by

@@ -585,7 +585,17 @@ class Interpolator2D(dv.Copyable):
         yq = np.clip(yh, knots[0], knots[-1])
         opy = _cached_operator(('i2y-dense', k, knots.tobytes(), yq.tobytes(), self.device.index),
                                lambda: LinearOperator.dense(self._operator('y', yq, dense=True), device=self.device))
-        out = opy.mid(self._operator('x', xq)(fun_t), post='exp10' if exp10 else None)     # (batch..., ny, nxq) -> (batch..., nyq, nxq)
+        opx = self._operator('x', xq)
+        lib = _lib.load()
+        if fun_t.ndim == 3 and lib.cp_tables_rows_available(opx._handle, opy._handle):
+            # both operators in one kernel (cp_tables_rows): the x-splined tables are never written
+            torch = dv.torch()
+            out = torch.empty((fun_t.shape[0], opy.nq, opx.nq), dtype=torch.float64, device=self.device)
+            if fun_t.shape[0]:
+                _lib.check(lib.cp_tables_rows(opx._handle, opy._handle, fun_t.data_ptr(), out.data_ptr(), fun_t.shape[0], 2 if exp10 else 0, 1.,
+                                              dv.stream_of(self.device)))
+        else:
+            out = opy.mid(opx(fun_t), post='exp10' if exp10 else None)     # (batch..., ny, nxq) -> (batch..., nyq, nxq)
         if self._nan_surfaces is not None:
             out = dv.torch().where(self._nan_surfaces[..., None, None], dv.torch().full_like(out, float('nan')), out)
         return out

@@ -254,6 +254,13 @@ int cp_linop_plan_create(cp_spline_plan** plan, int n, int nq, const double* w_d
  * RectBivariateSpline (jax.py:241-271) in PowerSpectrumInterpolator2D.sigma_rz (interpolator.py:846-875).  Plans of cp_linop_plan_create only. */
 int cp_linop_apply_mid(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nbatch, long long ninner, int post_op, double scale,
                        void* stream);
+/* Batches of (z, k) tables -> rows of P(k, z) in one kernel: d_out[b, zq, q] = f(scale x sum_zi Wz[zq, zi] sum_j Wk[q, j] d_tables[b, zi, j]),
+ * the two passes of RectBivariateSpline (jax.py:241-271) without the k-splined tables in between (the accumulators of the first contraction are
+ * the operands of the second).  kplan: spline / operator plan along k (n knots -> nq queries); zplan: cp_linop_plan_create plan of at most 32
+ * knots and 64 queries; d_tables : (nbatch, zplan.n, kplan.n), k fastest; d_out : (nbatch, zplan.nq, kplan.nq).  post_op as cp_linop_apply_mid. */
+int cp_tables_rows_available(const cp_spline_plan* kplan, const cp_spline_plan* zplan);
+int cp_tables_rows(const cp_spline_plan* kplan, const cp_spline_plan* zplan, const double* d_tables, double* d_out, long long nbatch, int post_op, double scale,
+                   void* stream);
 int cp_spline_plan_destroy(cp_spline_plan* plan);
 int cp_spline_plan_info(const cp_spline_plan* plan, int* n, int* nq, int* bandwidth);
 /* the dense operator W (nq x n, row-major, host) and per-query inside-range flags: what the plan is built from */

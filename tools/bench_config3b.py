@@ -23,7 +23,7 @@ def main():
     interp = cp.PowerSpectrumInterpolator2D(k, z, batch)
     torch.cuda.synchronize()
     print('setup (sort, log-log padding, log10): %.2f ms' % ((time.perf_counter() - t0) * 1e3))
-    for _ in range(3):
+    for _ in range(6):      # (the first two calls build plans and operators: tens of milliseconds)
         interp.sigma_rz(r, zq)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
