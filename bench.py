@@ -136,6 +136,27 @@ def config3(cp, torch, dev, ncosmo=10000, reps=5):
                          'frac': nbytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_cosmology': 256 * 64 * 8 + 80}}
 
 
+def config3b(cp, torch, dev, ncosmo=10000, reps=5):
+    """sigma_rz on 256 r x 64 z for a batch of TABULATED P(k, z) (500 k x 30 z per cosmology) through
+    PowerSpectrumInterpolator2D(k, z, pk=(B, nk, nz)).sigma_rz: cosmologies/s and the HBM fraction on the 120 000 + 131 072 algorithmic bytes
+    per cosmology.  The tables are the reference's (tests/golden/sigma.npz: the EH98 table of its own test) times one amplitude per cosmology."""
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'sigma.npz'))
+    rng = np.random.default_rng(1)
+    amp = torch.as_tensor(rng.uniform(0.5, 2., ncosmo), device=dev)
+    tables = amp[:, None, None] * torch.as_tensor(g['table_pk'], device=dev)[None]
+    interp = cp.PowerSpectrumInterpolator2D(g['table_k'], g['table_z'], tables)
+    r, z = torch.as_tensor(np.geomspace(1, 100, 256), device=dev), torch.as_tensor(np.linspace(0, 3, 64), device=dev)
+    wall, gpu = _gpu_ms(lambda: interp.sigma_rz(r, z), reps, torch, dev)
+    nbytes = ncosmo * (500 * 30 * 8 + 256 * 64 * 8)
+    return {'workload': 'config 3B: sigma_rz 256 r x 64 z, %d tabulated P(k, z) of 500 k x 30 z, method fftlog nk=1024 (64 FFTLogs per table), through '
+                        'PowerSpectrumInterpolator2D.sigma_rz' % ncosmo,
+            'value': ncosmo / (wall * 1e-3), 'unit': 'cosmologies/s', 'ms': wall, 'ms_gpu_events': gpu,
+            'roofline': {'bound': 'hbm', 'achieved': nbytes / (wall * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': nbytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_cosmology': 500 * 30 * 8 + 256 * 64 * 8,
+                         'note': '64 FFTLogs (Np = 2048) per table: their fp64 work alone is ~1.8 ms per 10 000 tables at the vector peak the headline '
+                                 'kernel reaches (DESIGN.md section 4), 11 % of HBM on these bytes'}}
+
+
 def config4(cp, torch, dev, par, chunk=16384):
     """wallish2018 and brieden2022 on EH98 P(k) vectors (nk = 1024) of the cosmologies ``par``, chunk by chunk (P(k) generation and sigma8
     normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time."""
@@ -210,6 +231,8 @@ def config5_samples(n, seed, torch, dev):
 def secondary(cp, torch, dev):
     """BASELINE configs 3, 4, 5 at one GPU's share of the smaller kind (a few ms to tens of ms each), for the N = 1 line."""
     out = {'config3': config3(cp, torch, dev)}
+    out['config3b'] = config3b(cp, torch, dev)
+    torch.cuda.empty_cache()
     c4 = config4(cp, torch, dev, eh_parameters(4 * 16384, 2, torch, dev))
     out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on 65 536 EH98 P(k) vectors (four 16 384-vector chunks of a GPU share of 125 000, '
                                          'queued back to back as the whole share is), P(k) generation and sigma8 normalisation included, results resident')

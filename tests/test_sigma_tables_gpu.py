@@ -33,6 +33,10 @@ def test_batch_of_tables_matches_single_tables(cp, golden):
     out = many.sigma_rz(r, zq)
     assert out.shape == (7, 256, 64)
     np.testing.assert_allclose(out[0], g['table_sigma_rz'], rtol=1e-9)              # the reference's numbers for its table
+    from oracle import interp as oi, sigma as osig
+    for i in range(1, 7):      # ... and the oracle's restatement of the reference's route for the perturbed ones
+        pk2d = oi.pk_interp_2d(k, z, batch[i])
+        np.testing.assert_allclose(out[i], np.sqrt(osig.sigma_r2(r, lambda kk: pk2d(kk, zq, grid=True))), rtol=1e-9, err_msg='table %d' % i)
     kq, zz = g['table_eval_k'], np.linspace(0.1, 2.5, 16)
     np.testing.assert_allclose(many(kq, zq[::4])[0], g['table_eval'], rtol=1e-10)               # ... and its values (64 k x 16 z)
     pairs = many(kq[:16], zz, grid=False)
@@ -77,6 +81,14 @@ def test_config3_variant_b_full_size(cp, golden):
     for i in (0, 5000, 9999):
         one = cp.PowerSpectrumInterpolator2D(k, z, batch[i])
         np.testing.assert_allclose(out[i].cpu().numpy(), one.sigma_rz(g['r'], g['z']), rtol=1e-11)
+    # sampled PERTURBED tables against the oracle's restatement of the reference's route (RectBivariateSpline of log10 P on (log10 k, z) with the
+    # log-log padding, P(k, z) at the 64 redshifts, one TophatVariance FFTLog per redshift, natural spline to r: interpolator.py:846-875) -- nothing
+    # of the package on the reference side
+    from oracle import interp as oi, sigma as osig
+    for i in (1, 4242, 9998):
+        pk2d = oi.pk_interp_2d(k, z, batch[i])
+        ref = np.sqrt(osig.sigma_r2(g['r'], lambda kk: pk2d(kk, g['z'], grid=True)))      # (nr, nz)
+        np.testing.assert_allclose(out[i].cpu().numpy(), ref, rtol=1e-9, err_msg='table %d' % i)
 
 
 def test_quad_method(cp, golden):
