@@ -1,6 +1,6 @@
 """One of the secondary configs of bench.py on its own, for a kernel trace (development aid):
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c3 -- python3 tools/profile_secondary.py 3
-Configs: 3, 4 (both filters, one 16 384-vector chunk timed 4 times), 5."""
+Configs: 3, 3b, 4 (both filters, one 16 384-vector chunk timed 4 times), 5."""
 import json
 import os
 import sys
@@ -17,6 +17,8 @@ def main():
     torch.cuda.set_device(dev)
     if which == '3':
         out = bench.config3(cp, torch, dev, reps=20)
+    elif which == '3b':
+        out = bench.config3b(cp, torch, dev, reps=10)
     elif which == '4':
         out = bench.config4(cp, torch, dev, bench.eh_parameters(4 * 16384, 2, torch, dev))
     else:
