@@ -40,11 +40,11 @@ __device__ __forceinline__ double log_pos(double x) {
     return k * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, k * 1.90821492927058770002e-10)) - f);
 }
 
-// sin(x) for 0 <= x < 1e6 (k rs_drag reaches 1e4 at k = 100 h/Mpc): n = round(x / (pi / 2)), r = x - n pi/2 with pi/2 in two pieces (33 + 53
+// sin(x) for |x| < 1e6 (k rs_drag reaches 1e4 at k = 100 h/Mpc): n = round(x / (pi / 2)), r = x - n pi/2 with pi/2 in two pieces (33 + 53
 // bits: n times the first is exact), then the degree-13 / degree-14 polynomials of sin and cos on [-pi/4, pi/4] picked by n mod 4; absolute
 // error below 2e-16 (checked against extended precision on 6e5 arguments up to 1e6).  Larger arguments take the library function.
 __device__ __forceinline__ double sin_bounded(double x) {
-    if (!(x < 1e6)) return sin_any(x);
+    if (!(fabs(x) < 1e6)) return sin_any(x);      // (also -Inf and arguments below -1e6: the two-piece reduction is exact for |n| < 2^20 only)
     const double n = rint(x * 6.36619772367581382433e-01);
     double r = fma(-n, 1.57079632673412561417e+00, x);
     r = fma(-n, 6.07710050650619224932e-11, r);

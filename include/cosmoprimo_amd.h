@@ -239,6 +239,10 @@ typedef struct cp_spline_plan cp_spline_plan;
  * extrapolate = 0: queries outside [x[0], x[n-1]] give NaN (Interpolator1D, jax.py:200). */
 int cp_spline_plan_create(cp_spline_plan** plan, int n, const double* x, int nq, const double* xq, int bc, int nu, int extrapolate, int device);
 /* d_out[row, q] = post_op(scale * sum_j W[q, j] d_y[row, j]);  d_y : (nrows, n), d_out : (nrows, nq), device, row-major */
+/* Non-finite knot values: the banded vector kernel confines a NaN / Inf at knot j to the queries whose band covers j; the matrix-core route
+ * multiplies the explicit zeros of a 64-query tile's window as well (0 x NaN = NaN), so there the NaN reaches every query of the tiles whose
+ * window covers j (the whole row for dense plans).  Callers that rely on containment inside a row (none in this package: rows holding a
+ * non-finite sample are NaN throughout in the reference too, jax.py:120-131) force CP_SPLINE_PATH_VALU. */
 int cp_spline_apply(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nrows, int post_op, double scale, void* stream);
 /* the same followed by an outer product with per-row factors, written once: d_out (nrows, nq, nz) = f(scale x spline(d_y)[row, q] x d_g[row, z]),
  * f = sqrt for CP_SPLINE_POST_SQRT, evaluated as sqrt(scale x spline) x sqrt(g): both factors are variances / squared growth factors (a negative one
