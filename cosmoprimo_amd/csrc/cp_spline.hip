@@ -866,7 +866,8 @@ struct TablesArgs {
     const double* wk;    // (nq_pad, n_pad) k operator, zero padded
     const int* kwin;     // windows of knots per 64 queries
     const int* j0k;      // (nq) < 0: NaN query
-    const double* wz;    // (64, 32) z operator, zero padded
+    const double* wz;    // (64, nz_pad) z operator, zero padded
+    int nz_pad;          // 16 or 32
     const int* j0z;      // (nzq)
     int post_op;
     double scale;
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void tables_rows_kernel(const TablesArgs A)
     __shared__ double wl[32 * TABLES_WSTRIDE];
     for (int e = threadIdx.x; e < 64 * 32; e += 256) {
         const int q = e >> 5, kz = e & 31;
-        wl[kz * TABLES_WSTRIDE + q] = A.wz[e];
+        wl[kz * TABLES_WSTRIDE + q] = kz < A.nz_pad ? A.wz[q * A.nz_pad + kz] : 0.;      // (the plan pads its knots to 16 or 32)
     }
     __syncthreads();
     // output redshifts whose operator row is NaN, among the 16 this lane stores (zq = 16 mi + (l >> 4) + 4 r): one bit each, for the launch
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void tables_rows_kernel(const TablesArgs A)
 }  // namespace
 
 extern "C" int cp_tables_rows_available(const cp_spline_plan* kplan, const cp_spline_plan* zplan) {
-    return kplan && zplan && kplan->d_wdense && kplan->d_kwin && zplan->d_wdense && zplan->n <= 32 && zplan->nq <= 64 && zplan->n_pad == 32 &&
+    return kplan && zplan && kplan->d_wdense && kplan->d_kwin && zplan->d_wdense && zplan->n <= 32 && zplan->nq <= 64 && zplan->n_pad <= 32 &&
            zplan->nq_pad == 64 && kplan->device == zplan->device;
 }
 
@@ -995,7 +996,7 @@ extern "C" int cp_tables_rows(const cp_spline_plan* kplan, const cp_spline_plan*
     TablesArgs T;
     T.t = d_tables; T.out = d_out; T.nbatch = nbatch;
     T.n = kplan->n; T.nq = kplan->nq; T.n_pad = kplan->n_pad; T.nq_pad = kplan->nq_pad; T.nzin = zplan->n; T.nzq = zplan->nq;
-    T.wk = kplan->d_wdense; T.kwin = kplan->d_kwin; T.j0k = kplan->d_j0; T.wz = zplan->d_wdense; T.j0z = zplan->d_j0;
+    T.wk = kplan->d_wdense; T.kwin = kplan->d_kwin; T.j0k = kplan->d_j0; T.wz = zplan->d_wdense; T.nz_pad = zplan->n_pad; T.j0z = zplan->d_j0;
     T.post_op = post_op; T.scale = scale;
     const long long items = nbatch * ((kplan->nq_pad + 255) / 256);
     const int grid = (int)(items < 256 * 2 ? items : 256 * 2);

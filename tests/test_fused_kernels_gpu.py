@@ -1,0 +1,144 @@
+"""GPU: the round-3 fused entry points called directly through the C ABI, against the separate kernels / plain torch arithmetic they replace:
+cp_tables_rows (both spline directions of a batch of tables), cp_fftlog_spline_execute (FFTLog + spline to radii), the elementwise passes of
+the two BAO filters (cp_wallish_finish, cp_brieden_ratio / _knots / _finish).  Odd sizes, NaN rows and queries, partial tiles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    import torch
+    from cosmoprimo_amd import _lib, _device as dv
+    dev = torch.device('cuda', 0)
+    return torch, _lib, _lib.load(), dv, dev
+
+
+@pytest.mark.parametrize('shape', [(7, 30, 504, 64, 1024), (3, 17, 200, 50, 1000), (1, 32, 64, 64, 64), (5, 4, 40, 9, 130)])
+@pytest.mark.parametrize('post', [None, 'exp10', 'sqrt'])
+def test_tables_rows_matches_two_launches(shape, post):
+    torch, _lib, lib, dv, dev = _env()
+    from cosmoprimo_amd.spline import LinearOperator, dense_operator
+    nb, nzin, n, nzq, nq = shape
+    rng = np.random.default_rng(nb + n)
+    x = np.linspace(0., 10., n) + rng.uniform(-0.3, 0.3, n) * 10. / n                        # uneven knots, no near-coincident ones (bounded splines)
+    xq = np.sort(rng.uniform(-0.5, 10.5, nq))                                                # some queries outside the knots: NaN rows of the operator
+    zk, zq = np.linspace(0., 3., nzin), np.linspace(0., 3., nzq)
+    opx = LinearOperator.spline(x, xq, bc='not-a-knot', extrapolate=False, device=dev)
+    opz = LinearOperator.dense(dense_operator(zk, zq, bc='not-a-knot', extrapolate=True), device=dev)
+    assert lib.cp_tables_rows_available(opx._handle, opz._handle) == 1
+    smooth = 1. + 0.3 * np.sin(x)[None, None, :] * np.cos(zk)[None, :, None] * rng.uniform(0.5, 1., (nb, 1, 1))
+    t = torch.as_tensor(smooth + 1e-3 * rng.standard_normal((nb, nzin, n)), device=dev)
+    out = torch.full((nb, nzq, nq), -7., dtype=torch.float64, device=dev)
+    code = {None: 0, 'sqrt': 1, 'exp10': 2}[post]
+    _lib.check(lib.cp_tables_rows(opx._handle, opz._handle, t.data_ptr(), out.data_ptr(), nb, code, 1., dv.stream_of(dev)))
+    ref = opz.mid(opx(t), post=post)
+    got, ref = out.cpu().numpy(), ref.cpu().numpy()
+    outside = (xq < x[0]) | (xq > x[-1])
+    assert np.isnan(got[..., outside]).all() and np.isfinite(got[..., ~outside]).all()
+    np.testing.assert_allclose(got[..., ~outside], ref[..., ~outside], rtol=1e-12, atol=1e-13)
+    # and against scipy on one table: the reference's own two passes (jax.py:241-271)
+    from scipy.interpolate import CubicSpline
+    inside = ~outside
+    one = CubicSpline(x, t[0].cpu().numpy(), axis=1)(xq[inside])                              # (nzin, nq_in)
+    two = CubicSpline(zk, one, axis=0)(zq) if nzin >= 4 else None
+    if two is not None:
+        two = two if post is None else (np.sqrt(two) if post == 'sqrt' else 10.**two)
+        np.testing.assert_allclose(got[0][:, inside], two, rtol=1e-10, atol=1e-12)
+    # a table holding a NaN is NaN throughout, its neighbours are untouched
+    if nb > 1:
+        t2 = t.clone()
+        t2[1, nzin // 2, n // 3] = float('nan')
+        _lib.check(lib.cp_tables_rows(opx._handle, opz._handle, t2.data_ptr(), out.data_ptr(), nb, code, 1., dv.stream_of(dev)))
+        again = out.cpu().numpy()
+        assert np.isnan(again[1]).any() and np.array_equal(np.delete(again, 1, axis=0), np.delete(got, 1, axis=0), equal_nan=True)
+
+
+def test_tables_rows_refuses_other_shapes():
+    torch, _lib, lib, dv, dev = _env()
+    from cosmoprimo_amd.spline import LinearOperator
+    rng = np.random.default_rng(0)
+    opx = LinearOperator.spline(np.linspace(0., 1., 50), np.linspace(0., 1., 80), device=dev)
+    wide = LinearOperator.dense(rng.normal(size=(70, 40)), device=dev)          # more than 64 output redshifts, more than 32 input ones
+    assert lib.cp_tables_rows_available(opx._handle, wide._handle) == 0
+    t = torch.zeros((2, 40, 50), dtype=torch.float64, device=dev)
+    out = torch.zeros((2, 70, 80), dtype=torch.float64, device=dev)
+    assert lib.cp_tables_rows(opx._handle, wide._handle, t.data_ptr(), out.data_ptr(), 2, 0, 1., dv.stream_of(dev)) != 0
+
+
+@pytest.mark.parametrize('nrows,nq', [(1, 1), (2, 40), (33, 256), (300, 130)])
+def test_fftlog_spline_execute(nrows, nq):
+    torch, _lib, lib, dv, dev = _env()
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd.spline import LinearOperator
+    k = np.geomspace(1e-7, 1e2, 1024)
+    fft = cp.TophatVariance(k, device=dev)
+    r = np.geomspace(0.7, 150., nq) if nq > 1 else np.array([8.])
+    if nq > 4:
+        r[0], r[-1] = 1e-5, 1e9                                                       # outside the output grid of the transform: NaN
+    op = LinearOperator.spline(fft.y[0], r, bc='natural', device=dev)
+    plan = fft._get_plan(dev)
+    assert lib.cp_sigma_rz_fused_available(plan.handle, op._handle) == 1
+    rng = np.random.default_rng(nrows)
+    rows = torch.as_tensor(rng.uniform(0.5, 2., (nrows, 1)) * (k / 0.05)**rng.uniform(-2.2, -1.8, (nrows, 1)) * 1e4, device=dev).contiguous()
+    if nrows > 2:
+        rows[1, 100] = float('nan')                                                   # row 1 shares a transform with row 0
+    for post in (0, 1):
+        out = torch.full((nrows, nq), -3., dtype=torch.float64, device=dev)
+        _lib.check(lib.cp_fftlog_spline_execute(plan.handle, op._handle, rows.data_ptr(), out.data_ptr(), nrows, post, dv.stream_of(dev)))
+        ref = op(fft(rows)[1], sqrt=bool(post)).cpu().numpy()
+        got = out.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        # (the separate spline kernel may take the matrix cores: another order of additions, 2e-15 of the ROW's largest value, which is 1e3 times
+        # the variances at the largest radii)
+        np.testing.assert_allclose(got[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=2e-11)
+        if nrows > 2:
+            assert np.isnan(got[1]).all() and np.isfinite(got[0][1:-1] if nq > 4 else got[0]).all()
+    # a transform of another size is refused (the caller makes the two calls)
+    other = cp.TophatVariance(np.geomspace(1e-5, 1e2, 512), device=dev)
+    op2 = LinearOperator.spline(other.y[0], np.array([8.]), bc='natural', device=dev)
+    assert lib.cp_sigma_rz_fused_available(other._get_plan(dev).handle, op2._handle) == 0
+
+
+def test_bao_elementwise_passes():
+    torch, _lib, lib, dv, dev = _env()
+    rng = np.random.default_rng(5)
+    st = dv.stream_of(dev)
+    T = lambda a: torch.as_tensor(a, device=dev).contiguous()      # noqa: E731
+    # wallish2018: pknow = a + b; out = pk / ((pk / pknow - 1) tophat + 1)
+    nrows, n = 37, 1024
+    pk, top = T(rng.uniform(0.5, 2., (nrows, n))), T(rng.uniform(0., 1., n))
+    a = pk * T(rng.uniform(0.3, 0.6, (nrows, n)))
+    b = pk * T(rng.uniform(0.97, 1.03, (nrows, n))) - a            # a + b = the smooth spectrum, within a few per cent of pk (the wiggles)
+    out = torch.empty_like(pk)
+    _lib.check(lib.cp_wallish_finish(pk.data_ptr(), a.data_ptr(), b.data_ptr(), top.data_ptr(), out.data_ptr(), nrows, n, 0, st))
+    ref = pk / ((pk / (a + b) - 1.) * top + 1.)
+    assert float(((out - ref) / ref).abs().max()) < 1e-14
+    _lib.check(lib.cp_wallish_finish(pk.data_ptr(), a.data_ptr(), None, top.data_ptr(), out.data_ptr(), nrows, n, 0, st))
+    assert float(((out - pk / ((pk / a - 1.) * top + 1.)) / ref).abs().max()) < 1e-13
+    # brieden2022: ratio, padded knots, finish
+    nb, m, nk, first = 23, 341, 1024, 300
+    rows, now = T(rng.uniform(0.5, 2., (nb, m))), T(rng.uniform(0.5, 2., (nb, m)))
+    g0, corr, rfid, rnow = T(rng.uniform(0.5, 2., nb)), T(rng.uniform(0.9, 1.1, m)), T(rng.uniform(0.9, 1.1, m)), T(rng.uniform(0.9, 1.1, m))
+    pknow, ratio = torch.empty_like(rows), torch.empty_like(rows)
+    _lib.check(lib.cp_brieden_ratio(rows.data_ptr(), now.data_ptr(), g0.data_ptr(), corr.data_ptr(), rfid.data_ptr(), pknow.data_ptr(), ratio.data_ptr(), nb, m, 0, st))
+    ref_pknow = now * g0[:, None] * corr
+    assert torch.equal(pknow, ref_pknow) and float((ratio / (rows / ref_pknow / rfid) - 1.).abs().max()) < 1e-15
+    k_fid, rescale = np.geomspace(1e-3, 1., m), rng.uniform(0.9, 1.1, nb)
+    env = T(rng.uniform(0.9, 1.1, (nb, m)))
+    xk, yk = torch.empty((m + 4, nb), dtype=torch.float64, device=dev), torch.empty((m + 4, nb), dtype=torch.float64, device=dev)
+    _lib.check(lib.cp_brieden_knots(env.data_ptr(), pknow.data_ptr(), rnow.data_ptr(), T(k_fid).data_ptr(), T(rescale).data_ptr(), 1e-7, 1e2, xk.data_ptr(),
+                                    yk.data_ptr(), nb, m, 0, st))
+    from cosmoprimo_amd.interpolator import _pad_log
+    cols = (env * pknow * rnow).cpu().numpy()
+    for c in (0, 11, nb - 1):      # _pad_log of the package's host path (pinned against the reference's in tests/test_oracle_interp.py) on the column's own knots
+        lk, lp = _pad_log(k_fid / rescale[c], cols[c], extrap_kmin=1e-7, extrap_kmax=1e2)
+        np.testing.assert_allclose(xk[:, c].cpu().numpy(), lk, rtol=1e-14, atol=1e-14)
+        np.testing.assert_allclose(yk[:, c].cpu().numpy(), lp, rtol=1e-13, atol=1e-13)
+    pkrows, res = T(rng.uniform(0.5, 2., (nb, nk))), T(rng.uniform(-1., 1., (m, nb)))
+    out = torch.empty_like(pkrows)
+    _lib.check(lib.cp_brieden_finish(pkrows.data_ptr(), res.data_ptr(), out.data_ptr(), nb, nk, first, m, 0, st))
+    ref = pkrows.clone()
+    ref[:, first:first + m] = (10.**res).T
+    assert float((out / ref - 1.).abs().max()) < 1e-15
+    assert lib.cp_brieden_finish(pkrows.data_ptr(), res.data_ptr(), out.data_ptr(), nb, nk, nk - 10, m, 0, st) != 0      # the range must fit the row
