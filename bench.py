@@ -157,7 +157,25 @@ def config3b(cp, torch, dev, ncosmo=10000, reps=5):
                                  'kernel reaches (DESIGN.md section 4), 11 % of HBM on these bytes'}}
 
 
-def config4(cp, torch, dev, par, chunk=16384):
+def _config4_valu_roofline(engine, vectors_per_s):
+    """What bounds the filters is instruction issue, not HBM: the vector-instruction roofline from the committed instruction census
+    (profiles/*_config4_valu.json: SQ_INSTS_VALU / SQ_INSTS_MFMA per vector from a rocprofv3 --pmc pass of this same workload)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_config4_valu.json')))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        census = json.load(fh)
+    per = census[engine]['per_vector']
+    peak = census['peaks']['valu_wave_instructions_per_s']
+    achieved = per['SQ_INSTS_VALU'] * vectors_per_s
+    return {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': achieved, 'peak': peak,
+            'unit': 'wave-instructions/s', 'frac': achieved / peak, 'valu_wave_instructions_per_vector': per['SQ_INSTS_VALU'],
+            'mfma_f64_16x16x4_per_vector': per['SQ_INSTS_MFMA'], 'mfma_frac': per['SQ_INSTS_MFMA'] * vectors_per_s / census['peaks']['mfma_f64_16x16x4_per_s'],
+            'source': os.path.relpath(files[-1], ROOT)}
+
+
+def config4(cp, torch, dev, par, chunk=16384, engines=('wallish2018', 'brieden2022')):
     """wallish2018 and brieden2022 on EH98 P(k) vectors (nk = 1024) of the cosmologies ``par``, chunk by chunk (P(k) generation and sigma8
     normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time."""
     import warnings
@@ -167,7 +185,7 @@ def config4(cp, torch, dev, par, chunk=16384):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         fid = cp.Cosmology(engine='eisenstein_hu')
-        for engine in ('wallish2018', 'brieden2022'):
+        for engine in engines:
             kw = dict(cosmo_fid=fid) if engine == 'brieden2022' else {}
             state = {}
 
@@ -191,7 +209,8 @@ def config4(cp, torch, dev, par, chunk=16384):
             torch.cuda.synchronize(dev)
             wall = time.perf_counter() - t0
             assert bool(torch.isfinite(res).all())
-            out[engine] = {'value': n / wall, 'unit': 'vectors/s', 'ms': wall * 1e3, 'ms_gpu_events': e0.elapsed_time(e1), 'vectors': n,
+            valu = _config4_valu_roofline(engine, n / wall)
+            out[engine] = {'value': n / wall, 'unit': 'vectors/s', 'ms': wall * 1e3, 'ms_gpu_events': e0.elapsed_time(e1), 'vectors': n, 'roofline_valu': valu,
                            'roofline': {'bound': 'hbm', 'achieved': n * 16384 / wall / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                         'frac': n * 16384 / wall / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_vector': 16384,
                                         'note': 'latency / ALU bound by construction (SURVEY.md 8(d)): the HBM fraction is reported, not targeted'}}

@@ -19,6 +19,11 @@ def main():
         out = bench.config3(cp, torch, dev, reps=20)
     elif which == '3b':
         out = bench.config3b(cp, torch, dev, reps=10)
+    elif which in ('4w', '4b'):      # one filter only (counter collection per filter)
+        engine = 'wallish2018' if which == '4w' else 'brieden2022'
+        bench.RAMP_S = 0.      # one untimed chunk, then the four timed ones: 5 x 16 384 vectors go through the filter in this process
+        out = bench.config4(cp, torch, dev, bench.eh_parameters(4 * 16384, 2, torch, dev), engines=(engine,))
+        out['vectors_through_the_filter_in_this_process'] = 5 * 16384
     elif which == '4':
         out = bench.config4(cp, torch, dev, bench.eh_parameters(4 * 16384, 2, torch, dev))
     else:
