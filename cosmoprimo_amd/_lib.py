@@ -71,6 +71,7 @@ SIGNATURES = {
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'cp_linop_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int]),
     'cp_spline_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
+    'cp_spline_apply_grouped': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     'cp_spline_apply_outer': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
                                             ctypes.c_double, ctypes.c_void_p]),
     'cp_linop_apply_mid': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_double,

@@ -31,6 +31,14 @@ using cpmath::exp10_mid;
 constexpr int TILE_Q = 256;      // at most one query per lane
 constexpr int SPAN_CAP = 480;    // knots a tile may cover when it holds more than one query: 16 rows x 480 knots = 60 KB of LDS
 
+// where the value of (row, query) is stored: (nrows, nq) row-major, or -- group > 0 -- (nrows / group, nq, group): the rows of a group (the
+// redshifts of one table) become the fastest axis, i.e. the (nz, nr) -> (nr, nz) transposition of sigma_rz is part of the store
+__device__ __forceinline__ long long out_index(long long row, int q, int nq, int group) {
+    if (group <= 0) return row * nq + q;
+    const long long b = row / group;
+    return (b * nq + q) * group + (row - b * group);
+}
+
 struct Args {
     const double* y;    // (nrows, n)
     double* out;        // (nrows, nq)
@@ -42,6 +50,7 @@ struct Args {
     int ntiles, span_max;
     int post_op;
     double scale;
+    int group;          // > 0: output (nrows / group, nq, group) -- row r lands at [r / group, q, r % group] (a transposition fused into the store)
 };
 
 // One work item = R rows x one tile of consecutive queries.  The knots the tile's bands cover are staged in LDS for the R rows; a lane owns
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256) void spline_apply_kernel(const Args A) {
                 double v = j0 >= 0 ? acc[r] * A.scale : __builtin_nan("");
                 if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
                 else if (A.post_op == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
-                A.out[(r0 + r) * A.nq + q] = v;
+                A.out[out_index(r0 + r, q, A.nq, A.group)] = v;
             }
         }
     }
@@ -213,6 +222,7 @@ struct DenseArgs {
     const int* kwin;   // (nq_pad / 64, 2): the knots [lo, hi), multiples of 16, that the bands of each tile of 64 queries cover
     int post_op;
     double scale;
+    int group;         // as Args::group
 };
 
 // Round 3: wave tile 64 rows x 64 queries (4 x 4 accumulator tiles, 128 registers) instead of 32 x 64.  The kernel reads its operands straight from
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
                     double v = nanq ? __builtin_nan("") : acc[i][j][r] * A.scale;
                     if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
                     else if (A.post_op == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
-                    A.out[row * A.nq + q] = v;
+                    A.out[out_index(row, q, A.nq, A.group)] = v;
                 }
         }
     }
@@ -742,8 +752,17 @@ extern "C" int cp_spline_plan_info(const cp_spline_plan* p, int* n, int* nq, int
     return CP_OK;
 }
 
+extern "C" int cp_spline_apply_grouped(const cp_spline_plan* p, const double* d_y, double* d_out, long long nrows, int group, int post_op, double scale,
+                                       void* stream);
+
 extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, double* d_out, long long nrows, int post_op, double scale, void* stream) {
+    return cp_spline_apply_grouped(p, d_y, d_out, nrows, 0, post_op, scale, stream);
+}
+
+extern "C" int cp_spline_apply_grouped(const cp_spline_plan* p, const double* d_y, double* d_out, long long nrows, int group, int post_op, double scale,
+                                       void* stream) {
     if (!p) return cp::fail(CP_EINVAL, "cp_spline_apply: null plan");
+    if (group < 0 || (group > 0 && nrows % group != 0)) return cp::fail(CP_EINVAL, "cp_spline_apply_grouped: %lld rows are not a whole number of groups of %d", nrows, group);
     if (nrows < 0) return cp::fail(CP_EINVAL, "cp_spline_apply: negative row count");
     if (nrows == 0) return CP_OK;
     if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_spline_apply: null device pointer");
@@ -761,7 +780,7 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
         if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: cannot select device %d", p->device);
         DenseArgs D;
         D.y = d_y; D.out = d_out; D.nrows = nrows; D.n = p->n; D.nq = p->nq; D.n_pad = p->n_pad; D.nq_pad = p->nq_pad; D.w = p->d_wdense; D.j0 = p->d_j0;
-        D.kwin = p->d_kwin; D.post_op = post_op; D.scale = scale;
+        D.kwin = p->d_kwin; D.post_op = post_op; D.scale = scale; D.group = group;
         const long long items = ((nrows + 16 * LINOP_MT - 1) / (16 * LINOP_MT)) * ((p->nq_pad + 255) / 256);
         const int grid = (int)(items < 256 * 2 ? items : 256 * 2);
         hipLaunchKernelGGL(linop_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), D);
@@ -783,7 +802,7 @@ extern "C" int cp_spline_apply(const cp_spline_plan* p, const double* d_y, doubl
     Args A;
     A.y = d_y; A.out = d_out; A.nrows = nrows; A.n = p->n; A.nq = p->nq; A.bw = p->bw; A.wb = p->d_wb; A.j0 = p->d_j0;
     A.tile = p->d_tile; A.ntiles = p->ntiles; A.span_max = p->span_max;
-    A.post_op = post_op; A.scale = scale;
+    A.post_op = post_op; A.scale = scale; A.group = group;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const hipError_t e = rows == 16 ? launch_apply<16>(A, lds, hs) : rows == 8 ? launch_apply<8>(A, lds, hs) : launch_apply<4>(A, lds, hs);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
@@ -812,7 +831,7 @@ extern "C" int cp_spline_apply_outer(const cp_spline_plan* p, const double* d_y,
     Args& A = O.a;
     A.y = d_y; A.out = d_out; A.nrows = nrows; A.n = p->n; A.nq = p->nq; A.bw = p->bw; A.wb = p->d_wb; A.j0 = p->d_j0;
     A.tile = p->d_tile; A.ntiles = p->ntiles; A.span_max = p->span_max;
-    A.post_op = post_op; A.scale = scale;
+    A.post_op = post_op; A.scale = scale; A.group = 0;
     O.g = d_g; O.nz = nz;
     hipStream_t hs = static_cast<hipStream_t>(stream);
     const hipError_t e = rows == 8 ? launch_outer<8>(O, lds, hs) : rows == 4 ? launch_outer<4>(O, lds, hs) : launch_outer<2>(O, lds, hs);

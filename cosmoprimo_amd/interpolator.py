@@ -170,6 +170,7 @@ def _cached_operator(key, build):
 # query to one thread: it pays for batches that are small enough to be launch / latency bound and wide enough in queries to keep its threads
 # busy (tools/bench_fused_spline.py); large batches (config 3B: 640 000 rows) and single radii (sigma8) take the two kernels.
 _FUSED_SPLINE_ROWS = (2, 8192)
+_TRANSPOSE_IN_STORE = True
 
 
 def _fftlog_then_spline(fft, op, rows, device, sqrt=False):
@@ -200,7 +201,8 @@ def _with_growth(sigma2, growth_sq):
     return (sigma2[..., :, None] * growth_sq[..., None, :]).sqrt()
 
 
-def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None, epsabs=1e-5, epsrel=1e-5, sqrt=False):
+def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None, epsabs=1e-5, epsrel=1e-5, sqrt=False,
+                       radii_before_last_axis=False):
     r"""
     :math:`\sigma_r^2 = \frac{1}{2\pi^2}\int dk\,k^2 P(k) W^2(kr)` (reference interpolator.py:200-292) for rows of P(k).
 
@@ -211,14 +213,21 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
     growth_sq : optional device tensor (..., nz), one row of factors per row of P(k): the result is then
         :math:`\sqrt{\sigma_r^2\,\mathrm{growth\_sq}(z)}` of shape (..., nr, nz), written once by the interpolation kernel.
     sqrt : return :math:`\sigma_r` instead (the root taken by the kernel that interpolates to ``r``, method 'fftlog').
+    radii_before_last_axis : rows (..., nz, nk): return (..., nr, nz) instead of (..., nz, nr) (method 'fftlog', large batches: the transposition
+        is part of the spline kernel's store; other cases: a transposed view).
     """
     device = dv.resolve_device(device)
+    if radii_before_last_axis and (method != 'fftlog' or growth_sq is not None):
+        out = integrate_sigma_r2(r, pk_rows, kmin=kmin, kmax=kmax, method=method, nk=nk, device=device, growth_sq=growth_sq, epsabs=epsabs, epsrel=epsrel, sqrt=sqrt)
+        return out.transpose(-1, -2) if growth_sq is None and out.ndim >= 2 else out
     rr = _host(r).ravel()
     nk_leggauss = 100 if nk is None else nk
     if nk is None:
         nk = 1024
     if rr.size == 0:
         rows = pk_rows(np.geomspace(kmin, kmax, 4))
+        if radii_before_last_axis and rows.ndim >= 2:
+            return rows.new_empty(tuple(rows.shape[:-2]) + (0, rows.shape[-2]))
         return rows.new_empty(tuple(rows.shape[:-1]) + (0,))
     if method == 'fftlog':
         k = np.geomspace(kmin, kmax, nk)
@@ -232,10 +241,14 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         # tmp = (2 pi^2) spline(var)(r); sigma^2 = tmp / (2 pi^2)  (interpolator.py:289-291)
         fused = _fftlog_then_spline(fft, op, rows, device, sqrt=sqrt) if growth_sq is None else None
         if fused is not None:
-            return fused
+            return fused.transpose(-1, -2) if radii_before_last_axis and fused.ndim >= 2 else fused
         var = fft(rows)[1]
         if growth_sq is not None:
             return op.outer(var, growth_sq, sqrt=True)
+        if radii_before_last_axis and var.ndim >= 2:      # (..., nz, nk) -> (..., nr, nz): sigma_rz's layout written by the spline kernel itself
+            if _TRANSPOSE_IN_STORE:
+                return op(var, sqrt=sqrt, last_axis_first=True)
+            return op(var, sqrt=sqrt).transpose(-1, -2)
         return op(var, sqrt=sqrt)
     if sqrt:
         return integrate_sigma_r2(r, pk_rows, kmin=kmin, kmax=kmax, method=method, nk=nk if method != 'leggauss' else nk_leggauss, device=device,
@@ -1116,8 +1129,9 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                                                                                  **kwargs), zh.ravel())
             out = base[..., :, None] * growth[..., None, :]
         else:
-            out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True, **kwargs)
-            out = out.transpose(-1, -2)   # (batch..., nz, nr) -> (batch..., nr, nz)
+            # (batch..., nz, nk) rows -> (batch..., nr, nz): the transposition is part of the store of the kernel that splines to r
+            out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True,
+                                     radii_before_last_axis=True, **kwargs)
         return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
 
     _two_stream_min_bytes = 1 << 20        # results smaller than this take the three separate calls (a few microseconds of kernels either way)

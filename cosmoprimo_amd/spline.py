@@ -45,19 +45,28 @@ class LinearOperator(object):
 
     _PATHS = {None: 0, 'valu': 16, 'mfma': 32}     # CP_SPLINE_PATH_*: force one kernel (measurements); default: the library's choice
 
-    def __call__(self, y, sqrt=False, scale=1., path=None):
+    def __call__(self, y, sqrt=False, scale=1., path=None, last_axis_first=False):
         """y : torch tensor (..., n) on the operator's device -> (..., nq).  Dense operators run as a float64 GEMM on the matrix cores,
-        banded ones (splines) on the vector ALUs; ``path`` = 'valu' / 'mfma' forces one of the two kernels."""
+        banded ones (splines) on the vector ALUs; ``path`` = 'valu' / 'mfma' forces one of the two kernels.
+        last_axis_first : y (..., m, n) -> (..., nq, m): the last-but-one axis of y becomes the fastest of the result (the transposition is
+        part of the kernel's store, ``cp_spline_apply_grouped``)."""
         torch = dv.torch()
         y = dv.to_device(y, self.device)
         if y.shape[-1] != self.n:
             raise ValueError('last dimension must be {:d}, got {}'.format(self.n, tuple(y.shape)))
         lead = tuple(y.shape[:-1])
         nrows = int(np.prod(lead, dtype=np.int64))
-        out = torch.empty(lead + (self.nq,), dtype=torch.float64, device=self.device)
+        group = 0
+        if last_axis_first:
+            if len(lead) < 1:
+                raise ValueError('last_axis_first needs y of at least two dimensions')
+            group, oshape = int(lead[-1]), lead[:-1] + (self.nq, lead[-1])
+        else:
+            oshape = lead + (self.nq,)
+        out = torch.empty(oshape, dtype=torch.float64, device=self.device)
         if nrows:
-            _lib.check(_lib.load().cp_spline_apply(self._handle, y.data_ptr(), out.data_ptr(), nrows, int(bool(sqrt)) | self._PATHS[path], float(scale),
-                                                   dv.stream_of(self.device)))
+            _lib.check(_lib.load().cp_spline_apply_grouped(self._handle, y.data_ptr(), out.data_ptr(), nrows, group, int(bool(sqrt)) | self._PATHS[path],
+                                                           float(scale), dv.stream_of(self.device)))
         return out
 
     _POSTS = {None: 0, 'sqrt': 1, 'exp10': 2}       # CP_SPLINE_POST_*

@@ -244,6 +244,10 @@ int cp_spline_plan_create(cp_spline_plan** plan, int n, const double* x, int nq,
  * window covers j (the whole row for dense plans).  Callers that rely on containment inside a row (none in this package: rows holding a
  * non-finite sample are NaN throughout in the reference too, jax.py:120-131) force CP_SPLINE_PATH_VALU. */
 int cp_spline_apply(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nrows, int post_op, double scale, void* stream);
+/* the same with the rows taken in groups of `group` (nrows a multiple of it) and the result stored as (nrows / group, nq, group): the rows of a
+ * group -- the redshifts of one table in sigma_rz -- become the fastest axis, i.e. the (nz, nr) -> (nr, nz) transposition (interpolator.py:875)
+ * is part of the store instead of a pass of its own.  group = 0: cp_spline_apply. */
+int cp_spline_apply_grouped(const cp_spline_plan* plan, const double* d_y, double* d_out, long long nrows, int group, int post_op, double scale, void* stream);
 /* the same followed by an outer product with per-row factors, written once: d_out (nrows, nq, nz) = f(scale x spline(d_y)[row, q] x d_g[row, z]),
  * f = sqrt for CP_SPLINE_POST_SQRT, evaluated as sqrt(scale x spline) x sqrt(g): both factors are variances / squared growth factors (a negative one
  * gives NaN).  sigma_rz of separable P(k, z) = P(k) x growth^2(z): PowerSpectrumInterpolator2D.sigma_rz, interpolator.py:846-875 */

@@ -142,3 +142,18 @@ def test_bao_elementwise_passes():
     ref[:, first:first + m] = (10.**res).T
     assert float((out / ref - 1.).abs().max()) < 1e-15
     assert lib.cp_brieden_finish(pkrows.data_ptr(), res.data_ptr(), out.data_ptr(), nb, nk, nk - 10, m, 0, st) != 0      # the range must fit the row
+
+
+@pytest.mark.parametrize('path', ['valu', 'mfma'])
+def test_spline_apply_grouped(path):
+    """cp_spline_apply_grouped: rows taken in groups, the group index the fastest axis of the result (sigma_rz's (nz, nr) -> (nr, nz) inside the store)."""
+    torch, _lib, lib, dv, dev = _env()
+    from cosmoprimo_amd.spline import LinearOperator
+    rng = np.random.default_rng(2)
+    op = LinearOperator.spline(np.linspace(0., 1., 300), np.sort(rng.uniform(0., 1., 77)), bc='natural', device=dev)
+    y = torch.as_tensor(rng.normal(size=(5, 12, 300)), device=dev)
+    plain = op(y, path=path)                                   # (5, 12, 77)
+    grouped = op(y, path=path, last_axis_first=True)           # (5, 77, 12)
+    assert tuple(grouped.shape) == (5, 77, 12) and torch.equal(grouped, plain.transpose(-1, -2).contiguous())
+    out = torch.empty((60 * 77,), dtype=torch.float64, device=dev)
+    assert lib.cp_spline_apply_grouped(op._handle, y.data_ptr(), out.data_ptr(), 60, 7, 0, 1., dv.stream_of(dev)) != 0      # 60 rows are not groups of 7
