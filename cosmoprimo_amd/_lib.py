@@ -123,7 +123,7 @@ BG_PARAMS = ('h', 'Omega_cdm', 'Omega_b', 'Omega_k', 'T_cmb', 'N_ur', 'w0_fld', 
 SPLINE_BC = {'natural': 0, 'clamped': 1, 'not-a-knot': 2}
 PK_PARAMS = ('A_s', 'n_s', 'alpha_s', 'beta_s', 'k_pivot')
 ENGINES = {'eisenstein_hu': 0, 'eisenstein_hu_nowiggle': 1, 'bbks': 2}
-PK_WHAT = {'matter': 0, 'transfer': 1, 'primordial': 2}
+PK_WHAT = {'matter': 0, 'transfer': 1, 'primordial': 2, 'log_k_matter': 3}
 EH_SCALARS = ('rs_drag', 'z_drag', 'z_eq', 'k_eq', 'r_drag', 'r_eq', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b', 'alpha_gamma',
               'gamma')
 BG_KINDS = {'comoving_radial_distance': 0, 'comoving_transverse_distance': 1, 'angular_diameter_distance': 2, 'luminosity_distance': 3,

@@ -14,6 +14,7 @@ import numpy as np
 
 from . import _lib
 from . import _device as dv
+from . import power as pwmod
 from .cosmology import Cosmology, Fourier
 from .dst import DST
 from .interpolator import _quadratic_interp_operator  # noqa: F401
@@ -229,14 +230,32 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
                                               dv.stream_of(self.device)))
         return box
 
+    def _log_k_rows(self, klin):
+        """log(k_lin P(k_lin)) rows (ncol, 4096) of a batch of cosmologies of an analytic engine, written by the evaluation kernel term by term
+        (``cp_power_eval``, CP_PK_LOG_K_MATTER) -- the transform then reads its input as it is, without 4096 logarithms per vector.  None for any
+        other input (tabulated spectra, several redshifts, rescaled amplitudes): the transform takes the logarithm itself."""
+        interp = self.pk_interpolator
+        call = getattr(interp, '_interp', None) if getattr(interp, 'is_from_callable', False) else None
+        rs = getattr(interp, '_rsigma8sq', None)
+        if not isinstance(interp, PowerSpectrumInterpolator2D) or not hasattr(call, 'analytic_engine') or np.size(interp.z) != 1 or not (
+                isinstance(rs, float) and rs == 1.):
+            return None
+        engine, bg, pk = call.analytic_engine()
+        rows = pwmod.analytic(engine, 'log_k_matter', klin, bg=bg, pk=pk, device=self.device)
+        return rows if rows.ndim == 2 and rows.shape[0] == self._pk_rows.shape[0] else None
+
     def _compute(self):
         torch = dv.torch()
         ops = self._operators()
         lib = _lib.load()
-        rows, _ = self._rows(ops['klin'])                                 # P(k_lin), (ncol, 4096)
         # dst(log(k P)), type 2, ortho, written as [even-indexed | odd-indexed] coefficients: seen as (2 ncol, 2048) the two sequences of
         # every vector are consecutive rows, and share the operators (x_even = x_odd = 1 + arange(2048), bao_filter.py:374-375)
-        ffted = ops['dst'](rows, fused=True, split=True)
+        logkp = self._log_k_rows(ops['klin'])
+        if logkp is not None:                                             # analytic engine: log(k_lin P) straight from the evaluation kernel
+            ffted = ops['dst'](logkp, split=True)
+        else:
+            rows, _ = self._rows(ops['klin'])                             # P(k_lin), (ncol, 4096)
+            ffted = ops['dst'](rows, fused=True, split=True)
         y = ffted.view(2 * ffted.shape[0], ffted.shape[1] // 2)
         dd = ops['dd'](y)
         box = self._box(dd)

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
     const long long nzs = with_z ? A.nz : 1;
     const double kfac = A.kscale ? A.kscale[ic] : 1.;
     const PkPerCosmology pc = pk_per_cosmology(c, pw);
+    const double ln_pk_unit = A.what == CP_PK_LOG_K_MATTER ? log(pc.pk_unit) : 0.;
     for (long long z0 = 0; z0 < nzs; z0 += 256) {
         if (z0) __syncthreads();  // the previous block of redshifts has been written
         if (with_z && z0 + tid < A.nz) {
@@ -91,6 +92,13 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
             }
             if (A.what == CP_PK_TRANSFER) {
                 out[0] = T;
+                continue;
+            }
+            if (A.what == CP_PK_LOG_K_MATTER) {
+                // log(k P(k)) term by term: log k + log(T^2) + log(k x constant) + the exponent of the tilt -- the logarithm of the transfer
+                // function replaces the exponential of the tilt, and the consumer (the DST of wallish2018, bao_filter.py:371) takes no
+                // logarithm of 4096 samples per vector
+                out[0] = 2. * (ln_kh + log_pos(fabs(T))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
                 continue;
             }
             const double tilt = primordial_tilt(pc, ln_kh);
@@ -302,7 +310,8 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
                              long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, void* d_work,
                              int device, void* stream) {
     if (engine < CP_ENGINE_EH || engine > CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_power_eval: unknown engine %d", engine);
-    if (what < CP_PK_MATTER || what > CP_PK_PRIMORDIAL) return cp::fail(CP_EINVAL, "cp_power_eval: unknown quantity %d", what);
+    if (what < CP_PK_MATTER || what > CP_PK_LOG_K_MATTER) return cp::fail(CP_EINVAL, "cp_power_eval: unknown quantity %d", what);
+    if (what == CP_PK_LOG_K_MATTER && nz > 0) return cp::fail(CP_EINVAL, "cp_power_eval: log(k P) is without growth factor (nz = 0)");
     if (ncosmo < 0 || nk < 0 || nz < 0) return cp::fail(CP_EINVAL, "cp_power_eval: negative size");
     if (ncosmo == 0 || nk == 0) return CP_OK;
     if (!bg_params || !pk_params || !d_k || !d_out || (nz > 0 && !d_z)) return cp::fail(CP_EINVAL, "cp_power_eval: null pointer");

@@ -155,9 +155,10 @@ __device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const
     return p;
 }
 
-__device__ __forceinline__ double primordial_tilt(const PkPerCosmology& p, double ln_kh) {
+__device__ __forceinline__ double primordial_tilt_exponent(const PkPerCosmology& p, double ln_kh) {
     const double lnkkp = ln_kh - p.ln_kp;
-    return exp_mid((p.n_s - 1. + 1. / 2. * p.alpha_s * lnkkp + 1. / 6. * p.beta_s * (lnkkp * lnkkp)) * lnkkp);
+    return (p.n_s - 1. + 1. / 2. * p.alpha_s * lnkkp + 1. / 6. * p.beta_s * (lnkkp * lnkkp)) * lnkkp;
 }
+__device__ __forceinline__ double primordial_tilt(const PkPerCosmology& p, double ln_kh) { return exp_mid(primordial_tilt_exponent(p, ln_kh)); }
 
 }  // namespace cppower

@@ -18,7 +18,7 @@ def A_s_fid(sigma8):
 
 def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=None, kscale=None):
     """
-    ``what`` in ('matter', 'transfer', 'primordial') for engine in ('eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks').
+    ``what`` in ('matter', 'transfer', 'primordial', 'log_k_matter' = log(k P), z=None) for engine in ('eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks').
 
     k : (nk,) wavenumbers [h/Mpc] (numpy or torch), shared by the batch; z : (nz,) redshifts or None (no growth factor).
     bg : background parameters (see :func:`cosmoprimo_amd.background.distance`), pk : ``A_s, n_s, alpha_s, beta_s, k_pivot``;
@@ -41,6 +41,8 @@ def analytic(engine, what, k, z=None, bg=None, pk=None, Omega_m=None, device=Non
     ncosmo = n1 or n2 or 1
     tk = dv.to_device(k, device).reshape(-1)
     nk = tk.numel()
+    if what == 'log_k_matter' and z is not None:
+        raise ValueError("'log_k_matter' is the spectrum without growth factor: z must be None")
     with_z = z is not None and what == 'matter'
     tz = dv.to_device(z, device).reshape(-1) if with_z else None
     nz = tz.numel() if with_z else 0

@@ -193,7 +193,9 @@ enum cp_engine { CP_ENGINE_EH = 0, CP_ENGINE_EH_NOWIGGLE = 1, CP_ENGINE_BBKS = 2
 enum cp_pk_what {
     CP_PK_MATTER = 0,    /* P(k, z) = T^2 x potential_to_density x curvature_to_potential x P_R x growth(z)^2 ; nz = 0: without growth */
     CP_PK_TRANSFER = 1,  /* transfer_k */
-    CP_PK_PRIMORDIAL = 2 /* Primordial.pk_k */
+    CP_PK_PRIMORDIAL = 2, /* Primordial.pk_k */
+    CP_PK_LOG_K_MATTER = 3 /* log(k P(k)), nz = 0: the input of the sine transform of wallish2018 (bao_filter.py:371), formed term by term
+                            * instead of as the logarithm of the evaluated spectrum */
 };
 enum cp_pk_param { CP_PK_A_S = 0, CP_PK_N_S = 1, CP_PK_ALPHA_S = 2, CP_PK_BETA_S = 3, CP_PK_K_PIVOT = 4 /* 1/Mpc */, CP_PK_NPARAMS = 5 };
 /* bg_params: the CP_BG_NPARAMS background parameters (cp_bg_param); pk_params: CP_PK_NPARAMS primordial parameters.

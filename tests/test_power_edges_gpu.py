@@ -23,3 +23,20 @@ def test_transfer_edges():
             ref = opw.transfer_eh(k, cosmo['h'], opw.eh_scalars(cosmo['h'], cosmo['Omega_cdm'], cosmo['Omega_b'], cosmo['T_cmb'])).ravel()
     assert got[0] == 1. and np.isnan(got[1]) and np.isnan(got[2])
     np.testing.assert_allclose(got[3:], ref[3:], rtol=2e-11)
+
+
+@pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
+def test_log_k_matter(engine):
+    """CP_PK_LOG_K_MATTER = log(k P(k)) formed term by term in the evaluation kernel: equal to the logarithm of the evaluated spectrum to
+    rounding (the input of the sine transform of wallish2018, where both forms are used: tabulated spectra take the logarithm in the transform)."""
+    from cosmoprimo_amd import power as pw
+    rng = np.random.default_rng(3)
+    nb = 7
+    bg = dict(h=rng.uniform(0.6, 0.8, nb), Omega_cdm=rng.uniform(0.2, 0.35, nb), Omega_b=rng.uniform(0.03, 0.06, nb))
+    pk = dict(A_s=rng.uniform(1e-9, 3e-9, nb), n_s=rng.uniform(0.9, 1., nb), alpha_s=rng.uniform(-0.01, 0.01, nb), beta_s=rng.uniform(-0.01, 0.01, nb))
+    k = np.linspace(7e-5, 7., 4096)
+    p = pw.analytic(engine, 'matter', k, bg=bg, pk=pk).cpu().numpy()
+    got = pw.analytic(engine, 'log_k_matter', k, bg=bg, pk=pk).cpu().numpy()
+    np.testing.assert_allclose(got, np.log(k * p), rtol=0, atol=2e-14)
+    with pytest.raises(Exception):
+        pw.analytic(engine, 'log_k_matter', k, z=np.array([0., 1.]), bg=bg, pk=pk)
