@@ -17,7 +17,7 @@ from . import _device as dv
 from . import power as pwmod
 from .cosmology import Cosmology, Fourier
 from .dst import DST
-from .interpolator import _quadratic_interp_operator  # noqa: F401
+from .interpolator import _quadratic_interp_operator, _simpson_weights, _bspline_basis  # noqa: F401
 from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, CorrelationFunctionInterpolator1D,
                            CorrelationFunctionInterpolator2D)
 from .spline import LinearOperator, dense_operator
@@ -653,6 +653,89 @@ class PeakAveragePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumB
         pknow = self._eh_nowiggle(self.k)
         op = LinearOperator.dense(self._operator(self._scalar_rs_drag_ratio()), device=self.device)
         self._pknow_rows = op(self._pk_rows / pknow) * pknow
+
+
+class BSplinePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumBAOFilter):
+
+    """
+    Ratio to the Eisenstein & Hu no-wiggle spectrum emulated by B-splines in log10 k, mixed so that the result keeps the sigma8 (, sigma_d)
+    of the input (reference bao_filter.py:583-688; https://arxiv.org/pdf/1509.02120.pdf App. A).
+
+    Each B-spline fit, pinned at its four end samples, is a fixed linear map of the ratio (one dense operator per fit, built on the host);
+    the constraints are linear functionals of P (Simpson weights), so the mixing is a 1 x 1 ... 3 x 3 system per column, solved on the device
+    in closed form.  The system is read as the reference wrote it for numpy < 2 -- one right-hand-side VECTOR per column: under numpy 2 its
+    ``numpy.linalg.solve(system, target)`` (:685) raises for any constraint or several columns.
+    """
+    name = 'bspline'
+    _functionals = ('sigma8', 'sigmad')
+
+    def __init__(self, pk_interpolator, constraint=('sigma8',), cosmo=None, **kwargs):
+        if not isinstance(constraint, (tuple, list)):
+            constraint = [constraint]
+        self.constraint = list(constraint)
+        for name in self.constraint:
+            if name not in self._functionals:
+                raise ValueError('unknown constraint {}; choices are {}'.format(name, list(self._functionals)))
+        if len(self.constraint) > 2:
+            raise ValueError('at most two constraints (three B-spline models), got {}'.format(self.constraint))
+        super(BSplinePowerSpectrumBAOFilter, self).__init__(pk_interpolator, cosmo=cosmo, **kwargs)
+
+    def _prepare(self):
+        kmin, kmax = 5e-3, 1.
+        self.kmask_fid = (self.k >= kmin) & (self.k <= kmax)
+        logk = np.log10(self.k[self.kmask_fid])
+        weights = 1 + 1e6 * np.tanh(0.005 * (logk + 1.1)**16)
+        weights /= np.sum(weights)
+        ends = _end_constraints(logk.size, order=2)
+        self._fits = []
+        for nknots, degree in [(14, 5), (14, 6), (15, 7)][:1 + len(self.constraint)]:
+            inner = nknots - 2 * degree
+            ts = np.concatenate([np.zeros(degree + 1), np.arange(1, inner) / inner, np.ones(degree + 1)])
+            gradient = _bspline_basis(np.log10((kmax - kmin) * ts + kmin), degree, logk).T       # (ncoef, nk): scipy BSpline(ts, e_i, degree)(logk)
+            A = _constrained_lsq_operator(gradient, weights, gradient.dot(ends.T), ends, inverse=True)
+            self._fits.append(LinearOperator.dense(A, device=self.device))
+        # sigma8^2 and sigma_d^2 as weights on the samples of P (:665-672): the reference's Simpson rule on k, top-hat of radius 8
+        kr = 8. * self.k
+        simpson = _simpson_weights(self.k)
+        weights = {'sigma8': 1. / (2. * np.pi**2) * simpson * self.k**2 * (3. * (np.sin(kr) - kr * np.cos(kr)) / kr**3)**2,
+                   'sigmad': 1. / (6. * np.pi**2) * simpson}
+        self._constraint_weights = np.array([weights[name] for name in self.constraint]).reshape(len(self.constraint), self.k.size)
+
+    def _compute(self):
+        torch = dv.torch()
+        pk = self._pk_rows
+        mask = dv.upload(self.kmask_fid, self.device)
+        pknow = self._eh_nowiggle(self.k[self.kmask_fid])
+        ratio = (pk[:, mask] / pknow).contiguous()
+        models = []
+        for fit in self._fits:
+            model = pk.clone()
+            model[:, mask] = fit(ratio) * pknow
+            models.append(model)
+        if len(models) == 1:
+            self._pknow_rows = models[0]
+            return
+        w = dv.upload(self._constraint_weights, self.device)                       # (nc, nk)
+        rows = [[torch.ones_like(pk[:, 0])] * len(models)] + [[m @ wc for m in models] for wc in w]       # system[i][j]: (ncol,)
+        rhs = [torch.ones_like(pk[:, 0])] + [pk @ wc for wc in w]
+        coeffs = _solve_small(rows, rhs)
+        self._pknow_rows = sum(c[:, None] * m for c, m in zip(coeffs, models))
+
+
+def _solve_small(a, b):
+    """Solutions x_j (tensors over the batch) of the n x n systems sum_j a[i][j] x_j = b[i], n <= 3, by Cramer's rule on batch tensors."""
+    n = len(b)
+
+    def det(m):
+        if len(m) == 1:
+            return m[0][0]
+        if len(m) == 2:
+            return m[0][0] * m[1][1] - m[0][1] * m[1][0]
+        return (m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0])
+                + m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]))
+
+    d = det(a)
+    return [det([[b[i] if jj == j else a[i][jj] for jj in range(n)] for i in range(n)]) / d for j in range(n)]
 
 
 class RegisteredCorrelationFunctionBAOFilter(type):

@@ -251,3 +251,61 @@ def peakaverage(k, pk, pknow_eh, prep, rs_ratio=1.):
         logxx = np.log10(kp / rescale)
         out = out + spline1d(logxx, first(logxx))(logx)
     return out / 2. * pknow_eh[:, None]
+
+
+def _simpson_avg(y, x):
+    """The reference's simpson (jax.py:365-507, scipy v1.0.0 rule, even='avg') along the last axis, for an even or odd number of samples."""
+    def basic(y, start, stop, x):
+        s0, s1, s2 = slice(start, stop, 2), slice(start + 1, stop + 1, 2), slice(start + 2, stop + 2, 2)
+        h = np.diff(x)
+        h0, h1 = h[s0], h[s1]
+        hsum, hprod, h0divh1 = h0 + h1, h0 * h1, h0 / h1
+        return np.sum(hsum / 6. * (y[..., s0] * (2. - 1. / h0divh1) + y[..., s1] * (hsum * hsum / hprod) + y[..., s2] * (2. - h0divh1)), axis=-1)
+    n = y.shape[-1]
+    if n % 2 == 1:
+        return basic(y, 0, n - 2, x)
+    val = 0.5 * (x[-1] - x[-2]) * (y[..., -1] + y[..., -2]) + basic(y, 0, n - 3, x)
+    val = val + 0.5 * (x[1] - x[0]) * (y[..., 1] + y[..., 0]) + basic(y, 1, n - 2, x)
+    return val / 2.
+
+
+def bspline(k, pk, pknow_eh, constraint=('sigma8',)):
+    """BSpline (bao_filter.py:622-688): the ratio to the EH no-wiggle P(k, z=0) on 5e-3 <= k <= 1 fitted by B-splines in log10 k of degrees 5, 6
+    (, 7) on 14, 14 (, 15) knots, each pinned at its four end samples; the models are then mixed with coefficients that sum to one and
+    reproduce sigma8 (, sigma_d) of the input.  The mixing system is solved per column with right-hand sides taken as VECTORS, the meaning
+    of ``numpy.linalg.solve(a, b)`` for b.ndim == a.ndim - 1 before numpy 2 -- under numpy 2 the reference's call (:685) raises for any
+    constraint, see tests/golden/bspline.npz and oracle/gen_golden.py: gen_bspline."""
+    pk = pk.reshape(k.size, -1)
+    kmin, kmax = 5e-3, 1.
+    mask = (k >= kmin) & (k <= kmax)
+    logk = np.log10(k[mask])
+    weights = 1 + 1e6 * np.tanh(0.005 * (logk + 1.1)**16)
+    weights /= np.sum(weights)
+    ratio = pk[mask].T / pknow_eh[mask]
+    ends = np.column_stack([ratio[..., 0], ratio[..., 1] - ratio[..., 0], ratio[..., -1], ratio[..., -2] - ratio[..., -1]])
+    models = []
+    for nknots, degree in [(14, 5), (14, 6), (15, 7)][:1 + len(constraint)]:
+        ts = np.concatenate([np.zeros(degree + 1), np.arange(1, nknots - 2 * degree) / (nknots - 2 * degree), np.ones(degree + 1)])
+        ts = np.log10((kmax - kmin) * ts + kmin)
+        gradient = np.array([interpolate.BSpline(ts, np.eye(len(ts) - degree - 1)[i], degree)(logk) for i in range(nknots - degree)])
+        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+        params = np.concatenate([ratio, ends], axis=-1).dot(least_squares_projector(gradient, weights, cg))[..., :gradient.shape[0]]
+        model = pk.T.copy()
+        model[..., mask] = params.dot(gradient) * pknow_eh[mask]
+        models.append(model)
+    models = np.array(models)                    # (nmodels, ncol, nk)
+
+    def tophat(x):
+        return 3 * (np.sin(x) - x * np.cos(x)) / x**3
+
+    functionals = {'sigma8': lambda p: 1 / (2. * np.pi**2) * _simpson_avg(k**2 * tophat(8. * k)**2 * p, k),
+                   'sigmad': lambda p: 1 / (6. * np.pi**2) * _simpson_avg(p, k)}
+    out = np.empty_like(pk)
+    for ic in range(pk.shape[1]):
+        system, target = [np.ones(len(models))], [1.]
+        for name in constraint:
+            system.append(np.array([functionals[name](m[ic]) for m in models]))
+            target.append(functionals[name](pk[:, ic]))
+        coeffs = np.linalg.solve(np.array(system), np.array(target))
+        out[:, ic] = np.sum(coeffs[:, None] * models[:, ic], axis=0)
+    return out

@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, densities, ncdm, variants,
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants,
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -457,6 +457,48 @@ def gen_bao2(cp):
     save('bao2', **out)
 
 
+def gen_bspline(cp):
+    """The `bspline` P(k) filter (bao_filter.py:583-688).  Without constraint the reference runs as it is.  With constraints its mixing
+    system ends in ``numpy.linalg.solve(system, target)`` with ``target`` one dimension short of ``system`` (:685): a stack of vectors for the
+    numpy < 2 it was written for, a shape error under the numpy 2 of this image.  Those cases are generated with
+    ``numpy.linalg.solve`` given back its numpy-1 reading of such a right-hand side for the duration of the call -- the reference's code is run
+    unchanged -- and are stored under names ending in ``_np1``."""
+    import warnings
+    out = {}
+    solve = np.linalg.solve
+
+    def solve_np1(a, b):
+        return solve(a, b[..., None])[..., 0] if np.ndim(b) == np.ndim(a) - 1 else solve(a, b)
+
+    def run(interp, constraint, np1=None, **kw):
+        np.linalg.solve = solve_np1 if (bool(constraint) if np1 is None else np1) else solve
+        try:
+            f = cp.PowerSpectrumBAOFilter(interp, engine='bspline', constraint=constraint, **kw)
+            return f, np.asarray(f.pknow)
+        finally:
+            np.linalg.solve = solve
+
+    cases = {'none': (), 'sigma8_np1': ('sigma8',), 'sigma8_sigmad_np1': ('sigma8', 'sigmad')}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for i, par in enumerate(BAO_PARAMS):
+            cosmo = cp.Cosmology(engine='eisenstein_hu', **par)
+            interp = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+            for name, constraint in cases.items():
+                f, out['c%d_%s' % (i, name)] = run(interp, constraint, cosmo=cosmo)
+            out['c%d_pk' % i] = np.asarray(f.pk)
+            out['c%d_pknow_eh' % i] = cp.Fourier(cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(f.k, z=0.)
+        out['k'] = np.asarray(f.k)
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **BAO_PARAMS[2])
+        interp2 = cosmo.get_fourier().pk_interpolator()
+        kt, zt = np.logspace(-5, 1.5, 400), np.array([0., 0.5, 1., 2.])
+        tab = cp.PowerSpectrumInterpolator2D(kt, zt, interp2(kt, zt))
+        out['tab_k'], out['tab_z'], out['tab_pk'] = kt, zt, interp2(kt, zt)
+        for name, constraint in cases.items():      # several columns: the same shape error even without constraint
+            out['tab_%s' % (name if name.endswith('_np1') else name + '_np1')] = run(tab, constraint, np1=True, cosmo=cosmo)[1]
+    save('bspline', **out)
+
+
 DENSITY_NAMES = ['rho_g', 'rho_b', 'rho_ur', 'rho_cdm', 'rho_k', 'rho_de', 'rho_Lambda', 'rho_fld', 'rho_r', 'rho_m', 'rho_tot', 'rho_crit',
                  'Omega_g', 'Omega_b', 'Omega_ur', 'Omega_cdm', 'Omega_k', 'Omega_de', 'Omega_Lambda', 'Omega_fld', 'Omega_r', 'Omega_m', 'T_cmb',
                  'rho_ncdm_tot', 'p_ncdm_tot']
@@ -680,6 +722,8 @@ def main():
         gen_xi(cp)
     if 'bao2' in which:
         gen_bao2(cp)
+    if 'bspline' in which:
+        gen_bspline(cp)
     if 'densities' in which:
         gen_densities(cp)
     if 'ncdm' in which:

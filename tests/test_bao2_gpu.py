@@ -60,4 +60,43 @@ def test_filters_table(cp, golden):
     with pytest.raises(ValueError):
         cp.PowerSpectrumBAOFilter(tab, engine='peakaverage', cosmo=cosmo)      # cosmo_fid is mandatory
     with pytest.raises(ValueError):
-        cp.PowerSpectrumBAOFilter(tab, engine='bspline')
+        cp.PowerSpectrumBAOFilter(tab, engine='no_such_filter')
+
+
+BSPLINE_CASES = {'none': (), 'sigma8_np1': ('sigma8',), 'sigma8_sigmad_np1': ('sigma8', 'sigmad')}
+
+
+@pytest.mark.parametrize('ic', range(4))
+def test_bspline_1d(cp, golden, ic):
+    """`bspline` (reference bao_filter.py:583-688) against the reference's own outputs: as it runs here without constraint, and with the
+    numpy < 2 meaning of its final ``linalg.solve`` for the constrained cases (oracle/gen_golden.py: gen_bspline)."""
+    g = golden('bspline')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **BAO_PARAMS[ic])
+        interp = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+        for name, constraint in BSPLINE_CASES.items():
+            f = cp.PowerSpectrumBAOFilter(interp, engine='bspline', cosmo=cosmo, constraint=constraint)
+            np.testing.assert_allclose(f.k, g['k'], rtol=1e-14)
+            np.testing.assert_allclose(f.pknow, g['c%d_%s' % (ic, name)], rtol=1e-8, err_msg=name)
+            assert f.pknow.shape == (1024,)
+        f = cp.PowerSpectrumBAOFilter(interp, engine='bspline', cosmo=cosmo)       # default: sigma8 is kept
+        np.testing.assert_allclose(f.pknow, g['c%d_sigma8_np1' % ic], rtol=1e-8)
+    with pytest.raises(ValueError):
+        cp.PowerSpectrumBAOFilter(interp, engine='bspline', cosmo=cosmo, constraint=('sigma12',))
+
+
+def test_bspline_table(cp, golden):
+    g = golden('bspline')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **BAO_PARAMS[2])
+        tab = cp.PowerSpectrumInterpolator2D(g['tab_k'], g['tab_z'], g['tab_pk'])
+        for name, constraint in BSPLINE_CASES.items():
+            f = cp.PowerSpectrumBAOFilter(tab, engine='bspline', cosmo=cosmo, constraint=constraint)
+            ref = g['tab_' + (name if name.endswith('_np1') else name + '_np1')]
+            assert f.pknow.shape == ref.shape == (1024, 4)
+            np.testing.assert_allclose(f.pknow, ref, rtol=1e-8, err_msg=name)
+            # same input through the oracle's per-column arithmetic
+            pknow_eh = np.asarray(cp.Fourier(cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(f.k, z=0.))
+            np.testing.assert_allclose(f.pknow, obao.bspline(f.k, f.pk, pknow_eh, constraint=constraint), rtol=1e-8, err_msg=name)

@@ -60,3 +60,24 @@ def test_filters_table(golden):
     np.testing.assert_allclose(obao.savgol(k, pk), g['tab_savgol_pknow'], rtol=RTOL)
     np.testing.assert_allclose(obao.ehsavgol(k, pk, g['c2_pknow_eh']), g['tab_ehsavgol_pknow'], rtol=RTOL)
     np.testing.assert_allclose(obao.ehpoly(k, pk, g['c2_pknow_eh'], rs_ratio=float(g['c2_rs_ratio'])), g['tab_ehpoly_pknow'], rtol=RTOL)
+
+
+BSPLINE_CASES = {'none': (), 'sigma8_np1': ('sigma8',), 'sigma8_sigmad_np1': ('sigma8', 'sigmad')}
+
+
+@pytest.mark.parametrize('ic', range(4))
+def test_bspline_1d(golden, ic):
+    """oracle/bao.py: bspline against the reference's outputs (tests/golden/bspline.npz; the `_np1` cases are the reference run with the
+    numpy < 2 meaning of its last ``linalg.solve``, see oracle/gen_golden.py: gen_bspline)."""
+    g = golden('bspline')
+    for name, constraint in BSPLINE_CASES.items():
+        got = obao.bspline(g['k'], g['c%d_pk' % ic], g['c%d_pknow_eh' % ic], constraint=constraint)[:, 0]
+        np.testing.assert_allclose(got, g['c%d_%s' % (ic, name)], rtol=1e-12, err_msg=name)
+
+
+def test_bspline_table(golden):
+    g = golden('bspline')
+    pk = oi.pk_interp_2d(g['tab_k'], g['tab_z'], g['tab_pk'])(g['k'], g['tab_z'])
+    for name, constraint in BSPLINE_CASES.items():
+        ref = g['tab_' + (name if name.endswith('_np1') else name + '_np1')]
+        np.testing.assert_allclose(obao.bspline(g['k'], pk, g['c2_pknow_eh'], constraint=constraint), ref, rtol=1e-11, err_msg=name)
