@@ -82,10 +82,10 @@ typedef struct cp_fftlog_plan cp_fftlog_plan;
  *   pre, post : (nker, npad) float64  padded_prefactor / padded_postfactor (real part)
  *   u_re_im   : (nker, npad/2 + 1) complex128 padded_u, interleaved
  * npad must be the power of two 2**((n*minfolds-1).bit_length()); pad splits follow fftlog.py:152-153.
- * npad <= 8192 (every size the reference's own callers and BASELINE.json's configs use) runs the fused hand-written kernel.  Larger sizes, up to
- * 2^24, are a LIBRARY FALLBACK outside the BASELINE configs: the same arithmetic as three elementwise kernels around hipFFT D2Z / Z2D batches
- * (csrc/cp_fftlog_large.hip, hipFFT loaded on first use); it exists for completeness of FFTlog's size range, is not a native kernel, and no
- * performance figure of this package refers to it. */
+ * npad <= 8192 (every size the reference's own callers and BASELINE.json's configs use) runs the fused kernel.  Larger sizes, up to 2^24, run the
+ * same arithmetic split the four-step way (csrc/cp_fftlog_large.hip: column transforms of npad / 4096 points around a 4096-point row kernel that
+ * holds both transforms and the product with u, through a plan-owned scratch of at most 128 MB): hand-written kernels as well, outside the
+ * BASELINE configs, and no headline figure of this package refers to them. */
 int cp_fftlog_plan_create(cp_fftlog_plan** plan, int n, int npad, int nker, const double* pre, const double* post,
                           const double* u_re_im, int device);
 /* d_in : device (nbatch, nker, n) float64 C-contiguous;  d_out : device (nbatch, nker, n or npad).
