@@ -231,6 +231,9 @@ struct DenseArgs {
 // delivers -- 44-46 TFLOP/s = 58 % of the matrix peak, the ratio of the two.  A 64 x 64 tile fetches 16 KB for 64 MFMAs: 16 B per cycle and wave.
 // Two waves per SIMD (launch bound: 256 registers) alternate between fetching a chunk and multiplying one.
 constexpr int LINOP_MT = 4;   // 16-row tiles per wave
+#ifndef CP_LINOP_ABLATE
+#define CP_LINOP_ABLATE 0
+#endif
 
 __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (in a scalar register: what follows from it is wave-uniform for the compiler too)
@@ -262,11 +265,19 @@ __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
 #pragma unroll 1
         for (int kb = klo; kb < khi; kb += 16) {
             const int k = kb + 4 * g;
+#if CP_LINOP_ABLATE
+            static_assert(true, "diagnostic build (tools/linop_microbench.hip): bit 0 keeps the operator, bit 1 the rows, of the first chunk for all chunks");
+#endif
             double a[MT][4];
             cp_v4d b[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const cp_v4d*>(wr[j] + k);
-            if (kb + 16 <= A.n) {
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const cp_v4d*>(wr[j] + ((CP_LINOP_ABLATE & 1) ? klo + 4 * g : k));
+            if (CP_LINOP_ABLATE & 2) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) a[i][m] = yr[i][klo + 4 * g + m];
+            } else if (kb + 16 <= A.n) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
