@@ -17,8 +17,8 @@
 
 extern "C" int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline);
 int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, const double* d_k,
-                      const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz, double* d_out, void* d_coef,
-                      int device, void* stream);
+                      const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz, double* d_out, double* d_pk_out,
+                      void* d_coef, int device, void* stream);
 
 namespace {
 
@@ -65,7 +65,7 @@ extern "C" long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk) {
 
 extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
                                     const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
-                                    double* d_out, void* d_work, int nblocks, int device, void* stream) {
+                                    double* d_out, double* d_pk_out, void* d_work, int nblocks, int device, void* stream) {
     if (ncosmo < 0 || nk <= 0 || nz <= 0) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic: bad sizes");
     if (ncosmo == 0) return CP_OK;
     if (!bg_params || !pk_params || !d_k || !fftlog || !spline || !d_growth_sq || !d_out || !d_work)
@@ -78,7 +78,7 @@ extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param
         if (cp_sigma_rz_fused_available(fftlog, spline)) {
             char* coef = static_cast<char*>(d_work);
             coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-            return cp_sigma_rz_fused(engine, ncosmo, bg_params, second_is_omega_m, pk_params, d_k, fftlog, spline, d_growth_sq, nz, d_out, coef, device, stream);
+            return cp_sigma_rz_fused(engine, ncosmo, bg_params, second_is_omega_m, pk_params, d_k, fftlog, spline, d_growth_sq, nz, d_out, d_pk_out, coef, device, stream);
         }
         nblocks = 1;
     }
@@ -87,7 +87,7 @@ extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param
     hipStream_t main = static_cast<hipStream_t>(stream);
     SideStream* side = nblocks > 1 ? side_stream(device) : nullptr;
     if (nblocks > 1 && !side) return cp::fail(CP_EDEVICE, "cp_sigma_rz_analytic: cannot create the second stream on device %d", device);
-    double* rows = static_cast<double*>(d_work);
+    double* rows = d_pk_out ? d_pk_out : static_cast<double*>(d_work);      // the spectra are kept where the caller wants them
     double* var = rows + ncosmo * (long long)nk;
     char* coef = reinterpret_cast<char*>(var + ncosmo * (long long)nk);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;

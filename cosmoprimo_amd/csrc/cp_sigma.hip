@@ -53,6 +53,7 @@ struct SigmaArgs {
     int bw, nq, nz;
     const double* growth_sq;      // (ncosmo, nz)
     double* out;                  // (ncosmo, nq, nz)
+    double* pk_out;               // (ncosmo, n) the spectra themselves, or null
 };
 
 // phases 0 .. NPH - 2 of the FFTLog of one pair, with the barriers of run_phases (cp_fftlog_kernel.h)
@@ -202,6 +203,13 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
             for (int r = 0; r < H; ++r) st.va[r] = 1. + 1e-3 * (t + r), st.vb[r] = 2. - 1e-3 * (t + r);
         } else {
             evaluate_spectra<ENGINE, T, H>(S, ia, ib, t0, kh0, ln0, ratio, ln_ratio, lds, st.va, st.vb);
+            if (S.pk_out) {      // the caller keeps the spectra (the sigma8 normalisation: the filters ask for them on these wavenumbers next)
+#pragma unroll
+                for (int r = 0; r < H; ++r) {
+                    S.pk_out[ia * (NP / 2) + t0 + T * r] = st.va[r];
+                    if (has_b) S.pk_out[ib * (NP / 2) + t0 + T * r] = st.vb[r];
+                }
+            }
         }
         if (!(CP_SIGMA_ABLATE & 8)) front_phases<F, 0>(t, A, has_b, lds, st);
         // ---- last phase of the FFTLog, its outputs kept on the CU ----
@@ -375,8 +383,8 @@ extern "C" int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const c
 }
 
 int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, const double* d_k,
-                      const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz, double* d_out, void* d_coef,
-                      int device, void* stream) {
+                      const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz, double* d_out, double* d_pk_out,
+                      void* d_coef, int device, void* stream) {
     cp_fftlog_tables_view f;
     cp_spline_band_view b;
     if (!cp_fftlog_plan_view(fftlog, &f) || !cp_spline_plan_view(spline, &b)) return cp::fail(CP_EINVAL, "cp_sigma_rz_fused: plans without device tables");
@@ -398,6 +406,7 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     S.wb = b.d_wb; S.j0 = b.d_j0; S.bw = b.bw; S.nq = b.nq; S.nz = nz;
     S.growth_sq = d_growth_sq;
     S.out = d_out;
+    S.pk_out = d_pk_out;
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_fused: cannot select device %d", device);

@@ -211,4 +211,14 @@ class Fourier(BaseSection):
             return p0 * (g0[..., None] if g0.ndim else g0)
 
         e = self._engine
+        rs = e._rsigma8
+        if e.batch_size is not None and g0.ndim == 1 and (rs is None or (not dv.is_torch(rs) and rs == 1.)):
+            # a batch at its fiducial amplitude (the sigma8 normalisation, eisenstein_hu.py:94-103): ONE kernel evaluates the spectra, transforms them
+            # and reads sigma8 off -- and leaves the spectra where _pk0_device looks for them
+            from .interpolator import sigma_rz_analytic
+            res = sigma_rz_analytic(e._transfer, e.bg_params(), e.pk_params(rsigma8=1.), 8., g0[:, None], self.device, keep_spectra=True)
+            if res is not None:
+                out, spectra, k = res
+                e.__dict__['_pk0_fiducial'] = ((k.shape, k.tobytes()), spectra)
+                return out[:, 0, 0]
         return integrate_sigma_r2(8., rows, kmin=1e-7, kmax=1e2, device=self.device)[..., 0]**0.5

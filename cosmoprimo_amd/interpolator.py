@@ -867,6 +867,39 @@ class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
         return CorrelationFunctionInterpolator1D(s, xi=xi, device=self.device, **default_params)
 
 
+def sigma_rz_analytic(engine, bg, pk, r, growth_sq, device, kmin=1e-7, kmax=1e2, blocks=0, keep_spectra=False):
+    """``cp_sigma_rz_analytic``: sqrt(sigma^2(r) growth_sq) of a batch of cosmologies of an analytic engine, (batch, nr, nz), with P(k) evaluated
+    inside the call on the 1024 wavenumbers geomspace(kmin, kmax) of the default transform.  ``keep_spectra``: also return those spectra,
+    (batch, 1024) (the sigma8 normalisation keeps them: the filters ask for P on the same wavenumbers next).  None when the parameter arrays do
+    not match the batch of ``growth_sq`` (batch, nz)."""
+    torch = dv.torch()
+    from .background import DEFAULTS as bg_defaults
+    from .power import PK_DEFAULTS
+    nb, nz = growth_sq.shape
+    cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, device)
+    cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, device)
+    if {n for n in (n1, n2) if n is not None} - {nb}:
+        return None
+    nk = 1024
+    k = np.geomspace(kmin, kmax, nk)
+    rr = np.asarray(r, dtype='f8').ravel()
+    key = (float(kmin), float(kmax), nk, device.index)
+    if key not in _tophat_cache:
+        _tophat_cache[key] = TophatVariance(k, device=device)
+    fft = _tophat_cache[key]
+    s = fft.y[0]
+    op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
+    lib = _lib.load()
+    out = torch.empty((nb, rr.size, nz), dtype=torch.float64, device=device)
+    spectra = torch.empty((nb, nk), dtype=torch.float64, device=device) if keep_spectra else None
+    work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(nb, nk)), dtype=torch.uint8, device=device)
+    growth_sq = growth_sq.contiguous()
+    _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
+                                        fft._get_plan(device).handle, op._handle, growth_sq.data_ptr(), nz, out.data_ptr(),
+                                        spectra.data_ptr() if keep_spectra else None, work.data_ptr(), blocks, device.index, dv.stream_of(device)))
+    return out, spectra, k
+
+
 class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
 
     """2D power spectrum interpolator with ``sigma_rz``, ``sigma_dz``, ``to_1d``, ``to_xi`` (reference interpolator.py:609-987)."""
@@ -1152,29 +1185,8 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         if nb * rh.size * nz * 8 < self._two_stream_min_bytes:
             return None
         engine, bg, pk = call.analytic_engine()
-        from .background import DEFAULTS as bg_defaults
-        from .power import PK_DEFAULTS
-        cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, self.device)
-        cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, self.device)
-        if {n for n in (n1, n2) if n is not None} - {nb}:
-            return None
-        nk = 1024
-        k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
-        rr = rh.ravel()
-        key = (float(self.extrap_kmin), float(self.extrap_kmax), nk, self.device.index)
-        if key not in _tophat_cache:
-            _tophat_cache[key] = TophatVariance(k, device=self.device)
-        fft = _tophat_cache[key]
-        s = fft.y[0]
-        op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), self.device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=self.device))
-        lib = _lib.load()
-        out = torch.empty((nb, rr.size, nz), dtype=torch.float64, device=self.device)
-        work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(nb, nk)), dtype=torch.uint8, device=self.device)
-        growth_sq = growth_sq.contiguous()
-        _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, self.device).data_ptr(),
-                                            fft._get_plan(self.device).handle, op._handle, growth_sq.data_ptr(), nz, out.data_ptr(), work.data_ptr(),
-                                            self._two_stream_blocks, self.device.index, dv.stream_of(self.device)))
-        return out
+        res = sigma_rz_analytic(engine, bg, pk, rh.ravel(), growth_sq, self.device, kmin=self.extrap_kmin, kmax=self.extrap_kmax, blocks=self._two_stream_blocks)
+        return None if res is None else res[0]
 
     def sigma8_z(self, z=0, **kwargs):
         """R.m.s. of perturbations in a sphere of 8."""

@@ -285,6 +285,8 @@ int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc,
  *      into the row registers, FFTLog in LDS, spline out of LDS, results written once (csrc/cp_sigma.hip) -- when the transform is the default
  *      one (1024 samples padded to 2048: cp_sigma_rz_fused_available), else one block on `stream`.  fftlog: plan of the transform on d_k
  *      (nker = 1, n = nk); spline: plan from the transform's output grid to the radii.  d_work: cp_sigma_rz_workspace_bytes(ncosmo, nk) bytes.
+ *      d_pk_out: (ncosmo, nk) or NULL -- the spectra themselves, for a caller that needs them afterwards (the sigma8 normalisation of a batch of
+ *      cosmologies: eisenstein_hu.py:94-103 evaluates sigma8 of the fiducial amplitude, the filters then ask for P on the same wavenumbers).
  *      Allocates nothing, asynchronous. ---- */
 int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline);
 /* FFTLog of (nbatch, n) rows followed by the spline of every output row to the spline plan's queries, root taken for CP_SPLINE_POST_SQRT, as one
@@ -295,7 +297,7 @@ int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_spline_plan*
 long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk);
 int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
                          const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
-                         double* d_out, void* d_work, int nblocks, int device, void* stream);
+                         double* d_out, double* d_pk_out, void* d_work, int nblocks, int device, void* stream);
 
 
 /* clamped cubic spline through uniformly spaced knots (positions 1..n) of x^2-weighted data with the knots of a per-column box
