@@ -84,6 +84,8 @@ SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_wallish_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_void_p]),
+    'cp_wallish_dd_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_gap_spline': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_wallish_finish': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_brieden_ratio': (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

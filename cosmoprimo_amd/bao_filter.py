@@ -196,8 +196,6 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             return self._ops
         kmin = self.pk_interpolator.extrap_kmin
         klin = np.linspace(kmin, 2., self._nlin)
-        x = 1. + np.arange(self._nlin // 2)
-        dd = LinearOperator.spline(x, x, bc='clamped', nu=2, device=self.device)               # bao_filter.py:377-382
         mask = (klin > 1e-2) & (klin < 1.5)                                                   # :415
         mask_left, mask_right = self.k < 5e-4, self.k > 2.                                    # :417
         knots = np.concatenate([self.k[mask_left], klin[mask], self.k[mask_right]], axis=0)
@@ -215,7 +213,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         tophat = np.ones_like(self.k)
         m = self.k > 1.
         tophat[m] *= np.exp(-20.**2 * (self.k[m] / 1. - 1.)**2)                                # :426-431
-        self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=dd, splice=splice,
+        self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=None, splice=splice,
                          tophat=dv.to_device(tophat, self.device))
         self._ops_cache[key] = self._ops
         return self._ops
@@ -229,6 +227,27 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         _lib.check(_lib.load().cp_wallish_box(dd.data_ptr(), dd.shape[0], dd.shape[1], mf, ms, off[0], off[1], box.data_ptr(), self.device.index,
                                               dv.stream_of(self.device)))
         return box
+
+    _keep_second_derivatives = 256      # sequences up to which the second derivatives are kept as ``_dd`` (they are only looked at, never used again)
+
+    def _second_derivatives_and_box(self, y, ops):
+        """``spline(x, nu=2)`` of the clamped spline through each sequence (reference bao_filter.py:377-382) and the box between its two maxima
+        (:390-394), as one kernel that solves the tridiagonal system in LDS (``cp_wallish_dd_box``).  y : (nseq, n).  Returns (dd or None, box)."""
+        torch = dv.torch()
+        nseq, n = y.shape
+        mf, ms, off = self._margin_first, self._margin_second, self._offset
+        if n in (1024, 2048):
+            dd = torch.empty_like(y) if nseq <= self._keep_second_derivatives else None
+            box = torch.empty((nseq, 2), dtype=torch.int32, device=y.device)
+            if nseq:
+                _lib.check(_lib.load().cp_wallish_dd_box(y.data_ptr(), nseq, n, mf, ms, off[0], off[1], box.data_ptr(), dd.data_ptr() if dd is not None else None,
+                                                         self.device.index, dv.stream_of(self.device)))
+            return dd, box
+        if ops['dd'] is None:       # other lengths: the second derivatives as a spline operator, then the searches
+            x = 1. + np.arange(n)
+            ops['dd'] = LinearOperator.spline(x, x, bc='clamped', nu=2, device=self.device)
+        dd = ops['dd'](y)
+        return dd, self._box(dd)
 
     def _log_k_rows(self, klin):
         """log(k_lin P(k_lin)) rows (ncol, 4096) of a batch of cosmologies of an analytic engine, written by the evaluation kernel term by term
@@ -257,11 +276,10 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             rows, _ = self._rows(ops['klin'])                             # P(k_lin), (ncol, 4096)
             ffted = ops['dst'](rows, fused=True, split=True)
         y = ffted.view(2 * ffted.shape[0], ffted.shape[1] // 2)
-        dd = ops['dd'](y)
-        box = self._box(dd)
+        dd, box = self._second_derivatives_and_box(y, ops)
         out = y      # in place: the kept coefficients stay where they are, only the boxes are rewritten
         _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index, dv.stream_of(self.device)))
-        self._dd, self._boxes = [dd[0::2], dd[1::2]], [box[0::2], box[1::2]]
+        self._dd, self._boxes = None if dd is None else [dd[0::2], dd[1::2]], [box[0::2], box[1::2]]
         self._even_now, self._odd_now = out[0::2], out[1::2]
         pknow_lin = ops['dst'](out.view(ffted.shape), inverse=True, fused=True, split=True)          # exp(idst(.)) / k_lin
         pk = self._pk_rows.contiguous()

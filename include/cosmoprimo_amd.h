@@ -309,6 +309,12 @@ int cp_gap_spline(const double* d_y, const int* d_box, double* d_out, long long 
  * first index of the maximum as ndarray.argmax (index 0 when the second range is empty). */
 int cp_wallish_box(const double* d_dd, long long ncol, int n, int margin_first, int margin_second, int offset_first, int offset_second, int* d_box,
                    int device, void* stream);
+/* Both of the above steps of wallish2018 that come before cp_gap_spline, as one kernel (bao_filter.py:377-394): the second derivatives at the knots
+ * of the clamped CubicSpline through (1 .. n, d_y[row]) -- spline(x, nu=2) -- by a tridiagonal solve in LDS, a wave per sequence, and the box of
+ * cp_wallish_box found on them.  d_y : (nrows, n), n in {1024, 2048} (CP_EUNSUPPORTED otherwise: the two calls above); d_box : (nrows, 2) int32; d_dd : (nrows, n) or NULL (the second
+ * derivatives are written only on request). */
+int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int margin_first, int margin_second, int offset_first, int offset_second, int* d_box,
+                      double* d_dd, int device, void* stream);
 
 /* the elementwise stages of the two filters over (nrows, n) batches of spectra, one pass each (csrc/cp_bao.hip):
  * cp_wallish_finish: pknow = d_a (+ d_b when not NULL: the spliced spline applied as two operators), wiggles = (pk / pknow - 1) tophat + 1,

@@ -157,3 +157,42 @@ def test_spline_apply_grouped(path):
     assert tuple(grouped.shape) == (5, 77, 12) and torch.equal(grouped, plain.transpose(-1, -2).contiguous())
     out = torch.empty((60 * 77,), dtype=torch.float64, device=dev)
     assert lib.cp_spline_apply_grouped(op._handle, y.data_ptr(), out.data_ptr(), 60, 7, 0, 1., dv.stream_of(dev)) != 0      # 60 rows are not groups of 7
+
+
+@pytest.mark.parametrize('n', [1024, 2048])
+def test_wallish_dd_box(n):
+    """cp_wallish_dd_box (tridiagonal solve in LDS + the two arg-max searches) against scipy's clamped CubicSpline(x, nu=2) and numpy's argmax
+    rule (reference bao_filter.py:377-394), on DST-like sequences and on rows with ties, NaN and a maximum at the edge of the search range."""
+    import ctypes
+    import torch
+    from scipy import interpolate
+    from cosmoprimo_amd import _lib, _device as dv
+    rng = np.random.default_rng(n)
+    nseq = 37
+    x = 1. + np.arange(n)
+    y = rng.normal(size=(nseq, n)) / x**1.5 + 3e-3 * np.exp(-0.5 * ((x - 0.35 * n) / 12.)**2) * rng.uniform(0.5, 2., size=(nseq, 1))
+    y[3, 40:60] = 0.        # flat stretch: ties
+    y[5, 100] = np.nan
+    y[7] = 0.
+    dev = torch.device('cuda', 0)
+    ty = torch.as_tensor(y, device=dev)
+    dd = torch.empty_like(ty)
+    box = torch.empty((nseq, 2), dtype=torch.int32, device=dev)
+    mf, ms, off = 20, 5, (-10, 20)
+    lib = _lib.load()
+    _lib.check(lib.cp_wallish_dd_box(ty.data_ptr(), nseq, n, mf, ms, off[0], off[1], box.data_ptr(), dd.data_ptr(), 0, dv.stream_of(dev)))
+    box2 = torch.empty_like(box)
+    _lib.check(lib.cp_wallish_dd_box(ty.data_ptr(), nseq, n, mf, ms, off[0], off[1], box2.data_ptr(), None, 0, dv.stream_of(dev)))
+    got, gbox = dd.cpu().numpy(), box.cpu().numpy()
+    assert np.array_equal(gbox, box2.cpu().numpy())
+    for i in range(nseq):
+        if i == 5:
+            continue
+        ref = interpolate.CubicSpline(x, y[i], bc_type='clamped')(x, nu=2)
+        np.testing.assert_allclose(got[i], ref, rtol=1e-9, atol=1e-13 * np.abs(ref).max() + 1e-300)
+        first = got[i][mf:-mf].argmax() + mf
+        second = first + ms + got[i][first + ms:-mf].argmax()
+        assert tuple(gbox[i]) == (first + off[0], second + off[1]), i
+    assert np.isnan(got[5]).any()
+    first = np.argmax(got[5][mf:-mf]) + mf      # numpy: NaN is the maximum
+    assert gbox[5][0] == first + off[0]
