@@ -20,7 +20,7 @@ from .dst import DST
 from .interpolator import _quadratic_interp_operator, _simpson_weights, _bspline_basis  # noqa: F401
 from .interpolator import (PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, CorrelationFunctionInterpolator1D,
                            CorrelationFunctionInterpolator2D)
-from .spline import LinearOperator, dense_operator
+from .spline import LinearOperator, SplicedClampedSpline, dense_operator
 
 
 def _host_value(x):
@@ -199,17 +199,21 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         mask = (klin > 1e-2) & (klin < 1.5)                                                   # :415
         mask_left, mask_right = self.k < 5e-4, self.k > 2.                                    # :417
         knots = np.concatenate([self.k[mask_left], klin[mask], self.k[mask_right]], axis=0)
-        # The clamped spline through the spliced knots (:420) is linear in their values, which are contiguous pieces of two arrays that already
-        # sit in HBM: P at self.k (left and right pieces) and the smoothed spectrum on the linear grid (middle piece).  Written as one operator
-        # on each array -- the dense spline operator with its columns moved to the positions of those pieces, zero elsewhere (the plans keep
-        # bands only) -- the spline needs neither the three gathers nor the concatenation of the 3666 knot values of every vector.
-        w = dense_operator(knots, self.k, bc='clamped')                                        # (nk, nknots)
+        # The clamped spline through the spliced knots (:420): their values are contiguous pieces of two arrays that already sit in HBM -- P at
+        # self.k (left and right pieces) and the smoothed spectrum on the linear grid (middle piece).  One kernel solves the spline's tridiagonal
+        # system per vector in LDS, evaluates it at self.k and applies the damping (SplicedClampedSpline); where its scheme does not fit, the
+        # spline is applied as one dense operator on each array (its columns moved to the positions of the pieces, zero elsewhere).
         n_left, n_mid = int(mask_left.sum()), int(mask.sum())
-        w_pk, w_lin = np.zeros((self.k.size, self.k.size)), np.zeros((self.k.size, self._nlin))
-        w_pk[:, np.flatnonzero(mask_left)] = w[:, :n_left]
-        w_pk[:, np.flatnonzero(mask_right)] = w[:, n_left + n_mid:]
-        w_lin[:, np.flatnonzero(mask)] = w[:, n_left:n_left + n_mid]
-        splice = (LinearOperator.dense(w_pk, device=self.device), LinearOperator.dense(w_lin, device=self.device))
+        try:
+            pieces = [(0, 0, n_left), (1, int(np.flatnonzero(mask)[0]), n_mid), (0, int(np.flatnonzero(mask_right)[0]), int(mask_right.sum()))]
+            splice = SplicedClampedSpline(knots, pieces, self.k, device=self.device)
+        except (NotImplementedError, IndexError):
+            w = dense_operator(knots, self.k, bc='clamped')                                    # (nk, nknots)
+            w_pk, w_lin = np.zeros((self.k.size, self.k.size)), np.zeros((self.k.size, self._nlin))
+            w_pk[:, np.flatnonzero(mask_left)] = w[:, :n_left]
+            w_pk[:, np.flatnonzero(mask_right)] = w[:, n_left + n_mid:]
+            w_lin[:, np.flatnonzero(mask)] = w[:, n_left:n_left + n_mid]
+            splice = (LinearOperator.dense(w_pk, device=self.device), LinearOperator.dense(w_lin, device=self.device))
         tophat = np.ones_like(self.k)
         m = self.k > 1.
         tophat[m] *= np.exp(-20.**2 * (self.k[m] / 1. - 1.)**2)                                # :426-431
@@ -283,11 +287,13 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         self._even_now, self._odd_now = out[0::2], out[1::2]
         pknow_lin = ops['dst'](out.view(ffted.shape), inverse=True, fused=True, split=True)          # exp(idst(.)) / k_lin
         pk = self._pk_rows.contiguous()
-        from_pk, from_lin = ops['splice'][0](pk), ops['splice'][1](pknow_lin)      # clamped CubicSpline on the spliced knots at self.k, in two parts
-        out = torch.empty_like(pk)
-        # pknow = from_pk + from_lin; wiggles = (pk / pknow - 1) tophat + 1; pk / wiggles (:421-431), one pass
-        _lib.check(lib.cp_wallish_finish(pk.data_ptr(), from_pk.data_ptr(), from_lin.data_ptr(), ops['tophat'].data_ptr(), out.data_ptr(), pk.shape[0],
-                                         pk.shape[1], self.device.index, dv.stream_of(self.device)))
+        if isinstance(ops['splice'], SplicedClampedSpline):     # spline through the spliced knots at self.k, then pk / ((pk / pknow - 1) tophat + 1) (:420-431)
+            out = ops['splice'](pk, pknow_lin, tophat=ops['tophat'])
+        else:
+            from_pk, from_lin = ops['splice'][0](pk), ops['splice'][1](pknow_lin)
+            out = torch.empty_like(pk)
+            _lib.check(lib.cp_wallish_finish(pk.data_ptr(), from_pk.data_ptr(), from_lin.data_ptr(), ops['tophat'].data_ptr(), out.data_ptr(), pk.shape[0],
+                                             pk.shape[1], self.device.index, dv.stream_of(self.device)))
         self._pknow_rows = out
 
 

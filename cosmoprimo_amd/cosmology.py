@@ -438,6 +438,8 @@ class BaseCosmoParams(dv.Copyable):
         if name in ('Omega_ncdm', 'Omega_pncdm'):   # today's density / 3 x pressure of every species over rho_crit (cosmology.py:371-376)
             rck = bgmod_constants()[2] / (1e10 * 1.98847 * 1e30) * (1e6 * 3.085677581491367e16)**3
             fac = 1. if name == 'Omega_ncdm' else 3.
+            if not params['m_ncdm']:      # no species: nothing to bring to the host (a device-to-host copy of h would stall the queue)
+                return np.array([])
             T_cmb, h = np.asarray(_host(params['T_cmb']), dtype='f8'), np.asarray(_host(params['h']), dtype='f8')
             vals = [fac * _ncdm_momenta_z0(T_cmb * t, m, 'rho' if name == 'Omega_ncdm' else 'p') / h**2 / rck for t, m in zip(params['T_ncdm_over_cmb'], params['m_ncdm'])]
             return np.array(vals) if all(np.ndim(v) == 0 for v in vals) else vals

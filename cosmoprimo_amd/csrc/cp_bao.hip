@@ -9,7 +9,10 @@
 //                                                      solve in LDS, a wave per sequence) and the two arg-max searches that delimit the knots to remove
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <new>
+#include <vector>
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
@@ -335,5 +338,331 @@ extern "C" int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int 
 #undef CP_DD_LAUNCH
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_wallish_dd_box: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+// ---- wallish2018: the clamped spline through the spliced knots, evaluated on the filter's wavenumbers, and the wiggle damping -- one kernel ----
+// bao_filter.py:415-431: knots = [k < 5e-4 | the linear grid inside (1e-2, 1.5) | k > 2], values = [P | smoothed P on the linear grid | P],
+// CubicSpline(bc_type='clamped') evaluated at the filter's k, then pk / ((pk / pknow - 1) tophat + 1).  As spline operators on the two arrays
+// (two block-banded GEMMs of 64-wide bands, then an elementwise pass) this was 1.04 ms per 16 384 vectors.  The spline is a tridiagonal system
+// for the second derivatives M:  h_{i-1} M_{i-1} + 2 (h_{i-1} + h_i) M_i + h_i M_{i+1} = 6 (s_i - s_{i-1}),  s_i = (y_{i+1} - y_i) / h_i, with
+// s_{-1} = s_{n-1} = 0 for the clamped ends.  Its elimination factors 1 / (2 (h_{i-1} + h_i) - h_{i-1} c_{i-1}) depend on the knots only (host,
+// plan creation); a wave takes a vector's knot values into LDS and runs both sweeps as in cp_wallish_dd_box -- a lane per segment of S =
+// ceil(n / 64) knots, started `halo` knots outside its segment with d = 0 (M = 0), the halo chosen at plan creation so that what is left of the
+// start is below 1e-18 -- then evaluates  A y_j + B y_{j+1} + ((A^3 - A) M_j + (B^3 - B) M_{j+1}) h_j^2 / 6  at the queries (weights from the
+// plan).  Most knots lie on the uniform grid, where h and the factor are constants once the elimination has forgotten the junction (the
+// spacings of a linspace differ by the rounding of its knots, 1e-12 of h: the constants stand for all of them, 1e-13 on the second derivatives):
+// only the knots outside that stretch have table entries (LDS).
+namespace {
+
+struct SpliceTables {
+    int n, nq, S, halo;
+    int piece_src[3], piece_first[3], piece_start[3];      // knot i of piece p = src[piece_src[p]][piece_start[p] + i - piece_first[p]]; piece_first ascending
+    int ntab_left, uniform_end;                             // knots [0, ntab_left) and [uniform_end, n) have table entries, the others the constants
+    double h0, rh0, inv0;
+    const double* tab;                                      // (ntab + 1, 4) h, 1 / h, factor, h x factor; ntab = ntab_left + n - uniform_end, the last row the constants
+    const int* qj;                                          // (nq) interval of each query, -1: outside the knots
+    const int* qcol;                                        // (nq, 2) columns of y_j and y_{j+1} in their source rows; bit 30 set: source 1
+    const double* qw;                                       // (nq, 4) A, B, (A^3 - A) h^2 / 6, (B^3 - B) h^2 / 6
+};
+
+struct SpliceArgs {
+    SpliceTables T;
+    const double* src0;
+    const double* src1;
+    int n0, n1;
+    long long nrows;
+    const double* tophat;      // (nq) or null
+    double* out;               // (nrows, nq)
+};
+
+// S (odd: 64 lanes x S doubles apart fall on 32 different bank pairs, no padding) knots per lane; LDS: a buffer of 64 S + 1 doubles per wave (the
+// knot values, then d, then M, in place as in wallish_dd_box_kernel), then the coefficient table: slot -> (h, 1 / h, factor, h x factor), the
+// last slot the constants of the uniform stretch.
+__global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
+    extern __shared__ __attribute__((aligned(32))) double sp_lds[];
+    const SpliceTables& T = A.T;
+    const int S = T.S, n = T.n, stride = 64 * S + 2;
+    const int ntab = T.ntab_left + n - T.uniform_end;
+    double* tab = sp_lds + 4 * stride;
+    for (int e = threadIdx.x; e < 4 * (ntab + 1); e += 256) tab[e] = T.tab[e];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + wave;
+    if (row >= A.nrows) return;
+    double* buf = sp_lds + wave * stride;
+    const double* s0 = A.src0 + row * A.n0;
+    const double* s1 = A.src1 + row * A.n1;
+    // the knot values, piece by piece (contiguous in their source rows)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int first = T.piece_first[p], count = (p < 2 ? T.piece_first[p + 1] : n) - first;
+        const double* src = (T.piece_src[p] ? s1 : s0) + T.piece_start[p];
+#pragma unroll 4
+        for (int e = lane; e < count; e += 64) buf[first + e] = src[e];
+    }
+    // knots read beyond either end repeat the end knot: the slopes there vanish, which is the clamped boundary condition, and d stays 0 to the left
+    auto value = [&](int i) { return buf[i < 0 ? 0 : (i > n - 1 ? n - 1 : i)]; };
+    auto coefficients = [&](int i) {
+        i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+        const int slot = i < T.ntab_left ? i : (i < T.uniform_end ? ntab : i - (T.uniform_end - T.ntab_left));
+        return reinterpret_cast<const double4*>(tab)[slot];      // h, 1 / h, factor, h x factor
+    };
+    const int own = S * lane, halo = T.halo;
+    {
+        const double beyond = value(own + S);      // the next segment's first knot, before its owner writes there
+        const int start = own - halo;
+        double ym = value(start - 1), y0 = value(start), d = 0.;
+        const double4 cm = coefficients(start - 1);
+        double sm = (y0 - ym) * cm.y, hm = cm.x;     // slope and spacing of the interval to the left
+#pragma unroll 4
+        for (int t = 0; t < halo; ++t) {             // towards the segment: nothing stored
+            const int i = start + t;
+            const double4 c = coefficients(i);
+            const double yp = value(i + 1);
+            const double s = (yp - y0) * c.y;
+            d = (6. * (s - sm) - hm * d) * c.z;
+            sm = s;
+            hm = c.x;
+            y0 = yp;
+        }
+#pragma unroll 4
+        for (int t = 0; t < S - 1; ++t) {
+            const int i = own + t;
+            const double4 c = coefficients(i);
+            const double yp = value(i + 1);
+            const double s = (yp - y0) * c.y;
+            d = (6. * (s - sm) - hm * d) * c.z;
+            buf[i] = d;                              // (segments past the last knot: slots nobody reads)
+            sm = s;
+            hm = c.x;
+            y0 = yp;
+        }
+        {
+            const int i = own + S - 1;
+            const double4 c = coefficients(i);
+            const double s = i >= n - 1 ? 0. : (beyond - y0) * c.y;
+            buf[i] = (6. * (s - sm) - hm * d) * c.z;
+        }
+    }
+    {
+        double m = 0.;
+#pragma unroll 4
+        for (int t = 0; t < halo; ++t) {
+            const int i = own + S + halo - 1 - t;
+            const double d = value(i);
+            m = i >= n - 1 ? d : d - coefficients(i).w * m;
+        }
+#pragma unroll 4
+        for (int t = 0; t < S; ++t) {
+            const int i = own + S - 1 - t;
+            const double d = buf[i];
+            m = i >= n - 1 ? d : d - coefficients(i).w * m;
+            buf[i] = m;
+        }
+    }
+    double* out = A.out + row * T.nq;
+#pragma unroll 2
+    for (int q = lane; q < T.nq; q += 64) {
+        const int j = T.qj[q];
+        double v = __builtin_nan("");
+        if (j >= 0) {
+            const int c0 = T.qcol[2 * q], c1 = T.qcol[2 * q + 1];
+            const double y0 = ((c0 >> 30) & 1 ? s1 : s0)[c0 & 0x3fffffff], y1 = ((c1 >> 30) & 1 ? s1 : s0)[c1 & 0x3fffffff];
+            const double4 w = reinterpret_cast<const double4*>(T.qw)[q];
+            v = w.x * y0 + w.y * y1 + (w.z * buf[j] + w.w * buf[j + 1]);
+        }
+        if (A.tophat) {      // pk / ((pk / pknow - 1) tophat + 1), bao_filter.py:421-431: the queries are the grid of source 0
+            const double p = s0[q];
+            v = p / ((p / v - 1.) * A.tophat[q] + 1.);
+        }
+        out[q] = v;
+    }
+}
+
+}  // namespace
+
+struct cp_splice_plan {
+    SpliceTables T;
+    int device;
+    double* d_tab;
+    int* d_qj;
+    int* d_qcol;
+    double* d_qw;
+    size_t lds_bytes;
+};
+
+extern "C" int cp_splice_plan_destroy(cp_splice_plan* p) {
+    if (!p) return CP_OK;
+    {
+        DeviceScope scope(p->device);
+        if (p->d_tab) (void)hipFree(p->d_tab);
+        if (p->d_qj) (void)hipFree(p->d_qj);
+        if (p->d_qcol) (void)hipFree(p->d_qcol);
+        if (p->d_qw) (void)hipFree(p->d_qw);
+    }
+    delete p;
+    return CP_OK;
+}
+
+extern "C" int cp_splice_plan_create(cp_splice_plan** out, int nknots, const double* x, int npieces, const int* piece_src, const int* piece_start,
+                                     const int* piece_count, int nq, const double* xq, int device) {
+    if (!out) return cp::fail(CP_EINVAL, "cp_splice_plan_create: null plan pointer");
+    *out = nullptr;
+    if (nknots < 4 || !x || npieces < 1 || npieces > 3 || !piece_src || !piece_start || !piece_count || nq < 1 || !xq)
+        return cp::fail(CP_EINVAL, "cp_splice_plan_create: bad arguments");
+    const int n = nknots;
+    int total = 0;
+    for (int p = 0; p < npieces; ++p) {
+        if (piece_count[p] < 0 || piece_start[p] < 0 || (piece_src[p] != 0 && piece_src[p] != 1)) return cp::fail(CP_EINVAL, "cp_splice_plan_create: bad piece %d", p);
+        total += piece_count[p];
+    }
+    if (total != n) return cp::fail(CP_EINVAL, "cp_splice_plan_create: the pieces hold %d knots, not %d", total, n);
+    for (int i = 0; i + 1 < n; ++i)
+        if (!(x[i + 1] > x[i])) return cp::fail(CP_EINVAL, "cp_splice_plan_create: knots must increase");
+    // elimination factors of the system for the second derivatives (clamped ends)
+    std::vector<double> h(n), rh(n), inv(n), c(n);
+    for (int i = 0; i + 1 < n; ++i) h[i] = x[i + 1] - x[i];
+    h[n - 1] = h[n - 2];      // (never multiplies anything that is used: s_{n-1} = 0, and M_{n-1} has no successor)
+    for (int i = 0; i < n; ++i) rh[i] = 1. / h[i];
+    inv[0] = 1. / (2. * h[0]);
+    c[0] = h[0] * inv[0];
+    for (int i = 1; i < n; ++i) {
+        const double diag = i < n - 1 ? 2. * (h[i - 1] + h[i]) : 2. * h[n - 2];
+        inv[i] = 1. / (diag - h[i - 1] * c[i - 1]);
+        c[i] = h[i] * inv[i];
+    }
+    // how far a sweep remembers its start: the forward one by h_{i-1} inv_i per knot, the backward one by c_i
+    int halo = 8;
+    for (;; halo += 8) {
+        if (halo > 128) return cp::fail(CP_EUNSUPPORTED, "cp_splice_plan_create: the elimination does not forget its start within 128 knots");
+        double worst = 0.;
+        for (int i = halo; i < n; ++i) {
+            double f = 1., b = 1.;
+            for (int t = 0; t < halo; ++t) {
+                f *= std::fabs(h[i - t - 1] * inv[i - t]);
+                b *= std::fabs(c[i - t - 1]);
+            }
+            worst = f > worst ? f : worst;
+            worst = b > worst ? b : worst;
+        }
+        if (worst < 1e-18) break;
+    }
+    // the uniform stretch: the longest run of equal spacings, shortened on the left until the factor has converged
+    int best_lo = 0, best_hi = 0;
+    for (int lo = 0; lo < n - 1;) {
+        int hi = lo + 1;
+        while (hi < n - 1 && std::fabs(h[hi] - h[lo]) <= 2e-11 * h[lo]) ++hi;      // (a linspace: its spacings differ by the rounding of its knots)
+        if (hi - lo > best_hi - best_lo) { best_lo = lo; best_hi = hi; }
+        lo = hi;
+    }
+    int ntab_left = n, uniform_end = n;
+    double h0 = 1., inv0 = 1.;
+    if (best_hi - best_lo > 256) {
+        h0 = h[(best_lo + best_hi) / 2];
+        inv0 = inv[(best_lo + best_hi) / 2];
+        int lo = best_lo + 1;      // the row of knot best_lo still has the spacing of the piece before it
+        while (lo < best_hi && std::fabs(inv[lo] - inv0) > 2e-11 * inv0) ++lo;
+        int hi = best_hi;          // rows best_lo + 1 .. best_hi - 1 have both spacings on the uniform grid
+        while (hi > lo && std::fabs(inv[hi - 1] - inv0) > 2e-11 * inv0) --hi;
+        if (hi - lo > 128) { ntab_left = lo; uniform_end = hi; }
+    }
+    const int ntab = ntab_left + n - uniform_end;
+    const int S = ((n + 63) / 64) | 1;      // odd
+    const size_t lds = ((size_t)4 * (64 * S + 2) + 4 * ((size_t)ntab + 1)) * sizeof(double);
+    if (lds > 160 * 1024) return cp::fail(CP_EUNSUPPORTED, "cp_splice_plan_create: %d knots (%d outside a uniform stretch) exceed the LDS of a CU", n, ntab);
+    std::vector<double> tab((size_t)4 * (ntab + 1));
+    for (int i = 0, slot = 0; i < n; ++i) {
+        if (i >= ntab_left && i < uniform_end) continue;
+        tab[4 * slot] = h[i];
+        tab[4 * slot + 1] = rh[i];
+        tab[4 * slot + 2] = inv[i];
+        tab[4 * slot + 3] = c[i];
+        ++slot;
+    }
+    tab[4 * ntab] = h0;
+    tab[4 * ntab + 1] = 1. / h0;
+    tab[4 * ntab + 2] = inv0;
+    tab[4 * ntab + 3] = h0 * inv0;
+    // queries: interval, source columns of its two knots, weights
+    std::vector<int> first(3, n), qj(nq), qcol((size_t)2 * nq);
+    std::vector<double> qw((size_t)4 * nq);
+    cp_splice_plan* p = new (std::nothrow) cp_splice_plan();
+    if (!p) return cp::fail(CP_ENOMEM, "cp_splice_plan_create: host allocation failed");
+    for (int k = 0, f = 0; k < 3; ++k) {
+        p->T.piece_src[k] = k < npieces ? piece_src[k] : 0;
+        p->T.piece_start[k] = k < npieces ? piece_start[k] : 0;
+        p->T.piece_first[k] = f;
+        f += k < npieces ? piece_count[k] : 0;
+    }
+    auto column_of = [&](int i) {
+        int k = 2;
+        while (k > 0 && i < p->T.piece_first[k]) --k;
+        return (p->T.piece_start[k] + i - p->T.piece_first[k]) | (p->T.piece_src[k] << 30);
+    };
+    for (int q = 0; q < nq; ++q) {
+        const double v = xq[q];
+        if (!(v >= x[0] && v <= x[n - 1])) {
+            qj[q] = -1;
+            qcol[2 * q] = qcol[2 * q + 1] = 0;
+            continue;
+        }
+        int j = (int)(std::upper_bound(x, x + n, v) - x) - 1;
+        j = j > n - 2 ? n - 2 : j;
+        const double a = (x[j + 1] - v) / h[j], b = (v - x[j]) / h[j];
+        qj[q] = j;
+        qcol[2 * q] = column_of(j);
+        qcol[2 * q + 1] = column_of(j + 1);
+        qw[4 * q] = a;
+        qw[4 * q + 1] = b;
+        qw[4 * q + 2] = (a * a * a - a) * (h[j] * h[j]) / 6.;
+        qw[4 * q + 3] = (b * b * b - b) * (h[j] * h[j]) / 6.;
+    }
+    p->device = device;
+    p->d_tab = nullptr; p->d_qj = nullptr; p->d_qcol = nullptr; p->d_qw = nullptr;
+    p->lds_bytes = lds;
+    p->T.n = n; p->T.nq = nq; p->T.S = S; p->T.halo = halo;
+    p->T.ntab_left = ntab_left; p->T.uniform_end = uniform_end;
+    p->T.h0 = h0; p->T.rh0 = 1. / h0; p->T.inv0 = inv0;
+    DeviceScope scope(device);
+    bool ok = scope.ok && hipMalloc(&p->d_tab, tab.size() * sizeof(double)) == hipSuccess && hipMalloc(&p->d_qj, qj.size() * sizeof(int)) == hipSuccess &&
+              hipMalloc(&p->d_qcol, qcol.size() * sizeof(int)) == hipSuccess && hipMalloc(&p->d_qw, qw.size() * sizeof(double)) == hipSuccess;
+    ok = ok && hipMemcpy(p->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_qj, qj.data(), qj.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_qcol, qcol.data(), qcol.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_qw, qw.data(), qw.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        cp_splice_plan_destroy(p);
+        return cp::fail(CP_ENOMEM, "cp_splice_plan_create: cannot place the tables on device %d", device);
+    }
+    p->T.tab = p->d_tab; p->T.qj = p->d_qj; p->T.qcol = p->d_qcol; p->T.qw = p->d_qw;
+    *out = p;
+    return CP_OK;
+}
+
+extern "C" int cp_splice_apply(const cp_splice_plan* p, const double* d_src0, int n0, const double* d_src1, int n1, long long nrows, const double* d_tophat,
+                               double* d_out, void* stream) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_splice_apply: null plan");
+    if (nrows < 0) return cp::fail(CP_EINVAL, "cp_splice_apply: negative batch");
+    if (nrows == 0) return CP_OK;
+    if (!d_src0 || !d_out) return cp::fail(CP_EINVAL, "cp_splice_apply: null device pointer");
+    for (int k = 0; k < 3; ++k) {
+        const int count = (k < 2 ? p->T.piece_first[k + 1] : p->T.n) - p->T.piece_first[k];
+        if (count == 0) continue;
+        if (p->T.piece_src[k] == 1 && !d_src1) return cp::fail(CP_EINVAL, "cp_splice_apply: the plan takes knots from a second array");
+        if (p->T.piece_start[k] + count > (p->T.piece_src[k] ? n1 : n0)) return cp::fail(CP_EINVAL, "cp_splice_apply: piece %d does not fit its source rows", k);
+    }
+    if (d_tophat && p->T.nq != n0) return cp::fail(CP_EINVAL, "cp_splice_apply: the damping step needs one query per column of the first array");
+    if ((nrows + 3) / 4 > 2147483647LL) return cp::fail(CP_EUNSUPPORTED, "cp_splice_apply: too many rows for one launch");
+    DeviceScope scope(p->device);
+    if (!scope.ok) return cp::fail(CP_EDEVICE, "cp_splice_apply: cannot select device %d", p->device);
+    SpliceArgs A;
+    A.T = p->T;
+    A.src0 = d_src0; A.src1 = d_src1 ? d_src1 : d_src0; A.n0 = n0; A.n1 = d_src1 ? n1 : n0; A.nrows = nrows; A.tophat = d_tophat; A.out = d_out;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&splice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr;
+    hipLaunchKernelGGL(splice_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), p->lds_bytes, static_cast<hipStream_t>(stream), A);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_splice_apply: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }

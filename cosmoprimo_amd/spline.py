@@ -121,3 +121,46 @@ def dense_operator(x, xq, bc='natural', nu=0, extrapolate=False):
     _lib.check(_lib.load().cp_spline_operator(x.size, _lib.as_double_p(x), xq.size, _lib.as_double_p(xq), _lib.SPLINE_BC[bc], int(nu),
                                               int(bool(extrapolate)), _lib.as_double_p(w), None))
     return w
+
+
+class SplicedClampedSpline(object):
+
+    """Clamped cubic spline through knots whose values are contiguous pieces of the rows of two arrays, evaluated at fixed queries: the
+    tridiagonal system of ``scipy.interpolate.CubicSpline(knots, values, bc_type='clamped')`` solved for every row in LDS (``cp_splice_*``),
+    with the wiggle damping of wallish2018 as an optional last step of the same kernel (reference bao_filter.py:415-431).
+
+    pieces : up to three (source, start, count): knots take the columns [start, start + count) of the rows of array ``source`` (0 or 1).
+    Raises NotImplementedError when the knots do not fit the kernel's scheme (the caller applies the spline as operators then)."""
+
+    def __init__(self, knots, pieces, xq, device=None):
+        self.device = dv.resolve_device(device)
+        knots = np.ascontiguousarray(knots, dtype='f8').ravel()
+        xq = np.ascontiguousarray(xq, dtype='f8').ravel()
+        src, start, count = (np.ascontiguousarray([p[i] for p in pieces], dtype=np.int32) for i in range(3))
+        as_int_p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        self._handle = ctypes.c_void_p()
+        _lib.check(_lib.load().cp_splice_plan_create(ctypes.byref(self._handle), knots.size, _lib.as_double_p(knots), len(pieces), as_int_p(src), as_int_p(start),
+                                                     as_int_p(count), xq.size, _lib.as_double_p(xq), self.device.index))
+        self.nq = xq.size
+
+    def __call__(self, rows0, rows1=None, tophat=None):
+        """rows0 (nrows, n0), rows1 (nrows, n1) device tensors -> (nrows, nq); ``tophat`` (nq,): rows0 / ((rows0 / spline - 1) tophat + 1)."""
+        torch = dv.torch()
+        rows0 = dv.to_device(rows0, self.device).contiguous()
+        if rows1 is not None:
+            rows1 = dv.to_device(rows1, self.device).contiguous()
+            if rows1.shape[0] != rows0.shape[0]:
+                raise ValueError('the two arrays must hold the same rows')
+        out = torch.empty((rows0.shape[0], self.nq), dtype=torch.float64, device=self.device)
+        _lib.check(_lib.load().cp_splice_apply(self._handle, rows0.data_ptr(), rows0.shape[1], rows1.data_ptr() if rows1 is not None else None,
+                                               rows1.shape[1] if rows1 is not None else 0, rows0.shape[0], tophat.data_ptr() if tophat is not None else None,
+                                               out.data_ptr(), dv.stream_of(self.device)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._handle:
+                _lib.load().cp_splice_plan_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass

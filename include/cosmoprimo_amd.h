@@ -316,6 +316,20 @@ int cp_wallish_box(const double* d_dd, long long ncol, int n, int margin_first, 
 int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int margin_first, int margin_second, int offset_first, int offset_second, int* d_box,
                       double* d_dd, int device, void* stream);
 
+/* ---- clamped cubic spline through knots spliced from contiguous pieces of two row arrays (wallish2018, bao_filter.py:415-431) ----
+ * The knots x (nknots, increasing) take their values from up to three pieces: piece p = columns [piece_start[p], piece_start[p] + piece_count[p])
+ * of the rows of array piece_src[p] (0 or 1), in this order.  cp_splice_apply solves the tridiagonal system of
+ * scipy.interpolate.CubicSpline(x, values, bc_type='clamped') for every row in LDS (a wave per row) and evaluates the spline at the queries xq
+ * (NaN outside the knots): d_out (nrows, nq).  With d_tophat (nq; the queries must be the columns of array 0) the damping of wallish2018 follows in
+ * the same kernel: d_out = p / ((p / spline - 1) tophat + 1), p = array 0 (bao_filter.py:421-431).  CP_EUNSUPPORTED from plan creation when the
+ * knots do not fit the LDS scheme (more than a few thousand knots off a uniform stretch): apply the spline as operators then. */
+typedef struct cp_splice_plan cp_splice_plan;
+int cp_splice_plan_create(cp_splice_plan** plan, int nknots, const double* x, int npieces, const int* piece_src, const int* piece_start,
+                          const int* piece_count, int nq, const double* xq, int device);
+int cp_splice_apply(const cp_splice_plan* plan, const double* d_src0, int n0, const double* d_src1, int n1, long long nrows, const double* d_tophat,
+                    double* d_out, void* stream);
+int cp_splice_plan_destroy(cp_splice_plan* plan);
+
 /* the elementwise stages of the two filters over (nrows, n) batches of spectra, one pass each (csrc/cp_bao.hip):
  * cp_wallish_finish: pknow = d_a (+ d_b when not NULL: the spliced spline applied as two operators), wiggles = (pk / pknow - 1) tophat + 1,
  *   out = pk / wiggles (bao_filter.py:421-431); d_tophat : (n).

@@ -196,3 +196,49 @@ def test_wallish_dd_box(n):
     assert np.isnan(got[5]).any()
     first = np.argmax(got[5][mf:-mf]) + mf      # numpy: NaN is the maximum
     assert gbox[5][0] == first + off[0]
+
+
+def test_spliced_clamped_spline():
+    """cp_splice_* (the clamped spline of wallish2018 through knots spliced from two arrays: tridiagonal solve in LDS, evaluation, damping) against
+    scipy's CubicSpline(bc_type='clamped') on the gathered knots (reference bao_filter.py:415-431), for the filter's own grids and for knots
+    without a uniform stretch; a row holding NaN stays alone."""
+    import torch
+    from scipy import interpolate
+    from cosmoprimo_amd.spline import SplicedClampedSpline
+    rng = np.random.default_rng(2)
+    dev = torch.device('cuda', 0)
+    k = np.geomspace(1e-7, 1e2, 1024)
+    klin = np.linspace(1e-7, 2., 4096)
+    mask = (klin > 1e-2) & (klin < 1.5)
+    left, right = k < 5e-4, k > 2.
+    knots = np.concatenate([k[left], klin[mask], k[right]])
+    pieces = [(0, 0, int(left.sum())), (1, int(np.flatnonzero(mask)[0]), int(mask.sum())), (0, int(np.flatnonzero(right)[0]), int(right.sum()))]
+    nrows = 11
+    amp = rng.uniform(0.5, 2., size=(nrows, 1))
+    shape = lambda x: x / (1. + (x / 0.02)**2.6)
+    pk = amp * shape(k) * (1. + 0.05 * np.sin(k[None, :] / 0.01) * np.exp(-(k / 0.3)**2))
+    lin = amp * shape(klin) * (1. + 1e-3 * rng.normal(size=(nrows, klin.size)))
+    tophat = np.ones_like(k)
+    tophat[k > 1.] *= np.exp(-20.**2 * (k[k > 1.] - 1.)**2)
+    op = SplicedClampedSpline(knots, pieces, k, device=dev)
+    got = op(torch.as_tensor(pk, device=dev), torch.as_tensor(lin, device=dev)).cpu().numpy()
+    damped = op(torch.as_tensor(pk, device=dev), torch.as_tensor(lin, device=dev), tophat=torch.as_tensor(tophat, device=dev)).cpu().numpy()
+    for i in range(nrows):
+        values = np.concatenate([pk[i][left], lin[i][mask], pk[i][right]])
+        ref = interpolate.CubicSpline(knots, values, bc_type='clamped', extrapolate=False)(k)
+        np.testing.assert_allclose(got[i], ref, rtol=1e-11)
+        np.testing.assert_allclose(damped[i], pk[i] / ((pk[i] / ref - 1.) * tophat + 1.), rtol=1e-11)
+    bad = pk.copy()
+    bad[4, 3] = np.nan
+    gotb = op(torch.as_tensor(bad, device=dev), torch.as_tensor(lin, device=dev)).cpu().numpy()
+    assert np.isnan(gotb[4]).any() and np.array_equal(np.delete(gotb, 4, axis=0), np.delete(got, 4, axis=0))
+    # irregular knots from one array, queries inside and outside
+    x = np.sort(rng.uniform(0., 10., 700))
+    xq = np.concatenate([[-1.], rng.uniform(x[0], x[-1], 300), [x[0], x[-1], 11.]])
+    y = rng.normal(size=(5, 700))
+    op = SplicedClampedSpline(x, [(0, 0, 700)], xq, device=dev)
+    got = op(torch.as_tensor(y, device=dev)).cpu().numpy()
+    for i in range(5):
+        ref = interpolate.CubicSpline(x, y[i], bc_type='clamped', extrapolate=False)(xq)
+        assert np.isnan(got[i][0]) and np.isnan(got[i][-1])
+        np.testing.assert_allclose(got[i][1:-1], ref[1:-1], rtol=1e-9, atol=1e-11)

@@ -52,7 +52,9 @@ def test_bao_filter_chunk(engine):
         fid = cp.Cosmology(engine='eisenstein_hu')
 
         def chunk():
-            cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **static)
+            # (fresh views of the parameter arrays on every call, as a loop over chunks of a larger batch makes them: a host copy cached by tensor
+            # identity would hide a device-to-host transfer)
+            cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{name: v[:] for name, v in static.items()})
             interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
             kw = dict(cosmo_fid=fid, cosmo=cosmo) if engine == 'brieden2022' else {}
             if 'filter' not in state:
@@ -72,7 +74,8 @@ def test_sigma_rz_of_a_batch_of_cosmologies():
     r, z = torch.as_tensor(np.geomspace(1., 100., 64), device=dev), torch.as_tensor(np.linspace(0., 2., 16), device=dev)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        capture_and_compare(torch, lambda: cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **static).get_fourier().pk_interpolator().sigma_rz(r, z), static, fresh)
+        capture_and_compare(torch, lambda: cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{name: v[:] for name, v in static.items()}).get_fourier().pk_interpolator().sigma_rz(r, z),
+                            static, fresh)
 
 
 def test_fftlog_and_distances():
