@@ -355,12 +355,15 @@ extern "C" int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int 
 // only the knots outside that stretch have table entries (LDS).
 namespace {
 
+constexpr int SPLICE_KMAX = 60;      // knots per lane the kernel keeps in registers: at most 64 x 60 knots
+
 struct SpliceTables {
     int n, nq, S, halo;
     int piece_src[3], piece_first[3], piece_start[3];      // knot i of piece p = src[piece_src[p]][piece_start[p] + i - piece_first[p]]; piece_first ascending
     int ntab_left, uniform_end;                             // knots [0, ntab_left) and [uniform_end, n) have table entries, the others the constants
     double h0, rh0, inv0;
-    const double* tab;                                      // (ntab + 1, 4) h, 1 / h, factor, h x factor; ntab = ntab_left + n - uniform_end, the last row the constants
+    const double* tab;                                      // (nslots, 4): 6 / h_i, factor_i, h_{i-1} factor_i, h_i factor_i per slot (see splice_kernel)
+    int generic_first, generic_end;                          // queries outside [generic_first, generic_end) fall on a knot taken from the same column of array 0: the result is that value
     const int* qj;                                          // (nq) interval of each query, -1: outside the knots
     const int* qcol;                                        // (nq, 2) columns of y_j and y_{j+1} in their source rows; bit 30 set: source 1
     const double* qw;                                       // (nq, 4) A, B, (A^3 - A) h^2 / 6, (B^3 - B) h^2 / 6
@@ -376,107 +379,141 @@ struct SpliceArgs {
     double* out;               // (nrows, nq)
 };
 
-// S (odd: 64 lanes x S doubles apart fall on 32 different bank pairs, no padding) knots per lane; LDS: a buffer of 64 S + 1 doubles per wave (the
-// knot values, then d, then M, in place as in wallish_dd_box_kernel), then the coefficient table: slot -> (h, 1 / h, factor, h x factor), the
-// last slot the constants of the uniform stretch.
+// S (odd: 64 lanes x S doubles apart fall on 32 different bank pairs) knots per lane.  LDS per wave: halo + 1 | 64 S | halo + 1 doubles -- the knot
+// values with the end values repeated on either side (slopes beyond the ends vanish: the clamped boundary condition, and no index is ever
+// clamped), then d, then M in the same places, as in wallish_dd_box_kernel -- and, per workgroup, the coefficient table: slot -> (6 / h, factor,
+// h_{i-1} x factor, h_i x factor), the knots left of the uniform stretch, ONE slot for the stretch, the knots right of it.  The dependent
+// chain of the forward sweep is one FMA per knot: d_i = P_i - Q_i d_{i-1}, P_i = factor_i (sigma_i - sigma_{i-1}), sigma_i = (y_{i+1} - y_i) 6 / h_i.
+#ifndef CP_SPLICE_ABLATE      // diagnostic builds (tools/splice_microbench.hip): 1 no sweeps, 2 no evaluation, 4 no knot loads
+#define CP_SPLICE_ABLATE 0
+#endif
 __global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
     extern __shared__ __attribute__((aligned(32))) double sp_lds[];
     const SpliceTables& T = A.T;
-    const int S = T.S, n = T.n, stride = 64 * S + 2;
-    const int ntab = T.ntab_left + n - T.uniform_end;
+    const int S = T.S, n = T.n, halo = T.halo, pad = halo + 1, stride = 64 * S + 2 * pad + (halo & 1);
+    const int nslots = T.ntab_left + 1 + (64 * S + pad - T.uniform_end);      // (entries past the last knot repeat it)
     double* tab = sp_lds + 4 * stride;
-    for (int e = threadIdx.x; e < 4 * (ntab + 1); e += 256) tab[e] = T.tab[e];
+    for (int e = threadIdx.x; e < 4 * nslots; e += 256) tab[e] = T.tab[e];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + wave;
-    if (row >= A.nrows) return;
-    double* buf = sp_lds + wave * stride;
+    double* buf = sp_lds + wave * stride + pad;      // buf[i], -pad <= i < 64 S + pad
+    const int L = T.ntab_left, U = T.uniform_end;
+    auto slot_of = [&](int i) {      // i < L: i; L <= i < U: L (the uniform stretch); i >= U: i - U + L + 1
+        const int lo = i < L ? i : L, hi = i - U + 1;
+        return (lo < 0 ? 0 : lo) + (hi < 0 ? 0 : hi);
+    };
+    const double4* coef = reinterpret_cast<const double4*>(tab);
+    const int own = S * lane;
+    // persistent workgroups (one per CU: the buffers fill its LDS): the table is fetched once, a wave walks its share of the rows.  One wave per
+    // SIMD leaves it 512 registers: the knot values of the NEXT row are fetched into them (a lane takes the knots lane + 64 k, contiguous in their
+    // source rows piece by piece) while this row is solved and evaluated.
+    constexpr int KMAX = SPLICE_KMAX;
+    const int f1 = T.piece_first[1], f2 = T.piece_first[2];
+    auto fetch = [&](long long r, double* v) {
+        const double* a = A.src0 + r * A.n0;
+        const double* b = A.src1 + r * A.n1;
+        const double* p0 = (T.piece_src[0] ? b : a) + T.piece_start[0];
+        const double* p1 = (T.piece_src[1] ? b : a) + T.piece_start[1] - f1;
+        const double* p2 = (T.piece_src[2] ? b : a) + T.piece_start[2] - f2;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int i = lane + 64 * k;
+            const double* src = i < f1 ? p0 : (i < f2 ? p1 : p2);
+            v[k] = (i < n && !(CP_SPLICE_ABLATE & 4)) ? src[i] : 0.;
+        }
+    };
+    double knots[KMAX];
+    long long row = (long long)blockIdx.x * 4 + wave;
+    if (row < A.nrows) fetch(row, knots);
+    for (; row < A.nrows; row += (long long)gridDim.x * 4) {
     const double* s0 = A.src0 + row * A.n0;
     const double* s1 = A.src1 + row * A.n1;
-    // the knot values, piece by piece (contiguous in their source rows)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int first = T.piece_first[p], count = (p < 2 ? T.piece_first[p + 1] : n) - first;
-        const double* src = (T.piece_src[p] ? s1 : s0) + T.piece_start[p];
-#pragma unroll 4
-        for (int e = lane; e < count; e += 64) buf[first + e] = src[e];
+    for (int k = 0; k < KMAX; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) buf[i] = knots[k];
     }
-    // knots read beyond either end repeat the end knot: the slopes there vanish, which is the clamped boundary condition, and d stays 0 to the left
-    auto value = [&](int i) { return buf[i < 0 ? 0 : (i > n - 1 ? n - 1 : i)]; };
-    auto coefficients = [&](int i) {
-        i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
-        const int slot = i < T.ntab_left ? i : (i < T.uniform_end ? ntab : i - (T.uniform_end - T.ntab_left));
-        return reinterpret_cast<const double4*>(tab)[slot];      // h, 1 / h, factor, h x factor
-    };
-    const int own = S * lane, halo = T.halo;
     {
-        const double beyond = value(own + S);      // the next segment's first knot, before its owner writes there
+        const double first = buf[0], last = buf[n - 1];      // (LDS takes a wave's accesses in order)
+        for (int e = lane; e < pad; e += 64) buf[-1 - e] = first;
+        for (int e = n + lane; e < 64 * S + pad; e += 64) buf[e] = last;
+    }
+    if (row + (long long)gridDim.x * 4 < A.nrows) fetch(row + (long long)gridDim.x * 4, knots);
+    if (!(CP_SPLICE_ABLATE & 1)) {
+        const double beyond = buf[own + S];      // the next segment's first knot, before its owner writes there
         const int start = own - halo;
-        double ym = value(start - 1), y0 = value(start), d = 0.;
-        const double4 cm = coefficients(start - 1);
-        double sm = (y0 - ym) * cm.y, hm = cm.x;     // slope and spacing of the interval to the left
+        double y0 = buf[start], d = 0.;
+        double sigma_m = (y0 - buf[start - 1]) * coef[slot_of(start - 1)].x;
 #pragma unroll 4
         for (int t = 0; t < halo; ++t) {             // towards the segment: nothing stored
             const int i = start + t;
-            const double4 c = coefficients(i);
-            const double yp = value(i + 1);
-            const double s = (yp - y0) * c.y;
-            d = (6. * (s - sm) - hm * d) * c.z;
-            sm = s;
-            hm = c.x;
+            const double4 c = coef[slot_of(i)];
+            const double yp = buf[i + 1];
+            const double sigma = (yp - y0) * c.x;
+            d = fma(-c.z, d, c.y * (sigma - sigma_m));
+            sigma_m = sigma;
             y0 = yp;
         }
 #pragma unroll 4
         for (int t = 0; t < S - 1; ++t) {
             const int i = own + t;
-            const double4 c = coefficients(i);
-            const double yp = value(i + 1);
-            const double s = (yp - y0) * c.y;
-            d = (6. * (s - sm) - hm * d) * c.z;
-            buf[i] = d;                              // (segments past the last knot: slots nobody reads)
-            sm = s;
-            hm = c.x;
+            const double4 c = coef[slot_of(i)];
+            const double yp = buf[i + 1];
+            const double sigma = (yp - y0) * c.x;
+            d = fma(-c.z, d, c.y * (sigma - sigma_m));
+            buf[i] = d;                              // (segments past the last knot: slots nobody uses)
+            sigma_m = sigma;
             y0 = yp;
         }
         {
             const int i = own + S - 1;
-            const double4 c = coefficients(i);
-            const double s = i >= n - 1 ? 0. : (beyond - y0) * c.y;
-            buf[i] = (6. * (s - sm) - hm * d) * c.z;
+            const double4 c = coef[slot_of(i)];
+            const double sigma = (beyond - y0) * c.x;
+            buf[i] = fma(-c.z, d, c.y * (sigma - sigma_m));
         }
     }
-    {
+    if (!(CP_SPLICE_ABLATE & 1)) {
         double m = 0.;
 #pragma unroll 4
         for (int t = 0; t < halo; ++t) {
             const int i = own + S + halo - 1 - t;
-            const double d = value(i);
-            m = i >= n - 1 ? d : d - coefficients(i).w * m;
+            const double d = buf[i];
+            m = i >= n - 1 ? d : fma(-coef[slot_of(i)].w, m, d);      // (beyond the last knot: M_{n-1} = d_{n-1} when the sweep gets there)
         }
 #pragma unroll 4
         for (int t = 0; t < S; ++t) {
             const int i = own + S - 1 - t;
             const double d = buf[i];
-            m = i >= n - 1 ? d : d - coefficients(i).w * m;
+            m = i >= n - 1 ? d : fma(-coef[slot_of(i)].w, m, d);
             buf[i] = m;
         }
     }
+    // Queries that fall on a knot taken from their own column of array 0 (wallish2018: every k below and above the linear grid) return that
+    // value: whole blocks of 64 such queries skip the tables.  For the others the table entries and the gathered knot values of four blocks are
+    // fetched together (registers are plentiful at one wave per SIMD).
     double* out = A.out + row * T.nq;
-#pragma unroll 2
-    for (int q = lane; q < T.nq; q += 64) {
-        const int j = T.qj[q];
-        double v = __builtin_nan("");
-        if (j >= 0) {
-            const int c0 = T.qcol[2 * q], c1 = T.qcol[2 * q + 1];
-            const double y0 = ((c0 >> 30) & 1 ? s1 : s0)[c0 & 0x3fffffff], y1 = ((c1 >> 30) & 1 ? s1 : s0)[c1 & 0x3fffffff];
-            const double4 w = reinterpret_cast<const double4*>(T.qw)[q];
-            v = w.x * y0 + w.y * y1 + (w.z * buf[j] + w.w * buf[j + 1]);
+    const int nblocks = (CP_SPLICE_ABLATE & 2) ? 1 : (T.nq + 63) / 64;
+#pragma unroll 4
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int q = 64 * blk + lane;
+        if (64 * blk + 64 <= T.generic_first || 64 * blk >= T.generic_end) {
+            if (q < T.nq) out[q] = s0[q];
+            continue;
         }
+        if (q >= T.nq) continue;
+        const int j = T.qj[q];
+        const int c0 = T.qcol[2 * q], c1 = T.qcol[2 * q + 1];
+        const double y0 = ((c0 >> 30) & 1 ? s1 : s0)[c0 & 0x3fffffff], y1 = ((c1 >> 30) & 1 ? s1 : s0)[c1 & 0x3fffffff];
+        const double4 w = reinterpret_cast<const double4*>(T.qw)[q];
+        const int jj = j < 0 ? 0 : j;
+        double v = w.x * y0 + w.y * y1 + (w.z * buf[jj] + w.w * buf[jj + 1]);
+        if (j < 0) v = __builtin_nan("");
         if (A.tophat) {      // pk / ((pk / pknow - 1) tophat + 1), bao_filter.py:421-431: the queries are the grid of source 0
             const double p = s0[q];
             v = p / ((p / v - 1.) * A.tophat[q] + 1.);
         }
         out[q] = v;
+    }
     }
 }
 
@@ -567,23 +604,31 @@ extern "C" int cp_splice_plan_create(cp_splice_plan** out, int nknots, const dou
         while (hi > lo && std::fabs(inv[hi - 1] - inv0) > 2e-11 * inv0) --hi;
         if (hi - lo > 128) { ntab_left = lo; uniform_end = hi; }
     }
-    const int ntab = ntab_left + n - uniform_end;
+    if (n > 64 * SPLICE_KMAX) return cp::fail(CP_EUNSUPPORTED, "cp_splice_plan_create: %d knots, the kernel takes %d", n, 64 * SPLICE_KMAX);
     const int S = ((n + 63) / 64) | 1;      // odd
-    const size_t lds = ((size_t)4 * (64 * S + 2) + 4 * ((size_t)ntab + 1)) * sizeof(double);
-    if (lds > 160 * 1024) return cp::fail(CP_EUNSUPPORTED, "cp_splice_plan_create: %d knots (%d outside a uniform stretch) exceed the LDS of a CU", n, ntab);
-    std::vector<double> tab((size_t)4 * (ntab + 1));
-    for (int i = 0, slot = 0; i < n; ++i) {
-        if (i >= ntab_left && i < uniform_end) continue;
-        tab[4 * slot] = h[i];
-        tab[4 * slot + 1] = rh[i];
-        tab[4 * slot + 2] = inv[i];
+    const int pad = halo + 1;
+    // slots: the knots left of the uniform stretch, one slot for the stretch, the knots right of it, and the positions a lane's segment may
+    // reach past the last knot (they repeat it)
+    const int nslots = ntab_left + 1 + (64 * S + pad - uniform_end);
+    const size_t lds = ((size_t)4 * (64 * S + 2 * pad + (halo & 1)) + 4 * (size_t)nslots) * sizeof(double);
+    if (lds > 160 * 1024) return cp::fail(CP_EUNSUPPORTED, "cp_splice_plan_create: %d knots (%d outside a uniform stretch) exceed the LDS of a CU", n, nslots);
+    std::vector<double> tab((size_t)4 * nslots);
+    auto fill = [&](int slot, int i) {      // 6 / h_i, factor_i, h_{i-1} factor_i, h_i factor_i
+        tab[4 * slot] = 6. * rh[i];
+        tab[4 * slot + 1] = inv[i];
+        tab[4 * slot + 2] = i > 0 ? h[i - 1] * inv[i] : 0.;
         tab[4 * slot + 3] = c[i];
-        ++slot;
+    };
+    for (int i = 0; i < ntab_left; ++i) fill(i, i);
+    tab[4 * ntab_left] = 6. / h0;
+    tab[4 * ntab_left + 1] = inv0;
+    tab[4 * ntab_left + 2] = h0 * inv0;
+    tab[4 * ntab_left + 3] = h0 * inv0;
+    for (int i = uniform_end; i < 64 * S + pad; ++i) fill(i - uniform_end + ntab_left + 1, i < n ? i : n - 1);
+    if (ntab_left == n) {      // (no uniform stretch: its slot is never addressed; keep it finite)
+        tab[4 * ntab_left] = tab[4 * ntab_left + 1] = 1.;
+        tab[4 * ntab_left + 2] = tab[4 * ntab_left + 3] = 0.;
     }
-    tab[4 * ntab] = h0;
-    tab[4 * ntab + 1] = 1. / h0;
-    tab[4 * ntab + 2] = inv0;
-    tab[4 * ntab + 3] = h0 * inv0;
     // queries: interval, source columns of its two knots, weights
     std::vector<int> first(3, n), qj(nq), qcol((size_t)2 * nq);
     std::vector<double> qw((size_t)4 * nq);
@@ -618,6 +663,17 @@ extern "C" int cp_splice_plan_create(cp_splice_plan** out, int nknots, const dou
         qw[4 * q + 2] = (a * a * a - a) * (h[j] * h[j]) / 6.;
         qw[4 * q + 3] = (b * b * b - b) * (h[j] * h[j]) / 6.;
     }
+    int generic_first = nq, generic_end = 0;
+    for (int q = 0; q < nq; ++q) {
+        const bool on_first = qj[q] >= 0 && qw[4 * q] == 1. && qw[4 * q + 1] == 0. && qcol[2 * q] == q;
+        const bool on_second = qj[q] >= 0 && qw[4 * q] == 0. && qw[4 * q + 1] == 1. && qcol[2 * q + 1] == q;
+        if (on_first || on_second) continue;
+        generic_first = q < generic_first ? q : generic_first;
+        generic_end = q + 1;
+    }
+    if (generic_end <= generic_first) generic_first = generic_end = 0;
+    p->T.generic_first = generic_first;
+    p->T.generic_end = generic_end;
     p->device = device;
     p->d_tab = nullptr; p->d_qj = nullptr; p->d_qcol = nullptr; p->d_qw = nullptr;
     p->lds_bytes = lds;
@@ -661,7 +717,12 @@ extern "C" int cp_splice_apply(const cp_splice_plan* p, const double* d_src0, in
     A.src0 = d_src0; A.src1 = d_src1 ? d_src1 : d_src0; A.n0 = n0; A.n1 = d_src1 ? n1 : n0; A.nrows = nrows; A.tophat = d_tophat; A.out = d_out;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&splice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)attr;
-    hipLaunchKernelGGL(splice_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), p->lds_bytes, static_cast<hipStream_t>(stream), A);
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;
+    const long long blocks = (nrows + 3) / 4;
+    const long long per_cu = p->lds_bytes ? (160 * 1024) / (long long)p->lds_bytes : 1;
+    const long long resident = (long long)ncu * (per_cu < 1 ? 1 : per_cu);
+    hipLaunchKernelGGL(splice_kernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(256), p->lds_bytes, static_cast<hipStream_t>(stream), A);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_splice_apply: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
