@@ -85,7 +85,7 @@ SIGNATURES = {
     'cp_wallish_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_void_p]),
     'cp_wallish_dd_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_splice_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                             ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_int, _c_double_p, ctypes.c_int]),
     'cp_splice_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p,

@@ -236,7 +236,8 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     def _second_derivatives_and_box(self, y, ops):
         """``spline(x, nu=2)`` of the clamped spline through each sequence (reference bao_filter.py:377-382) and the box between its two maxima
-        (:390-394), as one kernel that solves the tridiagonal system in LDS (``cp_wallish_dd_box``).  y : (nseq, n).  Returns (dd or None, box)."""
+        (:390-394), as one kernel that solves the tridiagonal system in LDS (``cp_wallish_dd_box``), which also rewrites the boxes in place (:395-405).  y : (nseq, n).  Returns (dd or None, box, whether the boxes are
+        rewritten already)."""
         torch = dv.torch()
         nseq, n = y.shape
         mf, ms, off = self._margin_first, self._margin_second, self._offset
@@ -245,13 +246,13 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             box = torch.empty((nseq, 2), dtype=torch.int32, device=y.device)
             if nseq:
                 _lib.check(_lib.load().cp_wallish_dd_box(y.data_ptr(), nseq, n, mf, ms, off[0], off[1], box.data_ptr(), dd.data_ptr() if dd is not None else None,
-                                                         self.device.index, dv.stream_of(self.device)))
-            return dd, box
+                                                         y.data_ptr(), self.device.index, dv.stream_of(self.device)))      # (the boxes are rewritten in place, :395-405)
+            return dd, box, True
         if ops['dd'] is None:       # other lengths: the second derivatives as a spline operator, then the searches
             x = 1. + np.arange(n)
             ops['dd'] = LinearOperator.spline(x, x, bc='clamped', nu=2, device=self.device)
         dd = ops['dd'](y)
-        return dd, self._box(dd)
+        return dd, self._box(dd), False
 
     def _log_k_rows(self, klin):
         """log(k_lin P(k_lin)) rows (ncol, 4096) of a batch of cosmologies of an analytic engine, written by the evaluation kernel term by term
@@ -280,9 +281,10 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             rows, _ = self._rows(ops['klin'])                             # P(k_lin), (ncol, 4096)
             ffted = ops['dst'](rows, fused=True, split=True)
         y = ffted.view(2 * ffted.shape[0], ffted.shape[1] // 2)
-        dd, box = self._second_derivatives_and_box(y, ops)
+        dd, box, removed = self._second_derivatives_and_box(y, ops)
         out = y      # in place: the kept coefficients stay where they are, only the boxes are rewritten
-        _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index, dv.stream_of(self.device)))
+        if not removed:
+            _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index, dv.stream_of(self.device)))
         self._dd, self._boxes = None if dd is None else [dd[0::2], dd[1::2]], [box[0::2], box[1::2]]
         self._even_now, self._odd_now = out[0::2], out[1::2]
         pknow_lin = ops['dst'](out.view(ffted.shape), inverse=True, fused=True, split=True)          # exp(idst(.)) / k_lin

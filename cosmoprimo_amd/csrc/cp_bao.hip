@@ -123,6 +123,7 @@ int finish(const char* what, int status_device_ok) {
 // per sequence instead of 4096, nothing but the sequence read from memory; the arg-max searches run on the M in LDS; M itself is written only
 // on request (tests).
 constexpr int DD_HALO = 32;
+constexpr int DD_GAP_WINDOW = 64;      // knots on either side of the box from which its end slopes are eliminated (gap_spline_kernel: GAP_WINDOW)
 constexpr double DD_CINF = 0.26794919243112270647;      // 2 - sqrt(3)
 constexpr double DD_CLAST = 1. / (2. - DD_CINF);         // the last row has diagonal 2
 constexpr int DD_NTAB = 40;                              // c_i equals its limit to the last bit from knot 30 on
@@ -138,6 +139,18 @@ struct DdTable {
     }
 };
 __constant__ DdTable dd_table = DdTable();
+struct GapTable {      // the same recurrence started from 0 (gap_spline_kernel starts its eliminations inside the sequence with c = 0)
+    double c[DD_NTAB];
+    constexpr GapTable() : c() {
+        double v = 0.;
+        c[0] = v;
+        for (int i = 1; i < DD_NTAB; ++i) {
+            v = 1. / (4. - v);
+            c[i] = v;
+        }
+    }
+};
+__constant__ GapTable gap_table = GapTable();
 
 __device__ __forceinline__ void dd_argmax_merge(double& v, int& i, double ov, int oi) {      // first index of the maximum, NaN counts as largest (numpy)
     const bool take = (ov > v && !(v != v)) || (ov != ov && !(v != v)) || (((ov == v) || (ov != ov && v != v)) && oi < i);
@@ -173,12 +186,14 @@ __device__ __forceinline__ int dd_wave_argmax(const double* buf, int lo, int hi,
 // then d over it (a lane reads ahead of where its left neighbour writes; the one value it needs from its right neighbour's segment it takes
 // before the sweep), then M over d (a lane is through its neighbour's segment before the neighbour writes there: the wave runs in lockstep).
 template <int S>
-__global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* __restrict__ y, long long nrows, int margin_first, int margin_second, int off0,
-                                                             int off1, int* __restrict__ box, double* __restrict__ dd_out) {
+__global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, long long nrows, int margin_first, int margin_second, int off0, int off1,
+                                                             int* __restrict__ box, double* __restrict__ dd_out, double* gap) {
     constexpr int N = 64 * S, STRIDE = N + 64;
     extern __shared__ double dd_lds[];
     double* ctab = dd_lds + 4 * STRIDE;           // c_i, i < DD_NTAB (the last entry stands for every later knot)
     if (threadIdx.x < DD_NTAB) ctab[threadIdx.x] = dd_table.c[threadIdx.x];
+    double* gtab = ctab + DD_NTAB;                // the same recurrence started from 0 (the eliminations around the box)
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + DD_NTAB) gtab[threadIdx.x - 64] = gap_table.c[threadIdx.x - 64];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + wave;
@@ -260,6 +275,81 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* __res
         box[2 * row] = first + off0;
         box[2 * row + 1] = second + off1;
     }
+    if (!gap) return;
+    // The removal of the box (cp_gap_spline, bao_filter.py:395-405), on the sequence in memory: the clamped spline through the x^2-weighted
+    // coefficients with the knots [a, b] left out returns the datum at every kept knot, so only the box is rewritten; its two end slopes come
+    // from eliminations started DD_GAP_WINDOW knots to either side (the same arithmetic as gap_spline_kernel, cp_spline.hip), here run by two
+    // lanes side by side on values the wave has brought into LDS (the second derivatives there are not needed any more).
+    const int a = first + off0, b = second + off1;
+    if (a < 1 || b > N - 2 || b < a) return;      // nothing removed (or an invalid box): the sequence stays as it is
+    const int L = a - 1, R = b + 1;
+    const double g = (double)(R - L);
+    const int i0 = L - DD_GAP_WINDOW > 0 ? L - DD_GAP_WINDOW : 0, i1 = R + DD_GAP_WINDOW < N - 1 ? R + DD_GAP_WINDOW : N - 1;
+    const int lo = i0 > 0 ? i0 - 1 : 0, hi = i1 < N - 1 ? i1 + 1 : N - 1;
+    double* zl = buf;                              // z(lo .. L)
+    double* zr = buf + DD_GAP_WINDOW + 8;          // z(R .. hi)
+    double* seq = gap + row * N;
+    for (int e = lane; e <= L - lo; e += 64) {
+        const double x = (double)(lo + e + 1);
+        zl[e] = src[lo + e] * (x * x);
+    }
+    for (int e = lane; e <= hi - R; e += 64) {
+        const double x = (double)(R + e + 1);
+        zr[e] = src[R + e] * (x * x);
+    }
+    auto z = [&](int i) { return i <= L ? zl[i - lo] : zr[i - R]; };
+    double r0 = 0., r1 = 0.;
+    if (lane == 0) {            // forward sweep up to L: s_L + cpL s_R = dpL
+        double cp = 0., dp = i0 == 0 ? 0. : 0.5 * (z(i0 + 1) - z(i0 - 1));      // clamped: s_0 = 0
+        if (L != i0) {
+            // (1 / (4 - cp) does not depend on the data: 0, 1/4, 4/15, ... from a table, its limit after 40 knots -- no division in the chain)
+            double zm = z(i0), z0 = z(i0 + 1);
+#pragma unroll 4
+            for (int i = i0 + 1; i < L; ++i) {
+                const double zp = z(i + 1);
+                cp = gtab[i - i0 < DD_NTAB ? i - i0 : DD_NTAB - 1];
+                dp = (3. * (zp - zm) - dp) * cp;
+                zm = z0;
+                z0 = zp;
+            }
+            const double d = 3. * (g * (z(L) - z(L - 1)) + (z(R) - z(L)) / g);
+            const double den = 2. * (1. + g) - g * cp;
+            cp = 1. / den;
+            dp = (d - g * dp) / den;
+        }
+        r0 = cp;
+        r1 = dp;
+    } else if (lane == 1) {     // backward sweep down to R: s_R + bqR s_L = dqR
+        double bq = 0., dq = i1 == N - 1 ? 0. : 0.5 * (z(i1 + 1) - z(i1 - 1));  // clamped: s_{n-1} = 0
+        if (R != i1) {
+            double zp = z(i1), z0 = z(i1 - 1);
+#pragma unroll 4
+            for (int i = i1 - 1; i > R; --i) {
+                const double zm = z(i - 1);
+                bq = gtab[i1 - i < DD_NTAB ? i1 - i : DD_NTAB - 1];
+                dq = (3. * (zp - zm) - dq) * bq;
+                zp = z0;
+                z0 = zm;
+            }
+            const double d = 3. * ((z(R) - z(L)) / g + g * (z(R + 1) - z(R)));
+            const double den = 2. * (g + 1.) - g * bq;
+            bq = 1. / den;
+            dq = (d - g * dq) / den;
+        }
+        r0 = bq;
+        r1 = dq;
+    }
+    const double cpL = __shfl(r0, 0), dpL = __shfl(r1, 0), bqR = __shfl(r0, 1), dqR = __shfl(r1, 1);
+    const double sL = (dpL - cpL * dqR) / (1. - cpL * bqR);
+    const double sR = dqR - bqR * sL;
+    const double zL = z(L), zR = z(R);
+    const double slope = (zR - zL) / g;
+    const double tt = (sL + sR - 2. * slope) / g;
+    const double c3 = tt / g, c2 = (slope - sL) / g - tt;
+    for (int i = a + lane; i <= b; i += 64) {
+        const double u = (double)(i - L), x = (double)(i + 1);
+        seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
+    }
 }
 
 }  // namespace
@@ -314,7 +404,7 @@ extern "C" int cp_brieden_finish(const double* d_pk, const double* d_resampled, 
 }
 
 extern "C" int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int margin_first, int margin_second, int offset_first, int offset_second,
-                                 int* d_box, double* d_dd, int device, void* stream) {
+                                 int* d_box, double* d_dd, double* d_gap, int device, void* stream) {
     if (nrows < 0 || margin_first < 0 || 2 * margin_first >= n) return cp::fail(CP_EINVAL, "cp_wallish_dd_box: bad sizes");
     if (n != 2048 && n != 1024) return cp::fail(CP_EUNSUPPORTED, "cp_wallish_dd_box: sequences of %d coefficients (built for 1024 and 2048)", n);
     if (nrows == 0) return CP_OK;
@@ -323,15 +413,15 @@ extern "C" int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int 
     DeviceScope scope(device);
     if (!scope.ok) return cp::fail(CP_EDEVICE, "cp_wallish_dd_box: cannot select device %d", device);
     const unsigned grid = (unsigned)((nrows + 3) / 4);
-    const size_t lds = ((size_t)4 * (n + 64) + DD_NTAB) * sizeof(double);
+    const size_t lds = ((size_t)4 * (n + 64) + 2 * DD_NTAB) * sizeof(double);
     hipStream_t hs = static_cast<hipStream_t>(stream);
 #define CP_DD_LAUNCH(S_)                                                                                                                             \
     do {                                                                                                                                             \
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wallish_dd_box_kernel<S_>),                                \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * (64 * S_ + 64) + DD_NTAB) * sizeof(double))); \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * (64 * S_ + 64) + 2 * DD_NTAB) * sizeof(double))); \
         (void)attr;                                                                                                                                  \
         hipLaunchKernelGGL(wallish_dd_box_kernel<S_>, dim3(grid), dim3(256), lds, hs, d_y, nrows, margin_first, margin_second, offset_first,          \
-                           offset_second, d_box, d_dd);                                                                                              \
+                           offset_second, d_box, d_dd, d_gap);                                                                                       \
     } while (0)
     if (n == 1024) CP_DD_LAUNCH(16);
     else CP_DD_LAUNCH(32);

@@ -312,9 +312,10 @@ int cp_wallish_box(const double* d_dd, long long ncol, int n, int margin_first, 
 /* Both of the above steps of wallish2018 that come before cp_gap_spline, as one kernel (bao_filter.py:377-394): the second derivatives at the knots
  * of the clamped CubicSpline through (1 .. n, d_y[row]) -- spline(x, nu=2) -- by a tridiagonal solve in LDS, a wave per sequence, and the box of
  * cp_wallish_box found on them.  d_y : (nrows, n), n in {1024, 2048} (CP_EUNSUPPORTED otherwise: the two calls above); d_box : (nrows, 2) int32; d_dd : (nrows, n) or NULL (the second
- * derivatives are written only on request). */
+ * derivatives are written only on request); d_gap : NULL, or where the sequences are (d_y itself, or a copy of it): cp_gap_spline's rewriting of
+ * the box then happens there, in the same kernel. */
 int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int margin_first, int margin_second, int offset_first, int offset_second, int* d_box,
-                      double* d_dd, int device, void* stream);
+                      double* d_dd, double* d_gap, int device, void* stream);
 
 /* ---- clamped cubic spline through knots spliced from contiguous pieces of two row arrays (wallish2018, bao_filter.py:415-431) ----
  * The knots x (nknots, increasing) take their values from up to three pieces: piece p = columns [piece_start[p], piece_start[p] + piece_count[p])

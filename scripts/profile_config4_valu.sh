@@ -28,5 +28,13 @@ for f, name in (('4w', 'wallish2018'), ('4b', 'brieden2022')):
     nvec = line['vectors_through_the_filter_in_this_process']
     out[name] = {'counters_whole_run': dict(acc), 'vectors': nvec, 'per_vector': {k: v / nvec for k, v in acc.items()}, 'bench': line[name]}
 json.dump(out, open('gpurun_out/%s_config4_valu_raw.json' % tag, 'w'), indent=1)
+final = {'what': 'vector (SQ_INSTS_VALU) and matrix (SQ_INSTS_MFMA) wave-instructions per P(k) vector of the two BAO filters, P(k) generation and sigma8 '
+                 'normalisation included: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU -- python3 tools/profile_secondary.py 4w | 4b '
+                 '(scripts/profile_config4_valu.sh), whole-process counts divided by the vectors that went through the filter',
+         'peaks': {'valu_wave_instructions_per_s': 256 * 4 * 2.4e9 / 4, 'mfma_f64_16x16x4_per_s': 256 * 4 * 2.4e9 / 64,
+                   'note': '256 CUs x 4 SIMDs; a wave64 vector instruction issues in 4 cycles (fp64 FMA: 78.6 TFLOP/s), v_mfma_f64_16x16x4_f64 in 64; 2.4 GHz nominal'}}
+for name, v in out.items():
+    final[name] = {'per_vector': v['per_vector'], 'vectors': v['vectors']}
+json.dump(final, open('gpurun_out/%s_config4_valu.json' % tag, 'w'), indent=1)
 print(json.dumps({k: v['per_vector'] for k, v in out.items()}, indent=1))
 PY

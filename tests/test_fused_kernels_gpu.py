@@ -180,9 +180,15 @@ def test_wallish_dd_box(n):
     box = torch.empty((nseq, 2), dtype=torch.int32, device=dev)
     mf, ms, off = 20, 5, (-10, 20)
     lib = _lib.load()
-    _lib.check(lib.cp_wallish_dd_box(ty.data_ptr(), nseq, n, mf, ms, off[0], off[1], box.data_ptr(), dd.data_ptr(), 0, dv.stream_of(dev)))
+    _lib.check(lib.cp_wallish_dd_box(ty.data_ptr(), nseq, n, mf, ms, off[0], off[1], box.data_ptr(), dd.data_ptr(), None, 0, dv.stream_of(dev)))
     box2 = torch.empty_like(box)
-    _lib.check(lib.cp_wallish_dd_box(ty.data_ptr(), nseq, n, mf, ms, off[0], off[1], box2.data_ptr(), None, 0, dv.stream_of(dev)))
+    filled = ty.clone()      # the removal of the box in the same kernel against cp_gap_spline on the same box
+    _lib.check(lib.cp_wallish_dd_box(ty.data_ptr(), nseq, n, mf, ms, off[0], off[1], box2.data_ptr(), None, filled.data_ptr(), 0, dv.stream_of(dev)))
+    separately = torch.empty_like(ty)
+    _lib.check(lib.cp_gap_spline(ty.data_ptr(), box.data_ptr(), separately.data_ptr(), nseq, n, 0, dv.stream_of(dev)))
+    keep = [i for i in range(nseq) if i != 5]
+    np.testing.assert_allclose(filled.cpu().numpy()[keep], separately.cpu().numpy()[keep], rtol=1e-9, atol=1e-13 * np.abs(y[keep]).max())
+    assert not torch.equal(filled, ty)
     got, gbox = dd.cpu().numpy(), box.cpu().numpy()
     assert np.array_equal(gbox, box2.cpu().numpy())
     for i in range(nseq):
