@@ -29,6 +29,11 @@ t0 = disp[0][0]
 dur = lambda rows: [(e - s) * 1e-6 for s, e, *_ in rows]      # noqa: E731  (ms)
 ramp = [d for d in disp if d[0] - t0 < RAMP_NS]
 steady = [d for d in disp if d[0] - t0 >= RAMP_NS]
+# ... up to the first idle period: behind the timed steps the bench checks rows against the oracle on the host (seconds), and what it launches
+# after that (the `value_api` measurement) starts from an idle device again -- those dispatches are listed apart
+IDLE_NS = 20e6
+cut = next((i for i in range(1, len(steady)) if steady[i][0] - steady[i - 1][1] > IDLE_NS), len(steady))
+after_idle, steady = steady[cut:], steady[:cut]
 
 
 def summary(rows):
@@ -47,7 +52,7 @@ out = {
     'command': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary',
     'kernel': 'cpfft::fftlog_kernel<4096, 16, 3, 1>', 'rows_per_launch': ROWS, 'algorithmic_bytes_per_launch': ROWS * BYTES_PER_ROW,
     'vgpr_count': disp[0][2], 'grid': disp[0][3], 'lds_bytes': disp[0][4],
-    'all_dispatches': summary(disp), 'ramp_first_300ms': summary(ramp), 'steady_state': summary(steady),
+    'all_dispatches': summary(disp), 'ramp_first_300ms': summary(ramp), 'steady_state': summary(steady), 'after_an_idle_period_of_the_process': summary(after_idle),
     'same_run_bench_line': None if bench_line is None else {'kernel_ms_hip_events': bench_line['roofline']['kernel_ms'], 'frac': bench_line['roofline']['frac'],
                                                             'ms_per_step': bench_line['ms_per_step'], 'value': bench_line['value']},
 }
