@@ -411,22 +411,29 @@ class BaseCosmoParams(dv.Copyable):
             return default
         raise CosmologyError('Parameter {} not found.'.format(name))
 
+    def _h2(self):
+        """h^2, kept with the derived values: half a dozen derivations use it, and for a batch of cosmologies every square is a device kernel."""
+        memo = self.__dict__.setdefault('_derived_memo', {})
+        if '_h2' not in memo:
+            memo['_h2'] = self._params['h']**2
+        return memo['_h2']
+
     def _derive(self, name):
         """``name`` from the compiled parameters, ``_missing`` if it is not a derived parameter."""
         params = self._params
         c, sb, rck = bgmod_constants()
         if name.startswith('omega'):
-            return self.get('O' + name[1:]) * params['h']**2
+            return self.get('O' + name[1:]) * self._h2()
         if name == 'H0':
             return params['h'] * 100
         if name in ['logA', 'ln10^{10}A_s', 'ln10^10A_s', 'ln_A_s_1e10'] and 'A_s' in params:
             return np.log(1e10 * params['A_s'])
         if name == 'Omega_g':
-            return params['T_cmb']**4 * 4. / c**3 * sb / (params['h']**2 * rck)
+            return params['T_cmb']**4 * 4. / c**3 * sb / (self._h2() * rck)
         if name == 'T_ur':
             return params['T_cmb'] * (4. / 11.)**(1. / 3.)
         if name == 'Omega_ur':
-            return params['N_ur'] * 7. / 8. * self.get('T_ur')**4 * 4. / c**3 * sb / (params['h']**2 * rck)
+            return params['N_ur'] * 7. / 8. * self.get('T_ur')**4 * 4. / c**3 * sb / (self._h2() * rck)
         if name == 'Omega_r':
             return self.get('Omega_g') + self.get('Omega_ur') + self._like(self.get('Omega_pncdm_tot'))
         if name == 'N_ncdm':
@@ -535,6 +542,9 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
 
     def __init__(self, cosmo, device=None, **extra_params):
         self._params = dict(cosmo._params)
+        # derived parameters depend on the parameters only: the engines of one cosmology (and the cosmology) keep them in one place -- a second
+        # engine (the no-wiggle template of a filter, say) then derives nothing again (each derivation is a few tiny device kernels for a batch)
+        self._derived_memo = cosmo.__dict__.setdefault('_derived_memo', {})
         self._extra_params = extra_params
         self._rsigma8 = None
         self.device = dv.resolve_device(device if device is not None else getattr(cosmo, '_device', None), *self._params.values())
