@@ -248,3 +248,42 @@ def test_spliced_clamped_spline():
         ref = interpolate.CubicSpline(x, y[i], bc_type='clamped', extrapolate=False)(xq)
         assert np.isnan(got[i][0]) and np.isnan(got[i][-1])
         np.testing.assert_allclose(got[i][1:-1], ref[1:-1], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize('bc', ['natural', 'clamped'])
+def test_spline_rows(bc):
+    """cp_spline_rows_* (the spline's tridiagonal system solved per row in LDS, only the knots the queries can see) against scipy's CubicSpline and
+    against the operator route, for the three rows-per-wave layouts: a short window of a long geometric grid (the FFTLog output -> radii step of
+    sigma_r), a medium one, and all knots; root, scale and the grouped store; queries outside the knots; a row holding NaN stays alone."""
+    import torch
+    from scipy import interpolate
+    from cosmoprimo_amd.spline import SplineRows, LinearOperator
+    rng = np.random.default_rng(5)
+    dev = torch.device('cuda', 0)
+    outside = lambda q: np.concatenate([[1e-3], q, [2e7]])
+    cases = [(1024, np.geomspace(1., 100., 256), 4), (1024, np.geomspace(0.1, 3e3, 300), 2), (1024, outside(np.geomspace(1e-2, 1e7, 500)), 2),
+             (2000, outside(np.geomspace(1e-2, 1e7, 700)), 1)]
+    for n, xq, rows_per_wave in cases:
+        x = np.geomspace(1e-2, 1e7, n)
+        op = SplineRows(x, xq, bc=bc, device=dev)
+        first, nknots, rpw, halo = op.window
+        assert rpw == rows_per_wave, (op.window, rows_per_wave)
+        y = rng.uniform(0.5, 1.5, size=(3, 7, n)) * (1. + x / 50.)**-1.5
+        ty = torch.as_tensor(y, device=dev)
+        got = op(ty).cpu().numpy()
+        ref = interpolate.CubicSpline(x, y, axis=-1, bc_type=bc, extrapolate=False)(xq)
+        inside = (xq >= x[0]) & (xq <= x[-1])
+        assert np.isnan(got[..., ~inside]).all()
+        np.testing.assert_allclose(got[..., inside], ref[..., inside], rtol=1e-11)
+        banded = LinearOperator.spline(x, xq, bc=bc, device=dev)
+        np.testing.assert_allclose(got[..., inside], banded(ty).cpu().numpy()[..., inside], rtol=1e-11)
+        rooted = op(ty, sqrt=True, scale=0.25, last_axis_first=True).cpu().numpy()      # (3, nq, 7)
+        np.testing.assert_allclose(rooted[:, inside], np.sqrt(0.25 * ref).transpose(0, 2, 1)[:, inside], rtol=1e-11)
+        bad = y.copy()
+        bad[1, 3, first + nknots // 2] = np.nan
+        gotb = op(torch.as_tensor(bad, device=dev)).cpu().numpy()
+        mask = np.ones(got.shape[:2], dtype=bool)
+        mask[1, 3] = False
+        assert np.array_equal(gotb[mask], got[mask], equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        SplineRows(x, cases[0][1], bc='not-a-knot', device=dev)

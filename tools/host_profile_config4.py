@@ -44,3 +44,10 @@ prof.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(prof)
 st.sort_stats('cumulative').print_stats(45)
+if len(sys.argv) > 2:      # who calls the small tensor operations
+    import io
+    buf = io.StringIO()
+    st = pstats.Stats(prof, stream=buf)
+    st.print_callers('TensorBase|_tensor.py|torch._C._VariableFunctions')
+    lines = [l for l in buf.getvalue().splitlines() if 'cosmoprimo_amd' in l or 'was called by' in l or '<-' in l or 'TensorBase' in l or '_VariableFunctions' in l]
+    print('\n'.join(lines[:150]))
