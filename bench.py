@@ -217,11 +217,20 @@ def config4(cp, torch, dev, par, chunk=16384, engines=('wallish2018', 'brieden20
     return out
 
 
-# comoving_radial_distance, fresh cosmology per sample: 237 evaluations of 1 / E(z) on the 119-knot Simpson grid, each ~13 fp64 operations of
-# the polynomial part + exp (~22) + rsqrt (~9), plus the Simpson sums and the two-sided natural-spline elimination (~12 per knot): the count
-# of fp64 VALU instructions of bg_kernel per sample (tools/isa_census.py on cp_background.hip)
-CONFIG5_FLOP_PER_SAMPLE = 237 * 44 + 119 * 12
-FP64_VECTOR_PEAK_TFLOPS = 78.6
+def _config5_valu_roofline(samples_per_s):
+    """Vector-instruction roofline of config 5 from the committed census (profiles/*_config5_valu.json: SQ_INSTS_VALU of bg_kernel per sample,
+    tools/census_config5.sh): what bounds the kernel is the issue rate of the vector pipes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_config5_valu.json')))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        per = json.load(fh)['per_sample']
+    peak = 256 * 4 * 2.4e9 / 4
+    achieved = per['SQ_INSTS_VALU'] * samples_per_s
+    return {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': achieved, 'peak': peak, 'unit': 'wave-instructions/s',
+            'frac': achieved / peak, 'valu_wave_instructions_per_sample': per['SQ_INSTS_VALU'], 'valu_instructions_per_thread': 64 * per['SQ_INSTS_VALU'],
+            'source': os.path.relpath(files[-1], ROOT)}
 
 
 def config5(torch, dev, om, w0, wa, zz, reps=5):
@@ -229,11 +238,11 @@ def config5(torch, dev, om, w0, wa, zz, reps=5):
     n = int(zz.numel())
     wall, gpu = _gpu_ms(lambda: background.distance('comoving_radial_distance', zz[:, None], dict(w0_fld=w0, wa_fld=wa), Omega_m=om, per_cosmology_z=True),
                         reps, torch, dev)
-    tflops = n * CONFIG5_FLOP_PER_SAMPLE / (wall * 1e-3) / 1e12
     return {'workload': 'config 5: comoving_radial_distance for %d (Omega_m, w0, wa, z) samples, one fresh cosmology per sample' % n,
             'value': n / (wall * 1e-3), 'unit': 'samples/s', 'ms': wall, 'ms_gpu_events': gpu,
-            'roofline': {'bound': 'fp64 valu', 'achieved': tflops, 'peak': FP64_VECTOR_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': tflops / FP64_VECTOR_PEAK_TFLOPS,
-                         'flop_per_sample': CONFIG5_FLOP_PER_SAMPLE, 'hbm_GBps': n * 40 / (wall * 1e-3) / 1e9}}
+            # what bounds the kernel is the issue rate of the vector pipes: every vector instruction it executes, counted by the profiler
+            # (the intervals a sample needs -- those below it and `reach` above it -- times two ordinates of ~44 instructions, plus the eliminations)
+            'roofline': dict(_config5_valu_roofline(n / (wall * 1e-3)) or {}, hbm_GBps=n * 40 / (wall * 1e-3) / 1e9)}
 
 
 def config5_samples(n, seed, torch, dev):

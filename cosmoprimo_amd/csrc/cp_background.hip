@@ -37,6 +37,7 @@ struct TablesN {
     double zc[NK], dx[NK], l[NK], u[NK], idf[NK], idb[NK], cp[NK], bq[NK], ra[NK], rb[NK];
     // log(1 + z) and 1 / (1 + z) at the knots and at the interval midpoints zc + dx / 2: every integrand ordinate is one of them
     double lk[NK], lm[NK], ik[NK], im[NK];
+    int reach, reach_pad;     // knots after which the backward elimination has forgotten its start (1e-18 left)
 };
 using Tables = TablesN<NK_DIST>;
 
@@ -144,13 +145,45 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     }
     const int k = lo;
     const double f_first = integrand(T.zc[0], T.lk[0], T.ik[0]);
-    const double f_last = integrand(T.zc[NK - 1], T.lk[NK - 1], T.ik[NK - 1]);
     double total = 0.;          // TIME: T_last = sum of all increments
     double fprev = f_first;     // integrand at the shared end of the previous interval
     double tk = 0.;             // T_k = sum of inc_i, i < k, accumulated in knot order like the reference's scan
     double inc_prev = 0.;       // inc of the previously processed interval (idx - 1 going up, idx + 1 going down)
     double inc_k = 0.;          // inc of interval k (needed by both eliminations)
     double dp = 0., dq = 0.;    // running right-hand sides of the forward / backward eliminations
+    if (!TIME) {
+        // The intervals 0 .. k in knot order (the integral up to the sample and the forward elimination, exact), then the intervals above the
+        // sample from `reach` knots above it downwards: the backward elimination forgets where it started at the rate of its multipliers
+        // u_j / pivot_j (T.reach: after that many knots 1e-18 is left, build_pivots), so the grid above -- it runs to z = 9999, a sample at
+        // z < 3 sits in interval 31 at most -- contributes nothing a double can hold.  65 intervals instead of 118 for config 5, and within a
+        // pass all lanes that are still busy walk the same interval: the table reads are broadcasts.
+        for (int idx = 0; idx <= k; ++idx) {
+            const double h = T.dx[idx];
+            const double fm = integrand(T.zc[idx] + h / 2, T.lm[idx], T.im[idx]);
+            const double fe = integrand(T.zc[idx + 1], T.lk[idx + 1], T.ik[idx + 1]);
+            const double inc = h / 6. * (fprev + 2 * fm + 2 * fm + fe);  // jax.py:709 with k2 == k3
+            fprev = fe;
+            const double d = T.ra[idx] * inc_prev + T.rb[idx] * inc;      // knot idx: d = ra * inc_{idx-1} + rb * inc_idx
+            dp = (d - T.l[idx] * dp) * T.idf[idx];
+            if (idx < k) tk = tk + inc;
+            inc_k = inc;
+            inc_prev = inc;
+        }
+        const int top = k + 1 + T.reach < NK - 1 ? k + 1 + T.reach : NK - 1;      // intervals k + 1 .. top - 1, visited top down
+        fprev = integrand(T.zc[top], T.lk[top], T.ik[top]);
+        inc_prev = 0.;
+        for (int idx = top - 1; idx > k; --idx) {
+            const double h = T.dx[idx];
+            const double fm = integrand(T.zc[idx] + h / 2, T.lm[idx], T.im[idx]);
+            const double fe = integrand(T.zc[idx], T.lk[idx], T.ik[idx]);
+            const double inc = h / 6. * (fe + 2 * fm + 2 * fm + fprev);
+            fprev = fe;
+            const double d = T.ra[idx + 1] * inc + T.rb[idx + 1] * inc_prev;      // knot idx + 1: d = ra * inc_idx + rb * inc_{idx+1}
+            dq = (d - T.u[idx + 1] * dq) * T.idb[idx + 1];
+            inc_prev = inc;
+        }
+    } else {
+    const double f_last = integrand(T.zc[NK - 1], T.lk[NK - 1], T.ik[NK - 1]);
     for (int it = 0; it < NK - 1; ++it) {
         const bool fwd = it <= k;
         const int idx = fwd ? it : (NK - 1) - it + k;  // k+1 .. 117 visited top down
@@ -178,8 +211,9 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         }
         inc_prev = inc;
     }
+    }
     {   // knot k + 1 closes the backward elimination: intervals k (from the forward sweep) and k + 1
-        const double inc_up = (k == NK - 2) ? 0. : inc_prev;  // inc_{k+1}: the last interval visited going down
+        const double inc_up = (k == NK - 2) ? 0. : inc_prev;  // inc_{k+1}: the last interval visited going down (none above the last interval)
         const double d = T.ra[k + 1] * inc_k + T.rb[k + 1] * inc_up;
         dq = (d - T.u[k + 1] * dq) * T.idb[k + 1];
     }
@@ -241,6 +275,17 @@ void build_pivots(TablesN<NK>& t) {
     for (int i = n - 2; i >= 0; --i) {
         t.idb[i] = 1. / (b[i] - t.u[i] * t.bq[i + 1]);
         t.bq[i] = t.l[i] * t.idb[i];
+    }
+    // dq_j = (d_j - u_j dq_{j+1}) / pivot_j: what a start at knot j + r leaves at knot j is the product of the r multipliers u / pivot in between
+    t.reach_pad = 0;
+    for (t.reach = 8; t.reach < n; t.reach += 4) {
+        double worst = 0.;
+        for (int j = 1; j + t.reach < n; ++j) {
+            double f = 1.;
+            for (int r = 0; r < t.reach; ++r) f *= std::fabs(t.u[j + r] * t.idb[j + r]);
+            worst = f > worst ? f : worst;
+        }
+        if (worst < 1e-18) break;
     }
 }
 
