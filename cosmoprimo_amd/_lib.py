@@ -80,6 +80,7 @@ SIGNATURES = {
     'cp_tables_rows': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     'cp_spline_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_spline_plan_info': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, _c_int_p]),
+    'cp_spline_columns_scratch_doubles': (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
     'cp_spline_columns': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_wallish_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,

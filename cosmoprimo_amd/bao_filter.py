@@ -467,7 +467,7 @@ def _brieden_compute_batched(self, rescale):
     _lib.check(lib.cp_brieden_knots(envelope.data_ptr(), pknow.data_ptr(), const['ratio_now_fid'].data_ptr(), const['k_fid'].data_ptr(), rescale.data_ptr(),
                                     float(interp.extrap_kmin), float(interp.extrap_kmax), xk.data_ptr(), yk.data_ptr(), nb, n, self.device.index, stream))
     out = torch.empty((n, nb), dtype=torch.float64, device=self.device)
-    scratch = torch.empty((2, n + 4, nb), dtype=torch.float64, device=self.device)
+    scratch = torch.empty(int(lib.cp_spline_columns_scratch_doubles(nb, n + 4)), dtype=torch.float64, device=self.device)
     _lib.check(lib.cp_spline_columns(xk.data_ptr(), yk.data_ptr(), nb, n + 4, const['log_k_fid'].data_ptr(), n, out.data_ptr(), scratch.data_ptr(),
                                      self.device.index, stream))
     # the input spectra with 10^(re-sampled) written over the k_fid range (bao_filter.py:509): one pass

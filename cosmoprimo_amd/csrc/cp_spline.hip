@@ -1210,85 +1210,119 @@ extern "C" int cp_wallish_box(const double* d_dd, long long ncol, int n, int mar
 // fly from the top interval down.  Queries outside a column's knots give NaN (Interpolator1D, jax.py:200).
 namespace {
 
-__global__ __launch_bounds__(256) void column_spline_kernel(const double* __restrict__ xk, const double* __restrict__ yk, long long ncol, int n,
-                                                           const double* __restrict__ xq, int nq, double* __restrict__ out,
-                                                           double* __restrict__ scratch) {
-    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// Each column is cut in `parts` runs of intervals, a thread per (part, column): the system of a natural spline is diagonally dominant, its
+// elimination forgets where it started by a factor <= 0.27 per knot, so a part eliminates from COL_HALO knots below its run to COL_HALO knots
+// above it -- treating those two knots as if the spline ended there -- and has its own slopes to 1e-18.  Four times the threads (the kernel
+// waits on memory: a wave per CU could not hide it) on chains a third as long.
+constexpr int COL_HALO = 32;
+
+__host__ __device__ inline int column_parts(int n) {
+    const int p = (n - 1) / 80;
+    return p < 1 ? 1 : (p > 8 ? 8 : p);
+}
+__host__ __device__ inline int column_run(int n) { return (n - 1 + column_parts(n) - 1) / column_parts(n); }      // intervals per part
+__host__ __device__ inline int column_span(int n) { return column_run(n) + 2 * COL_HALO + 2; }                       // knots a part eliminates, at most
+
+__global__ __launch_bounds__(64) void column_spline_kernel(const double* __restrict__ xk, const double* __restrict__ yk, long long ncol, int n,
+                                                          const double* __restrict__ xq, int nq, double* __restrict__ out,
+                                                          double* __restrict__ scratch) {
+    const long long ncol_r = (ncol + 63) / 64 * 64;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int part = (int)(g / ncol_r);
+    const long long c = g - part * ncol_r;
     if (c >= ncol) return;
-    double* cp = scratch + c;                 // (n, ncol)
-    double* dp = scratch + (long long)n * ncol + c;
+    const int run = column_run(n), span = column_span(n);
+    const int a = part * run, b = a + run < n - 1 ? a + run : n - 1;      // the part evaluates the intervals [a, b)
+    if (a >= b) return;
+    const int f0 = a - COL_HALO > 0 ? a - COL_HALO : 0, f1 = b + COL_HALO < n - 1 ? b + COL_HALO : n - 1;      // ... and eliminates the knots f0 .. f1
+    double* cp = scratch + (long long)part * 2 * span * ncol + c;      // (span, ncol) of this part, local index = knot - f0
+    double* dp = cp + (long long)span * ncol;
     auto X = [&](int i) { return xk[(long long)i * ncol + c]; };
     auto Y = [&](int i) { return yk[(long long)i * ncol + c]; };
-    // forward elimination of the system for the knot derivatives (scipy CubicSpline, bc_type='natural')
-    double x0 = X(0), x1 = X(1), y0 = Y(0), y1 = Y(1);
-    double dxm = x1 - x0, slm = (y1 - y0) / dxm;   // left interval of knot 1
+    // forward elimination of the system for the knot derivatives (scipy CubicSpline, bc_type='natural'), the first knot as a natural end
+    double x0 = X(f0), x1 = X(f0 + 1), y0 = Y(f0), y1 = Y(f0 + 1);
+    double dxm = x1 - x0, slm = (y1 - y0) / dxm;   // left interval of knot f0 + 1
     double cprev = 0.5, dprev = 3. * slm / 2.;     // row 0: 2 dx0 s0 + dx0 s1 = 3 dx0 slope0
     cp[0] = cprev;
     dp[0] = dprev;
-    // the sweeps are chains of dependent divisions fed by one knot per step: with a handful of waves per CU nothing hides the latency of a load
-    // issued when its value is needed (1.5 us per knot), so the knots of the next CHUNK steps are fetched together, ahead of the arithmetic
+    // the sweeps are chains of dependent divisions fed by one knot per step: the knots of the next CHUNK steps are fetched together, ahead of
+    // the arithmetic
     constexpr int CHUNK = 8;
-    for (int i0 = 1; i0 < n - 1; i0 += CHUNK) {
+    for (int i0 = f0 + 1; i0 < f1; i0 += CHUNK) {
         double xs[CHUNK], ys[CHUNK];
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
-            const int j = i0 + u + 1 < n ? i0 + u + 1 : n - 1;
+            const int j = i0 + u + 1 < f1 ? i0 + u + 1 : f1;
             xs[u] = X(j);
             ys[u] = Y(j);
         }
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
             const int i = i0 + u;
-            if (i < n - 1) {
+            if (i < f1) {
                 const double x2 = xs[u], y2 = ys[u];
                 const double dxp = x2 - x1, slp = (y2 - y1) / dxp;
                 // dxp s_{i-1} + 2 (dxm + dxp) s_i + dxm s_{i+1} = 3 (dxp slm + dxm slp)
                 const double den = 2. * (dxm + dxp) - dxp * cprev;
                 cprev = dxm / den;
                 dprev = (3. * (dxp * slm + dxm * slp) - dxp * dprev) / den;
-                cp[(long long)i * ncol] = cprev;
-                dp[(long long)i * ncol] = dprev;
+                cp[(long long)(i - f0) * ncol] = cprev;
+                dp[(long long)(i - f0) * ncol] = dprev;
                 x1 = x2; y1 = y2; dxm = dxp; slm = slp;
             }
         }
     }
-    // last row: dx s_{n-2} + 2 dx s_{n-1} = 3 dx slope
+    // last row (knot f1, the last knot or a natural end in its place): dx s_{f1-1} + 2 dx s_{f1} = 3 dx slope
     double s_hi = (3. * slm - dprev) / (2. - cprev);
     const double nan = __builtin_nan("");
     int iq = nq - 1;
-    const double xtop = x1;
-    while (iq >= 0 && xq[iq] > xtop) out[(long long)iq-- * ncol + c] = nan;
-    double xh = x1, yh = y1;   // upper knot of the current interval
-    for (int i0 = n - 2; i0 >= 0; i0 -= CHUNK) {
+    const bool top = b == n - 1, bottom = a == 0;
+    if (top) {
+        const double xtop = X(n - 1);
+        while (iq >= 0 && xq[iq] > xtop) out[(long long)iq-- * ncol + c] = nan;
+    } else {      // queries at or above knot b belong to the parts above
+        const double xb = X(b);
+        while (iq >= 0 && xq[iq] >= xb) --iq;
+    }
+    double xh = x1, yh = y1;   // upper knot of the current interval (knot f1)
+    for (int i0 = f1 - 1; i0 >= a; i0 -= CHUNK) {
         double xs[CHUNK], ys[CHUNK], cs[CHUNK], ds[CHUNK];
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
-            const int j = i0 - u >= 0 ? i0 - u : 0;
+            const int j = i0 - u >= a ? i0 - u : a;
             xs[u] = X(j);
             ys[u] = Y(j);
-            cs[u] = cp[(long long)j * ncol];
-            ds[u] = dp[(long long)j * ncol];
+            cs[u] = cp[(long long)(j - f0) * ncol];
+            ds[u] = dp[(long long)(j - f0) * ncol];
         }
 #pragma unroll
         for (int u = 0; u < CHUNK; ++u) {
-            if (i0 - u < 0) continue;
+            if (i0 - u < a) continue;
             const double xl = xs[u], yl = ys[u];
             const double s_lo = ds[u] - cs[u] * s_hi;
-            const double h = xh - xl, slope = (yh - yl) / h;
-            const double tt = (s_lo + s_hi - 2. * slope) / h;
-            const double c3 = tt / h, c2 = (slope - s_lo) / h - tt;
-            while (iq >= 0 && xq[iq] >= xl) {
-                const double v = xq[iq] - xl;
-                out[(long long)iq * ncol + c] = yl + v * (s_lo + v * (c2 + v * c3));
-                --iq;
+            if (i0 - u < b) {      // an interval of this part: its queries
+                const double h = xh - xl, slope = (yh - yl) / h;
+                const double tt = (s_lo + s_hi - 2. * slope) / h;
+                const double c3 = tt / h, c2 = (slope - s_lo) / h - tt;
+                while (iq >= 0 && xq[iq] >= xl) {
+                    const double v = xq[iq] - xl;
+                    out[(long long)iq * ncol + c] = yl + v * (s_lo + v * (c2 + v * c3));
+                    --iq;
+                }
             }
             xh = xl; yh = yl; s_hi = s_lo;
         }
     }
-    while (iq >= 0) out[(long long)iq-- * ncol + c] = nan;
+    if (bottom)
+        while (iq >= 0) out[(long long)iq-- * ncol + c] = nan;
 }
 
 }  // namespace
+
+extern "C" long long cp_spline_columns_scratch_doubles(long long ncol, int n) {
+    if (ncol < 0 || n < 3) return -1;
+    return 2LL * column_parts(n) * column_span(n) * ncol;
+}
 
 extern "C" int cp_spline_columns(const double* d_xk, const double* d_yk, long long ncol, int n, const double* d_xq, int nq, double* d_out,
                                  double* d_scratch, int device, void* stream) {
@@ -1298,8 +1332,8 @@ extern "C" int cp_spline_columns(const double* d_xk, const double* d_yk, long lo
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_columns: cannot select device %d", device);
-    hipLaunchKernelGGL(column_spline_kernel, dim3((unsigned)((ncol + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), d_xk, d_yk, ncol, n,
-                       d_xq, nq, d_out, d_scratch);
+    hipLaunchKernelGGL(column_spline_kernel, dim3((unsigned)((ncol + 63) / 64 * column_parts(n))), dim3(64), 0, static_cast<hipStream_t>(stream), d_xk, d_yk,
+                       ncol, n, d_xq, nq, d_out, d_scratch);
     hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_columns: launch failed: %s", hipGetErrorString(e));

@@ -363,7 +363,9 @@ int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_o
 
 /* natural cubic spline per column with per-column knots (brieden2022 re-sampling with one rs_drag ratio per column, bao_filter.py:503-509):
  * d_xk, d_yk : (n, ncol) knot-major; d_xq : (nq) ascending queries shared by all columns; d_out : (nq, ncol);
- * d_scratch : 2 * n * ncol doubles.  Queries outside a column's knots give NaN. */
+ * d_scratch : cp_spline_columns_scratch_doubles(ncol, n) doubles (the columns are cut in runs of knots eliminated side by side, each with its own
+ * scratch).  Queries outside a column's knots give NaN. */
+long long cp_spline_columns_scratch_doubles(long long ncol, int n);
 int cp_spline_columns(const double* d_xk, const double* d_yk, long long ncol, int n, const double* d_xq, int nq, double* d_out, double* d_scratch,
                       int device, void* stream);
 
