@@ -97,6 +97,7 @@ SIGNATURES = {
                                                ctypes.POINTER(ctypes.c_int)]),
     'cp_spline_rows_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p]),
+    'cp_spline_rows_second_derivatives': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]),
     'cp_spline_rows_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_gap_spline': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_wallish_finish': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -22,6 +22,7 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
+#include "cp_internal.h"
 
 namespace {
 
@@ -33,6 +34,10 @@ struct RowsTables {
     const double* tab;        // (nslots, 4): 6 / h_i, 1 / pivot_i, h_{i-1} / pivot_i, h_i / pivot_i
     const int* qj;            // (nq) interval of each query relative to w0, -1: outside the knots
     const double* qw;         // (nq, 4): A, B, (A^3 - A) h^2 / 6, (B^3 - B) h^2 / 6
+    // not-a-knot: the outermost second derivatives follow from their neighbours once the sweeps are done, M_0 = fix[0] M_1 + fix[1] M_2 and
+    // M_{n-1} = fix[2] M_{n-2} + fix[3] M_{n-3} (continuity of the third derivative at the second and the last-but-one knot)
+    int fix_first, fix_last;
+    double fix[4];
 };
 
 struct RowsArgs {
@@ -42,6 +47,7 @@ struct RowsArgs {
     int post_op, group;
     double scale;
     double* out;
+    double* out_m;            // (nrows, n_src) or null: the second derivatives at the knots of the window instead of the queries
 };
 
 __device__ __forceinline__ long long rows_out_index(long long row, int q, int nq, int group) {      // cp_spline.hip: out_index
@@ -129,6 +135,14 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
                 buf[i] = m;
             }
         }
+        if (T.fix_first && l == 0) buf[0] = T.fix[0] * buf[1] + T.fix[1] * buf[2];
+        if (T.fix_last && l == 0) buf[nw - 1] = T.fix[2] * buf[nw - 2] + T.fix[3] * buf[nw - 3];
+        if (A.out_m) {
+            double* dst = A.out_m + row * T.n_src + T.w0;
+            if (live)
+                for (int i = l; i < nw; i += LPR) dst[i] = buf[i];
+            continue;
+        }
 #pragma unroll 16
         for (int q = l; q < T.nq; q += LPR) {
             const int j = T.qj[q];
@@ -170,23 +184,38 @@ extern "C" int cp_spline_rows_plan_create(cp_spline_rows_plan** out, int n, cons
     if (!out) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: null plan pointer");
     *out = nullptr;
     if (n < 4 || !x || nq < 1 || !xq) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: bad arguments");
-    if (bc != CP_SPLINE_NATURAL && bc != CP_SPLINE_CLAMPED)
-        return cp::fail(CP_EUNSUPPORTED, "cp_spline_rows_plan_create: boundary condition %d (natural and clamped splines have a tridiagonal system; use cp_spline_plan_create)", bc);
+    if (bc != CP_SPLINE_NATURAL && bc != CP_SPLINE_CLAMPED && bc != CP_SPLINE_NOT_A_KNOT) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: unknown boundary condition %d", bc);
     for (int i = 0; i + 1 < n; ++i)
         if (!(x[i + 1] > x[i])) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: knots must increase");
-    // the system for the second derivatives and its elimination factors; natural ends: M_0 = M_{n-1} = 0, i.e. factor 0 in the outermost rows
-    std::vector<double> h(n), inv(n), c(n), q(n);
+    // the system for the second derivatives, sub_i M_{i-1} + diag_i M_i + sup_i M_{i+1} = 6 (s_i - s_{i-1}), and its elimination factors.
+    // clamped: 2 h_0 M_0 + h_0 M_1 = 6 s_0 and its mirror image; natural: M_0 = M_{n-1} = 0 (factor 0 in the outermost rows); not-a-knot: the
+    // outermost unknowns eliminated through M_0 = (1 + h_0 / h_1) M_1 - (h_0 / h_1) M_2 and its mirror image (factor 0 again, filled in afterwards)
+    std::vector<double> h(n), inv(n), c(n), q(n), sub(n), diag(n), sup(n);
     for (int i = 0; i + 1 < n; ++i) h[i] = x[i + 1] - x[i];
     h[n - 1] = h[n - 2];
-    const bool natural = bc == CP_SPLINE_NATURAL;
-    inv[0] = natural ? 0. : 1. / (2. * h[0]);
-    c[0] = h[0] * inv[0];
+    for (int i = 1; i < n - 1; ++i) {
+        sub[i] = h[i - 1];
+        diag[i] = 2. * (h[i - 1] + h[i]);
+        sup[i] = h[i];
+    }
+    sub[0] = 0.; diag[0] = 2. * h[0]; sup[0] = h[0];
+    sub[n - 1] = h[n - 2]; diag[n - 1] = 2. * h[n - 2]; sup[n - 1] = 0.;
+    const bool open_ends = bc != CP_SPLINE_CLAMPED;      // rows 0 and n - 1 are not equations of the system
+    double fix[4] = {0., 0., 0., 0.};
+    if (bc == CP_SPLINE_NOT_A_KNOT) {
+        if (n < 5) return cp::fail(CP_EUNSUPPORTED, "cp_spline_rows_plan_create: a not-a-knot spline through %d knots", n);
+        fix[0] = 1. + h[0] / h[1]; fix[1] = -h[0] / h[1];
+        fix[2] = 1. + h[n - 2] / h[n - 3]; fix[3] = -h[n - 2] / h[n - 3];
+        diag[1] += h[0] * fix[0]; sup[1] += h[0] * fix[1]; sub[1] = 0.;
+        diag[n - 2] += h[n - 2] * fix[2]; sub[n - 2] += h[n - 2] * fix[3]; sup[n - 2] = 0.;
+    }
+    inv[0] = open_ends ? 0. : 1. / diag[0];
+    c[0] = sup[0] * inv[0];
     q[0] = 0.;
     for (int i = 1; i < n; ++i) {
-        const double diag = i < n - 1 ? 2. * (h[i - 1] + h[i]) : 2. * h[n - 2];
-        inv[i] = (natural && i == n - 1) ? 0. : 1. / (diag - h[i - 1] * c[i - 1]);
-        c[i] = h[i] * inv[i];
-        q[i] = h[i - 1] * inv[i];
+        inv[i] = (open_ends && i == n - 1) ? 0. : 1. / (diag[i] - sub[i] * c[i - 1]);
+        c[i] = sup[i] * inv[i];
+        q[i] = sub[i] * inv[i];
     }
     // the queries' intervals
     std::vector<int> qj(nq);
@@ -251,6 +280,9 @@ extern "C" int cp_spline_rows_plan_create(cp_spline_rows_plan** out, int n, cons
     p->device = device;
     p->d_tab = nullptr; p->d_qj = nullptr; p->d_qw = nullptr;
     p->lds_bytes = lds;
+    p->T.fix_first = bc == CP_SPLINE_NOT_A_KNOT && w0 == 0;
+    p->T.fix_last = bc == CP_SPLINE_NOT_A_KNOT && w1 == n;
+    for (int i = 0; i < 4; ++i) p->T.fix[i] = fix[i];
     p->T.n_src = n; p->T.w0 = w0; p->T.nw = nw; p->T.nq = nq; p->T.S = S; p->T.halo = halo; p->T.R = R; p->T.nslots = nslots;
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
@@ -279,20 +311,7 @@ extern "C" int cp_spline_rows_plan_info(const cp_spline_rows_plan* p, int* first
     return CP_OK;
 }
 
-extern "C" int cp_spline_rows_apply(const cp_spline_rows_plan* p, const double* d_y, long long nrows, int post_op, double scale, int group, double* d_out,
-                                    void* stream) {
-    if (!p) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: null plan");
-    if (nrows < 0) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: negative batch");
-    if (nrows == 0) return CP_OK;
-    if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: null device pointer");
-    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: post op %d (none or sqrt)", post_op);
-    if (group < 0 || (group > 0 && nrows % group != 0)) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: %lld rows are not whole groups of %d", nrows, group);
-    int prev = -1;
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_apply: cannot select device %d", p->device);
-    RowsArgs A;
-    A.T = p->T;
-    A.y = d_y; A.nrows = nrows; A.post_op = post_op; A.group = group; A.scale = scale; A.out = d_out;
+static int launch_rows(const cp_spline_rows_plan* p, const RowsArgs& A, long long nrows, void* stream) {
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;
     const long long blocks = ((nrows + p->T.R - 1) / p->T.R + 3) / 4;
@@ -308,7 +327,50 @@ extern "C" int cp_spline_rows_apply(const cp_spline_rows_plan* p, const double* 
     else if (p->T.R == 2) hipLaunchKernelGGL(spline_rows_kernel<2>, dim3(grid), dim3(256), p->lds_bytes, hs, A);
     else hipLaunchKernelGGL(spline_rows_kernel<1>, dim3(grid), dim3(256), p->lds_bytes, hs, A);
     const hipError_t e = hipGetLastError();
-    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
-    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_apply: launch failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
+}
+
+extern "C" int cp_spline_rows_apply(const cp_spline_rows_plan* p, const double* d_y, long long nrows, int post_op, double scale, int group, double* d_out,
+                                    void* stream) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: null plan");
+    if (nrows < 0) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: negative batch");
+    if (nrows == 0) return CP_OK;
+    if (!d_y || !d_out) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: null device pointer");
+    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: post op %d (none or sqrt)", post_op);
+    if (group < 0 || (group > 0 && nrows % group != 0)) return cp::fail(CP_EINVAL, "cp_spline_rows_apply: %lld rows are not whole groups of %d", nrows, group);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_apply: cannot select device %d", p->device);
+    RowsArgs A;
+    A.T = p->T;
+    A.y = d_y; A.nrows = nrows; A.post_op = post_op; A.group = group; A.scale = scale; A.out = d_out; A.out_m = nullptr;
+    const int st = launch_rows(p, A, nrows, stream);
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    return st;
+}
+
+extern "C" int cp_spline_rows_second_derivatives(const cp_spline_rows_plan* p, const double* d_y, long long nrows, double* d_m, void* stream) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_spline_rows_second_derivatives: null plan");
+    if (nrows < 0) return cp::fail(CP_EINVAL, "cp_spline_rows_second_derivatives: negative batch");
+    if (nrows == 0) return CP_OK;
+    if (!d_y || !d_m) return cp::fail(CP_EINVAL, "cp_spline_rows_second_derivatives: null device pointer");
+    if (p->T.w0 != 0 || p->T.nw != p->T.n_src)
+        return cp::fail(CP_EUNSUPPORTED, "cp_spline_rows_second_derivatives: the plan solves the knots %d .. %d only (its queries do not span the knots)", p->T.w0, p->T.w0 + p->T.nw - 1);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_second_derivatives: cannot select device %d", p->device);
+    RowsArgs A;
+    A.T = p->T;
+    A.y = d_y; A.nrows = nrows; A.post_op = CP_SPLINE_POST_NONE; A.group = 0; A.scale = 1.; A.out = nullptr; A.out_m = d_m;
+    const int st = launch_rows(p, A, nrows, stream);
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    return st;
+}
+
+// what the two-direction kernel of cp_spline.hip needs of a plan whose queries are the output wavenumbers of (z, k) tables (cp_internal.h)
+bool cp_spline_rows_plan_view(const cp_spline_rows_plan* p, cp_spline_rows_view* out) {
+    if (!p || !out) return false;
+    *out = cp_spline_rows_view{p->T.n_src, p->T.nq, p->T.w0, p->T.nw, p->device, p->d_qj, p->d_qw};
+    return true;
 }

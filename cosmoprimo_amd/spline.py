@@ -168,10 +168,9 @@ class SplicedClampedSpline(object):
 
 class SplineRows(object):
 
-    """Natural or clamped cubic spline through fixed knots ``x`` for very many rows, evaluated at fixed queries ``xq``, by elimination in LDS
+    """Natural, clamped or not-a-knot cubic spline through fixed knots ``x`` for very many rows, evaluated at fixed queries ``xq``, by elimination in LDS
     (``cp_spline_rows_*``): the function ``LinearOperator.spline(x, xq, bc=...)`` applies as a banded operator, at a tenth of the arithmetic and
-    reading only the knots the queries can see.  Raises NotImplementedError where the scheme does not fit (other boundary conditions, very long
-    windows): use the operator then."""
+    reading only the knots the queries can see.  Raises NotImplementedError where the scheme does not fit (very long windows): use the operator then."""
 
     def __init__(self, x, xq, bc='natural', device=None):
         self.device = dv.resolve_device(device)
@@ -209,6 +208,18 @@ class SplineRows(object):
         if nrows:
             _lib.check(_lib.load().cp_spline_rows_apply(self._handle, y.data_ptr(), nrows, int(bool(sqrt)), float(scale), group, out.data_ptr(),
                                                         dv.stream_of(self.device)))
+        return out
+
+    def second_derivatives(self, y):
+        """y (..., n) -> (..., n): the second derivatives of the spline at its knots (needs queries that span the knots)."""
+        torch = dv.torch()
+        y = dv.to_device(y, self.device).contiguous()
+        if y.shape[-1] != self.n:
+            raise ValueError('last dimension must be {:d}, got {}'.format(self.n, tuple(y.shape)))
+        out = torch.empty_like(y)
+        nrows = y.numel() // self.n
+        if nrows:
+            _lib.check(_lib.load().cp_spline_rows_second_derivatives(self._handle, y.data_ptr(), nrows, out.data_ptr(), dv.stream_of(self.device)))
         return out
 
     def __del__(self):

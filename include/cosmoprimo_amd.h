@@ -332,18 +332,22 @@ int cp_splice_apply(const cp_splice_plan* plan, const double* d_src0, int n0, co
 int cp_splice_plan_destroy(cp_splice_plan* plan);
 
 /* ---- natural / clamped cubic spline of very many rows by elimination in LDS (csrc/cp_spline_rows.hip) ----
- * The same function as cp_spline_plan_create(bc = CP_SPLINE_NATURAL or CP_SPLINE_CLAMPED, nu = 0) + cp_spline_apply / cp_spline_apply_grouped
+ * The same function as cp_spline_plan_create(bc, nu = 0) + cp_spline_apply / cp_spline_apply_grouped
  * (scipy.interpolate.CubicSpline, jax.py:169-175; the FFTLog output -> radii step of sigma_r / sigma_rz, interpolator.py:285-291, 846-876), computed
  * by solving the spline's tridiagonal system per row instead of applying its inverse as a banded operator: ~10 operations per knot the queries
  * can see and 8 per query, against 64 multiply-adds per query (the matrix-core route: whole windows of knots).  Only the knots the queries touch
  * (plus a halo) are read.  d_y : (nrows, n); d_out : (nrows, nq), or (nrows / group, nq, group) for group > 0; post_op : CP_SPLINE_POST_NONE or
- * CP_SPLINE_POST_SQRT of scale x spline; queries outside the knots: NaN.  CP_EUNSUPPORTED from plan creation for other boundary conditions or
- * windows of more than a few thousand knots: use cp_spline_plan_create. */
+ * CP_SPLINE_POST_SQRT of scale x spline; queries outside the knots: NaN.  bc: any of cp_spline_bc (not-a-knot: the outermost unknowns are
+ * eliminated by hand, the system stays tridiagonal).  CP_EUNSUPPORTED from plan creation for windows of more than a few thousand knots: use
+ * cp_spline_plan_create. */
 typedef struct cp_spline_rows_plan cp_spline_rows_plan;
 int cp_spline_rows_plan_create(cp_spline_rows_plan** plan, int n, const double* x, int bc, int nq, const double* xq, int device);
 int cp_spline_rows_plan_info(const cp_spline_rows_plan* plan, int* first_knot, int* nknots, int* rows_per_wave, int* halo);
 int cp_spline_rows_apply(const cp_spline_rows_plan* plan, const double* d_y, long long nrows, int post_op, double scale, int group, double* d_out,
                          void* stream);
+/* the second derivatives of the spline at its knots, (nrows, n) -- the spline's own representation, from which any query follows by the four-term
+ * formula above; needs a plan whose queries span the knots */
+int cp_spline_rows_second_derivatives(const cp_spline_rows_plan* plan, const double* d_y, long long nrows, double* d_m, void* stream);
 int cp_spline_rows_plan_destroy(cp_spline_rows_plan* plan);
 
 /* the elementwise stages of the two filters over (nrows, n) batches of spectra, one pass each (csrc/cp_bao.hip):

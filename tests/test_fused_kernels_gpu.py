@@ -250,7 +250,7 @@ def test_spliced_clamped_spline():
         np.testing.assert_allclose(got[i][1:-1], ref[1:-1], rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize('bc', ['natural', 'clamped'])
+@pytest.mark.parametrize('bc', ['natural', 'clamped', 'not-a-knot'])
 def test_spline_rows(bc):
     """cp_spline_rows_* (the spline's tridiagonal system solved per row in LDS, only the knots the queries can see) against scipy's CubicSpline and
     against the operator route, for the three rows-per-wave layouts: a short window of a long geometric grid (the FFTLog output -> radii step of
@@ -285,5 +285,10 @@ def test_spline_rows(bc):
         mask = np.ones(got.shape[:2], dtype=bool)
         mask[1, 3] = False
         assert np.array_equal(gotb[mask], got[mask], equal_nan=True)
-    with pytest.raises(NotImplementedError):
-        SplineRows(x, cases[0][1], bc='not-a-knot', device=dev)
+    # the second derivatives at the knots (the spline's own representation)
+    x = np.sort(np.concatenate([[0.], rng.uniform(0., 9., 502), [9.]]))
+    y = rng.normal(size=(13, x.size))
+    op = SplineRows(x, x, bc=bc, device=dev)
+    got = op.second_derivatives(torch.as_tensor(y, device=dev)).cpu().numpy()
+    ref = interpolate.CubicSpline(x, y, axis=-1, bc_type=bc)(x, nu=2)
+    np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * np.abs(ref).max())
