@@ -92,13 +92,16 @@ SIGNATURES = {
     'cp_splice_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p]),
     'cp_splice_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
-    'cp_spline_rows_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int]),
+    'cp_spline_rows_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
+                                                 ctypes.c_int]),
     'cp_spline_rows_plan_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                                ctypes.POINTER(ctypes.c_int)]),
     'cp_spline_rows_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p]),
     'cp_spline_rows_second_derivatives': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]),
     'cp_spline_rows_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_tables_rows_direct': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+                                            ctypes.c_double, ctypes.c_void_p]),
     'cp_gap_spline': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_wallish_finish': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_brieden_ratio': (ctypes.c_int, [ctypes.c_void_p] * 7 + [ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),

@@ -1004,6 +1004,107 @@ __global__ __launch_bounds__(256, 2) void tables_rows_kernel(const TablesArgs A)
     }
 }
 
+// The same two directions with the k direction evaluated instead of multiplied: a cubic spline at a query is A y_j + B y_{j+1} + wM0 M_j + wM1 M_{j+1}
+// with M the second derivatives of the spline at its knots -- which belong to the table, not to the queries (cp_spline_rows_second_derivatives:
+// one tridiagonal solve per table row, kept by the caller as long as the table lives, like the coefficients scipy's RectBivariateSpline computes
+// when it is built).  The lane that holds element (row z = (l >> 4) + 4 r + 16 i, column q = q0 + 16 j + (l & 15)) of the B fragments of the z
+// contraction evaluates it from four table entries: 128 multiply-adds per lane and tile of 64 wavenumbers, where the k operator cost 224
+// MFMAs over a window of 112 knots -- the matrix cores are left with the z contraction (128 MFMAs per tile).
+struct TablesDirectArgs {
+    const double* t;     // (nbatch, nzin, n) tables, k fastest
+    const double* m;     // (nbatch, nzin, n) their second derivatives along k
+    double* out;         // (nbatch, nzq, nq)
+    long long nbatch;
+    int n, nq, nzin, nzq;
+    const int* qj;       // (nq) interval of each output wavenumber, -1: outside the knots -> NaN
+    const double* qw;    // (nq, 4)
+    const double* wz;    // (64, nz_pad) z operator, zero padded
+    int nz_pad;
+    const int* j0z;      // (nzq)
+    double scale;
+};
+
+template <int POST>
+__global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const TablesDirectArgs A) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqt = (A.nq + 255) / 256;
+    __shared__ double wl[32 * TABLES_WSTRIDE];
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+        const int q = e >> 5, kz = e & 31;
+        wl[kz * TABLES_WSTRIDE + q] = kz < A.nz_pad ? A.wz[q * A.nz_pad + kz] : 0.;
+    }
+    __syncthreads();
+    unsigned nan_z = 0u;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int zq = 16 * mi + g + 4 * r;
+            if (zq < A.nzq && A.j0z[zq] < 0) nan_z |= 1u << (4 * mi + r);
+        }
+    typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
+    for (long long item = blockIdx.x; item < A.nbatch * nqt; item += gridDim.x) {
+        const long long b = item / nqt;
+        const int q0 = (int)(item % nqt) * 256 + wave * 64;
+        if (q0 >= A.nq) continue;
+        // One column tile (16 wavenumbers: the lane's is q0 + 16 jj + (l & 15), its interval and weights from the plan) at a time: the k splines
+        // of the table's rows there, in the layout of the B fragments of the z contraction (2 x 4 registers); R = Wz L on the matrix cores (4 tiles
+        // of 16 output redshifts); f applied, rows of P(k, z) stored.
+        int rowoff[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = 16 * i + g + 4 * r;
+                row = row < A.nzin ? row : A.nzin - 1;      // rows past the table repeat its last one: Wz is zero there
+                rowoff[i][r] = row * A.n;
+            }
+        const double* tb = A.t + b * (long long)A.nzin * A.n;      // (wave-uniform)
+        const double* mb = A.m + b * (long long)A.nzin * A.n;
+        double* ob = A.out + b * (long long)A.nzq * A.nq;
+#pragma unroll 1
+        for (int jj = 0; jj < 4; ++jj) {
+            const int q = q0 + 16 * jj + l15;
+            const int qc = q < A.nq ? q : A.nq - 1;
+            const int jraw = A.qj[qc];
+            const bool nanq = jraw < 0;
+            const int jq = jraw < 0 ? 0 : jraw;
+            const double4 w = reinterpret_cast<const double4*>(A.qw)[qc];
+            cp_v4d lt[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const v2u y = *reinterpret_cast<const v2u*>(tb + rowoff[i][r] + jq), m = *reinterpret_cast<const v2u*>(mb + rowoff[i][r] + jq);
+                    lt[i][r] = w.x * y.x + w.y * y.y + (w.z * m.x + w.w * m.y);
+                }
+            cp_v4d r2[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) r2[mi] = cp_v4d{0., 0., 0., 0.};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    r2[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(4 * kk + g) * TABLES_WSTRIDE + 16 * mi + l15], lt[kk >> 2][kk & 3], r2[mi], 0, 0, 0);
+            const bool full = q0 + 16 * (jj + 1) <= A.nq && A.nzq == 64;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int zq = 16 * mi + g + 4 * r;
+                    double v = r2[mi][r] * A.scale;
+                    if (POST == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                    else if (POST == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
+                    v = (nanq || ((nan_z >> (4 * mi + r)) & 1u)) ? __builtin_nan("") : v;
+                    if (full || (q < A.nq && zq < A.nzq)) ob[(long long)zq * A.nq + q] = v;
+                }
+                __builtin_amdgcn_sched_barrier(0);      // (four exponentials in flight, not sixteen: their temporaries set the register count)
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int cp_tables_rows_available(const cp_spline_plan* kplan, const cp_spline_plan* zplan) {
@@ -1037,6 +1138,37 @@ extern "C" int cp_tables_rows(const cp_spline_plan* kplan, const cp_spline_plan*
     const hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != kplan->device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_tables_rows: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+extern "C" int cp_tables_rows_direct(const cp_spline_rows_plan* kplan, const cp_spline_plan* zplan, const double* d_tables, const double* d_m, double* d_out,
+                                     long long nbatch, int post_op, double scale, void* stream) {
+    if (!kplan || !zplan) return cp::fail(CP_EINVAL, "cp_tables_rows_direct: null plan");
+    if (nbatch < 0) return cp::fail(CP_EINVAL, "cp_tables_rows_direct: negative batch");
+    if (nbatch == 0) return CP_OK;
+    if (!d_tables || !d_m || !d_out) return cp::fail(CP_EINVAL, "cp_tables_rows_direct: null device pointer");
+    if (post_op < CP_SPLINE_POST_NONE || post_op > CP_SPLINE_POST_EXP10) return cp::fail(CP_EINVAL, "cp_tables_rows_direct: unknown post op %d", post_op);
+    cp_spline_rows_view kv;
+    if (!cp_spline_rows_plan_view(kplan, &kv)) return cp::fail(CP_EINVAL, "cp_tables_rows_direct: bad k plan");
+    if (kv.first_knot != 0 || kv.nknots != kv.n) return cp::fail(CP_EUNSUPPORTED, "cp_tables_rows_direct: the output wavenumbers must span the knots of the tables");
+    if (!(zplan->d_wdense && zplan->n <= 32 && zplan->nq <= 64 && zplan->n_pad <= 32 && zplan->nq_pad == 64 && zplan->device == kv.device))
+        return cp::fail(CP_EUNSUPPORTED, "cp_tables_rows_direct: needs a z operator of at most 32 knots and 64 queries on the device of the k plan");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != kv.device && hipSetDevice(kv.device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_tables_rows_direct: cannot select device %d", kv.device);
+    TablesDirectArgs T;
+    T.t = d_tables; T.m = d_m; T.out = d_out; T.nbatch = nbatch;
+    T.n = kv.n; T.nq = kv.nq; T.nzin = zplan->n; T.nzq = zplan->nq;
+    T.qj = kv.d_qj; T.qw = kv.d_qw; T.wz = zplan->d_wdense; T.nz_pad = zplan->n_pad; T.j0z = zplan->d_j0; T.scale = scale;
+    const long long items = nbatch * ((kv.nq + 255) / 256);
+    const int grid = (int)(items < 256 * 8 ? items : 256 * 8);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    if (post_op == CP_SPLINE_POST_EXP10) hipLaunchKernelGGL(tables_rows_direct_kernel<CP_SPLINE_POST_EXP10>, dim3(grid), dim3(256), 0, hs, T);
+    else if (post_op == CP_SPLINE_POST_SQRT) hipLaunchKernelGGL(tables_rows_direct_kernel<CP_SPLINE_POST_SQRT>, dim3(grid), dim3(256), 0, hs, T);
+    else hipLaunchKernelGGL(tables_rows_direct_kernel<CP_SPLINE_POST_NONE>, dim3(grid), dim3(256), 0, hs, T);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != kv.device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_tables_rows_direct: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
 

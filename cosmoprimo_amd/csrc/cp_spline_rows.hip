@@ -180,7 +180,7 @@ extern "C" int cp_spline_rows_plan_destroy(cp_spline_rows_plan* p) {
     return CP_OK;
 }
 
-extern "C" int cp_spline_rows_plan_create(cp_spline_rows_plan** out, int n, const double* x, int bc, int nq, const double* xq, int device) {
+extern "C" int cp_spline_rows_plan_create(cp_spline_rows_plan** out, int n, const double* x, int bc, int extrapolate, int nq, const double* xq, int device) {
     if (!out) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: null plan pointer");
     *out = nullptr;
     if (n < 4 || !x || nq < 1 || !xq) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: bad arguments");
@@ -222,12 +222,12 @@ extern "C" int cp_spline_rows_plan_create(cp_spline_rows_plan** out, int n, cons
     int jmin = n, jmax = -1;
     for (int k = 0; k < nq; ++k) {
         const double v = xq[k];
-        if (!(v >= x[0] && v <= x[n - 1])) {
+        if (!(v >= x[0] && v <= x[n - 1]) && !(extrapolate && v == v)) {      // outside the knots: NaN, or the cubic of the end interval continued
             qj[k] = -1;
             continue;
         }
         int j = (int)(std::upper_bound(x, x + n, v) - x) - 1;
-        j = j > n - 2 ? n - 2 : j;
+        j = j > n - 2 ? n - 2 : (j < 0 ? 0 : j);
         qj[k] = j;
         jmin = j < jmin ? j : jmin;
         jmax = j > jmax ? j : jmax;

@@ -171,6 +171,7 @@ def _cached_operator(key, build):
 # busy (tools/bench_fused_spline.py); large batches (config 3B: 640 000 rows) and single radii (sigma8) take the two kernels.
 _FUSED_SPLINE_ROWS = (2, 8192)
 _TRANSPOSE_IN_STORE = True
+_DIRECT_K_SPLINE = True        # batches of (k, z) tables: the k splines evaluated from the tables' second derivatives (cp_tables_rows_direct) instead of multiplied
 
 
 def _fftlog_then_spline(fft, op, rows, device, sqrt=False):
@@ -598,9 +599,12 @@ class Interpolator2D(dv.Copyable):
         yq = np.clip(yh, knots[0], knots[-1])
         opy = _cached_operator(('i2y-dense', k, knots.tobytes(), yq.tobytes(), self.device.index),
                                lambda: LinearOperator.dense(self._operator('y', yq, dense=True), device=self.device))
-        opx = self._operator('x', xq)
         lib = _lib.load()
-        if fun_t.ndim == 3 and lib.cp_tables_rows_available(opx._handle, opy._handle):
+        out = self._rows_y_major_direct(fun_t, xq, opy, exp10) if fun_t.ndim == 3 and self.kx == 3 and _DIRECT_K_SPLINE else None
+        if out is not None:
+            pass
+        elif fun_t.ndim == 3 and lib.cp_tables_rows_available(self._operator('x', xq)._handle, opy._handle):
+            opx = self._operator('x', xq)
             # both operators in one kernel (cp_tables_rows): the x-splined tables are never written
             torch = dv.torch()
             out = torch.empty((fun_t.shape[0], opy.nq, opx.nq), dtype=torch.float64, device=self.device)
@@ -608,10 +612,34 @@ class Interpolator2D(dv.Copyable):
                 _lib.check(lib.cp_tables_rows(opx._handle, opy._handle, fun_t.data_ptr(), out.data_ptr(), fun_t.shape[0], 2 if exp10 else 0, 1.,
                                               dv.stream_of(self.device)))
         else:
-            out = opy.mid(opx(fun_t), post='exp10' if exp10 else None)     # (batch..., ny, nxq) -> (batch..., nyq, nxq)
+            out = opy.mid(self._operator('x', xq)(fun_t), post='exp10' if exp10 else None)     # (batch..., ny, nxq) -> (batch..., nyq, nxq)
         if self._nan_surfaces is not None:
             out = dv.torch().where(self._nan_surfaces[..., None, None], dv.torch().full_like(out, float('nan')), out)
         return out
+
+    def _rows_y_major_direct(self, fun_t, xq, opy, exp10):
+        """Cubic splines along x for a batch of tables: the second derivatives of every table row at the knots are the tables' own (one
+        tridiagonal solve per row, ``cp_spline_rows_second_derivatives``, kept with the object like the coefficients the reference's
+        RectBivariateSpline computes when it is built), and a query is four multiply-adds on them -- evaluated by the kernel that contracts the
+        y direction on the matrix cores (``cp_tables_rows_direct``).  None where that kernel does not apply (the caller multiplies by operators)."""
+        from .spline import SplineRows
+        torch = dv.torch()
+        lib = _lib.load()
+        try:
+            kplan = _cached_operator(('i2x-rows', self._x.tobytes(), xq.tobytes(), self.device.index),
+                                     lambda: SplineRows(self._x, xq, bc='not-a-knot', extrapolate=True, device=self.device))
+            m = self.__dict__.get('_fun_y_major_m', None)
+            if m is None:
+                ends = _cached_operator(('i2x-rows-m', self._x.tobytes(), self.device.index),
+                                        lambda: SplineRows(self._x, self._x[[0, -1]], bc='not-a-knot', device=self.device))
+                m = self._fun_y_major_m = ends.second_derivatives(fun_t)
+            out = torch.empty((fun_t.shape[0], opy.nq, xq.size), dtype=torch.float64, device=self.device)
+            if fun_t.shape[0]:
+                _lib.check(lib.cp_tables_rows_direct(kplan._handle, opy._handle, fun_t.data_ptr(), m.data_ptr(), out.data_ptr(), fun_t.shape[0], 2 if exp10 else 0, 1.,
+                                                     dv.stream_of(self.device)))
+            return out
+        except NotImplementedError:
+            return None
 
     def _call_many_x(self, x, y, bounds_error):
         """Grid evaluation at very many x (a mesh of wavenumbers) and a few y: the y direction first (operator, few queries), then one spline

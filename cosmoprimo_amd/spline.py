@@ -172,13 +172,13 @@ class SplineRows(object):
     (``cp_spline_rows_*``): the function ``LinearOperator.spline(x, xq, bc=...)`` applies as a banded operator, at a tenth of the arithmetic and
     reading only the knots the queries can see.  Raises NotImplementedError where the scheme does not fit (very long windows): use the operator then."""
 
-    def __init__(self, x, xq, bc='natural', device=None):
+    def __init__(self, x, xq, bc='natural', extrapolate=False, device=None):
         self.device = dv.resolve_device(device)
         x = np.ascontiguousarray(x, dtype='f8').ravel()
         xq = np.ascontiguousarray(xq, dtype='f8').ravel()
         self._handle = ctypes.c_void_p()
-        _lib.check(_lib.load().cp_spline_rows_plan_create(ctypes.byref(self._handle), x.size, _lib.as_double_p(x), _lib.SPLINE_BC[bc], xq.size, _lib.as_double_p(xq),
-                                                          self.device.index))
+        _lib.check(_lib.load().cp_spline_rows_plan_create(ctypes.byref(self._handle), x.size, _lib.as_double_p(x), _lib.SPLINE_BC[bc], int(bool(extrapolate)), xq.size,
+                                                          _lib.as_double_p(xq), self.device.index))
         self.n, self.nq = x.size, xq.size
 
     @property

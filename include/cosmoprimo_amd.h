@@ -337,11 +337,11 @@ int cp_splice_plan_destroy(cp_splice_plan* plan);
  * by solving the spline's tridiagonal system per row instead of applying its inverse as a banded operator: ~10 operations per knot the queries
  * can see and 8 per query, against 64 multiply-adds per query (the matrix-core route: whole windows of knots).  Only the knots the queries touch
  * (plus a halo) are read.  d_y : (nrows, n); d_out : (nrows, nq), or (nrows / group, nq, group) for group > 0; post_op : CP_SPLINE_POST_NONE or
- * CP_SPLINE_POST_SQRT of scale x spline; queries outside the knots: NaN.  bc: any of cp_spline_bc (not-a-knot: the outermost unknowns are
+ * CP_SPLINE_POST_SQRT of scale x spline; queries outside the knots: NaN, or -- extrapolate -- the cubic of the end interval continued.  bc: any of cp_spline_bc (not-a-knot: the outermost unknowns are
  * eliminated by hand, the system stays tridiagonal).  CP_EUNSUPPORTED from plan creation for windows of more than a few thousand knots: use
  * cp_spline_plan_create. */
 typedef struct cp_spline_rows_plan cp_spline_rows_plan;
-int cp_spline_rows_plan_create(cp_spline_rows_plan** plan, int n, const double* x, int bc, int nq, const double* xq, int device);
+int cp_spline_rows_plan_create(cp_spline_rows_plan** plan, int n, const double* x, int bc, int extrapolate, int nq, const double* xq, int device);
 int cp_spline_rows_plan_info(const cp_spline_rows_plan* plan, int* first_knot, int* nknots, int* rows_per_wave, int* halo);
 int cp_spline_rows_apply(const cp_spline_rows_plan* plan, const double* d_y, long long nrows, int post_op, double scale, int group, double* d_out,
                          void* stream);
@@ -349,6 +349,12 @@ int cp_spline_rows_apply(const cp_spline_rows_plan* plan, const double* d_y, lon
  * formula above; needs a plan whose queries span the knots */
 int cp_spline_rows_second_derivatives(const cp_spline_rows_plan* plan, const double* d_y, long long nrows, double* d_m, void* stream);
 int cp_spline_rows_plan_destroy(cp_spline_rows_plan* plan);
+/* cp_tables_rows with the k direction evaluated from the tables' own second derivatives instead of multiplied by an operator: d_m (nbatch, nz, n) =
+ * cp_spline_rows_second_derivatives of the tables along k for the knots of kplan (a cp_spline_rows plan, any boundary condition, whose queries --
+ * the output wavenumbers -- span the knots); zplan as in cp_tables_rows.  The second derivatives belong to the tables: a caller evaluates them once
+ * per table set (what scipy's RectBivariateSpline does when it is built, jax.py:241-271) and re-uses them for every grid of wavenumbers / redshifts. */
+int cp_tables_rows_direct(const cp_spline_rows_plan* kplan, const cp_spline_plan* zplan, const double* d_tables, const double* d_m, double* d_out,
+                          long long nbatch, int post_op, double scale, void* stream);
 
 /* the elementwise stages of the two filters over (nrows, n) batches of spectra, one pass each (csrc/cp_bao.hip):
  * cp_wallish_finish: pknow = d_a (+ d_b when not NULL: the spliced spline applied as two operators), wiggles = (pk / pknow - 1) tophat + 1,
