@@ -265,9 +265,7 @@ __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
 #pragma unroll 1
         for (int kb = klo; kb < khi; kb += 16) {
             const int k = kb + 4 * g;
-#if CP_LINOP_ABLATE
-            static_assert(true, "diagnostic build (tools/linop_microbench.hip): bit 0 keeps the operator, bit 1 the rows, of the first chunk for all chunks");
-#endif
+            // (CP_LINOP_ABLATE, diagnostic builds of tools/linop_microbench.hip only: bit 0 re-reads the operator, bit 1 the rows, of the first chunk)
             double a[MT][4];
             cp_v4d b[4];
 #pragma unroll
