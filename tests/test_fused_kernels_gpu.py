@@ -292,3 +292,42 @@ def test_spline_rows(bc):
     got = op.second_derivatives(torch.as_tensor(y, device=dev)).cpu().numpy()
     ref = interpolate.CubicSpline(x, y, axis=-1, bc_type=bc)(x, nu=2)
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('shape', [(3, 30, 504, 64, 1024), (2, 13, 211, 37, 1000), (1, 5, 64, 3, 70), (5, 32, 100, 64, 256)])
+@pytest.mark.parametrize('post', [None, 'exp10'])
+def test_tables_rows_direct(shape, post):
+    """cp_tables_rows_direct (the k splines evaluated from the tables' second derivatives, the z contraction on the matrix cores) against the two
+    operator launches and against scipy's two passes (jax.py:241-271): odd shapes, wavenumbers outside the knots, a table holding NaN."""
+    torch, _lib, lib, dv, dev = _env()
+    from scipy.interpolate import CubicSpline
+    from cosmoprimo_amd.spline import LinearOperator, SplineRows, dense_operator
+    nb, nzin, n, nzq, nq = shape
+    rng = np.random.default_rng(nb + n)
+    x = np.linspace(0., 10., n) + rng.uniform(-0.3, 0.3, n) * 10. / n
+    x[0], x[-1] = 0., 10.
+    xq = np.sort(np.concatenate([[0., 10.], rng.uniform(-0.5, 10.5, nq - 2)]))               # the ends of the knots, and some queries outside them: NaN
+    zk, zq = np.linspace(0., 3., nzin), np.linspace(0., 3., nzq)
+    kplan = SplineRows(x, xq, bc='not-a-knot', device=dev)
+    opx = LinearOperator.spline(x, xq, bc='not-a-knot', extrapolate=False, device=dev)
+    opz = LinearOperator.dense(dense_operator(zk, zq, bc='not-a-knot', extrapolate=True), device=dev)
+    smooth = 1. + 0.3 * np.sin(x)[None, None, :] * np.cos(zk)[None, :, None] * rng.uniform(0.5, 1., (nb, 1, 1))
+    t = torch.as_tensor(smooth + 1e-3 * rng.standard_normal((nb, nzin, n)), device=dev)
+    m = SplineRows(x, x[[0, -1]], bc='not-a-knot', device=dev).second_derivatives(t)
+    out = torch.full((nb, nzq, nq), -7., dtype=torch.float64, device=dev)
+    code = {None: 0, 'exp10': 2}[post]
+    _lib.check(lib.cp_tables_rows_direct(kplan._handle, opz._handle, t.data_ptr(), m.data_ptr(), out.data_ptr(), nb, code, 1., dv.stream_of(dev)))
+    got, ref = out.cpu().numpy(), opz.mid(opx(t), post=post).cpu().numpy()
+    outside = (xq < x[0]) | (xq > x[-1])
+    assert np.isnan(got[..., outside]).all() and np.isfinite(got[..., ~outside]).all()
+    np.testing.assert_allclose(got[..., ~outside], ref[..., ~outside], rtol=1e-11, atol=1e-12)
+    if nzin >= 4:
+        two = CubicSpline(zk, CubicSpline(x, t[0].cpu().numpy(), axis=1)(xq[~outside]), axis=0)(zq)
+        np.testing.assert_allclose(got[0][:, ~outside], two if post is None else 10.**two, rtol=1e-10, atol=1e-12)
+    if nb > 1:
+        t2 = t.clone()
+        t2[1, nzin // 2, n // 3] = float('nan')
+        m2 = SplineRows(x, x[[0, -1]], bc='not-a-knot', device=dev).second_derivatives(t2)
+        _lib.check(lib.cp_tables_rows_direct(kplan._handle, opz._handle, t2.data_ptr(), m2.data_ptr(), out.data_ptr(), nb, code, 1., dv.stream_of(dev)))
+        again = out.cpu().numpy()
+        assert np.isnan(again[1]).any() and np.array_equal(np.delete(again, 1, axis=0), np.delete(got, 1, axis=0), equal_nan=True)
