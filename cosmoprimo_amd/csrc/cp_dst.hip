@@ -102,6 +102,36 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     __shared__ int bad_row[2];
     __shared__ int pair_flag;   // inverse transform: some sample of the pair is not finite
     const double nan = __builtin_nan("");
+    // forward transform: the rows of the NEXT pair are fetched (in Makhoul order) while this pair is transformed -- the loads of a pair used to sit
+    // at the top of its iteration, in front of everything that needs them, with two waves per SIMD to cover their latency
+    double na[P], nb[P];
+    auto fetch = [&](long long p) {
+        const double* ra = A.in + 2 * p * N;
+        const double* rb = 2 * p + 1 < A.nrows ? ra + N : ra;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const int m = t + T * r;
+            const int n = m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1;
+            na[r] = ra[n];
+            nb[r] = rb[n];
+        }
+    };
+    // inverse transform: half of a pair's samples (the coefficients N - 1 - k of both rows) the same way; the other half (k - 1) are read in place
+    auto at_ = [&](int j) { return A.split ? ((j & 1) * (N / 2) + (j >> 1)) : j; };
+    auto fetch_inverse = [&](long long p) {
+        const double* ra = A.in + 2 * p * N;
+        const double* rb = 2 * p + 1 < A.nrows ? ra + N : ra;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            const int ia = at_(N - 1 - (t + T * r));
+            na[r] = ra[ia];
+            nb[r] = rb[ia];
+        }
+    };
+    if ((long long)blockIdx.x < npairs) {
+        if (INVERSE) fetch_inverse(blockIdx.x);
+        else fetch(blockIdx.x);
+    }
     for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
         const bool has_b = 2 * p + 1 < A.nrows;
         const double* ra = A.in + 2 * p * N;
@@ -124,7 +154,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 const int m = tt + T * r;
                 const bool lower = m < N / 2;
                 const int n = lower ? 2 * m : 2 * (N - 1 - m) + 1;
-                double a = ra[n], b = rb[n];
+                double a = na[r], b = nb[r];
                 bad_a |= !(fabs(a) <= 1.7976931348623157e308) || (A.fused && !(a > 0.));
                 bad_b |= !(fabs(b) <= 1.7976931348623157e308) || (A.fused && !(b > 0.));
                 if (A.fused) {
@@ -135,6 +165,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 x[r].re = lower ? a : -a;
                 x[r].im = has_b ? (lower ? b : -b) : 0.;
             }
+            if (p + gridDim.x < npairs) fetch(p + gridDim.x);
             if (bad_a) bad_row[0] = 1;
             if (bad_b) bad_row[1] = 1;
             __syncthreads();
@@ -164,14 +195,14 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
             }
         } else {
             // Hermitian-symmetrised, conjugated spectrum of the pair; a row that is skipped does not take part
-            auto spectrum = [&](bool keep_a, bool keep_b) {
+            auto spectrum = [&](bool keep_a, bool keep_b, bool prefetched) {
 #pragma unroll
                 for (int r = 0; r < P; ++r) {
                     const int k = tt + T * r;
                     const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
                     const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
                     const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-                    const double Aa = fa * ra[at(ia)], Ab = fa * rb[at(ia)];
+                    const double Aa = fa * (prefetched ? na[r] : ra[at(ia)]), Ab = fa * (prefetched ? nb[r] : rb[at(ia)]);
                     const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
                     const cplx rot = A.rot[k];
                     const double cs = rot.re, sn = -rot.im;
@@ -190,7 +221,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                     x[r].im = -(Ha.im + Hb.re);
                 }
             };
-            spectrum(true, has_b);
+            spectrum(true, has_b, true);
+            if (p + gridDim.x < npairs) fetch_inverse(p + gridDim.x);
             // a sample that is not finite shows in the packed spectrum, though not which row it came from: the pair is flagged from the registers
             // (no second pass over the rows), and only a flagged pair -- rare -- reads its rows again to tell the two apart and leave the bad one out
             bool suspect = false;
@@ -215,7 +247,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 skip_a = bad_row[0] != 0;
                 skip_b = bad_row[1] != 0;
                 // finite rows whose sum overflowed in the packing stay as they are (skip_a = skip_b = false): nothing to separate
-                if (skip_a | skip_b) spectrum(!skip_a, has_b && !skip_b);
+                if (skip_a | skip_b) spectrum(!skip_a, has_b && !skip_b, false);
             }
             dif_all<N, P>(tt, A, x, lds, ltw);
             asm volatile("" : "+v"(tt));
