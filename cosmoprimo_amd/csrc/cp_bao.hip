@@ -196,12 +196,22 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
     if (threadIdx.x >= 64 && threadIdx.x < 64 + DD_NTAB) gtab[threadIdx.x - 64] = gap_table.c[threadIdx.x - 64];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + wave;
-    if (row >= nrows) return;
     double* buf = dd_lds + wave * STRIDE;
+    // persistent workgroups: the next sequence of a wave is fetched into registers while this one is solved
+    double nxt[S];
+    long long row = (long long)blockIdx.x * 4 + wave;
+    if (row < nrows) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) nxt[k] = y[row * N + lane + 64 * k];
+    }
+    for (; row < nrows; row += (long long)gridDim.x * 4) {
     const double* src = y + row * N;
-#pragma unroll 4
-    for (int j = lane; j < N; j += 64) buf[j + j / S] = src[j];
+#pragma unroll
+    for (int k = 0; k < S; ++k) buf[(lane + 64 * k) + (lane + 64 * k) / S] = nxt[k];
+    if (row + (long long)gridDim.x * 4 < nrows) {
+#pragma unroll
+        for (int k = 0; k < S; ++k) nxt[k] = y[(row + (long long)gridDim.x * 4) * N + lane + 64 * k];
+    }
     auto at = [&](int i) -> double& { return buf[i + i / S]; };
     auto clamped = [&](int i) { return buf[(i < 0 ? 0 : (i > N - 1 ? N - 1 : i)) + (i < 0 ? 0 : (i > N - 1 ? N - 1 : i)) / S]; };
     auto c_of = [&](int i) { return i >= N - 1 ? DD_CLAST : ctab[i < 0 ? 0 : (i < DD_NTAB ? i : DD_NTAB - 1)]; };
@@ -275,13 +285,13 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
         box[2 * row] = first + off0;
         box[2 * row + 1] = second + off1;
     }
-    if (!gap) return;
+    if (!gap) continue;
     // The removal of the box (cp_gap_spline, bao_filter.py:395-405), on the sequence in memory: the clamped spline through the x^2-weighted
     // coefficients with the knots [a, b] left out returns the datum at every kept knot, so only the box is rewritten; its two end slopes come
     // from eliminations started DD_GAP_WINDOW knots to either side (the same arithmetic as gap_spline_kernel, cp_spline.hip), here run by two
     // lanes side by side on values the wave has brought into LDS (the second derivatives there are not needed any more).
     const int a = first + off0, b = second + off1;
-    if (a < 1 || b > N - 2 || b < a) return;      // nothing removed (or an invalid box): the sequence stays as it is
+    if (a < 1 || b > N - 2 || b < a) continue;      // nothing removed (or an invalid box): the sequence stays as it is
     const int L = a - 1, R = b + 1;
     const double g = (double)(R - L);
     const int i0 = L - DD_GAP_WINDOW > 0 ? L - DD_GAP_WINDOW : 0, i1 = R + DD_GAP_WINDOW < N - 1 ? R + DD_GAP_WINDOW : N - 1;
@@ -350,6 +360,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
         const double u = (double)(i - L), x = (double)(i + 1);
         seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
     }
+    }
 }
 
 }  // namespace
@@ -412,8 +423,11 @@ extern "C" int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int 
     if ((nrows + 3) / 4 > 2147483647LL) return cp::fail(CP_EUNSUPPORTED, "cp_wallish_dd_box: too many sequences for one launch");
     DeviceScope scope(device);
     if (!scope.ok) return cp::fail(CP_EDEVICE, "cp_wallish_dd_box: cannot select device %d", device);
-    const unsigned grid = (unsigned)((nrows + 3) / 4);
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
     const size_t lds = ((size_t)4 * (n + 64) + 2 * DD_NTAB) * sizeof(double);
+    const long long resident = (long long)ncu * (long long)((160 * 1024) / lds < 1 ? 1 : (160 * 1024) / lds);
+    const unsigned grid = (unsigned)((nrows + 3) / 4 < resident ? (nrows + 3) / 4 : resident);
     hipStream_t hs = static_cast<hipStream_t>(stream);
 #define CP_DD_LAUNCH(S_)                                                                                                                             \
     do {                                                                                                                                             \
