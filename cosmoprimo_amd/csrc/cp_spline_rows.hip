@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
             for (int e = l; e < pad; e += LPR) buf[-1 - e] = first;
             for (int e = nw + l; e < LPR * S + pad; e += LPR) buf[e] = last;
         }
-        {
+#ifndef CP_ROWS_ABLATE
+#define CP_ROWS_ABLATE 0      // tools/spline_rows_variants.sh, what the parts cost: 1 no forward sweep, 2 no back substitution, 4 one query per lane,
+#endif                        // 8 no values gathered from memory, 16 no root, 32 no stores
+        if (!(CP_ROWS_ABLATE & 1)) {
             const double beyond = buf[own + S];
             const int start = own - halo;
             double y0 = buf[start], d = 0.;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
                 buf[i] = fma(-c.z, d, c.y * (sigma - sigma_m));
             }
         }
-        {
+        if (!(CP_ROWS_ABLATE & 2)) {
             double m = 0.;
 #pragma unroll 8
             for (int t = 0; t < halo; ++t) {
@@ -144,14 +147,14 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
             continue;
         }
 #pragma unroll 16
-        for (int q = l; q < T.nq; q += LPR) {
+        for (int q = l; q < ((CP_ROWS_ABLATE & 4) ? LPR : T.nq); q += LPR) {
             const int j = T.qj[q];
             const int jj = j < 0 ? 0 : j;
             const double4 w = reinterpret_cast<const double4*>(T.qw)[q];
-            double v = w.x * src[jj] + w.y * src[jj + 1] + (w.z * buf[jj] + w.w * buf[jj + 1]);
+            double v = ((CP_ROWS_ABLATE & 8) ? w.x + w.y : w.x * src[jj] + w.y * src[jj + 1]) + (w.z * buf[jj] + w.w * buf[jj + 1]);
             v = j < 0 ? __builtin_nan("") : v * A.scale;
-            if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
-            if (live) A.out[rows_out_index(row, q, T.nq, A.group)] = v;
+            if (A.post_op == CP_SPLINE_POST_SQRT && !(CP_ROWS_ABLATE & 16)) v = sqrt(v);
+            if (live && (!(CP_ROWS_ABLATE & 32) || v == 12345.678)) A.out[rows_out_index(row, q, T.nq, A.group)] = v;
         }
     }
 }
