@@ -42,6 +42,8 @@ SIGNATURES = {
                                             _c_double_p, _c_double_p, ctypes.c_int]),
     'cp_fftlog_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double,
                                         ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]),
+    'cp_fftlog_execute_window': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double,
+                                               ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_fftlog_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_fftlog_plan_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, _c_int_p, _c_int_p, _c_int_p]),
     'cp_background_distance': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
@@ -80,6 +82,7 @@ SIGNATURES = {
     'cp_tables_rows': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
     'cp_spline_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_spline_plan_info': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, _c_int_p]),
+    'cp_spline_plan_columns': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p]),
     'cp_spline_columns_scratch_doubles': (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
     'cp_spline_columns': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),

@@ -196,8 +196,9 @@ extern "C" int cp_fftlog_plan_info(const cp_fftlog_plan* p, long long nbatch, in
     return CP_OK;
 }
 
-extern "C" int cp_fftlog_execute(const cp_fftlog_plan* p, const double* d_in, double* d_out, long long nbatch, int extrap_left,
-                                 double val_left, int extrap_right, double val_right, int keep_padding, void* stream) {
+// out_count < 0: whole rows
+static int execute_impl(const cp_fftlog_plan* p, const double* d_in, double* d_out, long long nbatch, int extrap_left, double val_left, int extrap_right,
+                        double val_right, int keep_padding, int out_first, int out_count, void* stream) {
     if (!p) return cp::fail(CP_EINVAL, "cp_fftlog_execute: null plan");
     if (nbatch < 0) return cp::fail(CP_EINVAL, "cp_fftlog_execute: negative batch");
     if (nbatch == 0) return CP_OK;
@@ -229,9 +230,17 @@ extern "C" int cp_fftlog_execute(const cp_fftlog_plan* p, const double* d_in, do
     A.post = p->d_post;
     A.u = p->d_u;
     A.tw = p->d_tw;
+    A.out_first = 0;
+    A.out_last = A.n_out;
     DeviceGuard guard(p->device);
     if (!guard.ok) return cp::fail(CP_EDEVICE, "cp_fftlog_execute: cannot select device %d", p->device);
-    const int variant = select_variant(p->npad, p->l.p, p->n, extrap_left, val_left, extrap_right, val_right, keep_padding);
+    int variant = select_variant(p->npad, p->l.p, p->n, extrap_left, val_left, extrap_right, val_right, keep_padding);
+    if (variant == VAR_HALF_ZERO && out_count >= 0 && out_count < A.n_out && p->l.func[VAR_HALF_ZERO_WINDOW]) {      // other kernels store whole rows
+        variant = VAR_HALF_ZERO_WINDOW;
+        A.out_first = out_first;
+        A.out_last = out_first + out_count;
+        A.stream_rows = (double)nbatch * p->nker * ((double)p->n + out_count) * 8. > 512. * 1024. * 1024.;
+    }
     const int grid = grid_for(p, variant, nbatch);
     // the kernel walks the rows with 32-bit element steps (cp_fftlog_kernel.h: PairWalk): nker rows, and 2 grid rows, of
     // the padded length must stay below 2^31 elements (Np <= 8192: nker < 262144)
@@ -241,4 +250,19 @@ extern "C" int cp_fftlog_execute(const cp_fftlog_plan* p, const double* d_in, do
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_execute: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
+}
+
+extern "C" int cp_fftlog_execute(const cp_fftlog_plan* p, const double* d_in, double* d_out, long long nbatch, int extrap_left,
+                                 double val_left, int extrap_right, double val_right, int keep_padding, void* stream) {
+    return execute_impl(p, d_in, d_out, nbatch, extrap_left, val_left, extrap_right, val_right, keep_padding, 0, -1, stream);
+}
+
+extern "C" int cp_fftlog_execute_window(const cp_fftlog_plan* p, const double* d_in, double* d_out, long long nbatch, int extrap_left, double val_left,
+                                        int extrap_right, double val_right, int keep_padding, int out_first, int out_count, void* stream) {
+    if (p) {
+        const int n_out = keep_padding ? p->npad : p->n;
+        if (out_first < 0 || out_count < 0 || out_first > n_out - out_count)
+            return cp::fail(CP_EINVAL, "cp_fftlog_execute_window: columns [%d, %d + %d) are not inside the %d of an output row", out_first, out_first, out_count, n_out);
+    }
+    return execute_impl(p, d_in, d_out, nbatch, extrap_left, val_left, extrap_right, val_right, keep_padding, out_first, out_count, stream);
 }

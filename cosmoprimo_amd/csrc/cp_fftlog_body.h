@@ -66,8 +66,10 @@ enum { CP_EXTRAP_CONST = 0, CP_EXTRAP_EDGE = 1, CP_EXTRAP_LOG = 2 };
 // Output back ends:
 //   OUT_GENERIC  bounds-checked crop (any out_off / n_out, incl. keep_padding)
 //   OUT_HALF     n == NP/2, cropped output: exactly s in [P/4, 3P/4) (out_left = NP/4)
+//   OUT_HALF_WINDOW  OUT_HALF that stores the output columns [out_first, out_last) only (a consumer that reads a part of every row: the
+//                step from the FFTLog grid to 256 radii of sigma(r, z) reads a third of it -- the rest never has to reach HBM)
 enum { IN_GENERIC = 0, IN_LOG = 1, IN_HALF = 2, IN_HALF_ZERO = 3, IN_HALF_ZERO_GEN = 4 };
-enum { OUT_GENERIC = 0, OUT_HALF = 1 };
+enum { OUT_GENERIC = 0, OUT_HALF = 1, OUT_HALF_WINDOW = 2 };
 
 struct FftlogArgs {
     const double* in;   // (nbatch, nker, n) row-major
@@ -85,6 +87,7 @@ struct FftlogArgs {
     const double* post; // (nker, NP) padded postfactor
     const cplx* u;      // (nker, NP) Hermitian-extended u / NP in thread layout [(i R + s) T + t]
     const cplx* tw;     // concatenated per-pass twiddles, Plan::tw_offset
+    int out_first, out_last;  // OUT_HALF_WINDOW only: the columns of an output row that are stored
 #if defined(CP_STAMPS)
     double* val_stamp;  // diagnostic builds: per-wave cycle sums
 #endif
@@ -153,7 +156,8 @@ struct Fftlog {
     static CP_HD const cplx* lds_tw(const cplx* lds) {
         return lds + LDS_DATA + (PL::tw_offset(I) - NP);
     }
-    static_assert((!HALF_IN && OUT_MODE != OUT_HALF) || ((P == 16 || P == 8) && NPASS > 1), "HALF modes need P in {8, 16} and NP > P");
+    static constexpr bool HALF_OUT = OUT_MODE == OUT_HALF || OUT_MODE == OUT_HALF_WINDOW;
+    static_assert((!HALF_IN && !HALF_OUT) || ((P == 16 || P == 8) && NPASS > 1), "HALF modes need P in {8, 16} and NP > P");
     // HALF modes: the row occupies points r in [Q, Q + H) of every thread's P (Q = P/4 padded points on either side)
     static constexpr int H = P / 2, Q = P / 4;
 
@@ -449,6 +453,22 @@ struct Fftlog {
             if (acc == 1.2345e301) oa[t] = acc;  // keeps the results alive, never taken
             return;
         }
+        if constexpr (OUT_MODE == OUT_HALF_WINDOW) {  // column t + T s of the row, kept if inside the window
+#pragma unroll
+            for (int s = 0; s < H; ++s) {
+                const int c = t + T * s;
+                if (c >= A.out_first && c < A.out_last) {
+                    if (A.stream_rows) {
+                        st_row_f64_nt(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
+                        if (has_b) st_row_f64_nt(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
+                    } else {
+                        st_f64(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
+                        if (has_b) st_f64(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
+                    }
+                }
+            }
+            return;
+        }
 #if defined(__HIP_DEVICE_COMPILE__) && CP_WIDE_IO
         if (T >= 2) {
             // 16-byte stores, mirror image of prefetch_rows: even lanes write (g_a[n], g_a[n+1]) to row a, odd lanes
@@ -484,8 +504,8 @@ struct Fftlog {
     // last phase back end: natural-order outputs n = t + T s -> crop, x post, split Re/Im to the two rows
     static CP_HD void store_output(int t, const FftlogArgs& A, double* __restrict__ oa, double* __restrict__ ob, bool has_b,
                                    const double* __restrict__ post, unsigned fix, const cplx* x) {
-        if constexpr (OUT_MODE == OUT_HALF) {
-            static_assert(OUT_MODE != OUT_HALF, "OUT_HALF goes through store_output_half");
+        if constexpr (HALF_OUT) {
+            static_assert(!HALF_OUT, "OUT_HALF goes through store_output_half");
         } else {
 #pragma unroll
             for (int s = 0; s < P; ++s) {
@@ -728,7 +748,7 @@ struct Fftlog {
             }
             CP_FS(st, 6);
             Pass<NP, P, 0>::butterflies(x);
-            if constexpr (HALF_IN && OUT_MODE == OUT_HALF) {
+            if constexpr (HALF_IN && HALF_OUT) {
                 store_output_half(t0, A, oa, ob, has_b, nxt_ker, st, x);
             } else {
                 store_output(t0, A, oa, ob, has_b, post, st.info_cur, x);

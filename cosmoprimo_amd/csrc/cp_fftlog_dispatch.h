@@ -24,7 +24,8 @@
 #define CP_FFTLOG_MAX_NP 8192
 
 // Kernel variants (cp_fftlog_body.h front / back ends) and the rule that picks one.
-enum { VAR_GENERIC = 0, VAR_LOG = 1, VAR_HALF = 2, VAR_HALF_ZERO = 3, VAR_COUNT = 4 };
+// VAR_HALF_ZERO_WINDOW: VAR_HALF_ZERO storing a window of the output columns only (cp_fftlog_execute_window)
+enum { VAR_GENERIC = 0, VAR_LOG = 1, VAR_HALF = 2, VAR_HALF_ZERO = 3, VAR_HALF_ZERO_WINDOW = 4, VAR_COUNT = 5 };
 
 // HALF variants exist for P == 16 and NP >= CP_FFTLOG_HALF_MIN_NP
 #define CP_FFTLOG_HALF_MIN_NP 512

@@ -210,6 +210,10 @@ void launch_impl(int variant, const FftlogArgs& A, int grid, hipStream_t stream)
             hipLaunchKernelGGL((fftlog_kernel<NP, P, IN_HALF, OUT_HALF>), dim3(grid), dim3(T), lds, stream, A);
             return;
         }
+        if (variant == VAR_HALF_ZERO_WINDOW) {
+            hipLaunchKernelGGL((fftlog_kernel<NP, P, IN_HALF_ZERO, OUT_HALF_WINDOW>), dim3(grid), dim3(T), lds, stream, A);
+            return;
+        }
     }
     if (variant == VAR_LOG)
         hipLaunchKernelGGL((fftlog_kernel<NP, P, IN_LOG, OUT_GENERIC>), dim3(grid), dim3(T), lds, stream, A);
@@ -226,6 +230,7 @@ Launcher make_launcher() {
     if constexpr (has_half<NP, P>()) {
         l.func[VAR_HALF] = reinterpret_cast<const void*>(&fftlog_kernel<NP, P, IN_HALF, OUT_HALF>);
         l.func[VAR_HALF_ZERO] = reinterpret_cast<const void*>(&fftlog_kernel<NP, P, IN_HALF_ZERO, OUT_HALF>);
+        l.func[VAR_HALF_ZERO_WINDOW] = reinterpret_cast<const void*>(&fftlog_kernel<NP, P, IN_HALF_ZERO, OUT_HALF_WINDOW>);
     }
     l.launch = &launch_impl<NP, P>;
     l.np = NP;

@@ -508,6 +508,7 @@ struct cp_spline_plan {
     int* d_kwin;         // windows of knots per tile of 64 queries, for the matrix-core kernel
     int n_pad, nq_pad;
     bool prefer_dense;
+    int col_first, col_last;   // cp_spline_plan_columns: the entries of a row that cp_spline_apply(_grouped) may read, on either route
 };
 
 bool cp_spline_plan_view(const cp_spline_plan* p, cp_spline_band_view* out) {
@@ -709,6 +710,21 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     } else {
         p->prefer_dense = false;
     }
+    // the entries of a row the kernels read: the tiles of the vector route, the windows (multiples of 16 knots) of the matrix-core route
+    p->col_first = n;
+    p->col_last = 0;
+    for (int t = 0; t < ntiles; ++t) {
+        p->col_first = std::min(p->col_first, tile[4 * t + 2]);
+        p->col_last = std::max(p->col_last, tile[4 * t + 2] + tile[4 * t + 3]);
+    }
+    if (dense)
+        for (size_t t = 0; t < kwin.size() / 2; ++t)
+            if (kwin[2 * t + 1] > kwin[2 * t]) {
+                p->col_first = std::min(p->col_first, kwin[2 * t]);
+                p->col_last = std::max(p->col_last, kwin[2 * t + 1]);
+            }
+    p->col_last = std::min(p->col_last, n);
+    p->col_first = std::min(p->col_first, p->col_last);
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     int status = CP_OK;
@@ -758,6 +774,13 @@ extern "C" int cp_spline_plan_info(const cp_spline_plan* p, int* n, int* nq, int
     if (n) *n = p->n;
     if (nq) *nq = p->nq;
     if (bandwidth) *bandwidth = p->bw;
+    return CP_OK;
+}
+
+extern "C" int cp_spline_plan_columns(const cp_spline_plan* p, int* first, int* count) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_spline_plan_columns: null plan");
+    if (first) *first = p->col_first;
+    if (count) *count = p->col_last - p->col_first;
     return CP_OK;
 }
 

@@ -364,13 +364,15 @@ class FFTlog(dv.Copyable):
         self.__dict__.pop('_device_tables', None)
         return plan
 
-    def __call__(self, fun, extrap=0, keep_padding=False):
+    def __call__(self, fun, extrap=0, keep_padding=False, out_window=None):
         """
         Perform the transforms (reference fftlog.py:198-241).
 
         fun : numpy array or torch CUDA tensor; last dimensions must broadcast against (:attr:`nparallel`, len(x)).
         extrap : 0 (default), number, 'edge', 'log', or a (left, right) tuple.
         keep_padding : return the padded transform.
+        out_window : (first, count), not in the reference: the caller reads these entries of every output row only; the others are unspecified
+            (the default transform then does not write them: cp_fftlog_execute_window).
 
         Returns ``(y, fftloged)``, numpy for numpy input, torch (same device) for torch input.  Output is float64
         (complex128 for ``complex=True`` transforms) as in the reference.
@@ -405,7 +407,10 @@ class FFTlog(dv.Copyable):
         nbatch = int(np.prod(bshape[:-2] if nker > 1 else bshape[:-1], dtype='i8'))
         nout = npad if keep_padding else n
         tout = torch.empty(bshape[:-1] + (nout,), dtype=torch.float64, device=dev)
-        if nbatch > 0:
+        if nbatch > 0 and out_window is not None:
+            _lib.check(_lib.load().cp_fftlog_execute_window(plan.handle, tin.data_ptr(), tout.data_ptr(), nbatch, cl, vl, cr, vr, int(bool(keep_padding)),
+                                                            int(out_window[0]), int(out_window[1]), torch.cuda.current_stream(dev).cuda_stream))
+        elif nbatch > 0:
             _lib.check(_lib.load().cp_fftlog_execute(plan.handle, tin.data_ptr(), tout.data_ptr(), nbatch, cl, vl, cr, vr, int(bool(keep_padding)),
                                                      torch.cuda.current_stream(dev).cuda_stream))
         if self._phase is not None:

@@ -243,9 +243,9 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         fused = _fftlog_then_spline(fft, op, rows, device, sqrt=sqrt) if growth_sq is None else None
         if fused is not None:
             return fused.transpose(-1, -2) if radii_before_last_axis and fused.ndim >= 2 else fused
-        var = fft(rows)[1]
         if growth_sq is not None:
-            return op.outer(var, growth_sq, sqrt=True)
+            return op.outer(fft(rows)[1], growth_sq, sqrt=True)
+        var = fft(rows, out_window=op.columns)[1]      # the radii see a part of the FFTLog grid: only that part is written
         if radii_before_last_axis and var.ndim >= 2:      # (..., nz, nk) -> (..., nr, nz): sigma_rz's layout written by the spline kernel itself
             if _TRANSPOSE_IN_STORE:
                 return op(var, sqrt=sqrt, last_axis_first=True)

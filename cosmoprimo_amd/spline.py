@@ -43,6 +43,14 @@ class LinearOperator(object):
         _lib.check(_lib.load().cp_spline_plan_info(self._handle, None, None, ctypes.byref(bw)))
         return bw.value
 
+    @property
+    def columns(self):
+        """(first, count): the entries of an input row that :meth:`__call__` reads, whichever kernel it runs (cp_spline_plan_columns) -- the
+        producer of the rows may leave the others unwritten (``FFTlog.__call__(..., out_window=op.columns)``)."""
+        first, count = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().cp_spline_plan_columns(self._handle, ctypes.byref(first), ctypes.byref(count)))
+        return first.value, count.value
+
     _PATHS = {None: 0, 'valu': 16, 'mfma': 32}     # CP_SPLINE_PATH_*: force one kernel (measurements); default: the library's choice
 
     def __call__(self, y, sqrt=False, scale=1., path=None, last_axis_first=False):

@@ -95,6 +95,12 @@ int cp_fftlog_plan_create(cp_fftlog_plan** plan, int n, int npad, int nker, cons
  * of two when their (tilted) magnitudes differ by more than a factor 32, so that rounding is relative to each row's own magnitude. */
 int cp_fftlog_execute(const cp_fftlog_plan* plan, const double* d_in, double* d_out, long long nbatch, int extrap_left,
                       double val_left, int extrap_right, double val_right, int keep_padding, void* stream);
+/* cp_fftlog_execute for a consumer that reads the columns [out_first, out_first + out_count) of every output row only (the step of sigma_r from the
+ * FFTLog grid to the radii, interpolator.py:285-291, reads the third of the grid its radii can see: cp_spline_plan_columns): the default transform
+ * (zero padding, n = npad / 2) then stores that window only -- d_out keeps its row length, entries outside the window are left as they were --;
+ * every other case stores whole rows. */
+int cp_fftlog_execute_window(const cp_fftlog_plan* plan, const double* d_in, double* d_out, long long nbatch, int extrap_left, double val_left,
+                             int extrap_right, double val_right, int keep_padding, int out_first, int out_count, void* stream);
 int cp_fftlog_plan_destroy(cp_fftlog_plan* plan);
 /* introspection for the bench / tests: workgroups launched per execute for `nbatch`, threads per workgroup, LDS bytes */
 int cp_fftlog_plan_info(const cp_fftlog_plan* plan, long long nbatch, int* grid, int* block, int* lds_bytes);
@@ -273,6 +279,9 @@ int cp_tables_rows(const cp_spline_plan* kplan, const cp_spline_plan* zplan, con
                    void* stream);
 int cp_spline_plan_destroy(cp_spline_plan* plan);
 int cp_spline_plan_info(const cp_spline_plan* plan, int* n, int* nq, int* bandwidth);
+/* the entries [first, first + count) of a row of knots that cp_spline_apply / cp_spline_apply_grouped read (whichever kernel they choose): a producer
+ * may leave the others unwritten (cp_fftlog_execute_window) */
+int cp_spline_plan_columns(const cp_spline_plan* plan, int* first, int* count);
 /* the dense operator W (nq x n, row-major, host) and per-query inside-range flags: what the plan is built from */
 int cp_spline_operator(int n, const double* x, int nq, const double* xq, int bc, int nu, int extrapolate, double* w_out, int* inside_out);
 

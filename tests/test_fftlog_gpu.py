@@ -243,6 +243,46 @@ def direct_execute(cp, f, rows, extrap=(0, 0., 0, 0.), keep=False):
     return tout.cpu().numpy()
 
 
+@pytest.mark.parametrize('n', [1024, 2048, 256, 500, 6000])
+def test_execute_window(cp, n):
+    """cp_fftlog_execute_window: the columns inside the window are those of cp_fftlog_execute bit for bit; the default transform (zero padding,
+    power-of-two rows) leaves the others as they were, every other case may write whole rows; odd batches, one and two kernels, NaN rows."""
+    import torch
+    from cosmoprimo_amd import _lib
+    rng = np.random.default_rng(n)
+    k = np.logspace(-3, 2, n)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    for ell, codes in [(0, (0, 0., 0, 0.)), ([0, 2], (0, 0., 0, 0.)), (0, (1, 0., 1, 0.))]:
+        f = cp.PowerToCorrelation(k, ell=ell)
+        nker = 2 if isinstance(ell, list) else 1
+        rows = rng.uniform(0.9, 1.1, size=(7, nker, n)) * k**-1.2
+        rows[3, 0, 5] = np.nan
+        with np.errstate(all='ignore'):
+            full = direct_execute(cp, f, rows, codes)
+        plan = f._get_plan(dev)
+        tin = torch.as_tensor(rows, device=dev)
+        for first, count in [(n // 6, n // 3), (0, 1), (n - 3, 3), (0, n), (n // 2 - 1, 2), (5, 0)]:
+            tout = torch.full(tin.shape, 7.5, dtype=torch.float64, device=dev)
+            _lib.check(_lib.load().cp_fftlog_execute_window(plan.handle, tin.data_ptr(), tout.data_ptr(), rows.shape[0], codes[0], codes[1], codes[2], codes[3], 0,
+                                                            first, count, torch.cuda.current_stream(dev).cuda_stream))
+            got = tout.cpu().numpy()
+            np.testing.assert_array_equal(got[..., first:first + count], full[..., first:first + count])
+            outside = np.ones(n, dtype=bool)
+            outside[first:first + count] = False
+            if codes[0] == 0 and n in (256, 1024, 2048):      # the windowed kernel
+                assert (got[..., outside] == 7.5).all(), (n, ell, first, count)
+            else:
+                same = (got[..., outside] == full[..., outside]) | (np.isnan(got[..., outside]) & np.isnan(full[..., outside]))
+                assert (same | (got[..., outside] == 7.5)).all()
+        with pytest.raises(ValueError):
+            _lib.check(_lib.load().cp_fftlog_execute_window(plan.handle, tin.data_ptr(), tout.data_ptr(), rows.shape[0], 0, 0., 0, 0., 0, n - 2, 3, None))
+    # the facade: FFTlog.__call__(..., out_window=)
+    f = cp.TophatVariance(k)
+    rows = torch.as_tensor(rng.uniform(0.9, 1.1, size=(5, n)) * k**-1.2, device=dev)
+    a, b = f(rows)[1], f(rows, out_window=(n // 4, n // 2))[1]
+    assert torch.equal(a[:, n // 4:n // 4 + n // 2], b[:, n // 4:n // 4 + n // 2])
+
+
 @pytest.mark.parametrize('n', [2048, 1024, 500, 100, 16, 6, 6000, 40000])
 def test_rows_are_independent_through_the_c_abi(cp, golden, n):
     """The kernel itself keeps rows independent (reference: numpy transforms row by row, fftlog.py:538-544): rows spanning
