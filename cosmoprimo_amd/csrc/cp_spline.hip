@@ -293,21 +293,34 @@ __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
         }
+        // where element (row, q) goes is out_index(row, q): with the rows of the tile inside one group (or no groups) that is a base of the tile plus
+        // row x rstride + q x qstride -- one 64-bit division per tile instead of one per stored element (64 of them per lane)
+        const bool plain = A.group <= 0, one_group = A.group > 0 && A.group % ROWS == 0;
+        long long base = row0 * A.nq;
+        long long rstride = A.nq, qstride = 1;
+        if (one_group) {
+            const long long b = row0 / A.group;
+            base = b * A.nq * A.group + (row0 - b * A.group);
+            rstride = 1;
+            qstride = A.group;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int q = q0 + 16 * j + l15;
             if (q >= A.nq) continue;
             const bool nanq = A.j0[q] < 0;
+            double* outq = A.out + base + q * qstride;
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const long long row = row0 + 16 * i + g + 4 * r;
-                    if (row >= A.nrows) continue;
+                    const int rowin = 16 * i + g + 4 * r;
+                    if (row0 + rowin >= A.nrows) continue;
                     double v = nanq ? __builtin_nan("") : acc[i][j][r] * A.scale;
                     if (A.post_op == CP_SPLINE_POST_SQRT) v = sqrt(v);
                     else if (A.post_op == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
-                    A.out[out_index(row, q, A.nq, A.group)] = v;
+                    if (plain || one_group) outq[rowin * rstride] = v;
+                    else A.out[out_index(row0 + rowin, q, A.nq, A.group)] = v;
                 }
         }
     }
