@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
                     if (POST == CP_SPLINE_POST_SQRT) v = sqrt(v);
                     else if (POST == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
                     v = (nanq || ((nan_z >> (4 * mi + r)) & 1u)) ? __builtin_nan("") : v;
-                    if (full || (q < A.nq && zq < A.nzq)) ob[(long long)zq * A.nq + q] = v;
+                    if (full || (q < A.nq && zq < A.nzq)) ob[zq * A.nq + q] = v;      // (at most 64 rows of nq: 32-bit)
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (four exponentials in flight, not sixteen: their temporaries set the register count)
             }
@@ -1185,6 +1185,8 @@ extern "C" int cp_tables_rows_direct(const cp_spline_rows_plan* kplan, const cp_
     cp_spline_rows_view kv;
     if (!cp_spline_rows_plan_view(kplan, &kv)) return cp::fail(CP_EINVAL, "cp_tables_rows_direct: bad k plan");
     if (kv.first_knot != 0 || kv.nknots != kv.n) return cp::fail(CP_EUNSUPPORTED, "cp_tables_rows_direct: the output wavenumbers must span the knots of the tables");
+    if ((long long)kv.nq * 64 >= (1LL << 31) || (long long)kv.n * 32 >= (1LL << 31))
+        return cp::fail(CP_EUNSUPPORTED, "cp_tables_rows_direct: %d wavenumbers (%d knots) per row exceed the 32-bit offsets inside a table", kv.nq, kv.n);
     if (!(zplan->d_wdense && zplan->n <= 32 && zplan->nq <= 64 && zplan->n_pad <= 32 && zplan->nq_pad == 64 && zplan->device == kv.device))
         return cp::fail(CP_EUNSUPPORTED, "cp_tables_rows_direct: needs a z operator of at most 32 knots and 64 queries on the device of the k plan");
     int prev = -1;
