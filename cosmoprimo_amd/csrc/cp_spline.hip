@@ -219,7 +219,7 @@ struct DenseArgs {
     int n, nq, n_pad, nq_pad;
     const double* w;   // (nq_pad, n_pad), zero padded
     const int* j0;     // (nq): < 0 marks a query that evaluates to NaN
-    const int* kwin;   // (nq_pad / 64, 2): the knots [lo, hi), multiples of 16, that the bands of each tile of 64 queries cover
+    const int* kwin;   // (nq_pad / 64, 2): the knots [lo, hi), multiples of 16, that the bands of each tile of 64 queries cover; then (nq_pad / 16, 2): per 16 queries
     int post_op;
     double scale;
     int group;         // as Args::group
@@ -235,6 +235,9 @@ constexpr int LINOP_MT = 4;   // 16-row tiles per wave
 #define CP_LINOP_ABLATE 0
 #endif
 
+// SUB: the four tiles of 16 queries of a wave each skip the chunks of the wave's window that their own bands do not reach (plans whose tiles of 16
+// need at most two thirds of the chunks: cp_spline_plan::sub_windows; elsewhere the tests and the split loop cost more than the MFMAs they save)
+template <bool SUB>
 __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;      // (in a scalar register: what follows from it is wave-uniform for the compiler too)
     const int l15 = lane & 15, g = lane >> 4;
@@ -262,14 +265,26 @@ __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
         for (int j = 0; j < 4; ++j) wr[j] = A.w + (long long)(q0 + 16 * j + l15) * A.n_pad;
         // a banded operator (spline) is a block-banded GEMM: the wave's 64 queries only couple to the knots of their window
         const int klo = A.kwin[2 * (q0 >> 6)], khi = A.kwin[2 * (q0 >> 6) + 1];
+        // ... and each of its four tiles of 16 queries to a part of that window (64 + 16 / density knots of 64 + 64 / density): chunks of the
+        // window outside it are skipped for that tile -- a third of the MFMAs of a spline between grids of similar density (wave-uniform tests)
+        int slo[4], shi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            slo[j] = SUB ? A.kwin[2 * (A.nq_pad >> 6) + 2 * ((q0 >> 4) + j)] : klo;
+            shi[j] = SUB ? A.kwin[2 * (A.nq_pad >> 6) + 2 * ((q0 >> 4) + j) + 1] : khi;
+        }
 #pragma unroll 1
         for (int kb = klo; kb < khi; kb += 16) {
             const int k = kb + 4 * g;
             // (CP_LINOP_ABLATE, diagnostic builds of tools/linop_microbench.hip only: bit 0 re-reads the operator, bit 1 the rows, of the first chunk)
             double a[MT][4];
             cp_v4d b[4];
+            bool act[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const cp_v4d*>(wr[j] + ((CP_LINOP_ABLATE & 1) ? klo + 4 * g : k));
+            for (int j = 0; j < 4; ++j) {
+                act[j] = !SUB || (kb >= slo[j] && kb < shi[j]);
+                if (act[j]) b[j] = *reinterpret_cast<const cp_v4d*>(wr[j] + ((CP_LINOP_ABLATE & 1) ? klo + 4 * g : k));
+            }
             if (CP_LINOP_ABLATE & 2) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -286,12 +301,23 @@ __global__ __launch_bounds__(256, 2) void linop_mfma_kernel(const DenseArgs A) {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) a[i][m] = k + m < A.n ? yr[i][k + m] : 0.;
             }
+            if (SUB) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int j = 0; j < 4; ++j)
+                    if (act[j]) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
+                            for (int i = 0; i < MT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i][m], b[j][m], acc[i][j], 0, 0, 0);
+            }
         }
         // where element (row, q) goes is out_index(row, q): with the rows of the tile inside one group (or no groups) that is a base of the tile plus
         // row x rstride + q x qstride -- one 64-bit division per tile instead of one per stored element (64 of them per lane)
@@ -521,6 +547,7 @@ struct cp_spline_plan {
     int* d_kwin;         // windows of knots per tile of 64 queries, for the matrix-core kernel
     int n_pad, nq_pad;
     bool prefer_dense;
+    bool sub_windows;          // linop_mfma_kernel<true>: the tiles of 16 queries need at most two thirds of the chunks of their tiles of 64
     int col_first, col_last;   // cp_spline_plan_columns: the entries of a row that cp_spline_apply(_grouped) may read, on either route
 };
 
@@ -719,9 +746,30 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
             kwin[2 * t + 1] = (hi + 15) / 16 * 16;
             work += 64. * (kwin[2 * t + 1] - kwin[2 * t]);
         }
+        // behind them, the same per tile of 16 queries (linop_mfma_kernel)
+        const size_t sub = kwin.size();
+        kwin.resize(sub + (size_t)2 * (p->nq_pad / 16), 0);
+        double work_sub = 0.;
+        for (int t = 0; t < p->nq_pad / 16; ++t) {
+            int lo = n, hi = 0;
+            for (int q = 16 * t; q < 16 * (t + 1) && q < nq; ++q)
+                if (j0[q] >= 0) {
+                    lo = j0[q] < lo ? j0[q] : lo;
+                    hi = j1[q] + 1 > hi ? j1[q] + 1 : hi;
+                }
+            if (hi <= lo) lo = hi = 0;
+            kwin[sub + 2 * t] = lo / 16 * 16;
+            kwin[sub + 2 * t + 1] = (hi + 15) / 16 * 16;
+            work_sub += 16. * (kwin[sub + 2 * t + 1] - kwin[sub + 2 * t]);
+        }
+#ifndef CP_LINOP_SUB_FRACTION
+#define CP_LINOP_SUB_FRACTION 0.67      // (tools/ab_linop_sub.sh measures 0: never)
+#endif
+        p->sub_windows = work_sub <= CP_LINOP_SUB_FRACTION * work;
         p->prefer_dense = n >= 16 && work <= 5. * (double)nq * bw;
     } else {
         p->prefer_dense = false;
+        p->sub_windows = false;
     }
     // the entries of a row the kernels read: the tiles of the vector route, the windows (multiples of 16 knots) of the matrix-core route
     p->col_first = n;
@@ -731,7 +779,7 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
         p->col_last = std::max(p->col_last, tile[4 * t + 2] + tile[4 * t + 3]);
     }
     if (dense)
-        for (size_t t = 0; t < kwin.size() / 2; ++t)
+        for (size_t t = 0; t < (size_t)(p->nq_pad / 64); ++t)
             if (kwin[2 * t + 1] > kwin[2 * t]) {
                 p->col_first = std::min(p->col_first, kwin[2 * t]);
                 p->col_last = std::max(p->col_last, kwin[2 * t + 1]);
@@ -828,7 +876,8 @@ extern "C" int cp_spline_apply_grouped(const cp_spline_plan* p, const double* d_
         D.kwin = p->d_kwin; D.post_op = post_op; D.scale = scale; D.group = group;
         const long long items = ((nrows + 16 * LINOP_MT - 1) / (16 * LINOP_MT)) * ((p->nq_pad + 255) / 256);
         const int grid = (int)(items < 256 * 2 ? items : 256 * 2);
-        hipLaunchKernelGGL(linop_mfma_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), D);
+        if (p->sub_windows) hipLaunchKernelGGL(linop_mfma_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), D);
+        else hipLaunchKernelGGL(linop_mfma_kernel<false>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), D);
         const hipError_t e = hipGetLastError();
         if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
         if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_apply: launch failed: %s", hipGetErrorString(e));
