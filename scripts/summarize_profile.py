@@ -3,19 +3,26 @@ profiles/<tag>_kernel_stats.csv and profiles/<tag>_pmc_summary.json.   python sc
 import collections
 import csv
 import glob
+import os
 import json
 import shutil
 import sys
 
 tag = sys.argv[1]
 src = 'gpurun_out/prof_%s' % tag
-stats = glob.glob(src + '/trace/**/*kernel_stats.csv', recursive=True)[0]
+
+
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/: several runs of one tag leave several files, the last one counts"""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
+stats = newest(src + '/trace/**/*kernel_stats.csv')
 shutil.copy(stats, 'profiles/%s_kernel_stats.csv' % tag)
 
 
 def collect(folder, match):
     acc = collections.defaultdict(list)
-    for f in glob.glob('%s/%s/**/*counter_collection.csv' % (src, folder), recursive=True):
+    for f in [newest('%s/%s/**/*counter_collection.csv' % (src, folder))]:
         for row in csv.DictReader(open(f)):
             if match in row.get('Kernel_Name', ''):
                 acc[row['Counter_Name']].append(float(row['Counter_Value']))

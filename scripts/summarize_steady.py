@@ -8,18 +8,25 @@ The bench line printed by the SAME profiled run is kept beside the summary, so t
 one run (under the profiler both read about 1-3 % longer than in an unprofiled run)."""
 import csv
 import glob
+import os
 import json
 import shutil
 import sys
 
 tag = sys.argv[1]
 src = 'gpurun_out/prof_%s' % tag
+
+
+def newest(pattern):
+    """gpurun merges every call's output into gpurun_out/: several runs of one tag leave several files, the last one counts"""
+    return max(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+
 RAMP_NS = 300e6
 ROWS, BYTES_PER_ROW, PEAK = 100000, 2 * 8 * 2048, 8e12
 
-stats = glob.glob(src + '/trace/**/*kernel_stats.csv', recursive=True)[0]
+stats = newest(src + '/trace/**/*kernel_stats.csv')
 shutil.copy(stats, 'profiles/%s_headline_kernel_stats.csv' % tag)
-trace = glob.glob(src + '/trace/**/*kernel_trace.csv', recursive=True)[0]
+trace = newest(src + '/trace/**/*kernel_trace.csv')
 disp = []
 for row in csv.DictReader(open(trace)):
     if 'fftlog_kernel' in row['Kernel_Name']:
