@@ -725,15 +725,12 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     // factor 5 -- dense operators (quadrature weights, projectors: factor 1), splines between grids of similar density (factor 1.5 for 504 ->
     // 1024 knots of a P(k) table), the wallish2018 splice from 3666 linear knots to 1024 log-spaced ones (factor 4.x: 0.98 against 1.18 ms) --
     // and a measurement option otherwise (CP_SPLINE_PATH_MFMA).
-    const bool dense = keep_dense && (size_t)p->n_pad * p->nq_pad * sizeof(double) <= ((size_t)256 << 20);
+    const size_t dense_bytes = (size_t)p->n_pad * p->nq_pad * sizeof(double);
+    bool dense = keep_dense && dense_bytes <= ((size_t)256 << 20);
     std::vector<double> wd;
     std::vector<int> kwin((size_t)2 * (p->nq_pad / 64), 0);
     if (dense) {
-        wd.assign((size_t)p->n_pad * p->nq_pad, 0.);
         double work = 0.;
-        for (int q = 0; q < nq; ++q)
-            if (j0[q] >= 0)
-                for (int j = j0[q]; j <= j1[q]; ++j) wd[(size_t)q * p->n_pad + j] = w[(size_t)q * n + j];
         for (int t = 0; t < p->nq_pad / 64; ++t) {
             int lo = n, hi = 0;
             for (int q = 64 * t; q < 64 * (t + 1) && q < nq; ++q)
@@ -767,6 +764,16 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
 #endif
         p->sub_windows = work_sub <= CP_LINOP_SUB_FRACTION * work;
         p->prefer_dense = n >= 16 && work <= 5. * (double)nq * bw;
+        // a plan that will run on the vector route keeps no large dense copy (1024 knots -> 16 384 queries: 134 MB of device memory and a
+        // blocking upload per plan); small ones stay, for the measurement option and for cp_tables_rows
+        const bool valu_fits = (size_t)4 * span_max * sizeof(double) <= 160 * 1024;
+        if (!p->prefer_dense && valu_fits && dense_bytes > ((size_t)16 << 20)) dense = false;
+    }
+    if (dense) {
+        wd.assign((size_t)p->n_pad * p->nq_pad, 0.);
+        for (int q = 0; q < nq; ++q)
+            if (j0[q] >= 0)
+                for (int j = j0[q]; j <= j1[q]; ++j) wd[(size_t)q * p->n_pad + j] = w[(size_t)q * n + j];
     } else {
         p->prefer_dense = false;
         p->sub_windows = false;
@@ -863,7 +870,7 @@ extern "C" int cp_spline_apply_grouped(const cp_spline_plan* p, const double* d_
     post_op &= ~(CP_SPLINE_PATH_VALU | CP_SPLINE_PATH_MFMA);
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT && post_op != CP_SPLINE_POST_EXP10)
         return cp::fail(CP_EINVAL, "cp_spline_apply: unknown post op %d", post_op);
-    if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the plan holds no dense copy of the operator (more than 256 MB), it has no matrix-core path");
+    if (path == CP_SPLINE_PATH_MFMA && !p->d_wdense) return cp::fail(CP_EINVAL, "cp_spline_apply: the plan holds no dense copy of the operator (more than 256 MB, or more than 16 MB for an operator that runs on the vector route), it has no matrix-core path");
     // the vector kernel stages the knots under a tile of queries in LDS, 4 rows at least: operators wider than that only have the dense route
     const bool valu_fits = (size_t)4 * p->span_max * sizeof(double) <= 160 * 1024;
     if (p->d_wdense && path != CP_SPLINE_PATH_VALU &&

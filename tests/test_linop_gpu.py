@@ -37,6 +37,28 @@ def test_dense_operator_paths(n, nq, nrows):
     assert bad[nrows // 2] and bad.sum() == 1
 
 
+def test_large_vector_route_plan_keeps_no_dense_copy():
+    """A spline from many more knots than queries runs on the vector route (the window of knots under 64 queries is many bandwidths wide); its
+    dense copy (16 384 x 1024 doubles = 134 MB per plan) is not built: forcing the matrix-core route is refused, the default and the vector
+    route agree with the dense operator."""
+    import torch
+    from cosmoprimo_amd.spline import LinearOperator, dense_operator
+    rng = np.random.default_rng(5)
+    x, xq = np.linspace(0., 1., 16384), np.sort(rng.uniform(0., 1., 1024))
+    LinearOperator.spline(x[:64], xq[:8] * x[63], bc='natural')      # (the library and its kernels are loaded)
+    torch.cuda.synchronize()
+    before = torch.cuda.mem_get_info()[0]
+    op = LinearOperator.spline(x, xq, bc='natural')
+    assert before - torch.cuda.mem_get_info()[0] < (64 << 20)
+    y = rng.normal(size=(20, 16384))
+    ty = torch.as_tensor(y, device=op.device)
+    with pytest.raises(ValueError):
+        op(ty, path='mfma')
+    ref = y.dot(dense_operator(x, xq, bc='natural').T)
+    for path in (None, 'valu'):
+        assert np.abs(op(ty, path=path).cpu().numpy() - ref).max() < 1e-13 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize('n,nq,bc,nrows', [(512, 300, 'natural', 1), (504, 1024, 'not-a-knot', 77), (2048, 2048, 'clamped', 40), (1024, 256, 'natural', 33),
                                            (40, 1000, 'not-a-knot', 16), (3666, 1024, 'clamped', 19)])
 def test_banded_operator_on_both_paths(n, nq, bc, nrows):
