@@ -435,6 +435,115 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     return CP_OK;
 }
 
+// ---- few radii: sigma^2(r_q) as a linear functional of the spectrum --------------------------------------------------------------------------
+// The transform and the spline are linear in P(k): for fixed wavenumbers and radii sigma^2(r_q) = sum_j F[q, j] P(k_j), with F the rows that
+// the pipeline (FFTLog, natural spline to r) returns for unit spectra.  For the sigma8 normalisation of a batch of analytic cosmologies (one radius,
+// one redshift: eisenstein_hu.py:94-103, 331-342) that is a dot product per cosmology behind the evaluation of P(k) -- no transform, no LDS, no
+// barrier: one wave per cosmology, a lane evaluates nk / 64 samples (the arithmetic of power_kernel on the tabulated log k: the same bits),
+// multiplies them into its NQ partial sums, the wave adds them up.  16 384 cosmologies: see DESIGN.md section 4 (config 4).
+namespace {
+
+constexpr int FUNCTIONAL_MAX_NQ = 4;
+
+struct FunctionalArgs {
+    long long ncosmo;
+    Param bg[CP_BG_NPARAMS];
+    Param pw[CP_PK_NPARAMS];
+    int second_is_omega_m;
+    int nk, nq, nz;
+    const double* k;              // (nk) wavenumbers, h/Mpc
+    const double* ln_k;           // (nk) their logarithms (log_wavenumbers_kernel)
+    const EhScalars* scal;        // (ncosmo) fit coefficients, unused for BBKS
+    const double* functional;     // (nq, nk)
+    const double* growth_sq;      // (ncosmo, nz)
+    double* out;                  // (ncosmo, nq, nz)
+    double* pk_out;               // (ncosmo, nk) or null
+};
+
+template <int ENGINE>
+__global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalArgs S) {
+    const int lane = threadIdx.x & 63;
+    const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ic >= S.ncosmo) return;
+    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m);
+    double pw[CP_PK_NPARAMS];
+#pragma unroll
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
+    EhScalars s{};
+    if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
+    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
+    const PkPerCosmology pc = pk_per_cosmology(c, pw);
+    double acc[FUNCTIONAL_MAX_NQ];
+#pragma unroll
+    for (int q = 0; q < FUNCTIONAL_MAX_NQ; ++q) acc[q] = 0.;
+#pragma unroll 2
+    for (int j = lane; j < S.nk; j += 64) {
+        const double kh = S.k[j], ln_kh = S.ln_k[j];
+        double Tk;
+        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
+        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh);
+        if (S.pk_out) S.pk_out[ic * S.nk + j] = pk;
+#pragma unroll
+        for (int q = 0; q < FUNCTIONAL_MAX_NQ; ++q)
+            if (q < S.nq) acc[q] = fma(S.functional[q * S.nk + j], pk, acc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < FUNCTIONAL_MAX_NQ; ++q)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc[q] += __shfl_xor(acc[q], off);
+    for (int e = lane; e < S.nq * S.nz; e += 64) {
+        const int q = e / S.nz, z = e - q * S.nz;
+        double v = acc[0];
+#pragma unroll
+        for (int qq = 1; qq < FUNCTIONAL_MAX_NQ; ++qq) v = q == qq ? acc[qq] : v;
+        S.out[ic * (long long)(S.nq * S.nz) + e] = sqrt(v) * sqrt(S.growth_sq[ic * S.nz + z]);      // the fused kernel's product of roots
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+                                      const double* d_k, const double* d_functional, int nq, const double* d_growth_sq, int nz, double* d_out,
+                                      double* d_pk_out, void* d_work, int device, void* stream) {
+    if (ncosmo < 0 || nk <= 0 || nz <= 0 || nq <= 0) return cp::fail(CP_EINVAL, "cp_sigma_rz_functional: bad sizes");
+    if (nq > FUNCTIONAL_MAX_NQ) return cp::fail(CP_EUNSUPPORTED, "cp_sigma_rz_functional: %d radii (at most %d: use cp_sigma_rz_analytic)", nq, FUNCTIONAL_MAX_NQ);
+    if (engine != CP_ENGINE_EH && engine != CP_ENGINE_EH_NOWIGGLE && engine != CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_sigma_rz_functional: unknown engine %d", engine);
+    if (ncosmo == 0) return CP_OK;
+    if (!bg_params || !pk_params || !d_k || !d_functional || !d_growth_sq || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_sigma_rz_functional: null pointer");
+    char* coef = static_cast<char*>(d_work);
+    coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, coef, device, stream);
+    if (st != CP_OK) return st;
+    FunctionalArgs S{};
+    S.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) S.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) S.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};
+    S.second_is_omega_m = second_is_omega_m;
+    S.nk = nk; S.nq = nq; S.nz = nz;
+    S.k = d_k;
+    S.scal = reinterpret_cast<const EhScalars*>(coef);
+    double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
+    S.ln_k = ln_k;
+    S.functional = d_functional;
+    S.growth_sq = d_growth_sq;
+    S.out = d_out;
+    S.pk_out = d_pk_out;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_functional: cannot select device %d", device);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(log_wavenumbers_kernel, dim3((nk + 255) / 256), dim3(256), 0, hs, d_k, ln_k, nk);
+    const unsigned grid = (unsigned)((ncosmo + 3) / 4);
+    if (engine == CP_ENGINE_EH) hipLaunchKernelGGL(sigma_functional_kernel<CP_ENGINE_EH>, dim3(grid), dim3(256), 0, hs, S);
+    else if (engine == CP_ENGINE_EH_NOWIGGLE) hipLaunchKernelGGL(sigma_functional_kernel<CP_ENGINE_EH_NOWIGGLE>, dim3(grid), dim3(256), 0, hs, S);
+    else hipLaunchKernelGGL(sigma_functional_kernel<CP_ENGINE_BBKS>, dim3(grid), dim3(256), 0, hs, S);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_functional: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
 // FFTLog of (nbatch, n) rows followed by the spline of every output row to the plan's queries (root taken when post_op is CP_SPLINE_POST_SQRT), as one
 // kernel; d_out : (nbatch, nq).  Plans as for cp_sigma_rz_fused_available.
 extern "C" int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_in, double* d_out, long long nbatch,

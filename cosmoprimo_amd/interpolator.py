@@ -171,6 +171,7 @@ def _cached_operator(key, build):
 # busy (tools/bench_fused_spline.py); large batches (config 3B: 640 000 rows) and single radii (sigma8) take the two kernels.
 _FUSED_SPLINE_ROWS = (2, 8192)
 _TRANSPOSE_IN_STORE = True
+_FUNCTIONAL_RADII = 4          # sigma_rz_analytic: up to this many radii as dot products with the spectrum (cp_sigma_rz_functional)
 _DIRECT_K_SPLINE = True        # batches of (k, z) tables: the k splines evaluated from the tables' second derivatives (cp_tables_rows_direct) instead of multiplied
 
 
@@ -922,6 +923,15 @@ def sigma_rz_analytic(engine, bg, pk, r, growth_sq, device, kmin=1e-7, kmax=1e2,
     spectra = torch.empty((nb, nk), dtype=torch.float64, device=device) if keep_spectra else None
     work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(nb, nk)), dtype=torch.uint8, device=device)
     growth_sq = growth_sq.contiguous()
+    if 1 <= rr.size <= _FUNCTIONAL_RADII and blocks == 0:
+        # few radii (sigma8: one): transform and spline are linear in P(k) -- sigma^2(r_q) = sum_j F[q, j] P(k_j), F = what the two return for unit
+        # spectra, computed once per (grid, radii) -- and the kernel is the evaluation of P(k) with a dot product behind it
+        functional = _cached_operator(('sigma_functional', key, rr.tobytes()),
+                                      lambda: op(fft(torch.eye(nk, dtype=torch.float64, device=device))[1]).transpose(0, 1).contiguous())
+        _lib.check(lib.cp_sigma_rz_functional(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
+                                              functional.data_ptr(), rr.size, growth_sq.data_ptr(), nz, out.data_ptr(),
+                                              spectra.data_ptr() if keep_spectra else None, work.data_ptr(), device.index, dv.stream_of(device)))
+        return out, spectra, k
     _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
                                         fft._get_plan(device).handle, op._handle, growth_sq.data_ptr(), nz, out.data_ptr(),
                                         spectra.data_ptr() if keep_spectra else None, work.data_ptr(), blocks, device.index, dv.stream_of(device)))

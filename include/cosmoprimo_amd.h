@@ -307,6 +307,12 @@ long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk);
 int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
                          const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
                          double* d_out, double* d_pk_out, void* d_work, int nblocks, int device, void* stream);
+/* the same for at most 4 radii (the sigma8 normalisation: one) as a linear functional of the spectrum: d_functional (nq, nk) holds the rows F with
+ * sigma^2(r_q) = sum_j F[q, j] P(k_j) -- what the caller's transform + spline return for unit spectra --, the kernel evaluates P(k) and the dot
+ * products, one wave per cosmology, no transform.  d_work, d_pk_out as for cp_sigma_rz_analytic; d_out (ncosmo, nq, nz). */
+int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+                           const double* d_k, const double* d_functional, int nq, const double* d_growth_sq, int nz, double* d_out, double* d_pk_out,
+                           void* d_work, int device, void* stream);
 
 
 /* clamped cubic spline through uniformly spaced knots (positions 1..n) of x^2-weighted data with the knots of a per-column box

@@ -95,3 +95,42 @@ def test_block_walk_on_two_streams():
             np.testing.assert_allclose(interp.sigma_rz(r, z), separate, rtol=1e-13, atol=0)      # (pairs of cosmologies differ at block edges)
     finally:
         kind._two_stream_min_bytes, kind._two_stream_blocks = saved
+
+
+@pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
+def test_few_radii_as_a_functional_of_the_spectrum(engine):
+    """cp_sigma_rz_functional (up to four radii: the sigma8 normalisation) against the fused kernel of the same helper: sigma(r, z), and the spectra
+    it hands back, which are cp_power_eval's bit for bit; odd batches, one to four radii, a NaN cosmology next to good ones."""
+    import torch
+    from cosmoprimo_amd import interpolator as itp
+    warnings.simplefilter('ignore')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    for n, nr, nz in ((1, 1, 1), (7, 1, 1), (130, 3, 5), (33, 4, 2)):
+        par = parameters(n, 3 * n + nr)
+        if n == 7:
+            par['n_s'][4] = np.nan
+        bg = dict(h=torch.as_tensor(par['h'], device=dev), Omega_cdm=torch.as_tensor(par['Omega_m'] - par['Omega_b'], device=dev),
+                  Omega_b=torch.as_tensor(par['Omega_b'], device=dev))
+        pk = dict(n_s=torch.as_tensor(par['n_s'], device=dev))
+        r = np.geomspace(2., 60., nr) if nr > 1 else np.array([8.])
+        g2 = torch.as_tensor(np.random.default_rng(n).uniform(0.2, 1., (n, nz)), device=dev)
+        saved = itp._FUNCTIONAL_RADII
+        try:
+            itp._FUNCTIONAL_RADII = 4
+            out_f, pk_f, k = itp.sigma_rz_analytic(engine, bg, pk, r, g2, dev, keep_spectra=True)
+            itp._FUNCTIONAL_RADII = 0
+            out_t, pk_t, _ = itp.sigma_rz_analytic(engine, bg, pk, r, g2, dev, keep_spectra=True)
+        finally:
+            itp._FUNCTIONAL_RADII = saved
+        out_f, out_t, pk_f, pk_t = (t.cpu().numpy() for t in (out_f, out_t, pk_f, pk_t))
+        assert out_f.shape == (n, nr, nz)
+        assert np.array_equal(np.isnan(out_f), np.isnan(out_t))
+        if n == 7:
+            assert np.isnan(out_f[4]).all() and np.isfinite(np.delete(out_f, 4, axis=0)).all()
+        np.testing.assert_allclose(out_f, out_t, rtol=2e-13, atol=0, err_msg=str((engine, n, nr, nz)))
+        # the fused kernel steps k geometrically (1e-15 on k after 8 steps of 128 samples); BBKS as coded takes log(1 + 2.34 q) / (2.34 q) at q ~ 1e-5,
+        # where an ulp of q is 1e-11 of the ratio (bbks.py:64)
+        np.testing.assert_allclose(pk_f, pk_t, rtol=1e-10 if engine == 'bbks' else 2e-13, atol=0)
+        from cosmoprimo_amd import power
+        direct = power.analytic(engine, 'matter', k, bg=bg, pk=pk, device=dev).cpu().numpy().reshape(pk_f.shape)
+        assert np.array_equal(direct, pk_f, equal_nan=True)
