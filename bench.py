@@ -175,9 +175,11 @@ def _config4_valu_roofline(engine, vectors_per_s):
             'source': os.path.relpath(files[-1], ROOT)}
 
 
-def config4(cp, torch, dev, par, chunk=16384, engines=('wallish2018', 'brieden2022')):
+def config4(cp, torch, dev, par, chunk=32768, engines=('wallish2018', 'brieden2022')):
     """wallish2018 and brieden2022 on EH98 P(k) vectors (nk = 1024) of the cosmologies ``par``, chunk by chunk (P(k) generation and sigma8
-    normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time."""
+    normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time.
+    chunk : vectors per pass (1 GB per 4096-sample intermediate at 32 768; rounds 2 and 3 up to their last hours: 16 384, where the ~40 launches
+    of brieden2022 per chunk take the host about as long as they take the device -- 9 to 10.9e6 vectors/s from run to run against 12e6)."""
     import warnings
     from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
     n = int(par['Omega_m'].numel())
@@ -262,7 +264,7 @@ def secondary(cp, torch, dev):
     out['config3b'] = config3b(cp, torch, dev)
     torch.cuda.empty_cache()
     c4 = config4(cp, torch, dev, eh_parameters(4 * 16384, 2, torch, dev))
-    out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on 65 536 EH98 P(k) vectors (four 16 384-vector chunks of a GPU share of 125 000, '
+    out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on 65 536 EH98 P(k) vectors (two 32 768-vector chunks of a GPU share of 125 000, '
                                          'queued back to back as the whole share is), P(k) generation and sigma8 normalisation included, results resident')
     out['config5'] = config5(torch, dev, *config5_samples(1250000, 3, torch, dev))
     return out
