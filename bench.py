@@ -34,6 +34,8 @@ if ROOT not in sys.path:
 N_K = 2048
 ROWS_PER_GPU = 100000
 HBM_PEAK_GBS = 8000.          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6       # MI355X_MICROARCH.md: dense fp64, vector = matrix
+CONFIG4_CHUNK = 32768         # vectors per pass of config 4; tests/test_full_size_gpu.py runs the one-GPU share at this size (imported from here)
 BYTES_PER_ROW = 2 * 8 * N_K   # read N f64 + write N f64 (tables are batch-shared, excluded)
 
 
@@ -129,11 +131,18 @@ def config3(cp, torch, dev, ncosmo=10000, reps=5):
         interp = cosmo.get_fourier().pk_interpolator()
         r, z = torch.as_tensor(np.geomspace(1, 100, 256), device=dev), torch.as_tensor(np.linspace(0, 3, 64), device=dev)
         wall, gpu = _gpu_ms(lambda: interp.sigma_rz(r, z), reps, torch, dev)
+        # untimed, after the clock: one sampled cosmology of the timed call's result against the oracle (1e-9)
+        from oracle import checks
+        par, i = eh_parameters(ncosmo, 1, torch, torch.device('cpu')), 4321 % ncosmo
+        ref = checks.config3_sigma_rz({name: float(v[i]) for name, v in par.items()}, r.cpu().numpy(), z.cpu().numpy())
+        err = checks.max_relative_error(interp.sigma_rz(r, z)[i].cpu().numpy(), ref)
+        assert err < checks.TOLERANCES['config3'], 'config 3 failed its parity spot check: %g' % err
     nbytes = ncosmo * (256 * 64 * 8 + 80)
     return {'workload': 'config 3: sigma_rz 256 r x 64 z, %d EH98 cosmologies, method fftlog nk=1024, through PowerSpectrumInterpolator2D.sigma_rz' % ncosmo,
             'value': ncosmo / (wall * 1e-3), 'unit': 'cosmologies/s', 'ms': wall, 'ms_gpu_events': gpu,
             'roofline': {'bound': 'hbm', 'achieved': nbytes / (wall * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': nbytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_cosmology': 256 * 64 * 8 + 80}}
+                         'frac': nbytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_cosmology': 256 * 64 * 8 + 80},
+            'parity_spot_check': {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config3'], 'unit_checked': 'cosmology %d, 256 r x 64 z, vs oracle' % i}}
 
 
 def config3b(cp, torch, dev, ncosmo=10000, reps=5):
@@ -147,14 +156,26 @@ def config3b(cp, torch, dev, ncosmo=10000, reps=5):
     interp = cp.PowerSpectrumInterpolator2D(g['table_k'], g['table_z'], tables)
     r, z = torch.as_tensor(np.geomspace(1, 100, 256), device=dev), torch.as_tensor(np.linspace(0, 3, 64), device=dev)
     wall, gpu = _gpu_ms(lambda: interp.sigma_rz(r, z), reps, torch, dev)
+    # untimed, after the clock: one sampled table of the timed call's result against the oracle's RectBivariateSpline route (1e-9)
+    from oracle import checks
+    i = 4242 % ncosmo
+    ref = checks.config3b_sigma_rz(g['table_k'], g['table_z'], float(amp[i]) * g['table_pk'], r.cpu().numpy(), z.cpu().numpy())
+    err = checks.max_relative_error(interp.sigma_rz(r, z)[i].cpu().numpy(), ref)
+    assert err < checks.TOLERANCES['config3b'], 'config 3B failed its parity spot check: %g' % err
     nbytes = ncosmo * (500 * 30 * 8 + 256 * 64 * 8)
+    # fp64 work per table that no implementation of this route can avoid: 64 FFTLogs of Np = 2048 (two complex FFTs per packed pair of rows = one
+    # per row, 5 Np log2 Np flop) and the contraction of the 30 tabulated redshifts onto the 64 requested ones at the 1024 wavenumbers of the transform
+    flop = 64 * 5 * 2048 * 11 + 2 * 64 * 30 * 1024
     return {'workload': 'config 3B: sigma_rz 256 r x 64 z, %d tabulated P(k, z) of 500 k x 30 z, method fftlog nk=1024 (64 FFTLogs per table), through '
                         'PowerSpectrumInterpolator2D.sigma_rz' % ncosmo,
             'value': ncosmo / (wall * 1e-3), 'unit': 'cosmologies/s', 'ms': wall, 'ms_gpu_events': gpu,
             'roofline': {'bound': 'hbm', 'achieved': nbytes / (wall * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': nbytes / (wall * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_cosmology': 500 * 30 * 8 + 256 * 64 * 8,
-                         'note': '64 FFTLogs (Np = 2048) per table: their fp64 work alone is ~1.8 ms per 10 000 tables at the vector peak the headline '
-                                 'kernel reaches (DESIGN.md section 4), 11 % of HBM on these bytes'}}
+                         'note': 'compute-bound on these bytes (arithmetic intensity %.0f flop/B): see roofline_fp64' % (flop / (500 * 30 * 8 + 256 * 64 * 8))},
+            'roofline_fp64': {'bound': 'mfma', 'achieved': ncosmo * flop / (wall * 1e-3) / 1e12, 'peak': FP64_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                              'frac': ncosmo * flop / (wall * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, 'algorithmic_flop_per_cosmology': flop,
+                              'note': '64 FFTLogs (5 Np log2 Np, Np = 2048) + the 30 -> 64 redshift contraction at 1024 wavenumbers; vector and matrix fp64 peaks are equal'},
+            'parity_spot_check': {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config3b'], 'unit_checked': 'table %d, 256 r x 64 z, vs oracle' % i}}
 
 
 def _config4_valu_roofline(engine, vectors_per_s):
@@ -175,7 +196,7 @@ def _config4_valu_roofline(engine, vectors_per_s):
             'source': os.path.relpath(files[-1], ROOT)}
 
 
-def config4(cp, torch, dev, par, chunk=32768, engines=('wallish2018', 'brieden2022')):
+def config4(cp, torch, dev, par, chunk=CONFIG4_CHUNK, engines=('wallish2018', 'brieden2022'), spot_check=True):
     """wallish2018 and brieden2022 on EH98 P(k) vectors (nk = 1024) of the cosmologies ``par``, chunk by chunk (P(k) generation and sigma8
     normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time.
     chunk : vectors per pass (1 GB per 4096-sample intermediate at 32 768; rounds 2 and 3 up to their last hours: 16 384, where the ~40 launches
@@ -198,6 +219,7 @@ def config4(cp, torch, dev, par, chunk=32768, engines=('wallish2018', 'brieden20
                     state['filter'] = PowerSpectrumBAOFilter(interp, engine=engine, **(dict(kw, cosmo=cosmo) if kw else {}))
                 else:
                     state['filter'](interp, cosmo=cosmo if kw else None)
+                state['cosmo'] = cosmo
                 return state['filter']._pknow_rows
 
             _ramp(lambda: run(slice(0, min(n, chunk))), torch, dev)       # plans, operators and code objects are built on first use; clock ramp
@@ -211,8 +233,19 @@ def config4(cp, torch, dev, par, chunk=32768, engines=('wallish2018', 'brieden20
             torch.cuda.synchronize(dev)
             wall = time.perf_counter() - t0
             assert bool(torch.isfinite(res).all())
+            check = None
+            if spot_check:      # untimed, after the clock: one sampled vector of the last timed chunk against the oracle's filter (1e-9 on pknow)
+                from oracle import checks
+                last = (n - 1) // chunk * chunk
+                j = (n - last) // 3
+                rsig = float(state['cosmo']._engine._rsigma8.reshape(-1)[j])
+                ref = checks.config4_pknow({name: float(v[last + j]) for name, v in par.items()}, rsig, engine)
+                err = checks.max_relative_error(res.reshape(n - last, -1)[j].cpu().numpy(), ref)
+                assert err < checks.TOLERANCES['config4'], 'config 4 (%s) failed its parity spot check: %g' % (engine, err)
+                check = {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config4'], 'unit_checked': 'vector %d (chunk of %d), pknow at 1024 k, vs oracle' % (last + j, chunk)}
             valu = _config4_valu_roofline(engine, n / wall)
-            out[engine] = {'value': n / wall, 'unit': 'vectors/s', 'ms': wall * 1e3, 'ms_gpu_events': e0.elapsed_time(e1), 'vectors': n, 'roofline_valu': valu,
+            out[engine] = {'value': n / wall, 'unit': 'vectors/s', 'ms': wall * 1e3, 'ms_gpu_events': e0.elapsed_time(e1), 'vectors': n, 'chunk': chunk,
+                           'parity_spot_check': check, 'roofline_valu': valu,
                            'roofline': {'bound': 'hbm', 'achieved': n * 16384 / wall / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                         'frac': n * 16384 / wall / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_vector': 16384,
                                         'note': 'latency / ALU bound by construction (SURVEY.md 8(d)): the HBM fraction is reported, not targeted'}}
@@ -235,13 +268,22 @@ def _config5_valu_roofline(samples_per_s):
             'source': os.path.relpath(files[-1], ROOT)}
 
 
-def config5(torch, dev, om, w0, wa, zz, reps=5):
+def config5(torch, dev, om, w0, wa, zz, reps=5, spot_check=True):
     from cosmoprimo_amd import background
     n = int(zz.numel())
-    wall, gpu = _gpu_ms(lambda: background.distance('comoving_radial_distance', zz[:, None], dict(w0_fld=w0, wa_fld=wa), Omega_m=om, per_cosmology_z=True),
-                        reps, torch, dev)
+    fn = lambda: background.distance('comoving_radial_distance', zz[:, None], dict(w0_fld=w0, wa_fld=wa), Omega_m=om, per_cosmology_z=True)      # noqa: E731
+    wall, gpu = _gpu_ms(fn, reps, torch, dev)
+    check = None
+    if spot_check:      # untimed, after the clock: 300 sampled distances against the oracle (1e-10)
+        from oracle import checks
+        idx = np.random.default_rng(33).integers(0, n, 300)
+        tidx = torch.as_tensor(idx, device=dev)
+        ref = checks.config5_distances(*(v[tidx].cpu().numpy() for v in (om, w0, wa, zz)))
+        err = checks.max_relative_error(fn()[:, 0][tidx].cpu().numpy(), ref)
+        assert err < checks.TOLERANCES['config5'], 'config 5 failed its parity spot check: %g' % err
+        check = {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config5'], 'unit_checked': '300 sampled distances vs oracle'}
     return {'workload': 'config 5: comoving_radial_distance for %d (Omega_m, w0, wa, z) samples, one fresh cosmology per sample' % n,
-            'value': n / (wall * 1e-3), 'unit': 'samples/s', 'ms': wall, 'ms_gpu_events': gpu,
+            'value': n / (wall * 1e-3), 'unit': 'samples/s', 'ms': wall, 'ms_gpu_events': gpu, 'parity_spot_check': check,
             # what bounds the kernel is the issue rate of the vector pipes: every vector instruction it executes, counted by the profiler
             # (the intervals a sample needs -- those below it and `reach` above it -- times two ordinates of ~44 instructions, plus the eliminations)
             'roofline': dict(_config5_valu_roofline(n / (wall * 1e-3)) or {}, hbm_GBps=n * 40 / (wall * 1e-3) / 1e9)}
@@ -263,9 +305,10 @@ def secondary(cp, torch, dev):
     out = {'config3': config3(cp, torch, dev)}
     out['config3b'] = config3b(cp, torch, dev)
     torch.cuda.empty_cache()
-    c4 = config4(cp, torch, dev, eh_parameters(4 * 16384, 2, torch, dev))
-    out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on 65 536 EH98 P(k) vectors (two 32 768-vector chunks of a GPU share of 125 000, '
-                                         'queued back to back as the whole share is), P(k) generation and sigma8 normalisation included, results resident')
+    c4 = config4(cp, torch, dev, eh_parameters(2 * CONFIG4_CHUNK, 2, torch, dev))
+    out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on %d EH98 P(k) vectors (two %d-vector chunks of a GPU share of 125 000, '
+                                         'queued back to back as the whole share is), P(k) generation and sigma8 normalisation included, results resident'
+                                         % (2 * CONFIG4_CHUNK, CONFIG4_CHUNK))
     out['config5'] = config5(torch, dev, *config5_samples(1250000, 3, torch, dev))
     return out
 
@@ -290,11 +333,11 @@ def main_split(args, config):
     if config == 4:
         full = eh_parameters(total, 2, torch, torch.device('cpu'))
         par = {name: v[start:stop].to(dev) for name, v in full.items()}
-        run = lambda: config4(cp, torch, dev, par)      # noqa: E731
+        run = lambda check=False: config4(cp, torch, dev, par, spot_check=check)      # noqa: E731
     else:
         full = config5_samples(total, 3, torch, torch.device('cpu'))
         mine = tuple(v[start:stop].to(dev) for v in full)
-        run = lambda: config5(torch, dev, *mine, reps=1)      # noqa: E731
+        run = lambda check=False: config5(torch, dev, *mine, reps=1, spot_check=check)      # noqa: E731
     for _ in range(max(1, args.warmup)):
         run()
     torch.cuda.synchronize(dev)
@@ -304,14 +347,21 @@ def main_split(args, config):
     for _ in range(args.steps):
         last = run()
     torch.cuda.synchronize(dev)
+    t_done = time.perf_counter()
     if launched:
         dist.barrier()
     elapsed = time.perf_counter() - tic
+    own_ms = (t_done - tic) / args.steps * 1e3      # this rank's own steps, before it waited for the others
+    rank_ms = [own_ms]
+    checked = run(check=True) if rank == 0 else None      # untimed: the rank's share once more with the oracle spot check of each config
     gather_ms = None
     if launched:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax[0])
+        every = torch.zeros(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, torch.tensor([own_ms], device=dev, dtype=torch.float64))
+        rank_ms = [float(v) for v in every]
         if args.gather:
             local = torch.zeros((stop - start, 1024 if config == 4 else 1), dtype=torch.float64, device=dev)      # the shape of a rank's results
             gather_rows(local, n_total=total)
@@ -331,6 +381,8 @@ def main_split(args, config):
                 'config': {'workload': 'config %d: %d %s split over %d GPU(s) in contiguous blocks, no collective' % (
                     config, total, 'EH98 P(k) vectors through both filters' if config == 4 else '(Omega_m, w0, wa, z) samples', world),
                     'per_gpu': stop - start, 'rccl_ranks': world if launched else 0},
+                'ms_per_step_rank_min': min(rank_ms), 'ms_per_step_rank_max': max(rank_ms), 'ms_per_step_by_rank': rank_ms,
+                'parity_spot_check': ({e: checked[e]['parity_spot_check'] for e in checked} if config == 4 else checked['parity_spot_check']),
                 'rank0_detail': last}
         if gather_ms is not None:
             line['gather_ms'] = gather_ms
@@ -456,11 +508,13 @@ def main():
         step()
     e1.record(stream)
     torch.cuda.synchronize(dev)
+    t_done = time.perf_counter()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - tic
     kernel_ms = e0.elapsed_time(e1) / args.steps
+    rank_ms = [(t_done - tic) / args.steps * 1e3]      # this rank's own K steps, before it waited for the others
     # untimed, afterwards: the same K launches bracketed one by one (the spread between launches; the minimum is the quiet-device duration)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -496,6 +550,9 @@ def main():
         tmax = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tmax[0]), float(tmax[1])
+        every = torch.zeros(world, device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, torch.tensor(rank_ms, device=dev, dtype=torch.float64))
+        rank_ms = [float(v) for v in every]      # a straggler shows at a glance on the first multi-GPU run
         if args.gather:
             from cosmoprimo_amd.distributed import gather_rows
             full = torch.empty((world * nb, N_K), dtype=out.dtype, device=dev)
@@ -542,6 +599,7 @@ def main():
         line = {
             'metric': 'batched FFTLog P(k)->xi(r) transforms/sec (N=2048)', 'value': value, 'unit': 'transforms/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'ms_per_step_rank_min': min(rank_ms), 'ms_per_step_rank_max': max(rank_ms), 'ms_per_step_by_rank': rank_ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'config 2: %d rows x N_k=%d per GPU, PowerToCorrelation(ell=0), Np=4096, extrap=0' % (nb, N_K),
                        'rows_per_gpu': nb, 'n_k': N_K, 'padded_size': 4096, 'parallelism': 'rows sharded over %d GPU(s), no collective' % world,

@@ -62,7 +62,12 @@ SIGNATURES = {
                                     ctypes.c_void_p]),
     'cp_power_eval_variants': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'cp_rfft_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
+    'cp_rfft_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_rfft_forward': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]),
+    'cp_rfft_backward': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
     'cp_eh_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'cp_variants_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_sigma_rz_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
     'cp_sigma_rz_fused_available': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'cp_fftlog_spline_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
@@ -148,6 +153,8 @@ SPLINE_BC = {'natural': 0, 'clamped': 1, 'not-a-knot': 2}
 PK_PARAMS = ('A_s', 'n_s', 'alpha_s', 'beta_s', 'k_pivot')
 ENGINES = {'eisenstein_hu': 0, 'eisenstein_hu_nowiggle': 1, 'bbks': 2}
 PK_WHAT = {'matter': 0, 'transfer': 1, 'primordial': 2, 'log_k_matter': 3}
+VARIANTS_SCALARS = ('omega_b', 'omega_m', 'frac_b', 'frac_cdm', 'frac_cb', 'frac_ncdm', 'theta_cmb', 'z_eq', 'k_eq', 'z_drag', 'rs_drag', 'p_c', 'p_cb',
+                    'gamma_ncdm', 'beta_c')      # enum cp_variants_scalar
 EH_SCALARS = ('rs_drag', 'z_drag', 'z_eq', 'k_eq', 'r_drag', 'r_eq', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b', 'alpha_gamma',
               'gamma')
 BG_KINDS = {'comoving_radial_distance': 0, 'comoving_transverse_distance': 1, 'angular_diameter_distance': 2, 'luminosity_distance': 3,

@@ -16,6 +16,7 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
+#include "cp_internal.h"
 
 namespace {
 
@@ -152,6 +153,8 @@ struct GapTable {      // the same recurrence started from 0 (gap_spline_kernel 
 };
 __constant__ GapTable gap_table = GapTable();
 
+using cp::wave_lds_phase;
+
 __device__ __forceinline__ void dd_argmax_merge(double& v, int& i, double ov, int oi) {      // first index of the maximum, NaN counts as largest (numpy)
     const bool take = (ov > v && !(v != v)) || (ov != ov && !(v != v)) || (((ov == v) || (ov != ov && v != v)) && oi < i);
     if (take) {
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
     const double* src = y + row * N;
 #pragma unroll
     for (int k = 0; k < S; ++k) buf[(lane + 64 * k) + (lane + 64 * k) / S] = nxt[k];
+    wave_lds_phase();      // the sequence is in LDS before any lane reads its neighbours' knots
     if (row + (long long)gridDim.x * 4 < nrows) {
 #pragma unroll
         for (int k = 0; k < S; ++k) nxt[k] = y[(row + (long long)gridDim.x * 4) * N + lane + 64 * k];
@@ -230,6 +234,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
             ym = y0;
             y0 = yp;
         }
+        wave_lds_phase();      // every lane is through its run-in (knots of its left neighbours) before those are overwritten by d
 #pragma unroll 8
         for (int t = 0; t < S; ++t) {
             const int i = own + t;
@@ -240,6 +245,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
             y0 = yp;
         }
     }
+    wave_lds_phase();      // d complete
     double best = -__builtin_inf();
     int best_i = 0x7fffffff;
     {
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
             const double d = clamped(i);
             m = i >= N - 1 ? d : d - c_of(i) * m;
         }
+        wave_lds_phase();      // run-in from the right done before the neighbours' d become M
 #pragma unroll 8
         for (int t = 0; t < S; ++t) {
             const int i = own + S - 1 - t;
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
             }
         }
     }
+    wave_lds_phase();      // M complete
     if (dd_out) {
         double* dst = dd_out + row * N;
 #pragma unroll 4
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
         box[2 * row] = first + off0;
         box[2 * row + 1] = second + off1;
     }
+    wave_lds_phase();      // the last reads of M are done: the buffer is free for the next phase / the next sequence
     if (!gap) continue;
     // The removal of the box (cp_gap_spline, bao_filter.py:395-405), on the sequence in memory: the clamped spline through the x^2-weighted
     // coefficients with the knots [a, b] left out returns the datum at every kept knot, so only the box is rewritten; its two end slopes come
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
         const double x = (double)(R + e + 1);
         zr[e] = src[R + e] * (x * x);
     }
+    wave_lds_phase();      // zl / zr written by all lanes, read by lanes 0 and 1
     auto z = [&](int i) { return i <= L ? zl[i - lo] : zr[i - R]; };
     double r0 = 0., r1 = 0.;
     if (lane == 0) {            // forward sweep up to L: s_L + cpL s_R = dpL
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
         const double u = (double)(i - L), x = (double)(i + 1);
         seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
     }
+    wave_lds_phase();      // zl / zr read before the next sequence is staged over them
     }
 }
 
@@ -431,9 +442,7 @@ extern "C" int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int 
     hipStream_t hs = static_cast<hipStream_t>(stream);
 #define CP_DD_LAUNCH(S_)                                                                                                                             \
     do {                                                                                                                                             \
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&wallish_dd_box_kernel<S_>),                                \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * (64 * S_ + 64) + 2 * DD_NTAB) * sizeof(double))); \
-        (void)attr;                                                                                                                                  \
+        (void)cp::allow_full_lds<&wallish_dd_box_kernel<S_>>();                                                                                      \
         hipLaunchKernelGGL(wallish_dd_box_kernel<S_>, dim3(grid), dim3(256), lds, hs, d_y, nrows, margin_first, margin_second, offset_first,          \
                            offset_second, d_box, d_dd, d_gap);                                                                                       \
     } while (0)
@@ -537,11 +546,13 @@ __global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
         const int i = lane + 64 * k;
         if (i < n) buf[i] = knots[k];
     }
+    wave_lds_phase();
     {
         const double first = buf[0], last = buf[n - 1];      // (LDS takes a wave's accesses in order)
         for (int e = lane; e < pad; e += 64) buf[-1 - e] = first;
         for (int e = n + lane; e < 64 * S + pad; e += 64) buf[e] = last;
     }
+    wave_lds_phase();      // knot values staged, ends repeated
     if (row + (long long)gridDim.x * 4 < A.nrows) fetch(row + (long long)gridDim.x * 4, knots);
     if (!(CP_SPLICE_ABLATE & 1)) {
         const double beyond = buf[own + S];      // the next segment's first knot, before its owner writes there
@@ -558,6 +569,7 @@ __global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
             sigma_m = sigma;
             y0 = yp;
         }
+        wave_lds_phase();      // run-ins done before the neighbours' knot values become d
 #pragma unroll 4
         for (int t = 0; t < S - 1; ++t) {
             const int i = own + t;
@@ -576,6 +588,7 @@ __global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
             buf[i] = fma(-c.z, d, c.y * (sigma - sigma_m));
         }
     }
+    wave_lds_phase();      // d complete
     if (!(CP_SPLICE_ABLATE & 1)) {
         double m = 0.;
 #pragma unroll 4
@@ -584,6 +597,7 @@ __global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
             const double d = buf[i];
             m = i >= n - 1 ? d : fma(-coef[slot_of(i)].w, m, d);      // (beyond the last knot: M_{n-1} = d_{n-1} when the sweep gets there)
         }
+        wave_lds_phase();
 #pragma unroll 4
         for (int t = 0; t < S; ++t) {
             const int i = own + S - 1 - t;
@@ -592,6 +606,7 @@ __global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
             buf[i] = m;
         }
     }
+    wave_lds_phase();      // M complete: the evaluation gathers across segments
     // Queries that fall on a knot taken from their own column of array 0 (wallish2018: every k below and above the linear grid) return that
     // value: whole blocks of 64 such queries skip the tables.  For the others the table entries and the gathered knot values of four blocks are
     // fetched together (registers are plentiful at one wave per SIMD).
@@ -618,6 +633,7 @@ __global__ __launch_bounds__(256) void splice_kernel(const SpliceArgs A) {
         }
         out[q] = v;
     }
+    wave_lds_phase();      // last reads of M before the next row is staged
     }
 }
 
@@ -819,8 +835,7 @@ extern "C" int cp_splice_apply(const cp_splice_plan* p, const double* d_src0, in
     SpliceArgs A;
     A.T = p->T;
     A.src0 = d_src0; A.src1 = d_src1 ? d_src1 : d_src0; A.n0 = n0; A.n1 = d_src1 ? n1 : n0; A.nrows = nrows; A.tophat = d_tophat; A.out = d_out;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&splice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr;
+    (void)cp::allow_full_lds<&splice_kernel>();
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;
     const long long blocks = (nrows + 3) / 4;

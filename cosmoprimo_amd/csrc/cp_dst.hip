@@ -19,6 +19,7 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
+#include "cp_internal.h"
 #include "cp_fft_core.h"
 #include "cp_fftlog_tables.h"
 #include "cp_math.h"
@@ -278,8 +279,8 @@ void launch(bool inverse, const Args& A, int grid, hipStream_t stream) {
     constexpr int P = 16, T = N / P;
     constexpr int lds = (lds_data_slots(N, P) + Plan<N, P>::TW_TOTAL - N) * (int)sizeof(cplx);
     if (lds > 64 * 1024) {  // opt in to more than 64 KiB of dynamic LDS (once per process would do; the call is cheap)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dst_kernel<N, P, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dst_kernel<N, P, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)cp::allow_full_lds<&dst_kernel<N, P, true>>();
+        (void)cp::allow_full_lds<&dst_kernel<N, P, false>>();
     }
     if (inverse) hipLaunchKernelGGL((dst_kernel<N, P, true>), dim3(grid), dim3(T), lds, stream, A);
     else hipLaunchKernelGGL((dst_kernel<N, P, false>), dim3(grid), dim3(T), lds, stream, A);

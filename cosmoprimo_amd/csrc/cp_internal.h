@@ -40,3 +40,30 @@ struct cp_spline_rows_view {
     const double* d_qw;     // (nq, 4)
 };
 bool cp_spline_rows_plan_view(const cp_spline_rows_plan* plan, cp_spline_rows_view* out);
+
+// Dynamic LDS above 64 KB is an opt-in per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize).  Raises the limit of KERNEL to the
+// whole 160 KB of a CU the first time it is launched on the device that is current (once per (kernel, device): a multi-GPU process configures every
+// device it launches on, and a later launch with more LDS than the first finds the limit already at the maximum).
+namespace cp {
+template <auto KERNEL>
+inline hipError_t allow_full_lds() {
+    static bool configured[64] = {false};      // benign race: two threads may both set the same attribute to the same value
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64 && configured[dev]) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && dev >= 0 && dev < 64) configured[dev] = true;
+    return e;
+}
+
+// Kernels that hand data from lane to lane of ONE wave through LDS without a workgroup barrier (the tridiagonal eliminations of cp_bao.hip and
+// cp_spline_rows.hip): the hardware executes a wave's LDS instructions in order; this pins the compiler to the same order between the phases
+// (staging, forward sweep, backward sweep, evaluation): no LDS access moves across it.  At wavefront scope neither the fences nor the barrier
+// emit an instruction.
+__device__ __forceinline__ void wave_lds_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+}  // namespace cp

@@ -93,7 +93,7 @@ __device__ __forceinline__ double rsqrt_pos(double x) {
 // polynomial on |r ln 10| <= ln(2) / 2, ldexp -- relative error 2e-16 (checked against 50-digit arithmetic), half the instructions of the
 // library's exp10, which matters where every lane of the GEMM epilogue takes 64 of them per tile
 __device__ __forceinline__ double exp10_mid(double x) {
-    // branch-free over the whole line: the exponent is clamped (beyond +-1100 the result is 0 or Inf whatever the polynomial says), NaN goes
+    // branch-free over the whole line: the exponent is clamped (so that the int conversion is defined for any x; arguments that far out are settled by the selects at the end), NaN goes
     // through the arithmetic, and -Inf / +Inf (whose reduced argument is not finite) are settled by the two selects at the end.  An unrolled
     // GEMM epilogue holds 64 copies of this function: a library call for the rare arguments would put 64 call sites, with their register
     // spills, into it.
@@ -117,8 +117,10 @@ __device__ __forceinline__ double exp10_mid(double x) {
     p = fma(p, y, 1.);
     p = fma(p, y, 1.);
     double v = ldexp(p, (int)n);
-    v = x < -400. ? 0. : v;
-    v = x > 400. ? __builtin_inf() : v;
+    // the cut-offs sit where the true result leaves the doubles (10^-324 rounds to 0, 10^308.26 overflows): inside them |n| <= 1077, the clamp above
+    // never binds and the polynomial only sees reduced arguments; outside, whatever it returned is replaced
+    v = x < -324. ? 0. : v;
+    v = x > 308.3 ? __builtin_inf() : v;
     return v;
 }
 

@@ -87,8 +87,9 @@ extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param
     hipStream_t main = static_cast<hipStream_t>(stream);
     SideStream* side = nblocks > 1 ? side_stream(device) : nullptr;
     if (nblocks > 1 && !side) return cp::fail(CP_EDEVICE, "cp_sigma_rz_analytic: cannot create the second stream on device %d", device);
-    double* rows = d_pk_out ? d_pk_out : static_cast<double*>(d_work);      // the spectra are kept where the caller wants them
-    double* var = rows + ncosmo * (long long)nk;
+    double* work = static_cast<double*>(d_work);
+    double* rows = d_pk_out ? d_pk_out : work;      // the spectra are kept where the caller wants them: (ncosmo, nk), nothing behind them is the callee's
+    double* var = d_pk_out ? work : work + ncosmo * (long long)nk;      // variances and coefficients always live in the workspace
     char* coef = reinterpret_cast<char*>(var + ncosmo * (long long)nk);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
     if (side) {  // what the caller queued before this call (growth factors, the result buffer) is ready once its stream gets here

@@ -165,6 +165,7 @@ struct VarArgs {
 
 struct VarScalars {
     double Omega_ncdm, Omega_pncdm, omega_m, frac_cb, frac_ncdm, theta_cmb, z_eq, rs_drag, p_cb, gamma_ncdm, beta_c;
+    double omega_b, frac_b, frac_cdm, k_eq, z_drag, p_c;      // not read by variants_kernel: the engine's attributes (cp_variants_scalars)
 };
 
 // engine scalars, _set_rsdrag / compute (eisenstein_hu_nowiggle_variants.py:32-76)
@@ -190,9 +191,15 @@ __device__ __forceinline__ VarScalars variants_scalars(const Cosmo& c) {
     const double b1 = 0.313 * pow(omega_m, -0.419) * (1 + 0.607 * pow(omega_m, 0.674));
     const double b2 = 0.238 * pow(omega_m, 0.223);
     const double z_drag = 1291 * pow(omega_m, 0.251) / (1. + 0.659 * pow(omega_m, 0.828)) * (1. + b1 * pow(omega_b, b2));
+    v.omega_b = omega_b;
+    v.frac_b = frac_b;
+    v.frac_cdm = frac_cdm;
+    v.k_eq = 0.0746 * omega_m * pow(v.theta_cmb, -2.);
+    v.z_drag = z_drag;
     v.rs_drag = 44.5 * log(9.83 / omega_m) / sqrt(1. + 10. * pow(omega_b, 0.75));
     const double fbn = frac_b + frac_ncdm;
     const double p_c = (5. - sqrt(1 + 24 * frac_cdm)) / 4.;
+    v.p_c = p_c;
     v.p_cb = (5. - sqrt(1 + 24. * frac_cb)) / 4.;
     const double p_cb = v.p_cb;
     const double y_drag = (1 + v.z_eq) / (1 + z_drag);
@@ -202,6 +209,40 @@ __device__ __forceinline__ VarScalars variants_scalars(const Cosmo& c) {
     v.gamma_ncdm = sqrt(alpha);
     v.beta_c = 1 / (1 - 0.949 * fbn);
     return v;
+}
+
+// the engine's attributes for a batch of cosmologies, one lane each: (ncosmo, CP_VAR_NSCALARS) in the order of enum cp_variants_scalar
+struct VarScalArgs {
+    long long ncosmo;
+    Param bg[CP_BG_NPARAMS];
+    int second_is_omega_m;
+    const double* ncdm_tab;
+    const double* ncdm_knots;
+    int nsp;
+    double* out;
+};
+
+__global__ __launch_bounds__(256) void variants_scalars_kernel(const VarScalArgs A) {
+    const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ic >= A.ncosmo) return;
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
+    const VarScalars v = variants_scalars(c);
+    double* o = A.out + ic * CP_VAR_NSCALARS;
+    o[CP_VAR_OMEGA_B] = v.omega_b;
+    o[CP_VAR_OMEGA_M] = v.omega_m;
+    o[CP_VAR_FRAC_B] = v.frac_b;
+    o[CP_VAR_FRAC_CDM] = v.frac_cdm;
+    o[CP_VAR_FRAC_CB] = v.frac_cb;
+    o[CP_VAR_FRAC_NCDM] = v.frac_ncdm;
+    o[CP_VAR_THETA_CMB] = v.theta_cmb;
+    o[CP_VAR_Z_EQ] = v.z_eq;
+    o[CP_VAR_K_EQ] = v.k_eq;
+    o[CP_VAR_Z_DRAG] = v.z_drag;
+    o[CP_VAR_RS_DRAG] = v.rs_drag;
+    o[CP_VAR_P_C] = v.p_c;
+    o[CP_VAR_P_CB] = v.p_cb;
+    o[CP_VAR_GAMMA_NCDM] = v.gamma_ncdm;
+    o[CP_VAR_BETA_C] = v.beta_c;
 }
 
 // Same shape as power_kernel: one workgroup = one cosmology x kspan wavenumbers; the engine scalars (one lane) and the CPT growth of every
@@ -407,6 +448,35 @@ extern "C" int cp_power_eval_variants(int what, int of, long long ncosmo, const 
     hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_eval_variants: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+extern "C" int cp_variants_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, double* d_out, int device,
+                                   void* stream) {
+    if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_variants_scalars: negative size");
+    if (ncosmo == 0) return CP_OK;
+    if (!bg_params || !d_out) return cp::fail(CP_EINVAL, "cp_variants_scalars: null pointer");
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_variants_scalars: bad massive-neutrino tables");
+    int prev;
+    int st = select_device(device, &prev);
+    if (st != CP_OK) return st;
+    VarScalArgs A;
+    A.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) A.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
+    A.second_is_omega_m = second_is_omega_m;
+    A.nsp = nsp;
+    A.ncdm_tab = nsp ? ncdm->tab : nullptr;
+    A.ncdm_knots = nsp ? cpcosmo::ncdm_knots_device(device) : nullptr;
+    A.out = d_out;
+    if (nsp && !A.ncdm_knots) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return cp::fail(CP_ENOMEM, "cp_variants_scalars: cannot allocate the massive-neutrino knots on device %d", device);
+    }
+    hipLaunchKernelGGL(variants_scalars_kernel, dim3((unsigned)((ncosmo + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_variants_scalars: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
 

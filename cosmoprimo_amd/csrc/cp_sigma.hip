@@ -361,13 +361,7 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_spline_kernel(const RowsArgs
 
 template <int ENGINE>
 hipError_t launch(const SigmaArgs& S, int grid, size_t lds, hipStream_t stream) {
-    static bool configured[64] = {false};      // per device: dynamic LDS above 64 KB needs the attribute once
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds > 64 * 1024 && dev >= 0 && dev < 64 && !configured[dev]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sigma_rz_kernel<ENGINE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured[dev] = true;
-    }
+    if (lds > 64 * 1024) (void)cp::allow_full_lds<&sigma_rz_kernel<ENGINE>>();
     hipLaunchKernelGGL(sigma_rz_kernel<ENGINE>, dim3(grid), dim3(NP / P), lds, stream, S);
     return hipGetLastError();
 }
@@ -574,11 +568,7 @@ extern "C" int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_s
         if (prev >= 0) (void)hipSetDevice(prev);
         return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_spline_execute: %d queries exceed the LDS staging", b.nq);
     }
-    static bool configured[64] = {false};
-    if (lds > 64 * 1024 && f.device >= 0 && f.device < 64 && !configured[f.device]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fftlog_spline_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured[f.device] = true;
-    }
+    if (lds > 64 * 1024) (void)cp::allow_full_lds<&fftlog_spline_kernel>();
     int ncu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, f.device);
     const long long npairs = (nbatch + 1) / 2;

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void spline_outer_kernel(const OuterArgs O) {
 template <int R>
 hipError_t launch_outer(const OuterArgs& O, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_outer_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)cp::allow_full_lds<&spline_outer_kernel<R>>();
     const long long nitems = ((O.a.nrows + R - 1) / R) * O.a.ntiles;
     const int grid = (int)(nitems < 256 * 8 ? nitems : 256 * 8);
     hipLaunchKernelGGL(spline_outer_kernel<R>, dim3(grid), dim3(256), lds, stream, O);
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(256, 4) void linop_mid_mfma_kernel(const MidArgs A)
 template <int R>
 hipError_t launch_apply(const Args& A, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_apply_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)cp::allow_full_lds<&spline_apply_kernel<R>>();
     const long long nitems = ((A.nrows + R - 1) / R) * A.ntiles;
     const int grid = (int)(nitems < 256 * 8 ? nitems : 256 * 8);
     hipLaunchKernelGGL(spline_apply_kernel<R>, dim3(grid), dim3(256), lds, stream, A);

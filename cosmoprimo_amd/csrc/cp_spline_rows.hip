@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
         const long long row = g * R + rr;
         const bool live = row < A.nrows;
         const double* src = A.y + (live ? row : A.nrows - 1) * T.n_src + T.w0;
+        cp::wave_lds_phase();      // the previous group's last reads are done before its buffers are staged over
         // the knots of the window, the end values repeated beyond either end (slopes there vanish: the clamped condition; for the natural one and
         // for an end that is not an end of the row the table makes the outermost equations harmless)
 #pragma unroll 8
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
             for (int e = l; e < pad; e += LPR) buf[-1 - e] = first;
             for (int e = nw + l; e < LPR * S + pad; e += LPR) buf[e] = last;
         }
+        cp::wave_lds_phase();      // knot values staged
 #ifndef CP_ROWS_ABLATE
 #define CP_ROWS_ABLATE 0      // tools/spline_rows_variants.sh, what the parts cost: 1 no forward sweep, 2 no back substitution, 4 one query per lane,
 #endif                        // 8 no values gathered from memory, 16 no root, 32 no stores
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
                 sigma_m = sigma;
                 y0 = yp;
             }
+            cp::wave_lds_phase();      // run-ins done before the neighbours' knot values become d
 #pragma unroll 8
             for (int t = 0; t < S - 1; ++t) {
                 const int i = own + t;
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
                 buf[i] = fma(-c.z, d, c.y * (sigma - sigma_m));
             }
         }
+        cp::wave_lds_phase();      // d complete
         if (!(CP_ROWS_ABLATE & 2)) {
             double m = 0.;
 #pragma unroll 8
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
                 const double d = buf[i];
                 m = i >= nw - 1 ? d : fma(-coef[slot_of(i)].w, m, d);
             }
+            cp::wave_lds_phase();
 #pragma unroll 8
             for (int t = 0; t < S; ++t) {
                 const int i = own + S - 1 - t;
@@ -138,8 +143,10 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
                 buf[i] = m;
             }
         }
+        cp::wave_lds_phase();      // M complete
         if (T.fix_first && l == 0) buf[0] = T.fix[0] * buf[1] + T.fix[1] * buf[2];
         if (T.fix_last && l == 0) buf[nw - 1] = T.fix[2] * buf[nw - 2] + T.fix[3] * buf[nw - 3];
+        cp::wave_lds_phase();      // end fixes in place: the evaluation gathers across segments
         if (A.out_m) {
             double* dst = A.out_m + row * T.n_src + T.w0;
             if (live)
@@ -322,10 +329,9 @@ static int launch_rows(const cp_spline_rows_plan* p, const RowsArgs& A, long lon
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     const unsigned grid = (unsigned)std::min(blocks, (long long)ncu * per_cu);
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_rows_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)attr4; (void)attr2; (void)attr1;
+    if (p->T.R == 4) (void)cp::allow_full_lds<&spline_rows_kernel<4>>();
+    else if (p->T.R == 2) (void)cp::allow_full_lds<&spline_rows_kernel<2>>();
+    else (void)cp::allow_full_lds<&spline_rows_kernel<1>>();
     if (p->T.R == 4) hipLaunchKernelGGL(spline_rows_kernel<4>, dim3(grid), dim3(256), p->lds_bytes, hs, A);
     else if (p->T.R == 2) hipLaunchKernelGGL(spline_rows_kernel<2>, dim3(grid), dim3(256), p->lds_bytes, hs, A);
     else hipLaunchKernelGGL(spline_rows_kernel<1>, dim3(grid), dim3(256), p->lds_bytes, hs, A);

@@ -28,37 +28,16 @@ class EisensteinHuNoWiggleVariantsEngine(BaseEngine):
         self.compute()
         self._A_s = self._get_A_s_fid()
 
-    def _set_rsdrag(self):
-        """Sound horizon at the drag epoch and friends (reference :32-59); floats, or arrays for a batch of cosmologies."""
-        g = lambda name: np.asarray(_host(self[name]), dtype='f8') if np.ndim(_host(self[name])) else float(_host(self[name]))   # noqa: E731
-        self.omega_b = g('omega_b')
-        self.omega_m = g('omega_cdm') + g('omega_b') + g('omega_ncdm_tot') - g('omega_pncdm_tot')
-        self.frac_b = self.omega_b / self.omega_m
-        self.frac_cdm = g('omega_cdm') / self.omega_m
-        self.frac_cb = self.frac_cdm + self.frac_b
-        self.frac_ncdm = 1. - self.frac_cb
-        self.N_ncdm = self['N_ncdm']
-        self.theta_cmb = g('T_cmb') / 2.7
-        self.z_eq = 2.5e4 * self.omega_m * self.theta_cmb ** (-4) - 1.
-        self.k_eq = 0.0746 * self.omega_m * self.theta_cmb ** (-2)
-        z_drag_b1 = 0.313 * self.omega_m ** (-0.419) * (1 + 0.607 * self.omega_m ** 0.674)
-        z_drag_b2 = 0.238 * self.omega_m ** 0.223
-        self.z_drag = 1291 * self.omega_m ** 0.251 / (1. + 0.659 * self.omega_m ** 0.828) * (1. + z_drag_b1 * self.omega_b ** z_drag_b2)
-        self.rs_drag = 44.5 * np.log(9.83 / self.omega_m) / np.sqrt(1. + 10. * self.omega_b ** 0.75)
-
     def compute(self):
-        """Coefficients of the transfer function (reference :61-76), as attributes."""
-        self._set_rsdrag()
-        frac_bncdm = self.frac_b + self.frac_ncdm
-        self.p_c = (5. - np.sqrt(1 + 24 * self.frac_cdm)) / 4.
-        self.p_cb = (5. - np.sqrt(1 + 24. * self.frac_cb)) / 4.
-        y_drag = (1 + self.z_eq) / (1 + self.z_drag)
-        alpha_ncdm = self.frac_cdm / self.frac_cb * (5. - 2. * (self.p_c + self.p_cb)) / (5. - 4. * self.p_cb) * (1 + y_drag) ** (self.p_cb - self.p_c)\
-            * (1 + frac_bncdm * (-0.553 + 0.126 * frac_bncdm ** 2))\
-            / (1 - 0.193 * np.sqrt(self.frac_ncdm * self.N_ncdm) + 0.169 * self.frac_ncdm * self.N_ncdm ** 0.2)\
-            * (1 + (self.p_c - self.p_cb) / 2 * (1 + 1 / (3. - 4. * self.p_c) / (7. - 4. * self.p_cb)) / (1 + y_drag))
-        self.gamma_ncdm = np.sqrt(alpha_ncdm)
-        self.beta_c = 1 / (1 - 0.949 * frac_bncdm)
+        """The engine's attributes -- densities and fractions, z_eq, k_eq, z_drag, rs_drag [Mpc], p_c, p_cb, gamma_ncdm, beta_c (what the
+        reference's ``_set_rsdrag`` and ``compute`` leave on the engine, eisenstein_hu_nowiggle_variants.py:32-76) -- read back from
+        ``cp_variants_scalars``, i.e. from the device function the evaluation kernel takes them from: floats for one cosmology, (B,) numpy arrays
+        for a batch."""
+        scalars = pwmod.variants_scalars(self.bg_params(), ncdm=self.get_background()._ncdm, device=self.device)
+        table = dv.torch().stack([scalars[name].reshape(-1) for name in scalars], dim=0).cpu().numpy()      # one copy for all of them
+        for name, row in zip(scalars, table):
+            setattr(self, name, float(row[0]) if self.batch_size is None else row.copy())
+        self.N_ncdm = self['N_ncdm']
 
     def pk_params(self, rsigma8=None):
         rs = self._rsigma8 if rsigma8 is None else rsigma8

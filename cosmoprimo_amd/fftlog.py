@@ -512,13 +512,14 @@ class GaussianVariance(_WindowVariance):
 
 
 # ---------------------------------------------------------------------------------------------
-# engines (reference fftlog.py:508-663): the reference's engine protocol splits the transform into
-# forward / backward FFTs; here the whole of FFTlog.__call__ is one kernel, so the engine object only
-# names the backend.
+# engines (reference fftlog.py:508-663).  The reference's protocol splits a transform into forward / backward FFTs done by an engine
+# object; here FFTlog.__call__ is one fused kernel whatever the engine's name.  The engine classes keep the reference's names and
+# methods: an instance handed to FFTlog(engine=...) selects the fused kernel, and forward / backward called by hand are device FFTs
+# of this package (cp_rfft_forward / cp_rfft_backward), not numpy's or FFTW's.
 # ---------------------------------------------------------------------------------------------
 class BaseFFTEngine(object):
 
-    """FFT engine descriptor (reference fftlog.py:508-531); does not touch OMP_NUM_THREADS."""
+    """FFT engine descriptor (reference fftlog.py:508-531); does not touch OMP_NUM_THREADS (no host threads are used)."""
 
     def __init__(self, size, nparallel=1, nthreads=None):
         self.size = size
@@ -528,25 +529,118 @@ class BaseFFTEngine(object):
 
 class MI355XFFTEngine(BaseFFTEngine):
 
-    """The fused HIP FFTLog kernel (pad, prefactor, FFT, u, inverse FFT, postfactor, crop in one launch)."""
+    """The fused HIP FFTLog kernel (pad, prefactor, FFT, u, inverse FFT, postfactor, crop in one launch) when given to :class:`FFTlog`;
+    ``forward`` / ``backward`` are the two real FFTs of the reference's protocol on the device, for code that calls them itself."""
     name = 'mi355x'
 
-    def __init__(self, size, nparallel=1, nthreads=None, **kwargs):
+    def __init__(self, size, nparallel=1, nthreads=None, device=None, **kwargs):
         super(MI355XFFTEngine, self).__init__(size, nparallel=nparallel, nthreads=nthreads)
         _lib.load()  # fail loudly when the HIP library is missing
+        self._device = device
+        self._rfft_plans = {}
+
+    def _rfft_plan(self, device):
+        import ctypes
+        key = device.index
+        if key not in self._rfft_plans:
+            handle = ctypes.c_void_p()
+            _lib.check(_lib.load().cp_rfft_plan_create(ctypes.byref(handle), int(self.size), key))
+            self._rfft_plans[key] = handle
+        return self._rfft_plans[key]
+
+    def _run(self, fun, backward):
+        torch = _torch()
+        is_torch = _is_torch(fun)
+        dev = dv.resolve_device(self._device, fun)
+        nin = self.size // 2 + 1 if backward else self.size
+        nout = self.size if backward else self.size // 2 + 1
+        dtype = torch.complex128 if backward else torch.float64
+        if is_torch:
+            tin = fun.to(device=dev, dtype=dtype)
+        else:
+            tin = torch.as_tensor(np.ascontiguousarray(fun, dtype='c16' if backward else 'f8')).to(dev)
+        if tin.ndim < 1 or tin.shape[-1] != nin:
+            raise ValueError('last dimension must be {:d}, got shape {}'.format(nin, tuple(tin.shape)))
+        tin = tin.contiguous()
+        lead = tuple(tin.shape[:-1])
+        nrows = int(np.prod(lead, dtype='i8'))
+        tout = torch.empty(lead + (nout,), dtype=torch.float64 if backward else torch.complex128, device=dev)
+        if nrows:
+            lib, plan, stream = _lib.load(), self._rfft_plan(dev), torch.cuda.current_stream(dev).cuda_stream
+            if backward:
+                _lib.check(lib.cp_rfft_backward(plan, tin.data_ptr(), tout.data_ptr(), nrows, 1, stream))
+            else:
+                _lib.check(lib.cp_rfft_forward(plan, tin.data_ptr(), tout.data_ptr(), nrows, stream))
+        return tout if is_torch else dv.to_host(tout)
+
+    def forward(self, fun):
+        """``rfft(fun, axis=-1)``: (..., size) real -> (..., size // 2 + 1) complex (reference fftlog.py:536-539); numpy in, numpy out;
+        device tensor in, device tensor out."""
+        return self._run(fun, backward=False)
+
+    def backward(self, fun):
+        """``irfft(conj(fun), n=size, axis=-1)`` (reference fftlog.py:541-544): (..., size // 2 + 1) complex -> (..., size) real."""
+        return self._run(fun, backward=True)
+
+    def __del__(self):
+        try:
+            for handle in self.__dict__.get('_rfft_plans', {}).values():
+                _lib.load().cp_rfft_plan_destroy(handle)
+            self._rfft_plans = {}
+        except Exception:
+            pass
+
+
+class NumpyFFTEngine(MI355XFFTEngine):
+
+    """The reference's default engine by name (fftlog.py:533-544), for code written against it: same constructor, same ``forward`` /
+    ``backward`` contract, served by this package's device FFTs."""
+    name = 'numpy'
+
+
+class FFTWEngine(MI355XFFTEngine):
+
+    """The reference's :mod:`pyfftw` engine by name (fftlog.py:567-638): same constructor; ``wisdom`` and ``plan`` are validated as there
+    and otherwise unused (there is nothing to plan), ``nthreads`` is recorded.  Parity with FFTW itself is unpinned (pyfftw is not in the image)."""
+    name = 'fftw'
+
+    def __init__(self, size, nparallel=1, nthreads=None, wisdom=None, plan='measure', **kwargs):
+        if str(plan).lower() not in ('estimate', 'measure', 'patient', 'exhaustive'):
+            raise ValueError('Plan {} unknown'.format(plan))
+        super(FFTWEngine, self).__init__(size, nparallel=nparallel, nthreads=nthreads, **kwargs)
+        self.wisdom, self.plan = wisdom, str(plan).lower()
+
+
+def apply_along_last_axes(func, array, naxes=1, toret=None):
+    """``func`` on every block of the last ``naxes`` axes of ``array`` (reference fftlog.py:547-560), results gathered in ``toret`` (made like
+    ``array`` if not given; it must have the same leading axes).  The reference reshapes both arrays in place around its loop; this one
+    walks views and leaves the callers' arrays alone."""
+    array = np.asarray(array)
+    if toret is None:
+        toret = np.empty_like(array)
+    nlead = array.ndim - naxes
+    if nlead < 0 or toret.shape[:toret.ndim - naxes] != array.shape[:nlead]:
+        raise ValueError('array {} and toret {} must share the axes in front of the last {:d}'.format(array.shape, toret.shape, naxes))
+    for index in np.ndindex(*array.shape[:nlead]):
+        toret[index] = func(array[index])
+    return toret
+
+
+_ENGINE_NAMES = {'mi355x': MI355XFFTEngine, 'hip': MI355XFFTEngine, 'numpy': NumpyFFTEngine, 'fftw': FFTWEngine}
 
 
 def get_fft_engine(engine, *args, **kwargs):
     """
-    Return the engine (reference fftlog.py:641-663).  ``'mi355x'`` / ``'hip'`` and, for drop-in use of code written
-    against the reference, ``'numpy'`` / ``'fftw'`` all select the fused HIP kernel.  Anything that is not a string is passed
-    through, as in the reference: an object with ``forward`` / ``backward`` methods (protocol of fftlog.py:508-544) makes
+    Return the engine (reference fftlog.py:641-663): ``'numpy'`` -> :class:`NumpyFFTEngine`, ``'fftw'`` -> :class:`FFTWEngine` as there, plus
+    ``'mi355x'`` / ``'hip'``; every one of them makes :meth:`FFTlog.__call__` the fused HIP kernel.  Anything that is not a string is passed
+    through, as in the reference: a foreign object with ``forward`` / ``backward`` methods (protocol of fftlog.py:508-544) makes
     :meth:`FFTlog.__call__` run un-fused around it.
     """
     if isinstance(engine, str):
-        if engine.lower() in ('mi355x', 'hip', 'numpy', 'fftw'):
-            return MI355XFFTEngine(*args, **kwargs)
-        raise ValueError('FFT engine {} is unknown'.format(engine))
+        cls = _ENGINE_NAMES.get(engine.lower())
+        if cls is None:
+            raise ValueError('FFT engine {} is unknown'.format(engine))
+        return cls(*args, **kwargs)
     if not isinstance(engine, MI355XFFTEngine) and not (callable(getattr(engine, 'forward', None)) and callable(getattr(engine, 'backward', None))):
         raise ValueError('FFT engine {!r} has no forward / backward methods'.format(engine))
     return engine

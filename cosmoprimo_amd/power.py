@@ -75,6 +75,26 @@ def eh_scalars(bg=None, Omega_m=None, device=None):
     return {name: (out[:, i] if n is not None else out[0, i]) for i, name in enumerate(_lib.EH_SCALARS)}
 
 
+def variants_scalars(bg=None, ncdm=None, device=None):
+    """dict of the attributes of the 'eisenstein_hu_nowiggle_variants' engine (reference eisenstein_hu_nowiggle_variants.py:32-76) through
+    ``cp_variants_scalars``: torch tensors of shape (ncosmo,) or ().  ``ncdm``: :class:`cosmoprimo_amd.background.NcdmTables` or None."""
+    import ctypes
+    torch = dv.torch()
+    bg = dict(bg or {})
+    device = dv.resolve_device(device, *bg.values())
+    cbg, n, keep = dv.pack_params(_lib.BG_PARAMS, bg, BG_DEFAULTS, device)
+    ncosmo = n or 1
+    cn = None
+    if ncdm is not None and ncdm.nspecies:
+        if ncdm.ncosmo != ncosmo:
+            raise ValueError('massive-neutrino tables hold {:d} cosmologies, the parameters {:d}'.format(ncdm.ncosmo, ncosmo))
+        cn = ncdm.struct()
+    out = torch.empty((ncosmo, len(_lib.VARIANTS_SCALARS)), dtype=torch.float64, device=device)
+    _lib.check(_lib.load().cp_variants_scalars(ncosmo, dv.as_void_p(cbg), 0, ctypes.byref(cn) if cn is not None else None, out.data_ptr(), device.index,
+                                               dv.stream_of(device)))
+    return {name: (out[:, i] if n is not None else out[0, i]) for i, name in enumerate(_lib.VARIANTS_SCALARS)}
+
+
 def variants(what, k, z, of='delta_m', bg=None, pk=None, ncdm=None, device=None):
     """
     ``what`` in ('matter', 'transfer') of the 'eisenstein_hu_nowiggle_variants' engine (reference eisenstein_hu_nowiggle_variants.py:

@@ -230,6 +230,16 @@ int cp_power_eval_variants(int what, int of, long long ncosmo, const cp_param* b
                            const cp_param* pk_params, long long nk, const double* d_k, long long nz, const double* d_z, double* d_out, int device,
                            void* stream);
 int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, double* d_out, int device, void* stream);
+/* the attributes of the eisenstein_hu_nowiggle_variants engine (EisensteinHuNoWiggleVariantsEngine._set_rsdrag / compute,
+ * eisenstein_hu_nowiggle_variants.py:32-76) for a batch of cosmologies, by the device function the evaluation kernel itself uses.
+ * ncdm as for cp_power_eval_variants.  d_out : (ncosmo, CP_VAR_NSCALARS). */
+enum cp_variants_scalar {
+    CP_VAR_OMEGA_B = 0, CP_VAR_OMEGA_M = 1, CP_VAR_FRAC_B = 2, CP_VAR_FRAC_CDM = 3, CP_VAR_FRAC_CB = 4, CP_VAR_FRAC_NCDM = 5, CP_VAR_THETA_CMB = 6,
+    CP_VAR_Z_EQ = 7, CP_VAR_K_EQ = 8, CP_VAR_Z_DRAG = 9, CP_VAR_RS_DRAG = 10 /* Mpc */, CP_VAR_P_C = 11, CP_VAR_P_CB = 12, CP_VAR_GAMMA_NCDM = 13,
+    CP_VAR_BETA_C = 14, CP_VAR_NSCALARS = 15
+};
+int cp_variants_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, double* d_out, int device,
+                        void* stream);
 
 /* ---- cubic splines from fixed knots to fixed queries, applied to batches of rows as a banded linear operator
  *      (replaces scipy.interpolate.CubicSpline / RectBivariateSpline where the grids are shared by the batch:
@@ -393,6 +403,20 @@ int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_o
 long long cp_spline_columns_scratch_doubles(long long ncol, int n);
 int cp_spline_columns(const double* d_xk, const double* d_yk, long long ncol, int n, const double* d_xq, int nq, double* d_out, double* d_scratch,
                       int device, void* stream);
+
+/* ---- batched real FFTs of rows: the two methods of the reference's FFT engine protocol (BaseFFTEngine, fftlog.py:508-544) as standalone
+ *      transforms, for callers that hold a NumpyFFTEngine / FFTWEngine object and call forward / backward themselves (FFTlog.__call__ is
+ *      the fused kernel and does not come through here) ---- */
+typedef struct cp_rfft_plan cp_rfft_plan;
+/* size : real samples per row, a power of two from 8 to 16384 (FFTlog's padded sizes) */
+int cp_rfft_plan_create(cp_rfft_plan** plan, int size, int device);
+int cp_rfft_plan_destroy(cp_rfft_plan* plan);
+/* NumpyFFTEngine.forward (fftlog.py:536-539): d_in (nrows, size) real -> d_out (nrows, size / 2 + 1) complex (re, im interleaved) = rfft */
+int cp_rfft_forward(const cp_rfft_plan* plan, const double* d_in, double* d_out, long long nrows, void* stream);
+/* NumpyFFTEngine.backward (fftlog.py:541-544): d_in (nrows, size / 2 + 1) complex -> d_out (nrows, size) real = irfft(conj(in), n=size) when
+ * conj_input != 0, irfft(in, n=size) otherwise; imaginary parts of the DC and Nyquist bins are ignored, as numpy's c2r does.  Rows are
+ * independent (one transform per row).  Not in place. */
+int cp_rfft_backward(const cp_rfft_plan* plan, const double* d_in, double* d_out, long long nrows, int conj_input, void* stream);
 
 /* ---- batched orthonormal DST-II / DST-III of rows (replaces scipy.fftpack.dst / idst(type=2, norm='ortho') of the
  *      wallish2018 filter, bao_filter.py:371-372, 412) ---- */

@@ -46,6 +46,14 @@ def test_one_rank_under_torchrun():
     assert line['config']['rccl_ranks'] == 1 and line['gather_ms'] > 0 and line['value_with_gather'] > 0
     split = run(base + ['--master-port', '29542', 'bench.py', '--gpus', '1', '--config', '5', '--rows', '200000', '--steps', '2', '--warmup', '1', '--gather'])
     assert split['scaling'] == 'strong' and split['config']['rccl_ranks'] == 1 and split['value'] > 0 and split['unit'] == 'samples/s'
+    assert split['parity_spot_check']['max_rel_err'] < 1e-10 and split['ms_per_step_rank_min'] <= split['ms_per_step_rank_max'] <= split['ms_per_step'] * 1.01
+    # config 4 under the launcher: both filters on the rank's block of cosmologies, each with its oracle spot check on the line
+    filt = run(base + ['--master-port', '29543', 'bench.py', '--gpus', '1', '--config', '4', '--rows', '3000', '--steps', '2', '--warmup', '1', '--gather'])
+    assert filt['scaling'] == 'strong' and filt['config']['rccl_ranks'] == 1 and filt['unit'] == 'filtered vectors/s' and filt['value'] > 0
+    assert filt['config']['per_gpu'] == 3000 and len(filt['ms_per_step_by_rank']) == 1 and filt['gather_ms'] > 0
+    for engine in ('wallish2018', 'brieden2022'):
+        assert filt['parity_spot_check'][engine]['max_rel_err'] < 1e-9
+    assert line['ms_per_step_rank_min'] <= line['ms_per_step_rank_max'] and len(line['ms_per_step_by_rank']) == 1
 
 
 def test_self_launch():

@@ -71,64 +71,62 @@ def test_config2_golden_rows(cp, golden):
         assert pointwise(a, b, s) < TOL_POINT
 
 
-def test_hankel_pair(cp, golden):
-    """Analytic pair f=(1+x^2)^-1.5 <-> g=exp(-y) incl. inv() and batched input; reference tests/test_fftlog.py:56-89."""
-    def ffun(x):
-        return 1 / (1 + x**2)**1.5
-
-    def gfun(y):
-        return np.exp(-y)
-
+@pytest.mark.parametrize('engine', ['numpy', 'fftw', 'mi355x'])
+def test_hankel60_against_the_reference_numbers(cp, golden, engine):
+    """Order-0 Hankel transform of the 60-sample (1 + x^2)^-3/2 the reference transformed for goldens (`hankel60_*`, oracle/gen_golden.py): the
+    forward result, its closed form exp(-y), and the inverse transform of that result, for every engine name (all three select the fused
+    kernel).  Tolerances: 1e-11 against the reference's forward numbers, 1e-10 against its inverse."""
     g = golden('fftlog_transforms')
-    for kwargs in [{'engine': 'numpy'}, {'engine': 'fftw', 'plan': 'estimate'}, {'engine': 'mi355x'}]:
-        x = np.logspace(-3, 3, num=60, endpoint=False)
-        f = ffun(x)
-        hf = cp.HankelTransform(x, nu=0, q=1, lowring=True, **kwargs)
-        y, gg = hf(f, extrap='log')
-        assert np.allclose(gg, gfun(y), rtol=1e-8, atol=1e-8)
-        np.testing.assert_allclose(gg, g['hankel60_g'], rtol=1e-11, atol=1e-14)
-        hf.inv()
-        x2, f2 = hf(gg, extrap='log')
-        assert np.allclose(f2, f, rtol=1e-7, atol=1e-7)
-        np.testing.assert_allclose(f2, g['hankel60_inv_f'], rtol=1e-10, atol=1e-13)
-
-        y = np.logspace(-4, 2, num=60, endpoint=False)
-        gy = gfun(y)
-        hg = cp.HankelTransform(y, nu=0, q=1, lowring=True, **kwargs)
-        x, f = hg(gy, extrap='log')
-        assert np.allclose(f, ffun(x), rtol=1e-10, atol=1e-10)
-
-        y = np.array([np.logspace(-4, 2, num=60, endpoint=False)] * 3)
-        scales = np.linspace(1., 3., 3)
-        gy = gfun(y)
-        x, f = hg(gy * scales[:, None], extrap='log')
-        assert x.shape == (60, )
-        assert f.shape == (3, 60)
-        assert np.allclose(f / scales[:, None], ffun(x), rtol=1e-10, atol=1e-10)
+    forward = cp.HankelTransform(g['hankel60_x'], nu=0, q=1, lowring=True, engine=engine)
+    y, got = forward(g['hankel60_f'], extrap='log')
+    np.testing.assert_allclose(y, g['hankel60_y'], rtol=1e-14)
+    np.testing.assert_allclose(got, g['hankel60_g'], rtol=1e-11, atol=1e-14)
+    assert np.abs(got - np.exp(-y)).max() < 1e-8              # the closed form, to the accuracy 60 samples give
+    forward.inv()                                              # in place: the same object now maps g back to f
+    x_back, f_back = forward(got, extrap='log')
+    np.testing.assert_allclose(x_back, g['hankel60_inv_x'], rtol=1e-14)
+    np.testing.assert_allclose(f_back, g['hankel60_inv_f'], rtol=1e-10, atol=1e-13)
+    assert np.abs(f_back - g['hankel60_f']).max() < 1e-7
 
 
-def test_power_to_correlation_roundtrip(cp, golden):
-    """reference tests/test_fftlog.py:92-109 with the golden EH P(k) as input."""
+def test_hankel_of_a_stack_of_scaled_rows(cp):
+    """The transform is linear and row-wise: exp(-y) on another 60-sample grid gives (1 + x^2)^-3/2 (1e-10), and a stack of scaled copies of the
+    row gives the scaled results on ONE output grid."""
+    y = np.logspace(-4, 2, num=60, endpoint=False)
+    transform = cp.HankelTransform(y, nu=0, q=1, lowring=True)
+    x, single = transform(np.exp(-y), extrap='log')
+    closed_form = (1. + x**2)**-1.5
+    assert np.abs(single - closed_form).max() < 1e-10
+    factors = np.array([1., 2., 3.])
+    x3, stack = transform(factors[:, None] * np.exp(-y)[None, :], extrap='log')
+    assert x3.shape == (60,) and stack.shape == (3, 60)
+    np.testing.assert_array_equal(x3, x)
+    np.testing.assert_allclose(stack, factors[:, None] * single[None, :], rtol=1e-13, atol=1e-16)
+
+
+def test_multipoles_there_and_back(cp, golden):
+    """P -> xi_ell -> P for ell = 0 ... 4 on the golden EH98 spectrum: the round trip returns P where the transform is well conditioned (1 % on
+    1e-2 < k < 10), the five multipoles in one call equal the five single calls, without low-ringing s k = 1 holds exactly, and the complex
+    convention carries the (-i)^ell phases (oracle)."""
     pkd = golden('pk_eh_default')
     k, pk = pkd['k1024'], pkd['pk1024']
-    multipoles = []
-    ells = [0, 1, 2, 3, 4]
+    ells = (0, 1, 2, 3, 4)
+    singles = []
     for ell in ells:
         s, xi = cp.PowerToCorrelation(k, ell=ell, lowring=True, complex=False)(pk)
-        assert xi.shape == (1024, )
-        k2, pk2 = cp.CorrelationToPower(s, ell=ell, lowring=True, complex=False)(xi)
-        idx = (1e-2 < k2) & (k2 < 10.)
-        assert np.allclose(pk2[idx], np.interp(np.log(k2[idx]), np.log(k), pk), rtol=1e-2)
-        multipoles.append(xi)
-    assert np.allclose(cp.PowerToCorrelation(k, ell=ells, lowring=True, q=0, complex=False)(pk)[-1], multipoles)
-    s, xi = cp.PowerToCorrelation(k, ell=0, lowring=False)(pk)
-    assert np.allclose(s[::-1] * k, 1.)
-    s, xi1 = cp.PowerToCorrelation(k, ell=1)(pk)
-    assert np.abs(xi1).max() > 0.
-    # complex=True: (-i)^ell phases, complex128 output
-    sc, xic = cp.PowerToCorrelation(k, ell=ells, complex=True)(pk)
+        assert xi.shape == (1024,) and np.abs(xi).max() > 0.
+        singles.append(xi)
+        k_back, pk_back = cp.CorrelationToPower(s, ell=ell, lowring=True, complex=False)(xi)
+        window = (k_back > 1e-2) & (k_back < 10.)
+        expected = np.exp(np.interp(np.log(k_back[window]), np.log(k), np.log(pk)))
+        assert np.abs(pk_back[window] / expected - 1.).max() < 1e-2, ell
+    _, together = cp.PowerToCorrelation(k, ell=list(ells), lowring=True, q=0, complex=False)(pk)
+    np.testing.assert_allclose(together, np.array(singles), rtol=1e-5, atol=1e-8)      # (another tilt q: equal to the accuracy of the transform, not to rounding)
+    s_plain, _ = cp.PowerToCorrelation(k, ell=0, lowring=False)(pk)
+    np.testing.assert_allclose(s_plain[::-1] * k, 1., rtol=1e-13)
+    sc, xic = cp.PowerToCorrelation(k, ell=list(ells), complex=True)(pk)
     assert xic.dtype == np.complex128
-    t = ofl.power_to_correlation(k, ell=ells)
+    t = ofl.power_to_correlation(k, ell=list(ells))
     ref = ofl.apply(t, pk) * ((-1.) ** (np.array(ells) // 2))[:, None] * ((-1j) ** np.array(ells))[:, None]
     for i in range(5):
         assert np.abs((xic[i] - ref[i]) * sc[i]**1.5).max() / np.abs(ref[i] * sc[i]**1.5).max() < TOL_NORM
@@ -413,3 +411,67 @@ def test_nonfinite_rows_stay_isolated(cp, golden):
     t = torch.as_tensor(rows, device='cuda')
     xi_t = f(t)[1]
     assert bool(torch.isnan(xi_t[1]).all()) and bool(torch.isfinite(xi_t[0]).all())
+
+
+@pytest.mark.parametrize('size', [8, 16, 32, 64, 256, 512, 1024, 4096, 8192, 16384])
+def test_engine_forward_backward_are_real_ffts(cp, size):
+    """NumpyFFTEngine / FFTWEngine by name (reference fftlog.py:533-544): forward = rfft, backward = irfft(conj(.), n=size) on the package's own
+    device FFTs (cp_rfft_forward / cp_rfft_backward) against numpy's, rows of very different magnitudes each on its own scale (one transform per
+    row), leading axes kept, numpy in -> numpy out and tensor in -> tensor out."""
+    import torch
+    from cosmoprimo_amd.fftlog import NumpyFFTEngine, FFTWEngine
+    rng = np.random.default_rng(size)
+    x = rng.normal(size=(3, 5, size)) * np.array([1e-12, 1., 1e9])[:, None, None]
+    for engine in (NumpyFFTEngine(size), FFTWEngine(size, nparallel=5, plan='estimate')):
+        spectrum = engine.forward(x)
+        ref = np.fft.rfft(x, axis=-1)
+        assert isinstance(spectrum, np.ndarray) and spectrum.dtype == np.complex128 and spectrum.shape == (3, 5, size // 2 + 1)
+        for i in range(3):
+            assert np.abs(spectrum[i] - ref[i]).max() < 4e-16 * np.log2(size) * np.abs(ref[i]).max() * 4
+        assert (spectrum[..., 0].imag == 0.).all() and (spectrum[..., -1].imag == 0.).all()
+        z = rng.normal(size=(3, 5, size // 2 + 1)) + 1j * rng.normal(size=(3, 5, size // 2 + 1))
+        z *= np.array([1e-12, 1., 1e9])[:, None, None]
+        back = engine.backward(z)
+        ref = np.fft.irfft(z.conj(), n=size, axis=-1)
+        assert back.dtype == np.float64 and back.shape == (3, 5, size)
+        for i in range(3):
+            assert np.abs(back[i] - ref[i]).max() < 4e-16 * np.log2(size) * np.abs(ref[i]).max() * 4
+        np.testing.assert_allclose(engine.backward(engine.forward(x).conj()), x, rtol=0, atol=1e-14 * np.abs(x).max(axis=-1, keepdims=True).max(axis=-2, keepdims=True))
+        t = engine.forward(torch.as_tensor(x[1, 0], device='cuda'))
+        assert t.is_cuda and t.dtype == torch.complex128 and t.shape == (size // 2 + 1,)
+        np.testing.assert_array_equal(t.cpu().numpy(), spectrum[1, 0])
+    bad = x[1].copy()
+    bad[2, 3] = np.nan
+    out = NumpyFFTEngine(size).forward(bad)
+    assert np.isnan(out[2]).all() and np.isfinite(np.delete(out, 2, axis=0)).all()
+    with pytest.raises(ValueError):
+        NumpyFFTEngine(size).forward(np.zeros(size + 1))
+    with pytest.raises(NotImplementedError):
+        NumpyFFTEngine(24).forward(np.zeros(24))
+
+
+def test_engine_instance_gives_the_fused_result(cp, golden):
+    """FFTlog(engine=NumpyFFTEngine(size)) is the fused kernel: bit-identical to the default engine; the same class wrapped in a foreign object
+    (only forward / backward visible: the reference's plug point) runs un-fused around the device FFTs and agrees to 1e-13 in tilted space."""
+    from cosmoprimo_amd.fftlog import NumpyFFTEngine
+    pkd = golden('pk_eh_default')
+    k, pk = pkd['k1024'], pkd['pk1024']
+    rows = np.stack([pk, 3. * pk, pk**1.01])
+    s0, ref = cp.PowerToCorrelation(k, ell=0)(rows)
+    s1, got = cp.PowerToCorrelation(k, ell=0, engine=NumpyFFTEngine(2048))(rows)
+    np.testing.assert_array_equal(s1, s0)
+    np.testing.assert_array_equal(got, ref)
+
+    class Foreign(object):
+        def __init__(self, size):
+            self._inner, self.size = NumpyFFTEngine(size), size
+
+        def forward(self, fun):
+            return self._inner.forward(fun)
+
+        def backward(self, fun):
+            return self._inner.backward(fun)
+
+    s2, unfused = cp.PowerToCorrelation(k, ell=0, engine=Foreign(2048))(rows)
+    for a, b in zip(unfused, ref):
+        assert tilted_err(a, b, s0, 1.5) < TOL_NORM

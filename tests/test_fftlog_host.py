@@ -249,3 +249,28 @@ def test_inverse_tables_of_complex_transforms():
     np.testing.assert_allclose(real * phase[:, None], f.padded_prefactor, rtol=1e-14)
     with pytest.raises(NotImplementedError):
         fl._unit_phase_split(np.exp(1j * np.linspace(0, 1, 8))[None, :], 'table')
+
+
+def test_engine_classes_by_name():
+    """The reference's engine names (fftlog.py:508-663) exist with their constructors: strings map onto the classes as there, the FFTW engine
+    validates its plan, ``apply_along_last_axes`` walks the leading axes.  (Their forward / backward need the device: tests/test_fftlog_gpu.py.)"""
+    assert issubclass(fl.NumpyFFTEngine, fl.BaseFFTEngine) and issubclass(fl.FFTWEngine, fl.BaseFFTEngine)
+    e = fl.get_fft_engine('numpy', size=256, nparallel=3)
+    assert type(e) is fl.NumpyFFTEngine and (e.size, e.nparallel) == (256, 3)
+    w = fl.get_fft_engine('FFTW', size=128, nthreads=4, plan='Estimate')
+    assert type(w) is fl.FFTWEngine and w.plan == 'estimate' and w.nthreads == 4
+    assert fl.get_fft_engine(e) is e
+    with pytest.raises(ValueError):
+        fl.FFTWEngine(128, plan='fastest')
+    k = np.logspace(-3, 1, 100)
+    for engine in (fl.NumpyFFTEngine(256), 'numpy', fl.FFTWEngine(256, plan='patient')):
+        f = cp.PowerToCorrelation(k, engine=engine)
+        assert isinstance(f._engine, fl.MI355XFFTEngine)      # the fused kernel, whatever the name
+    a = np.arange(24.).reshape(2, 3, 4)
+    kept = a.copy()
+    np.testing.assert_array_equal(fl.apply_along_last_axes(lambda row: row[::-1], a), a[..., ::-1])
+    out = fl.apply_along_last_axes(lambda block: block.sum(axis=0), a, naxes=2, toret=np.empty((2, 1, 4)))
+    np.testing.assert_array_equal(out[:, 0], a.sum(axis=1))
+    np.testing.assert_array_equal(a, kept)
+    with pytest.raises(ValueError):
+        fl.apply_along_last_axes(lambda row: row, a, toret=np.empty((3, 3, 4)))

@@ -72,7 +72,7 @@ def test_config4_filters_full_chunk():
     for i in (0, 7777, nb - 1):
         Om, Ob, h, ns = (float(par[name][i]) for name in ('Omega_m', 'Omega_b', 'h', 'n_s'))
         ref = obao.wallish2018(lambda k: op.pk_z0(k, 'eisenstein_hu', h=h, Omega_cdm=Om - Ob, Omega_b=Ob, n_s=ns, rsigma8=float(rsig[i]))[:, None])[:, 0]
-        np.testing.assert_allclose(pknow[i], ref, rtol=1e-8)
+        np.testing.assert_allclose(pknow[i], ref, rtol=1e-9)
     # smoothing what is already smooth changes little: the filter is (nearly) idempotent
     smooth = cp.PowerSpectrumInterpolator1D(filt.k, pknow[:64].T)
     again = cp.PowerSpectrumBAOFilter(smooth, engine='wallish2018').pknow
@@ -91,17 +91,24 @@ def test_config4_filters_full_chunk():
     assert np.median(dev) < 0.02 and dev.max() < 0.2
 
 
-def test_config4_one_gpu_share():
+def _benched_chunk():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    return bench.CONFIG4_CHUNK
+
+
+@pytest.mark.parametrize('chunk', sorted({16384, _benched_chunk()}))
+def test_config4_one_gpu_share(chunk):
     """Config 4 at the size one of 8 GPUs gets: 125 000 EH98 P(k) vectors through wallish2018 and brieden2022, chunk by chunk as bench.py
-    runs them (results kept on the device), sampled vectors of every chunk boundary against the oracle, every vector finite and positive."""
+    runs them (results kept on the device) -- at the chunk size bench.py times (bench.CONFIG4_CHUNK, imported: the two cannot drift apart) and at
+    16 384 --, sampled vectors of every chunk boundary against the oracle (1e-9), every vector finite and positive."""
     import torch
     import cosmoprimo_amd as cp
     import bench
-    import test_oracle_bao as tob
-    from oracle import bao as obao
+    from oracle import checks
     warnings.simplefilter('ignore')
     dev = torch.device('cuda', 0)
-    n, chunk = 125000, 16384
+    n = 125000
     par = bench.eh_parameters(n, 2, torch, dev)
     host = {name: v.cpu().numpy() for name, v in par.items()}
     fid = cp.Cosmology(engine='eisenstein_hu')
@@ -122,31 +129,17 @@ def test_config4_one_gpu_share():
                 rsig.append(cp.interpolator._host(cosmo._engine._rsigma8))
         rows[engine] = torch.cat(parts)
         assert rows[engine].shape == (n, 1024) and bool(torch.isfinite(rows[engine]).all()) and bool((rows[engine] > 0.).all())
-    # sampled vectors: first / last of the batch and both sides of chunk boundaries
-    pk_fid, rs_fid = tob.eh_pk({})
-    pknow_fid, _ = tob.eh_pk({}, 'eisenstein_hu_nowiggle')
-    prep = obao.brieden2022_prepare(pk_fid, pknow_fid)
-    # The oracle's own find_peaks differs from the reference's run by one knot that rounding decides (ratio_fid is pinned to 1 +- 1 ulp at its
-    # last samples: tests/test_oracle_bao.py); the knot lists the reference itself produced (golden vectors) go into the oracle -- nothing of
-    # the package does -- and the package's own search must have found the same lists.
-    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'bao.npz'))
-    prep['peaks'] = [gold['brieden_peaks_high'], gold['brieden_peaks_low']]
+    # sampled vectors: first / last of the batch and both sides of chunk boundaries.  The oracle's own find_peaks differs from the reference's run
+    # by one knot that rounding decides (tests/test_oracle_bao.py); checks.brieden2022_prepared() takes the knot lists the reference itself
+    # produced (golden vectors) -- nothing of the package does -- and the package's own search must have found the same lists.
+    prep, _ = checks.brieden2022_prepared()
     assert all(np.array_equal(np.asarray(mine), ref) for mine, ref in zip(flt.ik_fid_peaks, prep['peaks']))
-    prep['ratio_now_fid'] = obao._interp_envelopes(*prep['peaks'], prep['k_fid'], prep['ratio_fid'])
     rsig = np.concatenate(rsig)
-    from oracle import power as op
-    for i in (0, chunk - 1, chunk, 5 * chunk + 17, n - 1):
+    for i in (0, chunk - 1, chunk, (n // chunk - 1) * chunk + 17, n - 1):
         p = {name: float(v[i]) for name, v in host.items()}
-        _, rs = tob.eh_pk(p)                                         # rs_drag of the cosmology
-
-        def pk(k, p=p, i=i):      # the filters work on the growth-less P(k) of a 2-D interpolator (reference bao_filter.py:363, 493: ignore_growth=True)
-            return op.pk_z0(k, 'eisenstein_hu', h=p['h'], Omega_cdm=p['Omega_m'] - p['Omega_b'], Omega_b=p['Omega_b'], n_s=p['n_s'], rsigma8=float(rsig[i]))
-
-        ref = obao.wallish2018(lambda k: pk(k)[:, None])[:, 0]
-        np.testing.assert_allclose(rows['wallish2018'][i].cpu().numpy(), ref, rtol=1e-8, err_msg='wallish2018 %d' % i)
-        pknow_c, _ = tob.eh_pk(p, 'eisenstein_hu_nowiggle')
-        ref = obao.brieden2022_compute(prep, lambda k: pk(k)[:, None], pknow_c, rs / rs_fid, lambda kk, pp, ke: tob.pad_log_natural_eval(kk, pp[:, 0], ke))[:, 0]
-        np.testing.assert_allclose(rows['brieden2022'][i].cpu().numpy(), ref, rtol=1e-8, err_msg='brieden2022 %d' % i)
+        for engine in ('wallish2018', 'brieden2022'):
+            ref = checks.config4_pknow(p, rsig[i], engine)
+            np.testing.assert_allclose(rows[engine][i].cpu().numpy(), ref, rtol=checks.TOLERANCES['config4'], err_msg='%s %d' % (engine, i))
 
 
 def test_config5_distances_full_size():

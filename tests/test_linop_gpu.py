@@ -140,3 +140,24 @@ def test_dense_operator_along_the_middle_axis(n, nq, m, nb):
     z = rng.normal(size=(2, 40, 9))
     got = LinearOperator.spline(xk, xq).mid(torch.as_tensor(z, device=op.device)).cpu().numpy()
     np.testing.assert_allclose(got, np.einsum('qj,bjc->bqc', dense_operator(xk, xq), z), rtol=0., atol=1e-13)
+
+
+def test_exp10_epilogue_over_the_whole_line():
+    """The branch-free 10^x of the operator epilogues (csrc/cp_math.h: exp10_mid) where the result leaves the doubles: subnormal results, the
+    underflow to 0 (never a negative or huge value from a polynomial evaluated outside its range), the overflow to Inf, NaN and +-Inf."""
+    import torch
+    from cosmoprimo_amd.spline import LinearOperator
+    x = np.concatenate([np.linspace(-420., -300., 1201), np.linspace(300., 320., 201), np.linspace(-30., 30., 61),
+                        [-1e300, -1100., -400.5, -331.2, -324.1, -323.9, -323.3, -308., -307.6, 308.25, 308.2548, 308.31, 400.5, 1100., 1e300,
+                         np.nan, np.inf, -np.inf]])
+    op = LinearOperator.dense(np.array([[1.]]))
+    got = op.mid(torch.as_tensor(x[None, None, :], device=op.device), post='exp10').cpu().numpy().ravel()
+    with np.errstate(over='ignore', under='ignore'):
+        ref = np.power(10., x)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert (got[~np.isnan(got)] >= 0.).all()
+    normal = np.isfinite(ref) & (ref > 2.3e-308)
+    np.testing.assert_allclose(got[normal], ref[normal], rtol=1e-15 * 4)
+    sub = np.isfinite(ref) & (ref <= 2.3e-308)
+    assert np.abs(got[sub] - ref[sub]).max() <= 2 * 4.95e-324      # subnormals: within two units of the last place of the subnormal range
+    assert np.array_equal(np.isinf(got), np.isinf(ref))

@@ -4,36 +4,7 @@ from scipy.interpolate import CubicSpline
 
 from oracle import background as ob, bao as obao, power as op, sigma as osg
 from oracle.gen_golden import BAO_PARAMS
-
-
-def eh_pk(par, engine='eisenstein_hu'):
-    """Normalised P(k, z=0) callable of an analytic engine for reference-style parameters (oracle power + sigma pipeline)."""
-    par = dict(par)
-    h, Ob = par.get('h', 0.7), par.get('Omega_b', 0.05)
-    Ocdm = par['Omega_m'] - Ob if 'Omega_m' in par else 0.25
-    s8, ns = par.get('sigma8', 0.8), par.get('n_s', 0.96)
-    p = ob.derived(h=h, Omega_cdm=Ocdm, Omega_b=Ob)
-    D0 = op.growth_factor(0., p, znorm=0.)
-
-    def raw(k):
-        return op.pk_z0(k, engine, h=h, Omega_cdm=Ocdm, Omega_b=Ob, sigma8=s8, n_s=ns) * D0**2
-
-    rs = s8 / np.sqrt(osg.sigma_r2(8., raw))
-    return (lambda k: np.where((k >= 1e-7) & (k <= 1e2), raw(k) * rs**2, np.nan)), op.eh_scalars(h, Ocdm, Ob)['rs_drag'] * h
-
-
-def pad_log_natural_eval(kk, pp, ke):
-    """PowerSpectrumInterpolator1D(kk, pp)(ke): _pad_log + natural cubic spline in log10-log10 (interpolator.py:42-87, 419-451; jax.py:172)."""
-    logk, logp = np.log10(kk), np.log10(pp)
-    lmin, lmax = np.log10(np.minimum(1e-7, kk[0] * (1 - 1e-9))), np.log10(np.maximum(1e2, kk[-1] * (1 + 1e-9)))
-    sl = (logp[-1] - logp[-2]) / (logk[-1] - logk[-2])
-    hk = np.array([logk[-1] * 0.1 + lmax * 0.9, lmax])
-    hp = np.array([logp[-1] + sl * (hk[0] - logk[-1]), logp[-1] + sl * (hk[1] - logk[-1])])
-    sl = (logp[1] - logp[0]) / (logk[1] - logk[0])
-    lk = np.array([lmin, logk[0] * 0.1 + lmin * 0.9])
-    lp = np.array([logp[0] + sl * (lk[0] - logk[0]), logp[0] + sl * (lk[1] - logk[0])])
-    x, y = np.concatenate([lk, logk, hk]), np.concatenate([lp, logp, hp])
-    return 10**CubicSpline(x, y, axis=0, bc_type='natural')(np.log10(ke))
+from oracle.checks import eh_pk, pad_log_natural_eval      # noqa: F401  (other test modules take them from here)
 
 
 def test_wallish(golden):

@@ -134,3 +134,77 @@ def test_few_radii_as_a_functional_of_the_spectrum(engine):
         from cosmoprimo_amd import power
         direct = power.analytic(engine, 'matter', k, bg=bg, pk=pk, device=dev).cpu().numpy().reshape(pk_f.shape)
         assert np.array_equal(direct, pk_f, equal_nan=True)
+
+
+def _oracle_sigma(engine, par, i, r, g2):
+    """sqrt(sigma^2(r) growth_sq) of cosmology i straight from the oracle (oracle/sigma.py: integrate_sigma_r2 restated, interpolator.py:200-292),
+    with the fiducial amplitude the entry points default to."""
+    from oracle import power as op, sigma as osig
+    Om, Ob, h, ns = (float(par[name][i]) for name in ('Omega_m', 'Omega_b', 'h', 'n_s'))
+    pk0 = lambda k: op.pk_z0(k, engine, h=h, Omega_cdm=Om - Ob, Omega_b=Ob, n_s=ns, sigma8=0.8)        # noqa: E731
+    k = np.geomspace(1e-7, 1e2, 1024)
+    return (osig.sigma_r2(r, pk0)[:, None] * g2[None, :])**0.5, pk0(k)
+
+
+@pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
+def test_functional_against_the_oracle(engine):
+    """cp_sigma_rz_functional pinned on the oracle itself (not on the fused kernel): sigma8 and sigma(r) at up to four radii of sampled
+    cosmologies, and the spectra it hands back, 1e-10."""
+    import torch
+    from cosmoprimo_amd import interpolator as itp
+    warnings.simplefilter('ignore')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    for n, radii in ((5, [8.]), (9, [2., 8., 25., 90.]), (3, [0.7, 140.])):
+        par = parameters(n, 40 + n)
+        bg = dict(h=torch.as_tensor(par['h'], device=dev), Omega_cdm=torch.as_tensor(par['Omega_m'] - par['Omega_b'], device=dev),
+                  Omega_b=torch.as_tensor(par['Omega_b'], device=dev))
+        pk = dict(n_s=torch.as_tensor(par['n_s'], device=dev))
+        g2 = np.random.default_rng(n).uniform(0.2, 1., (n, 3))
+        r = np.array(radii)
+        assert r.size <= itp._FUNCTIONAL_RADII
+        out, spectra, k = itp.sigma_rz_analytic(engine, bg, pk, r, torch.as_tensor(g2, device=dev), dev, keep_spectra=True)
+        out, spectra = out.cpu().numpy(), spectra.cpu().numpy()
+        for i in range(n):
+            ref, pk_ref = _oracle_sigma(engine, par, i, r, g2[i])
+            np.testing.assert_allclose(out[i], ref, rtol=1e-10, atol=0, err_msg=str((engine, n, i)))
+            np.testing.assert_allclose(spectra[i], pk_ref, rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize('blocks', [1, 2, 5])
+def test_block_route_keeps_spectra_inside_their_buffer(blocks):
+    """cp_sigma_rz_analytic, block route, with d_pk_out given: the (ncosmo, nk) spectra buffer is exactly that size (variances and coefficients
+    belong to the workspace); a guard region behind the spectra must stay untouched and the results must be the fused route's."""
+    import torch
+    from cosmoprimo_amd import _lib, _device as dv, interpolator as itp
+    from cosmoprimo_amd.background import DEFAULTS as bg_defaults
+    from cosmoprimo_amd.power import PK_DEFAULTS
+    warnings.simplefilter('ignore')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    n, nz, nk = 37, 3, 1024
+    par = parameters(n, 77)
+    bg = dict(h=torch.as_tensor(par['h'], device=dev), Omega_cdm=torch.as_tensor(par['Omega_m'] - par['Omega_b'], device=dev),
+              Omega_b=torch.as_tensor(par['Omega_b'], device=dev))
+    pk = dict(n_s=torch.as_tensor(par['n_s'], device=dev))
+    r = np.geomspace(1., 100., 48)
+    g2 = torch.as_tensor(np.random.default_rng(3).uniform(0.2, 1., (n, nz)), device=dev)
+    ref, pk_ref, _ = itp.sigma_rz_analytic('eisenstein_hu', bg, pk, r, g2, dev, keep_spectra=True)
+    got, pk_got, _ = itp.sigma_rz_analytic('eisenstein_hu', bg, pk, r, g2, dev, blocks=blocks, keep_spectra=True)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-13, atol=0)
+    np.testing.assert_allclose(pk_got.cpu().numpy(), pk_ref.cpu().numpy(), rtol=2e-13, atol=0)
+    # the same call through the C ABI with the spectra at the head of a larger allocation whose tail is a canary
+    lib = _lib.load()
+    cbg, _, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, dev)
+    cpk, _, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, dev)
+    fft = itp.TophatVariance(np.geomspace(1e-7, 1e2, nk), device=dev)
+    op = itp.LinearOperator.spline(fft.y[0], r, bc='natural', device=dev)
+    guard = 3 * n * nk
+    buf = torch.full((n * nk + guard,), -7.25, dtype=torch.float64, device=dev)
+    out = torch.empty((n, r.size, nz), dtype=torch.float64, device=dev)
+    work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(n, nk)), dtype=torch.uint8, device=dev)
+    kdev = dv.upload(np.geomspace(1e-7, 1e2, nk), dev)
+    _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES['eisenstein_hu'], n, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, kdev.data_ptr(),
+                                        fft._get_plan(dev).handle, op._handle, g2.data_ptr(), nz, out.data_ptr(), buf.data_ptr(), work.data_ptr(),
+                                        blocks, dev.index, dv.stream_of(dev)))
+    torch.cuda.synchronize()
+    assert bool((buf[n * nk:] == -7.25).all()), 'cp_sigma_rz_analytic wrote behind the (ncosmo, nk) spectra it was given'
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-13, atol=0)
