@@ -52,7 +52,10 @@ inline hipError_t allow_full_lds() {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64 && configured[dev]) return hipSuccess;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncAttributes attr;      // the limit covers static + dynamic LDS: a kernel with __shared__ variables of its own gets what they leave
+    e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(KERNEL));
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)attr.sharedSizeBytes);
     if (e == hipSuccess && dev >= 0 && dev < 64) configured[dev] = true;
     return e;
 }

@@ -18,6 +18,11 @@
 // doubles for the roots of the splined variances and of the growth factors.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
 #include "cp_fftlog_body.h"
@@ -359,6 +364,266 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_spline_kernel(const RowsArgs
     }
 }
 
+// ---- the same front end with the spline SOLVED instead of multiplied: natural cubic spline from the (geometric) output grid to the radii, the
+// tridiagonal system solved in registers.  fftlog_spline_kernel above fetches a query's band of ~44 weights from L2 per pair of rows (90 KB per
+// pair: why it loses beyond a few thousand rows).  On a geometric grid s_i = s_0 rho^i the system has CONSTANT coefficients once the second
+// derivatives are scaled by their interval: with N_i = M_i h_{i-1}^2 / 6,
+//     rho^2 N_{i-1} + 2 (1 + rho) N_i + N_{i+1} / rho = d_i := (y_{i+1} - y_i) / rho - (y_i - y_{i-1}),
+//     s(r) = A y_j + B y_{j+1} + (A^3 - A) rho^2 N_j + (B^3 - B) N_{j+1},   A = (s_{j+1} - r) / h_j,  B = 1 - A,
+// and the inverse of a constant tridiagonal matrix is two geometric tails: N_i = kappa (sum_{j <= i} pL^(i-j) d_j + sum_{j > i} pR^(j-i) d_j),
+// |pL|, |pR| ~ 0.27: a causal and an anti-causal first-order recursion, F_i = d_i + pL F_{i-1} and B_i = d_i + pR B_{i+1}, N_i = kappa (F_i +
+// pR B_{i+1}).  One wave per row; lane l owns the S knots [S l, S l + S) of the stretch the radii see (+ >= 32 knots on either side, 64 S in
+// all): it reads its S + 2 values from LDS ONCE, runs both recursions over its own knots from zero, and takes what the knots outside its
+// segment contribute from its neighbours' segment totals, handed from lane to lane by DPP shifts of the whole wave (a segment away the weight is
+// pL^S: nine lanes reach the 1e-19 that the 32 knots of margin stand for; lanes beyond the stretch count as zero).  No LDS round trip but the
+// initial read and the hand-over of N to the evaluation -- a first version that reduced the system cyclically through LDS (five dependent round
+// trips, each queueing behind the FFT traffic of the other workgroups of the CU) spent 0.7 ms of 4.1 there (profiles/r4_geospline_ablate.txt).
+// Plans whose stretch would leave the interior of the grid are refused and take the operator route.  group > 0: rows come in groups (the
+// redshifts of one table) and out is (nbatch / group, nq, group), the transposition PowerSpectrumInterpolator2D.sigma_rz needs, written by the
+// kernel itself: the pairs of a group are then handed to workgroups of ONE XCD in the same round (workgroups are dealt round-robin to the 8 XCDs),
+// so that the 8-byte pieces of a 512-byte output line meet in that XCD's L2.
+constexpr int GEO_SMAX = 8;          // knots per lane: stretches of at most 512 knots
+constexpr int GEO_SMIN = 4;          // (fewer knots per lane would need more than GEO_REACH lanes of carry)
+constexpr int GEO_QMAX = 8;          // queries per lane: at most 512 radii
+constexpr int GEO_HALO = 32, GEO_REACH = 9;      // GEO_REACH x GEO_SMIN >= GEO_HALO + 1
+#ifndef CP_GEO_ABLATE      // diagnostic builds (tools/geospline_ablate.sh; wrong results): 1 no carries between lanes, 2 one query per lane, 4 no root,
+#define CP_GEO_ABLATE 0    // 8 no solve at all (the tail is the barriers only), 16 no stores
+#endif
+
+struct GeoConsts {                  // on the device, read by scalar loads right in front of the solve (kernel arguments would sit in SGPRs through the FFT)
+    double inv_rho, rho_sq, kappa, pL, pR;
+    double pLk[GEO_SMAX];           // pL^(k + 1): what the carry into the segment weighs at its knot k
+    double pRk[GEO_SMAX];           // pR^(S - k)
+    double cL[GEO_REACH];           // (pL^S)^m: the segment total of the lane m + 1 to the left
+    double cR[GEO_REACH];
+};
+
+struct GeoArgs {
+    FftlogArgs fft;
+    int ws, ne, S;                   // first knot of the stretch, its length (64 S), knots per lane
+    int nq, post_sqrt, group;
+    int ntables, pt;                 // grouped: tables and pairs per table; plain: pairs and 1
+    const GeoConsts* consts;
+    const int* qe;                   // (nq) interval of each query relative to ws, -1: outside the knots
+    const double* qa;                // (nq) A of each query
+    double* out;
+};
+
+// lane l receives the value of lane l - 1 (lane 0: zero) / of lane l + 1 (lane 63: zero): DPP shifts of the whole wave, no LDS
+typedef int geo_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double wave_from_left(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    geo_v2i w = __builtin_bit_cast(geo_v2i, v);
+    w.x = __builtin_amdgcn_update_dpp(0, w.x, 0x138, 0xf, 0xf, true);      // wave_shr:1
+    w.y = __builtin_amdgcn_update_dpp(0, w.y, 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, w);
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ double wave_from_right(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    geo_v2i w = __builtin_bit_cast(geo_v2i, v);
+    w.x = __builtin_amdgcn_update_dpp(0, w.x, 0x130, 0xf, 0xf, true);      // wave_shl:1
+    w.y = __builtin_amdgcn_update_dpp(0, w.y, 0x130, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, w);
+#else
+    return v;
+#endif
+}
+
+// sqrt for the epilogue: positive normal arguments (every variance) take the hardware reciprocal-root estimate with its third-order correction
+// (cp_math.h: rsqrt_pos, relative error 1e-16) and one multiplication; zero, subnormal, negative, Inf and NaN take the library's
+__device__ __forceinline__ double geo_sqrt(double v) {
+    return v >= 2.2250738585072014e-308 && v <= 1.7976931348623157e308 ? v * cpmath::rsqrt_pos(v) : sqrt(v);
+}
+
+__global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoArgs R) {
+    using F = Fftlog<NP, P, IN_HALF_ZERO, OUT_HALF>;
+    constexpr int T = F::T, H = F::H, Q = F::Q;
+    extern __shared__ __attribute__((aligned(4096))) char smem[];
+    cplx* lds = reinterpret_cast<cplx*>(smem);
+    const int t = threadIdx.x;
+    const FftlogArgs& A = R.fft;
+    // Work items without a division in the loop: an item is (tl, w) = (table of this share, pair inside the table); plain layout: one share,
+    // tables of one pair, dealt blockIdx + k gridDim; grouped: a share per XCD (workgroup b runs on XCD b % 8), tables xcd + 8 tl, dealt
+    // slot + k slots over the pairs of the share's tables in order.  tl only grows: the first table beyond the batch ends the walk.
+    const bool grouped = R.group > 0 && !(CP_GEO_ABLATE & 64);      // (64: the grouped layout written in the plain work order, diagnostic)
+    const int xcd = grouped ? (int)(blockIdx.x & 7) : 0, mult = grouped ? 8 : 1;
+    const int pt = grouped ? R.pt : 1;
+    const int first = grouped ? (int)(blockIdx.x >> 3) : (int)blockIdx.x, step = grouped ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    int tl = first / pt, w = first - tl * pt;
+    const int dtl = step / pt, dw = step - dtl * pt;
+    const int ntables = grouped ? R.ntables : (int)((A.nbatch + 1) / 2);
+    if (tl * mult + xcd >= ntables) return;
+    long long p = (long long)(tl * mult + xcd) * pt + w;
+    typename F::State st;
+    const long long n = A.n;
+    {
+        const double* ra = A.in + 2 * p * n;
+        F::init_state(t, A, ra, ra + (2 * p + 1 < A.nbatch ? n : 0), 0, st);
+    }
+    F::fill_lds_tables(t, A, lds);
+    F::screen_prefetched(t, st.t0, A, 0, lds, st);
+    __syncthreads();
+    st.info_nxt = F::screen_collect(lds);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see fftlog_kernel
+    const int t0 = st.t0;
+    const int wave = t >> 6, lane = t & 63;
+    // the data region as doubles: the stretch of both rows (one knot of margin on either side), then their scaled second derivatives
+    double* base = reinterpret_cast<double*>(lds);
+    constexpr int YSTRIDE = 64 * GEO_SMAX + 8;
+    static_assert(4 * YSTRIDE <= 2 * NP, "the solve lives in the data region of the FFT");
+    bool more = true;
+    while (more) {
+        const bool has_b = 2 * p + 1 < A.nbatch;
+        const int table = tl * mult + xcd, within = w;
+        // the next item (this one again on the last round: its rows are prefetched and screened, never used)
+        w += dw;
+        tl += dtl;
+        if (w >= pt) {
+            w -= pt;
+            ++tl;
+        }
+        more = tl * mult + xcd < ntables;
+        const long long pn = more ? (long long)(tl * mult + xcd) * pt + w : p;
+        const double* nra = A.in + 2 * pn * n;
+        const double* nrb = nra + (2 * pn + 1 < A.nbatch ? n : 0);
+        {
+            F::template phase<0>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            __syncthreads();
+            F::template phase<1>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            if constexpr (!F::template barrier_free_after<1>()) __syncthreads();
+            F::template phase<2>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            if constexpr (!F::template barrier_free_after<2>()) __syncthreads();
+            static_assert(F::NPH == 5, "three passes");
+            F::template phase<3>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
+            __syncthreads();
+        }
+        {
+            cplx x[P];
+            Pass<NP, P, 0>::load_lds(t0, lds, x);
+            st.info_nxt = F::screen_collect(lds);
+            __syncthreads();      // every thread has its inputs: the data region is free
+            Pass<NP, P, 0>::twiddle_apply(st.w, x);
+            Pass<NP, P, 0>::butterflies(x);
+            double ya[H], yb[H];
+#pragma unroll
+            for (int s = 0; s < H; ++s) {
+                ya[s] = x[s + Q].re * st.fpost[s];
+                yb[s] = x[s + Q].im * st.fpost[s];
+            }
+            F::template fix_output<H>(st.info_cur, ya, yb);
+#pragma unroll
+            for (int s = 0; s < H; ++s) {      // the stretch of both rows (and one knot beyond either end) in natural order
+                const int e = t0 + T * s - R.ws;
+                if (e >= -1 && e <= R.ne) {
+                    base[1 + e] = ya[s];
+                    base[YSTRIDE + 1 + e] = yb[s];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- one wave per row from here to the stores ----
+        if ((wave == 0 || has_b) && !(CP_GEO_ABLATE & 8)) {
+            const double* Y = base + wave * YSTRIDE + 1;              // Y[-1 .. ne]
+            double* N = base + (2 + wave) * YSTRIDE;                  // N[0 .. ne)
+            const int S = R.S;
+            // the queries of this lane (12 bytes per radius, L1 / L2 resident): in flight during the solve
+            int qe[GEO_QMAX];
+            double qa[GEO_QMAX];
+#pragma unroll
+            for (int j = 0; j < GEO_QMAX; ++j) {
+                const int q = lane + 64 * j;
+                if (CP_GEO_ABLATE & 32) {      // (queries made up in registers: what their loads cost)
+                    qe[j] = q < R.nq ? 32 + q : -1;
+                    qa[j] = 0.25;
+                } else {
+                    qe[j] = q < R.nq ? R.qe[q] : -1;
+                    qa[j] = q < R.nq ? R.qa[q] : 0.;
+                }
+            }
+            const GeoConsts* C = R.consts;
+            asm volatile("" : "+s"(C));      // (not hoisted out of the loop over pairs: the scalar registers are the FFT's there)
+            // the lane's knots and their two neighbours, one LDS round trip
+            double y[GEO_SMAX + 2];
+            const double* mine = Y + S * lane - 1;
+#pragma unroll
+            for (int i = 0; i < GEO_SMAX + 2; ++i) y[i] = i < S + 2 ? mine[i] : 0.;
+            const double inv_rho = C->inv_rho, pL = C->pL, pR = C->pR;
+            double f[GEO_SMAX], g[GEO_SMAX];
+            {      // F_k = d_k + pL F_{k-1} upwards and B_k = d_k + pR B_{k+1} downwards over the segment, both from zero
+                double d[GEO_SMAX];
+#pragma unroll
+                for (int k = 0; k < GEO_SMAX; ++k) d[k] = k < S ? (y[k + 2] - y[k + 1]) * inv_rho - (y[k + 1] - y[k]) : 0.;
+                double acc = 0.;
+#pragma unroll
+                for (int k = 0; k < GEO_SMAX; ++k) {
+                    acc = fma(pL, acc, d[k]);
+                    f[k] = acc;
+                }
+                acc = 0.;
+#pragma unroll
+                for (int k = GEO_SMAX - 1; k >= 0; --k) {      // (knots k >= S hold d = 0: the recursion starts at the segment's last knot)
+                    acc = fma(pR, acc, d[k]);
+                    g[k] = acc;
+                }
+            }
+            // what the knots left of the segment add to F at its first knot (x pL^(k + 1) further in), and the knots right of it to B
+            double fin = 0., gin = 0.;
+            if (!(CP_GEO_ABLATE & 1)) {
+                double fl = 0., gr = g[0];
+#pragma unroll
+                for (int k = 0; k < GEO_SMAX; ++k) fl = k == S - 1 ? f[k] : fl;      // the segment's total: F at its last knot
+#pragma unroll
+                for (int m = 0; m < GEO_REACH; ++m) {
+                    fl = wave_from_left(fl);
+                    gr = wave_from_right(gr);
+                    fin = fma(C->cL[m], fl, fin);
+                    gin = fma(C->cR[m], gr, gin);
+                }
+            }
+            // N_k = kappa (F_k + pR B_{k+1}), B beyond the segment's last knot being the carry itself
+            {
+                const double kappa = C->kappa;
+                double bnext = gin;      // true B at the first knot of the next segment
+#pragma unroll
+                for (int k = GEO_SMAX - 1; k >= 0; --k) {
+                    if (k < S) {
+                        const double fk = fma(C->pLk[k], fin, f[k]);
+                        N[S * lane + k] = kappa * fma(pR, bnext, fk);
+                        bnext = fma(C->pRk[k], gin, g[k]);
+                    }
+                }
+            }
+            cp::wave_lds_phase();
+            const double rho_sq = C->rho_sq;
+            // plain: out[row, q]; grouped: out[table, q, 2 within + wave]
+            double* dst = grouped ? R.out + (long long)table * R.nq * R.group + 2 * within + wave : R.out + (2 * p + wave) * R.nq;
+            int qstride = grouped ? R.group : 1;
+            if ((CP_GEO_ABLATE & 64) && R.group > 0) {
+                const long long row = 2 * p + wave;
+                dst = R.out + (row / R.group) * R.nq * R.group + row % R.group;
+                qstride = R.group;
+            }
+#pragma unroll
+            for (int j = 0; j < ((CP_GEO_ABLATE & 2) ? 1 : GEO_QMAX); ++j) {
+                const int q = lane + 64 * j;
+                if (q < R.nq) {
+                    const int e = qe[j] < 0 ? 0 : qe[j];
+                    const double a = qa[j], b = 1. - a;
+                    double v = fma(a, Y[e], b * Y[e + 1]) + (fma(a * a, a, -a) * (rho_sq * N[e]) + fma(b * b, b, -b) * N[e + 1]);
+                    if (R.post_sqrt && !(CP_GEO_ABLATE & 4)) v = geo_sqrt(v);
+                    if (qe[j] < 0) v = __builtin_nan("");
+                    if (!(CP_GEO_ABLATE & 16) || v == 12345.678) dst[(long long)q * qstride] = v;
+                }
+            }
+        }
+        __syncthreads();      // the next pair's phase 0 writes the data region
+        p = pn;
+    }
+}
+
 template <int ENGINE>
 hipError_t launch(const SigmaArgs& S, int grid, size_t lds, hipStream_t stream) {
     if (lds > 64 * 1024) (void)cp::allow_full_lds<&sigma_rz_kernel<ENGINE>>();
@@ -580,5 +845,164 @@ extern "C" int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_s
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_spline_execute: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+// ---- natural spline on a geometric grid, solved inside the FFTLog kernel (fftlog_geospline_kernel above) -----------------------------------------
+struct cp_geospline_plan {
+    int n, nq, ws, ne, S, device;
+    int* d_qe;
+    double* d_qa;
+    GeoConsts* d_consts;
+};
+
+extern "C" int cp_geospline_plan_destroy(cp_geospline_plan* p) {
+    if (!p) return CP_OK;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device) (void)hipSetDevice(p->device);
+    if (p->d_qe) (void)hipFree(p->d_qe);
+    if (p->d_qa) (void)hipFree(p->d_qa);
+    if (p->d_consts) (void)hipFree(p->d_consts);
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    delete p;
+    return CP_OK;
+}
+
+extern "C" int cp_geospline_plan_create(cp_geospline_plan** out, const double* knots, int n, const double* queries, int nq, int device) {
+    if (!out) return cp::fail(CP_EINVAL, "cp_geospline_plan_create: null plan pointer");
+    *out = nullptr;
+    if (!knots || !queries || n < 4 || nq < 1) return cp::fail(CP_EINVAL, "cp_geospline_plan_create: bad arguments");
+    if (nq > 64 * GEO_QMAX) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: %d queries (at most %d)", nq, 64 * GEO_QMAX);
+    if (!(knots[0] > 0.) || !(knots[n - 1] > knots[0])) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: the knots are not an ascending geometric grid");
+    const double rho = pow(knots[n - 1] / knots[0], 1. / (n - 1));
+    for (int i = 0; i + 1 < n; ++i)
+        if (!(fabs(knots[i + 1] / (knots[i] * rho) - 1.) < 1e-12)) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: the knots are not a geometric grid (knot %d)", i + 1);
+    std::vector<int> qj(nq);
+    std::vector<double> qa(nq);
+    int jmin = n, jmax = -1;
+    for (int q = 0; q < nq; ++q) {
+        const double r = queries[q];
+        if (!(r >= knots[0] && r <= knots[n - 1])) {      // outside the knots (or NaN): NaN, as the spline without extrapolation returns
+            qj[q] = -1;
+            qa[q] = 0.;
+            continue;
+        }
+        int j = (int)(std::upper_bound(knots, knots + n, r) - knots) - 1;
+        if (j > n - 2) j = n - 2;
+        qj[q] = j;
+        qa[q] = (knots[j + 1] - r) / (knots[j + 1] - knots[j]);
+        jmin = std::min(jmin, j);
+        jmax = std::max(jmax, j + 1);
+    }
+    if (jmax < 0) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: no query inside the knots");
+    const int need = jmax - jmin + 1 + 2 * GEO_HALO;
+    const int S = std::max(GEO_SMIN, (need + 63) / 64);
+    if (S > GEO_SMAX) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: the queries span %d knots (at most %d)", jmax - jmin + 1, 64 * GEO_SMAX - 2 * GEO_HALO);
+    const int ne = 64 * S;
+    int ws = jmin - GEO_HALO - (ne - need) / 2;
+    // the stretch [ws, ws + ne) and one knot on either side must be interior knots (the solve uses the interior equation everywhere)
+    if (ws < 2) ws = 2;
+    if (ws + ne > n - 2) ws = n - 2 - ne;
+    if (ws < 2 || jmin - ws < GEO_HALO || ws + ne - 1 - jmax < GEO_HALO)
+        return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: the queries come within %d knots of the ends of the grid", GEO_HALO);
+    cp_geospline_plan* p = new (std::nothrow) cp_geospline_plan();
+    if (!p) return cp::fail(CP_ENOMEM, "cp_geospline_plan_create: host allocation failed");
+    p->n = n; p->nq = nq; p->ws = ws; p->ne = ne; p->S = S; p->device = device; p->d_qe = nullptr; p->d_qa = nullptr; p->d_consts = nullptr;
+    GeoConsts consts{};
+    {
+        // a N_{i-1} + b N_i + c N_{i+1} = d_i on the infinite grid: N_i = kappa (sum_{j <= i} pL^(i-j) d_j + sum_{j > i} pR^(j-i) d_j), pL the root of
+        // c t^2 + b t + a inside the unit circle (a source to the left decays to the right), pR that of a t^2 + b t + c, kappa = 1 / (a pR + b + c pL)
+        const long double a = (long double)rho * rho, b = 2.0L * (1.0L + rho), c = 1.0L / rho;
+        const long double disc = sqrtl(b * b - 4.0L * a * c);
+        const long double pL = -2.0L * a / (b + disc);      // = (-b + disc) / (2 c), without the cancellation
+        const long double pR = -2.0L * c / (b + disc);
+        const long double kappa = 1.0L / (a * pR + b + c * pL);
+        consts.inv_rho = (double)(1.0L / rho); consts.rho_sq = (double)a; consts.kappa = (double)kappa; consts.pL = (double)pL; consts.pR = (double)pR;
+        for (int k = 0; k < GEO_SMAX; ++k) {
+            consts.pLk[k] = (double)powl(pL, k + 1);
+            consts.pRk[k] = k < S ? (double)powl(pR, S - k) : 0.;
+        }
+        for (int m = 0; m < GEO_REACH; ++m) {
+            consts.cL[m] = (double)powl(pL, (long double)S * m);
+            consts.cR[m] = (double)powl(pR, (long double)S * m);
+        }
+    }
+    for (int q = 0; q < nq; ++q)
+        if (qj[q] >= 0) qj[q] -= ws;
+    int prev = -1, status = CP_OK;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_geospline_plan_create: cannot select device %d", device);
+    if (status == CP_OK && (hipMalloc(&p->d_qe, nq * sizeof(int)) != hipSuccess || hipMalloc(&p->d_qa, nq * sizeof(double)) != hipSuccess ||
+                            hipMalloc(&p->d_consts, sizeof(GeoConsts)) != hipSuccess))
+        status = cp::fail(CP_ENOMEM, "cp_geospline_plan_create: device allocation failed");
+    if (status == CP_OK && (hipMemcpy(p->d_qe, qj.data(), nq * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->d_qa, qa.data(), nq * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->d_consts, &consts, sizeof(GeoConsts), hipMemcpyHostToDevice) != hipSuccess))
+        status = cp::fail(CP_EDEVICE, "cp_geospline_plan_create: upload failed");
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (status != CP_OK) {
+        cp_geospline_plan_destroy(p);
+        return status;
+    }
+    *out = p;
+    return CP_OK;
+}
+
+extern "C" int cp_geospline_plan_info(const cp_geospline_plan* p, int* first_knot, int* nknots, int* nq) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_geospline_plan_info: null plan");
+    if (first_knot) *first_knot = p->ws;
+    if (nknots) *nknots = p->ne;
+    if (nq) *nq = p->nq;
+    return CP_OK;
+}
+
+extern "C" int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const cp_geospline_plan* spline, const double* d_in, double* d_out,
+                                           long long nbatch, int group, int post_op, void* stream) {
+    if (nbatch < 0 || group < 0) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: negative size");
+    if (nbatch > 2000000000LL) return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_geospline_execute: %lld rows in one call (split the batch)", nbatch);
+    if (nbatch == 0) return CP_OK;
+    if (!fftlog || !spline || !d_in || !d_out) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: null pointer");
+    if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: unknown post op %d", post_op);
+    if (group > 0 && ((group & 1) || nbatch % group)) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: %lld rows do not come in groups of an even %d", nbatch, group);
+    cp_fftlog_tables_view f;
+    if (!cp_fftlog_plan_view(fftlog, &f) || !(f.npad == NP && f.n == NP / 2 && f.nker == 1 && f.in_left == NP / 4 && f.out_left == NP / 4))
+        return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_geospline_execute: transform outside the fused kernel's shape (1024 samples padded to 2048, one kernel)");
+    if (spline->n != f.n || spline->device != f.device) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: the spline plan is for %d knots on device %d", spline->n, spline->device);
+    GeoArgs R{};
+    FftlogArgs& A = R.fft;
+    A.in = d_in; A.out = nullptr; A.nbatch = nbatch; A.nker = 1; A.n = f.n; A.in_left = f.in_left; A.out_off = f.out_left; A.n_out = f.n;
+    A.ext_l = A.ext_r = CP_EXTRAP_CONST; A.val_l = A.val_r = 0.;
+    A.stream_rows = (double)nbatch * f.n * 8. > 512. * 1024. * 1024.;
+    A.pre = f.d_pre; A.post = f.d_post; A.u = f.d_u; A.tw = f.d_tw;
+    R.ws = spline->ws; R.ne = spline->ne; R.S = spline->S; R.nq = spline->nq; R.post_sqrt = post_op == CP_SPLINE_POST_SQRT; R.group = group;
+    R.ntables = group > 0 ? (int)(nbatch / group) : (int)((nbatch + 1) / 2);
+    R.pt = group > 0 ? group / 2 : 1;
+    R.consts = spline->d_consts;
+    R.qe = spline->d_qe; R.qa = spline->d_qa; R.out = d_out;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != f.device && hipSetDevice(f.device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_geospline_execute: cannot select device %d", f.device);
+    using F = Fftlog<NP, P, IN_HALF_ZERO, OUT_HALF>;
+    const size_t lds = (size_t)F::LDS_BYTES;
+    if (lds > 64 * 1024) (void)cp::allow_full_lds<&fftlog_geospline_kernel>();
+    int ncu = 0;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, f.device);
+    const long long npairs = (nbatch + 1) / 2;
+    const size_t per_cu = (160 * 1024) / lds;
+    const long long resident = (long long)(ncu > 0 ? ncu : 256) * (long long)(per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    long long grid;
+    if (group > 0) {      // a multiple of 8 (one share per XCD), every workgroup of an XCD the same number of rounds
+        const long long per_xcd = ((nbatch / group + 7) / 8) * (group / 2), slots = std::max(1LL, resident / 8);
+        const long long rounds = (per_xcd + slots - 1) / slots;
+        grid = 8 * ((per_xcd + rounds - 1) / rounds);
+    } else {
+        const long long rounds = (npairs + resident - 1) / resident;
+        grid = (npairs + rounds - 1) / rounds;
+    }
+    hipLaunchKernelGGL(fftlog_geospline_kernel, dim3((unsigned)grid), dim3(NP / P), lds, static_cast<hipStream_t>(stream), R);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_geospline_execute: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }

@@ -1136,9 +1136,13 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
     typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
     for (long long item = blockIdx.x; item < A.nbatch * nqt; item += gridDim.x) {
         const long long b = item / nqt;
-        const int q0 = (int)(item % nqt) * 256 + wave * 64;
+        // The four waves of the workgroup take ADJACENT column tiles at every step (wave w: wavenumbers q0 + 64 jj + 16 w ...): together they walk the
+        // table rows 256 bytes at a time, two whole cache lines that all four touch within the same few hundred cycles.  (Each wave walking its own
+        // 64 wavenumbers used half of a line per step and came back for the other half thousands of cycles later, when it had often left the L2:
+        // FETCH_SIZE 4.7 GB for 2.4 GB of tables.)
+        const int q0 = (int)(item % nqt) * 256 + wave * 16;
         if (q0 >= A.nq) continue;
-        // One column tile (16 wavenumbers: the lane's is q0 + 16 jj + (l & 15), its interval and weights from the plan) at a time: the k splines
+        // One column tile (16 wavenumbers: the lane's is q0 + 64 jj + (l & 15), its interval and weights from the plan) at a time: the k splines
         // of the table's rows there, in the layout of the B fragments of the z contraction (2 x 4 registers); R = Wz L on the matrix cores (4 tiles
         // of 16 output redshifts); f applied, rows of P(k, z) stored.
         int rowoff[2][4];
@@ -1155,7 +1159,7 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
         double* ob = A.out + b * (long long)A.nzq * A.nq;
 #pragma unroll 1
         for (int jj = 0; jj < 4; ++jj) {
-            const int q = q0 + 16 * jj + l15;
+            const int q = q0 + 64 * jj + l15;
             const int qc = q < A.nq ? q : A.nq - 1;
             const int jraw = A.qj[qc];
             const bool nanq = jraw < 0;
@@ -1177,7 +1181,7 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     r2[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(4 * kk + g) * TABLES_WSTRIDE + 16 * mi + l15], lt[kk >> 2][kk & 3], r2[mi], 0, 0, 0);
-            const bool full = q0 + 16 * (jj + 1) <= A.nq && A.nzq == 64;
+            const bool full = q0 + 64 * jj + 16 <= A.nq && A.nzq == 64;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -1187,7 +1191,9 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
                     if (POST == CP_SPLINE_POST_SQRT) v = sqrt(v);
                     else if (POST == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
                     v = (nanq || ((nan_z >> (4 * mi + r)) & 1u)) ? __builtin_nan("") : v;
-                    if (full || (q < A.nq && zq < A.nzq)) ob[zq * A.nq + q] = v;      // (at most 64 rows of nq: 32-bit)
+                    // written once, read by the next kernel from memory: the non-temporal policy keeps these 5.2 GB (config 3B) from evicting the table
+                    // lines the wave comes back to at its next column tile (FETCH_SIZE of this kernel: 5.8 GB with plain stores for 2.4 GB of tables)
+                    if (full || (q < A.nq && zq < A.nzq)) __builtin_nontemporal_store(v, ob + zq * A.nq + q);      // (at most 64 rows of nq: 32-bit)
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (four exponentials in flight, not sixteen: their temporaries set the register count)
             }

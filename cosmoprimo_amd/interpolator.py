@@ -196,6 +196,63 @@ def _fftlog_then_spline(fft, op, rows, device, sqrt=False):
     return out
 
 
+class _GeoSpline(object):
+
+    """Owner of a ``cp_geospline_plan``: the natural spline from a geometric grid (the output grid of an FFTLog) to fixed queries, solved inside the
+    FFTLog kernel by cyclic reduction.  ``handle`` is None where the library refuses the plan (queries near the ends of the grid, too wide a span)."""
+
+    def __init__(self, knots, queries, device):
+        import ctypes
+        self.handle, self.nq = None, int(np.size(queries))
+        handle = ctypes.c_void_p()
+        knots, queries = np.ascontiguousarray(knots, dtype='f8'), np.ascontiguousarray(queries, dtype='f8')
+        status = _lib.load().cp_geospline_plan_create(ctypes.byref(handle), _lib.as_double_p(knots), knots.size, _lib.as_double_p(queries), queries.size, device.index)
+        if status == _lib.CP_EUNSUPPORTED:
+            return
+        _lib.check(status)
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().cp_geospline_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+_GEOSPLINE_MIN_ROWS = 8193      # below: the band-operator kernel of _fftlog_then_spline (launch- / latency-bound regime)
+_GEOSPLINE_GROUPED = True      # sigma_rz's (..., nr, nz) layout written by the kernel itself (False: (..., nz, nr) and a transposed view; measurements)
+
+
+def _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=False, group=0):
+    """The transform of ``rows`` (..., nk) and the natural spline of every transformed row to the radii ``rr`` as ONE kernel with the spline solved
+    on the CU (``cp_fftlog_geospline_execute``), for the default transform (1024 samples).  group > 0: rows (..., group, nk) -> (..., nr, group).
+    None when it does not apply."""
+    torch = dv.torch()
+    if not dv.is_torch(rows) or rows.dtype != torch.float64 or rows.shape[-1] != fft.size or fft.nparallel != 1 or fft.size != 1024 or fft.padded_size != 2048:
+        return None
+    if getattr(fft, '_phase', None) is not None or getattr(fft, '_phase_in', None) is not None:
+        return None
+    plan = _cached_operator(('geospline', s.tobytes(), rr.tobytes(), device.index), lambda: _GeoSpline(s, rr, device))
+    if plan.handle is None:
+        return None
+    rows = rows.contiguous()
+    lead = tuple(rows.shape[:-1])
+    nrows = int(np.prod(lead, dtype=np.int64))
+    if group:
+        if len(lead) < 1 or lead[-1] != group or group % 2:
+            return None
+        oshape = lead[:-1] + (plan.nq, group)
+    else:
+        oshape = lead + (plan.nq,)
+    out = torch.empty(oshape, dtype=torch.float64, device=device)
+    if nrows:
+        _lib.check(_lib.load().cp_fftlog_geospline_execute(fft._get_plan(device).handle, plan.handle, rows.data_ptr(), out.data_ptr(), nrows, int(group),
+                                                           int(bool(sqrt)), dv.stream_of(device)))
+    return out
+
+
 def _with_growth(sigma2, growth_sq):
     """sqrt(sigma2[..., r] growth_sq[..., z]) as (..., nr, nz) (methods other than 'fftlog': elementwise), or sigma2 as it is."""
     if growth_sq is None:
@@ -244,6 +301,14 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         fused = _fftlog_then_spline(fft, op, rows, device, sqrt=sqrt) if growth_sq is None else None
         if fused is not None:
             return fused.transpose(-1, -2) if radii_before_last_axis and fused.ndim >= 2 else fused
+        if growth_sq is None and dv.is_torch(rows) and rows.numel() // max(rows.shape[-1], 1) >= _GEOSPLINE_MIN_ROWS:
+            # many rows (config 3B: 640 000): transform and spline in one kernel, the spline solved on the CU, sigma_rz's layout written by it
+            group = int(rows.shape[-2]) if radii_before_last_axis and rows.ndim >= 2 and _TRANSPOSE_IN_STORE and _GEOSPLINE_GROUPED else 0
+            solved = _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=sqrt, group=group if group % 2 == 0 else 0)
+            if solved is not None:
+                if radii_before_last_axis and rows.ndim >= 2 and not (group and group % 2 == 0):
+                    return solved.transpose(-1, -2)
+                return solved
         if growth_sq is not None:
             return op.outer(fft(rows)[1], growth_sq, sqrt=True)
         var = fft(rows, out_window=op.columns)[1]      # the radii see a part of the FFTLog grid: only that part is written

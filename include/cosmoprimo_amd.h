@@ -313,6 +313,21 @@ int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const cp_spline_pl
  * are never written.  Plans for which cp_sigma_rz_fused_available() is 1 (CP_EUNSUPPORTED otherwise: make the two calls). */
 int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_in, double* d_out, long long nbatch, int post_op,
                              void* stream);
+/* The same for any number of rows, with the spline SOLVED inside the kernel instead of applied as a banded operator: the output grid of an FFTLog
+ * is geometric, the natural spline's tridiagonal system then has constant coefficients (second derivatives scaled by their interval), and five
+ * steps of cyclic reduction in LDS on the knots the queries see (+ 32 on either side) give them exactly to rounding -- no weights to fetch but
+ * 12 bytes per query (interpolator.py:285-291, jax.py:169-175 with bc_type='natural').
+ * cp_geospline_plan_create: knots (n) a geometric grid (host), queries (nq <= 512, host; outside the knots: NaN); CP_EUNSUPPORTED when the knots
+ * are not geometric, the queries span more than 448 knots or come within 32 knots of either end of the grid (take cp_spline_plan + cp_spline_apply).
+ * cp_fftlog_geospline_execute: d_in (nbatch, n) rows; group = 0: d_out (nbatch, nq); group > 0 (even, dividing nbatch): rows come in groups
+ * (the redshifts of one table) and d_out is (nbatch / group, nq, group), the layout of PowerSpectrumInterpolator2D.sigma_rz (interpolator.py:846-875).
+ * d_out = post(spline), post_op CP_SPLINE_POST_NONE or CP_SPLINE_POST_SQRT.  Transform: 1024 samples padded to 2048, one kernel. */
+typedef struct cp_geospline_plan cp_geospline_plan;
+int cp_geospline_plan_create(cp_geospline_plan** plan, const double* knots, int n, const double* queries, int nq, int device);
+int cp_geospline_plan_destroy(cp_geospline_plan* plan);
+int cp_geospline_plan_info(const cp_geospline_plan* plan, int* first_knot, int* nknots, int* nq);
+int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const cp_geospline_plan* spline, const double* d_in, double* d_out, long long nbatch,
+                                int group, int post_op, void* stream);
 long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk);
 int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
                          const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,

@@ -100,6 +100,84 @@ def test_fftlog_spline_execute(nrows, nq):
     assert lib.cp_sigma_rz_fused_available(other._get_plan(dev).handle, op2._handle) == 0
 
 
+@pytest.mark.parametrize('nrows,nq,group', [(1, 1, 0), (2, 40, 0), (33, 256, 0), (301, 130, 0), (64, 256, 64), (6 * 10, 100, 10), (9 * 64, 256, 64), (4 * 2, 511, 2)])
+def test_fftlog_geospline_execute(nrows, nq, group):
+    """cp_fftlog_geospline_execute (FFTLog + natural spline SOLVED on the CU by cyclic reduction on the geometric output grid) against scipy's
+    CubicSpline(bc_type='natural') of the package's own transformed rows (1e-13 in tilted space) and against the band-operator route; plain and grouped (transposed) layouts, odd batches, a NaN row next to good ones, queries outside the grid, tables
+    (groups) that do not fill the eight XCD shares."""
+    from scipy.interpolate import CubicSpline
+    torch, _lib, lib, dv, dev = _env()
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import interpolator as itp
+    from cosmoprimo_amd.spline import LinearOperator
+    k = np.geomspace(1e-7, 1e2, 1024)
+    fft = cp.TophatVariance(k, device=dev)
+    s = fft.y[0]
+    r = np.geomspace(0.7, 150., nq) if nq > 1 else np.array([8.])
+    if nq > 4:
+        r[0], r[-1] = 1e-5, 1e9                                                       # outside the output grid of the transform: NaN
+    rng = np.random.default_rng(nrows + nq)
+    rows = torch.as_tensor(rng.uniform(0.5, 2., (nrows, 1)) * (k / 0.05)**rng.uniform(-2.2, -1.8, (nrows, 1)) * 1e4, device=dev).contiguous()
+    if nrows > 2:
+        rows[1, 100] = float('nan')                                                   # row 1 shares a transform with row 0
+    var = fft(rows)[1].cpu().numpy()
+    inside = (r >= s[0]) & (r <= s[-1])
+    op = LinearOperator.spline(s, r, bc='natural', device=dev)
+    for sqrt in (False, True):
+        shaped = rows.reshape(nrows // group, group, 1024) if group else rows
+        got = itp._fftlog_then_geospline(fft, s, r, shaped, dev, sqrt=sqrt, group=group)
+        assert got is not None
+        got = got.cpu().numpy()
+        if group:
+            assert got.shape == (nrows // group, nq, group)
+            got = got.transpose(0, 2, 1).reshape(nrows, nq)
+        assert got.shape == (nrows, nq)
+        assert np.isnan(got[:, ~inside]).all()
+        for i in range(nrows):
+            if nrows > 2 and i == 1:
+                assert np.isnan(got[i]).all()
+                continue
+            # the reference splines the rows ANOTHER launch transformed: two evaluations of an FFTLog agree to ~1e-14 in tilted space (g y^1.5
+            # against its largest value: tests/test_fftlog_gpu.py), i.e. worse by (r_max / r)^1.5 at the small radii; the solve itself adds 1e-15
+            ref = CubicSpline(s, var[i], bc_type='natural')(r[inside])
+            tilted = np.abs((got[i, inside]**2 if sqrt else got[i, inside]) - ref) * r[inside]**1.5
+            assert tilted.max() < 1e-13 * np.abs(var[i] * s**1.5).max(), 'row %d' % i
+        # the kernel with the same front end and the band operator behind it transforms with the same arithmetic: what is left is the solve
+        same_front = itp._fftlog_then_spline(fft, op, rows, dev, sqrt=sqrt)
+        if same_front is not None:
+            same_front = same_front.cpu().numpy()
+            keep = np.isfinite(same_front)
+            assert np.array_equal(np.isfinite(got), keep)
+            np.testing.assert_allclose(got[keep], same_front[keep], rtol=1e-12)
+        banded = op(torch.as_tensor(var, device=dev), sqrt=sqrt).cpu().numpy()
+        keep = np.isfinite(banded)
+        np.testing.assert_allclose(got[keep], banded[keep], rtol=2e-11)
+
+
+def test_geospline_plans_the_library_refuses():
+    """Radii within 32 knots of either end of the grid, spans of more than 448 knots, grids that are not geometric, transforms of another size:
+    no plan (the caller takes the band operator), never a wrong number."""
+    torch, _lib, lib, dv, dev = _env()
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import interpolator as itp
+    k = np.geomspace(1e-7, 1e2, 1024)
+    fft = cp.TophatVariance(k, device=dev)
+    s = fft.y[0]
+    rows = torch.as_tensor((k / 0.05)**-2. * 1e4, device=dev)[None, :].repeat(4, 1).contiguous()
+    assert itp._GeoSpline(s, np.array([8.]), dev).handle is not None
+    assert itp._GeoSpline(s, np.array([s[5] * 1.01, 8.]), dev).handle is None                 # 5 knots from the first one
+    assert itp._GeoSpline(s, np.array([8., s[-20]]), dev).handle is None
+    assert itp._GeoSpline(s, np.geomspace(s[100], s[900], 64), dev).handle is None            # 800 knots
+    assert itp._GeoSpline(np.linspace(1., 2., 1024), np.array([1.5]), dev).handle is None
+    assert itp._fftlog_then_geospline(fft, s, np.array([s[5] * 1.01, 8.]), rows, dev) is None
+    other = cp.TophatVariance(np.geomspace(1e-5, 1e2, 512), device=dev)
+    assert itp._fftlog_then_geospline(other, other.y[0], np.array([8.]), rows[:, :512].contiguous(), dev) is None
+    with pytest.raises(ValueError):
+        plan = itp._GeoSpline(s, np.array([8.]), dev)
+        out = torch.empty((4, 1), dtype=torch.float64, device=dev)
+        _lib.check(lib.cp_fftlog_geospline_execute(fft._get_plan(dev).handle, plan.handle, rows.data_ptr(), out.data_ptr(), 4, 3, 0, dv.stream_of(dev)))
+
+
 def test_bao_elementwise_passes():
     torch, _lib, lib, dv, dev = _env()
     rng = np.random.default_rng(5)
