@@ -178,22 +178,49 @@ def config3b(cp, torch, dev, ncosmo=10000, reps=5):
             'parity_spot_check': {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config3b'], 'unit_checked': 'table %d, 256 r x 64 z, vs oracle' % i}}
 
 
-def _config4_valu_roofline(engine, vectors_per_s):
-    """What bounds the filters is instruction issue, not HBM: the vector-instruction roofline from the committed instruction census
-    (profiles/*_config4_valu.json: SQ_INSTS_VALU / SQ_INSTS_MFMA per vector from a rocprofv3 --pmc pass of this same workload)."""
+# Vector instructions one P(k) vector NEEDS, whatever the implementation (wave-instructions = lane operations / 64): the evaluations of the fit formulae
+# (EH98 ~390 fp64 instructions per wavenumber, its no-wiggle form ~150: ISA census of power_kernel, tools/isa_census.py) and the transforms / solves
+# (a radix-2 FFT count, 5 N log2 N flops per complex transform = N log2 N x 2.5 multiply-adds; three multiply-adds per knot and sweep for a tridiagonal system).
+_EH98, _NOWIGGLE = 390, 150
+CONFIG4_ALGORITHMIC = {
+    # 4096 wavenumbers of the linear grid + the 1024 of the sigma8 normalisation (the filter's own k); forward and inverse DST of 4096 samples (each
+    # half a complex transform of 4096 points per row); clamped splines through 2 x 2048 coefficients and through the 3666 spliced knots, two sweeps
+    # each, and the 1024 evaluations of the latter
+    'wallish2018': ((4096 + 1024) * _EH98 + 2 * 0.5 * 2.5 * 4096 * 12 + 2 * 3 * (4096 + 3666) + 8 * 1024) / 64.,
+    # sigma8 normalisation of both engines (1024 each), EH98 at k_fid / r and k_fid r (2 x 341), the no-wiggle template at k_fid (341); the envelope
+    # operator (341 x 341, matrix cores: counted apart); the per-column spline through 345 knots evaluated at 1024 wavenumbers
+    'brieden2022': ((1024 + 2 * 341) * _EH98 + (1024 + 341) * _NOWIGGLE + 2 * 3 * 345 + 8 * 1024) / 64.,
+}
+
+
+def _library_sha():
+    import hashlib
+    path = os.path.join(ROOT, 'cosmoprimo_amd', 'libcosmoprimo_amd.so')
+    return hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16] if os.path.isfile(path) else None
+
+
+def _config4_valu_roofline(engine, vectors_per_s, chunk):
+    """What bounds the filters is instruction issue, not HBM.  `achieved` / `frac`: the ALGORITHMIC vector instructions per vector (CONFIG4_ALGORITHMIC,
+    a count no implementation can go below) x the measured vectors/s against the issue peak of the vector pipes.  Next to it the instructions the
+    package's own kernels EXECUTE per vector (committed census profiles/*_config4_valu.json: rocprofv3 --pmc SQ_INSTS_VALU per kernel, framework
+    kernels excluded, scripts/profile_config4_valu.sh), flagged when the census was not taken on this library or chunk size."""
     import glob
+    peak = 256 * 4 * 2.4e9 / 4
+    alg = CONFIG4_ALGORITHMIC[engine]
+    out = {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': alg * vectors_per_s, 'peak': peak,
+           'unit': 'wave-instructions/s', 'frac': alg * vectors_per_s / peak, 'algorithmic_wave_instructions_per_vector': alg}
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_config4_valu.json')))
-    if not files:
-        return None
-    with open(files[-1]) as fh:
-        census = json.load(fh)
-    per = census[engine]['per_vector']
-    peak = census['peaks']['valu_wave_instructions_per_s']
-    achieved = per['SQ_INSTS_VALU'] * vectors_per_s
-    return {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': achieved, 'peak': peak,
-            'unit': 'wave-instructions/s', 'frac': achieved / peak, 'valu_wave_instructions_per_vector': per['SQ_INSTS_VALU'],
-            'mfma_f64_16x16x4_per_vector': per['SQ_INSTS_MFMA'], 'mfma_frac': per['SQ_INSTS_MFMA'] * vectors_per_s / census['peaks']['mfma_f64_16x16x4_per_s'],
-            'source': os.path.relpath(files[-1], ROOT)}
+    if files:
+        with open(files[-1]) as fh:
+            census = json.load(fh)
+        entry = census.get(engine, {})
+        per = entry.get('per_vector', {})
+        if 'SQ_INSTS_VALU' in per:
+            current = census.get('library_sha256_16') == _library_sha() and entry.get('chunk') == chunk
+            out['executed'] = {'valu_wave_instructions_per_vector': per['SQ_INSTS_VALU'], 'mfma_f64_16x16x4_per_vector': per.get('SQ_INSTS_MFMA', 0.),
+                               'issue_slots_used': per['SQ_INSTS_VALU'] * vectors_per_s / peak, 'algorithmic_over_executed': alg / per['SQ_INSTS_VALU'],
+                               'source': os.path.relpath(files[-1], ROOT), 'census_taken_on_this_library_and_chunk': bool(current)}
+    return out
 
 
 def config4(cp, torch, dev, par, chunk=CONFIG4_CHUNK, engines=('wallish2018', 'brieden2022'), spot_check=True):
@@ -243,7 +270,7 @@ def config4(cp, torch, dev, par, chunk=CONFIG4_CHUNK, engines=('wallish2018', 'b
                 err = checks.max_relative_error(res.reshape(n - last, -1)[j].cpu().numpy(), ref)
                 assert err < checks.TOLERANCES['config4'], 'config 4 (%s) failed its parity spot check: %g' % (engine, err)
                 check = {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config4'], 'unit_checked': 'vector %d (chunk of %d), pknow at 1024 k, vs oracle' % (last + j, chunk)}
-            valu = _config4_valu_roofline(engine, n / wall)
+            valu = _config4_valu_roofline(engine, n / wall, chunk)
             out[engine] = {'value': n / wall, 'unit': 'vectors/s', 'ms': wall * 1e3, 'ms_gpu_events': e0.elapsed_time(e1), 'vectors': n, 'chunk': chunk,
                            'parity_spot_check': check, 'roofline_valu': valu,
                            'roofline': {'bound': 'hbm', 'achieved': n * 16384 / wall / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -260,12 +287,18 @@ def _config5_valu_roofline(samples_per_s):
     if not files:
         return None
     with open(files[-1]) as fh:
-        per = json.load(fh)['per_sample']
+        census = json.load(fh)
+    per = census['per_sample']
     peak = 256 * 4 * 2.4e9 / 4
     achieved = per['SQ_INSTS_VALU'] * samples_per_s
+    # fp64 operations of the algorithm itself: ~65 of the 118 intervals per sample (those below it and `reach` above it), two ordinates of 1 / E(z)
+    # (~44 flop) and one elimination row (~12 flop) each -- what the instructions above are spent on
+    useful = 65 * (2 * 44 + 12)
     return {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': achieved, 'peak': peak, 'unit': 'wave-instructions/s',
             'frac': achieved / peak, 'valu_wave_instructions_per_sample': per['SQ_INSTS_VALU'], 'valu_instructions_per_thread': 64 * per['SQ_INSTS_VALU'],
-            'source': os.path.relpath(files[-1], ROOT)}
+            'useful_fp64_flop_per_sample': useful, 'useful_fp64_frac_of_peak': useful * samples_per_s / (FP64_PEAK_TFLOPS * 1e12),
+            'source': os.path.relpath(files[-1], ROOT),
+            'census_taken_on_this_library': census.get('library_sha256_16') == _library_sha() if 'library_sha256_16' in census else None}
 
 
 def config5(torch, dev, om, w0, wa, zz, reps=5, spot_check=True):

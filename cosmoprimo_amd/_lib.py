@@ -48,6 +48,7 @@ SIGNATURES = {
     'cp_fftlog_plan_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, _c_int_p, _c_int_p, _c_int_p]),
     'cp_background_distance': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cp_derived_parameters': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_background_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
     'cp_ncdm_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
     'cp_growth_ode_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
@@ -133,6 +134,9 @@ SIGNATURES = {
     'cp_rows_screen': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_void_p]),
     'cp_dst_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_dst_forward_analytic_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong]),
+    'cp_dst_forward_analytic': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_spline_operator': (ctypes.c_int, [ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                                          _c_int_p]),
 }
@@ -150,6 +154,9 @@ class cp_ncdm(ctypes.Structure):
 
 SIGNATURES['cp_ncdm_tables'] = (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, cp_param, cp_param, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                _c_double_p, _c_double_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p])
+SIGNATURES['cp_sigma8_normalise'] = (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.c_void_p, cp_param, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                    ctypes.c_void_p])
 NCDM_NKNOTS = 119
 GROWTH_NKNOTS = 201
 
@@ -158,6 +165,8 @@ SPLINE_BC = {'natural': 0, 'clamped': 1, 'not-a-knot': 2}
 PK_PARAMS = ('A_s', 'n_s', 'alpha_s', 'beta_s', 'k_pivot')
 ENGINES = {'eisenstein_hu': 0, 'eisenstein_hu_nowiggle': 1, 'bbks': 2}
 PK_WHAT = {'matter': 0, 'transfer': 1, 'primordial': 2, 'log_k_matter': 3}
+DERIVED_VALUES = ('_h2', 'H0', 'Omega_g', 'T_ur', 'Omega_ur', 'Omega_r', 'Omega_m', 'Omega_de', 'K', 'omega_b', 'omega_cdm', 'omega_m', 'omega_g', 'omega_ur',
+                  'omega_r', 'omega_k', 'omega_de')      # enum cp_derived_value
 VARIANTS_SCALARS = ('omega_b', 'omega_m', 'frac_b', 'frac_cdm', 'frac_cb', 'frac_ncdm', 'theta_cmb', 'z_eq', 'k_eq', 'z_drag', 'rs_drag', 'p_c', 'p_cb',
                     'gamma_ncdm', 'beta_c')      # enum cp_variants_scalar
 EH_SCALARS = ('rs_drag', 'z_drag', 'z_eq', 'k_eq', 'r_drag', 'r_eq', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b', 'alpha_gamma',

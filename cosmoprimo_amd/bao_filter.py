@@ -173,6 +173,9 @@ class BasePowerSpectrumBAOFilter(dv.Copyable, metaclass=RegisteredPowerSpectrumB
         return float(ratio)
 
 
+_TRANSFORM_EVALUATES_SPECTRA = True      # wallish2018 on batches of analytic cosmologies: cp_dst_forward_analytic (False: evaluation kernel, then transform)
+
+
 class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     """
@@ -254,7 +257,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         dd = ops['dd'](y)
         return dd, self._box(dd), False
 
-    def _log_k_rows(self, klin):
+    def _log_k_rows(self, klin, dst=None):
         """log(k_lin P(k_lin)) rows (ncol, 4096) of a batch of cosmologies of an analytic engine, written by the evaluation kernel term by term
         (``cp_power_eval``, CP_PK_LOG_K_MATTER) -- the transform then reads its input as it is, without 4096 logarithms per vector.  None for any
         other input (tabulated spectra, several redshifts, rescaled amplitudes): the transform takes the logarithm itself."""
@@ -263,10 +266,14 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         rs = getattr(interp, '_rsigma8sq', None)
         if not isinstance(interp, PowerSpectrumInterpolator2D) or not hasattr(call, 'analytic_engine') or np.size(interp.z) != 1 or not (
                 isinstance(rs, float) and rs == 1.):
-            return None
+            return None, None
         engine, bg, pk = call.analytic_engine()
+        if dst is not None and _TRANSFORM_EVALUATES_SPECTRA:      # a batch of cosmologies: the transform kernel evaluates the spectra itself
+            ffted = dst.forward_analytic(engine, bg, pk, split=True)
+            if ffted is not None and ffted.shape[0] == self._pk_rows.shape[0]:
+                return None, ffted
         rows = pwmod.analytic(engine, 'log_k_matter', klin, bg=bg, pk=pk, device=self.device)
-        return rows if rows.ndim == 2 and rows.shape[0] == self._pk_rows.shape[0] else None
+        return (rows if rows.ndim == 2 and rows.shape[0] == self._pk_rows.shape[0] else None), None
 
     def _compute(self):
         torch = dv.torch()
@@ -274,8 +281,10 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         lib = _lib.load()
         # dst(log(k P)), type 2, ortho, written as [even-indexed | odd-indexed] coefficients: seen as (2 ncol, 2048) the two sequences of
         # every vector are consecutive rows, and share the operators (x_even = x_odd = 1 + arange(2048), bao_filter.py:374-375)
-        logkp = self._log_k_rows(ops['klin'])
-        if logkp is not None:                                             # analytic engine: log(k_lin P) straight from the evaluation kernel
+        logkp, ffted = self._log_k_rows(ops['klin'], dst=ops['dst'])
+        if ffted is not None:                                             # a batch of analytic cosmologies: evaluated inside the transform
+            pass
+        elif logkp is not None:                                           # analytic engine: log(k_lin P) straight from the evaluation kernel
             ffted = ops['dst'](logkp, split=True)
         else:
             rows, _ = self._rows(ops['klin'])                             # P(k_lin), (ncol, 4096)

@@ -320,14 +320,17 @@ def _compile_params(args):
             value = value.upper()
         out[name] = value
     r, n_s = out['r'], out['n_s']
+    # no tensors (r = 0, the default) and a batch of tilts: both rules give zero for every cosmology -- the number, not six kernels on (B,) arrays
+    no_tensors = not _is_array(r) and r == 0. and _is_array(n_s)
     if isinstance(out['n_t'], str):        # single-field slow-roll consistency (cosmology.py:1212-1215)
-        out['n_t'] = - r / 8.0 * (2.0 - n_s - r / 8.0)
+        out['n_t'] = 0. if no_tensors else - r / 8.0 * (2.0 - n_s - r / 8.0)
     if isinstance(out['alpha_t'], str):
-        out['alpha_t'] = r / 8.0 * (r / 8.0 + n_s - 1)
+        out['alpha_t'] = 0. if no_tensors else r / 8.0 * (r / 8.0 + n_s - 1)
     return out
 
 
 _missing = object()
+_DEVICE_DERIVED = frozenset(_lib.DERIVED_VALUES)
 
 
 class BaseCosmoParams(dv.Copyable):
@@ -403,6 +406,11 @@ class BaseCosmoParams(dv.Copyable):
         memo = self.__dict__.setdefault('_derived_memo', {})
         if name in memo:
             return memo[name]
+        if name in _DEVICE_DERIVED:      # a batch on the device: every derived value from ONE kernel, at the first that is asked for
+            table = self._device_derived()
+            if table is not None:
+                memo.update(table)
+                return memo[name]
         found = self._derive(name)
         if found is not _missing:
             memo[name] = found
@@ -415,8 +423,32 @@ class BaseCosmoParams(dv.Copyable):
         """h^2, kept with the derived values: half a dozen derivations use it, and for a batch of cosmologies every square is a device kernel."""
         memo = self.__dict__.setdefault('_derived_memo', {})
         if '_h2' not in memo:
-            memo['_h2'] = self._params['h']**2
+            table = self._device_derived()
+            if table is not None:
+                memo.update(table)
+            else:
+                memo['_h2'] = self._params['h']**2
         return memo['_h2']
+
+    def _device_derived(self):
+        """{name: (B,) device tensor} of the derived parameters of a batch of cosmologies kept on the device (``cp_derived_parameters``: one
+        launch for all of them; elementwise framework arithmetic took two to five launches for each), None for anything else -- host
+        parameters, massive species (their densities are derived on the host)."""
+        params = self._params
+        if params.get('m_ncdm'):
+            return None
+        tensors = [params[name] for name in _lib.BG_PARAMS if dv.is_torch(params[name])]
+        if not tensors or not all(t.is_cuda and t.ndim == 1 and t.dtype == tensors[0].dtype for t in tensors):
+            return None
+        torch, device = dv.torch(), tensors[0].device
+        if tensors[0].dtype != torch.float64:
+            return None
+        carr, n, keep = dv.pack_params(_lib.BG_PARAMS, params, bgmod.DEFAULTS, device)
+        if n is None:
+            return None
+        out = torch.empty((len(_lib.DERIVED_VALUES), n), dtype=torch.float64, device=device)
+        _lib.check(_lib.load().cp_derived_parameters(n, dv.as_void_p(carr), out.data_ptr(), device.index, dv.stream_of(device)))
+        return {name: out[i] for i, name in enumerate(_lib.DERIVED_VALUES)}
 
     def _derive(self, name):
         """``name`` from the compiled parameters, ``_missing`` if it is not a derived parameter."""
@@ -567,6 +599,8 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
         if getattr(self, '_rsigma8', None) is not None:
             return self._rsigma8
         self._rsigma8 = 1.
+        if 'sigma8' in self._params and self._normalise_batch_on_device():
+            return self._rsigma8
         if 'sigma8' in self._params:
             fo = self.get_fourier()
             sigma8 = self['sigma8']
@@ -576,6 +610,23 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
                 self._rsigma8 = float(self._rsigma8)
             self._sections = {name: section for name, section in self._sections.items() if name in ('background', 'thermodynamics')}   # untouched by the rescaling
         return self._rsigma8
+
+    def _normalise_batch_on_device(self):
+        """The sigma8 normalisation of a batch of cosmologies of an analytic engine as one kernel (``cp_sigma8_normalise``): the factors, the
+        normalised amplitudes and the normalised spectra on the 1024 wavenumbers every sigma integral and every filter asks for next, left where
+        :meth:`pk_params` and the Fourier section look for them.  False (nothing done) for anything else."""
+        transfer = getattr(self, '_transfer', None)
+        if self.batch_size is None or transfer not in _lib.ENGINES or self._params.get('m_ncdm') or getattr(self.device, 'type', None) != 'cuda':
+            return False
+        from .interpolator import sigma8_normalise
+        res = sigma8_normalise(transfer, self.bg_params(), self.pk_params(rsigma8=1.), self['sigma8'], self.device)
+        if res is None:
+            return False
+        rsigma8, amplitude, spectra, k = res
+        self._rsigma8 = rsigma8
+        self.__dict__['_A_s_normalised'] = (rsigma8, amplitude)
+        self.__dict__['_pk0_normalised'] = ((k.shape, k.tobytes()), rsigma8, spectra)
+        return True
 
     def _any_mass(self):
         masses = self['m_ncdm']

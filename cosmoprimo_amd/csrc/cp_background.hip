@@ -709,3 +709,74 @@ extern "C" int cp_background_eval(long long ncosmo, long long nz, const cp_param
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_distance: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
+
+// ---- derived parameters of a batch of cosmologies (BaseCosmoParams.__getitem__ -> _get_derived, cosmology.py:331-415), one launch -------------------
+// A batch kept on the device derived each of these with two to five framework kernels on (ncosmo,) arrays -- two dozen launches of 3-5 us per
+// chunk of config 4, the cosmology object being made anew for every chunk -- where one lane per cosmology does all of it.
+namespace {
+
+struct DerivedArgs {
+    long long ncosmo;
+    Param p[CP_BG_NPARAMS];
+    double* out;      // (CP_DERIVED_NVALUES, ncosmo): one row per derived value, so that each is a contiguous (ncosmo,) array
+};
+
+__global__ __launch_bounds__(256) void derived_parameters_kernel(const DerivedArgs A) {
+    const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ic >= A.ncosmo) return;
+    double v[CP_BG_NPARAMS];
+#pragma unroll
+    for (int k = 0; k < CP_BG_NPARAMS; ++k) v[k] = A.p[k].ptr ? A.p[k].ptr[ic] : A.p[k].value;
+    const double h = v[CP_BG_H], Omega_cdm = v[CP_BG_OMEGA_CDM], Omega_b = v[CP_BG_OMEGA_B], Omega_k = v[CP_BG_OMEGA_K], T_cmb = v[CP_BG_T_CMB], N_ur = v[CP_BG_N_UR];
+    // the operation order of the host formulas (cosmology.py:355-383 as restated in BaseCosmoParams._derive): batches and single cosmologies agree to rounding
+    const double h2 = h * h;
+    const double c3 = kC * kC * kC;
+    const double Omega_g = (T_cmb * T_cmb) * (T_cmb * T_cmb) * 4. / c3 * kStefanBoltzmann / (h2 * kRhoCritKg);
+    const double T_ur = T_cmb * 0.7137658555036082;      // (4 / 11)^(1 / 3)
+    const double Omega_ur = N_ur * 7. / 8. * ((T_ur * T_ur) * (T_ur * T_ur)) * 4. / c3 * kStefanBoltzmann / (h2 * kRhoCritKg);
+    const double Omega_r = Omega_g + Omega_ur;
+    const double Omega_m = Omega_b + Omega_cdm;
+    const double Omega_de = 1. - (Omega_cdm + Omega_b + Omega_g + Omega_ur + Omega_k);
+    double* o = A.out + ic;
+    const long long n = A.ncosmo;
+    o[CP_DERIVED_H2 * n] = h2;
+    o[CP_DERIVED_H0 * n] = h * 100;
+    o[CP_DERIVED_OMEGA_G * n] = Omega_g;
+    o[CP_DERIVED_T_UR * n] = T_ur;
+    o[CP_DERIVED_OMEGA_UR * n] = Omega_ur;
+    o[CP_DERIVED_OMEGA_R * n] = Omega_r;
+    o[CP_DERIVED_OMEGA_M * n] = Omega_m;
+    o[CP_DERIVED_OMEGA_DE * n] = Omega_de;
+    o[CP_DERIVED_K * n] = -(100. * 100.) / (kCkms * kCkms) * Omega_k;
+    o[CP_DERIVED_LITTLE_OMEGA_B * n] = Omega_b * h2;
+    o[CP_DERIVED_LITTLE_OMEGA_CDM * n] = Omega_cdm * h2;
+    o[CP_DERIVED_LITTLE_OMEGA_M * n] = Omega_m * h2;
+    o[CP_DERIVED_LITTLE_OMEGA_G * n] = Omega_g * h2;
+    o[CP_DERIVED_LITTLE_OMEGA_UR * n] = Omega_ur * h2;
+    o[CP_DERIVED_LITTLE_OMEGA_R * n] = Omega_r * h2;
+    o[CP_DERIVED_LITTLE_OMEGA_K * n] = Omega_k * h2;
+    o[CP_DERIVED_LITTLE_OMEGA_DE * n] = Omega_de * h2;
+}
+
+}  // namespace
+
+extern "C" int cp_derived_parameters(long long ncosmo, const cp_param* params, double* d_out, int device, void* stream) {
+    if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_derived_parameters: negative size");
+    if (ncosmo == 0) return CP_OK;
+    if (!params || !d_out) return cp::fail(CP_EINVAL, "cp_derived_parameters: null pointer");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_derived_parameters: cannot select device %d", device);
+    DerivedArgs A;
+    A.ncosmo = ncosmo;
+    for (int k = 0; k < CP_BG_NPARAMS; ++k) {
+        A.p[k].ptr = params[k].ptr;
+        A.p[k].value = params[k].value;
+    }
+    A.out = d_out;
+    hipLaunchKernelGGL(derived_parameters_kernel, dim3((unsigned)((ncosmo + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_derived_parameters: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

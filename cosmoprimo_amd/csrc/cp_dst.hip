@@ -23,6 +23,7 @@
 #include "cp_fft_core.h"
 #include "cp_fftlog_tables.h"
 #include "cp_math.h"
+#include "cp_power_eval.h"
 
 namespace {
 
@@ -274,6 +275,130 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     }
 }
 
+// ---- forward transform of log(k P_c(k)) with the spectra of an analytic engine EVALUATED in the kernel (wallish2018 on a batch of cosmologies,
+// bao_filter.py:371 behind eisenstein_hu.py:315-324): the evaluation (~400 fp64 instructions per sample, vector-ALU bound) and the transform
+// (16 N bytes of LDS / HBM traffic per row, memory bound) were two launches with 4096 doubles per vector written and read between them; here a
+// workgroup evaluates the 2 x 4096 samples of a pair of cosmologies straight into the transform's input (Makhoul order, (-1)^n folded in) and the
+// chip sees both kinds of work at once, as in the fused sigma(r, z) kernel (cp_sigma.hip).  The arithmetic of a sample is power_kernel's
+// CP_PK_LOG_K_MATTER (cp_power.hip), term by term, on the tabulated log k: the same bits.
+struct GenArgs {
+    Args dst;                        // out, tw, rot, split; in / kx / fused unused
+    long long ncosmo;
+    cpcosmo::Param bg[CP_BG_NPARAMS];
+    cpcosmo::Param pw[CP_PK_NPARAMS];
+    int second_is_omega_m;
+    const double* k;                 // (N) wavenumbers, h/Mpc
+    const double* ln_k;              // (N) their logarithms (log_pos, as power_kernel takes them)
+    const cppower::EhScalars* scal;  // (ncosmo) fit coefficients (cp_power_coefficients), unused for BBKS
+};
+
+#ifndef CP_DST_GEN_ILP
+#define CP_DST_GEN_ILP 2
+#endif
+
+__global__ void dst_log_kernel(const double* k, double* ln_k, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ln_k[i] = cpmath::log_pos(k[i]);
+}
+
+// log(k P(k)) of cosmology ic at the thread's P samples m = t + T r of the reordered sequence, into the thread's own slots of the data region
+// (double index 2 (t + T r) + row).  NOT unrolled: sixteen copies of a 400-instruction evaluation would not fit the instruction cache.
+template <int N, int P, int ENGINE>
+__device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int t, double* slots) {
+    using namespace cppower;
+    constexpr int T = N / P;
+    const Cosmo c = load_cosmo(G.bg, ic, G.second_is_omega_m);
+    double pw[CP_PK_NPARAMS];
+#pragma unroll
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = G.pw[i].ptr ? G.pw[i].ptr[ic] : G.pw[i].value;
+    EhScalars s{};
+    if (ENGINE != CP_ENGINE_BBKS) s = G.scal[ic];
+    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
+    const PkPerCosmology pc = pk_per_cosmology(c, pw);
+    const double ln_pk_unit = log(pc.pk_unit);
+    // CP_DST_GEN_ILP samples per iteration: independent chains of logarithms / exponentials / reciprocals for the two waves of a SIMD to interleave
+#pragma unroll 1
+    for (int r0 = 0; r0 < P; r0 += CP_DST_GEN_ILP) {
+#pragma unroll
+        for (int u = 0; u < CP_DST_GEN_ILP; ++u) {
+            const int m = t + T * (r0 + u);
+            const int n = m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1;
+            const double kh = G.k[n], ln_kh = G.ln_k[n];
+            double Tk;
+            if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
+            slots[2 * m] = 2. * (ln_kh + log_pos(fabs(Tk))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
+        }
+    }
+}
+
+template <int N, int P, int ENGINE>
+__global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G) {
+    using PL = Plan<N, P>;
+    constexpr int T = PL::T;
+    const Args& A = G.dst;
+    extern __shared__ __attribute__((aligned(4096))) char smem[];
+    cplx* lds = reinterpret_cast<cplx*>(smem);
+    cplx* ltw = lds + lds_data_slots(N, P);
+    const int t = threadIdx.x;
+    for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = A.tw[N + i];
+    const long long npairs = (G.ncosmo + 1) / 2;
+    const double fn = sqrt(2. / N), fl = sqrt(1. / N);
+    __shared__ int bad_row[2];
+    const double nan = __builtin_nan("");
+    static_assert(!padded_lds(N, P), "the generated samples go through natural-order slots of the data region");
+    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const bool has_b = 2 * p + 1 < G.ncosmo;
+        double* oa = A.out + 2 * p * N;
+        double* ob = has_b ? oa + N : oa;
+        auto at = [&](int j) { return A.split ? ((j & 1) * (N / 2) + (j >> 1)) : j; };
+        if (t == 0) bad_row[0] = bad_row[1] = 0;
+        __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
+        double* slots = reinterpret_cast<double*>(lds);
+        generate_row<N, P, ENGINE>(G, 2 * p, t, slots);
+        if (has_b) generate_row<N, P, ENGINE>(G, 2 * p + 1, t, slots + 1);
+        cplx x[P];
+        bool bad_a = false, bad_b = false;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {      // the thread's own slots: no barrier
+            const int m = t + T * r;
+            const bool lower = m < N / 2;
+            const double a = slots[2 * m], b = has_b ? slots[2 * m + 1] : 0.;
+            bad_a |= !(fabs(a) <= 1.7976931348623157e308);
+            bad_b |= !(fabs(b) <= 1.7976931348623157e308);
+            x[r].re = lower ? a : -a;
+            x[r].im = lower ? b : -b;
+        }
+        if (bad_a) bad_row[0] = 1;
+        if (bad_b) bad_row[1] = 1;
+        __syncthreads();      // flags published; every thread has read its slots before the first pass overwrites the region
+        const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
+        if (skip_a | skip_b) {
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                if (skip_a) x[r].re = 0.;
+                if (skip_b) x[r].im = 0.;
+            }
+        }
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        dif_all<N, P>(tt, A, x, lds, ltw);
+        asm volatile("" : "+v"(tt));
+#pragma unroll 4
+        for (int s = 0; s < P; ++s) {
+            const int k = tt + T * s;
+            const cplx v = lds_at<N, P>(lds, pos_of_freq<N, P>(k));
+            const cplx u = lds_at<N, P>(lds, pos_of_freq<N, P>((N - k) % N));
+            const cplx rot = A.rot[k];
+            const double f = k == 0 ? fl : fn;
+            const double ya = 0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im));
+            const double yb = 0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re));
+            oa[at(N - 1 - k)] = skip_a ? nan : f * ya;
+            if (has_b) ob[at(N - 1 - k)] = skip_b ? nan : f * yb;
+        }
+    }
+}
+
 template <int N>
 void launch(bool inverse, const Args& A, int grid, hipStream_t stream) {
     constexpr int P = 16, T = N / P;
@@ -293,6 +418,7 @@ struct cp_dst_plan {
     cplx* d_tw;
     cplx* d_rot;
     double* d_kx;
+    double* d_ln_kx;      // log of the abscissa, filled at the first cp_dst_forward_analytic (device kernel: the bits of power_kernel's own logarithm)
 };
 
 extern "C" int cp_dst_plan_destroy(cp_dst_plan* p) {
@@ -303,6 +429,7 @@ extern "C" int cp_dst_plan_destroy(cp_dst_plan* p) {
     if (p->d_tw) (void)hipFree(p->d_tw);
     if (p->d_rot) (void)hipFree(p->d_rot);
     if (p->d_kx) (void)hipFree(p->d_kx);
+    if (p->d_ln_kx) (void)hipFree(p->d_ln_kx);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     delete p;
     return CP_OK;
@@ -319,17 +446,21 @@ extern "C" int cp_dst_plan_create(cp_dst_plan** out, int n, const double* kx, in
     for (int k = 0; k < n; ++k) rot[k] = unit_root(k, 4LL * n);  // e^{-2 pi i k / 4N} = e^{-i pi k / 2N}
     cp_dst_plan* p = new (std::nothrow) cp_dst_plan();
     if (!p) return cp::fail(CP_ENOMEM, "cp_dst_plan_create: host allocation failed");
-    p->n = n; p->device = device; p->d_tw = nullptr; p->d_rot = nullptr; p->d_kx = nullptr;
+    p->n = n; p->device = device; p->d_tw = nullptr; p->d_rot = nullptr; p->d_kx = nullptr; p->d_ln_kx = nullptr;
     int prev = -1, status = CP_OK;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: cannot select device %d", device);
     if (status == CP_OK && (hipMalloc(&p->d_tw, tw.size() * sizeof(cplx)) != hipSuccess || hipMalloc(&p->d_rot, n * sizeof(cplx)) != hipSuccess ||
-                            (kx && hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess)))
+                            (kx && (hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ln_kx, n * sizeof(double)) != hipSuccess))))
         status = cp::fail(CP_ENOMEM, "cp_dst_plan_create: device allocation failed");
     if (status == CP_OK && (hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(p->d_rot, rot.data(), n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
                             (kx && hipMemcpy(p->d_kx, kx, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)))
         status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: upload failed");
+    if (status == CP_OK && kx) {      // log of the abscissa with the kernels' own logarithm (default stream, then waited for: plan creation is synchronous)
+        hipLaunchKernelGGL(dst_log_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, p->d_kx, p->d_ln_kx, n);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: cannot tabulate log k");
+    }
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (status != CP_OK) {
         cp_dst_plan_destroy(p);
@@ -361,5 +492,61 @@ extern "C" int cp_dst_execute(const cp_dst_plan* p, const double* d_in, double* 
     hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_execute: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+namespace {
+
+template <int ENGINE>
+void launch_generate(const GenArgs& G, int grid, hipStream_t stream) {
+    constexpr int N = 4096, P = 16, T = N / P;
+    constexpr int lds = (lds_data_slots(N, P) + Plan<N, P>::TW_TOTAL - N) * (int)sizeof(cplx);
+    (void)cp::allow_full_lds<&dst_generate_kernel<N, P, ENGINE>>();
+    hipLaunchKernelGGL((dst_generate_kernel<N, P, ENGINE>), dim3(grid), dim3(T), lds, stream, G);
+}
+
+}  // namespace
+
+extern "C" long long cp_dst_forward_analytic_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : cp_power_workspace_bytes(ncosmo) + 64; }
+
+extern "C" int cp_dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
+                                       const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: null plan");
+    if (flags & ~CP_DST_SPLIT) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: unknown flags %d", flags);
+    if (p->n != 4096 || !p->d_kx) return cp::fail(CP_EUNSUPPORTED, "cp_dst_forward_analytic: needs a plan of length 4096 made with its abscissa (wallish2018's linear grid)");
+    if (engine != CP_ENGINE_EH && engine != CP_ENGINE_EH_NOWIGGLE && engine != CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: unknown engine %d", engine);
+    if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: negative batch");
+    if (ncosmo == 0) return CP_OK;
+    if (!bg_params || !pk_params || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: null pointer");
+    char* coef = static_cast<char*>(d_work);
+    coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, coef, p->device, stream);
+    if (st != CP_OK) return st;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_forward_analytic: cannot select device %d", p->device);
+    GenArgs G{};
+    G.dst.in = nullptr; G.dst.out = d_out; G.dst.nrows = ncosmo; G.dst.tw = p->d_tw; G.dst.rot = p->d_rot; G.dst.kx = nullptr; G.dst.fused = 0;
+    G.dst.split = (flags & CP_DST_SPLIT) != 0;
+    G.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) G.bg[i] = cpcosmo::Param{bg_params[i].ptr, bg_params[i].value};
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) G.pw[i] = cpcosmo::Param{pk_params[i].ptr, pk_params[i].value};
+    G.second_is_omega_m = second_is_omega_m;
+    G.k = p->d_kx;
+    G.ln_k = p->d_ln_kx;
+    G.scal = reinterpret_cast<const cppower::EhScalars*>(coef);
+    const long long npairs = (ncosmo + 1) / 2;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;
+    // two workgroups per CU are resident (LDS): every workgroup the same number of pairs
+    const long long resident = 2LL * ncu, rounds = (npairs + resident - 1) / resident;
+    const int grid = (int)((npairs + rounds - 1) / rounds);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (engine == CP_ENGINE_EH) launch_generate<CP_ENGINE_EH>(G, grid, s);
+    else if (engine == CP_ENGINE_EH_NOWIGGLE) launch_generate<CP_ENGINE_EH_NOWIGGLE>(G, grid, s);
+    else launch_generate<CP_ENGINE_BBKS>(G, grid, s);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_forward_analytic: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }

@@ -717,7 +717,58 @@ struct FunctionalArgs {
     const double* growth_sq;      // (ncosmo, nz)
     double* out;                  // (ncosmo, nq, nz)
     double* pk_out;               // (ncosmo, nk) or null
+    // the sigma8 normalisation (sigma8_normalise_kernel): target sigma8, factors sigma8 / sigma8(fiducial amplitude) and normalised amplitudes out
+    Param target;
+    double* rsigma8_out;          // (ncosmo)
+    double* amplitude_out;        // (ncosmo) A_s x rsigma8^2, or null
 };
+
+// The sigma8 normalisation of a batch of analytic cosmologies as ONE kernel (eisenstein_hu.py:94-103 with :331-342, cosmology.py:505-510): sigma8 of
+// the fiducial amplitude -- P(k) x the functional of r = 8, x the CPT92 growth factor at z = 0 squared (Background.growth_factor(0, znorm=0),
+// eisenstein_hu.py:134-139), evaluated here instead of by a launch of the background kernel --, the factor rsigma8 = sigma8 / that, the normalised
+// amplitude A_s rsigma8^2, and the spectra at the NORMALISED amplitude (P is linear in A_s): what the engine hands to the filters next, with no
+// pass over (ncosmo, 1024) arrays behind the kernel.  1024 wavenumbers: a lane keeps its 16 samples in registers until the factor is known.
+template <int ENGINE>
+__global__ __launch_bounds__(256) void sigma8_normalise_kernel(const FunctionalArgs S) {
+    constexpr int PER_LANE = 16;      // nk = 1024
+    const int lane = threadIdx.x & 63;
+    const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ic >= S.ncosmo) return;
+    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m);
+    double pw[CP_PK_NPARAMS];
+#pragma unroll
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
+    EhScalars s{};
+    if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
+    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
+    const PkPerCosmology pc = pk_per_cosmology(c, pw);
+    double acc = 0.;
+    double pks[PER_LANE];
+#pragma unroll 2
+    for (int i = 0; i < PER_LANE; ++i) {
+        const int j = lane + 64 * i;
+        const double kh = S.k[j], ln_kh = S.ln_k[j];
+        double Tk;
+        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
+        pks[i] = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh);
+        acc = fma(S.functional[j], pks[i], acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    const double g0 = growth_cpt(c, 0.);
+    const double sigma8_fid = sqrt(acc) * sqrt(g0 * g0);      // (the product of roots of the fused kernels: sqrt(sigma^2) sqrt(growth^2))
+    const double target = S.target.ptr ? S.target.ptr[ic] : S.target.value;
+    const double rs = target / sigma8_fid, rs2 = rs * rs;
+    if (lane == 0) {
+        S.rsigma8_out[ic] = rs;
+        if (S.amplitude_out) S.amplitude_out[ic] = pw[CP_PK_A_S] * rs2;
+    }
+    if (S.pk_out) {
+#pragma unroll
+        for (int i = 0; i < PER_LANE; ++i) S.pk_out[ic * 1024 + lane + 64 * i] = pks[i] * rs2;
+    }
+}
 
 template <int ENGINE>
 __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalArgs S) {
@@ -800,6 +851,48 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     const hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_functional: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+                                   const double* d_k, const double* d_functional, cp_param sigma8, double* d_rsigma8, double* d_amplitude, double* d_pk_out,
+                                   void* d_work, int device, void* stream) {
+    if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_sigma8_normalise: negative size");
+    if (nk != 1024) return cp::fail(CP_EUNSUPPORTED, "cp_sigma8_normalise: %d wavenumbers (built for the 1024 of the default transform)", nk);
+    if (engine != CP_ENGINE_EH && engine != CP_ENGINE_EH_NOWIGGLE && engine != CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_sigma8_normalise: unknown engine %d", engine);
+    if (ncosmo == 0) return CP_OK;
+    if (!bg_params || !pk_params || !d_k || !d_functional || !d_rsigma8 || !d_work) return cp::fail(CP_EINVAL, "cp_sigma8_normalise: null pointer");
+    char* coef = static_cast<char*>(d_work);
+    coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, coef, device, stream);
+    if (st != CP_OK) return st;
+    FunctionalArgs S{};
+    S.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) S.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) S.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};
+    S.second_is_omega_m = second_is_omega_m;
+    S.nk = nk; S.nq = 1; S.nz = 1;
+    S.k = d_k;
+    S.scal = reinterpret_cast<const EhScalars*>(coef);
+    double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
+    S.ln_k = ln_k;
+    S.functional = d_functional;
+    S.pk_out = d_pk_out;
+    S.target = Param{sigma8.ptr, sigma8.value};
+    S.rsigma8_out = d_rsigma8;
+    S.amplitude_out = d_amplitude;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma8_normalise: cannot select device %d", device);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(log_wavenumbers_kernel, dim3((nk + 255) / 256), dim3(256), 0, hs, d_k, ln_k, nk);
+    const unsigned grid = (unsigned)((ncosmo + 3) / 4);
+    if (engine == CP_ENGINE_EH) hipLaunchKernelGGL(sigma8_normalise_kernel<CP_ENGINE_EH>, dim3(grid), dim3(256), 0, hs, S);
+    else if (engine == CP_ENGINE_EH_NOWIGGLE) hipLaunchKernelGGL(sigma8_normalise_kernel<CP_ENGINE_EH_NOWIGGLE>, dim3(grid), dim3(256), 0, hs, S);
+    else hipLaunchKernelGGL(sigma8_normalise_kernel<CP_ENGINE_BBKS>, dim3(grid), dim3(256), 0, hs, S);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma8_normalise: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
 

@@ -40,6 +40,27 @@ class DST(object):
                                                   dv.stream_of(self.device)))
         return out
 
+    def forward_analytic(self, engine, bg, pk, split=False):
+        """dst(log(kx P_c(kx))) of a batch of cosmologies of an analytic engine with the spectra evaluated inside the transform kernel
+        (``cp_dst_forward_analytic``): (ncosmo, n), or None when the parameters are not a batch or the plan is not wallish2018's (n = 4096 with kx)."""
+        torch = dv.torch()
+        from .background import DEFAULTS as bg_defaults
+        from .power import PK_DEFAULTS
+        if self.n != 4096 or engine not in _lib.ENGINES:
+            return None
+        cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, self.device)
+        cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, self.device)
+        sizes = {n for n in (n1, n2) if n is not None}
+        if len(sizes) != 1:
+            return None
+        ncosmo = sizes.pop()
+        lib = _lib.load()
+        out = torch.empty((ncosmo, self.n), dtype=torch.float64, device=self.device)
+        work = torch.empty(int(lib.cp_dst_forward_analytic_workspace_bytes(ncosmo)), dtype=torch.uint8, device=self.device)
+        _lib.check(lib.cp_dst_forward_analytic(self._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), out.data_ptr(), work.data_ptr(),
+                                               2 if split else 0, dv.stream_of(self.device)))
+        return out
+
     def __del__(self):
         try:
             if self._handle:

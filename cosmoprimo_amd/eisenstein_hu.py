@@ -141,6 +141,9 @@ class Fourier(BaseSection):
         if kscale is None and e.batch_size is not None and not dv.is_torch(kh) and np.size(kh) <= 2048 and (rs is None or dv.is_torch(rs) or rs == 1.):
             kh = np.asarray(kh, dtype='f8')
             key = (kh.shape, kh.tobytes())
+            ready = e.__dict__.get('_pk0_normalised')      # left by the sigma8 normalisation kernel: these wavenumbers at the normalised amplitude
+            if ready is not None and ready[0] == key and ready[1] is rs:
+                return ready[2]
             held = e.__dict__.get('_pk0_fiducial')
             if held is None or held[0] != key:
                 unit = pwmod.analytic(e._transfer, 'matter', kh, bg=e.bg_params(), pk=e.pk_params(rsigma8=1.), device=self.device)
@@ -185,7 +188,12 @@ class Fourier(BaseSection):
 
         interp = PowerSpectrumInterpolator2D.from_callable(pk_callable=pk_callable, growth_factor_sq=growth_factor_sq, device=device, **kwargs)
         # batched cosmologies: P_c(k * kscale_c) in one launch (used by the brieden2022 filter, one rs_drag ratio per cosmology)
-        interp._pk_scaled = lambda k, kscale: self._pk0_device(np.asarray(k, dtype='f8'), kscale=kscale) * interp._rsigma8sq
+        def pk_scaled(k, kscale):
+            rows = self._pk0_device(np.asarray(k, dtype='f8'), kscale=kscale)
+            rs = interp._rsigma8sq
+            return rows if isinstance(rs, float) and rs == 1. else rows * rs      # (no pass over the batch for a factor of one)
+
+        interp._pk_scaled = pk_scaled
         return interp
 
     def sigma_rz(self, r, z, of='delta_m', **kwargs):

@@ -1003,6 +1003,48 @@ def sigma_rz_analytic(engine, bg, pk, r, growth_sq, device, kmin=1e-7, kmax=1e2,
     return out, spectra, k
 
 
+def sigma8_normalise(engine, bg, pk, sigma8, device, kmin=1e-7, kmax=1e2):
+    """``cp_sigma8_normalise``: the sigma8 normalisation of a batch of cosmologies of an analytic engine in one kernel (reference
+    eisenstein_hu.py:94-103, 331-342).  ``pk`` carries the first-guess amplitudes; ``sigma8`` a float or a (batch,) device tensor.  Returns
+    (rsigma8 (batch,), A_s rsigma8^2 (batch,), spectra without growth at the normalised amplitude (batch, 1024), their wavenumbers), or None when
+    the parameters are not a batch."""
+    torch = dv.torch()
+    from .background import DEFAULTS as bg_defaults
+    from .power import PK_DEFAULTS
+    cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, device)
+    cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, device)
+    sizes = {n for n in (n1, n2) if n is not None}
+    if len(sizes) != 1:
+        return None
+    nb, nk = sizes.pop(), 1024
+    k = np.geomspace(kmin, kmax, nk)
+    key = (float(kmin), float(kmax), nk, device.index)
+    if key not in _tophat_cache:
+        _tophat_cache[key] = TophatVariance(k, device=device)
+    fft = _tophat_cache[key]
+    s, rr = fft.y[0], np.array([8.])
+    op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
+    functional = _cached_operator(('sigma_functional', key, rr.tobytes()),
+                                  lambda: op(fft(torch.eye(nk, dtype=torch.float64, device=device))[1]).transpose(0, 1).contiguous())
+    target = _lib.cp_param()
+    if (dv.is_torch(sigma8) and sigma8.ndim) or (not dv.is_torch(sigma8) and np.ndim(sigma8)):
+        st = dv.to_device(sigma8, device, cache=False).reshape(-1)
+        if st.numel() != nb:
+            return None
+        target.ptr, target.value = st.data_ptr(), 0.
+    else:
+        target.ptr, target.value = None, float(sigma8)
+    lib = _lib.load()
+    rsigma8 = torch.empty(nb, dtype=torch.float64, device=device)
+    amplitude = torch.empty(nb, dtype=torch.float64, device=device)
+    spectra = torch.empty((nb, nk), dtype=torch.float64, device=device)
+    work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(nb, nk)), dtype=torch.uint8, device=device)
+    _lib.check(lib.cp_sigma8_normalise(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
+                                       functional.data_ptr(), target, rsigma8.data_ptr(), amplitude.data_ptr(), spectra.data_ptr(), work.data_ptr(),
+                                       device.index, dv.stream_of(device)))
+    return rsigma8, amplitude, spectra, k
+
+
 class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
 
     """2D power spectrum interpolator with ``sigma_rz``, ``sigma_dz``, ``to_1d``, ``to_xi`` (reference interpolator.py:609-987)."""

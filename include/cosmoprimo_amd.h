@@ -157,6 +157,16 @@ typedef struct cp_param {
  * (Mpc/h for distances).  z outside [0, 9999] gives NaN as in the reference.  Asynchronous on `stream` of `device`. */
 int cp_background_distance(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const double* d_z, int z_shared,
                            double* d_out, int kind, int device, void* stream);
+/* Derived parameters of a batch of cosmologies without massive species (BaseCosmoParams._get_derived, cosmology.py:331-415: Omega_g from T_cmb,
+ * Omega_ur from N_ur, Omega_r, Omega_m, Omega_de by closure, the omega_x = Omega_x h^2, H0, K), one lane per cosmology.
+ * params: the CP_BG_NPARAMS background parameters; d_out: (CP_DERIVED_NVALUES, ncosmo), one contiguous row per value. */
+enum cp_derived_value {
+    CP_DERIVED_H2 = 0, CP_DERIVED_H0 = 1, CP_DERIVED_OMEGA_G = 2, CP_DERIVED_T_UR = 3, CP_DERIVED_OMEGA_UR = 4, CP_DERIVED_OMEGA_R = 5,
+    CP_DERIVED_OMEGA_M = 6, CP_DERIVED_OMEGA_DE = 7, CP_DERIVED_K = 8, CP_DERIVED_LITTLE_OMEGA_B = 9, CP_DERIVED_LITTLE_OMEGA_CDM = 10,
+    CP_DERIVED_LITTLE_OMEGA_M = 11, CP_DERIVED_LITTLE_OMEGA_G = 12, CP_DERIVED_LITTLE_OMEGA_UR = 13, CP_DERIVED_LITTLE_OMEGA_R = 14,
+    CP_DERIVED_LITTLE_OMEGA_K = 15, CP_DERIVED_LITTLE_OMEGA_DE = 16, CP_DERIVED_NVALUES = 17
+};
+int cp_derived_parameters(long long ncosmo, const cp_param* params, double* d_out, int device, void* stream);
 /* the 119 interpolation knots (host), get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949 (n = 119),
  * or the 400 knots of time / age, cosmology.py:1945-1946 (n = 400) */
 int cp_background_knots(double* zc_out, int n);
@@ -328,6 +338,14 @@ int cp_geospline_plan_destroy(cp_geospline_plan* plan);
 int cp_geospline_plan_info(const cp_geospline_plan* plan, int* first_knot, int* nknots, int* nq);
 int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const cp_geospline_plan* spline, const double* d_in, double* d_out, long long nbatch,
                                 int group, int post_op, void* stream);
+/* The sigma8 normalisation of a batch of analytic cosmologies (BaseEngine._rescale_sigma8: eisenstein_hu.py:94-103 with Fourier.sigma8_m :331-342) as
+ * one kernel: sigma8 at the amplitudes pk_params carry (the reference's first guess _get_A_s_fid, cosmology.py:505-510) from the spectra, the
+ * functional d_functional (1, nk) of r = 8 (what transform + spline return for unit spectra: cp_sigma_rz_functional) and the CPT92 growth factor
+ * at z = 0; then d_rsigma8[c] = sigma8 / that, d_amplitude[c] = A_s rsigma8^2 (or NULL) and d_pk_out (ncosmo, nk) = the spectra WITHOUT growth at
+ * the normalised amplitude (or NULL).  sigma8: one target for all (ptr NULL) or per cosmology.  nk = 1024; d_work as for cp_sigma_rz_functional. */
+int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+                        const double* d_k, const double* d_functional, cp_param sigma8, double* d_rsigma8, double* d_amplitude, double* d_pk_out,
+                        void* d_work, int device, void* stream);
 long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk);
 int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
                          const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
@@ -448,6 +466,14 @@ int cp_dst_plan_create(cp_dst_plan** plan, int n, const double* kx, int device);
 #define CP_DST_SPLIT 2
 int cp_dst_execute(const cp_dst_plan* plan, const double* d_in, double* d_out, long long nrows, int inverse, int flags, void* stream);
 int cp_dst_plan_destroy(cp_dst_plan* plan);
+/* Forward transform (inverse = 0) of the rows log(kx_n P_c(kx_n)), c < ncosmo, with P_c the spectrum WITHOUT growth of cosmology c of an analytic
+ * engine (cp_engine; bg_params / pk_params as for cp_power_eval) evaluated inside the kernel: wallish2018 on a batch of cosmologies
+ * (bao_filter.py:371 behind eisenstein_hu.py:315-324) without the (ncosmo, 4096) rows of cp_power_eval(CP_PK_LOG_K_MATTER) in between -- same
+ * arithmetic per sample.  Plans of length 4096 made with their abscissa kx; flags: CP_DST_SPLIT.  d_out: (ncosmo, 4096).
+ * d_work: cp_dst_forward_analytic_workspace_bytes(ncosmo) bytes, free again once the call's kernels have run on `stream`. */
+long long cp_dst_forward_analytic_workspace_bytes(long long ncosmo);
+int cp_dst_forward_analytic(const cp_dst_plan* plan, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
+                            const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream);
 
 /* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
  * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];

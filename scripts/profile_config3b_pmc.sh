@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage (on the GPU box, from the repo root): bash scripts/profile_config3b_pmc.sh <tag>
 # Config 3B (10 000 tabulated P(k, z) -> sigma_rz) under rocprofv3: kernel trace, then HBM bytes per kernel from FETCH_SIZE and WRITE_SIZE in
-# separate passes (program directly after `--`), with the calibration copies of the same session; summary: profiles/<tag>_config3b_pmc_summary.json
+# separate passes (program directly after `--`), with the calibration copies of the same session; summary: profiles/<tag>_config3b_traffic.json
 tag=${1:-r4}
 R=$PWD
 out=$R/gpurun_out/prof3b_$tag

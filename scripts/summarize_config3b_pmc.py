@@ -1,4 +1,4 @@
-"""gpurun_out/prof3b_<tag>/ (scripts/profile_config3b_pmc.sh) -> profiles/<tag>_config3b_kernel_stats.csv and profiles/<tag>_config3b_pmc_summary.json:
+"""gpurun_out/prof3b_<tag>/ (scripts/profile_config3b_pmc.sh) -> profiles/<tag>_config3b_kernel_stats.csv and profiles/<tag>_config3b_traffic.json:
 HBM bytes per sigma_rz call of config 3B, kernel by kernel, next to the algorithmic bytes.   python scripts/summarize_config3b_pmc.py <tag>"""
 import collections
 import csv
@@ -56,5 +56,5 @@ out = {'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --o
                                'fetch': cal_f, 'write': cal_w},
        'kernels_per_call': per_call, 'kernels_per_table_set': {k: v for k, v in kernels.items() if k not in per_call},
        'hbm_bytes_per_call': total, 'algorithmic_bytes_per_call': ALGORITHMIC, 'traffic_over_algorithmic': total / ALGORITHMIC}
-json.dump(out, open('profiles/%s_config3b_pmc_summary.json' % tag, 'w'), indent=1)
+json.dump(out, open('profiles/%s_config3b_traffic.json' % tag, 'w'), indent=1)
 print(json.dumps({k: out[k] for k in ('kernels_per_call', 'hbm_bytes_per_call', 'traffic_over_algorithmic')}, indent=1))

@@ -88,3 +88,37 @@ def test_rows_screen():
     big[69999, 3] = float('nan')
     ok = dv.screen_rows(big)
     assert bool(ok[:69999].all()) and not bool(ok[69999])
+
+
+@pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
+def test_forward_transform_that_evaluates_the_spectra(engine):
+    """cp_dst_forward_analytic (log(k P_c(k)) of a batch of analytic cosmologies evaluated inside the transform kernel) against the two launches it
+    replaces (cp_power_eval CP_PK_LOG_K_MATTER, then cp_dst_execute) and, through them, scipy: odd batches (a cosmology without a partner), both
+    coefficient layouts, a cosmology whose parameters give NaN next to good ones."""
+    import torch
+    from cosmoprimo_amd import power
+    from cosmoprimo_amd.dst import DST
+    dev = torch.device('cuda', 0)
+    klin = np.linspace(1e-4, 5., 4096)
+    dst = DST(4096, kx=klin, device=dev)
+    for n in (1, 2, 7, 130):
+        rng = np.random.default_rng(n)
+        Om, Ob, h, ns = rng.uniform(.25, .40, n), rng.uniform(.04, .06, n), rng.uniform(.6, .8, n), rng.uniform(.92, 1., n)
+        if n == 7:
+            ns[4] = np.nan
+        bg = dict(h=torch.as_tensor(h, device=dev), Omega_cdm=torch.as_tensor(Om - Ob, device=dev), Omega_b=torch.as_tensor(Ob, device=dev))
+        pk = dict(n_s=torch.as_tensor(ns, device=dev), A_s=torch.as_tensor(rng.uniform(1.8e-9, 2.4e-9, n), device=dev))
+        rows = power.analytic(engine, 'log_k_matter', klin, bg=bg, pk=pk, device=dev).reshape(n, 4096)
+        for split in (False, True):
+            ref = dst(rows, split=split).cpu().numpy()
+            got = dst.forward_analytic(engine, bg, pk, split=split)
+            assert got is not None and got.shape == (n, 4096)
+            got = got.cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            if n == 7:
+                assert np.isnan(got[4]).all() and np.isfinite(np.delete(got, 4, axis=0)).all()
+            scale = np.abs(ref[np.isfinite(ref).all(axis=1)]).max(axis=1, keepdims=True)
+            assert np.abs((got - ref)[np.isfinite(ref).all(axis=1)] / scale).max() < 1e-14
+        host = fftpack.dst(rows[:1].cpu().numpy(), type=2, axis=-1, norm='ortho')
+        np.testing.assert_allclose(dst.forward_analytic(engine, bg, pk)[:1].cpu().numpy(), host, rtol=0, atol=1e-12 * np.abs(host).max())
+    assert DST(1024, kx=np.linspace(1e-4, 5., 1024), device=dev).forward_analytic(engine, bg, pk) is None

@@ -14,6 +14,8 @@ for r in csv.DictReader(open(f)):
 n = 1250000
 out = {k: sum(v) / len(v) / n for k, v in acc.items()}
 print(json.dumps({'samples_per_launch': n, 'per_sample': out, 'launches': {k: len(v) for k, v in acc.items()}}, indent=1))
-json.dump({'what': 'wave-instructions of bg_kernel<119, false, false> per (Omega_m, w0, wa, z) sample of config 5: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -- python3 tools/profile_secondary.py 5 (tools/census_config5.sh), mean over the launches of the run / 1 250 000 samples; multiply by 64 lanes for per-thread counts', 'samples_per_launch': n, 'per_sample': out}, open('$OUT/config5_valu.json', 'w'), indent=1)
+import hashlib
+lib = hashlib.sha256(open('$GRAFT_REPO_ROOT/cosmoprimo_amd/libcosmoprimo_amd.so', 'rb').read()).hexdigest()[:16]
+json.dump({'library_sha256_16': lib, 'what': 'wave-instructions of bg_kernel<119, false, false> per (Omega_m, w0, wa, z) sample of config 5: rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -- python3 tools/profile_secondary.py 5 (tools/census_config5.sh), mean over the launches of the run / 1 250 000 samples; multiply by 64 lanes for per-thread counts', 'samples_per_launch': n, 'per_sample': out}, open('$OUT/config5_valu.json', 'w'), indent=1)
 PY
 tail -1 $OUT/log.txt | cut -c1-400

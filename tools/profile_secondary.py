@@ -1,6 +1,6 @@
 """One of the secondary configs of bench.py on its own, for a kernel trace (development aid):
     rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c3 -- python3 tools/profile_secondary.py 3
-Configs: 3, 3b, 4 (both filters, one 16 384-vector chunk timed 4 times), 5."""
+Configs: 3, 3b, 4 (both filters, chunks of bench.CONFIG4_CHUNK vectors), 4w / 4b (one filter, for counter collection), 5."""
 import json
 import os
 import sys
@@ -21,11 +21,13 @@ def main():
         out = bench.config3b(cp, torch, dev, reps=10)
     elif which in ('4w', '4b'):      # one filter only (counter collection per filter)
         engine = 'wallish2018' if which == '4w' else 'brieden2022'
-        bench.RAMP_S = 0.      # one untimed chunk, then the four timed ones: 5 x 16 384 vectors go through the filter in this process
-        out = bench.config4(cp, torch, dev, bench.eh_parameters(4 * 16384, 2, torch, dev), engines=(engine,))
-        out['vectors_through_the_filter_in_this_process'] = 5 * 16384
+        bench.RAMP_S = 0.      # one untimed chunk, then the timed ones
+        n = 2 * bench.CONFIG4_CHUNK
+        out = bench.config4(cp, torch, dev, bench.eh_parameters(n, 2, torch, dev), engines=(engine,), spot_check=False)
+        out['vectors_through_the_filter_in_this_process'] = bench.CONFIG4_CHUNK + n
+        out['chunk'] = bench.CONFIG4_CHUNK
     elif which == '4':
-        out = bench.config4(cp, torch, dev, bench.eh_parameters(4 * 16384, 2, torch, dev))
+        out = bench.config4(cp, torch, dev, bench.eh_parameters(2 * bench.CONFIG4_CHUNK, 2, torch, dev))
     else:
         out = bench.config5(torch, dev, *bench.config5_samples(1250000, 3, torch, dev), reps=20)
     print(json.dumps(out))
