@@ -55,10 +55,42 @@ bench_line = None
 for line in open(src + '/trace.log'):
     if line.startswith('{'):
         bench_line = json.loads(line)
+
+
+def kernel_resources():
+    """Registers and scratch of the headline kernel from its code object metadata (hipcc -S of the size group it is built in, the Makefile's flags):
+    the profiler's trace columns VGPR_Count / LDS_Block_Size report the allocation granule of the architected half (128) and the STATIC LDS (0: the
+    kernel's 69 920 bytes are dynamic), not what the kernel uses."""
+    import re
+    import subprocess
+    import tempfile
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'cosmoprimo_amd', 'csrc')
+    with tempfile.TemporaryDirectory() as tmp:
+        asm = os.path.join(tmp, 'g3.s')
+        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-mllvm', '-amdgpu-mfma-vgpr-form', '-DCP_INST_GROUP=3', '-S', '--cuda-device-only', '-o', asm,
+               os.path.join(csrc, 'cp_fftlog_inst.hip')]
+        try:
+            subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+        except Exception as exc:      # no compiler here: say so instead of printing the profiler's columns
+            return {'error': 'hipcc -S failed: %s' % exc}
+        text = open(asm).read()
+    # metadata entries: .name: <mangled>, then .vgpr_count / .vgpr_spill_count / .private_segment_fixed_size / .sgpr_count
+    for block in text.split('  - .agpr_count:')[1:]:
+        name = re.search(r'\.name:\s+(\S+)', block)
+        if name and 'fftlog_kernelILi4096ELi16ELi3ELi1E' in name.group(1):
+            get = lambda key: int(re.search(r'\.%s:\s+(\d+)' % key, block).group(1))      # noqa: E731
+            return {'vgpr_count': get('vgpr_count'), 'vgpr_spill_count': get('vgpr_spill_count'), 'sgpr_count': get('sgpr_count'),
+                    'scratch_bytes_per_lane': get('private_segment_fixed_size'), 'static_lds_bytes': get('group_segment_fixed_size'), 'source': 'code object metadata (hipcc -S)'}
+    return {'error': 'kernel not found in the metadata'}
+
+
+resources = kernel_resources()
 out = {
     'command': 'rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary',
     'kernel': 'cpfft::fftlog_kernel<4096, 16, 3, 1>', 'rows_per_launch': ROWS, 'algorithmic_bytes_per_launch': ROWS * BYTES_PER_ROW,
-    'vgpr_count': disp[0][2], 'grid': disp[0][3], 'lds_bytes': disp[0][4],
+    'kernel_resources': resources, 'lds_bytes_dynamic': None if bench_line is None else bench_line['config'].get('lds_bytes'),
+    'grid_threads': disp[0][3], 'profiler_trace_columns': {'VGPR_Count': disp[0][2], 'LDS_Block_Size': disp[0][4],
+                                                           'note': 'allocation granule of the architected registers and static LDS only: not the kernel\'s use'},
     'all_dispatches': summary(disp), 'ramp_first_300ms': summary(ramp), 'steady_state': summary(steady), 'after_an_idle_period_of_the_process': summary(after_idle),
     'same_run_bench_line': None if bench_line is None else {'kernel_ms_hip_events': bench_line['roofline']['kernel_ms'], 'frac': bench_line['roofline']['frac'],
                                                             'ms_per_step': bench_line['ms_per_step'], 'value': bench_line['value']},
