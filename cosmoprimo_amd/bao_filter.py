@@ -750,11 +750,29 @@ class BSplinePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumBAOFi
         if len(models) == 1:
             self._pknow_rows = models[0]
             return
-        w = dv.upload(self._constraint_weights, self.device)                       # (nc, nk)
-        rows = [[torch.ones_like(pk[:, 0])] * len(models)] + [[m @ wc for m in models] for wc in w]       # system[i][j]: (ncol,)
-        rhs = [torch.ones_like(pk[:, 0])] + [pk @ wc for wc in w]
+        # the constraint integrals of every model and of the input, (ncol, nc) each, through the package's dense-operator kernel
+        weigh = _cached_dense_operator(self._constraint_weights, self.device)       # (nc, nk) operator
+        integrals = [weigh(m.contiguous()) for m in models]
+        target = weigh(pk.contiguous())
+        nc = self._constraint_weights.shape[0]
+        rows = [[torch.ones_like(pk[:, 0])] * len(models)] + [[integral[:, c] for integral in integrals] for c in range(nc)]       # system[i][j]: (ncol,)
+        rhs = [torch.ones_like(pk[:, 0])] + [target[:, c] for c in range(nc)]
         coeffs = _solve_small(rows, rhs)
         self._pknow_rows = sum(c[:, None] * m for c, m in zip(coeffs, models))
+
+
+def _cached_dense_operator(weights, device):
+    """:class:`LinearOperator` of a small host matrix, kept by content (the constraint weights of a filter do not change between calls)."""
+    weights = np.ascontiguousarray(weights, dtype='f8')
+    key = (weights.shape, weights.tobytes(), device.index)
+    if key not in _dense_operators:
+        if len(_dense_operators) > 16:
+            _dense_operators.clear()
+        _dense_operators[key] = LinearOperator.dense(weights, device=device)
+    return _dense_operators[key]
+
+
+_dense_operators = {}
 
 
 def _solve_small(a, b):

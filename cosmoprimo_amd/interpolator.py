@@ -770,7 +770,12 @@ class Interpolator2D(dv.Copyable):
         else:
             wx = dv.upload(self._operator('x', xq, dense=True), self.device)   # (nq, nx)
             wy = dv.upload(self._operator('y', yh, dense=True), self.device)   # (nq, ny)
-            out = ((wx @ self._fun) * wy).sum(dim=-1)
+            # sum_i sum_j wx[q, i] f[..., i, j] wy[q, j], one wave per (table, pair) (cp_bilinear_pairs)
+            fun = self._fun.contiguous()
+            nb = int(np.prod(self._lead, dtype=np.int64)) if self._lead else 1
+            out = torch.empty(self._lead + (xq.size,), dtype=torch.float64, device=self.device)
+            _lib.check(_lib.load().cp_bilinear_pairs(wx.data_ptr(), wy.data_ptr(), fun.data_ptr(), out.data_ptr(), nb, xq.size, fun.shape[-2], fun.shape[-1],
+                                                     self.device.index, dv.stream_of(self.device)))
             mask = mask_x & mask_y
         if self.interp_fun == 'log':
             out = 10**out

@@ -478,6 +478,11 @@ int cp_dst_forward_analytic(const cp_dst_plan* plan, int engine, long long ncosm
 /* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
  * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];
  * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */
+/* tensor-product spline at PAIRS of points, RectBivariateSpline(...)(x, y, grid=False) (Interpolator2D, jax.py:241-287):
+ * d_out[b, q] = sum_i sum_j d_wx[q, i] d_f[b, i, j] d_wy[q, j]; d_wx (nq, nx), d_wy (nq, ny): rows of the two 1-D spline operators at the queries,
+ * d_f (nbatch, nx, ny) tables, d_out (nbatch, nq). */
+int cp_bilinear_pairs(const double* d_wx, const double* d_wy, const double* d_f, double* d_out, long long nbatch, int nq, int nx, int ny, int device,
+                      void* stream);
 int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const double* d_x, double* d_out, long long nx, int device, void* stream);
 
 /* ---- cubic splines at many points (replaces Interpolator1D.__call__ = CubicSpline(x, fun)(xq) when there are few splines and 1e6-1e9 queries:
