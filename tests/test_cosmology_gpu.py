@@ -222,3 +222,27 @@ def test_power_extreme_parameters(cp, eng):
         ref_pk = op.pk_z0(k, eng, h=h, Omega_cdm=Om - Ob, Omega_b=Ob, A_s=2e-9, n_s=ns, alpha_s=0.02, beta_s=-0.01)
         # (growth at z = 0 is not 1 for these engines: compare shapes through the ratio to the first wavenumber)
         np.testing.assert_allclose(pk[i] / pk[i][0], ref_pk / ref_pk[0], rtol=1e-9)
+
+
+def test_derived_parameters_of_a_device_batch_in_one_kernel():
+    """cp_derived_parameters: every derived parameter of a batch of cosmologies kept on the device equals what the host formulas give for each
+    cosmology on its own (BaseCosmoParams._derive: reference cosmology.py:331-415), to rounding."""
+    import torch
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import _lib
+    rng = np.random.default_rng(8)
+    n = 7
+    par = dict(Omega_m=rng.uniform(.25, .40, n), Omega_b=rng.uniform(.04, .06, n), h=rng.uniform(.6, .8, n), Omega_k=rng.uniform(-.05, .05, n),
+               T_cmb=rng.uniform(2.6, 2.8, n), w0_fld=rng.uniform(-1.2, -.8, n))
+    batch = cp.Cosmology(**{name: torch.as_tensor(v, device='cuda') for name, v in par.items()})
+    assert batch._device_derived() is not None
+    names = [name for name in _lib.DERIVED_VALUES if not name.startswith('_')] + ['Omega_Lambda', 'Omega_fld', 'omega_b', 'Omega_m', 'Omega_de']
+    for i in range(n):
+        one = cp.Cosmology(**{name: float(v[i]) for name, v in par.items()})
+        for name in names:
+            got = batch[name]
+            got = float(got[i]) if torch.is_tensor(got) and got.ndim else float(got)
+            np.testing.assert_allclose(got, one[name], rtol=4e-15, atol=1e-18, err_msg=name)
+    host = cp.Cosmology(**par)      # numpy arrays stay on the host path
+    assert host._device_derived() is None
+    np.testing.assert_allclose(host['Omega_de'], cp.interpolator._host(batch['Omega_de']), rtol=4e-15)

@@ -269,3 +269,23 @@ def test_2d_spline_degrees():
         np.testing.assert_allclose(got, ref, rtol=1e-10, err_msg=str((ok, oz)))
         sig = cp.PowerSpectrumInterpolator2D(k, z, table, interp_order_k=ok, interp_order_z=oz).sigma8_z(zq)
         np.testing.assert_allclose(sig, cp.PowerSpectrumInterpolator2D(k, z, table).sigma8_z(zq), rtol=5e-3)
+
+
+def test_pairs_kernel_against_numpy():
+    """cp_bilinear_pairs: out[b, q] = sum_ij wx[q, i] f[b, i, j] wy[q, j] against numpy, odd sizes, more than 64 columns, zero and NaN weights."""
+    import torch
+    from cosmoprimo_amd import _lib, _device as dv
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(2)
+    for nb, nq, nx, ny in ((1, 1, 4, 3), (3, 77, 50, 30), (2, 130, 33, 100)):
+        wx, wy, f = rng.normal(size=(nq, nx)), rng.normal(size=(nq, ny)), rng.normal(size=(nb, nx, ny))
+        wx[rng.uniform(size=wx.shape) < 0.7] = 0.
+        if nq > 5:
+            wx[5, 1] = np.nan
+        twx, twy, tf = (torch.as_tensor(v, device=dev) for v in (wx, wy, f))
+        out = torch.empty((nb, nq), dtype=torch.float64, device=dev)
+        _lib.check(_lib.load().cp_bilinear_pairs(twx.data_ptr(), twy.data_ptr(), tf.data_ptr(), out.data_ptr(), nb, nq, nx, ny, 0, dv.stream_of(dev)))
+        ref = np.einsum('qi,bij,qj->bq', wx, f, wy)
+        got = out.cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        np.testing.assert_allclose(got[np.isfinite(ref)], ref[np.isfinite(ref)], rtol=0, atol=1e-13 * np.abs(ref[np.isfinite(ref)]).max())
