@@ -1,10 +1,15 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash scripts/final_profiles.sh <tag>
-# Everything the committed profiles/<tag>_* files come from, in one session: the headline kernel trace + counters (scripts/gpu_profile.sh), the
-# instruction census of config 4 (scripts/profile_config4_valu.sh), the per-kernel statistics of the secondary configs and a plain bench line
-# (scripts/profile_secondary.sh).  Copy gpurun_out/<tag>_* and gpurun_out/prof_<tag>/ summaries into profiles/ afterwards.
-tag=${1:-r3z}
+# Everything the committed profiles/<tag>_* files come from, in one session on one box: the headline kernel trace + counters
+# (scripts/gpu_profile.sh), the HBM traffic of config 3B kernel by kernel (scripts/profile_config3b_pmc.sh), the instruction census of configs 4
+# and 5 (scripts/profile_config4_valu.sh, tools/census_config5.sh), the per-kernel statistics of the secondary configs and a plain bench line
+# (scripts/profile_secondary.sh, scripts/profile_config4.sh).  Afterwards, in the build container: bash scripts/collect_final_profiles.sh <tag>.
+tag=${1:-r4z}
 bash scripts/gpu_profile.sh $tag
-bash scripts/profile_config4_valu.sh $tag
+bash scripts/profile_config3b_pmc.sh $tag > gpurun_out/${tag}_config3b_pmc.log 2>&1
+bash scripts/profile_config4_valu.sh $tag > gpurun_out/${tag}_config4_valu.log 2>&1
+bash tools/census_config5.sh > gpurun_out/${tag}_config5_census.log 2>&1
+cp gpurun_out/census_c5/config5_valu.json gpurun_out/${tag}_config5_valu.json
+bash scripts/profile_config4.sh $tag
 bash scripts/profile_secondary.sh $tag
-ls gpurun_out | head -40
+ls gpurun_out | grep "^${tag}_"
