@@ -137,6 +137,8 @@ SIGNATURES = {
                                       ctypes.c_void_p]),
     'cp_dst_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_dst_forward_analytic_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong]),
+    'cp_dst_forward_analytic_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_dst_forward_analytic': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_spline_operator': (ctypes.c_int, [ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,

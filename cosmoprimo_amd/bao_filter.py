@@ -173,6 +173,10 @@ class BasePowerSpectrumBAOFilter(dv.Copyable, metaclass=RegisteredPowerSpectrumB
         return float(ratio)
 
 
+# ... whose epilogue can also run the second-derivative / box step (cp_dst_forward_analytic_box).  NOT the default: measured on 32 768-vector chunks the
+# transform grows from 2.35 to 3.11 ms for the 0.62 ms of cp_wallish_dd_box it replaces (the solve is a chain of dependent steps: at the two
+# workgroups per CU of the transform it is not hidden, and it holds the transform's registers and LDS while it runs) -- profiles/r4_wallish_box_in_transform.txt
+_TRANSFORM_FINDS_BOXES = False
 _TRANSFORM_EVALUATES_SPECTRA = True      # wallish2018 on batches of analytic cosmologies: cp_dst_forward_analytic (False: evaluation kernel, then transform)
 
 
@@ -269,8 +273,15 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             return None, None
         engine, bg, pk = call.analytic_engine()
         if dst is not None and _TRANSFORM_EVALUATES_SPECTRA:      # a batch of cosmologies: the transform kernel evaluates the spectra itself
+            ncol = self._pk_rows.shape[0]
+            if _TRANSFORM_FINDS_BOXES and 2 * ncol > self._keep_second_derivatives and dst.n == 4096:
+                # ... and runs the next step on the coefficients it holds (second derivatives, boxes, boxes rewritten): nothing is kept of
+                # the second derivatives, as for every large batch
+                res = dst.forward_analytic(engine, bg, pk, split=True, box=(self._margin_first, self._margin_second, self._offset[0], self._offset[1]))
+                if res is not None and res[0].shape[0] == ncol:
+                    return None, res
             ffted = dst.forward_analytic(engine, bg, pk, split=True)
-            if ffted is not None and ffted.shape[0] == self._pk_rows.shape[0]:
+            if ffted is not None and ffted.shape[0] == ncol:
                 return None, ffted
         rows = pwmod.analytic(engine, 'log_k_matter', klin, bg=bg, pk=pk, device=self.device)
         return (rows if rows.ndim == 2 and rows.shape[0] == self._pk_rows.shape[0] else None), None
@@ -282,6 +293,9 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         # dst(log(k P)), type 2, ortho, written as [even-indexed | odd-indexed] coefficients: seen as (2 ncol, 2048) the two sequences of
         # every vector are consecutive rows, and share the operators (x_even = x_odd = 1 + arange(2048), bao_filter.py:374-375)
         logkp, ffted = self._log_k_rows(ops['klin'], dst=ops['dst'])
+        solved = None
+        if isinstance(ffted, tuple):                                      # ... which has also found and rewritten the boxes
+            ffted, solved = ffted
         if ffted is not None:                                             # a batch of analytic cosmologies: evaluated inside the transform
             pass
         elif logkp is not None:                                           # analytic engine: log(k_lin P) straight from the evaluation kernel
@@ -290,7 +304,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             rows, _ = self._rows(ops['klin'])                             # P(k_lin), (ncol, 4096)
             ffted = ops['dst'](rows, fused=True, split=True)
         y = ffted.view(2 * ffted.shape[0], ffted.shape[1] // 2)
-        dd, box, removed = self._second_derivatives_and_box(y, ops)
+        dd, box, removed = (None, solved, True) if solved is not None else self._second_derivatives_and_box(y, ops)
         out = y      # in place: the kept coefficients stay where they are, only the boxes are rewritten
         if not removed:
             _lib.check(lib.cp_gap_spline(y.data_ptr(), box.data_ptr(), out.data_ptr(), y.shape[0], y.shape[1], self.device.index, dv.stream_of(self.device)))

@@ -17,6 +17,7 @@
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
 #include "cp_internal.h"
+#include "cp_wallish_dd.h"
 
 namespace {
 
@@ -113,90 +114,21 @@ int finish(const char* what, int status_device_ok) {
 
 
 // ---- wallish2018: second derivatives at the knots and the box, one kernel ---------------------------------------------------------------------
-// The clamped cubic spline through (x = 1 .. n, y) has second derivatives M with  2 M_0 + M_1 = 6 (y_1 - y_0),  M_{i-1} + 4 M_i + M_{i+1} =
-// 6 (y_{i+1} - 2 y_i + y_{i-1}),  M_{n-2} + 2 M_{n-1} = -6 (y_{n-1} - y_{n-2}):  what scipy's CubicSpline(bc_type='clamped')(x, nu=2) returns
-// (bao_filter.py:377-382).  The operator route applied the inverse of that matrix as a banded GEMM (2048 x 2048 with bands of 64: 0.48 ms per
-// 32 768 sequences, then 0.2 ms for the searches over the 537 MB it wrote).  Here a wave takes a sequence into LDS and runs the elimination
-// itself: lane l owns the knots [S l, S l + S), S = n / 64.  The modified diagonal c_i = 1 / (4 - c_{i-1}) does not depend on the data and
-// converges to 2 - sqrt(3) within 40 knots; the forward recurrence d_i = (rhs_i - d_{i-1}) c_i forgets its start at that rate (0.268 per knot),
-// so a lane starts HALO = 32 knots to the left of its own with d = 0 (5e-19 of the starting error is left when it reaches them; the first two
-// lanes start at knot 0 and are exact), and the back substitution M_i = d_i - c_i M_{i+1} the same from the right.  64 + 64 dependent steps
-// per sequence instead of 4096, nothing but the sequence read from memory; the arg-max searches run on the M in LDS; M itself is written only
-// on request (tests).
-constexpr int DD_HALO = 32;
-constexpr int DD_GAP_WINDOW = 64;      // knots on either side of the box from which its end slopes are eliminated (gap_spline_kernel: GAP_WINDOW)
-constexpr double DD_CINF = 0.26794919243112270647;      // 2 - sqrt(3)
-constexpr double DD_CLAST = 1. / (2. - DD_CINF);         // the last row has diagonal 2
-constexpr int DD_NTAB = 40;                              // c_i equals its limit to the last bit from knot 30 on
-struct DdTable {
-    double c[DD_NTAB];
-    constexpr DdTable() : c() {
-        double v = 0.5;
-        c[0] = v;
-        for (int i = 1; i < DD_NTAB; ++i) {
-            v = 1. / (4. - v);
-            c[i] = v;
-        }
-    }
-};
-__constant__ DdTable dd_table = DdTable();
-struct GapTable {      // the same recurrence started from 0 (gap_spline_kernel starts its eliminations inside the sequence with c = 0)
-    double c[DD_NTAB];
-    constexpr GapTable() : c() {
-        double v = 0.;
-        c[0] = v;
-        for (int i = 1; i < DD_NTAB; ++i) {
-            v = 1. / (4. - v);
-            c[i] = v;
-        }
-    }
-};
-__constant__ GapTable gap_table = GapTable();
+// The wave-level solve, the two arg-max searches and the removal of the box are device functions of cp_wallish_dd.h (shared with the forward
+// transform that produces its sequences itself, cp_dst.hip); here a wave takes a sequence from memory.  The operator route applied the inverse of
+// the spline's matrix as a banded GEMM (2048 x 2048 with bands of 64: 0.48 ms per 32 768 sequences, then 0.2 ms for the searches over the 537 MB
+// it wrote); M itself is written only on request (tests).
+using namespace cpdd;
 
-using cp::wave_lds_phase;
-
-__device__ __forceinline__ void dd_argmax_merge(double& v, int& i, double ov, int oi) {      // first index of the maximum, NaN counts as largest (numpy)
-    const bool take = (ov > v && !(v != v)) || (ov != ov && !(v != v)) || (((ov == v) || (ov != ov && v != v)) && oi < i);
-    if (take) {
-        v = ov;
-        i = oi;
-    }
-}
-
-__device__ __forceinline__ int dd_wave_merge(double v, int idx) {
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(idx, off);
-        dd_argmax_merge(v, idx, ov, oi);
-    }
-    return idx == 0x7fffffff ? 0 : idx;
-}
-
-template <int S>
-__device__ __forceinline__ int dd_wave_argmax(const double* buf, int lo, int hi, int lane) {
-    double v = -__builtin_inf();
-    int idx = 0x7fffffff;
-    for (int j = lo + lane; j < hi; j += 64) dd_argmax_merge(v, idx, buf[j + j / S], j);
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off);
-        const int oi = __shfl_xor(idx, off);
-        dd_argmax_merge(v, idx, ov, oi);
-    }
-    return idx == 0x7fffffff ? 0 : idx;
-}
-
-// S = n / 64 knots per lane; LDS per wave: n + 64 doubles, index i -> i + i / S (a lane's segment starts on its own bank), the sequence first,
-// then d over it (a lane reads ahead of where its left neighbour writes; the one value it needs from its right neighbour's segment it takes
-// before the sweep), then M over d (a lane is through its neighbour's segment before the neighbour writes there: the wave runs in lockstep).
+// S = n / 64 knots per lane; LDS per wave: n + 64 doubles, index i -> i + i / S, the sequence first, then d over it, then M over d.
 template <int S>
 __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, long long nrows, int margin_first, int margin_second, int off0, int off1,
                                                              int* __restrict__ box, double* __restrict__ dd_out, double* gap) {
     constexpr int N = 64 * S, STRIDE = N + 64;
     extern __shared__ double dd_lds[];
     double* ctab = dd_lds + 4 * STRIDE;           // c_i, i < DD_NTAB (the last entry stands for every later knot)
-    if (threadIdx.x < DD_NTAB) ctab[threadIdx.x] = dd_table.c[threadIdx.x];
     double* gtab = ctab + DD_NTAB;                // the same recurrence started from 0 (the eliminations around the box)
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + DD_NTAB) gtab[threadIdx.x - 64] = gap_table.c[threadIdx.x - 64];
+    fill_tables(ctab);
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* buf = dd_lds + wave * STRIDE;
@@ -208,169 +140,40 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
         for (int k = 0; k < S; ++k) nxt[k] = y[row * N + lane + 64 * k];
     }
     for (; row < nrows; row += (long long)gridDim.x * 4) {
-    const double* src = y + row * N;
+        const double* src = y + row * N;
 #pragma unroll
-    for (int k = 0; k < S; ++k) buf[(lane + 64 * k) + (lane + 64 * k) / S] = nxt[k];
-    wave_lds_phase();      // the sequence is in LDS before any lane reads its neighbours' knots
-    if (row + (long long)gridDim.x * 4 < nrows) {
+        for (int k = 0; k < S; ++k) buf[(lane + 64 * k) + (lane + 64 * k) / S] = nxt[k];
+        wave_lds_phase();      // the sequence is in LDS before any lane reads its neighbours' knots
+        if (row + (long long)gridDim.x * 4 < nrows) {
 #pragma unroll
-        for (int k = 0; k < S; ++k) nxt[k] = y[(row + (long long)gridDim.x * 4) * N + lane + 64 * k];
-    }
-    auto at = [&](int i) -> double& { return buf[i + i / S]; };
-    auto clamped = [&](int i) { return buf[(i < 0 ? 0 : (i > N - 1 ? N - 1 : i)) + (i < 0 ? 0 : (i > N - 1 ? N - 1 : i)) / S]; };
-    auto c_of = [&](int i) { return i >= N - 1 ? DD_CLAST : ctab[i < 0 ? 0 : (i < DD_NTAB ? i : DD_NTAB - 1)]; };
-    const int own = S * lane;
-    // Both sweeps without a branch: knots read beyond either end repeat the end knot, which makes the right-hand sides of the two clamped rows
-    // come out of the general formula (6 ((y_1 - y_0) - (y_0 - y_0)) and 6 ((y_{n-1} - y_{n-1}) - (y_{n-1} - y_{n-2}))) and keeps d = 0 to the
-    // left of knot 0.
-    {
-        const double beyond = clamped(own + S);      // the next segment's first knot, before its owner writes there
-        double d = 0., ym = clamped(own - DD_HALO - 1), y0 = clamped(own - DD_HALO);
-#pragma unroll 8
-        for (int t = 0; t < DD_HALO; ++t) {          // towards the segment: nothing stored
-            const int i = own - DD_HALO + t;
-            const double yp = clamped(i + 1);
-            d = (6. * ((yp - y0) - (y0 - ym)) - d) * c_of(i);
-            ym = y0;
-            y0 = yp;
+            for (int k = 0; k < S; ++k) nxt[k] = y[(row + (long long)gridDim.x * 4) * N + lane + 64 * k];
         }
-        wave_lds_phase();      // every lane is through its run-in (knots of its left neighbours) before those are overwritten by d
-#pragma unroll 8
-        for (int t = 0; t < S; ++t) {
-            const int i = own + t;
-            const double yp = t == S - 1 ? beyond : clamped(i + 1);
-            d = (6. * ((yp - y0) - (y0 - ym)) - d) * c_of(i);
-            at(i) = d;
-            ym = y0;
-            y0 = yp;
-        }
-    }
-    wave_lds_phase();      // d complete
-    double best = -__builtin_inf();
-    int best_i = 0x7fffffff;
-    {
-        double m = 0.;
-#pragma unroll 8
-        for (int t = 0; t < DD_HALO; ++t) {          // towards the segment from the right (beyond the last knot: M_{n-1} = d_{n-1} again)
-            const int i = own + S + DD_HALO - 1 - t;
-            const double d = clamped(i);
-            m = i >= N - 1 ? d : d - c_of(i) * m;
-        }
-        wave_lds_phase();      // run-in from the right done before the neighbours' d become M
-#pragma unroll 8
-        for (int t = 0; t < S; ++t) {
-            const int i = own + S - 1 - t;
-            const double d = at(i);
-            m = i >= N - 1 ? d : d - c_of(i) * m;
-            at(i) = m;
-            // the lane's own maximum inside [margin_first, n - margin_first), first index on ties, NaN as the largest value (numpy's argmax): the
-            // sweep runs towards smaller i, so an equal value replaces the one held
-            const bool inside = i >= margin_first && i < N - margin_first;
-            if (inside && ((m != m) || (!(best != best) && m >= best))) {
-                best = m;
-                best_i = i;
-            }
-        }
-    }
-    wave_lds_phase();      // M complete
-    if (dd_out) {
-        double* dst = dd_out + row * N;
+        int first, second;
+        second_derivatives_and_box<S>(buf, ctab, lane, margin_first, margin_second, first, second);
+        if (dd_out) {
+            double* dst = dd_out + row * N;
 #pragma unroll 4
-        for (int j = lane; j < N; j += 64) dst[j] = buf[j + j / S];
-    }
-    // arg-max over [margin_first, n - margin_first): the lanes' maxima merged; then over [first + margin_second, n - margin_first): the maxima of
-    // the lanes whose segments lie inside it, and the segment that straddles its lower end looked at once more, a knot per lane
-    const int first = dd_wave_merge(best, best_i);
-    const int lower = first + margin_second;
-    double v2 = own >= lower ? best : -__builtin_inf();
-    int i2 = own >= lower ? best_i : 0x7fffffff;
-    {
-        const int e = lower - lower % S + lane % S;
-        if (e >= lower && e < N - margin_first && lane < S) dd_argmax_merge(v2, i2, at(e), e);
-    }
-    const int second = dd_wave_merge(v2, i2);
-    if (lane == 0) {
-        box[2 * row] = first + off0;
-        box[2 * row + 1] = second + off1;
-    }
-    wave_lds_phase();      // the last reads of M are done: the buffer is free for the next phase / the next sequence
-    if (!gap) continue;
-    // The removal of the box (cp_gap_spline, bao_filter.py:395-405), on the sequence in memory: the clamped spline through the x^2-weighted
-    // coefficients with the knots [a, b] left out returns the datum at every kept knot, so only the box is rewritten; its two end slopes come
-    // from eliminations started DD_GAP_WINDOW knots to either side (the same arithmetic as gap_spline_kernel, cp_spline.hip), here run by two
-    // lanes side by side on values the wave has brought into LDS (the second derivatives there are not needed any more).
-    const int a = first + off0, b = second + off1;
-    if (a < 1 || b > N - 2 || b < a) continue;      // nothing removed (or an invalid box): the sequence stays as it is
-    const int L = a - 1, R = b + 1;
-    const double g = (double)(R - L);
-    const int i0 = L - DD_GAP_WINDOW > 0 ? L - DD_GAP_WINDOW : 0, i1 = R + DD_GAP_WINDOW < N - 1 ? R + DD_GAP_WINDOW : N - 1;
-    const int lo = i0 > 0 ? i0 - 1 : 0, hi = i1 < N - 1 ? i1 + 1 : N - 1;
-    double* zl = buf;                              // z(lo .. L)
-    double* zr = buf + DD_GAP_WINDOW + 8;          // z(R .. hi)
-    double* seq = gap + row * N;
-    for (int e = lane; e <= L - lo; e += 64) {
-        const double x = (double)(lo + e + 1);
-        zl[e] = src[lo + e] * (x * x);
-    }
-    for (int e = lane; e <= hi - R; e += 64) {
-        const double x = (double)(R + e + 1);
-        zr[e] = src[R + e] * (x * x);
-    }
-    wave_lds_phase();      // zl / zr written by all lanes, read by lanes 0 and 1
-    auto z = [&](int i) { return i <= L ? zl[i - lo] : zr[i - R]; };
-    double r0 = 0., r1 = 0.;
-    if (lane == 0) {            // forward sweep up to L: s_L + cpL s_R = dpL
-        double cp = 0., dp = i0 == 0 ? 0. : 0.5 * (z(i0 + 1) - z(i0 - 1));      // clamped: s_0 = 0
-        if (L != i0) {
-            // (1 / (4 - cp) does not depend on the data: 0, 1/4, 4/15, ... from a table, its limit after 40 knots -- no division in the chain)
-            double zm = z(i0), z0 = z(i0 + 1);
-#pragma unroll 4
-            for (int i = i0 + 1; i < L; ++i) {
-                const double zp = z(i + 1);
-                cp = gtab[i - i0 < DD_NTAB ? i - i0 : DD_NTAB - 1];
-                dp = (3. * (zp - zm) - dp) * cp;
-                zm = z0;
-                z0 = zp;
-            }
-            const double d = 3. * (g * (z(L) - z(L - 1)) + (z(R) - z(L)) / g);
-            const double den = 2. * (1. + g) - g * cp;
-            cp = 1. / den;
-            dp = (d - g * dp) / den;
+            for (int j = lane; j < N; j += 64) dst[j] = buf[j + j / S];
         }
-        r0 = cp;
-        r1 = dp;
-    } else if (lane == 1) {     // backward sweep down to R: s_R + bqR s_L = dqR
-        double bq = 0., dq = i1 == N - 1 ? 0. : 0.5 * (z(i1 + 1) - z(i1 - 1));  // clamped: s_{n-1} = 0
-        if (R != i1) {
-            double zp = z(i1), z0 = z(i1 - 1);
-#pragma unroll 4
-            for (int i = i1 - 1; i > R; --i) {
-                const double zm = z(i - 1);
-                bq = gtab[i1 - i < DD_NTAB ? i1 - i : DD_NTAB - 1];
-                dq = (3. * (zp - zm) - dq) * bq;
-                zp = z0;
-                z0 = zm;
-            }
-            const double d = 3. * ((z(R) - z(L)) / g + g * (z(R + 1) - z(R)));
-            const double den = 2. * (g + 1.) - g * bq;
-            bq = 1. / den;
-            dq = (d - g * dq) / den;
+        if (lane == 0) {
+            box[2 * row] = first + off0;
+            box[2 * row + 1] = second + off1;
         }
-        r0 = bq;
-        r1 = dq;
-    }
-    const double cpL = __shfl(r0, 0), dpL = __shfl(r1, 0), bqR = __shfl(r0, 1), dqR = __shfl(r1, 1);
-    const double sL = (dpL - cpL * dqR) / (1. - cpL * bqR);
-    const double sR = dqR - bqR * sL;
-    const double zL = z(L), zR = z(R);
-    const double slope = (zR - zL) / g;
-    const double tt = (sL + sR - 2. * slope) / g;
-    const double c3 = tt / g, c2 = (slope - sL) / g - tt;
-    for (int i = a + lane; i <= b; i += 64) {
-        const double u = (double)(i - L), x = (double)(i + 1);
-        seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
-    }
-    wave_lds_phase();      // zl / zr read before the next sequence is staged over them
+        wave_lds_phase();      // the last reads of M are done: the buffer is free for the next phase / the next sequence
+        if (!gap) continue;
+        // the removal of the box on the sequence in memory: the knots around it come from there (the second derivatives in LDS are not needed any more)
+        remove_box<S>(buf, gtab, lane, first + off0, second + off1,
+                      [&](int lo, int L, int R, int hi, double* zl, double* zr) {
+                          for (int e = lane; e <= L - lo; e += 64) {
+                              const double x = (double)(lo + e + 1);
+                              zl[e] = src[lo + e] * (x * x);
+                          }
+                          for (int e = lane; e <= hi - R; e += 64) {
+                              const double x = (double)(R + e + 1);
+                              zr[e] = src[R + e] * (x * x);
+                          }
+                      },
+                      gap + row * N);
     }
 }
 

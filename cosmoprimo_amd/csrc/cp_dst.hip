@@ -24,6 +24,7 @@
 #include "cp_fftlog_tables.h"
 #include "cp_math.h"
 #include "cp_power_eval.h"
+#include "cp_wallish_dd.h"
 
 namespace {
 
@@ -290,6 +291,10 @@ struct GenArgs {
     const double* k;                 // (N) wavenumbers, h/Mpc
     const double* ln_k;              // (N) their logarithms (log_pos, as power_kernel takes them)
     const cppower::EhScalars* scal;  // (ncosmo) fit coefficients (cp_power_coefficients), unused for BBKS
+    // the next step of wallish2018 in the epilogue (bao_filter.py:373-405): second derivatives of the clamped splines through the even- and the
+    // odd-indexed coefficients, the box between their maxima, the box rewritten -- box != null (split layout only)
+    int* box;                        // (2 ncosmo, 2) or null
+    int margin_first, margin_second, off0, off1;
 };
 
 #ifndef CP_DST_GEN_ILP
@@ -342,6 +347,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
     cplx* ltw = lds + lds_data_slots(N, P);
     const int t = threadIdx.x;
     for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = A.tw[N + i];
+    double* dd_tabs = reinterpret_cast<double*>(ltw + (PL::TW_TOTAL - N));      // 2 x DD_NTAB elimination factors of the box step (G.box only)
+    if (G.box) cpdd::fill_tables(dd_tabs);
     const long long npairs = (G.ncosmo + 1) / 2;
     const double fn = sqrt(2. / N), fl = sqrt(1. / N);
     __shared__ int bad_row[2];
@@ -384,17 +391,84 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
         asm volatile("" : "+v"(tt));
         dif_all<N, P>(tt, A, x, lds, ltw);
         asm volatile("" : "+v"(tt));
+        if (!G.box) {
 #pragma unroll 4
-        for (int s = 0; s < P; ++s) {
-            const int k = tt + T * s;
-            const cplx v = lds_at<N, P>(lds, pos_of_freq<N, P>(k));
-            const cplx u = lds_at<N, P>(lds, pos_of_freq<N, P>((N - k) % N));
-            const cplx rot = A.rot[k];
-            const double f = k == 0 ? fl : fn;
-            const double ya = 0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im));
-            const double yb = 0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re));
-            oa[at(N - 1 - k)] = skip_a ? nan : f * ya;
-            if (has_b) ob[at(N - 1 - k)] = skip_b ? nan : f * yb;
+            for (int s = 0; s < P; ++s) {
+                const int k = tt + T * s;
+                const cplx v = lds_at<N, P>(lds, pos_of_freq<N, P>(k));
+                const cplx u = lds_at<N, P>(lds, pos_of_freq<N, P>((N - k) % N));
+                const cplx rot = A.rot[k];
+                const double f = k == 0 ? fl : fn;
+                const double ya = 0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im));
+                const double yb = 0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re));
+                oa[at(N - 1 - k)] = skip_a ? nan : f * ya;
+                if (has_b) ob[at(N - 1 - k)] = skip_b ? nan : f * yb;
+            }
+            continue;
+        }
+        // ---- the coefficients stay on the CU for the next step of the filter: the four sequences of the pair (even / odd coefficients of rows a, b),
+        // one per wave, in the data region of the transform (4 x 2048 doubles, XOR layout) ----
+        if constexpr (N == 4096) {
+            using namespace cpdd;
+            constexpr int S = 32, NS = N / 2;
+            double va[P], vb[P];
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const int k = tt + T * s;
+                const cplx v = lds_at<N, P>(lds, pos_of_freq<N, P>(k));
+                const cplx u = lds_at<N, P>(lds, pos_of_freq<N, P>((N - k) % N));
+                const cplx rot = A.rot[k];
+                const double f = k == 0 ? fl : fn;
+                va[s] = skip_a ? nan : f * (0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im)));
+                vb[s] = skip_b ? nan : f * (0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re)));
+            }
+            __syncthreads();      // every thread has its coefficients: the data region is free
+            double* seqs = reinterpret_cast<double*>(lds);
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const int j = N - 1 - (tt + T * s);      // coefficient j of its row: sequence (j & 1), knot j >> 1
+                const int slot = Xor32Layout::at(j >> 1);
+                seqs[(j & 1) * NS + slot] = va[s];
+                seqs[(2 + (j & 1)) * NS + slot] = vb[s];
+            }
+            __syncthreads();
+            const int wave = t >> 6;
+            int lane = t & 63;
+            asm volatile("" : "+v"(lane));      // (nothing of the tail is hoisted out of the loop over pairs: 32 squared abscissae and 32 slots would live through the transform)
+            if (wave < 2 || has_b) {
+                double* buf = seqs + wave * NS;
+                const long long row = 2 * p + (wave >> 1);
+                double* seq = A.out + row * N + (wave & 1) * NS;      // split layout: [even-indexed | odd-indexed] coefficients of the row
+                double own[S];      // the wave's sequence, knot lane + 64 k in register k: the solve overwrites the buffer
+#pragma unroll
+                for (int k = 0; k < S; ++k) own[k] = buf[Xor32Layout::at(lane + 64 * k)];
+                int first, second;
+                second_derivatives_and_box<S, Xor32Layout>(buf, dd_tabs, lane, G.margin_first, G.margin_second, first, second);
+                const long long srow = 2 * row + (wave & 1);
+                if (lane == 0) {
+                    G.box[2 * srow] = first + G.off0;
+                    G.box[2 * srow + 1] = second + G.off1;
+                }
+                wave_lds_phase();      // the last reads of M are done: the buffer is free
+                const int a = first + G.off0, b = second + G.off1;
+                const bool removed = remove_box<S>(buf, dd_tabs + DD_NTAB, lane, a, b,
+                                                   [&](int lo, int L, int R, int hi, double* zl, double* zr) {
+#pragma unroll
+                                                       for (int k = 0; k < S; ++k) {
+                                                           const int i = lane + 64 * k;
+                                                           const double x = (double)(i + 1);
+                                                           if (i >= lo && i <= L) zl[i - lo] = own[k] * (x * x);
+                                                           if (i >= R && i <= hi) zr[i - R] = own[k] * (x * x);
+                                                       }
+                                                   },
+                                                   seq);
+                // the knots that stay: every address of the sequence is written exactly once (the box by remove_box, the rest here)
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    const int i = lane + 64 * k;
+                    if (!(removed && i >= a && i <= b)) seq[i] = own[k];
+                }
+            }
         }
     }
 }
@@ -500,7 +574,7 @@ namespace {
 template <int ENGINE>
 void launch_generate(const GenArgs& G, int grid, hipStream_t stream) {
     constexpr int N = 4096, P = 16, T = N / P;
-    constexpr int lds = (lds_data_slots(N, P) + Plan<N, P>::TW_TOTAL - N) * (int)sizeof(cplx);
+    constexpr int lds = (lds_data_slots(N, P) + Plan<N, P>::TW_TOTAL - N) * (int)sizeof(cplx) + 2 * cpdd::DD_NTAB * (int)sizeof(double);
     (void)cp::allow_full_lds<&dst_generate_kernel<N, P, ENGINE>>();
     hipLaunchKernelGGL((dst_generate_kernel<N, P, ENGINE>), dim3(grid), dim3(T), lds, stream, G);
 }
@@ -509,8 +583,27 @@ void launch_generate(const GenArgs& G, int grid, hipStream_t stream) {
 
 extern "C" long long cp_dst_forward_analytic_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : cp_power_workspace_bytes(ncosmo) + 64; }
 
+static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
+                                double* d_out, void* d_work, int flags, int* d_box, int margin_first, int margin_second, int offset_first, int offset_second,
+                                void* stream);
+
 extern "C" int cp_dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
                                        const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream) {
+    return dst_forward_analytic(p, engine, ncosmo, bg_params, second_is_omega_m, pk_params, d_out, d_work, flags, nullptr, 0, 0, 0, 0, stream);
+}
+
+extern "C" int cp_dst_forward_analytic_box(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
+                                           const cp_param* pk_params, double* d_out, void* d_work, int* d_box, int margin_first, int margin_second,
+                                           int offset_first, int offset_second, void* stream) {
+    if (!d_box) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic_box: null box pointer");
+    if (margin_first < 0 || 2 * margin_first >= 2048) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic_box: bad margins");
+    return dst_forward_analytic(p, engine, ncosmo, bg_params, second_is_omega_m, pk_params, d_out, d_work, CP_DST_SPLIT, d_box, margin_first, margin_second,
+                                offset_first, offset_second, stream);
+}
+
+static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
+                                double* d_out, void* d_work, int flags, int* d_box, int margin_first, int margin_second, int offset_first, int offset_second,
+                                void* stream) {
     if (!p) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: null plan");
     if (flags & ~CP_DST_SPLIT) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: unknown flags %d", flags);
     if (p->n != 4096 || !p->d_kx) return cp::fail(CP_EUNSUPPORTED, "cp_dst_forward_analytic: needs a plan of length 4096 made with its abscissa (wallish2018's linear grid)");
@@ -535,6 +628,7 @@ extern "C" int cp_dst_forward_analytic(const cp_dst_plan* p, int engine, long lo
     G.k = p->d_kx;
     G.ln_k = p->d_ln_kx;
     G.scal = reinterpret_cast<const cppower::EhScalars*>(coef);
+    G.box = d_box; G.margin_first = margin_first; G.margin_second = margin_second; G.off0 = offset_first; G.off1 = offset_second;
     const long long npairs = (ncosmo + 1) / 2;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;

@@ -1,0 +1,243 @@
+// cp_wallish_dd.h -- wallish2018: second derivatives of the clamped spline through a sequence of sine-transform coefficients, the box between
+// their two maxima, and the removal of that box, as wave-level device functions (reference bao_filter.py:377-405).  Used by the stand-alone kernel
+// (cp_bao.hip: wallish_dd_box_kernel, sequences read from memory) and by the forward transform that produces the sequences itself (cp_dst.hip:
+// dst_generate_kernel, the four sequences of a pair of vectors one per wave of its workgroup).
+//
+// The clamped cubic spline through (x = 1 .. n, y) has second derivatives M with  2 M_0 + M_1 = 6 (y_1 - y_0),  M_{i-1} + 4 M_i + M_{i+1} =
+// 6 (y_{i+1} - 2 y_i + y_{i-1}),  M_{n-2} + 2 M_{n-1} = -6 (y_{n-1} - y_{n-2}):  what scipy's CubicSpline(bc_type='clamped')(x, nu=2) returns
+// (bao_filter.py:377-382).  A wave holds a sequence in LDS and runs the elimination itself: lane l owns the knots [S l, S l + S), S = n / 64.
+// The modified diagonal c_i = 1 / (4 - c_{i-1}) does not depend on the data and converges to 2 - sqrt(3) within 40 knots; the forward recurrence
+// d_i = (rhs_i - d_{i-1}) c_i forgets its start at that rate (0.268 per knot), so a lane starts DD_HALO = 32 knots to the left of its own with
+// d = 0 (5e-19 of the starting error is left when it reaches them; the first two lanes start at knot 0 and are exact), and the back
+// substitution M_i = d_i - c_i M_{i+1} the same from the right.  64 + 64 dependent steps per sequence instead of 4096.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cp_internal.h"
+
+namespace cpdd {
+
+using cp::wave_lds_phase;
+
+constexpr int DD_HALO = 32;
+constexpr int DD_GAP_WINDOW = 64;      // knots on either side of the box from which its end slopes are eliminated (gap_spline_kernel: GAP_WINDOW)
+constexpr double DD_CINF = 0.26794919243112270647;      // 2 - sqrt(3)
+constexpr double DD_CLAST = 1. / (2. - DD_CINF);         // the last row has diagonal 2
+constexpr int DD_NTAB = 40;                              // c_i equals its limit to the last bit from knot 30 on
+struct DdTable {
+    double c[DD_NTAB];
+    constexpr DdTable() : c() {
+        double v = 0.5;
+        c[0] = v;
+        for (int i = 1; i < DD_NTAB; ++i) {
+            v = 1. / (4. - v);
+            c[i] = v;
+        }
+    }
+};
+struct GapTable {      // the same recurrence started from 0 (gap_spline_kernel starts its eliminations inside the sequence with c = 0)
+    double c[DD_NTAB];
+    constexpr GapTable() : c() {
+        double v = 0.;
+        c[0] = v;
+        for (int i = 1; i < DD_NTAB; ++i) {
+            v = 1. / (4. - v);
+            c[i] = v;
+        }
+    }
+};
+
+// the two tables into LDS (2 DD_NTAB doubles at `tabs`), by threads 0 .. 39 and 64 .. 103 of a workgroup (the recurrences run in IEEE arithmetic: the
+// values of the constexpr tables above, which the host uses); a barrier follows at the caller's
+__device__ __forceinline__ void fill_tables(double* tabs) {
+    const int t = threadIdx.x;
+    const bool gap = t >= 64;
+    const int n = gap ? t - 64 : t;
+    if (n < DD_NTAB && t < 64 + DD_NTAB) {
+        double v = gap ? 0. : 0.5;
+        for (int i = 0; i < n; ++i) v = 1. / (4. - v);
+        tabs[(gap ? DD_NTAB : 0) + n] = v;
+    }
+}
+
+__device__ __forceinline__ void argmax_merge(double& v, int& i, double ov, int oi) {      // first index of the maximum, NaN counts as largest (numpy)
+    const bool take = (ov > v && !(v != v)) || (ov != ov && !(v != v)) || (((ov == v) || (ov != ov && v != v)) && oi < i);
+    if (take) {
+        v = ov;
+        i = oi;
+    }
+}
+
+__device__ __forceinline__ int wave_merge(double v, int idx) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        argmax_merge(v, idx, ov, oi);
+    }
+    return idx == 0x7fffffff ? 0 : idx;
+}
+
+// Where knot i of a sequence sits in its LDS buffer.  A lane walks S consecutive knots, so consecutive lanes are S doubles apart: without a
+// permutation all of them would sit on one bank.  Padded: i + i / S (n + 64 doubles per sequence); Xor32 (S = 32 only): the low five bits XOR-ed
+// with the segment number -- a permutation inside blocks of 32, exactly n doubles per sequence (four sequences of 2048 then fill the 64 KB data
+// region of a 4096-point transform).
+template <int S>
+struct PaddedLayout {
+    static __device__ __forceinline__ int at(int i) { return i + i / S; }
+};
+struct Xor32Layout {
+    static __device__ __forceinline__ int at(int i) { return i ^ ((i >> 5) & 31); }
+};
+
+// S = n / 64 knots per lane; buf: the sequence in LDS under the layout LAY (every lane's LDS writes fenced by the caller), its second derivatives M
+// on exit.  first / second: the arg-max of M over [margin_first, n - margin_first) and over [first + margin_second, n - margin_first)
+// (bao_filter.py:390-394, before the offsets).
+template <int S, class LAY = PaddedLayout<S>>
+__device__ __forceinline__ void second_derivatives_and_box(double* buf, const double* ctab, int lane, int margin_first, int margin_second, int& first,
+                                                           int& second) {
+    constexpr int N = 64 * S;
+    auto at = [&](int i) -> double& { return buf[LAY::at(i)]; };
+    auto clamped = [&](int i) { return buf[LAY::at(i < 0 ? 0 : (i > N - 1 ? N - 1 : i))]; };
+    auto c_of = [&](int i) { return i >= N - 1 ? DD_CLAST : ctab[i < 0 ? 0 : (i < DD_NTAB ? i : DD_NTAB - 1)]; };
+    const int own = S * lane;
+    // Both sweeps without a branch: knots read beyond either end repeat the end knot, which makes the right-hand sides of the two clamped rows
+    // come out of the general formula (6 ((y_1 - y_0) - (y_0 - y_0)) and 6 ((y_{n-1} - y_{n-1}) - (y_{n-1} - y_{n-2}))) and keeps d = 0 to the
+    // left of knot 0.
+    {
+        const double beyond = clamped(own + S);      // the next segment's first knot, before its owner writes there
+        double d = 0., ym = clamped(own - DD_HALO - 1), y0 = clamped(own - DD_HALO);
+#pragma unroll 8
+        for (int t = 0; t < DD_HALO; ++t) {          // towards the segment: nothing stored
+            const int i = own - DD_HALO + t;
+            const double yp = clamped(i + 1);
+            d = (6. * ((yp - y0) - (y0 - ym)) - d) * c_of(i);
+            ym = y0;
+            y0 = yp;
+        }
+        wave_lds_phase();      // every lane is through its run-in (knots of its left neighbours) before those are overwritten by d
+#pragma unroll 8
+        for (int t = 0; t < S; ++t) {
+            const int i = own + t;
+            const double yp = t == S - 1 ? beyond : clamped(i + 1);
+            d = (6. * ((yp - y0) - (y0 - ym)) - d) * c_of(i);
+            at(i) = d;
+            ym = y0;
+            y0 = yp;
+        }
+    }
+    wave_lds_phase();      // d complete
+    double best = -__builtin_inf();
+    int best_i = 0x7fffffff;
+    {
+        double m = 0.;
+#pragma unroll 8
+        for (int t = 0; t < DD_HALO; ++t) {          // towards the segment from the right (beyond the last knot: M_{n-1} = d_{n-1} again)
+            const int i = own + S + DD_HALO - 1 - t;
+            const double d = clamped(i);
+            m = i >= N - 1 ? d : d - c_of(i) * m;
+        }
+        wave_lds_phase();      // run-in from the right done before the neighbours' d become M
+#pragma unroll 8
+        for (int t = 0; t < S; ++t) {
+            const int i = own + S - 1 - t;
+            const double d = at(i);
+            m = i >= N - 1 ? d : d - c_of(i) * m;
+            at(i) = m;
+            // the lane's own maximum inside [margin_first, n - margin_first), first index on ties, NaN as the largest value (numpy's argmax): the
+            // sweep runs towards smaller i, so an equal value replaces the one held
+            const bool inside = i >= margin_first && i < N - margin_first;
+            if (inside && ((m != m) || (!(best != best) && m >= best))) {
+                best = m;
+                best_i = i;
+            }
+        }
+    }
+    wave_lds_phase();      // M complete
+    // arg-max over [margin_first, n - margin_first): the lanes' maxima merged; then over [first + margin_second, n - margin_first): the maxima of
+    // the lanes whose segments lie inside it, and the segment that straddles its lower end looked at once more, a knot per lane
+    first = wave_merge(best, best_i);
+    const int lower = first + margin_second;
+    double v2 = own >= lower ? best : -__builtin_inf();
+    int i2 = own >= lower ? best_i : 0x7fffffff;
+    {
+        const int e = lower - lower % S + lane % S;
+        if (e >= lower && e < N - margin_first && lane < S) argmax_merge(v2, i2, at(e), e);
+    }
+    second = wave_merge(v2, i2);
+}
+
+// The removal of the box [a, b] (cp_gap_spline, bao_filter.py:395-405): the clamped spline through the x^2-weighted coefficients with the knots
+// [a, b] left out returns the datum at every kept knot, so only the box is rewritten; its two end slopes come from eliminations started
+// DD_GAP_WINDOW knots to either side (the arithmetic of gap_spline_kernel, cp_spline.hip), run by two lanes side by side on values the wave has
+// brought into LDS.  `stage(lo, L, R, hi, zl, zr)` fills zl[i - lo] = y_i (i + 1)^2 for lo <= i <= L and zr[i - R] likewise for R <= i <= hi
+// (all lanes take part); `seq` is where the rewritten knots go.  Returns false when nothing is removed (an invalid box: the sequence stays).
+template <int S, class Stage>
+__device__ __forceinline__ bool remove_box(double* buf, const double* gtab, int lane, int a, int b, Stage stage, double* seq) {
+    constexpr int N = 64 * S;
+    if (a < 1 || b > N - 2 || b < a) return false;
+    const int L = a - 1, R = b + 1;
+    const double g = (double)(R - L);
+    const int i0 = L - DD_GAP_WINDOW > 0 ? L - DD_GAP_WINDOW : 0, i1 = R + DD_GAP_WINDOW < N - 1 ? R + DD_GAP_WINDOW : N - 1;
+    const int lo = i0 > 0 ? i0 - 1 : 0, hi = i1 < N - 1 ? i1 + 1 : N - 1;
+    double* zl = buf;                              // z(lo .. L)
+    double* zr = buf + DD_GAP_WINDOW + 8;          // z(R .. hi)
+    stage(lo, L, R, hi, zl, zr);
+    wave_lds_phase();      // zl / zr written by all lanes, read by lanes 0 and 1
+    auto z = [&](int i) { return i <= L ? zl[i - lo] : zr[i - R]; };
+    double r0 = 0., r1 = 0.;
+    if (lane == 0) {            // forward sweep up to L: s_L + cpL s_R = dpL
+        double cp = 0., dp = i0 == 0 ? 0. : 0.5 * (z(i0 + 1) - z(i0 - 1));      // clamped: s_0 = 0
+        if (L != i0) {
+            // (1 / (4 - cp) does not depend on the data: 0, 1/4, 4/15, ... from a table, its limit after 40 knots -- no division in the chain)
+            double zm = z(i0), z0 = z(i0 + 1);
+#pragma unroll 4
+            for (int i = i0 + 1; i < L; ++i) {
+                const double zp = z(i + 1);
+                cp = gtab[i - i0 < DD_NTAB ? i - i0 : DD_NTAB - 1];
+                dp = (3. * (zp - zm) - dp) * cp;
+                zm = z0;
+                z0 = zp;
+            }
+            const double d = 3. * (g * (z(L) - z(L - 1)) + (z(R) - z(L)) / g);
+            const double den = 2. * (1. + g) - g * cp;
+            cp = 1. / den;
+            dp = (d - g * dp) / den;
+        }
+        r0 = cp;
+        r1 = dp;
+    } else if (lane == 1) {     // backward sweep down to R: s_R + bqR s_L = dqR
+        double bq = 0., dq = i1 == N - 1 ? 0. : 0.5 * (z(i1 + 1) - z(i1 - 1));  // clamped: s_{n-1} = 0
+        if (R != i1) {
+            double zp = z(i1), z0 = z(i1 - 1);
+#pragma unroll 4
+            for (int i = i1 - 1; i > R; --i) {
+                const double zm = z(i - 1);
+                bq = gtab[i1 - i < DD_NTAB ? i1 - i : DD_NTAB - 1];
+                dq = (3. * (zp - zm) - dq) * bq;
+                zp = z0;
+                z0 = zm;
+            }
+            const double d = 3. * ((z(R) - z(L)) / g + g * (z(R + 1) - z(R)));
+            const double den = 2. * (g + 1.) - g * bq;
+            bq = 1. / den;
+            dq = (d - g * dq) / den;
+        }
+        r0 = bq;
+        r1 = dq;
+    }
+    const double cpL = __shfl(r0, 0), dpL = __shfl(r1, 0), bqR = __shfl(r0, 1), dqR = __shfl(r1, 1);
+    const double sL = (dpL - cpL * dqR) / (1. - cpL * bqR);
+    const double sR = dqR - bqR * sL;
+    const double zL = z(L), zR = z(R);
+    const double slope = (zR - zL) / g;
+    const double tt = (sL + sR - 2. * slope) / g;
+    const double c3 = tt / g, c2 = (slope - sL) / g - tt;
+    for (int i = a + lane; i <= b; i += 64) {
+        const double u = (double)(i - L), x = (double)(i + 1);
+        seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
+    }
+    wave_lds_phase();      // zl / zr read before the buffer is staged over again
+    return true;
+}
+
+}  // namespace cpdd

@@ -40,9 +40,11 @@ class DST(object):
                                                   dv.stream_of(self.device)))
         return out
 
-    def forward_analytic(self, engine, bg, pk, split=False):
+    def forward_analytic(self, engine, bg, pk, split=False, box=None):
         """dst(log(kx P_c(kx))) of a batch of cosmologies of an analytic engine with the spectra evaluated inside the transform kernel
-        (``cp_dst_forward_analytic``): (ncosmo, n), or None when the parameters are not a batch or the plan is not wallish2018's (n = 4096 with kx)."""
+        (``cp_dst_forward_analytic``): (ncosmo, n), or None when the parameters are not a batch or the plan is not wallish2018's (n = 4096 with kx).
+        box = (margin_first, margin_second, offset_first, offset_second): also the next step of the filter in the kernel's epilogue
+        (``cp_dst_forward_analytic_box``: split layout, boxes rewritten); returns (coefficients, boxes (2 ncosmo, 2) int32)."""
         torch = dv.torch()
         from .background import DEFAULTS as bg_defaults
         from .power import PK_DEFAULTS
@@ -57,6 +59,11 @@ class DST(object):
         lib = _lib.load()
         out = torch.empty((ncosmo, self.n), dtype=torch.float64, device=self.device)
         work = torch.empty(int(lib.cp_dst_forward_analytic_workspace_bytes(ncosmo)), dtype=torch.uint8, device=self.device)
+        if box is not None:
+            boxes = torch.empty((2 * ncosmo, 2), dtype=torch.int32, device=self.device)
+            _lib.check(lib.cp_dst_forward_analytic_box(self._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), out.data_ptr(),
+                                                       work.data_ptr(), boxes.data_ptr(), int(box[0]), int(box[1]), int(box[2]), int(box[3]), dv.stream_of(self.device)))
+            return out, boxes
         _lib.check(lib.cp_dst_forward_analytic(self._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), out.data_ptr(), work.data_ptr(),
                                                2 if split else 0, dv.stream_of(self.device)))
         return out

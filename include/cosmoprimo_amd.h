@@ -474,6 +474,13 @@ int cp_dst_plan_destroy(cp_dst_plan* plan);
 long long cp_dst_forward_analytic_workspace_bytes(long long ncosmo);
 int cp_dst_forward_analytic(const cp_dst_plan* plan, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
                             const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream);
+/* The same with the NEXT step of wallish2018 in the kernel's epilogue (cp_wallish_dd_box with d_gap = d_y, bao_filter.py:373-405): the coefficients are
+ * written de-interleaved (CP_DST_SPLIT: every row is its even-indexed sequence followed by its odd-indexed one, 2048 knots each), d_box (2 ncosmo, 2)
+ * receives the box of every sequence, and the boxes are already rewritten in d_out -- the four sequences of a pair of cosmologies are solved by the
+ * four waves of the workgroup that transformed them, without the (2 ncosmo, 2048) coefficients being read again. */
+int cp_dst_forward_analytic_box(const cp_dst_plan* plan, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
+                                const cp_param* pk_params, double* d_out, void* d_work, int* d_box, int margin_first, int margin_second,
+                                int offset_first, int offset_second, void* stream);
 
 /* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
  * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];

@@ -122,3 +122,43 @@ def test_forward_transform_that_evaluates_the_spectra(engine):
         host = fftpack.dst(rows[:1].cpu().numpy(), type=2, axis=-1, norm='ortho')
         np.testing.assert_allclose(dst.forward_analytic(engine, bg, pk)[:1].cpu().numpy(), host, rtol=0, atol=1e-12 * np.abs(host).max())
     assert DST(1024, kx=np.linspace(1e-4, 5., 1024), device=dev).forward_analytic(engine, bg, pk) is None
+
+
+@pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle'])
+def test_forward_transform_that_also_finds_and_rewrites_the_boxes(engine):
+    """cp_dst_forward_analytic_box against the two calls it replaces (cp_dst_forward_analytic with the split layout, then cp_wallish_dd_box in
+    place): same coefficients to the last bit outside the boxes, same boxes, the rewritten knots to 1e-13 of the sequence's scale; odd batches
+    (a cosmology without a partner), a NaN cosmology next to good ones."""
+    import torch
+    from cosmoprimo_amd import _lib, _device as dv
+    from cosmoprimo_amd.dst import DST
+    dev = torch.device('cuda', 0)
+    klin = np.linspace(1e-4, 5., 4096)
+    dst = DST(4096, kx=klin, device=dev)
+    lib = _lib.load()
+    mf, ms, off = 20, 5, (-10, 20)      # the filter's own margins and offsets (bao_filter.py:388-394)
+    for n in (1, 2, 7, 301):
+        rng = np.random.default_rng(n)
+        Om, Ob, h, ns = rng.uniform(.25, .40, n), rng.uniform(.04, .06, n), rng.uniform(.6, .8, n), rng.uniform(.92, 1., n)
+        if n == 7:
+            ns[4] = np.nan
+        bg = dict(h=torch.as_tensor(h, device=dev), Omega_cdm=torch.as_tensor(Om - Ob, device=dev), Omega_b=torch.as_tensor(Ob, device=dev))
+        pk = dict(n_s=torch.as_tensor(ns, device=dev), A_s=torch.as_tensor(rng.uniform(1.8e-9, 2.4e-9, n), device=dev))
+        plain = dst.forward_analytic(engine, bg, pk, split=True)
+        y = plain.clone().view(2 * n, 2048)
+        box_ref = torch.empty((2 * n, 2), dtype=torch.int32, device=dev)
+        _lib.check(lib.cp_wallish_dd_box(y.data_ptr(), 2 * n, 2048, mf, ms, off[0], off[1], box_ref.data_ptr(), None, y.data_ptr(), 0, dv.stream_of(dev)))
+        got, box = dst.forward_analytic(engine, bg, pk, split=True, box=(mf, ms, off[0], off[1]))
+        got, box, y, box_ref, plain = (v.cpu().numpy() for v in (got.view(2 * n, 2048), box, y, box_ref, plain.view(2 * n, 2048)))
+        good = np.isfinite(plain).all(axis=1)
+        assert good.sum() == 2 * n - (2 if n == 7 else 0)
+        assert np.array_equal(box[good], box_ref[good])
+        assert np.array_equal(np.isnan(got), np.isnan(y))
+        for i in np.flatnonzero(good):
+            a, b = box[i]
+            inside = np.zeros(2048, dtype=bool)
+            if a >= 1 and b <= 2046 and b >= a:
+                inside[a:b + 1] = True
+                assert not np.array_equal(got[i, inside], plain[i, inside])          # the box was rewritten
+            assert np.array_equal(got[i, ~inside], plain[i, ~inside])
+            assert np.abs(got[i, inside] - y[i, inside]).max(initial=0.) <= 1e-13 * np.abs(plain[i]).max()
