@@ -1,49 +1,102 @@
-"""LeastSquareSolver (host numpy): the reference's own known-answer identities (tests/test_utils.py:8-60)
-and agreement with the oracle's restatement."""
+"""LeastSquareSolver (host numpy; reference utils.py:144-272): properties a weighted, linearly constrained least-squares fit must
+have -- normal equations, constraints met exactly, the unconstrained optimum never beaten, closed forms for polynomial data, stacks of data
+vectors -- and agreement with the oracle's restatement on the constrained fit the BAO filters make."""
 import numpy as np
+import pytest
 
 from oracle import bao as obao
 
 
-def test_least_squares():
+def _basis(x):
+    return np.array([x**p for p in (-1., 0., 1., 2.)])      # four smooth functions, (4, nx)
+
+
+@pytest.mark.parametrize('compute_inverse', [False, True])
+@pytest.mark.parametrize('weights', ['scalar', 'vector', 'matrix'])
+def test_unconstrained_fit_solves_the_normal_equations(compute_inverse, weights):
     from cosmoprimo_amd.utils import LeastSquareSolver
-    for compute_inverse in [False, True]:
-        x = np.linspace(1, 100, 10)
-        gradient = np.array([1. / x, np.ones_like(x), x, x ** 2, x ** 3])
-        rng = np.random.RandomState(seed=42)
-        y = rng.uniform(0., 1., x.size)
-        for cov in [np.diag(x), np.diag(x) + 0.1]:
-            precision = np.linalg.inv(cov)
-            solver = LeastSquareSolver(gradient, precision, compute_inverse=compute_inverse)
-            result = solver(y)
-            # normal equations: gradient F (y - p gradient) = 0
-            np.testing.assert_allclose(gradient.dot(precision).dot(y - result.dot(gradient)), 0., atol=1e-8)
-            lss_c = LeastSquareSolver(gradient, precision, constraint_gradient=np.ones((len(gradient), 1)), compute_inverse=compute_inverse)
-            result = lss_c(y, constraint=0.42)
-            assert lss_c.chi2() >= solver.chi2()
-            assert np.allclose(sum(result), 0.42)
-            weights = np.arange(len(gradient))
-            lss_c = LeastSquareSolver(gradient, precision, constraint_gradient=np.column_stack([np.ones(len(gradient)), weights]), compute_inverse=compute_inverse)
-            result = lss_c(y, constraint=[0.42, 2.])
-            assert lss_c.chi2() >= solver.chi2()
-            assert np.allclose(sum(result), 0.42) and np.allclose(sum(r * w for r, w in zip(result, weights)), 2.)
-        result_ref = LeastSquareSolver(gradient, precision=np.eye(x.size), compute_inverse=compute_inverse)(y)
-        for precision in [1., np.ones_like(x)]:
-            assert np.allclose(LeastSquareSolver(gradient, precision=precision, compute_inverse=compute_inverse)(y), result_ref)
-        solver = LeastSquareSolver(gradient, precision=np.eye(x.size), compute_inverse=compute_inverse)
-        ys = np.array([y] * 12)
-        result = solver(ys)
-        assert result.shape == (len(ys), len(gradient)) and np.allclose(result, result_ref)
-        assert solver.model().shape == ys.shape and solver.chi2().shape == (len(ys),)
-        solver = LeastSquareSolver(np.ones_like(x), precision=np.eye(x.size), compute_inverse=compute_inverse)
-        assert solver(y).ndim == 0 and solver(ys).shape == (len(ys),)
-    # the constrained fit of the BAO filters: same model as the oracle's restatement
+    rng = np.random.default_rng(7)
+    x = np.linspace(0.5, 3., 23)
+    gradient = _basis(x)
+    data = rng.normal(size=x.size)
+    if weights == 'scalar':
+        given, full = 2.5, 2.5 * np.eye(x.size)
+    elif weights == 'vector':
+        given = rng.uniform(0.5, 2., x.size)
+        full = np.diag(given)
+    else:
+        a = rng.normal(size=(x.size, x.size))
+        given = full = a.dot(a.T) + x.size * np.eye(x.size)      # a dense, positive-definite precision matrix
+    solver = LeastSquareSolver(gradient, given, compute_inverse=compute_inverse)
+    coefficients = solver(data)
+    residual = data - coefficients.dot(gradient)
+    assert np.abs(gradient.dot(full).dot(residual)).max() < 1e-9 * np.abs(gradient.dot(full).dot(data)).max()
+    np.testing.assert_allclose(solver.model(), coefficients.dot(gradient), rtol=1e-13)
+    np.testing.assert_allclose(solver.chi2(), residual.dot(full).dot(residual), rtol=1e-10)
+    # data inside the span of the basis are reproduced, whatever the weights
+    truth = np.array([0.3, -1.2, 0.7, 0.05])
+    np.testing.assert_allclose(solver(truth.dot(gradient)), truth, rtol=1e-8, atol=1e-10)
+    assert solver.chi2() < 1e-16 * truth.dot(gradient).dot(full).dot(truth.dot(gradient))
+
+
+@pytest.mark.parametrize('compute_inverse', [False, True])
+def test_constraints_are_met_and_cost_something(compute_inverse):
+    from cosmoprimo_amd.utils import LeastSquareSolver
+    rng = np.random.default_rng(11)
+    x = np.linspace(1., 4., 17)
+    gradient = _basis(x)
+    data = rng.normal(size=x.size)
+    precision = np.diag(rng.uniform(0.5, 2., x.size))
+    free = LeastSquareSolver(gradient, precision, compute_inverse=compute_inverse)
+    free(data)
+    # one constraint: the fitted curve goes through a given value at x[0]; two: also a given slope between the first two samples
+    through = gradient[:, :1]
+    one = LeastSquareSolver(gradient, precision, constraint_gradient=through, compute_inverse=compute_inverse)
+    c1 = one(data, constraint=1.75)
+    np.testing.assert_allclose(c1.dot(gradient)[0], 1.75, rtol=1e-11)
+    both = np.column_stack([gradient[:, 0], gradient[:, 1] - gradient[:, 0]])
+    two = LeastSquareSolver(gradient, precision, constraint_gradient=both, compute_inverse=compute_inverse)
+    c2 = two(data, constraint=[1.75, -0.2])
+    fitted = c2.dot(gradient)
+    np.testing.assert_allclose([fitted[0], fitted[1] - fitted[0]], [1.75, -0.2], rtol=1e-10)
+    assert free.chi2() <= one.chi2() * (1. + 1e-12) <= two.chi2() * (1. + 1e-12)
+    # constraints the free optimum already meets change nothing
+    best = free(data)
+    same = one(data, constraint=best.dot(gradient)[0])
+    np.testing.assert_allclose(same, best, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('compute_inverse', [False, True])
+def test_stacks_of_data_vectors_and_a_single_template(compute_inverse):
+    from cosmoprimo_amd.utils import LeastSquareSolver
+    rng = np.random.default_rng(3)
+    x = np.linspace(1., 2., 9)
+    gradient = _basis(x)
+    stack = rng.normal(size=(5, x.size))
+    solver = LeastSquareSolver(gradient, np.eye(x.size), compute_inverse=compute_inverse)
+    together = solver(stack)
+    assert together.shape == (5, 4) and solver.model().shape == stack.shape and solver.chi2().shape == (5,)
+    chi2 = solver.chi2().copy()
+    for i, row in enumerate(stack):
+        np.testing.assert_allclose(solver(row), together[i], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(solver.chi2(), chi2[i], rtol=1e-10)
+    # one template: the coefficient is a number (an array over the stack), the weighted mean of data / template
+    template = 1. + x
+    single = LeastSquareSolver(template, np.eye(x.size), compute_inverse=compute_inverse)
+    amplitude = single(stack[0])
+    assert np.ndim(amplitude) == 0 and single(stack).shape == (5,)
+    np.testing.assert_allclose(amplitude, stack[0].dot(template) / template.dot(template), rtol=1e-12)
+
+
+def test_the_constrained_fit_of_the_bao_filters_against_the_oracle():
+    """Polynomial x 1 / k broad band pinned to its value and first difference at both ends (bao_filter.py:461-472): same model as oracle/bao.py."""
+    from cosmoprimo_amd.utils import LeastSquareSolver
     k = np.geomspace(1e-3, 1., 50)
     gradient = np.array([k**(i - 1) for i in range(4)])
-    cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
-    d = 1. + 0.05 * np.sin(40. * k)
-    c = [d[0], d[1] - d[0], d[-1], d[-2] - d[-1]]
-    s = LeastSquareSolver(gradient, precision=k**2, constraint_gradient=cg, compute_inverse=False)
-    s(d, constraint=c)
-    np.testing.assert_allclose(s.model(), obao.least_squares_constrained(gradient, k**2, cg, d, c), rtol=1e-12)
-    np.testing.assert_allclose(s.model()[[0, -1]], d[[0, -1]], rtol=1e-10)
+    ends = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+    data = 1. + 0.05 * np.sin(40. * k)
+    pinned = [data[0], data[1] - data[0], data[-1], data[-2] - data[-1]]
+    solver = LeastSquareSolver(gradient, precision=k**2, constraint_gradient=ends, compute_inverse=False)
+    solver(data, constraint=pinned)
+    np.testing.assert_allclose(solver.model(), obao.least_squares_constrained(gradient, k**2, ends, data, pinned), rtol=1e-12)
+    np.testing.assert_allclose(solver.model()[[0, -1]], data[[0, -1]], rtol=1e-10)
