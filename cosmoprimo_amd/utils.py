@@ -14,69 +14,74 @@ from .interpolator import Interpolator1D
 
 class LeastSquareSolver(_Copyable):
     r"""
-    Solve :math:`d\chi^2 / d\mathbf{p} = 0` for
-    :math:`\chi^2 = (\delta - \mathbf{p} \cdot \mathrm{grad})^T \mathbf{F} (\delta - \mathbf{p} \cdot \mathrm{grad})`, optionally
-    under linear equality constraints :math:`\mathbf{p} \cdot \mathrm{cgrad} = c` (reference utils.py:144-272).
+    Weighted linear least squares, optionally under linear equality constraints: the coefficients :math:`\mathbf{p}` that minimise
+    :math:`\chi^2 = (\delta - \mathbf{p} G)^T F (\delta - \mathbf{p} G)` subject to :math:`\mathbf{p} C = c`
+    (same constructor, call, ``model`` and ``chi2`` as the reference's class, utils.py:144-272).
+
+    The stationarity conditions with Lagrange multipliers are one linear system, the Karush-Kuhn-Tucker matrix
+    :math:`K = \begin{pmatrix} G F G^T & -C \\ C^T & 0 \end{pmatrix}` acting on (coefficients, multipliers) with right-hand side
+    :math:`(G F \delta, c)`; the data enter linearly, so the solve is a fixed matrix applied to (data, constraint values), kept as
+    ``projector`` when ``compute_inverse`` is set (many data vectors) and redone with ``numpy.linalg.solve`` per call otherwise.
     """
     def __init__(self, gradient, precision=1., constraint_gradient=None, compute_inverse=True):
-        self.gradient = np.atleast_1d(np.asarray(gradient, dtype='f8'))
-        self.isscalar = self.gradient.ndim == 1
-        if self.isscalar:
-            self.gradient = self.gradient[None, :]
-        elif self.gradient.ndim != 2:
+        basis = np.asarray(gradient, dtype='f8')
+        if basis.ndim > 2:
             raise ValueError('gradient must be at most 2D')
+        self.isscalar = basis.ndim < 2          # one template: the coefficient is returned without its axis
+        self.gradient = basis.reshape(-1, basis.shape[-1]) if basis.ndim else basis.reshape(1, 1)
+        nparams, ndata = self.gradient.shape
         self.precision = np.asarray(precision, dtype='f8')
-        hv = self.gradient * self.precision if self.precision.ndim < 2 else self.gradient.dot(self.precision)
-        invfisher = hv.dot(self.gradient.T)
-        if constraint_gradient is None:
-            self.nconstraints = 0
-        else:
-            cg = np.atleast_2d(np.asarray(constraint_gradient, dtype='f8'))
-            self.nconstraints = cg.shape[-1]
-            if cg.ndim != 2 or cg.shape[0] != self.gradient.shape[0]:
+        # G F: a full precision matrix multiplies from the right, a scalar or a diagonal scales the columns
+        weighted = self.gradient.dot(self.precision) if self.precision.ndim == 2 else self.gradient * self.precision
+        normal = weighted.dot(self.gradient.T)
+        self.nconstraints = 0
+        if constraint_gradient is not None:
+            columns = np.atleast_2d(np.asarray(constraint_gradient, dtype='f8'))
+            if columns.ndim != 2 or columns.shape[0] != nparams:
                 raise ValueError('constraint_gradient must be 2D, of first dimension the number of model parameters (gradient first dimension)')
-            nc = self.nconstraints
-            invfisher = np.block([[invfisher, -cg], [cg.T, np.zeros((nc, nc))]])     # bordered normal matrix (reference :211-214)
-            hv = np.block([[hv, np.zeros(cg.shape)], [np.zeros((nc, self.gradient.shape[-1])), np.eye(nc)]])
-        self.inverse_fisher = invfisher
-        self.gradient_precision = hv
+            nc = self.nconstraints = columns.shape[1]
+            kkt = np.zeros((nparams + nc,) * 2)
+            kkt[:nparams, :nparams], kkt[:nparams, nparams:], kkt[nparams:, :nparams] = normal, -columns, columns.T
+            load = np.zeros((nparams + nc, ndata + nc))      # (data, constraint values) -> right-hand side
+            load[:nparams, :ndata] = weighted
+            load[nparams:, ndata:] = np.eye(nc)
+            normal, weighted = kkt, load
+        self.inverse_fisher, self.gradient_precision = normal, weighted
         if compute_inverse:
-            fisher = np.linalg.inv(invfisher)
-            tmp = fisher.dot(invfisher)
-            if not np.allclose(tmp, np.eye(tmp.shape[0]), rtol=1e-04, atol=1e-04):
+            inverse = np.linalg.inv(normal)
+            defect = np.abs(inverse.dot(normal) - np.eye(normal.shape[0])).max()
+            if not defect <= 1e-4:
                 import warnings
-                warnings.warn('Numerically inaccurate inverse matrix, max absolute diff {:.6f}.'.format(np.max(np.abs(tmp - np.eye(tmp.shape[0])))))
-            self.projector = fisher.dot(hv).T
+                warnings.warn('Numerically inaccurate inverse matrix, max absolute diff {:.6f}.'.format(defect))
+            self.projector = inverse.dot(weighted).T
 
     def compute(self, delta, constraint=None):
-        """Solve the least-square problem for ``delta`` (..., ndata)."""
-        self.delta = delta = np.atleast_1d(np.asarray(delta, dtype='f8'))
+        """Solve for the data vector(s) ``delta`` (..., ndata), with the constraint values ``constraint`` if the solver has constraints."""
+        self.delta = np.atleast_1d(np.asarray(delta, dtype='f8'))
+        loaded = self.delta
         if constraint is not None:
-            constraint = np.atleast_1d(np.asarray(constraint, dtype='f8'))
-            delta = np.concatenate([self.delta, np.broadcast_to(constraint, self.delta.shape[:-1] + constraint.shape[-1:])], axis=-1)
-        if hasattr(self, 'projector'):
-            params = delta.dot(self.projector)
+            values = np.atleast_1d(np.asarray(constraint, dtype='f8'))
+            loaded = np.concatenate([loaded, np.broadcast_to(values, loaded.shape[:-1] + values.shape[-1:])], axis=-1)
+        if 'projector' in self.__dict__:
+            solution = loaded.dot(self.projector)
         else:
-            params = np.linalg.solve(self.inverse_fisher, self.gradient_precision.dot(delta.T)).T
-        self.params = params[..., :self.gradient.shape[0]]
+            solution = np.linalg.solve(self.inverse_fisher, self.gradient_precision.dot(loaded.T)).T
+        self.params = solution[..., :self.gradient.shape[0]]      # (the multipliers behind them are not kept)
 
     def __call__(self, delta, constraint=None):
-        """Best-fit parameters."""
+        """Best-fit coefficients, (..., nparams); (...) for a single template."""
         self.compute(delta, constraint=constraint)
-        if self.isscalar:
-            return self.params[..., 0]
-        return self.params
+        return self.params[..., 0] if self.isscalar else self.params
 
     def model(self):
-        """Model at the best fit."""
+        """The fitted model, (..., ndata)."""
         return self.params.dot(self.gradient)
 
     def chi2(self):
-        r""":math:`\chi^2` at the best fit."""
-        delta = self.delta - self.model()
-        if self.precision.ndim < 2:
-            return ((delta * self.precision) * delta).sum(axis=-1)
-        return (delta.dot(self.precision) * delta).sum(axis=-1)
+        r""":math:`\chi^2` of the fit, (...)."""
+        residual = self.delta - self.model()
+        weighted = residual.dot(self.precision) if self.precision.ndim == 2 else residual * self.precision
+        return (weighted * residual).sum(axis=-1)
 
 
 class DistanceToRedshift(_Copyable):
