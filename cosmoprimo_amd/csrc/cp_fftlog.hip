@@ -225,7 +225,7 @@ static int execute_impl(const cp_fftlog_plan* p, const double* d_in, double* d_o
     A.val_l = val_left;
     A.val_r = val_right;
     // once-read / once-written rows bypass the caches when the launch moves more than the Infinity Cache (256 MB) can keep for a consumer
-    A.stream_rows = (double)nbatch * p->nker * ((double)p->n + A.n_out) * 8. > 512. * 1024. * 1024.;
+    A.stream_rows = (double)nbatch * p->nker * ((double)p->n + A.n_out) * 8. > 512. * 1024. * 1024. ? 3 : 0;
     A.pre = p->d_pre;
     A.post = p->d_post;
     A.u = p->d_u;
@@ -239,7 +239,7 @@ static int execute_impl(const cp_fftlog_plan* p, const double* d_in, double* d_o
         variant = VAR_HALF_ZERO_WINDOW;
         A.out_first = out_first;
         A.out_last = out_first + out_count;
-        A.stream_rows = (double)nbatch * p->nker * ((double)p->n + out_count) * 8. > 512. * 1024. * 1024.;
+        A.stream_rows = (double)nbatch * p->nker * ((double)p->n + out_count) * 8. > 512. * 1024. * 1024. ? 3 : 0;
     }
     const int grid = grid_for(p, variant, nbatch);
     // the kernel walks the rows with 32-bit element steps (cp_fftlog_kernel.h: PairWalk): nker rows, and 2 grid rows, of

@@ -82,7 +82,7 @@ struct FftlogArgs {
     int n_out;          // output row length (n or NP)
     int ext_l, ext_r;   // CP_EXTRAP_*
     double val_l, val_r;
-    int stream_rows;    // != 0: the rows are moved with the non-temporal cache policy (launches larger than the Infinity Cache)
+    int stream_rows;    // bit 0: the rows are read, bit 1: written with the non-temporal cache policy (3: launches larger than the Infinity Cache)
     const double* pre;  // (nker, NP) padded prefactor
     const double* post; // (nker, NP) padded postfactor
     const cplx* u;      // (nker, NP) Hermitian-extended u / NP in thread layout [(i R + s) T + t]
@@ -339,7 +339,7 @@ struct Fftlog {
             return;
         }
 #endif
-        if (stream_rows && !(CP_ABLATE & 8)) {  // wave-uniform (a kernel argument)
+        if ((stream_rows & 1) && !(CP_ABLATE & 8)) {  // wave-uniform (a kernel argument)
 #pragma unroll
             for (int r = 0; r < H; ++r) {
                 va[r] = ld_row_f64_nt(ra, (unsigned)t * 8u, (unsigned)(T * r) * 8u);
@@ -458,7 +458,7 @@ struct Fftlog {
             for (int s = 0; s < H; ++s) {
                 const int c = t + T * s;
                 if (c >= A.out_first && c < A.out_last) {
-                    if (A.stream_rows) {
+                    if (A.stream_rows & 2) {
                         st_row_f64_nt(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
                         if (has_b) st_row_f64_nt(ob, (unsigned)t * 8u, (unsigned)(T * s) * 8u, yb[s]);
                     } else {
@@ -484,7 +484,7 @@ struct Fftlog {
             return;
         }
 #endif
-        if (A.stream_rows) {  // wave-uniform (a kernel argument)
+        if (A.stream_rows & 2) {  // wave-uniform (a kernel argument)
 #pragma unroll
             for (int s = 0; s < H; ++s) st_row_f64_nt(oa, (unsigned)t * 8u, (unsigned)(T * s) * 8u, ya[s]);
             if (has_b) {

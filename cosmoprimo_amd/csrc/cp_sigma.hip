@@ -913,7 +913,7 @@ extern "C" int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_s
     FftlogArgs& A = R.fft;
     A.in = d_in; A.out = nullptr; A.nbatch = nbatch; A.nker = 1; A.n = f.n; A.in_left = f.in_left; A.out_off = f.out_left; A.n_out = f.n;
     A.ext_l = A.ext_r = CP_EXTRAP_CONST; A.val_l = A.val_r = 0.;
-    A.stream_rows = (double)nbatch * f.n * 8. > 512. * 1024. * 1024.;
+    A.stream_rows = (double)nbatch * f.n * 8. > 512. * 1024. * 1024. ? 3 : 0;
     A.pre = f.d_pre; A.post = f.d_post; A.u = f.d_u; A.tw = f.d_tw;
     R.wb = b.d_wb; R.j0 = b.d_j0; R.bw = b.bw; R.nq = b.nq; R.post_sqrt = post_op == CP_SPLINE_POST_SQRT;
     R.out = d_out;
@@ -1066,7 +1066,7 @@ extern "C" int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const c
     FftlogArgs& A = R.fft;
     A.in = d_in; A.out = nullptr; A.nbatch = nbatch; A.nker = 1; A.n = f.n; A.in_left = f.in_left; A.out_off = f.out_left; A.n_out = f.n;
     A.ext_l = A.ext_r = CP_EXTRAP_CONST; A.val_l = A.val_r = 0.;
-    A.stream_rows = (double)nbatch * f.n * 8. > 512. * 1024. * 1024.;
+    A.stream_rows = (double)nbatch * f.n * 8. > 512. * 1024. * 1024. ? 3 : 0;
     A.pre = f.d_pre; A.post = f.d_post; A.u = f.d_u; A.tw = f.d_tw;
     R.ws = spline->ws; R.ne = spline->ne; R.S = spline->S; R.nq = spline->nq; R.post_sqrt = post_op == CP_SPLINE_POST_SQRT; R.group = group;
     R.ntables = group > 0 ? (int)(nbatch / group) : (int)((nbatch + 1) / 2);

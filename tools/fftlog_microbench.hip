@@ -30,8 +30,8 @@ using namespace cpfft;
 #ifndef MB_GENERIC  // 1: the generic front / back ends; 2: the HALF front end with 'edge' padding; 0: HALF_ZERO (flagship)
 #define MB_GENERIC 0
 #endif
-#ifndef MB_STREAM_ROWS  // non-temporal row accesses (what cp_fftlog_execute selects for launches of this size)
-#define MB_STREAM_ROWS 1
+#ifndef MB_STREAM_ROWS  // non-temporal row accesses, bit 0 loads, bit 1 stores (3: what cp_fftlog_execute selects for launches of this size)
+#define MB_STREAM_ROWS 3
 #endif
 #ifndef MB_WGS_PER_CU
 #define MB_WGS_PER_CU 2
