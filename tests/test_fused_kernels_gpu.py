@@ -409,3 +409,31 @@ def test_tables_rows_direct(shape, post):
         _lib.check(lib.cp_tables_rows_direct(kplan._handle, opz._handle, t2.data_ptr(), m2.data_ptr(), out.data_ptr(), nb, code, 1., dv.stream_of(dev)))
         again = out.cpu().numpy()
         assert np.isnan(again[1]).any() and np.array_equal(np.delete(again, 1, axis=0), np.delete(got, 1, axis=0), equal_nan=True)
+
+
+def test_round4_entry_points_take_empty_batches():
+    """Zero rows / cosmologies / pairs through every entry point added in round 4: CP_OK, nothing launched, outputs of the right (empty) shape."""
+    torch, _lib, lib, dv, dev = _env()
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import interpolator as itp
+    from cosmoprimo_amd.dst import DST
+    from cosmoprimo_amd.fftlog import NumpyFFTEngine
+    k = np.geomspace(1e-7, 1e2, 1024)
+    fft = cp.TophatVariance(k, device=dev)
+    empty = torch.empty((0, 1024), dtype=torch.float64, device=dev)
+    out = itp._fftlog_then_geospline(fft, fft.y[0], np.array([8., 20.]), empty, dev)
+    assert out is not None and tuple(out.shape) == (0, 2)
+    grouped = itp._fftlog_then_geospline(fft, fft.y[0], np.array([8., 20.]), empty.reshape(0, 4, 1024), dev, group=4)
+    assert grouped is not None and tuple(grouped.shape) == (0, 2, 4)
+    assert NumpyFFTEngine(64).forward(np.empty((0, 64))).shape == (0, 33)
+    assert NumpyFFTEngine(64).backward(np.empty((3, 0, 33), dtype='c16')).shape == (3, 0, 64)
+    for name, args in (('cp_derived_parameters', (0, None, None, 0, None)),
+                       ('cp_bilinear_pairs', (None, None, None, None, 0, 5, 4, 3, 0, None)),
+                       ('cp_variants_scalars', (0, None, 0, None, None, 0, None))):
+        assert getattr(lib, name)(*args) == _lib.CP_OK, name
+    none = torch.empty(0, dtype=torch.float64, device=dev)
+    bg = dict(h=none, Omega_cdm=none, Omega_b=none)
+    rs, amp, spectra, kk = itp.sigma8_normalise('eisenstein_hu', bg, dict(n_s=none), 0.8, dev)
+    assert tuple(rs.shape) == (0,) and tuple(amp.shape) == (0,) and tuple(spectra.shape) == (0, 1024) and kk.shape == (1024,)
+    coefficients = DST(4096, kx=np.linspace(1e-4, 5., 4096), device=dev).forward_analytic('eisenstein_hu', bg, dict(n_s=none))
+    assert tuple(coefficients.shape) == (0, 4096)

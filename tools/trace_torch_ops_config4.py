@@ -75,6 +75,8 @@ def main():
         print('==== %s: %d aten ops that launch kernels in one chunk of %d (%d ops in all)' % (engine, sum(launching.values()), chunk, sum(log.sites.values())))
         for (op, where), n in sorted(launching.items(), key=lambda kv: kv[0][1]):
             print('%3d  %-34s %s' % (n, op.replace('aten.', ''), where))
+        copies = {k: v for k, v in log.sites.items() if 'copy' in k[0] or 'zeros' in k[0] or 'scalar_tensor' in k[0] or 'full' in k[0]}
+        print('     (of which copies / fills: %s)' % ', '.join('%s x%d @ %s' % (k[0].replace('aten.', ''), v, k[1]) for k, v in sorted(copies.items(), key=lambda kv: kv[0][1])))
 
 
 if __name__ == '__main__':
