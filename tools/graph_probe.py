@@ -17,7 +17,7 @@ def main():
     engine = sys.argv[1] if len(sys.argv) > 1 else 'wallish2018'
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
-    n = 16384
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else bench.CONFIG4_CHUNK
     par = bench.eh_parameters(2 * n, 2, torch, dev)
     static = {name: v[:n].clone() for name, v in par.items()}
     warnings.simplefilter('ignore')
