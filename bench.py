@@ -338,10 +338,10 @@ def secondary(cp, torch, dev):
     out = {'config3': config3(cp, torch, dev)}
     out['config3b'] = config3b(cp, torch, dev)
     torch.cuda.empty_cache()
-    c4 = config4(cp, torch, dev, eh_parameters(2 * CONFIG4_CHUNK, 2, torch, dev))
-    out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on %d EH98 P(k) vectors (two %d-vector chunks of a GPU share of 125 000, '
-                                         'queued back to back as the whole share is), P(k) generation and sigma8 normalisation included, results resident'
-                                         % (2 * CONFIG4_CHUNK, CONFIG4_CHUNK))
+    share = 125000      # one GPU's share of the 1 M vectors of BASELINE config 4
+    c4 = config4(cp, torch, dev, eh_parameters(share, 2, torch, dev))
+    out['config4'] = dict(c4, workload='config 4: wallish2018 and brieden2022 on the %d EH98 P(k) vectors of one GPU (an eighth of 1 M), in chunks of %d queued '
+                                         'back to back, P(k) generation and sigma8 normalisation included, results resident' % (share, CONFIG4_CHUNK))
     out['config5'] = config5(torch, dev, *config5_samples(1250000, 3, torch, dev))
     return out
 
