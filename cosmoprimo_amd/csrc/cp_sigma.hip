@@ -727,9 +727,10 @@ struct FunctionalArgs {
 // the fiducial amplitude -- P(k) x the functional of r = 8, x the CPT92 growth factor at z = 0 squared (Background.growth_factor(0, znorm=0),
 // eisenstein_hu.py:134-139), evaluated here instead of by a launch of the background kernel --, the factor rsigma8 = sigma8 / that, the normalised
 // amplitude A_s rsigma8^2, and the spectra at the NORMALISED amplitude (P is linear in A_s): what the engine hands to the filters next, with no
-// pass over (ncosmo, 1024) arrays behind the kernel.  1024 wavenumbers: a lane keeps its 16 samples in registers until the factor is known.
+// pass over (ncosmo, 1024) arrays behind the kernel.  1024 wavenumbers: a lane keeps its 16 samples in LDS (its own slots: no barrier) until the factor
+// is known -- in registers they put the kernel at 190 VGPRs, two waves per SIMD, where the evaluation runs best at three (power_kernel).
 template <int ENGINE>
-__global__ __launch_bounds__(256) void sigma8_normalise_kernel(const FunctionalArgs S) {
+__global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const FunctionalArgs S) {      // three waves per SIMD, as power_kernel (the evaluation is the same)
     constexpr int PER_LANE = 16;      // nk = 1024
     const int lane = threadIdx.x & 63;
     const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -743,7 +744,8 @@ __global__ __launch_bounds__(256) void sigma8_normalise_kernel(const FunctionalA
     const EhPerCosmology eh = eh_per_cosmology(s, c.h);
     const PkPerCosmology pc = pk_per_cosmology(c, pw);
     double acc = 0.;
-    double pks[PER_LANE];
+    __shared__ double kept[4 * PER_LANE * 64];
+    double* pks = kept + (threadIdx.x >> 6) * (PER_LANE * 64) + lane;      // sample i of this lane at pks[64 i]
 #pragma unroll 2
     for (int i = 0; i < PER_LANE; ++i) {
         const int j = lane + 64 * i;
@@ -751,8 +753,9 @@ __global__ __launch_bounds__(256) void sigma8_normalise_kernel(const FunctionalA
         double Tk;
         if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
         else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
-        pks[i] = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh);
-        acc = fma(S.functional[j], pks[i], acc);
+        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh);
+        pks[64 * i] = pk;
+        acc = fma(S.functional[j], pk, acc);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
@@ -766,7 +769,7 @@ __global__ __launch_bounds__(256) void sigma8_normalise_kernel(const FunctionalA
     }
     if (S.pk_out) {
 #pragma unroll
-        for (int i = 0; i < PER_LANE; ++i) S.pk_out[ic * 1024 + lane + 64 * i] = pks[i] * rs2;
+        for (int i = 0; i < PER_LANE; ++i) S.pk_out[ic * 1024 + lane + 64 * i] = pks[64 * i] * rs2;
     }
 }
 
