@@ -109,6 +109,8 @@ SIGNATURES = {
     'cp_splice_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p,
                                       ctypes.c_void_p, ctypes.c_void_p]),
     'cp_splice_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_splice_plan_scheme': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_splice_plan_set_scheme': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'cp_spline_rows_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                                                  ctypes.c_int]),
     'cp_spline_rows_plan_info': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),

@@ -17,6 +17,7 @@
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
 #include "cp_internal.h"
+#include "cp_splice_uniform.h"
 #include "cp_wallish_dd.h"
 
 namespace {
@@ -526,6 +527,13 @@ struct cp_splice_plan {
     int* d_qcol;
     double* d_qw;
     size_t lds_bytes;
+    // the scheme for knots on a long uniform stretch (cp_splice_uniform.h), where it fits
+    bool has_uniform, use_uniform;
+    cpsu::Tables U;
+    double* d_uwin;
+    double* d_uqw;
+    int* d_uqe;
+    size_t uniform_lds_bytes;
 };
 
 extern "C" int cp_splice_plan_destroy(cp_splice_plan* p) {
@@ -536,6 +544,9 @@ extern "C" int cp_splice_plan_destroy(cp_splice_plan* p) {
         if (p->d_qj) (void)hipFree(p->d_qj);
         if (p->d_qcol) (void)hipFree(p->d_qcol);
         if (p->d_qw) (void)hipFree(p->d_qw);
+        if (p->d_uwin) (void)hipFree(p->d_uwin);
+        if (p->d_uqw) (void)hipFree(p->d_uqw);
+        if (p->d_uqe) (void)hipFree(p->d_uqe);
     }
     delete p;
     return CP_OK;
@@ -675,6 +686,9 @@ extern "C" int cp_splice_plan_create(cp_splice_plan** out, int nknots, const dou
     p->T.generic_end = generic_end;
     p->device = device;
     p->d_tab = nullptr; p->d_qj = nullptr; p->d_qcol = nullptr; p->d_qw = nullptr;
+    p->d_uwin = nullptr; p->d_uqw = nullptr; p->d_uqe = nullptr;
+    p->has_uniform = p->use_uniform = false;
+    p->uniform_lds_bytes = 0;
     p->lds_bytes = lds;
     p->T.n = n; p->T.nq = nq; p->T.S = S; p->T.halo = halo;
     p->T.ntab_left = ntab_left; p->T.uniform_end = uniform_end;
@@ -691,7 +705,37 @@ extern "C" int cp_splice_plan_create(cp_splice_plan** out, int nknots, const dou
         return cp::fail(CP_ENOMEM, "cp_splice_plan_create: cannot place the tables on device %d", device);
     }
     p->T.tab = p->d_tab; p->T.qj = p->d_qj; p->T.qcol = p->d_qcol; p->T.qw = p->d_qw;
+    if (best_hi - best_lo + 1 >= 256) {
+        cpsu::Built built = cpsu::build(n, x, p->T.piece_first, p->T.piece_src, p->T.piece_start, npieces, nq, xq, qj.data(), best_lo, best_hi, generic_first,
+                                        generic_end);
+        if (built.ok) {
+            ok = hipMalloc(&p->d_uwin, built.win.size() * sizeof(double)) == hipSuccess && hipMalloc(&p->d_uqw, built.qw.size() * sizeof(double)) == hipSuccess &&
+                 hipMalloc(&p->d_uqe, built.qe.size() * sizeof(int)) == hipSuccess &&
+                 hipMemcpy(p->d_uwin, built.win.data(), built.win.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(p->d_uqw, built.qw.data(), built.qw.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(p->d_uqe, built.qe.data(), built.qe.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) {
+                cp_splice_plan_destroy(p);
+                return cp::fail(CP_ENOMEM, "cp_splice_plan_create: cannot place the tables on device %d", device);
+            }
+            p->U = built.T;
+            p->U.win = p->d_uwin; p->U.qw = p->d_uqw; p->U.qe = p->d_uqe;
+            p->uniform_lds_bytes = built.lds_bytes;
+            p->has_uniform = p->use_uniform = true;
+        }
+    }
     *out = p;
+    return CP_OK;
+}
+
+// which kernel a plan runs: 0 the elimination in LDS (any knots), 1 the recursions on a uniform stretch (cp_splice_uniform.h; the default where it fits)
+extern "C" int cp_splice_plan_scheme(const cp_splice_plan* p) { return p && p->use_uniform ? 1 : 0; }
+
+extern "C" int cp_splice_plan_set_scheme(cp_splice_plan* p, int scheme) {
+    if (!p) return cp::fail(CP_EINVAL, "cp_splice_plan_set_scheme: null plan");
+    if (scheme != 0 && scheme != 1) return cp::fail(CP_EINVAL, "cp_splice_plan_set_scheme: unknown scheme %d", scheme);
+    if (scheme == 1 && !p->has_uniform) return cp::fail(CP_EUNSUPPORTED, "cp_splice_plan_set_scheme: the knots and queries of this plan do not fit the uniform-stretch kernel");
+    p->use_uniform = scheme == 1;
     return CP_OK;
 }
 
@@ -711,13 +755,21 @@ extern "C" int cp_splice_apply(const cp_splice_plan* p, const double* d_src0, in
     if ((nrows + 3) / 4 > 2147483647LL) return cp::fail(CP_EUNSUPPORTED, "cp_splice_apply: too many rows for one launch");
     DeviceScope scope(p->device);
     if (!scope.ok) return cp::fail(CP_EDEVICE, "cp_splice_apply: cannot select device %d", p->device);
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;
+    const long long blocks = (nrows + 3) / 4;
+    if (p->use_uniform) {
+        cpsu::Args U;
+        U.T = p->U;
+        U.src0 = d_src0; U.src1 = d_src1 ? d_src1 : d_src0; U.n0 = n0; U.n1 = d_src1 ? n1 : n0; U.nrows = nrows; U.tophat = d_tophat; U.out = d_out;
+        const hipError_t e = cpsu::launch(U, (unsigned)(blocks < ncu ? blocks : ncu), p->uniform_lds_bytes, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_splice_apply: launch failed: %s", hipGetErrorString(e));
+        return CP_OK;
+    }
     SpliceArgs A;
     A.T = p->T;
     A.src0 = d_src0; A.src1 = d_src1 ? d_src1 : d_src0; A.n0 = n0; A.n1 = d_src1 ? n1 : n0; A.nrows = nrows; A.tophat = d_tophat; A.out = d_out;
     (void)cp::allow_full_lds<&splice_kernel>();
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;
-    const long long blocks = (nrows + 3) / 4;
     const long long per_cu = p->lds_bytes ? (160 * 1024) / (long long)p->lds_bytes : 1;
     const long long resident = (long long)ncu * (per_cu < 1 ? 1 : per_cu);
     hipLaunchKernelGGL(splice_kernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(256), p->lds_bytes, static_cast<hipStream_t>(stream), A);

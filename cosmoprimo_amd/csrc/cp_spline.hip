@@ -1114,6 +1114,10 @@ struct TablesDirectArgs {
     double scale;
 };
 
+#ifndef CP_TABLES_ABLATE      // diagnostic builds (tools/tables_ablate.sh; wrong results): 1 no stores, 2 no exponential, 4 no z contraction, 8 no table loads
+#define CP_TABLES_ABLATE 0
+#endif
+
 template <int POST>
 __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const TablesDirectArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -1170,6 +1174,10 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    if (CP_TABLES_ABLATE & 8) {
+                        lt[i][r] = w.x * (double)rowoff[i][r] + w.y;
+                        continue;
+                    }
                     const v2u y = *reinterpret_cast<const v2u*>(tb + rowoff[i][r] + jq), m = *reinterpret_cast<const v2u*>(mb + rowoff[i][r] + jq);
                     lt[i][r] = w.x * y.x + w.y * y.y + (w.z * m.x + w.w * m.y);
                 }
@@ -1177,10 +1185,15 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) r2[mi] = cp_v4d{0., 0., 0., 0.};
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < ((CP_TABLES_ABLATE & 4) ? 1 : 8); ++kk)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     r2[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(4 * kk + g) * TABLES_WSTRIDE + 16 * mi + l15], lt[kk >> 2][kk & 3], r2[mi], 0, 0, 0);
+            if (CP_TABLES_ABLATE & 4)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) r2[mi][r] += lt[mi & 1][r];
             const bool full = q0 + 64 * jj + 16 <= A.nq && A.nzq == 64;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
@@ -1189,8 +1202,9 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
                     const int zq = 16 * mi + g + 4 * r;
                     double v = r2[mi][r] * A.scale;
                     if (POST == CP_SPLINE_POST_SQRT) v = sqrt(v);
-                    else if (POST == CP_SPLINE_POST_EXP10) v = exp10_mid(v);
+                    else if (POST == CP_SPLINE_POST_EXP10 && !(CP_TABLES_ABLATE & 2)) v = exp10_mid(v);
                     v = (nanq || ((nan_z >> (4 * mi + r)) & 1u)) ? __builtin_nan("") : v;
+                    if ((CP_TABLES_ABLATE & 1) && v != 12345.678) continue;
                     // written once, read by the next kernel from memory: the non-temporal policy keeps these 5.2 GB (config 3B) from evicting the table
                     // lines the wave comes back to at its next column tile (FETCH_SIZE of this kernel: 5.8 GB with plain stores for 2.4 GB of tables)
                     if (full || (q < A.nq && zq < A.nzq)) __builtin_nontemporal_store(v, ob + zq * A.nq + q);      // (at most 64 rows of nq: 32-bit)

@@ -151,6 +151,15 @@ class SplicedClampedSpline(object):
                                                      as_int_p(count), xq.size, _lib.as_double_p(xq), self.device.index))
         self.nq = xq.size
 
+    @property
+    def scheme(self):
+        """0: elimination in LDS; 1: recursions on a uniform stretch of knots (the default where the knots and queries fit it)."""
+        return int(_lib.load().cp_splice_plan_scheme(self._handle))
+
+    @scheme.setter
+    def scheme(self, scheme):
+        _lib.check(_lib.load().cp_splice_plan_set_scheme(self._handle, int(scheme)))
+
     def __call__(self, rows0, rows1=None, tophat=None):
         """rows0 (nrows, n0), rows1 (nrows, n1) device tensors -> (nrows, nq); ``tophat`` (nq,): rows0 / ((rows0 / spline - 1) tophat + 1)."""
         torch = dv.torch()

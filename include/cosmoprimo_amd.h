@@ -388,6 +388,11 @@ int cp_splice_plan_create(cp_splice_plan** plan, int nknots, const double* x, in
 int cp_splice_apply(const cp_splice_plan* plan, const double* d_src0, int n0, const double* d_src1, int n1, long long nrows, const double* d_tophat,
                     double* d_out, void* stream);
 int cp_splice_plan_destroy(cp_splice_plan* plan);
+/* Which kernel the plan runs: 0 the elimination in LDS (any knots); 1 two first-order recursions per lane in registers, for plans most of whose knots
+ * lie on a uniform grid with every spline query inside that stretch or in the interval on either side of it (wallish2018: 3 051 of 3 666 knots;
+ * csrc/cp_splice_uniform.h) -- the default where it fits.  cp_splice_plan_set_scheme(plan, 1) returns CP_EUNSUPPORTED where it does not. */
+int cp_splice_plan_scheme(const cp_splice_plan* plan);
+int cp_splice_plan_set_scheme(cp_splice_plan* plan, int scheme);
 
 /* ---- natural / clamped cubic spline of very many rows by elimination in LDS (csrc/cp_spline_rows.hip) ----
  * The same function as cp_spline_plan_create(bc, nu = 0) + cp_spline_apply / cp_spline_apply_grouped

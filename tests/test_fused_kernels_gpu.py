@@ -305,17 +305,52 @@ def test_spliced_clamped_spline():
     tophat = np.ones_like(k)
     tophat[k > 1.] *= np.exp(-20.**2 * (k[k > 1.] - 1.)**2)
     op = SplicedClampedSpline(knots, pieces, k, device=dev)
-    got = op(torch.as_tensor(pk, device=dev), torch.as_tensor(lin, device=dev)).cpu().numpy()
-    damped = op(torch.as_tensor(pk, device=dev), torch.as_tensor(lin, device=dev), tophat=torch.as_tensor(tophat, device=dev)).cpu().numpy()
-    for i in range(nrows):
-        values = np.concatenate([pk[i][left], lin[i][mask], pk[i][right]])
-        ref = interpolate.CubicSpline(knots, values, bc_type='clamped', extrapolate=False)(k)
-        np.testing.assert_allclose(got[i], ref, rtol=1e-11)
-        np.testing.assert_allclose(damped[i], pk[i] / ((pk[i] / ref - 1.) * tophat + 1.), rtol=1e-11)
-    bad = pk.copy()
-    bad[4, 3] = np.nan
-    gotb = op(torch.as_tensor(bad, device=dev), torch.as_tensor(lin, device=dev)).cpu().numpy()
-    assert np.isnan(gotb[4]).any() and np.array_equal(np.delete(gotb, 4, axis=0), np.delete(got, 4, axis=0))
+    assert op.scheme == 1      # 3 051 of the 3 666 knots on a uniform grid, every spline query inside: the recursions of cp_splice_uniform.h
+    refs = [interpolate.CubicSpline(knots, np.concatenate([pk[i][left], lin[i][mask], pk[i][right]]), bc_type='clamped', extrapolate=False)(k) for i in range(nrows)]
+    for scheme in (1, 0):      # ... and the elimination in LDS on the same plan
+        op.scheme = scheme
+        assert op.scheme == scheme
+        got = op(torch.as_tensor(pk, device=dev), torch.as_tensor(lin, device=dev)).cpu().numpy()
+        damped = op(torch.as_tensor(pk, device=dev), torch.as_tensor(lin, device=dev), tophat=torch.as_tensor(tophat, device=dev)).cpu().numpy()
+        for i in range(nrows):
+            np.testing.assert_allclose(got[i], refs[i], rtol=1e-11)
+            np.testing.assert_allclose(damped[i], pk[i] / ((pk[i] / refs[i] - 1.) * tophat + 1.), rtol=1e-11)
+        bad = pk.copy()
+        bad[4, 400] = np.nan      # (one of the knots in front of the uniform stretch)
+        gotb = op(torch.as_tensor(bad, device=dev), torch.as_tensor(lin, device=dev)).cpu().numpy()
+        assert np.isnan(gotb[4]).any() and np.array_equal(np.delete(gotb, 4, axis=0), np.delete(got, 4, axis=0))
+    # smooth spectra (no noise on the linear grid: second derivatives eight orders of magnitude apart along a row), more rows than one launch's waves
+    op.scheme = 1
+    many = 4099
+    amp = rng.uniform(0.5, 2., size=(many, 1))
+    tilt = rng.uniform(-0.1, 0.1, size=(many, 1))
+    pk, lin = amp * shape(k) * k**tilt, amp * shape(klin) * klin**tilt
+    got = op(torch.as_tensor(pk, device=dev), torch.as_tensor(lin, device=dev), tophat=torch.as_tensor(tophat, device=dev)).cpu().numpy()
+    for i in list(range(0, many, 173)) + [many - 1]:
+        ref = interpolate.CubicSpline(knots, np.concatenate([pk[i][left], lin[i][mask], pk[i][right]]), bc_type='clamped', extrapolate=False)(k)
+        np.testing.assert_allclose(got[i], pk[i] / ((pk[i] / ref - 1.) * tophat + 1.), rtol=1e-9)
+    # other grids: fewer queries, a stretch that ends the knots (clamped end next to it), knots of ONE array
+    for nk, kmax_lin, nlin in ((512, 2., 3600), (1024, 1.2, 3000), (640, 3., 3500)):
+        k2 = np.geomspace(1e-6, 50., nk)
+        klin2 = np.linspace(1e-6, kmax_lin, nlin)
+        m2 = (klin2 > 2e-2) & (klin2 < 0.9 * kmax_lin)
+        l2, r2 = k2 < 1e-3, k2 > kmax_lin
+        knots2 = np.concatenate([k2[l2], klin2[m2], k2[r2]])
+        pieces2 = [(0, 0, int(l2.sum())), (1, int(np.flatnonzero(m2)[0]), int(m2.sum())), (0, int(np.flatnonzero(r2)[0]), int(r2.sum()))]
+        op2 = SplicedClampedSpline(knots2, pieces2, k2, device=dev)
+        assert op2.scheme == 1, (nk, kmax_lin, nlin)
+        amp = rng.uniform(0.5, 2., size=(9, 1))
+        pk2, lin2 = amp * shape(k2), amp * shape(klin2) * (1. + 1e-4 * rng.normal(size=(9, nlin)))
+        got = op2(torch.as_tensor(pk2, device=dev), torch.as_tensor(lin2, device=dev)).cpu().numpy()
+        for i in range(9):
+            ref = interpolate.CubicSpline(knots2, np.concatenate([pk2[i][l2], lin2[i][m2], pk2[i][r2]]), bc_type='clamped', extrapolate=False)(k2)
+            np.testing.assert_allclose(got[i], ref, rtol=1e-10)
+    # a plan whose queries need the spline far from the uniform stretch keeps the elimination
+    xk = np.concatenate([np.geomspace(1e-4, 9e-3, 200), np.linspace(1e-2, 1., 1500)])
+    opq = SplicedClampedSpline(xk, [(0, 0, xk.size)], np.geomspace(2e-4, 0.9, 300), device=dev)
+    assert opq.scheme == 0
+    with pytest.raises(Exception):
+        opq.scheme = 1
     # irregular knots from one array, queries inside and outside
     x = np.sort(rng.uniform(0., 10., 700))
     xq = np.concatenate([[-1.], rng.uniform(x[0], x[-1], 300), [x[0], x[-1], 11.]])

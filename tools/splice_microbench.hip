@@ -1,4 +1,4 @@
-// The spliced-spline kernel of cp_bao.hip on 16 384 vectors with the grids of wallish2018, with parts left out (-DCP_SPLICE_ABLATE=1: no sweeps,
+// The spliced-spline kernels of cp_bao.hip (scheme 1: cp_splice_uniform.h, scheme 0: elimination in LDS) on 32 768 vectors with the grids of wallish2018, with parts left out (-DCP_SPLICE_ABLATE=1: no sweeps,
 // 2: one query per lane instead of 16, 4: no knot loads): where its time goes.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCP_SPLICE_ABLATE=0 -o /tmp/smb tools/splice_microbench.hip && /tmp/smb
 #include "../cosmoprimo_amd/csrc/cp_bao.hip"
@@ -7,7 +7,7 @@
 
 int main() {
     const int nk = 1024, nlin = 4096;
-    const long long nrows = 16384;
+    const long long nrows = 32768;
     std::vector<double> k(nk), klin(nlin), knots;
     for (int i = 0; i < nk; ++i) k[i] = std::pow(10., -7. + 9. * i / (nk - 1));
     for (int i = 0; i < nlin; ++i) klin[i] = 1e-7 + (2. - 1e-7) * i / (nlin - 1);
@@ -32,7 +32,8 @@ int main() {
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 6; ++rep) {
+        if (cp_splice_plan_set_scheme(plan, rep < 3 ? 1 : 0) != CP_OK) { std::printf("no uniform-stretch scheme for this plan\n"); continue; }
         (void)hipEventRecord(e0, 0);
         for (int i = 0; i < 20; ++i)
             if (cp_splice_apply(plan, a, nk, b, nlin, nrows, th, out, nullptr) != CP_OK) { std::printf("apply failed\n"); return 1; }
@@ -40,7 +41,7 @@ int main() {
         (void)hipEventSynchronize(e1);
         float ms;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        std::printf("ablate %d: %.3f ms per launch\n", CP_SPLICE_ABLATE, ms / 20);
+        std::printf("scheme %d, ablate %d / %d: %.3f ms per launch\n", cp_splice_plan_scheme(plan), CP_SPLICE_ABLATE, CP_SPLICE_UNIFORM_ABLATE, ms / 20);
     }
     return 0;
 }
