@@ -198,8 +198,11 @@ int finish(const char* what, int status_device_ok) {
 using namespace cpdd;
 
 // S = n / 64 knots per lane; LDS per wave: n + 64 doubles, index i -> i + i / S, the sequence first, then d over it, then M over d.
+#ifndef CP_DD_ELIMINATION      // 1: sequences of 2048 knots through the elimination in LDS as well (measurements; the default runs the recursions in registers)
+#define CP_DD_ELIMINATION 0
+#endif
 template <int S>
-__global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, long long nrows, int margin_first, int margin_second, int off0, int off1,
+__global__ __launch_bounds__(256, 2) void wallish_dd_box_kernel(const double* y, long long nrows, int margin_first, int margin_second, int off0, int off1,
                                                              int* __restrict__ box, double* __restrict__ dd_out, double* gap) {
     constexpr int N = 64 * S, STRIDE = N + 64;
     extern __shared__ double dd_lds[];
@@ -226,6 +229,22 @@ __global__ __launch_bounds__(256) void wallish_dd_box_kernel(const double* y, lo
             for (int k = 0; k < S; ++k) nxt[k] = y[(row + (long long)gridDim.x * 4) * N + lane + 64 * k];
         }
         int first, second;
+        if constexpr (S == 32 && !CP_DD_ELIMINATION) {
+            // 2048 knots: the recursions in registers; the sequence stays in LDS, where the removal of the box reads the knots around it
+            double m[S];
+            second_derivatives_and_box_recursive<PaddedLayout<S>>(buf, lane, margin_first, margin_second, m, first, second);
+            if (dd_out) {
+#pragma unroll
+                for (int t = 0; t < S; ++t) dd_out[row * N + S * lane + t] = m[t];
+            }
+            if (lane == 0) {
+                box[2 * row] = first + off0;
+                box[2 * row + 1] = second + off1;
+            }
+            if (gap) remove_box_parallel<S, PaddedLayout<S>>(buf, gtab, lane, first + off0, second + off1, gap + row * N);
+            wave_lds_phase();      // the last reads of the sequence are done before the next one is staged
+            continue;
+        }
         second_derivatives_and_box<S>(buf, ctab, lane, margin_first, margin_second, first, second);
         if (dd_out) {
             double* dst = dd_out + row * N;

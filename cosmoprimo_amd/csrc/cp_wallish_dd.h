@@ -166,6 +166,126 @@ __device__ __forceinline__ void second_derivatives_and_box(double* buf, const do
     second = wave_merge(v2, i2);
 }
 
+// The same for sequences of 2048 knots (S = 32) without an elimination: the knots are uniformly spaced, so the system has constant coefficients and
+// its inverse is two geometric tails, M_i = sqrt 3 sum_j p^|i-j| r_j with p = sqrt 3 - 2 and r_j = y_{j+1} - 2 y_j + y_{j-1} -- over the sequence
+// continued by REFLECTION about its two end knots, which is what the clamped ends amount to (the spline of the even continuation has no slope at
+// the mirror, and its rows there are the clamped rows: 2 M_0 + M_1 = 6 (y_1 - y_0)).  A lane reads its 32 knots (and one on either side) from LDS
+// ONCE and runs the anti-causal recursion g_t = r_t + p g_{t+1}, then the causal one in the same registers (r_t = g_t - p g_{t+1}: e_t = g_t +
+// p f_{t-1} is M_t / sqrt 3, f_t = e_t - p g_{t+1}), both from zero; what the knots outside its segment add comes from the neighbours' segment
+// totals by one DPP shift each way (a segment away the weight is p^32 = 5e-19), and at the two ends from the lane's own sums (the mirror image of
+// the causal sum in front of knot 0 is the anti-causal sum at knot 1).  64 register steps and 66 LDS accesses per lane where the elimination walks
+// 128 knots through LDS with three accesses each (cp_splice_uniform.h: the same recursions on the uniform stretch of the spliced spline).
+typedef int dd_v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double dd_from_left(double v) {      // lane l receives lane l - 1's value, lane 0 zero (wave_shr:1)
+#if defined(__HIP_DEVICE_COMPILE__)
+    dd_v2i w = __builtin_bit_cast(dd_v2i, v);
+    w.x = __builtin_amdgcn_update_dpp(0, w.x, 0x138, 0xf, 0xf, true);
+    w.y = __builtin_amdgcn_update_dpp(0, w.y, 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, w);
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ double dd_from_right(double v) {     // lane l receives lane l + 1's value, lane 63 zero (wave_shl:1)
+#if defined(__HIP_DEVICE_COMPILE__)
+    dd_v2i w = __builtin_bit_cast(dd_v2i, v);
+    w.x = __builtin_amdgcn_update_dpp(0, w.x, 0x130, 0xf, 0xf, true);
+    w.y = __builtin_amdgcn_update_dpp(0, w.y, 0x130, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, w);
+#else
+    return v;
+#endif
+}
+constexpr double dd_ipow(double x, int k) {
+    double v = 1.;
+    for (int i = 0; i < k; ++i) v *= x;
+    return v;
+}
+
+// m[32]: the lane's second derivatives on exit; the sequence in LDS is only read.
+template <class LAY = PaddedLayout<32>>
+__device__ __forceinline__ void second_derivatives_and_box_recursive(const double* buf, int lane, int margin_first, int margin_second, double* m, int& first,
+                                                                     int& second) {
+    constexpr int S = 32, N = 64 * S;
+    constexpr double P = -DD_CINF, SCALE = 1.7320508075688772935;      // 6 kappa = 6 / (2 sqrt 3)
+    auto at = [&](int i) { return buf[LAY::at(i)]; };
+    const int own = S * lane;
+    {
+        double ym = at(lane == 0 ? 1 : own - 1), y0 = at(own);            // (the mirror image of knot 1 stands in front of knot 0)
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const double yp = t < S - 1 ? at(own + t + 1) : at(lane == 63 ? N - 2 : own + S);
+            m[t] = (yp - y0) - (y0 - ym);
+            ym = y0;
+            y0 = yp;
+        }
+    }
+#pragma unroll
+    for (int t = S - 2; t >= 0; --t) m[t] = fma(P, m[t + 1], m[t]);
+    const double g1 = m[1];
+    double gin = dd_from_right(m[0]);
+    double f = 0., fs2 = 0.;
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        const double e = fma(P, f, m[t]);
+        f = t + 1 < S ? fma(-P, m[t + 1], e) : e;
+        if (t == S - 2) fs2 = f;
+        m[t] = e;
+    }
+    double fin = dd_from_left(f);
+    gin = lane == 63 ? fma(dd_ipow(P, S - 1), fin, fs2) : gin;      // the anti-causal sum at the mirror image of knot n - 2
+    fin = lane == 0 ? fma(dd_ipow(P, S - 1), gin, g1) : fin;        // the causal sum at the mirror image of knot 1
+    {
+        double c = gin;
+#pragma unroll
+        for (int t = S - 1; t >= 0; --t) {
+            c *= P;
+            m[t] += c;
+        }
+        c = fin;
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            c *= P;
+            m[t] += c;
+        }
+    }
+    // arg-max over [margin_first, n - margin_first): first index on ties, NaN as the largest value (numpy's argmax); the walk runs towards smaller
+    // i, so an equal value replaces the one held
+    double best = -__builtin_inf();
+    int best_i = 0x7fffffff;
+#pragma unroll
+    for (int t = S - 1; t >= 0; --t) {
+        const int i = own + t;
+        m[t] *= SCALE;
+        const bool inside = i >= margin_first && i < N - margin_first;
+        if (inside && ((m[t] != m[t]) || (!(best != best) && m[t] >= best))) {
+            best = m[t];
+            best_i = i;
+        }
+    }
+    first = wave_merge(best, best_i);
+    // ... and over [first + margin_second, n - margin_first): the lanes whose knots all lie inside hold their maximum already
+    const int lower = first + margin_second;
+    double v2 = best;
+    int i2 = best_i;
+    if (own < lower) {      // (the lanes in front of the range, and the one it starts in: that one looks at its knots again)
+        v2 = -__builtin_inf();
+        i2 = 0x7fffffff;
+        if (own + S > lower) {
+#pragma unroll
+            for (int t = S - 1; t >= 0; --t) {
+                const int i = own + t;
+                const bool inside = i >= lower && i < N - margin_first;
+                if (inside && ((m[t] != m[t]) || (!(v2 != v2) && m[t] >= v2))) {
+                    v2 = m[t];
+                    i2 = i;
+                }
+            }
+        }
+    }
+    second = wave_merge(v2, i2);
+}
+
 // The removal of the box [a, b] (cp_gap_spline, bao_filter.py:395-405): the clamped spline through the x^2-weighted coefficients with the knots
 // [a, b] left out returns the datum at every kept knot, so only the box is rewritten; its two end slopes come from eliminations started
 // DD_GAP_WINDOW knots to either side (the arithmetic of gap_spline_kernel, cp_spline.hip), run by two lanes side by side on values the wave has
@@ -237,6 +357,78 @@ __device__ __forceinline__ bool remove_box(double* buf, const double* gtab, int 
         seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
     }
     wave_lds_phase();      // zl / zr read before the buffer is staged over again
+    return true;
+}
+
+// The same removal with the two eliminations as REDUCTIONS over the wave: a step of either sweep is an affine map of the running right-hand side,
+// d <- (3 (z_{i+1} - z_{i-1}) - d) c_i, and affine maps compose -- each lane builds the map of one knot of the window on either side (64 knots
+// each), six ordered butterfly steps compose them, where two lanes walked 64 dependent steps each while 62 waited.  The knots are read from the
+// sequence in LDS (layout LAY), nothing is staged.
+template <int S, class LAY>
+__device__ __forceinline__ bool remove_box_parallel(const double* ybuf, const double* gtab, int lane, int a, int b, double* seq) {
+    constexpr int N = 64 * S;
+    static_assert(DD_GAP_WINDOW == 64, "a knot of either window per lane");
+    if (a < 1 || b > N - 2 || b < a) return false;
+    const int L = a - 1, R = b + 1;
+    const double g = (double)(R - L);
+    const int i0 = L - DD_GAP_WINDOW > 0 ? L - DD_GAP_WINDOW : 0, i1 = R + DD_GAP_WINDOW < N - 1 ? R + DD_GAP_WINDOW : N - 1;
+    auto z = [&](int i) {
+        const double x = (double)(i + 1);
+        return ybuf[LAY::at(i)] * (x * x);
+    };
+    // left: knots i0 + 1 .. L - 1 in this order, lane k the knot i0 + 1 + k; right: knots i1 - 1 .. R + 1 downwards, lane k the knot i1 - 1 - k
+    const int nl = L - 1 - i0, nr = i1 - 1 - R;
+    double al = 1., bl = 0., ar = 1., br = 0.;
+    if (lane < nl) {
+        const int i = i0 + 1 + lane;
+        const double c = gtab[i - i0 < DD_NTAB ? i - i0 : DD_NTAB - 1];
+        al = -c;
+        bl = 3. * (z(i + 1) - z(i - 1)) * c;
+    }
+    if (lane < nr) {
+        const int i = i1 - 1 - lane;
+        const double c = gtab[i1 - i < DD_NTAB ? i1 - i : DD_NTAB - 1];
+        ar = -c;
+        br = 3. * (z(i + 1) - z(i - 1)) * c;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double pal = __shfl_xor(al, off), pbl = __shfl_xor(bl, off), par = __shfl_xor(ar, off), pbr = __shfl_xor(br, off);
+        const bool lower = !(lane & off);      // this lane's block comes first: the partner's map is applied behind it
+        bl = lower ? fma(pal, bl, pbl) : fma(al, pbl, bl);
+        al *= pal;
+        br = lower ? fma(par, br, pbr) : fma(ar, pbr, br);
+        ar *= par;
+    }
+    // the sweeps' starting values (clamped ends: slope 0; inside the sequence: the centred difference), then the two rows at the gap
+    double cpL = 0., dpL = i0 == 0 ? 0. : 0.5 * (z(i0 + 1) - z(i0 - 1));
+    if (L != i0) {
+        dpL = fma(al, dpL, bl);
+        const double cp = nl > 0 ? gtab[nl < DD_NTAB ? nl : DD_NTAB - 1] : 0.;
+        const double d = 3. * (g * (z(L) - z(L - 1)) + (z(R) - z(L)) / g);
+        const double den = 2. * (1. + g) - g * cp;
+        cpL = 1. / den;
+        dpL = (d - g * dpL) / den;
+    }
+    double bqR = 0., dqR = i1 == N - 1 ? 0. : 0.5 * (z(i1 + 1) - z(i1 - 1));
+    if (R != i1) {
+        dqR = fma(ar, dqR, br);
+        const double bq = nr > 0 ? gtab[nr < DD_NTAB ? nr : DD_NTAB - 1] : 0.;
+        const double d = 3. * ((z(R) - z(L)) / g + g * (z(R + 1) - z(R)));
+        const double den = 2. * (g + 1.) - g * bq;
+        bqR = 1. / den;
+        dqR = (d - g * dqR) / den;
+    }
+    const double sL = (dpL - cpL * dqR) / (1. - cpL * bqR);
+    const double sR = dqR - bqR * sL;
+    const double zL = z(L), zR = z(R);
+    const double slope = (zR - zL) / g;
+    const double tt = (sL + sR - 2. * slope) / g;
+    const double c3 = tt / g, c2 = (slope - sL) / g - tt;
+    for (int i = a + lane; i <= b; i += 64) {
+        const double u = (double)(i - L), x = (double)(i + 1);
+        seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
+    }
     return true;
 }
 
