@@ -606,16 +606,32 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
                 dst = R.out + (row / R.group) * R.nq * R.group + row % R.group;
                 qstride = R.group;
             }
+            // Four radii per lane at a time, without a branch between them: their four LDS reads each are issued together, the stores follow each
+            // other (a radius per block of its own -- one predicate, two LDS round trips and a 64-bit address each -- took 0.15 ms of the 3.8 per
+            // radius and lane: profiles/r4_geospline_ablate.txt, bit 2).  Lanes past the last radius compute on the last one and do not store.
+            const unsigned voff = (unsigned)(lane * qstride) * 8u;
+            const int nqi = (CP_GEO_ABLATE & 2) ? 1 : (R.nq + 63) >> 6;      // (wave-uniform)
 #pragma unroll
-            for (int j = 0; j < ((CP_GEO_ABLATE & 2) ? 1 : GEO_QMAX); ++j) {
-                const int q = lane + 64 * j;
-                if (q < R.nq) {
-                    const int e = qe[j] < 0 ? 0 : qe[j];
+            for (int j0 = 0; j0 < GEO_QMAX; j0 += 4) {
+                if (j0 >= nqi) break;
+                double ya[4], yb[4], na[4], nb[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int e = qe[j0 + jj] < 0 ? 0 : qe[j0 + jj];
+                    ya[jj] = Y[e];
+                    yb[jj] = Y[e + 1];
+                    na[jj] = N[e];
+                    nb[jj] = N[e + 1];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = j0 + jj;
                     const double a = qa[j], b = 1. - a;
-                    double v = fma(a, Y[e], b * Y[e + 1]) + (fma(a * a, a, -a) * (rho_sq * N[e]) + fma(b * b, b, -b) * N[e + 1]);
+                    double v = fma(a, ya[jj], b * yb[jj]) + (fma(a * a, a, -a) * (rho_sq * na[jj]) + fma(b * b, b, -b) * nb[jj]);
                     if (R.post_sqrt && !(CP_GEO_ABLATE & 4)) v = geo_sqrt(v);
                     if (qe[j] < 0) v = __builtin_nan("");
-                    if (!(CP_GEO_ABLATE & 16) || v == 12345.678) dst[(long long)q * qstride] = v;
+                    char* obase = reinterpret_cast<char*>(dst) + (size_t)(64 * j) * (size_t)qstride * 8u;      // (wave-uniform)
+                    if (lane + 64 * j < R.nq && (!(CP_GEO_ABLATE & 16) || v == 12345.678)) *reinterpret_cast<double*>(obase + voff) = v;
                 }
             }
         }

@@ -1114,19 +1114,40 @@ struct TablesDirectArgs {
     double scale;
 };
 
+#ifndef CP_TABLES_WAVES      // waves per SIMD the direct kernel is built for (register budget 512 / CP_TABLES_WAVES)
+#define CP_TABLES_WAVES 3
+#endif
+#ifndef CP_TABLES_PREFETCH   // 1: the table entries of a step are fetched during the step before (64 more registers in flight)
+#define CP_TABLES_PREFETCH 0
+#endif
 #ifndef CP_TABLES_ABLATE      // diagnostic builds (tools/tables_ablate.sh; wrong results): 1 no stores, 2 no exponential, 4 no z contraction, 8 no table loads
 #define CP_TABLES_ABLATE 0
 #endif
 
+// The grid is a multiple of the number of 256-column tiles of a row, so a workgroup keeps ITS tile for every table it takes: the intervals and weights
+// of its 256 wavenumbers sit in LDS for the whole launch, and a wave's work is one flat sequence of steps (table, jj) whose table entries are
+// fetched ONE STEP AHEAD -- issued as soon as the splines of the current step are evaluated, in flight during its contraction, exponentials and
+// stores (fetched at the top of the step they stalled every wave for a memory round trip: with loads, stores, exponentials or the contraction
+// taken out one at a time the kernel lost 0.5, 0.4, 0.2 and 0.45 of its 2.0 ms -- parts that add up do not overlap).
 template <int POST>
-__global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const TablesDirectArgs A) {
+__global__ __launch_bounds__(256, CP_TABLES_WAVES) void tables_rows_direct_kernel(const TablesDirectArgs A) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int l15 = lane & 15, g = lane >> 4;
     const int nqt = (A.nq + 255) / 256;
     __shared__ double wl[32 * TABLES_WSTRIDE];
+    __shared__ double4 tile_w[256];
+    __shared__ int tile_j[256];
+    __shared__ double exp_tab[64];
+    if (threadIdx.x < 64) exp_tab[threadIdx.x] = cpmath::exp10_table[threadIdx.x];
+    const int tile = (int)(blockIdx.x % nqt);
     for (int e = threadIdx.x; e < 64 * 32; e += 256) {
         const int q = e >> 5, kz = e & 31;
         wl[kz * TABLES_WSTRIDE + q] = kz < A.nz_pad ? A.wz[q * A.nz_pad + kz] : 0.;
+    }
+    {
+        const int q = tile * 256 + threadIdx.x, qc = q < A.nq ? q : A.nq - 1;
+        tile_w[threadIdx.x] = reinterpret_cast<const double4*>(A.qw)[qc];
+        tile_j[threadIdx.x] = A.qj[qc];
     }
     __syncthreads();
     unsigned nan_z = 0u;
@@ -1138,79 +1159,126 @@ __global__ __launch_bounds__(256, 3) void tables_rows_direct_kernel(const Tables
             if (zq < A.nzq && A.j0z[zq] < 0) nan_z |= 1u << (4 * mi + r);
         }
     typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
-    for (long long item = blockIdx.x; item < A.nbatch * nqt; item += gridDim.x) {
-        const long long b = item / nqt;
-        // The four waves of the workgroup take ADJACENT column tiles at every step (wave w: wavenumbers q0 + 64 jj + 16 w ...): together they walk the
-        // table rows 256 bytes at a time, two whole cache lines that all four touch within the same few hundred cycles.  (Each wave walking its own
-        // 64 wavenumbers used half of a line per step and came back for the other half thousands of cycles later, when it had often left the L2:
-        // FETCH_SIZE 4.7 GB for 2.4 GB of tables.)
-        const int q0 = (int)(item % nqt) * 256 + wave * 16;
-        if (q0 >= A.nq) continue;
-        // One column tile (16 wavenumbers: the lane's is q0 + 64 jj + (l & 15), its interval and weights from the plan) at a time: the k splines
-        // of the table's rows there, in the layout of the B fragments of the z contraction (2 x 4 registers); R = Wz L on the matrix cores (4 tiles
-        // of 16 output redshifts); f applied, rows of P(k, z) stored.
-        int rowoff[2][4];
+    // The four waves of the workgroup take ADJACENT column tiles at every step (wave w: wavenumbers q0 + 64 jj + 16 w ...): together they walk the
+    // table rows 256 bytes at a time, two whole cache lines that all four touch within the same few hundred cycles.  (Each wave walking its own
+    // 64 wavenumbers used half of a line per step and came back for the other half thousands of cycles later, when it had often left the L2:
+    // FETCH_SIZE 4.7 GB for 2.4 GB of tables.)
+    const int q0 = tile * 256 + wave * 16;
+    if (q0 >= A.nq) return;
+    int rowoff[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int row = 16 * i + g + 4 * r;
+            row = row < A.nzin ? row : A.nzin - 1;      // rows past the table repeat its last one: Wz is zero there
+            rowoff[i][r] = row * A.n;
+        }
+    const long long first = blockIdx.x / nqt, stride = gridDim.x / nqt;
+    if (first >= A.nbatch) return;
+    const long long nsteps = 4 * ((A.nbatch - first + stride - 1) / stride);
+    v2u ty[2][4], tm[2][4];
+    auto fetch = [&](long long s) {      // the table entries of step s: the two knots around the lane's wavenumber in each of its 8 rows, and their second derivatives
+        const long long b = first + (s >> 2) * stride;
+        const int slot = 64 * (int)(s & 3) + 16 * wave + l15;
+        const int jraw = tile_j[slot];
+        const int jq = jraw < 0 ? 0 : jraw;
+        const double* tb = A.t + b * (long long)A.nzin * A.n + jq;
+        const double* mb = A.m + b * (long long)A.nzin * A.n + jq;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int row = 16 * i + g + 4 * r;
-                row = row < A.nzin ? row : A.nzin - 1;      // rows past the table repeat its last one: Wz is zero there
-                rowoff[i][r] = row * A.n;
+                ty[i][r] = *reinterpret_cast<const v2u*>(tb + rowoff[i][r]);
+                tm[i][r] = *reinterpret_cast<const v2u*>(mb + rowoff[i][r]);
             }
-        const double* tb = A.t + b * (long long)A.nzin * A.n;      // (wave-uniform)
-        const double* mb = A.m + b * (long long)A.nzin * A.n;
-        double* ob = A.out + b * (long long)A.nzq * A.nq;
+    };
+    if (!(CP_TABLES_ABLATE & 8) && CP_TABLES_PREFETCH) fetch(0);
 #pragma unroll 1
-        for (int jj = 0; jj < 4; ++jj) {
-            const int q = q0 + 64 * jj + l15;
-            const int qc = q < A.nq ? q : A.nq - 1;
-            const int jraw = A.qj[qc];
-            const bool nanq = jraw < 0;
-            const int jq = jraw < 0 ? 0 : jraw;
-            const double4 w = reinterpret_cast<const double4*>(A.qw)[qc];
-            cp_v4d lt[2];
+    for (long long s = 0; s < nsteps; ++s) {
+        if (!(CP_TABLES_ABLATE & 8) && !CP_TABLES_PREFETCH) fetch(s);
+        const long long b = first + (s >> 2) * stride;
+        const int jj = (int)(s & 3);
+        // One column tile (16 wavenumbers: the lane's is q0 + 64 jj + (l & 15), its interval and weights from the plan) at a time: the k splines
+        // of the table's rows there, in the layout of the B fragments of the z contraction (2 x 4 registers); R = Wz L on the matrix cores (4 tiles
+        // of 16 output redshifts); f applied, rows of P(k, z) stored.
+        const int slot = 64 * jj + 16 * wave + l15;
+        const int q = q0 + 64 * jj + l15;
+        const bool nanq = tile_j[slot] < 0;
+        const double4 w = tile_w[slot];
+        cp_v4d lt[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (CP_TABLES_ABLATE & 8) {
-                        lt[i][r] = w.x * (double)rowoff[i][r] + w.y;
-                        continue;
-                    }
-                    const v2u y = *reinterpret_cast<const v2u*>(tb + rowoff[i][r] + jq), m = *reinterpret_cast<const v2u*>(mb + rowoff[i][r] + jq);
-                    lt[i][r] = w.x * y.x + w.y * y.y + (w.z * m.x + w.w * m.y);
+            for (int r = 0; r < 4; ++r) {
+                if (CP_TABLES_ABLATE & 8) {
+                    lt[i][r] = w.x * (double)rowoff[i][r] + w.y;
+                    continue;
                 }
-            cp_v4d r2[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) r2[mi] = cp_v4d{0., 0., 0., 0.};
-#pragma unroll
-            for (int kk = 0; kk < ((CP_TABLES_ABLATE & 4) ? 1 : 8); ++kk)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    r2[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(4 * kk + g) * TABLES_WSTRIDE + 16 * mi + l15], lt[kk >> 2][kk & 3], r2[mi], 0, 0, 0);
-            if (CP_TABLES_ABLATE & 4)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) r2[mi][r] += lt[mi & 1][r];
-            const bool full = q0 + 64 * jj + 16 <= A.nq && A.nzq == 64;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int zq = 16 * mi + g + 4 * r;
-                    double v = r2[mi][r] * A.scale;
-                    if (POST == CP_SPLINE_POST_SQRT) v = sqrt(v);
-                    else if (POST == CP_SPLINE_POST_EXP10 && !(CP_TABLES_ABLATE & 2)) v = exp10_mid(v);
-                    v = (nanq || ((nan_z >> (4 * mi + r)) & 1u)) ? __builtin_nan("") : v;
-                    if ((CP_TABLES_ABLATE & 1) && v != 12345.678) continue;
-                    // written once, read by the next kernel from memory: the non-temporal policy keeps these 5.2 GB (config 3B) from evicting the table
-                    // lines the wave comes back to at its next column tile (FETCH_SIZE of this kernel: 5.8 GB with plain stores for 2.4 GB of tables)
-                    if (full || (q < A.nq && zq < A.nzq)) __builtin_nontemporal_store(v, ob + zq * A.nq + q);      // (at most 64 rows of nq: 32-bit)
-                }
-                __builtin_amdgcn_sched_barrier(0);      // (four exponentials in flight, not sixteen: their temporaries set the register count)
+                lt[i][r] = w.x * ty[i][r].x + w.y * ty[i][r].y + (w.z * tm[i][r].x + w.w * tm[i][r].y);
             }
+        if (s + 1 < nsteps && !(CP_TABLES_ABLATE & 8) && CP_TABLES_PREFETCH) fetch(s + 1);
+        cp_v4d r2[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) r2[mi] = cp_v4d{0., 0., 0., 0.};
+#pragma unroll
+        for (int kk = 0; kk < ((CP_TABLES_ABLATE & 4) ? 1 : 8); ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                r2[mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(wl[(4 * kk + g) * TABLES_WSTRIDE + 16 * mi + l15], lt[kk >> 2][kk & 3], r2[mi], 0, 0, 0);
+        if (CP_TABLES_ABLATE & 4)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) r2[mi][r] += lt[mi & 1][r];
+        const bool full = q0 + 64 * jj + 16 <= A.nq && A.nzq == 64;
+        double* ob = A.out + b * (long long)A.nzq * A.nq;
+        if (POST == CP_SPLINE_POST_EXP10 && full && A.nq <= (1 << 20) && !(CP_TABLES_ABLATE & 2)) {
+            // The tile lies inside the arrays: when, besides, no lane holds a NaN query / redshift or an exponent beyond +-300 (a wave-uniform test), the
+            // sixteen exponentials take the table-driven form and the stores neither a select nor a predicate.  The epilogue was 54 instructions per
+            // element (860 of the 1 200 a step issues; the kernel is bound by instruction issue: 625 steps per SIMD x 1 200 x 4 cycles + the
+            // contraction = the 2.0 ms it took).
+            double amax = 0., sum = 0.;      // (fmax drops a NaN operand: the sum catches them)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    amax = fmax(amax, fabs(r2[mi][r]));
+                    sum += r2[mi][r];
+                }
+            const bool plain = !nanq && nan_z == 0u && amax * fabs(A.scale) < 300. && sum == sum;
+            if (__builtin_amdgcn_ballot_w64(!plain) == 0ull) {
+                char* base = reinterpret_cast<char*>(ob);                                   // (wave-uniform)
+                const unsigned voff = (unsigned)((g * A.nq + q) * 8);
+                const unsigned rstride = (unsigned)A.nq * 8u;
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double v = cpmath::exp10_tab(r2[mi][r] * A.scale, exp_tab);
+                        if (!(CP_TABLES_ABLATE & 1) || v == 12345.678)
+                            __builtin_nontemporal_store(v, reinterpret_cast<double*>(base + (size_t)(16 * mi + 4 * r) * rstride + voff));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                continue;
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int zq = 16 * mi + g + 4 * r;
+                double v = r2[mi][r] * A.scale;
+                if (POST == CP_SPLINE_POST_SQRT) v = sqrt(v);
+                else if (POST == CP_SPLINE_POST_EXP10 && !(CP_TABLES_ABLATE & 2)) v = exp10_mid(v);
+                v = (nanq || ((nan_z >> (4 * mi + r)) & 1u)) ? __builtin_nan("") : v;
+                if ((CP_TABLES_ABLATE & 1) && v != 12345.678) continue;
+                // written once, read by the next kernel from memory: the non-temporal policy keeps these 5.2 GB (config 3B) from evicting the table
+                // lines the wave comes back to at its next column tile (FETCH_SIZE of this kernel: 5.8 GB with plain stores for 2.4 GB of tables)
+                if (full || (q < A.nq && zq < A.nzq)) __builtin_nontemporal_store(v, ob + zq * A.nq + q);      // (at most 64 rows of nq: 32-bit)
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (four exponentials in flight, not sixteen: their temporaries set the register count)
         }
     }
 }
@@ -1272,8 +1340,9 @@ extern "C" int cp_tables_rows_direct(const cp_spline_rows_plan* kplan, const cp_
     T.t = d_tables; T.m = d_m; T.out = d_out; T.nbatch = nbatch;
     T.n = kv.n; T.nq = kv.nq; T.nzin = zplan->n; T.nzq = zplan->nq;
     T.qj = kv.d_qj; T.qw = kv.d_qw; T.wz = zplan->d_wdense; T.nz_pad = zplan->n_pad; T.j0z = zplan->d_j0; T.scale = scale;
-    const long long items = nbatch * ((kv.nq + 255) / 256);
-    const int grid = (int)(items < 256 * 8 ? items : 256 * 8);
+    const int nqt = (kv.nq + 255) / 256;
+    const long long items = nbatch * nqt;
+    const int grid = (int)(items < 256 * 8 ? items : (256 * 8 / nqt > 0 ? (256 * 8 / nqt) * nqt : nqt));      // a multiple of the tiles of a row: a workgroup keeps its tile
     hipStream_t hs = static_cast<hipStream_t>(stream);
     if (post_op == CP_SPLINE_POST_EXP10) hipLaunchKernelGGL(tables_rows_direct_kernel<CP_SPLINE_POST_EXP10>, dim3(grid), dim3(256), 0, hs, T);
     else if (post_op == CP_SPLINE_POST_SQRT) hipLaunchKernelGGL(tables_rows_direct_kernel<CP_SPLINE_POST_SQRT>, dim3(grid), dim3(256), 0, hs, T);
