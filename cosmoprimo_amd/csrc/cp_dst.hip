@@ -309,7 +309,7 @@ __global__ void dst_log_kernel(const double* k, double* ln_k, int n) {
 // log(k P(k)) of cosmology ic at the thread's P samples m = t + T r of the reordered sequence, into the thread's own slots of the data region
 // (double index 2 (t + T r) + row).  NOT unrolled: sixteen copies of a 400-instruction evaluation would not fit the instruction cache.
 template <int N, int P, int ENGINE>
-__device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int t, double* slots) {
+__device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int t, double* slots, const cpmath::MathTables* mt) {
     using namespace cppower;
     constexpr int T = N / P;
     const Cosmo c = load_cosmo(G.bg, ic, G.second_is_omega_m);
@@ -331,8 +331,8 @@ __device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int
             const double kh = G.k[n], ln_kh = G.ln_k[n];
             double Tk;
             if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
-            slots[2 * m] = 2. * (ln_kh + log_pos(fabs(Tk))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
+            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, mt) : transfer_nowiggle(s, c.h, kh, mt);
+            slots[2 * m] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(Tk)) : log_tab_any(fabs(Tk), mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
         }
     }
 }
@@ -352,6 +352,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
     const long long npairs = (G.ncosmo + 1) / 2;
     const double fn = sqrt(2. / N), fl = sqrt(1. / N);
     __shared__ int bad_row[2];
+    __shared__ cpmath::MathTables mt;      // (the barrier at the top of the first pair covers it)
+    cpmath::fill_math_tables(&mt);
     const double nan = __builtin_nan("");
     static_assert(!padded_lds(N, P), "the generated samples go through natural-order slots of the data region");
     for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
@@ -362,8 +364,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
         if (t == 0) bad_row[0] = bad_row[1] = 0;
         __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
         double* slots = reinterpret_cast<double*>(lds);
-        generate_row<N, P, ENGINE>(G, 2 * p, t, slots);
-        if (has_b) generate_row<N, P, ENGINE>(G, 2 * p + 1, t, slots + 1);
+        generate_row<N, P, ENGINE>(G, 2 * p, t, slots, &mt);
+        if (has_b) generate_row<N, P, ENGINE>(G, 2 * p + 1, t, slots + 1, &mt);
         cplx x[P];
         bool bad_a = false, bad_b = false;
 #pragma unroll

@@ -124,11 +124,13 @@ __device__ __forceinline__ double exp10_mid(double x) {
     return v;
 }
 
+// ---- table-driven forms: 64 entries in LDS (a gather of 8- or 16-byte entries no two of which share a bank), short polynomials ----
 // 10^x where every lane of a tile takes sixteen of them (cp_tables_rows_direct): n = round(64 x log2 10), 10^x = 2^(n >> 6) 2^((n & 63) / 64) 10^r
 // with r = x - n log10(2) / 64 in two pieces (|r| <= 0.00236), 2^(j / 64) from a table of 64 correctly rounded doubles in LDS and 10^r - 1 by its
 // degree-5 series (remainder 4e-17): relative error 2.0e-16 over |x| < 300 (checked against 50-digit arithmetic), 10 double-precision
 // instructions where exp10_mid takes 20 and six selects.  NO range handling: the caller sends tiles that hold |x| >= 300, Inf or NaN to exp10_mid.
-__device__ const double exp10_table[64] = {
+// 2^(j / 64), j < 64, correctly rounded (shared by exp10_tab and exp_tab)
+__device__ const double exp2_table[64] = {
     1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284, 1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
     1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418, 1.1387886347566916, 1.1511892299529827, 1.1637248587775775,
     1.1763969916502812, 1.189207115002721, 1.2021567314527031, 1.215247359980469, 1.22848053610687, 1.241857812073484, 1.2553807570246911,
@@ -152,6 +154,87 @@ __device__ __forceinline__ double exp10_tab(double x, const double* lds_table) {
     const int ni = (int)n;
     const double t = lds_table[ni & 63];
     return ldexp(fma(t, p, t), ni >> 6);
+}
+
+// {1 / c_j, -log(1 / c_j)}, c_j = (1 + (j + 1/2) / 64) / 2 the midpoint of the j-th of 64 equal pieces of [1/2, 1): log m = log(m / c_j) + log c_j
+__device__ const double log_table[128] = {
+    1.9844961240310077, -0.68536504011789035, 1.9541984732824427, -0.66998012127841089, 1.9248120300751879, -0.65482831625780868,
+    1.8962962962962964, -0.63990266604113311, 1.8686131386861313, -0.62519651865143755, 1.8417266187050361, -0.6107035113488708,
+    1.8156028368794326, -0.59641755410139419, 1.7902097902097902, -0.58233281421965521, 1.7655172413793103, -0.56844370205898809,
+    1.7414965986394557, -0.55474485770082615, 1.7181208053691275, -0.54123113853410332, 1.695364238410596, -0.52789760766463811,
+    1.673202614379085, -0.514739523087127, 1.6516129032258065, -0.50175232756031585, 1.6305732484076434, -0.48893163913125448,
+    1.6100628930817611, -0.47627324225933099, 1.5900621118012421, -0.46377307949509944, 1.5705521472392638, -0.45142724367280018,
+    1.5515151515151515, -0.43923197057898189, 1.532934131736527, -0.42718363206280741, 1.514792899408284, -0.41527872955648898,
+    1.4970760233918128, -0.40351388797690257, 1.4797687861271676, -0.3918858499817835, 1.4628571428571429, -0.38039147055604844,
+    1.4463276836158192, -0.3690277119057333, 1.4301675977653632, -0.35779163863880753, 1.4143646408839778, -0.34668041321373666,
+    1.3989071038251366, -0.33569129163814154, 1.3837837837837839, -0.32482161940123772, 1.3689839572192513, -0.31406882762497579,
+    1.3544973544973544, -0.30343042941992004, 1.3403141361256545, -0.29290401643293268, 1.3264248704663213, -0.28248725557467697,
+    1.3128205128205128, -0.27217788591581565, 1.2994923857868019, -0.26197371574157391, 1.2864321608040201, -0.25187261975507008,
+    1.2736318407960199, -0.2418725364204867, 1.2610837438423645, -0.23197146543777517, 1.248780487804878, -0.22216746534115431,
+    1.2367149758454106, -0.21245865121419336, 1.2248803827751196, -0.20284319251475144, 1.2132701421800949, -0.19331931100349606,
+    1.2018779342723005, -0.18388527877013738, 1.1906976744186046, -0.17453941635189965, 1.1797235023041475, -0.16528009093910292,
+    1.1689497716894977, -0.15610571466306161, 1.158371040723982, -0.14701474296180975, 1.147982062780269, -0.13800567301944369,
+    1.1377777777777778, -0.12907704227514236, 1.1277533039647578, -0.12022742699815989, 1.1179039301310043, -0.11145544092532278,
+    1.1082251082251082, -0.10275973395776894, 1.0987124463519313, -0.094138990913861909, 1.0893617021276596, -0.085591930335403535,
+    1.0801687763713079, -0.077117303344431204, 1.0711297071129706, -0.068713892548051728, 1.0622406639004149, -0.060380510988907482,
+    1.0534979423868314, -0.052116001139014101, 1.0448979591836736, -0.043919233934835579, 1.0364372469635628, -0.035789107851585289,
+    1.0281124497991967, -0.027724548014854768, 1.0199203187250996, -0.019724505347778573, 1.0118577075098814, -0.011787955752042173,
+    1.003921568627451, -0.0039138993211363148};
+
+struct MathTables {      // in LDS, one per workgroup
+    double exp2[64];
+    double logc[128];
+};
+
+// every thread of the workgroup calls this; a barrier follows at the caller's
+__device__ __forceinline__ void fill_math_tables(MathTables* t) {
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) t->exp2[i] = exp2_table[i];
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) t->logc[i] = log_table[i];
+}
+
+// e^x: n = round(64 x / ln 2), ln(2) / 64 in two pieces (|r| <= 0.0055), e^r - 1 by its degree-5 series (remainder 4e-17), 2^((n & 63) / 64)
+// from the table, ldexp -- relative error 2.0e-16 (checked against 50-digit arithmetic over |x| < 700), 11 double-precision instructions where
+// exp_mid takes 20.  Arguments below -800 give 0 (as beyond -745 anyway), NaN passes.
+__device__ __forceinline__ double exp_tab(double x, const MathTables* t) {
+    x = x < -800. ? -800. : x;
+    const double n = rint(x * 92.332482616893657);
+    double r = fma(-n, 0.010830424695086549, x);      // (33 significant bits: exact for |n| < 2^20)
+    r = fma(-n, 1.162596423439437e-12, r);
+    double p = 1. / 120.;
+    p = fma(p, r, 1. / 24.);
+    p = fma(p, r, 1. / 6.);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.);
+    p *= r;
+    const int ni = (int)n;
+    const double e = t->exp2[ni & 63];
+    return ldexp(fma(e, p, e), ni >> 6);
+}
+
+// log(x) for positive, finite, normal x: x = 2^e m, m in [1/2, 1) split into 64 pieces by its top mantissa bits, r = m / c_j - 1 (|r| < 0.0079, one
+// fma on the tabulated reciprocal), log(1 + r) by its degree-7 series (remainder 2e-18): ABSOLUTE error below 2e-16 max(1, |log x|) -- for
+// arguments away from 1 (every logarithm of the fits: log(e + ...)) the relative error of log_pos at 17 instructions for its 40; next to 1 the
+// result keeps its absolute, not its relative accuracy.  Zero, negative, subnormal, Inf, NaN: not handled (log_pos).
+__device__ __forceinline__ double log_tab(double x, const MathTables* t) {
+    const double m = __builtin_amdgcn_frexp_mant(x);
+    const int e = __builtin_amdgcn_frexp_exp(x);
+    const int j = (__double2hiint(m) >> 14) & 63;
+    const double inv = t->logc[2 * j], lc = t->logc[2 * j + 1];
+    const double r = fma(m, inv, -1.);
+    double p = 1. / 7.;
+    p = fma(p, r, -1. / 6.);
+    p = fma(p, r, 0.2);
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 1. / 3.);
+    p = fma(p, r, -0.5);
+    p = fma(p, r, 1.);
+    return fma((double)e, 6.93147180559945309417e-01, fma(p, r, lc));
+}
+
+// log_tab where the argument may leave its domain (the logarithm of |T(k)|: a transfer function can cross zero): the library's answers there
+__device__ __forceinline__ double log_tab_any(double x, const MathTables* t) {
+    if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log_any(x);
+    return log_tab(x, t);
 }
 
 }  // namespace cpmath

@@ -55,6 +55,8 @@ __global__ __launch_bounds__(64) void coefficients_kernel(const Args A, EhScalar
 template <int ENGINE>   // one instance per engine: the registers of a launch are those of its own transfer function, not the maximum over the three
 __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 waves per SIMD (168 registers): 0.204 ms per 10 000 x 1024 EH98 spectra against 0.23 at 2 waves and 0.29 at 4 (spills)
     __shared__ double sh_g2[256];
+    __shared__ MathTables mt;
+    fill_math_tables(&mt);      // (the barrier in front of the loop over wavenumbers covers it)
     const int tid = threadIdx.x;
     const long long ic = blockIdx.x / A.kchunks;
     const long long k0 = (long long)(blockIdx.x % A.kchunks) * A.kspan;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
                 if (ENGINE == CP_ENGINE_BBKS)
                     T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
                 else
-                    T = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
+                    T = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, &mt) : transfer_nowiggle(s, c.h, kh, &mt);
             }
             if (A.what == CP_PK_TRANSFER) {
                 out[0] = T;
@@ -98,10 +100,10 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
                 // log(k P(k)) term by term: log k + log(T^2) + log(k x constant) + the exponent of the tilt -- the logarithm of the transfer
                 // function replaces the exponential of the tilt, and the consumer (the DST of wallish2018, bao_filter.py:371) takes no
                 // logarithm of 4096 samples per vector
-                out[0] = 2. * (ln_kh + log_pos(fabs(T))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
+                out[0] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(T)) : log_tab_any(fabs(T), &mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
                 continue;
             }
-            const double tilt = primordial_tilt(pc, ln_kh);
+            const double tilt = primordial_tilt(pc, ln_kh, &mt);
             if (A.what == CP_PK_PRIMORDIAL) {
                 out[0] = pc.h3_A_s * tilt;
                 continue;

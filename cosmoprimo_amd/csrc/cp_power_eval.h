@@ -89,12 +89,18 @@ __device__ __forceinline__ EhPerCosmology eh_per_cosmology(const EhScalars& s, d
 // factors taken out of the loop over wavenumbers; within 1e-14 of the operation-for-operation form (tests/test_cosmology_gpu.py, 1e-11 against
 // the reference's numbers).  ln_kh = log(kh): the powers of q and k / k_silk go through it, x^p = exp(p (log kh + log(x / kh))), one log
 // shared by the three powers of k of a P(k) evaluation instead of a pow() each; the relative error of exp(p log x) is |p log x| eps < 2e-15 here.
-__device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh, double ln_kh) {
+#ifndef CP_MATH_TABLES_OFF      // 1: the polynomial forms everywhere (measurements)
+#define CP_MATH_TABLES_OFF 0
+#endif
+
+__device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh, double ln_kh, const MathTables* mt) {
+    if (CP_MATH_TABLES_OFF) mt = nullptr;
     const double q = kh * d.q_per_kh;
     const double ks = kh * d.ks_per_kh;
-    const double ln_beta = log_pos(kE + d.beta18 * q);
-    const double ln_nobeta = log_pos(kE + 1.8 * q);
-    const double q108 = exp_mid(1.08 * (ln_kh + d.ln_q_over_kh));
+    // mt: the table-driven logarithm and exponential (cp_math.h) where the kernel keeps their tables in LDS, else (null) the polynomial forms
+    const double ln_beta = mt ? log_tab(kE + d.beta18 * q, mt) : log_pos(kE + d.beta18 * q);      // (arguments >= e: log_tab's relative error is log_pos's there)
+    const double ln_nobeta = mt ? log_tab(kE + 1.8 * q, mt) : log_pos(kE + 1.8 * q);
+    const double q108 = mt ? exp_tab(1.08 * (ln_kh + d.ln_q_over_kh), mt) : exp_mid(1.08 * (ln_kh + d.ln_q_over_kh));
     const double c386 = 386. * recip(1 + 69.9 * q108);
     const double C_alpha = d.c_alpha0 + c386, C_noalpha = 14.2 + c386;
     const double ks54 = ks * (1. / 5.4), ks52 = ks * (1. / 5.2);
@@ -107,19 +113,20 @@ __device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh
     const double ks3 = ks * ks * ks;
     const double ks_tilde = ks * ks * rcbrt(ks3 + d.beta_node3);         // k rs_drag / cbrt(1 + (beta_node / ks)^3)
     const double T_b_1 = ln_nobeta * recip((ln_nobeta + C_noalpha * q2) * fma(ks52, ks52, 1.));
-    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * exp_mid(-exp_mid(1.4 * (ln_kh + d.ln_ksilk_over_kh)));
+    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * (mt ? exp_tab(-exp_tab(1.4 * (ln_kh + d.ln_ksilk_over_kh), mt), mt) : exp_mid(-exp_mid(1.4 * (ln_kh + d.ln_ksilk_over_kh))));
     const double sinc = ks_tilde == 0. ? 1. : sin_bounded(ks_tilde) * recip(ks_tilde);   // numpy.sinc(x / pi)
     const double T_b = sinc * (T_b_1 + T_b_2);
     return d.frac_b * T_b + (1 - d.frac_b) * T_c;
 }
 
-__device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h, double kh) {  // eisenstein_hu_nowiggle.py:45-51
+__device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h, double kh, const MathTables* mt) {  // eisenstein_hu_nowiggle.py:45-51
+    if (CP_MATH_TABLES_OFF) mt = nullptr;
     const double k = kh * h;
     const double ks = k * s.rs_drag;
     const double x = 0.43 * ks;
     const double gamma_eff = s.omega_m * (s.alpha_gamma + (1 - s.alpha_gamma) / (1 + (x * x) * (x * x)));
     const double q = k * (s.theta_cmb * s.theta_cmb) / gamma_eff;
-    const double L0 = log_pos(2 * kE + 1.8 * q);
+    const double L0 = mt ? log_tab(2 * kE + 1.8 * q, mt) : log_pos(2 * kE + 1.8 * q);
     const double C0 = 14.2 + 731.0 / (1 + 62.5 * q);
     return L0 / (L0 + C0 * (q * q));
 }
@@ -159,6 +166,8 @@ __device__ __forceinline__ double primordial_tilt_exponent(const PkPerCosmology&
     const double lnkkp = ln_kh - p.ln_kp;
     return (p.n_s - 1. + 1. / 2. * p.alpha_s * lnkkp + 1. / 6. * p.beta_s * (lnkkp * lnkkp)) * lnkkp;
 }
-__device__ __forceinline__ double primordial_tilt(const PkPerCosmology& p, double ln_kh) { return exp_mid(primordial_tilt_exponent(p, ln_kh)); }
+__device__ __forceinline__ double primordial_tilt(const PkPerCosmology& p, double ln_kh, const MathTables* mt) {
+    return (mt && !CP_MATH_TABLES_OFF) ? exp_tab(primordial_tilt_exponent(p, ln_kh), mt) : exp_mid(primordial_tilt_exponent(p, ln_kh));
+}
 
 }  // namespace cppower

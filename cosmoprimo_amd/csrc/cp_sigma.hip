@@ -61,6 +61,10 @@ struct SigmaArgs {
     double* pk_out;               // (ncosmo, n) the spectra themselves, or null
 };
 
+#ifndef CP_SIGMA_RZ_TABLES
+#define CP_SIGMA_RZ_TABLES 0
+#endif
+
 // phases 0 .. NPH - 2 of the FFTLog of one pair, with the barriers of run_phases (cp_fftlog_kernel.h)
 template <class F, int PH>
 __device__ __forceinline__ void front_phases(int t, const FftlogArgs& A, bool has_b, cplx* lds, typename F::State& st) {
@@ -82,7 +86,8 @@ __device__ __forceinline__ void front_phases(int t, const FftlogArgs& A, bool ha
 // load here would make the wave wait for the 256 stores of the previous pair (the vector-memory counter retires in order), which are meant
 // to drain under this arithmetic.  (k_j differs from the tabulated one by a few ulp: 1e-15 on P.)
 template <int ENGINE, int T, int H>
-__device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long ic, int t0, double kh0, double ln0, double ratio, double ln_ratio, double* slots) {
+__device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long ic, int t0, double kh0, double ln0, double ratio, double ln_ratio, double* slots,
+                                                  const MathTables* mt) {
     const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
@@ -100,8 +105,8 @@ __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long 
             const int j = t0 + T * (r0 + u);
             double Tk;
             if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
-            slots[2 * j] = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh);
+            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, mt) : transfer_nowiggle(s, c.h, kh, mt);
+            slots[2 * j] = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, mt);
             kh *= ratio;
             ln_kh += ln_ratio;
         }
@@ -110,10 +115,10 @@ __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long 
 
 template <int ENGINE, int T, int H>
 __device__ __forceinline__ void evaluate_spectra(const SigmaArgs& S, long long ia, long long ib, int t0, double kh0, double ln0, double ratio,
-                                                 double ln_ratio, cplx* lds, double* va, double* vb) {
+                                                 double ln_ratio, cplx* lds, double* va, double* vb, const MathTables* mt) {
     double* slots = reinterpret_cast<double*>(lds);      // (re, im) of slot j = (row a, row b) at sample j
-    evaluate_spectrum<ENGINE, T, H>(S, ia, t0, kh0, ln0, ratio, ln_ratio, slots);
-    evaluate_spectrum<ENGINE, T, H>(S, ib, t0, kh0, ln0, ratio, ln_ratio, slots + 1);
+    evaluate_spectrum<ENGINE, T, H>(S, ia, t0, kh0, ln0, ratio, ln_ratio, slots, mt);
+    evaluate_spectrum<ENGINE, T, H>(S, ib, t0, kh0, ln0, ratio, ln_ratio, slots + 1, mt);
 #pragma unroll
     for (int r = 0; r < H; ++r) {      // the thread's own slots: no barrier
         va[r] = slots[2 * (t0 + T * r)];
@@ -188,6 +193,15 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
     cplx* lds = reinterpret_cast<cplx*>(smem);
     double* roots_r = reinterpret_cast<double*>(smem + F::LDS_BYTES);   // (2, nq) sqrt of the splined variances of rows a and b
     double* roots_g = roots_r + 2 * S.nq;                               // (2, nz) sqrt of the growth factors
+    // the table-driven logarithm / exponential of the evaluation (cp_math.h): measured SLOWER here (0.41 against 0.335 ms per 10 000 cosmologies --
+    // the gathers sit in dependent chains that this kernel, at two waves per SIMD with the FFT's registers, cannot cover), so off
+#if CP_SIGMA_RZ_TABLES
+    __shared__ MathTables mt;      // (the barrier behind the FFT tables covers it)
+    fill_math_tables(&mt);
+    const MathTables* mtp = &mt;
+#else
+    const MathTables* mtp = nullptr;
+#endif
     const int t = threadIdx.x;
     const FftlogArgs& A = S.fft;
     const long long npairs = (S.ncosmo + 1) / 2;
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
 #pragma unroll
             for (int r = 0; r < H; ++r) st.va[r] = 1. + 1e-3 * (t + r), st.vb[r] = 2. - 1e-3 * (t + r);
         } else {
-            evaluate_spectra<ENGINE, T, H>(S, ia, ib, t0, kh0, ln0, ratio, ln_ratio, lds, st.va, st.vb);
+            evaluate_spectra<ENGINE, T, H>(S, ia, ib, t0, kh0, ln0, ratio, ln_ratio, lds, st.va, st.vb, mtp);
             if (S.pk_out) {      // the caller keeps the spectra (the sigma8 normalisation: the filters ask for them on these wavenumbers next)
 #pragma unroll
                 for (int r = 0; r < H; ++r) {
@@ -748,6 +762,9 @@ struct FunctionalArgs {
 template <int ENGINE>
 __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const FunctionalArgs S) {      // three waves per SIMD, as power_kernel (the evaluation is the same)
     constexpr int PER_LANE = 16;      // nk = 1024
+    __shared__ MathTables mt;
+    fill_math_tables(&mt);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ic >= S.ncosmo) return;
@@ -768,8 +785,8 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
         const double kh = S.k[j], ln_kh = S.ln_k[j];
         double Tk;
         if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
-        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh);
+        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, &mt) : transfer_nowiggle(s, c.h, kh, &mt);
+        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         pks[64 * i] = pk;
         acc = fma(S.functional[j], pk, acc);
     }
@@ -791,6 +808,9 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
 
 template <int ENGINE>
 __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalArgs S) {
+    __shared__ MathTables mt;
+    fill_math_tables(&mt);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ic >= S.ncosmo) return;
@@ -810,8 +830,8 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
         const double kh = S.k[j], ln_kh = S.ln_k[j];
         double Tk;
         if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh) : transfer_nowiggle(s, c.h, kh);
-        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh);
+        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, &mt) : transfer_nowiggle(s, c.h, kh, &mt);
+        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         if (S.pk_out) S.pk_out[ic * S.nk + j] = pk;
 #pragma unroll
         for (int q = 0; q < FUNCTIONAL_MAX_NQ; ++q)

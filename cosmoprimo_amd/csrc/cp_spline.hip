@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256, CP_TABLES_WAVES) void tables_rows_direct_kerne
     __shared__ double4 tile_w[256];
     __shared__ int tile_j[256];
     __shared__ double exp_tab[64];
-    if (threadIdx.x < 64) exp_tab[threadIdx.x] = cpmath::exp10_table[threadIdx.x];
+    if (threadIdx.x < 64) exp_tab[threadIdx.x] = cpmath::exp2_table[threadIdx.x];
     const int tile = (int)(blockIdx.x % nqt);
     for (int e = threadIdx.x; e < 64 * 32; e += 256) {
         const int q = e >> 5, kz = e & 31;
