@@ -301,9 +301,9 @@ struct GenArgs {
 #define CP_DST_GEN_ILP 2
 #endif
 
-__global__ void dst_log_kernel(const double* k, double* ln_k, int n) {
+__global__ void dst_log_kernel(const double* k, double* ln_k, int n) {      // ln_k: (3, n) log k, k^1.08, k^1.4 (cp_power_eval.h)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ln_k[i] = cpmath::log_pos(k[i]);
+    if (i < n) cppower::powers_of_wavenumber(k[i], ln_k, i, n);
 }
 
 // log(k P(k)) of cosmology ic at the thread's P samples m = t + T r of the reordered sequence, into the thread's own slots of the data region
@@ -331,7 +331,7 @@ __device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int
             const double kh = G.k[n], ln_kh = G.ln_k[n];
             double Tk;
             if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, mt) : transfer_nowiggle(s, c.h, kh, mt);
+            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, G.ln_k[N + n], G.ln_k[2 * N + n], mt) : transfer_nowiggle(s, c.h, kh, mt);
             slots[2 * m] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(Tk)) : log_tab_any(fabs(Tk), mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
         }
     }
@@ -527,7 +527,7 @@ extern "C" int cp_dst_plan_create(cp_dst_plan** out, int n, const double* kx, in
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: cannot select device %d", device);
     if (status == CP_OK && (hipMalloc(&p->d_tw, tw.size() * sizeof(cplx)) != hipSuccess || hipMalloc(&p->d_rot, n * sizeof(cplx)) != hipSuccess ||
-                            (kx && (hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ln_kx, n * sizeof(double)) != hipSuccess))))
+                            (kx && (hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ln_kx, 3 * (size_t)n * sizeof(double)) != hipSuccess))))
         status = cp::fail(CP_ENOMEM, "cp_dst_plan_create: device allocation failed");
     if (status == CP_OK && (hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(p->d_rot, rot.data(), n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||

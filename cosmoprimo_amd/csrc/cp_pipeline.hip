@@ -60,7 +60,7 @@ void offset_params(const cp_param* in, cp_param* out, int n, long long first) {
 
 extern "C" long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk) {
     if (ncosmo < 0 || nk < 0) return -1;
-    return 2 * ncosmo * (long long)nk * (long long)sizeof(double) + cp_power_workspace_bytes(ncosmo) + 192 + (long long)nk * (long long)sizeof(double);
+    return 2 * ncosmo * (long long)nk * (long long)sizeof(double) + cp_power_workspace_bytes(ncosmo) + 192 + 3 * (long long)nk * (long long)sizeof(double);      // ... + log k, k^1.08, k^1.4
 }
 
 extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,

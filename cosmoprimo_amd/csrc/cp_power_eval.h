@@ -20,6 +20,7 @@ struct EhScalars {
     double omega_b, omega_m, frac_b, theta_cmb, z_eq, k_eq, z_drag, r_drag, r_eq, rs_drag, k_silk, alpha_c, beta_c, alpha_b, beta_node, beta_b,
         alpha_gamma;
     double ln_q_over_kh, ln_ksilk_over_kh;  // log(q / kh) = log(h / (13.41 k_eq)) and log((k / k_silk) / kh) = log(h / k_silk): see transfer_eh
+    double q108_per_kh, ksilk14_per_kh;     // (q / kh)^1.08 and ((k / k_silk) / kh)^1.4: with tabulated kh^1.08, kh^1.4 the two powers of a sample are products (transfer_eh_powers)
 };
 
 // eisenstein_hu.py:34-92 (+ eisenstein_hu_nowiggle.py:21), operation for operation
@@ -54,9 +55,11 @@ __device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, doub
         s.beta_b = 0.5 + s.frac_b + (3. - 2. * s.frac_b) * sqrt((17.2 * s.omega_m) * (17.2 * s.omega_m) + 1);
         s.ln_q_over_kh = log(h / (13.41 * s.k_eq));
         s.ln_ksilk_over_kh = log(h / s.k_silk);
+        s.q108_per_kh = exp(1.08 * s.ln_q_over_kh);
+        s.ksilk14_per_kh = exp(1.4 * s.ln_ksilk_over_kh);
     } else {
         s.k_silk = s.alpha_c = s.beta_c = s.alpha_b = s.beta_node = s.beta_b = 0.;
-        s.ln_q_over_kh = s.ln_ksilk_over_kh = 0.;
+        s.ln_q_over_kh = s.ln_ksilk_over_kh = s.q108_per_kh = s.ksilk14_per_kh = 0.;
     }
     return s;
 }
@@ -67,7 +70,7 @@ struct EhPerCosmology {
     double ks_per_kh;    // ks = kh h rs_drag
     double c_alpha0;     // 14.2 / alpha_c
     double beta18, beta_node3, beta_b3, alpha_b, frac_b;
-    double ln_q_over_kh, ln_ksilk_over_kh;
+    double ln_q_over_kh, ln_ksilk_over_kh, q108_per_kh, ksilk14_per_kh;
 };
 
 __device__ __forceinline__ EhPerCosmology eh_per_cosmology(const EhScalars& s, double h) {
@@ -82,25 +85,23 @@ __device__ __forceinline__ EhPerCosmology eh_per_cosmology(const EhScalars& s, d
     d.frac_b = s.frac_b;
     d.ln_q_over_kh = s.ln_q_over_kh;
     d.ln_ksilk_over_kh = s.ln_ksilk_over_kh;
+    d.q108_per_kh = s.q108_per_kh;
+    d.ksilk14_per_kh = s.ksilk14_per_kh;
     return d;
 }
 
-// eisenstein_hu.py:252-283, the same rational functions with their quotients gathered (6 reciprocals instead of 16 divisions) and the cosmology-only
-// factors taken out of the loop over wavenumbers; within 1e-14 of the operation-for-operation form (tests/test_cosmology_gpu.py, 1e-11 against
-// the reference's numbers).  ln_kh = log(kh): the powers of q and k / k_silk go through it, x^p = exp(p (log kh + log(x / kh))), one log
-// shared by the three powers of k of a P(k) evaluation instead of a pow() each; the relative error of exp(p log x) is |p log x| eps < 2e-15 here.
 #ifndef CP_MATH_TABLES_OFF      // 1: the polynomial forms everywhere (measurements)
 #define CP_MATH_TABLES_OFF 0
 #endif
 
-__device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh, double ln_kh, const MathTables* mt) {
+// q108 = q^1.08, silk14 = (k / k_silk)^1.4: the two powers of the wavenumber the fit takes
+__device__ __forceinline__ double transfer_eh_core(const EhPerCosmology& d, double kh, double q108, double silk14, const MathTables* mt) {
     if (CP_MATH_TABLES_OFF) mt = nullptr;
     const double q = kh * d.q_per_kh;
     const double ks = kh * d.ks_per_kh;
     // mt: the table-driven logarithm and exponential (cp_math.h) where the kernel keeps their tables in LDS, else (null) the polynomial forms
     const double ln_beta = mt ? log_tab(kE + d.beta18 * q, mt) : log_pos(kE + d.beta18 * q);      // (arguments >= e: log_tab's relative error is log_pos's there)
     const double ln_nobeta = mt ? log_tab(kE + 1.8 * q, mt) : log_pos(kE + 1.8 * q);
-    const double q108 = mt ? exp_tab(1.08 * (ln_kh + d.ln_q_over_kh), mt) : exp_mid(1.08 * (ln_kh + d.ln_q_over_kh));
     const double c386 = 386. * recip(1 + 69.9 * q108);
     const double C_alpha = d.c_alpha0 + c386, C_noalpha = 14.2 + c386;
     const double ks54 = ks * (1. / 5.4), ks52 = ks * (1. / 5.2);
@@ -113,10 +114,39 @@ __device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh
     const double ks3 = ks * ks * ks;
     const double ks_tilde = ks * ks * rcbrt(ks3 + d.beta_node3);         // k rs_drag / cbrt(1 + (beta_node / ks)^3)
     const double T_b_1 = ln_nobeta * recip((ln_nobeta + C_noalpha * q2) * fma(ks52, ks52, 1.));
-    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * (mt ? exp_tab(-exp_tab(1.4 * (ln_kh + d.ln_ksilk_over_kh), mt), mt) : exp_mid(-exp_mid(1.4 * (ln_kh + d.ln_ksilk_over_kh))));
+    const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * (mt ? exp_tab(-silk14, mt) : exp_mid(-silk14));
     const double sinc = ks_tilde == 0. ? 1. : sin_bounded(ks_tilde) * recip(ks_tilde);   // numpy.sinc(x / pi)
     const double T_b = sinc * (T_b_1 + T_b_2);
     return d.frac_b * T_b + (1 - d.frac_b) * T_c;
+}
+
+// eisenstein_hu.py:252-283, the same rational functions with their quotients gathered (6 reciprocals instead of 16 divisions) and the cosmology-only
+// factors taken out of the loop over wavenumbers; within 1e-14 of the operation-for-operation form (tests/test_cosmology_gpu.py, 1e-11 against
+// the reference's numbers).  ln_kh = log(kh): the powers of q and k / k_silk go through it, x^p = exp(p (log kh + log(x / kh))), one log
+// shared by the three powers of k of a P(k) evaluation instead of a pow() each; the relative error of exp(p log x) is |p log x| eps < 2e-15 here.
+__device__ __forceinline__ double transfer_eh(const EhPerCosmology& d, double kh, double ln_kh, const MathTables* mt) {
+    const bool tab = mt && !CP_MATH_TABLES_OFF;
+    const double q108 = tab ? exp_tab(1.08 * (ln_kh + d.ln_q_over_kh), mt) : exp_mid(1.08 * (ln_kh + d.ln_q_over_kh));
+    const double silk14 = tab ? exp_tab(1.4 * (ln_kh + d.ln_ksilk_over_kh), mt) : exp_mid(1.4 * (ln_kh + d.ln_ksilk_over_kh));
+    return transfer_eh_core(d, kh, q108, silk14, mt);
+}
+
+// ... on a grid of wavenumbers shared by the cosmologies of a launch: kh^1.08 and kh^1.4 come from tables next to log kh (powers_of_wavenumbers), and
+// the two powers are products with the cosmology's own factors -- two exponentials fewer per sample (3e-16 from the form above)
+#ifndef CP_K_POWER_TABLES      // 0: the exponentials of log kh instead (measurements)
+#define CP_K_POWER_TABLES 1
+#endif
+__device__ __forceinline__ double transfer_eh_powers(const EhPerCosmology& d, double kh, double ln_kh, double kh108, double kh14, const MathTables* mt) {
+    if (!CP_K_POWER_TABLES) return transfer_eh(d, kh, ln_kh, mt);
+    return transfer_eh_core(d, kh, kh108 * d.q108_per_kh, kh14 * d.ksilk14_per_kh, mt);
+}
+
+// log k, k^1.08, k^1.4 of the n wavenumbers of a launch: tab (3, n)
+__device__ __forceinline__ void powers_of_wavenumber(double k, double* tab, int i, int n) {
+    const double l = log_pos(k);
+    tab[i] = l;
+    tab[n + i] = exp(1.08 * l);
+    tab[2 * n + i] = exp(1.4 * l);
 }
 
 __device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h, double kh, const MathTables* mt) {  // eisenstein_hu_nowiggle.py:45-51

@@ -86,8 +86,8 @@ __device__ __forceinline__ void front_phases(int t, const FftlogArgs& A, bool ha
 // load here would make the wave wait for the 256 stores of the previous pair (the vector-memory counter retires in order), which are meant
 // to drain under this arithmetic.  (k_j differs from the tabulated one by a few ulp: 1e-15 on P.)
 template <int ENGINE, int T, int H>
-__device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long ic, int t0, double kh0, double ln0, double ratio, double ln_ratio, double* slots,
-                                                  const MathTables* mt) {
+__device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long ic, int t0, double kh0, double ln0, double ratio, double ln_ratio, double2 pw0,
+                                                  double2 pw_ratio, double* slots, const MathTables* mt) {
     const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
@@ -96,7 +96,7 @@ __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long 
     if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
     const EhPerCosmology eh = eh_per_cosmology(s, c.h);
     const PkPerCosmology pc = pk_per_cosmology(c, pw);
-    double kh = kh0, ln_kh = ln0;
+    double kh = kh0, ln_kh = ln0, kh108 = pw0.x, kh14 = pw0.y;
     // CP_SIGMA_ILP samples per iteration: independent chains of logarithms / exponentials / reciprocals for the two waves of a SIMD to interleave
 #pragma unroll 1
     for (int r0 = 0; r0 < H; r0 += CP_SIGMA_ILP) {
@@ -105,20 +105,22 @@ __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long 
             const int j = t0 + T * (r0 + u);
             double Tk;
             if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, mt) : transfer_nowiggle(s, c.h, kh, mt);
+            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, kh108, kh14, mt) : transfer_nowiggle(s, c.h, kh, mt);
             slots[2 * j] = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, mt);
             kh *= ratio;
             ln_kh += ln_ratio;
+            kh108 *= pw_ratio.x;
+            kh14 *= pw_ratio.y;
         }
     }
 }
 
 template <int ENGINE, int T, int H>
 __device__ __forceinline__ void evaluate_spectra(const SigmaArgs& S, long long ia, long long ib, int t0, double kh0, double ln0, double ratio,
-                                                 double ln_ratio, cplx* lds, double* va, double* vb, const MathTables* mt) {
+                                                 double ln_ratio, double2 pw0, double2 pw_ratio, cplx* lds, double* va, double* vb, const MathTables* mt) {
     double* slots = reinterpret_cast<double*>(lds);      // (re, im) of slot j = (row a, row b) at sample j
-    evaluate_spectrum<ENGINE, T, H>(S, ia, t0, kh0, ln0, ratio, ln_ratio, slots, mt);
-    evaluate_spectrum<ENGINE, T, H>(S, ib, t0, kh0, ln0, ratio, ln_ratio, slots + 1, mt);
+    evaluate_spectrum<ENGINE, T, H>(S, ia, t0, kh0, ln0, ratio, ln_ratio, pw0, pw_ratio, slots, mt);
+    evaluate_spectrum<ENGINE, T, H>(S, ib, t0, kh0, ln0, ratio, ln_ratio, pw0, pw_ratio, slots + 1, mt);
 #pragma unroll
     for (int r = 0; r < H; ++r) {      // the thread's own slots: no barrier
         va[r] = slots[2 * (t0 + T * r)];
@@ -127,9 +129,9 @@ __device__ __forceinline__ void evaluate_spectra(const SigmaArgs& S, long long i
 }
 
 // log of the wavenumbers with the kernels' own logarithm (what power_kernel evaluates per sample), once per launch
-__global__ void log_wavenumbers_kernel(const double* k, double* ln_k, int n) {
+__global__ void log_wavenumbers_kernel(const double* k, double* ln_k, int n) {      // ln_k: (3, n) log k, k^1.08, k^1.4 (cp_power_eval.h)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ln_k[i] = log_pos(k[i]);
+    if (i < n) powers_of_wavenumber(k[i], ln_k, i, n);
 }
 
 // the cropped outputs of the pair, variance j = t0 + T s of (row a, row b), into the (now free) data region in natural order, 16-byte slots
@@ -212,6 +214,10 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
     F::fill_lds_tables(t, A, lds);
     const int t0 = st.t0;
     const double kh0 = S.k[t0], ln0 = S.ln_k[t0], ratio = S.k[T] / S.k[0], ln_ratio = S.ln_k[T] - S.ln_k[0];
+    // k^1.08 and k^1.4 of the thread's first sample and their steps along the geometric grid (tables behind log k: log_wavenumbers_kernel)
+    const int nk_tab = NP / 2;
+    const double2 pw0 = double2{S.ln_k[nk_tab + t0], S.ln_k[2 * nk_tab + t0]};
+    const double2 pw_ratio = double2{S.ln_k[nk_tab + T] / S.ln_k[nk_tab], S.ln_k[2 * nk_tab + T] / S.ln_k[2 * nk_tab]};
     __syncthreads();
     for (; p < npairs; p += gridDim.x) {
         const long long ia = 2 * p;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
 #pragma unroll
             for (int r = 0; r < H; ++r) st.va[r] = 1. + 1e-3 * (t + r), st.vb[r] = 2. - 1e-3 * (t + r);
         } else {
-            evaluate_spectra<ENGINE, T, H>(S, ia, ib, t0, kh0, ln0, ratio, ln_ratio, lds, st.va, st.vb, mtp);
+            evaluate_spectra<ENGINE, T, H>(S, ia, ib, t0, kh0, ln0, ratio, ln_ratio, pw0, pw_ratio, lds, st.va, st.vb, mtp);
             if (S.pk_out) {      // the caller keeps the spectra (the sigma8 normalisation: the filters ask for them on these wavenumbers next)
 #pragma unroll
                 for (int r = 0; r < H; ++r) {
@@ -785,7 +791,7 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
         const double kh = S.k[j], ln_kh = S.ln_k[j];
         double Tk;
         if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, &mt) : transfer_nowiggle(s, c.h, kh, &mt);
+        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, S.ln_k[1024 + j], S.ln_k[2048 + j], &mt) : transfer_nowiggle(s, c.h, kh, &mt);
         const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         pks[64 * i] = pk;
         acc = fma(S.functional[j], pk, acc);
@@ -830,7 +836,7 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
         const double kh = S.k[j], ln_kh = S.ln_k[j];
         double Tk;
         if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
-        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, &mt) : transfer_nowiggle(s, c.h, kh, &mt);
+        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, S.ln_k[S.nk + j], S.ln_k[2 * S.nk + j], &mt) : transfer_nowiggle(s, c.h, kh, &mt);
         const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         if (S.pk_out) S.pk_out[ic * S.nk + j] = pk;
 #pragma unroll

@@ -100,7 +100,7 @@ def test_block_walk_on_two_streams():
 @pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
 def test_few_radii_as_a_functional_of_the_spectrum(engine):
     """cp_sigma_rz_functional (up to four radii: the sigma8 normalisation) against the fused kernel of the same helper: sigma(r, z), and the spectra
-    it hands back, which are cp_power_eval's bit for bit; odd batches, one to four radii, a NaN cosmology next to good ones."""
+    it hands back, which are cp_power_eval's to a few ulp; odd batches, one to four radii, a NaN cosmology next to good ones."""
     import torch
     from cosmoprimo_amd import interpolator as itp
     warnings.simplefilter('ignore')
@@ -133,7 +133,10 @@ def test_few_radii_as_a_functional_of_the_spectrum(engine):
         np.testing.assert_allclose(pk_f, pk_t, rtol=1e-10 if engine == 'bbks' else 2e-13, atol=0)
         from cosmoprimo_amd import power
         direct = power.analytic(engine, 'matter', k, bg=bg, pk=pk, device=dev).cpu().numpy().reshape(pk_f.shape)
-        assert np.array_equal(direct, pk_f, equal_nan=True)
+        # the same evaluation but for the two powers of k the fit takes: cp_power_eval forms them as exp(p (log k + log c)), this kernel as k^p c^p
+        # with k^p tabulated once per launch (cp_power_eval.h: transfer_eh_powers) -- a few ulp apart
+        assert np.array_equal(np.isnan(direct), np.isnan(pk_f))
+        np.testing.assert_allclose(pk_f, direct, rtol=0 if engine == 'bbks' else 4e-15, atol=0)
 
 
 def _oracle_sigma(engine, par, i, r, g2):

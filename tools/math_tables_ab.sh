@@ -13,7 +13,7 @@ PY
 }
 build() { ( cd cosmoprimo_amd/csrc && for f in cp_power cp_sigma cp_dst; do hipcc $base $1 -c $f.hip -o $f.o & done; wait; make > /dev/null 2>&1 ); }
 for round in 1 2; do
-  for v in "-DCP_MATH_TABLES_OFF=0" "-DCP_MATH_TABLES_OFF=1" "-DCP_SIGMA_RZ_TABLES=1"; do
+  for v in ${VARIANTS:-"-DCP_K_POWER_TABLES=1" "-DCP_K_POWER_TABLES=0" "-DCP_MATH_TABLES_OFF=1"}; do
     build "$v"; echo "== $v"; line
   done
 done
