@@ -37,6 +37,7 @@ struct Args {
     const cplx* tw;     // Plan twiddles
     const cplx* rot;    // (N) e^{-i pi k / (2N)} = (cos, -sin)
     const double* kx;   // (N) optional abscissa for the fused maps, or nullptr
+    const double* ikx;  // (N) its reciprocals (the plan's table), or nullptr
     int fused;          // forward: x_n := log(kx_n * in_n); inverse: out_n := exp(y_n) / kx_n
     int split;          // coefficients stored de-interleaved: Y_0, Y_2, ... in the first half of the row, Y_1, Y_3, ... in the second
 };
@@ -88,6 +89,10 @@ __device__ __forceinline__ void dif_all(int t, const Args& A, cplx* x, cplx* lds
     __syncthreads();
 }
 
+#ifndef CP_DST_ABLATE      // diagnostic builds of the inverse transform (wrong results): 1 no fused map, 2 no in-place loads of the second half, 4 no stores, 8 no transform
+#define CP_DST_ABLATE 0
+#endif
+
 template <int N, int P, bool INVERSE>
 __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     using PL = Plan<N, P>;
@@ -104,6 +109,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
     // partner is untouched.  The flags of the pair are raised by whichever thread meets such a sample and read behind one barrier.
     __shared__ int bad_row[2];
     __shared__ int pair_flag;   // inverse transform: some sample of the pair is not finite
+    __shared__ cpmath::MathTables mt;      // the table-driven exponential of the fused inverse map (the barrier at the top of the first pair covers the fill)
+    if (INVERSE) cpmath::fill_math_tables(&mt);
     const double nan = __builtin_nan("");
     // forward transform: the rows of the NEXT pair are fetched (in Makhoul order) while this pair is transformed -- the loads of a pair used to sit
     // at the top of its iteration, in front of everything that needs them, with two waves per SIMD to cover their latency
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                     const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
                     const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
                     const double Aa = fa * (prefetched ? na[r] : ra[at(ia)]), Ab = fa * (prefetched ? nb[r] : rb[at(ia)]);
-                    const double Ba = (k == 0 ? fa : fb) * ra[at(ib)], Bb = (k == 0 ? fa : fb) * rb[at(ib)];
+                    const double Ba = (k == 0 ? fa : fb) * ((CP_DST_ABLATE & 2) ? na[r] : ra[at(ib)]), Bb = (k == 0 ? fa : fb) * ((CP_DST_ABLATE & 2) ? nb[r] : rb[at(ib)]);
                     const cplx rot = A.rot[k];
                     const double cs = rot.re, sn = -rot.im;
                     cplx Ha, Hb;
@@ -252,7 +259,11 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 // finite rows whose sum overflowed in the packing stay as they are (skip_a = skip_b = false): nothing to separate
                 if (skip_a | skip_b) spectrum(!skip_a, has_b && !skip_b, false);
             }
-            dif_all<N, P>(tt, A, x, lds, ltw);
+            if (!(CP_DST_ABLATE & 8)) dif_all<N, P>(tt, A, x, lds, ltw);
+            else {
+                Pass<N, P, 0>::store_lds(tt, lds, x);
+                __syncthreads();
+            }
             asm volatile("" : "+v"(tt));
             // LDS holds (v_a[m], -v_b[m]) at pos(m); undo the reordering and the (-1)^n sign
 #pragma unroll 4
@@ -263,12 +274,12 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                 const cplx g = lds_at<N, P>(lds, pos_of_freq<N, P>(m));
                 double ya = even ? g.re : -g.re;
                 double yb = even ? -g.im : g.im;
-                if (A.fused) {
-                    const double kk = A.kx[n];
-                    const double ik = cpmath::recip(kk);
-                    ya = cpmath::exp_mid(ya) * ik;
-                    yb = cpmath::exp_mid(yb) * ik;
+                if (A.fused && !(CP_DST_ABLATE & 1)) {
+                    const double ik = A.ikx ? A.ikx[n] : cpmath::recip(A.kx[n]);
+                    ya = cpmath::exp_tab(ya, &mt) * ik;
+                    yb = cpmath::exp_tab(yb, &mt) * ik;
                 }
+                if ((CP_DST_ABLATE & 4) && ya != 12345.678) continue;
                 oa[n] = skip_a ? nan : ya;
                 if (has_b) ob[n] = skip_b ? nan : yb;
             }
@@ -301,9 +312,12 @@ struct GenArgs {
 #define CP_DST_GEN_ILP 2
 #endif
 
-__global__ void dst_log_kernel(const double* k, double* ln_k, int n) {      // ln_k: (3, n) log k, k^1.08, k^1.4 (cp_power_eval.h)
+__global__ void dst_log_kernel(const double* k, double* ln_k, int n) {      // ln_k: (4, n) log k, k^1.08, k^1.4 (cp_power_eval.h), 1 / k
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cppower::powers_of_wavenumber(k[i], ln_k, i, n);
+    if (i < n) {
+        cppower::powers_of_wavenumber(k[i], ln_k, i, n);
+        ln_k[3 * n + i] = 1. / k[i];
+    }
 }
 
 // log(k P(k)) of cosmology ic at the thread's P samples m = t + T r of the reordered sequence, into the thread's own slots of the data region
@@ -527,7 +541,7 @@ extern "C" int cp_dst_plan_create(cp_dst_plan** out, int n, const double* kx, in
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: cannot select device %d", device);
     if (status == CP_OK && (hipMalloc(&p->d_tw, tw.size() * sizeof(cplx)) != hipSuccess || hipMalloc(&p->d_rot, n * sizeof(cplx)) != hipSuccess ||
-                            (kx && (hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ln_kx, 3 * (size_t)n * sizeof(double)) != hipSuccess))))
+                            (kx && (hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ln_kx, 4 * (size_t)n * sizeof(double)) != hipSuccess))))
         status = cp::fail(CP_ENOMEM, "cp_dst_plan_create: device allocation failed");
     if (status == CP_OK && (hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(p->d_rot, rot.data(), n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
@@ -558,7 +572,7 @@ extern "C" int cp_dst_execute(const cp_dst_plan* p, const double* d_in, double* 
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_execute: cannot select device %d", p->device);
     Args A;
-    A.in = d_in; A.out = d_out; A.nrows = nrows; A.tw = p->d_tw; A.rot = p->d_rot; A.kx = p->d_kx; A.fused = fused; A.split = (flags & CP_DST_SPLIT) != 0;
+    A.in = d_in; A.out = d_out; A.nrows = nrows; A.tw = p->d_tw; A.rot = p->d_rot; A.kx = p->d_kx; A.ikx = p->d_ln_kx ? p->d_ln_kx + 3 * (size_t)p->n : nullptr; A.fused = fused; A.split = (flags & CP_DST_SPLIT) != 0;
     const long long npairs = (nrows + 1) / 2;
     const int grid = (int)(npairs < 512 ? npairs : 512);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -621,7 +635,7 @@ static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncos
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_forward_analytic: cannot select device %d", p->device);
     GenArgs G{};
-    G.dst.in = nullptr; G.dst.out = d_out; G.dst.nrows = ncosmo; G.dst.tw = p->d_tw; G.dst.rot = p->d_rot; G.dst.kx = nullptr; G.dst.fused = 0;
+    G.dst.in = nullptr; G.dst.out = d_out; G.dst.nrows = ncosmo; G.dst.tw = p->d_tw; G.dst.rot = p->d_rot; G.dst.kx = nullptr; G.dst.ikx = nullptr; G.dst.fused = 0;
     G.dst.split = (flags & CP_DST_SPLIT) != 0;
     G.ncosmo = ncosmo;
     for (int i = 0; i < CP_BG_NPARAMS; ++i) G.bg[i] = cpcosmo::Param{bg_params[i].ptr, bg_params[i].value};

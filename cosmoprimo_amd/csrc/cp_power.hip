@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
         for (long long ik = k0 + tid; ik < k1; ik += 256) {
             const double kh = A.kscale ? A.k[ik] * kfac : A.k[ik];
             double* out = A.out + (ic * nzs + z0) * A.nk + ik;
-            const double ln_kh = log_pos(kh);
+            const double ln_kh = CP_MATH_TABLES_OFF ? log_pos(kh) : log_tab_any(kh, &mt);      // (2e-16 max(1, |log kh|): the tilt and the powers of k take it times O(1) factors)
             double T = 1.;
             if (A.what != CP_PK_PRIMORDIAL) {
                 if (ENGINE == CP_ENGINE_BBKS)

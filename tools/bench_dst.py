@@ -1,31 +1,35 @@
-"""The two DST launches of a wallish2018 chunk: 16 384 rows of 4096, fused log(k x) forward, fused exp(.)/k inverse, split coefficient layout.
-    python tools/bench_dst.py"""
+"""The inverse DST of wallish2018 (exp(idst(.)) / k_lin, split layout) on 32 768 rows of 4096 coefficients.    python tools/bench_dst.py [nrows]"""
 import os
 import sys
-import time
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch      # noqa: E402
-from cosmoprimo_amd.dst import DST      # noqa: E402
 
-dev = torch.device('cuda', 0)
-n, nrows = 4096, 16384
-klin = np.linspace(1e-7, 2., n)
-d = DST(n, kx=klin, device=dev)
-x = torch.rand((nrows, n), dtype=torch.float64, device=dev) + 0.5
-y = d(x, fused=True, split=True)
-for label, fn in (('forward, fused log', lambda: d(x, fused=True, split=True)), ('inverse, fused exp / k', lambda: d(y, inverse=True, fused=True, split=True)),
-                  ('forward, plain', lambda: d(x)), ('inverse, plain', lambda: d(y, inverse=True))):
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        fn()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 20 * 1e3
-    print('%-24s %.3f ms  (%.2f TB/s)' % (label, ms, 2 * nrows * n * 8 / ms / 1e9))
-back = d(y, inverse=True, fused=True, split=True)
-print('round trip error %.2e' % float((back / x - 1).abs().max()))
+
+def main():
+    import torch
+    from cosmoprimo_amd.dst import DST
+    nrows, n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768, 4096
+    dev = torch.device('cuda', 0)
+    klin = np.linspace(1e-7, 2., n)
+    dst = DST(n, kx=klin, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1)
+    y = torch.randn((nrows, n), generator=gen, device=dev, dtype=torch.float64) * 0.1
+    for label, kw in (('inverse, fused exp / k, split', dict(inverse=True, fused=True, split=True)), ('inverse, plain', dict(inverse=True)), ('forward, plain', dict())):
+        ms = []
+        for rep in range(3):
+            for _ in range(2):
+                out = dst(y, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                out = dst(y, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / 10)
+        print('%-34s %s ms per %d rows' % (label, ' '.join('%.3f' % v for v in ms), nrows))
+
+
+if __name__ == '__main__':
+    main()
