@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage (build container, repo root, after `gpurun -- bash scripts/final_profiles.sh <tag>`): bash scripts/collect_final_profiles.sh <tag>
 # Summaries of gpurun_out/ into the committed profiles/<tag>_* files.
-tag=${1:-r4z}
+tag=${1:-r4y}
 python3 scripts/summarize_profile.py $tag > /dev/null
 python3 scripts/summarize_steady.py $tag > /dev/null
 python3 scripts/summarize_config3b_pmc.py $tag > /dev/null

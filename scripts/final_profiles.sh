@@ -4,7 +4,7 @@
 # (scripts/gpu_profile.sh), the HBM traffic of config 3B kernel by kernel (scripts/profile_config3b_pmc.sh), the instruction census of configs 4
 # and 5 (scripts/profile_config4_valu.sh, tools/census_config5.sh), the per-kernel statistics of the secondary configs and a plain bench line
 # (scripts/profile_secondary.sh, scripts/profile_config4.sh).  Afterwards, in the build container: bash scripts/collect_final_profiles.sh <tag>.
-tag=${1:-r4z}
+tag=${1:-r4y}
 bash scripts/gpu_profile.sh $tag
 bash scripts/profile_config3b_pmc.sh $tag > gpurun_out/${tag}_config3b_pmc.log 2>&1
 bash scripts/profile_config4_valu.sh $tag > gpurun_out/${tag}_config4_valu.log 2>&1
