@@ -110,6 +110,7 @@ SIGNATURES = {
                                       ctypes.c_void_p, ctypes.c_void_p]),
     'cp_splice_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_splice_plan_scheme': (ctypes.c_int, [ctypes.c_void_p]),
+    'cp_math_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
     'cp_splice_plan_set_scheme': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     'cp_spline_rows_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                                                  ctypes.c_int]),
@@ -175,6 +176,7 @@ DERIVED_VALUES = ('_h2', 'H0', 'Omega_g', 'T_ur', 'Omega_ur', 'Omega_r', 'Omega_
                   'omega_r', 'omega_k', 'omega_de')      # enum cp_derived_value
 VARIANTS_SCALARS = ('omega_b', 'omega_m', 'frac_b', 'frac_cdm', 'frac_cb', 'frac_ncdm', 'theta_cmb', 'z_eq', 'k_eq', 'z_drag', 'rs_drag', 'p_c', 'p_cb',
                     'gamma_ncdm', 'beta_c')      # enum cp_variants_scalar
+MATH_FUNCTIONS = {'exp_mid': 0, 'exp_tab': 1, 'log_pos': 2, 'log_tab': 3, 'exp10_mid': 4, 'exp10_tab': 5, 'sin_bounded': 6, 'recip': 7, 'rsqrt_pos': 8}      # enum cp_math_function
 EH_SCALARS = ('rs_drag', 'z_drag', 'z_eq', 'k_eq', 'r_drag', 'r_eq', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b', 'alpha_gamma',
               'gamma')
 BG_KINDS = {'comoving_radial_distance': 0, 'comoving_transverse_distance': 1, 'angular_diameter_distance': 2, 'luminosity_distance': 3,

@@ -127,7 +127,7 @@ __device__ __forceinline__ double exp10_mid(double x) {
 // ---- table-driven forms: 64 entries in LDS (a gather of 8- or 16-byte entries no two of which share a bank), short polynomials ----
 // 10^x where every lane of a tile takes sixteen of them (cp_tables_rows_direct): n = round(64 x log2 10), 10^x = 2^(n >> 6) 2^((n & 63) / 64) 10^r
 // with r = x - n log10(2) / 64 in two pieces (|r| <= 0.00236), 2^(j / 64) from a table of 64 correctly rounded doubles in LDS and 10^r - 1 by its
-// degree-5 series (remainder 4e-17): relative error 2.0e-16 over |x| < 300 (checked against 50-digit arithmetic), 10 double-precision
+// degree-5 series (remainder 4e-17): relative error 2.4e-16 over |x| < 300 (tests/test_math_gpu.py, against 80-bit arithmetic), 10 double-precision
 // instructions where exp10_mid takes 20 and six selects.  NO range handling: the caller sends tiles that hold |x| >= 300, Inf or NaN to exp10_mid.
 // 2^(j / 64), j < 64, correctly rounded (shared by exp10_tab and exp_tab)
 __device__ const double exp2_table[64] = {
@@ -193,7 +193,7 @@ __device__ __forceinline__ void fill_math_tables(MathTables* t) {
 }
 
 // e^x: n = round(64 x / ln 2), ln(2) / 64 in two pieces (|r| <= 0.0055), e^r - 1 by its degree-5 series (remainder 4e-17), 2^((n & 63) / 64)
-// from the table, ldexp -- relative error 2.0e-16 (checked against 50-digit arithmetic over |x| < 700), 11 double-precision instructions where
+// from the table, ldexp -- relative error 2.3e-16 (tests/test_math_gpu.py, against 80-bit arithmetic over |x| < 700), 11 double-precision instructions where
 // exp_mid takes 20.  Arguments below -800 give 0 (as beyond -745 anyway), NaN passes.
 __device__ __forceinline__ double exp_tab(double x, const MathTables* t) {
     x = x < -800. ? -800. : x;

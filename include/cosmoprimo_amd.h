@@ -375,6 +375,21 @@ int cp_wallish_box(const double* d_dd, long long ncol, int n, int margin_first, 
 int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int margin_first, int margin_second, int offset_first, int offset_second, int* d_box,
                       double* d_dd, double* d_gap, int device, void* stream);
 
+/* ---- the short forms of the transcendental functions the ALU-bound kernels use (csrc/cp_math.h), evaluated on an array ----
+ * A diagnostic: what the accuracies stated for them are tested on.  No counterpart in the reference (numpy's libm calls).  d_y[i] = f(d_x[i]). */
+enum cp_math_function {
+    CP_MATH_EXP_MID = 0,       /* e^x, degree-13 series */
+    CP_MATH_EXP_TAB = 1,       /* e^x, 64-entry table + degree-5 series */
+    CP_MATH_LOG_POS = 2,       /* log x, degree-14 odd series */
+    CP_MATH_LOG_TAB = 3,       /* log x, 64-entry table + degree-7 series (absolute error 2e-16 max(1, |log x|)) */
+    CP_MATH_EXP10_MID = 4,
+    CP_MATH_EXP10_TAB = 5,     /* |x| < 300 */
+    CP_MATH_SIN_BOUNDED = 6,
+    CP_MATH_RECIP = 7,         /* finite, normal x */
+    CP_MATH_RSQRT_POS = 8      /* positive, finite, normal x */
+};
+int cp_math_eval(int kind, const double* d_x, double* d_y, long long n, int device, void* stream);
+
 /* ---- clamped cubic spline through knots spliced from contiguous pieces of two row arrays (wallish2018, bao_filter.py:415-431) ----
  * The knots x (nknots, increasing) take their values from up to three pieces: piece p = columns [piece_start[p], piece_start[p] + piece_count[p])
  * of the rows of array piece_src[p] (0 or 1), in this order.  cp_splice_apply solves the tridiagonal system of
