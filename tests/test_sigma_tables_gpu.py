@@ -67,6 +67,37 @@ def test_batch_of_tables_matches_single_tables(cp, golden):
     assert many.pk.shape == (7, 500, 30)
 
 
+@pytest.mark.parametrize('nk,nzq', [(1024, 64), (300, 17), (1000, 64), (257, 1), (4100, 33)])
+def test_rows_of_tables_both_routes(cp, golden, nk, nzq):
+    """Interpolator2D.rows_y_major for a batch of tables (the rows of P(k, z) the sigma integrals transform): the kernel that evaluates the k splines from
+    the tables' second derivatives and contracts z on the matrix cores (cp_tables_rows_direct: whole tiles through its table-driven 10^x, partial
+    tiles, NaN tables and few redshifts through the general epilogue) against the two banded operators, for sizes that do and do not fill its tiles."""
+    import torch
+    from cosmoprimo_amd import interpolator as itp
+    g = golden('sigma')
+    k, z, batch = tables(g, 5, seed=nk)
+    batch[2, 40, 3] = -1.      # (the logarithm of this table is NaN: the whole surface)
+    many = cp.PowerSpectrumInterpolator2D(k, z, torch.as_tensor(batch, device='cuda'))
+    # (away from the two ends of the tables: _pad_log puts its extrapolation knots within 1e-9 of the end knots when the table reaches the extrapolation
+    # range, as this one does at k = 100 -- the last intervals of such a spline are conditioned like 1e9, and the two routes, like FITPACK, differ by 1e-7 there)
+    kq = np.geomspace(k[16], k[-17], nk)      # (the disturbance decays by 0.27 per knot)
+    zq = np.linspace(z[0], z[-1], nzq) if nzq > 1 else np.array([0.7])
+    saved = itp._DIRECT_K_SPLINE
+    try:
+        itp._DIRECT_K_SPLINE = True
+        direct = many._interp.rows_y_major(kq, zq, exp10=True).cpu().numpy()
+        itp._DIRECT_K_SPLINE = False
+        operators = many._interp.rows_y_major(kq, zq, exp10=True).cpu().numpy()
+    finally:
+        itp._DIRECT_K_SPLINE = saved
+    assert direct.shape == (5, nzq, nk)
+    assert np.isnan(direct[2]).all() and np.isnan(operators[2]).all()
+    keep = [0, 1, 3, 4]
+    np.testing.assert_allclose(direct[keep], operators[keep], rtol=1e-11)
+    one = cp.PowerSpectrumInterpolator2D(k, z, batch[4])
+    np.testing.assert_allclose(direct[4], one(kq, zq).T, rtol=1e-11)
+
+
 def test_config3_variant_b_full_size(cp, golden):
     """10 000 tables (500 k x 30 z) -> sigma_rz on 256 r x 64 z: finite, deterministic, falling with r and z, sampled entries against single tables."""
     import torch
