@@ -1,8 +1,7 @@
-"""Padded sizes beyond the fused kernel (Np > 8192): time per transform and algorithmic bandwidth of the large-size path.
-python tools/bench_fftlog_large.py"""
+"""FFTLog rows beyond the LDS-resident kernel (Np > 8192: cp_fftlog_large.hip): rows/s and algorithmic GB/s (16 N bytes per row).
+    python tools/bench_fftlog_large.py [N] [nrows]"""
 import os
 import sys
-import time
 
 import numpy as np
 
@@ -12,23 +11,26 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     import torch
     import cosmoprimo_amd as cp
-    dev = torch.device('cuda', 0)
-    for n in (4096, 8192, 32768, 262144, 2097152):
-        k = np.logspace(-4, 2, n)
-        f = cp.PowerToCorrelation(k, ell=0)
-        nrows = max((1 << 26) // n, 2)
-        fun = torch.rand((nrows, n), dtype=torch.float64, device=dev) + 0.5
-        for _ in range(3):
-            out = f(fun)[1]
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+    nrows = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+    k = np.geomspace(1e-5, 1e3, n)
+    fft = cp.PowerToCorrelation(k, ell=0, q=0)
+    rows = torch.rand((nrows, n), dtype=torch.float64, device='cuda') + 0.5
+    for _ in range(3):
+        s, out = fft(rows)
+    torch.cuda.synchronize()
+    ms = []
+    for rep in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            s, out = fft(rows)
+        e1.record()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        nrep = 10
-        for _ in range(nrep):
-            out = f(fun)[1]
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / nrep
-        print('n = %8d (Np = %8d) x %6d rows: %8.3f ms, %.3g transforms/s, %.0f GB/s algorithmic (16 n B per row)' % (
-            n, f.padded_size, nrows, dt * 1e3, nrows / dt, 16. * n * nrows / dt / 1e9))
+        ms.append(e0.elapsed_time(e1) / 5)
+    best = min(ms)
+    print('N %d (padded %d), %d rows: %s ms -> %.3e rows/s, %.0f GB/s algorithmic' % (n, fft.padded_size, nrows, ' '.join('%.3f' % v for v in ms), nrows / best * 1e3,
+                                                                                       16. * n * nrows / best / 1e6))
 
 
 if __name__ == '__main__':
