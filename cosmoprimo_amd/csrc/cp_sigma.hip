@@ -18,6 +18,8 @@
 // doubles for the roots of the splined variances and of the growth factors.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cmath>
 #include <new>
@@ -565,56 +567,64 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
             }
             const GeoConsts* C = R.consts;
             asm volatile("" : "+s"(C));      // (not hoisted out of the loop over pairs: the scalar registers are the FFT's there)
-            // the lane's knots and their two neighbours, one LDS round trip
-            double y[GEO_SMAX + 2];
-            const double* mine = Y + S * lane - 1;
+            // The solve, instantiated for the plan's knots per lane (4 ... 8: a switch on a wave-uniform value): loops of exactly S steps and
+            // ceil(33 / S) carries, where one body for 8 knots spent a third of its instructions on knots a plan of 5 does not have.
+            auto solve = [&](auto sc) {
+                constexpr int SS = decltype(sc)::value;
+                constexpr int REACH = (GEO_HALO + SS) / SS;      // REACH x SS >= GEO_HALO + 1
+                static_assert(REACH <= GEO_REACH, "the plan's carry weights");
+                // the lane's knots and their two neighbours, one LDS round trip
+                double y[SS + 2];
+                const double* mine = Y + SS * lane - 1;
 #pragma unroll
-            for (int i = 0; i < GEO_SMAX + 2; ++i) y[i] = i < S + 2 ? mine[i] : 0.;
-            const double inv_rho = C->inv_rho, pL = C->pL, pR = C->pR;
-            double f[GEO_SMAX], g[GEO_SMAX];
-            {      // F_k = d_k + pL F_{k-1} upwards and B_k = d_k + pR B_{k+1} downwards over the segment, both from zero
-                double d[GEO_SMAX];
+                for (int i = 0; i < SS + 2; ++i) y[i] = mine[i];
+                const double inv_rho = C->inv_rho, pL = C->pL, pR = C->pR;
+                double f[SS], g[SS];
+                {      // F_k = d_k + pL F_{k-1} upwards and B_k = d_k + pR B_{k+1} downwards over the segment, both from zero
+                    double d[SS];
 #pragma unroll
-                for (int k = 0; k < GEO_SMAX; ++k) d[k] = k < S ? (y[k + 2] - y[k + 1]) * inv_rho - (y[k + 1] - y[k]) : 0.;
-                double acc = 0.;
+                    for (int k = 0; k < SS; ++k) d[k] = (y[k + 2] - y[k + 1]) * inv_rho - (y[k + 1] - y[k]);
+                    double acc = 0.;
 #pragma unroll
-                for (int k = 0; k < GEO_SMAX; ++k) {
-                    acc = fma(pL, acc, d[k]);
-                    f[k] = acc;
+                    for (int k = 0; k < SS; ++k) {
+                        acc = fma(pL, acc, d[k]);
+                        f[k] = acc;
+                    }
+                    acc = 0.;
+#pragma unroll
+                    for (int k = SS - 1; k >= 0; --k) {
+                        acc = fma(pR, acc, d[k]);
+                        g[k] = acc;
+                    }
                 }
-                acc = 0.;
+                // what the knots left of the segment add to F at its first knot (x pL^(k + 1) further in), and the knots right of it to B
+                double fin = 0., gin = 0.;
+                if (!(CP_GEO_ABLATE & 1)) {
+                    double fl = f[SS - 1], gr = g[0];      // the segment's totals: F at its last knot, B at its first
 #pragma unroll
-                for (int k = GEO_SMAX - 1; k >= 0; --k) {      // (knots k >= S hold d = 0: the recursion starts at the segment's last knot)
-                    acc = fma(pR, acc, d[k]);
-                    g[k] = acc;
+                    for (int m = 0; m < REACH; ++m) {
+                        fl = wave_from_left(fl);
+                        gr = wave_from_right(gr);
+                        fin = fma(C->cL[m], fl, fin);
+                        gin = fma(C->cR[m], gr, gin);
+                    }
                 }
-            }
-            // what the knots left of the segment add to F at its first knot (x pL^(k + 1) further in), and the knots right of it to B
-            double fin = 0., gin = 0.;
-            if (!(CP_GEO_ABLATE & 1)) {
-                double fl = 0., gr = g[0];
-#pragma unroll
-                for (int k = 0; k < GEO_SMAX; ++k) fl = k == S - 1 ? f[k] : fl;      // the segment's total: F at its last knot
-#pragma unroll
-                for (int m = 0; m < GEO_REACH; ++m) {
-                    fl = wave_from_left(fl);
-                    gr = wave_from_right(gr);
-                    fin = fma(C->cL[m], fl, fin);
-                    gin = fma(C->cR[m], gr, gin);
-                }
-            }
-            // N_k = kappa (F_k + pR B_{k+1}), B beyond the segment's last knot being the carry itself
-            {
+                // N_k = kappa (F_k + pR B_{k+1}), B beyond the segment's last knot being the carry itself
                 const double kappa = C->kappa;
                 double bnext = gin;      // true B at the first knot of the next segment
 #pragma unroll
-                for (int k = GEO_SMAX - 1; k >= 0; --k) {
-                    if (k < S) {
-                        const double fk = fma(C->pLk[k], fin, f[k]);
-                        N[S * lane + k] = kappa * fma(pR, bnext, fk);
-                        bnext = fma(C->pRk[k], gin, g[k]);
-                    }
+                for (int k = SS - 1; k >= 0; --k) {
+                    const double fk = fma(C->pLk[k], fin, f[k]);
+                    N[SS * lane + k] = kappa * fma(pR, bnext, fk);
+                    bnext = fma(C->pRk[k], gin, g[k]);
                 }
+            };
+            switch (S) {
+                case 4: solve(std::integral_constant<int, 4>{}); break;
+                case 5: solve(std::integral_constant<int, 5>{}); break;
+                case 6: solve(std::integral_constant<int, 6>{}); break;
+                case 7: solve(std::integral_constant<int, 7>{}); break;
+                default: solve(std::integral_constant<int, 8>{}); break;
             }
             cp::wave_lds_phase();
             const double rho_sq = C->rho_sq;
