@@ -6,6 +6,7 @@
 //     array of exactly the size the launch requests, its rows are heap arrays of exactly n samples, so an index of the kernel that leaves
 //     its LDS allocation or its rows is an AddressSanitizer report here (GPU sanitizers are not available on the pool).
 // Exit status 0 and a last line "ok" mean no report; numerical checks are the business of tests/test_fftlog_host.py.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -116,10 +117,46 @@ static void kernel_phases() {
         }
 }
 
+extern "C" int emu_splice_build(int n, const double* x, int npieces, const int* piece_first, const int* piece_src, const int* piece_start, int nq, const double* xq,
+                                const int* qj, int u0, int u1, int generic_first, int generic_end, int* ints, double* doubles, double* win, int* qe, double* qw);
+
+// the plan builder of the uniform-stretch spliced spline (csrc/cp_splice_uniform_plan.h) on the knots of wallish2018 and on knots it must refuse,
+// every array of exactly the size the builder is told
+static void splice_plans() {
+    for (int variant = 0; variant < 3; ++variant) {
+        const int nk = 1024, nlin = variant == 2 ? 8192 : 4096;
+        std::vector<double> k(nk), klin(nlin), knots;
+        for (int i = 0; i < nk; ++i) k[i] = std::pow(10., -7. + 9. * i / (nk - 1));
+        for (int i = 0; i < nlin; ++i) klin[i] = 1e-7 + (2. - 1e-7) * i / (nlin - 1);
+        std::vector<int> first(3, 0), src = {0, 1, 0}, start(3, 0);
+        int nleft = 0, nmid = 0, nright = 0;
+        for (int i = 0; i < nk; ++i) if (k[i] < 5e-4) { knots.push_back(k[i]); ++nleft; }
+        for (int i = 0; i < nlin; ++i) if (klin[i] > 1e-2 && klin[i] < 1.5) { if (!nmid) start[1] = i; knots.push_back(klin[i]); ++nmid; }
+        for (int i = 0; i < nk; ++i) if (k[i] > 2.) { if (!nright) start[2] = i; knots.push_back(k[i]); ++nright; }
+        first[1] = nleft; first[2] = nleft + nmid;
+        const int n = (int)knots.size();
+        std::vector<int> qj(nk);
+        int gf = nk, ge = 0;
+        for (int q = 0; q < nk; ++q) {
+            int j = (int)(std::upper_bound(knots.begin(), knots.end(), k[q]) - knots.begin()) - 1;
+            j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);
+            qj[q] = j;
+            if ((k[q] >= 5e-4 && k[q] <= 2.) || (variant == 1 && q >= 100)) { gf = q < gf ? q : gf; ge = q + 1; }      // (1: spline queries inside the left piece)
+        }
+        std::vector<int> ints(15), qe(512);
+        std::vector<double> doubles(2), win(512), qw(2048);
+        const int ok = emu_splice_build(n, knots.data(), 3, first.data(), src.data(), start.data(), nk, k.data(), qj.data(), nleft, nleft + nmid - 1, gf, ge, ints.data(),
+                                        doubles.data(), win.data(), qe.data(), qw.data());
+        EXPECT(ok == (variant == 0 ? 1 : 0));      // 1: spline queries far from the stretch; 2: more knots on it than 64 x 57
+        if (ok) EXPECT(ints[1] == nmid && ints[0] * 64 >= nmid);
+    }
+}
+
 int main() {
     special_functions();
     table_setup_errors();
     kernel_phases();
+    splice_plans();
     if (failures) { std::fprintf(stderr, "%d expectation(s) failed\n", failures); return 1; }
     std::puts("ok");
     return 0;
