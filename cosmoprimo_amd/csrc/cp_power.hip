@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
     __shared__ double sh_g2[256];
     __shared__ MathTables mt;
     fill_math_tables(&mt);      // (the barrier in front of the loop over wavenumbers covers it)
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, bs = blockDim.x;      // 256 threads, or ONE wave per cosmology for large batches (cp_power_eval: the per-cosmology part of a thread -- parameters, constants of the fit, ~150 instructions -- is then paid by 64 lanes instead of 256)
     const long long ic = blockIdx.x / A.kchunks;
     const long long k0 = (long long)(blockIdx.x % A.kchunks) * A.kspan;
     const long long k1 = k0 + A.kspan < A.nk ? k0 + A.kspan : A.nk;
@@ -73,15 +73,15 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
     const double kfac = A.kscale ? A.kscale[ic] : 1.;
     const PkPerCosmology pc = pk_per_cosmology(c, pw);
     const double ln_pk_unit = A.what == CP_PK_LOG_K_MATTER ? log(pc.pk_unit) : 0.;
-    for (long long z0 = 0; z0 < nzs; z0 += 256) {
+    for (long long z0 = 0; z0 < nzs; z0 += bs) {
         if (z0) __syncthreads();  // the previous block of redshifts has been written
         if (with_z && z0 + tid < A.nz) {
             const double g = growth_cpt(c, A.z[z0 + tid]);  // growth_factor(z, znorm=0), eisenstein_hu.py:317
             sh_g2[tid] = g * g;
         }
         __syncthreads();
-        const int nzi = with_z ? (int)(A.nz - z0 < 256 ? A.nz - z0 : 256) : 1;
-        for (long long ik = k0 + tid; ik < k1; ik += 256) {
+        const int nzi = with_z ? (int)(A.nz - z0 < bs ? A.nz - z0 : bs) : 1;
+        for (long long ik = k0 + tid; ik < k1; ik += bs) {
             const double kh = A.kscale ? A.k[ik] * kfac : A.k[ik];
             double* out = A.out + (ic * nzs + z0) * A.nk + ik;
             const double ln_kh = CP_MATH_TABLES_OFF ? log_pos(kh) : log_tab_any(kh, &mt);      // (2e-16 max(1, |log kh|): the tilt and the powers of k take it times O(1) factors)
@@ -375,8 +375,10 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     A.z = d_z;
     A.out = d_out;
     A.scal = nullptr;
-    // wavenumbers per workgroup: all of a cosmology's when the batch alone fills the chip (>= 8 workgroups per CU), fewer for small batches
-    const long long block = 256;
+    // wavenumbers per workgroup: all of a cosmology's when the batch alone fills the chip (>= 8 workgroups per CU), fewer for small batches.  A batch
+    // that fills the chip with one WAVE per cosmology (12 waves per CU) takes that shape: a thread's per-cosmology part is amortised over nk / 64
+    // wavenumbers instead of nk / 256 (brieden2022 evaluates 341 per cosmology: 2 282 -> ~900 instructions per spectrum for the no-wiggle form)
+    const long long block = ncosmo >= 256 * 12 ? 64 : 256;
     long long kiter = (nk + block - 1) / block;
     while (kiter > 1 && ncosmo * ((nk + block * kiter - 1) / (block * kiter)) < 2048) kiter = (kiter + 1) / 2;
     A.kspan = block * kiter;
