@@ -47,7 +47,9 @@ __global__ __launch_bounds__(64) void coefficients_kernel(const Args A, EhScalar
     const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= A.ncosmo) return;
     const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
-    out[ic] = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
+    EhScalars s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
+    s.growth0 = growth_cpt(c, 0.);
+    out[ic] = s;
 }
 
 // One workgroup = one cosmology x kspan wavenumbers: growth(z)^2 of every output redshift is evaluated once per workgroup (one lane per

@@ -21,11 +21,13 @@ struct EhScalars {
         alpha_gamma;
     double ln_q_over_kh, ln_ksilk_over_kh;  // log(q / kh) = log(h / (13.41 k_eq)) and log((k / k_silk) / kh) = log(h / k_silk): see transfer_eh
     double q108_per_kh, ksilk14_per_kh;     // (q / kh)^1.08 and ((k / k_silk) / kh)^1.4: with tabulated kh^1.08, kh^1.4 the two powers of a sample are products (transfer_eh_powers)
+    double growth0;                         // CPT92 growth factor at z = 0 (Background.growth_factor(0, znorm=0)): the pre-kernel's lane evaluates it once per cosmology (coefficients_kernel), the sigma8 normalisation reads it
 };
 
 // eisenstein_hu.py:34-92 (+ eisenstein_hu_nowiggle.py:21), operation for operation
 __device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, double Omega_b, double T_cmb, bool full) {
     EhScalars s;
+    s.growth0 = 0.;      // (set by the caller that has the whole cosmology)
     s.omega_b = Omega_b * (h * h);
     s.omega_m = Omega_cdm * (h * h) + Omega_b * (h * h);
     s.frac_b = s.omega_b / s.omega_m;

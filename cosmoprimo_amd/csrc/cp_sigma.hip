@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    const double g0 = growth_cpt(c, 0.);
+    const double g0 = ENGINE != CP_ENGINE_BBKS ? s.growth0 : growth_cpt(c, 0.);      // (the lane of the coefficient pre-kernel has evaluated it: ~350 instructions per wave here)
     const double sigma8_fid = sqrt(acc) * sqrt(g0 * g0);      // (the product of roots of the fused kernels: sqrt(sigma^2) sqrt(growth^2))
     const double target = S.target.ptr ? S.target.ptr[ic] : S.target.value;
     const double rs = target / sigma8_fid, rs2 = rs * rs;
