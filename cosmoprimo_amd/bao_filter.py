@@ -454,6 +454,9 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         self._pknow_rows = out
 
 
+_RESAMPLE_IN_ONE_KERNEL = True      # brieden2022 over a batch: knots, per-cosmology spline and the final pass as cp_brieden_resample (False: the three kernels)
+
+
 def _brieden_compute_batched(self, rescale):
     """
     One rs_drag ratio per cosmology (``cosmo`` is a batch): same steps as :meth:`Brieden2022PowerSpectrumBAOFilter._compute`, with the
@@ -484,6 +487,17 @@ def _brieden_compute_batched(self, rescale):
     _lib.check(lib.cp_brieden_ratio(rows.data_ptr(), raw.data_ptr(), g0.data_ptr(), const['correction'].data_ptr(), const['ratio_fid'].data_ptr(),
                                     pknow.data_ptr(), ratio.data_ptr(), nb, n, self.device.index, stream))
     envelope = self._envelope(ratio)                                                                  # (B, 341)
+    pk = self._pk_rows.contiguous()
+    if _RESAMPLE_IN_ONE_KERNEL and 129 <= n <= 512:
+        # log10 of envelope x pknow x ratio_now_fid on the per-cosmology knots k_fid / rescale with the two extrapolated knots of _pad_log on either side,
+        # its natural spline at k_fid, 10^x written over the k_fid range of P (bao_filter.py:500-509): one kernel, a wave per cosmology (k_fid is a
+        # range of the filter's geometric grid: the spline's system has constant coefficients)
+        res = torch.empty_like(pk)
+        _lib.check(lib.cp_brieden_resample(envelope.data_ptr(), pknow.data_ptr(), const['ratio_now_fid'].data_ptr(), const['k_fid'].data_ptr(), const['log_k_fid'].data_ptr(),
+                                           rescale.data_ptr(), float(interp.extrap_kmin), float(interp.extrap_kmax), pk.data_ptr(), res.data_ptr(), nb, n, pk.shape[1],
+                                           const['first'], self.device.index, stream))
+        self._pknow_rows = res
+        return
     # log10 of envelope x pknow x ratio_now_fid on the per-cosmology knots k_fid / rescale, knot-major (345, B), with the two extrapolated knots of
     # _pad_log (interpolator.py:42-87) on either side: one pass
     xk, yk = torch.empty((n + 4, nb), dtype=torch.float64, device=self.device), torch.empty((n + 4, nb), dtype=torch.float64, device=self.device)
@@ -494,7 +508,6 @@ def _brieden_compute_batched(self, rescale):
     _lib.check(lib.cp_spline_columns(xk.data_ptr(), yk.data_ptr(), nb, n + 4, const['log_k_fid'].data_ptr(), n, out.data_ptr(), scratch.data_ptr(),
                                      self.device.index, stream))
     # the input spectra with 10^(re-sampled) written over the k_fid range (bao_filter.py:509): one pass
-    pk = self._pk_rows.contiguous()
     res = torch.empty_like(pk)
     _lib.check(lib.cp_brieden_finish(pk.data_ptr(), out.data_ptr(), res.data_ptr(), nb, pk.shape[1], const['first'], n, self.device.index, stream))
     self._pknow_rows = res

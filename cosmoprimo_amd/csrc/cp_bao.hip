@@ -12,11 +12,13 @@
 #include <algorithm>
 #include <cmath>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
 #include "cp_internal.h"
+#include "cp_math.h"
 #include "cp_splice_uniform.h"
 #include "cp_wallish_dd.h"
 
@@ -310,6 +312,279 @@ extern "C" int cp_brieden_knots(const double* d_envelope, const double* d_pknow,
     hipLaunchKernelGGL(brieden_knots_kernel, dim3(grid_tiles(nb, n)), dim3(256), 0, static_cast<hipStream_t>(stream), d_envelope, d_pknow,
                        d_ratio_now_fid, d_k_fid, d_rescale, extrap_kmin, extrap_kmax, d_xk, d_yk, nb, n);
     return finish("cp_brieden_knots", 0);
+}
+
+// ---- brieden2022: the re-sampling of the smooth spectrum (bao_filter.py:500-509) as ONE kernel, a wave per cosmology --------------------------
+// cp_brieden_knots (cosmology-major -> knot-major, the two extrapolated knots of _pad_log on either side), cp_spline_columns (a natural cubic spline per
+// column through its own knots log10(k_fid / rescale), elimination factors through a global scratch) and cp_brieden_finish (10^x, knot-major ->
+// cosmology-major into the k_fid range of P) move every value through memory three times and turn the layout twice: 0.52 ms per 32 768 cosmologies.
+// The knots of a cosmology are a GEOMETRIC grid (k_fid is a range of the filter's geomspace) shifted by log10(rescale): uniform in log10 k, so the
+// system for the second derivatives has constant coefficients and is solved by the two first-order recursions of cp_splice_uniform.h (p = sqrt 3 - 2),
+// a lane per S knots in registers, the neighbours' totals by DPP shifts.  What the two extrapolated knots on either side change is A p^i + B p^(n-1-i);
+// they lie ON the lines through the first / last two samples, so the right-hand sides of the two rows at each junction vanish and A (B) follows in
+// closed form from the first (last) two second derivatives of the recursion and the three spacings there; the queries log10(k_fid) all sit at the same
+// fraction of their interval, log10(rescale) / h intervals away from their own knot.  (The same steps with the general elimination in LDS, a lane
+// per run of intervals, were measured SLOWER than the three kernels: profiles/r4_kernel_experiments.txt.)
+namespace {
+
+#ifndef CP_RS_WAVES
+#define CP_RS_WAVES 3      // waves per SIMD the kernel is compiled for
+#endif
+#ifndef CP_RS_EVAL_UNROLL
+#define CP_RS_EVAL_UNROLL 8
+#endif
+constexpr int RS_SMIN = 3, RS_SMAX = 8;      // knots per lane: 129 <= n <= 512
+constexpr double RS_P = -0.26794919243112270647, RS_KAPPA = 0.28867513459481288225;      // sqrt 3 - 2, 1 / (2 sqrt 3)
+
+struct ResampleArgs {
+    const double* envelope;       // (nb, n)
+    const double* pknow;          // (nb, n)
+    const double* ratio_now_fid;  // (n)
+    const double* k_fid;          // (n)
+    const double* log_k_fid;      // (n) log10 of it: the queries
+    const double* rescale;        // (nb)
+    double kmin, kmax;
+    const double* pk;             // (nb, nk)
+    double* out;                  // (nb, nk)
+    long long nb;
+    int n, nk, first, S;
+};
+
+constexpr double rs_ipow(double x, int k) {
+    double v = 1.;
+    for (int i = 0; i < k; ++i) v *= x;
+    return v;
+}
+
+// LDS per wave: Y[n + 4] (log10 of the samples, the extrapolated values at 0, 1, n + 2, n + 3), M[n + 4] (second derivatives in units of 6 kappa / h^2).
+// S = knots (= samples = queries) per lane.  What does not depend on the cosmology is set up once: the queries and ratio_now_fid (in LDS, shared by
+// the four waves), p^(distance of the lane's knots from either end); the next cosmology's samples are requested before this one's are worked on.
+template <int S>
+__global__ __launch_bounds__(256, CP_RS_WAVES) void brieden_resample_kernel(const ResampleArgs A) {
+    extern __shared__ double rs_lds[];
+    __shared__ cpmath::MathTables mt;
+    cpmath::fill_math_tables(&mt);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = A.n, N = n + 4;
+    const int stride = N + 4;
+    double* Y = rs_lds + (size_t)wave * 2 * stride;
+    double* M = Y + stride;
+    double* XQ = rs_lds + (size_t)8 * stride;      // the queries and ratio_now_fid: the same for every cosmology, shared by the four waves
+    double* RNF = XQ + n;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        XQ[j] = A.log_k_fid[j];
+        RNF[j] = A.ratio_now_fid[j];
+    }
+    __syncthreads();
+    constexpr double LOG10E = 0.43429448190325182765;
+    constexpr int REACH = (32 + S) / S;      // REACH x S >= 33 knots: p^33 = 1e-19
+    constexpr double PS = rs_ipow(RS_P, S);
+    auto lg10 = [&](double x) { return cpmath::log_tab_any(x, &mt) * LOG10E; };
+    const int own = S * lane;
+    // p^i for the lane's first knot, p^(n-1-i) for its last one: beyond 40 knots from an end nothing is left (and the powers would underflow);
+    // a lane that straddles the last knot: its knots beyond n - 1 do not exist, the power then belongs to knot n - 1 (its knot tlast)
+    const int dr = n - 1 - (own + S - 1);
+    const int tlast = dr < 0 ? S - 1 + dr : S - 1;
+    const double pa = own <= 40 ? pow(RS_P, (double)own) : 0.;
+    const double pb = dr <= 40 && dr > -S ? pow(RS_P, (double)(dr < 0 ? 0 : dr)) : 0.;
+    const double kf0 = A.k_fid[0], kf1 = A.k_fid[n - 1], lkf0 = A.log_k_fid[0], lkf1 = A.log_k_fid[n - 1];
+    const long long step = (long long)gridDim.x * 4;
+    long long c = (long long)blockIdx.x * 4 + wave;
+    double e[S], pn[S], r = 1.;
+    auto request = [&](long long cc) {
+        if (cc >= A.nb) return;
+        r = A.rescale[cc];
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const int j = lane + 64 * t;
+            e[t] = j < n ? A.envelope[cc * n + j] : 1.;
+            pn[t] = j < n ? A.pknow[cc * n + j] : 1.;
+        }
+    };
+    request(c);
+    for (; c < A.nb; c += step) {
+        // the geometry of this cosmology's knots (wave-uniform): the uniform stretch x_first + i h, the two knots of _pad_log on either side (interpolator.py:42-87)
+        // (kept in scalar registers: some twenty values that live through the whole iteration)
+        const double lr = lg10(r);
+        const double x_first = cp::wave_uniform(lkf0 - lr), x_last = cp::wave_uniform(lkf1 - lr);
+        const double h = cp::wave_uniform((x_last - x_first) / (n - 1)), inv_h = cp::wave_uniform(1. / h);
+        const double lmin = lg10(fmin(A.kmin, kf0 / r * (1 - 1e-9))), lmax = lg10(fmax(A.kmax, kf1 / r * (1 + 1e-9)));
+        const double xa = cp::wave_uniform(lmin), xb = cp::wave_uniform(x_first * 0.1 + lmin * 0.9), xc = cp::wave_uniform(x_last * 0.1 + lmax * 0.9), xd = cp::wave_uniform(lmax);
+        // ---- the samples, read where they are; the next cosmology's requested ----
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const int j = lane + 64 * t;
+            if (j < n) Y[2 + j] = lg10(e[t] * pn[t] * RNF[j]);
+        }
+        request(c + step);
+        cp::wave_lds_phase();
+        const double y0 = Y[2], y1 = Y[3], yn1 = Y[n + 1], yn2 = Y[n];
+        const double slope_l = (y1 - y0) * inv_h, slope_r = (yn1 - yn2) * inv_h;
+        if (lane == 0) {
+            Y[0] = y0 + slope_l * (xa - x_first);
+            Y[1] = y0 + slope_l * (xb - x_first);
+            Y[n + 2] = yn1 + slope_r * (xc - x_last);
+            Y[n + 3] = yn1 + slope_r * (xd - x_last);
+            M[0] = 0.;
+            M[n + 3] = 0.;
+        }
+        // ---- second derivatives on the uniform stretch: the two recursions over the lane's knots, the neighbours' totals ----
+        double g[S];
+        {
+            const int lo = own - 1 < 0 ? 0 : own - 1;
+            double ym = Y[2 + lo], yc = Y[2 + (own < n ? own : n - 1)];
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                const int i = own + t;
+                const double yp = Y[2 + (i + 1 < n ? i + 1 : n - 1)];
+                g[t] = (i >= 1 && i <= n - 2) ? (yp - yc) - (yc - ym) : 0.;      // (the rows of the two end knots: their right-hand sides vanish)
+                ym = yc;
+                yc = yp;
+            }
+        }
+#pragma unroll
+        for (int t = S - 2; t >= 0; --t) g[t] = fma(RS_P, g[t + 1], g[t]);
+        double gr = g[0];
+        double f = 0.;
+#pragma unroll
+        for (int t = 0; t < S; ++t) {
+            const double ee = fma(RS_P, f, g[t]);
+            f = t + 1 < S ? fma(-RS_P, g[t + 1], ee) : ee;
+            g[t] = ee;
+        }
+        double fl = f, fin = 0., gin = 0., wgt = 1.;
+#pragma unroll
+        for (int m = 0; m < REACH; ++m) {
+            fl = cpsu::from_left(fl);
+            gr = cpsu::from_right(gr);
+            fin = fma(wgt, fl, fin);
+            gin = fma(wgt, gr, gin);
+            wgt *= PS;
+        }
+        {
+            double cg = gin, cf = fin;
+#pragma unroll
+            for (int t = S - 1; t >= 0; --t) {
+                cg *= RS_P;
+                g[t] += cg;
+            }
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                cf *= RS_P;
+                g[t] += cf;
+            }
+        }
+        // ---- what the extrapolated knots change: A p^i + B p^(n-1-i), from the rows of the junctions (right-hand sides zero): the first and last two
+        // second derivatives of the recursion, by shuffles from the lanes that hold them ----
+        const int l_last = (n - 1) / S, t_last = (n - 1) - l_last * S, l_prev = (n - 2) / S, t_prev = (n - 2) - l_prev * S;
+        double g_last = g[0], g_prev = g[0];
+#pragma unroll
+        for (int t = 1; t < S; ++t) {
+            g_last = t == t_last ? g[t] : g_last;
+            g_prev = t == t_prev ? g[t] : g_prev;
+        }
+        const double m0 = cp::lane_value(g[0], 0), m1 = cp::lane_value(g[1], 0), mn1 = cp::lane_value(g_last, l_last), mn2 = cp::lane_value(g_prev, l_prev);
+        auto amplitude = [&](double ha, double H, double ma, double mb) {
+            const double alpha = 2. * (H + h) - H * H / (2. * (ha + H));
+            return -(alpha * ma + h * mb) / (alpha + h * RS_P);
+        };
+        const double Hl = x_first - xb, Hr = xc - x_last;
+        const double Aamp = amplitude(xb - xa, Hl, m0, m1), Bamp = amplitude(xd - xc, Hr, mn1, mn2);
+        {
+            double ca = Aamp * pa, cb = Bamp * pb;
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                g[t] += ca;
+                ca *= RS_P;
+            }
+#pragma unroll
+            for (int t = S - 1; t >= 0; --t) {
+                if (t <= tlast) {
+                    g[t] += cb;
+                    cb *= RS_P;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < S; ++t)
+                if (own + t < n) M[2 + own + t] = g[t];
+        }
+        if (lane == 0) {      // (M[2] is this lane's; M[n + 1] = the last knot's: recursion + the two corrections there)
+            M[1] = -Hl * g[0] / (2. * ((xb - xa) + Hl));
+            M[n + 2] = -Hr * (mn1 + Bamp) / (2. * ((xd - xc) + Hr));
+        }
+        cp::wave_lds_phase();
+        // ---- evaluation at log10(k_fid), 10^x into the k_fid range of the row; the rest of the row as it is ----
+        double* orow = A.out + c * A.nk;
+        const double* prow = A.pk + c * A.nk;
+#pragma unroll CP_RS_EVAL_UNROLL
+        for (int t = 0; t < S; ++t) {
+            const int q = lane + 64 * t;
+            if (q >= n) continue;
+            const double x = XQ[q];
+            double v = __builtin_nan("");
+            if (x >= xa && x <= xd) {
+                const double u = (x - x_first) * inv_h;
+                const double fi = floor(u);
+                if (x >= x_first && fi < (double)(n - 1)) {      // an interval of the uniform stretch: this is where the queries are, but for a few at either end
+                    const int j = 2 + (int)fi;
+                    const double b = u - fi, a = 1. - b;
+                    v = fma(a, Y[j], b * Y[j + 1]) + RS_KAPPA * (fma(a * a, a, -a) * M[j] + fma(b * b, b, -b) * M[j + 1]);
+                } else {
+                    int j;
+                    double xl, hh;
+                    if (x < x_first) {
+                        j = x >= xb ? 1 : 0;
+                        xl = j ? xb : xa;
+                        hh = j ? x_first - xb : xb - xa;
+                    } else {
+                        j = x < xc ? n + 1 : n + 2;
+                        xl = j == n + 1 ? x_last : xc;
+                        hh = j == n + 1 ? xc - x_last : xd - xc;
+                    }
+                    const double b = (x - xl) / hh, a = 1. - b;
+                    const double ratio = hh * inv_h;
+                    v = fma(a, Y[j], b * Y[j + 1]) + RS_KAPPA * (ratio * ratio) * (fma(a * a, a, -a) * M[j] + fma(b * b, b, -b) * M[j + 1]);
+                }
+            }
+            orow[A.first + q] = fabs(v) < 300. ? cpmath::exp10_tab(v, mt.exp2) : cpmath::exp10_mid(v);      // (NaN and what leaves the doubles: the branch-free general form)
+        }
+        for (int k = lane; k < A.first; k += 64) orow[k] = prow[k];
+        for (int k = A.first + n + lane; k < A.nk; k += 64) orow[k] = prow[k];
+        cp::wave_lds_phase();      // last reads before the next cosmology's samples are staged
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_brieden_resample(const double* d_envelope, const double* d_pknow, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_log_k_fid,
+                                   const double* d_rescale, double extrap_kmin, double extrap_kmax, const double* d_pk, double* d_out, long long nb, int n,
+                                   int nk, int first, int device, void* stream) {
+    if (nb < 0 || n < 4 || nk < 1 || first < 0 || first + n > nk) return cp::fail(CP_EINVAL, "cp_brieden_resample: bad sizes");
+    const int S = (n + 63) / 64;
+    if (S < RS_SMIN || S > RS_SMAX)
+        return cp::fail(CP_EUNSUPPORTED, "cp_brieden_resample: %d samples per cosmology (129 ... 512): cp_brieden_knots, cp_spline_columns, cp_brieden_finish", n);
+    if (nb == 0) return CP_OK;
+    if (!d_envelope || !d_pknow || !d_ratio_now_fid || !d_k_fid || !d_log_k_fid || !d_rescale || !d_pk || !d_out) return cp::fail(CP_EINVAL, "cp_brieden_resample: null pointer");
+    DeviceScope scope(device);
+    if (!scope.ok) return cp::fail(CP_EDEVICE, "cp_brieden_resample: cannot select device %d", device);
+    ResampleArgs A;
+    A.envelope = d_envelope; A.pknow = d_pknow; A.ratio_now_fid = d_ratio_now_fid; A.k_fid = d_k_fid; A.log_k_fid = d_log_k_fid; A.rescale = d_rescale;
+    A.kmin = extrap_kmin; A.kmax = extrap_kmax; A.pk = d_pk; A.out = d_out; A.nb = nb; A.n = n; A.nk = nk; A.first = first; A.S = S;
+    const size_t lds = ((size_t)4 * 2 * (n + 8) + 2 * (size_t)n) * sizeof(double);
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+    const long long blocks = (nb + 3) / 4, resident = (long long)ncu * CP_RS_WAVES;
+    const dim3 grid((unsigned)(blocks < resident ? blocks : resident)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (S) {
+        case 3: hipLaunchKernelGGL(brieden_resample_kernel<3>, grid, block, lds, st, A); break;
+        case 4: hipLaunchKernelGGL(brieden_resample_kernel<4>, grid, block, lds, st, A); break;
+        case 5: hipLaunchKernelGGL(brieden_resample_kernel<5>, grid, block, lds, st, A); break;
+        case 6: hipLaunchKernelGGL(brieden_resample_kernel<6>, grid, block, lds, st, A); break;
+        case 7: hipLaunchKernelGGL(brieden_resample_kernel<7>, grid, block, lds, st, A); break;
+        default: hipLaunchKernelGGL(brieden_resample_kernel<8>, grid, block, lds, st, A); break;
+    }
+    return finish("cp_brieden_resample", 0);
 }
 
 extern "C" int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_out, long long nb, int nk, int first, int n, int device,

@@ -64,6 +64,20 @@ inline hipError_t allow_full_lds() {
 // cp_spline_rows.hip): the hardware executes a wave's LDS instructions in order; this pins the compiler to the same order between the phases
 // (staging, forward sweep, backward sweep, evaluation): no LDS access moves across it.  At wavefront scope neither the fences nor the barrier
 // emit an instruction.
+// the value lane `src` (the same for the whole wave) holds, in every lane
+__device__ __forceinline__ double lane_value(double v, int src) {
+    const long long bits = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// a value every lane holds alike, moved to scalar registers (first active lane's)
+__device__ __forceinline__ double wave_uniform(double v) {
+    const long long bits = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bits), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bits >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 __device__ __forceinline__ void wave_lds_phase() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

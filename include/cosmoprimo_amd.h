@@ -448,6 +448,13 @@ int cp_brieden_ratio(const double* d_rows, const double* d_now, const double* d_
 int cp_brieden_knots(const double* d_envelope, const double* d_pknow, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_rescale,
                      double extrap_kmin, double extrap_kmax, double* d_xk, double* d_yk, long long nb, int n, int device, void* stream);
 int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_out, long long nb, int nk, int first, int n, int device, void* stream);
+/* The three steps above as one kernel, a wave per cosmology (no knot-major arrays, no scratch): d_out (nb, nk) = d_pk with the columns [first, first + n)
+ * replaced by 10^(natural cubic spline through (log10(k_fid / rescale[c]), log10(envelope pknow ratio_now_fid)) and the two extrapolated knots of _pad_log on
+ * either side, evaluated at d_log_k_fid = log10(k_fid)) (bao_filter.py:500-509).  k_fid must be a geometric grid (it is a range of the filter's geomspace):
+ * the spline's system then has constant coefficients.  129 <= n <= 512; CP_EUNSUPPORTED otherwise (the three calls then). */
+int cp_brieden_resample(const double* d_envelope, const double* d_pknow, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_log_k_fid,
+                        const double* d_rescale, double extrap_kmin, double extrap_kmax, const double* d_pk, double* d_out, long long nb, int n, int nk,
+                        int first, int device, void* stream);
 
 /* natural cubic spline per column with per-column knots (brieden2022 re-sampling with one rs_drag ratio per column, bao_filter.py:503-509):
  * d_xk, d_yk : (n, ncol) knot-major; d_xq : (nq) ascending queries shared by all columns; d_out : (nq, ncol);
