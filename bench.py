@@ -35,7 +35,7 @@ N_K = 2048
 ROWS_PER_GPU = 100000
 HBM_PEAK_GBS = 8000.          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6       # MI355X_MICROARCH.md: dense fp64, vector = matrix
-CONFIG4_CHUNK = 32768         # vectors per pass of config 4; tests/test_full_size_gpu.py runs the one-GPU share at this size (imported from here)
+CONFIG4_CHUNK = 65536         # vectors per pass of config 4; tests/test_full_size_gpu.py runs the one-GPU share at this size (imported from here)
 BYTES_PER_ROW = 2 * 8 * N_K   # read N f64 + write N f64 (tables are batch-shared, excluded)
 
 
@@ -228,8 +228,9 @@ def _config4_valu_roofline(engine, vectors_per_s, chunk):
 def config4(cp, torch, dev, par, chunk=CONFIG4_CHUNK, engines=('wallish2018', 'brieden2022'), spot_check=True):
     """wallish2018 and brieden2022 on EH98 P(k) vectors (nk = 1024) of the cosmologies ``par``, chunk by chunk (P(k) generation and sigma8
     normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time.
-    chunk : vectors per pass (1 GB per 4096-sample intermediate at 32 768; rounds 2 and 3 up to their last hours: 16 384, where the ~40 launches
-    of brieden2022 per chunk take the host about as long as they take the device -- 9 to 10.9e6 vectors/s from run to run against 12e6)."""
+    chunk : vectors per pass (2 GB per 4096-sample intermediate at 65 536).  The host needs ~1 ms to queue a chunk of brieden2022 whatever its size; the
+    device took that long for 16 384 vectors in round 3 and takes it for 32 768 now (tools/chunk_config4.py: 1.6e7 vectors/s in chunks of 16 384,
+    2.4-3.0e7 at 32 768, 3.5e7 at 65 536 and for the whole share at once; wallish2018 9.2e6 at any of them)."""
     import warnings
     from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
     n = int(par['Omega_m'].numel())

@@ -420,6 +420,9 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             ix = np.asarray(ix) % n
             M[:, ix] += 0.5 * _quadratic_interp_operator(self.k_fid[ix], self.k_fid)
         self._envelope = LinearOperator.dense(M, device=self.device)
+        # the columns that are not zero -- the extrema -- and the operator restricted to them, (np, n): what a batch is run with (cp_brieden_smooth)
+        columns = np.flatnonzero(np.any(M != 0., axis=0))
+        self._envelope_columns = (columns, np.ascontiguousarray(M[:, columns].T))
         self.ratio_now_fid = M.dot(self.ratio_fid)
 
     def _compute(self):
@@ -454,7 +457,9 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         self._pknow_rows = out
 
 
-_RESAMPLE_IN_ONE_KERNEL = True      # brieden2022 over a batch: knots, per-cosmology spline and the final pass as cp_brieden_resample (False: the three kernels)
+# brieden2022 over a batch, what follows the two P(k) evaluations: 2 = one kernel (cp_brieden_smooth: P taken at the extrema of the fiducial wiggles only),
+# 1 = ratio kernel, dense envelope operator, cp_brieden_resample, 0 = ratio kernel, operator, knots / per-column spline / final pass
+_RESAMPLE_IN_ONE_KERNEL = 2
 
 
 def _brieden_compute_batched(self, rescale):
@@ -471,7 +476,9 @@ def _brieden_compute_batched(self, rescale):
     nb, n = rescale.numel(), self.k_fid.size
     lib, stream = _lib.load(), dv.stream_of(self.device)
     rescale = rescale.contiguous()
-    rows = interp._pk_scaled(self.k_fid, 1. / rescale).contiguous()                              # P_c(k_fid / r_c), (B, 341)
+    fused = _RESAMPLE_IN_ONE_KERNEL == 2 and 129 <= n <= 512 and self._envelope_columns[0].size <= 64
+    # P_c(k_fid / r_c), (B, 341) -- or at the extrema only, (B, 23): all the envelope depends on
+    rows = interp._pk_scaled(self.k_fid[self._envelope_columns[0]] if fused else self.k_fid, 1. / rescale).contiguous()
     now = Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator(z=np.array([0.]))
     g0 = dv.to_device(now.growth_factor_sq(np.array([0.])), self.device).reshape(nb).contiguous()
     raw = now._pk_scaled(self.k_fid, rescale).contiguous()
@@ -482,12 +489,26 @@ def _brieden_compute_batched(self, rescale):
         const = self._device_constants = dict(correction=dv.to_device(self.pknow_correction[:, 0], self.device), ratio_fid=dv.to_device(self.ratio_fid[:, 0], self.device),
                                               ratio_now_fid=dv.to_device(self.ratio_now_fid[:, 0], self.device), k_fid=dv.to_device(self.k_fid, self.device),
                                               log_k_fid=dv.to_device(np.log10(self.k_fid), self.device), first=first)
+    pk = self._pk_rows.contiguous()
+    if fused:
+        # pknow = P_nowiggle x growth x correction, ratio = P / pknow / ratio_fid at the extrema, the envelope from it, log10 of envelope x pknow x ratio_now_fid
+        # on the per-cosmology knots k_fid / rescale with the two extrapolated knots of _pad_log on either side, its natural spline at k_fid, 10^x written
+        # over the k_fid range of P (bao_filter.py:493-509): one kernel, a wave per cosmology
+        if 'peaks' not in const:
+            const['peaks'] = dv.upload(self._envelope_columns[0].astype(np.int32), self.device)
+            const['operator'] = dv.to_device(np.ascontiguousarray(self._envelope_columns[1]), self.device)
+        res = torch.empty_like(pk)
+        _lib.check(lib.cp_brieden_smooth(rows.data_ptr(), raw.data_ptr(), g0.data_ptr(), const['correction'].data_ptr(), const['ratio_fid'].data_ptr(), const['peaks'].data_ptr(),
+                                         const['operator'].data_ptr(), int(self._envelope_columns[0].size), const['ratio_now_fid'].data_ptr(), const['k_fid'].data_ptr(),
+                                         const['log_k_fid'].data_ptr(), rescale.data_ptr(), float(interp.extrap_kmin), float(interp.extrap_kmax), pk.data_ptr(), res.data_ptr(),
+                                         nb, n, pk.shape[1], const['first'], self.device.index, stream))
+        self._pknow_rows = res
+        return
     # pknow = P_nowiggle x growth x correction; ratio = P / pknow / ratio_fid (reference bao_filter.py:493-499): one pass
     pknow, ratio = torch.empty_like(rows), torch.empty_like(rows)
     _lib.check(lib.cp_brieden_ratio(rows.data_ptr(), raw.data_ptr(), g0.data_ptr(), const['correction'].data_ptr(), const['ratio_fid'].data_ptr(),
                                     pknow.data_ptr(), ratio.data_ptr(), nb, n, self.device.index, stream))
     envelope = self._envelope(ratio)                                                                  # (B, 341)
-    pk = self._pk_rows.contiguous()
     if _RESAMPLE_IN_ONE_KERNEL and 129 <= n <= 512:
         # log10 of envelope x pknow x ratio_now_fid on the per-cosmology knots k_fid / rescale with the two extrapolated knots of _pad_log on either side,
         # its natural spline at k_fid, 10^x written over the k_fid range of P (bao_filter.py:500-509): one kernel, a wave per cosmology (k_fid is a

@@ -348,6 +348,13 @@ struct ResampleArgs {
     double* out;                  // (nb, nk)
     long long nb;
     int n, nk, first, S;
+    // the form that builds envelope and pknow itself (cp_brieden_smooth): `envelope` = P at the extrema (nb, np), `pknow` = the no-wiggle spectra (nb, n)
+    const double* g0;             // (nb)
+    const double* correction;     // (n)
+    const double* ratio_fid;      // (n)
+    const int* peaks;             // (np) positions of the extrema in k_fid
+    const double* op;             // (np, n) the columns of the envelope operator that are not zero
+    int np;
 };
 
 constexpr double rs_ipow(double x, int k) {
@@ -359,8 +366,14 @@ constexpr double rs_ipow(double x, int k) {
 // LDS per wave: Y[n + 4] (log10 of the samples, the extrapolated values at 0, 1, n + 2, n + 3), M[n + 4] (second derivatives in units of 6 kappa / h^2).
 // S = knots (= samples = queries) per lane.  What does not depend on the cosmology is set up once: the queries and ratio_now_fid (in LDS, shared by
 // the four waves), p^(distance of the lane's knots from either end); the next cosmology's samples are requested before this one's are worked on.
-template <int S>
-__global__ __launch_bounds__(256, CP_RS_WAVES) void brieden_resample_kernel(const ResampleArgs A) {
+// PEAKS: the envelope is linear in the ratio P / pknow / ratio_fid AT THE EXTREMA of the fiducial wiggles only (bao_filter.py:482-488: two quadratic splines
+// through them) -- np = 23 of the 341 columns of the operator are not zero.  A lane p < np forms the ratio at its extremum, the lanes take the np columns
+// for their S samples from memory (np x n doubles, L2-resident) and sum; pknow = no-wiggle x growth x correction in registers: neither array exists in memory.
+// OPLDS: the np x n columns in LDS (63 KB for 23 extrema of 341 samples) shared by the twelve waves of a workgroup of 768 -- one workgroup per CU; from memory
+// the 138 loads per lane and cosmology are what the kernel waits for (0.31 ms per 32 768 against 0.17 without the envelope).
+template <int S, bool PEAKS, bool OPLDS>
+__global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void brieden_resample_kernel(const ResampleArgs A) {
+    constexpr int W = OPLDS ? 12 : 4;      // waves = cosmologies in flight per workgroup
     extern __shared__ double rs_lds[];
     __shared__ cpmath::MathTables mt;
     cpmath::fill_math_tables(&mt);
@@ -369,12 +382,17 @@ __global__ __launch_bounds__(256, CP_RS_WAVES) void brieden_resample_kernel(cons
     const int stride = N + 4;
     double* Y = rs_lds + (size_t)wave * 2 * stride;
     double* M = Y + stride;
-    double* XQ = rs_lds + (size_t)8 * stride;      // the queries and ratio_now_fid: the same for every cosmology, shared by the four waves
+    double* XQ = rs_lds + (size_t)2 * W * stride;      // the queries and ratio_now_fid: the same for every cosmology, shared by the waves
     double* RNF = XQ + n;
-    for (int j = threadIdx.x; j < n; j += 256) {
+    double* CORR = RNF + n;
+    double* OP = CORR + n;
+    for (int j = threadIdx.x; j < n; j += 64 * W) {
         XQ[j] = A.log_k_fid[j];
         RNF[j] = A.ratio_now_fid[j];
+        if (PEAKS) CORR[j] = A.correction[j];
     }
+    if (OPLDS)
+        for (int j = threadIdx.x; j < A.np * n; j += 64 * W) OP[j] = A.op[j];
     __syncthreads();
     constexpr double LOG10E = 0.43429448190325182765;
     constexpr int REACH = (32 + S) / S;      // REACH x S >= 33 knots: p^33 = 1e-19
@@ -388,16 +406,24 @@ __global__ __launch_bounds__(256, CP_RS_WAVES) void brieden_resample_kernel(cons
     const double pa = own <= 40 ? pow(RS_P, (double)own) : 0.;
     const double pb = dr <= 40 && dr > -S ? pow(RS_P, (double)(dr < 0 ? 0 : dr)) : 0.;
     const double kf0 = A.k_fid[0], kf1 = A.k_fid[n - 1], lkf0 = A.log_k_fid[0], lkf1 = A.log_k_fid[n - 1];
-    const long long step = (long long)gridDim.x * 4;
-    long long c = (long long)blockIdx.x * 4 + wave;
-    double e[S], pn[S], r = 1.;
+    const long long step = (long long)gridDim.x * W;
+    long long c = (long long)blockIdx.x * W + wave;
+    double e[PEAKS ? 1 : S], pn[S], r = 1., g0 = 1., now_peak = 1.;
+    // (PEAKS) what lane p < np divides by besides pknow, where its extremum is
+    const int peak = PEAKS && lane < A.np ? A.peaks[lane] : 0;
+    const double corr_peak = PEAKS ? A.correction[peak] : 1., fid_peak = PEAKS ? A.ratio_fid[peak] : 1.;
     auto request = [&](long long cc) {
         if (cc >= A.nb) return;
         r = A.rescale[cc];
+        if (PEAKS) {
+            g0 = A.g0[cc];
+            e[0] = lane < A.np ? A.envelope[cc * A.np + lane] : 0.;
+            now_peak = A.pknow[cc * n + peak];
+        }
 #pragma unroll
         for (int t = 0; t < S; ++t) {
             const int j = lane + 64 * t;
-            e[t] = j < n ? A.envelope[cc * n + j] : 1.;
+            if (!PEAKS) e[t] = j < n ? A.envelope[cc * n + j] : 1.;
             pn[t] = j < n ? A.pknow[cc * n + j] : 1.;
         }
     };
@@ -411,10 +437,29 @@ __global__ __launch_bounds__(256, CP_RS_WAVES) void brieden_resample_kernel(cons
         const double lmin = lg10(fmin(A.kmin, kf0 / r * (1 - 1e-9))), lmax = lg10(fmax(A.kmax, kf1 / r * (1 + 1e-9)));
         const double xa = cp::wave_uniform(lmin), xb = cp::wave_uniform(x_first * 0.1 + lmin * 0.9), xc = cp::wave_uniform(x_last * 0.1 + lmax * 0.9), xd = cp::wave_uniform(lmax);
         // ---- the samples, read where they are; the next cosmology's requested ----
+        if (PEAKS) {
+            const double ratio = e[0] / (now_peak * g0 * corr_peak) / fid_peak;      // (bao_filter.py:493-499, at the lane's extremum)
+            double env[S];
 #pragma unroll
-        for (int t = 0; t < S; ++t) {
-            const int j = lane + 64 * t;
-            if (j < n) Y[2 + j] = lg10(e[t] * pn[t] * RNF[j]);
+            for (int t = 0; t < S; ++t) env[t] = 0.;
+#pragma unroll 4
+            for (int p = 0; p < A.np; ++p) {
+                const double rp = cp::lane_value(ratio, p);
+                const double* col = (OPLDS ? OP : A.op) + (size_t)p * n + lane;
+#pragma unroll
+                for (int t = 0; t < S; ++t) env[t] = fma(lane + 64 * t < n ? col[64 * t] : 0., rp, env[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                const int j = lane + 64 * t;
+                if (j < n) Y[2 + j] = lg10(env[t] * (pn[t] * g0 * CORR[j]) * RNF[j]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < S; ++t) {
+                const int j = lane + 64 * t;
+                if (j < n) Y[2 + j] = lg10(e[t] * pn[t] * RNF[j]);
+            }
         }
         request(c + step);
         cp::wave_lds_phase();
@@ -556,35 +601,83 @@ __global__ __launch_bounds__(256, CP_RS_WAVES) void brieden_resample_kernel(cons
 
 }  // namespace
 
+namespace {
+
+template <int S, bool PEAKS, bool OPLDS>
+int launch_resample_as(const ResampleArgs& A, size_t lds, int ncu, void* stream) {
+    constexpr int W = OPLDS ? 12 : 4;
+    if (lds > 64 * 1024 && cp::allow_full_lds<brieden_resample_kernel<S, PEAKS, OPLDS>>() != hipSuccess) return CP_EDEVICE;
+    const long long blocks = (A.nb + W - 1) / W, resident = (long long)ncu * (OPLDS ? 1 : CP_RS_WAVES);
+    hipLaunchKernelGGL((brieden_resample_kernel<S, PEAKS, OPLDS>), dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(64 * W), lds,
+                       static_cast<hipStream_t>(stream), A);
+    return CP_OK;
+}
+
+template <bool PEAKS>
+int launch_resample(ResampleArgs& A, const char* who, int device, void* stream) {
+    const int n = A.n;
+    A.S = (n + 63) / 64;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
+    // per wave Y and M, per workgroup the queries, ratio_now_fid, correction -- and the operator's columns where twelve waves' arrays leave room for them
+    const size_t shared = 3 * (size_t)n * sizeof(double), per_wave = 2 * ((size_t)n + 8) * sizeof(double), op = PEAKS ? (size_t)A.np * n * sizeof(double) : 0;
+    const bool oplds = PEAKS && 12 * per_wave + shared + op + 2048 <= 160 * 1024;
+    const size_t lds = oplds ? 12 * per_wave + shared + op : 4 * per_wave + shared;
+    int st = CP_OK;
+    auto go = [&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        if constexpr (PEAKS) st = oplds ? launch_resample_as<S, true, true>(A, lds, ncu, stream) : launch_resample_as<S, true, false>(A, lds, ncu, stream);
+        else st = launch_resample_as<S, false, false>(A, lds, ncu, stream);
+    };
+    switch (A.S) {
+        case 3: go(std::integral_constant<int, 3>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 5: go(std::integral_constant<int, 5>{}); break;
+        case 6: go(std::integral_constant<int, 6>{}); break;
+        case 7: go(std::integral_constant<int, 7>{}); break;
+        default: go(std::integral_constant<int, 8>{}); break;
+    }
+    if (st != CP_OK) return cp::fail(st, "%s: cannot configure the kernel's LDS", who);
+    return finish(who, 0);
+}
+
+bool resample_sizes_ok(int n) { return (n + 63) / 64 >= RS_SMIN && (n + 63) / 64 <= RS_SMAX; }
+
+}  // namespace
+
 extern "C" int cp_brieden_resample(const double* d_envelope, const double* d_pknow, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_log_k_fid,
                                    const double* d_rescale, double extrap_kmin, double extrap_kmax, const double* d_pk, double* d_out, long long nb, int n,
                                    int nk, int first, int device, void* stream) {
     if (nb < 0 || n < 4 || nk < 1 || first < 0 || first + n > nk) return cp::fail(CP_EINVAL, "cp_brieden_resample: bad sizes");
-    const int S = (n + 63) / 64;
-    if (S < RS_SMIN || S > RS_SMAX)
+    if (!resample_sizes_ok(n))
         return cp::fail(CP_EUNSUPPORTED, "cp_brieden_resample: %d samples per cosmology (129 ... 512): cp_brieden_knots, cp_spline_columns, cp_brieden_finish", n);
     if (nb == 0) return CP_OK;
     if (!d_envelope || !d_pknow || !d_ratio_now_fid || !d_k_fid || !d_log_k_fid || !d_rescale || !d_pk || !d_out) return cp::fail(CP_EINVAL, "cp_brieden_resample: null pointer");
     DeviceScope scope(device);
     if (!scope.ok) return cp::fail(CP_EDEVICE, "cp_brieden_resample: cannot select device %d", device);
-    ResampleArgs A;
+    ResampleArgs A = {};
     A.envelope = d_envelope; A.pknow = d_pknow; A.ratio_now_fid = d_ratio_now_fid; A.k_fid = d_k_fid; A.log_k_fid = d_log_k_fid; A.rescale = d_rescale;
-    A.kmin = extrap_kmin; A.kmax = extrap_kmax; A.pk = d_pk; A.out = d_out; A.nb = nb; A.n = n; A.nk = nk; A.first = first; A.S = S;
-    const size_t lds = ((size_t)4 * 2 * (n + 8) + 2 * (size_t)n) * sizeof(double);
-    int ncu = 0;
-    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
-    const long long blocks = (nb + 3) / 4, resident = (long long)ncu * CP_RS_WAVES;
-    const dim3 grid((unsigned)(blocks < resident ? blocks : resident)), block(256);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (S) {
-        case 3: hipLaunchKernelGGL(brieden_resample_kernel<3>, grid, block, lds, st, A); break;
-        case 4: hipLaunchKernelGGL(brieden_resample_kernel<4>, grid, block, lds, st, A); break;
-        case 5: hipLaunchKernelGGL(brieden_resample_kernel<5>, grid, block, lds, st, A); break;
-        case 6: hipLaunchKernelGGL(brieden_resample_kernel<6>, grid, block, lds, st, A); break;
-        case 7: hipLaunchKernelGGL(brieden_resample_kernel<7>, grid, block, lds, st, A); break;
-        default: hipLaunchKernelGGL(brieden_resample_kernel<8>, grid, block, lds, st, A); break;
-    }
-    return finish("cp_brieden_resample", 0);
+    A.kmin = extrap_kmin; A.kmax = extrap_kmax; A.pk = d_pk; A.out = d_out; A.nb = nb; A.n = n; A.nk = nk; A.first = first;
+    return launch_resample<false>(A, "cp_brieden_resample", device, stream);
+}
+
+extern "C" int cp_brieden_smooth(const double* d_pk_peaks, const double* d_now, const double* d_g0, const double* d_correction, const double* d_ratio_fid,
+                                 const int* d_peaks, const double* d_operator, int np, const double* d_ratio_now_fid, const double* d_k_fid,
+                                 const double* d_log_k_fid, const double* d_rescale, double extrap_kmin, double extrap_kmax, const double* d_pk, double* d_out,
+                                 long long nb, int n, int nk, int first, int device, void* stream) {
+    if (nb < 0 || n < 4 || nk < 1 || first < 0 || first + n > nk || np < 1 || np > 64) return cp::fail(CP_EINVAL, "cp_brieden_smooth: bad sizes");
+    if (!resample_sizes_ok(n)) return cp::fail(CP_EUNSUPPORTED, "cp_brieden_smooth: %d samples per cosmology (129 ... 512)", n);
+    if (nb == 0) return CP_OK;
+    if (!d_pk_peaks || !d_now || !d_g0 || !d_correction || !d_ratio_fid || !d_peaks || !d_operator || !d_ratio_now_fid || !d_k_fid || !d_log_k_fid || !d_rescale ||
+        !d_pk || !d_out)
+        return cp::fail(CP_EINVAL, "cp_brieden_smooth: null pointer");
+    DeviceScope scope(device);
+    if (!scope.ok) return cp::fail(CP_EDEVICE, "cp_brieden_smooth: cannot select device %d", device);
+    ResampleArgs A = {};
+    A.envelope = d_pk_peaks; A.pknow = d_now; A.ratio_now_fid = d_ratio_now_fid; A.k_fid = d_k_fid; A.log_k_fid = d_log_k_fid; A.rescale = d_rescale;
+    A.kmin = extrap_kmin; A.kmax = extrap_kmax; A.pk = d_pk; A.out = d_out; A.nb = nb; A.n = n; A.nk = nk; A.first = first;
+    A.g0 = d_g0; A.correction = d_correction; A.ratio_fid = d_ratio_fid; A.peaks = d_peaks; A.op = d_operator; A.np = np;
+    return launch_resample<true>(A, "cp_brieden_smooth", device, stream);
 }
 
 extern "C" int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_out, long long nb, int nk, int first, int n, int device,

@@ -455,6 +455,15 @@ int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_o
 int cp_brieden_resample(const double* d_envelope, const double* d_pknow, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_log_k_fid,
                         const double* d_rescale, double extrap_kmin, double extrap_kmax, const double* d_pk, double* d_out, long long nb, int n, int nk,
                         int first, int device, void* stream);
+/* cp_brieden_ratio + the envelope operator + cp_brieden_resample as one kernel: the envelope (two quadratic splines through the extrema of the fiducial
+ * wiggles, bao_filter.py:482-488) is linear in the ratio AT THOSE EXTREMA only, so the spectra are needed at np wavenumbers instead of n, and neither pknow,
+ * ratio nor envelope is written to memory.  d_pk_peaks : (nb, np) P_c(k_fid[peaks] / rescale[c]); d_now : (nb, n) the no-wiggle spectra at k_fid x rescale[c];
+ * d_g0 : (nb) growth; d_correction, d_ratio_fid : (n); d_peaks : (np) ascending positions in k_fid; d_operator : (np, n), row p = column peaks[p] of the (n x n)
+ * operator (its other columns are zero); np <= 64; the rest as cp_brieden_resample (bao_filter.py:493-509). */
+int cp_brieden_smooth(const double* d_pk_peaks, const double* d_now, const double* d_g0, const double* d_correction, const double* d_ratio_fid, const int* d_peaks,
+                      const double* d_operator, int np, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_log_k_fid, const double* d_rescale,
+                      double extrap_kmin, double extrap_kmax, const double* d_pk, double* d_out, long long nb, int n, int nk, int first, int device,
+                      void* stream);
 
 /* natural cubic spline per column with per-column knots (brieden2022 re-sampling with one rs_drag ratio per column, bao_filter.py:503-509):
  * d_xk, d_yk : (n, ncol) knot-major; d_xq : (nq) ascending queries shared by all columns; d_out : (nq, ncol);

@@ -108,16 +108,17 @@ def test_batched_cosmologies(cp, golden):
 
 
 def test_brieden_resampling_in_one_kernel(cp):
-    """brieden2022 over a batch: cp_brieden_resample (the knots of a cosmology are a geometric grid: second derivatives by two recursions per lane, the
+    """brieden2022 over a batch: cp_brieden_smooth (the same with ratio and envelope formed inside, from P at the extrema of the fiducial wiggles only)
+    and cp_brieden_resample (the knots of a cosmology are a geometric grid: second derivatives by two recursions per lane, the
     extrapolated knots of _pad_log as a closed-form correction at either end, 10^x into the k_fid range of P: a wave per cosmology) against the three
-    kernels it replaces (knot-major arrays, the general per-column spline, the final pass), for batches that do and do not fill the waves of a workgroup,
+    kernels they replace (knot-major arrays, the general per-column spline, the final pass), for batches that do and do not fill the waves of a workgroup,
     rs_drag ratios on both sides of 1 (queries shifted either way, into the long intervals at the ends), a cosmology equal to the fiducial one, and
     fewer wavenumbers (4 knots per lane)."""
     from cosmoprimo_amd import bao_filter as bf
     from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
     fid = cp.Cosmology(engine='eisenstein_hu')
     rng = np.random.default_rng(5)
-    for nb, nk in ((1, 1024), (7, 1024), (130, 1024), (9, 640)):
+    for nb, nk in ((1, 1024), (7, 1024), (130, 1024), (9, 640), (5, 1500)):      # (1500: 8 samples per lane, the operator too large for LDS)
         par = dict(Omega_m=rng.uniform(0.24, 0.40, nb), Omega_b=rng.uniform(0.04, 0.06, nb), h=rng.uniform(0.6, 0.8, nb), n_s=rng.uniform(0.92, 1., nb))
         if nb > 1:
             par = {name: np.concatenate([[fid[name]], v[1:]]) for name, v in par.items()}
@@ -125,15 +126,15 @@ def test_brieden_resampling_in_one_kernel(cp):
         interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
         saved = bf._RESAMPLE_IN_ONE_KERNEL
         try:
-            bf._RESAMPLE_IN_ONE_KERNEL = True
-            one = PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid, nk=nk).pknow
-            bf._RESAMPLE_IN_ONE_KERNEL = False
-            three = PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid, nk=nk).pknow
+            got = []
+            for scheme in (2, 1, 0):      # everything behind the two P(k) evaluations as one kernel | ratio, operator, re-sampling kernel | ... , three kernels
+                bf._RESAMPLE_IN_ONE_KERNEL = scheme
+                got.append(np.asarray(PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid, nk=nk).pknow))
         finally:
             bf._RESAMPLE_IN_ONE_KERNEL = saved
-        one, three = np.asarray(one), np.asarray(three)
-        assert one.shape == three.shape == (nb, nk, 1) and np.isfinite(one).all()
-        np.testing.assert_allclose(one, three, rtol=1e-11)
+        for one in got[:2]:
+            assert one.shape == got[2].shape == (nb, nk, 1) and np.isfinite(one).all()
+            np.testing.assert_allclose(one, got[2], rtol=1e-11)
 
 
 def test_wallish_box_kernel():
