@@ -137,6 +137,33 @@ def test_brieden_resampling_in_one_kernel(cp):
             np.testing.assert_allclose(one, got[2], rtol=1e-11)
 
 
+def test_brieden_one_kernel_refusals():
+    """cp_brieden_smooth / cp_brieden_resample: sizes outside the kernel (fewer than 129 or more than 512 samples per cosmology: CP_EUNSUPPORTED, the caller
+    then takes the three kernels), more extrema than lanes, null pointers, a range that does not fit the rows (CP_EINVAL); an empty batch is a success."""
+    import torch
+    from cosmoprimo_amd import _lib, _device as dv
+    lib = _lib.load()
+    dev = torch.device('cuda', 0)
+    st = dv.stream_of(dev)
+    buf = torch.ones(4096, dtype=torch.float64, device=dev)
+    idx = torch.zeros(64, dtype=torch.int32, device=dev)
+    p = buf.data_ptr()
+
+    def smooth(nb, n, nk, first, npk=23, pk=p):
+        return lib.cp_brieden_smooth(p, p, p, p, p, idx.data_ptr(), p, npk, p, p, p, p, 1e-5, 10., pk, p, nb, n, nk, first, 0, st)
+
+    def resample(nb, n, nk, first, pk=p):
+        return lib.cp_brieden_resample(p, p, p, p, p, p, 1e-5, 10., pk, p, nb, n, nk, first, 0, st)
+
+    for call in (smooth, resample):
+        assert call(0, 341, 1024, 300) == _lib.CP_OK
+        assert call(1, 128, 1024, 300) == _lib.CP_EUNSUPPORTED and call(1, 513, 1024, 300) == _lib.CP_EUNSUPPORTED
+        assert call(1, 341, 1024, 700) == _lib.CP_EINVAL and call(-1, 341, 1024, 300) == _lib.CP_EINVAL and call(1, 341, 1024, -1) == _lib.CP_EINVAL
+        assert call(1, 341, 1024, 300, pk=None) == _lib.CP_EINVAL
+    assert smooth(1, 341, 1024, 300, npk=65) == _lib.CP_EINVAL and smooth(1, 341, 1024, 300, npk=0) == _lib.CP_EINVAL
+    torch.cuda.synchronize(dev)
+
+
 def test_wallish_box_kernel():
     """cp_wallish_box against ndarray.argmax on the reference's ranges (bao_filter.py:390-394): first index on ties, NaN as the maximum, the
     index-0 convention for an empty second range."""
