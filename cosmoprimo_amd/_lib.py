@@ -119,6 +119,7 @@ SIGNATURES = {
     'cp_spline_rows_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p,
                                            ctypes.c_void_p]),
     'cp_spline_rows_second_derivatives': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]),
+    'cp_spline_rows_pairs': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]),
     'cp_spline_rows_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_tables_rows_direct': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
                                             ctypes.c_double, ctypes.c_void_p]),

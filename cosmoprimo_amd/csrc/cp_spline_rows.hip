@@ -48,6 +48,7 @@ struct RowsArgs {
     double scale;
     double* out;
     double* out_m;            // (nrows, n_src) or null: the second derivatives at the knots of the window instead of the queries
+    int pairs;                // out_m is (nrows, n_src, 2): the knot values with their second derivatives, (y_j, M_j)
 };
 
 __device__ __forceinline__ long long rows_out_index(long long row, int q, int nq, int group) {      // cp_spline.hip: out_index
@@ -148,6 +149,12 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
         if (T.fix_last && l == 0) buf[nw - 1] = T.fix[2] * buf[nw - 2] + T.fix[3] * buf[nw - 3];
         cp::wave_lds_phase();      // end fixes in place: the evaluation gathers across segments
         if (A.out_m) {
+            if (A.pairs) {
+                double2* dst = reinterpret_cast<double2*>(A.out_m) + row * T.n_src + T.w0;
+                if (live)
+                    for (int i = l; i < nw; i += LPR) dst[i] = double2{src[i], buf[i]};
+                continue;
+            }
             double* dst = A.out_m + row * T.n_src + T.w0;
             if (live)
                 for (int i = l; i < nw; i += LPR) dst[i] = buf[i];
@@ -353,13 +360,24 @@ extern "C" int cp_spline_rows_apply(const cp_spline_rows_plan* p, const double* 
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_apply: cannot select device %d", p->device);
     RowsArgs A;
     A.T = p->T;
-    A.y = d_y; A.nrows = nrows; A.post_op = post_op; A.group = group; A.scale = scale; A.out = d_out; A.out_m = nullptr;
+    A.y = d_y; A.nrows = nrows; A.post_op = post_op; A.group = group; A.scale = scale; A.out = d_out; A.out_m = nullptr; A.pairs = 0;
     const int st = launch_rows(p, A, nrows, stream);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     return st;
 }
 
+static int second_derivatives(const cp_spline_rows_plan* p, const double* d_y, long long nrows, double* d_m, int pairs, void* stream);
+
 extern "C" int cp_spline_rows_second_derivatives(const cp_spline_rows_plan* p, const double* d_y, long long nrows, double* d_m, void* stream) {
+    return second_derivatives(p, d_y, nrows, d_m, 0, stream);
+}
+
+// the same, written with the knot values beside them: d_ym (nrows, n, 2) = (y_j, M_j) -- the layout cp_tables_rows_direct reads with d_m null
+extern "C" int cp_spline_rows_pairs(const cp_spline_rows_plan* p, const double* d_y, long long nrows, double* d_ym, void* stream) {
+    return second_derivatives(p, d_y, nrows, d_ym, 1, stream);
+}
+
+static int second_derivatives(const cp_spline_rows_plan* p, const double* d_y, long long nrows, double* d_m, int pairs, void* stream) {
     if (!p) return cp::fail(CP_EINVAL, "cp_spline_rows_second_derivatives: null plan");
     if (nrows < 0) return cp::fail(CP_EINVAL, "cp_spline_rows_second_derivatives: negative batch");
     if (nrows == 0) return CP_OK;
@@ -371,7 +389,7 @@ extern "C" int cp_spline_rows_second_derivatives(const cp_spline_rows_plan* p, c
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_second_derivatives: cannot select device %d", p->device);
     RowsArgs A;
     A.T = p->T;
-    A.y = d_y; A.nrows = nrows; A.post_op = CP_SPLINE_POST_NONE; A.group = 0; A.scale = 1.; A.out = nullptr; A.out_m = d_m;
+    A.y = d_y; A.nrows = nrows; A.post_op = CP_SPLINE_POST_NONE; A.group = 0; A.scale = 1.; A.out = nullptr; A.out_m = d_m; A.pairs = pairs;
     const int st = launch_rows(p, A, nrows, stream);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
     return st;

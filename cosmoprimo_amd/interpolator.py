@@ -173,6 +173,7 @@ _FUSED_SPLINE_ROWS = (2, 8192)
 _TRANSPOSE_IN_STORE = True
 _FUNCTIONAL_RADII = 4          # sigma_rz_analytic: up to this many radii as dot products with the spectrum (cp_sigma_rz_functional)
 _DIRECT_K_SPLINE = True        # batches of (k, z) tables: the k splines evaluated from the tables' second derivatives (cp_tables_rows_direct) instead of multiplied
+_PAIRED_TABLES = True          # ... from (value, second derivative) pairs in one array, cp_spline_rows_pairs (False: tables and second derivatives as two arrays)
 
 
 def _fftlog_then_spline(fft, op, rows, device, sqrt=False):
@@ -698,11 +699,13 @@ class Interpolator2D(dv.Copyable):
             if m is None:
                 ends = _cached_operator(('i2x-rows-m', self._x.tobytes(), self.device.index),
                                         lambda: SplineRows(self._x, self._x[[0, -1]], bc='not-a-knot', device=self.device))
-                m = self._fun_y_major_m = ends.second_derivatives(fun_t)
+                # (y_j, M_j) pairs: the four numbers of a query are 32 contiguous bytes (kept besides the tables: twice their size)
+                m = self._fun_y_major_m = ends.second_derivatives(fun_t, pairs=_PAIRED_TABLES)
             out = torch.empty((fun_t.shape[0], opy.nq, xq.size), dtype=torch.float64, device=self.device)
             if fun_t.shape[0]:
-                _lib.check(lib.cp_tables_rows_direct(kplan._handle, opy._handle, fun_t.data_ptr(), m.data_ptr(), out.data_ptr(), fun_t.shape[0], 2 if exp10 else 0, 1.,
-                                                     dv.stream_of(self.device)))
+                paired = m.dim() == fun_t.dim() + 1
+                _lib.check(lib.cp_tables_rows_direct(kplan._handle, opy._handle, m.data_ptr() if paired else fun_t.data_ptr(), None if paired else m.data_ptr(), out.data_ptr(),
+                                                     fun_t.shape[0], 2 if exp10 else 0, 1., dv.stream_of(self.device)))
             return out
         except NotImplementedError:
             return None

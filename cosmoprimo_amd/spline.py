@@ -227,16 +227,18 @@ class SplineRows(object):
                                                         dv.stream_of(self.device)))
         return out
 
-    def second_derivatives(self, y):
-        """y (..., n) -> (..., n): the second derivatives of the spline at its knots (needs queries that span the knots)."""
+    def second_derivatives(self, y, pairs=False):
+        """y (..., n) -> (..., n): the second derivatives of the spline at its knots (needs queries that span the knots);
+        pairs=True: (..., n, 2), the knot values with their second derivatives (y_j, M_j) -- what ``cp_tables_rows_direct`` reads fastest."""
         torch = dv.torch()
         y = dv.to_device(y, self.device).contiguous()
         if y.shape[-1] != self.n:
             raise ValueError('last dimension must be {:d}, got {}'.format(self.n, tuple(y.shape)))
-        out = torch.empty_like(y)
+        out = torch.empty(tuple(y.shape) + (2,), dtype=torch.float64, device=self.device) if pairs else torch.empty_like(y)
         nrows = y.numel() // self.n
         if nrows:
-            _lib.check(_lib.load().cp_spline_rows_second_derivatives(self._handle, y.data_ptr(), nrows, out.data_ptr(), dv.stream_of(self.device)))
+            fun = _lib.load().cp_spline_rows_pairs if pairs else _lib.load().cp_spline_rows_second_derivatives
+            _lib.check(fun(self._handle, y.data_ptr(), nrows, out.data_ptr(), dv.stream_of(self.device)))
         return out
 
     def __del__(self):

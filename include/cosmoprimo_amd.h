@@ -426,11 +426,14 @@ int cp_spline_rows_apply(const cp_spline_rows_plan* plan, const double* d_y, lon
 /* the second derivatives of the spline at its knots, (nrows, n) -- the spline's own representation, from which any query follows by the four-term
  * formula above; needs a plan whose queries span the knots */
 int cp_spline_rows_second_derivatives(const cp_spline_rows_plan* plan, const double* d_y, long long nrows, double* d_m, void* stream);
+/* the same with the knot values beside them: d_ym (nrows, n, 2) = (y_j, M_j), the four numbers of a query in 32 contiguous bytes */
+int cp_spline_rows_pairs(const cp_spline_rows_plan* plan, const double* d_y, long long nrows, double* d_ym, void* stream);
 int cp_spline_rows_plan_destroy(cp_spline_rows_plan* plan);
 /* cp_tables_rows with the k direction evaluated from the tables' own second derivatives instead of multiplied by an operator: d_m (nbatch, nz, n) =
  * cp_spline_rows_second_derivatives of the tables along k for the knots of kplan (a cp_spline_rows plan, any boundary condition, whose queries --
  * the output wavenumbers -- span the knots); zplan as in cp_tables_rows.  The second derivatives belong to the tables: a caller evaluates them once
- * per table set (what scipy's RectBivariateSpline does when it is built, jax.py:241-271) and re-uses them for every grid of wavenumbers / redshifts. */
+ * per table set (what scipy's RectBivariateSpline does when it is built, jax.py:241-271) and re-uses them for every grid of wavenumbers / redshifts.
+ * d_m NULL: d_tables holds (nbatch, nz, n, 2) pairs (cp_spline_rows_pairs of the tables) -- one partly used cache line per piece of a row instead of two. */
 int cp_tables_rows_direct(const cp_spline_rows_plan* kplan, const cp_spline_plan* zplan, const double* d_tables, const double* d_m, double* d_out,
                           long long nbatch, int post_op, double scale, void* stream);
 

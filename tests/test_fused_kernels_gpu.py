@@ -405,6 +405,9 @@ def test_spline_rows(bc):
     got = op.second_derivatives(torch.as_tensor(y, device=dev)).cpu().numpy()
     ref = interpolate.CubicSpline(x, y, axis=-1, bc_type=bc)(x, nu=2)
     np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-9 * np.abs(ref).max())
+    # ... written beside the knot values, (y_j, M_j): the same numbers
+    pairs = op.second_derivatives(torch.as_tensor(y, device=dev), pairs=True).cpu().numpy()
+    assert pairs.shape == y.shape + (2,) and np.array_equal(pairs[..., 0], y) and np.array_equal(pairs[..., 1], got)
 
 
 @pytest.mark.parametrize('shape', [(3, 30, 504, 64, 1024), (2, 13, 211, 37, 1000), (1, 5, 64, 3, 70), (5, 32, 100, 64, 256)])
@@ -431,6 +434,11 @@ def test_tables_rows_direct(shape, post):
     code = {None: 0, 'exp10': 2}[post]
     _lib.check(lib.cp_tables_rows_direct(kplan._handle, opz._handle, t.data_ptr(), m.data_ptr(), out.data_ptr(), nb, code, 1., dv.stream_of(dev)))
     got, ref = out.cpu().numpy(), opz.mid(opx(t), post=post).cpu().numpy()
+    # tables and second derivatives as (y, M) pairs in one array (d_m null): the same operations on the same numbers
+    ym = SplineRows(x, x[[0, -1]], bc='not-a-knot', device=dev).second_derivatives(t, pairs=True)
+    out2 = torch.full((nb, nzq, nq), -7., dtype=torch.float64, device=dev)
+    _lib.check(lib.cp_tables_rows_direct(kplan._handle, opz._handle, ym.data_ptr(), None, out2.data_ptr(), nb, code, 1., dv.stream_of(dev)))
+    assert np.array_equal(out2.cpu().numpy(), got, equal_nan=True)
     outside = (xq < x[0]) | (xq > x[-1])
     assert np.isnan(got[..., outside]).all() and np.isfinite(got[..., ~outside]).all()
     np.testing.assert_allclose(got[..., ~outside], ref[..., ~outside], rtol=1e-11, atol=1e-12)

@@ -82,15 +82,21 @@ def test_rows_of_tables_both_routes(cp, golden, nk, nzq):
     # range, as this one does at k = 100 -- the last intervals of such a spline are conditioned like 1e9, and the two routes, like FITPACK, differ by 1e-7 there)
     kq = np.geomspace(k[16], k[-17], nk)      # (the disturbance decays by 0.27 per knot)
     zq = np.linspace(z[0], z[-1], nzq) if nzq > 1 else np.array([0.7])
-    saved = itp._DIRECT_K_SPLINE
+    saved = itp._DIRECT_K_SPLINE, itp._PAIRED_TABLES
     try:
         itp._DIRECT_K_SPLINE = True
-        direct = many._interp.rows_y_major(kq, zq, exp10=True).cpu().numpy()
+        direct = many._interp.rows_y_major(kq, zq, exp10=True).cpu().numpy()      # (tables and second derivatives as pairs in one array)
+        assert many._interp._fun_y_major_m.shape == many._interp._fun_y_major.shape + (2,)
+        itp._PAIRED_TABLES = False
+        del many._interp._fun_y_major_m
+        two_arrays = many._interp.rows_y_major(kq, zq, exp10=True).cpu().numpy()
+        assert many._interp._fun_y_major_m.shape == many._interp._fun_y_major.shape
         itp._DIRECT_K_SPLINE = False
         operators = many._interp.rows_y_major(kq, zq, exp10=True).cpu().numpy()
     finally:
-        itp._DIRECT_K_SPLINE = saved
+        itp._DIRECT_K_SPLINE, itp._PAIRED_TABLES = saved
     assert direct.shape == (5, nzq, nk)
+    assert np.array_equal(direct, two_arrays, equal_nan=True)      # the same numbers in the same operations, read from another layout
     assert np.isnan(direct[2]).all() and np.isnan(operators[2]).all()
     keep = [0, 1, 3, 4]
     np.testing.assert_allclose(direct[keep], operators[keep], rtol=1e-11)

@@ -8,10 +8,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def main():
+def main(paired):
     import torch
     import cosmoprimo_amd as cp
-    from cosmoprimo_amd import _lib
+    from cosmoprimo_amd import _lib, interpolator
+    interpolator._PAIRED_TABLES = paired
+    print('tables and second derivatives as %s' % ('(y, M) pairs' if paired else 'two arrays'))
     nb = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'sigma.npz'))
     rng = np.random.default_rng(1)
@@ -55,4 +57,5 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    for paired in (False, True):
+        main(paired)
