@@ -330,9 +330,6 @@ namespace {
 #ifndef CP_RS_WAVES
 #define CP_RS_WAVES 3      // waves per SIMD the kernel is compiled for
 #endif
-#ifndef CP_RS_EVAL_UNROLL
-#define CP_RS_EVAL_UNROLL 8
-#endif
 constexpr int RS_SMIN = 3, RS_SMAX = 8;      // knots per lane: 129 <= n <= 512
 constexpr double RS_P = -0.26794919243112270647, RS_KAPPA = 0.28867513459481288225;      // sqrt 3 - 2, 1 / (2 sqrt 3)
 
@@ -347,7 +344,7 @@ struct ResampleArgs {
     const double* pk;             // (nb, nk)
     double* out;                  // (nb, nk)
     long long nb;
-    int n, nk, first, S;
+    int n, nk, first;
     // the form that builds envelope and pknow itself (cp_brieden_smooth): `envelope` = P at the extrema (nb, np), `pknow` = the no-wiggle spectra (nb, n)
     const double* g0;             // (nb)
     const double* correction;     // (n)
@@ -442,12 +439,19 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
             double env[S];
 #pragma unroll
             for (int t = 0; t < S; ++t) env[t] = 0.;
-#pragma unroll 4
-            for (int p = 0; p < A.np; ++p) {
-                const double rp = cp::lane_value(ratio, p);
-                const double* col = (OPLDS ? OP : A.op) + (size_t)p * n + lane;
+            for (int p = 0; p < A.np; p += 2) {      // two columns at a time (2 S independent loads in flight); an odd count: the last one again, times zero
+                const int p1 = p + 1 < A.np ? p + 1 : p;
+                const double rp0 = cp::lane_value(ratio, p), rp1 = p + 1 < A.np ? cp::lane_value(ratio, p1) : 0.;
+                const double* col0 = (OPLDS ? OP : A.op) + (size_t)p * n + lane;
+                const double* col1 = (OPLDS ? OP : A.op) + (size_t)p1 * n + lane;
+                double c0[S], c1[S];
 #pragma unroll
-                for (int t = 0; t < S; ++t) env[t] = fma(lane + 64 * t < n ? col[64 * t] : 0., rp, env[t]);
+                for (int t = 0; t < S; ++t) {
+                    c0[t] = lane + 64 * t < n ? col0[64 * t] : 0.;
+                    c1[t] = lane + 64 * t < n ? col1[64 * t] : 0.;
+                }
+#pragma unroll
+                for (int t = 0; t < S; ++t) env[t] = fma(c1[t], rp1, fma(c0[t], rp0, env[t]));
             }
 #pragma unroll
             for (int t = 0; t < S; ++t) {
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
         // ---- evaluation at log10(k_fid), 10^x into the k_fid range of the row; the rest of the row as it is ----
         double* orow = A.out + c * A.nk;
         const double* prow = A.pk + c * A.nk;
-#pragma unroll CP_RS_EVAL_UNROLL
+#pragma unroll
         for (int t = 0; t < S; ++t) {
             const int q = lane + 64 * t;
             if (q >= n) continue;
@@ -616,7 +620,6 @@ int launch_resample_as(const ResampleArgs& A, size_t lds, int ncu, void* stream)
 template <bool PEAKS>
 int launch_resample(ResampleArgs& A, const char* who, int device, void* stream) {
     const int n = A.n;
-    A.S = (n + 63) / 64;
     int ncu = 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256;
     // per wave Y and M, per workgroup the queries, ratio_now_fid, correction -- and the operator's columns where twelve waves' arrays leave room for them
@@ -629,7 +632,7 @@ int launch_resample(ResampleArgs& A, const char* who, int device, void* stream) 
         if constexpr (PEAKS) st = oplds ? launch_resample_as<S, true, true>(A, lds, ncu, stream) : launch_resample_as<S, true, false>(A, lds, ncu, stream);
         else st = launch_resample_as<S, false, false>(A, lds, ncu, stream);
     };
-    switch (A.S) {
+    switch ((n + 63) / 64) {      // samples per lane
         case 3: go(std::integral_constant<int, 3>{}); break;
         case 4: go(std::integral_constant<int, 4>{}); break;
         case 5: go(std::integral_constant<int, 5>{}); break;
