@@ -391,6 +391,14 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
     if (OPLDS)
         for (int j = threadIdx.x; j < A.np * n; j += 64 * W) OP[j] = A.op[j];
     __syncthreads();
+    // what the solve rests on: log10(k_fid) uniformly spaced (k_fid a range of a geometric grid).  Anything else: NaN over the k_fid range of every row
+    // (the three-kernel route takes any knots)
+    int crooked = 0;
+    {
+        const double x0 = XQ[0], step_x = (XQ[n - 1] - XQ[0]) / (n - 1);
+        for (int j = threadIdx.x; j < n; j += 64 * W) crooked |= !(fabs(XQ[j] - fma((double)j, step_x, x0)) <= 1e-9 * fabs(step_x));
+    }
+    crooked = __syncthreads_or(crooked);
     constexpr double LOG10E = 0.43429448190325182765;
     constexpr int REACH = (32 + S) / S;      // REACH x S >= 33 knots: p^33 = 1e-19
     constexpr double PS = rs_ipow(RS_P, S);
@@ -595,6 +603,7 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
                     v = fma(a, Y[j], b * Y[j + 1]) + RS_KAPPA * (ratio * ratio) * (fma(a * a, a, -a) * M[j] + fma(b * b, b, -b) * M[j + 1]);
                 }
             }
+            if (crooked) v = __builtin_nan("");
             orow[A.first + q] = fabs(v) < 300. ? cpmath::exp10_tab(v, mt.exp2) : cpmath::exp10_mid(v);      // (NaN and what leaves the doubles: the branch-free general form)
         }
         for (int k = lane; k < A.first; k += 64) orow[k] = prow[k];

@@ -454,7 +454,8 @@ int cp_brieden_finish(const double* d_pk, const double* d_resampled, double* d_o
 /* The three steps above as one kernel, a wave per cosmology (no knot-major arrays, no scratch): d_out (nb, nk) = d_pk with the columns [first, first + n)
  * replaced by 10^(natural cubic spline through (log10(k_fid / rescale[c]), log10(envelope pknow ratio_now_fid)) and the two extrapolated knots of _pad_log on
  * either side, evaluated at d_log_k_fid = log10(k_fid)) (bao_filter.py:500-509).  k_fid must be a geometric grid (it is a range of the filter's geomspace):
- * the spline's system then has constant coefficients.  129 <= n <= 512; CP_EUNSUPPORTED otherwise (the three calls then). */
+ * the spline's system then has constant coefficients; for a d_log_k_fid that is not uniformly spaced to 1e-9 of its step the kernel writes NaN over
+ * the range instead of a wrong spline).  129 <= n <= 512; CP_EUNSUPPORTED otherwise (the three calls then). */
 int cp_brieden_resample(const double* d_envelope, const double* d_pknow, const double* d_ratio_now_fid, const double* d_k_fid, const double* d_log_k_fid,
                         const double* d_rescale, double extrap_kmin, double extrap_kmax, const double* d_pk, double* d_out, long long nb, int n, int nk,
                         int first, int device, void* stream);
