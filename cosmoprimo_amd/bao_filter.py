@@ -377,6 +377,21 @@ def _wiggle_extrema(residual, start):
     return found
 
 
+def _envelope_operator(k_fid, peaks):
+    """
+    The mean of the quadratic ``interp1d`` through the maxima and through the minima (reference bao_filter.py:482-488) as a matrix acting on the
+    samples at ``k_fid``: (n, n), zero but for the columns of the extrema; those columns (ascending positions in ``k_fid``) and the operator
+    restricted to them, one row per extremum, (len(columns), n).
+    """
+    n = k_fid.size
+    M = np.zeros((n, n))
+    for ix in peaks:
+        ix = np.asarray(ix) % n
+        M[:, ix] += 0.5 * _quadratic_interp_operator(k_fid[ix], k_fid)
+    columns = np.unique(np.concatenate([np.asarray(ix) % n for ix in peaks]))
+    return M, columns, np.ascontiguousarray(M[:, columns].T)
+
+
 class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     """
@@ -414,15 +429,9 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     def _set_envelope_operator(self):
         """``_interp`` (reference bao_filter.py:482-488) is linear in y for fixed peak indices: one dense (341 x 341) operator."""
-        n = self.k_fid.size
-        M = np.zeros((n, n))
-        for ix in self.ik_fid_peaks:
-            ix = np.asarray(ix) % n
-            M[:, ix] += 0.5 * _quadratic_interp_operator(self.k_fid[ix], self.k_fid)
+        M, columns, rows = _envelope_operator(self.k_fid, self.ik_fid_peaks)
         self._envelope = LinearOperator.dense(M, device=self.device)
-        # the columns that are not zero -- the extrema -- and the operator restricted to them, (np, n): what a batch is run with (cp_brieden_smooth)
-        columns = np.flatnonzero(np.any(M != 0., axis=0))
-        self._envelope_columns = (columns, np.ascontiguousarray(M[:, columns].T))
+        self._envelope_columns = (columns, rows)      # what a batch is run with (cp_brieden_smooth)
         self.ratio_now_fid = M.dot(self.ratio_fid)
 
     def _compute(self):
