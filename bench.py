@@ -189,9 +189,9 @@ CONFIG4_ALGORITHMIC = {
     # half a complex transform of 4096 points per row); clamped splines through 2 x 2048 coefficients and through the 3666 spliced knots, two sweeps
     # each, and the 1024 evaluations of the latter
     'wallish2018': ((4096 + 1024) * _EH98 + 2 * 0.5 * 2.5 * 4096 * 12 + 2 * 3 * (4096 + 3666) + 8 * 1024) / 64.,
-    # sigma8 normalisation of both engines (1024 each), EH98 at k_fid / r at the 23 extrema of the fiducial wiggles (all the envelope depends on; rounds 2-4
-    # up to cp_brieden_smooth counted -- and evaluated -- it at the 341 wavenumbers of k_fid, twice), the no-wiggle template at k_fid r (341); the envelope
-    # operator's 23 columns; the per-cosmology spline through 345 knots, its evaluation and 10^x at 341 wavenumbers, 1024 values written
+    # sigma8 normalisation of both engines (1024 each), EH98 at k_fid / r at the 23 extrema of the fiducial wiggles (all the envelope depends on; up to
+    # cp_brieden_smooth it was evaluated at the 341 wavenumbers of k_fid, and this count carried 2 x 341), the no-wiggle template at k_fid r (341); the
+    # envelope operator's 23 columns; the per-cosmology spline through 345 knots, its evaluation and 10^x at 341 wavenumbers, 1024 values written
     'brieden2022': ((1024 + 23) * _EH98 + (1024 + 341) * _NOWIGGLE + 23 * 341 + 2 * 3 * 345 + 30 * 341 + 1024) / 64.,
 }
 
