@@ -434,6 +434,25 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
     };
     request(c);
     for (; c < A.nb; c += step) {
+        // the rest of the row as it is, eight loads in flight per lane: a load and its store one after the other -- what the loop `out[k] = pk[k]` compiles to,
+        // the two arrays possibly being one -- was eleven memory round trips in a row per cosmology (0.435 -> 0.364 ms per 65 536; both pieces of the row
+        // requested together 0.38, the next row's pieces requested an iteration ahead at two waves per SIMD 0.42: profiles/r4_kernel_experiments.txt)
+        {
+            double* orow = A.out + c * A.nk;
+            const double* prow = A.pk + c * A.nk;
+            auto copy = [&](int lo, int hi) {
+                for (int k0 = lo + lane; k0 < hi; k0 += 64 * 8) {
+                    double v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = k0 + 64 * i < hi ? prow[k0 + 64 * i] : 0.;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (k0 + 64 * i < hi) orow[k0 + 64 * i] = v[i];
+                }
+            };
+            copy(0, A.first);
+            copy(A.first + n, A.nk);
+        }
         // the geometry of this cosmology's knots (wave-uniform): the uniform stretch x_first + i h, the two knots of _pad_log on either side (interpolator.py:42-87)
         // (kept in scalar registers: some twenty values that live through the whole iteration)
         const double lr = lg10(r);
@@ -572,7 +591,6 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
         cp::wave_lds_phase();
         // ---- evaluation at log10(k_fid), 10^x into the k_fid range of the row; the rest of the row as it is ----
         double* orow = A.out + c * A.nk;
-        const double* prow = A.pk + c * A.nk;
 #pragma unroll
         for (int t = 0; t < S; ++t) {
             const int q = lane + 64 * t;
@@ -606,8 +624,6 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
             if (crooked) v = __builtin_nan("");
             orow[A.first + q] = fabs(v) < 300. ? cpmath::exp10_tab(v, mt.exp2) : cpmath::exp10_mid(v);      // (NaN and what leaves the doubles: the branch-free general form)
         }
-        for (int k = lane; k < A.first; k += 64) orow[k] = prow[k];
-        for (int k = A.first + n + lane; k < A.nk; k += 64) orow[k] = prow[k];
         cp::wave_lds_phase();      // last reads before the next cosmology's samples are staged
     }
 }
