@@ -179,11 +179,11 @@ def config3b(cp, torch, dev, ncosmo=10000, reps=5):
 
 
 # Vector instructions one P(k) vector NEEDS, whatever the implementation (wave-instructions = lane operations / 64): the evaluations of the fit formulae
-# (EH98 ~250 vector instructions per wavenumber, its no-wiggle form ~115, with the table-driven logarithm / exponential and the tabulated powers of k of
-# round 4 -- rounds 2-3: 390 and 150 with polynomial forms throughout: SQ_INSTS_VALU of sigma8_normalise_kernel per sample net of its per-cosmology
+# (EH98 ~250 vector instructions per wavenumber, its no-wiggle form ~95, with the table-driven logarithm / exponential, the tabulated powers of k and, for
+# the no-wiggle form, reciprocals in place of its four divisions (115 before) of round 4 -- rounds 2-3: 390 and 150 with polynomial forms throughout: SQ_INSTS_VALU of sigma8_normalise_kernel per sample net of its per-cosmology
 # part, profiles/*_config4_valu.json) and the transforms / solves (a radix-2 FFT count, 5 N log2 N flops per complex transform = N log2 N x 2.5
 # multiply-adds; three multiply-adds per knot and sweep for a tridiagonal system).
-_EH98, _NOWIGGLE = 250, 115
+_EH98, _NOWIGGLE = 250, 95
 CONFIG4_ALGORITHMIC = {
     # 4096 wavenumbers of the linear grid + the 1024 of the sigma8 normalisation (the filter's own k); forward and inverse DST of 4096 samples (each
     # half a complex transform of 4096 points per row); clamped splines through 2 x 2048 coefficients and through the 3666 spliced knots, two sweeps
