@@ -416,7 +416,8 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
     double e[PEAKS ? 1 : S], pn[S], r = 1., g0 = 1., now_peak = 1.;
     // (PEAKS) what lane p < np divides by besides pknow, where its extremum is
     const int peak = PEAKS && lane < A.np ? A.peaks[lane] : 0;
-    const double corr_peak = PEAKS ? A.correction[peak] : 1., fid_peak = PEAKS ? A.ratio_fid[peak] : 1.;
+    const double corr_peak = PEAKS ? A.correction[peak] : 1., inv_fid_peak = PEAKS ? 1. / A.ratio_fid[peak] : 1.;
+    const double inv_nm1 = 1. / (n - 1);
     auto request = [&](long long cc) {
         if (cc >= A.nb) return;
         r = A.rescale[cc];
@@ -457,12 +458,14 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
         // (kept in scalar registers: some twenty values that live through the whole iteration)
         const double lr = lg10(r);
         const double x_first = cp::wave_uniform(lkf0 - lr), x_last = cp::wave_uniform(lkf1 - lr);
-        const double h = cp::wave_uniform((x_last - x_first) / (n - 1)), inv_h = cp::wave_uniform(1. / h);
-        const double lmin = lg10(fmin(A.kmin, kf0 / r * (1 - 1e-9))), lmax = lg10(fmax(A.kmax, kf1 / r * (1 + 1e-9)));
+        // (quotients as reciprocals, cp_math.h: a dozen IEEE divisions per cosmology were a sixth of the instructions of the kernel)
+        const double h = cp::wave_uniform((x_last - x_first) * inv_nm1), inv_h = cp::wave_uniform(cpmath::recip(h));
+        const double inv_r = cpmath::recip(r);
+        const double lmin = lg10(fmin(A.kmin, kf0 * inv_r * (1 - 1e-9))), lmax = lg10(fmax(A.kmax, kf1 * inv_r * (1 + 1e-9)));
         const double xa = cp::wave_uniform(lmin), xb = cp::wave_uniform(x_first * 0.1 + lmin * 0.9), xc = cp::wave_uniform(x_last * 0.1 + lmax * 0.9), xd = cp::wave_uniform(lmax);
         // ---- the samples, read where they are; the next cosmology's requested ----
         if (PEAKS) {
-            const double ratio = e[0] / (now_peak * g0 * corr_peak) / fid_peak;      // (bao_filter.py:493-499, at the lane's extremum)
+            const double ratio = e[0] * cpmath::recip(now_peak * g0 * corr_peak) * inv_fid_peak;      // P / pknow / ratio_fid (bao_filter.py:493-499), at the lane's extremum
             double env[S];
 #pragma unroll
             for (int t = 0; t < S; ++t) env[t] = 0.;
@@ -561,8 +564,8 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
         }
         const double m0 = cp::lane_value(g[0], 0), m1 = cp::lane_value(g[1], 0), mn1 = cp::lane_value(g_last, l_last), mn2 = cp::lane_value(g_prev, l_prev);
         auto amplitude = [&](double ha, double H, double ma, double mb) {
-            const double alpha = 2. * (H + h) - H * H / (2. * (ha + H));
-            return -(alpha * ma + h * mb) / (alpha + h * RS_P);
+            const double alpha = 2. * (H + h) - H * H * cpmath::recip(2. * (ha + H));
+            return -(alpha * ma + h * mb) * cpmath::recip(alpha + h * RS_P);
         };
         const double Hl = x_first - xb, Hr = xc - x_last;
         const double Aamp = amplitude(xb - xa, Hl, m0, m1), Bamp = amplitude(xd - xc, Hr, mn1, mn2);
@@ -585,8 +588,8 @@ __global__ __launch_bounds__(OPLDS ? 768 : 256, OPLDS ? 1 : CP_RS_WAVES) void br
                 if (own + t < n) M[2 + own + t] = g[t];
         }
         if (lane == 0) {      // (M[2] is this lane's; M[n + 1] = the last knot's: recursion + the two corrections there)
-            M[1] = -Hl * g[0] / (2. * ((xb - xa) + Hl));
-            M[n + 2] = -Hr * (mn1 + Bamp) / (2. * ((xd - xc) + Hr));
+            M[1] = -Hl * g[0] * cpmath::recip(2. * ((xb - xa) + Hl));
+            M[n + 2] = -Hr * (mn1 + Bamp) * cpmath::recip(2. * ((xd - xc) + Hr));
         }
         cp::wave_lds_phase();
         // ---- evaluation at log10(k_fid), 10^x into the k_fid range of the row; the rest of the row as it is ----
