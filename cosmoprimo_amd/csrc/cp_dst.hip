@@ -333,8 +333,8 @@ __device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int
     EhScalars s{};
     if (ENGINE != CP_ENGINE_BBKS) s = G.scal[ic];
     const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw);
-    const double ln_pk_unit = log(pc.pk_unit);
+    const PkPerCosmology pc = pk_per_cosmology(c, pw, mt);
+    const double ln_pk_unit = CP_MATH_TABLES_OFF ? log(pc.pk_unit) : log_tab_any(pc.pk_unit, mt);
     // CP_DST_GEN_ILP samples per iteration: independent chains of logarithms / exponentials / reciprocals for the two waves of a SIMD to interleave
 #pragma unroll 1
     for (int r0 = 0; r0 < P; r0 += CP_DST_GEN_ILP) {

@@ -58,7 +58,8 @@ template <int ENGINE>   // one instance per engine: the registers of a launch ar
 __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 waves per SIMD (168 registers): 0.204 ms per 10 000 x 1024 EH98 spectra against 0.23 at 2 waves and 0.29 at 4 (spills)
     __shared__ double sh_g2[256];
     __shared__ MathTables mt;
-    fill_math_tables(&mt);      // (the barrier in front of the loop over wavenumbers covers it)
+    fill_math_tables(&mt);
+    __syncthreads();      // (the per-cosmology part below takes its logarithms from the tables)
     const int tid = threadIdx.x, bs = blockDim.x;      // 256 threads, or ONE wave per cosmology for large batches (cp_power_eval: the per-cosmology part of a thread -- parameters, constants of the fit, ~150 instructions -- is then paid by 64 lanes instead of 256)
     const long long ic = blockIdx.x / A.kchunks;
     const long long k0 = (long long)(blockIdx.x % A.kchunks) * A.kspan;
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
     const bool with_z = A.what == CP_PK_MATTER && A.nz > 0;
     const long long nzs = with_z ? A.nz : 1;
     const double kfac = A.kscale ? A.kscale[ic] : 1.;
-    const PkPerCosmology pc = pk_per_cosmology(c, pw);
-    const double ln_pk_unit = A.what == CP_PK_LOG_K_MATTER ? log(pc.pk_unit) : 0.;
+    const PkPerCosmology pc = pk_per_cosmology(c, pw, &mt);
+    const double ln_pk_unit = A.what == CP_PK_LOG_K_MATTER ? (CP_MATH_TABLES_OFF ? log(pc.pk_unit) : log_tab_any(pc.pk_unit, &mt)) : 0.;
     for (long long z0 = 0; z0 < nzs; z0 += bs) {
         if (z0) __syncthreads();  // the previous block of redshifts has been written
         if (with_z && z0 + tid < A.nz) {

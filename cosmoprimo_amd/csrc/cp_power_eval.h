@@ -77,9 +77,9 @@ struct EhPerCosmology {
 
 __device__ __forceinline__ EhPerCosmology eh_per_cosmology(const EhScalars& s, double h) {
     EhPerCosmology d;
-    d.q_per_kh = h / (13.41 * s.k_eq);
+    d.q_per_kh = h * recip(13.41 * s.k_eq);
     d.ks_per_kh = h * s.rs_drag;
-    d.c_alpha0 = 14.2 / s.alpha_c;
+    d.c_alpha0 = 14.2 * recip(s.alpha_c);
     d.beta18 = 1.8 * s.beta_c;
     d.beta_node3 = s.beta_node * s.beta_node * s.beta_node;
     d.beta_b3 = s.beta_b * s.beta_b * s.beta_b;
@@ -182,16 +182,23 @@ struct PkPerCosmology {
     double n_s, alpha_s, beta_s, ln_kp, pk_unit, h3_A_s;
 };
 
-__device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const double* pw) {
+// mt: the kernel's tables for the short logarithm (cp_math.h) -- every thread of a kernel goes through this once per cosmology, and with the library's
+// logarithm and IEEE divisions that was 6 % of the instructions of the transform that generates its own spectra (two cosmologies x 32 samples per thread)
+__device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const double* pw, const MathTables* mt = nullptr) {
     PkPerCosmology p;
     const double A_s = pw[CP_PK_A_S];
     p.n_s = pw[CP_PK_N_S];
     p.alpha_s = pw[CP_PK_ALPHA_S];
     p.beta_s = pw[CP_PK_BETA_S];
-    p.ln_kp = log(pw[CP_PK_K_PIVOT] / c.h);
     const double Omega0_m = c.Omega_b + c.Omega_cdm + 0. - 0.;  // cosmology.py:381
-    const double p2d_unit = 3. * Omega0_m * (100. * 100.) / (2. * (kCkms * kCkms));
-    p.pk_unit = 9. / 25. * 2. * (kPi * kPi) / (p2d_unit * p2d_unit) * A_s;
+    const double p2d_unit = 3. * Omega0_m * (100. * 100.) * (1. / (2. * (kCkms * kCkms)));
+    if (mt && !CP_MATH_TABLES_OFF) {
+        p.ln_kp = log_tab_any(pw[CP_PK_K_PIVOT] * recip(c.h), mt);
+        p.pk_unit = 9. / 25. * 2. * (kPi * kPi) * recip(p2d_unit * p2d_unit) * A_s;
+    } else {
+        p.ln_kp = log(pw[CP_PK_K_PIVOT] / c.h);
+        p.pk_unit = 9. / 25. * 2. * (kPi * kPi) / (p2d_unit * p2d_unit) * A_s;
+    }
     p.h3_A_s = (c.h * c.h * c.h) * A_s;
     return p;
 }

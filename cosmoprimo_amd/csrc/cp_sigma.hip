@@ -97,7 +97,7 @@ __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long 
     EhScalars s{};
     if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
     const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw);
+    const PkPerCosmology pc = pk_per_cosmology(c, pw, mt);
     double kh = kh0, ln_kh = ln0, kh108 = pw0.x, kh14 = pw0.y;
     // CP_SIGMA_ILP samples per iteration: independent chains of logarithms / exponentials / reciprocals for the two waves of a SIMD to interleave
 #pragma unroll 1
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
     EhScalars s{};
     if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
     const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw);
+    const PkPerCosmology pc = pk_per_cosmology(c, pw, &mt);
     double acc = 0.;
     __shared__ double kept[4 * PER_LANE * 64];
     double* pks = kept + (threadIdx.x >> 6) * (PER_LANE * 64) + lane;      // sample i of this lane at pks[64 i]
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
     EhScalars s{};
     if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
     const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw);
+    const PkPerCosmology pc = pk_per_cosmology(c, pw, &mt);
     double acc[FUNCTIONAL_MAX_NQ];
 #pragma unroll
     for (int q = 0; q < FUNCTIONAL_MAX_NQ; ++q) acc[q] = 0.;
