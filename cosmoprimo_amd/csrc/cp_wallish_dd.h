@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "cp_internal.h"
+#include "cp_math.h"
 
 namespace cpdd {
 
@@ -370,7 +371,7 @@ __device__ __forceinline__ bool remove_box_parallel(const double* ybuf, const do
     static_assert(DD_GAP_WINDOW == 64, "a knot of either window per lane");
     if (a < 1 || b > N - 2 || b < a) return false;
     const int L = a - 1, R = b + 1;
-    const double g = (double)(R - L);
+    const double g = (double)(R - L), inv_g = cpmath::recip(g);      // (the quotients below as reciprocals: thirteen IEEE divisions in a row per sequence were a quarter of the kernel's vector instructions, all of them in one dependent chain)
     const int i0 = L - DD_GAP_WINDOW > 0 ? L - DD_GAP_WINDOW : 0, i1 = R + DD_GAP_WINDOW < N - 1 ? R + DD_GAP_WINDOW : N - 1;
     auto z = [&](int i) {
         const double x = (double)(i + 1);
@@ -405,29 +406,29 @@ __device__ __forceinline__ bool remove_box_parallel(const double* ybuf, const do
     if (L != i0) {
         dpL = fma(al, dpL, bl);
         const double cp = nl > 0 ? gtab[nl < DD_NTAB ? nl : DD_NTAB - 1] : 0.;
-        const double d = 3. * (g * (z(L) - z(L - 1)) + (z(R) - z(L)) / g);
+        const double d = 3. * (g * (z(L) - z(L - 1)) + (z(R) - z(L)) * inv_g);
         const double den = 2. * (1. + g) - g * cp;
-        cpL = 1. / den;
-        dpL = (d - g * dpL) / den;
+        cpL = cpmath::recip(den);
+        dpL = (d - g * dpL) * cpL;
     }
     double bqR = 0., dqR = i1 == N - 1 ? 0. : 0.5 * (z(i1 + 1) - z(i1 - 1));
     if (R != i1) {
         dqR = fma(ar, dqR, br);
         const double bq = nr > 0 ? gtab[nr < DD_NTAB ? nr : DD_NTAB - 1] : 0.;
-        const double d = 3. * ((z(R) - z(L)) / g + g * (z(R + 1) - z(R)));
+        const double d = 3. * ((z(R) - z(L)) * inv_g + g * (z(R + 1) - z(R)));
         const double den = 2. * (g + 1.) - g * bq;
-        bqR = 1. / den;
-        dqR = (d - g * dqR) / den;
+        bqR = cpmath::recip(den);
+        dqR = (d - g * dqR) * bqR;
     }
-    const double sL = (dpL - cpL * dqR) / (1. - cpL * bqR);
+    const double sL = (dpL - cpL * dqR) * cpmath::recip(1. - cpL * bqR);
     const double sR = dqR - bqR * sL;
     const double zL = z(L), zR = z(R);
-    const double slope = (zR - zL) / g;
-    const double tt = (sL + sR - 2. * slope) / g;
-    const double c3 = tt / g, c2 = (slope - sL) / g - tt;
+    const double slope = (zR - zL) * inv_g;
+    const double tt = (sL + sR - 2. * slope) * inv_g;
+    const double c3 = tt * inv_g, c2 = (slope - sL) * inv_g - tt;
     for (int i = a + lane; i <= b; i += 64) {
         const double u = (double)(i - L), x = (double)(i + 1);
-        seq[i] = (zL + u * (sL + u * (c2 + u * c3))) / (x * x);
+        seq[i] = (zL + u * (sL + u * (c2 + u * c3))) * cpmath::recip(x * x);
     }
     return true;
 }
