@@ -89,6 +89,9 @@ __device__ __forceinline__ void dif_all(int t, const Args& A, cplx* x, cplx* lds
     __syncthreads();
 }
 
+#ifndef CP_DST_INVERSE_VIA_LDS      // inverse transform: 1 the rows are read once, in memory order, and handed to the threads through LDS; 0 every coefficient is read by
+#define CP_DST_INVERSE_VIA_LDS 1    // two threads (one an iteration ahead, one in place)
+#endif
 #ifndef CP_DST_ABLATE      // diagnostic builds of the inverse transform (wrong results): 1 no fused map, 2 no in-place loads of the second half, 4 no stores, 8 no transform
 #define CP_DST_ABLATE 0
 #endif
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
         const double* rb = 2 * p + 1 < A.nrows ? ra + N : ra;
 #pragma unroll
         for (int r = 0; r < P; ++r) {
-            const int ia = at_(N - 1 - (t + T * r));
+            // CP_DST_INVERSE_VIA_LDS: the rows as they lie in memory (every coefficient read ONCE; the threads pick what they need out of LDS)
+            const int ia = CP_DST_INVERSE_VIA_LDS ? t + T * r : at_(N - 1 - (t + T * r));
             na[r] = ra[ia];
             nb[r] = rb[ia];
         }
@@ -205,6 +209,13 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
             }
         } else {
             // Hermitian-symmetrised, conjugated spectrum of the pair; a row that is skipped does not take part
+            const double2* staged = reinterpret_cast<const double2*>(lds);      // (a, b) of the pair at their positions in memory (CP_DST_INVERSE_VIA_LDS)
+            if (CP_DST_INVERSE_VIA_LDS) {
+                double2* w = reinterpret_cast<double2*>(lds);
+#pragma unroll
+                for (int r = 0; r < P; ++r) w[tt + T * r] = double2{na[r], nb[r]};
+                __syncthreads();
+            }
             auto spectrum = [&](bool keep_a, bool keep_b, bool prefetched) {
 #pragma unroll
                 for (int r = 0; r < P; ++r) {
@@ -212,8 +223,15 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
                     const double fa = k == 0 ? fl : fn;                 // f_{N-1-k}
                     const double fb = (k == 0 || k == 1) ? (k == 0 ? fl : fn) : fn;   // f_{k-1} (k = 0 handled below)
                     const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-                    const double Aa = fa * (prefetched ? na[r] : ra[at(ia)]), Ab = fa * (prefetched ? nb[r] : rb[at(ia)]);
-                    const double Ba = (k == 0 ? fa : fb) * ((CP_DST_ABLATE & 2) ? na[r] : ra[at(ib)]), Bb = (k == 0 ? fa : fb) * ((CP_DST_ABLATE & 2) ? nb[r] : rb[at(ib)]);
+                    double Aa, Ab, Ba, Bb;
+                    if (CP_DST_INVERSE_VIA_LDS && prefetched) {
+                        const double2 va = staged[at(ia)], vb = staged[at(ib)];
+                        Aa = fa * va.x; Ab = fa * va.y;
+                        Ba = (k == 0 ? fa : fb) * vb.x; Bb = (k == 0 ? fa : fb) * vb.y;
+                    } else {
+                        Aa = fa * (prefetched ? na[r] : ra[at(ia)]); Ab = fa * (prefetched ? nb[r] : rb[at(ia)]);
+                        Ba = (k == 0 ? fa : fb) * ((CP_DST_ABLATE & 2) ? na[r] : ra[at(ib)]); Bb = (k == 0 ? fa : fb) * ((CP_DST_ABLATE & 2) ? nb[r] : rb[at(ib)]);
+                    }
                     const cplx rot = A.rot[k];
                     const double cs = rot.re, sn = -rot.im;
                     cplx Ha, Hb;
