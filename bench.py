@@ -226,6 +226,27 @@ def _config4_valu_roofline(engine, vectors_per_s, chunk):
     return out
 
 
+def _headline_valu_roofline(pmc, rows, kernel_ms, source):
+    """The second bound of the headline kernel: the vector instructions it executes per row (SQ_INSTS_VALU of the committed rocprofv3 --pmc pass of
+    this command) x the rows/s measured live, against the issue peak of the vector pipes (1024 SIMDs, one wave instruction per 4 cycles at the
+    nominal 2.4 GHz); and the clock the chip ran the profiled launches at (GRBM_GUI_ACTIVE is summed over the 8 XCDs)."""
+    counters = pmc.get('counters', {})
+    if 'SQ_INSTS_VALU' not in counters:
+        return None
+    peak = 256 * 4 * 2.4e9 / 4
+    per_row = counters['SQ_INSTS_VALU']['mean'] / pmc['rows_per_launch']
+    achieved = per_row * rows / (kernel_ms * 1e-3)
+    out = {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': achieved, 'peak': peak,
+           'unit': 'wave-instructions/s', 'frac': achieved / peak, 'valu_wave_instructions_per_row': per_row, 'source': source}
+    if pmc.get('effective_clock_GHz'):
+        clock = pmc['effective_clock_GHz'] * 1e9
+        out['effective_clock_GHz'] = clock / 1e9
+        out['frac_at_effective_clock'] = achieved / (256 * 4 * clock / 4)
+        if 'SQ_WAVE_CYCLES' in counters and 'SQ_BUSY_CYCLES' in counters:      # waves resident per SIMD while the shader engines are busy (32 SE-level busy counters, 1024 SIMDs)
+            out['waves_per_simd_while_busy'] = counters['SQ_WAVE_CYCLES']['mean'] / (counters['SQ_BUSY_CYCLES']['mean'] / 32 * 1024)
+    return out
+
+
 def config4(cp, torch, dev, par, chunk=CONFIG4_CHUNK, engines=('wallish2018', 'brieden2022'), spot_check=True):
     """wallish2018 and brieden2022 on EH98 P(k) vectors (nk = 1024) of the cosmologies ``par``, chunk by chunk (P(k) generation and sigma8
     normalisation included, results left on the device): per filter vectors/s, HBM fraction on 16 384 B per vector, HIP-event time.
@@ -621,10 +642,13 @@ def main():
         traffic, traffic_src = None, None
         import glob
         prof = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_summary.json')))
+        valu = None
         if prof and nb == ROWS_PER_GPU:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
             with open(prof[-1]) as fh:
-                traffic = json.load(fh)['hbm_bytes_per_launch']['total']
+                pmc = json.load(fh)
+            traffic = pmc['hbm_bytes_per_launch']['total']
             traffic_src = os.path.relpath(prof[-1], ROOT)
+            valu = _headline_valu_roofline(pmc, nb, kernel_ms, traffic_src)
         # the committed rocprofv3 --kernel-trace summary of this same command (scripts/gpu_profile.sh, scripts/summarize_steady.py): steady-state
         # dispatches only, next to the HIP-event time measured live above
         rocprof = None
@@ -644,6 +668,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic, 'traffic_source': traffic_src, 'kernel': 'fftlog_kernel<4096,16,IN_HALF_ZERO,OUT_HALF>', 'kernel_ms': kernel_ms,
                          'kernel_ms_bracketed_one_by_one': kernel_ms_each, 'kernel_ms_min': kernel_ms_min, 'rocprof_steady_state': rocprof, 'algorithmic_bytes_per_launch': BYTES_PER_ROW * nb},
+            'roofline_valu': valu,
             'parity_spot_check_tilted_err': err,
             'value_api': nb * world * args.steps / elapsed_api,   # same batch through cp.PowerToCorrelation.__call__ (resident tensors)
         }

@@ -195,5 +195,17 @@ def pack_params(names, params, defaults, device):
     return carr, ncosmo, keep
 
 
+def ncdm_arg(bg, ncosmo):
+    """The ``const cp_ncdm*`` argument for a background parameter block: ``bg['ncdm']`` (a :class:`cosmoprimo_amd.background.NcdmTables`, what
+    :meth:`BaseEngine.bg_params` adds for cosmologies with massive neutrinos) as (ctypes reference or None, the struct to keep alive)."""
+    ncdm = bg.get('ncdm', None) if bg else None
+    if ncdm is None or not ncdm.nspecies:
+        return None, None
+    if ncdm.ncosmo != ncosmo:
+        raise ValueError('massive-neutrino tables hold {:d} cosmologies, the parameters {:d}'.format(ncdm.ncosmo, ncosmo))
+    cn = ncdm.struct()
+    return ctypes.byref(cn), cn
+
+
 def as_void_p(carr):
     return ctypes.cast(carr, ctypes.c_void_p)

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcosmoprimo_amd.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 CP_OK, CP_EINVAL, CP_EUNSUPPORTED, CP_EDEVICE, CP_ENOMEM = range(5)
 EXTRAP_CONSTANT, EXTRAP_EDGE, EXTRAP_LOGLOG = range(3)
@@ -58,16 +58,17 @@ SIGNATURES = {
     'cp_background_eval': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_power_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong]),
-    'cp_power_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong,
-                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                    ctypes.c_void_p]),
+    'cp_power_eval': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_power_eval_variants': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_rfft_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int]),
     'cp_rfft_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_rfft_forward': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]),
     'cp_rfft_backward': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
-    'cp_eh_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'cp_eh_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p]),
     'cp_variants_scalars': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_sigma_rz_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
     'cp_sigma_rz_fused_available': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
@@ -77,12 +78,12 @@ SIGNATURES = {
     'cp_fftlog_geospline_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
                                                   ctypes.c_int, ctypes.c_void_p]),
     'cp_fftlog_spline_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
-    'cp_sigma_rz_analytic': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                           ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    'cp_sigma_rz_functional': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                             ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                             ctypes.c_int, ctypes.c_void_p]),
+    'cp_sigma_rz_analytic': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'cp_sigma_rz_functional': (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_spline_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'cp_linop_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, _c_double_p, ctypes.c_int]),
@@ -145,10 +146,11 @@ SIGNATURES = {
                                       ctypes.c_void_p]),
     'cp_dst_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_dst_forward_analytic_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong]),
-    'cp_dst_forward_analytic_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
-    'cp_dst_forward_analytic': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
-                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'cp_dst_forward_analytic_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+        ctypes.c_int, ctypes.c_void_p]),
+    'cp_dst_forward_analytic': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_spline_operator': (ctypes.c_int, [ctypes.c_int, _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_double_p,
                                          _c_int_p]),
 }
@@ -166,9 +168,9 @@ class cp_ncdm(ctypes.Structure):
 
 SIGNATURES['cp_ncdm_tables'] = (ctypes.c_int, [ctypes.c_longlong, ctypes.c_int, cp_param, cp_param, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                                _c_double_p, _c_double_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p])
-SIGNATURES['cp_sigma8_normalise'] = (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-                                                    ctypes.c_void_p, cp_param, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                                    ctypes.c_void_p])
+SIGNATURES['cp_sigma8_normalise'] = (ctypes.c_int, [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+        ctypes.c_void_p, ctypes.c_void_p, cp_param, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+        ctypes.c_int, ctypes.c_void_p])
 NCDM_NKNOTS = 119
 GROWTH_NKNOTS = 201
 

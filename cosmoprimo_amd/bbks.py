@@ -11,6 +11,8 @@ class BBKSEngine(EisensteinHuEngine):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
+        if self['N_ncdm']:      # bbks.py:24-31: these warnings are live in the reference
+            warnings.warn('{} cannot cope with massive neutrinos'.format(self.__class__.__name__))
         if self.batch_size is None:
             if self['Omega_k'] != 0.:
                 warnings.warn('{} cannot cope with non-zero curvature'.format(self.__class__.__name__))

@@ -542,8 +542,28 @@ class BaseCosmoParams(dv.Copyable):
         return None
 
     def bg_params(self):
-        """The background parameter block of the kernels."""
-        return {name: self._params[name] for name in _lib.BG_PARAMS}
+        """The background parameter block of the kernels; with massive neutrinos also their density / pressure tables, under 'ncdm'."""
+        bg = {name: self._params[name] for name in _lib.BG_PARAMS}
+        ncdm = self.ncdm_tables()
+        if ncdm is not None:
+            bg['ncdm'] = ncdm
+        return bg
+
+    def ncdm_tables(self):
+        """:class:`cosmoprimo_amd.background.NcdmTables` of the cosmology (the splines of density and pressure of every massive species the
+        reference's background builds, cosmology.py:1961-1998), None without species; built on the device once and shared by the sections and
+        engines of one cosmology."""
+        params = self._params
+        if not params.get('m_ncdm'):
+            return None
+        memo = self.__dict__.setdefault('_derived_memo', {})
+        if '_ncdm_tables' not in memo:
+            device = getattr(self, 'device', None)
+            if device is None:
+                device = dv.resolve_device(getattr(self, '_device', None), *[v for v in params.values() if not isinstance(v, (list, tuple))])
+            memo['_ncdm_tables'] = bgmod.NcdmTables(params['m_ncdm'], params['T_ncdm_over_cmb'], h=params['h'], T_cmb=params['T_cmb'],
+                                                    ncosmo=self.batch_size or 1, device=device)
+        return memo['_ncdm_tables']
 
 
 def bgmod_constants():
@@ -616,7 +636,7 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
         normalised amplitudes and the normalised spectra on the 1024 wavenumbers every sigma integral and every filter asks for next, left where
         :meth:`pk_params` and the Fourier section look for them.  False (nothing done) for anything else."""
         transfer = getattr(self, '_transfer', None)
-        if self.batch_size is None or transfer not in _lib.ENGINES or self._params.get('m_ncdm') or getattr(self.device, 'type', None) != 'cuda':
+        if self.batch_size is None or transfer not in _lib.ENGINES or getattr(self.device, 'type', None) != 'cuda':
             return False
         from .interpolator import sigma8_normalise
         res = sigma8_normalise(transfer, self.bg_params(), self.pk_params(rsigma8=1.), self['sigma8'], self.device)
@@ -628,20 +648,11 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
         self.__dict__['_pk0_normalised'] = ((k.shape, k.tobytes()), rsigma8, spectra)
         return True
 
-    def _any_mass(self):
-        masses = self['m_ncdm']
-        return any(bool((m > 0.).any()) if dv.is_torch(m) else bool(np.any(np.asarray(m) > 0.)) for m in (masses if isinstance(masses, (list, tuple)) else [masses]))
-
     def __getattr__(self, name):
         if name.startswith('get_'):
             section = name[4:]
             if section in self.__dict__.get('_Sections', {}):
                 def getter():
-                    # species of zero mass are radiation: nothing for the fits to cope with (the reference keeps them in N_ncdm as well, cosmology.py:1119-1121)
-                    if section != 'background' and self['N_ncdm'] and not getattr(self, '_copes_with_ncdm', False) and self._any_mass():
-                        raise NotImplementedError('with massive neutrinos only the background section is available on the MI355X path '
-                                                  '(these analytic engines "cannot cope with massive neutrinos" in the reference either: use '
-                                                  "engine='eisenstein_hu_nowiggle_variants')")
                     if section not in self._sections:
                         self._sections[section] = self._Sections[section](self)
                     return self._sections[section]
@@ -962,12 +973,9 @@ class BaseBackground(BaseSection):
         self._T0_cmb = engine['T_cmb']
         for name in ['cdm', 'b', 'k', 'g', 'ur', 'r', 'ncdm', 'pncdm', 'ncdm_tot', 'pncdm_tot', 'm', 'Lambda', 'fld', 'de']:
             setattr(self, '_Omega0_{}'.format(name), engine['Omega_{}'.format(name)])
-        self._bg = engine.bg_params()
+        self._bg = {name: engine._params[name] for name in _lib.BG_PARAMS}
         self._T0_ncdm = engine['T_ncdm']
-        self._ncdm = None
-        if self._N_ncdm:   # massive neutrinos: spline tables of density and pressure, built on the device once (cosmology.py:1961-1998)
-            self._ncdm = bgmod.NcdmTables(self._m_ncdm, engine['T_ncdm_over_cmb'], h=self._h, T_cmb=self._T0_cmb, ncosmo=engine.batch_size or 1,
-                                          device=self.device)
+        self._ncdm = engine.ncdm_tables()   # massive neutrinos: spline tables of density and pressure, built on the device once (cosmology.py:1961-1998)
 
     def __getattr__(self, name):
         # properties H0, h, Omega0_x, ... (reference utils.addproperty, cosmology.py:1627-1630)

@@ -725,7 +725,7 @@ extern "C" int cp_brieden_finish(const double* d_pk, const double* d_resampled, 
 
 extern "C" int cp_wallish_dd_box(const double* d_y, long long nrows, int n, int margin_first, int margin_second, int offset_first, int offset_second,
                                  int* d_box, double* d_dd, double* d_gap, int device, void* stream) {
-    if (nrows < 0 || margin_first < 0 || 2 * margin_first >= n) return cp::fail(CP_EINVAL, "cp_wallish_dd_box: bad sizes");
+    if (nrows < 0 || margin_first < 0 || 2 * margin_first >= n || margin_second < 0 || margin_second >= n) return cp::fail(CP_EINVAL, "cp_wallish_dd_box: bad sizes");
     if (n != 2048 && n != 1024) return cp::fail(CP_EUNSUPPORTED, "cp_wallish_dd_box: sequences of %d coefficients (built for 1024 and 2048)", n);
     if (nrows == 0) return CP_OK;
     if (!d_y || !d_box) return cp::fail(CP_EINVAL, "cp_wallish_dd_box: null device pointer");

@@ -4,6 +4,7 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_math.h"
+#include "cp_error.h"
 
 namespace cpcosmo {
 
@@ -31,6 +32,7 @@ struct Param {
 struct Cosmo {
     double h, Omega_cdm, Omega_b, Omega_k, T_cmb, N_ur, w0, wa;  // inputs
     double Omega_g, Omega_ur, Omega_de;                            // derived, cosmology.py:355-383
+    double Omega_nu_m;                                             // Omega_ncdm_tot - Omega_pncdm_tot today (0 without massive species): Omega0_m = Omega_b + Omega_cdm + this, cosmology.py:381
     // massive neutrinos: spline tables of this cosmology (nsp, 4, CP_NCDM_NKNOTS) + the shared knots; nsp == 0: none
     const double* ncdm_tab;
     const double* ncdm_knots;
@@ -87,6 +89,7 @@ __device__ __forceinline__ Cosmo load_cosmo(const Param* p, long long ic, int se
     c.ncdm_knots = ncdm_knots;
     c.ncdm_tab = nsp ? ncdm_tab + ic * (long long)nsp * 4 * CP_NCDM_NKNOTS : nullptr;
     double Omega_ncdm_tot = 0.;
+    c.Omega_nu_m = 0.;
     if (nsp) {  // z = 0 is the first knot: the tabulated values are the reference's _get_ncdm(z=0) (cosmology.py:371-376)
         double rho0 = 0., p0 = 0.;
         for (int s = 0; s < nsp; ++s) {
@@ -94,6 +97,7 @@ __device__ __forceinline__ Cosmo load_cosmo(const Param* p, long long ic, int se
             p0 = p0 + c.ncdm_tab[((long long)s * 4 + 2) * CP_NCDM_NKNOTS];
         }
         Omega_ncdm_tot = rho0 / kRhoCrit;
+        c.Omega_nu_m = rho0 / kRhoCrit - 3. * p0 / kRhoCrit;
         if (second_is_omega_m) c.Omega_cdm = c.Omega_cdm - (rho0 - 3 * p0) / kRhoCrit;  // cosmology.py:1163-1165
     }
     c.Omega_de = 1. - (c.Omega_cdm + c.Omega_b + c.Omega_g + c.Omega_ur + Omega_ncdm_tot + c.Omega_k);
@@ -157,5 +161,24 @@ __device__ __forceinline__ double growth_cpt(const Cosmo& c, double z) {
 
 // device copy of the CP_NCDM_NKNOTS massive-neutrino knots (cp_background.hip), nullptr on failure
 const double* ncdm_knots_device(int device);
+
+// the massive-neutrino tables of a call as the kernels take them (load_cosmo): nothing for ncdm == NULL or nspecies == 0.  Called with the
+// call's device current (the knots are allocated on it the first time).
+struct NcdmView {
+    const double* tab = nullptr;
+    const double* knots = nullptr;
+    int nsp = 0;
+};
+inline int ncdm_view(const cp_ncdm* ncdm, int device, const char* who, NcdmView* v) {
+    *v = NcdmView{};
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "%s: bad massive-neutrino tables", who);
+    if (!nsp) return CP_OK;
+    v->knots = ncdm_knots_device(device);
+    if (!v->knots) return cp::fail(CP_ENOMEM, "%s: cannot allocate the massive-neutrino knots on device %d", who, device);
+    v->tab = ncdm->tab;
+    v->nsp = nsp;
+    return CP_OK;
+}
 
 }  // namespace cpcosmo

@@ -310,13 +310,16 @@ __global__ __launch_bounds__(N / P, 2) void dst_kernel(const Args A) {
 // (16 N bytes of LDS / HBM traffic per row, memory bound) were two launches with 4096 doubles per vector written and read between them; here a
 // workgroup evaluates the 2 x 4096 samples of a pair of cosmologies straight into the transform's input (Makhoul order, (-1)^n folded in) and the
 // chip sees both kinds of work at once, as in the fused sigma(r, z) kernel (cp_sigma.hip).  The arithmetic of a sample is power_kernel's
-// CP_PK_LOG_K_MATTER (cp_power.hip), term by term, on the tabulated log k: the same bits.
+// CP_PK_LOG_K_MATTER (cp_power.hip), term by term, with k^1.08 and k^1.4 from tables next to log k (transfer_eh_powers) where power_kernel takes
+// exponentials of the tabulated logarithm: the two agree to rounding (3e-16), not bit for bit.
 struct GenArgs {
     Args dst;                        // out, tw, rot, split; in / kx / fused unused
     long long ncosmo;
     cpcosmo::Param bg[CP_BG_NPARAMS];
     cpcosmo::Param pw[CP_PK_NPARAMS];
     int second_is_omega_m;
+    const double* ncdm_tab;          // massive neutrinos (cp_ncdm.tab; nsp == 0: none): today's densities only -- Omega0_m of pk_callable, Omega_m of BBKS
+    int nsp;
     const double* k;                 // (N) wavenumbers, h/Mpc
     const double* ln_k;              // (N) their logarithms (log_pos, as power_kernel takes them)
     const cppower::EhScalars* scal;  // (ncosmo) fit coefficients (cp_power_coefficients), unused for BBKS
@@ -344,7 +347,7 @@ template <int N, int P, int ENGINE>
 __device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int t, double* slots, const cpmath::MathTables* mt) {
     using namespace cppower;
     constexpr int T = N / P;
-    const Cosmo c = load_cosmo(G.bg, ic, G.second_is_omega_m);
+    const Cosmo c = load_cosmo(G.bg, ic, G.second_is_omega_m, G.ncdm_tab, nullptr, G.nsp);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = G.pw[i].ptr ? G.pw[i].ptr[ic] : G.pw[i].value;
@@ -362,7 +365,7 @@ __device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int
             const int n = m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1;
             const double kh = G.k[n], ln_kh = G.ln_k[n];
             double Tk;
-            if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+            if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
             else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, G.ln_k[N + n], G.ln_k[2 * N + n], mt) : transfer_nowiggle(s, c.h, kh, mt);
             slots[2 * m] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(Tk)) : log_tab_any(fabs(Tk), mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
         }
@@ -617,26 +620,27 @@ void launch_generate(const GenArgs& G, int grid, hipStream_t stream) {
 
 extern "C" long long cp_dst_forward_analytic_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : cp_power_workspace_bytes(ncosmo) + 64; }
 
-static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                                double* d_out, void* d_work, int flags, int* d_box, int margin_first, int margin_second, int offset_first, int offset_second,
+static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                                const cp_param* pk_params, double* d_out, void* d_work, int flags, int* d_box, int margin_first, int margin_second, int offset_first, int offset_second,
                                 void* stream);
 
 extern "C" int cp_dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
-                                       const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream) {
-    return dst_forward_analytic(p, engine, ncosmo, bg_params, second_is_omega_m, pk_params, d_out, d_work, flags, nullptr, 0, 0, 0, 0, stream);
+                                       const cp_ncdm* ncdm, const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream) {
+    return dst_forward_analytic(p, engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_out, d_work, flags, nullptr, 0, 0, 0, 0, stream);
 }
 
 extern "C" int cp_dst_forward_analytic_box(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
-                                           const cp_param* pk_params, double* d_out, void* d_work, int* d_box, int margin_first, int margin_second,
+                                           const cp_ncdm* ncdm, const cp_param* pk_params, double* d_out, void* d_work, int* d_box, int margin_first, int margin_second,
                                            int offset_first, int offset_second, void* stream) {
     if (!d_box) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic_box: null box pointer");
-    if (margin_first < 0 || 2 * margin_first >= 2048) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic_box: bad margins");
-    return dst_forward_analytic(p, engine, ncosmo, bg_params, second_is_omega_m, pk_params, d_out, d_work, CP_DST_SPLIT, d_box, margin_first, margin_second,
+    if (margin_first < 0 || 2 * margin_first >= 2048 || margin_second < 0 || margin_second >= 2048)
+        return cp::fail(CP_EINVAL, "cp_dst_forward_analytic_box: bad margins");
+    return dst_forward_analytic(p, engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_out, d_work, CP_DST_SPLIT, d_box, margin_first, margin_second,
                                 offset_first, offset_second, stream);
 }
 
-static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                                double* d_out, void* d_work, int flags, int* d_box, int margin_first, int margin_second, int offset_first, int offset_second,
+static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                                const cp_param* pk_params, double* d_out, void* d_work, int flags, int* d_box, int margin_first, int margin_second, int offset_first, int offset_second,
                                 void* stream) {
     if (!p) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: null plan");
     if (flags & ~CP_DST_SPLIT) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: unknown flags %d", flags);
@@ -647,8 +651,10 @@ static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncos
     if (!bg_params || !pk_params || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, coef, p->device, stream);
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, p->device, stream);      // (validates the massive-neutrino tables)
     if (st != CP_OK) return st;
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: bad massive-neutrino tables");
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_dst_forward_analytic: cannot select device %d", p->device);
@@ -659,6 +665,8 @@ static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncos
     for (int i = 0; i < CP_BG_NPARAMS; ++i) G.bg[i] = cpcosmo::Param{bg_params[i].ptr, bg_params[i].value};
     for (int i = 0; i < CP_PK_NPARAMS; ++i) G.pw[i] = cpcosmo::Param{pk_params[i].ptr, pk_params[i].value};
     G.second_is_omega_m = second_is_omega_m;
+    G.ncdm_tab = nsp ? ncdm->tab : nullptr;
+    G.nsp = nsp;
     G.k = p->d_kx;
     G.ln_k = p->d_ln_kx;
     G.scal = reinterpret_cast<const cppower::EhScalars*>(coef);

@@ -16,7 +16,8 @@
 #include "cp_internal.h"
 
 extern "C" int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline);
-int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, const double* d_k,
+int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+                      const double* d_k,
                       const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz, double* d_out, double* d_pk_out,
                       void* d_coef, int device, void* stream);
 
@@ -63,7 +64,8 @@ extern "C" long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk) {
     return 2 * ncosmo * (long long)nk * (long long)sizeof(double) + cp_power_workspace_bytes(ncosmo) + 192 + 3 * (long long)nk * (long long)sizeof(double);      // ... + log k, k^1.08, k^1.4
 }
 
-extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                                    const cp_param* pk_params, int nk,
                                     const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
                                     double* d_out, double* d_pk_out, void* d_work, int nblocks, int device, void* stream) {
     if (ncosmo < 0 || nk <= 0 || nz <= 0) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic: bad sizes");
@@ -78,7 +80,7 @@ extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param
         if (cp_sigma_rz_fused_available(fftlog, spline)) {
             char* coef = static_cast<char*>(d_work);
             coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-            return cp_sigma_rz_fused(engine, ncosmo, bg_params, second_is_omega_m, pk_params, d_k, fftlog, spline, d_growth_sq, nz, d_out, d_pk_out, coef, device, stream);
+            return cp_sigma_rz_fused(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_k, fftlog, spline, d_growth_sq, nz, d_out, d_pk_out, coef, device, stream);
         }
         nblocks = 1;
     }
@@ -97,11 +99,17 @@ extern "C" int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param
             return cp::fail(CP_EDEVICE, "cp_sigma_rz_analytic: cannot order the second stream");
     }
     cp_param bg[CP_BG_NPARAMS], pk[CP_PK_NPARAMS];
+    const bool massive = ncdm && ncdm->nspecies > 0 && ncdm->tab;
     for (int i = 0; i < nblocks; ++i) {
         const long long first = ncosmo * i / nblocks, count = ncosmo * (i + 1) / nblocks - first;
         offset_params(bg_params, bg, CP_BG_NPARAMS, first);
         offset_params(pk_params, pk, CP_PK_NPARAMS, first);
-        st = cp_power_eval(engine, CP_PK_MATTER, count, bg, second_is_omega_m, pk, nk, d_k, nullptr, 0, nullptr, rows + first * nk,
+        cp_ncdm nu_block{};      // the tables of the block's cosmologies
+        if (massive) {
+            nu_block = *ncdm;
+            nu_block.tab = ncdm->tab + first * (long long)ncdm->nspecies * 4 * CP_NCDM_NKNOTS;
+        }
+        st = cp_power_eval(engine, CP_PK_MATTER, count, bg, second_is_omega_m, massive ? &nu_block : ncdm, pk, nk, d_k, nullptr, 0, nullptr, rows + first * nk,
                            coef + cp_power_workspace_bytes(first), device, main);
         if (st != CP_OK) return st;
         st = cp_fftlog_execute(fftlog, rows + first * nk, var + first * nk, count, CP_EXTRAP_CONSTANT, 0., CP_EXTRAP_CONSTANT, 0., 0, main);

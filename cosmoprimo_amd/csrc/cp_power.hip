@@ -38,6 +38,11 @@ struct Args {
     double* out;      // (ncosmo, max(nz, 1), nk)
     long long kchunks, kspan;  // a workgroup evaluates kspan consecutive k of ONE cosmology; kchunks = ceil(nk / kspan) workgroups per cosmology
     const EhScalars* scal;     // (ncosmo) fit coefficients from coefficients_kernel (EH98 / no-wiggle transfer), else unused
+    // massive neutrinos (cp_ncdm; nsp == 0: none).  The fits themselves know nothing of them (scalars from omega_cdm + omega_b, eisenstein_hu.py:37-38);
+    // they enter through the background: Omega0_m of pk_callable (:322), Omega_m(z) / Omega_de(z) of the CPT92 growth (:134-135), Omega_m of BBKS (bbks.py:38)
+    const double* ncdm_tab;
+    const double* ncdm_knots;
+    int nsp;
 };
 
 // The ~25 pow() of the EH98 / no-wiggle fit coefficients depend on the cosmology alone: one lane per cosmology here, read back by
@@ -46,7 +51,7 @@ struct Args {
 __global__ __launch_bounds__(64) void coefficients_kernel(const Args A, EhScalars* out) {
     const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= A.ncosmo) return;
-    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
     EhScalars s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
     s.growth0 = growth_cpt(c, 0.);
     out[ic] = s;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
     const long long ic = blockIdx.x / A.kchunks;
     const long long k0 = (long long)(blockIdx.x % A.kchunks) * A.kspan;
     const long long k1 = k0 + A.kspan < A.nk ? k0 + A.kspan : A.nk;
-    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
             double T = 1.;
             if (A.what != CP_PK_PRIMORDIAL) {
                 if (ENGINE == CP_ENGINE_BBKS)
-                    T = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+                    T = transfer_bbks(c, kh);
                 else
                     T = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, &mt) : transfer_nowiggle(s, c.h, kh, &mt);
             }
@@ -125,13 +130,15 @@ struct ScalArgs {
     long long ncosmo;
     Param bg[CP_BG_NPARAMS];
     int second_is_omega_m;
+    const double* ncdm_tab;
+    int nsp;
     double* out;  // (ncosmo, CP_EH_NSCALARS)
 };
 
 __global__ __launch_bounds__(256) void eh_scalars_kernel(const ScalArgs A) {
     const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= A.ncosmo) return;
-    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m);
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, nullptr, A.nsp);      // (today's densities only: no knots)
     const EhScalars s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, true);
     double* o = A.out + ic * CP_EH_NSCALARS;
     o[CP_EH_RS_DRAG] = s.rs_drag;
@@ -147,8 +154,7 @@ __global__ __launch_bounds__(256) void eh_scalars_kernel(const ScalArgs A) {
     o[CP_EH_BETA_NODE] = s.beta_node;
     o[CP_EH_BETA_B] = s.beta_b;
     o[CP_EH_ALPHA_GAMMA] = s.alpha_gamma;
-    const double Omega_m = c.Omega_b + c.Omega_cdm;
-    o[CP_EH_BBKS_GAMMA] = Omega_m * (c.h * c.h) * exp(-c.Omega_b * (1. + sqrt(2. * c.h) / Omega_m));
+    o[CP_EH_BBKS_GAMMA] = bbks_gamma(c);
 }
 
 // ---- eisenstein_hu_nowiggle_variants: Eisenstein & Hu 1997 with massive neutrinos (reference eisenstein_hu_nowiggle_variants.py) ----
@@ -333,7 +339,8 @@ int select_device(int device, int* prev) {
 
 extern "C" long long cp_power_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : (long long)sizeof(EhScalars) * ncosmo; }
 
-int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, void* d_work, int device, void* stream) {
+int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, void* d_work, int device,
+                          void* stream) {
     if (engine != CP_ENGINE_EH && engine != CP_ENGINE_EH_NOWIGGLE) return CP_OK;      // BBKS has no fit coefficients
     if (ncosmo <= 0) return CP_OK;
     if (!bg_params || !d_work) return cp::fail(CP_EINVAL, "cp_power_coefficients: null pointer");
@@ -345,6 +352,15 @@ int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_param
     for (int i = 0; i < CP_BG_NPARAMS; ++i) A.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
     A.second_is_omega_m = second_is_omega_m;
     A.engine = engine;
+    NcdmView nu;
+    st = ncdm_view(ncdm, device, "cp_power_coefficients", &nu);
+    if (st != CP_OK) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return st;
+    }
+    A.ncdm_tab = nu.tab;
+    A.ncdm_knots = nu.knots;
+    A.nsp = nu.nsp;
     hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), A, static_cast<EhScalars*>(d_work));
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
@@ -352,8 +368,8 @@ int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_param
     return CP_OK;
 }
 
-extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                             long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, void* d_work,
+extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                             const cp_param* pk_params, long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, void* d_work,
                              int device, void* stream) {
     if (engine < CP_ENGINE_EH || engine > CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_power_eval: unknown engine %d", engine);
     if (what < CP_PK_MATTER || what > CP_PK_LOG_K_MATTER) return cp::fail(CP_EINVAL, "cp_power_eval: unknown quantity %d", what);
@@ -378,6 +394,15 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     A.z = d_z;
     A.out = d_out;
     A.scal = nullptr;
+    NcdmView nu;
+    st = ncdm_view(ncdm, device, "cp_power_eval", &nu);
+    if (st != CP_OK) {
+        if (prev >= 0) (void)hipSetDevice(prev);
+        return st;
+    }
+    A.ncdm_tab = nu.tab;
+    A.ncdm_knots = nu.knots;
+    A.nsp = nu.nsp;
     // wavenumbers per workgroup: all of a cosmology's when the batch alone fills the chip (>= 8 workgroups per CU), fewer for small batches.  A batch
     // that fills the chip with one WAVE per cosmology (12 waves per CU) takes that shape: a thread's per-cosmology part is amortised over nk / 64
     // wavenumbers instead of nk / 256 (brieden2022 evaluates 341 per cosmology: 2 282 -> ~900 instructions per spectrum for the no-wiggle form)
@@ -487,10 +512,13 @@ extern "C" int cp_variants_scalars(long long ncosmo, const cp_param* bg_params, 
     return CP_OK;
 }
 
-extern "C" int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, double* d_out, int device, void* stream) {
+extern "C" int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, double* d_out, int device,
+                             void* stream) {
     if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_eh_scalars: negative size");
     if (ncosmo == 0) return CP_OK;
     if (!bg_params || !d_out) return cp::fail(CP_EINVAL, "cp_eh_scalars: null pointer");
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_eh_scalars: bad massive-neutrino tables");
     int prev;
     int st = select_device(device, &prev);
     if (st != CP_OK) return st;
@@ -498,6 +526,8 @@ extern "C" int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int se
     A.ncosmo = ncosmo;
     for (int i = 0; i < CP_BG_NPARAMS; ++i) A.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
     A.second_is_omega_m = second_is_omega_m;
+    A.ncdm_tab = nsp ? ncdm->tab : nullptr;
+    A.nsp = nsp;
     A.out = d_out;
     hipLaunchKernelGGL(eh_scalars_kernel, dim3((unsigned)((ncosmo + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), A);
     hipError_t e = hipGetLastError();

@@ -165,9 +165,15 @@ __device__ __forceinline__ double transfer_nowiggle(const EhScalars& s, double h
     return L0 * recip(L0 + C0 * (q * q));
 }
 
-__device__ __forceinline__ double transfer_bbks(double h, double Omega_cdm, double Omega_b, double kh) {  // bbks.py:34-38, 62-64
-    const double Omega_m = Omega_b + Omega_cdm;
-    const double gamma = Omega_m * (h * h) * exp(-Omega_b * (1. + sqrt(2. * h) / Omega_m));
+// bbks.py:38: gamma = omega_m exp(-Omega_b (1 + sqrt(2 h) / Omega_m)) with the cosmology's Omega_m, massive neutrinos included (cosmology.py:381)
+__device__ __forceinline__ double bbks_gamma(const Cosmo& c) {
+    const double Omega_m = c.Omega_b + c.Omega_cdm + c.Omega_nu_m;
+    return Omega_m * (c.h * c.h) * exp(-c.Omega_b * (1. + sqrt(2. * c.h) / Omega_m));
+}
+
+__device__ __forceinline__ double transfer_bbks(const Cosmo& cosmo, double kh) {  // bbks.py:34-38, 62-64
+    const double h = cosmo.h;
+    const double gamma = bbks_gamma(cosmo);
     const double q = kh * h / gamma;
     const double x = 2.34 * q;
     const double a = 16.2 * q, b = 5.47 * q, c = 6.71 * q;
@@ -190,7 +196,7 @@ __device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const
     p.n_s = pw[CP_PK_N_S];
     p.alpha_s = pw[CP_PK_ALPHA_S];
     p.beta_s = pw[CP_PK_BETA_S];
-    const double Omega0_m = c.Omega_b + c.Omega_cdm + 0. - 0.;  // cosmology.py:381
+    const double Omega0_m = c.Omega_b + c.Omega_cdm + c.Omega_nu_m;  // cosmology.py:381: + Omega_ncdm_tot - Omega_pncdm_tot (ba.Omega0_m of pk_callable, eisenstein_hu.py:322)
     const double p2d_unit = 3. * Omega0_m * (100. * 100.) * (1. / (2. * (kCkms * kCkms)));
     if (mt && !CP_MATH_TABLES_OFF) {
         p.ln_kp = log_tab_any(pw[CP_PK_K_PIVOT] * recip(c.h), mt);

@@ -52,6 +52,8 @@ struct SigmaArgs {
     Param bg[CP_BG_NPARAMS];
     Param pw[CP_PK_NPARAMS];
     int second_is_omega_m;
+    const double* ncdm_tab;       // massive neutrinos (cp_ncdm.tab; nsp == 0: none): today's densities only -- Omega0_m of pk_callable, Omega_m of BBKS
+    int nsp;
     const double* k;              // (n) wavenumbers of the transform, h/Mpc
     const double* ln_k;           // (n) their logarithms (log_wavenumbers_kernel)
     const EhScalars* scal;        // (ncosmo) fit coefficients (cp_power_coefficients), unused for BBKS
@@ -90,7 +92,7 @@ __device__ __forceinline__ void front_phases(int t, const FftlogArgs& A, bool ha
 template <int ENGINE, int T, int H>
 __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long ic, int t0, double kh0, double ln0, double ratio, double ln_ratio, double2 pw0,
                                                   double2 pw_ratio, double* slots, const MathTables* mt) {
-    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m);
+    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m, S.ncdm_tab, nullptr, S.nsp);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
@@ -106,7 +108,7 @@ __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long 
         for (int u = 0; u < CP_SIGMA_ILP; ++u) {
             const int j = t0 + T * (r0 + u);
             double Tk;
-            if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+            if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
             else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, kh108, kh14, mt) : transfer_nowiggle(s, c.h, kh, mt);
             slots[2 * j] = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, mt);
             kh *= ratio;
@@ -687,15 +689,19 @@ extern "C" int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const c
     return f.npad == NP && f.n == NP / 2 && f.nker == 1 && f.in_left == NP / 4 && f.out_left == NP / 4 && b.n == f.n && b.device == f.device;
 }
 
-int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, const double* d_k,
+int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+                      const double* d_k,
                       const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz, double* d_out, double* d_pk_out,
                       void* d_coef, int device, void* stream) {
     cp_fftlog_tables_view f;
     cp_spline_band_view b;
     if (!cp_fftlog_plan_view(fftlog, &f) || !cp_spline_plan_view(spline, &b)) return cp::fail(CP_EINVAL, "cp_sigma_rz_fused: plans without device tables");
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, d_coef, device, stream);
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, d_coef, device, stream);      // (validates the massive-neutrino tables)
     if (st != CP_OK) return st;
     SigmaArgs S{};
+    S.nsp = ncdm ? ncdm->nspecies : 0;
+    if (S.nsp < 0 || (S.nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_sigma_rz_fused: bad massive-neutrino tables");
+    S.ncdm_tab = S.nsp ? ncdm->tab : nullptr;
     FftlogArgs& A = S.fft;
     A.in = nullptr; A.out = nullptr; A.nbatch = ncosmo; A.nker = 1; A.n = f.n; A.in_left = f.in_left; A.out_off = f.out_left; A.n_out = f.n;
     A.ext_l = A.ext_r = CP_EXTRAP_CONST; A.val_l = A.val_r = 0.; A.stream_rows = 0;
@@ -755,6 +761,9 @@ struct FunctionalArgs {
     Param bg[CP_BG_NPARAMS];
     Param pw[CP_PK_NPARAMS];
     int second_is_omega_m;
+    const double* ncdm_tab;       // massive neutrinos (cp_ncdm.tab; nsp == 0: none), their knots for the growth factor at z = 0
+    const double* ncdm_knots;
+    int nsp;
     int nk, nq, nz;
     const double* k;              // (nk) wavenumbers, h/Mpc
     const double* ln_k;           // (nk) their logarithms (log_wavenumbers_kernel)
@@ -784,7 +793,7 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
     const int lane = threadIdx.x & 63;
     const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ic >= S.ncosmo) return;
-    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m);
+    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m, S.ncdm_tab, S.ncdm_knots, S.nsp);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
@@ -800,7 +809,7 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
         const int j = lane + 64 * i;
         const double kh = S.k[j], ln_kh = S.ln_k[j];
         double Tk;
-        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
         else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, S.ln_k[1024 + j], S.ln_k[2048 + j], &mt) : transfer_nowiggle(s, c.h, kh, &mt);
         const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         pks[64 * i] = pk;
@@ -830,7 +839,7 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
     const int lane = threadIdx.x & 63;
     const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ic >= S.ncosmo) return;
-    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m);
+    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m, S.ncdm_tab, S.ncdm_knots, S.nsp);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
     for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
@@ -845,7 +854,7 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
     for (int j = lane; j < S.nk; j += 64) {
         const double kh = S.k[j], ln_kh = S.ln_k[j];
         double Tk;
-        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c.h, c.Omega_cdm, c.Omega_b, kh);
+        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
         else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, S.ln_k[S.nk + j], S.ln_k[2 * S.nk + j], &mt) : transfer_nowiggle(s, c.h, kh, &mt);
         const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         if (S.pk_out) S.pk_out[ic * S.nk + j] = pk;
@@ -868,7 +877,8 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
 
 }  // namespace
 
-extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+        int nk,
                                       const double* d_k, const double* d_functional, int nq, const double* d_growth_sq, int nz, double* d_out,
                                       double* d_pk_out, void* d_work, int device, void* stream) {
     if (ncosmo < 0 || nk <= 0 || nz <= 0 || nq <= 0) return cp::fail(CP_EINVAL, "cp_sigma_rz_functional: bad sizes");
@@ -878,9 +888,21 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     if (!bg_params || !pk_params || !d_k || !d_functional || !d_growth_sq || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_sigma_rz_functional: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, coef, device, stream);
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, device, stream);
     if (st != CP_OK) return st;
     FunctionalArgs S{};
+    {
+        int prev_nu = -1;
+        if (hipGetDevice(&prev_nu) != hipSuccess) prev_nu = -1;
+        if (prev_nu != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cannot select device %d", device);
+        NcdmView nu;
+        st = ncdm_view(ncdm, device, "cp_sigma_rz_functional / cp_sigma8_normalise", &nu);
+        if (prev_nu >= 0 && prev_nu != device) (void)hipSetDevice(prev_nu);
+        if (st != CP_OK) return st;
+        S.ncdm_tab = nu.tab;
+        S.ncdm_knots = nu.knots;
+        S.nsp = nu.nsp;
+    }
     S.ncosmo = ncosmo;
     for (int i = 0; i < CP_BG_NPARAMS; ++i) S.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
     for (int i = 0; i < CP_PK_NPARAMS; ++i) S.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};
@@ -909,7 +931,8 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     return CP_OK;
 }
 
-extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+        int nk,
                                    const double* d_k, const double* d_functional, cp_param sigma8, double* d_rsigma8, double* d_amplitude, double* d_pk_out,
                                    void* d_work, int device, void* stream) {
     if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_sigma8_normalise: negative size");
@@ -919,9 +942,21 @@ extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param*
     if (!bg_params || !pk_params || !d_k || !d_functional || !d_rsigma8 || !d_work) return cp::fail(CP_EINVAL, "cp_sigma8_normalise: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, coef, device, stream);
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, device, stream);
     if (st != CP_OK) return st;
     FunctionalArgs S{};
+    {
+        int prev_nu = -1;
+        if (hipGetDevice(&prev_nu) != hipSuccess) prev_nu = -1;
+        if (prev_nu != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cannot select device %d", device);
+        NcdmView nu;
+        st = ncdm_view(ncdm, device, "cp_sigma_rz_functional / cp_sigma8_normalise", &nu);
+        if (prev_nu >= 0 && prev_nu != device) (void)hipSetDevice(prev_nu);
+        if (st != CP_OK) return st;
+        S.ncdm_tab = nu.tab;
+        S.ncdm_knots = nu.knots;
+        S.nsp = nu.nsp;
+    }
     S.ncosmo = ncosmo;
     for (int i = 0; i < CP_BG_NPARAMS; ++i) S.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
     for (int i = 0; i < CP_PK_NPARAMS; ++i) S.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};

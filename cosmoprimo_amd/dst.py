@@ -59,12 +59,13 @@ class DST(object):
         lib = _lib.load()
         out = torch.empty((ncosmo, self.n), dtype=torch.float64, device=self.device)
         work = torch.empty(int(lib.cp_dst_forward_analytic_workspace_bytes(ncosmo)), dtype=torch.uint8, device=self.device)
+        nu, keep_nu = dv.ncdm_arg(bg, ncosmo)
         if box is not None:
             boxes = torch.empty((2 * ncosmo, 2), dtype=torch.int32, device=self.device)
-            _lib.check(lib.cp_dst_forward_analytic_box(self._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), out.data_ptr(),
+            _lib.check(lib.cp_dst_forward_analytic_box(self._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), out.data_ptr(),
                                                        work.data_ptr(), boxes.data_ptr(), int(box[0]), int(box[1]), int(box[2]), int(box[3]), dv.stream_of(self.device)))
             return out, boxes
-        _lib.check(lib.cp_dst_forward_analytic(self._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), out.data_ptr(), work.data_ptr(),
+        _lib.check(lib.cp_dst_forward_analytic(self._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), out.data_ptr(), work.data_ptr(),
                                                2 if split else 0, dv.stream_of(self.device)))
         return out
 

@@ -3,7 +3,6 @@ Eisenstein & Hu 1998 engine on MI355X (reference cosmoprimo/eisenstein_hu.py): f
 primordial spectrum, P(k, z) and the sigma8 normalisation, all evaluated by the HIP kernels of ``cp_power.hip`` /
 ``cp_fftlog*.hip`` / ``cp_spline.hip`` for one cosmology or a batch.
 """
-import warnings
 
 import numpy as np
 
@@ -21,8 +20,8 @@ class EisensteinHuEngine(BaseEngine):
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        if self['N_ncdm']:
-            warnings.warn('{} cannot cope with massive neutrinos'.format(self.__class__.__name__))
+        # (no warning for massive neutrinos, curvature or a dark-energy fluid: the reference's are commented out, eisenstein_hu.py:24-32 -- the
+        # species enter through the background the sections read: Omega0_m, Omega_m(z), Omega_de(z))
         self.compute()
         self._A_s = self._get_A_s_fid()
 

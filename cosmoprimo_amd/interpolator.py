@@ -996,16 +996,17 @@ def sigma_rz_analytic(engine, bg, pk, r, growth_sq, device, kmin=1e-7, kmax=1e2,
     spectra = torch.empty((nb, nk), dtype=torch.float64, device=device) if keep_spectra else None
     work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(nb, nk)), dtype=torch.uint8, device=device)
     growth_sq = growth_sq.contiguous()
+    nu, keep_nu = dv.ncdm_arg(bg, nb)
     if 1 <= rr.size <= _FUNCTIONAL_RADII and blocks == 0:
         # few radii (sigma8: one): transform and spline are linear in P(k) -- sigma^2(r_q) = sum_j F[q, j] P(k_j), F = what the two return for unit
         # spectra, computed once per (grid, radii) -- and the kernel is the evaluation of P(k) with a dot product behind it
         functional = _cached_operator(('sigma_functional', key, rr.tobytes()),
                                       lambda: op(fft(torch.eye(nk, dtype=torch.float64, device=device))[1]).transpose(0, 1).contiguous())
-        _lib.check(lib.cp_sigma_rz_functional(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
+        _lib.check(lib.cp_sigma_rz_functional(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
                                               functional.data_ptr(), rr.size, growth_sq.data_ptr(), nz, out.data_ptr(),
                                               spectra.data_ptr() if keep_spectra else None, work.data_ptr(), device.index, dv.stream_of(device)))
         return out, spectra, k
-    _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
+    _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
                                         fft._get_plan(device).handle, op._handle, growth_sq.data_ptr(), nz, out.data_ptr(),
                                         spectra.data_ptr() if keep_spectra else None, work.data_ptr(), blocks, device.index, dv.stream_of(device)))
     return out, spectra, k
@@ -1047,7 +1048,8 @@ def sigma8_normalise(engine, bg, pk, sigma8, device, kmin=1e-7, kmax=1e2):
     amplitude = torch.empty(nb, dtype=torch.float64, device=device)
     spectra = torch.empty((nb, nk), dtype=torch.float64, device=device)
     work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(nb, nk)), dtype=torch.uint8, device=device)
-    _lib.check(lib.cp_sigma8_normalise(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
+    nu, keep_nu = dv.ncdm_arg(bg, nb)
+    _lib.check(lib.cp_sigma8_normalise(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
                                        functional.data_ptr(), target, rsigma8.data_ptr(), amplitude.data_ptr(), spectra.data_ptr(), work.data_ptr(),
                                        device.index, dv.stream_of(device)))
     return rsigma8, amplitude, spectra, k

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 2
+#define CP_ABI_VERSION 3
 
 enum cp_status {
     CP_OK = 0,
@@ -220,10 +220,15 @@ enum cp_pk_param { CP_PK_A_S = 0, CP_PK_N_S = 1, CP_PK_ALPHA_S = 2, CP_PK_BETA_S
  * (CP_PK_MATTER only).  d_out : (ncosmo, max(nz, 1), nk), k fastest, (Mpc/h)^3.
  * d_work : device workspace of cp_power_workspace_bytes(ncosmo) bytes for the fit coefficients of the cosmologies (EH98 / no-wiggle; unused
  * and may be NULL for CP_ENGINE_BBKS and CP_PK_PRIMORDIAL), owned by the caller and free again once the call's kernels have run on `stream`:
- * nothing is allocated inside the call. */
+ * nothing is allocated inside the call.
+ * ncdm (here and in every entry point below that takes one): the massive-neutrino tables of the same cosmologies (cp_ncdm_tables), NULL or nspecies == 0
+ * for none.  The fits themselves do not know massive neutrinos (their scalars use omega_cdm + omega_b, eisenstein_hu.py:37-38) and the reference computes
+ * with them all the same (its warnings are commented out, eisenstein_hu.py:21-33): the species enter through the background -- Omega0_m of pk_callable
+ * (eisenstein_hu.py:322 with cosmology.py:381), Omega_m(z) and Omega_de(z) of the CPT92 growth factor (eisenstein_hu.py:134-135 with cosmology.py:1704-1736),
+ * Omega_m / omega_m of the BBKS shape parameter (bbks.py:38), and Omega_cdm when the second background parameter is Omega_m (cosmology.py:1163-1165). */
 long long cp_power_workspace_bytes(long long ncosmo);
-int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params,
-                  long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, void* d_work,
+int cp_power_eval(int engine, int what, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                  const cp_param* pk_params, long long nk, const double* d_k, const double* d_kscale, long long nz, const double* d_z, double* d_out, void* d_work,
                   int device, void* stream);
 enum cp_eh_scalar {
     CP_EH_RS_DRAG = 0 /* Mpc */, CP_EH_Z_DRAG = 1, CP_EH_Z_EQ = 2, CP_EH_K_EQ = 3, CP_EH_R_DRAG = 4, CP_EH_R_EQ = 5, CP_EH_K_SILK = 6,
@@ -239,7 +244,7 @@ enum cp_eh_scalar {
 int cp_power_eval_variants(int what, int of, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
                            const cp_param* pk_params, long long nk, const double* d_k, long long nz, const double* d_z, double* d_out, int device,
                            void* stream);
-int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, double* d_out, int device, void* stream);
+int cp_eh_scalars(long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, double* d_out, int device, void* stream);
 /* the attributes of the eisenstein_hu_nowiggle_variants engine (EisensteinHuNoWiggleVariantsEngine._set_rsdrag / compute,
  * eisenstein_hu_nowiggle_variants.py:32-76) for a batch of cosmologies, by the device function the evaluation kernel itself uses.
  * ncdm as for cp_power_eval_variants.  d_out : (ncosmo, CP_VAR_NSCALARS). */
@@ -343,17 +348,20 @@ int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const cp_geospline
  * functional d_functional (1, nk) of r = 8 (what transform + spline return for unit spectra: cp_sigma_rz_functional) and the CPT92 growth factor
  * at z = 0; then d_rsigma8[c] = sigma8 / that, d_amplitude[c] = A_s rsigma8^2 (or NULL) and d_pk_out (ncosmo, nk) = the spectra WITHOUT growth at
  * the normalised amplitude (or NULL).  sigma8: one target for all (ptr NULL) or per cosmology.  nk = 1024; d_work as for cp_sigma_rz_functional. */
-int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+        int nk,
                         const double* d_k, const double* d_functional, cp_param sigma8, double* d_rsigma8, double* d_amplitude, double* d_pk_out,
                         void* d_work, int device, void* stream);
 long long cp_sigma_rz_workspace_bytes(long long ncosmo, int nk);
-int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+        int nk,
                          const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
                          double* d_out, double* d_pk_out, void* d_work, int nblocks, int device, void* stream);
 /* the same for at most 4 radii (the sigma8 normalisation: one) as a linear functional of the spectrum: d_functional (nq, nk) holds the rows F with
  * sigma^2(r_q) = sum_j F[q, j] P(k_j) -- what the caller's transform + spline return for unit spectra --, the kernel evaluates P(k) and the dot
  * products, one wave per cosmology, no transform.  d_work, d_pk_out as for cp_sigma_rz_analytic; d_out (ncosmo, nq, nz). */
-int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_param* pk_params, int nk,
+int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+        int nk,
                            const double* d_k, const double* d_functional, int nq, const double* d_growth_sq, int nz, double* d_out, double* d_pk_out,
                            void* d_work, int device, void* stream);
 
@@ -513,13 +521,13 @@ int cp_dst_plan_destroy(cp_dst_plan* plan);
  * d_work: cp_dst_forward_analytic_workspace_bytes(ncosmo) bytes, free again once the call's kernels have run on `stream`. */
 long long cp_dst_forward_analytic_workspace_bytes(long long ncosmo);
 int cp_dst_forward_analytic(const cp_dst_plan* plan, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
-                            const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream);
+                            const cp_ncdm* ncdm, const cp_param* pk_params, double* d_out, void* d_work, int flags, void* stream);
 /* The same with the NEXT step of wallish2018 in the kernel's epilogue (cp_wallish_dd_box with d_gap = d_y, bao_filter.py:373-405): the coefficients are
  * written de-interleaved (CP_DST_SPLIT: every row is its even-indexed sequence followed by its odd-indexed one, 2048 knots each), d_box (2 ncosmo, 2)
  * receives the box of every sequence, and the boxes are already rewritten in d_out -- the four sequences of a pair of cosmologies are solved by the
  * four waves of the workgroup that transformed them, without the (2 ncosmo, 2048) coefficients being read again. */
 int cp_dst_forward_analytic_box(const cp_dst_plan* plan, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
-                                const cp_param* pk_params, double* d_out, void* d_work, int* d_box, int margin_first, int margin_second,
+                                const cp_ncdm* ncdm, const cp_param* pk_params, double* d_out, void* d_work, int* d_box, int margin_first, int margin_second,
                                 int offset_first, int offset_second, void* stream);
 
 /* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----

@@ -17,7 +17,7 @@ from .framework_stubs import install_cosmosis_stub, install_cobaya_stub, DataBlo
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 COSMOSIS_OPTIONS = dict(zmin=0., zmax=2., nz=9, fourier=True, harmonic=False, engine='eisenstein_hu')
-COSMOSIS_PARAMS = {'A_s': 2.1e-9, 'n_s': 0.965, 'h0': 0.68, 'ombh2': 0.0224, 'omch2': 0.12, 'omega_k': 0., 'tau': 0.054, 'w': -0.95, 'wa': 0.1, 'mnu': 0.}
+COSMOSIS_PARAMS = {'A_s': 2.1e-9, 'n_s': 0.965, 'h0': 0.68, 'ombh2': 0.0224, 'omch2': 0.12, 'omega_k': 0., 'tau': 0.054, 'w': -0.95, 'wa': 0.1}      # no 'mnu': the adapter's default, 0.06 eV (cosmoprimo_interface.py:44)
 
 COBAYA_PARAMS = dict(H0=68., omega_b=0.0224, omega_cdm=0.12, A_s=2.1e-9, n_s=0.965, tau_reio=0.054)
 COBAYA_Z = np.array([0., 0.3, 0.7, 1.1, 2.])

@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants,
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm,
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -604,6 +604,80 @@ def gen_variants(cp):
     save('variants', **out)
 
 
+# massive neutrinos through the analytic engines (the reference computes: eisenstein_hu.py:21-33, its warnings are commented out): 'desi' is
+# fiducial.DESI(engine=...) (m_ncdm = [0.06], the AbacusSummit base cosmology); the others as the variants / ncdm targets take them
+POWER_NCDM_CASES = [dict(m_ncdm=[0.06]), 'desi', dict(m_ncdm=[0.02, 0.03, 0.05], Omega_m=0.31, h=0.6766, n_s=0.9665, sigma8=0.81, w0_fld=-0.9, wa_fld=0.1),
+                    dict(m_ncdm=[0.1, 0.4], Omega_b=0.045, T_cmb=2.6, A_s=2.2e-9, Omega_k=0.01), dict(m_ncdm=0.3, neutrino_hierarchy='normal', Omega_m=0.29)]
+POWER_NCDM_FILTERS = ['wallish2018', 'brieden2022', 'ehpoly', 'hinton2017', 'peakaverage', 'savgol', 'ehsavgol']
+
+
+def _power_ncdm_cosmo(cp, case, engine):
+    if case == 'desi':
+        from cosmoprimo.fiducial import DESI
+        return DESI(engine=engine)
+    return cp.Cosmology(engine=engine, **case)
+
+
+def gen_power_ncdm(cp):
+    """a29 with massive species: the three analytic engines on POWER_NCDM_CASES -- engine scalars, rs_drag / z_drag, transfer_k, pk_k, P(k, z) of
+    delta_m and theta_m, sigma8_z, sigma8_m, growth factor / rate, the sigma8 rescaling factor and A_s; the cosmology's derived Omega_m / Omega_cdm;
+    and the P(k) filters with cosmo = cosmo_fid = DESI(engine='eisenstein_hu') and cosmo = the first case (rs_drag ratio != 1)."""
+    import warnings
+    k = np.concatenate([np.logspace(-7, 2, 46), [1e-5, 0.05, 0.1, 1.]])
+    z = np.array([0., 0.5, 1., 2., 3.])
+    out = {'k': k, 'z': z}
+    names_sc = ['z_eq', 'k_eq', 'z_drag', 'r_drag', 'r_eq', 'rs_drag', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b', 'alpha_gamma', 'gamma']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for eng in ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks']:
+            for i, case in enumerate(POWER_NCDM_CASES):
+                cosmo = _power_ncdm_cosmo(cp, case, eng)
+                fo, tr, pm, ba = cosmo.get_fourier(), cosmo.get_transfer(), cosmo.get_primordial(), cosmo.get_background()
+                pre = '%s_c%d_' % (eng, i)
+                out[pre + 'transfer'] = np.asarray(tr.transfer_k(k))
+                out[pre + 'pk_prim'] = np.asarray(pm.pk_k(k))
+                out[pre + 'pkz'] = np.asarray(fo.pk_interpolator()(k, z))
+                out[pre + 'pkz_theta'] = np.asarray(fo.pk_interpolator(of='theta_m')(k, z))
+                out[pre + 'pkz_delta_theta'] = np.asarray(fo.pk_interpolator(of=('delta_m', 'theta_m'))(k, z))
+                out[pre + 'sigma8_z'] = np.asarray(fo.sigma8_z(z))
+                out[pre + 'sigma_rz'] = np.asarray(fo.sigma_rz(np.array([2., 8., 30.]), z))
+                out[pre + 'sigma8_m'] = float(fo.sigma8_m)
+                out[pre + 'growth_factor'] = np.asarray(ba.growth_factor(z))
+                out[pre + 'growth_factor_znorm0'] = np.asarray(ba.growth_factor(z, znorm=0.))
+                out[pre + 'growth_rate'] = np.asarray(ba.growth_rate(z))
+                out[pre + 'rsigma8'] = float(cosmo._engine._rsigma8)
+                out[pre + 'A_s'] = float(pm.A_s)
+                for name in ['Omega_m', 'Omega_cdm', 'Omega_de', 'Omega_ncdm_tot', 'Omega_pncdm_tot', 'N_ur', 'h', 'Omega_b', 'Omega_k', 'T_cmb', 'w0_fld', 'wa_fld',
+                             'n_s', 'alpha_s', 'beta_s', 'k_pivot']:
+                    out[pre + 'par_' + name] = float(cosmo[name])
+                out[pre + 'par_m_ncdm'] = np.asarray(cosmo['m_ncdm'], dtype='f8')
+                out[pre + 'par_T_ncdm_over_cmb'] = np.asarray(cosmo['T_ncdm_over_cmb'], dtype='f8')
+                out[pre + 'A_s_fid'] = float(cosmo._engine._A_s)      # the amplitude before the sigma8 rescaling (cosmology.py:505-510)
+                for name in names_sc:
+                    v = getattr(cosmo._engine, name, None)
+                    if v is not None:
+                        out[pre + name] = float(v)
+                if eng != 'bbks':
+                    th = cosmo.get_thermodynamics()
+                    out[pre + 'rs_drag_h'], out[pre + 'z_drag_th'] = float(th.rs_drag), float(th.z_drag)
+        # the filters on cosmologies with a massive species: cosmo_fid = DESI(); cosmo = DESI() (ratio 1) and cosmo = the first case
+        fid = _power_ncdm_cosmo(cp, 'desi', 'eisenstein_hu')
+        for j, case in enumerate(['desi', POWER_NCDM_CASES[0], POWER_NCDM_CASES[2]]):
+            cosmo = _power_ncdm_cosmo(cp, case, 'eisenstein_hu')
+            interp = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+            for name in POWER_NCDM_FILTERS:
+                f = cp.PowerSpectrumBAOFilter(interp, engine=name, cosmo=cosmo, cosmo_fid=fid)
+                out['filter%d_%s_pknow' % (j, name)] = np.asarray(f.pknow)
+            out['filter%d_pk' % j] = np.asarray(f.pk)
+            out['filter%d_rs_ratio' % j] = float(f.rs_drag_ratio())
+            out['filter%d_pknow_eh' % j] = np.asarray(cp.Fourier(cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(f.k, z=0.))
+            interp2d = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+            for name in ['wallish2018', 'brieden2022']:
+                out['filter%d_%s_pknow_2d' % (j, name)] = np.asarray(cp.PowerSpectrumBAOFilter(interp2d, engine=name, cosmo=cosmo, cosmo_fid=fid).pknow)
+        out['filter_k'] = np.asarray(f.k)
+    save('power_ncdm', **out)
+
+
 CALCULATOR_CASES = [('eisenstein_hu', {}, dict(Omega_m=0.3)), ('eisenstein_hu', {}, dict(h=0.65, n_s=0.95, w0_fld=-0.9)),
                     ('eisenstein_hu_nowiggle_variants', dict(m_ncdm=[0.06]), dict(Omega_m=0.28)), ('bbks', {}, dict(Omega_b=0.045))]
 CALCULATOR_PK_STRIDE = (8, 3)
@@ -730,6 +804,8 @@ def main():
         gen_ncdm(cp)
     if 'variants' in which:
         gen_variants(cp)
+    if 'power_ncdm' in which:
+        gen_power_ncdm(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:

@@ -5,7 +5,7 @@ transfer :241-283, pk_callable :321-324), eisenstein_hu_nowiggle.py (:17-51) and
 `3.89*q*(16.2*q)**2` term exactly as coded).  Vectorised over a leading batch of cosmologies:
 every parameter may be an array of shape (B,), k has shape (nk,) -> outputs (B, nk) (or (nk,) for scalars).
 
-Parity status: PINNED by tests/golden/power.npz (G7).
+Parity status: PINNED by tests/golden/power.npz (G7) and, with massive neutrinos, tests/golden/power_ncdm.npz.
 """
 import numpy as np
 
@@ -86,10 +86,11 @@ def transfer_nowiggle(k, h, s):
     return L0 / (L0 + C0 * q**2)
 
 
-def bbks_gamma(h, Omega_cdm, Omega_b):
-    """BBKSEngine.compute (bbks.py:34-38); Omega_m = Omega_b + Omega_cdm (no massive neutrinos)."""
+def bbks_gamma(h, Omega_cdm, Omega_b, Omega_nu_m=0.):
+    """BBKSEngine.compute (bbks.py:34-38); Omega_m = Omega_b + Omega_cdm + Omega_ncdm_tot - Omega_pncdm_tot (cosmology.py:381; ``Omega_nu_m`` = the
+    last two, 0 without massive neutrinos)."""
     h, Omega_cdm, Omega_b = (np.asarray(v, dtype='f8') for v in (h, Omega_cdm, Omega_b))
-    Omega_m = Omega_b + Omega_cdm
+    Omega_m = Omega_b + Omega_cdm + Omega_nu_m
     return Omega_m * h**2 * np.exp(-Omega_b * (1. + np.sqrt(2. * h) / Omega_m))
 
 
@@ -164,6 +165,55 @@ def pk_z0(k, engine='eisenstein_hu', h=0.7, Omega_cdm=0.25, Omega_b=0.05, T_cmb=
         tr = transfer_eh(k, h, s) if engine == 'eisenstein_hu' else transfer_nowiggle(k, h, s)
     Omega_m = np.asarray(Omega_b, dtype='f8') + np.asarray(Omega_cdm, dtype='f8')
     return pk_callable(k, tr, Omega_m, h, primordial_pk(k, h, A, n_s, alpha_s, beta_s, k_pivot))
+
+
+# ---- the analytic engines on a cosmology with massive neutrinos.  The reference computes (eisenstein_hu.py:21-33: the warnings are commented out): the
+# fits take omega_cdm + omega_b (:37-38); the species enter through the background -- Omega0_m of pk_callable (:322, cosmology.py:381), Omega_m(z) and
+# Omega_de(z) of the growth factor / rate (:134-135, 151-152 with cosmology.py:1704-1736), Omega_m of the BBKS shape parameter (bbks.py:38).
+def _omegas_ncdm(z, p):
+    """Omega_m(z), Omega_de(z) of one cosmology ``p`` = oracle.background.derived_ncdm (cosmology.py:1704-1707, 1724-1728, 1796, 1850)."""
+    rc = ob.rho_crit_over_Msunph_per_Mpcph3
+    z = np.asarray(z, dtype='f8')
+    E = ob.efunc_ncdm(z, p)
+    rho_crit = E**2 * rc / (1 + z)**3
+    rho_m = p['Omega_cdm'] * np.ones_like(z) * rc + p['Omega_b'] * np.ones_like(z) * rc + ob.ncdm_interp(p, z, 'rho').sum(axis=0) \
+        - 3. * ob.ncdm_interp(p, z, 'p').sum(axis=0)
+    rho_de = p['Omega_de'] * (1 + z) ** (3. * (p['w0_fld'] + p['wa_fld'])) * np.exp(3. * p['wa_fld'] * (1. / (1 + z) - 1)) * rc
+    return rho_m / rho_crit, rho_de / rho_crit
+
+
+def growth_factor_ncdm(z, p, znorm=None):
+    """Background.growth_factor (eisenstein_hu.py:115-140) of one cosmology with massive neutrinos."""
+    def growth(z):
+        z = np.asarray(z, dtype='f8')
+        Om, Ode = _omegas_ncdm(z, p)
+        return 1. / (1 + z) * 5 * Om / 2. / (Om**(4. / 7.) - Ode + (1. + Om / 2.) * (1 + Ode / 70.))
+
+    if znorm is not None:
+        return (1. + znorm) * growth(z)
+    return growth(z) / growth(np.zeros(()))
+
+
+def growth_rate_ncdm(z, p):
+    """Background.growth_rate (eisenstein_hu.py:143-152) of one cosmology with massive neutrinos."""
+    Om, _ = _omegas_ncdm(z, p)
+    wz1 = p['w0_fld'] + (1. - 0.5) * p['wa_fld']
+    return Om**(0.55 + 0.05 * (1 + wz1))
+
+
+def pk_z0_ncdm(k, p, engine='eisenstein_hu', A_s=None, sigma8=0.8, n_s=0.96, alpha_s=0., beta_s=0., k_pivot=0.05, rsigma8=1.):
+    """P(k, z=0) WITHOUT the growth factor of one cosmology with massive neutrinos: (transfer, P); ``p`` = oracle.background.derived_ncdm."""
+    A = A_s_fid(sigma8) if A_s is None else np.asarray(A_s, dtype='f8')
+    A = A * np.asarray(rsigma8, dtype='f8')**2
+    nu_m = float(np.sum(p['Omega_ncdm']) - np.sum(p['Omega_pncdm']))
+    h, Omega_cdm, Omega_b = float(p['h']), float(p['Omega_cdm']), float(p['Omega_b'])
+    if engine == 'bbks':
+        tr = transfer_bbks(k, h, bbks_gamma(h, Omega_cdm, Omega_b, nu_m))
+    else:
+        s = eh_scalars(h, Omega_cdm, Omega_b, p['T_cmb'])
+        tr = transfer_eh(k, h, s) if engine == 'eisenstein_hu' else transfer_nowiggle(k, h, s)
+    Omega_m = Omega_b + Omega_cdm + np.sum(p['Omega_ncdm']) - np.sum(p['Omega_pncdm'])      # cosmology.py:381
+    return tr, pk_callable(k, tr, Omega_m, h, primordial_pk(k, h, A, n_s, alpha_s, beta_s, k_pivot))
 
 
 # ---- eisenstein_hu_nowiggle_variants (SURVEY.md 8(f) f3): Eisenstein & Hu 1997 (astro-ph/9710252) with massive neutrinos -------

@@ -57,7 +57,20 @@ out = {
         'total': read + write, 'algorithmic': rows * 2048 * 8 * 2},
 }
 if 'GRBM_GUI_ACTIVE' in counters:
-    out['note_clock'] = 'effective clock ~ GRBM_GUI_ACTIVE / 8 / kernel time (reads high on dispatches shorter than 0.3 ms: MI355X_MICROARCH.md, DVFS give-back)'
+    # the clock the chip ran the kernel at: the counter is summed over the 8 XCDs; the duration of every dispatch comes from the SAME pass (the timestamps
+    # of its own counter rows), dispatch by dispatch
+    clocks, durations = [], []
+    for row in csv.DictReader(open(newest('%s/pmc_grbm/**/*counter_collection.csv' % src))):
+        if 'fftlog_kernel' in row.get('Kernel_Name', '') and row['Counter_Name'] == 'GRBM_GUI_ACTIVE':
+            ns = int(row['End_Timestamp']) - int(row['Start_Timestamp'])
+            if ns > 0:
+                durations.append(ns * 1e-6)
+                clocks.append(float(row['Counter_Value']) / 8 / (ns * 1e-9))
+    if clocks:
+        out['kernel_ms_profiled'] = sum(durations) / len(durations)
+        out['effective_clock_GHz'] = sum(clocks) / len(clocks) / 1e9
+    out['note_clock'] = ('effective clock = GRBM_GUI_ACTIVE / 8 XCDs / the dispatch\'s own duration in the same pass, mean over its dispatches (reads high on '
+                         'dispatches shorter than 0.3 ms: MI355X_MICROARCH.md, DVFS give-back)')
 json.dump(out, open('profiles/%s_pmc_summary.json' % tag, 'w'), indent=1)
 print(json.dumps({k: out[k] for k in ('counter_calibration', 'hbm_bytes_per_launch')}, indent=1))
 for k, v in counters.items():

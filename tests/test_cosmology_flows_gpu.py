@@ -189,10 +189,8 @@ def test_primordial_fourier_flows(cp, params):
         expected_log = np.log(1e10 * cosmo['A_s'])
         assert cosmo['ln10^{10}A_s'] == expected_log == cosmo['ln10^10A_s']
     has_ncdm = bool(cosmo['N_ncdm'])
-    engines = ['eisenstein_hu_nowiggle_variants'] if has_ncdm else ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'eisenstein_hu_nowiggle_variants', 'bbks']
-    if has_ncdm:
-        with pytest.raises(NotImplementedError):     # "cannot cope with massive neutrinos" is a warning in the reference, an error here
-            Fourier(cosmo, engine='eisenstein_hu')
+    # with massive neutrinos too: the reference's fits compute for any N_ncdm (eisenstein_hu.py:21-33), values pinned in tests/test_power_ncdm_gpu.py
+    engines = ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'eisenstein_hu_nowiggle_variants', 'bbks']
     k = np.logspace(-3, 1, 100)
     pk_eh = None
     for engine in engines:

@@ -54,8 +54,8 @@ def test_ncdm_background(cp, golden, ic):
     np.testing.assert_allclose(ba.efunc(z), ob.efunc_ncdm(z, p), rtol=1e-12)
     np.testing.assert_allclose(ba.comoving_radial_distance(z), ob.comoving_radial_distance_ncdm(z, p), rtol=1e-10, atol=1e-300)
     assert np.isnan(ba.rho_ncdm_tot(np.array([-0.5, 1e9]))).all()
-    with pytest.raises(NotImplementedError):
-        cosmo.get_fourier()
+    # the other sections compute with the species in the background, as the reference's do (eisenstein_hu.py:21-33; values: tests/test_power_ncdm_gpu.py)
+    assert np.all(np.isfinite(cosmo.get_fourier().pk_interpolator()(np.array([1e-3, 0.1, 1.]), z=np.array([0., 1.]))))
 
 
 def test_ncdm_tables_and_batch(cp, golden):

@@ -1,0 +1,162 @@
+"""GPU parity of the analytic engines (EH98, EH no-wiggle, BBKS) on cosmologies WITH massive neutrinos against golden vectors of the reference
+(tests/golden/power_ncdm.npz, `python -m oracle.gen_golden power_ncdm`): the reference computes for any N_ncdm (eisenstein_hu.py:21-33, its warnings
+are commented out) -- fiducial.DESI(engine=...) and the CosmoSIS default mnu = 0.06 are such cosmologies.  Tolerances of SURVEY.md 8(d): 1e-10 on
+P(k), sigma, growth and the scalars, 1e-9 on the filters' pknow."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import background as ob, power as op
+from oracle.gen_golden import POWER_NCDM_CASES, POWER_NCDM_FILTERS
+
+pytestmark = pytest.mark.gpu
+ENGINES = ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks']
+RTOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def cp():
+    import torch
+    assert torch.cuda.is_available()
+    import cosmoprimo_amd
+    warnings.simplefilter('ignore')
+    return cosmoprimo_amd
+
+
+def make(cp, case, engine):
+    if case == 'desi':
+        from cosmoprimo_amd.fiducial import DESI
+        return DESI(engine=engine)
+    return cp.Cosmology(engine=engine, **case)
+
+
+@pytest.mark.parametrize('engine', ENGINES)
+@pytest.mark.parametrize('ic', range(len(POWER_NCDM_CASES)))
+def test_engines_against_the_reference(cp, golden, engine, ic):
+    g = golden('power_ncdm')
+    k, z = g['k'], g['z']
+    pre = '%s_c%d_' % (engine, ic)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = make(cp, POWER_NCDM_CASES[ic], engine)
+    for name in ['Omega_m', 'Omega_cdm', 'Omega_de', 'Omega_ncdm_tot', 'Omega_pncdm_tot', 'N_ur']:
+        np.testing.assert_allclose(cosmo[name], g[pre + 'par_' + name], rtol=1e-13, err_msg=name)
+    fo, tr, pm, ba = cosmo.get_fourier(), cosmo.get_transfer(), cosmo.get_primordial(), cosmo.get_background()
+    np.testing.assert_allclose(tr.transfer_k(k), g[pre + 'transfer'], rtol=RTOL)
+    np.testing.assert_allclose(pm.pk_k(k), g[pre + 'pk_prim'], rtol=RTOL)
+    np.testing.assert_allclose(fo.pk_interpolator()(k, z), g[pre + 'pkz'], rtol=RTOL)
+    np.testing.assert_allclose(fo.pk_interpolator(of='theta_m')(k, z), g[pre + 'pkz_theta'], rtol=RTOL)
+    np.testing.assert_allclose(fo.pk_interpolator(of=('delta_m', 'theta_m'))(k, z), g[pre + 'pkz_delta_theta'], rtol=RTOL)
+    np.testing.assert_allclose(fo.sigma8_z(z), g[pre + 'sigma8_z'], rtol=RTOL)
+    np.testing.assert_allclose(fo.sigma_rz(np.array([2., 8., 30.]), z), g[pre + 'sigma_rz'], rtol=RTOL)
+    np.testing.assert_allclose(fo.sigma8_m, g[pre + 'sigma8_m'], rtol=RTOL)
+    np.testing.assert_allclose(ba.growth_factor(z), g[pre + 'growth_factor'], rtol=RTOL)
+    np.testing.assert_allclose(ba.growth_factor(z, znorm=0.), g[pre + 'growth_factor_znorm0'], rtol=RTOL)
+    np.testing.assert_allclose(ba.growth_rate(z), g[pre + 'growth_rate'], rtol=RTOL)
+    np.testing.assert_allclose(cosmo._engine._rsigma8, g[pre + 'rsigma8'], rtol=RTOL)
+    np.testing.assert_allclose(pm.A_s, g[pre + 'A_s'], rtol=RTOL)
+    names = {'eisenstein_hu': ['z_eq', 'k_eq', 'z_drag', 'r_drag', 'r_eq', 'rs_drag', 'k_silk', 'alpha_c', 'beta_c', 'alpha_b', 'beta_node', 'beta_b'],
+             'eisenstein_hu_nowiggle': ['z_eq', 'k_eq', 'z_drag', 'r_drag', 'r_eq', 'rs_drag', 'alpha_gamma'], 'bbks': ['gamma']}[engine]
+    for name in names:
+        attr = 'bbks_gamma' if name == 'gamma' and not hasattr(cosmo._engine, 'gamma') else name
+        np.testing.assert_allclose(getattr(cosmo._engine, attr), g[pre + name], rtol=1e-12, err_msg=name)
+    if engine != 'bbks':
+        th = cosmo.get_thermodynamics()
+        np.testing.assert_allclose(th.rs_drag, g[pre + 'rs_drag_h'], rtol=1e-12)
+        np.testing.assert_allclose(th.z_drag, g[pre + 'z_drag_th'], rtol=1e-12)
+
+
+def test_warnings_as_the_reference(cp):
+    """EH98 / no-wiggle: silent with massive neutrinos (eisenstein_hu.py:24-32, commented out); BBKS warns (bbks.py:24-31)."""
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        cp.Cosmology(engine='eisenstein_hu', m_ncdm=[0.06])
+        cp.Cosmology(engine='eisenstein_hu_nowiggle', m_ncdm=[0.06])
+        with pytest.raises(UserWarning, match='massive neutrinos'):
+            cp.Cosmology(engine='bbks', m_ncdm=[0.06])
+
+
+@pytest.mark.parametrize('ifilter', range(3))
+def test_filters_with_a_massive_species(cp, golden, ifilter):
+    """cosmo_fid = DESI(); cosmo = DESI() (rs_drag ratio 1), one massive species on the defaults, three species + w0wa: every P(k) filter of the registry."""
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    g = golden('power_ncdm')
+    fid = make(cp, 'desi', 'eisenstein_hu')
+    cosmo = make(cp, ['desi', POWER_NCDM_CASES[0], POWER_NCDM_CASES[2]][ifilter], 'eisenstein_hu')
+    interp = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+    for name in POWER_NCDM_FILTERS:
+        f = PowerSpectrumBAOFilter(interp, engine=name, cosmo=cosmo, cosmo_fid=fid)
+        np.testing.assert_allclose(f.k, g['filter_k'], rtol=1e-14)
+        np.testing.assert_allclose(f.pk, g['filter%d_pk' % ifilter], rtol=RTOL)
+        np.testing.assert_allclose(f.rs_drag_ratio(), g['filter%d_rs_ratio' % ifilter], rtol=1e-12)
+        np.testing.assert_allclose(f.pknow, g['filter%d_%s_pknow' % (ifilter, name)], rtol=1e-7 if name == 'hinton2017' else 1e-9, err_msg=name)
+    nowiggle = cp.Fourier(cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(f.k, z=0.)
+    np.testing.assert_allclose(nowiggle, g['filter%d_pknow_eh' % ifilter], rtol=RTOL)
+    interp2d = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+    for name in ['wallish2018', 'brieden2022']:
+        f = PowerSpectrumBAOFilter(interp2d, engine=name, cosmo=cosmo, cosmo_fid=fid)
+        np.testing.assert_allclose(f.pknow, g['filter%d_%s_pknow_2d' % (ifilter, name)], rtol=1e-9, err_msg=name)
+
+
+@pytest.mark.parametrize('engine', ENGINES)
+def test_batch_with_masses_per_cosmology(cp, engine):
+    """A batch of cosmologies with an array of masses (the way configs 3 and 4 are expressed): every entry is what the cosmology gives on its own, and what
+    the oracle gives -- P(k, z), sigma(r, z), the sigma8 normalisation (cp_sigma8_normalise / cp_sigma_rz_functional / the fused sigma(r, z) kernel with the
+    massive-neutrino tables of the batch)."""
+    rng = np.random.default_rng(11)
+    nb = 37
+    par = dict(h=rng.uniform(0.6, 0.8, nb), Omega_m=rng.uniform(0.26, 0.36, nb), Omega_b=rng.uniform(0.04, 0.06, nb), n_s=rng.uniform(0.93, 1., nb),
+               sigma8=rng.uniform(0.7, 0.9, nb))
+    m1, m2 = rng.uniform(0.02, 0.4, nb), 0.05
+    k = np.concatenate([np.logspace(-5, 1.5, 40), [0.05, 0.2]])
+    z = np.array([0., 0.7, 2.])
+    r = np.geomspace(1., 60., 9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        batch = cp.Cosmology(engine=engine, m_ncdm=[m1, m2], **par)
+        fo = batch.get_fourier()
+        pkz = np.asarray(fo.pk_interpolator()(k, z))
+        sig = np.asarray(fo.sigma_rz(r, z))
+        sig_few = np.asarray(fo.sigma_rz(np.array([8., 12.]), z))
+        s8 = np.asarray(fo.sigma8_m)
+        rs = np.asarray(batch._engine._rsigma8.cpu())
+        assert pkz.shape == (nb, k.size, z.size) and sig.shape == (nb, r.size, z.size) and s8.shape == (nb,)
+        np.testing.assert_allclose(s8, par['sigma8'], rtol=1e-10)
+        for i in (0, 5, nb - 1):
+            one = cp.Cosmology(engine=engine, m_ncdm=[m1[i], m2], **{name: float(v[i]) for name, v in par.items()})
+            fo1 = one.get_fourier()
+            np.testing.assert_allclose(pkz[i], fo1.pk_interpolator()(k, z), rtol=1e-11)
+            np.testing.assert_allclose(sig[i], fo1.sigma_rz(r, z), rtol=1e-10)
+            np.testing.assert_allclose(sig_few[i], fo1.sigma_rz(np.array([8., 12.]), z), rtol=1e-10)
+            np.testing.assert_allclose(rs[i], one._engine._rsigma8, rtol=1e-10)
+            # and the oracle on the same compiled parameters
+            p = ob.derived_ncdm([m1[i], m2], h=par['h'][i], Omega_m=par['Omega_m'][i], Omega_b=par['Omega_b'][i])
+            np.testing.assert_allclose(one['Omega_cdm'], p['Omega_cdm'], rtol=1e-13)
+            tr, pk0 = op.pk_z0_ncdm(k, p, engine=engine, sigma8=par['sigma8'][i], n_s=par['n_s'][i], rsigma8=rs[i])
+            growth = op.growth_factor_ncdm(z, p, znorm=0.)
+            np.testing.assert_allclose(pkz[i], pk0[:, None] * growth**2, rtol=1e-10)
+
+
+def test_batched_filters_with_masses(cp):
+    """wallish2018 and brieden2022 over a batch of cosmologies with massive neutrinos (the transform that evaluates P(k) itself, cp_dst_forward_analytic,
+    and brieden2022's kernels take the tables of the batch) against the same cosmologies one at a time."""
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    from cosmoprimo_amd.fiducial import DESI
+    rng = np.random.default_rng(3)
+    nb = 9
+    par = dict(h=rng.uniform(0.62, 0.74, nb), Omega_m=rng.uniform(0.28, 0.34, nb), Omega_b=rng.uniform(0.045, 0.055, nb), n_s=rng.uniform(0.94, 0.98, nb))
+    masses = rng.uniform(0.03, 0.3, nb)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fid = DESI(engine='eisenstein_hu')
+        batch = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, m_ncdm=[masses], **par)
+        interp = batch.get_fourier().pk_interpolator(z=np.array([0.]))
+        w = np.asarray(PowerSpectrumBAOFilter(interp, engine='wallish2018', cosmo=batch, cosmo_fid=fid).pknow)
+        b = np.asarray(PowerSpectrumBAOFilter(interp, engine='brieden2022', cosmo=batch, cosmo_fid=fid).pknow)
+        assert w.shape == b.shape == (nb, 1024, 1)
+        for i in (0, 4, nb - 1):
+            one = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, m_ncdm=[masses[i]], **{name: float(v[i]) for name, v in par.items()})
+            interp1 = one.get_fourier().pk_interpolator(z=np.array([0.]))
+            np.testing.assert_allclose(w[i], PowerSpectrumBAOFilter(interp1, engine='wallish2018', cosmo=one, cosmo_fid=fid).pknow, rtol=1e-9)
+            np.testing.assert_allclose(b[i], PowerSpectrumBAOFilter(interp1, engine='brieden2022', cosmo=one, cosmo_fid=fid).pknow, rtol=1e-9)

@@ -206,7 +206,7 @@ def test_block_route_keeps_spectra_inside_their_buffer(blocks):
     out = torch.empty((n, r.size, nz), dtype=torch.float64, device=dev)
     work = torch.empty(int(lib.cp_sigma_rz_workspace_bytes(n, nk)), dtype=torch.uint8, device=dev)
     kdev = dv.upload(np.geomspace(1e-7, 1e2, nk), dev)
-    _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES['eisenstein_hu'], n, dv.as_void_p(cbg), 0, dv.as_void_p(cpk), nk, kdev.data_ptr(),
+    _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES['eisenstein_hu'], n, dv.as_void_p(cbg), 0, None, dv.as_void_p(cpk), nk, kdev.data_ptr(),
                                         fft._get_plan(dev).handle, op._handle, g2.data_ptr(), nz, out.data_ptr(), buf.data_ptr(), work.data_ptr(),
                                         blocks, dev.index, dv.stream_of(dev)))
     torch.cuda.synchronize()
