@@ -146,6 +146,8 @@ SIGNATURES = {
                                       ctypes.c_void_p]),
     'cp_dst_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_dst_forward_analytic_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong]),
+    'cp_wallish_tail': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'cp_dst_forward_analytic_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
         ctypes.c_int, ctypes.c_void_p]),
@@ -207,7 +209,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(LIB_PATH):
+    path = LIB_PATH
+    variant = os.environ.get('COSMOPRIMO_AMD_LIBRARY')      # measurements only (tools/variant_lib.sh: a variant of ONE source linked beside the shipped library,
+    if variant:                                             # which is never rebuilt in place): an explicit path, which must exist
+        if not os.path.isfile(variant):
+            raise LibraryError('COSMOPRIMO_AMD_LIBRARY = {} does not exist'.format(variant))
+        path = variant
+    if not os.path.isfile(path):
         raise LibraryError('{} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` or '
                            '`make -C cosmoprimo_amd/csrc -j8` (hipcc, gfx950). There is no CPU fallback.'.format(LIB_PATH))
     try:
@@ -215,12 +223,12 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            raise LibraryError('{} does not export {} (stale build?)'.format(LIB_PATH, name))
+            raise LibraryError('{} does not export {} (stale build?)'.format(path, name))
         fn.restype = restype
         fn.argtypes = argtypes
     if lib.cp_abi_version() != ABI_VERSION:

@@ -177,6 +177,9 @@ class BasePowerSpectrumBAOFilter(dv.Copyable, metaclass=RegisteredPowerSpectrumB
 # transform grows from 2.35 to 3.11 ms for the 0.62 ms of cp_wallish_dd_box it replaces (the solve is a chain of dependent steps: at the two
 # workgroups per CU of the transform it is not hidden, and it holds the transform's registers and LDS while it runs) -- profiles/r4_wallish_box_in_transform.txt
 _TRANSFORM_FINDS_BOXES = False
+# everything behind the forward transform (second derivatives + box, inverse transform, spliced spline + damping) as ONE kernel, the transformed rows never
+# leaving the CU (cp_wallish_tail): batches too large for the second derivatives to be kept (they are not written then)
+_TAIL_IN_ONE_KERNEL = True
 _TRANSFORM_EVALUATES_SPECTRA = True      # wallish2018 on batches of analytic cosmologies: cp_dst_forward_analytic (False: evaluation kernel, then transform)
 
 
@@ -261,6 +264,26 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         dd = ops['dd'](y)
         return dd, self._box(dd), False
 
+    def _tail(self, ffted, y, ops):
+        """Everything behind the forward transform in one kernel (``cp_wallish_tail``, reference bao_filter.py:373-431); False where the plans are not the
+        ones the kernel is written for (the three separate calls then)."""
+        torch = dv.torch()
+        pk = self._pk_rows.contiguous()
+        if pk.shape[0] != ffted.shape[0] or not ffted.is_contiguous():
+            return False
+        mf, ms, off = self._margin_first, self._margin_second, self._offset
+        box = torch.empty((y.shape[0], 2), dtype=torch.int32, device=y.device)
+        out = torch.empty_like(pk)
+        status = _lib.load().cp_wallish_tail(ops['dst']._handle, ops['splice']._handle, ffted.data_ptr(), pk.data_ptr(), pk.shape[1], pk.shape[0], mf, ms, off[0], off[1],
+                                             ops['tophat'].data_ptr(), box.data_ptr(), out.data_ptr(), dv.stream_of(self.device))
+        if status == _lib.CP_EUNSUPPORTED:
+            return False
+        _lib.check(status)
+        self._dd, self._boxes = None, [box[0::2], box[1::2]]
+        self._even_now, self._odd_now = y[0::2], y[1::2]      # (the boxes are rewritten in place)
+        self._pknow_rows = out
+        return True
+
     def _log_k_rows(self, klin, dst=None):
         """log(k_lin P(k_lin)) rows (ncol, 4096) of a batch of cosmologies of an analytic engine, written by the evaluation kernel term by term
         (``cp_power_eval``, CP_PK_LOG_K_MATTER) -- the transform then reads its input as it is, without 4096 logarithms per vector.  None for any
@@ -304,6 +327,9 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             rows, _ = self._rows(ops['klin'])                             # P(k_lin), (ncol, 4096)
             ffted = ops['dst'](rows, fused=True, split=True)
         y = ffted.view(2 * ffted.shape[0], ffted.shape[1] // 2)
+        if (_TAIL_IN_ONE_KERNEL and solved is None and isinstance(ops['splice'], SplicedClampedSpline) and ffted.shape[1] == 4096 and
+                y.shape[0] > self._keep_second_derivatives and self._tail(ffted, y, ops)):
+            return
         dd, box, removed = (None, solved, True) if solved is not None else self._second_derivatives_and_box(y, ops)
         out = y      # in place: the kept coefficients stay where they are, only the boxes are rewritten
         if not removed:

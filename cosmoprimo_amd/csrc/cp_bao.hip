@@ -1146,6 +1146,13 @@ extern "C" int cp_splice_plan_create(cp_splice_plan** out, int nknots, const dou
     return CP_OK;
 }
 
+bool cp_splice_plan_uniform_view(const cp_splice_plan* p, cpsu::Tables* out, int* device) {
+    if (!p || !p->has_uniform || !p->use_uniform) return false;
+    *out = p->U;
+    *device = p->device;
+    return true;
+}
+
 // which kernel a plan runs: 0 the elimination in LDS (any knots), 1 the recursions on a uniform stretch (cp_splice_uniform.h; the default where it fits)
 extern "C" int cp_splice_plan_scheme(const cp_splice_plan* p) { return p && p->use_uniform ? 1 : 0; }
 

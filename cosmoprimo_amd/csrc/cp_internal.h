@@ -42,6 +42,13 @@ struct cp_spline_rows_view {
 };
 bool cp_spline_rows_plan_view(const cp_spline_rows_plan* plan, cp_spline_rows_view* out);
 
+// the uniform-stretch scheme of a splice plan (cp_splice_uniform_plan.h: its tables with their device pointers) for the kernel that runs the spline step
+// of wallish2018 behind the inverse transform (cp_dst.hip: wallish_tail_kernel); false when the plan does not run that scheme
+namespace cpsu {
+struct Tables;
+}
+bool cp_splice_plan_uniform_view(const cp_splice_plan* plan, cpsu::Tables* out, int* device);
+
 // Dynamic LDS above 64 KB is an opt-in per kernel AND per device (hipFuncAttributeMaxDynamicSharedMemorySize).  Raises the limit of KERNEL to the
 // whole 160 KB of a CU the first time it is launched on the device that is current (once per (kernel, device): a multi-GPU process configures every
 // device it launches on, and a later launch with more LDS than the first finds the limit already at the maximum).

@@ -365,10 +365,13 @@ __device__ __forceinline__ bool remove_box(double* buf, const double* gtab, int 
 // d <- (3 (z_{i+1} - z_{i-1}) - d) c_i, and affine maps compose -- each lane builds the map of one knot of the window on either side (64 knots
 // each), six ordered butterfly steps compose them, where two lanes walked 64 dependent steps each while 62 waited.  The knots are read from the
 // sequence in LDS (layout LAY), nothing is staged.
-template <int S, class LAY>
-__device__ __forceinline__ bool remove_box_parallel(const double* ybuf, const double* gtab, int lane, int a, int b, double* seq) {
+// INPLACE: the rewritten knots also replace the ones in LDS (the fused tail of the filter, cp_dst.hip: wallish_tail_kernel, transforms the sequence
+// back from there), and *all_finite tells whether this lane's were finite.
+template <int S, class LAY, bool INPLACE = false>
+__device__ __forceinline__ bool remove_box_parallel(const double* ybuf, const double* gtab, int lane, int a, int b, double* seq, bool* all_finite = nullptr) {
     constexpr int N = 64 * S;
     static_assert(DD_GAP_WINDOW == 64, "a knot of either window per lane");
+    if (all_finite) *all_finite = true;
     if (a < 1 || b > N - 2 || b < a) return false;
     const int L = a - 1, R = b + 1;
     const double g = (double)(R - L), inv_g = cpmath::recip(g);      // (the quotients below as reciprocals: thirteen IEEE divisions in a row per sequence were a quarter of the kernel's vector instructions, all of them in one dependent chain)
@@ -426,10 +429,17 @@ __device__ __forceinline__ bool remove_box_parallel(const double* ybuf, const do
     const double slope = (zR - zL) * inv_g;
     const double tt = (sL + sR - 2. * slope) * inv_g;
     const double c3 = tt * inv_g, c2 = (slope - sL) * inv_g - tt;
+    bool finite = true;
     for (int i = a + lane; i <= b; i += 64) {
         const double u = (double)(i - L), x = (double)(i + 1);
-        seq[i] = (zL + u * (sL + u * (c2 + u * c3))) * cpmath::recip(x * x);
+        const double v = (zL + u * (sL + u * (c2 + u * c3))) * cpmath::recip(x * x);
+        seq[i] = v;
+        if constexpr (INPLACE) {      // ... and into the sequence in LDS (the knots read above lie outside the box: nothing read here is rewritten)
+            const_cast<double*>(ybuf)[LAY::at(i)] = v;
+            finite &= fabs(v) <= 1.7976931348623157e308;
+        }
     }
+    if (all_finite) *all_finite = finite;
     return true;
 }
 

@@ -530,6 +530,17 @@ int cp_dst_forward_analytic_box(const cp_dst_plan* plan, int engine, long long n
                                 const cp_ncdm* ncdm, const cp_param* pk_params, double* d_out, void* d_work, int* d_box, int margin_first, int margin_second,
                                 int offset_first, int offset_second, void* stream);
 
+/* Everything of wallish2018 behind its forward transform as ONE kernel (bao_filter.py:373-431): for every row of d_coef (nrows, 4096: the sine-transform
+ * coefficients in the CP_DST_SPLIT layout, as cp_dst_forward_analytic / cp_dst_execute write them) the second derivatives of its two sequences, their boxes
+ * (d_box (2 nrows, 2), as cp_wallish_dd_box) and the boxes rewritten IN PLACE in d_coef; the inverse transform with exp(.) / k_lin; the clamped spline through
+ * the spliced knots (plan `splice`: cp_splice_plan_create with the stretch of the linear grid taken from the transformed rows, array 1, the knots outside it
+ * from the rows d_pk (nrows, npk) of P, array 0) at the filter's npk wavenumbers and the damping with d_tophat (or NULL): d_out (nrows, npk).  What
+ * cp_wallish_dd_box + cp_dst_execute(inverse, CP_DST_FUSED | CP_DST_SPLIT) + cp_splice_apply compute with the transformed rows never leaving the CU.
+ * CP_EUNSUPPORTED when the plans are not the filter's (transform of length 4096 with its abscissa; a splice plan that runs the uniform-stretch scheme with
+ * 49 knots per lane): the caller then takes the three calls. */
+int cp_wallish_tail(const cp_dst_plan* dst, const cp_splice_plan* splice, double* d_coef, const double* d_pk, int npk, long long nrows, int margin_first,
+                    int margin_second, int offset_first, int offset_second, const double* d_tophat, int* d_box, double* d_out, void* stream);
+
 /* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
  * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];
  * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */

@@ -235,3 +235,38 @@ def test_wallish_box_kernel():
             second = first + ms + tail.argmax() if tail.size else 0
             ref[i] = first + off[0], second + off[1]
         assert np.array_equal(box.cpu().numpy(), ref), n
+
+
+def test_wallish_tail_in_one_kernel(cp):
+    """cp_wallish_tail (second derivatives + box + removal, inverse transform, spliced spline + damping of wallish2018 as one kernel, the transformed rows
+    kept on the CU) against the three calls it replaces: pknow, the boxes and the rewritten sequences; odd batches (a vector without a partner) and a
+    vector that is not finite next to good ones (it comes out as the three calls leave it, its partner untouched)."""
+    import torch
+    from cosmoprimo_amd import bao_filter as bf
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    fid = cp.Cosmology(engine='eisenstein_hu')
+    rng = np.random.default_rng(17)
+    for nb in (129, 200, 513):
+        par = dict(Omega_m=rng.uniform(0.24, 0.40, nb), Omega_b=rng.uniform(0.04, 0.06, nb), h=rng.uniform(0.6, 0.8, nb), n_s=rng.uniform(0.92, 1., nb))
+        if nb == 200:
+            par['h'][7] = np.nan      # a vector of NaN in the middle of a pair
+        cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **par)
+        interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+        saved = bf._TAIL_IN_ONE_KERNEL
+        try:
+            got = []
+            for fused in (True, False):
+                bf._TAIL_IN_ONE_KERNEL = fused
+                f = PowerSpectrumBAOFilter(interp, engine='wallish2018', cosmo=cosmo, cosmo_fid=fid)
+                got.append((np.asarray(f.pknow), [b.cpu().numpy() for b in f._boxes], f._even_now.cpu().numpy(), f._odd_now.cpu().numpy()))
+        finally:
+            bf._TAIL_IN_ONE_KERNEL = saved
+        (pk1, box1, even1, odd1), (pk0, box0, even0, odd0) = got
+        assert pk1.shape == pk0.shape == (nb, 1024, 1)
+        good = np.isfinite(par['h'])
+        assert np.isfinite(pk1[good]).all() and np.isnan(pk1[~good]).all() == np.isnan(pk0[~good]).all()
+        np.testing.assert_allclose(pk1[good], pk0[good], rtol=1e-12)
+        for a, b in zip(box1, box0):
+            assert np.array_equal(a[good], b[good])
+        np.testing.assert_allclose(even1[good], even0[good], rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(odd1[good], odd0[good], rtol=1e-13, atol=1e-300)

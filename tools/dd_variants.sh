@@ -1,5 +1,7 @@
-base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form"
+#!/bin/bash
+# second derivatives + box of wallish2018 (cp_wallish_dd_box): the recursions in registers (default) against the elimination in LDS (-DCP_DD_ELIMINATION=1),
+# the variant built BESIDE the shipped library (tools/variant_lib.sh).  bash tools/dd_variants.sh
 python -m pytest tests/test_fused_kernels_gpu.py tests/test_bao_gpu.py -x -q -k "dd_box or wallish" 2>&1 | tail -3
 echo "== recursions, launch bounds (256, 2)"; python tools/bench_dd_box.py
-( cd cosmoprimo_amd/csrc && hipcc $base -DCP_DD_ELIMINATION=1 -c cp_bao.hip -o cp_bao.o && make > /dev/null 2>&1 )
-echo "== elimination"; python tools/bench_dd_box.py
+bash tools/variant_lib.sh /tmp/cp_dd_elimination.so "-DCP_DD_ELIMINATION=1" cp_bao.hip || exit 1
+echo "== elimination"; COSMOPRIMO_AMD_LIBRARY=/tmp/cp_dd_elimination.so python tools/bench_dd_box.py
