@@ -164,6 +164,29 @@ def _ncdm_momenta_z0(T_eff, m, out='rho'):
     return 7. / 8. * 4 / c**3 * sb * T_eff**4 * np.sum(f * wi, axis=-1) / (7. * np.pi**4 / 120.) / (1e10 * msun) * mpc**3
 
 
+def compute_ncdm_momenta(T_eff, m_ncdm, z, out='rho'):
+    """Density ('rho') or pressure ('p') of one massive species of temperature ``T_eff`` today [K] and mass ``m_ncdm`` [eV] at redshift ``z``, in
+    1e10 Msun / Mpc^3, by the reference's name and arguments (cosmology.py:74-137, 188-200): the integral depends on the temperature at z only,
+    T_eff (1 + z)."""
+    if out not in ('rho', 'p'):
+        raise ValueError("out must be 'rho' or 'p'")
+    return _ncdm_momenta_z0(np.asarray(_host(T_eff), dtype='f8') * (1. + np.asarray(_host(z), dtype='f8')), m_ncdm, out=out)
+
+
+def get_default_z_interp(name):
+    """The redshift knots the reference's background tabulates ``name`` on (cosmology.py:1940-1952): 'rho_ncdm' / 'p_ncdm' (119), 'time' / 'age' (400),
+    'comoving_radial_distance' (119) -- the grids the kernels of ``cp_background.hip`` are built on, read back from the library."""
+    if name in ('rho_ncdm', 'p_ncdm'):
+        knots = np.empty(_lib.NCDM_NKNOTS)
+        _lib.check(_lib.load().cp_ncdm_knots(_lib.as_double_p(knots), knots.size))
+        return knots
+    if name in ('time', 'age', 'comoving_radial_distance'):
+        knots = np.empty(400 if name in ('time', 'age') else 119)
+        _lib.check(_lib.load().cp_background_knots(_lib.as_double_p(knots), knots.size))
+        return knots
+    raise ValueError('No default z interpolation grid for {}'.format(name))
+
+
 def _split_neutrino_masses(sum_ncdm, hierarchy):
     """Three masses adding up to ``sum_ncdm`` [eV] under the 'normal', 'inverted' or 'degenerate' hierarchy, by Newton's method on the
     lightest mass with the squared-mass splittings of arXiv:1907.12598 (reference cosmology.py:1047-1104)."""
@@ -865,6 +888,13 @@ class Cosmology(BaseCosmoParams):
         if engine is not None:
             toret.update(engine.get_default_params(of=of, include_conflicts=include_conflicts))
         return toret
+
+    @_class_or_instancemethod
+    def get_default_parameters(self=None):
+        """Deprecated name of :meth:`get_default_params` (reference cosmology.py:848-852)."""
+        import warnings
+        warnings.warn('get_default_parameters is deprecated, use get_default_params')
+        return Cosmology.get_default_params() if self is None or not isinstance(self, Cosmology) else self.get_default_params()
 
     def get_params(self, of='base'):
         toret = super().get_params(of=of)

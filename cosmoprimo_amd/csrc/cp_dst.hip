@@ -512,318 +512,7 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
 }
 
 
-// ---- wallish2018 behind its forward transform as ONE kernel (bao_filter.py:373-431) ----
-// The three steps that follow the forward sine transform -- second derivatives of the two coefficient sequences, the box between their maxima and its
-// removal (:373-405: wallish_dd_box_kernel), the inverse transform with exp(.) / k_lin (:407-413: dst_kernel<..., true>) and the clamped spline through
-// the spliced knots at the filter's wavenumbers with the damping (:415-431: splice_uniform_kernel) -- each read what the one before had written:
-// 34 + 34 + 33 KB read and 33 KB written per vector for 16 KB that have to move (the 8 KB row of P in, the 8 KB result out), at 5 500 + 2 733 + 1 073
-// vector instructions per vector, i.e. idle ALUs (profiles/r4y_config4_traffic.json).  Here a workgroup takes a PAIR of vectors through all of it on
-// the CU: the pair's four sequences of 2048 coefficients fill the 64 KB data region of the 4096-point transform (XOR layout of cp_wallish_dd.h), a wave
-// each; the boxes are rewritten there (and in memory, where the filter keeps the sequences); the packed spectrum of the inverse transform is formed
-// from LDS; the transformed pair goes back into the same region as two real rows in natural order, on which waves 0 and 1 run the recursions of the
-// spliced spline (cp_splice_uniform.h: a lane owns SU consecutive knots of the uniform stretch, its second derivatives overwrite them) and evaluate
-// the queries, while waves 2 and 3 copy the columns that do not go through the spline.  Per vector: 32 KB of coefficients + 8 KB of P in, 8 KB out.
-struct TailArgs {
-    Args dst;                  // in: the coefficient rows (split layout), tw, rot, ikx; out unused
-    double* coef;              // = dst.in, written: the boxes are rewritten in place (what cp_wallish_dd_box leaves there)
-    cpsu::Tables U;            // the uniform-stretch scheme of the splice plan: stretch from the transformed rows (src_u = 1), outer knots from P (src 0)
-    const double* pk;          // (nrows, nq)
-    const double* tophat;      // (nq) or null
-    double* out;               // (nrows, nq)
-    int* box;                  // (2 nrows, 2)
-    int margin_first, margin_second, off0, off1;
-};
-
-#ifndef CP_TAIL_OWN_EARLY      // 1: the values the spline step takes of the first array are requested at the top of the pair (20 registers held through the transform)
-#define CP_TAIL_OWN_EARLY 1
-#endif
-#ifndef CP_TAIL_ABLATE      // diagnostic builds (wrong results): 1 no second derivatives / box, 2 no transform, 4 no exponential, 8 no splice, 16 no stores of the result
-#define CP_TAIL_ABLATE 0
-#endif
-
-// the spliced spline of ONE row by one wave: yu = the row's stretch in LDS (natural order: knot i at yu[i], yu[-1] and yu[nm .. 64 SU] belong to the
-// row and are free), pkrow = the row of the first array.  The arithmetic of cpsu::splice_uniform_kernel, statement for statement.
-template <int SU>
-__device__ __forceinline__ void tail_splice_row(const cpsu::Tables& U, double* yu, const double* pkrow, const double* tophat, double* outrow, int lane, double gvl,
-                                                double gvr, const double* own) {
-    using cpsu::P;
-    using cpsu::WIN_U;
-    using cpsu::NGB;
-    const int nm = U.nm;
-    const double gl_last = __shfl(gvl, U.wl > 0 ? U.wl - 1 : 0), gr_first = __shfl(gvr, 0);
-    // ---- A / p, M_left, B, M_right: weighted sums over the differences of the knots next to the two junctions ----
-    double sums[4];
-    {
-        double ww[8];
-#pragma unroll
-        for (int o = 0; o < 8; ++o) ww[o] = U.win[64 * o + lane];
-        const double ul = yu[lane < WIN_U ? lane : 0], ur = yu[lane < WIN_U ? nm - 1 - lane : 0];
-        const double yfirst = yu[0], ylast = yu[nm - 1];
-        sums[0] = fma(ww[0], gvl - yfirst, ww[1] * (ul - yfirst));
-        sums[1] = fma(ww[2], gvl - gl_last, ww[3] * (ul - gl_last));
-        sums[2] = fma(ww[4], ur - ylast, ww[5] * (gvr - ylast));
-        sums[3] = fma(ww[6], ur - gr_first, ww[7] * (gvr - gr_first));
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) sums[o] += __shfl_xor(sums[o], off);
-    }
-    // ---- the queries' knot values, before the second derivatives take their place ----
-    double part[NGB];
-#pragma unroll
-    for (int e = 0; e < NGB; ++e) {
-        part[e] = 0.;
-        if (e < U.ngb) {
-            const int slot = 64 * e + lane;
-            const int j = U.qe[slot];
-            const double4 w = reinterpret_cast<const double4*>(U.qw)[slot];
-            const double ya = yu[j], yb = yu[j + 1];      // (j = -1 and j + 1 = nm read slots of the row that hold no knot: replaced)
-            part[e] = fma(w.x, j < 0 ? gl_last : ya, w.y * (j + 1 >= nm ? gr_first : yb));
-        }
-    }
-    // ---- the lane's knots: second differences (beyond either end of the stretch its end value again) ----
-    double g[SU];
-    {
-        const int base = SU * lane - 1;
-        auto yk = [&](int i) { return yu[i < 0 ? 0 : (i > nm - 1 ? nm - 1 : i)]; };
-        double y1 = yk(base + 1);
-        double dprev = y1 - yk(base);
-#pragma unroll
-        for (int t = 0; t < SU; ++t) {
-            const double y2 = yk(base + t + 2);
-            const double dn = y2 - y1;
-            g[t] = dn - dprev;
-            dprev = dn;
-            y1 = y2;
-        }
-    }
-    cp::wave_lds_phase();      // every read of the knot values is done
-    const double m_a = lane == 0 ? 1. : 0.;
-    const double m_b = lane == U.lane_b ? U.mb0 : (lane == U.lane_b - 1 ? U.mb1 : 0.);
-    {
-#pragma unroll
-        for (int t = SU - 2; t >= 0; --t) g[t] = fma(P, g[t + 1], g[t]);
-        double c = fma(m_b, sums[2], cpdd::dd_from_right(g[0]));
-        double f = 0.;
-#pragma unroll
-        for (int t = 0; t < SU; ++t) {
-            const double e = fma(P, f, g[t]);
-            f = t + 1 < SU ? fma(-P, g[t + 1], e) : e;
-            g[t] = e;
-        }
-#pragma unroll
-        for (int t = SU - 1; t >= 0; --t) {
-            c *= P;
-            g[t] += c;
-        }
-        c = fma(m_a, sums[0], cpdd::dd_from_left(f));
-#pragma unroll
-        for (int t = 0; t < (SU < 36 ? SU : 36); ++t) {
-            c *= P;
-            g[t] += c;
-        }
-        double* mine = yu + SU * lane;
-#pragma unroll
-        for (int t = 0; t < SU; ++t) mine[t] = g[t];
-    }
-    cp::wave_lds_phase();
-    if (lane == 0) yu[-1] = sums[1];
-    if (lane == 1) yu[nm] = sums[3];
-    cp::wave_lds_phase();
-    // ---- evaluation of the queries that go through the spline (the other columns are copied by the waves that have no row) ----
-#pragma unroll
-    for (int e = 0; e < NGB; ++e) {
-        if (e < U.ngb) {
-            const int slot = 64 * e + lane, q = 64 * U.gb0 + slot;
-            const int j = U.qe[slot];
-            const double4 w = reinterpret_cast<const double4*>(U.qw)[slot];
-            double v = part[e] + fma(w.z, yu[j], w.w * yu[j + 1]);
-            const double p = own[e];
-            if (tophat) v = p * (v * cpmath::recip(fma(p - v, (q < U.nq ? tophat[q] : 0.), v)));      // pk / ((pk / pknow - 1) tophat + 1), as splice_uniform_kernel forms it
-            if (q >= U.gfirst && q < U.gend && !(CP_TAIL_ABLATE & 16)) outrow[q] = v;
-        }
-    }
-}
-
-template <int SU>
-__global__ __launch_bounds__(256, 2) void wallish_tail_kernel(const TailArgs G) {
-    constexpr int N = 4096, P = 16, NS = N / 2, S = 32;
-    using PL = Plan<N, P>;
-    constexpr int T = PL::T;
-    using namespace cpdd;
-    static_assert(!padded_lds(N, P) && lds_data_slots(N, P) == N, "four sequences of 2048 doubles / two real rows of 4096 fill the data region");
-    const Args& A = G.dst;
-    const cpsu::Tables& U = G.U;
-    extern __shared__ __attribute__((aligned(4096))) char smem[];
-    cplx* lds = reinterpret_cast<cplx*>(smem);
-    cplx* ltw = lds + N;
-    double* dd_tabs = reinterpret_cast<double*>(ltw + (PL::TW_TOTAL - N));
-    const int t = threadIdx.x, wave = t >> 6;
-    for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = A.tw[N + i];
-    fill_tables(dd_tabs);
-    __shared__ int bad_row[2];
-    __shared__ cpmath::MathTables mt;      // (the barrier at the top of the first pair covers the fills)
-    cpmath::fill_math_tables(&mt);
-    const long long npairs = (A.nrows + 1) / 2;
-    const double fn = sqrt(2. / N), fl = sqrt(1. / N);
-    const double nan = __builtin_nan("");
-    double* seqs = reinterpret_cast<double*>(lds);      // sequence w (row w >> 1, parity w & 1) at seqs + w NS, XOR layout; later: row a | row b, natural order
-    double na[P], nb[P];
-    auto fetch = [&](long long p) {      // the pair's rows as they lie in memory: every coefficient read once
-        const double* ra = G.coef + 2 * p * N;
-        const double* rb = 2 * p + 1 < A.nrows ? ra + N : ra;
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-            na[r] = ra[t + T * r];
-            nb[r] = rb[t + T * r];
-        }
-    };
-    if ((long long)blockIdx.x < npairs) fetch(blockIdx.x);
-    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
-        const bool has_b = 2 * p + 1 < A.nrows;
-        if (t == 0) bad_row[0] = bad_row[1] = 0;
-        __syncthreads();      // the data region is free (and the tables are filled)
-        // ---- 1. the four sequences into LDS; a row with a sample that is not finite is left out of the transform and comes out as NaN (dst_kernel) ----
-        {
-            bool bad_a = false, bad_b = false;
-#pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const int i = t + T * r;      // split layout: [even-indexed | odd-indexed] coefficients
-                const int slot = (i >> 11) * NS + Xor32Layout::at(i & (NS - 1));
-                seqs[slot] = na[r];
-                seqs[2 * NS + slot] = nb[r];
-                bad_a |= !(fabs(na[r]) <= 1.7976931348623157e308);
-                bad_b |= !(fabs(nb[r]) <= 1.7976931348623157e308);
-            }
-            if (bad_a) bad_row[0] = 1;
-            if (bad_b && has_b) bad_row[1] = 1;
-        }
-        __syncthreads();
-        if (p + gridDim.x < npairs) fetch(p + gridDim.x);
-        int lane = t & 63;
-        asm volatile("" : "+v"(lane));
-        // what the spline step takes of the first array, requested now: the row's values at the queries that go through the spline and the knots
-        // outside the stretch (waves 0 and 1: rows a and b)
-        const long long myrow = 2 * p + (wave & 1);
-        const bool spline_wave = wave < 2 && (wave == 0 || has_b), copy_wave = wave >= 2 && (wave == 2 || has_b);
-        double own[cpsu::NGB], gvl = 0., gvr = 0.;
-#pragma unroll
-        for (int e = 0; e < cpsu::NGB; ++e) own[e] = 0.;
-        auto fetch_own = [&]() {
-            const double* pkrow = G.pk + myrow * U.nq;
-#pragma unroll
-            for (int e = 0; e < cpsu::NGB; ++e) {
-                const int q = 64 * (U.gb0 + e) + lane;
-                if (e < U.ngb && q < U.nq) own[e] = pkrow[q];
-            }
-            if (lane < U.wl) gvl = pkrow[U.col_l + lane];
-            if (lane < U.wr) gvr = pkrow[U.col_r + lane];
-        };
-        if (CP_TAIL_OWN_EARLY && spline_wave) fetch_own();
-        // ---- 2. second derivatives, box, box rewritten: wave w <-> sequence w ----
-        if ((wave < 2 || has_b) && !(CP_TAIL_ABLATE & 1)) {
-            double* buf = seqs + wave * NS;
-            const long long row = 2 * p + (wave >> 1), srow = 2 * row + (wave & 1);
-            double m[S];
-            int first, second;
-            second_derivatives_and_box_recursive<Xor32Layout>(buf, lane, G.margin_first, G.margin_second, m, first, second);
-            if (lane == 0) {
-                G.box[2 * srow] = first + G.off0;
-                G.box[2 * srow + 1] = second + G.off1;
-            }
-            bool finite;
-            remove_box_parallel<S, Xor32Layout, true>(buf, dd_tabs + DD_NTAB, lane, first + G.off0, second + G.off1, G.coef + row * N + (wave & 1) * NS, &finite);
-            if (!finite) bad_row[wave >> 1] = 1;
-        }
-        __syncthreads();
-        // ---- 3. Hermitian-symmetrised, conjugated spectrum of the pair from the sequences (dst_kernel's, coefficient j of a row = knot j >> 1 of its sequence j & 1) ----
-        const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
-        int tt = t;
-        asm volatile("" : "+v"(tt));
-        cplx x[P];
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-            const int k = tt + T * r;
-            const double fa = k == 0 ? fl : fn;
-            const int ia = N - 1 - k, ib = k == 0 ? N - 1 : k - 1;
-            const int sa = (ia & 1) * NS + Xor32Layout::at(ia >> 1), sb = (ib & 1) * NS + Xor32Layout::at(ib >> 1);
-            const double Aa = fa * seqs[sa], Ab = fa * seqs[2 * NS + sa];
-            const double fb = k == 0 ? fa : fn;
-            const double Ba = fb * seqs[sb], Bb = fb * seqs[2 * NS + sb];
-            const cplx rot = A.rot[k];
-            const double cs = rot.re, sn = -rot.im;
-            cplx Ha, Hb;
-            if (k == 0) {
-                Ha = cplx{Aa, 0.};
-                Hb = cplx{Ab, 0.};
-            } else {
-                Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
-                Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
-            }
-            if (skip_a) Ha = cplx{0., 0.};
-            if (skip_b || !has_b) Hb = cplx{0., 0.};
-            x[r].re = Ha.re - Hb.im;
-            x[r].im = -(Ha.im + Hb.re);
-        }
-        __syncthreads();      // every read of the sequences is done: the transform takes the region
-        if (!(CP_TAIL_ABLATE & 2)) dif_all<N, P>(tt, A, x, lds, ltw);
-        else {
-            Pass<N, P, 0>::store_lds(tt, lds, x);
-            __syncthreads();
-        }
-        asm volatile("" : "+v"(tt));
-        // ---- 4. exp(.) / k_lin on the stretch; the pair as two real rows in natural order ----
-        {
-            double va[P], vb[P];
-            const int u_lo = U.col_u, u_hi = U.col_u + U.nm;
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-                const int n = tt + T * s;
-                const bool even = (n & 1) == 0;
-                const int m = even ? n / 2 : N - 1 - (n - 1) / 2;
-                const cplx g = lds_at<N, P>(lds, pos_of_freq<N, P>(m));
-                double ya = even ? g.re : -g.re;
-                double yb = even ? -g.im : g.im;
-                if (T * s < u_hi && T * s + T > u_lo && !(CP_TAIL_ABLATE & 4)) {      // (uniform over the workgroup: the columns outside the stretch are never looked at)
-                    const double ik = A.ikx[n];
-                    ya = cpmath::exp_tab(ya, &mt) * ik;
-                    yb = cpmath::exp_tab(yb, &mt) * ik;
-                }
-                va[s] = skip_a ? nan : ya;
-                vb[s] = skip_b ? nan : yb;
-            }
-            __syncthreads();      // every thread holds its samples: the region is free
-#pragma unroll
-            for (int s = 0; s < P; ++s) {
-                seqs[tt + T * s] = va[s];
-                seqs[N + tt + T * s] = vb[s];
-            }
-        }
-        __syncthreads();
-        // ---- 5. the spliced spline at the filter's wavenumbers, damping ----
-        asm volatile("" : "+v"(lane));
-        if (spline_wave && !(CP_TAIL_ABLATE & 8)) {
-            if (!CP_TAIL_OWN_EARLY) fetch_own();
-            tail_splice_row<SU>(U, seqs + (wave & 1) * N + U.col_u, G.pk + myrow * U.nq, G.tophat, G.out + myrow * U.nq, lane, gvl, gvr, own);
-        } else if (copy_wave && !(CP_TAIL_ABLATE & 16)) {
-            const double* src = G.pk + myrow * U.nq;
-            double* dst = G.out + myrow * U.nq;
-            for (int q0 = 0; q0 < U.nq; q0 += 256) {      // four loads in flight
-                double v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = q0 + 64 * u + lane;
-                    v[u] = (q < U.nq && !(q >= U.gfirst && q < U.gend)) ? src[q] : 0.;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int q = q0 + 64 * u + lane;
-                    if (q < U.nq && !(q >= U.gfirst && q < U.gend)) dst[q] = v[u];
-                }
-            }
-        }
-    }
-}
+#include "cp_wallish_tail.h"      // wallish_tail_kernel: everything of the filter behind its forward transform (cp_wallish_tail below)
 
 template <int N>
 void launch(bool inverse, const Args& A, int grid, hipStream_t stream) {
@@ -1027,9 +716,7 @@ extern "C" int cp_wallish_tail(const cp_dst_plan* p, const cp_splice_plan* splic
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_wallish_tail: cannot select device %d", p->device);
     TailArgs G{};
-    G.dst.in = d_coef; G.dst.out = nullptr; G.dst.nrows = nrows; G.dst.tw = p->d_tw; G.dst.rot = p->d_rot; G.dst.kx = p->d_kx; G.dst.ikx = p->d_ln_kx + 3 * (size_t)p->n;
-    G.dst.fused = 1; G.dst.split = 1;
-    G.coef = d_coef;
+    G.nrows = nrows; G.coef = d_coef; G.tw = p->d_tw; G.rot = p->d_rot; G.ikx = p->d_ln_kx + 3 * (size_t)p->n;
     G.U = U;
     G.pk = d_pk; G.tophat = d_tophat; G.out = d_out; G.box = d_box;
     G.margin_first = margin_first; G.margin_second = margin_second; G.off0 = offset_first; G.off1 = offset_second;

@@ -203,8 +203,65 @@ constexpr double dd_ipow(double x, int k) {
     return v;
 }
 
-// m[32]: the lane's second derivatives on exit; the sequence in LDS is only read.
-template <class LAY = PaddedLayout<32>>
+// ---- wave reductions by DPP (row operations within 16 lanes, then row_bcast15 / row_bcast31 across the rows: the total arrives in lane 63) ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dd_dpp(double v) {      // lanes the row mask leaves out keep their own value
+#if defined(__HIP_DEVICE_COMPILE__)
+    dd_v2i w = __builtin_bit_cast(dd_v2i, v);
+    w.x = __builtin_amdgcn_update_dpp(w.x, w.x, CTRL, ROW_MASK, 0xf, false);
+    w.y = __builtin_amdgcn_update_dpp(w.y, w.y, CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, w);
+#else
+    return v;
+#endif
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dd_dpp(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ double wave_max(double v) {      // the maximum over the wave, in every lane (no NaN among the values)
+    v = fmax(v, dd_dpp<0xB1, 0xf>(v));      // quad_perm [1, 0, 3, 2]
+    v = fmax(v, dd_dpp<0x4E, 0xf>(v));      // quad_perm [2, 3, 0, 1]
+    v = fmax(v, dd_dpp<0x141, 0xf>(v));     // row_half_mirror
+    v = fmax(v, dd_dpp<0x140, 0xf>(v));     // row_mirror
+    v = fmax(v, dd_dpp<0x142, 0xa>(v));     // row_bcast15 into rows 1 and 3
+    v = fmax(v, dd_dpp<0x143, 0xc>(v));     // row_bcast31 into rows 2 and 3
+    return cp::lane_value(v, 63);
+}
+__device__ __forceinline__ int wave_min(int v) {
+    auto mn = [](int a, int b) { return a < b ? a : b; };
+    v = mn(v, dd_dpp<0xB1, 0xf>(v));
+    v = mn(v, dd_dpp<0x4E, 0xf>(v));
+    v = mn(v, dd_dpp<0x141, 0xf>(v));
+    v = mn(v, dd_dpp<0x140, 0xf>(v));
+    v = mn(v, dd_dpp<0x142, 0xa>(v));
+    v = mn(v, dd_dpp<0x143, 0xc>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// first index of the maximum of the wave's knots i = own + t with lo <= t < hi (own, lo, hi per lane; the range may be empty in a lane); no NaN among
+// the values.  0 when the range is empty in every lane (as wave_merge returns for it).
+template <int S>
+__device__ __forceinline__ int masked_argmax(const double* m, int own, int lo, int hi) {
+    const double ninf = -__builtin_inf();
+    double b = ninf;
+#pragma unroll
+    for (int t = 0; t < S; ++t) b = fmax(b, (t >= lo && t < hi) ? m[t] : ninf);
+    const double top = wave_max(b);
+    int idx = 0x7fffffff;
+#pragma unroll
+    for (int t = S - 1; t >= 0; --t) idx = (t >= lo && t < hi && m[t] == top) ? own + t : idx;
+    idx = wave_min(idx);
+    return idx == 0x7fffffff ? 0 : idx;
+}
+
+// m[32]: the lane's second derivatives on exit (SCALED: in the units of the spline's; else short of the factor sqrt 3, which no arg-max sees); the
+// sequence in LDS is only read.
+template <class LAY = PaddedLayout<32>, bool SCALED = true>
 __device__ __forceinline__ void second_derivatives_and_box_recursive(const double* buf, int lane, int margin_first, int margin_second, double* m, int& first,
                                                                      int& second) {
     constexpr int S = 32, N = 64 * S;
@@ -250,14 +307,28 @@ __device__ __forceinline__ void second_derivatives_and_box_recursive(const doubl
             m[t] += c;
         }
     }
-    // arg-max over [margin_first, n - margin_first): first index on ties, NaN as the largest value (numpy's argmax); the walk runs towards smaller
-    // i, so an equal value replaces the one held
+    // arg-max over [margin_first, n - margin_first) and over [first + margin_second, n - margin_first): first index on ties, NaN as the largest value
+    // (numpy's argmax).  Sequences without a NaN -- a wave-uniform test on a sum that any NaN (or infinity) poisons -- take masked_argmax: the lane's
+    // maximum as a chain of v_max, the wave's by DPP, the index from one pass of equality tests: a third of the instructions of the general walk,
+    // which tracks value and index side by side with NaN-aware comparisons (it stays for the sequences that need it).
+    double poison = 0.;
+#pragma unroll
+    for (int t = 0; t < S; ++t) {
+        if (SCALED) m[t] *= SCALE;
+        poison = fma(m[t], 0., poison);
+    }
+    if (__builtin_amdgcn_ballot_w64(poison != 0.) == 0) {      // (NaN != 0 holds: the ballot is zero when every lane's sum is a clean zero)
+        const int lo1 = margin_first - own, hi1 = N - margin_first - own;
+        first = masked_argmax<S>(m, own, lo1, hi1);
+        const int lo2 = first + margin_second - own;
+        second = masked_argmax<S>(m, own, lo2, hi1);
+        return;
+    }
     double best = -__builtin_inf();
     int best_i = 0x7fffffff;
 #pragma unroll
-    for (int t = S - 1; t >= 0; --t) {
+    for (int t = S - 1; t >= 0; --t) {      // (the walk runs towards smaller i, so an equal value replaces the one held)
         const int i = own + t;
-        m[t] *= SCALE;
         const bool inside = i >= margin_first && i < N - margin_first;
         if (inside && ((m[t] != m[t]) || (!(best != best) && m[t] >= best))) {
             best = m[t];

@@ -6,10 +6,76 @@ Utilities with the reference's names (cosmoprimo/utils.py): :class:`LeastSquareS
 "negligible"); the BAO filters turn its solution into a dense operator that is applied to all columns on the device
 (:func:`cosmoprimo_amd.bao_filter._constrained_lsq_operator`).  ``DistanceToRedshift`` is a device spline (:class:`Interpolator1D`).
 """
+import functools
+import inspect
+
 import numpy as np
 
-from ._device import Copyable as _Copyable
+from ._device import Copyable as _Copyable, float_dtype as _float_dtype, is_torch as _is_torch
 from .interpolator import Interpolator1D
+
+
+class BaseClass(_Copyable):
+    """Base class with the reference's ``copy()`` / ``__copy__`` (utils.py:51-64): a shallow copy."""
+
+    def __copy__(self):
+        other = self.__class__.__new__(self.__class__)
+        other.__dict__.update(self.__dict__)
+        return other
+
+    def copy(self):
+        return self.__copy__()
+
+
+def addproperty(*attrs):
+    """Class decorator of the reference (utils.py:67-87): read-only properties ``attr`` for values stored as ``_attr``."""
+    def decorate(cls):
+        for attr in attrs:
+            setattr(cls, attr, property(functools.partial(lambda self, name: getattr(self, '_' + name), name=attr)))
+        return cls
+    return decorate
+
+
+def flatarray(iargs=(0,), dtype=np.float64):
+    """Method decorator of the reference (utils.py:98-138): the array arguments ``iargs`` (positions behind ``self``) reach the method flattened --
+    they must share one shape --, and its result (an array or a dict of arrays, last axis = the flat one) is given that shape back, float32 only
+    if every such input was float32.  The sections of this package do the same inside their kernels' wrappers; this is for code written
+    against the reference's helper."""
+    positions = tuple(iargs)
+
+    def decorate(method):
+        signature = inspect.signature(method)
+
+        @functools.wraps(method)
+        def wrapper(*args, **kwargs):
+            bound = signature.bind_partial(*args, **kwargs)
+            bound.apply_defaults()
+            obj, rest = bound.args[0], list(bound.args[1:])
+            out_dtype = _float_dtype(*[rest[i] for i in positions])
+            in_dtype = out_dtype if dtype is None else dtype
+            shape = None
+            for i in positions:
+                value = rest[i]
+                value = value.detach().cpu().numpy() if _is_torch(value) else value
+                flat = np.asarray(value, dtype=in_dtype)
+                if shape is None:
+                    shape = flat.shape
+                elif flat.shape != shape:
+                    raise ValueError('input arrays must have same shape, found {}, {}'.format(shape, flat.shape))
+                rest[i] = flat.ravel()
+            result = method(obj, *rest, **bound.kwargs)
+
+            def restore(value):
+                value = np.asarray(value, dtype=out_dtype)
+                return value.reshape(value.shape[:-1] + shape)
+
+            if isinstance(result, dict):
+                return {key: restore(value) for key, value in result.items()}
+            return restore(result)
+
+        return wrapper
+
+    return decorate
 
 
 class LeastSquareSolver(_Copyable):

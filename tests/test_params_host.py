@@ -90,3 +90,49 @@ def test_clone_equality_persistence(tmp_path, golden):
     with pytest.raises(AttributeError):
         cosmo.comoving_radial_distance
     assert 'tau_reio' not in dir(cosmo) and 'comoving_radial_distance' not in dir(cosmo)
+
+
+def test_reference_helper_names(golden):
+    """The small names of the reference a caller may import (cosmology.py:188-200, 848-852, 1940-1952; utils.py:51-138), by name: the knots against the
+    golden grids of the reference, compute_ncdm_momenta against the reference's tabulated density, the decorators by behaviour."""
+    import warnings
+    import numpy as np
+    from cosmoprimo_amd import Cosmology
+    from cosmoprimo_amd.cosmology import get_default_z_interp, compute_ncdm_momenta
+    from cosmoprimo_amd import utils
+    g = golden('ncdm')
+    np.testing.assert_allclose(get_default_z_interp('rho_ncdm'), g['ncdm_knots'], rtol=1e-15)
+    np.testing.assert_allclose(get_default_z_interp('p_ncdm'), g['ncdm_knots'], rtol=1e-15)
+    zc = get_default_z_interp('comoving_radial_distance')
+    assert zc.shape == (119,) and zc[0] == 0. and abs(zc[-1] - 9999.) < 1e-8 and get_default_z_interp('time').shape == (400,)
+    with pytest.raises(ValueError):
+        get_default_z_interp('nope')
+    # the tabulated density of the last golden cosmology: rho(z) = momenta / (1 + z)^3 / h^2 on the knots (cosmology.py:441-442)
+    from oracle.gen_golden import NCDM_PARAMS
+    par = NCDM_PARAMS[-1]
+    T = 2.7255 * np.atleast_1d(par['T_ncdm_over_cmb'])[0]
+    zk = g['ncdm_knots']
+    rho = compute_ncdm_momenta(T, np.atleast_1d(par['m_ncdm'])[0], zk, out='rho') / (1 + zk)**3 / par.get('h', 0.7)**2
+    np.testing.assert_allclose(rho, g['rho_ncdm_table'][:, 0], rtol=1e-13)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        assert Cosmology.get_default_parameters() == Cosmology.get_default_params()
+    assert any('deprecated' in str(w.message) for w in caught)
+
+    @utils.addproperty('a', 'b')
+    class Holder(utils.BaseClass):
+        def __init__(self):
+            self._a, self._b = 1, [2]
+
+        @utils.flatarray(iargs=[0, 1], dtype=None)
+        def add(self, x, y, scale=1.):
+            assert x.ndim == 1 and y.ndim == 1
+            return {'sum': scale * (x + y), 'pair': np.array([x, y])}
+
+    h = Holder()
+    c = h.copy()
+    assert (h.a, h.b) == (1, [2]) and c is not h and c.b is h.b
+    out = h.add(np.ones((2, 3), dtype='f4'), np.full((2, 3), 2., dtype='f4'), scale=2.)
+    assert out['sum'].shape == (2, 3) and out['sum'].dtype == np.float32 and out['pair'].shape == (2, 2, 3) and np.all(out['sum'] == 6.)
+    with pytest.raises(ValueError):
+        h.add(np.ones(3), np.ones(4))
