@@ -512,7 +512,10 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
 }
 
 
-#include "cp_wallish_tail.h"      // wallish_tail_kernel: everything of the filter behind its forward transform (cp_wallish_tail below)
+#ifndef CP_TAIL_HEADER      // (measurements: another version of the kernel, tools/variants/, built beside the shipped library by tools/variant_lib.sh)
+#define CP_TAIL_HEADER "cp_wallish_tail.h"
+#endif
+#include CP_TAIL_HEADER      // wallish_tail_kernel: everything of the filter behind its forward transform (cp_wallish_tail below)
 
 template <int N>
 void launch(bool inverse, const Args& A, int grid, hipStream_t stream) {

@@ -1,0 +1,414 @@
+// cp_wallish_tail.h -- wallish2018 behind its forward transform as ONE kernel (reference bao_filter.py:373-431).  Part of cp_dst.hip (included inside its
+// anonymous namespace, behind the transform kernels whose pass machinery it uses); the C entry point cp_wallish_tail is at the end of that file.
+//
+// The three steps that follow the forward sine transform -- second derivatives of the two coefficient sequences, the box between their maxima and its
+// removal (:373-405: wallish_dd_box_kernel), the inverse transform with exp(.) / k_lin (:407-413: dst_kernel<..., true>) and the clamped spline through
+// the spliced knots at the filter's wavenumbers with the damping (:415-431: splice_uniform_kernel) -- each read what the one before had written:
+// 34 + 34 + 33 KB read and 33 KB written per vector for 16 KB that have to move (the 8 KB row of P in, the 8 KB result out), at 5 500 + 2 733 + 1 073
+// vector instructions per vector (profiles/r4y_config4_traffic.json, r4y_config4_valu.json).  Here a workgroup takes a PAIR of vectors through all of it
+// on the CU: the pair's four sequences of 2048 coefficients fill the 64 KB data region of the 4096-point transform (XOR layout of cp_wallish_dd.h), a wave
+// each; the boxes are rewritten there (and in memory, where the filter keeps the sequences); the packed spectrum of the inverse transform is formed
+// from LDS; the transformed pair goes back into the same region as two real rows in natural order, on which waves 0 and 1 run the recursions of the
+// spliced spline (cp_splice_uniform.h: a lane owns SU consecutive knots of the uniform stretch, its second derivatives overwrite them) while waves 2
+// and 3 take the queries' knot values, copy the columns that do not go through the spline and evaluate the queries.  Per vector: 32 KB of coefficients + 8 KB of P in, 8 KB out.
+struct TailArgs {
+    long long nrows;
+    double* coef;              // (nrows, 4096) coefficient rows, split layout; the boxes are rewritten in place (what cp_wallish_dd_box leaves there)
+    const cplx* tw;            // the transform plan: twiddles, e^{-i pi k / 2N}, 1 / k_lin
+    const cplx* rot;
+    const double* ikx;
+    cpsu::Tables U;            // the uniform-stretch scheme of the splice plan: stretch from the transformed rows (src_u = 1), outer knots from P (array 0)
+    const double* pk;          // (nrows, nq)
+    const double* tophat;      // (nq) or null
+    double* out;               // (nrows, nq)
+    int* box;                  // (2 nrows, 2)
+    int margin_first, margin_second, off0, off1;
+};
+
+#ifndef CP_TAIL_ABLATE      // diagnostic builds (wrong results): 1 no second derivatives / box, 2 no transform, 4 no exponential, 8 no splice, 16 no stores of the result
+#define CP_TAIL_ABLATE 0
+#endif
+#ifndef CP_TAIL_KERNARG_RELOAD      // 0: the arguments as an ordinary by-value parameter, live over the whole loop (measurements)
+#define CP_TAIL_KERNARG_RELOAD 1
+#endif
+
+// The kernel's arguments are read where they are used, through the constant address space from a pointer the compiler cannot see through: held in
+// scalar registers for the whole loop over pairs they (and what is derived from them) were ~130 values for 102 registers, and every use of a spilled
+// one is a v_readlane -- a quarter of the vector instructions of the spline step, a tenth of the kernel's.
+typedef const TailArgs __attribute__((address_space(4))) * TailArgsK;
+__device__ __forceinline__ TailArgsK tail_args() {
+    TailArgsK p = (TailArgsK)__builtin_amdgcn_kernarg_segment_ptr();      // the kernel's only explicit argument: offset 0 of the segment
+    if (CP_TAIL_KERNARG_RELOAD) asm volatile("" : "+s"(p));
+    return p;
+}
+
+// The spliced spline of a row is the work of TWO waves (cpsu::splice_uniform_kernel's arithmetic, statement for statement, dealt out): the row's
+// SOLVING wave (waves 0 / 1 for rows a / b) forms the junction sums and the second differences of its lanes' knots, runs the recursions and writes the
+// second derivatives over the knots; its QUERY wave (waves 2 / 3) takes the queries' knot values before that, copies the columns that do not go
+// through the spline while the recursions run, and evaluates + damps + stores behind them.  Two workgroup barriers order the two (every wave of the
+// workgroup meets them).  One wave doing all of it left the other two of the workgroup idle for a third of the pair's time.
+//
+// `row`: the transformed row in LDS, natural order (its stretch starts at column col_u; the slot in front of the stretch and the slots behind it up to
+// 64 SU belong to the row and are free).
+
+// query wave, before the second derivatives take the knots' place: part[e] = w.x y_j + w.y y_{j+1}
+__device__ __forceinline__ void tail_query_values(const double* row, int lane, double gl_last, double gr_first, double* part) {
+    TailArgsK g = tail_args();
+    const int nm = g->U.nm, ngb = g->U.ngb;
+    const double* yu = row + g->U.col_u;
+    const int* qe = g->U.qe;
+    const double4* qw = reinterpret_cast<const double4*>(g->U.qw);
+#pragma unroll
+    for (int e = 0; e < cpsu::NGB; ++e) {
+        part[e] = 0.;
+        if (e < ngb) {
+            const int slot = 64 * e + lane;
+            const int j = qe[slot];
+            const double4 w = qw[slot];
+            const double ya = yu[j], yb = yu[j + 1];      // (j = -1 and j + 1 = nm read slots of the row that hold no knot: replaced)
+            part[e] = fma(w.x, j < 0 ? gl_last : ya, w.y * (j + 1 >= nm ? gr_first : yb));
+        }
+    }
+}
+
+// query wave, behind the recursions: v = part + w.z M_j + w.w M_{j+1}, then pk / ((pk / pknow - 1) tophat + 1) as splice_uniform_kernel forms it
+__device__ __forceinline__ void tail_evaluate(const double* row, double* outrow, int lane, const double* part, const double* own) {
+    TailArgsK g = tail_args();
+    const int ngb = g->U.ngb, gb0 = g->U.gb0, nq = g->U.nq, gfirst = g->U.gfirst, gend = g->U.gend;
+    const double* yu = row + g->U.col_u;
+    const int* qe = g->U.qe;
+    const double4* qw = reinterpret_cast<const double4*>(g->U.qw);
+    const double* tophat = g->tophat;
+#pragma unroll
+    for (int e = 0; e < cpsu::NGB; ++e) {
+        if (e < ngb) {
+            const int slot = 64 * e + lane, q = 64 * gb0 + slot;
+            const int j = qe[slot];
+            const double4 w = qw[slot];
+            double v = part[e] + fma(w.z, yu[j], w.w * yu[j + 1]);
+            const double p = own[e];
+            if (tophat) v = p * (v * cpmath::recip(fma(p - v, (q < nq ? tophat[q] : 0.), v)));
+            if (q >= gfirst && q < gend && !(CP_TAIL_ABLATE & 16)) outrow[q] = v;
+        }
+    }
+}
+
+// solving wave, first half: the junction sums (A / p, M_left, B, M_right: weighted sums over the differences of the knots next to the two junctions)
+// and the second differences of the lane's knots (beyond either end of the stretch its end value again)
+template <int SU>
+__device__ __forceinline__ void tail_differences(const double* row, int lane, double gvl, double gvr, double* sums, double* g) {
+    using cpsu::WIN_U;
+    TailArgsK g0 = tail_args();
+    const int nm = g0->U.nm, wl = g0->U.wl;
+    const double* yu = row + g0->U.col_u;
+    const double gl_last = __shfl(gvl, wl > 0 ? wl - 1 : 0), gr_first = __shfl(gvr, 0);
+    {
+        const double* win = g0->U.win;
+        double ww[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) ww[o] = win[64 * o + lane];
+        const double ul = yu[lane < WIN_U ? lane : 0], ur = yu[lane < WIN_U ? nm - 1 - lane : 0];
+        const double yfirst = yu[0], ylast = yu[nm - 1];
+        sums[0] = fma(ww[0], gvl - yfirst, ww[1] * (ul - yfirst));
+        sums[1] = fma(ww[2], gvl - gl_last, ww[3] * (ul - gl_last));
+        sums[2] = fma(ww[4], ur - ylast, ww[5] * (gvr - ylast));
+        sums[3] = fma(ww[6], ur - gr_first, ww[7] * (gvr - gr_first));
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) sums[o] += __shfl_xor(sums[o], off);
+    }
+    const int base = SU * lane - 1;
+    auto yk = [&](int i) { return yu[i < 0 ? 0 : (i > nm - 1 ? nm - 1 : i)]; };
+    double y1 = yk(base + 1);
+    double dprev = y1 - yk(base);
+#pragma unroll
+    for (int t = 0; t < SU; ++t) {
+        const double y2 = yk(base + t + 2);
+        const double dn = y2 - y1;
+        g[t] = dn - dprev;
+        dprev = dn;
+        y1 = y2;
+    }
+}
+
+// solving wave, second half (every read of the knot values is done): the two recursions over the lane's knots from zero, the neighbours' totals, the
+// second derivatives (unscaled) over the knots; M_left and M_right into the slots on either side of the stretch
+template <int SU>
+__device__ __forceinline__ void tail_recursions(double* row, int lane, const double* sums, double* g) {
+    using cpsu::P;
+    TailArgsK g0 = tail_args();
+    const int nm = g0->U.nm, lane_b = g0->U.lane_b;
+    double* yu = row + g0->U.col_u;
+    const double m_b = lane == lane_b ? g0->U.mb0 : (lane == lane_b - 1 ? g0->U.mb1 : 0.);
+    const double m_a = lane == 0 ? 1. : 0.;
+#pragma unroll
+    for (int t = SU - 2; t >= 0; --t) g[t] = fma(P, g[t + 1], g[t]);
+    double c = fma(m_b, sums[2], cpdd::dd_from_right(g[0]));      // G at the first knot of the next segment (+ what B adds there)
+    double f = 0.;
+#pragma unroll
+    for (int t = 0; t < SU; ++t) {
+        const double e = fma(P, f, g[t]);
+        f = t + 1 < SU ? fma(-P, g[t + 1], e) : e;
+        g[t] = e;
+    }
+#pragma unroll
+    for (int t = SU - 1; t >= 0; --t) {
+        c *= P;
+        g[t] += c;
+    }
+    c = fma(m_a, sums[0], cpdd::dd_from_left(f));                 // F at the last knot of the previous segment (+ A / p in lane 0)
+#pragma unroll
+    for (int t = 0; t < (SU < 36 ? SU : 36); ++t) {
+        c *= P;
+        g[t] += c;
+    }
+    double* mine = yu + SU * lane;
+#pragma unroll
+    for (int t = 0; t < SU; ++t) mine[t] = g[t];
+    cp::wave_lds_phase();      // (the slots on either side of the stretch are written behind the lanes' own)
+    if (lane == 0) yu[-1] = sums[1];
+    if (lane == 1) yu[nm] = sums[3];
+}
+
+template <int SU>
+__global__ __launch_bounds__(256, 2) void wallish_tail_kernel(const TailArgs G_by_value) {
+    constexpr int N = 4096, P = 16, NS = N / 2, S = 32;
+    using PL = Plan<N, P>;
+    constexpr int T = PL::T;
+    using namespace cpdd;
+    static_assert(!padded_lds(N, P) && lds_data_slots(N, P) == N, "four sequences of 2048 doubles / two real rows of 4096 fill the data region");
+    extern __shared__ __attribute__((aligned(4096))) char smem[];
+    cplx* lds = reinterpret_cast<cplx*>(smem);
+    cplx* ltw = lds + N;
+    double* dd_tabs = reinterpret_cast<double*>(ltw + (PL::TW_TOTAL - N));
+    const int t = threadIdx.x;
+    long long npairs;
+    {
+        TailArgsK g = tail_args();
+        const cplx* tw = g->tw;
+        for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = tw[N + i];
+        npairs = (g->nrows + 1) / 2;
+    }
+    fill_tables(dd_tabs);
+    __shared__ int bad_row[2];
+    __shared__ cpmath::MathTables mt;      // (the barrier at the top of the first pair covers the fills)
+    cpmath::fill_math_tables(&mt);
+    const double fn = sqrt(2. / N), fl = sqrt(1. / N);
+    const double nan = __builtin_nan("");
+    double* seqs = reinterpret_cast<double*>(lds);      // sequence w (row w >> 1, parity w & 1) at seqs + w NS, XOR layout; later: row a | row b, natural order
+    double na[P], nb[P];
+    auto fetch = [&](long long p) {      // the pair's rows as they lie in memory: every coefficient read once
+        TailArgsK g = tail_args();
+        int tf = t;
+        asm volatile("" : "+v"(tf));      // (nothing derived from the thread's number is kept in registers from one pair to the next)
+        const double* ra = g->coef + 2 * p * N + tf;
+        const double* rb = 2 * p + 1 < g->nrows ? ra + N : ra;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            na[r] = ra[T * r];
+            nb[r] = rb[T * r];
+        }
+    };
+    if ((long long)blockIdx.x < npairs) fetch(blockIdx.x);
+    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const bool has_b = 2 * p + 1 < tail_args()->nrows;
+        if (t == 0) bad_row[0] = bad_row[1] = 0;
+        __syncthreads();      // the data region is free (and the tables are filled)
+        // ---- 1. the four sequences into LDS; a row with a sample that is not finite is left out of the transform and comes out as NaN (dst_kernel) ----
+        {
+            bool bad_a = false, bad_b = false;
+            int ts = t;
+            asm volatile("" : "+v"(ts));
+            // coefficient i = ts + 256 r of a row (split layout: [even-indexed | odd-indexed] coefficients) is knot i & 2047 of sequence i >> 11; its slot
+            // (i & 2047) ^ ((i >> 5) & 31) = 256 r' + (ts & 224) + ((ts & 31) ^ (ts >> 5) ^ 8 (r & 3)) with r' = r & 7: a thread constant XOR a constant of r
+            const int hs = (ts & 31) ^ (ts >> 5), bs = ts & 224;
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const int slot = (r >> 3) * NS + 256 * (r & 7) + bs + (hs ^ (8 * (r & 3)));
+                seqs[slot] = na[r];
+                seqs[2 * NS + slot] = nb[r];
+                bad_a |= !(fabs(na[r]) <= 1.7976931348623157e308);
+                bad_b |= !(fabs(nb[r]) <= 1.7976931348623157e308);
+            }
+            if (bad_a) bad_row[0] = 1;
+            if (bad_b && has_b) bad_row[1] = 1;
+        }
+        __syncthreads();
+        if (p + gridDim.x < npairs) fetch(p + gridDim.x);
+        int lane = t;
+        asm volatile("" : "+v"(lane));      // (as above: the wave's number and the lane are formed anew for every pair)
+        const int wave = __builtin_amdgcn_readfirstlane(lane >> 6);
+        lane &= 63;
+        // what the spline step takes of the first array, requested now: the knots outside the stretch (solving waves 0 / 1 of rows a / b), the row's
+        // values at the queries that go through the spline and the two knots next to the stretch (query waves 2 / 3)
+        const long long myrow = 2 * p + (wave & 1);
+        const bool has_row = (wave & 1) == 0 || has_b;
+        double gvl = 0., gvr = 0.;      // (query waves: gvl / gvr = the last knot in front of the stretch / the first behind it)
+        if (has_row) {
+            TailArgsK g = tail_args();
+            const int nq = g->U.nq, wl = g->U.wl, wr = g->U.wr;
+            const double* pkrow = g->pk + myrow * nq;
+            if (wave < 2) {
+                if (lane < wl) gvl = pkrow[g->U.col_l + lane];
+                if (lane < wr) gvr = pkrow[g->U.col_r + lane];
+            } else {
+                if (wl > 0) gvl = pkrow[g->U.col_l + wl - 1];
+                if (wr > 0) gvr = pkrow[g->U.col_r];
+            }
+        }
+        // ---- 2. second derivatives, box, box rewritten: wave w <-> sequence w ----
+        if ((wave < 2 || has_b) && !(CP_TAIL_ABLATE & 1)) {
+            TailArgsK g = tail_args();
+            double* buf = seqs + wave * NS;
+            const long long row = 2 * p + (wave >> 1), srow = 2 * row + (wave & 1);
+            double m[S];
+            int first, second;
+            second_derivatives_and_box_recursive<Xor32Layout, false>(buf, lane, g->margin_first, g->margin_second, m, first, second);
+            const int a = first + g->off0, b = second + g->off1;
+            if (lane == 0) {
+                int* box = g->box;
+                box[2 * srow] = a;
+                box[2 * srow + 1] = b;
+            }
+            bool finite;
+            remove_box_parallel<S, Xor32Layout, true>(buf, dd_tabs + DD_NTAB, lane, a, b, g->coef + row * N + (wave & 1) * NS, &finite);
+            if (!finite) bad_row[wave >> 1] = 1;
+        }
+        __syncthreads();
+        // ---- 3. Hermitian-symmetrised, conjugated spectrum of the pair from the sequences (dst_kernel's; coefficient j of a row = knot j >> 1 of its sequence j & 1) ----
+        const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        cplx x[P];
+        {
+            // Where coefficient j of a row sits: sequence j & 1, knot j >> 1 at slot (j >> 1) ^ ((j >> 6) & 31).  With k = tt + 256 r the two coefficients a
+            // thread takes, ia = 4095 - k and ib = k - 1, have knots 128 (15 - r) + w and 128 r + w' (w = 127 - (tt >> 1), w' = (tt - 1) >> 1, both below
+            // 128), whose slots are a thread constant XOR a constant of r, plus a constant of r -- written out: the index arithmetic of the general
+            // expression was three fifths of this stage's vector instructions (38 per coefficient pair)
+            const int wa = 127 - (tt >> 1), wb = ((tt + 255) & 255) >> 1;      // (tt = 0: its ib = 256 r - 1 belongs to the column of tt = 256, one r earlier)
+            const int base_a = ((tt & 1) ^ 1) * NS + (wa & 96), ha = (wa & 31) ^ (wa >> 5);
+            const int base_b = (((tt + 255) & 255) & 1) * NS + (wb & 96), hb = (wb & 31) ^ (wb >> 5);
+            const bool first = tt == 0;
+            const cplx* rots = tail_args()->rot;
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const int sa = base_a + 128 * (15 - r) + (ha ^ (4 * ((7 - r) & 7)));
+                const int rb = (r + 15) & 15;      // the r of ib's column for tt = 0
+                const int sb = first ? base_b + 128 * rb + (hb ^ (4 * (rb & 7))) : base_b + 128 * r + (hb ^ (4 * (r & 7)));
+                const bool k0 = r == 0 && first;
+                const double fa = k0 ? fl : fn;
+                const double Aa = fa * seqs[sa], Ab = fa * seqs[2 * NS + sa];
+                const double Ba = fa * seqs[sb], Bb = fa * seqs[2 * NS + sb];      // (f_{k-1} = f_n for k >= 1; k = 0 takes f_l and is real)
+                const cplx rot = rots[tt + T * r];
+                const double cs = rot.re, sn = -rot.im;
+                cplx Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
+                cplx Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
+                if (r == 0 && k0) {
+                    Ha = cplx{Aa, 0.};
+                    Hb = cplx{Ab, 0.};
+                }
+                if (skip_a) Ha = cplx{0., 0.};
+                if (skip_b || !has_b) Hb = cplx{0., 0.};
+                x[r].re = Ha.re - Hb.im;
+                x[r].im = -(Ha.im + Hb.re);
+            }
+        }
+        __syncthreads();      // every read of the sequences is done: the transform takes the region
+        {
+            Args A{};      // (the pass machinery of dst_kernel takes its twiddles from here)
+            A.tw = tail_args()->tw;
+            if (!(CP_TAIL_ABLATE & 2)) dif_all<N, P>(tt, A, x, lds, ltw);
+            else {
+                Pass<N, P, 0>::store_lds(tt, lds, x);
+                __syncthreads();
+            }
+        }
+        asm volatile("" : "+v"(tt));
+        // ---- 4. exp(.) / k_lin on the stretch; the pair as two real rows in natural order ----
+        {
+            double va[P], vb[P];
+            TailArgsK g = tail_args();
+            const int u_lo = g->U.col_u, u_hi = u_lo + g->U.nm;
+            const double* ikx = g->ikx;
+            // sample n = tt + 256 s of the pair sits at frequency m = n / 2 (n even) or 4095 - (n - 1) / 2 (n odd) of the network's output, digit-reversed and
+            // swizzled: with a = tt >> 1 = a0 + 16 a1 that is slot 256 a0 + 16 a1 + 136 (s & 1) + ((s >> 1) ^ a1) for even tt and its mirror image
+            // 256 (15 - a0) + 16 (15 - a1) - 120 (s & 1) + ((s >> 1) ^ a1) for odd tt -- a thread constant, a constant of s and one XOR, where the
+            // general expression (pos_of_freq + swz) took fifty integer instructions per sample
+            const bool even = (tt & 1) == 0;
+            const int a0 = (tt >> 1) & 15, a1 = tt >> 5;
+            const int obase = even ? 256 * a0 + 16 * a1 : 256 * (15 - a0) + 16 * (15 - a1), ostep = even ? 136 : -120;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const int n = tt + T * s;
+                const cplx g = lds[obase + ostep * (s & 1) + ((s >> 1) ^ a1)];
+                double ya = even ? g.re : -g.re;
+                double yb = even ? -g.im : g.im;
+                if (T * s < u_hi && T * s + T > u_lo && !(CP_TAIL_ABLATE & 4)) {      // (uniform over the workgroup: the columns outside the stretch are never looked at)
+                    const double ik = ikx[n];
+                    ya = cpmath::exp_tab(ya, &mt) * ik;
+                    yb = cpmath::exp_tab(yb, &mt) * ik;
+                }
+                va[s] = skip_a ? nan : ya;
+                vb[s] = skip_b ? nan : yb;
+            }
+            __syncthreads();      // every thread holds its samples: the region is free
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                seqs[tt + T * s] = va[s];
+                seqs[N + tt + T * s] = vb[s];
+            }
+        }
+        __syncthreads();
+        // ---- 5. the spliced spline at the filter's wavenumbers, damping: solving waves 0 / 1, query waves 2 / 3 (see above) ----
+        asm volatile("" : "+v"(lane));
+        double* row = seqs + (wave & 1) * N;
+        const bool active = has_row && !(CP_TAIL_ABLATE & 8);
+        // Every wave of the workgroup meets two barriers here, each on its own path (`wave` and `active` are uniform over a wave, and a barrier counts
+        // the waves that arrive, wherever in the program they do): with the paths joined between the barriers the 49 second differences of the solving
+        // waves crossed the joins as that many copies, and the prefetched rows of the next pair were spilled to make room
+        if (active && wave < 2) {
+            double g[SU], sums[4];
+            tail_differences<SU>(row, lane, gvl, gvr, sums, g);
+            __syncthreads();      // every read of the knot values is done
+            tail_recursions<SU>(row, lane, sums, g);
+            __syncthreads();      // the second derivatives are in place
+        } else if (active) {
+            double part[cpsu::NGB], own[cpsu::NGB];
+            tail_query_values(row, lane, gvl, gvr, part);
+            __syncthreads();
+            {      // while the recursions run: the row's values at the queries, and the columns that do not go through the spline
+                TailArgsK g = tail_args();
+                const int nq = g->U.nq, gfirst = g->U.gfirst, gend = g->U.gend, gb0 = g->U.gb0, ngb = g->U.ngb;
+                const double* src = g->pk + myrow * nq;
+                double* dst = g->out + myrow * nq;
+#pragma unroll
+                for (int e = 0; e < cpsu::NGB; ++e) {
+                    const int q = 64 * (gb0 + e) + lane;
+                    own[e] = (e < ngb && q < nq) ? src[q] : 0.;
+                }
+                if (!(CP_TAIL_ABLATE & 16)) {
+                    for (int q0 = 0; q0 < nq; q0 += 256) {      // four loads in flight
+                        double v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + 64 * u + lane;
+                            v[u] = (q < nq && !(q >= gfirst && q < gend)) ? src[q] : 0.;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + 64 * u + lane;
+                            if (q < nq && !(q >= gfirst && q < gend)) dst[q] = v[u];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            TailArgsK g = tail_args();
+            tail_evaluate(row, g->out + myrow * g->U.nq, lane, part, own);
+        } else {      // (a wave without a row: the last vector of an odd batch has no partner)
+            __syncthreads();
+            __syncthreads();
+        }
+    }
+}
