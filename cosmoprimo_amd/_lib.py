@@ -99,6 +99,8 @@ SIGNATURES = {
     'cp_spline_plan_info': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, _c_int_p]),
     'cp_spline_plan_columns': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p]),
     'cp_spline_columns_scratch_doubles': (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
+    'cp_spline_rows_at_queries': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_spline_columns': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_wallish_box': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,

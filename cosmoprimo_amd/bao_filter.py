@@ -639,9 +639,32 @@ def _savgol_operator(n, window, polyorder=4):
 class _OperatorFilterMixin(object):
 
     def _eh_nowiggle(self, k):
-        """Eisenstein & Hu no-wiggle P(k, z=0) of ``cosmo`` on the device (reference: Fourier(cosmo, engine='eisenstein_hu_nowiggle'))."""
-        pknow = np.asarray(Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k, z=0.), dtype='f8')
-        return dv.upload(pknow, self.device)
+        """Eisenstein & Hu no-wiggle P(k, z=0) of ``cosmo`` on the device (reference: Fourier(cosmo, engine='eisenstein_hu_nowiggle')): (nk,) for one
+        cosmology; for a batch of cosmologies one row per row of the input spectra, (ncol, nk) (the columns of a cosmology share its row)."""
+        fo = Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False)
+        if self._batch_size() is None:
+            return dv.upload(np.asarray(fo.pk_interpolator()(k, z=0.), dtype='f8'), self.device)
+        rows = fo.pk_interpolator()._rows_z(np.zeros(1))(np.asarray(k, dtype='f8'))      # (B, 1, nk), on the device
+        rows = rows.reshape(rows.shape[0], rows.shape[-1])
+        return rows.repeat_interleave(self._columns_per_cosmology(), dim=0) if self._columns_per_cosmology() > 1 else rows
+
+    def _batch_size(self):
+        """Number of cosmologies of a batched ``cosmo`` whose spectra the input holds row by row (one rs_drag ratio, one no-wiggle template per
+        cosmology), None for one cosmology -- the reference's case, any number of columns."""
+        nb = getattr(self._cosmo, 'batch_size', None) if self._cosmo is not None else None
+        if nb is None:
+            return None
+        ncol = self._pk_rows.shape[0]
+        if ncol % nb:
+            raise ValueError('the input holds {:d} spectra, the cosmology {:d} parameter sets'.format(ncol, nb))
+        return nb
+
+    def _columns_per_cosmology(self):
+        return self._pk_rows.shape[0] // self._batch_size()
+
+    def _per_row(self, values):
+        """Per-cosmology host values (B,) -> one per row of the input spectra."""
+        return np.repeat(np.asarray(values), self._columns_per_cosmology())
 
 
 class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
@@ -653,23 +676,45 @@ class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         self.degree, self.sigma, self.weight = degree, sigma, weight
         super(Hinton2017PowerSpectrumBAOFilter, self).__init__(pk_interpolator, **kwargs)
 
+    def _fit_operator(self, imax):
+        """The weighted, end-pinned polynomial fit in log-log space as a dense operator, for a spectrum whose maximum sits at sample ``imax`` of the
+        fitted range (reference bao_filter.py:215-235: the weights dip around the maximum); kept per position."""
+        cache = self.__dict__.setdefault('_fit_operators', {})
+        if imax not in cache:
+            logk = np.log10(self.k[self.kmask])
+            w = 1. - self.weight * np.exp(-0.5 * ((logk - logk[imax]) / self.sigma)**2)
+            gradient = np.array([((logk - np.mean(logk)) / np.std(logk))**i for i in range(self.degree + 1)])
+            cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., 2] - 2. * gradient[..., 1] + gradient[..., 0],
+                                  gradient[..., -1], gradient[..., -2] - gradient[..., -1], gradient[..., -3] - 2. * gradient[..., -2] + gradient[..., -1]])
+            A = _constrained_lsq_operator(gradient, w**2, cg, _end_constraints(logk.size, order=3), inverse=True)
+            cache[imax] = LinearOperator.dense(A, device=self.device)
+        return cache[imax]
+
     def _prepare(self):
+        """The fit's weights follow the maximum of the FIRST column of the spectrum ("approximation", :219).  A batch of cosmologies (a batched 2D
+        interpolator: one cosmology per leading index) is that many inputs of the reference: each takes the weights of its own first column -- the
+        cosmologies whose maxima fall on the same sample share an operator (the positions are read back once: one integer per cosmology)."""
+        torch = dv.torch()
         self.kmask = (self.k > 1e-4) & (self.k < 5.)
-        logk = np.log10(self.k[self.kmask])
-        logpk0 = np.log10(self._pk_rows[0].cpu().numpy()[self.kmask])       # the first column only ("approximation", :219)
-        maxk = logk[np.argmax(logpk0)]
-        w = 1. - self.weight * np.exp(-0.5 * ((logk - maxk) / self.sigma)**2)
-        gradient = np.array([((logk - np.mean(logk)) / np.std(logk))**i for i in range(self.degree + 1)])
-        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., 2] - 2. * gradient[..., 1] + gradient[..., 0],
-                              gradient[..., -1], gradient[..., -2] - gradient[..., -1], gradient[..., -3] - 2. * gradient[..., -2] + gradient[..., -1]])
-        A = _constrained_lsq_operator(gradient, w**2, cg, _end_constraints(logk.size, order=3), inverse=True)
-        self._op = LinearOperator.dense(A, device=self.device)
+        ncosmo = int(np.prod(self._lead[:-1])) if isinstance(self.pk_interpolator, PowerSpectrumInterpolator2D) and len(self._lead) > 1 else 1
+        per = self._pk_rows.shape[0] // ncosmo
+        first = self._pk_rows[::per][:, dv.upload(self.kmask, self.device)]      # the first column of every cosmology, fitted range
+        imax = torch.log10(first).argmax(dim=1).cpu().numpy()
+        imax = np.repeat(imax, per)
+        self._groups = [(self._fit_operator(int(i)), None if ncosmo == 1 else dv.upload(np.flatnonzero(imax == i), self.device)) for i in np.unique(imax)]
 
     def _compute(self):
         torch = dv.torch()
         mask = dv.upload(self.kmask, self.device)
         res = self._pk_rows.clone()
-        res[:, mask] = 10**self._op(torch.log10(self._pk_rows[:, mask]).contiguous())
+        logpk = torch.log10(self._pk_rows[:, mask]).contiguous()
+        fitted = torch.empty_like(logpk)
+        for op, rows in self._groups:
+            if rows is None:
+                fitted = op(logpk)
+            else:
+                fitted[rows] = op(logpk[rows].contiguous())
+        res[:, mask] = 10**fitted
         self._pknow_rows = res
 
 
@@ -711,21 +756,44 @@ class EHNoWigglePolyPowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectr
         self.rescale_krange = rescale_krange
         super(EHNoWigglePolyPowerSpectrumBAOFilter, self).__init__(pk_interpolator, cosmo=cosmo, **kwargs)
 
+    def _range_operator(self, first, last):
+        """The constrained fit on the wavenumbers k[first:last] as a dense operator on the ratio there; kept per range (a batch of cosmologies has a
+        few dozen different ranges)."""
+        cache = self.__dict__.setdefault('_range_operators', {})
+        if (first, last) not in cache:
+            k = self.k[first:last]
+            gradient = np.array([k**(i - 2) for i in range(6)])
+            cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
+            A = _constrained_lsq_operator(gradient, k**2, cg, _end_constraints(k.size, order=2))
+            cache[(first, last)] = LinearOperator.dense(A, device=self.device)
+        return cache[(first, last)]
+
     def _compute(self):
         torch = dv.torch()
-        krange = np.asarray(self.krange)
-        if self.rescale_krange:
-            krange = krange / self._scalar_rs_drag_ratio()
-        mask = (self.k >= krange[0]) & (self.k <= krange[1])
-        k = self.k[mask]
-        gradient = np.array([k**(i - 2) for i in range(6)])
-        cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., -1], gradient[..., -2] - gradient[..., -1]])
-        A = _constrained_lsq_operator(gradient, k**2, cg, _end_constraints(k.size, order=2))
-        pknow = self._eh_nowiggle(k)
-        tmask = dv.upload(mask, self.device)
-        ratio = (self._pk_rows[:, tmask] / pknow).contiguous()
+        krange = np.asarray(self.krange, dtype='f8')
         res = self._pk_rows.clone()
-        res[:, tmask] = LinearOperator.dense(A, device=self.device)(ratio) * pknow      # pk / (ratio / model)
+        if self._batch_size() is None:
+            if self.rescale_krange:
+                krange = krange / self._scalar_rs_drag_ratio()
+            mask = (self.k >= krange[0]) & (self.k <= krange[1])
+            first, last = int(np.flatnonzero(mask)[0]), int(np.flatnonzero(mask)[-1]) + 1
+            pknow = self._eh_nowiggle(self.k[first:last])
+            ratio = (self._pk_rows[:, first:last] / pknow).contiguous()
+            res[:, first:last] = self._range_operator(first, last)(ratio) * pknow      # pk / (ratio / model)
+            self._pknow_rows = res
+            return
+        # a batch of cosmologies: the fit depends on the cosmology through the RANGE of wavenumbers only (krange / its rs_drag ratio) -- the
+        # cosmologies that share a range share the operator (the ranges are read back once: B pairs of integers)
+        ratios = _host_value(self.rs_drag_ratio()) if self.rescale_krange else np.ones(self._batch_size())
+        ratios = np.broadcast_to(ratios, (self._batch_size(),))
+        inside = (self.k >= (krange[0] / ratios)[:, None]) & (self.k <= (krange[1] / ratios)[:, None])      # (B, nk): the reference's mask, cosmology by cosmology
+        first, last = inside.argmax(axis=1), inside.shape[1] - inside[:, ::-1].argmax(axis=1)
+        pknow = self._eh_nowiggle(self.k)                                                                   # (ncol, nk)
+        first, last = self._per_row(first), self._per_row(last)
+        for f, l in sorted(set(zip(first.tolist(), last.tolist()))):
+            rows = dv.upload(np.flatnonzero((first == f) & (last == l)), self.device)
+            now = pknow[rows, f:l]
+            res[rows, f:l] = self._range_operator(f, l)((self._pk_rows[rows, f:l] / now).contiguous()) * now
         self._pknow_rows = res
 
 
@@ -769,8 +837,47 @@ class PeakAveragePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumB
 
     def _compute(self):
         pknow = self._eh_nowiggle(self.k)
-        op = LinearOperator.dense(self._operator(self._scalar_rs_drag_ratio()), device=self.device)
-        self._pknow_rows = op(self._pk_rows / pknow) * pknow
+        if self._batch_size() is None:
+            op = LinearOperator.dense(self._operator(self._scalar_rs_drag_ratio()), device=self.device)
+            self._pknow_rows = op(self._pk_rows / pknow) * pknow
+            return
+        self._pknow_rows = self._interp_batch(self._pk_rows / pknow) * pknow
+
+    def _interp_batch(self, ratio):
+        """``_interp`` (reference bao_filter.py:565-574) for a batch of cosmologies, one rs_drag ratio each: the dense operator of one cosmology is two
+        natural splines in a row -- data on log10 k -> the moved knots (extrapolating), moved knots -> all log10 k -- and the knots move with the
+        ratio, so neither is shared.  First spline: shared knots, per-row queries (second derivatives of all rows by ``cp_spline_rows``, then
+        ``cp_spline_rows_at_queries``); second: per-row knots, shared queries (``cp_spline_columns``).  ratio : (ncol, nk) on the device."""
+        from .spline import SplineRows
+        torch = dv.torch()
+        lib = _lib.load()
+        ncol, nk = ratio.shape
+        logx = np.log10(self.k)
+        solver = self.__dict__.get('_log_solver')
+        if solver is None:
+            solver = self.__dict__['_log_solver'] = SplineRows(logx, logx, bc='natural', device=self.device)
+        ratio = ratio.contiguous()
+        second = solver.second_derivatives(ratio)
+        rescale = dv.to_device(self.rs_drag_ratio(), self.device).reshape(-1)
+        rescale = rescale.repeat_interleave(self._columns_per_cosmology()) if self._columns_per_cosmology() > 1 else rescale
+        tlogx = dv.upload(logx, self.device)
+        total = torch.zeros((nk, ncol), dtype=torch.float64, device=self.device)
+        for kp, npad in zip(self.k_peaks, self.pad_peaks):
+            # the knots' scale: 1 -> rescale over the samples kept in front, rescale at the extrema, rescale -> 1 over the samples kept behind
+            weight = np.concatenate([np.linspace(0., 1., npad[0]), np.ones(npad[1]), np.linspace(1., 0., npad[2])])
+            scale = 1. + (rescale[:, None] - 1.) * dv.upload(weight, self.device)
+            knots = (dv.upload(np.log10(kp), self.device) - torch.log10(scale)).contiguous()               # (ncol, nknots) = log10(kp / scale)
+            nknots = knots.shape[1]
+            values = torch.empty((nknots, ncol), dtype=torch.float64, device=self.device)                  # knot-major
+            _lib.check(lib.cp_spline_rows_at_queries(tlogx.data_ptr(), ratio.data_ptr(), second.data_ptr(), ncol, nk, knots.data_ptr(), nknots, values.data_ptr(), 1,
+                                                     self.device.index, dv.stream_of(self.device)))
+            xk = knots.t().contiguous()
+            out = torch.empty((nk, ncol), dtype=torch.float64, device=self.device)
+            scratch = torch.empty(int(lib.cp_spline_columns_scratch_doubles(ncol, nknots)), dtype=torch.float64, device=self.device)
+            _lib.check(lib.cp_spline_columns(xk.data_ptr(), values.data_ptr(), ncol, nknots, tlogx.data_ptr(), nk, out.data_ptr(), scratch.data_ptr(),
+                                             self.device.index, dv.stream_of(self.device)))
+            total += out
+        return (0.5 * total).t().contiguous()
 
 
 class BSplinePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumBAOFilter):

@@ -152,3 +152,59 @@ extern "C" int cp_spline_points(const double* d_xk, const double* d_y, const dou
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_points: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
+
+// ---- cubic splines of many rows, each at ITS OWN queries: one lane per (row, query) --------------------------------------------------------
+// peakaverage over a batch of cosmologies (reference bao_filter.py:565-574): the knots of the filter's two splines move with the cosmology's
+// rs_drag ratio, so the data -> moved knots step is a spline through SHARED knots (the filter's log10 k) evaluated at queries that differ from row to
+// row.  The rows' second derivatives at the knots come from cp_spline_rows_second_derivatives; here the four-term formula
+//   a y_j + b y_{j+1} + ((a^3 - a) M_j + (b^3 - b) M_{j+1}) h_j^2 / 6,  a = (x_{j+1} - x) / h_j, b = (x - x_j) / h_j,
+// with the interval found from a uniform first guess (the knots are a geomspace in log10: uniform to rounding) and set right against the knots
+// themselves.  Outside the knots the cubic of the end interval is continued (scipy's extrapolate=True).
+namespace {
+
+#pragma clang fp contract(fast)
+__global__ __launch_bounds__(256) void spline_rows_at_queries_kernel(const double* __restrict__ xk, const double* __restrict__ y, const double* __restrict__ m,
+                                                                     long long nrows, int n, const double* __restrict__ xq, int nq, double* __restrict__ out,
+                                                                     int transposed) {
+    const double x0 = xk[0], inv_h = (double)(n - 1) / (xk[n - 1] - x0);
+    const long long total = nrows * nq;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // transposed: consecutive lanes are consecutive ROWS of one query (the stores are contiguous: knot-major output, the layout cp_spline_columns reads)
+        const long long row = transposed ? i % nrows : i / nq;
+        const int q = (int)(transposed ? i / nrows : i % nq);
+        const double v = xq[row * nq + q];
+        double r = __builtin_nan("");
+        if (v == v) {
+            int j = (int)((v - x0) * inv_h);
+            j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);
+            while (j > 0 && v < xk[j]) --j;
+            while (j < n - 2 && v >= xk[j + 1]) ++j;
+            const double h = xk[j + 1] - xk[j];
+            const double a = (xk[j + 1] - v) / h, b = (v - xk[j]) / h;
+            const double* yr = y + row * n;
+            const double* mr = m + row * n;
+            r = a * yr[j] + b * yr[j + 1] + ((a * a * a - a) * mr[j] + (b * b * b - b) * mr[j + 1]) * (h * h) / 6.;
+        }
+        out[transposed ? (long long)q * nrows + row : row * nq + q] = r;
+    }
+}
+
+}  // namespace
+
+extern "C" int cp_spline_rows_at_queries(const double* d_xk, const double* d_y, const double* d_m, long long nrows, int n, const double* d_xq, int nq,
+                                         double* d_out, int transposed, int device, void* stream) {
+    if (nrows < 0 || n < 2 || nq < 0) return cp::fail(CP_EINVAL, "cp_spline_rows_at_queries: bad sizes");
+    if (nrows == 0 || nq == 0) return CP_OK;
+    if (!d_xk || !d_y || !d_m || !d_xq || !d_out) return cp::fail(CP_EINVAL, "cp_spline_rows_at_queries: null pointer");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_at_queries: cannot select device %d", device);
+    const long long blocks = (nrows * nq + 255) / 256;
+    const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
+    hipLaunchKernelGGL(spline_rows_at_queries_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_xk, d_y, d_m, nrows, n, d_xq, nq, d_out,
+                       transposed);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_rows_at_queries: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

@@ -445,6 +445,14 @@ int cp_spline_rows_plan_destroy(cp_spline_rows_plan* plan);
 int cp_tables_rows_direct(const cp_spline_rows_plan* kplan, const cp_spline_plan* zplan, const double* d_tables, const double* d_m, double* d_out,
                           long long nbatch, int post_op, double scale, void* stream);
 
+/* cubic splines of many rows through SHARED knots d_xk (n, ascending; uniformly spaced to rounding: the interval of a query is found from a uniform
+ * first guess and set right against the knots), each row evaluated at ITS OWN queries: d_y (nrows, n) values, d_m (nrows, n) second derivatives at the
+ * knots (cp_spline_rows_second_derivatives, any boundary condition), d_xq (nrows, nq); outside the knots the cubic of the end interval is continued, NaN
+ * queries give NaN.  d_out (nrows, nq), or transposed != 0: (nq, nrows), the knot-major layout cp_spline_columns reads.  peakaverage over a batch of
+ * cosmologies (bao_filter.py:565-574: the knots of its two splines move with the rs_drag ratio of the cosmology). */
+int cp_spline_rows_at_queries(const double* d_xk, const double* d_y, const double* d_m, long long nrows, int n, const double* d_xq, int nq, double* d_out,
+                              int transposed, int device, void* stream);
+
 /* the elementwise stages of the two filters over (nrows, n) batches of spectra, one pass each (csrc/cp_bao.hip):
  * cp_wallish_finish: pknow = d_a (+ d_b when not NULL: the spliced spline applied as two operators), wiggles = (pk / pknow - 1) tophat + 1,
  *   out = pk / wiggles (bao_filter.py:421-431); d_tophat : (n).

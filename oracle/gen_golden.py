@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm,
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch,
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -678,6 +678,43 @@ def gen_power_ncdm(cp):
     save('power_ncdm', **out)
 
 
+BAO_BATCH_FILTERS = ['peakaverage', 'ehpoly', 'hinton2017', 'ehsavgol', 'savgol']
+BAO_BATCH_STRIDE = 4
+
+
+def bao_batch_params(n=24, seed=7):
+    """The cosmologies of the 'bao_batch' target: rs_drag ratios to the default fiducial cosmology from 0.90 to 1.12."""
+    rng = np.random.RandomState(seed)
+    return dict(Omega_m=rng.uniform(0.24, 0.40, n), Omega_b=rng.uniform(0.04, 0.06, n), h=rng.uniform(0.6, 0.8, n), n_s=rng.uniform(0.92, 1., n))
+
+
+def gen_bao_batch(cp):
+    """f2 over batches: the P(k) filters that depend on the cosmology through its rs_drag ratio and its no-wiggle template (peakaverage, ehpoly, ehsavgol)
+    or on the spectrum's own maximum (hinton2017), cosmology by cosmology through the reference for 24 cosmologies (every 4th wavenumber kept): what a
+    batched run must reproduce entry by entry."""
+    import warnings
+    par = bao_batch_params()
+    n = len(par['h'])
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fid = cp.Cosmology(engine='eisenstein_hu')
+        acc = {name: [] for name in BAO_BATCH_FILTERS}
+        ratios = []
+        for i in range(n):
+            cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{name: float(v[i]) for name, v in par.items()})
+            interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
+            for name in BAO_BATCH_FILTERS:
+                f = cp.PowerSpectrumBAOFilter(interp, engine=name, cosmo=cosmo, cosmo_fid=fid)
+                acc[name].append(np.asarray(f.pknow)[::BAO_BATCH_STRIDE, 0])
+            ratios.append(float(f.rs_drag_ratio()))
+        for name in BAO_BATCH_FILTERS:
+            out[name] = np.array(acc[name])
+        out['rs_ratio'] = np.array(ratios)
+        out['k'] = np.asarray(f.k)[::BAO_BATCH_STRIDE]
+    save('bao_batch', **out)
+
+
 CALCULATOR_CASES = [('eisenstein_hu', {}, dict(Omega_m=0.3)), ('eisenstein_hu', {}, dict(h=0.65, n_s=0.95, w0_fld=-0.9)),
                     ('eisenstein_hu_nowiggle_variants', dict(m_ncdm=[0.06]), dict(Omega_m=0.28)), ('bbks', {}, dict(Omega_b=0.045))]
 CALCULATOR_PK_STRIDE = (8, 3)
@@ -806,6 +843,8 @@ def main():
         gen_variants(cp)
     if 'power_ncdm' in which:
         gen_power_ncdm(cp)
+    if 'bao_batch' in which:
+        gen_bao_batch(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:

@@ -1,6 +1,6 @@
 """GPU parity of the remaining P(k) BAO filters (hinton2017, savgol, ehsavgol, ehpoly, peakaverage) against
-golden vectors from the reference (tests/golden/bao2.npz) and the oracle restatement (oracle/bao.py).  Tolerance 1e-8 on pknow
-(1e-7 for hinton2017, whose degree-12 normal equations the reference inverts explicitly)."""
+golden vectors from the reference (tests/golden/bao2.npz) and the oracle restatement (oracle/bao.py).  Tolerance 1e-9 on pknow (SURVEY.md 8(d);
+1e-7 for hinton2017, whose degree-12 normal equations the reference inverts explicitly: condition number ~1e9)."""
 import warnings
 
 import numpy as np
@@ -38,7 +38,7 @@ def test_filters_1d(cp, golden, ic):
                 for j in range(2):
                     np.testing.assert_allclose(f.k_peaks[j], g['peakaverage_k_peaks%d' % j], rtol=1e-14)
                     assert tuple(f.pad_peaks[j]) == tuple(g['peakaverage_pad_peaks%d' % j])
-            np.testing.assert_allclose(f.pknow, ref, rtol=RTOL.get(eng, 1e-8), err_msg=eng)
+            np.testing.assert_allclose(f.pknow, ref, rtol=RTOL.get(eng, 1e-9), err_msg=eng)
             assert f.pknow.shape == f.pk.shape == (1024,) and np.abs(f.wiggles - 1.).max() < 0.2
     np.testing.assert_allclose(f.rs_drag_ratio(), g['c%d_rs_ratio' % ic], rtol=1e-10)
 
@@ -54,9 +54,9 @@ def test_filters_table(cp, golden):
             kw = dict(cosmo=cosmo, cosmo_fid=fid) if eng in ('ehsavgol', 'ehpoly', 'peakaverage') else {}
             f = cp.PowerSpectrumBAOFilter(tab, engine=eng, **kw)
             assert f.pknow.shape == (1024, 4)
-            np.testing.assert_allclose(f.pknow, g['tab_%s_pknow' % eng], rtol=RTOL.get(eng, 1e-8), err_msg=eng)
+            np.testing.assert_allclose(f.pknow, g['tab_%s_pknow' % eng], rtol=RTOL.get(eng, 1e-9), err_msg=eng)
             if eng in ('savgol', 'hinton2017'):     # same input: device operator == oracle arithmetic
-                np.testing.assert_allclose(f.pknow, getattr(obao, eng)(f.k, f.pk), rtol=RTOL.get(eng, 1e-8))
+                np.testing.assert_allclose(f.pknow, getattr(obao, eng)(f.k, f.pk), rtol=RTOL.get(eng, 1e-9))
     with pytest.raises(ValueError):
         cp.PowerSpectrumBAOFilter(tab, engine='peakaverage', cosmo=cosmo)      # cosmo_fid is mandatory
     with pytest.raises(ValueError):
@@ -78,10 +78,10 @@ def test_bspline_1d(cp, golden, ic):
         for name, constraint in BSPLINE_CASES.items():
             f = cp.PowerSpectrumBAOFilter(interp, engine='bspline', cosmo=cosmo, constraint=constraint)
             np.testing.assert_allclose(f.k, g['k'], rtol=1e-14)
-            np.testing.assert_allclose(f.pknow, g['c%d_%s' % (ic, name)], rtol=1e-8, err_msg=name)
+            np.testing.assert_allclose(f.pknow, g['c%d_%s' % (ic, name)], rtol=1e-9, err_msg=name)
             assert f.pknow.shape == (1024,)
         f = cp.PowerSpectrumBAOFilter(interp, engine='bspline', cosmo=cosmo)       # default: sigma8 is kept
-        np.testing.assert_allclose(f.pknow, g['c%d_sigma8_np1' % ic], rtol=1e-8)
+        np.testing.assert_allclose(f.pknow, g['c%d_sigma8_np1' % ic], rtol=1e-9)
     with pytest.raises(ValueError):
         cp.PowerSpectrumBAOFilter(interp, engine='bspline', cosmo=cosmo, constraint=('sigma12',))
 
@@ -96,7 +96,58 @@ def test_bspline_table(cp, golden):
             f = cp.PowerSpectrumBAOFilter(tab, engine='bspline', cosmo=cosmo, constraint=constraint)
             ref = g['tab_' + (name if name.endswith('_np1') else name + '_np1')]
             assert f.pknow.shape == ref.shape == (1024, 4)
-            np.testing.assert_allclose(f.pknow, ref, rtol=1e-8, err_msg=name)
+            np.testing.assert_allclose(f.pknow, ref, rtol=1e-9, err_msg=name)
             # same input through the oracle's per-column arithmetic
             pknow_eh = np.asarray(cp.Fourier(cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(f.k, z=0.))
-            np.testing.assert_allclose(f.pknow, obao.bspline(f.k, f.pk, pknow_eh, constraint=constraint), rtol=1e-8, err_msg=name)
+            np.testing.assert_allclose(f.pknow, obao.bspline(f.k, f.pk, pknow_eh, constraint=constraint), rtol=1e-9, err_msg=name)
+
+
+def test_f2_filters_over_a_batch_of_cosmologies(cp, golden):
+    """peakaverage, ehpoly, ehsavgol (rs_drag ratio and no-wiggle template per cosmology), hinton2017 (weights from the spectrum's own maximum), savgol: a
+    batch of 1 032 cosmologies as ONE filter run -- the 24 cosmologies of golden/bao_batch.npz (the reference, cosmology by cosmology) sit in the batch,
+    and sampled entries are what the same cosmology gives on its own."""
+    from oracle.gen_golden import bao_batch_params, BAO_BATCH_FILTERS, BAO_BATCH_STRIDE
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    g = golden('bao_batch')
+    gold = bao_batch_params()
+    ngold = len(gold['h'])
+    rng = np.random.default_rng(21)
+    nb = 1032
+    par = {name: np.concatenate([v, rng.uniform(v.min(), v.max(), nb - ngold)]) for name, v in gold.items()}
+    fid = cp.Cosmology(engine='eisenstein_hu')
+    batch = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **par)
+    interp = batch.get_fourier().pk_interpolator(z=np.array([0.]))
+    for name in BAO_BATCH_FILTERS:
+        f = PowerSpectrumBAOFilter(interp, engine=name, cosmo=batch, cosmo_fid=fid)
+        pknow = np.asarray(f.pknow)
+        assert pknow.shape == (nb, 1024, 1) and np.isfinite(pknow).all()
+        if name == 'peakaverage':
+            np.testing.assert_allclose(np.asarray(f.rs_drag_ratio().cpu())[:ngold], g['rs_ratio'], rtol=1e-12)
+        np.testing.assert_allclose(pknow[:ngold, ::BAO_BATCH_STRIDE, 0], g[name], rtol=1e-7 if name == 'hinton2017' else 1e-9, err_msg=name)
+        for i in (ngold + 3, nb - 1):
+            one = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **{key: float(v[i]) for key, v in par.items()})
+            f1 = PowerSpectrumBAOFilter(one.get_fourier().pk_interpolator(z=np.array([0.])), engine=name, cosmo=one, cosmo_fid=fid)
+            np.testing.assert_allclose(pknow[i], f1.pknow, rtol=1e-7 if name == 'hinton2017' else 1e-9, err_msg=name)
+
+
+def test_spline_rows_at_their_own_queries(cp):
+    """cp_spline_rows_at_queries (shared knots, queries per row, the end cubics continued) against scipy's natural CubicSpline row by row; both layouts."""
+    import torch
+    from scipy.interpolate import CubicSpline
+    from cosmoprimo_amd import _lib, _device as dv
+    from cosmoprimo_amd.spline import SplineRows
+    dev = torch.device('cuda', 0)
+    rng = np.random.default_rng(4)
+    x = np.log10(np.geomspace(1e-5, 1e2, 300))
+    y = np.cumsum(rng.normal(size=(7, x.size)), axis=1) * 0.1
+    xq = np.sort(rng.uniform(x[0] - 0.05, x[-1] + 0.05, (7, 41)), axis=1)
+    xq[:, 0], xq[:, -1] = x[0], x[-1]
+    ty = dv.upload(y, dev)
+    second = SplineRows(x, x, bc='natural', device=dev).second_derivatives(ty)
+    ref = np.array([CubicSpline(x, y[i], bc_type='natural', extrapolate=True)(xq[i]) for i in range(7)])
+    for transposed in (0, 1):
+        out = torch.empty((41, 7) if transposed else (7, 41), dtype=torch.float64, device=dev)
+        _lib.check(_lib.load().cp_spline_rows_at_queries(dv.upload(x, dev).data_ptr(), ty.data_ptr(), second.data_ptr(), 7, x.size, dv.upload(xq, dev).data_ptr(), 41,
+                                                         out.data_ptr(), transposed, dev.index, dv.stream_of(dev)))
+        got = out.cpu().numpy().T if transposed else out.cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-12)
