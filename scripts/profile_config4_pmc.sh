@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage (on the GPU box, from the repo root): bash scripts/profile_config4_pmc.sh <tag>
-# Config 4, one filter at a time (tools/profile_secondary.py 4w / 4b: three chunks of bench.CONFIG4_CHUNK vectors): HBM bytes per kernel from FETCH_SIZE and
+# Config 4, one filter at a time (tools/profile_secondary.py 4w / 4b: one untimed chunk and bench.CONFIG4_PROFILE_CHUNKS timed ones of bench.CONFIG4_CHUNK vectors): HBM bytes per kernel from FETCH_SIZE and
 # WRITE_SIZE in separate passes (program directly after `--`), with the calibration copies of the same session; summary: profiles/<tag>_config4_traffic.json
 tag=${1:-r4y}
 R=$PWD

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage (GPU box, repo root): bash scripts/profile_config4_valu.sh <tag>
 # Vector and matrix instruction counts of the two BAO filters (one rocprofv3 --pmc pass per filter over tools/profile_secondary.py 4w / 4b:
-# one untimed chunk, then two timed chunks of bench.CONFIG4_CHUNK vectors) -> gpurun_out/<tag>_config4_valu.json: wave-instructions per vector
+# one untimed chunk, then bench.CONFIG4_PROFILE_CHUNKS timed chunks of bench.CONFIG4_CHUNK vectors) -> gpurun_out/<tag>_config4_valu.json: wave-instructions per vector
 # of the PACKAGE'S OWN kernels (framework and runtime kernels are listed apart), kernel by kernel, stamped with the library they were taken on.
 tag=${1:-r4}
 export TMPDIR=/tmp

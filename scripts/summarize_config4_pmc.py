@@ -13,7 +13,7 @@ import bench      # noqa: E402  (the chunk size the runs used)
 
 tag = sys.argv[1]
 src = 'gpurun_out/prof4pmc_%s' % tag
-VECTORS = 3 * bench.CONFIG4_CHUNK      # tools/profile_secondary.py 4w / 4b: one untimed chunk and two timed ones
+VECTORS = (1 + bench.CONFIG4_PROFILE_CHUNKS) * bench.CONFIG4_CHUNK      # tools/profile_secondary.py 4w / 4b: one untimed chunk and the timed ones
 
 
 def newest(pattern):

@@ -22,7 +22,7 @@ def main():
     elif which in ('4w', '4b'):      # one filter only (counter collection per filter)
         engine = 'wallish2018' if which == '4w' else 'brieden2022'
         bench.RAMP_S = 0.      # one untimed chunk, then the timed ones
-        n = 2 * bench.CONFIG4_CHUNK
+        n = bench.CONFIG4_PROFILE_CHUNKS * bench.CONFIG4_CHUNK      # (steady state: the first chunk builds the filter's plans and operators -- uploads that happen once per filter object)
         out = bench.config4(cp, torch, dev, bench.eh_parameters(n, 2, torch, dev), engines=(engine,), spot_check=False)
         out['vectors_through_the_filter_in_this_process'] = bench.CONFIG4_CHUNK + n
         out['chunk'] = bench.CONFIG4_CHUNK
