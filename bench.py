@@ -305,26 +305,45 @@ def config4(cp, torch, dev, par, chunk=CONFIG4_CHUNK, engines=('wallish2018', 'b
     return out
 
 
-def _config5_valu_roofline(samples_per_s):
-    """Vector-instruction roofline of config 5 from the committed census (profiles/*_config5_valu.json: SQ_INSTS_VALU of bg_kernel per sample,
-    tools/census_config5.sh): what bounds the kernel is the issue rate of the vector pipes."""
+# config 5, per interval of the quadrature grid and per sample: what the formulae ask for, independent of the kernel -- two new ordinates of 1 / E(z) (the
+# midpoint and the far end: RK4 on dy/dz = f(z) is Simpson's rule, jax.py:700-710), each E^2 = matter + radiation + curvature (3 multiply-adds in 1 + z)
+# + the dark-energy term (2 multiply-adds for the exponent, one exponential, 2 products), then its reciprocal root; the Simpson sum (4) and one row of the
+# natural spline's elimination (4: cosmology.py:2027-2042 with jax.py:135-196).  The transcendentals at the shortest forms this hardware has for doubles
+# (cp_math.h: exp 11 instructions table-driven, reciprocal square root 8 from the hardware estimate): a count of operations of the algorithm priced in
+# instructions, not a census of the kernel.
+CONFIG5_ALGORITHMIC_PER_INTERVAL = 2 * (3 + 2 + 11 + 2 + 8) + 4 + 4
+
+
+def _config5_valu_roofline(samples_per_s, z_samples=None):
+    """Vector-instruction roofline of config 5.  `achieved` / `frac`: the ALGORITHMIC instructions per sample -- the intervals a sample needs (those from
+    z = 0 up to its own, which the cumulative integral runs over, and the `reach` above it from which the spline's slope at the sample is eliminated:
+    what is left of the arbitrary start falls by 0.27 per knot, 1e-13 after 24) x CONFIG5_ALGORITHMIC_PER_INTERVAL -- x samples/s against the issue peak
+    of the vector pipes.  Beside it what bg_kernel EXECUTES per sample (committed census profiles/*_config5_valu.json: SQ_INSTS_VALU, tools/census_config5.sh)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_config5_valu.json')))
-    if not files:
-        return None
-    with open(files[-1]) as fh:
-        census = json.load(fh)
-    per = census['per_sample']
     peak = 256 * 4 * 2.4e9 / 4
-    achieved = per['SQ_INSTS_VALU'] * samples_per_s
-    # fp64 operations of the algorithm itself: ~65 of the 118 intervals per sample (those below it and `reach` above it), two ordinates of 1 / E(z)
-    # (~44 flop) and one elimination row (~12 flop) each -- what the instructions above are spent on
-    useful = 65 * (2 * 44 + 12)
-    return {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': achieved, 'peak': peak, 'unit': 'wave-instructions/s',
-            'frac': achieved / peak, 'valu_wave_instructions_per_sample': per['SQ_INSTS_VALU'], 'valu_instructions_per_thread': 64 * per['SQ_INSTS_VALU'],
-            'useful_fp64_flop_per_sample': useful, 'useful_fp64_frac_of_peak': useful * samples_per_s / (FP64_PEAK_TFLOPS * 1e12),
-            'source': os.path.relpath(files[-1], ROOT),
-            'census_taken_on_this_library': census.get('library_sha256_16') == _library_sha() if 'library_sha256_16' in census else None}
+    out = {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'peak': peak, 'unit': 'wave-instructions/s'}
+    reach = 24
+    if z_samples is not None:
+        from cosmoprimo_amd.cosmology import get_default_z_interp
+        knots = get_default_z_interp('comoving_radial_distance')
+        k = np.clip(np.searchsorted(knots, z_samples, side='right') - 1, 0, knots.size - 2)
+        needed = float(np.mean(np.minimum(k + 1 + reach, knots.size - 1)))
+    else:
+        needed = 26. + reach
+    alg = needed * CONFIG5_ALGORITHMIC_PER_INTERVAL / 64.      # wave-instructions per sample
+    out.update(achieved=alg * samples_per_s, frac=alg * samples_per_s / peak, algorithmic_wave_instructions_per_sample=alg, intervals_needed_per_sample=needed,
+               algorithmic_instructions_per_interval_and_thread=CONFIG5_ALGORITHMIC_PER_INTERVAL,
+               useful_fp64_flop_per_sample=needed * 2 * 44 + needed * 12, useful_fp64_frac_of_peak=(needed * 2 * 44 + needed * 12) * samples_per_s / (FP64_PEAK_TFLOPS * 1e12))
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_config5_valu.json')))
+    if files:
+        with open(files[-1]) as fh:
+            census = json.load(fh)
+        per = census['per_sample']
+        out['executed'] = {'valu_wave_instructions_per_sample': per['SQ_INSTS_VALU'], 'valu_instructions_per_thread': 64 * per['SQ_INSTS_VALU'],
+                           'issue_slots_used': per['SQ_INSTS_VALU'] * samples_per_s / peak, 'algorithmic_over_executed': alg / per['SQ_INSTS_VALU'],
+                           'source': os.path.relpath(files[-1], ROOT),
+                           'census_taken_on_this_library': census.get('library_sha256_16') == _library_sha() if 'library_sha256_16' in census else None}
+    return out
 
 
 def config5(torch, dev, om, w0, wa, zz, reps=5, spot_check=True):
@@ -343,9 +362,9 @@ def config5(torch, dev, om, w0, wa, zz, reps=5, spot_check=True):
         check = {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config5'], 'unit_checked': '300 sampled distances vs oracle'}
     return {'workload': 'config 5: comoving_radial_distance for %d (Omega_m, w0, wa, z) samples, one fresh cosmology per sample' % n,
             'value': n / (wall * 1e-3), 'unit': 'samples/s', 'ms': wall, 'ms_gpu_events': gpu, 'parity_spot_check': check,
-            # what bounds the kernel is the issue rate of the vector pipes: every vector instruction it executes, counted by the profiler
-            # (the intervals a sample needs -- those below it and `reach` above it -- times two ordinates of ~44 instructions, plus the eliminations)
-            'roofline': dict(_config5_valu_roofline(n / (wall * 1e-3)) or {}, hbm_GBps=n * 40 / (wall * 1e-3) / 1e9)}
+            # what bounds the kernel is the issue rate of the vector pipes: the algorithm's own operation count against the issue peak, with the
+            # instructions the kernel executes (profiler census) beside it
+            'roofline': dict(_config5_valu_roofline(n / (wall * 1e-3), zz[:200000].cpu().numpy()), hbm_GBps=n * 40 / (wall * 1e-3) / 1e9)}
 
 
 def config5_samples(n, seed, torch, dev):

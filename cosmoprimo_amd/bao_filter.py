@@ -164,6 +164,24 @@ class BasePowerSpectrumBAOFilter(dv.Copyable, metaclass=RegisteredPowerSpectrumB
         ratio = _host_value(rs_drag) / _host_value(rs_drag_fid)
         return float(ratio) if np.ndim(ratio) == 0 else ratio
 
+    def _batch_size(self):
+        """Number of cosmologies whose spectra the input holds row by row, None for one cosmology (the reference's case, any number of columns): the
+        batch size of ``cosmo`` when a batched cosmology is given (one rs_drag ratio, one no-wiggle template per cosmology)."""
+        nb = getattr(self._cosmo, 'batch_size', None) if self._cosmo is not None else None
+        if nb is None:
+            return None
+        ncol = self._pk_rows.shape[0]
+        if ncol % nb:
+            raise ValueError('the input holds {:d} spectra, the cosmology {:d} parameter sets'.format(ncol, nb))
+        return nb
+
+    def _columns_per_cosmology(self):
+        return self._pk_rows.shape[0] // self._batch_size()
+
+    def _per_row(self, values):
+        """Per-cosmology host values (B,) -> one per row of the input spectra."""
+        return np.repeat(np.asarray(values), self._columns_per_cosmology())
+
     def _scalar_rs_drag_ratio(self):
         """The ratio for filters whose operator is built for ONE ratio (a dense matrix per value): a batch of cosmologies is refused."""
         ratio = self.rs_drag_ratio()
@@ -648,23 +666,6 @@ class _OperatorFilterMixin(object):
         rows = rows.reshape(rows.shape[0], rows.shape[-1])
         return rows.repeat_interleave(self._columns_per_cosmology(), dim=0) if self._columns_per_cosmology() > 1 else rows
 
-    def _batch_size(self):
-        """Number of cosmologies of a batched ``cosmo`` whose spectra the input holds row by row (one rs_drag ratio, one no-wiggle template per
-        cosmology), None for one cosmology -- the reference's case, any number of columns."""
-        nb = getattr(self._cosmo, 'batch_size', None) if self._cosmo is not None else None
-        if nb is None:
-            return None
-        ncol = self._pk_rows.shape[0]
-        if ncol % nb:
-            raise ValueError('the input holds {:d} spectra, the cosmology {:d} parameter sets'.format(ncol, nb))
-        return nb
-
-    def _columns_per_cosmology(self):
-        return self._pk_rows.shape[0] // self._batch_size()
-
-    def _per_row(self, values):
-        """Per-cosmology host values (B,) -> one per row of the input spectra."""
-        return np.repeat(np.asarray(values), self._columns_per_cosmology())
 
 
 class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
@@ -691,12 +692,12 @@ class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         return cache[imax]
 
     def _prepare(self):
-        """The fit's weights follow the maximum of the FIRST column of the spectrum ("approximation", :219).  A batch of cosmologies (a batched 2D
-        interpolator: one cosmology per leading index) is that many inputs of the reference: each takes the weights of its own first column -- the
+        """The fit's weights follow the maximum of the FIRST column of the spectrum ("approximation", :219).  A batch of cosmologies (a batched ``cosmo``, or a
+        batched 2D interpolator: one cosmology per leading index) is that many inputs of the reference: each takes the weights of its own first column -- the
         cosmologies whose maxima fall on the same sample share an operator (the positions are read back once: one integer per cosmology)."""
         torch = dv.torch()
         self.kmask = (self.k > 1e-4) & (self.k < 5.)
-        ncosmo = int(np.prod(self._lead[:-1])) if isinstance(self.pk_interpolator, PowerSpectrumInterpolator2D) and len(self._lead) > 1 else 1
+        ncosmo = self._batch_size() or (int(np.prod(self._lead[:-1])) if isinstance(self.pk_interpolator, PowerSpectrumInterpolator2D) and len(self._lead) > 1 else 1)
         per = self._pk_rows.shape[0] // ncosmo
         first = self._pk_rows[::per][:, dv.upload(self.kmask, self.device)]      # the first column of every cosmology, fitted range
         imax = torch.log10(first).argmax(dim=1).cpu().numpy()

@@ -38,7 +38,7 @@ struct TablesN {
     // log(1 + z) and 1 / (1 + z) at the knots and at the interval midpoints zc + dx / 2: every integrand ordinate is one of them
     double lk[NK], lm[NK], ik[NK], im[NK];
     double h6[NK];            // dx / 6 (the same IEEE quotient the kernels used to form per interval: a division by 6 is not a multiplication, and it was a sixth of their instructions)
-    int reach, reach_pad;     // knots after which the backward elimination has forgotten its start (1e-18 left)
+    int reach, reach_pad;     // knots after which the backward elimination has forgotten its start (CP_BG_REACH_LEFT of it left)
 };
 using Tables = TablesN<NK_DIST>;
 
@@ -70,6 +70,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     __shared__ double ncdm_knots[CP_NCDM_NKNOTS];
     if (NCDM && A.nsp)
         for (int i = threadIdx.x; i < CP_NCDM_NKNOTS; i += blockDim.x) ncdm_knots[i] = A.ncdm_knots[i];
+    __shared__ cpmath::MathTables mt;      // the table-driven exponential of the dark-energy term (two ordinates per interval)
+    cpmath::fill_math_tables(&mt);
     __syncthreads();
     const long long nsamp = A.ncosmo * A.nz;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     // ordinates sit on the fixed grid, where log(1 + z) is tabulated: the dark-energy term of E(z) is then ONE exp() instead of pow() x exp()
     // and 1 / E(z) comes from rsqrt(E^2): no division, no sqrt per ordinate
     auto integrand = [&](double zz, double lzp1, double izp1) {
-        const double ie = inv_efunc_ln(c, zz, lzp1, izp1);
+        const double ie = inv_efunc_ln(c, zz, lzp1, izp1, &mt);
         return TIME ? (kCkms / 100.) * izp1 * ie : (kCkms / 100.) * ie;
     };
     if (!TIME && (A.kind == CP_BG_EFUNC || A.kind == CP_BG_HUBBLE)) {
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     if (!TIME) {
         // The intervals 0 .. k in knot order (the integral up to the sample and the forward elimination, exact), then the intervals above the
         // sample from `reach` knots above it downwards: the backward elimination forgets where it started at the rate of its multipliers
-        // u_j / pivot_j (T.reach: after that many knots 1e-18 is left, build_pivots), so the grid above -- it runs to z = 9999, a sample at
+        // u_j / pivot_j (T.reach: after that many knots CP_BG_REACH_LEFT = 1e-13 of it is left, build_pivots), so the grid above -- it runs to z = 9999, a sample at
         // z < 3 sits in interval 31 at most -- contributes nothing a double can hold.  65 intervals instead of 118 for config 5, and within a
         // pass all lanes that are still busy walk the same interval: the table reads are broadcasts.
         for (int idx = 0; idx <= k; ++idx) {
@@ -182,6 +184,19 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
             const double d = T.ra[idx + 1] * inc + T.rb[idx + 1] * inc_prev;      // knot idx + 1: d = ra * inc_idx + rb * inc_{idx+1}
             dq = (d - T.u[idx + 1] * dq) * T.idb[idx + 1];
             inc_prev = inc;
+        }
+        // The reference splines the WHOLE table: an ordinate that is not finite anywhere on the grid (E^2 <= 0 at some redshift: closed models with
+        // little matter, a negative dark-energy density) makes every distance of the cosmology NaN, also those far below it.  The ordinates above
+        // `top` are not looked at otherwise; E^2 is a sum of positive terms unless one of its density parameters is negative, so only those
+        // cosmologies walk them (no lane of config 5 does).
+        if (top < NK - 1 && (c.Omega_k < 0. || c.Omega_de < 0. || c.Omega_cdm + c.Omega_b < 0.)) {
+            bool bad = false;
+            for (int idx = top; idx < NK - 1; ++idx) {
+                const double fm = integrand(T.zc[idx] + T.dx[idx] / 2, T.lm[idx], T.im[idx]);
+                const double fe = integrand(T.zc[idx + 1], T.lk[idx + 1], T.ik[idx + 1]);
+                bad |= !(fabs(fm) <= 1.7976931348623157e308) || !(fabs(fe) <= 1.7976931348623157e308);
+            }
+            if (bad) dq = nan;
         }
     } else {
     const double f_last = integrand(T.zc[NK - 1], T.lk[NK - 1], T.ik[NK - 1]);
@@ -244,6 +259,12 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     A.out[i] = chi;
 }
 
+// What is left of the backward elimination's arbitrary start when it reaches the sample's interval: a relative error of the spline's first derivative
+// there, i.e. of the cubic's correction to the Simpson sum inside ONE interval -- 1e-13 of that correction is below 1e-14 of the distance (the 1e-18 of
+// the earlier rounds walked 32 knots above the sample where 24 do: a seventh of the kernel's ordinates)
+#ifndef CP_BG_REACH_LEFT
+#define CP_BG_REACH_LEFT 1e-13
+#endif
 template <int NK>
 void build_pivots(TablesN<NK>& t) {
     const int n = NK;
@@ -287,7 +308,7 @@ void build_pivots(TablesN<NK>& t) {
             for (int r = 0; r < t.reach; ++r) f *= std::fabs(t.u[j + r] * t.idb[j + r]);
             worst = f > worst ? f : worst;
         }
-        if (worst < 1e-18) break;
+        if (worst < CP_BG_REACH_LEFT) break;
     }
 }
 

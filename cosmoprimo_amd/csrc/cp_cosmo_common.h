@@ -128,13 +128,15 @@ __device__ __forceinline__ double efunc_ln(const Cosmo& c, double z, double lzp1
     return sqrt(rc * (zp1 * zp1 * zp1) / kRhoCrit);
 }
 
-// 1 / E(z) with log(1 + z) and 1 / (1 + z) given: rsqrt of E^2 (no division, no sqrt)
-__device__ __forceinline__ double inv_efunc_ln(const Cosmo& c, double z, double lzp1, double izp1) {
+// 1 / E(z) with log(1 + z) and 1 / (1 + z) given: rsqrt of E^2 (no division, no sqrt).  mt: the kernel's tables for the table-driven exponential
+// (cp_math.h: 11 instructions where the polynomial form takes 20; 2.3e-16), or null
+__device__ __forceinline__ double inv_efunc_ln(const Cosmo& c, double z, double lzp1, double izp1, const cpmath::MathTables* mt = nullptr) {
     const double zp1 = 1. + z;
     const double m = c.Omega_cdm * kRhoCrit + c.Omega_b * kRhoCrit + ncdm_eval(c, z, 0);
     const double r = c.Omega_g * zp1 * kRhoCrit + c.Omega_ur * zp1 * kRhoCrit;
+    const double arg = 3. * (c.w0 + c.wa) * lzp1 + 3. * c.wa * (izp1 - 1.);
     const double de = (c.w0 == -1. && c.wa == 0.) ? c.Omega_de * (izp1 * izp1 * izp1) * kRhoCrit
-                                                  : c.Omega_de * exp_mid(3. * (c.w0 + c.wa) * lzp1 + 3. * c.wa * (izp1 - 1.)) * kRhoCrit;
+                                                  : c.Omega_de * (mt ? cpmath::exp_tab(arg, mt) : exp_mid(arg)) * kRhoCrit;
     const double rc = (m + r + de) + c.Omega_k * izp1 * kRhoCrit;
     const double e2 = rc * (zp1 * zp1 * zp1) * (1. / kRhoCrit);
     return e2 >= 2.2250738585072014e-308 && e2 <= 1.7976931348623157e308 ? rsqrt_pos(e2) : rsqrt(e2);

@@ -46,13 +46,14 @@ def test_batch_consistency():
         same(fb.pknow, [cp.PowerSpectrumBAOFilter(p, engine=engine).pknow for p in p1s], 1e-7, cols=True)
     fb = cp.PowerSpectrumBAOFilter(pkb, engine='wallish2018')                 # 2D interpolator of the batch: (batch, nk, nz)
     same(fb.pknow, [cp.PowerSpectrumBAOFilter(p, engine='wallish2018').pknow for p in pks], 1e-7)
-    # what needs one object per cosmology says so
+    # the filters whose operator depends on the cosmology (its rs_drag ratio, its no-wiggle template): one per column of the batch
     fid = cp.Cosmology(engine='eisenstein_hu')
-    for engine in ['ehpoly', 'peakaverage']:
-        with pytest.raises(NotImplementedError):
-            cp.PowerSpectrumBAOFilter(p1b, engine=engine, cosmo=batch, cosmo_fid=fid)
-        one = cp.PowerSpectrumBAOFilter(p1s[1], engine=engine, cosmo=singles[1], cosmo_fid=fid)
-        assert np.all(np.isfinite(one.pknow))
+    for engine in ['ehpoly', 'peakaverage', 'ehsavgol', 'hinton2017']:
+        fb = cp.PowerSpectrumBAOFilter(p1b, engine=engine, cosmo=batch, cosmo_fid=fid)
+        assert fb.pknow.shape == (1024, 3)
+        same(fb.pknow, [cp.PowerSpectrumBAOFilter(p, engine=engine, cosmo=c, cosmo_fid=fid).pknow for p, c in zip(p1s, singles)], 1e-9 if engine != 'hinton2017' else 1e-7,
+             cols=True)
+    fb = cp.PowerSpectrumBAOFilter(pkb, engine='wallish2018')
     with pytest.raises(NotImplementedError):
         pkb.to_xi()
     with pytest.raises(NotImplementedError):
