@@ -204,15 +204,18 @@ def _library_sha():
 
 
 def _config4_valu_roofline(engine, vectors_per_s, chunk):
-    """What bounds the filters is instruction issue, not HBM.  `achieved` / `frac`: the ALGORITHMIC vector instructions per vector (CONFIG4_ALGORITHMIC,
-    a count no implementation can go below) x the measured vectors/s against the issue peak of the vector pipes.  Next to it the instructions the
+    """What bounds the filters is instruction issue, not HBM.  `achieved` / `frac`: the ALGORITHMIC vector instructions per vector (CONFIG4_ALGORITHMIC:
+    operation counts of the formulae with every EH98 / no-wiggle sample priced at what this package's shortest evaluation costs, _EH98 / _NOWIGGLE --
+    those two prices fell between rounds (390 / 150 in round 3), so `frac` compares rounds only at equal prices; `executed.issue_slots_used` is the
+    figure that does) x the measured vectors/s against the issue peak of the vector pipes.  Next to it the instructions the
     package's own kernels EXECUTE per vector (committed census profiles/*_config4_valu.json: rocprofv3 --pmc SQ_INSTS_VALU per kernel, framework
     kernels excluded, scripts/profile_config4_valu.sh), flagged when the census was not taken on this library or chunk size."""
     import glob
     peak = 256 * 4 * 2.4e9 / 4
     alg = CONFIG4_ALGORITHMIC[engine]
     out = {'bound': 'vector instruction issue (fp64 and integer VALU, 4 cycles per wave instruction)', 'achieved': alg * vectors_per_s, 'peak': peak,
-           'unit': 'wave-instructions/s', 'frac': alg * vectors_per_s / peak, 'algorithmic_wave_instructions_per_vector': alg}
+           'unit': 'wave-instructions/s', 'frac': alg * vectors_per_s / peak, 'algorithmic_wave_instructions_per_vector': alg,
+           'algorithmic_prices': {'eh98_sample': _EH98, 'nowiggle_sample': _NOWIGGLE, 'provenance': 'instructions per sample of this package\'s shortest evaluation (sigma8_normalise_kernel census)'}}
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_config4_valu.json')))
     if files:
         with open(files[-1]) as fh:

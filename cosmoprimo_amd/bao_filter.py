@@ -198,6 +198,9 @@ _TRANSFORM_FINDS_BOXES = False
 # everything behind the forward transform (second derivatives + box, inverse transform, spliced spline + damping) as ONE kernel, the transformed rows never
 # leaving the CU (cp_wallish_tail): batches too large for the second derivatives to be kept (they are not written then)
 _TAIL_IN_ONE_KERNEL = True
+# ... and the forward transform with its spectra in the same kernel (cp_wallish_full): the filter of a batch of analytic cosmologies is ONE launch behind the
+# sigma8 normalisation; the coefficient sequences are not written then (like the second derivatives, they are kept for small batches only)
+_ALL_IN_ONE_KERNEL = True
 _TRANSFORM_EVALUATES_SPECTRA = True      # wallish2018 on batches of analytic cosmologies: cp_dst_forward_analytic (False: evaluation kernel, then transform)
 
 
@@ -282,6 +285,38 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         dd = ops['dd'](y)
         return dd, self._box(dd), False
 
+    def _full(self, engine, bg, pk, dst):
+        """The whole filter of a batch of analytic cosmologies as one kernel (``cp_wallish_full``: the spectra evaluated into the forward transform, the
+        coefficients taken through the rest on the CU); False where the plans or the parameters are not the ones the kernel is written for."""
+        torch = dv.torch()
+        from .background import DEFAULTS as bg_defaults
+        from .power import PK_DEFAULTS
+        ops = self._operators()
+        if dst.n != 4096 or engine not in _lib.ENGINES or not isinstance(ops['splice'], SplicedClampedSpline):
+            return False
+        rows = self._pk_rows.contiguous()
+        cbg, n1, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, self.device)
+        cpk, n2, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, self.device)
+        sizes = {n for n in (n1, n2) if n is not None}
+        if len(sizes) != 1 or sizes.pop() != rows.shape[0]:
+            return False
+        ncosmo = rows.shape[0]
+        lib = _lib.load()
+        mf, ms, off = self._margin_first, self._margin_second, self._offset
+        box = torch.empty((2 * ncosmo, 2), dtype=torch.int32, device=self.device)
+        out = torch.empty_like(rows)
+        work = torch.empty(int(lib.cp_dst_forward_analytic_workspace_bytes(ncosmo)), dtype=torch.uint8, device=self.device)
+        nu, keep_nu = dv.ncdm_arg(bg, ncosmo)
+        status = lib.cp_wallish_full(dst._handle, ops['splice']._handle, _lib.ENGINES[engine], ncosmo, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), rows.data_ptr(), rows.shape[1],
+                                     mf, ms, off[0], off[1], ops['tophat'].data_ptr(), box.data_ptr(), None, out.data_ptr(), work.data_ptr(), dv.stream_of(self.device))
+        if status == _lib.CP_EUNSUPPORTED:
+            return False
+        _lib.check(status)
+        self._dd, self._boxes = None, [box[0::2], box[1::2]]
+        self._even_now = self._odd_now = None      # (not written for batches this large: the sequences never leave the CU)
+        self._pknow_rows = out
+        return True
+
     def _tail(self, ffted, y, ops):
         """Everything behind the forward transform in one kernel (``cp_wallish_tail``, reference bao_filter.py:373-431); False where the plans are not the
         ones the kernel is written for (the three separate calls then)."""
@@ -315,6 +350,8 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         engine, bg, pk = call.analytic_engine()
         if dst is not None and _TRANSFORM_EVALUATES_SPECTRA:      # a batch of cosmologies: the transform kernel evaluates the spectra itself
             ncol = self._pk_rows.shape[0]
+            if _ALL_IN_ONE_KERNEL and _TAIL_IN_ONE_KERNEL and 2 * ncol > self._keep_second_derivatives and self._full(engine, bg, pk, dst):
+                return None, 'done' 
             if _TRANSFORM_FINDS_BOXES and 2 * ncol > self._keep_second_derivatives and dst.n == 4096:
                 # ... and runs the next step on the coefficients it holds (second derivatives, boxes, boxes rewritten): nothing is kept of
                 # the second derivatives, as for every large batch
@@ -334,6 +371,8 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         # dst(log(k P)), type 2, ortho, written as [even-indexed | odd-indexed] coefficients: seen as (2 ncol, 2048) the two sequences of
         # every vector are consecutive rows, and share the operators (x_even = x_odd = 1 + arange(2048), bao_filter.py:374-375)
         logkp, ffted = self._log_k_rows(ops['klin'], dst=ops['dst'])
+        if isinstance(ffted, str):      # the whole filter ran in one kernel (cp_wallish_full)
+            return
         solved = None
         if isinstance(ffted, tuple):                                      # ... which has also found and rewritten the boxes
             ffted, solved = ffted

@@ -736,3 +736,75 @@ extern "C" int cp_wallish_tail(const cp_dst_plan* p, const cp_splice_plan* splic
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_wallish_tail: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
+
+
+// ---- cp_wallish_full: wallish2018 of a batch of analytic cosmologies, one kernel (wallish_full_kernel, cp_wallish_tail.h) ----
+namespace {
+template <int ENGINE>
+void launch_full(const FullArgs& F, int grid, int lds, hipStream_t stream) {
+    (void)cp::allow_full_lds<&wallish_full_kernel<49, ENGINE>>();
+    hipLaunchKernelGGL((wallish_full_kernel<49, ENGINE>), dim3(grid), dim3(256), lds, stream, F);
+}
+}  // namespace
+
+extern "C" int cp_wallish_full(const cp_dst_plan* p, const cp_splice_plan* splice, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
+                               const cp_ncdm* ncdm, const cp_param* pk_params, const double* d_pk, int npk, int margin_first, int margin_second, int offset_first,
+                               int offset_second, const double* d_tophat, int* d_box, double* d_coef, double* d_out, void* d_work, void* stream) {
+    if (!p || !splice) return cp::fail(CP_EINVAL, "cp_wallish_full: null plan");
+    if (ncosmo < 0) return cp::fail(CP_EINVAL, "cp_wallish_full: negative batch");
+    if (engine != CP_ENGINE_EH && engine != CP_ENGINE_EH_NOWIGGLE && engine != CP_ENGINE_BBKS) return cp::fail(CP_EINVAL, "cp_wallish_full: unknown engine %d", engine);
+    if (margin_first < 0 || 2 * margin_first >= 2048 || margin_second < 0 || margin_second >= 2048) return cp::fail(CP_EINVAL, "cp_wallish_full: bad margins");
+    if (p->n != 4096 || !p->d_kx || !p->d_ln_kx)
+        return cp::fail(CP_EUNSUPPORTED, "cp_wallish_full: needs a transform plan of length 4096 made with its abscissa (wallish2018's linear grid)");
+    cpsu::Tables U;
+    int device = -1;
+    if (!cp_splice_plan_uniform_view(splice, &U, &device) || device != p->device)
+        return cp::fail(CP_EUNSUPPORTED, "cp_wallish_full: the splice plan does not run the uniform-stretch scheme on the transform's device");
+    if (U.src_u != 1 || (U.wl > 0 && U.src_l != 0) || (U.wr > 0 && U.src_r != 0) || U.col_u < 1 || U.col_u + 64 * U.S + 1 > 4096 || U.nq != npk || U.ngb > cpsu::NGB ||
+        U.S != 49 || U.col_l + U.wl > npk || U.col_r + U.wr > npk)
+        return cp::fail(CP_EUNSUPPORTED, "cp_wallish_full: the splice plan is not the filter's (stretch of %d knots at column %d of array %d, %d queries)", U.nm, U.col_u,
+                        U.src_u, U.nq);
+    if (ncosmo == 0) return CP_OK;
+    if (!bg_params || !pk_params || !d_pk || !d_box || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_wallish_full: null pointer");
+    char* coef = static_cast<char*>(d_work);
+    coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, p->device, stream);      // (validates the massive-neutrino tables)
+    if (st != CP_OK) return st;
+    const int nsp = ncdm ? ncdm->nspecies : 0;
+    if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_wallish_full: bad massive-neutrino tables");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != p->device && hipSetDevice(p->device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_wallish_full: cannot select device %d", p->device);
+    FullArgs F{};
+    TailArgs& G = F.tail;
+    G.nrows = ncosmo; G.coef = d_coef; G.tw = p->d_tw; G.rot = p->d_rot; G.ikx = p->d_ln_kx + 3 * (size_t)p->n;
+    G.U = U;
+    G.pk = d_pk; G.tophat = d_tophat; G.out = d_out; G.box = d_box;
+    G.margin_first = margin_first; G.margin_second = margin_second; G.off0 = offset_first; G.off1 = offset_second;
+    GenArgs& E = F.gen;
+    E.dst.in = nullptr; E.dst.out = nullptr; E.dst.nrows = ncosmo; E.dst.tw = p->d_tw; E.dst.rot = p->d_rot; E.dst.kx = nullptr; E.dst.ikx = nullptr; E.dst.fused = 0; E.dst.split = 1;
+    E.ncosmo = ncosmo;
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) E.bg[i] = cpcosmo::Param{bg_params[i].ptr, bg_params[i].value};
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) E.pw[i] = cpcosmo::Param{pk_params[i].ptr, pk_params[i].value};
+    E.second_is_omega_m = second_is_omega_m;
+    E.ncdm_tab = nsp ? ncdm->tab : nullptr;
+    E.nsp = nsp;
+    E.k = p->d_kx;
+    E.ln_k = p->d_ln_kx;
+    E.scal = reinterpret_cast<const cppower::EhScalars*>(coef);
+    E.box = nullptr;
+    const long long npairs = (ncosmo + 1) / 2;
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p->device) != hipSuccess || ncu <= 0) ncu = 256;
+    const long long resident = 2LL * ncu, rounds = (npairs + resident - 1) / resident;
+    const int grid = (int)((npairs + rounds - 1) / rounds);
+    constexpr int lds = (4096 + Plan<4096, 16>::TW_TOTAL - 4096) * (int)sizeof(cplx) + 2 * cpdd::DD_NTAB * (int)sizeof(double);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (engine == CP_ENGINE_EH) launch_full<CP_ENGINE_EH>(F, grid, lds, s);
+    else if (engine == CP_ENGINE_EH_NOWIGGLE) launch_full<CP_ENGINE_EH_NOWIGGLE>(F, grid, lds, s);
+    else launch_full<CP_ENGINE_BBKS>(F, grid, lds, s);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_wallish_full: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}

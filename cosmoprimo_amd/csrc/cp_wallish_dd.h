@@ -504,7 +504,7 @@ __device__ __forceinline__ bool remove_box_parallel(const double* ybuf, const do
     for (int i = a + lane; i <= b; i += 64) {
         const double u = (double)(i - L), x = (double)(i + 1);
         const double v = (zL + u * (sL + u * (c2 + u * c3))) * cpmath::recip(x * x);
-        seq[i] = v;
+        if (!INPLACE || seq) seq[i] = v;      // (INPLACE: `seq` may be null -- the rewritten knots are wanted in LDS only)
         if constexpr (INPLACE) {      // ... and into the sequence in LDS (the knots read above lie outside the box: nothing read here is rewritten)
             const_cast<double*>(ybuf)[LAY::at(i)] = v;
             finite &= fabs(v) <= 1.7976931348623157e308;

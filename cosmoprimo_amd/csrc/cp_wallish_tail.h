@@ -163,71 +163,18 @@ __device__ __forceinline__ void tail_splice_row(double* row, double* outrow, int
     tail_evaluate(yu, outrow, lane, part, own);
 }
 
+// Stages 2 .. 5 of a pair whose four sequences sit in the data region (XOR layout) with bad_row set for rows that hold a sample that is not finite, behind a
+// barrier: second derivatives + box + removal, inverse transform, exp(.) / k_lin, spliced spline + damping.  Shared by wallish_tail_kernel (the sequences
+// read from memory) and wallish_full_kernel (produced by the forward transform of the spectra it evaluates).
 template <int SU>
-__global__ __launch_bounds__(256, 2) void wallish_tail_kernel(const TailArgs G_by_value) {
+__device__ __forceinline__ void tail_stages(long long p, bool has_b, int t, cplx* lds, cplx* ltw, double* dd_tabs, const cpmath::MathTables& mt, int* bad_row) {
     constexpr int N = 4096, P = 16, NS = N / 2, S = 32;
     using PL = Plan<N, P>;
     constexpr int T = PL::T;
     using namespace cpdd;
-    static_assert(!padded_lds(N, P) && lds_data_slots(N, P) == N, "four sequences of 2048 doubles / two real rows of 4096 fill the data region");
-    extern __shared__ __attribute__((aligned(4096))) char smem[];
-    cplx* lds = reinterpret_cast<cplx*>(smem);
-    cplx* ltw = lds + N;
-    double* dd_tabs = reinterpret_cast<double*>(ltw + (PL::TW_TOTAL - N));
-    const int t = threadIdx.x;
-    long long npairs;
-    {
-        TailArgsK g = tail_args();
-        const cplx* tw = g->tw;
-        for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = tw[N + i];
-        npairs = (g->nrows + 1) / 2;
-    }
-    fill_tables(dd_tabs);
-    __shared__ int bad_row[2];
-    __shared__ cpmath::MathTables mt;      // (the barrier at the top of the first pair covers the fills)
-    cpmath::fill_math_tables(&mt);
     const double fn = sqrt(2. / N), fl = sqrt(1. / N);
     const double nan = __builtin_nan("");
-    double* seqs = reinterpret_cast<double*>(lds);      // sequence w (row w >> 1, parity w & 1) at seqs + w NS, XOR layout; later: row a | row b, natural order
-    double na[P], nb[P];
-    auto fetch = [&](long long p) {      // the pair's rows as they lie in memory: every coefficient read once
-        TailArgsK g = tail_args();
-        int tf = t;
-        asm volatile("" : "+v"(tf));      // (nothing derived from the thread's number is kept in registers from one pair to the next)
-        const double* ra = g->coef + 2 * p * N + tf;
-        const double* rb = 2 * p + 1 < g->nrows ? ra + N : ra;
-#pragma unroll
-        for (int r = 0; r < P; ++r) {
-            na[r] = ra[T * r];
-            nb[r] = rb[T * r];
-        }
-    };
-    if ((long long)blockIdx.x < npairs) fetch(blockIdx.x);
-    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
-        const bool has_b = 2 * p + 1 < tail_args()->nrows;
-        if (t == 0) bad_row[0] = bad_row[1] = 0;
-        __syncthreads();      // the data region is free (and the tables are filled)
-        // ---- 1. the four sequences into LDS; a row with a sample that is not finite is left out of the transform and comes out as NaN (dst_kernel) ----
-        {
-            bool bad_a = false, bad_b = false;
-            int ts = t;
-            asm volatile("" : "+v"(ts));
-            // coefficient i = ts + 256 r of a row (split layout: [even-indexed | odd-indexed] coefficients) is knot i & 2047 of sequence i >> 11; its slot
-            // (i & 2047) ^ ((i >> 5) & 31) = 256 r' + (ts & 224) + ((ts & 31) ^ (ts >> 5) ^ 8 (r & 3)) with r' = r & 7: a thread constant XOR a constant of r
-            const int hs = (ts & 31) ^ (ts >> 5), bs = ts & 224;
-#pragma unroll
-            for (int r = 0; r < P; ++r) {
-                const int slot = (r >> 3) * NS + 256 * (r & 7) + bs + (hs ^ (8 * (r & 3)));
-                seqs[slot] = na[r];
-                seqs[2 * NS + slot] = nb[r];
-                bad_a |= !(fabs(na[r]) <= 1.7976931348623157e308);
-                bad_b |= !(fabs(nb[r]) <= 1.7976931348623157e308);
-            }
-            if (bad_a) bad_row[0] = 1;
-            if (bad_b && has_b) bad_row[1] = 1;
-        }
-        __syncthreads();
-        if (p + gridDim.x < npairs) fetch(p + gridDim.x);
+    double* seqs = reinterpret_cast<double*>(lds);
         int lane = t;
         asm volatile("" : "+v"(lane));      // (as above: the wave's number and the lane are formed anew for every pair)
         const int wave = __builtin_amdgcn_readfirstlane(lane >> 6);
@@ -266,7 +213,8 @@ __global__ __launch_bounds__(256, 2) void wallish_tail_kernel(const TailArgs G_b
                 box[2 * srow + 1] = b;
             }
             bool finite;
-            remove_box_parallel<S, Xor32Layout, true>(buf, dd_tabs + DD_NTAB, lane, a, b, g->coef + row * N + (wave & 1) * NS, &finite);
+            double* coef = g->coef;
+            remove_box_parallel<S, Xor32Layout, true>(buf, dd_tabs + DD_NTAB, lane, a, b, coef ? coef + row * N + (wave & 1) * NS : nullptr, &finite);
             if (!finite) bad_row[wave >> 1] = 1;
         }
         __syncthreads();
@@ -378,5 +326,182 @@ __global__ __launch_bounds__(256, 2) void wallish_tail_kernel(const TailArgs G_b
                 }
             }
         }
+}
+
+template <int SU>
+__global__ __launch_bounds__(256, 2) void wallish_tail_kernel(const TailArgs G_by_value) {
+    constexpr int N = 4096, P = 16, NS = N / 2;
+    using PL = Plan<N, P>;
+    constexpr int T = PL::T;
+    using namespace cpdd;
+    static_assert(!padded_lds(N, P) && lds_data_slots(N, P) == N, "four sequences of 2048 doubles / two real rows of 4096 fill the data region");
+    extern __shared__ __attribute__((aligned(4096))) char smem[];
+    cplx* lds = reinterpret_cast<cplx*>(smem);
+    cplx* ltw = lds + N;
+    double* dd_tabs = reinterpret_cast<double*>(ltw + (PL::TW_TOTAL - N));
+    const int t = threadIdx.x;
+    long long npairs;
+    {
+        TailArgsK g = tail_args();
+        const cplx* tw = g->tw;
+        for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = tw[N + i];
+        npairs = (g->nrows + 1) / 2;
+    }
+    fill_tables(dd_tabs);
+    __shared__ int bad_row[2];
+    __shared__ cpmath::MathTables mt;      // (the barrier at the top of the first pair covers the fills)
+    cpmath::fill_math_tables(&mt);
+    double* seqs = reinterpret_cast<double*>(lds);      // sequence w (row w >> 1, parity w & 1) at seqs + w NS, XOR layout; later: row a | row b, natural order
+    double na[P], nb[P];
+    auto fetch = [&](long long p) {      // the pair's rows as they lie in memory: every coefficient read once
+        TailArgsK g = tail_args();
+        int tf = t;
+        asm volatile("" : "+v"(tf));      // (nothing derived from the thread's number is kept in registers from one pair to the next)
+        const double* ra = g->coef + 2 * p * N + tf;
+        const double* rb = 2 * p + 1 < g->nrows ? ra + N : ra;
+#pragma unroll
+        for (int r = 0; r < P; ++r) {
+            na[r] = ra[T * r];
+            nb[r] = rb[T * r];
+        }
+    };
+    if ((long long)blockIdx.x < npairs) fetch(blockIdx.x);
+    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const bool has_b = 2 * p + 1 < tail_args()->nrows;
+        if (t == 0) bad_row[0] = bad_row[1] = 0;
+        __syncthreads();      // the data region is free (and the tables are filled)
+        // ---- 1. the four sequences into LDS; a row with a sample that is not finite is left out of the transform and comes out as NaN (dst_kernel) ----
+        {
+            bool bad_a = false, bad_b = false;
+            int ts = t;
+            asm volatile("" : "+v"(ts));
+            // coefficient i = ts + 256 r of a row (split layout: [even-indexed | odd-indexed] coefficients) is knot i & 2047 of sequence i >> 11; its slot
+            // (i & 2047) ^ ((i >> 5) & 31) = 256 r' + (ts & 224) + ((ts & 31) ^ (ts >> 5) ^ 8 (r & 3)) with r' = r & 7: a thread constant XOR a constant of r
+            const int hs = (ts & 31) ^ (ts >> 5), bs = ts & 224;
+#pragma unroll
+            for (int r = 0; r < P; ++r) {
+                const int slot = (r >> 3) * NS + 256 * (r & 7) + bs + (hs ^ (8 * (r & 3)));
+                seqs[slot] = na[r];
+                seqs[2 * NS + slot] = nb[r];
+                bad_a |= !(fabs(na[r]) <= 1.7976931348623157e308);
+                bad_b |= !(fabs(nb[r]) <= 1.7976931348623157e308);
+            }
+            if (bad_a) bad_row[0] = 1;
+            if (bad_b && has_b) bad_row[1] = 1;
+        }
+        __syncthreads();
+        if (p + gridDim.x < npairs) fetch(p + gridDim.x);
+        tail_stages<SU>(p, has_b, t, lds, ltw, dd_tabs, mt, bad_row);
+    }
+}
+
+// ---- wallish2018 of a batch of analytic cosmologies as ONE kernel: dst_generate_kernel's front (the spectra evaluated into the forward transform, cp_dst.hip)
+// and the stages above on the same pair, the coefficients never leaving the CU.  Per vector: the 8 KB row of P in, 8 KB out (+ the 32 KB of coefficients
+// when the caller wants the rewritten sequences: d_coef).  The two workgroups of a CU are at different points of a pair most of the time: one in the
+// evaluation of its 2 x 4096 samples (vector-ALU bound), the other in a transform or a recursion (LDS / latency bound).
+struct FullArgs {
+    TailArgs tail;      // at offset 0 of the kernel's arguments: read through tail_args()
+    GenArgs gen;        // the forward side: parameters of the cosmologies, tables of the evaluation, twiddles (dst.tw, dst.rot); dst.out / box unused
+};
+
+template <int SU, int ENGINE>
+__global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) {
+    constexpr int N = 4096, P = 16, NS = N / 2;
+    using PL = Plan<N, P>;
+    constexpr int T = PL::T;
+    using namespace cpdd;
+    static_assert(!padded_lds(N, P) && lds_data_slots(N, P) == N, "the generated samples go through natural-order slots of the data region");
+    const GenArgs& G = F.gen;
+    extern __shared__ __attribute__((aligned(4096))) char smem[];
+    cplx* lds = reinterpret_cast<cplx*>(smem);
+    cplx* ltw = lds + N;
+    double* dd_tabs = reinterpret_cast<double*>(ltw + (PL::TW_TOTAL - N));
+    const int t = threadIdx.x;
+    for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = G.dst.tw[N + i];
+    fill_tables(dd_tabs);
+    __shared__ int bad_row[2];
+    __shared__ cpmath::MathTables mt;      // (the barrier at the top of the first pair covers the fills)
+    cpmath::fill_math_tables(&mt);
+    const long long npairs = (G.ncosmo + 1) / 2;
+    const double fn = sqrt(2. / N), fl = sqrt(1. / N);
+    const double nan = __builtin_nan("");
+    double* seqs = reinterpret_cast<double*>(lds);
+    for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
+        const bool has_b = 2 * p + 1 < G.ncosmo;
+        if (t == 0) bad_row[0] = bad_row[1] = 0;
+        __syncthreads();      // the data region is free (and the tables are filled)
+        int tt = t;
+        asm volatile("" : "+v"(tt));      // (nothing derived from the thread's number is kept in registers from one pair to the next)
+        // ---- 0. log(k P_c(k)) of the pair's cosmologies at the 4096 wavenumbers of the linear grid, Makhoul order, into the thread's own slots; forward transform ----
+        generate_row<N, P, ENGINE>(G, 2 * p, tt, seqs, &mt);
+        if (has_b) generate_row<N, P, ENGINE>(G, 2 * p + 1, tt, seqs + 1, &mt);
+        {
+            cplx x[P];
+            bool bad_a = false, bad_b = false;
+#pragma unroll
+            for (int r = 0; r < P; ++r) {      // the thread's own slots: no barrier
+                const int m = tt + T * r;
+                const bool lower = m < N / 2;
+                const double a = seqs[2 * m], b = has_b ? seqs[2 * m + 1] : 0.;
+                bad_a |= !(fabs(a) <= 1.7976931348623157e308);
+                bad_b |= !(fabs(b) <= 1.7976931348623157e308);
+                x[r].re = lower ? a : -a;
+                x[r].im = lower ? b : -b;
+            }
+            if (bad_a) bad_row[0] = 1;
+            if (bad_b) bad_row[1] = 1;
+            __syncthreads();      // flags published; every thread has read its slots before the first pass overwrites the region
+            const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
+            if (skip_a | skip_b) {
+#pragma unroll
+                for (int r = 0; r < P; ++r) {
+                    if (skip_a) x[r].re = 0.;
+                    if (skip_b) x[r].im = 0.;
+                }
+            }
+            dif_all<N, P>(tt, G.dst, x, lds, ltw);
+        }
+        asm volatile("" : "+v"(tt));
+        // ---- 1. the pair's coefficients (frequency k of the packed transform -> coefficient 4095 - k of either row) into the four sequences, XOR layout ----
+        {
+            double va[P], vb[P];
+            const bool skip_a = bad_row[0] != 0, skip_b = bad_row[1] != 0;
+            // frequency k = tt + 256 s sits at slot 256 d0 + 16 d1 + (s ^ d1) (d0, d1: the two low hexadecimal digits of tt), its mirror 4096 - k at
+            // 256 e0 + 16 e1 + ((15 - s) ^ e1) with e = 256 - tt (tt = 0: at 16 - s, and at 0 for k = 0)
+            const int d1 = tt >> 4, vbase = 256 * (tt & 15) + 16 * d1;
+            const int e = 256 - tt, e1 = (e >> 4) & 15, ubase = 256 * (e & 15) + 16 * e1;
+            const bool first = tt == 0;
+            const cplx* rots = G.dst.rot;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const cplx v = lds[vbase + (s ^ d1)];
+                const cplx u = lds[first ? (s == 0 ? 0 : 16 - s) : ubase + ((15 - s) ^ e1)];
+                const cplx rot = rots[tt + T * s];
+                const double f = (s == 0 && first) ? fl : fn;
+                va[s] = skip_a ? nan : f * (0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im)));
+                vb[s] = skip_b ? nan : f * (0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re)));
+            }
+            __syncthreads();      // every thread has its coefficients: the data region is free
+            const int wa = 127 - (tt >> 1);
+            const int base_a = ((tt & 1) ^ 1) * NS + (wa & 96), ha = (wa & 31) ^ (wa >> 5);
+            double* coef = tail_args()->coef;
+#pragma unroll
+            for (int s = 0; s < P; ++s) {
+                const int slot = base_a + 128 * (15 - s) + (ha ^ (4 * ((7 - s) & 7)));      // coefficient j = 4095 - k: sequence j & 1, knot j >> 1 (tail_stages, stage 3)
+                seqs[slot] = va[s];
+                seqs[2 * NS + slot] = vb[s];
+            }
+            if (coef) {      // the sequences as the filter keeps them (the boxes are rewritten there by stage 2): split layout
+                const int j = N - 1 - tt;
+                double* oa = coef + 2 * p * N + (j & 1) * NS + (j >> 1);
+#pragma unroll
+                for (int s = 0; s < P; ++s) {
+                    oa[-128 * s] = va[s];
+                    if (has_b) oa[N - 128 * s] = vb[s];
+                }
+            }
+        }
+        __syncthreads();
+        tail_stages<SU>(p, has_b, t, lds, ltw, dd_tabs, mt, bad_row);
     }
 }

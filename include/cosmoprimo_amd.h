@@ -549,6 +549,15 @@ int cp_dst_forward_analytic_box(const cp_dst_plan* plan, int engine, long long n
 int cp_wallish_tail(const cp_dst_plan* dst, const cp_splice_plan* splice, double* d_coef, const double* d_pk, int npk, long long nrows, int margin_first,
                     int margin_second, int offset_first, int offset_second, const double* d_tophat, int* d_box, double* d_out, void* stream);
 
+/* cp_dst_forward_analytic + cp_wallish_tail as ONE kernel: wallish2018 (bao_filter.py:371-431) of a batch of cosmologies of an analytic engine from their
+ * parameters (engine, bg_params, ncdm, pk_params as for cp_power_eval; d_work: cp_dst_forward_analytic_workspace_bytes(ncosmo) bytes) and the rows d_pk
+ * (ncosmo, npk) of their spectra at the filter's wavenumbers: a workgroup evaluates log(k_lin P_c(k_lin)) of a pair of cosmologies into the forward
+ * transform and takes the coefficients through cp_wallish_tail's stages without their leaving the CU.  d_coef: NULL, or (ncosmo, 4096) to receive the
+ * coefficient sequences with their boxes rewritten (what the two calls leave in d_coef); d_box, d_out, the plans and CP_EUNSUPPORTED as for cp_wallish_tail. */
+int cp_wallish_full(const cp_dst_plan* dst, const cp_splice_plan* splice, int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m,
+                    const cp_ncdm* ncdm, const cp_param* pk_params, const double* d_pk, int npk, int margin_first, int margin_second, int offset_first,
+                    int offset_second, const double* d_tophat, int* d_box, double* d_coef, double* d_out, void* d_work, void* stream);
+
 /* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
  * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];
  * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */

@@ -240,7 +240,7 @@ def test_wallish_box_kernel():
 
 def test_wallish_tail_in_one_kernel(cp):
     """cp_wallish_tail (second derivatives + box + removal, inverse transform, spliced spline + damping of wallish2018 as one kernel, the transformed rows
-    kept on the CU) against the three calls it replaces: pknow, the boxes and the rewritten sequences; odd batches (a vector without a partner) and a
+    kept on the CU) and cp_wallish_full (the forward transform with its spectra in the same kernel) against the three calls they replace: pknow, the boxes and the rewritten sequences; odd batches (a vector without a partner) and a
     vector that is not finite next to good ones (it comes out as the three calls leave it, its partner untouched)."""
     import torch
     from cosmoprimo_amd import bao_filter as bf
@@ -253,15 +253,19 @@ def test_wallish_tail_in_one_kernel(cp):
             par['h'][7] = np.nan      # a vector of NaN in the middle of a pair
         cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **par)
         interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
-        saved = bf._TAIL_IN_ONE_KERNEL
+        saved = bf._TAIL_IN_ONE_KERNEL, bf._ALL_IN_ONE_KERNEL
         try:
             got = []
-            for fused in (True, False):
-                bf._TAIL_IN_ONE_KERNEL = fused
+            for fused, whole in ((True, False), (False, False), (True, True)):
+                bf._TAIL_IN_ONE_KERNEL, bf._ALL_IN_ONE_KERNEL = fused, whole
                 f = PowerSpectrumBAOFilter(interp, engine='wallish2018', cosmo=cosmo, cosmo_fid=fid)
-                got.append((np.asarray(f.pknow), [b.cpu().numpy() for b in f._boxes], f._even_now.cpu().numpy(), f._odd_now.cpu().numpy()))
+                if whole:      # cp_wallish_full: the sequences are not written
+                    assert f._even_now is None and f._odd_now is None
+                    pk2, box2 = np.asarray(f.pknow), [b.cpu().numpy() for b in f._boxes]
+                else:
+                    got.append((np.asarray(f.pknow), [b.cpu().numpy() for b in f._boxes], f._even_now.cpu().numpy(), f._odd_now.cpu().numpy()))
         finally:
-            bf._TAIL_IN_ONE_KERNEL = saved
+            bf._TAIL_IN_ONE_KERNEL, bf._ALL_IN_ONE_KERNEL = saved
         (pk1, box1, even1, odd1), (pk0, box0, even0, odd0) = got
         assert pk1.shape == pk0.shape == (nb, 1024, 1)
         good = np.isfinite(par['h'])
@@ -271,3 +275,8 @@ def test_wallish_tail_in_one_kernel(cp):
             assert np.array_equal(a[good], b[good])
         np.testing.assert_allclose(even1[good], even0[good], rtol=1e-13, atol=1e-300)
         np.testing.assert_allclose(odd1[good], odd0[good], rtol=1e-13, atol=1e-300)
+        # ... and the whole filter as one kernel
+        assert np.isfinite(pk2[good]).all() and np.isnan(pk2[~good]).all() == np.isnan(pk0[~good]).all()
+        np.testing.assert_allclose(pk2[good], pk0[good], rtol=1e-12)
+        for a, b in zip(box2, box0):
+            assert np.array_equal(a[good], b[good])

@@ -12,7 +12,7 @@ from cosmoprimo_amd import bao_filter as bf      # noqa: E402
 dev = torch.device('cuda', 0)
 par = bench.eh_parameters(125000, 2, torch, dev)
 for rep in range(3):
-    for fused in (True, False):
-        bf._TAIL_IN_ONE_KERNEL = fused
+    for label, fused, whole in (('whole filter in one kernel', True, True), ('tail in one kernel', True, False), ('three kernels', False, False)):
+        bf._TAIL_IN_ONE_KERNEL, bf._ALL_IN_ONE_KERNEL = fused, whole
         out = bench.config4(cp, torch, dev, par, engines=('wallish2018',), spot_check=False)
-        print('one kernel' if fused else 'three kernels', {name: '%.4g vectors/s, %.2f ms for the share' % (v['value'], v['ms']) for name, v in out.items()}, flush=True)
+        print(label, {name: '%.4g vectors/s, %.2f ms for the share' % (v['value'], v['ms']) for name, v in out.items()}, flush=True)
