@@ -534,9 +534,8 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         if isinstance(interp, PowerSpectrumInterpolator2D):
             z = interp.z
             pk2 = pknow_cols.reshape(self._lead + (knots.size,))
-            if pk2.ndim != 2:
-                raise NotImplementedError('brieden2022 on batched 2D interpolators is not available yet')
-            clone = PowerSpectrumInterpolator2D(knots, z, pk2.T, interp_k=interp.interp_k, extrap_pk=interp.extrap_pk, extrap_kmin=interp.extrap_kmin,
+            # (nz, nknots) -> the (nknots, nz) table of the clone; a batch of tables (batch, nz, nknots) -> (batch, nknots, nz): one clone for all of them
+            clone = PowerSpectrumInterpolator2D(knots, z, pk2.transpose(-1, -2).contiguous() if pk2.ndim > 2 else pk2.T, interp_k=interp.interp_k, extrap_pk=interp.extrap_pk, extrap_kmin=interp.extrap_kmin,
                                                 extrap_kmax=interp.extrap_kmax, interp_order_k=interp.interp_order_k, interp_order_z=interp.interp_order_z,
                                                 growth_factor_sq=interp.growth_factor_sq, device=self.device)
             new = clone._rows_z(z, ignore_growth=True)(self.k_fid).reshape(-1, self.k_fid.size)

@@ -548,7 +548,71 @@ class MI355XFFTEngine(BaseFFTEngine):
             self._rfft_plans[key] = handle
         return self._rfft_plans[key]
 
+    @staticmethod
+    def _native_size(size):
+        """Sizes the row kernels of ``cp_rfft.hip`` take: powers of two from 8 to 16 384; every other size goes through Bluestein's algorithm on them."""
+        return 8 <= size <= 16384 and size & (size - 1) == 0
+
+    def _dft_any_size(self, a):
+        """DFT along the last axis of the complex device tensor ``a`` (rows, n) for ANY n, by Bluestein's chirp-z identity: with w_j = exp(-i pi j^2 / n),
+        X_k = w_k sum_j (a_j w_j) conj(w)_{k-j} -- a cyclic convolution of length M >= 2 n - 1, taken as a power of two and run on this package's own real
+        FFTs (a complex transform of length M = the real transforms of its real and imaginary parts; the inverse = the forward transform of the conjugate)."""
+        torch = _torch()
+        n = a.shape[-1]
+        dev = a.device
+        M = 8
+        while M < 2 * n - 1:
+            M *= 2
+        if not self._native_size(M):      # (the convolution must itself be a native transform: no recursion)
+            raise NotImplementedError('FFT engine of size {:d}: sizes that are not a power of two go up to 8192 (their convolution of length {:d} must fit '
+                                      'the row kernels, 16 384 samples); powers of two up to 16 384'.format(n, M))
+        cache = self.__dict__.setdefault('_bluestein', {})
+        key = (n, dev.index)
+        if key not in cache:
+            j = np.arange(n, dtype='i8')
+            w = np.exp(-1j * np.pi * ((j * j) % (2 * n)) / n)      # (j^2 reduced modulo 2 n: the phase keeps its digits for long rows)
+            b = np.zeros(M, dtype='c16')
+            b[:n] = np.conj(w)
+            b[M - n + 1:] = np.conj(w[1:][::-1])
+            cache[key] = (torch.as_tensor(w).to(dev), torch.as_tensor(np.fft.fft(b)).to(dev), MI355XFFTEngine(M, device=dev))
+        w, B, sub = cache[key]
+
+        def fft(c):      # complex (rows, M) -> complex (rows, M)
+            halves = [sub.forward(part.contiguous()) for part in (c.real, c.imag)]      # (rows, M // 2 + 1) each
+            full = [torch.cat([h, torch.conj(h[..., 1:M // 2]).flip(-1)], dim=-1) for h in halves]
+            return full[0] + 1j * full[1]
+
+        padded = torch.zeros(a.shape[:-1] + (M,), dtype=torch.complex128, device=dev)
+        padded[..., :n] = a * w
+        conv = torch.conj(fft(torch.conj(fft(padded) * B))) / M
+        return conv[..., :n] * w
+
+    def _run_any_size(self, fun, backward):
+        torch = _torch()
+        is_torch = _is_torch(fun)
+        dev = dv.resolve_device(self._device, fun)
+        n = int(self.size)
+        nh = n // 2 + 1
+        if backward:      # irfft(conj(fun), n): the DFT of the Hermitian extension of fun is real; the imaginary parts of its DC (and Nyquist) bins are ignored, as numpy does
+            x = (fun if is_torch else torch.as_tensor(np.ascontiguousarray(fun, dtype='c16'))).to(device=dev, dtype=torch.complex128)
+            if x.ndim < 1 or x.shape[-1] != nh:
+                raise ValueError('last dimension must be {:d}, got shape {}'.format(nh, tuple(x.shape)))
+            x = x.reshape(-1, nh).clone()
+            x[:, 0] = x[:, 0].real
+            if n % 2 == 0:
+                x[:, -1] = x[:, -1].real
+            full = torch.cat([x, torch.conj(x[:, 1:(n + 1) // 2]).flip(-1)], dim=-1)
+            out = (self._dft_any_size(full).real / n).reshape(tuple(fun.shape[:-1]) + (n,))
+        else:
+            x = (fun if is_torch else torch.as_tensor(np.ascontiguousarray(fun, dtype='f8'))).to(device=dev, dtype=torch.float64)
+            if x.ndim < 1 or x.shape[-1] != n:
+                raise ValueError('last dimension must be {:d}, got shape {}'.format(n, tuple(x.shape)))
+            out = self._dft_any_size(x.reshape(-1, n).to(torch.complex128))[:, :nh].reshape(tuple(fun.shape[:-1]) + (nh,))
+        return out if is_torch else dv.to_host(out)
+
     def _run(self, fun, backward):
+        if not self._native_size(int(self.size)):
+            return self._run_any_size(fun, backward)
         torch = _torch()
         is_torch = _is_torch(fun)
         dev = dv.resolve_device(self._device, fun)

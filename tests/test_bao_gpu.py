@@ -280,3 +280,19 @@ def test_wallish_tail_in_one_kernel(cp):
         np.testing.assert_allclose(pk2[good], pk0[good], rtol=1e-12)
         for a, b in zip(box2, box0):
             assert np.array_equal(a[good], b[good])
+
+
+def test_brieden2022_on_a_batch_of_tables(cp, golden):
+    """brieden2022 with ONE cosmology on a batched 2D interpolator (a batch of (k, z) tables): every table as on its own."""
+    from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
+    g = golden('bao')
+    fid = cp.Cosmology(engine='eisenstein_hu')
+    cosmo = cp.Cosmology(engine='eisenstein_hu', **BAO_PARAMS[3])
+    tables = np.stack([g['tab_pk'], 1.1 * g['tab_pk'][:, ::-1], g['tab_pk']**1.01])      # (3, nk, nz)
+    batch = cp.PowerSpectrumInterpolator2D(g['tab_k'], g['tab_z'], tables)
+    b = PowerSpectrumBAOFilter(batch, engine='brieden2022', cosmo=cosmo, cosmo_fid=fid)
+    assert b.pknow.shape == (3, 1024, 4)
+    np.testing.assert_allclose(b.pknow[0], g['tab_brieden_pknow'], rtol=RTOL)
+    for i in range(3):
+        one = PowerSpectrumBAOFilter(cp.PowerSpectrumInterpolator2D(g['tab_k'], g['tab_z'], tables[i]), engine='brieden2022', cosmo=cosmo, cosmo_fid=fid)
+        np.testing.assert_allclose(b.pknow[i], one.pknow, rtol=1e-10)

@@ -448,8 +448,30 @@ def test_engine_forward_backward_are_real_ffts(cp, size):
     assert np.isnan(out[2]).all() and np.isfinite(np.delete(out, 2, axis=0)).all()
     with pytest.raises(ValueError):
         NumpyFFTEngine(size).forward(np.zeros(size + 1))
-    with pytest.raises(NotImplementedError):
-        NumpyFFTEngine(24).forward(np.zeros(24))
+
+
+@pytest.mark.parametrize('size', [6, 24, 100, 255, 1000, 8190])
+def test_engines_of_any_size(cp, size):
+    """Sizes the row kernels do not take (anything but a power of two from 8 to 16 384: numpy.fft.rfft takes any, reference fftlog.py:533-544) go through
+    Bluestein's algorithm on the package's own transforms: rows against numpy, each on its own scale; odd and even sizes."""
+    import torch
+    from cosmoprimo_amd.fftlog import NumpyFFTEngine
+    rng = np.random.default_rng(size)
+    x = rng.normal(size=(2, 3, size)) * np.array([1e-9, 1e6])[:, None, None]
+    engine = NumpyFFTEngine(size)
+    spectrum, ref = engine.forward(x), np.fft.rfft(x, axis=-1)
+    assert spectrum.dtype == np.complex128 and spectrum.shape == ref.shape
+    for i in range(2):
+        assert np.abs(spectrum[i] - ref[i]).max() < 1e-13 * np.abs(ref[i]).max()
+    z = rng.normal(size=(2, 3, size // 2 + 1)) + 1j * rng.normal(size=(2, 3, size // 2 + 1))
+    back, ref = engine.backward(z), np.fft.irfft(z.conj(), n=size, axis=-1)
+    assert back.dtype == np.float64 and back.shape == ref.shape
+    assert np.abs(back - ref).max() < 1e-13 * np.abs(ref).max()
+    assert np.abs(engine.backward(engine.forward(x[1]).conj()) - x[1]).max() < 1e-13 * np.abs(x[1]).max()
+    t = engine.forward(torch.as_tensor(x[1, 0], device='cuda'))
+    assert t.is_cuda and t.shape == (size // 2 + 1,)
+    with pytest.raises(NotImplementedError):      # beyond what a convolution of 16 384 samples covers
+        NumpyFFTEngine(3 * 4096).forward(np.zeros(3 * 4096))
 
 
 def test_engine_instance_gives_the_fused_result(cp, golden):
