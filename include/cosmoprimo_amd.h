@@ -329,9 +329,10 @@ int cp_sigma_rz_fused_available(const cp_fftlog_plan* fftlog, const cp_spline_pl
 int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_in, double* d_out, long long nbatch, int post_op,
                              void* stream);
 /* The same for any number of rows, with the spline SOLVED inside the kernel instead of applied as a banded operator: the output grid of an FFTLog
- * is geometric, the natural spline's tridiagonal system then has constant coefficients (second derivatives scaled by their interval), and five
- * steps of cyclic reduction in LDS on the knots the queries see (+ 32 on either side) give them exactly to rounding -- no weights to fetch but
- * 12 bytes per query (interpolator.py:285-291, jax.py:169-175 with bc_type='natural').
+ * is geometric, the natural spline's tridiagonal system then has constant coefficients (second derivatives scaled by their interval) and its inverse is
+ * two geometric tails: a lane owns a run of the knots the queries see (+ a halo of 32 on either side of the stretch, at most 512 knots in all), runs the
+ * causal and the anti-causal first-order recursion over them in registers, and takes its neighbours' segment totals by DPP wave shifts -- exact to
+ * rounding, no weights to fetch but 12 bytes per query (interpolator.py:285-291, jax.py:169-175 with bc_type='natural').
  * cp_geospline_plan_create: knots (n) a geometric grid (host), queries (nq <= 512, host; outside the knots: NaN); CP_EUNSUPPORTED when the knots
  * are not geometric, the queries span more than 448 knots or come within 32 knots of either end of the grid (take cp_spline_plan + cp_spline_apply).
  * cp_fftlog_geospline_execute: d_in (nbatch, n) rows; group = 0: d_out (nbatch, nq); group > 0 (even, dividing nbatch): rows come in groups
@@ -558,14 +559,15 @@ int cp_wallish_full(const cp_dst_plan* dst, const cp_splice_plan* splice, int en
                     const cp_ncdm* ncdm, const cp_param* pk_params, const double* d_pk, int npk, int margin_first, int margin_second, int offset_first,
                     int offset_second, const double* d_tophat, int* d_box, double* d_coef, double* d_out, void* d_work, void* stream);
 
-/* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
- * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];
- * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */
 /* tensor-product spline at PAIRS of points, RectBivariateSpline(...)(x, y, grid=False) (Interpolator2D, jax.py:241-287):
  * d_out[b, q] = sum_i sum_j d_wx[q, i] d_f[b, i, j] d_wy[q, j]; d_wx (nq, nx), d_wy (nq, ny): rows of the two 1-D spline operators at the queries,
  * d_f (nbatch, nx, ny) tables, d_out (nbatch, nq). */
 int cp_bilinear_pairs(const double* d_wx, const double* d_wy, const double* d_f, double* d_out, long long nbatch, int nq, int nx, int ny, int device,
                       void* stream);
+
+/* ---- piecewise-linear interpolation of one table at many points (replaces numpy.interp of the 'tabulated' engine, tabulated.py:31-36) ----
+ * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];
+ * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */
 int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const double* d_x, double* d_out, long long nx, int device, void* stream);
 
 /* ---- cubic splines at many points (replaces Interpolator1D.__call__ = CubicSpline(x, fun)(xq) when there are few splines and 1e6-1e9 queries:
