@@ -68,9 +68,6 @@ struct SigmaArgs {
 #ifndef CP_SIGMA_RZ_TABLES
 #define CP_SIGMA_RZ_TABLES 0
 #endif
-#ifndef CP_SIGMA_FIRST_K_IN_LDS      // 1: the per-thread constants of the evaluation in LDS, the steps in scalar registers (see sigma_rz_kernel)
-#define CP_SIGMA_FIRST_K_IN_LDS 1
-#endif
 
 // phases 0 .. NPH - 2 of the FFTLog of one pair, with the barriers of run_phases (cp_fftlog_kernel.h)
 template <class F, int PH>
@@ -221,33 +218,21 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
     F::fill_lds_tables(t, A, lds);
     const int t0 = st.t0;
     // The thread's first wavenumber, its logarithm, k^1.08 and k^1.4 there (tables behind log k: log_wavenumbers_kernel) and the steps along the geometric
-    // grid are the same for every pair.  Kept in vector registers over the loop they were spilled (the transform takes what two waves per SIMD leave), and a
-    // scratch reload at the top of a pair is a vector-memory load: it waits for the 256 stores of the previous pair (the counter retires in order), the very
-    // thing the evaluation is arranged to avoid.  The four per-thread values live in LDS instead (its own counter), the steps in scalar registers.
+    // grid are the same for every pair.  All eight in vector registers over the loop, they were spilled (the transform takes what two waves per SIMD
+    // leave), and a scratch reload at the top of a pair is a vector-memory load: it waits for the 256 stores of the previous pair (the counter retires in
+    // order), the very thing the evaluation is arranged to avoid.
     const int nk_tab = NP / 2;
-#if CP_SIGMA_FIRST_K_IN_LDS
+    // (the four steps along the grid are the same in every lane: scalar registers; the thread's own four constants stay in vector registers -- an LDS copy
+    // of them, 4 KB, costs the fourth workgroup of the CU: 0.33 -> 0.37 ms, measured)
     const double ratio = cp::wave_uniform(S.k[T] / S.k[0]), ln_ratio = cp::wave_uniform(S.ln_k[T] - S.ln_k[0]);
     const double2 pw_ratio = double2{cp::wave_uniform(S.ln_k[nk_tab + T] / S.ln_k[nk_tab]), cp::wave_uniform(S.ln_k[2 * nk_tab + T] / S.ln_k[2 * nk_tab])};
-    double* first_k = roots_g + 2 * S.nz;      // (4, T)
-    first_k[t] = S.k[t0];
-    first_k[T + t] = S.ln_k[t0];
-    first_k[2 * T + t] = S.ln_k[nk_tab + t0];
-    first_k[3 * T + t] = S.ln_k[2 * nk_tab + t0];
-#else
-    const double ratio = S.k[T] / S.k[0], ln_ratio = S.ln_k[T] - S.ln_k[0];
-    const double2 pw_ratio = double2{S.ln_k[nk_tab + T] / S.ln_k[nk_tab], S.ln_k[2 * nk_tab + T] / S.ln_k[2 * nk_tab]};
     const double kh0 = S.k[t0], ln0 = S.ln_k[t0];
     const double2 pw0 = double2{S.ln_k[nk_tab + t0], S.ln_k[2 * nk_tab + t0]};
-#endif
     __syncthreads();
     for (; p < npairs; p += gridDim.x) {
         const long long ia = 2 * p;
         const bool has_b = ia + 1 < S.ncosmo;
         const long long ib = has_b ? ia + 1 : ia;
-#if CP_SIGMA_FIRST_K_IN_LDS
-        const double kh0 = first_k[t], ln0 = first_k[T + t];
-        const double2 pw0 = double2{first_k[2 * T + t], first_k[3 * T + t]};
-#endif
         if (CP_SIGMA_ABLATE & 1) {
 #pragma unroll
             for (int r = 0; r < H; ++r) st.va[r] = 1. + 1e-3 * (t + r), st.vb[r] = 2. - 1e-3 * (t + r);
@@ -743,7 +728,7 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_fused: cannot select device %d", device);
     using F = Fftlog<NP, P, IN_HALF_ZERO_GEN, OUT_HALF>;
-    const size_t lds = (size_t)F::LDS_BYTES + (size_t)(2 * b.nq + 2 * nz + 4 * (NP / P)) * sizeof(double);      // ... + the threads' first wavenumbers (sigma_rz_kernel)
+    const size_t lds = (size_t)F::LDS_BYTES + (size_t)(2 * b.nq + 2 * nz) * sizeof(double);
     int ncu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
     const long long npairs = (ncosmo + 1) / 2;
