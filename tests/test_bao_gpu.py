@@ -238,7 +238,8 @@ def test_wallish_box_kernel():
         assert np.array_equal(box.cpu().numpy(), ref), n
 
 
-def test_wallish_tail_in_one_kernel(cp):
+@pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
+def test_wallish_tail_in_one_kernel(cp, engine):
     """cp_wallish_tail (second derivatives + box + removal, inverse transform, spliced spline + damping of wallish2018 as one kernel, the transformed rows
     kept on the CU) and cp_wallish_full (the forward transform with its spectra in the same kernel) against the three calls they replace: pknow, the boxes and the rewritten sequences; odd batches (a vector without a partner) and a
     vector that is not finite next to good ones (it comes out as the three calls leave it, its partner untouched)."""
@@ -247,11 +248,11 @@ def test_wallish_tail_in_one_kernel(cp):
     from cosmoprimo_amd.bao_filter import PowerSpectrumBAOFilter
     fid = cp.Cosmology(engine='eisenstein_hu')
     rng = np.random.default_rng(17)
-    for nb in (129, 200, 513):
+    for nb in (129, 200, 513) if engine == 'eisenstein_hu' else (131,):
         par = dict(Omega_m=rng.uniform(0.24, 0.40, nb), Omega_b=rng.uniform(0.04, 0.06, nb), h=rng.uniform(0.6, 0.8, nb), n_s=rng.uniform(0.92, 1., nb))
         if nb == 200:
             par['h'][7] = np.nan      # a vector of NaN in the middle of a pair
-        cosmo = cp.Cosmology(engine='eisenstein_hu', sigma8=0.8, **par)
+        cosmo = cp.Cosmology(engine=engine, sigma8=0.8, **par)
         interp = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
         saved = bf._TAIL_IN_ONE_KERNEL, bf._ALL_IN_ONE_KERNEL
         try:
@@ -280,6 +281,27 @@ def test_wallish_tail_in_one_kernel(cp):
         np.testing.assert_allclose(pk2[good], pk0[good], rtol=1e-12)
         for a, b in zip(box2, box0):
             assert np.array_equal(a[good], b[good])
+        if nb == 129:      # cp_wallish_full with d_coef: the rewritten sequences it can hand back are the ones the separate calls leave
+            from cosmoprimo_amd import _lib, _device as dv
+            from cosmoprimo_amd.background import DEFAULTS as bg_defaults
+            from cosmoprimo_amd.power import PK_DEFAULTS
+            ops = f._operators()
+            name, bg, pk = interp._interp.analytic_engine()
+            cbg, _, keep1 = dv.pack_params(_lib.BG_PARAMS, bg, bg_defaults, f.device)
+            cpk, _, keep2 = dv.pack_params(_lib.PK_PARAMS, pk, PK_DEFAULTS, f.device)
+            lib = _lib.load()
+            rows = f._pk_rows.contiguous()
+            coef = torch.empty((nb, 4096), dtype=torch.float64, device=f.device)
+            box = torch.empty((2 * nb, 2), dtype=torch.int32, device=f.device)
+            out = torch.empty_like(rows)
+            work = torch.empty(int(lib.cp_dst_forward_analytic_workspace_bytes(nb)), dtype=torch.uint8, device=f.device)
+            _lib.check(lib.cp_wallish_full(ops['dst']._handle, ops['splice']._handle, _lib.ENGINES[name], nb, dv.as_void_p(cbg), 0, None, dv.as_void_p(cpk), rows.data_ptr(),
+                                           rows.shape[1], 20, 5, -10, 20, ops['tophat'].data_ptr(), box.data_ptr(), coef.data_ptr(), out.data_ptr(), work.data_ptr(),
+                                           dv.stream_of(f.device)))
+            seqs = coef.view(2 * nb, 2048).cpu().numpy()
+            np.testing.assert_allclose(seqs[0::2], even0, rtol=1e-13, atol=1e-300)
+            np.testing.assert_allclose(seqs[1::2], odd0, rtol=1e-13, atol=1e-300)
+            np.testing.assert_allclose(out.cpu().numpy(), pk0[:, :, 0], rtol=1e-12)
 
 
 def test_brieden2022_on_a_batch_of_tables(cp, golden):
