@@ -567,7 +567,10 @@ def _brieden_compute_batched(self, rescale):
     nb, n = rescale.numel(), self.k_fid.size
     lib, stream = _lib.load(), dv.stream_of(self.device)
     rescale = rescale.contiguous()
-    fused = _RESAMPLE_IN_ONE_KERNEL == 2 and 129 <= n <= 512 and self._envelope_columns[0].size <= 64
+    # the one-kernel routes solve the re-sampling spline with the constant coefficients of a geometric k_fid: any other spacing takes the general route
+    steps = np.diff(np.log(self.k_fid))
+    geometric = bool(np.all(np.abs(steps - steps[0]) <= 1e-9 * abs(steps[0])))
+    fused = _RESAMPLE_IN_ONE_KERNEL == 2 and geometric and 129 <= n <= 512 and self._envelope_columns[0].size <= 64
     # P_c(k_fid / r_c), (B, 341) -- or at the extrema only, (B, 23): all the envelope depends on
     rows = interp._pk_scaled(self.k_fid[self._envelope_columns[0]] if fused else self.k_fid, 1. / rescale).contiguous()
     now = Fourier(self.cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator(z=np.array([0.]))
@@ -600,7 +603,7 @@ def _brieden_compute_batched(self, rescale):
     _lib.check(lib.cp_brieden_ratio(rows.data_ptr(), raw.data_ptr(), g0.data_ptr(), const['correction'].data_ptr(), const['ratio_fid'].data_ptr(),
                                     pknow.data_ptr(), ratio.data_ptr(), nb, n, self.device.index, stream))
     envelope = self._envelope(ratio)                                                                  # (B, 341)
-    if _RESAMPLE_IN_ONE_KERNEL and 129 <= n <= 512:
+    if _RESAMPLE_IN_ONE_KERNEL and geometric and 129 <= n <= 512:
         # log10 of envelope x pknow x ratio_now_fid on the per-cosmology knots k_fid / rescale with the two extrapolated knots of _pad_log on either side,
         # its natural spline at k_fid, 10^x written over the k_fid range of P (bao_filter.py:500-509): one kernel, a wave per cosmology (k_fid is a
         # range of the filter's geometric grid: the spline's system has constant coefficients)
