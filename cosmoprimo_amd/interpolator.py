@@ -311,7 +311,11 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
                     return solved.transpose(-1, -2)
                 return solved
         if growth_sq is not None:
-            return op.outer(fft(rows)[1], growth_sq, sqrt=True)
+            var = fft(rows)[1]
+            growth_sq = dv.to_device(growth_sq, device)
+            if growth_sq.ndim < var.ndim:      # one growth factor for the whole batch
+                growth_sq = growth_sq.expand(tuple(var.shape[:-1]) + (growth_sq.shape[-1],)).contiguous()
+            return op.outer(var, growth_sq, sqrt=True)
         var = fft(rows, out_window=op.columns)[1]      # the radii see a part of the FFTLog grid: only that part is written
         if radii_before_last_axis and var.ndim >= 2:      # (..., nz, nk) -> (..., nr, nz): sigma_rz's layout written by the spline kernel itself
             if _TRANSPOSE_IN_STORE:
@@ -1066,9 +1070,8 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         self.device = dv.resolve_device(device, pk)
         self._tables_batched = len(pk.shape if hasattr(pk, 'shape') else np.shape(pk)) == 3
         if self._tables_batched:
-            # (batch, nk, nz): one (k, z) table per cosmology on shared grids, kept on the device (extension of the reference's (nk, nz) table)
-            if growth_factor_sq is not None:
-                raise NotImplementedError('a batch of (k, z) tables and a growth factor')
+            # (batch, nk, nz): one (k, z) table per cosmology on shared grids, kept on the device (extension of the reference's (nk, nz) table);
+            # growth_factor_sq(z) -> (nz,) or (batch, nz) multiplies the interpolated tables as it does the reference's single table
             k, pk = self._prepare_tables(k, z, pk, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
         else:
             k, pk = self._prepare(k, pk, z=z, interp_k=interp_k, extrap_pk=extrap_pk, extrap_kmin=extrap_kmin, extrap_kmax=extrap_kmax)
@@ -1080,15 +1083,16 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         else:
             if self.growth_factor_sq is None:
                 raise ValueError('provide either 2D pk array or growth_factor_sq')
-            self._interp = Interpolator1D(k, pk[:, 0], k=self.interp_order_k, interp_x=self.interp_k, interp_fun=self.extrap_pk, assume_sorted=True,
-                                          device=self.device)
+            # one column of P(k) (a batch: one column per cosmology, (batch, nk, 1) -> the columns (nk, batch) of one 1D interpolator) x growth factor
+            self._interp = Interpolator1D(k, pk[:, :, 0].T if self._tables_batched else pk[:, 0], k=self.interp_order_k, interp_x=self.interp_k,
+                                          interp_fun=self.extrap_pk, assume_sorted=True, device=self.device)
         self.is_from_callable = False
 
     default_params = _get_default_kwargs(__init__, start=4, remove=('device',))
 
     def _is2d(self):
-        """A (k, z) table (or a batch of them), as opposed to one column of P(k) with a growth factor."""
-        return getattr(self, '_tables_batched', False) or self._pk.shape[1] > 1
+        """A (k, z) table (or a batch of them), as opposed to one column of P(k) (per cosmology) with a growth factor."""
+        return self._pk.shape[-1] > 1
 
     def _prepare_tables(self, k, z, pk, interp_k='log', extrap_pk='log', extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax):
         """``_prepare`` + ``_pad_log`` (reference interpolator.py:329-351, 42-87) for a batch of tables (batch, nk, nz), on the device: sorted grids,
@@ -1202,10 +1206,13 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
                 interp.extrap = saved
             else:
                 tmp = self._interp(dv.upload(kh, self.device))
+                if tmp.ndim > 1:      # a batch of columns: the batch axis leads
+                    tmp = tmp.T
                 if grid:
-                    tmp = tmp[:, None].expand(kh.size, zh.size)
+                    tmp = tmp[..., :, None].expand(tuple(tmp.shape) + (zh.size,))
             if self.growth_factor_sq is not None and not ignore_growth:
-                tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
+                growth = dv.to_device(self.growth_factor_sq(zh), self.device)
+                tmp = tmp * (growth[..., None, :] if grid and growth.ndim > 1 else growth)      # (batch, nz) against (batch, nk, nz)
             out = tmp if mask.all() else torch.where(dv.upload(mask, self.device), tmp, torch.full_like(tmp, float('nan')))
         if getattr(self, '_tables_batched', False):
             return self._rescaled(out, 1)
@@ -1403,13 +1410,32 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
 
     def to_xi(self, nk=1024, fftlog_kwargs=None, **kwargs):
         """Transform into a :class:`CorrelationFunctionInterpolator2D` with FFTLog (reference interpolator.py:965-987).
-        A batch of cosmologies has no tabulated interpolator: use :meth:`to_xi_arrays`."""
-        s, z, xi = self.to_xi_arrays(nk=nk, fftlog_kwargs=fftlog_kwargs)
-        if xi.ndim > 2:
-            raise NotImplementedError('to_xi() of a batch of cosmologies: use to_xi_arrays()')
+        A batch of cosmologies (leading dimensions) gives an interpolator of the batch: xi(s, z) -> (batch..., ns, nz), see :meth:`_to_xi_batch`."""
         default_params = dict(interp_s='log', interp_order_s=self.interp_order_k, interp_order_z=self.interp_order_z, growth_factor_sq=self.growth_factor_sq)
         default_params.update(kwargs)
+        batch = self._to_xi_batch(nk, fftlog_kwargs, default_params)
+        if batch is not None:
+            return batch
+        s, z, xi = self.to_xi_arrays(nk=nk, fftlog_kwargs=fftlog_kwargs)
         return CorrelationFunctionInterpolator2D(s, z=z, xi=xi, device=self.device, **default_params)
+
+    def _to_xi_batch(self, nk, fftlog_kwargs, params):
+        """:meth:`to_xi` of a batch of cosmologies, or None for one cosmology: a :class:`CorrelationFunctionInterpolator2D` of a batch of tables kept on
+        the device, (batch, ns, nz) -- or (batch, ns, 1) for P(k) x growth factor: ONE transform per cosmology, the growth factor handed on."""
+        k = np.geomspace(self.extrap_kmin, self.extrap_kmax, nk)
+        fft = _cached_fftlog(PowerToCorrelation, k, self.device, fftlog_kwargs)
+        if self._separable():
+            rows = self._eval_device(k, self.z[:1], grid=True, ignore_growth=True)[..., 0]      # (batch..., nk)
+            if rows.ndim < 2:
+                return None
+            rows = rows[..., None, :]
+        elif getattr(self, '_tables_batched', False) or (self.is_from_callable and self._eval_device(k[:1], self.z[:1]).ndim > 2):
+            rows = self._rows_z(self.z, ignore_growth=True)(k)      # (batch..., nz, nk)
+        else:
+            return None
+        s, xi = fft(rows.contiguous())
+        xi = xi.transpose(-1, -2)
+        return CorrelationFunctionInterpolator2D(s.cpu().numpy(), z=self.z, xi=xi.reshape((-1,) + tuple(xi.shape[-2:])), device=self.device, **params)
 
 
 def get_default_s_callable():
@@ -1569,8 +1595,14 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         self._rsigma8sq = 1.
         self.growth_factor_sq = growth_factor_sq
         self.device = dv.resolve_device(device, xi)
-        s, xi = self._prepare(s, xi, z=z, interp_s=interp_s)
-        is2d = self._xi.shape[1] > 1
+        self._tables_batched = len(xi.shape if hasattr(xi, 'shape') else np.shape(xi)) == 3
+        if self._tables_batched:
+            # (batch, ns, nz): one (s, z) table per cosmology on shared grids, kept on the device (extension of the reference's (ns, nz) table, what
+            # to_xi() of a batch of cosmologies returns); (batch, ns, 1) with several z: xi(s) x growth_factor_sq(z), z being the range of validity
+            s, xi = self._prepare_tables(s, z, xi, interp_s=interp_s)
+        else:
+            s, xi = self._prepare(s, xi, z=z, interp_s=interp_s)
+        is2d = self._xi.shape[-1] > 1
         # the reference does int(interp_order_z) on its own default None (TypeError); None means cubic here
         self.interp_order_s, self.interp_order_z = int(interp_order_s), 3 if interp_order_z is None else int(interp_order_z)
         if is2d:
@@ -1579,8 +1611,32 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         else:
             if self.growth_factor_sq is None:
                 raise ValueError('provide either 2D pk array or growth_factor_sq')
-            self._interp = Interpolator1D(s, xi[:, 0], k=self.interp_order_s, interp_x=self.interp_s, assume_sorted=True, device=self.device)
+            self._interp = Interpolator1D(s, xi[:, :, 0].T if self._tables_batched else xi[:, 0], k=self.interp_order_s, interp_x=self.interp_s, assume_sorted=True,
+                                          device=self.device)
         self.is_from_callable = False
+
+    def _prepare_tables(self, s, z, xi, interp_s='log'):
+        """``_prepare`` for a batch of tables (batch, ns, nz) -- or (batch, ns, 1): constant in z over the range of ``z`` -- on the device."""
+        self.s, self.z = np.array(_host(s), dtype='f8').ravel(), np.array(_host(z), dtype='f8').ravel()
+        xi = dv.to_device(xi, self.device)
+        if tuple(xi.shape[1:]) not in [(self.s.size, self.z.size), (self.s.size, 1)]:
+            raise ValueError('xi must be (batch, {0:d}, {1:d}) or (batch, {0:d}, 1), got {2}'.format(self.s.size, self.z.size, tuple(xi.shape)))
+        i_s, i_z = np.argsort(self.s), np.argsort(self.z)
+        if np.any(i_s[1:] < i_s[:-1]):
+            xi = xi.index_select(1, dv.upload(i_s, self.device))
+        if xi.shape[2] > 1 and np.any(i_z[1:] < i_z[:-1]):
+            xi = xi.index_select(2, dv.upload(i_z, self.device))
+        self.s, self.z, self._xi = self.s[i_s], self.z[i_z], xi.contiguous()
+        self.interp_s = str(interp_s)
+        return self.s, self._xi
+
+    def _rescaled(self, out):
+        """``out`` (batch..., ...) times the sigma8 rescaling factor (a float, or one value per batch entry)."""
+        rs = self._rsigma8sq
+        if np.ndim(rs) or dv.is_torch(rs):
+            rs = dv.to_device(rs, self.device)
+            rs = rs.reshape(tuple(rs.shape) + (1,) * (out.ndim - rs.ndim))
+        return out * rs
 
     default_params = _get_default_kwargs(__init__, start=4, remove=('device',))
 
@@ -1590,7 +1646,7 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         if self.is_from_callable:
             kwargs = {'ignore_growth': True} if self.growth_factor_sq is not None else {}
             return self(self.s, self.z, **kwargs)
-        return self._xi * self._rsigma8sq
+        return self._rescaled(self._xi)
 
     @property
     def zmin(self):
@@ -1635,28 +1691,32 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
             else:
                 tmp = dv.to_device(self._interp(sh, zh, grid=grid), self.device)
         else:
-            is2d = self._xi.shape[1] > 1
-            if not is2d:
+            is2d = self._xi.shape[-1] > 1
+            if not is2d and not (getattr(self, '_tables_batched', False) and self.z.size > 1):
                 mask_z = mask_z | True    # ignore input z
             mask = mask_s[:, None] & mask_z if grid else mask_s & mask_z
             if is2d:
                 tmp = self._interp(dv.upload(sh, self.device), dv.upload(zh, self.device), grid=grid)
             else:
                 tmp = self._interp(dv.upload(sh, self.device))
+                if tmp.ndim > 1:      # a batch of columns: the batch axis leads
+                    tmp = tmp.T
                 if grid:
-                    tmp = tmp[:, None].expand(sh.size, zh.size)
+                    tmp = tmp[..., :, None].expand(tuple(tmp.shape) + (zh.size,))
             if self.growth_factor_sq is not None and not ignore_growth:
-                tmp = tmp * dv.to_device(self.growth_factor_sq(zh), self.device)
+                growth = dv.to_device(self.growth_factor_sq(zh), self.device)
+                tmp = tmp * (growth[..., None, :] if grid and growth.ndim > 1 else growth)      # (batch, nz) against (batch, ns, nz)
         out = torch.where(dv.upload(mask, self.device), tmp, torch.full_like(tmp, float('nan')))
-        return out * self._rsigma8sq
+        return self._rescaled(out)
 
     def __call__(self, s, z, grid=True, ignore_growth=False, bounds_error=False):
-        """Evaluate at separations ``s`` and redshifts ``z``: shape s.shape + z.shape (``grid``) or s.shape (pairs)."""
+        """Evaluate at separations ``s`` and redshifts ``z``: shape (batch...) + s.shape + z.shape (``grid``) or + s.shape (pairs)."""
         like_torch = dv.is_torch(s) or dv.is_torch(z)
         dtype = dv.float_dtype(s, z)
         sh, zh = _host(s), _host(z)
         out = self._eval_device(sh.ravel(), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error)
-        return _finish(out, dtype, like_torch, sh.shape + zh.shape if grid else sh.shape)
+        lead = tuple(out.shape[:out.ndim - (2 if grid else 1)])
+        return _finish(out, dtype, like_torch, lead + (sh.shape + zh.shape if grid else sh.shape))
 
     def sigma_dz(self, z, **kwargs):
         """R.m.s. of the displacement field at ``z``, through :meth:`to_pk` (reference interpolator.py:1409-1415)."""
@@ -1690,9 +1750,16 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
     def to_pk(self, ns=1024, fftlog_kwargs=None, **kwargs):
         """Transform into a :class:`PowerSpectrumInterpolator2D` with FFTLog, growth factor left out (reference interpolator.py:1469-1498)."""
         s = np.geomspace(self.extrap_smin, self.extrap_smax, ns)
-        rows = self._eval_device(s, self.z, grid=True, ignore_growth=True).T.contiguous()     # (nz, ns)
+        constant = self.growth_factor_sq is not None and (self.is_from_callable or self._xi.shape[-1] == 1)      # xi(s) x growth factor: one transform (per cosmology)
+        zz = self.z[:1] if constant else self.z
+        rows = self._eval_device(s, zz, grid=True, ignore_growth=True).transpose(-1, -2).contiguous()     # (batch..., nz, ns)
         k, pk = _cached_fftlog(CorrelationToPower, s, self.device, fftlog_kwargs)(rows)
         default_params = dict(interp_k='log', extrap_pk='log', interp_order_k=self.interp_order_s, interp_order_z=self.interp_order_z,
                               growth_factor_sq=self.growth_factor_sq)
         default_params.update(kwargs)
-        return PowerSpectrumInterpolator2D(k.cpu().numpy(), z=self.z, pk=pk.T, device=self.device, **default_params)
+        pk = pk.transpose(-1, -2)
+        if constant:
+            pk = pk.expand(tuple(pk.shape[:-1]) + (self.z.size,))
+        if pk.ndim > 2:      # a batch of cosmologies: a batch of (k, z) tables on the device (leading dimensions flattened)
+            pk = pk.reshape((-1,) + tuple(pk.shape[-2:]))
+        return PowerSpectrumInterpolator2D(k.cpu().numpy(), z=self.z, pk=pk, device=self.device, **default_params)

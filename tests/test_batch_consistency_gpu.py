@@ -54,10 +54,23 @@ def test_batch_consistency():
         same(fb.pknow, [cp.PowerSpectrumBAOFilter(p, engine=engine, cosmo=c, cosmo_fid=fid).pknow for p, c in zip(p1s, singles)], 1e-9 if engine != 'hinton2017' else 1e-7,
              cols=True)
     fb = cp.PowerSpectrumBAOFilter(pkb, engine='wallish2018')
-    with pytest.raises(NotImplementedError):
-        pkb.to_xi()
-    with pytest.raises(NotImplementedError):
-        fb.smooth_pk_interpolator()
+    fs = [cp.PowerSpectrumBAOFilter(p, engine='wallish2018') for p in pks]
+    # to_xi of the batch: ONE transform per cosmology, the growth factor handed on; (batch, ns, nz)
+    xib, xis = pkb.to_xi(), [p.to_xi() for p in pks]
+    assert xib(s, z).shape == (3, 40, 3) and xib(s[:3], z, grid=False).shape == (3, 3)
+    same(xib(s, z), [x(s, z) for x in xis], 1e-8, atol=1e-13)
+    same(xib(s[:3], z, grid=False), [x(s[:3], z, grid=False) for x in xis], 1e-8, atol=1e-13)
+    same(xib(s, z, ignore_growth=True), [x(s, z, ignore_growth=True) for x in xis], 1e-8, atol=1e-13)
+    assert np.isnan(xib(s, [-0.5, 0.5])[:, :, 0]).all() and not np.isnan(xib(s, [-0.5, 0.5])[:, :, 1]).any()
+    # ... and back: a batch of (k, z) tables with the growth factor
+    back, backs = pkb.clone(extrap_kmin=1e-5).to_xi().to_pk(), [p.clone(extrap_kmin=1e-5).to_xi().to_pk() for p in pks]
+    same(back(k, z), [b(k, z) for b in backs], 1e-7)
+    same(back.sigma8_z(z), [b.sigma8_z(z) for b in backs], 1e-7)
+    same(xib.sigma8_z(z), [x.sigma8_z(z) for x in xis], 1e-7)
+    # the smooth interpolators of a filter of the batch: tables of the batch with the input's growth factor
+    smooth, smooths = fb.smooth_pk_interpolator(), [f.smooth_pk_interpolator() for f in fs]
+    same(smooth(k, z), [sm(k, z) for sm in smooths], 1e-7)
+    same(fb.smooth_xi_interpolator()(s, z), [f.smooth_xi_interpolator()(s, z) for f in fs], 1e-6, atol=1e-9)
     with pytest.raises(NotImplementedError):
         batch.solve('h', 'theta_MC_100', 1.04)
     s_arr, z_arr, xi_arr = pkb.to_xi_arrays()
@@ -75,3 +88,43 @@ def test_batch_consistency():
     same(nu.get_fourier().pk_interpolator()(k, z), [c.get_fourier().pk_interpolator()(k, z) for c in nus])
     same(nu.get_fourier().pk_interpolator(of='delta_cb')(k, z), [c.get_fourier().pk_interpolator(of='delta_cb')(k, z) for c in nus])
     same(nu.get_fourier().sigma8_z(z), [c.get_fourier().sigma8_z(z) for c in nus])
+
+
+def test_batches_of_tables_with_a_growth_factor():
+    """(batch, nk, nz) tables times growth_factor_sq(z), and (batch, nk, 1) columns times it, against the same tables one at a time."""
+    import cosmoprimo_amd as cp
+    warnings.simplefilter('ignore')
+    g = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'sigma.npz'))
+    kt, zt, table = g['table_k'], g['table_z'], g['table_pk']
+    amp = np.array([0.7, 1., 1.6])
+    tables = amp[:, None, None] * table[None]
+    k, z, r = np.geomspace(2e-4, 5., 60), np.array([0.1, 0.7, 1.4]), np.array([2., 8., 30.])
+
+    def growth_one(zz):
+        return 1. / (1. + np.asarray(zz))**2
+
+    def growth_each(zz):
+        return amp[:, None]**0.5 / (1. + np.asarray(zz))**2
+
+    for growth, singles_growth in [(growth_one, [growth_one] * 3), (growth_each, [lambda zz, a=a: a**0.5 / (1. + np.asarray(zz))**2 for a in amp])]:
+        b = cp.PowerSpectrumInterpolator2D(kt, zt, tables, growth_factor_sq=growth)
+        ones = [cp.PowerSpectrumInterpolator2D(kt, zt, t, growth_factor_sq=gs) for t, gs in zip(tables, singles_growth)]
+        same(b(k, z), [o(k, z) for o in ones])
+        same(b(k[:3], z, grid=False), [o(k[:3], z, grid=False) for o in ones])
+        same(b(k, z, ignore_growth=True), [o(k, z, ignore_growth=True) for o in ones])
+        same(b.sigma_rz(r, z), [o.sigma_rz(r, z) for o in ones], 1e-9)
+        same(b.sigma_dz(z), [o.sigma_dz(z) for o in ones], 1e-9)
+        # one column per cosmology times the growth factor
+        b1 = cp.PowerSpectrumInterpolator2D(kt, zt[:1], tables[:, :, :1], growth_factor_sq=growth)
+        ones1 = [cp.PowerSpectrumInterpolator2D(kt, zt[:1], t[:, :1], growth_factor_sq=gs) for t, gs in zip(tables, singles_growth)]
+        same(b1(k, z), [o(k, z) for o in ones1])
+        same(b1(k[:3], z, grid=False), [o(k[:3], z, grid=False) for o in ones1])
+        same(b1.sigma_rz(r, z), [o.sigma_rz(r, z) for o in ones1], 1e-9)
+        same(b1.to_xi()(r, z), [o.to_xi()(r, z) for o in ones1], 1e-8, atol=1e-13)
+    # to_xi of a batch of tables: one (s, z) surface per table
+    b = cp.PowerSpectrumInterpolator2D(kt, zt, tables)
+    ones = [cp.PowerSpectrumInterpolator2D(kt, zt, t) for t in tables]
+    s = np.geomspace(1., 150., 30)
+    same(b.to_xi()(s, z), [o.to_xi()(s, z) for o in ones], 1e-8, atol=1e-13)
+    same(b.to_xi()(s[:3], z, grid=False), [o.to_xi()(s[:3], z, grid=False) for o in ones], 1e-8, atol=1e-13)
+    same(b.to_xi().to_pk()(k[10:40], z), [o.to_xi().to_pk()(k[10:40], z) for o in ones], 1e-7)
