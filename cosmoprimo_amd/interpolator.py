@@ -1743,6 +1743,14 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         """:class:`CorrelationFunctionInterpolator1D` at redshift ``z`` (reference interpolator.py:1446-1467)."""
         if self.is_from_callable:
             return CorrelationFunctionInterpolator1D.from_callable(self.s, lambda s, **kw: self(s, z=z, **kw), device=self.device)
+        if getattr(self, '_tables_batched', False):
+            zh = _host(z)
+
+            def xi_callable(sh):      # the cosmologies of the batch become columns of the 1D interpolator: (ns, batch, nz), as PowerSpectrumInterpolator2D.to_1d
+                out = self._eval_device(np.asarray(sh, dtype='f8').ravel(), zh.ravel(), grid=True).permute(1, 0, 2)
+                return out.reshape(out.shape[:-1] + zh.shape) if zh.ndim else out[..., 0]
+
+            return CorrelationFunctionInterpolator1D.from_callable(self.s, xi_callable, device=self.device)
         default_params = dict(interp_order_s=self.interp_order_s)
         default_params.update(kwargs)
         return CorrelationFunctionInterpolator1D(self.s, self(self.s, z=z), device=self.device, **default_params)

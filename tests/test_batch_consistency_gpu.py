@@ -62,6 +62,9 @@ def test_batch_consistency():
     same(xib(s[:3], z, grid=False), [x(s[:3], z, grid=False) for x in xis], 1e-8, atol=1e-13)
     same(xib(s, z, ignore_growth=True), [x(s, z, ignore_growth=True) for x in xis], 1e-8, atol=1e-13)
     assert np.isnan(xib(s, [-0.5, 0.5])[:, :, 0]).all() and not np.isnan(xib(s, [-0.5, 0.5])[:, :, 1]).any()
+    assert xib.to_1d(z=0.5)(s).shape == (40, 3) and xib.to_1d(z=z)(s).shape == (40, 3, 3)
+    same(xib.to_1d(z=0.5)(s), [x.to_1d(z=0.5)(s) for x in xis], 1e-8, cols=True, atol=1e-13)
+    same(xib.to_1d(z=0.5).to_pk()(k[5:45]), [x.to_1d(z=0.5).to_pk()(k[5:45]) for x in xis], 1e-6, cols=True)
     # ... and back: a batch of (k, z) tables with the growth factor
     back, backs = pkb.clone(extrap_kmin=1e-5).to_xi().to_pk(), [p.clone(extrap_kmin=1e-5).to_xi().to_pk() for p in pks]
     same(back(k, z), [b(k, z) for b in backs], 1e-7)
