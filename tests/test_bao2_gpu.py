@@ -102,6 +102,24 @@ def test_bspline_table(cp, golden):
             np.testing.assert_allclose(f.pknow, obao.bspline(f.k, f.pk, pknow_eh, constraint=constraint), rtol=1e-9, err_msg=name)
 
 
+def test_peakaverage_as_a_dense_operator(cp):
+    """One cosmology: the two splines of peakaverage run as kernels (the shipped route) against their product built on the host as a dense operator."""
+    from cosmoprimo_amd.bao_filter import PeakAveragePowerSpectrumBAOFilter
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo, fid = cp.Cosmology(engine='eisenstein_hu', **BAO_PARAMS[1]), cp.Cosmology(engine='eisenstein_hu')
+        pk2d = cosmo.get_fourier().pk_interpolator()
+        for interp in [pk2d.to_1d(z=0.), pk2d.to_1d(z=np.array([0., 1.]))]:
+            kernels = PeakAveragePowerSpectrumBAOFilter(interp, cosmo=cosmo, cosmo_fid=fid).pknow
+            try:
+                PeakAveragePowerSpectrumBAOFilter._DENSE_OPERATOR = True
+                dense = PeakAveragePowerSpectrumBAOFilter(interp, cosmo=cosmo, cosmo_fid=fid).pknow
+            finally:
+                PeakAveragePowerSpectrumBAOFilter._DENSE_OPERATOR = False
+            assert kernels.shape == dense.shape
+            np.testing.assert_allclose(kernels, dense, rtol=1e-10)
+
+
 def test_f2_filters_over_a_batch_of_cosmologies(cp, golden):
     """peakaverage, ehpoly, ehsavgol (rs_drag ratio and no-wiggle template per cosmology), hinton2017 (weights from the spectrum's own maximum), savgol: a
     batch of 1 032 cosmologies as ONE filter run -- the 24 cosmologies of golden/bao_batch.npz (the reference, cosmology by cosmology) sit in the batch,
