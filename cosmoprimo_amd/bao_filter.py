@@ -475,6 +475,9 @@ def _envelope_operator(k_fid, peaks):
     return M, columns, np.ascontiguousarray(M[:, columns].T)
 
 
+_envelope_operators = {}
+
+
 class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     """
@@ -512,8 +515,14 @@ class Brieden2022PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     def _set_envelope_operator(self):
         """``_interp`` (reference bao_filter.py:482-488) is linear in y for fixed peak indices: one dense (341 x 341) operator."""
-        M, columns, rows = _envelope_operator(self.k_fid, self.ik_fid_peaks)
-        self._envelope = LinearOperator.dense(M, device=self.device)
+        # (the operator depends on the wavenumbers and the positions of the fiducial extrema only: filter objects of one fiducial cosmology share it)
+        key = (self.k_fid.tobytes(), tuple(np.asarray(ix).tobytes() for ix in self.ik_fid_peaks), self.device.index)
+        if key not in _envelope_operators:
+            if len(_envelope_operators) > 16:
+                _envelope_operators.clear()
+            M, columns, rows = _envelope_operator(self.k_fid, self.ik_fid_peaks)
+            _envelope_operators[key] = (M, LinearOperator.dense(M, device=self.device), columns, rows)
+        M, self._envelope, columns, rows = _envelope_operators[key]
         self._envelope_columns = (columns, rows)      # what a batch is run with (cp_brieden_smooth)
         self.ratio_now_fid = M.dot(self.ratio_fid)
 
@@ -767,7 +776,9 @@ class SavGolPowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     def _prepare(self):
         self.nfilter = int(np.ceil(np.log(7) / np.log(self.k[-1] / self.k[-2])) // 2 * 2 + 1)
-        self._op = LinearOperator.dense(_savgol_operator(self.k.size, self.nfilter), device=self.device)
+        from .interpolator import _cached_operator      # the operator depends on (nk, window) only: built and uploaded once, shared by every filter object
+        self._op = _cached_operator(('savgol', self.k.size, self.nfilter, self.device.index),
+                                    lambda: LinearOperator.dense(_savgol_operator(self.k.size, self.nfilter), device=self.device))
 
     def _compute(self):
         torch = dv.torch()
