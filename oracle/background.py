@@ -235,8 +235,10 @@ def ncdm_tables(p):
 
 def ncdm_interp(p, z, out='rho'):
     """DefaultBackground.rho_ncdm / p_ncdm (interpolated, natural cubic spline, NaN outside the knots): (nspecies,) + z.shape."""
-    zc, rho, pr = ncdm_tables(p)
     z = np.asarray(z, dtype='f8')
+    if not len(p['m_ncdm']):      # no massive species
+        return np.zeros((0,) + z.shape)
+    zc, rho, pr = ncdm_tables(p)
     tab = rho if out == 'rho' else pr
     val = CubicSpline(zc, tab.T, axis=0, bc_type='natural', extrapolate=False)(z.ravel()).T
     val = np.where((z.ravel() >= zc[0]) & (z.ravel() <= zc[-1]), val, np.nan)

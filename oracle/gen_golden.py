@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch,
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -810,6 +810,83 @@ def gen_api_flows(cp):
     save('api_flows', **results)
 
 
+# Cosmologies drawn from wide priors -- curvature, (w0, wa), one to three massive species, N_eff, T_cmb, sigma8 or A_s -- through the reference's analytic
+# engines and background: the corners the hand-picked cases of the other targets do not visit.
+FUZZ_N = 48
+FUZZ_ENGINES = ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks', 'eisenstein_hu_nowiggle_variants']
+
+
+def fuzz_params(n=FUZZ_N, seed=20261004):
+    """The n parameter sets (dicts of plain floats / lists): what the generator and tests/test_fuzz_gpu.py both build their cosmologies from."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    species = [None, [0.06], [0.1, 0.3], [0.02, 0.05, 0.2]]
+    for i in range(n):
+        par = dict(h=rng.uniform(0.5, 0.9), Omega_cdm=rng.uniform(0.15, 0.45), Omega_b=rng.uniform(0.03, 0.07), n_s=rng.uniform(0.85, 1.05),
+                   T_cmb=rng.uniform(2.6, 2.9), N_eff=rng.uniform(2.6, 4.))
+        if i % 2:
+            par['Omega_k'] = rng.uniform(-0.15, 0.15)
+        if i % 3:
+            par['w0_fld'], par['wa_fld'] = rng.uniform(-1.6, -0.5), rng.uniform(-1., 0.4)
+        if i % 4 < 2:
+            par['sigma8'] = rng.uniform(0.6, 1.)
+        else:
+            par['A_s'] = rng.uniform(1.5e-9, 3e-9)
+        m = species[(i // 2) % 4]
+        if m is not None:
+            par['m_ncdm'] = [float(x * rng.uniform(0.8, 1.2)) for x in m]
+        cases.append({name: (value if isinstance(value, list) else float(value)) for name, value in par.items()})
+    return cases
+
+
+def gen_fuzz(cp):
+    """FUZZ_N random cosmologies x the four analytic engines: P(k, z), sigma8_z, growth factor / rate, rs_drag / z_drag, rescaling factor; the
+    background of each (efunc, distances, time, age, Omega_m(z), ...) and its compiled parameters; wallish2018 and brieden2022 of every fourth.
+    Stacked over the cosmologies: <engine>_<quantity> (FUZZ_N, ...), <quantity> (FUZZ_N, ...); m_ncdm padded to three species with NaN."""
+    import warnings
+    k = np.geomspace(1e-4, 10., 12)
+    z = np.array([0., 0.8, 2.5])
+    zb = np.array([0.01, 0.5, 1.5, 3., 10.])
+    rows = {}
+
+    def put(name, value):
+        rows.setdefault(name, []).append(np.asarray(value, dtype='f8'))
+
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        fid = cp.Cosmology(engine='eisenstein_hu')
+        for i, par in enumerate(fuzz_params()):
+            for eng in FUZZ_ENGINES:
+                cosmo = cp.Cosmology(engine=eng, **par)
+                fo, ba = cosmo.get_fourier(), cosmo.get_background()
+                put(eng + '_pkz', fo.pk_interpolator()(k, z))
+                put(eng + '_sigma8_z', fo.sigma8_z(z))
+                put(eng + '_growth_factor', ba.growth_factor(z))
+                put(eng + '_growth_rate', ba.growth_rate(z))
+                if eng != 'bbks':
+                    th = cosmo.get_thermodynamics()
+                    put(eng + '_rs_drag', th.rs_drag)
+                    put(eng + '_z_drag', th.z_drag)
+                if eng != 'eisenstein_hu_nowiggle_variants':
+                    put(eng + '_rsigma8', cosmo._engine._rsigma8)
+                    put(eng + '_A_s_fid', cosmo._engine._A_s)
+            # (the background is the engines' common DefaultBackground: taken from the last one); the compiled parameters, for the oracle
+            for name in ['efunc', 'comoving_radial_distance', 'angular_diameter_distance', 'luminosity_distance', 'time', 'Omega_m', 'Omega_de', 'rho_ncdm_tot']:
+                put(name, getattr(ba, name)(zb))
+            put('age', ba.age)
+            for name in ['h', 'Omega_cdm', 'Omega_b', 'Omega_k', 'T_cmb', 'N_ur', 'w0_fld', 'wa_fld', 'n_s', 'alpha_s', 'beta_s', 'k_pivot', 'Omega_m', 'Omega_de']:
+                put('par_' + name, cosmo[name])
+            for name in ['m_ncdm', 'T_ncdm_over_cmb']:
+                v = np.asarray(cosmo[name], dtype='f8').ravel()
+                put('par_' + name, np.concatenate([v, np.full(3 - v.size, np.nan)]))
+            if i % 4 == 0:
+                cosmo = cp.Cosmology(engine='eisenstein_hu', **par)
+                interp = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+                for name in ['wallish2018', 'brieden2022']:
+                    put(name, np.asarray(cp.PowerSpectrumBAOFilter(interp, engine=name, cosmo=cosmo, cosmo_fid=fid).pknow)[::8])
+    save('fuzz', k=k, z=z, zb=zb, **{name: np.stack(v) for name, v in rows.items()})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -845,6 +922,8 @@ def main():
         gen_power_ncdm(cp)
     if 'bao_batch' in which:
         gen_bao_batch(cp)
+    if 'fuzz' in which:
+        gen_fuzz(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:
