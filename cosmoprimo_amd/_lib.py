@@ -142,6 +142,11 @@ SIGNATURES = {
                                         ctypes.c_int, ctypes.c_void_p]),
     'cp_interp_linear': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
                                         ctypes.c_void_p]),
+    'cp_interp_table_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_longlong, _c_double_p, _c_double_p, ctypes.c_int]),
+    'cp_interp_table_law': (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]),
+    'cp_interp_table_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    'cp_interp_table_apply_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]),
+    'cp_interp_table_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_spline_points': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_rows_screen': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,

@@ -4,6 +4,11 @@
 // (no FMA contraction), so that results are bit-identical to numpy.interp.  Samples outside [xp[0], xp[n-1]] and NaN give NaN.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+#include <new>
+#include <type_traits>
+#include <vector>
+
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
 
@@ -53,6 +58,13 @@ __global__ __launch_bounds__(256) void interp_linear_kernel(const double* __rest
     }
 }
 
+// samples outside [x0, xn] (or NaN) raise the plan's flag (cp_interp_table_apply on an irregular table: the bisection kernel has no flag)
+__global__ __launch_bounds__(256) void flag_outside_kernel(const double* __restrict__ x, long long nx, double x0, double xn, int* flag) {
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (long long)gridDim.x * blockDim.x) bad |= !(x[i] >= x0 && x[i] <= xn);
+    if (bad) atomicOr(flag, 1);
+}
+
 }  // namespace
 
 extern "C" int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const double* d_x, double* d_out, long long nx, int device,
@@ -73,6 +85,216 @@ extern "C" int cp_interp_linear(const double* d_xp, const double* d_fp, long lon
     const hipError_t e = hipGetLastError();
     if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_interp_linear: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
+// ---- the same interpolation on a table kept as a plan: (x, f) pairs, the interval GUESSED from the sample -----------------------------------
+// A catalogue's redshifts come in no order: every bisection step above is a dependent load, ~10 of them out of LDS and 5 out of L2 per sample.
+// Tables of background quantities are regular -- uniform in x, or, as the reference's data/desi.dat (0, then 40 001 redshifts from 1e-8 to 100),
+// uniform in log x behind a few leading knots -- so the interval follows from the sample itself: index = first + (T(x) - a) b with T = identity or
+// log2 (exponent + the hardware's single-precision log2 of the mantissa: the guess needs ~1e-5 of an interval, not 53 bits), then a walk to the
+// exact interval, xp[j] <= x < xp[j + 1] (numpy's), which is 0 or 1 steps for a table that passed the host's check of the fit.  The two knots
+// and two values of the interval are 32 contiguous bytes of the pair table.  Tables that fit neither law take the bisection.  Same arithmetic as
+// above, bit-identical to numpy.interp.  Samples outside the table (and NaN) come out NaN and raise the plan's flag.
+struct cp_interp_table {
+    int device;
+    long long n;
+    double* d_xf;         // (n, 2): (x_i, f_i)
+    double* d_x;          // (n): the knots alone (bisection of the irregular case)
+    double* d_f;
+    int* d_flag;          // raised by samples outside [x_0, x_{n-1}] / NaN
+    int law;              // 0 none (bisection), 1 uniform in x, 2 uniform in log2 x
+    long long first;      // the law holds from this knot on (the knots before it: bisection among them)
+    double a, b;          // index = first + (T(x) - a) * b
+    double x0, xn;        // the range of the table
+};
+
+namespace {
+
+__device__ __forceinline__ double log2_guess(double v) {      // log2 of a positive finite double to single precision
+    const int e = __builtin_amdgcn_frexp_exp(v);
+    const float m = (float)__builtin_amdgcn_frexp_mant(v);
+    return (double)e + (double)__builtin_amdgcn_logf(m);
+}
+
+template <int LAW, typename real>      // real: the type of the samples and of the results (float: computed in double, rounded once, as the reference's cast of its result)
+__global__ __launch_bounds__(256) void interp_table_kernel(const double2* __restrict__ xf, long long n, long long first, double a, double b,
+                                                           const real* __restrict__ x, real* __restrict__ out, long long nx, int* flag) {
+    const double x0 = xf[0].x, xn = xf[n - 1].x;
+    const double xfirst = xf[first].x;
+    bool outside = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (long long)gridDim.x * blockDim.x) {
+        const double v = (double)x[i];
+        double r = __builtin_nan("");
+        if (v >= x0 && v <= xn) {
+            if (v == xn) {
+                r = xf[n - 1].y;
+            } else {
+                long long lo;
+                double2 k0, k1;
+                if (first > 0 && v < xfirst) {      // among the leading knots (one, for the DESI table): bisection
+                    lo = 0;
+                    long long hi = first;
+                    while (hi - lo > 1) {
+                        const long long mid = (lo + hi) >> 1;
+                        if (xf[mid].x <= v) lo = mid; else hi = mid;
+                    }
+                    k0 = xf[lo]; k1 = xf[lo + 1];
+                } else {
+                    const double t = LAW == 2 ? log2_guess(v) : v;
+                    const double g = (t - a) * b;
+                    lo = first + (long long)(g > 0. ? g : 0.);
+                    lo = lo > n - 2 ? n - 2 : lo;
+                    k0 = xf[lo]; k1 = xf[lo + 1];      // the guessed interval: both ends in flight together; the walk (rare) re-uses the end it keeps
+                    while (lo > first && k0.x > v) { --lo; k1 = k0; k0 = xf[lo]; }
+                    while (lo < n - 2 && k1.x <= v) { ++lo; k0 = k1; k1 = xf[lo + 1]; }
+                }
+                if (k0.x == v) {  // numpy.interp returns the knot value here
+                    out[i] = (real)k0.y;
+                    continue;
+                }
+                const double slope = (k1.y - k0.y) / (k1.x - k0.x);
+                r = slope * (v - k0.x) + k0.y;   // product and sum rounded separately (contract(off) above)
+                if (r != r) {
+                    r = slope * (v - k1.x) + k1.y;
+                    if (r != r && k0.y == k1.y) r = k0.y;
+                }
+            }
+        } else {
+            outside = true;
+        }
+        out[i] = (real)r;
+    }
+    if (outside) atomicOr(flag, 1);
+}
+
+// the law of a table: the knots from `first` on against first + (T(x) - a) b, accepted when no knot and no interval midpoint is guessed further than
+// a quarter of an interval from where it is (the device's single-precision log2 adds ~1e-3 of an interval to that)
+bool fit_law(const double* x, long long n, int law, long long first, double* a, double* b) {
+    if (n - first < 3) return false;
+    auto T = [&](double v) { return law == 2 ? std::log2(v) : v; };
+    if (law == 2 && !(x[first] > 0.)) return false;
+    const double t0 = T(x[first]), t1 = T(x[n - 1]);
+    if (!(t1 > t0) || !std::isfinite(t0) || !std::isfinite(t1)) return false;
+    *a = t0;
+    *b = (double)(n - 1 - first) / (t1 - t0);
+    for (long long i = first; i < n; ++i) {
+        const double g = (T(x[i]) - *a) * *b;
+        if (std::fabs(g - (double)(i - first)) > 0.25) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int cp_interp_table_create(cp_interp_table** table, long long n, const double* x, const double* f, int device) {
+    if (!table) return cp::fail(CP_EINVAL, "cp_interp_table_create: null output");
+    *table = nullptr;
+    if (n < 1 || !x || !f) return cp::fail(CP_EINVAL, "cp_interp_table_create: need at least one (x, f) row");
+    for (long long i = 1; i < n; ++i)
+        if (!(x[i] >= x[i - 1])) return cp::fail(CP_EINVAL, "cp_interp_table_create: x must be ascending (row %lld)", i);
+    cp_interp_table* t = new (std::nothrow) cp_interp_table();
+    if (!t) return cp::fail(CP_ENOMEM, "cp_interp_table_create: out of host memory");
+    t->device = device; t->n = n; t->law = 0; t->first = 0; t->a = 0.; t->b = 0.; t->x0 = x[0]; t->xn = x[n - 1];
+    t->d_xf = t->d_x = t->d_f = nullptr; t->d_flag = nullptr;
+    // uniform in x, else uniform in log2 x from the first positive knot that starts a regular run (at most 8 leading knots are set aside)
+    double a = 0., b = 0.;
+    if (fit_law(x, n, 1, 0, &a, &b)) { t->law = 1; t->a = a; t->b = b; }
+    else {
+        for (long long first = 0; first < 8 && first < n - 3 && !t->law; ++first)
+            if (x[first] > 0. && fit_law(x, n, 2, first, &a, &b)) { t->law = 2; t->first = first; t->a = a; t->b = b; }
+    }
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) { delete t; return cp::fail(CP_EDEVICE, "cp_interp_table_create: cannot select device %d", device); }
+    std::vector<double> pairs(2 * (size_t)n);
+    for (long long i = 0; i < n; ++i) { pairs[2 * i] = x[i]; pairs[2 * i + 1] = f[i]; }
+    const int zero = 0;
+    bool ok = hipMalloc(&t->d_xf, 2 * n * sizeof(double)) == hipSuccess && hipMalloc(&t->d_x, n * sizeof(double)) == hipSuccess &&
+              hipMalloc(&t->d_f, n * sizeof(double)) == hipSuccess && hipMalloc(&t->d_flag, sizeof(int)) == hipSuccess;
+    ok = ok && hipMemcpy(t->d_xf, pairs.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(t->d_x, x, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(t->d_f, f, n * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(t->d_flag, &zero, sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (!ok) { (void)cp_interp_table_destroy(t); return cp::fail(CP_ENOMEM, "cp_interp_table_create: device allocation or upload failed"); }
+    *table = t;
+    return CP_OK;
+}
+
+extern "C" int cp_interp_table_law(const cp_interp_table* t, int* law, long long* first) {
+    if (!t) return cp::fail(CP_EINVAL, "cp_interp_table_law: null table");
+    if (law) *law = t->law;
+    if (first) *first = t->first;
+    return CP_OK;
+}
+
+namespace {
+
+template <typename real>
+int interp_table_apply(const cp_interp_table* t, const real* d_x, real* d_out, long long nx, int* outside, void* stream, const char* who) {
+    if (!t) return cp::fail(CP_EINVAL, "%s: null table", who);
+    if (nx < 0) return cp::fail(CP_EINVAL, "%s: negative sample count", who);
+    if (outside) *outside = 0;
+    if (nx == 0) return CP_OK;
+    if (!d_x || !d_out) return cp::fail(CP_EINVAL, "%s: null pointer", who);
+    if (t->law == 0 && !std::is_same<real, double>::value)
+        return cp::fail(CP_EUNSUPPORTED, "%s: single-precision samples need a table uniform in x or in log x (this one is bisected: widen the samples)", who);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != t->device && hipSetDevice(t->device) != hipSuccess) return cp::fail(CP_EDEVICE, "%s: cannot select device %d", who, t->device);
+    hipStream_t hs = static_cast<hipStream_t>(stream);
+    int st = CP_OK;
+    if (t->law == 0) {
+        // irregular table: bisection (NaN outside, no flag: raised below)
+        st = cp_interp_linear(t->d_x, t->d_f, t->n, reinterpret_cast<const double*>(d_x), reinterpret_cast<double*>(d_out), nx, t->device, stream);
+    } else {
+        const long long blocks = (nx + 255) / 256;
+        const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
+        const double2* xf = reinterpret_cast<const double2*>(t->d_xf);
+        if (t->law == 1) hipLaunchKernelGGL((interp_table_kernel<1, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, t->d_flag);
+        else hipLaunchKernelGGL((interp_table_kernel<2, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, t->d_flag);
+        if (hipGetLastError() != hipSuccess) st = cp::fail(CP_EDEVICE, "%s: launch failed", who);
+    }
+    if (st == CP_OK && outside) {
+        if (t->law == 0) {
+            hipLaunchKernelGGL(flag_outside_kernel, dim3(1024), dim3(256), 0, hs, reinterpret_cast<const double*>(d_x), nx, t->x0, t->xn, t->d_flag);
+            if (hipGetLastError() != hipSuccess) st = cp::fail(CP_EDEVICE, "%s: launch failed", who);
+        }
+        // the flag comes back with the stream drained: the caller of the reference gets its exception from the call itself (tabulated.py:33-34)
+        int host = 0;
+        if (st == CP_OK && (hipMemcpyAsync(&host, t->d_flag, sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess || hipStreamSynchronize(hs) != hipSuccess))
+            st = cp::fail(CP_EDEVICE, "%s: reading the range flag failed", who);
+        if (st == CP_OK && host) {
+            *outside = 1;
+            if (hipMemsetAsync(t->d_flag, 0, sizeof(int), hs) != hipSuccess) st = cp::fail(CP_EDEVICE, "%s: resetting the range flag failed", who);
+        }
+    }
+    if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
+    return st;
+}
+
+}  // namespace
+
+extern "C" int cp_interp_table_apply(const cp_interp_table* t, const double* d_x, double* d_out, long long nx, int* outside, void* stream) {
+    return interp_table_apply<double>(t, d_x, d_out, nx, outside, stream, "cp_interp_table_apply");
+}
+
+extern "C" int cp_interp_table_apply_f32(const cp_interp_table* t, const float* d_x, float* d_out, long long nx, int* outside, void* stream) {
+    return interp_table_apply<float>(t, d_x, d_out, nx, outside, stream, "cp_interp_table_apply_f32");
+}
+
+extern "C" int cp_interp_table_destroy(cp_interp_table* t) {
+    if (!t) return CP_OK;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != t->device) (void)hipSetDevice(t->device);
+    if (t->d_xf) (void)hipFree(t->d_xf);
+    if (t->d_x) (void)hipFree(t->d_x);
+    if (t->d_f) (void)hipFree(t->d_f);
+    if (t->d_flag) (void)hipFree(t->d_flag);
+    if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
+    delete t;
     return CP_OK;
 }
 

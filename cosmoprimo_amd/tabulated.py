@@ -31,14 +31,54 @@ class TabulatedEngine(BaseEngine):
         self.z = np.ascontiguousarray(table['z'], dtype='f8')
         if self.z.ndim != 1 or self.z.size < 1 or np.any(np.diff(self.z) < 0.):
             raise CosmologyError('tabulated redshifts must be a 1D ascending array')
-        self._dz = dv.to_device(self.z, self.device)
         self._tables = {}
         for name in self._names:
             array = np.ascontiguousarray(table[name], dtype='f8')
             if array.shape != self.z.shape:
                 raise CosmologyError('tabulated {} must have the shape of z'.format(name))
             setattr(self, name, array)
-            self._tables[name] = dv.to_device(array, self.device)
+            self._tables[name] = _InterpTable(self.z, array, self.device)
+
+
+class _InterpTable(object):
+
+    """Owner of a ``cp_interp_table``: one column of the table with its redshifts on the device, and the law of the redshift grid (uniform, uniform in
+    the logarithm behind a few leading knots as data/desi.dat, neither) from which the kernel guesses a sample's interval instead of bisecting."""
+
+    def __init__(self, x, f, device):
+        import ctypes
+        self._args = (x, f, device)
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().cp_interp_table_create(ctypes.byref(self.handle), x.size, _lib.as_double_p(x), _lib.as_double_p(f), device.index))
+        law, first = ctypes.c_int(), ctypes.c_longlong()
+        _lib.check(_lib.load().cp_interp_table_law(self.handle, ctypes.byref(law), ctypes.byref(first)))
+        self.law = (law.value, first.value)      # (0 none / 1 uniform / 2 uniform in the logarithm, the knot it holds from)
+
+    def __copy__(self):      # a handle has one owner: copies build their own table
+        return self.__class__(*self._args)
+
+    def __deepcopy__(self, memo):
+        return self.__class__(*self._args)
+
+    def __reduce__(self):
+        return (self.__class__, self._args)
+
+    def __call__(self, tz, out, stream):
+        """out = numpy.interp(tz) on the device (float64, or float32 samples and results: computed in double); True when a sample lies outside the
+        table (or is NaN)."""
+        import ctypes
+        outside = ctypes.c_int(0)
+        apply = _lib.load().cp_interp_table_apply if tz.dtype == dv.torch().float64 else _lib.load().cp_interp_table_apply_f32
+        _lib.check(apply(self.handle, tz.data_ptr(), out.data_ptr(), tz.numel(), ctypes.byref(outside), stream))
+        return bool(outside.value)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().cp_interp_table_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class Background(BaseSection):
@@ -54,14 +94,16 @@ class Background(BaseSection):
         ba = self.ba
         like_torch = dv.is_torch(z)
         dtype = dv.float_dtype(z)
-        tz = dv.to_device(z, self.device)
+        if like_torch and z.is_cuda and z.dtype == torch.float32 and ba._tables[name].law[0]:
+            tz = z.contiguous()      # a float32 catalogue on the device: read and written as it is (no widened copies)
+        else:
+            tz = dv.to_device(z, self.device).contiguous()
         out = torch.empty_like(tz)
         if tz.numel():
-            lo, hi = torch.aminmax(tz)         # NaN propagates: a NaN redshift is "outside" as well, unlike numpy's comparison; it comes out NaN
-            if bool((lo < ba.z[0]) | (hi > ba.z[-1])):
+            # the kernel itself reports samples outside the table (a NaN redshift is "outside" as well, unlike numpy's comparison): no pass over the
+            # redshifts before it, one flag read back behind it
+            if ba._tables[name](tz, out, dv.stream_of(self.device)):
                 raise CosmologyError('Input z outside of tabulated range.')
-            _lib.check(_lib.load().cp_interp_linear(ba._dz.data_ptr(), ba._tables[name].data_ptr(), ba.z.size, tz.data_ptr(), out.data_ptr(), tz.numel(),
-                                                    self.device.index, dv.stream_of(self.device)))
         if like_torch:
             return out.to(torch.float32 if dtype == np.float32 else torch.float64)
         return dv.to_host(out).astype(dtype, copy=False)

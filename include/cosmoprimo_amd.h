@@ -569,6 +569,20 @@ int cp_bilinear_pairs(const double* d_wx, const double* d_wy, const double* d_f,
  * d_xp (ascending), d_fp : (n) device table; d_x, d_out : (nx) device.  Bit-identical to numpy.interp inside [xp[0], xp[n-1]];
  * NaN outside (the reference raises CosmologyError there: its caller checks the range) and for NaN samples. */
 int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const double* d_x, double* d_out, long long nx, int device, void* stream);
+/* The same on a table kept as a plan (TabulatedEngine, tabulated.py:6-36: one table per column, built once, applied to every catalogue): x, f : (n) HOST
+ * arrays, x ascending.  The plan holds (x, f) pairs on the device and the LAW of the knots -- 1 uniform in x, 2 uniform in log x behind at most 8 leading
+ * knots (the reference's data/desi.dat: 0, then 40 001 redshifts from 1e-8 to 100), 0 neither: the interval of a sample is then guessed from the sample
+ * itself and corrected by a walk (0 or 1 steps) instead of bisected (15 dependent loads per sample); law 0 bisects.  Bit-identical to numpy.interp in all
+ * three cases.  outside (host, may be NULL): set to 1 when a sample lies outside [x_0, x_{n-1}] or is NaN (those come out NaN) -- the reference raises
+ * there (tabulated.py:33-34); asking for it makes the call wait for the stream, NULL leaves it asynchronous.  cp_interp_table_law reports the law found. */
+typedef struct cp_interp_table cp_interp_table;
+int cp_interp_table_create(cp_interp_table** table, long long n, const double* x, const double* f, int device);
+int cp_interp_table_law(const cp_interp_table* table, int* law, long long* first);
+int cp_interp_table_apply(const cp_interp_table* table, const double* d_x, double* d_out, long long nx, int* outside, void* stream);
+/* single-precision samples and results (catalogues kept in float32): computed in double as above, the result rounded once -- the reference's cast of its
+ * float64 result to the dtype of its input; tables with a law only (CP_EUNSUPPORTED otherwise: the caller widens the samples) */
+int cp_interp_table_apply_f32(const cp_interp_table* table, const float* d_x, float* d_out, long long nx, int* outside, void* stream);
+int cp_interp_table_destroy(cp_interp_table* table);
 
 /* ---- cubic splines at many points (replaces Interpolator1D.__call__ = CubicSpline(x, fun)(xq) when there are few splines and 1e6-1e9 queries:
  *      DistanceToRedshift, utils.py:275-316; jax.py:169-175) ----

@@ -65,6 +65,10 @@ def test_tabulated(golden, tmp_path):
     zt = torch.as_tensor(z, device='cuda:0')
     out = cosmo.comoving_radial_distance(zt)
     assert out.is_cuda and np.array_equal(out.cpu().numpy(), np.interp(z, table[0], table[2]))
+    z32 = z.astype('f4')
+    z32 = z32[(z32 >= table[0][0]) & (z32 <= table[0][-1])]
+    out = cosmo.comoving_radial_distance(torch.as_tensor(z32, device='cuda:0'))      # a float32 catalogue on the device stays float32
+    assert out.is_cuda and out.dtype == torch.float32 and np.array_equal(out.cpu().numpy(), np.interp(z32.astype('f8'), table[0], table[2]).astype('f4'))
     for bad in (-1., 100.1, [0.5, 200.]):
         with pytest.raises(CosmologyError):
             cosmo.comoving_radial_distance(bad)
@@ -126,3 +130,51 @@ def test_abacus(golden):
         mine = [cosmo['h'], cosmo['Omega_m'], cosmo['N_ur'], cosmo['N_eff'], cosmo['m_ncdm_tot'], cosmo['N_ncdm'], cosmo['w0_fld'], cosmo['wa_fld'],
                 cosmo.get_primordial().A_s, cosmo.comoving_radial_distance(1.)]
         np.testing.assert_allclose(np.array(mine, dtype='f8'), g['c' + name], rtol=1e-9, atol=1e-12, err_msg=name)
+
+
+def test_interp_table_laws():
+    """``cp_interp_table``: the interval of a sample guessed from the law of the knots (uniform in x; uniform in log x behind leading knots, the shape of
+    data/desi.dat; neither: bisection) and walked to numpy's interval -- bit-identical to numpy.interp in every case, repeated knots and knot hits included."""
+    import torch
+    from cosmoprimo_amd.tabulated import _InterpTable
+    from cosmoprimo_amd import _device as dv
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(11)
+    tables = {'uniform': (np.linspace(-2., 5., 3001), 1, 0),
+              'desi': (np.concatenate([[0.], np.logspace(-8, 2, 40001)]), 2, 1),
+              'geometric': (np.geomspace(3e-4, 7e5, 777), 2, 0),
+              'three leading knots': (np.concatenate([[-1., 0., 1e-12], np.geomspace(1e-6, 10., 500)]), 2, 3),
+              'irregular': (np.sort(rng.uniform(0., 10., 5000)), 0, 0),
+              'nearly uniform (off by a third of a step)': (np.linspace(0., 1., 200) + np.r_[0., 0.33 / 199 * np.sin(np.arange(1, 199)), 0.], 0, 0),
+              'repeated knots': (np.repeat(np.linspace(0., 1., 50), 2), 0, 0),
+              'two rows': (np.array([1., 2.]), 0, 0)}
+    for name, (x, law, first) in tables.items():
+        f = np.cos(3. * np.arange(x.size)) * np.sqrt(1. + np.arange(x.size))
+        table = _InterpTable(x, f, dev)
+        assert table.law == (law, first), (name, table.law)
+        inside = rng.uniform(x[0], x[-1], 50000)
+        if x[0] > 0:
+            inside = np.concatenate([inside, np.exp(rng.uniform(np.log(x[0]), np.log(x[-1]), 50000))])
+        q = np.concatenate([inside, x, np.nextafter(x[1:], -np.inf), np.nextafter(x[:-1], np.inf), 0.5 * (x[1:] + x[:-1])])
+        q = np.clip(q, x[0], x[-1])
+        tq = torch.as_tensor(q, device=dev)
+        out = torch.empty_like(tq)
+        assert table(tq, out, dv.stream_of(dev)) is False, name
+        assert np.array_equal(out.cpu().numpy(), np.interp(q, x, f)), name
+        if law:      # float32 samples on the device: computed in double, rounded once
+            q32 = q.astype('f4')
+            q32 = q32[(q32 >= x[0]) & (q32 <= x[-1])]
+            t32 = torch.as_tensor(q32, device=dev)
+            out32 = torch.empty_like(t32)
+            assert table(t32, out32, dv.stream_of(dev)) is False and out32.dtype == torch.float32
+            assert np.array_equal(out32.cpu().numpy(), np.interp(q32.astype('f8'), x, f).astype('f4')), name
+        # outside / NaN: NaN there, the flag raised (and lowered again for the next call)
+        bad = torch.as_tensor(np.concatenate([q[:1000], [np.nextafter(x[0], -np.inf), np.nextafter(x[-1], np.inf), np.nan]]), device=dev)
+        out = torch.empty_like(bad)
+        assert table(bad, out, dv.stream_of(dev)) is True, name
+        got = out.cpu().numpy()
+        assert np.isnan(got[-3:]).all() and np.array_equal(got[:-3], np.interp(q[:1000], x, f)), name
+        assert table(tq[:10], torch.empty(10, dtype=torch.float64, device=dev), dv.stream_of(dev)) is False, name
+    import copy
+    clone = copy.deepcopy(table)
+    assert clone.handle.value != table.handle.value and clone.law == table.law
