@@ -50,6 +50,7 @@ SIGNATURES = {
                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_derived_parameters': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_background_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
+    'cp_distance_from_radial': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_ncdm_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
     'cp_growth_ode_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
     'cp_growth_ode_tables': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,

@@ -1171,17 +1171,12 @@ class BaseBackground(BaseSection):
     def _curved_distance(self, kind, z):
         """Angular / transverse / luminosity distance of ONE cosmology from its radial-distance table (cosmology.py:1855-1912): the curvature
         map and the powers of 1 + z applied on the device in float64, in the kernel's operation order; dtype and container of ``z`` kept."""
-        torch = dv.torch()
-        zt = dv.to_device(z, self.device)
-        chi = self._table_spline('comoving_radial_distance')(zt)       # float64 device tensor
-        K = float(self._K)
-        if K > 0.:
-            chi = torch.sin(np.sqrt(K) * chi) / np.sqrt(K)
-        elif K < 0.:
-            chi = torch.sinh(np.sqrt(-K) * chi) / np.sqrt(-K)
-        da = chi / (1. + zt)
-        out = da if kind == 'angular_diameter_distance' else (da * (1. + zt) if kind == 'comoving_transverse_distance' else da * ((1. + zt) * (1. + zt)))
-        return _out(out, z)
+        zt = dv.to_device(z, self.device).contiguous()
+        chi = self._table_spline('comoving_radial_distance')(zt).contiguous()       # float64 device tensor
+        if chi.numel():      # one pass, in place (cp_distance_from_radial: the last lines of the background kernel)
+            _lib.check(_lib.load().cp_distance_from_radial(chi.data_ptr(), zt.data_ptr(), chi.numel(), float(self._K), _lib.BG_KINDS[kind], chi.data_ptr(),
+                                                           self.device.index, dv.stream_of(self.device)))
+        return _out(chi, z)
 
     def _distance(self, kind, z):
         if self._use_table_spline and self._engine.batch_size is None:

@@ -671,6 +671,41 @@ extern "C" int cp_background_knots(double* zc_out, int n) {
     return CP_OK;
 }
 
+// The derived distances of ONE cosmology from its radial distances (cosmology.py:1855-1912): the curvature map and the powers of 1 + z of bg_kernel's
+// last lines, as one pass over a catalogue whose radial distances came from the cosmology's table (cp_spline_points) -- the five elementwise passes the
+// same arithmetic costs as array operations are 2 / 3 of luminosity_distance(10^7 redshifts) otherwise.
+namespace {
+__global__ __launch_bounds__(256) void distance_from_radial_kernel(const double* __restrict__ chi_in, const double* __restrict__ z, long long n, double K, int kind,
+                                                                   double* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        double chi = chi_in[i];
+        const double zi = z[i];
+        if (K > 0.) chi = sin(sqrt(K) * chi) / sqrt(K);
+        else if (K < 0.) chi = sinh(sqrt(-K) * chi) / sqrt(-K);
+        const double da = chi / (1. + zi);  // cosmology.py:1868
+        out[i] = kind == CP_BG_ANGULAR_DIAMETER ? da : (kind == CP_BG_COMOVING_TRANSVERSE ? da * (1. + zi) : da * ((1. + zi) * (1. + zi)));
+    }
+}
+}  // namespace
+
+extern "C" int cp_distance_from_radial(const double* d_chi, const double* d_z, long long n, double K, int kind, double* d_out, int device, void* stream) {
+    if (n < 0) return cp::fail(CP_EINVAL, "cp_distance_from_radial: negative size");
+    if (kind != CP_BG_ANGULAR_DIAMETER && kind != CP_BG_COMOVING_TRANSVERSE && kind != CP_BG_LUMINOSITY)
+        return cp::fail(CP_EINVAL, "cp_distance_from_radial: kind %d is not a derived distance", kind);
+    if (n == 0) return CP_OK;
+    if (!d_chi || !d_z || !d_out) return cp::fail(CP_EINVAL, "cp_distance_from_radial: null pointer");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_distance_from_radial: cannot select device %d", device);
+    const long long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(distance_from_radial_kernel, dim3((unsigned)(blocks < 256 * 16 ? blocks : 256 * 16)), dim3(256), 0, static_cast<hipStream_t>(stream), d_chi, d_z,
+                       n, K, kind, d_out);
+    const hipError_t e = hipGetLastError();
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_distance_from_radial: launch failed: %s", hipGetErrorString(e));
+    return CP_OK;
+}
+
 extern "C" int cp_background_distance(long long ncosmo, long long nz, const cp_param* params, int second_is_omega_m, const double* d_z,
                                       int z_shared, double* d_out, int kind, int device, void* stream) {
     return cp_background_eval(ncosmo, nz, params, second_is_omega_m, nullptr, d_z, z_shared, d_out, kind, device, stream);

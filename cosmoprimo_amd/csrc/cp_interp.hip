@@ -352,6 +352,53 @@ __global__ __launch_bounds__(256) void spline_points_kernel(const double* __rest
     }
 }
 
+// ONE spline of up to SPLINE_LDS_KNOTS knots (the distance tables of a cosmology: 119 and 400 knots; DistanceToRedshift: 2048): the knots and the four
+// polynomial coefficients of every interval -- the same quotients as above, formed once per workgroup instead of once per sample (four IEEE divisions,
+// two thirds of a sample's instructions) -- sit in LDS; a sample is a bisection there, four LDS reads and the Horner form: no table read from memory.
+constexpr int SPLINE_LDS_KNOTS = 2048;
+
+__global__ __launch_bounds__(256) void spline_points_lds_kernel(const double* __restrict__ xk, const double* __restrict__ y, const double* __restrict__ s,
+                                                                int n, const double* __restrict__ xq, double* __restrict__ out, long long nq, int nu,
+                                                                int extrapolate) {
+    extern __shared__ double lds[];      // knots (n), then c0, c1, c2, c3 of the n - 1 intervals
+    double* xs = lds;
+    double* c0s = lds + n;
+    double* c1s = c0s + (n - 1);
+    double* c2s = c1s + (n - 1);
+    double* c3s = c2s + (n - 1);
+    for (int i = threadIdx.x; i < n; i += 256) xs[i] = xk[i];
+    for (int i = threadIdx.x; i < n - 1; i += 256) {
+        const double h = xk[i + 1] - xk[i];
+        const double slope = (y[i + 1] - y[i]) / h;
+        const double t = (s[i] + s[i + 1] - 2. * slope) / h;
+        c0s[i] = y[i]; c1s[i] = s[i]; c2s[i] = (slope - s[i]) / h - t; c3s[i] = t / h;
+    }
+    __syncthreads();
+    const double x0 = xs[0], xn = xs[n - 1];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long long)gridDim.x * blockDim.x) {
+        const double v = xq[i];
+        const bool inside = v >= x0 && v <= xn;
+        double r = __builtin_nan("");
+        if (inside || (extrapolate && v == v)) {
+            int lo = 0;
+            if (v >= xn) lo = n - 2;
+            else if (v > x0) {
+                int hi = n - 1;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (xs[mid] <= v) lo = mid; else hi = mid;
+                }
+            }
+            const double u = v - xs[lo];
+            const double c0 = c0s[lo], c1 = c1s[lo], c2 = c2s[lo], c3 = c3s[lo];
+            if (nu == 0) r = c0 + u * (c1 + u * (c2 + u * c3));
+            else if (nu == 1) r = c1 + u * (2. * c2 + u * 3. * c3);
+            else r = 2. * c2 + 6. * c3 * u;
+        }
+        out[i] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" int cp_spline_points(const double* d_xk, const double* d_y, const double* d_s, long long n, int ncol, const double* d_xq, double* d_out,
@@ -367,6 +414,17 @@ extern "C" int cp_spline_points(const double* d_xk, const double* d_y, const dou
     const int ncoarse = (int)((n + stride - 1) / stride);
     const long long blocks = (nq + 255) / 256;
     const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+    if (ncol == 1 && n <= SPLINE_LDS_KNOTS && nq >= 65536) {      // a catalogue through one spline: the spline in LDS (a few samples: not worth filling it per workgroup)
+        const size_t lds = (size_t)(n + 4 * (n - 1)) * sizeof(double);
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&spline_points_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const unsigned lgrid = (unsigned)(blocks < 256 * 4 ? blocks : 256 * 4);
+        hipLaunchKernelGGL(spline_points_lds_kernel, dim3(lgrid), dim3(256), lds, static_cast<hipStream_t>(stream), d_xk, d_y, d_s, (int)n, d_xq, d_out, nq, nu,
+                           extrapolate);
+        const hipError_t le = hipGetLastError();
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        if (le != hipSuccess) return cp::fail(CP_EDEVICE, "cp_spline_points: launch failed: %s", hipGetErrorString(le));
+        return CP_OK;
+    }
     hipLaunchKernelGGL(spline_points_kernel, dim3(grid), dim3(256), ncoarse * sizeof(double), static_cast<hipStream_t>(stream), d_xk, d_y, d_s, n, ncol, stride,
                        ncoarse, d_xq, d_out, nq, nu, extrapolate);
     const hipError_t e = hipGetLastError();

@@ -533,6 +533,7 @@ class Interpolator1D(dv.Copyable):
         self._nan_rows = some_nan | ~torch.isfinite(self._rows).all(dim=1)
         if self.k == 3 and bool((some_nan & ~all_nan).any()):
             self._nan_rows = torch.ones_like(self._nan_rows)
+        self._any_nan_row = bool(self._nan_rows.any())      # read back once, here: every call asks
 
     # With few splines (<= 64 columns) every evaluation goes point by point (cp_spline_points): no (queries x knots) operator to build on the
     # host for each new set of queries -- what a likelihood calling with its own redshifts pays at every step.  Many columns on shared queries
@@ -568,7 +569,7 @@ class Interpolator1D(dv.Copyable):
         _lib.check(_lib.load().cp_spline_points(self._x_device.data_ptr(), self._rows.data_ptr(), slopes.data_ptr(), self._x.size, self._rows.shape[0],
                                                 xq.data_ptr(), out.data_ptr(), xq.numel(), int(dx), int(self.extrap), self.device.index,
                                                 dv.stream_of(self.device)))
-        if bool(self._nan_rows.any()):
+        if self._any_nan_row:
             out = torch.where(self._nan_rows[:, None], torch.full_like(out, float('nan')), out)
         if self.interp_fun == 'log':
             out = 10**out
@@ -600,7 +601,7 @@ class Interpolator1D(dv.Copyable):
             op = _cached_operator(('i1d', self._x.tobytes(), xq.tobytes(), int(dx), self.extrap, self.device.index),
                                   lambda: LinearOperator.spline(self._x, xq, bc='natural', nu=dx, extrapolate=self.extrap, device=self.device))
         out = op(self._rows)   # (ncol, nq); NaN outside [xmin, xmax] unless extrap
-        if bool(self._nan_rows.any()):
+        if self._any_nan_row:
             out = dv.torch().where(self._nan_rows[:, None], dv.torch().full_like(out, float('nan')), out)
         if self.interp_fun == 'log':
             out = 10**out

@@ -170,6 +170,10 @@ int cp_derived_parameters(long long ncosmo, const cp_param* params, double* d_ou
 /* the 119 interpolation knots (host), get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949 (n = 119),
  * or the 400 knots of time / age, cosmology.py:1945-1946 (n = 400) */
 int cp_background_knots(double* zc_out, int n);
+/* the derived distances of ONE cosmology from its radial distances: d_chi, d_z, d_out (n) device (d_out may be d_chi), K = -Omega_k (100 / c)^2
+ * (cosmology.py:397), kind one of CP_BG_ANGULAR_DIAMETER / CP_BG_COMOVING_TRANSVERSE / CP_BG_LUMINOSITY -- the last lines of the background kernel
+ * (cosmology.py:1855-1912) as one pass over a catalogue whose radial distances come from the cosmology's table */
+int cp_distance_from_radial(const double* d_chi, const double* d_z, long long n, double K, int kind, double* d_out, int device, void* stream);
 
 /* ---- massive neutrinos (reference cosmology.py:74-137 _compute_ncdm_momenta, :1961-1998 DefaultBackground.rho_ncdm / p_ncdm) ----
  * The reference tabulates, per species, the comoving density and pressure on 119 redshift knots (get_default_z_interp('rho_ncdm'),

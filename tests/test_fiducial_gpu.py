@@ -178,3 +178,39 @@ def test_interp_table_laws():
     import copy
     clone = copy.deepcopy(table)
     assert clone.handle.value != table.handle.value and clone.law == table.law
+
+
+def test_spline_points_of_a_catalogue():
+    """``cp_spline_points`` on a catalogue (one spline, >= 65 536 points: knots and interval coefficients in LDS) against the same call on pieces short
+    enough to take the general kernel (coefficients formed per sample): the same bits, for values and derivatives, with and without extrapolation; and
+    against scipy's CubicSpline."""
+    import torch
+    from scipy.interpolate import CubicSpline
+    from cosmoprimo_amd import _lib, _device as dv
+    from cosmoprimo_amd.spline import dense_operator
+    dev = torch.device('cuda:0')
+    lib, stream = _lib.load(), dv.stream_of(dev)
+    rng = np.random.default_rng(5)
+    for n in [2, 3, 119, 400, 2048, 2049]:
+        xk = np.sort(np.concatenate([[0.], rng.uniform(0., 10., n - 2), [10.]])) if n > 2 else np.array([0., 10.])
+        y = np.sin(xk) + 0.1 * xk**2
+        slopes = dense_operator(xk, xk, bc='natural', nu=1).dot(y) if n > 2 else np.full(2, (y[1] - y[0]) / 10.)
+        xq = np.concatenate([rng.uniform(-1., 11., 200000), xk, [np.nan]])
+        txk, ty, ts, txq = [torch.as_tensor(a, device=dev) for a in (xk, y, slopes, xq)]
+        for nu in (0, 1, 2):
+            for extrapolate in (0, 1):
+                whole = torch.empty_like(txq)
+                _lib.check(lib.cp_spline_points(txk.data_ptr(), ty.data_ptr(), ts.data_ptr(), n, 1, txq.data_ptr(), whole.data_ptr(), txq.numel(), nu, extrapolate,
+                                                0, stream))
+                pieces = torch.empty_like(txq)
+                for lo in range(0, txq.numel(), 50000):
+                    m = min(50000, txq.numel() - lo)
+                    _lib.check(lib.cp_spline_points(txk.data_ptr(), ty.data_ptr(), ts.data_ptr(), n, 1, txq.data_ptr() + 8 * lo, pieces.data_ptr() + 8 * lo, m, nu,
+                                                    extrapolate, 0, stream))
+                got, ref = whole.cpu().numpy(), pieces.cpu().numpy()
+                assert np.array_equal(got, ref, equal_nan=True), (n, nu, extrapolate)
+                assert np.isnan(got[-1]) and (extrapolate or np.isnan(got[:200000][(xq[:200000] < 0.) | (xq[:200000] > 10.)]).all())
+        if n > 2:
+            inside = (xq >= 0.) & (xq <= 10.)
+            _lib.check(lib.cp_spline_points(txk.data_ptr(), ty.data_ptr(), ts.data_ptr(), n, 1, txq.data_ptr(), whole.data_ptr(), txq.numel(), 0, 0, 0, stream))
+            np.testing.assert_allclose(whole.cpu().numpy()[inside], CubicSpline(xk, y, bc_type='natural')(xq[inside]), rtol=1e-11, atol=1e-12)
