@@ -824,6 +824,11 @@ extern "C" int cp_spline_plan_create(cp_spline_plan** out, int n, const double* 
     if (!out) return cp::fail(CP_EINVAL, "cp_spline_plan_create: null plan pointer");
     *out = nullptr;
     if (nq < 1) return cp::fail(CP_EINVAL, "cp_spline_plan_create: need at least one query point");
+    // the operator is staged as a dense (nq, n) matrix on the host: a catalogue or a mesh of queries (1e7 x 600 = 48 GB) must not get here -- a host
+    // that runs out of memory is killed, it does not throw (cp_spline_points evaluates splines point by point, any number of points)
+    if (n >= 1 && (size_t)nq * (size_t)n > ((size_t)1 << 29))
+        return cp::fail(CP_EUNSUPPORTED, "cp_spline_plan_create: %d queries x %d knots: the operator form is for up to 2^29 weights (4 GB on the host); "
+                                         "evaluate point by point (cp_spline_points) or in pieces", nq, n);
     std::vector<double> w((size_t)nq * n);
     int st = cp_spline_operator(n, x, nq, xq, bc, nu, extrapolate, w.data(), nullptr);
     if (st != CP_OK) return st;

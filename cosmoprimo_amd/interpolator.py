@@ -715,6 +715,8 @@ class Interpolator2D(dv.Copyable):
         except NotImplementedError:
             return None
 
+    _pairs_chunk = 1 << 16      # pairs of (x, y) evaluated per pass of the pair route
+
     def _call_many_x(self, x, y, bounds_error):
         """Grid evaluation at very many x (a mesh of wavenumbers) and a few y: the y direction first (operator, few queries), then one spline
         along x per requested y evaluated point by point (``cp_spline_points``); x may live on the device and is not read back."""
@@ -735,6 +737,8 @@ class Interpolator2D(dv.Copyable):
             return _finish(torch.full((xq.numel(), yh.size), float('nan'), dtype=torch.float64, device=self.device), dtype, like_torch, shape)
         if self.interp_x == 'log':
             xq = torch.log10(xq)
+        if self.extrap:      # FITPACK's bispev evaluates queries outside the knots at the end knots (as _operator does for the grid route)
+            xq = xq.clamp(float(self._x[0]), float(self._x[-1]))
         opy = self._operator('y', yh)
         rows = opy(self._fun).T.contiguous()                      # (nyq, nx): the surface along x at every requested y
         slope_op = _cached_operator(('i2s', self._x.tobytes(), self.device.index),
@@ -759,8 +763,14 @@ class Interpolator2D(dv.Copyable):
         like_torch = dv.is_torch(x) or dv.is_torch(y)
         dtype = dv.float_dtype(x, y)
         nxq, nyq = (v.numel() if dv.is_torch(v) else np.size(v) for v in (x, y))
-        if grid and self.kx == 3 and not self.extrap and 0 < nyq <= 64 and (nxq > 16384 or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
+        if grid and self.kx == 3 and 0 < nyq <= 64 and (nxq > 16384 or (nxq > 1024 and nxq * self._x.size > (1 << 22))):
             return self._call_many_x(x, y, bounds_error)
+        if not grid and nxq > self._pairs_chunk and nxq == nyq:
+            # very many pairs: in pieces (the pair route multiplies two dense (pairs x knots) operators built on the host)
+            xf, yf = (v.reshape(-1) if dv.is_torch(v) else np.asarray(v).ravel() for v in (x, y))
+            pieces = [dv.to_device(self(xf[lo:lo + self._pairs_chunk], yf[lo:lo + self._pairs_chunk], grid=False, bounds_error=bounds_error), self.device)
+                      for lo in range(0, nxq, self._pairs_chunk)]
+            return _finish(torch.cat(pieces, dim=-1), dtype, like_torch, self._lead + tuple(x.shape if dv.is_torch(x) else np.shape(x)))
         xh, yh = _host(x), _host(y)
         shape = self._lead + (xh.shape + yh.shape if grid else xh.shape)
         xh, yh = xh.ravel(), yh.ravel()

@@ -125,6 +125,8 @@ def dense_operator(x, xq, bc='natural', nu=0, extrapolate=False):
     """The dense (nq, n) spline operator on the host (numpy); rows of out-of-range queries are NaN unless ``extrapolate``."""
     x = np.ascontiguousarray(x, dtype='f8').ravel()
     xq = np.ascontiguousarray(xq, dtype='f8').ravel()
+    if xq.size * x.size > (1 << 29):      # 4 GB of weights: a catalogue / mesh of queries is evaluated point by point or in pieces, never as one matrix
+        raise MemoryError('a dense spline operator of {:d} queries x {:d} knots'.format(xq.size, x.size))
     w = np.empty((xq.size, x.size))
     _lib.check(_lib.load().cp_spline_operator(x.size, _lib.as_double_p(x), xq.size, _lib.as_double_p(xq), _lib.SPLINE_BC[bc], int(nu),
                                               int(bool(extrapolate)), _lib.as_double_p(w), None))

@@ -207,6 +207,9 @@ def test_many_points_2d():
         keep = (xq >= x[0]) & (xq <= x[-1])        # (FITPACK clamps outside its knots; the reference masks there unless extrap)
         np.testing.assert_allclose(got[keep][:, :4], expected[keep][:, :4], rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(got[:20], interp(xq[:20], yq), rtol=1e-11, atol=1e-13, equal_nan=True)      # the operator path on a few of them
+        np.testing.assert_allclose(got[-4:], interp(xq[-4:], yq), rtol=1e-11, atol=1e-13, equal_nan=True)      # ... and on the end knots and the points outside
+        if extrap:      # outside the knots: FITPACK's value at the end knot, in x and in y
+            np.testing.assert_allclose(got[~keep], expected[~keep], rtol=1e-10, atol=1e-12)
     k, z = np.geomspace(1e-4, 10., 200), np.linspace(0., 2., 8)
     table = cp.Cosmology(engine='eisenstein_hu').get_fourier().pk_interpolator()(k, z)
     pk2d = cp.PowerSpectrumInterpolator2D(k, z, table)
@@ -215,6 +218,31 @@ def test_many_points_2d():
     assert out.is_cuda and out.shape == (300000, 2)
     some = kmesh[:50].cpu().numpy()
     np.testing.assert_allclose(out[:50].cpu().numpy(), pk2d(some, np.array([0.5, 1.])), rtol=1e-10)
+
+
+def test_many_pairs_2d_and_the_size_of_operators():
+    """Pairs of (x, y) beyond one pass of the pair route come in pieces; an operator whose dense staging would not fit a host is refused, not built."""
+    import cosmoprimo_amd.interpolator as it
+    from cosmoprimo_amd.spline import LinearOperator, dense_operator
+    rng = np.random.default_rng(8)
+    x, y = np.sort(rng.uniform(0., 5., 40)), np.linspace(0., 2., 9)
+    fun = np.sin(x)[:, None] * np.cos(y)[None, :]
+    interp = it.Interpolator2D(x, y, fun)
+    xq, yq = rng.uniform(-0.2, 5.2, 3500), rng.uniform(-0.1, 2.1, 3500)
+    whole = interp(xq, yq, grid=False)
+    try:
+        it.Interpolator2D._pairs_chunk = 1000
+        pieces = interp(xq, yq, grid=False)
+        mesh = interp(xq.reshape(70, 50), yq.reshape(70, 50), grid=False)
+    finally:
+        it.Interpolator2D._pairs_chunk = 1 << 16
+    assert pieces.shape == (3500,) and mesh.shape == (70, 50)
+    assert np.array_equal(pieces, whole, equal_nan=True) and np.array_equal(mesh.ravel(), whole, equal_nan=True) and np.isnan(whole).any()
+    knots = np.linspace(0., 1., 600)
+    with pytest.raises(NotImplementedError):
+        LinearOperator.spline(knots, np.linspace(0., 1., 1 << 20))      # 6.3e8 weights: 5 GB on the host
+    with pytest.raises(MemoryError):
+        dense_operator(knots, np.linspace(0., 1., 1 << 20))
 
 
 def test_device_mesh_through_callable():
