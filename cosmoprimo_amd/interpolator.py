@@ -413,9 +413,20 @@ def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, 
     return op(pk_rows(k))[..., 0]
 
 
+_MAX_OPERATOR_WEIGHTS = 1 << 29      # 4 GB of float64 on the host
+
+
+def _check_operator_size(nq, n):
+    """Dense (queries x knots) operators are built on the host: beyond 4 GB the caller must come in pieces (a host that runs out of memory is
+    killed, it does not raise)."""
+    if int(nq) * int(n) > _MAX_OPERATOR_WEIGHTS:
+        raise MemoryError('a dense interpolation operator of {:d} queries x {:d} knots: evaluate in pieces'.format(int(nq), int(n)))
+
+
 def _linear_interp_operator(x, xq, extrap=False):
     """(nq, n) matrix of piecewise-linear interpolation on the knots ``x`` (scipy interp1d kind='linear', reference jax.py:176-177):
     linear continuation of the end intervals if ``extrap``, else NaN rows outside [x[0], x[-1]].  Host numpy."""
+    _check_operator_size(xq.size, x.size)
     i = np.clip(np.searchsorted(x, xq, side='right') - 1, 0, x.size - 2)
     t = (xq - x[i]) / (x[i + 1] - x[i])
     w = np.zeros((xq.size, x.size))
@@ -430,6 +441,7 @@ def _linear_interp_operator(x, xq, extrap=False):
 def _bspline_basis(t, k, x):
     """Dense (len(x), len(t) - k - 1) matrix of B-spline basis values B_j(x) (Cox-de Boor), with polynomial extrapolation of the end pieces."""
     n = t.size - k - 1
+    _check_operator_size(x.size, n)
     out = np.zeros((x.size, n))
     for ix, xv in enumerate(x):
         ell = np.searchsorted(t, xv, side='right') - 1
@@ -539,6 +551,7 @@ class Interpolator1D(dv.Copyable):
     # host for each new set of queries -- what a likelihood calling with its own redshifts pays at every step.  Many columns on shared queries
     # (batches of spectra) keep the operator form, unless the operator would be larger than this many queries / 4 M entries.
     _npoints_operator = 0
+    _operator_chunk = 1 << 16      # queries per pass of the operator routes when the (queries x knots) operator would pass 64 M weights
 
     def _call_points(self, x, bounds_error, dx):
         """Few splines at very many points (``cp_spline_points``): the queries stay where they are (a device tensor is not read back), the
@@ -583,6 +596,12 @@ class Interpolator1D(dv.Copyable):
         if self.k == 3 and self._rows.shape[0] <= 64 and (nq > self._npoints_operator or (nq > 1024 and nq * self._x.size > (1 << 22))):
             # few splines, and a (queries x knots) operator that would be large: evaluate point by point
             return self._call_points(x, bounds_error, dx)
+        if nq > self._operator_chunk and nq * self._x.size > (1 << 26):
+            # a catalogue through one of the operator routes (linear / quadratic interpolation, many columns): in pieces of queries
+            xf = x.reshape(-1) if like_torch else np.asarray(x).ravel()
+            pieces = [dv.to_device(self(xf[lo:lo + self._operator_chunk], bounds_error=bounds_error, dx=dx), self.device)
+                      for lo in range(0, nq, self._operator_chunk)]
+            return _finish(dv.torch().cat(pieces, dim=0), dtype, like_torch, tuple(x.shape if like_torch else np.shape(x)) + self.shape)
         xh = _host(x)
         shape = xh.shape + self.shape
         xh = xh.ravel()

@@ -238,6 +238,19 @@ def test_many_pairs_2d_and_the_size_of_operators():
         it.Interpolator2D._pairs_chunk = 1 << 16
     assert pieces.shape == (3500,) and mesh.shape == (70, 50)
     assert np.array_equal(pieces, whole, equal_nan=True) and np.array_equal(mesh.ravel(), whole, equal_nan=True) and np.isnan(whole).any()
+    # linear interpolation of a catalogue: the operator route in pieces of queries (200 000 x 400 weights would be 640 MB as one matrix)
+    xk = np.sort(rng.uniform(0., 5., 400))
+    yk = np.stack([np.sin(xk), np.cos(xk)], axis=-1)
+    lin = it.Interpolator1D(xk, yk, k=1)
+    xc = rng.uniform(-0.1, 5.1, 200000)
+    got = lin(xc)
+    inside = (xc >= xk[0]) & (xc <= xk[-1])
+    assert got.shape == (200000, 2) and np.isnan(got[~inside]).all()
+    np.testing.assert_allclose(got[inside, 0], np.interp(xc[inside], xk, yk[:, 0]), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(got[inside, 1], np.interp(xc[inside], xk, yk[:, 1]), rtol=1e-12, atol=1e-14)
+    assert lin(xc.reshape(400, 500)).shape == (400, 500, 2)
+    with pytest.raises(MemoryError):
+        it._linear_interp_operator(xk, np.linspace(0., 5., 1 << 21))
     knots = np.linspace(0., 1., 600)
     with pytest.raises(NotImplementedError):
         LinearOperator.spline(knots, np.linspace(0., 1., 1 << 20))      # 6.3e8 weights: 5 GB on the host
