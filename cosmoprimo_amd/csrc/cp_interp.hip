@@ -11,6 +11,7 @@
 
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
+#include "cp_interp_table.h"
 
 // hipcc contracts a * b + c into an fma by default, also through the __dmul_rn / __dadd_rn wrappers of its headers: not in this file
 #pragma clang fp contract(off)
@@ -111,78 +112,15 @@ struct cp_interp_table {
 
 namespace {
 
-__device__ __forceinline__ double log2_guess(double v) {      // log2 of a positive finite double to single precision
-    const int e = __builtin_amdgcn_frexp_exp(v);
-    const float m = (float)__builtin_amdgcn_frexp_mant(v);
-    return (double)e + (double)__builtin_amdgcn_logf(m);
-}
-
 template <int LAW, typename real>      // real: the type of the samples and of the results (float: computed in double, rounded once, as the reference's cast of its result)
-__global__ __launch_bounds__(256) void interp_table_kernel(const double2* __restrict__ xf, long long n, long long first, double a, double b,
+__global__ __launch_bounds__(256) void interp_table_kernel(const cpit::Pair* __restrict__ xf, long long n, long long first, double a, double b,
                                                            const real* __restrict__ x, real* __restrict__ out, long long nx, int* flag) {
     const double x0 = xf[0].x, xn = xf[n - 1].x;
     const double xfirst = xf[first].x;
     bool outside = false;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (long long)gridDim.x * blockDim.x) {
-        const double v = (double)x[i];
-        double r = __builtin_nan("");
-        if (v >= x0 && v <= xn) {
-            if (v == xn) {
-                r = xf[n - 1].y;
-            } else {
-                long long lo;
-                double2 k0, k1;
-                if (first > 0 && v < xfirst) {      // among the leading knots (one, for the DESI table): bisection
-                    lo = 0;
-                    long long hi = first;
-                    while (hi - lo > 1) {
-                        const long long mid = (lo + hi) >> 1;
-                        if (xf[mid].x <= v) lo = mid; else hi = mid;
-                    }
-                    k0 = xf[lo]; k1 = xf[lo + 1];
-                } else {
-                    const double t = LAW == 2 ? log2_guess(v) : v;
-                    const double g = (t - a) * b;
-                    lo = first + (long long)(g > 0. ? g : 0.);
-                    lo = lo > n - 2 ? n - 2 : lo;
-                    k0 = xf[lo]; k1 = xf[lo + 1];      // the guessed interval: both ends in flight together; the walk (rare) re-uses the end it keeps
-                    while (lo > first && k0.x > v) { --lo; k1 = k0; k0 = xf[lo]; }
-                    while (lo < n - 2 && k1.x <= v) { ++lo; k0 = k1; k1 = xf[lo + 1]; }
-                }
-                if (k0.x == v) {  // numpy.interp returns the knot value here
-                    out[i] = (real)k0.y;
-                    continue;
-                }
-                const double slope = (k1.y - k0.y) / (k1.x - k0.x);
-                r = slope * (v - k0.x) + k0.y;   // product and sum rounded separately (contract(off) above)
-                if (r != r) {
-                    r = slope * (v - k1.x) + k1.y;
-                    if (r != r && k0.y == k1.y) r = k0.y;
-                }
-            }
-        } else {
-            outside = true;
-        }
-        out[i] = (real)r;
-    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (long long)gridDim.x * blockDim.x)
+        out[i] = (real)cpit::interp_sample<LAW>(xf, n, first, a, b, x0, xfirst, xn, (double)x[i], &outside);      // (cp_interp_table.h)
     if (outside) atomicOr(flag, 1);
-}
-
-// the law of a table: the knots from `first` on against first + (T(x) - a) b, accepted when no knot and no interval midpoint is guessed further than
-// a quarter of an interval from where it is (the device's single-precision log2 adds ~1e-3 of an interval to that)
-bool fit_law(const double* x, long long n, int law, long long first, double* a, double* b) {
-    if (n - first < 3) return false;
-    auto T = [&](double v) { return law == 2 ? std::log2(v) : v; };
-    if (law == 2 && !(x[first] > 0.)) return false;
-    const double t0 = T(x[first]), t1 = T(x[n - 1]);
-    if (!(t1 > t0) || !std::isfinite(t0) || !std::isfinite(t1)) return false;
-    *a = t0;
-    *b = (double)(n - 1 - first) / (t1 - t0);
-    for (long long i = first; i < n; ++i) {
-        const double g = (T(x[i]) - *a) * *b;
-        if (std::fabs(g - (double)(i - first)) > 0.25) return false;
-    }
-    return true;
 }
 
 }  // namespace
@@ -197,13 +135,8 @@ extern "C" int cp_interp_table_create(cp_interp_table** table, long long n, cons
     if (!t) return cp::fail(CP_ENOMEM, "cp_interp_table_create: out of host memory");
     t->device = device; t->n = n; t->law = 0; t->first = 0; t->a = 0.; t->b = 0.; t->x0 = x[0]; t->xn = x[n - 1];
     t->d_xf = t->d_x = t->d_f = nullptr; t->d_flag = nullptr;
-    // uniform in x, else uniform in log2 x from the first positive knot that starts a regular run (at most 8 leading knots are set aside)
-    double a = 0., b = 0.;
-    if (fit_law(x, n, 1, 0, &a, &b)) { t->law = 1; t->a = a; t->b = b; }
-    else {
-        for (long long first = 0; first < 8 && first < n - 3 && !t->law; ++first)
-            if (x[first] > 0. && fit_law(x, n, 2, first, &a, &b)) { t->law = 2; t->first = first; t->a = a; t->b = b; }
-    }
+    const cpit::Law law = cpit::find_law(x, n);      // uniform in x, uniform in log x behind a few leading knots, or neither (cp_interp_table.h)
+    t->law = law.law; t->first = law.first; t->a = law.a; t->b = law.b;
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) { delete t; return cp::fail(CP_EDEVICE, "cp_interp_table_create: cannot select device %d", device); }
@@ -251,7 +184,7 @@ int interp_table_apply(const cp_interp_table* t, const real* d_x, real* d_out, l
     } else {
         const long long blocks = (nx + 255) / 256;
         const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
-        const double2* xf = reinterpret_cast<const double2*>(t->d_xf);
+        const cpit::Pair* xf = reinterpret_cast<const cpit::Pair*>(t->d_xf);
         if (t->law == 1) hipLaunchKernelGGL((interp_table_kernel<1, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, t->d_flag);
         else hipLaunchKernelGGL((interp_table_kernel<2, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, t->d_flag);
         if (hipGetLastError() != hipSuccess) st = cp::fail(CP_EDEVICE, "%s: launch failed", who);

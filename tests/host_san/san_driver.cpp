@@ -152,7 +152,46 @@ static void splice_plans() {
     }
 }
 
+extern "C" int emu_interp_law(long long n, const double* x, int* law, long long* first, double* a, double* b);
+extern "C" int emu_interp_apply(long long n, const double* x, const double* f, int law, long long first, double a, double b, long long nx, const double* xq, double* out);
+
+// the table interpolation of the 'tabulated' engine (csrc/cp_interp_table.h): the law of the knots and the per-sample walk on exact-size tables --
+// the shape of data/desi.dat, a uniform table, and laws the table does not follow (guesses far outside the table, NaN and infinite guesses)
+static void interp_tables() {
+    for (int variant = 0; variant < 3; ++variant) {
+        std::vector<double> x, f;
+        if (variant == 0) { x.push_back(0.); for (int i = 0; i <= 4000; ++i) x.push_back(std::pow(10., -8. + 10. * i / 4000.)); }
+        if (variant == 1) for (int i = 0; i < 777; ++i) x.push_back(-3. + 0.01 * i);
+        if (variant == 2) for (int i = 0; i < 300; ++i) x.push_back(1. + 0.03 * i + 0.0299 * ((i * 7919) % 13) / 13.);
+        for (size_t i = 0; i < x.size(); ++i) f.push_back(std::cos(3. * i));
+        const long long n = (long long)x.size();
+        int law = 0; long long first = 0; double a = 0., b = 0.;
+        emu_interp_law(n, x.data(), &law, &first, &a, &b);
+        EXPECT(law == (variant == 0 ? 2 : (variant == 1 ? 1 : 0)) && first == (variant == 0 ? 1 : 0));
+        std::vector<double> q, out;
+        for (size_t i = 0; i + 1 < x.size(); ++i) { q.push_back(x[i]); q.push_back(0.5 * (x[i] + x[i + 1])); q.push_back(std::nextafter(x[i + 1], -1e308)); }
+        q.push_back(x.back()); q.push_back(std::nextafter(x.front(), -1e308)); q.push_back(std::nextafter(x.back(), 1e308)); q.push_back(std::nan(""));
+        out.resize(q.size());
+        const double laws[6][3] = {{(double)law, a, b}, {1., x[0], 1e300}, {1., -1e300, 1e300}, {2., 1e300, -1e300}, {1., std::nan(""), 1.}, {2., 0., std::nan("")}};
+        for (int l = (law ? 0 : 1); l < 6; ++l) {
+            if (laws[l][0] == 2. && !(x[first] > 0.)) continue;      // (the logarithm law is for positive knots)
+            const int outside = emu_interp_apply(n, x.data(), f.data(), (int)laws[l][0], first, laws[l][1], laws[l][2], (long long)q.size(), q.data(), out.data());
+            EXPECT(outside == 1);
+            bool same = true;
+            for (size_t i = 0; i + 3 < q.size(); ++i) {
+                const size_t j = (size_t)(std::upper_bound(x.begin(), x.end(), q[i]) - x.begin()) - 1;
+                const size_t k = j + 1 < x.size() ? j : x.size() - 2;
+                const double ref = q[i] == x.back() ? f.back() : (q[i] == x[k] ? f[k] : (f[k + 1] - f[k]) / (x[k + 1] - x[k]) * (q[i] - x[k]) + f[k]);
+                same = same && out[i] == ref;
+            }
+            EXPECT(same);
+            EXPECT(out[q.size() - 1] != out[q.size() - 1] && out[q.size() - 2] != out[q.size() - 2] && out[q.size() - 3] != out[q.size() - 3]);
+        }
+    }
+}
+
 int main() {
+    interp_tables();
     special_functions();
     table_setup_errors();
     kernel_phases();
