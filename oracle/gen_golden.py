@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors),
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -887,6 +887,94 @@ def gen_fuzz(cp):
     save('fuzz', k=k, z=z, zb=zb, **{name: np.stack(v) for name, v in rows.items()})
 
 
+# FFTLog configurations drawn at random: class, size (powers of two and not), range, tilt, folds, low-ringing, xy, padding mode, batch shape -- the
+# combinations the hand-picked G3 cases do not visit.  A configuration is a plain dict (tests rebuild the same object from it).
+FFTLOG_FUZZ_N = 60
+
+
+def fftlog_fuzz_configs(n=FFTLOG_FUZZ_N, seed=20261005):
+    rng = np.random.default_rng(seed)
+    kinds = ['PowerToCorrelation', 'CorrelationToPower', 'TophatVariance', 'GaussianVariance', 'HankelTransform', 'FFTlog']
+    extraps = [0, 'log', 'edge', 0.7, ('log', 0.), (1.5, 'edge'), ('edge', 'log')]
+    configs = []
+    for i in range(n):
+        kind = kinds[i % len(kinds)]
+        cfg = dict(kind=kind, n=int(rng.choice([64, 100, 127, 256, 500, 1024, 2048, 3000])), lo=float(rng.uniform(-6., -2.)), span=float(rng.uniform(4., 9.)),
+                   q=float(np.round(rng.uniform(-0.4, 0.9), 3)), minfolds=int(rng.choice([1, 2, 3])), lowring=bool(rng.integers(2)),
+                   xy=float(rng.choice([0.3, 1., 4.])), extrap=extraps[int(rng.integers(len(extraps)))], keep_padding=bool(i % 7 == 3),
+                   nbatch=int(rng.choice([0, 0, 3])), slope=float(rng.uniform(-2.5, 1.5)), knee=float(rng.uniform(0.2, 0.8)))
+        if kind in ('PowerToCorrelation', 'CorrelationToPower'):
+            cfg['ell'] = [0, 2, 4] if i % 5 == 0 else int(rng.choice([0, 1, 2, 3, 4]))
+            cfg['complex'] = bool(kind == 'PowerToCorrelation' and i % 4 == 1)
+        if kind == 'HankelTransform':
+            cfg['nu'] = float(rng.choice([0., 0.5, 1., 2.5]))
+        if kind == 'FFTlog':
+            cfg['kernel'] = [('SphericalBesselJKernel', 1), ('TophatKernel', 3), ('TophatSqKernel', 1), ('TophatSqKernel', 2), ('GaussianKernel', None),
+                             ('BesselJKernel', 1.5)][int(rng.integers(6))]
+        configs.append(cfg)
+    return configs
+
+
+def fftlog_fuzz_stride(size):
+    """Every how many-th output sample is kept in the fixture (at most 128 per row)."""
+    return max(1, -(-size // 128))
+
+
+def fftlog_fuzz_error(cfg, got, ref, y):
+    """max |got - ref| y^q / max |ref| y^q per row: norm-wise in the tilted space, where the transform's rounding is uniform."""
+    q = cfg['q'] + (1.5 if cfg['kind'] in ('PowerToCorrelation', 'CorrelationToPower', 'TophatVariance', 'GaussianVariance') else 0.)
+    tilt = np.broadcast_to(y, ref.shape[-y.ndim:] if y.ndim > 1 else ref.shape[-1:])**q
+    scale = np.abs(ref * tilt).max(axis=-1, keepdims=True)
+    return float((np.abs((got - ref) * tilt) / scale).max())
+
+
+def fftlog_fuzz_build(fl, cfg):
+    """(transform object of the module ``fl`` -- the reference's fftlog or this package's --, x, input function) of a configuration."""
+    x = np.logspace(cfg['lo'], cfg['lo'] + cfg['span'], cfg['n'])
+    kw = dict(q=cfg['q'], minfolds=cfg['minfolds'], lowring=cfg['lowring'], xy=cfg['xy'])
+    kind = cfg['kind']
+    if kind in ('PowerToCorrelation', 'CorrelationToPower'):
+        obj = getattr(fl, kind)(x, ell=cfg['ell'], **(dict(complex=True) if cfg['complex'] else {}), **kw)
+    elif kind == 'HankelTransform':
+        obj = fl.HankelTransform(x, nu=cfg['nu'], **kw)
+    elif kind == 'FFTlog':
+        name, arg = cfg['kernel']
+        obj = fl.FFTlog(x, getattr(fl, name)(*(() if arg is None else (arg,))), **kw)
+    else:
+        obj = getattr(fl, kind)(x, **kw)
+    # a smooth positive function of x: a power law with a knee inside the range (positive: the log extrapolation takes it)
+    xm = 10.**(cfg['lo'] + cfg['knee'] * cfg['span'])
+    fun = (x / xm)**cfg['slope'] / (1. + (x / xm)**2)**1.5
+    if cfg['nbatch']:
+        fun = fun * np.array([1., 0.5, 2.5])[:cfg['nbatch'], None] * (x / xm)**(0.1 * np.arange(cfg['nbatch'])[:, None])
+        if np.ndim(cfg.get('ell', 0)):      # several transforms at once: (batch, nell, n)
+            fun = fun[:, None, :] * np.ones((1, len(cfg['ell']), 1))
+    return obj, x, fun
+
+
+def gen_fftlog_fuzz(cp):
+    """FFTLOG_FUZZ_N random FFTLog configurations through the reference: output coordinates and transforms, every fftlog_fuzz_stride-th sample
+    of them: keys c<i>_y / c<i>_g (complex as it comes), c<i>_size the full length."""
+    from cosmoprimo import fftlog as fl
+    out = {}
+    for i, cfg in enumerate(fftlog_fuzz_configs()):
+        obj, x, fun = fftlog_fuzz_build(fl, cfg)
+        y, g = obj(fun, extrap=cfg['extrap'], keep_padding=cfg['keep_padding'])
+        y, g = np.asarray(y), np.asarray(g)
+        stride = fftlog_fuzz_stride(y.shape[-1])
+        out['c%d_y' % i], out['c%d_g' % i], out['c%d_size' % i] = y[..., ::stride], g[..., ::stride], np.array(y.shape[-1])
+        # how far the reference's own result moves when every input sample is off by one rounding error: with constant / edge padding over many
+        # decades the cropped output is orders of magnitude below what the padded transform carries, and holds that many digits fewer -- the
+        # tolerance a parity test can ask for (tests add 30 x this to their 1e-12)
+        pre = obj.padded_prefactor
+        up = np.random.default_rng(1000 + i).integers(2, size=np.shape(pre)).astype(bool)
+        obj.padded_prefactor = np.where(up, np.nextafter(pre, np.inf), np.nextafter(pre, -np.inf))      # (every padded, prefactored sample one ulp off)
+        moved = np.asarray(obj(fun, extrap=cfg['extrap'], keep_padding=cfg['keep_padding'])[1])
+        obj.padded_prefactor = pre
+        out['c%d_moves' % i] = np.array(fftlog_fuzz_error(cfg, moved, g, y))
+    save('fftlog_fuzz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -924,6 +1012,8 @@ def main():
         gen_bao_batch(cp)
     if 'fuzz' in which:
         gen_fuzz(cp)
+    if 'fftlog_fuzz' in which:
+        gen_fftlog_fuzz(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:
