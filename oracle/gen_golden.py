@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations),
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -975,6 +975,116 @@ def gen_fftlog_fuzz(cp):
     save('fftlog_fuzz', **out)
 
 
+# Tabulated P(k) / P(k, z) interpolators with options drawn at random -- grid sizes and spacings (geometric, jittered), interpolation in k or log k,
+# extrapolation mode and range, spline degrees, growth factor or table in z -- evaluated inside, in the extrapolation range and outside, with the sigma
+# integrals and the xi side: the option combinations the hand-picked G4 / G5 cases do not visit.
+INTERP_FUZZ_N = 36
+
+
+def interp_fuzz_configs(n=INTERP_FUZZ_N, seed=20261006):
+    rng = np.random.default_rng(seed)
+    configs = []
+    for i in range(n):
+        two_d = bool(i % 2)
+        log_k = bool(i % 5 != 3)
+        cfg = dict(two_d=two_d, nk=int(rng.choice([24, 57, 200, 540])), kmin=float(10.**rng.uniform(-4.5, -3.)), kmax=float(10.**rng.uniform(0.5, 1.7)),
+                   jitter=float(rng.choice([0., 0.3])), interp_k='log' if log_k else 'lin', extrap_pk='log' if (log_k and i % 3 != 2) else 'lin',
+                   extrap_down=int(rng.integers(1, 4)), extrap_up=int(rng.integers(0, 2)), interp_order_k=int(rng.choice([1, 3, 3])),
+                   tilt=float(rng.uniform(0.9, 1.05)), knee=float(10.**rng.uniform(-2., -1.3)), wiggle=float(rng.uniform(0., 0.06)))
+        if two_d:
+            cfg['nz'] = int(rng.choice([1, 6, 12, 30]))
+            cfg['zmax'] = float(rng.uniform(1., 4.))
+            cfg['interp_order_z'] = int(rng.choice([1, 2, 3, 3, 5])) if cfg['nz'] > 5 else 3
+            cfg['growth'] = bool(cfg['nz'] == 1 or i % 4 == 1)
+        # The extrapolation range: powers of ten beyond the table, as the reference's defaults (1e-7, 1e2) are.  The reference takes its knots through
+        # 10**log10(k): for an arbitrary end of the range that does not round-trip, P at the end itself is then NaN and with it every sigma / xi
+        # (their FFTLog grid starts and stops there) -- 14 of 36 random ranges; and a range that ends INSIDE the table puts two knots 1e-9 apart at
+        # the table's end (its own spline carries ~1e-7 of rounding there).
+        cfg['extrap_kmin'] = float(10.**(np.floor(np.log10(cfg['kmin'])) - cfg.pop('extrap_down')))
+        cfg['extrap_kmax'] = float(10.**(np.ceil(np.log10(cfg['kmax'])) + cfg.pop('extrap_up')))
+        configs.append(cfg)
+    return configs
+
+
+def interp_fuzz_table(cfg):
+    """(k, z or None, pk table, growth_factor_sq or None) of a configuration: plain numpy, the same for the generator and the tests."""
+    rng = np.random.default_rng(int(cfg['nk'] * 1000 + cfg['kmin'] * 1e9) % (2**31))
+    logk = np.linspace(np.log10(cfg['kmin']), np.log10(cfg['kmax']), cfg['nk'])
+    if cfg['jitter']:
+        logk[1:-1] += cfg['jitter'] * (logk[1] - logk[0]) * rng.uniform(-1., 1., cfg['nk'] - 2)
+    k = 10.**logk
+    pk = 2e4 * (k / cfg['knee'])**cfg['tilt'] / (1. + (k / cfg['knee'])**2)**1.9 * (1. + cfg['wiggle'] * np.sin(70. * k) * np.exp(-(3. * k)**2))
+    if not cfg['two_d']:
+        return k, None, pk, None
+    growth = (lambda zz: 1. / (1. + 0.8 * np.asarray(zz, dtype='f8'))**1.7) if cfg['growth'] else None
+    if cfg['nz'] == 1:
+        return k, np.array([0.]), pk[:, None], growth
+    z = np.sort(np.concatenate([[0.], rng.uniform(0., cfg['zmax'], cfg['nz'] - 2), [cfg['zmax']]]))
+    table = pk[:, None] * (1. + 0.1 * np.log10(k / cfg['knee'])[:, None] * z / (1. + z)) / (1. + z)**(0. if cfg['growth'] else 1.5)
+    return k, z, table, growth
+
+
+def interp_fuzz_build(mod, cfg):
+    """The interpolator of module ``mod`` (the reference or this package) for a configuration."""
+    k, z, pk, growth = interp_fuzz_table(cfg)
+    kw = dict(interp_k=cfg['interp_k'], extrap_pk=cfg['extrap_pk'], extrap_kmin=cfg['extrap_kmin'], extrap_kmax=cfg['extrap_kmax'], interp_order_k=cfg['interp_order_k'])
+    if not cfg['two_d']:
+        return mod.PowerSpectrumInterpolator1D(k, pk, **kw)
+    return mod.PowerSpectrumInterpolator2D(k, z, pk, interp_order_z=cfg['interp_order_z'], growth_factor_sq=growth, **kw)
+
+
+def interp_fuzz_queries(cfg):
+    """Wavenumbers (inside the table, in the extrapolation range, outside everything), redshifts (inside and outside), radii."""
+    # (not the ends of the table or of the extrapolation range themselves: the reference goes through 10**log10(k) for its knots, and whether a query
+    # AT an end is inside depends on how that rounds)
+    kq = np.concatenate([np.geomspace(cfg['kmin'] * 1.0001, cfg['kmax'] / 1.0001, 23), [cfg['kmin'] * 0.7, cfg['kmax'] * 1.3, cfg['extrap_kmin'] * 0.5,
+                         cfg['extrap_kmax'] * 2., 1e-9, 1e4]])
+    zq = np.array([0., 0.3 * cfg.get('zmax', 1.), 0.77 * cfg.get('zmax', 1.), cfg.get('zmax', 1.), 1.2 * cfg.get('zmax', 1.), -0.1])
+    return kq, zq, np.array([2., 8., 30.])
+
+
+def interp_fuzz_outputs(mod, cfg):
+    """What is recorded of a configuration: a dict of arrays (an exception becomes its class name as a string array)."""
+    import warnings
+    out = {}
+    with warnings.catch_warnings(), np.errstate(all='ignore'):
+        warnings.simplefilter('ignore')
+        interp = interp_fuzz_build(mod, cfg)
+        kq, zq, rq = interp_fuzz_queries(cfg)
+
+        def record(name, fn):
+            try:
+                out[name] = np.asarray(fn(), dtype='f8')
+            except Exception as exc:
+                out[name] = np.array(type(exc).__name__)
+
+        if not cfg['two_d']:
+            record('pk', lambda: interp(kq))
+            record('sigma_r', lambda: interp.sigma_r(rq))
+            record('sigma8', lambda: interp.sigma8())
+            record('sigma_d', lambda: interp.sigma_d())
+            record('xi', lambda: interp.to_xi()(np.geomspace(1., 150., 12)))
+        else:
+            record('pk', lambda: interp(kq, zq))
+            record('pk_pairs', lambda: interp(kq[:6], zq, grid=False))
+            record('pk_nogrowth', lambda: interp(kq, zq, ignore_growth=True))
+            zin = zq[:4] if cfg['nz'] > 1 else zq[:1]
+            record('sigma_rz', lambda: interp.sigma_rz(rq, zin))
+            record('sigma8_z', lambda: interp.sigma8_z(zin))
+            record('sigma_dz', lambda: interp.sigma_dz(zin))
+            record('to_1d', lambda: interp.to_1d(z=zin[1 % zin.size])(kq))
+            record('xi', lambda: interp.to_xi()(np.geomspace(1., 150., 12), zin))
+    return out
+
+
+def gen_interp_fuzz(cp):
+    out = {}
+    for i, cfg in enumerate(interp_fuzz_configs()):
+        for name, value in interp_fuzz_outputs(cp, cfg).items():
+            out['c%d_%s' % (i, name)] = value
+    save('interp_fuzz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -1014,6 +1124,8 @@ def main():
         gen_fuzz(cp)
     if 'fftlog_fuzz' in which:
         gen_fftlog_fuzz(cp)
+    if 'interp_fuzz' in which:
+        gen_interp_fuzz(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:

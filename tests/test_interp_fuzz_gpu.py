@@ -1,0 +1,40 @@
+"""GPU parity of the tabulated P(k) / P(k, z) interpolators with options drawn at random -- grid sizes and spacings (geometric, jittered), interpolation
+in k or log k, extrapolation mode and range, spline degrees along k and z, growth factor or table in z -- evaluated inside the table, in the extrapolation
+range and outside (NaN), with the sigma integrals, to_1d and the xi side, against the reference's own outputs (tests/golden/interp_fuzz.npz,
+`python -m oracle.gen_golden interp_fuzz`)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle.gen_golden import interp_fuzz_configs, interp_fuzz_outputs, INTERP_FUZZ_N
+
+pytestmark = pytest.mark.gpu
+RTOL = {'pk': 1e-10, 'pk_pairs': 1e-10, 'pk_nogrowth': 1e-10, 'to_1d': 1e-10, 'sigma_r': 1e-9, 'sigma8': 1e-9, 'sigma_d': 1e-9, 'sigma_rz': 1e-9, 'sigma8_z': 1e-9,
+        'sigma_dz': 1e-9, 'xi': 1e-8}
+
+
+@pytest.mark.parametrize('i', range(INTERP_FUZZ_N))
+def test_random_options(golden, i):
+    import torch
+    assert torch.cuda.is_available()
+    import cosmoprimo_amd as cp
+    warnings.simplefilter('ignore')
+    g = golden('interp_fuzz')
+    cfg = interp_fuzz_configs()[i]
+    got = interp_fuzz_outputs(cp, cfg)
+    names = [key[len('c%d_' % i):] for key in g if key.startswith('c%d_' % i)]
+    assert sorted(got) == sorted(names), cfg
+    for name in names:
+        ref = g['c%d_%s' % (i, name)]
+        if ref.dtype.kind in 'US':      # the reference raised: the same exception class
+            assert got[name].dtype.kind in 'US' and str(got[name]) == str(ref), (cfg, name, got[name], ref)
+            continue
+        assert got[name].dtype.kind == 'f', (cfg, name, str(got[name]))
+        assert got[name].shape == ref.shape, (cfg, name, got[name].shape, ref.shape)
+        assert np.array_equal(np.isnan(got[name]), np.isnan(ref)), (cfg, name)
+        scale = np.nanmax(np.abs(ref)) if np.isfinite(ref).any() else 1.
+        # xi: two rows share a transform (rounding relative to the larger one); splines of P itself (extrap_pk = 'lin') over nine decades of P: rounding
+        # relative to the largest value of the table
+        atol = (1e-13 if name == 'xi' else (1e-14 if cfg['extrap_pk'] == 'lin' else 0.)) * scale
+        np.testing.assert_allclose(got[name], ref, rtol=RTOL[name], atol=atol, equal_nan=True, err_msg='%s of %s' % (name, cfg))
