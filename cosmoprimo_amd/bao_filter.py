@@ -454,10 +454,16 @@ def _wiggle_extrema(residual, start):
     found = []
     for sign in (1., -1.):
         ix = _local_maxima(sign * x)
-        if sign * x[n - 3] < sign * x[n - 2]:
+        if sign * x[n - 3] < sign * x[n - 2] and PLATEAU_EXTREMUM:
             ix = np.append(ix, n - 2)
         found.append(ix + start)
     return found
+
+
+# The sample in front of the plateau as an extremum (see _wiggle_extrema): True, the rule above -- what the reference finds for its default fiducial
+# cosmology and for about half of any others (for the rest its fit's last bit falls the other way and it has no extremum there: pknow differs by ~1e-4 above
+# k = 0.36 h/Mpc); False: never.  tests/test_filter_fuzz_gpu.py checks both readings against the reference's outputs for random fiducial cosmologies.
+PLATEAU_EXTREMUM = True
 
 
 def _envelope_operator(k_fid, peaks):
@@ -774,11 +780,14 @@ class SavGolPowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
     """Savitzky-Golay smoothing of log(k P) along log k (reference bao_filter.py:244-266)."""
     name = 'savgol'
 
-    def _prepare(self):
+    @property
+    def _op(self):
+        """The filter as an operator on the CURRENT wavenumbers (the reference derives the window from them in ``_compute``, bao_filter.py:258-259: a filter
+        re-used after ``set_k`` follows); it depends on (nk, window) only: built and uploaded once, shared by every filter object."""
+        from .interpolator import _cached_operator
         self.nfilter = int(np.ceil(np.log(7) / np.log(self.k[-1] / self.k[-2])) // 2 * 2 + 1)
-        from .interpolator import _cached_operator      # the operator depends on (nk, window) only: built and uploaded once, shared by every filter object
-        self._op = _cached_operator(('savgol', self.k.size, self.nfilter, self.device.index),
-                                    lambda: LinearOperator.dense(_savgol_operator(self.k.size, self.nfilter), device=self.device))
+        nk, nfilter = self.k.size, self.nfilter
+        return _cached_operator(('savgol', nk, nfilter, self.device.index), lambda: LinearOperator.dense(_savgol_operator(nk, nfilter), device=self.device))
 
     def _compute(self):
         torch = dv.torch()
@@ -910,9 +919,9 @@ class PeakAveragePowerSpectrumBAOFilter(_OperatorFilterMixin, BasePowerSpectrumB
         lib = _lib.load()
         ncol, nk = ratio.shape
         logx = np.log10(self.k)
-        solver = self.__dict__.get('_log_solver')
-        if solver is None:
-            solver = self.__dict__['_log_solver'] = SplineRows(logx, logx, bc='natural', device=self.device)
+        key, solver = self.__dict__.get('_log_solver', (None, None))
+        if key != self.k.tobytes():      # (the wavenumbers may have changed since: set_k)
+            key, solver = self.__dict__['_log_solver'] = (self.k.tobytes(), SplineRows(logx, logx, bc='natural', device=self.device))
         ratio = ratio.contiguous()
         second = solver.second_derivatives(ratio)
         if self._batch_size() is None:      # one cosmology, any number of columns: one ratio

@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options),
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -1085,6 +1085,58 @@ def gen_interp_fuzz(cp):
     save('interp_fuzz', **out)
 
 
+# The filters that take options -- hinton2017 (degree, sigma, weight), ehpoly (krange, rescale_krange), kirkby2013 (the two side bands, rescale_sbox),
+# the number of wavenumbers of any P(k) filter -- with the options, the cosmology and the fiducial cosmology drawn at random.
+FILTER_FUZZ_N = 24
+
+
+def filter_fuzz_configs(n=FILTER_FUZZ_N, seed=20261007):
+    rng = np.random.default_rng(seed)
+    configs = []
+    for i in range(n):
+        cosmo = dict(h=float(rng.uniform(0.6, 0.8)), Omega_m=float(rng.uniform(0.25, 0.38)), Omega_b=float(rng.uniform(0.04, 0.06)), n_s=float(rng.uniform(0.92, 1.)))
+        engine = ['hinton2017', 'ehpoly', 'kirkby2013', 'wallish2018', 'savgol', 'peakaverage'][i % 6]
+        cfg = dict(engine=engine, cosmo=cosmo, fid_h=float(rng.uniform(0.65, 0.72)), kwargs={})
+        if engine == 'hinton2017':
+            cfg['kwargs'] = dict(degree=int(rng.choice([9, 12, 13])), sigma=float(rng.uniform(0.3, 1.)), weight=float(rng.uniform(0.5, 0.95)))
+        if engine == 'ehpoly':
+            cfg['kwargs'] = dict(krange=(float(10.**rng.uniform(-3.3, -2.7)), float(rng.uniform(0.6, 1.5))), rescale_krange=bool(i % 4 < 2))
+        if engine == 'kirkby2013':
+            left = float(rng.uniform(45., 55.))
+            cfg['kwargs'] = dict(srange_left=(left, left + float(rng.uniform(25., 35.))), srange_right=(float(rng.uniform(140., 155.)), float(rng.uniform(180., 200.))),
+                                 rescale_sbox=bool(i % 4 < 2))
+        if engine in ('wallish2018', 'savgol', 'peakaverage'):
+            cfg['nk'] = int(rng.choice([512, 1024, 2048]))
+        configs.append(cfg)
+    return configs
+
+
+def filter_fuzz_output(cp, cfg):
+    """(coordinates, smooth spectrum / correlation function) of a configuration with the package ``cp`` (the reference or this one), every 8th sample."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **cfg['cosmo'])
+        fid = cp.Cosmology(engine='eisenstein_hu', h=cfg['fid_h'])
+        pk = cosmo.get_fourier().pk_interpolator().to_1d(z=0.)
+        if cfg['engine'] == 'kirkby2013':
+            xi = pk.clone(extrap_kmin=1e-5).to_xi()      # (the default range of the reference's own xi-side tests)
+            f = cp.CorrelationFunctionBAOFilter(xi, engine='kirkby2013', cosmo=cosmo, cosmo_fid=fid, **cfg['kwargs'])
+            return np.asarray(f.s)[::8], np.asarray(f.xinow)[::8]
+        f = cp.PowerSpectrumBAOFilter(pk, engine=cfg['engine'], cosmo=cosmo, cosmo_fid=fid, **cfg['kwargs'])
+        if 'nk' in cfg:      # another number of wavenumbers, and the filter re-used on them (set_k + __call__: bao_filter.py:61-75, 99-107)
+            f.set_k(nk=cfg['nk'])
+            f(pk)
+        return np.asarray(f.k)[::8], np.asarray(f.pknow)[::8]
+
+
+def gen_filter_fuzz(cp):
+    out = {}
+    for i, cfg in enumerate(filter_fuzz_configs()):
+        out['c%d_x' % i], out['c%d_smooth' % i] = filter_fuzz_output(cp, cfg)
+    save('filter_fuzz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -1126,6 +1178,8 @@ def main():
         gen_fftlog_fuzz(cp)
     if 'interp_fuzz' in which:
         gen_interp_fuzz(cp)
+    if 'filter_fuzz' in which:
+        gen_filter_fuzz(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:
