@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options),
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options), params_fuzz (parameter conventions),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -1137,6 +1137,91 @@ def gen_filter_fuzz(cp):
     save('filter_fuzz', **out)
 
 
+# Parameter conventions drawn at random: the same cosmology can be given as h or H0, Omega_x or omega_x, Omega_m or Omega_cdm, m_ncdm (a list, or a
+# sum with a hierarchy) or Omega_ncdm, N_eff or N_ur, T_cmb or Omega_g, A_s or ln10^{10}A_s or logA or sigma8, w0 / wa ... (reference cosmology.py:
+# compile_params, :1049-1260): what the compiled cosmology holds for a fixed list of names.
+PARAMS_FUZZ_N = 40
+PARAMS_FUZZ_NAMES = ['h', 'H0', 'Omega_b', 'omega_b', 'Omega_cdm', 'omega_cdm', 'Omega_m', 'omega_m', 'Omega_k', 'Omega_g', 'omega_g', 'T_cmb', 'Omega_ur', 'N_ur',
+                     'N_eff', 'Omega_ncdm_tot', 'omega_ncdm_tot', 'Omega_pncdm_tot', 'm_ncdm_tot', 'N_ncdm', 'Omega_de', 'Omega_Lambda', 'Omega_fld', 'w0_fld', 'wa_fld',
+                     'n_s', 'alpha_s', 'k_pivot', 'Omega_r']
+
+
+def params_fuzz_configs(n=PARAMS_FUZZ_N, seed=20261008):
+    rng = np.random.default_rng(seed)
+    configs = []
+    for i in range(n):
+        h = float(rng.uniform(0.55, 0.85))
+        par = {}
+        par.update({'h': h} if i % 2 else {'H0': 100. * h})
+        ob = float(rng.uniform(0.04, 0.06))
+        par.update({'Omega_b': ob} if i % 3 else {'omega_b': ob * h**2})
+        kind = i % 4
+        if kind == 0:
+            par['Omega_cdm'] = float(rng.uniform(0.2, 0.35))
+        elif kind == 1:
+            par['omega_cdm'] = float(rng.uniform(0.2, 0.35)) * h**2
+        elif kind == 2:
+            par['Omega_m'] = float(rng.uniform(0.25, 0.4))
+        else:
+            par['omega_m'] = float(rng.uniform(0.25, 0.4)) * h**2
+        nu = (i // 4) % 5
+        if nu == 1:
+            par['m_ncdm'] = [0.06]
+        elif nu == 2:
+            par['m_ncdm'] = [float(rng.uniform(0.01, 0.1)), float(rng.uniform(0.05, 0.3))]
+        elif nu == 3:
+            par['m_ncdm'] = float(rng.uniform(0.07, 0.4))
+            par['neutrino_hierarchy'] = ['normal', 'inverted', 'degenerate'][i % 3]
+        elif nu == 4:
+            par['m_ncdm'] = [0.06]
+            par['T_ncdm_over_cmb'] = [float(rng.uniform(0.68, 0.73))]
+        if i % 5 == 1:
+            par['N_eff'] = float(rng.uniform(2.8, 4.))
+        elif i % 5 == 2 and nu == 0:
+            par['N_ur'] = float(rng.uniform(2.5, 3.5))
+        if i % 7 == 3:
+            par['T_cmb'] = float(rng.uniform(2.6, 2.8))
+        elif i % 7 == 5:
+            par['Omega_g'] = float(rng.uniform(4.5e-5, 6e-5))
+        if i % 3 == 1:
+            par['Omega_k'] = float(rng.uniform(-0.1, 0.1))
+        if i % 6 in (2, 3):
+            par['w0_fld'] = float(rng.uniform(-1.3, -0.7))
+        if i % 6 == 3:
+            par['wa_fld'] = float(rng.uniform(-0.5, 0.3))
+        amp = i % 4
+        if amp == 0:
+            par['A_s'] = float(rng.uniform(1.8e-9, 2.4e-9))
+        elif amp == 1:
+            par['ln10^{10}A_s'] = float(rng.uniform(2.9, 3.2))
+        elif amp == 2:
+            par['logA'] = float(rng.uniform(2.9, 3.2))
+        else:
+            par['sigma8'] = float(rng.uniform(0.7, 0.9))
+        par['n_s'] = float(rng.uniform(0.92, 1.))
+        if i % 8 == 5:
+            par['alpha_s'] = float(rng.uniform(-0.02, 0.02))
+        configs.append(par)
+    return configs
+
+
+def params_fuzz_output(cp, par):
+    """The compiled parameters PARAMS_FUZZ_NAMES of ``Cosmology(**par)`` and what the Eisenstein-Hu engine makes of its amplitude (A_s, sigma8, rs_drag)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **par)
+        values = [float(np.sum(cosmo[name])) if name == 'm_ncdm_tot' or np.ndim(cosmo[name]) else float(cosmo[name]) for name in PARAMS_FUZZ_NAMES]
+        values += [float(cosmo.get_primordial().A_s), float(cosmo.get_fourier().sigma8_m), float(cosmo.get_thermodynamics().rs_drag)]
+        masses = np.asarray(cosmo['m_ncdm'], dtype='f8').ravel()
+        return np.array(values), np.concatenate([masses, np.full(3 - masses.size, np.nan)])
+
+
+def gen_params_fuzz(cp):
+    values, masses = zip(*[params_fuzz_output(cp, par) for par in params_fuzz_configs()])
+    save('params_fuzz', values=np.stack(values), m_ncdm=np.stack(masses))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -1180,6 +1265,8 @@ def main():
         gen_interp_fuzz(cp)
     if 'filter_fuzz' in which:
         gen_filter_fuzz(cp)
+    if 'params_fuzz' in which:
+        gen_params_fuzz(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:
