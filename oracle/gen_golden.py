@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options), params_fuzz (parameter conventions),
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options), params_fuzz (parameter conventions), xi_fuzz (tabulated xi interpolators with random options),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -1222,6 +1222,85 @@ def gen_params_fuzz(cp):
     save('params_fuzz', values=np.stack(values), m_ncdm=np.stack(masses))
 
 
+# Tabulated xi(s) / xi(s, z) interpolators with options drawn at random (separations geometric or jittered, interpolation in s or log s, spline degrees,
+# growth factor or table in z): values inside and outside, pairs, to_pk and the sigma functions that go through it.
+XI_FUZZ_N = 24
+
+
+def xi_fuzz_configs(n=XI_FUZZ_N, seed=20261009):
+    rng = np.random.default_rng(seed)
+    configs = []
+    for i in range(n):
+        cfg = dict(two_d=bool(i % 2), ns=int(rng.choice([60, 200, 500])), smin=float(10.**int(rng.integers(-3, 0))), smax=float(10.**int(rng.integers(3, 5))),      # (powers of ten: see interp_fuzz_configs)
+                  
+                   jitter=float(rng.choice([0., 0.3])), interp_s='log' if i % 4 != 3 else 'lin', interp_order_s=int(rng.choice([1, 3, 3])),
+                   slope=float(rng.uniform(1.5, 2.1)), bump=float(rng.uniform(0., 0.01)))
+        if cfg['two_d']:
+            cfg['nz'] = int(rng.choice([1, 6, 12]))
+            cfg['zmax'] = float(rng.uniform(1., 3.))
+            cfg['interp_order_z'] = int(rng.choice([1, 3, 3])) if cfg['nz'] > 3 else 3
+            cfg['growth'] = bool(cfg['nz'] == 1 or i % 4 == 1)
+        configs.append(cfg)
+    return configs
+
+
+def xi_fuzz_build(mod, cfg):
+    rng = np.random.default_rng(int(cfg['ns'] * 1000 + cfg['smin'] * 1e7) % (2**31))
+    logs = np.linspace(np.log10(cfg['smin']), np.log10(cfg['smax']), cfg['ns'])
+    if cfg['jitter']:
+        logs[1:-1] += cfg['jitter'] * (logs[1] - logs[0]) * rng.uniform(-1., 1., cfg['ns'] - 2)
+    s = 10.**logs
+    xi = (s / 5.)**(-cfg['slope']) * np.exp(-(s / 300.)**2) + cfg['bump'] * np.exp(-(s - 100.)**2 / 200.) - 2e-4 * np.exp(-(s / 600.)**2)
+    kw = dict(interp_s=cfg['interp_s'], interp_order_s=cfg['interp_order_s'])
+    if not cfg['two_d']:
+        return mod.CorrelationFunctionInterpolator1D(s, xi, **kw), s
+    growth = (lambda zz: 1. / (1. + 0.8 * np.asarray(zz, dtype='f8'))**1.7) if cfg['growth'] else None
+    if cfg['nz'] == 1:
+        return mod.CorrelationFunctionInterpolator2D(s, np.array([0.]), xi[:, None], interp_order_z=3, growth_factor_sq=growth, **kw), s      # (the reference's default None does not construct)
+    z = np.sort(np.concatenate([[0.], rng.uniform(0., cfg['zmax'], cfg['nz'] - 2), [cfg['zmax']]]))
+    table = xi[:, None] * (1. + 0.05 * np.log10(s / 10.)[:, None] * z / (1. + z)) / (1. + z)**(0. if cfg['growth'] else 1.5)
+    return mod.CorrelationFunctionInterpolator2D(s, z, table, interp_order_z=cfg['interp_order_z'], growth_factor_sq=growth, **kw), s
+
+
+def xi_fuzz_outputs(mod, cfg):
+    import warnings
+    out = {}
+    with warnings.catch_warnings(), np.errstate(all='ignore'):
+        warnings.simplefilter('ignore')
+        interp, s = xi_fuzz_build(mod, cfg)
+        sq = np.concatenate([np.geomspace(cfg['smin'] * 1.0001, cfg['smax'] / 1.0001, 19), [cfg['smin'] * 0.5, cfg['smax'] * 2.]])
+        zq = np.array([0., 0.3 * cfg.get('zmax', 1.), 0.77 * cfg.get('zmax', 1.), 1.2 * cfg.get('zmax', 1.), -0.1])
+        kq = np.geomspace(2e-3, 3., 15)
+
+        def record(name, fn):
+            try:
+                out[name] = np.asarray(fn(), dtype='f8')
+            except Exception as exc:
+                out[name] = np.array(type(exc).__name__)
+
+        if not cfg['two_d']:
+            record('xi', lambda: interp(sq))
+            record('pk', lambda: interp.to_pk()(kq))
+            record('sigma8', lambda: interp.sigma8())
+        else:
+            zin = zq[:3] if cfg['nz'] > 1 else zq[:1]
+            record('xi', lambda: interp(sq, zq))
+            record('xi_pairs', lambda: interp(sq[:5], zq, grid=False))
+            record('xi_nogrowth', lambda: interp(sq, zq, ignore_growth=True))
+            record('to_1d', lambda: interp.to_1d(z=zin[1 % zin.size])(sq))
+            record('pk', lambda: interp.to_pk()(kq, zin))
+            record('sigma8_z', lambda: interp.sigma8_z(zin))
+    return out
+
+
+def gen_xi_fuzz(cp):
+    out = {}
+    for i, cfg in enumerate(xi_fuzz_configs()):
+        for name, value in xi_fuzz_outputs(cp, cfg).items():
+            out['c%d_%s' % (i, name)] = value
+    save('xi_fuzz', **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     cp = import_reference()
@@ -1267,6 +1346,8 @@ def main():
         gen_filter_fuzz(cp)
     if 'params_fuzz' in which:
         gen_params_fuzz(cp)
+    if 'xi_fuzz' in which:
+        gen_xi_fuzz(cp)
     if 'calculator' in which:
         gen_calculator(cp)
     if 'cosmology_api' in which:
