@@ -543,6 +543,12 @@ class Interpolator1D(dv.Copyable):
         nan = torch.isnan(self._rows)
         all_nan, some_nan = nan.all(dim=1), nan.any(dim=1)
         self._nan_rows = some_nan | ~torch.isfinite(self._rows).all(dim=1)
+        # ... linear interpolation (scipy's interp1d in the reference, jax.py:176-177) lets a NaN datum spoil the two intervals next to it and nothing else:
+        # only the columns that are NaN throughout are NaN throughout; the others are interpolated with the NaN knots masked per query (__call__)
+        self._local_nan = None
+        if self.k == 1 and bool((some_nan & ~all_nan).any()):
+            self._local_nan = nan
+            self._nan_rows = all_nan
         if self.k == 3 and bool((some_nan & ~all_nan).any()):
             self._nan_rows = torch.ones_like(self._nan_rows)
         self._any_nan_row = bool(self._nan_rows.any())      # read back once, here: every call asks
@@ -619,7 +625,15 @@ class Interpolator1D(dv.Copyable):
         else:
             op = _cached_operator(('i1d', self._x.tobytes(), xq.tobytes(), int(dx), self.extrap, self.device.index),
                                   lambda: LinearOperator.spline(self._x, xq, bc='natural', nu=dx, extrapolate=self.extrap, device=self.device))
-        out = op(self._rows)   # (ncol, nq); NaN outside [xmin, xmax] unless extrap
+        if self.k == 1 and self._local_nan is not None:
+            # interp1d takes the interval with x[lo] < xq <= x[hi] (the first one for xq <= x[0]) and returns y[lo] + slope (xq - x[lo]): NaN when either end is
+            torch = dv.torch()
+            lo = np.clip(np.searchsorted(self._x, xq, side='left'), 1, self._x.size - 1) - 1
+            tlo = dv.upload(lo, self.device)
+            bad = self._local_nan[:, tlo] | self._local_nan[:, tlo + 1]
+            out = torch.where(bad, torch.full((), float('nan'), dtype=torch.float64, device=self.device), op(torch.where(self._local_nan, torch.zeros((), dtype=torch.float64, device=self.device), self._rows)))
+        else:
+            out = op(self._rows)   # (ncol, nq); NaN outside [xmin, xmax] unless extrap
         if self._any_nan_row:
             out = dv.torch().where(self._nan_rows[:, None], dv.torch().full_like(out, float('nan')), out)
         if self.interp_fun == 'log':
