@@ -31,8 +31,9 @@ def test_random_options(golden, i):
         if cfg['interp_order_s'] == 1 and cfg['two_d'] and cfg['nz'] > 1 and name in ('pk', 'sigma8_z') and (np.isnan(ref).any() or np.isnan(got[name]).all()):
             # KNOWN DEVIATION.  to_pk() hands its order on; the transformed P(k) goes negative somewhere, its logarithm is NaN there.  With cubic splines
             # both packages then return NaN everywhere (jax.py:165-172); with linear interpolation scipy lets a NaN datum spoil only the intervals next to
-            # it: so does this package for one column of P(k) (interp1d's rule, Interpolator1D), but for a (k, z) TABLE (RectBivariateSpline(kx=1) in the
-            # reference) it returns NaN for the whole surface.
+            # it: so does this package for one column of P(k) (interp1d's rule, Interpolator1D); for a (k, z) TABLE the reference's
+            # RectBivariateSpline(kx=1) returns NaN at and below the offending knot and numbers above it (the order of FITPACK's elimination), this
+            # package NaN for the whole surface.
             assert np.isnan(got[name]).all(), (cfg, name)
             continue
         assert np.array_equal(np.isnan(got[name]), np.isnan(ref)), (cfg, name)
