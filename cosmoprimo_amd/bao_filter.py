@@ -429,13 +429,28 @@ def _fiducial_wiggles(cosmo_fid, k_fid):
     Returns ``(ratio, correction)``; ``ratio / correction`` oscillates around 1 and equals 1 (to rounding) at the two first and two
     last samples.
     """
-    pk = np.asarray(Fourier(cosmo_fid).pk_interpolator()(k_fid, z=0.), dtype='f8')
-    pknow = np.asarray(Fourier(cosmo_fid, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k_fid, z=0.), dtype='f8')
-    ratio = pk / pknow
-    powers = k_fid[None, :]**np.arange(-1., 3.)[:, None]                      # (4, n)
-    ends = _end_constraints(k_fid.size, order=2)                              # value and first difference at either end, as rows
-    correction = _constrained_lsq_operator(powers, k_fid**2, powers.dot(ends.T), ends).dot(ratio)
-    return ratio, correction
+    # (a sampler builds a filter per step with ONE fiducial cosmology: its wiggles are kept with the cosmology object, per set of wavenumbers)
+    try:
+        kept = _fiducial_wiggles_kept.setdefault(cosmo_fid, {})
+    except TypeError:      # (an object that takes no weak reference: nothing kept)
+        kept = {}
+    key = (k_fid.tobytes(), id(getattr(cosmo_fid, '_engine', None)))      # (another engine set on the same object: computed again)
+    if key not in kept:
+        if len(kept) > 8:
+            kept.clear()
+        pk = np.asarray(Fourier(cosmo_fid).pk_interpolator()(k_fid, z=0.), dtype='f8')
+        pknow = np.asarray(Fourier(cosmo_fid, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(k_fid, z=0.), dtype='f8')
+        ratio = pk / pknow
+        powers = k_fid[None, :]**np.arange(-1., 3.)[:, None]                      # (4, n)
+        ends = _end_constraints(k_fid.size, order=2)                              # value and first difference at either end, as rows
+        correction = _constrained_lsq_operator(powers, k_fid**2, powers.dot(ends.T), ends).dot(ratio)
+        kept[key] = (ratio, correction)
+    ratio, correction = kept[key]
+    return ratio.copy(), correction.copy()
+
+
+import weakref      # noqa: E402
+_fiducial_wiggles_kept = weakref.WeakKeyDictionary()
 
 
 def _wiggle_extrema(residual, start):
