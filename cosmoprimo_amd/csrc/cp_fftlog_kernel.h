@@ -156,6 +156,9 @@ __global__ __launch_bounds__(NP / P, CP_WAVES_PER_SIMD) void fftlog_kernel(const
     // entry path (where the row prefetch is the YOUNGEST operation) and emits vmcnt(0) at the top of every pair, which
     // makes each pair wait for the previous pair's stores to be acknowledged by memory.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+#if defined(CP_START_STAGGER)      // measurements (tools/mb_stagger.sh): the workgroups that share a CU start CP_START_STAGGER x s_sleep(64) apart
+    for (int i = 0, n = (int)((blockIdx.x / CP_STAGGER_DIV) % CP_STAGGER_MOD) * CP_START_STAGGER; i < n; ++i) __builtin_amdgcn_s_sleep(64);
+#endif
 #if defined(CP_STAMPS)
     unsigned long long cp_stamp_acc[2 * F::NPH] = {0};
     for (int i = 0; i < 8; ++i) st.fs[i] = 0;
