@@ -59,6 +59,10 @@ struct Args {
 
 // TIME: the integrand carries 1 / (1 + z) and the result is (T_last - spline(z)) / h / (Gyr per Mpc): DefaultBackground.time / age
 // (cosmology.py:2000-2025), same RK4 == Simpson scan and natural spline as the distances, on the 400-knot grid.
+#ifndef CP_BG_LEAN_ORDINATE      // 0: E^2 term by term in the reference's units (cp_cosmo_common.h: inv_efunc_ln), for measurements
+#define CP_BG_LEAN_ORDINATE 1
+#endif
+
 template <int NK, bool TIME, bool NCDM>   // NCDM = false: no massive species -- their table look-ups (one waterfall loop per ordinate) are not compiled in
 __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     __shared__ TablesN<NK> T;
@@ -82,8 +86,9 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     const double nan = __builtin_nan("");
     // ordinates sit on the fixed grid, where log(1 + z) is tabulated: the dark-energy term of E(z) is then ONE exp() instead of pow() x exp()
     // and 1 / E(z) comes from rsqrt(E^2): no division, no sqrt per ordinate
+    const GridCosmo gc = grid_cosmo(c);
     auto integrand = [&](double zz, double lzp1, double izp1) {
-        const double ie = inv_efunc_ln(c, zz, lzp1, izp1, &mt);
+        const double ie = CP_BG_LEAN_ORDINATE ? inv_efunc_grid(gc, c, zz, lzp1, izp1, &mt) : inv_efunc_ln(c, zz, lzp1, izp1, &mt);
         return TIME ? (kCkms / 100.) * izp1 * ie : (kCkms / 100.) * ie;
     };
     if (!TIME && (A.kind == CP_BG_EFUNC || A.kind == CP_BG_HUBBLE)) {

@@ -142,6 +142,35 @@ __device__ __forceinline__ double inv_efunc_ln(const Cosmo& c, double z, double 
     return e2 >= 2.2250738585072014e-308 && e2 <= 1.7976931348623157e308 ? rsqrt_pos(e2) : rsqrt(e2);
 }
 
+// The same for the quadrature of bg_kernel (two ordinates per interval, ~110 intervals per sample: its whole cost): the cosmology's constants gathered once
+// per sample -- densities in units of the critical density (the factor kRhoCrit of every term and the 1 / kRhoCrit at the end cancel), photons and massless
+// neutrinos as one term, the two coefficients of the dark-energy exponent -- and the reciprocal square root with one select for its special values.  Half the
+// instructions of the E^2 above; the sums associate differently (1e-16 of E^2).
+struct GridCosmo {
+    double Om, Or, Ode, Ok, ea, eb;      // Omega_cdm + Omega_b, Omega_g + Omega_ur, Omega_de, Omega_k; exponent = ea log(1 + z) + eb (1 / (1 + z) - 1)
+    bool lambda;                         // w0 = -1, wa = 0: the dark energy is (1 + z)^-3 in these units, no exponential
+};
+
+__device__ __forceinline__ GridCosmo grid_cosmo(const Cosmo& c) {
+    return GridCosmo{c.Omega_cdm + c.Omega_b, c.Omega_g + c.Omega_ur, c.Omega_de, c.Omega_k, 3. * (c.w0 + c.wa), 3. * c.wa, c.w0 == -1. && c.wa == 0.};
+}
+
+__device__ __forceinline__ double rsqrt_any(double x) {      // 1 / sqrt(x): x = 0 -> Inf, +Inf -> 0, negative / NaN -> NaN, as the library's rsqrt
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.);
+    const double r = fma(y * e, fma(0.375, e, 0.5), y);
+    return __builtin_isfinite(y) && y != 0. ? r : y;
+}
+
+__device__ __forceinline__ double inv_efunc_grid(const GridCosmo& g, const Cosmo& c, double z, double lzp1, double izp1, const cpmath::MathTables* mt) {
+    const double zp1 = 1. + z;
+    double m = g.Om;
+    if (c.nsp) m += ncdm_eval(c, z, 0) * (1. / kRhoCrit);
+    const double de = g.Ode * (g.lambda ? izp1 * izp1 * izp1 : cpmath::exp_tab_core(fma(g.ea, lzp1, g.eb * (izp1 - 1.)), mt));      // (|exponent| < 3 |w0 + wa| log(1e4) + 3 |wa|)
+    const double rc = fma(g.Ok, izp1, fma(g.Or, zp1, m) + de);
+    return rsqrt_any(rc * (zp1 * zp1 * zp1));
+}
+
 __device__ __forceinline__ double efunc(const Cosmo& c, double z) {
     const double zp1 = 1. + z;
     return sqrt(rho_crit(c, zp1) * (zp1 * zp1 * zp1) / kRhoCrit);  // cosmology.py:1754

@@ -195,8 +195,13 @@ __device__ __forceinline__ void fill_math_tables(MathTables* t) {
 // e^x: n = round(64 x / ln 2), ln(2) / 64 in two pieces (|r| <= 0.0055), e^r - 1 by its degree-5 series (remainder 4e-17), 2^((n & 63) / 64)
 // from the table, ldexp -- relative error 2.3e-16 (tests/test_math_gpu.py, against 80-bit arithmetic over |x| < 700), 11 double-precision instructions where
 // exp_mid takes 20.  Arguments below -800 give 0 (as beyond -745 anyway), NaN passes.
+// (exp_tab_core: without the clamp of very negative arguments -- for callers whose arguments stay within +-2e7: beyond, the conversion of n saturates,
+// the result is still 0 / Inf of the right sign through ldexp, but the clamp keeps the reduction exact down to the underflow)
+__device__ __forceinline__ double exp_tab_core(double x, const MathTables* t);
 __device__ __forceinline__ double exp_tab(double x, const MathTables* t) {
-    x = x < -800. ? -800. : x;
+    return exp_tab_core(x < -800. ? -800. : x, t);
+}
+__device__ __forceinline__ double exp_tab_core(double x, const MathTables* t) {
     const double n = rint(x * 92.332482616893657);
     double r = fma(-n, 0.010830424695086549, x);      // (33 significant bits: exact for |n| < 2^20)
     r = fma(-n, 1.162596423439437e-12, r);
