@@ -7,6 +7,23 @@
 
 namespace cpmath {
 
+// One Horner step p r + c as ONE instruction.  hipcc selects v_fmac_f64 (d += a b: the addend is the destination) for fma(p, r, c) and, the constant c
+// being needed again at the next sample, copies it into the destination first: two instructions per step, a fifth of the vector instructions of the
+// polynomial-heavy loops (the EH98 evaluation: 115 copies in 601).  The three-address form takes the constant where it lives: -6 % of that loop's vector
+// instructions, -2 % on wallish2018 and the distance quadrature (tools/ab_asm_fma.sh).
+#ifndef CP_ASM_FMA      // 0: plain fma() (measurements: tools/ab_asm_fma.sh)
+#define CP_ASM_FMA 1
+#endif
+__device__ __forceinline__ double horner(double p, double r, double c) {
+#if CP_ASM_FMA && defined(__HIP_DEVICE_COMPILE__)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "v"(c));
+    return d;
+#else
+    return fma(p, r, c);
+#endif
+}
+
 // 1 / x for finite, normal x: the hardware estimate and two Newton steps (relative error below 2 ulp), a third of the instructions of an
 // IEEE division (v_div_scale x 2, v_div_fmas, v_div_fixup around the same estimate and steps)
 __device__ __forceinline__ double recip(double x) {
@@ -49,10 +66,10 @@ __device__ __forceinline__ double sin_bounded(double x) {
     double r = fma(-n, 1.57079632673412561417e+00, x);
     r = fma(-n, 6.07710050650619224932e-11, r);
     const double z = r * r;
-    const double ps = fma(r * z, fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
-                                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01), r);
-    const double pc = fma(z * z, fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
-                                                  2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02), fma(-0.5, z, 1.));
+    const double ps = fma(r * z, horner(horner(horner(horner(horner(1.58969099521155010221e-10, z, -2.50507602534068634195e-08), z, 2.75573137070700676789e-06), z,
+                                                     -1.98412698298579493134e-04), z, 8.33333333332248946124e-03), z, -1.66666666666666324348e-01), r);
+    const double pc = fma(z * z, horner(horner(horner(horner(horner(-1.13596475577881948265e-11, z, 2.08757232129817482790e-09), z, -2.75573143513906633035e-07), z,
+                                                  2.48015872894767294178e-05), z, -1.38888888888741095749e-03), z, 4.16666666666666019037e-02), fma(-0.5, z, 1.));
     const int q = (int)n;
     const double v = (q & 1) ? pc : ps;
     return (q & 2) ? -v : v;
@@ -206,8 +223,8 @@ __device__ __forceinline__ double exp_tab_core(double x, const MathTables* t) {
     double r = fma(-n, 0.010830424695086549, x);      // (33 significant bits: exact for |n| < 2^20)
     r = fma(-n, 1.162596423439437e-12, r);
     double p = 1. / 120.;
-    p = fma(p, r, 1. / 24.);
-    p = fma(p, r, 1. / 6.);
+    p = horner(p, r, 1. / 24.);
+    p = horner(p, r, 1. / 6.);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.);
     p *= r;
@@ -227,10 +244,10 @@ __device__ __forceinline__ double log_tab(double x, const MathTables* t) {
     const double inv = t->logc[2 * j], lc = t->logc[2 * j + 1];
     const double r = fma(m, inv, -1.);
     double p = 1. / 7.;
-    p = fma(p, r, -1. / 6.);
-    p = fma(p, r, 0.2);
-    p = fma(p, r, -0.25);
-    p = fma(p, r, 1. / 3.);
+    p = horner(p, r, -1. / 6.);
+    p = horner(p, r, 0.2);
+    p = horner(p, r, -0.25);
+    p = horner(p, r, 1. / 3.);
     p = fma(p, r, -0.5);
     p = fma(p, r, 1.);
     return fma((double)e, 6.93147180559945309417e-01, fma(p, r, lc));
