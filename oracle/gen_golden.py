@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options), params_fuzz (parameter conventions), xi_fuzz (tabulated xi interpolators with random options),
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), fftlog_large (the same at padded lengths 16 384 ... 131 072), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options), params_fuzz (parameter conventions), xi_fuzz (tabulated xi interpolators with random options),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -952,6 +952,38 @@ def fftlog_fuzz_build(fl, cfg):
     return obj, x, fun
 
 
+def fftlog_large_configs():
+    """Sizes beyond the LDS-resident kernel (padded length 16 384 ... 131 072: the four-step path, cp_fftlog_large.hip), a few of each class."""
+    configs = fftlog_fuzz_configs(n=12, seed=20261010)
+    sizes = [6000, 10000, 20000, 40000]
+    for i, cfg in enumerate(configs):
+        cfg['n'] = sizes[i % 4]
+        cfg['minfolds'] = 2 if i % 3 else 3
+        cfg['nbatch'] = 3 if i % 4 == 1 else 0
+        if np.ndim(cfg.get('ell', 0)):
+            cfg['ell'] = [0, 2]
+    return configs
+
+
+def gen_fftlog_large(cp):
+    """The same record as fftlog_fuzz (transforms strided to 128 samples, the reference's own movement under one-ulp inputs) for fftlog_large_configs()."""
+    from cosmoprimo import fftlog as fl
+    out = {}
+    for i, cfg in enumerate(fftlog_large_configs()):
+        obj, x, fun = fftlog_fuzz_build(fl, cfg)
+        y, g = obj(fun, extrap=cfg['extrap'], keep_padding=cfg['keep_padding'])
+        y, g = np.asarray(y), np.asarray(g)
+        stride = fftlog_fuzz_stride(y.shape[-1])
+        out['c%d_y' % i], out['c%d_g' % i], out['c%d_size' % i] = y[..., ::stride], g[..., ::stride], np.array(y.shape[-1])
+        pre = obj.padded_prefactor
+        up = np.random.default_rng(2000 + i).integers(2, size=np.shape(pre)).astype(bool)
+        obj.padded_prefactor = np.where(up, np.nextafter(pre, np.inf), np.nextafter(pre, -np.inf))
+        moved = np.asarray(obj(fun, extrap=cfg['extrap'], keep_padding=cfg['keep_padding'])[1])
+        obj.padded_prefactor = pre
+        out['c%d_moves' % i] = np.array(fftlog_fuzz_error(cfg, moved, g, y))
+    save('fftlog_large', **out)
+
+
 def gen_fftlog_fuzz(cp):
     """FFTLOG_FUZZ_N random FFTLog configurations through the reference: output coordinates and transforms, every fftlog_fuzz_stride-th sample
     of them: keys c<i>_y / c<i>_g (complex as it comes), c<i>_size the full length."""
@@ -1340,6 +1372,8 @@ def main():
         gen_fuzz(cp)
     if 'fftlog_fuzz' in which:
         gen_fftlog_fuzz(cp)
+    if 'fftlog_large' in which:
+        gen_fftlog_large(cp)
     if 'interp_fuzz' in which:
         gen_interp_fuzz(cp)
     if 'filter_fuzz' in which:
