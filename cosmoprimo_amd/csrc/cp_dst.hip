@@ -344,16 +344,29 @@ __global__ void dst_log_kernel(const double* k, double* ln_k, int n) {      // l
 
 // log(k P(k)) of cosmology ic at the thread's P samples m = t + T r of the reordered sequence, into the thread's own slots of the data region
 // (double index 2 (t + T r) + row).  NOT unrolled: sixteen copies of a 400-instruction evaluation would not fit the instruction cache.
-template <int N, int P, int ENGINE>
-__device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int t, double* slots, const cpmath::MathTables* mt) {
+// GP: a pointer to the arguments -- const GenArgs* (a by-value kernel parameter: dst_generate_kernel), or GenArgsK: the kernel-argument segment itself, read
+// through the constant address space where a value is used (wallish_full_kernel: its arguments held in scalar registers over the whole loop over pairs were
+// ~800 v_readlane / v_writelane among the 9 300 vector instructions of a pair).  Everything is taken into locals that live as long as this function.
+typedef const GenArgs __attribute__((address_space(4))) * GenArgsK;
+
+template <int N, int P, int ENGINE, typename GP>
+__device__ __forceinline__ void generate_row(GP G, long long ic, int t, double* slots, const cpmath::MathTables* mt) {
     using namespace cppower;
     constexpr int T = N / P;
-    const Cosmo c = load_cosmo(G.bg, ic, G.second_is_omega_m, G.ncdm_tab, nullptr, G.nsp);
+    cpcosmo::Param bg[CP_BG_NPARAMS];
+#pragma unroll
+    for (int i = 0; i < CP_BG_NPARAMS; ++i) { bg[i].ptr = G->bg[i].ptr; bg[i].value = G->bg[i].value; }
+    const Cosmo c = load_cosmo(bg, ic, G->second_is_omega_m, G->ncdm_tab, nullptr, G->nsp);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
-    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = G.pw[i].ptr ? G.pw[i].ptr[ic] : G.pw[i].value;
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) {
+        const double* ptr = G->pw[i].ptr;
+        pw[i] = ptr ? ptr[ic] : G->pw[i].value;
+    }
     EhScalars s{};
-    if (ENGINE != CP_ENGINE_BBKS) s = G.scal[ic];
+    if (ENGINE != CP_ENGINE_BBKS) s = G->scal[ic];
+    const double* gk = G->k;
+    const double* gln = G->ln_k;
     const EhPerCosmology eh = eh_per_cosmology(s, c.h);
     const PkPerCosmology pc = pk_per_cosmology(c, pw, mt);
     const double ln_pk_unit = CP_MATH_TABLES_OFF ? log(pc.pk_unit) : log_tab_any(pc.pk_unit, mt);
@@ -364,10 +377,10 @@ __device__ __forceinline__ void generate_row(const GenArgs& G, long long ic, int
         for (int u = 0; u < CP_DST_GEN_ILP; ++u) {
             const int m = t + T * (r0 + u);
             const int n = m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1;
-            const double kh = G.k[n], ln_kh = G.ln_k[n];
+            const double kh = gk[n], ln_kh = gln[n];
             double Tk;
             if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
-            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, G.ln_k[N + n], G.ln_k[2 * N + n], mt) : transfer_nowiggle(s, c.h, kh, mt);
+            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, gln[N + n], gln[2 * N + n], mt) : transfer_nowiggle(s, c.h, kh, mt);
             slots[2 * m] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(Tk)) : log_tab_any(fabs(Tk), mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
         }
     }
@@ -400,8 +413,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
         if (t == 0) bad_row[0] = bad_row[1] = 0;
         __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
         double* slots = reinterpret_cast<double*>(lds);
-        generate_row<N, P, ENGINE>(G, 2 * p, t, slots, &mt);
-        if (has_b) generate_row<N, P, ENGINE>(G, 2 * p + 1, t, slots + 1, &mt);
+        generate_row<N, P, ENGINE>(&G, 2 * p, t, slots, &mt);
+        if (has_b) generate_row<N, P, ENGINE>(&G, 2 * p + 1, t, slots + 1, &mt);
         cplx x[P];
         bool bad_a = false, bad_b = false;
 #pragma unroll

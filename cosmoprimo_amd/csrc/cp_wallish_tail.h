@@ -404,6 +404,17 @@ struct FullArgs {
     GenArgs gen;        // the forward side: parameters of the cosmologies, tables of the evaluation, twiddles (dst.tw, dst.rot); dst.out / box unused
 };
 
+#ifndef CP_FULL_KERNARG_RELOAD      // 0: the forward side's arguments as an ordinary by-value parameter, live over the whole loop (measurements)
+#define CP_FULL_KERNARG_RELOAD 1
+#endif
+// ... and gen through gen_args(): the same treatment (tail_args above) for the forward side
+__device__ __forceinline__ GenArgsK gen_args() {
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    GenArgsK g = (GenArgsK)(p + __builtin_offsetof(FullArgs, gen));
+    asm volatile("" : "+s"(g));
+    return g;
+}
+
 template <int SU, int ENGINE>
 __global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) {
     constexpr int N = 4096, P = 16, NS = N / 2;
@@ -411,30 +422,37 @@ __global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) 
     constexpr int T = PL::T;
     using namespace cpdd;
     static_assert(!padded_lds(N, P) && lds_data_slots(N, P) == N, "the generated samples go through natural-order slots of the data region");
-    const GenArgs& G = F.gen;
+#if CP_FULL_KERNARG_RELOAD
+#define CP_GEN() gen_args()
+#else
+#define CP_GEN() (&F.gen)
+#endif
     extern __shared__ __attribute__((aligned(4096))) char smem[];
     cplx* lds = reinterpret_cast<cplx*>(smem);
     cplx* ltw = lds + N;
     double* dd_tabs = reinterpret_cast<double*>(ltw + (PL::TW_TOTAL - N));
     const int t = threadIdx.x;
-    for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = G.dst.tw[N + i];
+    {
+        const cplx* tw = CP_GEN()->dst.tw;
+        for (int i = t; i < PL::TW_TOTAL - N; i += T) ltw[i] = tw[N + i];
+    }
     fill_tables(dd_tabs);
     __shared__ int bad_row[2];
     __shared__ cpmath::MathTables mt;      // (the barrier at the top of the first pair covers the fills)
     cpmath::fill_math_tables(&mt);
-    const long long npairs = (G.ncosmo + 1) / 2;
+    const long long npairs = (CP_GEN()->ncosmo + 1) / 2;
     const double fn = sqrt(2. / N), fl = sqrt(1. / N);
     const double nan = __builtin_nan("");
     double* seqs = reinterpret_cast<double*>(lds);
     for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
-        const bool has_b = 2 * p + 1 < G.ncosmo;
+        const bool has_b = 2 * p + 1 < CP_GEN()->ncosmo;
         if (t == 0) bad_row[0] = bad_row[1] = 0;
         __syncthreads();      // the data region is free (and the tables are filled)
         int tt = t;
         asm volatile("" : "+v"(tt));      // (nothing derived from the thread's number is kept in registers from one pair to the next)
         // ---- 0. log(k P_c(k)) of the pair's cosmologies at the 4096 wavenumbers of the linear grid, Makhoul order, into the thread's own slots; forward transform ----
-        generate_row<N, P, ENGINE>(G, 2 * p, tt, seqs, &mt);
-        if (has_b) generate_row<N, P, ENGINE>(G, 2 * p + 1, tt, seqs + 1, &mt);
+        generate_row<N, P, ENGINE>(CP_GEN(), 2 * p, tt, seqs, &mt);
+        if (has_b) generate_row<N, P, ENGINE>(CP_GEN(), 2 * p + 1, tt, seqs + 1, &mt);
         {
             cplx x[P];
             bool bad_a = false, bad_b = false;
@@ -459,7 +477,9 @@ __global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) 
                     if (skip_b) x[r].im = 0.;
                 }
             }
-            dif_all<N, P>(tt, G.dst, x, lds, ltw);
+            Args A{};      // (the pass machinery takes its twiddles from here)
+            A.tw = CP_GEN()->dst.tw;
+            dif_all<N, P>(tt, A, x, lds, ltw);
         }
         asm volatile("" : "+v"(tt));
         // ---- 1. the pair's coefficients (frequency k of the packed transform -> coefficient 4095 - k of either row) into the four sequences, XOR layout ----
@@ -471,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) 
             const int d1 = tt >> 4, vbase = 256 * (tt & 15) + 16 * d1;
             const int e = 256 - tt, e1 = (e >> 4) & 15, ubase = 256 * (e & 15) + 16 * e1;
             const bool first = tt == 0;
-            const cplx* rots = G.dst.rot;
+            const cplx* rots = CP_GEN()->dst.rot;
 #pragma unroll
             for (int s = 0; s < P; ++s) {
                 const cplx v = lds[vbase + (s ^ d1)];
