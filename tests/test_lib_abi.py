@@ -47,6 +47,35 @@ def test_error_mapping():
     assert lib.cp_interp_linear(None, None, 8, None, None, 0, 0, None) == 0 and lib.cp_rows_screen(None, 0, 8, 0, None, None, 0, None) == 0     # nothing to do
 
 
+def test_error_mapping_of_the_table_and_distance_entry_points():
+    """Argument checks of cp_interp_table_* / cp_distance_from_radial / cp_spline_plan_create come before any device call."""
+    import ctypes
+    lib = _lib.load()
+    handle = ctypes.c_void_p()
+    x, f = np.array([0., 2., 1.]), np.zeros(3)
+    with pytest.raises(ValueError):      # x not ascending
+        _lib.check(lib.cp_interp_table_create(ctypes.byref(handle), 3, _lib.as_double_p(x), _lib.as_double_p(f), 0))
+    assert b'ascending' in lib.cp_last_error() and not handle.value
+    with pytest.raises(ValueError):      # no rows
+        _lib.check(lib.cp_interp_table_create(ctypes.byref(handle), 0, _lib.as_double_p(x), _lib.as_double_p(f), 0))
+    with pytest.raises(ValueError):      # null table
+        _lib.check(lib.cp_interp_table_apply(None, None, None, 4, None, None))
+    with pytest.raises(ValueError):
+        _lib.check(lib.cp_interp_table_apply_f32(None, None, None, 4, None, None))
+    with pytest.raises(ValueError):
+        _lib.check(lib.cp_interp_table_law(None, None, None))
+    assert lib.cp_interp_table_destroy(None) == 0
+    with pytest.raises(ValueError):      # comoving_radial_distance (kind 0) is not a derived distance
+        _lib.check(lib.cp_distance_from_radial(None, None, 4, 0., 0, None, 0, None))
+    with pytest.raises(ValueError):      # negative size
+        _lib.check(lib.cp_distance_from_radial(None, None, -1, 0., 3, None, 0, None))
+    assert lib.cp_distance_from_radial(None, None, 0, 0., 3, None, 0, None) == 0      # nothing to do
+    knots, queries = np.linspace(0., 1., 600), np.linspace(0., 1., 1 << 20)
+    with pytest.raises(NotImplementedError):      # 6.3e8 weights: the dense staging of the operator would take 5 GB on the host
+        _lib.check(lib.cp_spline_plan_create(ctypes.byref(handle), knots.size, _lib.as_double_p(knots), queries.size, _lib.as_double_p(queries), _lib.SPLINE_BC['natural'], 0, 0, 0))
+    assert b'2^29' in lib.cp_last_error()
+
+
 def test_loggamma_vs_scipy_golden(golden):
     # G2: scipy.special.loggamma / gamma on the kernels' arguments + stress grid
     g = golden('loggamma')
