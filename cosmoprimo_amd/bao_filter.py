@@ -204,6 +204,9 @@ _ALL_IN_ONE_KERNEL = True
 _TRANSFORM_EVALUATES_SPECTRA = True      # wallish2018 on batches of analytic cosmologies: cp_dst_forward_analytic (False: evaluation kernel, then transform)
 
 
+_DONE = object()      # second slot of Wallish2018PowerSpectrumBAOFilter._log_k_rows: the whole filter has run (cp_wallish_full)
+
+
 class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
 
     """
@@ -250,6 +253,8 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         tophat[m] *= np.exp(-20.**2 * (self.k[m] / 1. - 1.)**2)                                # :426-431
         self._ops = dict(klin=klin, dst=DST(self._nlin, kx=klin, device=self.device), dd=None, splice=splice,
                          tophat=dv.to_device(tophat, self.device))
+        if len(self._ops_cache) >= 8:      # (a sampler that varies the k range or nk: the plans of the grids it has left go with their last filter)
+            self._ops_cache.clear()
         self._ops_cache[key] = self._ops
         return self._ops
 
@@ -351,7 +356,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         if dst is not None and _TRANSFORM_EVALUATES_SPECTRA:      # a batch of cosmologies: the transform kernel evaluates the spectra itself
             ncol = self._pk_rows.shape[0]
             if _ALL_IN_ONE_KERNEL and _TAIL_IN_ONE_KERNEL and 2 * ncol > self._keep_second_derivatives and self._full(engine, bg, pk, dst):
-                return None, 'done' 
+                return None, _DONE
             if _TRANSFORM_FINDS_BOXES and 2 * ncol > self._keep_second_derivatives and dst.n == 4096:
                 # ... and runs the next step on the coefficients it holds (second derivatives, boxes, boxes rewritten): nothing is kept of
                 # the second derivatives, as for every large batch
@@ -371,7 +376,7 @@ class Wallish2018PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         # dst(log(k P)), type 2, ortho, written as [even-indexed | odd-indexed] coefficients: seen as (2 ncol, 2048) the two sequences of
         # every vector are consecutive rows, and share the operators (x_even = x_odd = 1 + arange(2048), bao_filter.py:374-375)
         logkp, ffted = self._log_k_rows(ops['klin'], dst=ops['dst'])
-        if isinstance(ffted, str):      # the whole filter ran in one kernel (cp_wallish_full)
+        if ffted is _DONE:      # the whole filter ran in one kernel (cp_wallish_full)
             return
         solved = None
         if isinstance(ffted, tuple):                                      # ... which has also found and rewritten the boxes
@@ -434,8 +439,13 @@ def _fiducial_wiggles(cosmo_fid, k_fid):
         kept = _fiducial_wiggles_kept.setdefault(cosmo_fid, {})
     except TypeError:      # (an object that takes no weak reference: nothing kept)
         kept = {}
-    key = (k_fid.tobytes(), id(getattr(cosmo_fid, '_engine', None)))      # (another engine set on the same object: computed again)
-    if key not in kept:
+    # (another engine set on the same object: computed again -- the entry holds a weak reference to the engine it was computed with and is valid
+    # for that very object only: an id() alone is reused once the engine is freed)
+    import weakref
+    engine = getattr(cosmo_fid, '_engine', None)
+    key = k_fid.tobytes()
+    entry = kept.get(key)
+    if entry is None or entry[0] is None or entry[0]() is not engine:
         if len(kept) > 8:
             kept.clear()
         pk = np.asarray(Fourier(cosmo_fid).pk_interpolator()(k_fid, z=0.), dtype='f8')
@@ -444,8 +454,11 @@ def _fiducial_wiggles(cosmo_fid, k_fid):
         powers = k_fid[None, :]**np.arange(-1., 3.)[:, None]                      # (4, n)
         ends = _end_constraints(k_fid.size, order=2)                              # value and first difference at either end, as rows
         correction = _constrained_lsq_operator(powers, k_fid**2, powers.dot(ends.T), ends).dot(ratio)
-        kept[key] = (ratio, correction)
-    ratio, correction = kept[key]
+        try:
+            kept[key] = (weakref.ref(engine), ratio, correction)
+        except TypeError:
+            kept[key] = (None, ratio, correction)      # (never valid again: computed at every call)
+    _, ratio, correction = kept[key]
     return ratio.copy(), correction.copy()
 
 

@@ -1,7 +1,8 @@
 """BBKS engine on MI355X (reference cosmoprimo/bbks.py; the polynomial is reproduced as coded there)."""
 import warnings
 
-from .eisenstein_hu import EisensteinHuEngine, Background, Primordial, Transfer, Fourier  # noqa: F401
+from .eisenstein_hu import EisensteinHuEngine, Background, Primordial, Fourier  # noqa: F401
+from .eisenstein_hu import Transfer as _Transfer
 
 
 class BBKSEngine(EisensteinHuEngine):
@@ -18,3 +19,8 @@ class BBKSEngine(EisensteinHuEngine):
                 warnings.warn('{} cannot cope with non-zero curvature'.format(self.__class__.__name__))
             if self._has_fld:
                 warnings.warn('{} cannot cope with non-constant dark energy'.format(self.__class__.__name__))
+
+
+class Transfer(_Transfer):
+    """BBKS matter transfer function, the polynomial as the reference codes it (bbks.py:41-64: ``3.89 q (16.2 q)^2``): the engine's
+    ``_transfer = 'bbks'`` selects ``CP_ENGINE_BBKS`` of ``cp_power_eval``."""

@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-from . import _lib, background as bgmod, power as pwmod
+from . import _lib, background as bgmod, power as pwmod, utils
 from . import _device as dv
 from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, _host, _finish
 
@@ -69,41 +69,52 @@ def _all_conflicts():
 _conflict_parameters = _all_conflicts()
 
 
-def find_conflicts(name, conflicts=None):
-    """The group of input names ``name`` excludes (itself included), () if none (reference cosmology.py:1606-1624)."""
-    for group in (_conflict_parameters if conflicts is None else conflicts):
+def find_conflicts(name, conflicts=tuple()):
+    """The group of ``conflicts`` that holds ``name`` (itself included), () if none -- and none for the default, empty, ``conflicts``, as the
+    reference (cosmology.py:1606-1624): its callers pass ``conflicts=cls._conflict_parameters``."""
+    for group in conflicts:
         if name in group:
             return group
     return ()
 
 
-def check_params(args, conflicts=None):
-    """Raise :class:`CosmologyInputError` if two names of ``args`` exclude each other (reference cosmology.py:1592-1603)."""
+def check_params(args, **kwargs):
+    """Raise :class:`CosmologyInputError` if two names of ``args`` exclude each other; ``kwargs`` (``conflicts=``) go to :func:`find_conflicts`
+    (reference cosmology.py:1592-1603)."""
     for name in args:
-        found = [other for other in find_conflicts(name, conflicts) if other != name and other in args]
+        found = [other for other in find_conflicts(name, **kwargs) if other != name and other in args]
         if found:
             raise CosmologyInputError('Conflicting parameters are given: {}'.format([name] + found))
 
 
-def merge_params(args, moreargs, conflicts=None):
-    """``moreargs`` into ``args`` (in place): a new name first removes everything it excludes (reference cosmology.py:1561-1589)."""
+def merge_params(args, moreargs, **kwargs):
+    """``moreargs`` into ``args`` (in place): a new name first removes everything it excludes; ``kwargs`` (``conflicts=``) go to
+    :func:`find_conflicts` (reference cosmology.py:1561-1589)."""
     for name in moreargs:
-        for other in find_conflicts(name, conflicts):
+        for other in find_conflicts(name, **kwargs):
             args.pop(other, None)
     args.update(moreargs)
     return args
+
+
+def is_sequence(item):
+    """Tuple or list? (reference cosmology.py:53-54)"""
+    return isinstance(item, (tuple, list))
 
 
 def _is_array(v):
     return dv.is_torch(v) or np.ndim(v) > 0
 
 
-class _class_or_instancemethod(classmethod):
+class class_or_instancemethod(classmethod):
 
-    """A method bound to the instance when called on one, to the class otherwise."""
+    """A method bound to the instance when called on one, to the class otherwise (reference cosmology.py:16-19)."""
 
-    def __get__(self, instance, owner):
-        return (super().__get__ if instance is None else self.__func__.__get__)(instance, owner)
+    def __get__(self, instance, type_):
+        return (super().__get__ if instance is None else self.__func__.__get__)(instance, type_)
+
+
+_class_or_instancemethod = class_or_instancemethod
 
 
 def _deepeq(a, b):
@@ -164,13 +175,33 @@ def _ncdm_momenta_z0(T_eff, m, out='rho'):
     return 7. / 8. * 4 / c**3 * sb * T_eff**4 * np.sum(f * wi, axis=-1) / (7. * np.pi**4 / 120.) / (1e10 * msun) * mpc**3
 
 
-def compute_ncdm_momenta(T_eff, m_ncdm, z, out='rho'):
-    """Density ('rho') or pressure ('p') of one massive species of temperature ``T_eff`` today [K] and mass ``m_ncdm`` [eV] at redshift ``z``, in
-    1e10 Msun / Mpc^3, by the reference's name and arguments (cosmology.py:74-137, 188-200): the integral depends on the temperature at z only,
-    T_eff (1 + z)."""
-    if out not in ('rho', 'p'):
-        raise ValueError("out must be 'rho' or 'p'")
-    return _ncdm_momenta_z0(np.asarray(_host(T_eff), dtype='f8') * (1. + np.asarray(_host(z), dtype='f8')), m_ncdm, out=out)
+def compute_ncdm_momenta(T_eff, m, z, method='laguerre', epsabs=1e-7, epsrel=1e-7, out='rho'):
+    """Density ('rho'), its derivative w.r.t. the mass ('drhodm', per eV) or pressure ('p') of one massive species of temperature ``T_eff`` today [K]
+    and mass ``m`` [eV] at redshift ``z``, in 1e10 Msun / Mpc^3, by the reference's name and arguments (``_compute_ncdm_momenta``,
+    cosmology.py:74-137): the integral depends on the temperature at z only, T_eff (1 + z).  ``method='laguerre'``: 100-point Gauss-Laguerre (what
+    the background tables of this package are built from, on the device: ``cp_ncdm_tables``); ``method='quad'``: ``scipy.integrate.quad`` on
+    (0, 100) with ``epsabs`` / ``epsrel``, redshift by redshift on the host, as the reference."""
+    if out not in ('rho', 'drhodm', 'p'):
+        raise ValueError('Cannot compute ncdm momenta {}; choices are ["rho", "drhodm", "p"]'.format(out))
+    z = np.asarray(_host(z), dtype='f8')
+    T = np.asarray(_host(T_eff), dtype='f8') * (1. + z)
+    if method != 'quad':
+        return _ncdm_momenta_z0(T, m, out=out)
+    from scipy import integrate
+    m = float(np.asarray(_host(m), dtype='f8'))
+    over_T = 1.602176634e-19 / (1.380649e-23 * T.ravel())
+
+    def integrand(q, m_over_T2, m2_over_T2):
+        if out == 'rho':
+            return q**2 * np.sqrt(q**2 + m2_over_T2) / (1. + np.exp(q))
+        if out == 'drhodm':
+            return m_over_T2 * q**2 / np.sqrt(q**2 + m2_over_T2) / (1. + np.exp(q))
+        return 1. / 3. * q**4 / np.sqrt(q**2 + m2_over_T2) / (1. + np.exp(q))
+
+    toret = np.array([integrate.quad(integrand, 0., 100., args=(m * ot**2, (m * ot)**2), epsabs=epsabs, epsrel=epsrel)[0] for ot in over_T])
+    c, sb, _ = bgmod_constants()
+    mpc, msun = 1e6 * 3.085677581491367e16, 1.98847 * 1e30
+    return (7. / 8. * 4 / c**3 * sb * T.ravel()**4 * toret / (7. * np.pi**4 / 120.) / (1e10 * msun) * mpc**3).reshape(z.shape)
 
 
 def get_default_z_interp(name):
@@ -224,14 +255,14 @@ def _split_neutrino_masses(sum_ncdm, hierarchy):
 
 def _compile_params(args):
     """Input parameters -> the canonical set (a reduced restatement of reference Cosmology._compile_params, cosmology.py:874-1217)."""
-    check_params(args)
+    check_params(args, conflicts=_conflict_parameters)
     params = {}
     for name, value in args.items():   # aliases
         for canon, aliases in _alias_parameters.items():
             if name in aliases:
                 name = canon
         params[name] = value
-    out = merge_params(dict(_default_cosmological_parameters, **_default_calculation_parameters), params)   # a given name removes the defaults it excludes
+    out = merge_params(dict(_default_cosmological_parameters, **_default_calculation_parameters), params, conflicts=_conflict_parameters)   # a given name removes the defaults it excludes
     hierarchy = out.pop('neutrino_hierarchy', None)
     if 'omega_ncdm' in out:
         out['Omega_ncdm'] = np.asarray(out.pop('omega_ncdm'), dtype='f8') / np.asarray(_host(out.get('h', out.get('H0', 70.) / 100.)), dtype='f8')**2
@@ -373,7 +404,7 @@ class BaseCosmoParams(dv.Copyable):
         toret = dict(_default_cosmological_parameters if of == 'cosmology' else _default_calculation_parameters)
         if include_conflicts:
             for name in list(toret):
-                for other in find_conflicts(name):
+                for other in find_conflicts(name, conflicts=_conflict_parameters):
                     toret[other] = toret[name]
         return toret
 
@@ -596,7 +627,9 @@ def bgmod_constants():
     return c, sb, rck
 
 
-_Sections = ['Background', 'Thermodynamics', 'Primordial', 'Transfer', 'Fourier']
+# the reference's list (cosmology.py:13); no engine of this package has the Perturbations / Harmonic sections (Boltzmann codes only): their getters
+# exist and raise what the reference's raise for an engine without the section
+_Sections = ['Background', 'Thermodynamics', 'Primordial', 'Perturbations', 'Transfer', 'Harmonic', 'Fourier']
 
 
 class RegisteredEngine(type):
@@ -671,16 +704,22 @@ class BaseEngine(BaseCosmoParams, metaclass=RegisteredEngine):
         self.__dict__['_pk0_normalised'] = ((k.shape, k.tobytes()), rsigma8, spectra)
         return True
 
-    def __getattr__(self, name):
-        if name.startswith('get_'):
-            section = name[4:]
-            if section in self.__dict__.get('_Sections', {}):
-                def getter():
-                    if section not in self._sections:
-                        self._sections[section] = self._Sections[section](self)
-                    return self._sections[section]
-                return getter
-        raise AttributeError('{} has no attribute {}'.format(self.__class__.__name__, name))
+
+def _make_section_getter(section):
+
+    def getter(self):
+        name = section.lower()
+        if name not in self._sections:
+            self._sections[name] = self._Sections[name](self)    # KeyError for a section the engine's module does not define, as the reference
+        return self._sections[name]
+
+    getter.__name__ = 'get_{}'.format(section.lower())
+    getter.__doc__ = """Return :class:`{}` calculations (reference cosmology.py:557-571).""".format(section)
+    return getter
+
+
+for section in _Sections:
+    setattr(BaseEngine, 'get_{}'.format(section.lower()), _make_section_getter(section))
 
 
 def get_engine(engine):
@@ -696,13 +735,18 @@ def get_engine(engine):
 class Cosmology(BaseCosmoParams):
 
     """Cosmology, defined as a set of parameters (and possibly a current engine attached to it) (reference cosmology.py:724-1477)."""
+    _default_cosmological_parameters = _default_cosmological_parameters
+    _default_calculation_parameters = _default_calculation_parameters
+    _conflict_parameters_no_alias = _conflict_parameters_no_alias
+    _alias_parameters = _alias_parameters
+    _conflict_parameters = _conflict_parameters
 
     def __init__(self, engine=None, extra_params=None, device=None, **params):
-        check_params(params)
+        check_params(params, conflicts=_conflict_parameters)
         self._derived = {}
         self._engine = None
         self._device = device
-        self._input_params = merge_params(self.get_default_params(include_conflicts=False), params)
+        self._input_params = merge_params(self.get_default_params(include_conflicts=False), params, conflicts=_conflict_parameters)
         self._params = _compile_params(self._input_params)
         if engine is not None:
             self.set_engine(engine, **(extra_params or {}))
@@ -727,7 +771,7 @@ class Cosmology(BaseCosmoParams):
         :math:`h, \omega_b, \omega_{cdm}`, a new ``h`` keeps the physical densities); ``base='internal'`` (or None): update the compiled
         :math:`h, \Omega_b, \Omega_{cdm}` basis (a new ``h`` keeps the density parameters).
         """
-        check_params(params)
+        check_params(params, conflicts=_conflict_parameters)
         if base == 'input':
             base_params = dict(self._input_params)
         elif base in ('internal', None):
@@ -739,7 +783,7 @@ class Cosmology(BaseCosmoParams):
         if extra_params is None:   # the current engine's, if the engine class is unchanged
             same = engine is not None and self._engine is not None and get_engine(engine).name == self._engine.name
             extra_params = dict(self._engine._extra_params) if same else {}
-        return self.__class__(engine=engine, extra_params=extra_params, device=self._device, **merge_params(base_params, params))
+        return self.__class__(engine=engine, extra_params=extra_params, device=self._device, **merge_params(base_params, params, conflicts=_conflict_parameters))
 
     def solve(self, param, func, target=0., limits=None, init=None, xtol=1e-6, maxiter=25):
         """
@@ -920,10 +964,6 @@ class Cosmology(BaseCosmoParams):
         ``cosmo.comoving_radial_distance`` is ``cosmo.get_background().comoving_radial_distance`` (reference cosmology.py:1459-1473)."""
         if name.startswith('__') or name in ('_engine', '_params', '_input_params', '_derived', '_device'):
             raise AttributeError(name)
-        if name.startswith('get_') and name[4:] in [s.lower() for s in _Sections]:
-            def getter(engine=None, set_engine=True, **extra_params):
-                return _get_section(self, name[4:], engine=engine, set_engine=set_engine, **extra_params)
-            return getter
         if self._engine is None:
             raise AttributeError('Attribute {} not found; try setting an engine ("set_engine")?'.format(name))
         Sections = self._engine._Sections
@@ -939,36 +979,64 @@ class Cosmology(BaseCosmoParams):
 
 
 def _section_dir(Section):
-    """Public names a section class offers: its class members and the per-instance quantities it declares in ``_shortcuts``."""
-    return [item for item in dir(Section) if not item.startswith('_')] + list(getattr(Section, '_shortcuts', ()))
+    """Public names a section class offers (per-instance quantities are properties of the class: ``utils.addproperty``)."""
+    return [item for item in dir(Section) if not item.startswith('_')]
 
 
-def _get_section(cosmo, section, engine=None, set_engine=True, **extra_params):
+def _get_cosmology_engine(cosmology, engine=None, set_engine=True, **extra_params):
+    """The engine of ``cosmology``: its current one (``engine`` None), or a new one, attached if ``set_engine`` (reference cosmology.py:636-668)."""
     if engine is None:
-        if cosmo._engine is None:
-            raise CosmologyError('Please provide an engine')
-        eng = cosmo._engine
-    else:
-        eng = cosmo.set_engine(engine, set_engine=set_engine, **extra_params)
-    return getattr(eng, 'get_' + section)()
+        if cosmology._engine is None:
+            raise CosmologyInputError('Please provide an engine')
+        return cosmology._engine
+    return cosmology.set_engine(engine, set_engine=set_engine, **extra_params)
+
+
+def _get_section(cosmology, section, engine=None, set_engine=True, **extra_params):
+    return getattr(_get_cosmology_engine(cosmology, engine=engine, set_engine=set_engine, **extra_params), 'get_' + section)()
 
 
 def _make_section_getter(section):
-    def getter(cosmo, engine=None, set_engine=True, **extra_params):
-        return _get_section(cosmo, section, engine=engine, set_engine=set_engine, **extra_params)
-    getter.__name__ = section.capitalize()
-    getter.__doc__ = 'Return the {} section of ``cosmo`` for ``engine`` (reference cosmology.py:671-705).'.format(section)
+
+    def getter(cosmology, engine=None, set_engine=True, **extra_params):
+        return _get_section(cosmology, section.lower(), engine=engine, set_engine=set_engine, **extra_params)
+
+    getter.__name__ = section
+    getter.__doc__ = 'Return :class:`{}` calculations of ``cosmology`` for ``engine`` (reference cosmology.py:671-705).'.format(section)
     return getter
 
 
-Background = _make_section_getter('background')
-Thermodynamics = _make_section_getter('thermodynamics')
-Primordial = _make_section_getter('primordial')
-Transfer = _make_section_getter('transfer')
-Fourier = _make_section_getter('fourier')
+for section in _Sections:    # Background(cosmology, engine=None, set_engine=True, **extra_params), ..., Harmonic(...)
+    globals()[section] = _make_section_getter(section)
 
 
-class BaseSection(object):
+def _make_section_getter(section):
+
+    def getter(self, engine=None, set_engine=True, **extra_params):
+        engine = _get_cosmology_engine(self, engine=engine, set_engine=set_engine, **extra_params)
+        toret = getattr(engine, 'get_{}'.format(section), None)
+        if toret is None:
+            raise CosmologyInputError('Engine {} does not provide {}'.format(engine.__class__.__name__, section))
+        return toret()
+
+    getter.__name__ = 'get_{}'.format(section)
+    getter.__doc__ = 'Get {} (reference cosmology.py:1509-1540).'.format(section)
+    return getter
+
+
+for section in _Sections:    # Cosmology.get_background(engine=None, set_engine=True, **extra_params), ...
+    setattr(Cosmology, 'get_{}'.format(section.lower()), _make_section_getter(section.lower()))
+
+
+class MetaSection(type(object)):
+
+    """Metaclass of the sections (reference cosmology.py:1480-1487: there it registers them as pytree nodes; nothing to register here)."""
+
+    def __new__(meta, name, bases, class_dict):
+        return super().__new__(meta, name, bases, class_dict)
+
+
+class BaseSection(object, metaclass=MetaSection):
 
     """Base section (reference cosmology.py:1480-1540)."""
 
@@ -988,13 +1056,14 @@ def _out(t, like, dtype=None):
     return _finish(t, dtype, dv.is_torch(like))
 
 
+# today's quantities, stored per instance as '_name' (the reference's utils.addproperty list, cosmology.py:1627-1630)
+@utils.addproperty('H0', 'h', 'N_ur', 'N_ncdm', 'm_ncdm', 'm_ncdm_tot', 'N_eff', 'T0_cmb', 'T0_ncdm', 'w0_fld', 'wa_fld', 'cs2_fld',
+                   'Omega0_cdm', 'Omega0_b', 'Omega0_k', 'K', 'Omega0_g', 'Omega0_ur', 'Omega0_r',
+                   'Omega0_pncdm', 'Omega0_pncdm_tot', 'Omega0_ncdm', 'Omega0_ncdm_tot',
+                   'Omega0_m', 'Omega0_Lambda', 'Omega0_fld', 'Omega0_de')
 class BaseBackground(BaseSection):
 
     """Background densities, E(z) and distances (reference BaseBackground, cosmology.py:1627-1933), evaluated by ``cp_background_distance``."""
-    # today's quantities, stored per instance as '_name' (the reference's utils.addproperty list, cosmology.py:1627-1630)
-    _shortcuts = ('H0', 'h', 'N_ur', 'N_ncdm', 'm_ncdm', 'm_ncdm_tot', 'N_eff', 'T0_cmb', 'T0_ncdm', 'w0_fld', 'wa_fld', 'cs2_fld', 'Omega0_cdm',
-                  'Omega0_b', 'Omega0_k', 'K', 'Omega0_g', 'Omega0_ur', 'Omega0_r', 'Omega0_pncdm', 'Omega0_pncdm_tot', 'Omega0_ncdm',
-                  'Omega0_ncdm_tot', 'Omega0_m', 'Omega0_Lambda', 'Omega0_fld', 'Omega0_de')
 
     def __init__(self, engine):
         super().__init__(engine)
@@ -1006,12 +1075,6 @@ class BaseBackground(BaseSection):
         self._bg = {name: engine._params[name] for name in _lib.BG_PARAMS}
         self._T0_ncdm = engine['T_ncdm']
         self._ncdm = engine.ncdm_tables()   # massive neutrinos: spline tables of density and pressure, built on the device once (cosmology.py:1961-1998)
-
-    def __getattr__(self, name):
-        # properties H0, h, Omega0_x, ... (reference utils.addproperty, cosmology.py:1627-1630)
-        if not name.startswith('_') and '_' + name in self.__dict__:
-            return self.__dict__['_' + name]
-        raise AttributeError(name)
 
     def _eval(self, kind, z, species=None):
         return bgmod.distance(kind, z, self._bg, device=self.device, ncdm=self._ncdm, species=species)

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void interp_table_kernel(const cpit::Pair* __r
     bool outside = false;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (long long)gridDim.x * blockDim.x)
         out[i] = (real)cpit::interp_sample<LAW>(xf, n, first, a, b, x0, xfirst, xn, (double)x[i], &outside);      // (cp_interp_table.h)
-    if (outside) atomicOr(flag, 1);
+    if (outside && flag) atomicOr(flag, 1);      // flag: null when the caller did not ask (cp_interp_table_apply with outside == NULL)
 }
 
 }  // namespace
@@ -178,6 +178,14 @@ int interp_table_apply(const cp_interp_table* t, const real* d_x, real* d_out, l
     if (prev != t->device && hipSetDevice(t->device) != hipSuccess) return cp::fail(CP_EDEVICE, "%s: cannot select device %d", who, t->device);
     hipStream_t hs = static_cast<hipStream_t>(stream);
     int st = CP_OK;
+    // The plan has ONE flag word.  A call that does not ask (outside == NULL) hands the kernels no flag at all, so it leaves nothing behind for a
+    // later call to trip over; a call that asks clears the word on its own stream in front of its kernels and reads it back behind them: calls
+    // that ask must not run concurrently on two streams of one plan (the header says so), calls that do not ask may.
+    int* flag = outside ? t->d_flag : nullptr;
+    if (flag && hipMemsetAsync(flag, 0, sizeof(int), hs) != hipSuccess) {
+        if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
+        return cp::fail(CP_EDEVICE, "%s: clearing the range flag failed", who);
+    }
     if (t->law == 0) {
         // irregular table: bisection (NaN outside, no flag: raised below)
         st = cp_interp_linear(t->d_x, t->d_f, t->n, reinterpret_cast<const double*>(d_x), reinterpret_cast<double*>(d_out), nx, t->device, stream);
@@ -185,8 +193,8 @@ int interp_table_apply(const cp_interp_table* t, const real* d_x, real* d_out, l
         const long long blocks = (nx + 255) / 256;
         const unsigned grid = (unsigned)(blocks < 256 * 16 ? blocks : 256 * 16);
         const cpit::Pair* xf = reinterpret_cast<const cpit::Pair*>(t->d_xf);
-        if (t->law == 1) hipLaunchKernelGGL((interp_table_kernel<1, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, t->d_flag);
-        else hipLaunchKernelGGL((interp_table_kernel<2, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, t->d_flag);
+        if (t->law == 1) hipLaunchKernelGGL((interp_table_kernel<1, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, flag);
+        else hipLaunchKernelGGL((interp_table_kernel<2, real>), dim3(grid), dim3(256), 0, hs, xf, t->n, t->first, t->a, t->b, d_x, d_out, nx, flag);
         if (hipGetLastError() != hipSuccess) st = cp::fail(CP_EDEVICE, "%s: launch failed", who);
     }
     if (st == CP_OK && outside) {
@@ -198,10 +206,7 @@ int interp_table_apply(const cp_interp_table* t, const real* d_x, real* d_out, l
         int host = 0;
         if (st == CP_OK && (hipMemcpyAsync(&host, t->d_flag, sizeof(int), hipMemcpyDeviceToHost, hs) != hipSuccess || hipStreamSynchronize(hs) != hipSuccess))
             st = cp::fail(CP_EDEVICE, "%s: reading the range flag failed", who);
-        if (st == CP_OK && host) {
-            *outside = 1;
-            if (hipMemsetAsync(t->d_flag, 0, sizeof(int), hs) != hipSuccess) st = cp::fail(CP_EDEVICE, "%s: resetting the range flag failed", who);
-        }
+        if (st == CP_OK && host) *outside = 1;
     }
     if (prev >= 0 && prev != t->device) (void)hipSetDevice(prev);
     return st;
@@ -388,8 +393,9 @@ __global__ __launch_bounds__(256) void spline_rows_at_queries_kernel(const doubl
         const double v = xq[row * nq + q];
         double r = __builtin_nan("");
         if (v == v) {
-            int j = (int)((v - x0) * inv_h);
-            j = j < 0 ? 0 : (j > n - 2 ? n - 2 : j);
+            double guess = (v - x0) * inv_h;      // clamped as a double: the conversion of an infinite or huge value to int is undefined
+            guess = guess > 0. ? guess : 0.;
+            int j = guess < (double)(n - 2) ? (int)guess : n - 2;
             while (j > 0 && v < xk[j]) --j;
             while (j < n - 2 && v >= xk[j + 1]) ++j;
             const double h = xk[j + 1] - xk[j];

@@ -7,9 +7,9 @@ primordial spectrum, P(k, z) and the sigma8 normalisation, all evaluated by the 
 import numpy as np
 
 from . import _device as dv
-from . import power as pwmod
+from . import power as pwmod, utils
 from .cosmology import BaseEngine, BaseSection, DefaultBackground, _out
-from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, integrate_sigma_r2, _host
+from .interpolator import PowerSpectrumInterpolator1D, PowerSpectrumInterpolator2D, sigma_r2_of_rows, _host
 
 
 class EisensteinHuEngine(BaseEngine):
@@ -63,27 +63,27 @@ class Background(DefaultBackground):
         return self._eval('growth_rate', z)
 
 
+@utils.addproperty('rs_drag', 'z_drag')
 class Thermodynamics(BaseSection):
 
     """rs_drag [Mpc/h] and z_drag (reference eisenstein_hu.py:155-162)."""
-    _shortcuts = ('rs_drag', 'z_drag')
 
     def __init__(self, engine):
         super().__init__(engine)
-        self.rs_drag = engine.rs_drag * engine['h'] if not dv.is_torch(engine.rs_drag) else engine.rs_drag * dv.to_device(engine['h'], engine.device)
-        self.z_drag = engine.z_drag
+        self._rs_drag = engine.rs_drag * engine['h'] if not dv.is_torch(engine.rs_drag) else engine.rs_drag * dv.to_device(engine['h'], engine.device)
+        self._z_drag = engine.z_drag
 
 
+@utils.addproperty('k_pivot', 'n_s', 'alpha_s', 'beta_s')
 class Primordial(BaseSection):
 
     """Primordial power spectrum (reference eisenstein_hu.py:165-230)."""
-    _shortcuts = ('k_pivot', 'n_s', 'alpha_s', 'beta_s')
 
     def __init__(self, engine):
         super().__init__(engine)
         self._rsigma8 = engine._rescale_sigma8()
-        self.n_s, self.alpha_s, self.beta_s = engine['n_s'], engine['alpha_s'], engine['beta_s']
-        self.k_pivot = engine['k_pivot'] / self._h
+        self._n_s, self._alpha_s, self._beta_s = engine['n_s'], engine['alpha_s'], engine['beta_s']
+        self._k_pivot = engine['k_pivot'] / self._h
 
     @property
     def A_s(self):
@@ -228,4 +228,4 @@ class Fourier(BaseSection):
                 out, spectra, k = res
                 e.__dict__['_pk0_fiducial'] = ((k.shape, k.tobytes()), spectra)
                 return out[:, 0, 0]
-        return integrate_sigma_r2(8., rows, kmin=1e-7, kmax=1e2, device=self.device)[..., 0]**0.5
+        return sigma_r2_of_rows(8., rows, kmin=1e-7, kmax=1e2, device=self.device)[..., 0]**0.5

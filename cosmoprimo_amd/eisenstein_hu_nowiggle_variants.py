@@ -12,7 +12,7 @@ from . import power as pwmod
 from .cosmology import BaseEngine, BaseSection, CosmologyError, _out
 from .eisenstein_hu import Background, Thermodynamics, Primordial  # noqa: F401  (sections discovered by name)
 from .eisenstein_hu import Fourier as EHFourier
-from .interpolator import PowerSpectrumInterpolator2D, _host, integrate_sigma_r2
+from .interpolator import PowerSpectrumInterpolator2D, _host, sigma_r2_of_rows
 
 
 class EisensteinHuNoWiggleVariantsEngine(BaseEngine):
@@ -116,4 +116,4 @@ class Fourier(EHFourier):
         """sigma8 of the current normalisation as a device tensor: P(k, z=0) -> TophatVariance FFTLog -> natural spline at r = 8."""
         def rows(kh):
             return self._pk_device(kh, np.zeros(1), ('delta_m', 'delta_m'))[..., 0]
-        return integrate_sigma_r2(8., rows, kmin=1e-7, kmax=1e2, device=self.device)[..., 0]**0.5
+        return sigma_r2_of_rows(8., rows, kmin=1e-7, kmax=1e2, device=self.device)[..., 0]**0.5

@@ -208,14 +208,14 @@ class FFTlog(dv.Copyable):
     # (tilt offset, prefactor power p, prefactor constant c, phase of order ell or None)
     _convention = (0., 0., 1., None)
 
-    def __init__(self, x, kernel, q=0, minfolds=2, lowring=True, xy=1, check_level=0, engine='mi355x', device=None, **engine_kwargs):
+    def __init__(self, x, kernel, q=0, minfolds=2, lowring=True, xy=1, check_level=0, engine='numpy', device=None, **engine_kwargs):
         r"""
         Parameters are those of the reference (fftlog.py:49-92): ``x`` log-spaced input coordinates (1D or one row per
         kernel), ``kernel`` callable(s) returning the Mellin transform, ``q`` tilt(s), ``minfolds``, ``lowring``, ``xy``,
         ``check_level``.
 
-        engine : string, default='mi355x'
-            The fused HIP kernel.  The reference's names ``'numpy'`` and ``'fftw'`` are accepted and run the same kernel
+        engine : string, default='numpy'
+            The reference's default by name; every named engine (``'numpy'``, ``'fftw'``, ``'mi355x'`` / ``'hip'``) runs the fused HIP kernel
             (this package has no CPU path); ``engine_kwargs`` of the FFTW engine (``nthreads``, ``wisdom``, ``plan``) are ignored.
             An object with the reference's ``forward`` / ``backward`` methods (fftlog.py:508-544) is honoured as well: the
             transform then runs un-fused around that engine (prefactor, engine.forward, x u, engine.backward, postfactor).
@@ -254,7 +254,7 @@ class FFTlog(dv.Copyable):
             cache[key] = dv.upload(array, dev)
         return cache[key]
 
-    def set_fft_engine(self, engine='mi355x', **engine_kwargs):
+    def set_fft_engine(self, engine='numpy', **engine_kwargs):
         """Select the engine (reference fftlog.py:119-132); see :func:`get_fft_engine`."""
         self._engine = get_fft_engine(engine, size=self.padded_size, nparallel=self.nparallel, **engine_kwargs)
 
@@ -482,6 +482,11 @@ class PowerToCorrelation(_MultipoleTransform):
     _convention = (1.5, 3., (2. * np.pi)**-1.5, None)
     _phase_unit = -1j
 
+    def __init__(self, k, ell=0, q=0, complex=False, **kwargs):
+        """``k``: input log-spaced wavenumbers, 1-D (broadcast to every ``ell``) or one row per ``ell``; ``q``: tilt on top of the 1.5 of the
+        convention; ``complex``: keep the phase (-i)^ell instead of its real sign; ``kwargs`` for :class:`FFTlog` (reference fftlog.py:292-330)."""
+        _MultipoleTransform.__init__(self, k, ell=ell, q=q, complex=complex, **kwargs)
+
 
 class CorrelationToPower(_MultipoleTransform):
     r"""
@@ -490,6 +495,11 @@ class CorrelationToPower(_MultipoleTransform):
     """
     _convention = (1.5, 3., (2. * np.pi)**1.5, None)
     _phase_unit = 1j
+
+    def __init__(self, s, ell=0, q=0, complex=False, **kwargs):
+        """``s``: input log-spaced separations, 1-D (broadcast to every ``ell``) or one row per ``ell``; ``q``: tilt on top of the 1.5 of the
+        convention; ``complex``: keep the phase i^ell instead of its real sign; ``kwargs`` for :class:`FFTlog` (reference fftlog.py:342-377)."""
+        _MultipoleTransform.__init__(self, s, ell=ell, q=q, complex=complex, **kwargs)
 
 
 class _WindowVariance(FFTlog):

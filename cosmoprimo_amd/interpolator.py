@@ -100,6 +100,16 @@ def _finish(t, dtype, like_torch, shape=None):
     return dv.to_host(t).astype(dtype, copy=False)
 
 
+def _call_options(kwargs, from_callable, names=('bounds_error',)):
+    """The ``**kwargs`` of the interpolators' ``__call__`` (reference interpolator.py:495, 741, 1142, 1337: they go to the inner evaluation):
+    the named options (False by default) and what is left, which a callable-built interpolator hands to its callable, as the reference does;
+    for a tabulated one the reference hands it to scipy's spline, which refuses unknown names -- so does this."""
+    options = [bool(kwargs.pop(name, False)) for name in names]
+    if kwargs and not from_callable:
+        raise TypeError('__call__() got an unexpected keyword argument {!r}'.format(sorted(kwargs)[0]))
+    return options + [kwargs]
+
+
 def _simpson_weights(x):
     """Weights w with simpson(y, x) == w @ y for the reference's rule (jax.py:365-507: scipy v1.0.0 simpson, even='avg'). Host numpy."""
     n = x.size
@@ -136,7 +146,19 @@ def kernel_tophat2(x):
     return np.where(x < 0.1, low, high)**2
 
 
-_tophat_cache = {}
+_tophat_cache = {}      # (kmin, kmax, nk, device) -> TophatVariance plan; bounded: _tophat_plan
+
+
+def _tophat_plan(key, k, device):
+    """The TophatVariance plan (tables on the device) of a k grid, kept for the next sigma integral on the same grid.  A sampler that varies the range
+    or the size of the grid would otherwise leave one plan per value behind (host tables + device memory): at most 16 are kept."""
+    fft = _tophat_cache.get(key)
+    if fft is None:
+        if len(_tophat_cache) >= 16:
+            _tophat_cache.clear()
+        fft = _tophat_cache[key] = TophatVariance(k, device=device)
+    return fft
+
 _op_cache = {}
 
 
@@ -261,8 +283,8 @@ def _with_growth(sigma2, growth_sq):
     return (sigma2[..., :, None] * growth_sq[..., None, :]).sqrt()
 
 
-def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None, epsabs=1e-5, epsrel=1e-5, sqrt=False,
-                       radii_before_last_axis=False):
+def sigma_r2_of_rows(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, device=None, growth_sq=None, epsabs=1e-5, epsrel=1e-5, sqrt=False,
+                      radii_before_last_axis=False, kernel=None):
     r"""
     :math:`\sigma_r^2 = \frac{1}{2\pi^2}\int dk\,k^2 P(k) W^2(kr)` (reference interpolator.py:200-292) for rows of P(k).
 
@@ -275,10 +297,14 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
     sqrt : return :math:`\sigma_r` instead (the root taken by the kernel that interpolates to ``r``, method 'fftlog').
     radii_before_last_axis : rows (..., nz, nk): return (..., nr, nz) instead of (..., nz, nr) (method 'fftlog', large batches: the transposition
         is part of the spline kernel's store; other cases: a transposed view).
+    kernel : host callable x -> W^2(x) of the quadrature methods (default :func:`kernel_tophat2`); 'fftlog' is the top-hat variance whatever it is,
+        as in the reference (interpolator.py:285-288).
     """
     device = dv.resolve_device(device)
+    window, window_key = (kernel_tophat2, None) if kernel is None or kernel is kernel_tophat2 else (kernel, id(kernel))
     if radii_before_last_axis and (method != 'fftlog' or growth_sq is not None):
-        out = integrate_sigma_r2(r, pk_rows, kmin=kmin, kmax=kmax, method=method, nk=nk, device=device, growth_sq=growth_sq, epsabs=epsabs, epsrel=epsrel, sqrt=sqrt)
+        out = sigma_r2_of_rows(r, pk_rows, kmin=kmin, kmax=kmax, method=method, nk=nk, device=device, growth_sq=growth_sq, epsabs=epsabs, epsrel=epsrel, sqrt=sqrt,
+                                kernel=kernel)
         return out.transpose(-1, -2) if growth_sq is None and out.ndim >= 2 else out
     rr = _host(r).ravel()
     nk_leggauss = 100 if nk is None else nk
@@ -292,9 +318,7 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
     if method == 'fftlog':
         k = np.geomspace(kmin, kmax, nk)
         key = (float(kmin), float(kmax), int(nk), device.index)
-        if key not in _tophat_cache:
-            _tophat_cache[key] = TophatVariance(k, device=device)
-        fft = _tophat_cache[key]
+        fft = _tophat_plan(key, k, device)
         rows = pk_rows(k)
         s = fft.y[0]
         op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
@@ -323,8 +347,8 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
             return op(var, sqrt=sqrt).transpose(-1, -2)
         return op(var, sqrt=sqrt)
     if sqrt:
-        return integrate_sigma_r2(r, pk_rows, kmin=kmin, kmax=kmax, method=method, nk=nk if method != 'leggauss' else nk_leggauss, device=device,
-                                  growth_sq=growth_sq, epsabs=epsabs, epsrel=epsrel).sqrt()
+        return sigma_r2_of_rows(r, pk_rows, kmin=kmin, kmax=kmax, method=method, nk=nk if method != 'leggauss' else nk_leggauss, device=device,
+                                  growth_sq=growth_sq, epsabs=epsabs, epsrel=epsrel, kernel=kernel).sqrt()
     if method == 'simpson':
         limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
         logk = np.linspace(*limits, nk)
@@ -332,9 +356,9 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
 
         def build():
             w = _simpson_weights(logk)
-            return LinearOperator.dense(1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * w)[None, :], device=device)
+            return LinearOperator.dense(1. / (2. * np.pi**2) * np.asarray(window(k[None, :] * rr[:, None])) * (k**3 * w)[None, :], device=device)
 
-        op = _cached_operator(('simpson_r', float(kmin), float(kmax), int(nk), rr.tobytes(), device.index), build)
+        op = build() if window_key else _cached_operator(('simpson_r', float(kmin), float(kmax), int(nk), rr.tobytes(), device.index), build)
         return _with_growth(op(pk_rows(k)), growth_sq)
     if method == 'leggauss':   # "not accurate" in the reference's own words (interpolator.py:274-280); nk = 100 nodes by default
         nl = nk_leggauss
@@ -343,15 +367,15 @@ def integrate_sigma_r2(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None
         logk = (limits[1] - limits[0]) / 2. * (1. + x) + limits[0]
         k = np.exp(logk)
         w = (limits[1] - limits[0]) / 2. * wx
-        op = _cached_operator(('leggauss_r', float(kmin), float(kmax), int(nl), rr.tobytes(), device.index),
-                              lambda: LinearOperator.dense(1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * w)[None, :], device=device))
+        build = lambda: LinearOperator.dense(1. / (2. * np.pi**2) * np.asarray(window(k[None, :] * rr[:, None])) * (k**3 * w)[None, :], device=device)  # noqa: E731
+        op = build() if window_key else _cached_operator(('leggauss_r', float(kmin), float(kmax), int(nl), rr.tobytes(), device.index), build)
         return _with_growth(op(pk_rows(k)), growth_sq)
     if method == 'quad':
         limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
 
         def rule(logk):
             k = np.exp(logk)
-            return 1. / (2. * np.pi**2) * kernel_tophat2(k[None, :] * rr[:, None]) * (k**3 * _simpson_weights(logk))[None, :]
+            return 1. / (2. * np.pi**2) * np.asarray(window(k[None, :] * rr[:, None])) * (k**3 * _simpson_weights(logk))[None, :]
 
         return _with_growth(_refined_rule(rule, limits, pk_rows, epsabs / (2. * np.pi**2), epsrel, device, what='sigma_r2'), growth_sq)
     raise NotImplementedError('integrate_sigma_r2 method {} is not available on the GPU path (use "fftlog", "simpson", "leggauss" or "quad")'.format(method))
@@ -383,7 +407,7 @@ def _refined_rule(rule, limits, pk_rows, epsabs, epsrel, device, what='integral'
         previous, n = current, 2 * n - 1
 
 
-def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, device=None, epsabs=1e-5, epsrel=1e-5):
+def sigma_d2_of_rows(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, device=None, epsabs=1e-5, epsrel=1e-5):
     r""":math:`\sigma_d^2 = \frac{1}{6\pi^2}\int dk\,P(k)` (reference interpolator.py:123-197, default 'simpson'); device tensor (...,)."""
     device = dv.resolve_device(device)
     limits = (np.log(kmin * (1. + 1e-9)), np.log(kmax * (1. - 1e-9)))
@@ -411,6 +435,61 @@ def integrate_sigma_d2(pk_rows, kmin=1e-7, kmax=1e2, method='simpson', nk=None, 
     op = _cached_operator(('simpson_d', float(kmin), float(kmax), int(nk), device.index),
                           lambda: LinearOperator.dense((1. / (6. * np.pi**2) * k * _simpson_weights(logk))[None, :], device=device))
     return op(pk_rows(k))[..., 0]
+
+
+def _rows_of_callable(pk, device):
+    """The reference's callable convention ``pk(k) -> (nk,) + pshape`` as rows for the kernels: k -> device tensor (ncol, nk)."""
+    def rows(k):
+        p = pk(k)
+        p = p if dv.is_torch(p) else np.asarray(p)
+        t = dv.to_device(p, device)
+        return t.reshape(t.shape[0], -1).T.contiguous()
+    return rows
+
+
+def _finish_sigma2(t, lead, p, *likes):
+    """Device tensor (ncol, ...) -> the reference's result ``lead + pshape`` in the float dtype of the inputs (torch if ``pk`` returned torch)."""
+    pshape = tuple(p.shape)
+    t = t.movedim(0, -1).reshape(tuple(lead) + pshape)
+    dtype = dv.float_dtype(*[x for x in likes if x is not None])
+    return _finish(t, dtype, dv.is_torch(p))
+
+
+def integrate_sigma_d2(pk, kmin=1e-7, kmax=1e2, method='simpson', epsabs=1e-5, epsrel=1e-5, nk=None, device=None):
+    r"""
+    Variance of the displacement field :math:`\sigma_{d}^{2} = \frac{1}{6 \pi^{2}} \int dk P(k)`, by the reference's name, arguments and callable
+    convention (interpolator.py:123-197): ``pk`` callable, ``pk(k)`` of shape ``(nk,)`` or ``(nk, ncol)`` for ``k`` of shape ``(nk,)``, a scalar or
+    ``(ncol,)`` for a scalar; methods 'simpson' (default, nk = 1024), 'leggauss' (nk = 100), 'quad' (``epsabs`` / ``epsrel``; :func:`_refined_rule`);
+    'romberg' raises here as it does upstream with numpy inputs.  Returns an array of the shape of ``pk(kmin)``.
+    The integrals run on the device (:func:`sigma_d2_of_rows`, which the interpolators call with device rows directly).
+    """
+    device = dv.resolve_device(device)
+    p = pk(kmin)
+    p = p if dv.is_torch(p) else np.asarray(p)
+    if not int(np.prod(tuple(p.shape), dtype='i8')):
+        return _finish(dv.torch().zeros(tuple(p.shape), dtype=dv.torch().float64, device=device), dv.float_dtype(p), dv.is_torch(p))
+    out = sigma_d2_of_rows(_rows_of_callable(pk, device), kmin=kmin, kmax=kmax, method=method, nk=nk, device=device, epsabs=epsabs, epsrel=epsrel)   # (ncol,)
+    return _finish_sigma2(out, (), p, p)
+
+
+def integrate_sigma_r2(r, pk, kmin=1e-7, kmax=1e2, method='fftlog', epsabs=1e-5, epsrel=1e-5, nk=None, kernel=kernel_tophat2, device=None):
+    r"""
+    Variance of perturbations smoothed by a kernel :math:`W` of radius :math:`r`,
+    :math:`\sigma_{r}^{2} = \frac{1}{2 \pi^{2}} \int dk k^{2} P(k) W^{2}(kr)`, by the reference's name, arguments and callable convention
+    (interpolator.py:200-292): ``pk`` callable as in :func:`integrate_sigma_d2`; methods 'fftlog' (default: :class:`TophatVariance` on nk = 1024
+    wavenumbers + natural spline to ``r``; ``kernel`` is not used, as in the reference), 'simpson' (nk = 1024), 'leggauss' (nk = 100), 'quad';
+    ``kernel`` : host callable :math:`x \mapsto W^2(x)` of the quadrature methods.  Returns an array of shape ``r.shape + pk(kmin).shape``.
+    The transform / the quadrature run on the device (:func:`sigma_r2_of_rows`).
+    """
+    device = dv.resolve_device(device)
+    p = pk(kmin)
+    p = p if dv.is_torch(p) else np.asarray(p)
+    rshape = tuple(np.shape(_host(r)))
+    if not int(np.prod(tuple(p.shape), dtype='i8')):
+        return _finish(dv.torch().zeros(rshape + tuple(p.shape), dtype=dv.torch().float64, device=device), dv.float_dtype(r, p if p.shape else None), dv.is_torch(p))
+    out = sigma_r2_of_rows(r, _rows_of_callable(pk, device), kmin=kmin, kmax=kmax, method=method, nk=nk, device=device, epsabs=epsabs, epsrel=epsrel,
+                           kernel=kernel)      # (ncol, nr)
+    return _finish_sigma2(out.reshape(out.shape[0], *rshape), rshape, p, r, p if p.shape else None)
 
 
 _MAX_OPERATOR_WEIGHTS = 1 << 29      # 4 GB of float64 on the host
@@ -572,8 +651,17 @@ class Interpolator1D(dv.Copyable):
             lo, hi = torch.aminmax(xq)
             if bool((lo < self.xmin) | (hi > self.xmax)):
                 raise ValueError('input outside of extrapolation range ({}, {})'.format(self.xmin, self.xmax))
+        outside = None
         if self.interp_x == 'log':
-            xq = torch.log10(xq)
+            if not self.extrap:
+                # The reference masks in x itself (jax.py:188: xmin <= x <= xmax, xmin = the first knot as handed in -- for the padded P(k) tables
+                # 10**log10(extrap_kmin), which need not be extrap_kmin) before its spline refuses what lies outside log10 of the knots.  The kernel
+                # compares logarithms; the device's log10 of a query AT an end knot may differ in the last bit from numpy's log10 of the knot: the
+                # mask is taken from x, and the logarithm of what it lets through is kept inside the knots
+                outside = ~((xq >= self.xmin) & (xq <= self.xmax))
+                xq = torch.log10(xq).clamp(float(self._x[0]), float(self._x[-1]))
+            else:
+                xq = torch.log10(xq)
         slopes = self.__dict__.get('_knot_slopes', None)
         if slopes is None:
             if self._x.size <= 512:     # a small (knots x knots) operator, shared by every spline on these knots
@@ -590,6 +678,8 @@ class Interpolator1D(dv.Copyable):
                                                 dv.stream_of(self.device)))
         if self._any_nan_row:
             out = torch.where(self._nan_rows[:, None], torch.full_like(out, float('nan')), out)
+        if outside is not None:
+            out = torch.where(outside, torch.full_like(out, float('nan')), out)
         if self.interp_fun == 'log':
             out = 10**out
         out = out.T if out.shape[0] > 1 else out.reshape(-1, 1)
@@ -611,7 +701,7 @@ class Interpolator1D(dv.Copyable):
         xh = _host(x)
         shape = xh.shape + self.shape
         xh = xh.ravel()
-        _mask_bounds([xh], [(self.xmin, self.xmax)], bounds_error=bounds_error)
+        inside, = _mask_bounds([xh], [(self.xmin, self.xmax)], bounds_error=bounds_error)
         if xh.size == 0:
             return _finish(dv.torch().empty((0, self._rows.shape[0]), dtype=dv.torch().float64, device=self.device), dtype, like_torch, shape)
         with np.errstate(all='ignore'):
@@ -636,9 +726,53 @@ class Interpolator1D(dv.Copyable):
             out = op(self._rows)   # (ncol, nq); NaN outside [xmin, xmax] unless extrap
         if self._any_nan_row:
             out = dv.torch().where(self._nan_rows[:, None], dv.torch().full_like(out, float('nan')), out)
+        if not self.extrap and not inside.all():      # the reference's mask in x itself (jax.py:188-192); the operator's own is in the knots' coordinates
+            out = dv.torch().where(dv.upload(inside, self.device), out, dv.torch().full_like(out, float('nan')))
         if self.interp_fun == 'log':
             out = 10**out
         return _finish(out.T, dtype, like_torch, shape)
+
+
+def _fitpack_nan_coefficients(nan, kx, ky):
+    """Which B-spline coefficients FITPACK's ``regrid`` (``RectBivariateSpline(s=0)``, reference jax.py:241) leaves NaN for data holding NaN, as a
+    boolean tensor like ``nan`` (..., nx, ny), by the order of its eliminations: along an axis of degree >= 2 the Givens rotations and the back
+    substitution carry a NaN through the whole axis; along an axis of degree 1 the rotations skip the zero entries and touch nothing, but the back
+    substitution ``c[i] = z[i] - 0 * c[i + 1]`` hands a NaN DOWN to every smaller index.  Both degrees >= 2: the whole surface."""
+    torch = dv.torch()
+
+    def along(mask, dim, degree):
+        if degree == 1:      # suffix "any": index i is NaN if any index >= i is
+            return mask.flip(dim).to(torch.int32).cumsum(dim).flip(dim) > 0
+        return mask.any(dim=dim, keepdim=True).expand_as(mask)
+
+    return along(along(nan, -2, kx), -1, ky)
+
+
+def _fitpack_nan_queries(coef_nan, knots_x, kx, xq, knots_y, ky, yq, grid=True):
+    """Which evaluations of ``bispev`` are NaN given NaN coefficients (:func:`_fitpack_nan_coefficients`): a query is a sum over the coefficients of
+    its knot interval, zero weights included (0 * NaN) -- along an axis of degree 1 those of the two ends of the interval ``t[a] <= q < t[a + 1]`` (the
+    last interval closed), along the others the mask is constant anyway.  ``xq``, ``yq``: host queries in the coordinates of the knots; returns a
+    device tensor (..., nxq, nyq) (``grid``) or (..., nq)."""
+    torch = dv.torch()
+    device = coef_nan.device
+
+    def ends(knots, q):
+        a = np.clip(np.searchsorted(knots, np.clip(q, knots[0], knots[-1]), side='right') - 1, 0, knots.size - 2)
+        return torch.as_tensor(a, dtype=torch.long, device=device)
+
+    if kx == 1:
+        a = ends(knots_x, xq)
+        mx = coef_nan.index_select(-2, a) | coef_nan.index_select(-2, a + 1)      # (..., nxq, ny)
+    else:
+        mx = coef_nan[..., :1, :].expand(coef_nan.shape[:-2] + (np.size(xq), coef_nan.shape[-1]))
+    if ky != 1:
+        m = mx[..., :1]                                                            # constant along y
+        return m.expand(mx.shape[:-1] + (np.size(yq),)) if grid else m[..., 0]
+    b = ends(knots_y, yq)
+    if grid:
+        return mx.index_select(-1, b) | mx.index_select(-1, b + 1)                 # (..., nxq, nyq)
+    index = b.expand(mx.shape[:-1]).unsqueeze(-1)
+    return (mx.gather(-1, index) | mx.gather(-1, index + 1))[..., 0]
 
 
 class Interpolator2D(dv.Copyable):
@@ -667,7 +801,15 @@ class Interpolator2D(dv.Copyable):
             fun = torch.log10(fun)
         self._fun = fun.contiguous()    # (batch..., nx, ny)
         self._lead = tuple(self._fun.shape[:-2])
-        # FITPACK propagates any NaN datum (e.g. the log of a negative P) to the whole surface (reference tests/test_interpolator.py:328-337)
+        # FITPACK propagates any NaN datum (e.g. the log of a negative P) to the whole surface (reference tests/test_interpolator.py:328-337) -- with
+        # cubic (any degree >= 2) splines along both axes.  Linear interpolation along an axis contains it: the coefficients FITPACK leaves NaN are
+        # _fitpack_nan_coefficients, the evaluations that see one _fitpack_nan_queries; the others are the numbers FITPACK returns (its solves along
+        # a linear axis do not mix rows: with the NaN data replaced by anything finite the clean evaluations come out as they do there)
+        self._coef_nan = None
+        if (self.kx == 1 or self.ky == 1) and (self._lead or bool(torch.isnan(self._fun).any())):
+            nan = torch.isnan(self._fun)
+            self._coef_nan = _fitpack_nan_coefficients(nan, self.kx, self.ky)
+            self._fun = torch.where(nan, torch.zeros((), dtype=self._fun.dtype, device=self.device), self._fun)
         nan = torch.isnan(self._fun).flatten(-2).any(dim=-1)           # per surface
         if self._lead:
             # a batch of surfaces: the ones holding a NaN are made NaN throughout, on the device -- every interpolated value of theirs is then NaN
@@ -720,6 +862,9 @@ class Interpolator2D(dv.Copyable):
             out = opy.mid(self._operator('x', xq)(fun_t), post='exp10' if exp10 else None)     # (batch..., ny, nxq) -> (batch..., nyq, nxq)
         if self._nan_surfaces is not None:
             out = dv.torch().where(self._nan_surfaces[..., None, None], dv.torch().full_like(out, float('nan')), out)
+        if self._coef_nan is not None:
+            bad = _fitpack_nan_queries(self._coef_nan, self._x, self.kx, xq, self._y, self.ky, yq).transpose(-1, -2)
+            out = dv.torch().where(bad, dv.torch().full_like(out, float('nan')), out)
         return out
 
     def _rows_y_major_direct(self, fun_t, xq, opy, exp10):
@@ -784,6 +929,9 @@ class Interpolator2D(dv.Copyable):
         _lib.check(_lib.load().cp_spline_points(xk.data_ptr(), rows.data_ptr(), slopes.data_ptr(), self._x.size, rows.shape[0], xq.data_ptr(), out.data_ptr(),
                                                 xq.numel(), 0, 1, self.device.index, dv.stream_of(self.device)))
         out = out.T
+        if self._coef_nan is not None:      # (kx = 3 on this route: the mask does not depend on x)
+            bad = _fitpack_nan_queries(self._coef_nan, self._x, self.kx, np.zeros(1), self._y, self.ky, yh)      # (1, nyq)
+            out = torch.where(bad, torch.full_like(out, float('nan')), out)
         if self.interp_fun == 'log':
             out = 10**out
         if not self.extrap:
@@ -828,6 +976,9 @@ class Interpolator2D(dv.Copyable):
             _lib.check(_lib.load().cp_bilinear_pairs(wx.data_ptr(), wy.data_ptr(), fun.data_ptr(), out.data_ptr(), nb, xq.size, fun.shape[-2], fun.shape[-1],
                                                      self.device.index, dv.stream_of(self.device)))
             mask = mask_x & mask_y
+        if self._coef_nan is not None:
+            bad = _fitpack_nan_queries(self._coef_nan, self._x, self.kx, xq, self._y, self.ky, yh, grid=grid)
+            out = torch.where(bad, torch.full_like(out, float('nan')), out)
         if self.interp_fun == 'log':
             out = 10**out
         if not self.extrap and not mask.all():
@@ -950,24 +1101,26 @@ class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
         self._interp = pk_callable
         return self
 
-    def _eval_device(self, kh, bounds_error=False):
+    def _eval_device(self, kh, bounds_error=False, extra=None):
         """P(k) at host wavenumbers ``kh`` (flat) as a device tensor (nk,) + trailing column shape."""
         torch = dv.torch()
         if self.is_from_callable:
             mask_k, = _mask_bounds([kh], [(self.extrap_kmin, self.extrap_kmax)], bounds_error=bounds_error)
-            out = dv.to_device(self._interp(kh), self.device)
+            out = dv.to_device(self._interp(kh, **(extra or {})), self.device)
             mask = dv.upload(mask_k, self.device).reshape((-1,) + (1,) * (out.ndim - 1))
             out = torch.where(mask, out, torch.full_like(out, float('nan')))
         else:
             out = self._interp(dv.upload(kh, self.device), bounds_error=bounds_error)
         return out * self._rsigma8sq
 
-    def __call__(self, k, bounds_error=False):
-        """Evaluate the power spectrum at wavenumbers ``k``; NaN outside [extrap_kmin, extrap_kmax] (``bounds_error`` raises)."""
+    def __call__(self, k, **kwargs):
+        """Evaluate the power spectrum at wavenumbers ``k``; NaN outside [extrap_kmin, extrap_kmax], ``bounds_error=True`` raises instead
+        (reference interpolator.py:495-520; other ``kwargs`` reach the callable of an interpolator built by :meth:`from_callable`)."""
+        bounds_error, extra = _call_options(kwargs, self.is_from_callable)
         like_torch = dv.is_torch(k)
         dtype = dv.float_dtype(k)
         kh = _host(k)
-        out = self._eval_device(kh.ravel(), bounds_error=bounds_error)
+        out = self._eval_device(kh.ravel(), bounds_error=bounds_error, extra=extra)
         return _finish(out, dtype, like_torch, kh.shape + tuple(out.shape[1:]))
 
     def _rows(self, kh):
@@ -981,7 +1134,7 @@ class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
     def sigma_d(self, **kwargs):
         r"""R.m.s. of the displacement field :math:`\sqrt{\frac{1}{6\pi^2}\int dk P(k)}` (reference interpolator.py:523-545)."""
         cs = self._colshape()
-        out = integrate_sigma_d2(self._rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+        out = sigma_d2_of_rows(self._rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
         return _finish(out, np.dtype('f8'), False, cs)
 
     def sigma_r(self, r, **kwargs):
@@ -990,7 +1143,7 @@ class PowerSpectrumInterpolator1D(_BasePowerSpectrumInterpolator):
         dtype = dv.float_dtype(r)
         rh = _host(r)
         cs = self._colshape()
-        out = integrate_sigma_r2(rh, self._rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5   # (ncol, nr)
+        out = sigma_r2_of_rows(rh, self._rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5   # (ncol, nr)
         return _finish(out.T, dtype, like_torch, rh.shape + cs)
 
     def sigma8(self, **kwargs):
@@ -1034,9 +1187,7 @@ def sigma_rz_analytic(engine, bg, pk, r, growth_sq, device, kmin=1e-7, kmax=1e2,
     k = np.geomspace(kmin, kmax, nk)
     rr = np.asarray(r, dtype='f8').ravel()
     key = (float(kmin), float(kmax), nk, device.index)
-    if key not in _tophat_cache:
-        _tophat_cache[key] = TophatVariance(k, device=device)
-    fft = _tophat_cache[key]
+    fft = _tophat_plan(key, k, device)
     s = fft.y[0]
     op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
     lib = _lib.load()
@@ -1076,9 +1227,7 @@ def sigma8_normalise(engine, bg, pk, sigma8, device, kmin=1e-7, kmax=1e2):
     nb, nk = sizes.pop(), 1024
     k = np.geomspace(kmin, kmax, nk)
     key = (float(kmin), float(kmax), nk, device.index)
-    if key not in _tophat_cache:
-        _tophat_cache[key] = TophatVariance(k, device=device)
-    fft = _tophat_cache[key]
+    fft = _tophat_plan(key, k, device)
     s, rr = fft.y[0], np.array([8.])
     op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
     functional = _cached_operator(('sigma_functional', key, rr.tobytes()),
@@ -1137,6 +1286,12 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
     def _is2d(self):
         """A (k, z) table (or a batch of them), as opposed to one column of P(k) (per cosmology) with a growth factor."""
         return self._pk.shape[-1] > 1
+
+    def _table_k_limits(self):
+        """Range of wavenumbers a tabulated interpolator returns numbers on: [extrap_kmin, extrap_kmax] (reference interpolator.py:802) AND the range of
+        the spline's own knots (jax.py:250: the first and last knot as handed in -- with log-log extrapolation ``10**log10(extrap_kmin)``, which is not
+        always ``extrap_kmin``: a query at such an end is NaN in the reference, and here)."""
+        return max(self.extrap_kmin, self._interp.xmin), min(self.extrap_kmax, self._interp.xmax)
 
     def _prepare_tables(self, k, z, pk, interp_k='log', extrap_pk='log', extrap_kmin=_default_extrap_kmin, extrap_kmax=_default_extrap_kmax):
         """``_prepare`` + ``_pad_log`` (reference interpolator.py:329-351, 42-87) for a batch of tables (batch, nk, nz), on the device: sorted grids,
@@ -1218,27 +1373,28 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         self._interp = pk_callable
         return self
 
-    def _eval_device(self, kh, zh, grid=True, ignore_growth=False, bounds_error=False):
+    def _eval_device(self, kh, zh, grid=True, ignore_growth=False, bounds_error=False, extra=None):
         """P(k, z) at flat host coordinates as a device tensor (batch..., nk, nz) (grid) or (batch..., nk) (pairs)."""
         torch = dv.torch()
+        extra = extra or {}
         if self.is_from_callable:
             mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
             if dv.is_torch(mask_k):      # wavenumbers that live on the device (a mesh): masks there too
                 mask_z = dv.upload(mask_z, mask_k.device)
             mask = mask_k[:, None] & mask_z if grid else mask_k & mask_z
             if self.growth_factor_sq is not None:
-                tmp = dv.to_device(self._interp(kh), self.device)                     # (..., nk)
+                tmp = dv.to_device(self._interp(kh, **extra), self.device)            # (..., nk)
                 if not ignore_growth:
                     growth = dv.to_device(self.growth_factor_sq(zh), self.device)     # (..., nz)
                     tmp = tmp[..., :, None] * growth[..., None, :] if grid else tmp * growth
                 elif grid:
                     tmp = tmp[..., :, None].expand(tmp.shape + (zh.size,))
             else:
-                tmp = dv.to_device(self._interp(kh, zh, grid=grid), self.device)
+                tmp = dv.to_device(self._interp(kh, zh, grid=grid, **extra), self.device)
             out = tmp if bool(mask.all()) else torch.where(dv.upload(mask, self.device), tmp, torch.full_like(tmp, float('nan')))
         else:
             is2d = self._is2d()
-            mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)], bounds_error=bounds_error)
+            mask_k, mask_z = _mask_bounds([kh, zh], [self._table_k_limits(), (self.zmin, self.zmax)], bounds_error=bounds_error)
             if not is2d:
                 mask_z = mask_z | True    # ignore input z
             mask = mask_k[:, None] & mask_z if grid else mask_k & mask_z
@@ -1264,8 +1420,11 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             return out
         return out * self._rsigma8sq
 
-    def __call__(self, k, z, grid=True, ignore_growth=False, bounds_error=False):
-        """Evaluate at wavenumbers ``k`` and redshifts ``z``: shape (batch...) + k.shape + z.shape (``grid``) or + k.shape (pairs)."""
+    def __call__(self, k, z, grid=True, **kwargs):
+        """Evaluate at wavenumbers ``k`` and redshifts ``z``: shape (batch...) + k.shape + z.shape (``grid``) or + k.shape (pairs).
+        ``kwargs``: ``ignore_growth`` (leave the growth factor out), ``bounds_error`` (raise outside the ranges instead of NaN), both False by
+        default (reference interpolator.py:741-817); anything else reaches the callable of an interpolator built by :meth:`from_callable`."""
+        ignore_growth, bounds_error, extra = _call_options(kwargs, self.is_from_callable, ('ignore_growth', 'bounds_error'))
         like_torch = dv.is_torch(k) or dv.is_torch(z)
         dtype = dv.float_dtype(k, z)
         zh = _host(z)
@@ -1273,7 +1432,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             kh = k.to(dv.torch().float64)      # a mesh of wavenumbers on the device goes to the callable as it is (no copy to the host and back)
         else:
             kh = _host(k)
-        out = self._eval_device(kh.reshape(-1), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error)
+        out = self._eval_device(kh.reshape(-1), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error, extra=extra)
         nlead = out.ndim - (2 if grid else 1)
         shape = tuple(out.shape[:nlead]) + (kh.shape + zh.shape if grid else kh.shape)
         return _finish(out, dtype, like_torch, shape)
@@ -1284,7 +1443,7 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             if not self.is_from_callable and self._is2d() and kh.size and zh.size:
                 # (k, z) tables: the surfaces come out of the two spline operators z-major already (z contraction first), no transposed copy
                 torch = dv.torch()
-                mask_k, mask_z = _mask_bounds([kh, zh], [(self.extrap_kmin, self.extrap_kmax), (self.zmin, self.zmax)])
+                mask_k, mask_z = _mask_bounds([kh, zh], [self._table_k_limits(), (self.zmin, self.zmax)])
                 out = self._interp.rows_y_major(kh, zh, exp10=self._interp.interp_fun == 'log')
                 mask = mask_z[:, None] & mask_k
                 if not mask.all():
@@ -1336,11 +1495,11 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
         dtype = dv.float_dtype(z)
         zh = _host(z)
         if self._separable():
-            base, growth = self._sigma_separable(lambda rows: integrate_sigma_d2(rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
+            base, growth = self._sigma_separable(lambda rows: sigma_d2_of_rows(rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
                                                                                  **kwargs)[..., None], zh.ravel())
             out = base * growth                                    # (batch..., 1) x (batch..., nz)
         else:
-            out = integrate_sigma_d2(self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
+            out = sigma_d2_of_rows(self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, **kwargs)**0.5
         return _finish(out, dtype, like_torch, tuple(out.shape[:-1]) + zh.shape)
 
     def sigma_rz(self, r, z, **kwargs):
@@ -1362,14 +1521,14 @@ class PowerSpectrumInterpolator2D(_BasePowerSpectrumInterpolator):
             def rows(kh):
                 return self._eval_device(kh, self.z[:1], grid=True, ignore_growth=True)[..., 0]      # (batch..., nk)
 
-            out = integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, growth_sq=growth_sq, **kwargs)
+            out = sigma_r2_of_rows(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, growth_sq=growth_sq, **kwargs)
         elif self._separable():
-            base, growth = self._sigma_separable(lambda rows: integrate_sigma_r2(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
+            base, growth = self._sigma_separable(lambda rows: sigma_r2_of_rows(rh, rows, kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device,
                                                                                  **kwargs), zh.ravel())
             out = base[..., :, None] * growth[..., None, :]
         else:
             # (batch..., nz, nk) rows -> (batch..., nr, nz): the transposition is part of the store of the kernel that splines to r
-            out = integrate_sigma_r2(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True,
+            out = sigma_r2_of_rows(rh, self._rows_z(zh.ravel()), kmin=self.extrap_kmin, kmax=self.extrap_kmax, device=self.device, sqrt=True,
                                      radii_before_last_axis=True, **kwargs)
         return _finish(out, dtype, like_torch, tuple(out.shape[:-2]) + rh.shape + zh.shape)
 
@@ -1582,24 +1741,26 @@ class CorrelationFunctionInterpolator1D(_BaseCorrelationFunctionInterpolator):
         self._interp = xi_callable
         return self
 
-    def _eval_device(self, sh, bounds_error=False):
+    def _eval_device(self, sh, bounds_error=False, extra=None):
         """xi(s) at host separations ``sh`` (flat) as a device tensor (ns,) + trailing column shape."""
         torch = dv.torch()
         if self.is_from_callable:
             mask_s, = _mask_bounds([sh], [(self.smin, self.smax)], bounds_error=bounds_error)
-            out = dv.to_device(self._interp(sh), self.device)
+            out = dv.to_device(self._interp(sh, **(extra or {})), self.device)
             mask = dv.upload(mask_s, self.device).reshape((-1,) + (1,) * (out.ndim - 1))
             out = torch.where(mask, out, torch.full_like(out, float('nan')))
         else:
             out = self._interp(dv.upload(sh, self.device), bounds_error=bounds_error)
         return out * self._rsigma8sq
 
-    def __call__(self, s, bounds_error=False):
-        """Evaluate the correlation function at separations ``s``; NaN outside [smin, smax] (``bounds_error`` raises)."""
+    def __call__(self, s, **kwargs):
+        """Evaluate the correlation function at separations ``s``; NaN outside [smin, smax], ``bounds_error=True`` raises instead
+        (reference interpolator.py:1142-1165; other ``kwargs`` reach the callable of an interpolator built by :meth:`from_callable`)."""
+        bounds_error, extra = _call_options(kwargs, self.is_from_callable)
         like_torch = dv.is_torch(s)
         dtype = dv.float_dtype(s)
         sh = _host(s)
-        out = self._eval_device(sh.ravel(), bounds_error=bounds_error)
+        out = self._eval_device(sh.ravel(), bounds_error=bounds_error, extra=extra)
         return _finish(out, dtype, like_torch, sh.shape + tuple(out.shape[1:]))
 
     def sigma_d(self, **kwargs):
@@ -1647,8 +1808,9 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         else:
             s, xi = self._prepare(s, xi, z=z, interp_s=interp_s)
         is2d = self._xi.shape[-1] > 1
-        # the reference does int(interp_order_z) on its own default None (TypeError); None means cubic here
-        self.interp_order_s, self.interp_order_z = int(interp_order_s), 3 if interp_order_z is None else int(interp_order_z)
+        # int() of the default None raises TypeError, as in the reference (interpolator.py:1262: its own default does not construct; to_xi() always
+        # passes the order of the P(k, z) interpolator it comes from)
+        self.interp_order_s, self.interp_order_z = int(interp_order_s), int(interp_order_z)
         if is2d:
             self._interp = Interpolator2D(s, self.z, xi, kx=self.interp_order_s, ky=self.interp_order_z, interp_x=self.interp_s, assume_sorted=True,
                                           device=self.device)
@@ -1719,21 +1881,22 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         self._interp = xi_callable
         return self
 
-    def _eval_device(self, sh, zh, grid=True, ignore_growth=False, bounds_error=False):
+    def _eval_device(self, sh, zh, grid=True, ignore_growth=False, bounds_error=False, extra=None):
         """xi(s, z) at flat host coordinates as a device tensor (ns, nz) (grid) or (ns,) (pairs)."""
         torch = dv.torch()
+        extra = extra or {}
         mask_s, mask_z = _mask_bounds([sh, zh], [(self.smin, self.smax), (self.zmin, self.zmax)], bounds_error=bounds_error)
         if self.is_from_callable:
             mask = mask_s[:, None] & mask_z if grid else mask_s & mask_z
             if self.growth_factor_sq is not None:
-                tmp = dv.to_device(self._interp(sh), self.device)
+                tmp = dv.to_device(self._interp(sh, **extra), self.device)
                 if not ignore_growth:
                     growth = dv.to_device(self.growth_factor_sq(zh), self.device)
                     tmp = tmp[..., :, None] * growth[..., None, :] if grid else tmp * growth
                 elif grid:
                     tmp = tmp[..., :, None].expand(tmp.shape + (zh.size,))
             else:
-                tmp = dv.to_device(self._interp(sh, zh, grid=grid), self.device)
+                tmp = dv.to_device(self._interp(sh, zh, grid=grid, **extra), self.device)
         else:
             is2d = self._xi.shape[-1] > 1
             if not is2d and not (getattr(self, '_tables_batched', False) and self.z.size > 1):
@@ -1753,12 +1916,15 @@ class CorrelationFunctionInterpolator2D(_BaseCorrelationFunctionInterpolator):
         out = torch.where(dv.upload(mask, self.device), tmp, torch.full_like(tmp, float('nan')))
         return self._rescaled(out)
 
-    def __call__(self, s, z, grid=True, ignore_growth=False, bounds_error=False):
-        """Evaluate at separations ``s`` and redshifts ``z``: shape (batch...) + s.shape + z.shape (``grid``) or + s.shape (pairs)."""
+    def __call__(self, s, z, grid=True, **kwargs):
+        """Evaluate at separations ``s`` and redshifts ``z``: shape (batch...) + s.shape + z.shape (``grid``) or + s.shape (pairs).
+        ``kwargs``: ``ignore_growth``, ``bounds_error``, both False by default (reference interpolator.py:1337-1406); anything else reaches the
+        callable of an interpolator built by :meth:`from_callable`."""
+        ignore_growth, bounds_error, extra = _call_options(kwargs, self.is_from_callable, ('ignore_growth', 'bounds_error'))
         like_torch = dv.is_torch(s) or dv.is_torch(z)
         dtype = dv.float_dtype(s, z)
         sh, zh = _host(s), _host(z)
-        out = self._eval_device(sh.ravel(), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error)
+        out = self._eval_device(sh.ravel(), zh.ravel(), grid=grid, ignore_growth=ignore_growth, bounds_error=bounds_error, extra=extra)
         lead = tuple(out.shape[:out.ndim - (2 if grid else 1)])
         return _finish(out, dtype, like_torch, lead + (sh.shape + zh.shape if grid else sh.shape))
 

@@ -94,7 +94,7 @@ class Background(BaseSection):
         ba = self.ba
         like_torch = dv.is_torch(z)
         dtype = dv.float_dtype(z)
-        if like_torch and z.is_cuda and z.dtype == torch.float32 and ba._tables[name].law[0]:
+        if like_torch and z.is_cuda and z.device == self.device and z.dtype == torch.float32 and ba._tables[name].law[0]:
             tz = z.contiguous()      # a float32 catalogue on the device: read and written as it is (no widened copies)
         else:
             tz = dv.to_device(z, self.device).contiguous()

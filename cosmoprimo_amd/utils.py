@@ -8,11 +8,36 @@ Utilities with the reference's names (cosmoprimo/utils.py): :class:`LeastSquareS
 """
 import functools
 import inspect
+import logging
+import os
 
 import numpy as np
 
 from ._device import Copyable as _Copyable, float_dtype as _float_dtype, is_torch as _is_torch
 from .interpolator import Interpolator1D
+
+
+logger = logging.getLogger('Utils')
+
+
+def mkdir(dirname):
+    """Try to create ``dirname`` and catch :class:`OSError` (reference utils.py:13-18)."""
+    try:
+        os.makedirs(dirname)
+    except OSError:
+        return
+
+
+def savefig(filename, fig=None, bbox_inches='tight', pad_inches=0.1, dpi=200, **kwargs):
+    """Save figure ``fig`` (default: the current one) to ``filename``, creating its directory; ``kwargs`` go to
+    :meth:`matplotlib.figure.Figure.savefig` (reference utils.py:322-351).  Returns the figure."""
+    from matplotlib import pyplot as plt
+    mkdir(os.path.dirname(filename))
+    logger.info('Saving figure to {}.'.format(filename))
+    if fig is None:
+        fig = plt.gcf()
+    fig.savefig(filename, bbox_inches=bbox_inches, pad_inches=pad_inches, dpi=dpi, **kwargs)
+    return fig
 
 
 class BaseClass(_Copyable):
@@ -36,7 +61,7 @@ def addproperty(*attrs):
     return decorate
 
 
-def flatarray(iargs=(0,), dtype=np.float64):
+def flatarray(iargs=[0], dtype=np.float64):
     """Method decorator of the reference (utils.py:98-138): the array arguments ``iargs`` (positions behind ``self``) reach the method flattened --
     they must share one shape --, and its result (an array or a dict of arrays, last axis = the flat one) is given that shape back, float32 only
     if every such input was float32.  The sections of this package do the same inside their kernels' wrappers; this is for code written

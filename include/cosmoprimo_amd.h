@@ -578,7 +578,9 @@ int cp_interp_linear(const double* d_xp, const double* d_fp, long long n, const 
  * knots (the reference's data/desi.dat: 0, then 40 001 redshifts from 1e-8 to 100), 0 neither: the interval of a sample is then guessed from the sample
  * itself and corrected by a walk (0 or 1 steps) instead of bisected (15 dependent loads per sample); law 0 bisects.  Bit-identical to numpy.interp in all
  * three cases.  outside (host, may be NULL): set to 1 when a sample lies outside [x_0, x_{n-1}] or is NaN (those come out NaN) -- the reference raises
- * there (tabulated.py:33-34); asking for it makes the call wait for the stream, NULL leaves it asynchronous.  cp_interp_table_law reports the law found. */
+ * there (tabulated.py:33-34); asking for it makes the call wait for the stream, NULL leaves it asynchronous (and raises nothing: a later call that asks
+ * reports its own samples only).  The table has one flag word: calls that ask for `outside` must not overlap on two streams of one table; calls that do
+ * not may.  cp_interp_table_law reports the law found. */
 typedef struct cp_interp_table cp_interp_table;
 int cp_interp_table_create(cp_interp_table** table, long long n, const double* x, const double* f, int device);
 int cp_interp_table_law(const cp_interp_table* table, int* law, long long* first);

@@ -2,7 +2,7 @@
 
     python -m oracle.gen_golden [target ...]      # default target: fftlog
 
-Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), fftlog_large (the same at padded lengths 16 384 ... 131 072), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options), params_fuzz (parameter conventions), xi_fuzz (tabulated xi interpolators with random options),
+Targets -> tests/golden/<name>.npz: fftlog (tables, loggamma, transforms), background, power, sigma, sigma_quad, sigma_api (the module-level sigma integrals with the reference's arguments), api_signatures (json: signatures of the public surface), bao, xi, bao2, bspline, densities, ncdm, variants, power_ncdm, bao_batch, fuzz (random cosmologies from wide priors), fftlog_fuzz (random FFTLog configurations), fftlog_large (the same at padded lengths 16 384 ... 131 072), interp_fuzz (tabulated interpolators with random options), filter_fuzz (BAO filters with random options), params_fuzz (parameter conventions), xi_fuzz (tabulated xi interpolators with random options),
 calculator, cosmology_api, api_flows (tests/api_scenarios.py replayed with the reference), abacus (also writes the package data cosmoprimo_amd/data/abacus_cosmologies.json), desi_table (161 rows of the
 reference's data/desi.dat).  Every vector is the output of the reference itself, imported from /root/reference; no reference source is stored.
 See SURVEY.md 8(c) for the list (G1..G8).  TEST INFRASTRUCTURE: the product never imports this module.
@@ -287,6 +287,118 @@ def gen_sigma_quad(cp):
         out['sigma_r_converged'] = np.array([(integrate.quad(lambda logk: kernel_tophat2(np.exp(logk) * rr) * np.exp(logk)**3 * tab1(np.exp(logk)), *limits,
                                                              epsabs=1e-12, epsrel=1e-12, limit=4000)[0] / (2. * np.pi**2))**0.5 for rr in out['r']])
     save('sigma_quad', **out)
+
+
+def sigma_api_spectrum(k, ncol=0):
+    """A smooth closed-form P(k) for the module-level sigma integrals (callable convention of the reference: (nk,) -> (nk,) or (nk, ncol));
+    shared by the generator and tests/test_sigma_api_gpu.py."""
+    k = np.asarray(k, dtype='f8')
+    q = k / 0.02
+    p = 2e4 * q**0.96 / (1. + 0.7 * q + (0.9 * q)**2)**1.9
+    if ncol:
+        return p[..., None] * (1. + 0.25 * np.arange(ncol))
+    return p
+
+
+def sigma_api_gaussian2(x):
+    """W^2 of a Gaussian window, a ``kernel=`` other than the default."""
+    return np.exp(-np.asarray(x, dtype='f8')**2)
+
+
+def gen_sigma_api(cp):
+    """integrate_sigma_r2 / integrate_sigma_d2 called as module-level functions with the reference's own arguments (interpolator.py:123, 200):
+    callable P(k), scalar / nd radii, one or several columns, every method, a custom kernel, float32 radii."""
+    from cosmoprimo.interpolator import integrate_sigma_r2, integrate_sigma_d2
+    out = {}
+    r1 = np.array([[2., 8., 30.], [4., 12., 50.]])
+    for ncol in (0, 3):
+        pk = lambda k: sigma_api_spectrum(k, ncol)      # noqa: E731
+        # (method='quad' with several columns fails in the reference -- interpolator.py:259 indexes p[:, i] on the 1-D pk(scalar k): one column only)
+        for method in ('fftlog', 'simpson', 'leggauss', 'quad')[:4 if ncol == 0 else 3]:
+            out['r2_%s_%d' % (method, ncol)] = integrate_sigma_r2(r1, pk, method=method)
+            out['r2s_%s_%d' % (method, ncol)] = integrate_sigma_r2(8., pk, method=method)
+        for method in ('simpson', 'leggauss', 'quad')[:3 if ncol == 0 else 2]:
+            out['d2_%s_%d' % (method, ncol)] = integrate_sigma_d2(pk, method=method)
+            out['r2g_%s_%d' % (method, ncol)] = integrate_sigma_r2(r1, pk, method=method, kernel=sigma_api_gaussian2)
+        out['r2_range_%d' % ncol] = integrate_sigma_r2(r1, pk, kmin=1e-5, kmax=10., nk=512, method='simpson')
+        out['r2_f4_%d' % ncol] = integrate_sigma_r2(r1.astype('f4'), pk)
+        # (its dtype is part of the fixture: float32 for one column -- pk(kmin) is a scalar and does not count, interpolator.py:247 --, float64 for several)
+        out['d2_range_%d' % ncol] = integrate_sigma_d2(pk, kmin=1e-5, kmax=10., nk=512)
+    out['r'] = r1
+    save('sigma_api', **out)
+
+
+API_MODULES = ['fftlog', 'interpolator', 'bao_filter', 'cosmology', 'eisenstein_hu', 'eisenstein_hu_nowiggle', 'eisenstein_hu_nowiggle_variants', 'bbks', 'utils']
+
+
+def api_signature(obj):
+    """Parameters of a callable as [name, kind, repr of the default or None]: data about a signature, no source text."""
+    import inspect
+    try:
+        signature = inspect.signature(obj)
+    except (TypeError, ValueError):
+        return None
+    out = []
+    for par in signature.parameters.values():
+        if par.default is inspect.Parameter.empty:
+            default = None
+        elif callable(par.default):
+            default = 'callable:' + getattr(par.default, '__name__', '?')
+        else:
+            default = repr(par.default)
+        out.append([par.name, par.kind.name, default])
+    return out
+
+
+def api_surface(package):
+    """Public surface of the section-8(a) modules of ``package`` ('cosmoprimo' here, 'cosmoprimo_amd' in tests/test_api_signatures.py): per module the
+    public functions (signature) and classes (constructor signature, and per public member -- inherited ones included -- its kind and signature),
+    plus ``__all__`` of the package."""
+    import importlib
+    import inspect
+    out = {}
+    for name in API_MODULES:
+        module = importlib.import_module(package + '.' + name)
+        entries = {}
+        for oname, obj in vars(module).items():
+            if oname.startswith('_') or getattr(obj, '__module__', None) != module.__name__:
+                continue
+            if inspect.isclass(obj):
+                members = {}
+                for mname in dir(obj):
+                    if mname.startswith('_') and mname not in ('__call__', '__init__'):
+                        continue
+                    try:
+                        member = inspect.getattr_static(obj, mname)
+                    except AttributeError:
+                        continue
+                    if isinstance(member, property):
+                        members[mname] = {'kind': 'property'}
+                        continue
+                    kind, raw = 'method', member
+                    if isinstance(member, staticmethod):
+                        kind, raw = 'staticmethod', member.__func__
+                    elif isinstance(member, classmethod):
+                        kind, raw = 'classmethod', member.__func__
+                    if inspect.isfunction(raw):
+                        members[mname] = {'kind': kind, 'sig': api_signature(raw)}
+                    elif not callable(raw) and not mname.startswith('_'):
+                        members[mname] = {'kind': 'attribute'}
+                entries[oname] = {'kind': 'class', 'init': api_signature(obj), 'members': members}
+            elif inspect.isfunction(obj):
+                entries[oname] = {'kind': 'function', 'sig': api_signature(obj)}
+        out[name] = entries
+    out['__init__'] = {'all': sorted(getattr(importlib.import_module(package), '__all__', []))}
+    return out
+
+
+def gen_api_signatures(cp):
+    """tests/golden/api_signatures.json: ``inspect.signature`` of every public class / function / method of the section-8(a) modules of the reference."""
+    import json
+    path = os.path.join(OUT, 'api_signatures.json')
+    with open(path, 'w') as f:
+        json.dump(api_surface('cosmoprimo'), f, indent=0, sort_keys=True)
+    print('wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1e3))
 
 
 BAO_PARAMS = [dict(), dict(Omega_m=0.27, Omega_b=0.045, h=0.72, n_s=0.95), dict(Omega_m=0.36, Omega_b=0.055, h=0.64, n_s=0.98, sigma8=0.85),
@@ -1028,12 +1140,15 @@ def interp_fuzz_configs(n=INTERP_FUZZ_N, seed=20261006):
             cfg['zmax'] = float(rng.uniform(1., 4.))
             cfg['interp_order_z'] = int(rng.choice([1, 2, 3, 3, 5])) if cfg['nz'] > 5 else 3
             cfg['growth'] = bool(cfg['nz'] == 1 or i % 4 == 1)
-        # The extrapolation range: powers of ten beyond the table, as the reference's defaults (1e-7, 1e2) are.  The reference takes its knots through
-        # 10**log10(k): for an arbitrary end of the range that does not round-trip, P at the end itself is then NaN and with it every sigma / xi
-        # (their FFTLog grid starts and stops there) -- 14 of 36 random ranges; and a range that ends INSIDE the table puts two knots 1e-9 apart at
-        # the table's end (its own spline carries ~1e-7 of rounding there).
+        # The extrapolation range, beyond the table (a range that ends INSIDE the table puts two knots 1e-9 apart at the table's end: the reference's own
+        # spline carries ~1e-7 of rounding there): powers of ten, as the reference's defaults (1e-7, 1e2) are, for a third of the configurations, any
+        # number for the others.  The reference takes its knots through 10**log10(k): for an end of the range that does not survive that round trip P
+        # at the end itself is NaN, and with it every sigma / xi (their FFTLog grid starts and stops there) -- part of what is recorded.
         cfg['extrap_kmin'] = float(10.**(np.floor(np.log10(cfg['kmin'])) - cfg.pop('extrap_down')))
         cfg['extrap_kmax'] = float(10.**(np.ceil(np.log10(cfg['kmax'])) + cfg.pop('extrap_up')))
+        if i % 3:
+            cfg['extrap_kmin'] *= 0.37 + cfg['wiggle']
+            cfg['extrap_kmax'] *= 1.9 + cfg['wiggle']
         configs.append(cfg)
     return configs
 
@@ -1067,10 +1182,10 @@ def interp_fuzz_build(mod, cfg):
 
 def interp_fuzz_queries(cfg):
     """Wavenumbers (inside the table, in the extrapolation range, outside everything), redshifts (inside and outside), radii."""
-    # (not the ends of the table or of the extrapolation range themselves: the reference goes through 10**log10(k) for its knots, and whether a query
-    # AT an end is inside depends on how that rounds)
+    # (the ends of the table and of the extrapolation range themselves among them: the reference goes through 10**log10(k) for its knots, and whether
+    # a query AT an end of the range is inside -- a number -- or outside -- NaN -- depends on how that rounds)
     kq = np.concatenate([np.geomspace(cfg['kmin'] * 1.0001, cfg['kmax'] / 1.0001, 23), [cfg['kmin'] * 0.7, cfg['kmax'] * 1.3, cfg['extrap_kmin'] * 0.5,
-                         cfg['extrap_kmax'] * 2., 1e-9, 1e4]])
+                         cfg['extrap_kmax'] * 2., 1e-9, 1e4, cfg['kmin'], cfg['kmax'], cfg['extrap_kmin'], cfg['extrap_kmax']]])
     zq = np.array([0., 0.3 * cfg.get('zmax', 1.), 0.77 * cfg.get('zmax', 1.), cfg.get('zmax', 1.), 1.2 * cfg.get('zmax', 1.), -0.1])
     return kq, zq, np.array([2., 8., 30.])
 
@@ -1263,8 +1378,7 @@ def xi_fuzz_configs(n=XI_FUZZ_N, seed=20261009):
     rng = np.random.default_rng(seed)
     configs = []
     for i in range(n):
-        cfg = dict(two_d=bool(i % 2), ns=int(rng.choice([60, 200, 500])), smin=float(10.**int(rng.integers(-3, 0))), smax=float(10.**int(rng.integers(3, 5))),      # (powers of ten: see interp_fuzz_configs)
-                  
+        cfg = dict(two_d=bool(i % 2), ns=int(rng.choice([60, 200, 500])), smin=float(10.**int(rng.integers(-3, 0))), smax=float(10.**int(rng.integers(3, 5))),
                    jitter=float(rng.choice([0., 0.3])), interp_s='log' if i % 4 != 3 else 'lin', interp_order_s=int(rng.choice([1, 3, 3])),
                    slope=float(rng.uniform(1.5, 2.1)), bump=float(rng.uniform(0., 0.01)))
         if cfg['two_d']:
@@ -1272,6 +1386,9 @@ def xi_fuzz_configs(n=XI_FUZZ_N, seed=20261009):
             cfg['zmax'] = float(rng.uniform(1., 3.))
             cfg['interp_order_z'] = int(rng.choice([1, 3, 3])) if cfg['nz'] > 3 else 3
             cfg['growth'] = bool(cfg['nz'] == 1 or i % 4 == 1)
+        if i % 3:      # ends of the table that are not powers of ten (see interp_fuzz_configs)
+            cfg['smin'] *= 0.37 + 10. * cfg['bump']
+            cfg['smax'] *= 1.9 + 10. * cfg['bump']
         configs.append(cfg)
     return configs
 
@@ -1300,7 +1417,7 @@ def xi_fuzz_outputs(mod, cfg):
     with warnings.catch_warnings(), np.errstate(all='ignore'):
         warnings.simplefilter('ignore')
         interp, s = xi_fuzz_build(mod, cfg)
-        sq = np.concatenate([np.geomspace(cfg['smin'] * 1.0001, cfg['smax'] / 1.0001, 19), [cfg['smin'] * 0.5, cfg['smax'] * 2.]])
+        sq = np.concatenate([np.geomspace(cfg['smin'] * 1.0001, cfg['smax'] / 1.0001, 19), [cfg['smin'] * 0.5, cfg['smax'] * 2., s[0], s[-1]]])
         zq = np.array([0., 0.3 * cfg.get('zmax', 1.), 0.77 * cfg.get('zmax', 1.), 1.2 * cfg.get('zmax', 1.), -0.1])
         kq = np.geomspace(2e-3, 3., 15)
 
@@ -1350,6 +1467,10 @@ def main():
         gen_sigma(cp)
     if 'sigma_quad' in which:
         gen_sigma_quad(cp)
+    if 'sigma_api' in which:
+        gen_sigma_api(cp)
+    if 'api_signatures' in which:
+        gen_api_signatures(cp)
     if 'bao' in which:
         gen_bao(cp)
     if 'xi' in which:

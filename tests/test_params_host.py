@@ -57,7 +57,7 @@ def test_param_tables_and_conflicts(golden):
     params = cosmo.get_params(of='cosmology')
     assert params['r'] == 0.1 and 'kmax_pk' not in params and cosmo.get_params(of='calculation')['kmax_pk'] == 10.
     assert cosmo.get_params(of='extra') == {} and set(cosmo.get_params()) == set(cosmo.get_params(of='all'))
-    assert cp.cosmology.find_conflicts('tau') == cp.cosmology.find_conflicts('z_reio') and cp.cosmology.find_conflicts('n_s') == ('n_s', 'ns')
+    assert cp.cosmology.find_conflicts('tau', conflicts=Cosmology._conflict_parameters) == cp.cosmology.find_conflicts('z_reio', conflicts=Cosmology._conflict_parameters) and cp.cosmology.find_conflicts('n_s', conflicts=Cosmology._conflict_parameters) == ('n_s', 'ns') and cp.cosmology.find_conflicts('n_s') == ()
 
 
 def test_clone_equality_persistence(tmp_path, golden):

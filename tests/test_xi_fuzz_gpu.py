@@ -1,6 +1,8 @@
 """GPU parity of the tabulated xi(s) / xi(s, z) interpolators with options drawn at random (separations geometric or jittered, interpolation in s or
-log s, spline degrees, growth factor or table in z): values inside and outside (NaN), pairs, ignore_growth, to_1d, to_pk and sigma8 through it -- NaN
-throughout where the transformed P(k) goes negative and the log-log interpolator refuses it, as in the reference -- against the reference's own outputs
+log s, spline degrees, growth factor or table in z): values inside, AT the ends of the table and outside (NaN), pairs, ignore_growth, to_1d, to_pk and
+sigma8 through it -- NaN where the transformed P(k) goes negative and the log-log interpolator refuses it, in the reference's own pattern (everywhere for
+cubic splines, at and below the offending knot for a (k, z) table interpolated linearly along k: FITPACK's elimination order,
+tests/test_fitpack_nan_host.py) -- against the reference's own outputs
 (tests/golden/xi_fuzz.npz, `python -m oracle.gen_golden xi_fuzz`)."""
 import warnings
 
@@ -28,14 +30,6 @@ def test_random_options(golden, i):
         ref = g['c%d_%s' % (i, name)]
         assert got[name].dtype.kind == 'f' and ref.dtype.kind == 'f', (cfg, name, str(got[name]), str(ref))
         assert got[name].shape == ref.shape, (cfg, name, got[name].shape, ref.shape)
-        if cfg['interp_order_s'] == 1 and cfg['two_d'] and cfg['nz'] > 1 and name in ('pk', 'sigma8_z') and (np.isnan(ref).any() or np.isnan(got[name]).all()):
-            # KNOWN DEVIATION.  to_pk() hands its order on; the transformed P(k) goes negative somewhere, its logarithm is NaN there.  With cubic splines
-            # both packages then return NaN everywhere (jax.py:165-172); with linear interpolation scipy lets a NaN datum spoil only the intervals next to
-            # it: so does this package for one column of P(k) (interp1d's rule, Interpolator1D); for a (k, z) TABLE the reference's
-            # RectBivariateSpline(kx=1) returns NaN at and below the offending knot and numbers above it (the order of FITPACK's elimination), this
-            # package NaN for the whole surface.
-            assert np.isnan(got[name]).all(), (cfg, name)
-            continue
         assert np.array_equal(np.isnan(got[name]), np.isnan(ref)), (cfg, name)
         scale = np.nanmax(np.abs(ref)) if np.isfinite(ref).any() else 1.
         # xi changes sign and two rows share a transform: rounding relative to the scale of the array

@@ -17,7 +17,7 @@ for nrows in (64, 512, 4096, 32768, 262144):
     line = '%7d rows:' % nrows
     for label, window in (('fused', (2, 1 << 40)), ('separate', (0, -1))):
         it._FUSED_SPLINE_ROWS = window
-        fn = lambda: it.integrate_sigma_r2(r, lambda k: rows, device=dev, sqrt=True)      # noqa: E731
+        fn = lambda: it.sigma_r2_of_rows(r, lambda k: rows, device=dev, sqrt=True)      # noqa: E731
         for _ in range(5):
             fn()
         torch.cuda.synchronize()
