@@ -115,7 +115,7 @@ def test_xi_tables(cp, golden):
     np.testing.assert_allclose(cp.CorrelationFunctionInterpolator1D(st[perm], tab[perm, 0])(sq2), t1(sq2)[:, 0], rtol=1e-13, atol=1e-16)
     np.testing.assert_allclose(t2.clone()(sq2, zq), t2(sq2, zq), rtol=1e-13, atol=1e-16)
     with pytest.raises(ValueError):
-        cp.CorrelationFunctionInterpolator2D(st, 0., tab[:, :1])     # single-column table without growth_factor_sq
+        cp.CorrelationFunctionInterpolator2D(st, 0., tab[:, :1], interp_order_z=3)     # single-column table without growth_factor_sq (interpolator.py:1266-1267)
 
 
 def test_kirkby2013(cp, golden):
