@@ -323,7 +323,7 @@ struct GenArgs {
     int nsp;
     const double* k;                 // (N) wavenumbers, h/Mpc
     const double* ln_k;              // (N) their logarithms (log_pos, as power_kernel takes them)
-    const cppower::EhScalars* scal;  // (ncosmo) fit coefficients (cp_power_coefficients), unused for BBKS
+    const cppower::CosmoConsts* consts;  // (ncosmo) the cosmologies' constants (cp_power_coefficients)
     // the next step of wallish2018 in the epilogue (bao_filter.py:373-405): second derivatives of the clamped splines through the even- and the
     // odd-indexed coefficients, the box between their maxima, the box rewritten -- box != null (split layout only)
     int* box;                        // (2 ncosmo, 2) or null
@@ -353,23 +353,11 @@ template <int N, int P, int ENGINE, typename GP>
 __device__ __forceinline__ void generate_row(GP G, long long ic, int t, double* slots, const cpmath::MathTables* mt) {
     using namespace cppower;
     constexpr int T = N / P;
-    cpcosmo::Param bg[CP_BG_NPARAMS];
-#pragma unroll
-    for (int i = 0; i < CP_BG_NPARAMS; ++i) { bg[i].ptr = G->bg[i].ptr; bg[i].value = G->bg[i].value; }
-    const Cosmo c = load_cosmo(bg, ic, G->second_is_omega_m, G->ncdm_tab, nullptr, G->nsp);
-    double pw[CP_PK_NPARAMS];
-#pragma unroll
-    for (int i = 0; i < CP_PK_NPARAMS; ++i) {
-        const double* ptr = G->pw[i].ptr;
-        pw[i] = ptr ? ptr[ic] : G->pw[i].value;
-    }
-    EhScalars s{};
-    if (ENGINE != CP_ENGINE_BBKS) s = G->scal[ic];
+    const CosmoConsts K = load_uniform(G->consts + ic);      // (scalar loads: the cosmology's constants in scalar registers)
+    const PkPerCosmology& pc = K.pk;
     const double* gk = G->k;
     const double* gln = G->ln_k;
-    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw, mt);
-    const double ln_pk_unit = CP_MATH_TABLES_OFF ? log(pc.pk_unit) : log_tab_any(pc.pk_unit, mt);
+    const double ln_pk_unit = K.ln_pk_unit;
     // CP_DST_GEN_ILP samples per iteration: independent chains of logarithms / exponentials / reciprocals for the two waves of a SIMD to interleave
 #pragma unroll 1
     for (int r0 = 0; r0 < P; r0 += CP_DST_GEN_ILP) {
@@ -378,9 +366,7 @@ __device__ __forceinline__ void generate_row(GP G, long long ic, int t, double* 
             const int m = t + T * (r0 + u);
             const int n = m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1;
             const double kh = gk[n], ln_kh = gln[n];
-            double Tk;
-            if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
-            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, gln[N + n], gln[2 * N + n], mt) : transfer_nowiggle(s, c.h, kh, mt);
+            const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, gln[N + n], gln[2 * N + n], mt);
             slots[2 * m] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(Tk)) : log_tab_any(fabs(Tk), mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
         }
     }
@@ -413,13 +399,16 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
         if (t == 0) bad_row[0] = bad_row[1] = 0;
         __syncthreads();  // LDS reuse across pairs (and the table fill on the first one)
         double* slots = reinterpret_cast<double*>(lds);
-        generate_row<N, P, ENGINE>(&G, 2 * p, t, slots, &mt);
-        if (has_b) generate_row<N, P, ENGINE>(&G, 2 * p + 1, t, slots + 1, &mt);
+        int tt = t;
+        asm volatile("" : "+v"(tt));      // (nothing derived from the thread's number is kept in registers from one pair to the next: what the compiler hoists
+                                           // out of this loop lives through the transform, in registers the kernel does not have -- spilled and reloaded)
+        generate_row<N, P, ENGINE>(&G, 2 * p, tt, slots, &mt);
+        if (has_b) generate_row<N, P, ENGINE>(&G, 2 * p + 1, tt, slots + 1, &mt);
         cplx x[P];
         bool bad_a = false, bad_b = false;
 #pragma unroll
         for (int r = 0; r < P; ++r) {      // the thread's own slots: no barrier
-            const int m = t + T * r;
+            const int m = tt + T * r;
             const bool lower = m < N / 2;
             const double a = slots[2 * m], b = has_b ? slots[2 * m + 1] : 0.;
             bad_a |= !(fabs(a) <= 1.7976931348623157e308);
@@ -438,7 +427,6 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
                 if (skip_b) x[r].im = 0.;
             }
         }
-        int tt = t;
         asm volatile("" : "+v"(tt));
         dif_all<N, P>(tt, A, x, lds, ltw);
         asm volatile("" : "+v"(tt));
@@ -483,9 +471,10 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
                 seqs[(2 + (j & 1)) * NS + slot] = vb[s];
             }
             __syncthreads();
-            const int wave = t >> 6;
-            int lane = t & 63;
+            int lane = tt;
             asm volatile("" : "+v"(lane));      // (nothing of the tail is hoisted out of the loop over pairs: 32 squared abscissae and 32 slots would live through the transform)
+            const int wave = __builtin_amdgcn_readfirstlane(lane >> 6);
+            lane &= 63;
             if (wave < 2 || has_b) {
                 double* buf = seqs + wave * NS;
                 const long long row = 2 * p + (wave >> 1);
@@ -671,7 +660,7 @@ static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncos
     if (!bg_params || !pk_params || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, p->device, stream);      // (validates the massive-neutrino tables)
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, p->device, stream);      // (validates the massive-neutrino tables)
     if (st != CP_OK) return st;
     const int nsp = ncdm ? ncdm->nspecies : 0;
     if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_dst_forward_analytic: bad massive-neutrino tables");
@@ -689,7 +678,7 @@ static int dst_forward_analytic(const cp_dst_plan* p, int engine, long long ncos
     G.nsp = nsp;
     G.k = p->d_kx;
     G.ln_k = p->d_ln_kx;
-    G.scal = reinterpret_cast<const cppower::EhScalars*>(coef);
+    G.consts = reinterpret_cast<const cppower::CosmoConsts*>(coef);
     G.box = d_box; G.margin_first = margin_first; G.margin_second = margin_second; G.off0 = offset_first; G.off1 = offset_second;
     const long long npairs = (ncosmo + 1) / 2;
     int ncu = 0;
@@ -781,7 +770,7 @@ extern "C" int cp_wallish_full(const cp_dst_plan* p, const cp_splice_plan* splic
     if (!bg_params || !pk_params || !d_pk || !d_box || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_wallish_full: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, p->device, stream);      // (validates the massive-neutrino tables)
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, p->device, stream);      // (validates the massive-neutrino tables)
     if (st != CP_OK) return st;
     const int nsp = ncdm ? ncdm->nspecies : 0;
     if (nsp < 0 || (nsp > 0 && !ncdm->tab)) return cp::fail(CP_EINVAL, "cp_wallish_full: bad massive-neutrino tables");
@@ -804,7 +793,7 @@ extern "C" int cp_wallish_full(const cp_dst_plan* p, const cp_splice_plan* splic
     E.nsp = nsp;
     E.k = p->d_kx;
     E.ln_k = p->d_ln_kx;
-    E.scal = reinterpret_cast<const cppower::EhScalars*>(coef);
+    E.consts = reinterpret_cast<const cppower::CosmoConsts*>(coef);
     E.box = nullptr;
     const long long npairs = (ncosmo + 1) / 2;
     int ncu = 0;

@@ -28,10 +28,11 @@ struct cp_spline_band_view {
 };
 bool cp_spline_plan_view(const cp_spline_plan* plan, cp_spline_band_view* out);
 
-// fit coefficients of the EH98 / no-wiggle engines for a batch of cosmologies into d_work (cp_power_workspace_bytes(ncosmo) bytes): the first
-// of the two kernels cp_power_eval launches
-int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, void* d_work, int device,
-                          void* stream);
+// the constants of a batch of cosmologies for the evaluation of engine `engine` (cppower::CosmoConsts: fit coefficients of EH98 / no-wiggle, Gamma of
+// BBKS, the primordial constants of pk_params -- NULL: transfer functions only) into d_work (cp_power_workspace_bytes(ncosmo) bytes): the first of
+// the two kernels cp_power_eval launches
+int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+                          void* d_work, int device, void* stream);
 
 // a cp_spline_rows plan seen from cp_spline.hip: its queries as (interval, four weights) per query -- A y_j + B y_{j+1} + wM0 M_j + wM1 M_{j+1}, the
 // second derivatives M from cp_spline_rows_second_derivatives -- for the kernel that evaluates the k direction of (z, k) tables itself

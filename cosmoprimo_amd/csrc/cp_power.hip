@@ -37,7 +37,7 @@ struct Args {
     const double* z;  // (nz) shared (what == CP_PK_MATTER with nz > 0), else unused
     double* out;      // (ncosmo, max(nz, 1), nk)
     long long kchunks, kspan;  // a workgroup evaluates kspan consecutive k of ONE cosmology; kchunks = ceil(nk / kspan) workgroups per cosmology
-    const EhScalars* scal;     // (ncosmo) fit coefficients from coefficients_kernel (EH98 / no-wiggle transfer), else unused
+    const CosmoConsts* consts; // (ncosmo) the cosmologies' constants from coefficients_kernel
     // massive neutrinos (cp_ncdm; nsp == 0: none).  The fits themselves know nothing of them (scalars from omega_cdm + omega_b, eisenstein_hu.py:37-38);
     // they enter through the background: Omega0_m of pk_callable (:322), Omega_m(z) / Omega_de(z) of the CPT92 growth (:134-135), Omega_m of BBKS (bbks.py:38)
     const double* ncdm_tab;
@@ -48,13 +48,14 @@ struct Args {
 // The ~25 pow() of the EH98 / no-wiggle fit coefficients depend on the cosmology alone: one lane per cosmology here, read back by
 // power_kernel through scalar loads.  (Evaluated in every (cosmology, k) lane, as the first version did, they were 3/4 of the time; evaluated
 // by one lane of each power_kernel workgroup they still were half of it for 1024 wavenumbers per cosmology, all on one SIMD of the CU.)
-__global__ __launch_bounds__(64) void coefficients_kernel(const Args A, EhScalars* out) {
+__global__ __launch_bounds__(64) void coefficients_kernel(const Args A, CosmoConsts* out, int with_pw) {
     const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= A.ncosmo) return;
     const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
-    EhScalars s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, A.engine == CP_ENGINE_EH);
-    s.growth0 = growth_cpt(c, 0.);
-    out[ic] = s;
+    double pw[CP_PK_NPARAMS];
+#pragma unroll
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = with_pw ? (A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value) : 0.;
+    out[ic] = cosmo_consts(c, with_pw ? pw : nullptr, A.engine);
 }
 
 // One workgroup = one cosmology x kspan wavenumbers: growth(z)^2 of every output redshift is evaluated once per workgroup (one lane per
@@ -69,21 +70,16 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
     const long long ic = blockIdx.x / A.kchunks;
     const long long k0 = (long long)(blockIdx.x % A.kchunks) * A.kspan;
     const long long k1 = k0 + A.kspan < A.nk ? k0 + A.kspan : A.nk;
-    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
-    double pw[CP_PK_NPARAMS];
-#pragma unroll
-    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value;
-    EhScalars s{};
-    if (A.scal) s = A.scal[ic];
-    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
+    const CosmoConsts K = load_uniform(A.consts + ic);      // (ic follows from the workgroup's index: scalar loads, the constants in scalar registers)
+    const PkPerCosmology& pc = K.pk;
     const bool with_z = A.what == CP_PK_MATTER && A.nz > 0;
     const long long nzs = with_z ? A.nz : 1;
     const double kfac = A.kscale ? A.kscale[ic] : 1.;
-    const PkPerCosmology pc = pk_per_cosmology(c, pw, &mt);
-    const double ln_pk_unit = A.what == CP_PK_LOG_K_MATTER ? (CP_MATH_TABLES_OFF ? log(pc.pk_unit) : log_tab_any(pc.pk_unit, &mt)) : 0.;
+    const double ln_pk_unit = K.ln_pk_unit;
     for (long long z0 = 0; z0 < nzs; z0 += bs) {
         if (z0) __syncthreads();  // the previous block of redshifts has been written
         if (with_z && z0 + tid < A.nz) {
+            const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);      // (the lanes that evaluate a growth factor only)
             const double g = growth_cpt(c, A.z[z0 + tid]);  // growth_factor(z, znorm=0), eisenstein_hu.py:317
             sh_g2[tid] = g * g;
         }
@@ -96,9 +92,9 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
             double T = 1.;
             if (A.what != CP_PK_PRIMORDIAL) {
                 if (ENGINE == CP_ENGINE_BBKS)
-                    T = transfer_bbks(c, kh);
+                    T = transfer_bbks(K.h, K.bbks_gamma, kh);
                 else
-                    T = ENGINE == CP_ENGINE_EH ? transfer_eh(eh, kh, ln_kh, &mt) : transfer_nowiggle(s, c.h, kh, &mt);
+                    T = ENGINE == CP_ENGINE_EH ? transfer_eh(K.eh, kh, ln_kh, &mt) : transfer_nowiggle(K.s, K.h, kh, &mt);
             }
             if (A.what == CP_PK_TRANSFER) {
                 out[0] = T;
@@ -337,11 +333,10 @@ int select_device(int device, int* prev) {
 
 }  // namespace
 
-extern "C" long long cp_power_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : (long long)sizeof(EhScalars) * ncosmo; }
+extern "C" long long cp_power_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : (long long)sizeof(CosmoConsts) * ncosmo; }
 
-int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, void* d_work, int device,
-                          void* stream) {
-    if (engine != CP_ENGINE_EH && engine != CP_ENGINE_EH_NOWIGGLE) return CP_OK;      // BBKS has no fit coefficients
+int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+                          void* d_work, int device, void* stream) {
     if (ncosmo <= 0) return CP_OK;
     if (!bg_params || !d_work) return cp::fail(CP_EINVAL, "cp_power_coefficients: null pointer");
     int prev;
@@ -350,6 +345,8 @@ int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_param
     Args A{};
     A.ncosmo = ncosmo;
     for (int i = 0; i < CP_BG_NPARAMS; ++i) A.bg[i] = Param{bg_params[i].ptr, bg_params[i].value};
+    if (pk_params)
+        for (int i = 0; i < CP_PK_NPARAMS; ++i) A.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};
     A.second_is_omega_m = second_is_omega_m;
     A.engine = engine;
     NcdmView nu;
@@ -361,7 +358,7 @@ int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_param
     A.ncdm_tab = nu.tab;
     A.ncdm_knots = nu.knots;
     A.nsp = nu.nsp;
-    hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), A, static_cast<EhScalars*>(d_work));
+    hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), A, static_cast<CosmoConsts*>(d_work), pk_params ? 1 : 0);
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_coefficients: launch failed: %s", hipGetErrorString(e));
@@ -393,7 +390,7 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
     A.kscale = d_kscale;
     A.z = d_z;
     A.out = d_out;
-    A.scal = nullptr;
+    A.consts = nullptr;
     NcdmView nu;
     st = ncdm_view(ncdm, device, "cp_power_eval", &nu);
     if (st != CP_OK) {
@@ -416,14 +413,14 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
         return cp::fail(CP_EUNSUPPORTED, "cp_power_eval: %lld cosmologies x %lld wavenumbers exceed one launch; split the batch", ncosmo, nk);
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    if (what != CP_PK_PRIMORDIAL && engine != CP_ENGINE_BBKS) {   // fit coefficients of the cosmologies: caller-owned workspace, nothing is allocated here
+    {   // the constants of the cosmologies: caller-owned workspace, nothing is allocated here
         if (!d_work) {
             if (prev >= 0) (void)hipSetDevice(prev);
-            return cp::fail(CP_EINVAL, "cp_power_eval: the EH engines need a workspace of cp_power_workspace_bytes(ncosmo) bytes");
+            return cp::fail(CP_EINVAL, "cp_power_eval: needs a workspace of cp_power_workspace_bytes(ncosmo) bytes");
         }
-        EhScalars* scal = static_cast<EhScalars*>(d_work);
-        A.scal = scal;
-        hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, hs, A, scal);
+        CosmoConsts* consts = static_cast<CosmoConsts*>(d_work);
+        A.consts = consts;
+        hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, hs, A, consts, 1);
     }
     const dim3 grid((unsigned)(ncosmo * A.kchunks)), threads((unsigned)block);
     if (engine == CP_ENGINE_EH) hipLaunchKernelGGL(power_kernel<CP_ENGINE_EH>, grid, threads, 0, hs, A);

@@ -171,21 +171,13 @@ __device__ __forceinline__ double bbks_gamma(const Cosmo& c) {
     return Omega_m * (c.h * c.h) * exp(-c.Omega_b * (1. + sqrt(2. * c.h) / Omega_m));
 }
 
-__device__ __forceinline__ double transfer_bbks(const Cosmo& cosmo, double kh) {  // bbks.py:34-38, 62-64
-    const double h = cosmo.h;
-    const double gamma = bbks_gamma(cosmo);
-    const double q = kh * h / gamma;
-    const double x = 2.34 * q;
-    const double a = 16.2 * q, b = 5.47 * q, c = 6.71 * q;
-    // as coded in the reference: 3.89 q (16.2 q)^2, not 3.89 q + (16.2 q)^2 (SURVEY.md App. A)
-    return log(1 + x) / x / sqrt(sqrt(1. + 3.89 * q * (a * a) + b * b * b + (c * c) * (c * c)));
-}
-
 // What one P(k) evaluation needs of a cosmology besides its transfer function: primordial tilt and the constant that turns T^2 k into P
 // (Primordial.pk_k, eisenstein_hu.py:214-215; pk_callable, eisenstein_hu.py:321-324: potential_to_density^-2 x curvature_to_potential x
 // h^3 A_s = kh x a constant of the cosmology -- the h^3 of the primordial spectrum and of curvature_to_potential cancel)
 struct PkPerCosmology {
-    double n_s, alpha_s, beta_s, ln_kp, pk_unit, h3_A_s;
+    double ns_m1, half_alpha_s, sixth_beta_s;      // n_s - 1, alpha_s / 2, beta_s / 6 as the exponent of the tilt takes them (the same products, formed once: in the loop
+                                                   // their literal factors were vector registers -- two scalar operands do not go into one instruction)
+    double ln_kp, pk_unit, h3_A_s;
 };
 
 // mt: the kernel's tables for the short logarithm (cp_math.h) -- every thread of a kernel goes through this once per cosmology, and with the library's
@@ -193,9 +185,9 @@ struct PkPerCosmology {
 __device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const double* pw, const MathTables* mt = nullptr) {
     PkPerCosmology p;
     const double A_s = pw[CP_PK_A_S];
-    p.n_s = pw[CP_PK_N_S];
-    p.alpha_s = pw[CP_PK_ALPHA_S];
-    p.beta_s = pw[CP_PK_BETA_S];
+    p.ns_m1 = pw[CP_PK_N_S] - 1.;
+    p.half_alpha_s = 1. / 2. * pw[CP_PK_ALPHA_S];
+    p.sixth_beta_s = 1. / 6. * pw[CP_PK_BETA_S];
     const double Omega0_m = c.Omega_b + c.Omega_cdm + c.Omega_nu_m;  // cosmology.py:381: + Omega_ncdm_tot - Omega_pncdm_tot (ba.Omega0_m of pk_callable, eisenstein_hu.py:322)
     const double p2d_unit = 3. * Omega0_m * (100. * 100.) * (1. / (2. * (kCkms * kCkms)));
     if (mt && !CP_MATH_TABLES_OFF) {
@@ -209,9 +201,68 @@ __device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const
     return p;
 }
 
+// Everything an evaluation of P(k) needs of ONE cosmology, in the units of the loops over wavenumbers: formed once per cosmology by one lane of
+// coefficients_kernel (cp_power.hip) and read back by the evaluating kernels with load_uniform -- scalar loads: the values sit in scalar registers, where
+// formed per thread (the parameters gathered, Omega_g by two IEEE divisions, two reciprocals and a logarithm: ~250 instructions per thread and
+// cosmology, a tenth of a thread's evaluations in the fused sigma(r, z) kernel) they were 36 vector registers of a kernel that has none to spare.
+struct CosmoConsts {
+    EhScalars s;             // the fit coefficients themselves (the no-wiggle form reads four of them; growth0 for the sigma8 normalisation)
+    EhPerCosmology eh;       // EH98 (zeros for the other engines)
+    PkPerCosmology pk;       // primordial tilt and the constant that turns T^2 k into P
+    double h, bbks_gamma;    // BBKS: q = kh h / gamma
+    double ln_pk_unit;       // log(pk.pk_unit): the log(k P) form (CP_PK_LOG_K_MATTER)
+    double A_s;
+};
+
+// pw: the CP_PK_NPARAMS primordial parameters of the cosmology, or null (the constants of the spectrum are then zero: transfer functions only)
+__device__ inline CosmoConsts cosmo_consts(const Cosmo& c, const double* pw, int engine) {
+    CosmoConsts K{};
+    if (engine != CP_ENGINE_BBKS) {
+        K.s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, engine == CP_ENGINE_EH);
+        if (engine == CP_ENGINE_EH) K.eh = eh_per_cosmology(K.s, c.h);
+    }
+    K.s.growth0 = growth_cpt(c, 0.);
+    K.h = c.h;
+    K.bbks_gamma = bbks_gamma(c);
+    if (pw) {
+        K.pk = pk_per_cosmology(c, pw, nullptr);
+        K.ln_pk_unit = log(K.pk.pk_unit);
+        K.A_s = pw[CP_PK_A_S];
+    }
+    return K;
+}
+
+// *p for a wave-uniform p into scalar registers: the loads go through the constant address space (scalar loads; only the fields that are used are
+// loaded).  The memory must not be written by the kernel that reads it this way (the scalar cache is not coherent with the vector stores of a launch).
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+    static_assert(sizeof(T) % sizeof(double) == 0 && alignof(T) <= alignof(double), "made of doubles");
+    const double __attribute__((address_space(4)))* q = (const double __attribute__((address_space(4)))*)(unsigned long long)p;
+    T v;
+    double* d = reinterpret_cast<double*>(&v);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / sizeof(double)); ++i) d[i] = q[i];
+    return v;
+}
+
+// the transfer function of engine ENGINE from the cosmology's constants
+__device__ __forceinline__ double transfer_bbks(double h, double gamma, double kh) {  // bbks.py:34-38, 62-64
+    const double q = kh * h / gamma;
+    const double x = 2.34 * q;
+    const double a = 16.2 * q, b = 5.47 * q, c = 6.71 * q;
+    // as coded in the reference: 3.89 q (16.2 q)^2, not 3.89 q + (16.2 q)^2 (SURVEY.md App. A)
+    return log(1 + x) / x / sqrt(sqrt(1. + 3.89 * q * (a * a) + b * b * b + (c * c) * (c * c)));
+}
+
+template <int ENGINE>
+__device__ __forceinline__ double transfer_any(const CosmoConsts& K, double kh, double ln_kh, double kh108, double kh14, const MathTables* mt) {
+    if (ENGINE == CP_ENGINE_BBKS) return transfer_bbks(K.h, K.bbks_gamma, kh);
+    return ENGINE == CP_ENGINE_EH ? transfer_eh_powers(K.eh, kh, ln_kh, kh108, kh14, mt) : transfer_nowiggle(K.s, K.h, kh, mt);
+}
+
 __device__ __forceinline__ double primordial_tilt_exponent(const PkPerCosmology& p, double ln_kh) {
     const double lnkkp = ln_kh - p.ln_kp;
-    return (p.n_s - 1. + 1. / 2. * p.alpha_s * lnkkp + 1. / 6. * p.beta_s * (lnkkp * lnkkp)) * lnkkp;
+    return (p.ns_m1 + p.half_alpha_s * lnkkp + p.sixth_beta_s * (lnkkp * lnkkp)) * lnkkp;      // eisenstein_hu.py:214: n_s - 1 + alpha_s / 2 ln + beta_s / 6 ln^2
 }
 __device__ __forceinline__ double primordial_tilt(const PkPerCosmology& p, double ln_kh, const MathTables* mt) {
     return (mt && !CP_MATH_TABLES_OFF) ? exp_tab(primordial_tilt_exponent(p, ln_kh), mt) : exp_mid(primordial_tilt_exponent(p, ln_kh));

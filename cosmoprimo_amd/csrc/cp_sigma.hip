@@ -58,7 +58,7 @@ struct SigmaArgs {
     int nsp;
     const double* k;              // (n) wavenumbers of the transform, h/Mpc
     const double* ln_k;           // (n) their logarithms (log_wavenumbers_kernel)
-    const EhScalars* scal;        // (ncosmo) fit coefficients (cp_power_coefficients), unused for BBKS
+    const CosmoConsts* consts;    // (ncosmo) the cosmologies' constants (cp_power_coefficients)
     int stagger_div, stagger_mod, stagger_sleeps;      // start offsets between workgroups (see the kernel), 0 sleeps: none
     const double* wb;             // (bw, nq) band of the spline operator, query fastest
     const int* j0;                // (nq) first knot of each band, -1: outside the knots
@@ -95,14 +95,8 @@ __device__ __forceinline__ void front_phases(int t, const FftlogArgs& A, bool ha
 template <int ENGINE, int T, int H>
 __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long ic, int t0, double kh0, double ln0, double ratio, double ln_ratio, double2 pw0,
                                                   double2 pw_ratio, double* slots, const MathTables* mt) {
-    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m, S.ncdm_tab, nullptr, S.nsp);
-    double pw[CP_PK_NPARAMS];
-#pragma unroll
-    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
-    EhScalars s{};
-    if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
-    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw, mt);
+    const CosmoConsts K = load_uniform(S.consts + ic);      // (scalar loads: the cosmology's constants in scalar registers)
+    const PkPerCosmology& pc = K.pk;
     double kh = kh0, ln_kh = ln0, kh108 = pw0.x, kh14 = pw0.y;
     // CP_SIGMA_ILP samples per iteration: independent chains of logarithms / exponentials / reciprocals for the two waves of a SIMD to interleave
 #pragma unroll 1
@@ -110,9 +104,7 @@ __device__ __forceinline__ void evaluate_spectrum(const SigmaArgs& S, long long 
 #pragma unroll
         for (int u = 0; u < CP_SIGMA_ILP; ++u) {
             const int j = t0 + T * (r0 + u);
-            double Tk;
-            if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
-            else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, kh108, kh14, mt) : transfer_nowiggle(s, c.h, kh, mt);
+            const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, kh108, kh14, mt);
             slots[2 * j] = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, mt);
             kh *= ratio;
             ln_kh += ln_ratio;
@@ -220,17 +212,16 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
     F::init_state(t, A, nullptr, nullptr, 0, st);
     F::fill_lds_tables(t, A, lds);
     const int t0 = st.t0;
-    // The thread's first wavenumber, its logarithm, k^1.08 and k^1.4 there (tables behind log k: log_wavenumbers_kernel) and the steps along the geometric
-    // grid are the same for every pair.  All eight in vector registers over the loop, they were spilled (the transform takes what two waves per SIMD
-    // leave), and a scratch reload at the top of a pair is a vector-memory load: it waits for the 256 stores of the previous pair (the counter retires in
-    // order), the very thing the evaluation is arranged to avoid.
+    // The thread's first wavenumber, its logarithm, k^1.08 and k^1.4 there and the steps along the geometric grid are the same for every pair.  The four
+    // steps are the same in every lane: scalar registers.  The thread's own four values (eight vector registers) do not survive the transform -- it takes
+    // what two waves per SIMD leave: held over the loop they were spilled, and a scratch reload is a vector-memory load: it waits for the 256 stores of the
+    // previous pair (the counter retires in order), the very thing the evaluation is arranged to avoid; an LDS copy of them, 4 KB, costs the fourth
+    // workgroup of the CU (0.33 -> 0.37 ms, measured).  They are FORMED AGAIN at the top of every pair from the thread's index -- log k linear in it, three
+    // exponentials: 60 of a pair's ~9 000 instructions -- behind an opaque copy of the index, so that the compiler does not hoist them back out.
     const int nk_tab = NP / 2;
-    // (the four steps along the grid are the same in every lane: scalar registers; the thread's own four constants stay in vector registers -- an LDS copy
-    // of them, 4 KB, costs the fourth workgroup of the CU: 0.33 -> 0.37 ms, measured)
     const double ratio = cp::wave_uniform(S.k[T] / S.k[0]), ln_ratio = cp::wave_uniform(S.ln_k[T] - S.ln_k[0]);
     const double2 pw_ratio = double2{cp::wave_uniform(S.ln_k[nk_tab + T] / S.ln_k[nk_tab]), cp::wave_uniform(S.ln_k[2 * nk_tab + T] / S.ln_k[2 * nk_tab])};
-    const double kh0 = S.k[t0], ln0 = S.ln_k[t0];
-    const double2 pw0 = double2{S.ln_k[nk_tab + t0], S.ln_k[2 * nk_tab + t0]};
+    const double ln_first = cp::wave_uniform(S.ln_k[0]), ln_step = cp::wave_uniform((S.ln_k[nk_tab - 1] - S.ln_k[0]) / (double)(nk_tab - 1));
     __syncthreads();
     // Every workgroup does the same work on its pairs and all start together: left alone they evaluate together and store together -- the chip alternates
     // between its vector ALUs and its memory instead of using both.  The workgroups of a CU start a fraction of a pair apart instead.
@@ -246,6 +237,10 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
 #pragma unroll
             for (int r = 0; r < H; ++r) st.va[r] = 1. + 1e-3 * (t + r), st.vb[r] = 2. - 1e-3 * (t + r);
         } else {
+            int t0v = t0;
+            asm volatile("" : "+v"(t0v));      // (what follows is not loop-invariant for the compiler)
+            const double ln0 = fma((double)t0v, ln_step, ln_first), kh0 = exp_mid(ln0);
+            const double2 pw0 = double2{exp_mid(1.08 * ln0), exp_mid(1.4 * ln0)};
             evaluate_spectra<ENGINE, T, H>(S, ia, ib, t0, kh0, ln0, ratio, ln_ratio, pw0, pw_ratio, lds, st.va, st.vb, mtp);
             if (S.pk_out) {      // the caller keeps the spectra (the sigma8 normalisation: the filters ask for them on these wavenumbers next)
 #pragma unroll
@@ -260,7 +255,11 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
         cplx x[P];
         Pass<NP, P, 0>::load_lds(t0, lds, x);
         __syncthreads();      // every thread has its inputs: the data region is free for the outputs
-        for (int z = t; z < 2 * S.nz; z += T) {      // (written behind the barrier: nobody is still in the previous pair's store loop)
+        // (the addresses the loops below form from the thread's index are formed here, pair by pair, not carried through the transform in registers it
+        // does not have -- spilled, their reloads were vector-memory loads at the top of these loops: the copy of the index is opaque to the compiler)
+        int tv = t;
+        asm volatile("" : "+v"(tv));
+        for (int z = tv; z < 2 * S.nz; z += T) {      // (written behind the barrier: nobody is still in the previous pair's store loop)
             const long long ic = z < S.nz ? ia : ib;
             roots_g[z] = sqrt(S.growth_sq[ic * S.nz + (z < S.nz ? z : z - S.nz)]);
         }
@@ -281,14 +280,14 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
         if (CP_SIGMA_ABLATE & 2) {
             for (int q = t; q < 2 * S.nq; q += T) roots_r[q] = 1. + q;
         } else {
-            spline_to_radii<T>(t, lds, S.wb, S.j0, S.bw, S.nq, roots_r);
+            spline_to_radii<T>(tv, lds, S.wb, S.j0, S.bw, S.nq, roots_r);
         }
         __syncthreads();
         // ---- out[c, q, z] = sqrt(var[q]) sqrt(growth_sq[z]): the (nq x nz) block of a cosmology is contiguous; 16-byte stores when nz is even ----
         {
             const int nz = S.nz, block = S.nq * nz;
             const bool even = (nz & 1) == 0;
-            const int stride = even ? 2 * T : T, e0 = even ? 2 * t : t;
+            const int stride = even ? 2 * T : T, e0 = even ? 2 * tv : tv;
             const int dq = stride / nz, dz = stride - dq * nz, q_first = e0 / nz, z_first = e0 - q_first * nz;
             for (int row = 0; row < ((CP_SIGMA_ABLATE & 4) ? 0 : has_b ? 2 : 1); ++row) {
                 double* dst = S.out + (ia + row) * (long long)block;
@@ -711,7 +710,7 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     cp_fftlog_tables_view f;
     cp_spline_band_view b;
     if (!cp_fftlog_plan_view(fftlog, &f) || !cp_spline_plan_view(spline, &b)) return cp::fail(CP_EINVAL, "cp_sigma_rz_fused: plans without device tables");
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, d_coef, device, stream);      // (validates the massive-neutrino tables)
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_coef, device, stream);      // (validates the massive-neutrino tables)
     if (st != CP_OK) return st;
     SigmaArgs S{};
     S.nsp = ncdm ? ncdm->nspecies : 0;
@@ -726,7 +725,7 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     for (int i = 0; i < CP_PK_NPARAMS; ++i) S.pw[i] = Param{pk_params[i].ptr, pk_params[i].value};
     S.second_is_omega_m = second_is_omega_m;
     S.k = d_k;
-    S.scal = static_cast<const EhScalars*>(d_coef);
+    S.consts = static_cast<const CosmoConsts*>(d_coef);
     double* ln_k = reinterpret_cast<double*>(static_cast<char*>(d_coef) + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients
     S.ln_k = ln_k;
     S.wb = b.d_wb; S.j0 = b.d_j0; S.bw = b.bw; S.nq = b.nq; S.nz = nz;
@@ -790,7 +789,7 @@ struct FunctionalArgs {
     int nk, nq, nz;
     const double* k;              // (nk) wavenumbers, h/Mpc
     const double* ln_k;           // (nk) their logarithms (log_wavenumbers_kernel)
-    const EhScalars* scal;        // (ncosmo) fit coefficients, unused for BBKS
+    const CosmoConsts* consts;    // (ncosmo) the cosmologies' constants (cp_power_coefficients)
     const double* functional;     // (nq, nk)
     const double* growth_sq;      // (ncosmo, nz)
     double* out;                  // (ncosmo, nq, nz)
@@ -814,16 +813,10 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
     fill_math_tables(&mt);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ic = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (a cosmology per wave: in a scalar register)
     if (ic >= S.ncosmo) return;
-    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m, S.ncdm_tab, S.ncdm_knots, S.nsp);
-    double pw[CP_PK_NPARAMS];
-#pragma unroll
-    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
-    EhScalars s{};
-    if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
-    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw, &mt);
+    const CosmoConsts K = load_uniform(S.consts + ic);      // (scalar loads: the cosmology's constants in scalar registers)
+    const PkPerCosmology& pc = K.pk;
     double acc = 0.;
     __shared__ double kept[4 * PER_LANE * 64];
     double* pks = kept + (threadIdx.x >> 6) * (PER_LANE * 64) + lane;      // sample i of this lane at pks[64 i]
@@ -831,22 +824,20 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
     for (int i = 0; i < PER_LANE; ++i) {
         const int j = lane + 64 * i;
         const double kh = S.k[j], ln_kh = S.ln_k[j];
-        double Tk;
-        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
-        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, S.ln_k[1024 + j], S.ln_k[2048 + j], &mt) : transfer_nowiggle(s, c.h, kh, &mt);
+        const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, S.ln_k[1024 + j], S.ln_k[2048 + j], &mt);
         const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         pks[64 * i] = pk;
         acc = fma(S.functional[j], pk, acc);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
-    const double g0 = ENGINE != CP_ENGINE_BBKS ? s.growth0 : growth_cpt(c, 0.);      // (the lane of the coefficient pre-kernel has evaluated it: ~350 instructions per wave here)
+    const double g0 = K.s.growth0;      // (the lane of the coefficient pre-kernel has evaluated it: ~350 instructions per wave here)
     const double sigma8_fid = sqrt(acc) * sqrt(g0 * g0);      // (the product of roots of the fused kernels: sqrt(sigma^2) sqrt(growth^2))
     const double target = S.target.ptr ? S.target.ptr[ic] : S.target.value;
     const double rs = target / sigma8_fid, rs2 = rs * rs;
     if (lane == 0) {
         S.rsigma8_out[ic] = rs;
-        if (S.amplitude_out) S.amplitude_out[ic] = pw[CP_PK_A_S] * rs2;
+        if (S.amplitude_out) S.amplitude_out[ic] = K.A_s * rs2;
     }
     if (S.pk_out) {
 #pragma unroll
@@ -860,25 +851,17 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
     fill_math_tables(&mt);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const long long ic = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ic = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // (a cosmology per wave: in a scalar register)
     if (ic >= S.ncosmo) return;
-    const Cosmo c = load_cosmo(S.bg, ic, S.second_is_omega_m, S.ncdm_tab, S.ncdm_knots, S.nsp);
-    double pw[CP_PK_NPARAMS];
-#pragma unroll
-    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = S.pw[i].ptr ? S.pw[i].ptr[ic] : S.pw[i].value;
-    EhScalars s{};
-    if (ENGINE != CP_ENGINE_BBKS) s = S.scal[ic];
-    const EhPerCosmology eh = eh_per_cosmology(s, c.h);
-    const PkPerCosmology pc = pk_per_cosmology(c, pw, &mt);
+    const CosmoConsts K = load_uniform(S.consts + ic);      // (scalar loads: the cosmology's constants in scalar registers)
+    const PkPerCosmology& pc = K.pk;
     double acc[FUNCTIONAL_MAX_NQ];
 #pragma unroll
     for (int q = 0; q < FUNCTIONAL_MAX_NQ; ++q) acc[q] = 0.;
 #pragma unroll 2
     for (int j = lane; j < S.nk; j += 64) {
         const double kh = S.k[j], ln_kh = S.ln_k[j];
-        double Tk;
-        if (ENGINE == CP_ENGINE_BBKS) Tk = transfer_bbks(c, kh);
-        else Tk = ENGINE == CP_ENGINE_EH ? transfer_eh_powers(eh, kh, ln_kh, S.ln_k[S.nk + j], S.ln_k[2 * S.nk + j], &mt) : transfer_nowiggle(s, c.h, kh, &mt);
+        const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, S.ln_k[S.nk + j], S.ln_k[2 * S.nk + j], &mt);
         const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
         if (S.pk_out) S.pk_out[ic * S.nk + j] = pk;
 #pragma unroll
@@ -911,7 +894,7 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     if (!bg_params || !pk_params || !d_k || !d_functional || !d_growth_sq || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_sigma_rz_functional: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, device, stream);
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, device, stream);
     if (st != CP_OK) return st;
     FunctionalArgs S{};
     {
@@ -932,7 +915,7 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     S.second_is_omega_m = second_is_omega_m;
     S.nk = nk; S.nq = nq; S.nz = nz;
     S.k = d_k;
-    S.scal = reinterpret_cast<const EhScalars*>(coef);
+    S.consts = reinterpret_cast<const CosmoConsts*>(coef);
     double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
     S.ln_k = ln_k;
     S.functional = d_functional;
@@ -965,7 +948,7 @@ extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param*
     if (!bg_params || !pk_params || !d_k || !d_functional || !d_rsigma8 || !d_work) return cp::fail(CP_EINVAL, "cp_sigma8_normalise: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, coef, device, stream);
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, device, stream);
     if (st != CP_OK) return st;
     FunctionalArgs S{};
     {
@@ -986,7 +969,7 @@ extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param*
     S.second_is_omega_m = second_is_omega_m;
     S.nk = nk; S.nq = 1; S.nz = 1;
     S.k = d_k;
-    S.scal = reinterpret_cast<const EhScalars*>(coef);
+    S.consts = reinterpret_cast<const CosmoConsts*>(coef);
     double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
     S.ln_k = ln_k;
     S.functional = d_functional;

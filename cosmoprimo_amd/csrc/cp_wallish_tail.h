@@ -43,7 +43,7 @@ __device__ __forceinline__ TailArgsK tail_args() {
 }
 
 // the queries that go through the spline: v = part + w.z M_j + w.w M_{j+1}, then pk / ((pk / pknow - 1) tophat + 1) as splice_uniform_kernel forms it
-__device__ __forceinline__ void tail_evaluate(const double* yu, double* outrow, int lane, const double* part, const double* own) {
+__device__ __forceinline__ void tail_evaluate(const double* yu, double* outrow, int lane, const double* part, const double* pkrow) {
     TailArgsK g = tail_args();
     const int ngb = g->U.ngb, gb0 = g->U.gb0, nq = g->U.nq, gfirst = g->U.gfirst, gend = g->U.gend;
     const int* qe = g->U.qe;
@@ -56,7 +56,7 @@ __device__ __forceinline__ void tail_evaluate(const double* yu, double* outrow, 
             const int j = qe[slot];
             const double4 w = qw[slot];
             double v = part[e] + fma(w.z, yu[j], w.w * yu[j + 1]);
-            const double p = own[e];
+            const double p = q < nq ? pkrow[q] : 0.;      // the row's own value at the query (requested here with the query's weights: ahead of the stages it was spilled)
             if (tophat) v = p * (v * cpmath::recip(fma(p - v, (q < nq ? tophat[q] : 0.), v)));
             if (q >= gfirst && q < gend && !(CP_TAIL_ABLATE & 16)) outrow[q] = v;
         }
@@ -66,21 +66,29 @@ __device__ __forceinline__ void tail_evaluate(const double* yu, double* outrow, 
 // the spliced spline of ONE row by one wave: `row` = the transformed row in LDS, natural order (its stretch starts at column col_u; the slot in front of
 // the stretch and the slots behind it up to 64 SU belong to the row and are free).  The arithmetic of cpsu::splice_uniform_kernel, statement for statement.
 template <int SU>
-__device__ __forceinline__ void tail_splice_row(double* row, double* outrow, int lane, double gvl, double gvr, const double* own) {
+__device__ __forceinline__ void tail_splice_row(double* row, double* outrow, int lane, const double* pkrow) {
     using cpsu::P;
     using cpsu::WIN_U;
     using cpsu::NGB;
     TailArgsK g0 = tail_args();
     const int nm = g0->U.nm, wl = g0->U.wl;
     double* yu = row + g0->U.col_u;
-    const double gl_last = __shfl(gvl, wl > 0 ? wl - 1 : 0), gr_first = __shfl(gvr, 0);
+    // the knots outside the stretch (the row's own values left and right of it), requested with the weights of the junctions below: one wait for both
+    // (requested ahead of the stages, with the row's values at the queries, they were eight registers the kernel that evaluates its own spectra does not
+    // have through the transform and the exponentials: spilled -- a load, a wait, a scratch store and a scratch reload)
+    double gvl = 0., gvr = 0.;
+    if (lane < wl) gvl = pkrow[g0->U.col_l + lane];
+    if (lane < g0->U.wr) gvr = pkrow[g0->U.col_r + lane];
     // ---- A / p, M_left, B, M_right: weighted sums over the differences of the knots next to the two junctions ----
     double sums[4];
+    double gl_last, gr_first;
     {
         const double* win = g0->U.win;
         double ww[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) ww[o] = win[64 * o + lane];
+        gl_last = __shfl(gvl, wl > 0 ? wl - 1 : 0);
+        gr_first = __shfl(gvr, 0);
         const double ul = yu[lane < WIN_U ? lane : 0], ur = yu[lane < WIN_U ? nm - 1 - lane : 0];
         const double yfirst = yu[0], ylast = yu[nm - 1];
         sums[0] = fma(ww[0], gvl - yfirst, ww[1] * (ul - yfirst));
@@ -160,7 +168,7 @@ __device__ __forceinline__ void tail_splice_row(double* row, double* outrow, int
     if (lane == 0) yu[-1] = sums[1];
     if (lane == 1) yu[nm] = sums[3];
     cp::wave_lds_phase();
-    tail_evaluate(yu, outrow, lane, part, own);
+    tail_evaluate(yu, outrow, lane, part, pkrow);
 }
 
 // Stages 2 .. 5 of a pair whose four sequences sit in the data region (XOR layout) with bad_row set for rows that hold a sample that is not finite, behind a
@@ -179,25 +187,8 @@ __device__ __forceinline__ void tail_stages(long long p, bool has_b, int t, cplx
         asm volatile("" : "+v"(lane));      // (as above: the wave's number and the lane are formed anew for every pair)
         const int wave = __builtin_amdgcn_readfirstlane(lane >> 6);
         lane &= 63;
-        // what the spline step takes of the first array, requested now: the row's values at the queries that go through the spline and the knots
-        // outside the stretch (waves 0 and 1: rows a and b)
         const long long myrow = 2 * p + (wave & 1);
         const bool spline_wave = wave < 2 && (wave == 0 || has_b), copy_wave = wave >= 2 && (wave == 2 || has_b);
-        double own[cpsu::NGB], gvl = 0., gvr = 0.;
-#pragma unroll
-        for (int e = 0; e < cpsu::NGB; ++e) own[e] = 0.;
-        if (spline_wave) {
-            TailArgsK g = tail_args();
-            const int nq = g->U.nq, gb0 = g->U.gb0, ngb = g->U.ngb;
-            const double* pkrow = g->pk + myrow * nq;
-#pragma unroll
-            for (int e = 0; e < cpsu::NGB; ++e) {
-                const int q = 64 * (gb0 + e) + lane;
-                if (e < ngb && q < nq) own[e] = pkrow[q];
-            }
-            if (lane < g->U.wl) gvl = pkrow[g->U.col_l + lane];
-            if (lane < g->U.wr) gvr = pkrow[g->U.col_r + lane];
-        }
         // ---- 2. second derivatives, box, box rewritten: wave w <-> sequence w ----
         if ((wave < 2 || has_b) && !(CP_TAIL_ABLATE & 1)) {
             TailArgsK g = tail_args();
@@ -306,7 +297,7 @@ __device__ __forceinline__ void tail_stages(long long p, bool has_b, int t, cplx
         asm volatile("" : "+v"(lane));
         if (spline_wave && !(CP_TAIL_ABLATE & 8)) {
             TailArgsK g = tail_args();
-            tail_splice_row<SU>(seqs + (wave & 1) * N, g->out + myrow * g->U.nq, lane, gvl, gvr, own);
+            tail_splice_row<SU>(seqs + (wave & 1) * N, g->out + myrow * g->U.nq, lane, g->pk + myrow * g->U.nq);
         } else if (copy_wave && !(CP_TAIL_ABLATE & 16)) {
             TailArgsK g = tail_args();
             const int nq = g->U.nq, gfirst = g->U.gfirst, gend = g->U.gend;
@@ -446,7 +437,11 @@ __global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) 
     double* seqs = reinterpret_cast<double*>(lds);
     for (long long p = blockIdx.x; p < npairs; p += gridDim.x) {
         const bool has_b = 2 * p + 1 < CP_GEN()->ncosmo;
-        if (t == 0) bad_row[0] = bad_row[1] = 0;
+        if (t == 0) {
+            int zero;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zero));      // (formed here: the compiler kept a pair of zeros in vector registers over the loop, spilled it, and
+            bad_row[0] = bad_row[1] = zero;                     // reloaded it here -- a vector-memory wait for the previous pair's stores at the top of every pair)
+        }
         __syncthreads();      // the data region is free (and the tables are filled)
         int tt = t;
         asm volatile("" : "+v"(tt));      // (nothing derived from the thread's number is kept in registers from one pair to the next)

@@ -222,9 +222,9 @@ enum cp_pk_param { CP_PK_A_S = 0, CP_PK_N_S = 1, CP_PK_ALPHA_S = 2, CP_PK_BETA_S
  * d_k : (nk) wavenumbers in h/Mpc shared by the batch; d_kscale : NULL, or (ncosmo) per-cosmology factors applied to d_k
  * (brieden2022 evaluates at k_fid / rescale and k_fid * rescale, bao_filter.py:493-499); d_z : (nz) redshifts shared by the batch
  * (CP_PK_MATTER only).  d_out : (ncosmo, max(nz, 1), nk), k fastest, (Mpc/h)^3.
- * d_work : device workspace of cp_power_workspace_bytes(ncosmo) bytes for the fit coefficients of the cosmologies (EH98 / no-wiggle; unused
- * and may be NULL for CP_ENGINE_BBKS and CP_PK_PRIMORDIAL), owned by the caller and free again once the call's kernels have run on `stream`:
- * nothing is allocated inside the call.
+ * d_work : device workspace of cp_power_workspace_bytes(ncosmo) bytes for the constants of the cosmologies (fit coefficients, primordial constants:
+ * formed by one lane per cosmology in front of the evaluation, read back by it through scalar loads), owned by the caller and free again once the call's
+ * kernels have run on `stream`: nothing is allocated inside the call.
  * ncdm (here and in every entry point below that takes one): the massive-neutrino tables of the same cosmologies (cp_ncdm_tables), NULL or nspecies == 0
  * for none.  The fits themselves do not know massive neutrinos (their scalars use omega_cdm + omega_b, eisenstein_hu.py:37-38) and the reference computes
  * with them all the same (its warnings are commented out, eisenstein_hu.py:21-33): the species enter through the background -- Omega0_m of pk_callable
