@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 #include <limits>
 #include <vector>
 
@@ -160,6 +161,16 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     double inc_k = 0.;          // inc of interval k (needed by both eliminations)
     double dp = 0., dq = 0.;    // running right-hand sides of the forward / backward eliminations
     if (!TIME) {
+        // what the wave knows of its samples (cp_cosmo_common.h: inv_efunc_grid_wave): scalar branches instead of per-lane ones
+        const bool wave_fld = __any(!gc.lambda);
+        const bool wave_safe = CP_BG_LEAN_ORDINATE && !NCDM && __all(gc.Om >= 0. && gc.Or >= 0. && gc.Ode >= 0. && gc.Ok >= 0.);
+        auto sweeps = [&](auto safe_tag) {
+        constexpr bool SAFE = decltype(safe_tag)::value;
+        auto integrand = [&](double zz, double lzp1, double izp1) {
+            if (!CP_BG_LEAN_ORDINATE) return (kCkms / 100.) * inv_efunc_ln(c, zz, lzp1, izp1, &mt);
+            return (kCkms / 100.) * inv_efunc_grid_wave<SAFE>(gc, c, zz, lzp1, izp1, &mt, wave_fld);
+        };
+        fprev = integrand(T.zc[0], T.lk[0], T.ik[0]);
         // The intervals 0 .. k in knot order (the integral up to the sample and the forward elimination, exact), then the intervals above the
         // sample from `reach` knots above it downwards: the backward elimination forgets where it started at the rate of its multipliers
         // u_j / pivot_j (T.reach: after that many knots CP_BG_REACH_LEFT = 1e-13 of it is left, build_pivots), so the grid above -- it runs to z = 9999, a sample at
@@ -203,6 +214,9 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
             }
             if (bad) dq = nan;
         }
+        };
+        if (wave_safe) sweeps(std::true_type{});
+        else sweeps(std::false_type{});
     } else {
     const double f_last = integrand(T.zc[NK - 1], T.lk[NK - 1], T.ik[NK - 1]);
     for (int it = 0; it < NK - 1; ++it) {

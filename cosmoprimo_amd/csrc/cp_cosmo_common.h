@@ -162,6 +162,26 @@ __device__ __forceinline__ double rsqrt_any(double x) {      // 1 / sqrt(x): x =
     return __builtin_isfinite(y) && y != 0. ? r : y;
 }
 
+// ... with what a whole wave knows about its samples (bg_kernel's distance sweeps: two ordinates per interval, the kernel's whole cost):
+// wave_fld -- some lane of the wave has a dark-energy fluid: the exponential is evaluated (for all lanes, a select keeps the cube for the lanes with a
+// cosmological constant: the same values as the per-lane branch, whose two sides a mixed wave ran one after the other behind exec-mask bookkeeping);
+// no lane has one: it is not.  SAFE -- every density parameter of every lane is >= 0: E^2 is a sum of positive terms, its reciprocal root needs no
+// select for zero / infinite / NaN estimates (the same arithmetic otherwise).  Both are wave-uniform: scalar branches.
+template <bool SAFE>
+__device__ __forceinline__ double inv_efunc_grid_wave(const GridCosmo& g, const Cosmo& c, double z, double lzp1, double izp1, const cpmath::MathTables* mt, bool wave_fld) {
+    const double zp1 = 1. + z;
+    double m = g.Om;
+    if (c.nsp) m += ncdm_eval(c, z, 0) * (1. / kRhoCrit);
+    double growth = izp1 * izp1 * izp1;
+    if (wave_fld) {
+        const double ex = cpmath::exp_tab_core(fma(g.ea, lzp1, g.eb * (izp1 - 1.)), mt);
+        growth = g.lambda ? growth : ex;
+    }
+    const double rc = fma(g.Ok, izp1, fma(g.Or, zp1, m) + g.Ode * growth);
+    const double x = rc * (zp1 * zp1 * zp1);
+    return SAFE ? rsqrt_pos(x) : rsqrt_any(x);
+}
+
 __device__ __forceinline__ double inv_efunc_grid(const GridCosmo& g, const Cosmo& c, double z, double lzp1, double izp1, const cpmath::MathTables* mt) {
     const double zp1 = 1. + z;
     double m = g.Om;

@@ -14,6 +14,9 @@ namespace cpmath {
 #ifndef CP_ASM_FMA      // 0: plain fma() (measurements: tools/ab_asm_fma.sh)
 #define CP_ASM_FMA 1
 #endif
+#ifndef CP_ASM_FMA_POLY      // the same for the polynomial form exp_mid (what sigma_rz_kernel evaluates: its tables are off); 0: plain fma() (measurements).  Round 5
+#define CP_ASM_FMA_POLY 1    // measured it slower (18 -> 42 spilled registers in sigma_rz_kernel); without spills, with the merged reciprocals: config 3 -3 % (profiles/r6_eh_variants.txt)
+#endif
 __device__ __forceinline__ double horner(double p, double r, double c) {
 #if CP_ASM_FMA && defined(__HIP_DEVICE_COMPILE__)
     double d;
@@ -83,16 +86,21 @@ __device__ __forceinline__ double exp_mid(double x) {
     double r = fma(-n, 0.6931471803691238, x);
     r = fma(-n, 1.9082149292705877e-10, r);
     double p = 1. / 6227020800.;
-    p = fma(p, r, 1. / 479001600.);
-    p = fma(p, r, 1. / 39916800.);
-    p = fma(p, r, 1. / 3628800.);
-    p = fma(p, r, 1. / 362880.);
-    p = fma(p, r, 1. / 40320.);
-    p = fma(p, r, 1. / 5040.);
-    p = fma(p, r, 1. / 720.);
-    p = fma(p, r, 1. / 120.);
-    p = fma(p, r, 1. / 24.);
-    p = fma(p, r, 1. / 6.);
+#if CP_ASM_FMA_POLY
+#define CP_POLY_STEP(p, r, c) horner(p, r, c)
+#else
+#define CP_POLY_STEP(p, r, c) fma(p, r, c)
+#endif
+    p = CP_POLY_STEP(p, r, 1. / 479001600.);
+    p = CP_POLY_STEP(p, r, 1. / 39916800.);
+    p = CP_POLY_STEP(p, r, 1. / 3628800.);
+    p = CP_POLY_STEP(p, r, 1. / 362880.);
+    p = CP_POLY_STEP(p, r, 1. / 40320.);
+    p = CP_POLY_STEP(p, r, 1. / 5040.);
+    p = CP_POLY_STEP(p, r, 1. / 720.);
+    p = CP_POLY_STEP(p, r, 1. / 120.);
+    p = CP_POLY_STEP(p, r, 1. / 24.);
+    p = CP_POLY_STEP(p, r, 1. / 6.);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.);
     p = fma(p, r, 1.);

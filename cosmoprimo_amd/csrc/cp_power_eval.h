@@ -92,6 +92,12 @@ __device__ __forceinline__ EhPerCosmology eh_per_cosmology(const EhScalars& s, d
     return d;
 }
 
+// Three of the six quotients of the EH98 fit through ONE reciprocal (1 / X = A B / (X A B): nine instructions fewer per sample, 1e-16 of T).  Round 5
+// measured it slower (the longer live ranges cost spilled registers); with the spills gone (round 6) config 3 -1.5 %, wallish2018 +1.5 %
+// (profiles/r6_eh_variants.txt).  0: the six reciprocals (measurements: tools/ab_variants.sh)
+#ifndef CP_EH_MERGED_RECIP
+#define CP_EH_MERGED_RECIP 1
+#endif
 #ifndef CP_MATH_TABLES_OFF      // 1: the polynomial forms everywhere (measurements)
 #define CP_MATH_TABLES_OFF 0
 #endif
@@ -111,12 +117,22 @@ __device__ __forceinline__ double transfer_eh_core(const EhPerCosmology& d, doub
     const double q2 = q * q;
     // T_c = f ln_beta / d1 + (1 - f) ln_beta / d2
     const double d1 = ln_beta + C_noalpha * q2, d2 = ln_beta + C_alpha * q2;
-    const double T_c = ln_beta * fma(f, d2 - d1, d1) * recip(d1 * d2);
     // 1 + (beta / ks)^3 = (ks^3 + beta^3) / ks^3
     const double ks3 = ks * ks * ks;
     const double ks_tilde = ks * ks * rcbrt(ks3 + d.beta_node3);         // k rs_drag / cbrt(1 + (beta_node / ks)^3)
+#if CP_EH_MERGED_RECIP
+    // the three quotients 1 / (d1 d2), 1 / A, 1 / B (A, B: the denominators of T_b_1, T_b_2) through ONE reciprocal: 1 / (X A B) = w, 1 / X = w A B, ...
+    const double X = d1 * d2, A = (ln_nobeta + C_noalpha * q2) * fma(ks52, ks52, 1.), B = ks3 + d.beta_b3;
+    const double AB = A * B, XA = X * A;
+    const double w = recip(X * AB);
+    const double T_c = ln_beta * fma(f, d2 - d1, d1) * (w * AB);
+    const double T_b_1 = ln_nobeta * (w * (X * B));
+    const double T_b_2 = d.alpha_b * ks3 * (w * XA) * (mt ? exp_tab(-silk14, mt) : exp_mid(-silk14));
+#else
+    const double T_c = ln_beta * fma(f, d2 - d1, d1) * recip(d1 * d2);
     const double T_b_1 = ln_nobeta * recip((ln_nobeta + C_noalpha * q2) * fma(ks52, ks52, 1.));
     const double T_b_2 = d.alpha_b * ks3 * recip(ks3 + d.beta_b3) * (mt ? exp_tab(-silk14, mt) : exp_mid(-silk14));
+#endif
     const double sinc = ks_tilde == 0. ? 1. : sin_bounded(ks_tilde) * recip(ks_tilde);   // numpy.sinc(x / pi)
     const double T_b = sinc * (T_b_1 + T_b_2);
     return d.frac_b * T_b + (1 - d.frac_b) * T_c;
