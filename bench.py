@@ -398,8 +398,6 @@ def main_split(args, config):
     """--config 4 / 5: strong split of the BASELINE 8-GPU workloads over the ranks, no data-path collective; rank 0 prints one JSON line."""
     import torch
     import torch.distributed as dist
-    global RAMP_S
-    RAMP_S = 0.     # the W untimed steps of this mode are whole passes over the rank's share (hundreds of ms each): they are the ramp
     rank, local_rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
@@ -407,6 +405,18 @@ def main_split(args, config):
     if launched:
         dist.init_process_group('nccl', device_id=dev)
         dist.barrier()      # communicator built here, not at the barrier in front of the timed steps
+    line = split_line(args, config, torch, dist, dev, rank, world, launched, args.steps, args.warmup, (args.gather or world > 1) and not args.no_gather)
+    if rank == 0:
+        print(json.dumps(line))
+    if launched:
+        dist.destroy_process_group()
+
+
+def split_line(args, config, torch, dist, dev, rank, world, launched, steps, warmup, gather):
+    """The JSON object of a strong split of BASELINE config 4 / 5 over the ranks of an initialised process group (every rank calls this; rank 0 gets
+    the object, the others None): the line of ``--config 4 / 5``, and what a bare ``--gpus N > 1`` run embeds under "split_configs"."""
+    global RAMP_S
+    RAMP_S = 0.     # the W untimed steps of this mode are whole passes over the rank's share (hundreds of ms each): they are the ramp
     import cosmoprimo_amd as cp
     from cosmoprimo_amd.distributed import shard_range, gather_rows
     total = args.rows if args.rows != ROWS_PER_GPU else (1000000 if config == 4 else 10000000)
@@ -419,20 +429,20 @@ def main_split(args, config):
         full = config5_samples(total, 3, torch, torch.device('cpu'))
         mine = tuple(v[start:stop].to(dev) for v in full)
         run = lambda check=False: config5(torch, dev, *mine, reps=1, spot_check=check)      # noqa: E731
-    for _ in range(max(1, args.warmup)):
+    for _ in range(max(1, warmup)):
         run()
     torch.cuda.synchronize(dev)
     if launched:
         dist.barrier()
     tic = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         last = run()
     torch.cuda.synchronize(dev)
     t_done = time.perf_counter()
     if launched:
         dist.barrier()
     elapsed = time.perf_counter() - tic
-    own_ms = (t_done - tic) / args.steps * 1e3      # this rank's own steps, before it waited for the others
+    own_ms = (t_done - tic) / steps * 1e3      # this rank's own steps, before it waited for the others
     rank_ms = [own_ms]
     checked = run(check=True) if rank == 0 else None      # untimed: the rank's share once more with the oracle spot check of each config
     gather_ms = None
@@ -443,7 +453,7 @@ def main_split(args, config):
         every = torch.zeros(world, device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(every, torch.tensor([own_ms], device=dev, dtype=torch.float64))
         rank_ms = [float(v) for v in every]
-        if args.gather:
+        if gather:
             local = torch.zeros((stop - start, 1024 if config == 4 else 1), dtype=torch.float64, device=dev)      # the shape of a rank's results
             gather_rows(local, n_total=total)
             torch.cuda.synchronize(dev)
@@ -453,23 +463,23 @@ def main_split(args, config):
             torch.cuda.synchronize(dev)
             dist.barrier()
             gather_ms = (time.perf_counter() - t0) * 1e3
-    if rank == 0:
-        units = total * (2 if config == 4 else 1)       # config 4: every vector goes through both filters
-        line = {'metric': 'BAO-filtered P(k) vectors/sec (wallish2018 + brieden2022, nk=1024)' if config == 4 else 'comoving_radial_distance samples/sec',
-                'value': units * args.steps / elapsed, 'unit': 'filtered vectors/s' if config == 4 else 'samples/s', 'n_gpus': world, 'steps': args.steps,
-                'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-                'dtype': 'f64', 'data': 'synthetic',
-                'config': {'workload': 'config %d: %d %s split over %d GPU(s) in contiguous blocks, no collective' % (
-                    config, total, 'EH98 P(k) vectors through both filters' if config == 4 else '(Omega_m, w0, wa, z) samples', world),
-                    'per_gpu': stop - start, 'rccl_ranks': world if launched else 0},
-                'ms_per_step_rank_min': min(rank_ms), 'ms_per_step_rank_max': max(rank_ms), 'ms_per_step_by_rank': rank_ms,
-                'parity_spot_check': ({e: checked[e]['parity_spot_check'] for e in checked} if config == 4 else checked['parity_spot_check']),
-                'rank0_detail': last}
-        if gather_ms is not None:
-            line['gather_ms'] = gather_ms
-        print(json.dumps(line))
-    if launched:
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    units = total * (2 if config == 4 else 1)       # config 4: every vector goes through both filters
+    line = {'metric': 'BAO-filtered P(k) vectors/sec (wallish2018 + brieden2022, nk=1024)' if config == 4 else 'comoving_radial_distance samples/sec',
+            'value': units * steps / elapsed, 'unit': 'filtered vectors/s' if config == 4 else 'samples/s', 'n_gpus': world, 'steps': steps,
+            'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'config %d: %d %s split over %d GPU(s) in contiguous blocks, no collective' % (
+                config, total, 'EH98 P(k) vectors through both filters' if config == 4 else '(Omega_m, w0, wa, z) samples', world),
+                'per_gpu': stop - start, 'rccl_ranks': world if launched else 0},
+            'ms_per_step_rank_min': min(rank_ms), 'ms_per_step_rank_max': max(rank_ms), 'ms_per_step_by_rank': rank_ms,
+            'parity_spot_check': ({e: checked[e]['parity_spot_check'] for e in checked} if config == 4 else checked['parity_spot_check']),
+            'rank0_detail': last}
+    if gather_ms is not None:
+        line['gather_ms'] = gather_ms
+        line['value_with_gather'] = units / (elapsed / steps + gather_ms * 1e-3)      # a step followed by the gather of its results
+    return line
 
 
 def _launch_ranks_if_needed(args):
@@ -507,11 +517,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rows', type=int, default=ROWS_PER_GPU, help='rows per GPU (default: the config-2 batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--gather', action='store_true', help='also time the final RCCL all_gather of the result shards (reported separately)')
+    ap.add_argument('--gather', action='store_true', help='also time the final RCCL all_gather of the result shards (reported separately); the default for N > 1')
+    ap.add_argument('--no-gather', action='store_true', help='N > 1: skip the timing of the final all_gather')
     ap.add_argument('--config', type=int, default=2, choices=[2, 4, 5], help='BASELINE.json config: 2 (headline, weak scaling), 4 or 5 (strong splits)')
     ap.add_argument('--ramp-ms', type=float, default=300., help='untimed load before the warmup steps (and before each secondary config), to reach the sustained device state')
     ap.add_argument('--launcher', action='store_true', help='start the rank(s) through torch.distributed.run even for --gpus 1 (RCCL initialised); N > 1 always does')
-    ap.add_argument('--no-secondary', action='store_true', help='skip the configs 3 / 4 / 5 numbers of the N = 1 line')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the configs 3 / 4 / 5 numbers of the N = 1 line (and the split configs 4 / 5 of an N > 1 line)')
+    ap.add_argument('--split-configs', action='store_true', help='under a launcher: the strong splits of configs 4 and 5 on the line ("split_configs"); the default for N > 1')
     args = ap.parse_args()
     _launch_ranks_if_needed(args)
     if args.config != 2:
@@ -607,16 +619,17 @@ def main():
     per_step = [s.elapsed_time(e) for s, e in zip(starts, ends)]
     kernel_ms_each, kernel_ms_min = float(np.mean(per_step)), float(np.min(per_step))
 
-    # the same K steps through the product API (cp.PowerToCorrelation.__call__ on the resident tensor: output allocation, plan
-    # lookup and the ctypes call included, no host synchronisation inside)
+    # the same K steps through the product API (cp.PowerToCorrelation.__call__ on the resident tensor into a resident result: plan
+    # lookup, argument checks and the ctypes call included, no allocation, no host synchronisation inside)
+    out_api = torch.empty_like(out)      # the caller's result buffer (FFTlog.__call__(out=)): a sampler keeps one, as this loop does
     for _ in range(max(1, args.warmup)):
-        f(rows)
+        f(rows, out=out_api)
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
     tic_api = time.perf_counter()
     for i in range(args.steps):
-        s_api, xi_api = f(rows)
+        s_api, xi_api = f(rows, out=out_api)
     torch.cuda.synchronize(dev)
     if distributed:
         dist.barrier()
@@ -634,7 +647,7 @@ def main():
         every = torch.zeros(world, device=dev, dtype=torch.float64)
         dist.all_gather_into_tensor(every, torch.tensor(rank_ms, device=dev, dtype=torch.float64))
         rank_ms = [float(v) for v in every]      # a straggler shows at a glance on the first multi-GPU run
-        if args.gather:
+        if (args.gather or world > 1) and not args.no_gather:
             from cosmoprimo_amd.distributed import gather_rows
             full = torch.empty((world * nb, N_K), dtype=out.dtype, device=dev)
             gather_rows(out, n_total=world * nb, out=full)      # equal shards: one all_gather_into_tensor into the preallocated result
@@ -701,12 +714,28 @@ def main():
         if world == 1 and not args.no_secondary:
             global RAMP_S
             RAMP_S = args.ramp_ms * 1e-3
-            del rows, out
+            del rows, out, out_api, xi_api
             torch.cuda.empty_cache()
             line['secondary'] = secondary(cp, torch, dev)
         if gather_ms is not None:
             line['gather_ms'] = gather_ms
-            line['value_with_gather'] = nb * world / (elapsed / args.steps + gather_ms * 1e-3)
+            line['value_with_gather'] = nb * world / (elapsed / args.steps + gather_ms * 1e-3)      # a step followed by the gather of its results
+    if distributed and (args.split_configs or (world > 1 and not args.no_secondary)):
+        # BASELINE configs 4 and 5 are DEFINED on the 8 GPUs of a node: a multi-GPU run reports their strong splits on the same line (every rank takes part:
+        # the barriers and the max over ranks are collectives), a few steps each
+        try:
+            del rows, out, out_api, xi_api
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        split = {}
+        for config in (4, 5):
+            res = split_line(args, config, torch, dist, dev, rank, world, True, min(args.steps, 5), 1, not args.no_gather)
+            if rank == 0:
+                split['config%d' % config] = res
+        if rank == 0:
+            line['split_configs'] = split
+    if rank == 0:
         print(json.dumps(line))
     if distributed:
         dist.destroy_process_group()

@@ -10,7 +10,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libcosmoprimo_amd.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 CP_OK, CP_EINVAL, CP_EUNSUPPORTED, CP_EDEVICE, CP_ENOMEM = range(5)
 EXTRAP_CONSTANT, EXTRAP_EDGE, EXTRAP_LOGLOG = range(3)
@@ -50,6 +50,7 @@ SIGNATURES = {
                                              ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'cp_derived_parameters': (ctypes.c_int, [ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_background_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
+    'cp_background_init': (ctypes.c_int, [ctypes.c_int]),
     'cp_distance_from_radial': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'cp_ncdm_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
     'cp_growth_ode_knots': (ctypes.c_int, [_c_double_p, ctypes.c_int]),
@@ -246,6 +247,17 @@ def load():
         raise LibraryError('ABI version mismatch: library {}, bindings {}'.format(lib.cp_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+_background_ready = set()
+
+
+def background_init(device_index):
+    """The knot tables of the background kernels on device ``device_index`` (``cp_background_init``: one allocation and synchronous uploads, once per
+    device), so that the entry points that read them stay asynchronous and allocation-free from their first call on."""
+    if device_index not in _background_ready:
+        check(load().cp_background_init(int(device_index)))
+        _background_ready.add(device_index)
 
 
 def check(status):

@@ -59,6 +59,7 @@ class NcdmTables(object):
                 raise ValueError('per-cosmology arrays must have length ncosmo = {:d}, got {:d}'.format(self.ncosmo, t.numel()))
         nodes, weights = np.polynomial.laguerre.laggauss(100)
         nodes, weights = np.ascontiguousarray(nodes, dtype='f8'), np.ascontiguousarray(weights, dtype='f8')
+        _lib.background_init(self.device.index)      # (the knot tables of the device: once, not inside an asynchronous entry point)
         _lib.check(_lib.load().cp_ncdm_tables(self.ncosmo, self.nspecies, ch, cT, ctypes.cast(cm, ctypes.c_void_p), ctypes.cast(ct, ctypes.c_void_p), 100,
                                               _lib.as_double_p(nodes), _lib.as_double_p(weights), self.tab.data_ptr(), self.device.index,
                                               torch.cuda.current_stream(self.device).cuda_stream))
@@ -83,6 +84,7 @@ def growth_ode_tables(params=None, mass='m', ncdm=None, ncosmo=1, device=None):
             raise ValueError('per-cosmology arrays must have length ncosmo = {:d}, got {:d}'.format(ncosmo, n))
     tab = torch.empty((ncosmo, 2, _lib.GROWTH_NKNOTS), dtype=torch.float64, device=device)
     cn = ncdm.struct() if ncdm is not None and ncdm.nspecies else None
+    _lib.background_init(device.index)
     _lib.check(_lib.load().cp_growth_ode_tables(ncosmo, ctypes.cast(cparams, ctypes.c_void_p), 0, ctypes.byref(cn) if cn is not None else None,
                                                 {'m': 0, 'cb': 1}[mass], tab.data_ptr(), device.index, torch.cuda.current_stream(device).cuda_stream))
     knots = np.empty(_lib.GROWTH_NKNOTS)
@@ -173,6 +175,7 @@ def distance(kind, z, params=None, Omega_m=None, per_cosmology_z=False, device=N
             if ncdm.ncosmo != ncosmo:
                 raise ValueError('massive-neutrino tables hold {:d} cosmologies, the parameters {:d}'.format(ncdm.ncosmo, ncosmo))
             cn = ncdm.struct(species)
+        _lib.background_init(device.index)
         _lib.check(_lib.load().cp_background_eval(ncosmo, nz, ctypes.cast(cparams, ctypes.c_void_p), int(Omega_m is not None),
                                                   ctypes.byref(cn) if cn is not None else None, tz.data_ptr(), int(not per_cosmology_z), out.data_ptr(),
                                                   _lib.BG_KINDS[kind], device.index, stream))

@@ -17,7 +17,9 @@
 // ALU-bound (pow, exp, sqrt per E(z)); HBM traffic is 8 bytes per parameter array + 8 in + 8 out per sample.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
+#include <mutex>
 #include <type_traits>
 #include <limits>
 #include <vector>
@@ -353,20 +355,32 @@ void build_tables(TablesN<NK_TIME>& t) {
     build_pivots(t);
 }
 
-// one device copy of the grid tables per device and grid, created on first use
+// one device copy of the grid tables per device and grid: created by cp_background_init(device), or -- for callers that did not ask -- by the first
+// entry point that needs it (a hipMalloc and a synchronous upload inside that one call; the mutex keeps two host threads from both doing it)
+std::mutex& table_mutex() {
+    static std::mutex m;
+    return m;
+}
+
 template <int NK>
 TablesN<NK>* device_tables(int device) {
-    static TablesN<NK>* cache[64] = {nullptr};
+    static std::atomic<TablesN<NK>*> cache[64];
     if (device < 0 || device >= 64) return nullptr;
-    if (!cache[device]) {
+    TablesN<NK>* d = cache[device].load(std::memory_order_acquire);
+    if (d) return d;
+    std::lock_guard<std::mutex> lock(table_mutex());
+    d = cache[device].load(std::memory_order_acquire);
+    if (!d) {
         std::vector<TablesN<NK>> h(1);
         build_tables(h[0]);
-        TablesN<NK>* d = nullptr;
         if (hipMalloc(&d, sizeof(TablesN<NK>)) != hipSuccess) return nullptr;
-        if (hipMemcpy(d, h.data(), sizeof(TablesN<NK>), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        cache[device] = d;
+        if (hipMemcpy(d, h.data(), sizeof(TablesN<NK>), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return nullptr;
+        }
+        cache[device].store(d, std::memory_order_release);
     }
-    return cache[device];
+    return d;
 }
 
 // ---- sound horizon: the reference's fixed-depth Romberg rule (jax.py:519-660, divmax = 15: 2^15 + 1 integrand evaluations) ----
@@ -492,17 +506,23 @@ void build_ncdm_knots(double* zc) {
 }
 
 double* device_ncdm_knots(int device) {
-    static double* cache[64] = {nullptr};
+    static std::atomic<double*> cache[64];
     if (device < 0 || device >= 64) return nullptr;
-    if (!cache[device]) {
+    double* d = cache[device].load(std::memory_order_acquire);
+    if (d) return d;
+    std::lock_guard<std::mutex> lock(table_mutex());
+    d = cache[device].load(std::memory_order_acquire);
+    if (!d) {
         double h[CP_NCDM_NKNOTS];
         build_ncdm_knots(h);
-        double* d = nullptr;
         if (hipMalloc(&d, sizeof(h)) != hipSuccess) return nullptr;
-        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        cache[device] = d;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d);
+            return nullptr;
+        }
+        cache[device].store(d, std::memory_order_release);
     }
-    return cache[device];
+    return d;
 }
 
 constexpr int NCDM_MAX_SPECIES = 8;
@@ -584,6 +604,16 @@ __global__ __launch_bounds__(64) void ncdm_spline_kernel(const NcdmArgs A) {
 }  // namespace
 
 const double* cpcosmo::ncdm_knots_device(int device) { return device_ncdm_knots(device); }
+
+extern "C" int cp_background_init(int device) {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_background_init: cannot select device %d", device);
+    const bool ok = device_tables<NK_DIST>(device) && device_tables<NK_TIME>(device) && device_ncdm_knots(device);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (!ok) return cp::fail(CP_ENOMEM, "cp_background_init: cannot allocate the knot tables on device %d", device);
+    return CP_OK;
+}
 
 extern "C" int cp_growth_ode_knots(double* zc_out, int n) {
     if (!zc_out || n != CP_GROWTH_NKNOTS) return cp::fail(CP_EINVAL, "cp_growth_ode_knots: need a buffer of %d doubles", CP_GROWTH_NKNOTS);

@@ -1,6 +1,7 @@
 // cp_internal.h -- what the translation units of libcosmoprimo_amd.so share with each other besides the public C ABI (not installed, not part
 // of the ABI): views of plan internals for kernels that fuse several stages (cp_sigma.hip).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include "../../include/cosmoprimo_amd.h"
@@ -56,16 +57,16 @@ bool cp_splice_plan_uniform_view(const cp_splice_plan* plan, cpsu::Tables* out, 
 namespace cp {
 template <auto KERNEL>
 inline hipError_t allow_full_lds() {
-    static bool configured[64] = {false};      // benign race: two threads may both set the same attribute to the same value
+    static std::atomic<bool> configured[64];      // (zero-initialised; two threads may both set the same attribute to the same value: harmless, and no data race)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64 && configured[dev]) return hipSuccess;
+    if (dev >= 0 && dev < 64 && configured[dev].load(std::memory_order_acquire)) return hipSuccess;
     hipFuncAttributes attr;      // the limit covers static + dynamic LDS: a kernel with __shared__ variables of its own gets what they leave
     e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(KERNEL));
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)attr.sharedSizeBytes);
-    if (e == hipSuccess && dev >= 0 && dev < 64) configured[dev] = true;
+    if (e == hipSuccess && dev >= 0 && dev < 64) configured[dev].store(true, std::memory_order_release);
     return e;
 }
 

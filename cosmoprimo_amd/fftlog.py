@@ -364,7 +364,7 @@ class FFTlog(dv.Copyable):
         self.__dict__.pop('_device_tables', None)
         return plan
 
-    def __call__(self, fun, extrap=0, keep_padding=False, out_window=None):
+    def __call__(self, fun, extrap=0, keep_padding=False, out_window=None, out=None):
         """
         Perform the transforms (reference fftlog.py:198-241).
 
@@ -373,6 +373,9 @@ class FFTlog(dv.Copyable):
         keep_padding : return the padded transform.
         out_window : (first, count), not in the reference: the caller reads these entries of every output row only; the others are unspecified
             (the default transform then does not write them: cp_fftlog_execute_window).
+        out : not in the reference: a float64, contiguous tensor on the plan's device with the number of elements of the result, which the kernel
+            writes (nothing is allocated: a sampler calling with the same batch shape step after step keeps one result buffer); the returned
+            transform is a view of it.  Real transforms only (a ``complex=True`` result is a product formed after the kernel).
 
         Returns ``(y, fftloged)``, numpy for numpy input, torch (same device) for torch input.  Output is float64
         (complex128 for ``complex=True`` transforms) as in the reference.
@@ -406,7 +409,14 @@ class FFTlog(dv.Copyable):
         # pass over the batch, no host synchronisation.
         nbatch = int(np.prod(bshape[:-2] if nker > 1 else bshape[:-1], dtype='i8'))
         nout = npad if keep_padding else n
-        tout = torch.empty(bshape[:-1] + (nout,), dtype=torch.float64, device=dev)
+        if out is None:
+            tout = torch.empty(bshape[:-1] + (nout,), dtype=torch.float64, device=dev)
+        else:
+            if self._phase is not None:
+                raise ValueError('out= is for real transforms (complex=True multiplies the result by a phase behind the kernel)')
+            if not (_is_torch(out) and out.dtype == torch.float64 and out.device == dev and out.is_contiguous() and out.numel() == nbatch * nker * nout):
+                raise ValueError('out must be a contiguous float64 tensor of {:d} elements on {}'.format(nbatch * nker * nout, dev))
+            tout = out.view(bshape[:-1] + (nout,))
         if nbatch > 0 and out_window is not None:
             _lib.check(_lib.load().cp_fftlog_execute_window(plan.handle, tin.data_ptr(), tout.data_ptr(), nbatch, cl, vl, cr, vr, int(bool(keep_padding)),
                                                             int(out_window[0]), int(out_window[1]), torch.cuda.current_stream(dev).cuda_stream))

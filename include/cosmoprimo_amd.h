@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CP_ABI_VERSION 3
+#define CP_ABI_VERSION 4
 
 enum cp_status {
     CP_OK = 0,
@@ -170,6 +170,11 @@ int cp_derived_parameters(long long ncosmo, const cp_param* params, double* d_ou
 /* the 119 interpolation knots (host), get_default_z_interp('comoving_radial_distance'), cosmology.py:1947-1949 (n = 119),
  * or the 400 knots of time / age, cosmology.py:1945-1946 (n = 400) */
 int cp_background_knots(double* zc_out, int n);
+/* The knot tables the background kernels read (the 119- and 400-knot grids with their elimination factors, the massive-neutrino knots: 60 KB) onto
+ * `device`: one hipMalloc and synchronous uploads, once per device and process (idempotent, thread-safe).  A caller that wants every later entry
+ * point asynchronous and allocation-free calls this when it sets the device up (cosmoprimo_amd/background.py does, with the first Background of a
+ * device); without it the first cp_background_* / cp_ncdm_* / cp_power_* call that needs a table does the same work inside that call. */
+int cp_background_init(int device);
 /* the derived distances of ONE cosmology from its radial distances: d_chi, d_z, d_out (n) device (d_out may be d_chi), K = -Omega_k (100 / c)^2
  * (cosmology.py:397), kind one of CP_BG_ANGULAR_DIAMETER / CP_BG_COMOVING_TRANSVERSE / CP_BG_LUMINOSITY -- the last lines of the background kernel
  * (cosmology.py:1855-1912) as one pass over a catalogue whose radial distances come from the cosmology's table */

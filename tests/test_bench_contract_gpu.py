@@ -54,6 +54,14 @@ def test_one_rank_under_torchrun():
     for engine in ('wallish2018', 'brieden2022'):
         assert filt['parity_spot_check'][engine]['max_rel_err'] < 1e-9
     assert line['ms_per_step_rank_min'] <= line['ms_per_step_rank_max'] and len(line['ms_per_step_by_rank']) == 1
+    # what a multi-GPU run prints by default (here forced on one rank): the gather timed, the strong splits of configs 4 and 5 on the same line
+    multi = run(base + ['--master-port', '29544', 'bench.py', '--gpus', '1', '--rows', '3000', '--steps', '2', '--warmup', '1', '--ramp-ms', '20',
+                        '--no-cpu-baseline', '--no-secondary', '--split-configs', '--gather'])
+    check(multi, 2, 1)
+    assert multi['gather_ms'] > 0 and set(multi['split_configs']) == {'config4', 'config5'}
+    for name, unit in (('config4', 'filtered vectors/s'), ('config5', 'samples/s')):
+        sub = multi['split_configs'][name]
+        assert sub['unit'] == unit and sub['value'] > 0 and sub['scaling'] == 'strong' and sub['config']['rccl_ranks'] == 1 and sub['value_with_gather'] > 0
 
 
 def test_self_launch():

@@ -499,3 +499,65 @@ def test_engine_instance_gives_the_fused_result(cp, golden):
     s2, unfused = cp.PowerToCorrelation(k, ell=0, engine=Foreign(2048))(rows)
     for a, b in zip(unfused, ref):
         assert tilted_err(a, b, s0, 1.5) < TOL_NORM
+
+
+def test_result_buffer_of_the_caller(cp):
+    """``FFTlog.__call__(out=)``: the kernel writes the caller's tensor (no allocation per call), the result is a view of it; wrong buffers are refused."""
+    import torch
+    n = 256
+    k = np.logspace(-3, 2, n)
+    rows = torch.as_tensor(np.tile(k**-1.5, (9, 1)) * np.linspace(1., 2., 9)[:, None], device='cuda')
+    f1 = cp.PowerToCorrelation(k, ell=0)
+    s, ref = f1(rows)
+    buf = torch.empty(9 * n, dtype=torch.float64, device='cuda')
+    s2, got = f1(rows, out=buf)
+    assert got.data_ptr() == buf.data_ptr() and got.shape == (9, n) and torch.equal(got, ref)
+    f3 = cp.PowerToCorrelation(k, ell=[0, 2, 4])
+    buf3 = torch.empty((9, 3, n), dtype=torch.float64, device='cuda')
+    assert torch.equal(f3(rows[:, None, :], out=buf3)[1], f3(rows[:, None, :])[1])
+    for bad in (torch.empty(9 * n - 1, dtype=torch.float64, device='cuda'), torch.empty(9 * n, dtype=torch.float32, device='cuda'),
+                torch.empty(9 * n, dtype=torch.float64), torch.empty((9, 2 * n), dtype=torch.float64, device='cuda')[:, ::2]):
+        with pytest.raises(ValueError):
+            f1(rows, out=bad)
+    with pytest.raises(ValueError):
+        cp.PowerToCorrelation(k, ell=2, complex=True)(rows, out=buf)
+
+
+def test_two_host_threads_on_one_plan(cp):
+    """execute is thread-safe across distinct streams for one plan (read-only tables).  Two host threads, each with its own stream,
+    its own rows and its own output, hammer ONE cp_fftlog_plan through the C ABI at the same time; every result equals the one-thread result bit for bit."""
+    import threading
+    import torch
+    from cosmoprimo_amd import _lib
+    n, nb, reps = 2048, 4096, 12
+    k = np.logspace(-5, 2, n)
+    f = cp.PowerToCorrelation(k, ell=0)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    plan, lib = f._get_plan(dev), _lib.load()
+    rng = np.random.default_rng(11)
+    inputs = [torch.as_tensor(rng.uniform(0.5, 2., (nb, 1)) * k**-1.2, device=dev) for _ in range(2)]
+    expected = [f(rows)[1] for rows in inputs]
+    torch.cuda.synchronize()
+    outs = [[torch.empty_like(rows) for _ in range(reps)] for rows in inputs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    errors = []
+    start = threading.Barrier(2)
+
+    def work(i):
+        try:
+            start.wait()
+            for r in range(reps):
+                _lib.check(lib.cp_fftlog_execute(plan.handle, inputs[i].data_ptr(), outs[i][r].data_ptr(), nb, 0, 0., 0, 0., 0, streams[i].cuda_stream))
+            streams[i].synchronize()
+        except Exception as exc:      # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        for r in range(reps):
+            assert torch.equal(outs[i][r], expected[i]), (i, r)
