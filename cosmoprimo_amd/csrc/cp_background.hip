@@ -40,6 +40,7 @@ struct TablesN {
     double zc[NK], dx[NK], l[NK], u[NK], idf[NK], idb[NK], cp[NK], bq[NK], ra[NK], rb[NK];
     // log(1 + z) and 1 / (1 + z) at the knots and at the interval midpoints zc + dx / 2: every integrand ordinate is one of them
     double lk[NK], lm[NK], ik[NK], im[NK];
+    double pk[NK], pm[NK], ck[NK], cm[NK];      // 1 + z and its cube p (p p) at the knots and at the midpoints, as the ordinate forms them
     double h6[NK];            // dx / 6 (the same IEEE quotient the kernels used to form per interval: a division by 6 is not a multiplication, and it was a sixth of their instructions)
     int reach, reach_pad;     // knots after which the backward elimination has forgotten its start (CP_BG_REACH_LEFT of it left)
 };
@@ -164,24 +165,27 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     double dp = 0., dq = 0.;    // running right-hand sides of the forward / backward eliminations
     if (!TIME) {
         // what the wave knows of its samples (cp_cosmo_common.h: inv_efunc_grid_wave): scalar branches instead of per-lane ones
-        const bool wave_fld = __any(!gc.lambda);
+        const bool wave_fld = __any(!gc.lambda), wave_lambda = __any(gc.lambda);
         const bool wave_safe = CP_BG_LEAN_ORDINATE && !NCDM && __all(gc.Om >= 0. && gc.Or >= 0. && gc.Ode >= 0. && gc.Ok >= 0.);
         auto sweeps = [&](auto safe_tag) {
         constexpr bool SAFE = decltype(safe_tag)::value;
-        auto integrand = [&](double zz, double lzp1, double izp1) {
-            if (!CP_BG_LEAN_ORDINATE) return (kCkms / 100.) * inv_efunc_ln(c, zz, lzp1, izp1, &mt);
-            return (kCkms / 100.) * inv_efunc_grid_wave<SAFE>(gc, c, zz, lzp1, izp1, &mt, wave_fld);
+        auto knot = [&](int j) {      // the ordinate at knot j / at the midpoint of interval j: every argument from the grid's tables
+            if (!CP_BG_LEAN_ORDINATE) return (kCkms / 100.) * inv_efunc_ln(c, T.zc[j], T.lk[j], T.ik[j], &mt);
+            return (kCkms / 100.) * inv_efunc_grid_wave<SAFE>(gc, c, NCDM ? T.zc[j] : 0., T.lk[j], T.ik[j], T.pk[j], T.ck[j], &mt, wave_fld, wave_lambda);
         };
-        fprev = integrand(T.zc[0], T.lk[0], T.ik[0]);
+        auto middle = [&](int j) {
+            if (!CP_BG_LEAN_ORDINATE) return (kCkms / 100.) * inv_efunc_ln(c, T.zc[j] + T.dx[j] / 2, T.lm[j], T.im[j], &mt);
+            return (kCkms / 100.) * inv_efunc_grid_wave<SAFE>(gc, c, NCDM ? T.zc[j] + T.dx[j] / 2 : 0., T.lm[j], T.im[j], T.pm[j], T.cm[j], &mt, wave_fld, wave_lambda);
+        };
+        fprev = knot(0);
         // The intervals 0 .. k in knot order (the integral up to the sample and the forward elimination, exact), then the intervals above the
         // sample from `reach` knots above it downwards: the backward elimination forgets where it started at the rate of its multipliers
         // u_j / pivot_j (T.reach: after that many knots CP_BG_REACH_LEFT = 1e-13 of it is left, build_pivots), so the grid above -- it runs to z = 9999, a sample at
         // z < 3 sits in interval 31 at most -- contributes nothing a double can hold.  65 intervals instead of 118 for config 5, and within a
         // pass all lanes that are still busy walk the same interval: the table reads are broadcasts.
         for (int idx = 0; idx <= k; ++idx) {
-            const double h = T.dx[idx];
-            const double fm = integrand(T.zc[idx] + h / 2, T.lm[idx], T.im[idx]);
-            const double fe = integrand(T.zc[idx + 1], T.lk[idx + 1], T.ik[idx + 1]);
+            const double fm = middle(idx);
+            const double fe = knot(idx + 1);
             const double inc = T.h6[idx] * (fprev + 2 * fm + 2 * fm + fe);  // h / 6 (...), jax.py:709 with k2 == k3
             fprev = fe;
             const double d = T.ra[idx] * inc_prev + T.rb[idx] * inc;      // knot idx: d = ra * inc_{idx-1} + rb * inc_idx
@@ -191,12 +195,11 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
             inc_prev = inc;
         }
         const int top = k + 1 + T.reach < NK - 1 ? k + 1 + T.reach : NK - 1;      // intervals k + 1 .. top - 1, visited top down
-        fprev = integrand(T.zc[top], T.lk[top], T.ik[top]);
+        fprev = knot(top);
         inc_prev = 0.;
         for (int idx = top - 1; idx > k; --idx) {
-            const double h = T.dx[idx];
-            const double fm = integrand(T.zc[idx] + h / 2, T.lm[idx], T.im[idx]);
-            const double fe = integrand(T.zc[idx], T.lk[idx], T.ik[idx]);
+            const double fm = middle(idx);
+            const double fe = knot(idx);
             const double inc = T.h6[idx] * (fe + 2 * fm + 2 * fm + fprev);
             fprev = fe;
             const double d = T.ra[idx + 1] * inc + T.rb[idx + 1] * inc_prev;      // knot idx + 1: d = ra * inc_idx + rb * inc_{idx+1}
@@ -210,8 +213,8 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
         if (top < NK - 1 && (c.Omega_k < 0. || c.Omega_de < 0. || c.Omega_cdm + c.Omega_b < 0.)) {
             bool bad = false;
             for (int idx = top; idx < NK - 1; ++idx) {
-                const double fm = integrand(T.zc[idx] + T.dx[idx] / 2, T.lm[idx], T.im[idx]);
-                const double fe = integrand(T.zc[idx + 1], T.lk[idx + 1], T.ik[idx + 1]);
+                const double fm = middle(idx);
+                const double fe = knot(idx + 1);
                 bad |= !(fabs(fm) <= 1.7976931348623157e308) || !(fabs(fe) <= 1.7976931348623157e308);
             }
             if (bad) dq = nan;
@@ -297,6 +300,10 @@ void build_pivots(TablesN<NK>& t) {
         t.lm[i] = std::log1p(t.zc[i] + t.dx[i] / 2);
         t.ik[i] = 1. / (1. + t.zc[i]);
         t.im[i] = 1. / (1. + (t.zc[i] + t.dx[i] / 2));
+        t.pk[i] = 1. + t.zc[i];
+        t.pm[i] = 1. + (t.zc[i] + t.dx[i] / 2);
+        t.ck[i] = t.pk[i] * (t.pk[i] * t.pk[i]);
+        t.cm[i] = t.pm[i] * (t.pm[i] * t.pm[i]);
     }
     std::vector<double> b(n);
     t.l[0] = 0.; b[0] = 2. * t.dx[0]; t.u[0] = t.dx[0]; t.ra[0] = 0.; t.rb[0] = 3.;

@@ -165,20 +165,27 @@ __device__ __forceinline__ double rsqrt_any(double x) {      // 1 / sqrt(x): x =
 // ... with what a whole wave knows about its samples (bg_kernel's distance sweeps: two ordinates per interval, the kernel's whole cost):
 // wave_fld -- some lane of the wave has a dark-energy fluid: the exponential is evaluated (for all lanes, a select keeps the cube for the lanes with a
 // cosmological constant: the same values as the per-lane branch, whose two sides a mixed wave ran one after the other behind exec-mask bookkeeping);
-// no lane has one: it is not.  SAFE -- every density parameter of every lane is >= 0: E^2 is a sum of positive terms, its reciprocal root needs no
+// no lane has one: it is not; wave_lambda -- some lane has a cosmological constant.  SAFE -- every density parameter of every lane is >= 0: E^2 is a sum of positive terms, its reciprocal root needs no
 // select for zero / infinite / NaN estimates (the same arithmetic otherwise).  Both are wave-uniform: scalar branches.
+// zp1 = 1 + z and zp1c = zp1 (zp1 zp1) come from the grid's tables as log(1 + z) and 1 / (1 + z) do (the same sums and products, formed once on the host:
+// four vector instructions fewer per ordinate); z itself is only looked at with massive neutrinos.
 template <bool SAFE>
-__device__ __forceinline__ double inv_efunc_grid_wave(const GridCosmo& g, const Cosmo& c, double z, double lzp1, double izp1, const cpmath::MathTables* mt, bool wave_fld) {
-    const double zp1 = 1. + z;
+__device__ __forceinline__ double inv_efunc_grid_wave(const GridCosmo& g, const Cosmo& c, double z, double lzp1, double izp1, double zp1, double zp1c,
+                                                      const cpmath::MathTables* mt, bool wave_fld, bool wave_lambda) {
     double m = g.Om;
     if (c.nsp) m += ncdm_eval(c, z, 0) * (1. / kRhoCrit);
-    double growth = izp1 * izp1 * izp1;
+    double growth;
     if (wave_fld) {
-        const double ex = cpmath::exp_tab_core(fma(g.ea, lzp1, g.eb * (izp1 - 1.)), mt);
-        growth = g.lambda ? growth : ex;
+        growth = cpmath::exp_tab_core(fma(g.ea, lzp1, g.eb * (izp1 - 1.)), mt);
+        if (wave_lambda) {      // (a wave of fluids only forms no cube and selects nothing: the empty statement keeps the compiler from turning the
+            asm volatile("");   // branch back into an unconditional cube and select)
+            growth = g.lambda ? izp1 * izp1 * izp1 : growth;
+        }
+    } else {
+        growth = izp1 * izp1 * izp1;
     }
     const double rc = fma(g.Ok, izp1, fma(g.Or, zp1, m) + g.Ode * growth);
-    const double x = rc * (zp1 * zp1 * zp1);
+    const double x = rc * zp1c;
     return SAFE ? rsqrt_pos(x) : rsqrt_any(x);
 }
 
