@@ -707,6 +707,26 @@ def _constrained_lsq_operator(gradient, precision, constraint_gradient, constrai
     return gradient.T.dot(to_params)
 
 
+def _constrained_lsq_steps(gradient, precision, constraint_gradient, constraint_matrix):
+    """
+    ``utils.LeastSquareSolver(..., compute_inverse=True)`` in the operation order of its ``compute`` and ``model`` (reference utils.py:218-232, 246-272):
+    constraint values c = C . delta, parameters = delta . P1 + c . P2 with (P1 | P2) the explicitly inverted Karush-Kuhn-Tucker matrix applied to
+    (G F | 1), model = parameters . G.  Returns the four host matrices (C, P1^T, P2^T, G^T) for dense operators applied in that order.
+
+    Why not the one (ndata, ndata) matrix of :func:`_constrained_lsq_operator`: for hinton2017 (degree 12: condition 5e12, the inverse off by 5e-6)
+    the reference's numbers follow from THIS inverse evaluated this way; the parameters are sums with 4e4 times their size in terms and the model
+    3e2, so any summation order reproduces them to 1e-12 -- whereas the products G^T P that form the single matrix cancel to 1e-10 of their terms
+    in its ENTRIES (numpy itself is 3e-10 from the reference through it, the device kernel's blocked sums 1e-7).
+    """
+    nparams, ndata = gradient.shape
+    nc = constraint_gradient.shape[-1]
+    hv = gradient * precision
+    invfisher = np.block([[hv.dot(gradient.T), -constraint_gradient], [constraint_gradient.T, np.zeros((nc, nc))]])
+    hv = np.block([[hv, np.zeros(constraint_gradient.shape)], [np.zeros((nc, ndata)), np.eye(nc)]])
+    proj = np.linalg.inv(invfisher).dot(hv)                  # (nparams + nc, ndata + nc): the reference's projector, transposed
+    return constraint_matrix, proj[:nparams, :ndata], proj[:nparams, ndata:], gradient.T
+
+
 def _end_constraints(n, order=2):
     """Rows picking delta[0], delta[1] - delta[0] (, second difference) and the same at the other end (reference bao_filter.py:226-229, 335)."""
     rows = []
@@ -762,8 +782,8 @@ class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         super(Hinton2017PowerSpectrumBAOFilter, self).__init__(pk_interpolator, **kwargs)
 
     def _fit_operator(self, imax):
-        """The weighted, end-pinned polynomial fit in log-log space as a dense operator, for a spectrum whose maximum sits at sample ``imax`` of the
-        fitted range (reference bao_filter.py:215-235: the weights dip around the maximum); kept per position."""
+        """The weighted, end-pinned polynomial fit in log-log space as dense operators (:func:`_constrained_lsq_steps`), for a spectrum whose maximum sits
+        at sample ``imax`` of the fitted range (reference bao_filter.py:215-235: the weights dip around the maximum); kept per position."""
         cache = self.__dict__.setdefault('_fit_operators', {})
         if imax not in cache:
             logk = np.log10(self.k[self.kmask])
@@ -771,9 +791,16 @@ class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
             gradient = np.array([((logk - np.mean(logk)) / np.std(logk))**i for i in range(self.degree + 1)])
             cg = np.column_stack([gradient[..., 0], gradient[..., 1] - gradient[..., 0], gradient[..., 2] - 2. * gradient[..., 1] + gradient[..., 0],
                                   gradient[..., -1], gradient[..., -2] - gradient[..., -1], gradient[..., -3] - 2. * gradient[..., -2] + gradient[..., -1]])
-            A = _constrained_lsq_operator(gradient, w**2, cg, _end_constraints(logk.size, order=3), inverse=True)
-            cache[imax] = LinearOperator.dense(A, device=self.device)
+            steps = _constrained_lsq_steps(gradient, w**2, cg, _end_constraints(logk.size, order=3))
+            cache[imax] = tuple(LinearOperator.dense(np.ascontiguousarray(m), device=self.device) for m in steps)
         return cache[imax]
+
+    @staticmethod
+    def _apply_fit(ops, logpk):
+        """The reference's ``solver(logpk, constraint=...)`` + ``solver.model()`` (bao_filter.py:229-235) in its order of operations, on rows of log10 P."""
+        to_constraint, from_data, from_constraint, to_model = ops
+        params = from_data(logpk) + from_constraint(to_constraint(logpk).contiguous())      # (ncol, degree + 1)
+        return to_model(params.contiguous())
 
     def _prepare(self):
         """The fit's weights follow the maximum of the FIRST column of the spectrum ("approximation", :219).  A batch of cosmologies (a batched ``cosmo``, or a
@@ -794,11 +821,11 @@ class Hinton2017PowerSpectrumBAOFilter(BasePowerSpectrumBAOFilter):
         res = self._pk_rows.clone()
         logpk = torch.log10(self._pk_rows[:, mask]).contiguous()
         fitted = torch.empty_like(logpk)
-        for op, rows in self._groups:
+        for ops, rows in self._groups:
             if rows is None:
-                fitted = op(logpk)
+                fitted = self._apply_fit(ops, logpk)
             else:
-                fitted[rows] = op(logpk[rows].contiguous())
+                fitted[rows] = self._apply_fit(ops, logpk[rows].contiguous())
         res[:, mask] = 10**fitted
         self._pknow_rows = res
 

@@ -8,6 +8,9 @@ import pytest
 from oracle.gen_golden import fftlog_fuzz_configs, fftlog_fuzz_build, fftlog_fuzz_stride, fftlog_fuzz_error, FFTLOG_FUZZ_N
 
 pytestmark = pytest.mark.gpu
+# error / movement of the reference's own result, measured over the configurations above 1e-12 (profiles/r6_fftlog_fuzz_errors.txt, tools/fuzz_error_distribution.py):
+# 11 of 60 + 3 of 12 configurations, median 1.0, maximum 3.5 -- the bound is twice the maximum and a bit (it was an unargued 30 until round 6)
+MOVES_FACTOR = 8.
 
 
 @pytest.mark.parametrize('i', range(FFTLOG_FUZZ_N))
@@ -28,5 +31,5 @@ def test_random_configurations(golden, i):
     np.testing.assert_allclose(y, ref_y, rtol=1e-13, err_msg=str(cfg))
     err = fftlog_fuzz_error(cfg, out, ref, ref_y)
     # 1e-12 where the problem is well conditioned; where one rounding error per input sample moves the reference's own result by more (constant / edge
-    # padding over many decades: the cropped output sits orders of magnitude below what the padded transform carries), 30 x that movement
-    assert err <= 1e-12 + 30. * float(g['c%d_moves' % i]), (cfg, err, float(g['c%d_moves' % i]))
+    # padding over many decades: the cropped output sits orders of magnitude below what the padded transform carries), MOVES_FACTOR x that movement
+    assert err <= 1e-12 + MOVES_FACTOR * float(g['c%d_moves' % i]), (cfg, err, float(g['c%d_moves' % i]))

@@ -1,7 +1,7 @@
 """GPU parity of the FFTLog classes at sizes beyond the LDS-resident kernel (padded lengths 16 384 ... 131 072: the four-step path of
 csrc/cp_fftlog_large.hip) on random configurations -- class / kernel, range, tilt, folds, low-ringing or xy, padding mode, several ell, batches,
 keep_padding -- against the reference's own outputs (tests/golden/fftlog_large.npz, `python -m oracle.gen_golden fftlog_large`): output coordinates
-1e-13, transforms norm-wise 1e-12 in the tilted space (+ 30 x the reference's own movement under one-ulp inputs where the padding makes the problem
+1e-13, transforms norm-wise 1e-12 in the tilted space (+ MOVES_FACTOR = 8 x the reference's own movement under one-ulp inputs where the padding makes the problem
 ill-conditioned)."""
 import numpy as np
 import pytest
@@ -9,6 +9,9 @@ import pytest
 from oracle.gen_golden import fftlog_large_configs, fftlog_fuzz_build, fftlog_fuzz_stride, fftlog_fuzz_error
 
 pytestmark = pytest.mark.gpu
+# error / movement of the reference's own result, measured over the configurations above 1e-12 (profiles/r6_fftlog_fuzz_errors.txt, tools/fuzz_error_distribution.py):
+# 11 of 60 + 3 of 12 configurations, median 1.0, maximum 3.5 -- the bound is twice the maximum and a bit (it was an unargued 30 until round 6)
+MOVES_FACTOR = 8.
 
 
 @pytest.mark.parametrize('i', range(12))
@@ -29,4 +32,4 @@ def test_large_sizes(golden, i):
     assert y.shape == ref_y.shape and out.shape == ref.shape and out.dtype == ref.dtype, (cfg, y.shape, ref_y.shape, out.shape, ref.shape, out.dtype)
     np.testing.assert_allclose(y, ref_y, rtol=1e-13, err_msg=str(cfg))
     err = fftlog_fuzz_error(cfg, out, ref, ref_y)
-    assert err <= 1e-12 + 30. * float(g['c%d_moves' % i]), (cfg, err, float(g['c%d_moves' % i]))
+    assert err <= 1e-12 + MOVES_FACTOR * float(g['c%d_moves' % i]), (cfg, err, float(g['c%d_moves' % i]))

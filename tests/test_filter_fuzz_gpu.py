@@ -1,7 +1,7 @@
 """GPU parity of the BAO filters that take options -- hinton2017 (degree, sigma, weight), ehpoly (krange, rescale_krange), kirkby2013 (side bands,
 rescale_sbox), and wallish2018 / savgol / peakaverage re-used on another number of wavenumbers (set_k + __call__) -- with options, cosmology and fiducial
 cosmology drawn at random, against the reference's own outputs (tests/golden/filter_fuzz.npz, `python -m oracle.gen_golden filter_fuzz`): 1e-9 on the
-smooth spectrum / correlation function (hinton2017 1e-6: the reference inverts its normal equations explicitly, condition up to 1e10 at degree 13)."""
+smooth spectrum / correlation function (hinton2017 included: its explicitly inverted normal equations applied in the reference's order of operations)."""
 import numpy as np
 import pytest
 
@@ -21,7 +21,7 @@ def test_random_options(golden, i):
     ref_x, ref = g['c%d_x' % i], g['c%d_smooth' % i]
     assert x.shape == ref_x.shape and smooth.shape == ref.shape, (cfg, x.shape, ref_x.shape)
     np.testing.assert_allclose(x, ref_x, rtol=1e-13, err_msg=str(cfg))
-    rtol = 1e-6 if cfg['engine'] == 'hinton2017' else 1e-9
+    rtol = 1e-9
     atol = 1e-12 * np.abs(ref).max() if cfg['engine'] == 'kirkby2013' else 0.      # (xi changes sign: rounding relative to its scale)
     if cfg['engine'] == 'peakaverage' and not np.allclose(smooth, ref, rtol=rtol, atol=atol):
         # the extrema of the fiducial wiggles end on a two-sample plateau (the fit pins its last two samples); whether the sample in front of it is an

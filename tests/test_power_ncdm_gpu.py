@@ -90,7 +90,7 @@ def test_filters_with_a_massive_species(cp, golden, ifilter):
         np.testing.assert_allclose(f.k, g['filter_k'], rtol=1e-14)
         np.testing.assert_allclose(f.pk, g['filter%d_pk' % ifilter], rtol=RTOL)
         np.testing.assert_allclose(f.rs_drag_ratio(), g['filter%d_rs_ratio' % ifilter], rtol=1e-12)
-        np.testing.assert_allclose(f.pknow, g['filter%d_%s_pknow' % (ifilter, name)], rtol=1e-7 if name == 'hinton2017' else 1e-9, err_msg=name)
+        np.testing.assert_allclose(f.pknow, g['filter%d_%s_pknow' % (ifilter, name)], rtol=1e-9, err_msg=name)
     nowiggle = cp.Fourier(cosmo, engine='eisenstein_hu_nowiggle', set_engine=False).pk_interpolator()(f.k, z=0.)
     np.testing.assert_allclose(nowiggle, g['filter%d_pknow_eh' % ifilter], rtol=RTOL)
     interp2d = cosmo.get_fourier().pk_interpolator(z=np.array([0.]))
