@@ -976,6 +976,7 @@ extern "C" int cp_splice_plan_create(cp_splice_plan** out, int nknots, const dou
     *out = nullptr;
     if (nknots < 4 || !x || npieces < 1 || npieces > 3 || !piece_src || !piece_start || !piece_count || nq < 1 || !xq)
         return cp::fail(CP_EINVAL, "cp_splice_plan_create: bad arguments");
+    if (nknots > (1 << 24) || nq > (1 << 26)) return cp::fail(CP_EUNSUPPORTED, "cp_splice_plan_create: %d knots, %d queries (at most 2^24 / 2^26)", nknots, nq);
     const int n = nknots;
     int total = 0;
     for (int p = 0; p < npieces; ++p) {

@@ -86,6 +86,9 @@ extern "C" int cp_fftlog_plan_create(cp_fftlog_plan** out, int n, int npad, int 
         return cp::fail(CP_EINVAL, "cp_fftlog_plan_create: padded size %d must be a power of two >= n=%d (fftlog.py:149-159)", npad, n);
     Launcher l;
     if (npad > (1 << 24)) return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_plan_create: padded size %d is beyond the supported range (2^24)", npad);
+    // (the plan stages nker x npad entries of three tables on the host: a request beyond 2^28 entries -- 8 GB -- is refused, not attempted)
+    if ((long long)nker * npad > (1LL << 28))
+        return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_plan_create: %d transforms of padded size %d: tables of more than 2^28 entries", nker, npad);
     if (npad > CP_FFTLOG_MAX_NP) {  // one packed pair no longer fits the LDS: elementwise kernels around a library FFT
         cp_fftlog_plan* p = new (std::nothrow) cp_fftlog_plan();
         if (!p) return cp::fail(CP_ENOMEM, "cp_fftlog_plan_create: host allocation failed");

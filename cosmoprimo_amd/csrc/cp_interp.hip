@@ -129,6 +129,7 @@ extern "C" int cp_interp_table_create(cp_interp_table** table, long long n, cons
     if (!table) return cp::fail(CP_EINVAL, "cp_interp_table_create: null output");
     *table = nullptr;
     if (n < 1 || !x || !f) return cp::fail(CP_EINVAL, "cp_interp_table_create: need at least one (x, f) row");
+    if (n > (1LL << 27)) return cp::fail(CP_EUNSUPPORTED, "cp_interp_table_create: %lld rows (at most 2^27: the table is staged as pairs on the host)", n);
     for (long long i = 1; i < n; ++i)
         if (!(x[i] >= x[i - 1])) return cp::fail(CP_EINVAL, "cp_interp_table_create: x must be ascending (row %lld)", i);
     cp_interp_table* t = new (std::nothrow) cp_interp_table();

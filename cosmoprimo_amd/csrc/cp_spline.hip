@@ -839,6 +839,8 @@ extern "C" int cp_linop_plan_create(cp_spline_plan** out, int n, int nq, const d
     if (!out) return cp::fail(CP_EINVAL, "cp_linop_plan_create: null plan pointer");
     *out = nullptr;
     if (n < 1 || nq < 1 || !w_dense) return cp::fail(CP_EINVAL, "cp_linop_plan_create: bad arguments");
+    if ((long long)n * nq > (1LL << 29))      // (the limit of cp_spline_plan_create: the plan stages bands and padded copies of the operator)
+        return cp::fail(CP_EUNSUPPORTED, "cp_linop_plan_create: an operator of %d x %d weights (at most 2^29): apply it in pieces of queries", nq, n);
     return plan_from_dense(out, n, nq, w_dense, device, true);
 }
 

@@ -201,6 +201,8 @@ extern "C" int cp_spline_rows_plan_create(cp_spline_rows_plan** out, int n, cons
     if (!out) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: null plan pointer");
     *out = nullptr;
     if (n < 4 || !x || nq < 1 || !xq) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: bad arguments");
+    if (nq > (1 << 26) || n > (1 << 26))      // (a query is staged as an interval and four weights on the host: 2^26 queries are 2.4 GB; a catalogue comes in pieces)
+        return cp::fail(CP_EUNSUPPORTED, "cp_spline_rows_plan_create: %d knots, %d queries (at most 2^26 each): evaluate in pieces", n, nq);
     if (bc != CP_SPLINE_NATURAL && bc != CP_SPLINE_CLAMPED && bc != CP_SPLINE_NOT_A_KNOT) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: unknown boundary condition %d", bc);
     for (int i = 0; i + 1 < n; ++i)
         if (!(x[i + 1] > x[i])) return cp::fail(CP_EINVAL, "cp_spline_rows_plan_create: knots must increase");

@@ -1277,10 +1277,28 @@ def filter_fuzz_output(cp, cfg):
         return np.asarray(f.k)[::8], np.asarray(f.pknow)[::8]
 
 
+def filter_fuzz_plateau_reading(cp, cfg):
+    """peakaverage: did the reference count the sample in front of the end plateau of its fiducial wiggles as an extremum (bao_filter.py:556-564)?  Its
+    fit pins the last two samples of the fitted range to one value; whether the sample before them is a peak for ``find_peaks`` is decided by the last
+    bit of its own arithmetic -- recorded, because no other implementation can reproduce that bit (cosmoprimo_amd/bao_filter.py: _wiggle_extrema)."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        cosmo = cp.Cosmology(engine='eisenstein_hu', **cfg['cosmo'])
+        fid = cp.Cosmology(engine='eisenstein_hu', h=cfg['fid_h'])
+        f = cp.PowerSpectrumBAOFilter(cosmo.get_fourier().pk_interpolator().to_1d(z=0.), engine='peakaverage', cosmo=cosmo, cosmo_fid=fid, **cfg['kwargs'])
+        # (a filter re-used on another number of wavenumbers keeps the extrema of the grid it was built on: `_prepare` runs once, bao_filter.py:61-75)
+        index = np.flatnonzero((f.k >= 1e-3) & (f.k <= 1.))
+        before_plateau = f.k[index[-1] - 1]
+        return bool(any(f.k_peaks[i][f.pad_peaks[i][0] + f.pad_peaks[i][1] - 1] == before_plateau for i in (0, 1)))
+
+
 def gen_filter_fuzz(cp):
     out = {}
     for i, cfg in enumerate(filter_fuzz_configs()):
         out['c%d_x' % i], out['c%d_smooth' % i] = filter_fuzz_output(cp, cfg)
+        if cfg['engine'] == 'peakaverage':
+            out['c%d_plateau_extremum' % i] = np.array(filter_fuzz_plateau_reading(cp, cfg))
     save('filter_fuzz', **out)
 
 

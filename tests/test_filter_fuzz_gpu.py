@@ -23,10 +23,14 @@ def test_random_options(golden, i):
     np.testing.assert_allclose(x, ref_x, rtol=1e-13, err_msg=str(cfg))
     rtol = 1e-9
     atol = 1e-12 * np.abs(ref).max() if cfg['engine'] == 'kirkby2013' else 0.      # (xi changes sign: rounding relative to its scale)
-    if cfg['engine'] == 'peakaverage' and not np.allclose(smooth, ref, rtol=rtol, atol=atol):
-        # the extrema of the fiducial wiggles end on a two-sample plateau (the fit pins its last two samples); whether the sample in front of it is an
-        # extremum is decided by the last bit of the reference's fit, and falls either way from one fiducial cosmology to the next
-        # (bao_filter._wiggle_extrema): the other reading must then be the reference's
+    if cfg['engine'] == 'peakaverage' and not bool(g['c%d_plateau_extremum' % i]):
+        # KNOWN DEVIATION.  The fiducial wiggles end on a two-sample plateau (the fit pins its last two samples to one value); whether
+        # the sample in front of it is an extremum for scipy's find_peaks is decided by the LAST BIT of the reference's own fit: it counts it for its default
+        # fiducial cosmology (h = 0.7) and for about a third of others (x[-2] - x[-1] = +2e-16, 0 or -2e-16 in its arithmetic; the fixture records which).
+        # No other implementation can reproduce that bit; this package settles the tie by rule (bao_filter._wiggle_extrema: an extremum, the default
+        # fiducial's reading).  For this configuration the reference's bit fell the other way: the default rule must differ from it (by ~1e-4 above
+        # k = 0.36 h/Mpc), and the other reading must reproduce it.
+        assert not np.allclose(smooth, ref, rtol=1e-7), cfg
         import cosmoprimo_amd.bao_filter as bf
         try:
             bf.PLATEAU_EXTREMUM = False

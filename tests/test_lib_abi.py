@@ -74,6 +74,17 @@ def test_error_mapping_of_the_table_and_distance_entry_points():
     with pytest.raises(NotImplementedError):      # 6.3e8 weights: the dense staging of the operator would take 5 GB on the host
         _lib.check(lib.cp_spline_plan_create(ctypes.byref(handle), knots.size, _lib.as_double_p(knots), queries.size, _lib.as_double_p(queries), _lib.SPLINE_BC['natural'], 0, 0, 0))
     assert b'2^29' in lib.cp_last_error()
+    # ... and every other *_create that stages caller-sized arrays on the host refuses sizes beyond its limit before it allocates or touches a device
+    one = np.ones(8)
+    with pytest.raises(NotImplementedError):      # 2^20 x 2^10 weights of a dense operator (the array itself is never read)
+        _lib.check(lib.cp_linop_plan_create(ctypes.byref(handle), 1 << 20, 1 << 10, _lib.as_double_p(one), 0))
+    with pytest.raises(NotImplementedError):      # 2^27 queries of a row spline
+        _lib.check(lib.cp_spline_rows_plan_create(ctypes.byref(handle), 8, _lib.as_double_p(np.arange(8.)), _lib.SPLINE_BC['natural'], 0, 1 << 27, _lib.as_double_p(one), 0))
+    with pytest.raises(NotImplementedError):      # a table of 2^28 rows
+        _lib.check(lib.cp_interp_table_create(ctypes.byref(handle), 1 << 28, _lib.as_double_p(one), _lib.as_double_p(one), 0))
+    with pytest.raises(NotImplementedError):      # 2^13 transforms in parallel of padded size 2^16: 2^29 table entries
+        _lib.check(lib.cp_fftlog_plan_create(ctypes.byref(handle), 1 << 15, 1 << 16, 1 << 13, _lib.as_double_p(one), _lib.as_double_p(one), _lib.as_double_p(one), 0))
+    assert not handle.value
 
 
 def test_loggamma_vs_scipy_golden(golden):
