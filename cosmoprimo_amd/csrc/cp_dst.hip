@@ -402,8 +402,8 @@ __global__ __launch_bounds__(N / P, 2) void dst_generate_kernel(const GenArgs G)
         int tt = t;
         asm volatile("" : "+v"(tt));      // (nothing derived from the thread's number is kept in registers from one pair to the next: what the compiler hoists
                                            // out of this loop lives through the transform, in registers the kernel does not have -- spilled and reloaded)
-        generate_row<N, P, ENGINE>(&G, 2 * p, tt, slots, &mt);
-        if (has_b) generate_row<N, P, ENGINE>(&G, 2 * p + 1, tt, slots + 1, &mt);
+        generate_row<N, P, ENGINE>(&G, 2 * p, tt, slots, cpmath::tables_present(&mt));
+        if (has_b) generate_row<N, P, ENGINE>(&G, 2 * p + 1, tt, slots + 1, cpmath::tables_present(&mt));
         cplx x[P];
         bool bad_a = false, bad_b = false;
 #pragma unroll

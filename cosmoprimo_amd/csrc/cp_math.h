@@ -211,6 +211,14 @@ struct MathTables {      // in LDS, one per workgroup
     double logc[128];
 };
 
+// The tables of a kernel that has them, as the evaluation functions take them (they accept null: "no tables, the polynomial forms").  Behind the
+// address-space cast of a __shared__ variable the compiler does not see that the pointer is not null: without this the kernels carried BOTH forms of every
+// logarithm and exponential with a run-time test in front of each (and the polynomial forms' constants in registers).
+__device__ __forceinline__ const MathTables* tables_present(const MathTables* t) {
+    __builtin_assume(t != nullptr);
+    return t;
+}
+
 // every thread of the workgroup calls this; a barrier follows at the caller's
 __device__ __forceinline__ void fill_math_tables(MathTables* t) {
     for (int i = threadIdx.x; i < 64; i += blockDim.x) t->exp2[i] = exp2_table[i];

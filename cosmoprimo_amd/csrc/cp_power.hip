@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
                 if (ENGINE == CP_ENGINE_BBKS)
                     T = transfer_bbks(K.h, K.bbks_gamma, kh);
                 else
-                    T = ENGINE == CP_ENGINE_EH ? transfer_eh(K.eh, kh, ln_kh, &mt) : transfer_nowiggle(K.s, K.h, kh, &mt);
+                    T = ENGINE == CP_ENGINE_EH ? transfer_eh(K.eh, kh, ln_kh, tables_present(&mt)) : transfer_nowiggle(K.s, K.h, kh, tables_present(&mt));
             }
             if (A.what == CP_PK_TRANSFER) {
                 out[0] = T;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 3) void power_kernel(const Args A) {   // 3 wa
                 out[0] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(T)) : log_tab_any(fabs(T), &mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
                 continue;
             }
-            const double tilt = primordial_tilt(pc, ln_kh, &mt);
+            const double tilt = primordial_tilt(pc, ln_kh, tables_present(&mt));
             if (A.what == CP_PK_PRIMORDIAL) {
                 out[0] = pc.h3_A_s * tilt;
                 continue;

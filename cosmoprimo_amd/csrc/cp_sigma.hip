@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
 #if CP_SIGMA_RZ_TABLES
     __shared__ MathTables mt;      // (the barrier behind the FFT tables covers it)
     fill_math_tables(&mt);
-    const MathTables* mtp = &mt;
+    const MathTables* mtp = tables_present(&mt);
 #else
     const MathTables* mtp = nullptr;
 #endif
@@ -824,8 +824,8 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
     for (int i = 0; i < PER_LANE; ++i) {
         const int j = lane + 64 * i;
         const double kh = S.k[j], ln_kh = S.ln_k[j];
-        const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, S.ln_k[1024 + j], S.ln_k[2048 + j], &mt);
-        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
+        const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, S.ln_k[1024 + j], S.ln_k[2048 + j], tables_present(&mt));
+        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, tables_present(&mt));
         pks[64 * i] = pk;
         acc = fma(S.functional[j], pk, acc);
     }
@@ -861,8 +861,8 @@ __global__ __launch_bounds__(256) void sigma_functional_kernel(const FunctionalA
 #pragma unroll 2
     for (int j = lane; j < S.nk; j += 64) {
         const double kh = S.k[j], ln_kh = S.ln_k[j];
-        const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, S.ln_k[S.nk + j], S.ln_k[2 * S.nk + j], &mt);
-        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, &mt);
+        const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, S.ln_k[S.nk + j], S.ln_k[2 * S.nk + j], tables_present(&mt));
+        const double pk = (Tk * Tk) * (kh * pc.pk_unit) * primordial_tilt(pc, ln_kh, tables_present(&mt));
         if (S.pk_out) S.pk_out[ic * S.nk + j] = pk;
 #pragma unroll
         for (int q = 0; q < FUNCTIONAL_MAX_NQ; ++q)

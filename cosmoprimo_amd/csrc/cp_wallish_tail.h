@@ -446,8 +446,8 @@ __global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) 
         int tt = t;
         asm volatile("" : "+v"(tt));      // (nothing derived from the thread's number is kept in registers from one pair to the next)
         // ---- 0. log(k P_c(k)) of the pair's cosmologies at the 4096 wavenumbers of the linear grid, Makhoul order, into the thread's own slots; forward transform ----
-        generate_row<N, P, ENGINE>(CP_GEN(), 2 * p, tt, seqs, &mt);
-        if (has_b) generate_row<N, P, ENGINE>(CP_GEN(), 2 * p + 1, tt, seqs + 1, &mt);
+        generate_row<N, P, ENGINE>(CP_GEN(), 2 * p, tt, seqs, cpmath::tables_present(&mt));
+        if (has_b) generate_row<N, P, ENGINE>(CP_GEN(), 2 * p + 1, tt, seqs + 1, cpmath::tables_present(&mt));
         {
             cplx x[P];
             bool bad_a = false, bad_b = false;
