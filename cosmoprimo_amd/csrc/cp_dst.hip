@@ -333,12 +333,24 @@ struct GenArgs {
 #ifndef CP_DST_GEN_ILP
 #define CP_DST_GEN_ILP 2
 #endif
+#ifndef CP_DST_GEN_PREFETCH
+#define CP_DST_GEN_PREFETCH 1
+#endif
 
-__global__ void dst_log_kernel(const double* k, double* ln_k, int n) {      // ln_k: (4, n) log k, k^1.08, k^1.4 (cp_power_eval.h), 1 / k
+// ln_k: (4, n) log k, k^1.08, k^1.4 (cp_power_eval.h), 1 / k; then (n, 4): (k, log k, k^1.08, k^1.4) of the sample the generating transform puts at
+// position m of its reordered sequence (Makhoul's order: m < n / 2: sample 2 m, else 2 (n - 1 - m) + 1) -- a thread of generate_row walks m = t + T r:
+// its four numbers are 32 contiguous bytes, a wave's 2 KB, where four tables indexed by the sample number took four scattered 8-byte loads and their addresses
+__global__ void dst_log_kernel(const double* k, double* ln_k, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         cppower::powers_of_wavenumber(k[i], ln_k, i, n);
         ln_k[3 * n + i] = 1. / k[i];
+        const int m = (i & 1) ? n - 1 - (i - 1) / 2 : i / 2;
+        double* g = ln_k + 4 * (size_t)n + 4 * (size_t)m;
+        g[0] = k[i];
+        g[1] = ln_k[i];
+        g[2] = ln_k[n + i];
+        g[3] = ln_k[2 * n + i];
     }
 }
 
@@ -355,18 +367,40 @@ __device__ __forceinline__ void generate_row(GP G, long long ic, int t, double* 
     constexpr int T = N / P;
     const CosmoConsts K = load_uniform(G->consts + ic);      // (scalar loads: the cosmology's constants in scalar registers)
     const PkPerCosmology& pc = K.pk;
-    const double* gk = G->k;
-    const double* gln = G->ln_k;
+    const double2* gen = reinterpret_cast<const double2*>(G->ln_k + 4 * (size_t)N);      // (k, log k), (k^1.08, k^1.4) of position m of the reordered sequence (dst_log_kernel)
     const double ln_pk_unit = K.ln_pk_unit;
     // CP_DST_GEN_ILP samples per iteration: independent chains of logarithms / exponentials / reciprocals for the two waves of a SIMD to interleave
+    // ... whose table entries are requested an iteration ahead (CP_DST_GEN_PREFETCH: the loads of iteration r0 + ILP are in flight under the ~500
+    // instructions of iteration r0; at the top of the iteration that uses them they sat in front of everything, with one other wave on the SIMD to cover them)
+    double2 kl[CP_DST_GEN_ILP], pw[CP_DST_GEN_ILP];
+#pragma unroll
+    for (int u = 0; u < CP_DST_GEN_ILP; ++u) {
+        kl[u] = gen[2 * (t + T * u)];
+        pw[u] = gen[2 * (t + T * u) + 1];
+    }
 #pragma unroll 1
     for (int r0 = 0; r0 < P; r0 += CP_DST_GEN_ILP) {
+        double2 kl_now[CP_DST_GEN_ILP], pw_now[CP_DST_GEN_ILP];
+#pragma unroll
+        for (int u = 0; u < CP_DST_GEN_ILP; ++u) {
+            kl_now[u] = kl[u];
+            pw_now[u] = pw[u];
+            if (CP_DST_GEN_PREFETCH) {
+                const int mn = t + T * ((r0 + CP_DST_GEN_ILP + u) & (P - 1));      // (the last iteration asks for the first entries again: never used)
+                kl[u] = gen[2 * mn];
+                pw[u] = gen[2 * mn + 1];
+            } else if (r0 + CP_DST_GEN_ILP < P) {
+                const int mn = t + T * (r0 + CP_DST_GEN_ILP + u);
+                kl[u] = gen[2 * mn];
+                pw[u] = gen[2 * mn + 1];
+            }
+        }
+        if (!CP_DST_GEN_PREFETCH) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (measurements: the entries waited for where they are requested)
 #pragma unroll
         for (int u = 0; u < CP_DST_GEN_ILP; ++u) {
             const int m = t + T * (r0 + u);
-            const int n = m < N / 2 ? 2 * m : 2 * (N - 1 - m) + 1;
-            const double kh = gk[n], ln_kh = gln[n];
-            const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, gln[N + n], gln[2 * N + n], mt);
+            const double kh = kl_now[u].x, ln_kh = kl_now[u].y;
+            const double Tk = transfer_any<ENGINE>(K, kh, ln_kh, pw_now[u].x, pw_now[u].y, mt);
             slots[2 * m] = 2. * (ln_kh + (CP_MATH_TABLES_OFF ? log_pos(fabs(Tk)) : log_tab_any(fabs(Tk), mt))) + ln_pk_unit + primordial_tilt_exponent(pc, ln_kh);
         }
     }
@@ -571,7 +605,7 @@ extern "C" int cp_dst_plan_create(cp_dst_plan** out, int n, const double* kx, in
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_dst_plan_create: cannot select device %d", device);
     if (status == CP_OK && (hipMalloc(&p->d_tw, tw.size() * sizeof(cplx)) != hipSuccess || hipMalloc(&p->d_rot, n * sizeof(cplx)) != hipSuccess ||
-                            (kx && (hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ln_kx, 4 * (size_t)n * sizeof(double)) != hipSuccess))))
+                            (kx && (hipMalloc(&p->d_kx, n * sizeof(double)) != hipSuccess || hipMalloc(&p->d_ln_kx, 8 * (size_t)n * sizeof(double)) != hipSuccess))))
         status = cp::fail(CP_ENOMEM, "cp_dst_plan_create: device allocation failed");
     if (status == CP_OK && (hipMemcpy(p->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
                             hipMemcpy(p->d_rot, rot.data(), n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
