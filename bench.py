@@ -513,8 +513,8 @@ def _launch_ranks_if_needed(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200, help='timed steps (default 200: 0.2 s of back-to-back launches -- long enough for a device monitor sampling the run to see the GPU busy)')
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--rows', type=int, default=ROWS_PER_GPU, help='rows per GPU (default: the config-2 batch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--gather', action='store_true', help='also time the final RCCL all_gather of the result shards (reported separately); the default for N > 1')

@@ -24,8 +24,16 @@ struct EhScalars {
     double growth0;                         // CPT92 growth factor at z = 0 (Background.growth_factor(0, znorm=0)): the pre-kernel's lane evaluates it once per cosmology (coefficients_kernel), the sigma8 normalisation reads it
 };
 
-// eisenstein_hu.py:34-92 (+ eisenstein_hu_nowiggle.py:21), operation for operation
+// x^y for positive, finite, normal x as exp(y log x) with the short forms of cp_math.h: relative error (|y log x| + 1) 2e-16 -- 1e-15 at most over the
+// powers of the fits (|y log x| < 3.1) -- at 65 instructions for the library's ~200.  For the pre-kernel that forms the evaluation's constants: its one lane
+// per cosmology walks ~25 of them in a row, and it runs in front of every evaluation (a fifteenth of brieden2022's kernel time, a twentieth of config 3).
+__device__ __forceinline__ double pow_short(double x, double y) { return exp_mid(y * log_pos(x)); }
+
+// eisenstein_hu.py:34-92 (+ eisenstein_hu_nowiggle.py:21), operation for operation.  SHORT: the powers through pow_short (the constants of the evaluating
+// kernels: cosmo_consts); the scalars handed to the caller (cp_eh_scalars: rs_drag, z_drag, ...) take the library's pow.
+template <bool SHORT = false>
 __device__ __forceinline__ EhScalars eh_scalars(double h, double Omega_cdm, double Omega_b, double T_cmb, bool full) {
+    auto pow = [](double x, double y) { return SHORT ? pow_short(x, y) : ::pow(x, y); };
     EhScalars s;
     s.growth0 = 0.;      // (set by the caller that has the whole cosmology)
     s.omega_b = Omega_b * (h * h);
@@ -217,6 +225,9 @@ __device__ __forceinline__ PkPerCosmology pk_per_cosmology(const Cosmo& c, const
     return p;
 }
 
+#ifndef CP_CONSTS_SHORT_POW      // 0: the library's pow in the pre-kernel (measurements)
+#define CP_CONSTS_SHORT_POW 1
+#endif
 // Everything an evaluation of P(k) needs of ONE cosmology, in the units of the loops over wavenumbers: formed once per cosmology by one lane of
 // coefficients_kernel (cp_power.hip) and read back by the evaluating kernels with load_uniform -- scalar loads: the values sit in scalar registers, where
 // formed per thread (the parameters gathered, Omega_g by two IEEE divisions, two reciprocals and a logarithm: ~250 instructions per thread and
@@ -234,7 +245,7 @@ struct CosmoConsts {
 __device__ inline CosmoConsts cosmo_consts(const Cosmo& c, const double* pw, int engine) {
     CosmoConsts K{};
     if (engine != CP_ENGINE_BBKS) {
-        K.s = eh_scalars(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, engine == CP_ENGINE_EH);
+        K.s = eh_scalars<CP_CONSTS_SHORT_POW != 0>(c.h, c.Omega_cdm, c.Omega_b, c.T_cmb, engine == CP_ENGINE_EH);
         if (engine == CP_ENGINE_EH) K.eh = eh_per_cosmology(K.s, c.h);
     }
     K.s.growth0 = growth_cpt(c, 0.);
