@@ -75,6 +75,8 @@ SIGNATURES = {
     'cp_sigma_rz_workspace_bytes': (ctypes.c_longlong, [ctypes.c_longlong, ctypes.c_int]),
     'cp_sigma_rz_fused_available': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     'cp_geospline_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int]),
+    'cp_geospline_plan_create_prefiltered': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p,
+                                                           _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int]),
     'cp_geospline_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_geospline_plan_info': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, _c_int_p]),
     'cp_fftlog_geospline_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,

@@ -420,12 +420,21 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_spline_kernel(const RowsArgs
 // redshifts of one table) and out is (nbatch / group, nq, group), the transposition PowerSpectrumInterpolator2D.sigma_rz needs, written by the
 // kernel itself: the pairs of a group are then handed to workgroups of ONE XCD in the same round (workgroups are dealt round-robin to the 8 XCDs),
 // so that the 8-byte pieces of a 512-byte output line meet in that XCD's L2.
+//
+// COEF (plans of cp_geospline_plan_create_prefiltered): no solve at all.  In the B-spline basis of the geometric knots -- B_j(s) = B_0(s / rho^j):
+// the knot sequence is scale invariant -- the spline is s(r) = sum_j c_j B_j(r) and the interpolation conditions are a tridiagonal system with
+// CONSTANT coefficients, alpha c_{j-1} + beta c_j + gamma c_{j+1} = y_j.  The FFTLog output is y_j = post_j g_j with post_j = post_0 lambda^j and
+// g the inverse DFT of a product, so c_j = post_j ct_j with (alpha / lambda) ct_{j-1} + beta ct_j + gamma lambda ct_{j+1} = g_j, which on the
+// periodic padded grid is a division in the frequency domain: the plan's transform carries u_m / conj(alpha / lambda e^{-i w_m} + beta + gamma
+// lambda e^{i w_m}) in place of u_m and the kernel's ordinary output IS the coefficient sequence.  Periodic ends on the padded grid instead of
+// natural ends on the unpadded one: both are forgotten like 0.27^distance, and the plan refuses radii within GEO_HALO knots of the ends as the
+// solve does.  A radius then costs four LDS reads and the four cubic weights (12 + 4 fused multiply-adds, the polynomials in scalar registers).
 constexpr int GEO_SMAX = 8;          // knots per lane: stretches of at most 512 knots
 constexpr int GEO_SMIN = 4;          // (fewer knots per lane would need more than GEO_REACH lanes of carry)
 constexpr int GEO_QMAX = 8;          // queries per lane: at most 512 radii
 constexpr int GEO_HALO = 32, GEO_REACH = 9;      // GEO_REACH x GEO_SMIN >= GEO_HALO + 1
 #ifndef CP_GEO_ABLATE      // diagnostic builds (tools/geospline_ablate.sh; wrong results): 1 no carries between lanes, 2 one query per lane, 4 no root,
-#define CP_GEO_ABLATE 0    // 8 no solve at all (the tail is the barriers only), 16 no stores
+#define CP_GEO_ABLATE 0    // 8 no solve at all (the tail is the barriers only), 16 no stores, 128 no reads of the coefficients, 256 the stretch not written
 #endif
 
 struct GeoConsts {                  // on the device, read by scalar loads right in front of the solve (kernel arguments would sit in SGPRs through the FFT)
@@ -434,6 +443,9 @@ struct GeoConsts {                  // on the device, read by scalar loads right
     double pRk[GEO_SMAX];           // pR^(S - k)
     double cL[GEO_REACH];           // (pL^S)^m: the segment total of the lane m + 1 to the left
     double cR[GEO_REACH];
+    struct Basis {
+        double k[4][4];             // prefiltered plans: the B-spline centred on knot j - 1 + i is sum_d k[i][d] x^d on [s_j, s_j+1], x = (r - s_j) / h_j
+    } basis;
 };
 
 struct GeoArgs {
@@ -443,7 +455,7 @@ struct GeoArgs {
     int ntables, pt;                 // grouped: tables and pairs per table; plain: pairs and 1
     const GeoConsts* consts;
     const int* qe;                   // (nq) interval of each query relative to ws, -1: outside the knots
-    const double* qa;                // (nq) A of each query
+    const double* qa;                // (nq) A of each query (prefiltered plans: x = 1 - A)
     double* out;
 };
 
@@ -476,6 +488,7 @@ __device__ __forceinline__ double geo_sqrt(double v) {
     return v >= 2.2250738585072014e-308 && v <= 1.7976931348623157e308 ? v * cpmath::rsqrt_pos(v) : sqrt(v);
 }
 
+template <bool COEF, int QS = GEO_QMAX>      // QS: blocks of 64 radii the COEF tail is compiled for (4: plans of at most 256 radii)
 __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoArgs R) {
     using F = Fftlog<NP, P, IN_HALF_ZERO, OUT_HALF>;
     constexpr int T = F::T, H = F::H, Q = F::Q;
@@ -512,6 +525,80 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
     double* base = reinterpret_cast<double*>(lds);
     constexpr int YSTRIDE = 64 * GEO_SMAX + 8;
     static_assert(4 * YSTRIDE <= 2 * NP, "the solve lives in the data region of the FFT");
+    // COEF: the coefficients of the stretch live BEHIND the FFT's LDS (two rows of ne + 2), so that the pair's radii are evaluated and stored after
+    // the first barrier of the NEXT pair: no barrier of its own (the last pass reads and the next phase 0 writes the same slots of the data region,
+    // thread by thread, as in fftlog_kernel), the reads of the coefficients land under phase 1's, and the stores have a whole pair to retire
+    // before anything waits on the memory counter behind them (tools/geospline_ablate.sh: the stores at the end of the pair cost 0.3 ms of 3.4).
+    double* side = reinterpret_cast<double*>(smem + F::LDS_BYTES);
+    const int side_stride = R.ne + 2;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    double* pending_dst = nullptr;      // where the previous pair's first row goes (null: nothing to evaluate)
+    bool pending_b = false;
+    // A wave takes half of the radii for BOTH rows of the pair: the cubic weights of a radius are formed once for the two, and in the grouped
+    // layout -- out[table, q, 2 within + row] -- the two values of a lane are neighbours in memory: one 16-byte store.
+    // the radii of this lane, for the whole launch (a load here would sit behind the rows that phase 0 has just requested: the memory counter retires in order)
+    constexpr int QW = COEF ? QS / 2 : 1;      // radii per lane and wave
+    int qe[QW];
+    double qx[QW];
+    if constexpr (COEF) {
+#pragma unroll
+        for (int j = 0; j < QW; ++j) {
+            const int q = lane + 64 * (2 * j + wave_s);      // the blocks of 64 radii alternate between the two waves
+            qe[j] = q < R.nq ? R.qe[q] : -1;
+            qx[j] = q < R.nq ? R.qa[q] : 0.;
+        }
+    }
+    auto evaluate = [&](double* dst, bool both) {
+        const double* Ca = side + 1;      // Ca[-1 .. ne]: the B-spline coefficients of the stretch, first row (second: side_stride further)
+        const GeoConsts* C = R.consts;
+        asm volatile("" : "+s"(C));      // (not hoisted out of the loop over pairs: the scalar registers are the FFT's there)
+        const GeoConsts::Basis B = load_uniform(&C->basis);      // scalar loads
+        const int qstride = grouped ? R.group : 1;
+        const unsigned voff = (unsigned)(lane * qstride) * 8u;
+        const int nqi = (CP_GEO_ABLATE & 2) ? 1 : (((R.nq + 63) >> 6) - wave_s + 1) >> 1;      // (wave-uniform) blocks of 64 radii of this wave
+        const long long row_b = grouped ? 1 : R.nq;      // the second row's value, in doubles from the first's
+#pragma unroll
+        for (int j0 = 0; j0 < QW; j0 += 2) {
+            if (j0 >= nqi) break;
+            double ca[2][4], cb[2][4];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int e = qe[j0 + jj] < 0 ? 0 : qe[j0 + jj];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ca[jj][i] = (CP_GEO_ABLATE & 128) ? (double)(e + i) : Ca[e - 1 + i];
+                    cb[jj][i] = (CP_GEO_ABLATE & 128) ? (double)(e - i) : Ca[side_stride + e - 1 + i];
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = j0 + jj;
+                const double x = qx[j];
+                double va = 0., vb = 0.;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double wgt = fma(fma(fma(B.k[i][3], x, B.k[i][2]), x, B.k[i][1]), x, B.k[i][0]);
+                    va = fma(wgt, ca[jj][i], va);
+                    vb = fma(wgt, cb[jj][i], vb);
+                }
+                if (R.post_sqrt && !(CP_GEO_ABLATE & 4)) {
+                    va = geo_sqrt(va);
+                    vb = geo_sqrt(vb);
+                }
+                if (qe[j] < 0) va = vb = __builtin_nan("");
+                char* obase = reinterpret_cast<char*>(dst) + (size_t)(64 * (2 * j + wave_s)) * (size_t)qstride * 8u;      // (wave-uniform)
+                if (lane + 64 * (2 * j + wave_s) < R.nq && (!(CP_GEO_ABLATE & 16) || va == 12345.678)) {
+                    double* o = reinterpret_cast<double*>(obase + voff);
+                    if (grouped) {      // (groups are even: every pair has its second row)
+                        *reinterpret_cast<double2*>(o) = make_double2(va, vb);
+                    } else {
+                        o[0] = va;
+                        if (both) o[row_b] = vb;
+                    }
+                }
+            }
+        }
+    };
     bool more = true;
     while (more) {
         const bool has_b = 2 * p + 1 < A.nbatch;
@@ -530,6 +617,9 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
         {
             F::template phase<0>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
             __syncthreads();
+            if constexpr (COEF) {
+                if (pending_dst && !(CP_GEO_ABLATE & 8)) evaluate(pending_dst, pending_b);
+            }
             F::template phase<1>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
             if constexpr (!F::template barrier_free_after<1>()) __syncthreads();
             F::template phase<2>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
@@ -542,7 +632,7 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
             cplx x[P];
             Pass<NP, P, 0>::load_lds(t0, lds, x);
             st.info_nxt = F::screen_collect(lds);
-            __syncthreads();      // every thread has its inputs: the data region is free
+            if constexpr (!COEF) __syncthreads();      // every thread has its inputs: the data region is free
             Pass<NP, P, 0>::twiddle_apply(st.w, x);
             Pass<NP, P, 0>::butterflies(x);
             double ya[H], yb[H];
@@ -552,14 +642,23 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
                 yb[s] = x[s + Q].im * st.fpost[s];
             }
             F::template fix_output<H>(st.info_cur, ya, yb);
+            double* ka = COEF ? side + 1 : base + 1;
+            double* kb = COEF ? side + side_stride + 1 : base + YSTRIDE + 1;
 #pragma unroll
             for (int s = 0; s < H; ++s) {      // the stretch of both rows (and one knot beyond either end) in natural order
                 const int e = t0 + T * s - R.ws;
-                if (e >= -1 && e <= R.ne) {
-                    base[1 + e] = ya[s];
-                    base[YSTRIDE + 1 + e] = yb[s];
+                if (e >= -1 && e <= R.ne && !(CP_GEO_ABLATE & 256 && ya[s] != 12345.678)) {
+                    ka[e] = ya[s];
+                    kb[e] = yb[s];
                 }
             }
+        }
+        if constexpr (COEF) {
+            // plain: out[row, q]; grouped: out[table, q, 2 within + wave]
+            pending_dst = grouped ? R.out + (long long)table * R.nq * R.group + 2 * within : R.out + 2 * p * R.nq;
+            pending_b = has_b;
+            p = pn;
+            continue;
         }
         __syncthreads();
         // ---- one wave per row from here to the stores ----
@@ -581,8 +680,10 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
                     qa[j] = q < R.nq ? R.qa[q] : 0.;
                 }
             }
-            const GeoConsts* C = R.consts;
-            asm volatile("" : "+s"(C));      // (not hoisted out of the loop over pairs: the scalar registers are the FFT's there)
+            const GeoConsts* Cp = R.consts;
+            asm volatile("" : "+s"(Cp));      // (not hoisted out of the loop over pairs: the scalar registers are the FFT's there)
+            const GeoConsts G = load_uniform(Cp);      // scalar loads of the fields the instantiation below uses (through the laundered generic pointer
+            const GeoConsts* C = &G;                   // they were flat vector loads, each behind a wait for every earlier store: 0.2 ms of 3.6)
             // The solve, instantiated for the plan's knots per lane (4 ... 8: a switch on a wave-uniform value): loops of exactly S steps and
             // ceil(33 / S) carries, where one body for 8 knots spent a third of its instructions on knots a plan of 5 does not have.
             auto solve = [&](auto sc) {
@@ -683,6 +784,10 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
         }
         __syncthreads();      // the next pair's phase 0 writes the data region
         p = pn;
+    }
+    if constexpr (COEF) {
+        __syncthreads();
+        if (pending_dst && !(CP_GEO_ABLATE & 8)) evaluate(pending_dst, pending_b);
     }
 }
 
@@ -1043,6 +1148,7 @@ struct cp_geospline_plan {
     int* d_qe;
     double* d_qa;
     GeoConsts* d_consts;
+    cp_fftlog_plan* prefiltered;      // plans of cp_geospline_plan_create_prefiltered: the transform whose output is the B-spline coefficients
 };
 
 extern "C" int cp_geospline_plan_destroy(cp_geospline_plan* p) {
@@ -1054,22 +1160,32 @@ extern "C" int cp_geospline_plan_destroy(cp_geospline_plan* p) {
     if (p->d_qa) (void)hipFree(p->d_qa);
     if (p->d_consts) (void)hipFree(p->d_consts);
     if (prev >= 0 && prev != p->device) (void)hipSetDevice(prev);
+    if (p->prefiltered) (void)cp_fftlog_plan_destroy(p->prefiltered);
     delete p;
     return CP_OK;
 }
 
-extern "C" int cp_geospline_plan_create(cp_geospline_plan** out, const double* knots, int n, const double* queries, int nq, int device) {
-    if (!out) return cp::fail(CP_EINVAL, "cp_geospline_plan_create: null plan pointer");
-    *out = nullptr;
-    if (!knots || !queries || n < 4 || nq < 1) return cp::fail(CP_EINVAL, "cp_geospline_plan_create: bad arguments");
-    if (nq > 64 * GEO_QMAX) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: %d queries (at most %d)", nq, 64 * GEO_QMAX);
-    if (!(knots[0] > 0.) || !(knots[n - 1] > knots[0])) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: the knots are not an ascending geometric grid");
+namespace {
+
+// the geometric ratio of the knots, or 0 when they are not an ascending geometric grid (the error is set)
+double geometric_ratio(const char* who, const double* knots, int n) {
+    if (!(knots[0] > 0.) || !(knots[n - 1] > knots[0])) {
+        (void)cp::fail(CP_EUNSUPPORTED, "%s: the knots are not an ascending geometric grid", who);
+        return 0.;
+    }
     const double rho = pow(knots[n - 1] / knots[0], 1. / (n - 1));
     for (int i = 0; i + 1 < n; ++i)
-        if (!(fabs(knots[i + 1] / (knots[i] * rho) - 1.) < 1e-12)) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: the knots are not a geometric grid (knot %d)", i + 1);
-    std::vector<int> qj(nq);
-    std::vector<double> qa(nq);
-    int jmin = n, jmax = -1;
+        if (!(fabs(knots[i + 1] / (knots[i] * rho) - 1.) < 1e-12)) {
+            (void)cp::fail(CP_EUNSUPPORTED, "%s: the knots are not a geometric grid (knot %d)", who, i + 1);
+            return 0.;
+        }
+    return rho;
+}
+
+// interval and position of every query: qj = -1 outside the knots (or NaN), else s_qj <= r <= s_qj+1 and qa = (s_qj+1 - r) / h_qj
+void locate_queries(const double* knots, int n, const double* queries, int nq, std::vector<int>& qj, std::vector<double>& qa, int* jmin, int* jmax) {
+    *jmin = n;
+    *jmax = -1;
     for (int q = 0; q < nq; ++q) {
         const double r = queries[q];
         if (!(r >= knots[0] && r <= knots[n - 1])) {      // outside the knots (or NaN): NaN, as the spline without extrapolation returns
@@ -1081,9 +1197,66 @@ extern "C" int cp_geospline_plan_create(cp_geospline_plan** out, const double* k
         if (j > n - 2) j = n - 2;
         qj[q] = j;
         qa[q] = (knots[j + 1] - r) / (knots[j + 1] - knots[j]);
-        jmin = std::min(jmin, j);
-        jmax = std::max(jmax, j + 1);
+        *jmin = std::min(*jmin, j);
+        *jmax = std::max(*jmax, j + 1);
     }
+}
+
+// The four cubic B-splines of the knots rho^m that live on [1, rho], as polynomials in x = (r - 1) / (rho - 1): basis[i] is the one centred on the
+// knot rho^(i - 1).  Cox - de Boor on the coefficients (the only piece of order 0 on that interval is B_{0,0} = 1).
+void geometric_bspline_pieces(long double rho, long double basis[4][4]) {
+    auto knot = [&](int m) { return powl(rho, (long double)m); };
+    const long double h = rho - 1.0L;
+    long double prev[5][4] = {}, cur[5][4];      // slot i + 3 holds B_{i,d}, i = -3 .. 0 (slot 4: B_{1,d} = 0 on the interval)
+    prev[3][0] = 1.0L;
+    for (int d = 1; d <= 3; ++d) {
+        for (int slot = 0; slot < 5; ++slot)
+            for (int e = 0; e < 4; ++e) cur[slot][e] = 0.0L;
+        for (int i = -d; i <= 0; ++i) {
+            // (r - t_i) / (t_{i+d} - t_i) B_{i,d-1} + (t_{i+d+1} - r) / (t_{i+d+1} - t_{i+1}) B_{i+1,d-1},   r = 1 + h x
+            const long double wl = 1.0L / (knot(i + d) - knot(i)), wr = 1.0L / (knot(i + d + 1) - knot(i + 1));
+            const long double l0 = (1.0L - knot(i)) * wl, l1 = h * wl, r0 = (knot(i + d + 1) - 1.0L) * wr, r1 = -h * wr;
+            for (int e = 0; e < 4; ++e) {
+                cur[i + 3][e] += l0 * prev[i + 3][e] + r0 * prev[i + 4][e];
+                if (e > 0) cur[i + 3][e] += l1 * prev[i + 3][e - 1] + r1 * prev[i + 4][e - 1];
+            }
+        }
+        for (int slot = 0; slot < 5; ++slot)
+            for (int e = 0; e < 4; ++e) prev[slot][e] = cur[slot][e];
+    }
+    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 4; ++e) basis[i][e] = prev[i][e];
+}
+
+int upload_geospline(cp_geospline_plan* p, const std::vector<int>& qj, const std::vector<double>& qa, const GeoConsts& consts) {
+    const int nq = p->nq, device = p->device;
+    int prev = -1, status = CP_OK;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_geospline_plan_create: cannot select device %d", device);
+    if (status == CP_OK && (hipMalloc(&p->d_qe, nq * sizeof(int)) != hipSuccess || hipMalloc(&p->d_qa, nq * sizeof(double)) != hipSuccess ||
+                            hipMalloc(&p->d_consts, sizeof(GeoConsts)) != hipSuccess))
+        status = cp::fail(CP_ENOMEM, "cp_geospline_plan_create: device allocation failed");
+    if (status == CP_OK && (hipMemcpy(p->d_qe, qj.data(), nq * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->d_qa, qa.data(), nq * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+                            hipMemcpy(p->d_consts, &consts, sizeof(GeoConsts), hipMemcpyHostToDevice) != hipSuccess))
+        status = cp::fail(CP_EDEVICE, "cp_geospline_plan_create: upload failed");
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    return status;
+}
+
+}  // namespace
+
+extern "C" int cp_geospline_plan_create(cp_geospline_plan** out, const double* knots, int n, const double* queries, int nq, int device) {
+    if (!out) return cp::fail(CP_EINVAL, "cp_geospline_plan_create: null plan pointer");
+    *out = nullptr;
+    if (!knots || !queries || n < 4 || nq < 1) return cp::fail(CP_EINVAL, "cp_geospline_plan_create: bad arguments");
+    if (nq > 64 * GEO_QMAX) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: %d queries (at most %d)", nq, 64 * GEO_QMAX);
+    const double rho = geometric_ratio("cp_geospline_plan_create", knots, n);
+    if (!(rho > 0.)) return CP_EUNSUPPORTED;
+    std::vector<int> qj(nq);
+    std::vector<double> qa(nq);
+    int jmin, jmax;
+    locate_queries(knots, n, queries, nq, qj, qa, &jmin, &jmax);
     if (jmax < 0) return cp::fail(CP_EUNSUPPORTED, "cp_geospline_plan_create: no query inside the knots");
     const int need = jmax - jmin + 1 + 2 * GEO_HALO;
     const int S = std::max(GEO_SMIN, (need + 63) / 64);
@@ -1098,6 +1271,7 @@ extern "C" int cp_geospline_plan_create(cp_geospline_plan** out, const double* k
     cp_geospline_plan* p = new (std::nothrow) cp_geospline_plan();
     if (!p) return cp::fail(CP_ENOMEM, "cp_geospline_plan_create: host allocation failed");
     p->n = n; p->nq = nq; p->ws = ws; p->ne = ne; p->S = S; p->device = device; p->d_qe = nullptr; p->d_qa = nullptr; p->d_consts = nullptr;
+    p->prefiltered = nullptr;
     GeoConsts consts{};
     {
         // a N_{i-1} + b N_i + c N_{i+1} = d_i on the infinite grid: N_i = kappa (sum_{j <= i} pL^(i-j) d_j + sum_{j > i} pR^(j-i) d_j), pL the root of
@@ -1119,17 +1293,74 @@ extern "C" int cp_geospline_plan_create(cp_geospline_plan** out, const double* k
     }
     for (int q = 0; q < nq; ++q)
         if (qj[q] >= 0) qj[q] -= ws;
-    int prev = -1, status = CP_OK;
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (prev != device && hipSetDevice(device) != hipSuccess) status = cp::fail(CP_EDEVICE, "cp_geospline_plan_create: cannot select device %d", device);
-    if (status == CP_OK && (hipMalloc(&p->d_qe, nq * sizeof(int)) != hipSuccess || hipMalloc(&p->d_qa, nq * sizeof(double)) != hipSuccess ||
-                            hipMalloc(&p->d_consts, sizeof(GeoConsts)) != hipSuccess))
-        status = cp::fail(CP_ENOMEM, "cp_geospline_plan_create: device allocation failed");
-    if (status == CP_OK && (hipMemcpy(p->d_qe, qj.data(), nq * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemcpy(p->d_qa, qa.data(), nq * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-                            hipMemcpy(p->d_consts, &consts, sizeof(GeoConsts), hipMemcpyHostToDevice) != hipSuccess))
-        status = cp::fail(CP_EDEVICE, "cp_geospline_plan_create: upload failed");
-    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    const int status = upload_geospline(p, qj, qa, consts);
+    if (status != CP_OK) {
+        cp_geospline_plan_destroy(p);
+        return status;
+    }
+    *out = p;
+    return CP_OK;
+}
+
+// The same spline for a transform the plan OWNS: built from the caller's FFTLog tables with the B-spline prefilter folded into u (see
+// fftlog_geospline_kernel<true>), so that the kernel's tail is four reads and sixteen multiply-adds per radius.
+extern "C" int cp_geospline_plan_create_prefiltered(cp_geospline_plan** out, int n, int npad, const double* pre, const double* post, const double* u_re_im,
+                                                    const double* knots, const double* queries, int nq, int device) {
+    const char* who = "cp_geospline_plan_create_prefiltered";
+    if (!out) return cp::fail(CP_EINVAL, "%s: null plan pointer", who);
+    *out = nullptr;
+    if (!pre || !post || !u_re_im || !knots || !queries || n < 4 || nq < 1) return cp::fail(CP_EINVAL, "%s: bad arguments", who);
+    if (npad != NP || n != NP / 2) return cp::fail(CP_EUNSUPPORTED, "%s: transform outside the fused kernel's shape (1024 samples padded to 2048)", who);
+    if (nq > 64 * GEO_QMAX) return cp::fail(CP_EUNSUPPORTED, "%s: %d queries (at most %d)", who, nq, 64 * GEO_QMAX);
+    const double rho = geometric_ratio(who, knots, n);
+    if (!(rho > 0.)) return CP_EUNSUPPORTED;
+    // the postfactor over the padded grid: post_0 lambda^j (a power of the geometric output grid, fftlog.py:175)
+    if (!(post[0] != 0.) || !std::isfinite(post[0]) || !std::isfinite(post[npad - 1])) return cp::fail(CP_EUNSUPPORTED, "%s: the postfactor is not a power law", who);
+    const long double lambda = powl((long double)post[npad - 1] / (long double)post[0], 1.0L / (npad - 1));
+    if (!(lambda > 0.0L)) return cp::fail(CP_EUNSUPPORTED, "%s: the postfactor is not a power law", who);
+    for (int j = 0; j + 1 < npad; ++j)
+        if (!(fabs(post[j + 1] / (post[j] * (double)lambda) - 1.) < 1e-11)) return cp::fail(CP_EUNSUPPORTED, "%s: the postfactor is not a power law (entry %d)", who, j + 1);
+    std::vector<int> qj(nq);
+    std::vector<double> qa(nq);
+    int jmin, jmax;
+    locate_queries(knots, n, queries, nq, qj, qa, &jmin, &jmax);
+    if (jmax < 0) return cp::fail(CP_EUNSUPPORTED, "%s: no query inside the knots", who);
+    // the kernel keeps the coefficients jmin - 1 ... jmax + 1; periodic ends on the padded grid stand for natural ends on the knots GEO_HALO knots away
+    const int ws = jmin, ne = jmax - jmin + 1;
+    if (ne + 2 > 64 * GEO_SMAX) return cp::fail(CP_EUNSUPPORTED, "%s: the queries span %d knots (at most %d)", who, ne, 64 * GEO_SMAX - 2);
+    if (jmin < GEO_HALO || jmax > n - 1 - GEO_HALO) return cp::fail(CP_EUNSUPPORTED, "%s: the queries come within %d knots of the ends of the grid", who, GEO_HALO);
+    long double basis[4][4];
+    geometric_bspline_pieces((long double)rho, basis);
+    std::vector<double> u((size_t)2 * (npad / 2 + 1));
+    {
+        // alpha c_{j-1} + beta c_j + gamma c_{j+1} = y_j: the values at s_j (x = 0) of the B-splines centred on s_{j-1}, s_j, s_{j+1}
+        const long double alpha = basis[0][0] / lambda, beta = basis[1][0], gamma = basis[2][0] * lambda;
+        const long double two_pi = 6.283185307179586476925286766559005768L;
+        for (int m = 0; m <= npad / 2; ++m) {
+            const long double w = two_pi * m / npad, cw = cosl(w), sw = sinl(w);
+            // conj(alpha e^{-i w} + beta + gamma e^{i w}) = (beta + (alpha + gamma) cos w) + i (alpha - gamma) sin w
+            const long double dr = beta + (alpha + gamma) * cw, di = (alpha - gamma) * sw, inv = 1.0L / (dr * dr + di * di);
+            const long double ur = u_re_im[2 * m], ui = u_re_im[2 * m + 1];
+            u[2 * m] = (double)((ur * dr + ui * di) * inv);
+            u[2 * m + 1] = (double)((ui * dr - ur * di) * inv);
+        }
+    }
+    cp_geospline_plan* p = new (std::nothrow) cp_geospline_plan();
+    if (!p) return cp::fail(CP_ENOMEM, "%s: host allocation failed", who);
+    p->n = n; p->nq = nq; p->ws = ws; p->ne = ne; p->S = 0; p->device = device; p->d_qe = nullptr; p->d_qa = nullptr; p->d_consts = nullptr;
+    p->prefiltered = nullptr;
+    int status = cp_fftlog_plan_create(&p->prefiltered, n, npad, 1, pre, post, u.data(), device);
+    if (status == CP_OK) {
+        GeoConsts consts{};
+        for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 4; ++e) consts.basis.k[i][e] = (double)basis[i][e];
+        for (int q = 0; q < nq; ++q)
+            if (qj[q] >= 0) {
+                qj[q] -= ws;
+                qa[q] = 1. - qa[q];
+            }
+        status = upload_geospline(p, qj, qa, consts);
+    }
     if (status != CP_OK) {
         cp_geospline_plan_destroy(p);
         return status;
@@ -1151,7 +1382,12 @@ extern "C" int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const c
     if (nbatch < 0 || group < 0) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: negative size");
     if (nbatch > 2000000000LL) return cp::fail(CP_EUNSUPPORTED, "cp_fftlog_geospline_execute: %lld rows in one call (split the batch)", nbatch);
     if (nbatch == 0) return CP_OK;
-    if (!fftlog || !spline || !d_in || !d_out) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: null pointer");
+    if (!spline || !d_in || !d_out) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: null pointer");
+    if ((fftlog != nullptr) == (spline->prefiltered != nullptr))
+        return cp::fail(CP_EINVAL, spline->prefiltered ? "cp_fftlog_geospline_execute: a prefiltered spline plan runs its own transform (pass a null fftlog plan)"
+                                                       : "cp_fftlog_geospline_execute: null pointer");
+    const bool coef = spline->prefiltered != nullptr;
+    if (coef) fftlog = spline->prefiltered;
     if (post_op != CP_SPLINE_POST_NONE && post_op != CP_SPLINE_POST_SQRT) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: unknown post op %d", post_op);
     if (group > 0 && ((group & 1) || nbatch % group)) return cp::fail(CP_EINVAL, "cp_fftlog_geospline_execute: %lld rows do not come in groups of an even %d", nbatch, group);
     cp_fftlog_tables_view f;
@@ -1173,8 +1409,12 @@ extern "C" int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const c
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != f.device && hipSetDevice(f.device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_geospline_execute: cannot select device %d", f.device);
     using F = Fftlog<NP, P, IN_HALF_ZERO, OUT_HALF>;
-    const size_t lds = (size_t)F::LDS_BYTES;
-    if (lds > 64 * 1024) (void)cp::allow_full_lds<&fftlog_geospline_kernel>();
+    // (prefiltered: the coefficients of the stretch behind the FFT's tables; up to 373 knots keep four workgroups on a CU)
+    const size_t lds = (size_t)F::LDS_BYTES + (coef ? (((size_t)2 * (spline->ne + 2) * sizeof(double) + 15) / 16) * 16 : 0);
+    const bool few = spline->nq <= 256;
+    if (lds > 64 * 1024)
+        (void)(!coef ? cp::allow_full_lds<&fftlog_geospline_kernel<false>>()
+                     : few ? cp::allow_full_lds<&fftlog_geospline_kernel<true, 4>>() : cp::allow_full_lds<&fftlog_geospline_kernel<true, GEO_QMAX>>());
     int ncu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, f.device);
     const long long npairs = (nbatch + 1) / 2;
@@ -1189,7 +1429,9 @@ extern "C" int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const c
         const long long rounds = (npairs + resident - 1) / resident;
         grid = (npairs + rounds - 1) / rounds;
     }
-    hipLaunchKernelGGL(fftlog_geospline_kernel, dim3((unsigned)grid), dim3(NP / P), lds, static_cast<hipStream_t>(stream), R);
+    if (coef && few) hipLaunchKernelGGL((fftlog_geospline_kernel<true, 4>), dim3((unsigned)grid), dim3(NP / P), lds, static_cast<hipStream_t>(stream), R);
+    else if (coef) hipLaunchKernelGGL((fftlog_geospline_kernel<true, GEO_QMAX>), dim3((unsigned)grid), dim3(NP / P), lds, static_cast<hipStream_t>(stream), R);
+    else hipLaunchKernelGGL(fftlog_geospline_kernel<false>, dim3((unsigned)grid), dim3(NP / P), lds, static_cast<hipStream_t>(stream), R);
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_fftlog_geospline_execute: launch failed: %s", hipGetErrorString(e));

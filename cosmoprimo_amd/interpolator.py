@@ -221,15 +221,30 @@ def _fftlog_then_spline(fft, op, rows, device, sqrt=False):
 
 class _GeoSpline(object):
 
-    """Owner of a ``cp_geospline_plan``: the natural spline from a geometric grid (the output grid of an FFTLog) to fixed queries, solved inside the
-    FFTLog kernel by cyclic reduction.  ``handle`` is None where the library refuses the plan (queries near the ends of the grid, too wide a span)."""
+    """Owner of a ``cp_geospline_plan``: the natural spline from a geometric grid (the output grid of an FFTLog) to fixed queries, evaluated inside the
+    FFTLog kernel.  With ``fft`` (and :data:`_GEOSPLINE_PREFILTERED`) the plan owns a copy of that transform with the B-spline prefilter folded into
+    its ``u`` (``prefiltered`` True: execute takes no FFTLog plan); otherwise, or where the library refuses that (a postfactor that is no power law),
+    the spline is solved on the CU from the transform's ordinary output.  ``handle`` is None where the library refuses both (queries near the ends
+    of the grid, too wide a span)."""
 
-    def __init__(self, knots, queries, device):
+    def __init__(self, knots, queries, device, fft=None, keep=None):
         import ctypes
-        self.handle, self.nq = None, int(np.size(queries))
+        self.handle, self.nq, self.prefiltered, self._keep = None, int(np.size(queries)), False, keep
         handle = ctypes.c_void_p()
         knots, queries = np.ascontiguousarray(knots, dtype='f8'), np.ascontiguousarray(queries, dtype='f8')
-        status = _lib.load().cp_geospline_plan_create(ctypes.byref(handle), _lib.as_double_p(knots), knots.size, _lib.as_double_p(queries), queries.size, device.index)
+        lib = _lib.load()
+        if fft is not None and _GEOSPLINE_PREFILTERED and fft.nparallel == 1 and not any(np.iscomplexobj(t) for t in (fft.padded_prefactor, fft.padded_postfactor)):
+            pre, post = (np.ascontiguousarray(t, dtype='f8').ravel() for t in (fft.padded_prefactor, fft.padded_postfactor))
+            u = np.ascontiguousarray(fft.padded_u, dtype='c16').ravel()
+            status = lib.cp_geospline_plan_create_prefiltered(ctypes.byref(handle), fft.size, fft.padded_size, _lib.as_double_p(pre), _lib.as_double_p(post),
+                                                              _lib.as_double_p(u.view('f8')), _lib.as_double_p(knots), _lib.as_double_p(queries), queries.size,
+                                                              device.index)
+            if status == _lib.CP_OK:
+                self.handle, self.prefiltered = handle, True
+                return
+            if status != _lib.CP_EUNSUPPORTED:
+                _lib.check(status)
+        status = lib.cp_geospline_plan_create(ctypes.byref(handle), _lib.as_double_p(knots), knots.size, _lib.as_double_p(queries), queries.size, device.index)
         if status == _lib.CP_EUNSUPPORTED:
             return
         _lib.check(status)
@@ -245,6 +260,7 @@ class _GeoSpline(object):
 
 
 _GEOSPLINE_MIN_ROWS = 8193      # below: the band-operator kernel of _fftlog_then_spline (launch- / latency-bound regime)
+_GEOSPLINE_PREFILTERED = True      # the spline's solve folded into the transform's u (False: solved on the CU from the ordinary output; measurements)
 _GEOSPLINE_GROUPED = True      # sigma_rz's (..., nr, nz) layout written by the kernel itself (False: (..., nz, nr) and a transposed view; measurements)
 
 
@@ -257,7 +273,10 @@ def _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=False, group=0):
         return None
     if getattr(fft, '_phase', None) is not None or getattr(fft, '_phase_in', None) is not None:
         return None
-    plan = _cached_operator(('geospline', s.tobytes(), rr.tobytes(), device.index), lambda: _GeoSpline(s, rr, device))
+    # (keyed by the transform's library plan, rebuilt whenever its tables change; the spline plan holds it, so that its id stays its own)
+    native = fft._get_plan(device)
+    plan = _cached_operator(('geospline', id(native), _GEOSPLINE_PREFILTERED, s.tobytes(), rr.tobytes(), device.index),
+                            lambda: _GeoSpline(s, rr, device, fft=fft, keep=native))
     if plan.handle is None:
         return None
     rows = rows.contiguous()
@@ -271,7 +290,7 @@ def _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=False, group=0):
         oshape = lead + (plan.nq,)
     out = torch.empty(oshape, dtype=torch.float64, device=device)
     if nrows:
-        _lib.check(_lib.load().cp_fftlog_geospline_execute(fft._get_plan(device).handle, plan.handle, rows.data_ptr(), out.data_ptr(), nrows, int(group),
+        _lib.check(_lib.load().cp_fftlog_geospline_execute(None if plan.prefiltered else native.handle, plan.handle, rows.data_ptr(), out.data_ptr(), nrows, int(group),
                                                            int(bool(sqrt)), dv.stream_of(device)))
     return out
 

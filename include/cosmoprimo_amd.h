@@ -349,6 +349,15 @@ int cp_fftlog_spline_execute(const cp_fftlog_plan* fftlog, const cp_spline_plan*
  * d_out = post(spline), post_op CP_SPLINE_POST_NONE or CP_SPLINE_POST_SQRT.  Transform: 1024 samples padded to 2048, one kernel. */
 typedef struct cp_geospline_plan cp_geospline_plan;
 int cp_geospline_plan_create(cp_geospline_plan** plan, const double* knots, int n, const double* queries, int nq, int device);
+/* The same spline with its solve folded into the transform: in the B-spline basis of the geometric knots (scale invariant: B_j(s) = B_0(s / rho^j))
+ * the interpolation conditions are a constant-coefficient tridiagonal system, and on FFTLog's periodic padded grid with a power-law postfactor that is
+ * a division of u in the frequency domain.  The plan builds and OWNS that transform from the caller's FFTLog tables (pre, post: (npad) of one kernel, u_re_im:
+ * (npad / 2 + 1) re / im pairs, as for cp_fftlog_plan_create) and execute then costs four reads and sixteen multiply-adds per query after the FFT;
+ * the periodic ends of the padded grid stand for the natural ends of the knots, both forgotten like 0.27^distance: queries within 32 knots of either
+ * end of the knots are refused (CP_EUNSUPPORTED, as are a postfactor that is no power law, other sizes than 1024 -> 2048, more than 512 queries or a
+ * span of more than 510 knots): take cp_geospline_plan_create.  cp_fftlog_geospline_execute with such a plan takes fftlog = NULL. */
+int cp_geospline_plan_create_prefiltered(cp_geospline_plan** plan, int n, int npad, const double* pre, const double* post, const double* u_re_im,
+                                         const double* knots, const double* queries, int nq, int device);
 int cp_geospline_plan_destroy(cp_geospline_plan* plan);
 int cp_geospline_plan_info(const cp_geospline_plan* plan, int* first_knot, int* nknots, int* nq);
 int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const cp_geospline_plan* spline, const double* d_in, double* d_out, long long nbatch,

@@ -101,8 +101,10 @@ def test_fftlog_spline_execute(nrows, nq):
 
 
 @pytest.mark.parametrize('nrows,nq,group', [(1, 1, 0), (2, 40, 0), (33, 256, 0), (301, 130, 0), (64, 256, 64), (6 * 10, 100, 10), (9 * 64, 256, 64), (4 * 2, 511, 2)])
-def test_fftlog_geospline_execute(nrows, nq, group):
-    """cp_fftlog_geospline_execute (FFTLog + natural spline SOLVED on the CU by cyclic reduction on the geometric output grid) against scipy's
+@pytest.mark.parametrize('prefiltered', [True, False])
+def test_fftlog_geospline_execute(nrows, nq, group, prefiltered, monkeypatch):
+    """cp_fftlog_geospline_execute (FFTLog + natural spline on the geometric output grid, SOLVED on the CU by two first-order recursions, or --
+    prefiltered -- evaluated from B-spline coefficients that the transform itself delivers, the solve being a division of its u) against scipy's
     CubicSpline(bc_type='natural') of the package's own transformed rows (1e-13 in tilted space) and against the band-operator route; plain and grouped (transposed) layouts, odd batches, a NaN row next to good ones, queries outside the grid, tables
     (groups) that do not fill the eight XCD shares."""
     from scipy.interpolate import CubicSpline
@@ -110,6 +112,7 @@ def test_fftlog_geospline_execute(nrows, nq, group):
     import cosmoprimo_amd as cp
     from cosmoprimo_amd import interpolator as itp
     from cosmoprimo_amd.spline import LinearOperator
+    monkeypatch.setattr(itp, '_GEOSPLINE_PREFILTERED', prefiltered)
     k = np.geomspace(1e-7, 1e2, 1024)
     fft = cp.TophatVariance(k, device=dev)
     s = fft.y[0]
@@ -142,14 +145,27 @@ def test_fftlog_geospline_execute(nrows, nq, group):
             ref = CubicSpline(s, var[i], bc_type='natural')(r[inside])
             tilted = np.abs((got[i, inside]**2 if sqrt else got[i, inside]) - ref) * r[inside]**1.5
             assert tilted.max() < 1e-13 * np.abs(var[i] * s**1.5).max(), 'row %d' % i
+        plan = [v for key, v in itp._op_cache.items() if key[0] == 'geospline' and key[2] == prefiltered][-1]
+        assert plan.prefiltered == prefiltered
         # the kernel with the same front end and the band operator behind it transforms with the same arithmetic: what is left is the solve
         same_front = itp._fftlog_then_spline(fft, op, rows, dev, sqrt=sqrt)
+        banded = op(torch.as_tensor(var, device=dev), sqrt=sqrt).cpu().numpy()
         if same_front is not None:
             same_front = same_front.cpu().numpy()
+            assert np.array_equal(np.isfinite(got), np.isfinite(same_front))
+        if prefiltered:      # another u: another evaluation of the transform, compared as the reference above is
+            for other in (same_front, banded):
+                if other is None:
+                    continue
+                for i in range(nrows):
+                    if nrows > 2 and i == 1:
+                        continue
+                    a, b = (x[i, inside]**2 if sqrt else x[i, inside] for x in (got, other))
+                    assert (np.abs(a - b) * r[inside]**1.5).max() < 1e-13 * np.abs(var[i] * s**1.5).max(), 'row %d' % i
+            continue
+        if same_front is not None:
             keep = np.isfinite(same_front)
-            assert np.array_equal(np.isfinite(got), keep)
             np.testing.assert_allclose(got[keep], same_front[keep], rtol=1e-12)
-        banded = op(torch.as_tensor(var, device=dev), sqrt=sqrt).cpu().numpy()
         keep = np.isfinite(banded)
         np.testing.assert_allclose(got[keep], banded[keep], rtol=2e-11)
 
@@ -176,6 +192,21 @@ def test_geospline_plans_the_library_refuses():
         plan = itp._GeoSpline(s, np.array([8.]), dev)
         out = torch.empty((4, 1), dtype=torch.float64, device=dev)
         _lib.check(lib.cp_fftlog_geospline_execute(fft._get_plan(dev).handle, plan.handle, rows.data_ptr(), out.data_ptr(), 4, 3, 0, dv.stream_of(dev)))
+    # the prefiltered plan: the same limits on the radii (the solve would be refused, the caller takes the band operator); a postfactor that is
+    # no power law leaves the solve on the CU; such a plan runs its OWN transform and says so when handed another
+    assert itp._GeoSpline(s, np.array([8.]), dev, fft=fft).prefiltered
+    for radii in (np.array([s[5] * 1.01, 8.]), np.array([8., s[-20]]), np.geomspace(s[100], s[900], 64)):
+        assert itp._GeoSpline(s, radii, dev, fft=fft).handle is None
+    bent = cp.TophatVariance(k, device=dev)
+    bent.padded_postfactor = bent.padded_postfactor * (1. + 1e-3 * np.sin(np.arange(2048) / 100.))
+    plan = itp._GeoSpline(s, np.array([8.]), dev, fft=bent)
+    assert plan.handle is not None and not plan.prefiltered
+    plan = itp._GeoSpline(s, np.array([8.]), dev, fft=fft)
+    out = torch.empty((4, 1), dtype=torch.float64, device=dev)
+    with pytest.raises(ValueError, match='its own transform'):
+        _lib.check(lib.cp_fftlog_geospline_execute(fft._get_plan(dev).handle, plan.handle, rows.data_ptr(), out.data_ptr(), 4, 0, 0, dv.stream_of(dev)))
+    with pytest.raises(ValueError):
+        _lib.check(lib.cp_fftlog_geospline_execute(None, itp._GeoSpline(s, np.array([8.]), dev).handle, rows.data_ptr(), out.data_ptr(), 4, 0, 0, dv.stream_of(dev)))
 
 
 def test_bao_elementwise_passes():

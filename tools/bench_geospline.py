@@ -1,5 +1,6 @@
 """640 000 rows of 1024 samples (the FFTLog stage of config 3B) -> 256 radii, alternately in one process: cp_fftlog_execute_window + the band
-operator on the matrix cores (round 3) against cp_fftlog_geospline_execute (the spline solved on the CU), plain and grouped layouts.
+operator on the matrix cores (round 3) against cp_fftlog_geospline_execute (the spline solved on the CU, round 4, or folded into the transform, round 6),
+plain and grouped layouts.
     python tools/bench_geospline.py [nrows]"""
 import os
 import sys
@@ -24,11 +25,17 @@ def main():
     rng = np.random.default_rng(0)
     base = torch.as_tensor((k / 0.05)**-1.5 * 1e3 / (1. + (k / 0.02)**2.2), device=dev)
     rows = (torch.as_tensor(rng.uniform(0.5, 2., (nrows, 1)), device=dev) * base[None, :]).contiguous()
+    def geo(prefiltered, shaped, group):      # the spline's solve folded into the transform (round 6) or run on the CU (round 4)
+        itp._GEOSPLINE_PREFILTERED = prefiltered
+        return itp._fftlog_then_geospline(fft, s, r, shaped, dev, sqrt=True, group=group)
+
     routes = {
         'fftlog (windowed stores) + operator': lambda: op(fft(rows, out_window=op.columns)[1], sqrt=True),
         'fftlog + operator, grouped store': lambda: op(fft(rows.reshape(-1, 64, 1024), out_window=op.columns)[1], sqrt=True, last_axis_first=True),
-        'geospline, (rows, radii)': lambda: itp._fftlog_then_geospline(fft, s, r, rows, dev, sqrt=True),
-        'geospline, (tables, radii, 64)': lambda: itp._fftlog_then_geospline(fft, s, r, rows.reshape(-1, 64, 1024), dev, sqrt=True, group=64),
+        'geospline, (rows, radii)': lambda: geo(True, rows, 0),
+        'geospline, (tables, radii, 64)': lambda: geo(True, rows.reshape(-1, 64, 1024), 64),
+        'geospline solved on the CU, (rows, radii)': lambda: geo(False, rows, 0),
+        'geospline solved on the CU, (tables, radii, 64)': lambda: geo(False, rows.reshape(-1, 64, 1024), 64),
     }
     res = {}
     for rnd in range(3):
@@ -42,7 +49,9 @@ def main():
             torch.cuda.synchronize()
             res.setdefault(name, []).append((time.perf_counter() - t0) / 10 * 1e3)
     for name, ms in res.items():
-        print('%-40s %s ms' % (name, ' '.join('%.3f' % v for v in ms)))
+        print('%-50s %s ms' % (name, ' '.join('%.3f' % v for v in ms)))
+    a, b = (geo(p, rows[:4096], 0) for p in (True, False))
+    print('prefiltered against solved, 4096 rows: max relative difference %.3g' % float(((a - b).abs() / b.abs()).max()))
 
 
 if __name__ == '__main__':
