@@ -49,15 +49,30 @@ __device__ __forceinline__ void tail_evaluate(const double* yu, double* outrow, 
     const int* qe = g->U.qe;
     const double4* qw = reinterpret_cast<const double4*>(g->U.qw);
     const double* tophat = g->tophat;
+    // Every block of 64 queries requests its plan entries and the row's own values FIRST, all blocks together, then they are consumed: written as one loop
+    // (request, use, store per block, the blocks behind wave-uniform branches) each block waited for its own loads -- two memory round trips, the second
+    // one (the window) behind the first -- and, the memory counter retiring in order, for the store of the block before: sixteen round trips in a row.
+    // Blocks past the last one request the entries of block 0 (valid addresses, results unused).
+    int jv[cpsu::NGB];
+    double wz[cpsu::NGB], ww[cpsu::NGB], pv[cpsu::NGB], tv[cpsu::NGB];
+#pragma unroll
+    for (int e = 0; e < cpsu::NGB; ++e) {
+        const int slot = 64 * (e < ngb ? e : 0) + lane, q = 64 * gb0 + slot, qc = q < nq ? q : 0;
+        jv[e] = qe[slot];
+        const double2 w = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(qw + slot) + 2);
+        wz[e] = w.x;
+        ww[e] = w.y;
+        pv[e] = pkrow[qc];      // the row's own value at the query
+        tv[e] = tophat ? tophat[qc] : 0.;
+    }
 #pragma unroll
     for (int e = 0; e < cpsu::NGB; ++e) {
         if (e < ngb) {
             const int slot = 64 * e + lane, q = 64 * gb0 + slot;
-            const int j = qe[slot];
-            const double4 w = qw[slot];
-            double v = part[e] + fma(w.z, yu[j], w.w * yu[j + 1]);
-            const double p = q < nq ? pkrow[q] : 0.;      // the row's own value at the query (requested here with the query's weights: ahead of the stages it was spilled)
-            if (tophat) v = p * (v * cpmath::recip(fma(p - v, (q < nq ? tophat[q] : 0.), v)));
+            const int j = jv[e];
+            double v = part[e] + fma(wz[e], yu[j], ww[e] * yu[j + 1]);
+            const double p = q < nq ? pv[e] : 0.;
+            if (tophat) v = p * (v * cpmath::recip(fma(p - v, (q < nq ? tv[e] : 0.), v)));
             if (q >= gfirst && q < gend && !(CP_TAIL_ABLATE & 16)) outrow[q] = v;
         }
     }
@@ -106,15 +121,24 @@ __device__ __forceinline__ void tail_splice_row(double* row, double* outrow, int
         const int ngb = g0->U.ngb;
         const int* qe = g0->U.qe;
         const double4* qw = reinterpret_cast<const double4*>(g0->U.qw);
+        // (the plan entries of all blocks requested together, then used: block by block behind wave-uniform branches each one waited for its own)
+        int jv[NGB];
+        double wx[NGB], wy[NGB];
+#pragma unroll
+        for (int e = 0; e < NGB; ++e) {
+            const int slot = 64 * (e < ngb ? e : 0) + lane;
+            jv[e] = qe[slot];
+            const double2 w = *reinterpret_cast<const double2*>(qw + slot);
+            wx[e] = w.x;
+            wy[e] = w.y;
+        }
 #pragma unroll
         for (int e = 0; e < NGB; ++e) {
             part[e] = 0.;
             if (e < ngb) {
-                const int slot = 64 * e + lane;
-                const int j = qe[slot];
-                const double4 w = qw[slot];
+                const int j = jv[e];
                 const double ya = yu[j], yb = yu[j + 1];      // (j = -1 and j + 1 = nm read slots of the row that hold no knot: replaced)
-                part[e] = fma(w.x, j < 0 ? gl_last : ya, w.y * (j + 1 >= nm ? gr_first : yb));
+                part[e] = fma(wx[e], j < 0 ? gl_last : ya, wy[e] * (j + 1 >= nm ? gr_first : yb));
             }
         }
     }
@@ -271,14 +295,17 @@ __device__ __forceinline__ void tail_stages(long long p, bool has_b, int t, cplx
             const bool even = (tt & 1) == 0;
             const int a0 = (tt >> 1) & 15, a1 = tt >> 5;
             const int obase = even ? 256 * a0 + 16 * a1 : 256 * (15 - a0) + 16 * (15 - a1), ostep = even ? 136 : -120;
+            // (1 / k of the thread's sixteen samples requested together: inside the branch below each one was a memory round trip of its own)
+            double ikv[P];
+#pragma unroll
+            for (int s = 0; s < P; ++s) ikv[s] = ikx[tt + T * s];
 #pragma unroll
             for (int s = 0; s < P; ++s) {
-                const int n = tt + T * s;
                 const cplx g = lds[obase + ostep * (s & 1) + ((s >> 1) ^ a1)];
                 double ya = even ? g.re : -g.re;
                 double yb = even ? -g.im : g.im;
                 if (T * s < u_hi && T * s + T > u_lo && !(CP_TAIL_ABLATE & 4)) {      // (uniform over the workgroup: the columns outside the stretch are never looked at)
-                    const double ik = ikx[n];
+                    const double ik = ikv[s];
                     ya = cpmath::exp_tab(ya, &mt) * ik;
                     yb = cpmath::exp_tab(yb, &mt) * ik;
                 }
