@@ -71,9 +71,25 @@ template <int NK, bool TIME, bool NCDM>   // NCDM = false: no massive species --
 __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     __shared__ TablesN<NK> T;
     {
+        // (the thread's entries requested together, then stored: entry by entry the copy was a memory round trip per 256 doubles in front of the barrier)
         const double* src = reinterpret_cast<const double*>(A.tab);
         double* dst = reinterpret_cast<double*>(&T);
-        for (int i = threadIdx.x; i < (int)(sizeof(TablesN<NK>) / sizeof(double)); i += blockDim.x) dst[i] = src[i];
+        constexpr int NT = (int)(sizeof(TablesN<NK>) / sizeof(double)), PER = (NT + 255) / 256;
+        if (blockDim.x == 256) {
+            double tmp[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int i = (int)threadIdx.x + 256 * j;
+                tmp[j] = src[i < NT ? i : NT - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int i = (int)threadIdx.x + 256 * j;
+                if (i < NT) dst[i] = tmp[j];
+            }
+        } else {
+            for (int i = threadIdx.x; i < NT; i += blockDim.x) dst[i] = src[i];
+        }
     }
     __shared__ double ncdm_knots[CP_NCDM_NKNOTS];
     if (NCDM && A.nsp)

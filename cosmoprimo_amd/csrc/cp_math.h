@@ -221,6 +221,13 @@ __device__ __forceinline__ const MathTables* tables_present(const MathTables* t)
 
 // every thread of the workgroup calls this; a barrier follows at the caller's
 __device__ __forceinline__ void fill_math_tables(MathTables* t) {
+    if (blockDim.x >= 128) {      // both entries of the thread requested before either is stored: one memory round trip in front of the barrier, not two
+        const int i = threadIdx.x;
+        const double e = exp2_table[i & 63], l = log_table[i & 127];
+        if (i < 64) t->exp2[i] = e;
+        if (i < 128) t->logc[i] = l;
+        return;
+    }
     for (int i = threadIdx.x; i < 64; i += blockDim.x) t->exp2[i] = exp2_table[i];
     for (int i = threadIdx.x; i < 128; i += blockDim.x) t->logc[i] = log_table[i];
 }
