@@ -77,6 +77,7 @@ SIGNATURES = {
     'cp_geospline_plan_create': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _c_double_p, ctypes.c_int, _c_double_p, ctypes.c_int, ctypes.c_int]),
     'cp_geospline_plan_create_prefiltered': (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, _c_double_p, _c_double_p, _c_double_p,
                                                            _c_double_p, _c_double_p, ctypes.c_int, ctypes.c_int]),
+    'cp_geospline_basis': (ctypes.c_int, [ctypes.c_double, _c_double_p]),
     'cp_geospline_plan_destroy': (ctypes.c_int, [ctypes.c_void_p]),
     'cp_geospline_plan_info': (ctypes.c_int, [ctypes.c_void_p, _c_int_p, _c_int_p, _c_int_p]),
     'cp_fftlog_geospline_execute': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,

@@ -1302,6 +1302,18 @@ extern "C" int cp_geospline_plan_create(cp_geospline_plan** out, const double* k
     return CP_OK;
 }
 
+// Host only (no device call): the four cubic B-splines of the geometric knots rho^m on [1, rho] as polynomials in x = (r - 1) / (rho - 1), basis[4 i + d] the
+// coefficient of x^d of the one centred on rho^(i - 1) -- what a prefiltered plan evaluates with; their values at x = 0 are the interpolation conditions'
+// alpha, beta, gamma (the fourth is 0).
+extern "C" int cp_geospline_basis(double rho, double* basis) {
+    if (!basis || !(rho > 1.) || !std::isfinite(rho)) return cp::fail(CP_EINVAL, "cp_geospline_basis: need rho > 1 and 16 doubles of room");
+    long double b[4][4];
+    geometric_bspline_pieces((long double)rho, b);
+    for (int i = 0; i < 4; ++i)
+        for (int d = 0; d < 4; ++d) basis[4 * i + d] = (double)b[i][d];
+    return CP_OK;
+}
+
 // The same spline for a transform the plan OWNS: built from the caller's FFTLog tables with the B-spline prefilter folded into u (see
 // fftlog_geospline_kernel<true>), so that the kernel's tail is four reads and sixteen multiply-adds per radius.
 extern "C" int cp_geospline_plan_create_prefiltered(cp_geospline_plan** out, int n, int npad, const double* pre, const double* post, const double* u_re_im,

@@ -358,6 +358,9 @@ int cp_geospline_plan_create(cp_geospline_plan** plan, const double* knots, int 
  * span of more than 510 knots): take cp_geospline_plan_create.  cp_fftlog_geospline_execute with such a plan takes fftlog = NULL. */
 int cp_geospline_plan_create_prefiltered(cp_geospline_plan** plan, int n, int npad, const double* pre, const double* post, const double* u_re_im,
                                          const double* knots, const double* queries, int nq, int device);
+/* host only: the B-spline pieces such a plan evaluates with -- basis[4 i + d] = coefficient of x^d, x = (r - s_j) / (s_j+1 - s_j), of the cubic B-spline of the
+ * geometric knots (ratio rho > 1) centred on s_(j-1+i); their values at x = 0 are the alpha, beta, gamma of the interpolation conditions */
+int cp_geospline_basis(double rho, double* basis);
 int cp_geospline_plan_destroy(cp_geospline_plan* plan);
 int cp_geospline_plan_info(const cp_geospline_plan* plan, int* first_knot, int* nknots, int* nq);
 int cp_fftlog_geospline_execute(const cp_fftlog_plan* fftlog, const cp_geospline_plan* spline, const double* d_in, double* d_out, long long nbatch,
