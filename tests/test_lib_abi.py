@@ -87,6 +87,39 @@ def test_error_mapping_of_the_table_and_distance_entry_points():
     assert not handle.value
 
 
+def test_error_mapping_of_the_prefiltered_spline_plan():
+    """Everything cp_geospline_plan_create_prefiltered refuses, it refuses before its first device call (this box has no device): sizes other than
+    1024 -> 2048, knots that are not geometric, a postfactor that is no power law, radii near the ends of the knots or too far apart; and
+    cp_fftlog_geospline_execute wants exactly one transform."""
+    import ctypes
+    lib = _lib.load()
+    handle = ctypes.c_void_p()
+    n, npad = 1024, 2048
+    knots = np.geomspace(1e-2, 1e7, n)
+    j = np.arange(npad)
+    pre, post, u = np.ones(npad), 3. * 0.97**j, np.ones(2 * (npad // 2 + 1))
+    radii = np.geomspace(1., 100., 16)
+
+    def create(n=n, npad=npad, pre=pre, post=post, u=u, knots=knots, radii=radii):
+        return lib.cp_geospline_plan_create_prefiltered(ctypes.byref(handle), n, npad, _lib.as_double_p(pre), _lib.as_double_p(post), _lib.as_double_p(u),
+                                                        _lib.as_double_p(knots), _lib.as_double_p(radii), radii.size, 0)
+
+    assert create(n=512, npad=1024) == _lib.CP_EUNSUPPORTED and b'1024 samples' in lib.cp_last_error()
+    assert create(knots=np.linspace(1., 2., n)) == _lib.CP_EUNSUPPORTED and b'geometric' in lib.cp_last_error()
+    assert create(post=post * (1. + 1e-6 * np.sin(j))) == _lib.CP_EUNSUPPORTED and b'power law' in lib.cp_last_error()
+    assert create(post=np.zeros(npad)) == _lib.CP_EUNSUPPORTED
+    assert create(radii=np.array([knots[3] * 1.01, 8.])) == _lib.CP_EUNSUPPORTED and b'within 32 knots' in lib.cp_last_error()
+    assert create(radii=np.array([8., knots[-5]])) == _lib.CP_EUNSUPPORTED
+    assert create(radii=np.geomspace(knots[40], knots[900], 8)) == _lib.CP_EUNSUPPORTED and b'span' in lib.cp_last_error()
+    assert create(radii=np.array([1e-9, 1e12])) == _lib.CP_EUNSUPPORTED and b'no query inside' in lib.cp_last_error()
+    assert create(radii=np.geomspace(1., 100., 513)) == _lib.CP_EUNSUPPORTED
+    assert lib.cp_geospline_plan_create_prefiltered(ctypes.byref(handle), n, npad, None, None, None, None, None, 4, 0) == _lib.CP_EINVAL
+    assert not handle.value
+    with pytest.raises(ValueError):      # no spline plan at all
+        _lib.check(lib.cp_fftlog_geospline_execute(None, None, ctypes.c_void_p(8), ctypes.c_void_p(8), 4, 0, 0, None))
+    assert lib.cp_fftlog_geospline_execute(None, None, None, None, 0, 0, 0, None) == 0      # nothing to do
+
+
 def test_loggamma_vs_scipy_golden(golden):
     # G2: scipy.special.loggamma / gamma on the kernels' arguments + stress grid
     g = golden('loggamma')
