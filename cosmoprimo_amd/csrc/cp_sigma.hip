@@ -48,6 +48,11 @@ constexpr int NP = 2048, P = 16;
 
 typedef double cp_v2d __attribute__((ext_vector_type(2)));
 
+// the four cubic B-splines of a geometric knot sequence that live on one interval, as polynomials of the position in it (cp_geospline_basis)
+struct GeoBasis {
+    double k[4][4];             // the B-spline centred on knot j - 1 + i is sum_d k[i][d] x^d on [s_j, s_j+1], x = (r - s_j) / h_j
+};
+
 struct SigmaArgs {
     FftlogArgs fft;               // tables of the TophatVariance plan; in / out unused
     long long ncosmo;
@@ -63,6 +68,12 @@ struct SigmaArgs {
     const double* wb;             // (bw, nq) band of the spline operator, query fastest
     const int* j0;                // (nq) first knot of each band, -1: outside the knots
     int bw, nq, nz;
+    // COEF (the transform's u carries the B-spline prefilter: see fftlog_geospline_kernel): the radii's intervals relative to knot ws (-1: outside the
+    // knots), their positions x in the interval, the four cubic pieces
+    const int* qe;
+    const double* qx;
+    const GeoBasis* basis;
+    int ws;
     const double* growth_sq;      // (ncosmo, nz)
     double* out;                  // (ncosmo, nq, nz)
     double* pk_out;               // (ncosmo, n) the spectra themselves, or null
@@ -186,7 +197,48 @@ CP_HD void spline_to_radii(int t, const cplx* lds, const double* __restrict__ wb
     }
 }
 
-template <int ENGINE>
+// The same spline from its B-spline coefficients (the transform carried the prefilter: the data region holds c_j of both rows where the variances would
+// be): a radius in [s_j, s_j+1] is c_{j-1} ... c_{j+2} times four cubic weights of its position -- four 16-byte LDS reads (both rows) and 20 multiply-adds
+// where the band operator takes ~44 weights from L2 and 88 multiply-adds.
+template <int T>
+CP_HD void bspline_to_radii(int t, const cplx* lds, const int* __restrict__ qes, const double* __restrict__ qxs, const GeoBasis* basis, int ws, int nq,
+                            double* roots_r) {
+    const LdsView v(lds);
+    const GeoBasis B = load_uniform(basis);      // scalar loads
+    for (int q = t; q < nq; q += 2 * T) {
+        const int q2 = q + T < nq ? q + T : q;      // the second query of the thread (the first again when there is none: not stored)
+        const int ea = qes[q], eb = qes[q2];
+        const double xa = qxs[q], xb = qxs[q2];
+        const int ja = ws + (ea < 0 ? 0 : ea) - 1, jb = ws + (eb < 0 ? 0 : eb) - 1;      // the first of the four coefficients
+        cplx ca[4], cb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ca[i] = v.read(v.l0 + (unsigned)(ja + i) * 16u);
+            cb[i] = v.read(v.l0 + (unsigned)(jb + i) * 16u);
+        }
+        double acc[4] = {0., 0., 0., 0.};             // (row a, row b) of query q, then of query q2
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double wa = fma(fma(fma(B.k[i][3], xa, B.k[i][2]), xa, B.k[i][1]), xa, B.k[i][0]);
+            const double wq = fma(fma(fma(B.k[i][3], xb, B.k[i][2]), xb, B.k[i][1]), xb, B.k[i][0]);
+            acc[0] = fma(wa, ca[i].re, acc[0]);
+            acc[1] = fma(wa, ca[i].im, acc[1]);
+            acc[2] = fma(wq, cb[i].re, acc[2]);
+            acc[3] = fma(wq, cb[i].im, acc[3]);
+        }
+        const double nan = __builtin_nan("");
+        if (ea < 0) acc[0] = acc[1] = nan;
+        if (eb < 0) acc[2] = acc[3] = nan;
+        roots_r[q] = sqrt(acc[0]);
+        roots_r[nq + q] = sqrt(acc[1]);
+        if (q2 != q) {
+            roots_r[q2] = sqrt(acc[2]);
+            roots_r[nq + q2] = sqrt(acc[3]);
+        }
+    }
+}
+
+template <int ENGINE, bool COEF>
 __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) {
     using F = Fftlog<NP, P, IN_HALF_ZERO_GEN, OUT_HALF>;
     constexpr int T = F::T, H = F::H, Q = F::Q;
@@ -280,7 +332,8 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
         if (CP_SIGMA_ABLATE & 2) {
             for (int q = t; q < 2 * S.nq; q += T) roots_r[q] = 1. + q;
         } else {
-            spline_to_radii<T>(tv, lds, S.wb, S.j0, S.bw, S.nq, roots_r);
+            if constexpr (COEF) bspline_to_radii<T>(tv, lds, S.qe, S.qx, S.basis, S.ws, S.nq, roots_r);
+            else spline_to_radii<T>(tv, lds, S.wb, S.j0, S.bw, S.nq, roots_r);
         }
         __syncthreads();
         // ---- out[c, q, z] = sqrt(var[q]) sqrt(growth_sq[z]): the (nq x nz) block of a cosmology is contiguous; 16-byte stores when nz is even ----
@@ -443,9 +496,7 @@ struct GeoConsts {                  // on the device, read by scalar loads right
     double pRk[GEO_SMAX];           // pR^(S - k)
     double cL[GEO_REACH];           // (pL^S)^m: the segment total of the lane m + 1 to the left
     double cR[GEO_REACH];
-    struct Basis {
-        double k[4][4];             // prefiltered plans: the B-spline centred on knot j - 1 + i is sum_d k[i][d] x^d on [s_j, s_j+1], x = (r - s_j) / h_j
-    } basis;
+    GeoBasis basis;                 // prefiltered plans
 };
 
 struct GeoArgs {
@@ -552,7 +603,7 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
         const double* Ca = side + 1;      // Ca[-1 .. ne]: the B-spline coefficients of the stretch, first row (second: side_stride further)
         const GeoConsts* C = R.consts;
         asm volatile("" : "+s"(C));      // (not hoisted out of the loop over pairs: the scalar registers are the FFT's there)
-        const GeoConsts::Basis B = load_uniform(&C->basis);      // scalar loads
+        const GeoBasis B = load_uniform(&C->basis);      // scalar loads
         const int qstride = grouped ? R.group : 1;
         const unsigned voff = (unsigned)(lane * qstride) * 8u;
         const int nqi = (CP_GEO_ABLATE & 2) ? 1 : (((R.nq + 63) >> 6) - wave_s + 1) >> 1;      // (wave-uniform) blocks of 64 radii of this wave
@@ -793,10 +844,27 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
 
 template <int ENGINE>
 hipError_t launch(const SigmaArgs& S, int grid, size_t lds, hipStream_t stream) {
-    if (lds > 64 * 1024) (void)cp::allow_full_lds<&sigma_rz_kernel<ENGINE>>();
-    hipLaunchKernelGGL(sigma_rz_kernel<ENGINE>, dim3(grid), dim3(NP / P), lds, stream, S);
+    if (S.qe) {      // the radii come from B-spline coefficients
+        if (lds > 64 * 1024) (void)cp::allow_full_lds<&sigma_rz_kernel<ENGINE, true>>();
+        hipLaunchKernelGGL((sigma_rz_kernel<ENGINE, true>), dim3(grid), dim3(NP / P), lds, stream, S);
+        return hipGetLastError();
+    }
+    if (lds > 64 * 1024) (void)cp::allow_full_lds<&sigma_rz_kernel<ENGINE, false>>();
+    hipLaunchKernelGGL((sigma_rz_kernel<ENGINE, false>), dim3(grid), dim3(NP / P), lds, stream, S);
     return hipGetLastError();
 }
+
+// what the fused kernel needs of a prefiltered spline plan (cp_geospline_plan, below)
+struct GeoTail {
+    int nq, ws;
+    const int* qe;
+    const double* qx;
+    const GeoBasis* basis;
+};
+
+int sigma_rz_fused_launch(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+                          const double* d_k, const cp_fftlog_tables_view& f, const cp_spline_band_view* band, const GeoTail* geo, const double* d_growth_sq,
+                          int nz, double* d_out, double* d_pk_out, void* d_coef, int device, void* stream);
 
 }  // namespace
 
@@ -815,6 +883,15 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     cp_fftlog_tables_view f;
     cp_spline_band_view b;
     if (!cp_fftlog_plan_view(fftlog, &f) || !cp_spline_plan_view(spline, &b)) return cp::fail(CP_EINVAL, "cp_sigma_rz_fused: plans without device tables");
+    return sigma_rz_fused_launch(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_k, f, &b, nullptr, d_growth_sq, nz, d_out, d_pk_out, d_coef, device,
+                                 stream);
+}
+
+namespace {
+int sigma_rz_fused_launch(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
+                          const double* d_k, const cp_fftlog_tables_view& f, const cp_spline_band_view* band, const GeoTail* geo, const double* d_growth_sq,
+                          int nz, double* d_out, double* d_pk_out, void* d_coef, int device, void* stream) {
+    const int nq = geo ? geo->nq : band->nq;
     int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_coef, device, stream);      // (validates the massive-neutrino tables)
     if (st != CP_OK) return st;
     SigmaArgs S{};
@@ -833,7 +910,12 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     S.consts = static_cast<const CosmoConsts*>(d_coef);
     double* ln_k = reinterpret_cast<double*>(static_cast<char*>(d_coef) + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients
     S.ln_k = ln_k;
-    S.wb = b.d_wb; S.j0 = b.d_j0; S.bw = b.bw; S.nq = b.nq; S.nz = nz;
+    S.nq = nq; S.nz = nz;
+    if (geo) {
+        S.qe = geo->qe; S.qx = geo->qx; S.basis = geo->basis; S.ws = geo->ws;
+    } else {
+        S.wb = band->d_wb; S.j0 = band->d_j0; S.bw = band->bw;
+    }
     S.growth_sq = d_growth_sq;
     S.out = d_out;
     S.pk_out = d_pk_out;
@@ -841,7 +923,7 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_fused: cannot select device %d", device);
     using F = Fftlog<NP, P, IN_HALF_ZERO_GEN, OUT_HALF>;
-    const size_t lds = (size_t)F::LDS_BYTES + (size_t)(2 * b.nq + 2 * nz) * sizeof(double);
+    const size_t lds = (size_t)F::LDS_BYTES + (size_t)(2 * nq + 2 * nz) * sizeof(double);
     int ncu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
     const long long npairs = (ncosmo + 1) / 2;
@@ -861,7 +943,7 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     hipError_t e = hipSuccess;
     if (lds > 160 * 1024) {
         if (prev >= 0) (void)hipSetDevice(prev);
-        return cp::fail(CP_EUNSUPPORTED, "cp_sigma_rz_fused: %d radii x %d redshifts exceed the LDS staging", b.nq, nz);
+        return cp::fail(CP_EUNSUPPORTED, "cp_sigma_rz_fused: %d radii x %d redshifts exceed the LDS staging", nq, nz);
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(log_wavenumbers_kernel, dim3((f.n + 255) / 256), dim3(256), 0, hs, d_k, ln_k, f.n);
@@ -872,6 +954,7 @@ int cp_sigma_rz_fused(int engine, long long ncosmo, const cp_param* bg_params, i
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_fused: launch failed: %s", hipGetErrorString(e));
     return CP_OK;
 }
+}  // namespace
 
 // ---- few radii: sigma^2(r_q) as a linear functional of the spectrum --------------------------------------------------------------------------
 // The transform and the spline are linear in P(k): for fixed wavenumbers and radii sigma^2(r_q) = sum_j F[q, j] P(k_j), with F the rows that
@@ -1379,6 +1462,25 @@ extern "C" int cp_geospline_plan_create_prefiltered(cp_geospline_plan** out, int
     }
     *out = p;
     return CP_OK;
+}
+
+// sigma(r, z) of a batch of analytic cosmologies as the fused kernel, its spline evaluated from the B-spline coefficients the plan's transform delivers
+extern "C" int cp_sigma_rz_analytic_prefiltered(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                                                const cp_param* pk_params, int nk, const double* d_k, const cp_geospline_plan* spline,
+                                                const double* d_growth_sq, int nz, double* d_out, double* d_pk_out, void* d_work, int device, void* stream) {
+    if (ncosmo < 0 || nk <= 0 || nz <= 0) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic_prefiltered: bad sizes");
+    if (ncosmo == 0) return CP_OK;
+    if (!bg_params || !pk_params || !d_k || !spline || !d_growth_sq || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic_prefiltered: null pointer");
+    if (!spline->prefiltered) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic_prefiltered: the spline plan carries no transform (cp_geospline_plan_create_prefiltered)");
+    if (spline->n != nk) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic_prefiltered: the spline plan has %d knots, the spectra %d samples", spline->n, nk);
+    if (spline->device != device) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic_prefiltered: the spline plan lives on device %d", spline->device);
+    cp_fftlog_tables_view f;
+    if (!cp_fftlog_plan_view(spline->prefiltered, &f)) return cp::fail(CP_EINVAL, "cp_sigma_rz_analytic_prefiltered: plan without device tables");
+    const GeoTail geo{spline->nq, spline->ws, spline->d_qe, spline->d_qa, &spline->d_consts->basis};
+    char* coef = static_cast<char*>(d_work);
+    coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
+    return sigma_rz_fused_launch(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_k, f, nullptr, &geo, d_growth_sq, nz, d_out, d_pk_out, coef, device,
+                                 stream);
 }
 
 extern "C" int cp_geospline_plan_info(const cp_geospline_plan* p, int* first_knot, int* nknots, int* nq) {

@@ -261,6 +261,7 @@ class _GeoSpline(object):
 
 _GEOSPLINE_MIN_ROWS = 8193      # below: the band-operator kernel of _fftlog_then_spline (launch- / latency-bound regime)
 _GEOSPLINE_PREFILTERED = True      # the spline's solve folded into the transform's u (False: solved on the CU from the ordinary output; measurements)
+_SIGMA_RZ_PREFILTERED = True       # ... also in the fused sigma(r, z) kernel of the analytic engines (False: the banded operator out of L2; measurements)
 _GEOSPLINE_GROUPED = True      # sigma_rz's (..., nr, nz) layout written by the kernel itself (False: (..., nz, nr) and a transposed view; measurements)
 
 
@@ -1224,6 +1225,15 @@ def sigma_rz_analytic(engine, bg, pk, r, growth_sq, device, kmin=1e-7, kmax=1e2,
                                               functional.data_ptr(), rr.size, growth_sq.data_ptr(), nz, out.data_ptr(),
                                               spectra.data_ptr() if keep_spectra else None, work.data_ptr(), device.index, dv.stream_of(device)))
         return out, spectra, k
+    if blocks == 0 and _GEOSPLINE_PREFILTERED and _SIGMA_RZ_PREFILTERED:
+        # the spline's solve folded into the transform (radii well inside its output grid): the kernel's tail is four coefficients per radius
+        native = fft._get_plan(device)
+        geo = _cached_operator(('geospline', id(native), True, s.tobytes(), rr.tobytes(), device.index), lambda: _GeoSpline(s, rr, device, fft=fft, keep=native))
+        if geo.prefiltered:
+            _lib.check(lib.cp_sigma_rz_analytic_prefiltered(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), nk,
+                                                            dv.upload(k, device).data_ptr(), geo.handle, growth_sq.data_ptr(), nz, out.data_ptr(),
+                                                            spectra.data_ptr() if keep_spectra else None, work.data_ptr(), device.index, dv.stream_of(device)))
+            return out, spectra, k
     _lib.check(lib.cp_sigma_rz_analytic(_lib.ENGINES[engine], nb, dv.as_void_p(cbg), 0, nu, dv.as_void_p(cpk), nk, dv.upload(k, device).data_ptr(),
                                         fft._get_plan(device).handle, op._handle, growth_sq.data_ptr(), nz, out.data_ptr(),
                                         spectra.data_ptr() if keep_spectra else None, work.data_ptr(), blocks, device.index, dv.stream_of(device)))

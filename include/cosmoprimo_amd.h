@@ -379,6 +379,12 @@ int cp_sigma_rz_analytic(int engine, long long ncosmo, const cp_param* bg_params
         int nk,
                          const double* d_k, const cp_fftlog_plan* fftlog, const cp_spline_plan* spline, const double* d_growth_sq, int nz,
                          double* d_out, double* d_pk_out, void* d_work, int nblocks, int device, void* stream);
+/* the fused kernel of cp_sigma_rz_analytic with the spline evaluated from B-spline coefficients: `spline` is a plan of cp_geospline_plan_create_prefiltered
+ * built from the transform's tables (it owns the transform whose u carries the prefilter), so a radius costs four LDS reads and 20 multiply-adds where the
+ * banded operator takes ~44 weights from L2.  Radii the plan refuses (near the ends of the output grid): cp_sigma_rz_analytic.  d_work as there. */
+int cp_sigma_rz_analytic_prefiltered(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm,
+                                     const cp_param* pk_params, int nk, const double* d_k, const cp_geospline_plan* spline, const double* d_growth_sq, int nz,
+                                     double* d_out, double* d_pk_out, void* d_work, int device, void* stream);
 /* the same for at most 4 radii (the sigma8 normalisation: one) as a linear functional of the spectrum: d_functional (nq, nk) holds the rows F with
  * sigma^2(r_q) = sum_j F[q, j] P(k_j) -- what the caller's transform + spline return for unit spectra --, the kernel evaluates P(k) and the dot
  * products, one wave per cosmology, no transform.  d_work, d_pk_out as for cp_sigma_rz_analytic; d_out (ncosmo, nq, nz). */

@@ -27,16 +27,26 @@ def both_routes(interp, r, z):
     return fused, separate
 
 
+@pytest.mark.parametrize('prefiltered', [False, True])
 @pytest.mark.parametrize('engine', ['eisenstein_hu', 'eisenstein_hu_nowiggle', 'bbks'])
-def test_fused_matches_separate_kernels(engine):
+def test_fused_matches_separate_kernels(engine, prefiltered, monkeypatch):
+    """prefiltered: the spline of the fused kernel evaluated from the B-spline coefficients its transform delivers (cp_sigma_rz_analytic_prefiltered: the
+    transform runs with another u, so the comparison is that of two evaluations of an FFTLog -- 1e-14 of the tilted transform's scale, a few 1e-13 on sigma at
+    these radii) instead of multiplied by the banded operator (the same arithmetic as the separate kernels: 1e-13)."""
     import cosmoprimo_amd as cp
+    from cosmoprimo_amd import interpolator as itp
     warnings.simplefilter('ignore')
+    monkeypatch.setattr(itp, '_SIGMA_RZ_PREFILTERED', prefiltered)
+    for key in [key for key in itp._op_cache if key[0] == 'geospline']:
+        del itp._op_cache[key]
     for n, nr, nz in ((1, 5, 3), (7, 256, 64), (64, 130, 7), (301, 33, 16)):
         interp = cp.Cosmology(engine=engine, sigma8=0.8, **parameters(n, n)).get_fourier().pk_interpolator()
         r, z = np.geomspace(0.5, 150., nr), np.linspace(0., 2.5, nz)
         fused, separate = both_routes(interp, r, z)
         assert fused.shape == (n, nr, nz) and np.isfinite(fused).all()
-        np.testing.assert_allclose(fused, separate, rtol=1e-13, atol=0, err_msg=str((engine, n, nr, nz)))
+        np.testing.assert_allclose(fused, separate, rtol=2e-12 if prefiltered else 1e-13, atol=0, err_msg=str((engine, n, nr, nz)))
+    plans = [v for key, v in itp._op_cache.items() if key[0] == 'geospline']
+    assert bool(plans) == prefiltered and all(p.prefiltered for p in plans)      # (the route taken is the one asked for)
 
 
 def test_fused_against_oracle():
