@@ -32,8 +32,10 @@ bool cp_spline_plan_view(const cp_spline_plan* plan, cp_spline_band_view* out);
 // the constants of a batch of cosmologies for the evaluation of engine `engine` (cppower::CosmoConsts: fit coefficients of EH98 / no-wiggle, Gamma of
 // BBKS, the primordial constants of pk_params -- NULL: transfer functions only) into d_work (cp_power_workspace_bytes(ncosmo) bytes): the first of
 // the two kernels cp_power_eval launches
+// d_k / d_ln_k (n wavenumbers; optional): extra workgroups of the same launch write the (3, n) table log k, k^1.08, k^1.4 of the kernels that evaluate on
+// a shared grid (cp_power_eval.h: powers_of_wavenumber) -- a launch of their own for 1024 values was 3 % of the fused sigma(r, z) call
 int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
-                          void* d_work, int device, void* stream);
+                          void* d_work, int device, void* stream, const double* d_k = nullptr, double* d_ln_k = nullptr, int n = 0);
 
 // a cp_spline_rows plan seen from cp_spline.hip: its queries as (interval, four weights) per query -- A y_j + B y_{j+1} + wM0 M_j + wM1 M_{j+1}, the
 // second derivatives M from cp_spline_rows_second_derivatives -- for the kernel that evaluates the k direction of (z, k) tables itself

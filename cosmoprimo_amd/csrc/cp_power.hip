@@ -48,7 +48,13 @@ struct Args {
 // The ~25 pow() of the EH98 / no-wiggle fit coefficients depend on the cosmology alone: one lane per cosmology here, read back by
 // power_kernel through scalar loads.  (Evaluated in every (cosmology, k) lane, as the first version did, they were 3/4 of the time; evaluated
 // by one lane of each power_kernel workgroup they still were half of it for 1024 wavenumbers per cosmology, all on one SIMD of the CU.)
-__global__ __launch_bounds__(64) void coefficients_kernel(const Args A, CosmoConsts* out, int with_pw) {
+__global__ __launch_bounds__(64) void coefficients_kernel(const Args A, CosmoConsts* out, int with_pw, const double* k_grid, double* ln_k_grid, int n_grid) {
+    const long long cosmo_blocks = (A.ncosmo + 63) / 64;
+    if ((long long)blockIdx.x >= cosmo_blocks) {      // the workgroups behind the cosmologies': the table of the shared wavenumbers (cp_power_coefficients)
+        const int i = (int)(((long long)blockIdx.x - cosmo_blocks) * 64 + threadIdx.x);
+        if (i < n_grid) powers_of_wavenumber(k_grid[i], ln_k_grid, i, n_grid);
+        return;
+    }
     const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= A.ncosmo) return;
     const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
@@ -336,7 +342,7 @@ int select_device(int device, int* prev) {
 extern "C" long long cp_power_workspace_bytes(long long ncosmo) { return ncosmo < 0 ? -1 : (long long)sizeof(CosmoConsts) * ncosmo; }
 
 int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_params, int second_is_omega_m, const cp_ncdm* ncdm, const cp_param* pk_params,
-                          void* d_work, int device, void* stream) {
+                          void* d_work, int device, void* stream, const double* d_k, double* d_ln_k, int n) {
     if (ncosmo <= 0) return CP_OK;
     if (!bg_params || !d_work) return cp::fail(CP_EINVAL, "cp_power_coefficients: null pointer");
     int prev;
@@ -358,7 +364,9 @@ int cp_power_coefficients(int engine, long long ncosmo, const cp_param* bg_param
     A.ncdm_tab = nu.tab;
     A.ncdm_knots = nu.knots;
     A.nsp = nu.nsp;
-    hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), A, static_cast<CosmoConsts*>(d_work), pk_params ? 1 : 0);
+    const int n_grid = d_k && d_ln_k ? n : 0;
+    hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64 + (n_grid + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream), A,
+                       static_cast<CosmoConsts*>(d_work), pk_params ? 1 : 0, d_k, d_ln_k, n_grid);
     const hipError_t e = hipGetLastError();
     if (prev >= 0) (void)hipSetDevice(prev);
     if (e != hipSuccess) return cp::fail(CP_EDEVICE, "cp_power_coefficients: launch failed: %s", hipGetErrorString(e));
@@ -420,7 +428,8 @@ extern "C" int cp_power_eval(int engine, int what, long long ncosmo, const cp_pa
         }
         CosmoConsts* consts = static_cast<CosmoConsts*>(d_work);
         A.consts = consts;
-        hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, hs, A, consts, 1);
+        hipLaunchKernelGGL(coefficients_kernel, dim3((unsigned)((ncosmo + 63) / 64)), dim3(64), 0, hs, A, consts, 1, static_cast<const double*>(nullptr),
+                           static_cast<double*>(nullptr), 0);
     }
     const dim3 grid((unsigned)(ncosmo * A.kchunks)), threads((unsigned)block);
     if (engine == CP_ENGINE_EH) hipLaunchKernelGGL(power_kernel<CP_ENGINE_EH>, grid, threads, 0, hs, A);

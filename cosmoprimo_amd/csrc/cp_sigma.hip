@@ -62,7 +62,7 @@ struct SigmaArgs {
     const double* ncdm_tab;       // massive neutrinos (cp_ncdm.tab; nsp == 0: none): today's densities only -- Omega0_m of pk_callable, Omega_m of BBKS
     int nsp;
     const double* k;              // (n) wavenumbers of the transform, h/Mpc
-    const double* ln_k;           // (n) their logarithms (log_wavenumbers_kernel)
+    const double* ln_k;           // (3, n) log k, k^1.08, k^1.4 (written by the coefficients' launch: cp_power_coefficients)
     const CosmoConsts* consts;    // (ncosmo) the cosmologies' constants (cp_power_coefficients)
     int stagger_div, stagger_mod, stagger_sleeps;      // start offsets between workgroups (see the kernel), 0 sleeps: none
     const double* wb;             // (bw, nq) band of the spline operator, query fastest
@@ -136,12 +136,6 @@ __device__ __forceinline__ void evaluate_spectra(const SigmaArgs& S, long long i
         va[r] = slots[2 * (t0 + T * r)];
         vb[r] = slots[2 * (t0 + T * r) + 1];
     }
-}
-
-// log of the wavenumbers with the kernels' own logarithm (what power_kernel evaluates per sample), once per launch
-__global__ void log_wavenumbers_kernel(const double* k, double* ln_k, int n) {      // ln_k: (3, n) log k, k^1.08, k^1.4 (cp_power_eval.h)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) powers_of_wavenumber(k[i], ln_k, i, n);
 }
 
 // the cropped outputs of the pair, variance j = t0 + T s of (row a, row b), into the (now free) data region in natural order, 16-byte slots
@@ -892,7 +886,9 @@ int sigma_rz_fused_launch(int engine, long long ncosmo, const cp_param* bg_param
                           const double* d_k, const cp_fftlog_tables_view& f, const cp_spline_band_view* band, const GeoTail* geo, const double* d_growth_sq,
                           int nz, double* d_out, double* d_pk_out, void* d_coef, int device, void* stream) {
     const int nq = geo ? geo->nq : band->nq;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_coef, device, stream);      // (validates the massive-neutrino tables)
+    double* ln_k = reinterpret_cast<double*>(static_cast<char*>(d_coef) + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients
+    // (validates the massive-neutrino tables; the same launch writes the table of the wavenumbers)
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, d_coef, device, stream, d_k, ln_k, f.n);
     if (st != CP_OK) return st;
     SigmaArgs S{};
     S.nsp = ncdm ? ncdm->nspecies : 0;
@@ -908,7 +904,6 @@ int sigma_rz_fused_launch(int engine, long long ncosmo, const cp_param* bg_param
     S.second_is_omega_m = second_is_omega_m;
     S.k = d_k;
     S.consts = static_cast<const CosmoConsts*>(d_coef);
-    double* ln_k = reinterpret_cast<double*>(static_cast<char*>(d_coef) + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients
     S.ln_k = ln_k;
     S.nq = nq; S.nz = nz;
     if (geo) {
@@ -946,7 +941,6 @@ int sigma_rz_fused_launch(int engine, long long ncosmo, const cp_param* bg_param
         return cp::fail(CP_EUNSUPPORTED, "cp_sigma_rz_fused: %d radii x %d redshifts exceed the LDS staging", nq, nz);
     }
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(log_wavenumbers_kernel, dim3((f.n + 255) / 256), dim3(256), 0, hs, d_k, ln_k, f.n);
     if (engine == CP_ENGINE_EH) e = launch<CP_ENGINE_EH>(S, grid, lds, hs);
     else if (engine == CP_ENGINE_EH_NOWIGGLE) e = launch<CP_ENGINE_EH_NOWIGGLE>(S, grid, lds, hs);
     else e = launch<CP_ENGINE_BBKS>(S, grid, lds, hs);
@@ -976,7 +970,7 @@ struct FunctionalArgs {
     int nsp;
     int nk, nq, nz;
     const double* k;              // (nk) wavenumbers, h/Mpc
-    const double* ln_k;           // (nk) their logarithms (log_wavenumbers_kernel)
+    const double* ln_k;           // (3, nk) log k, k^1.08, k^1.4 (cp_power_coefficients)
     const CosmoConsts* consts;    // (ncosmo) the cosmologies' constants (cp_power_coefficients)
     const double* functional;     // (nq, nk)
     const double* growth_sq;      // (ncosmo, nz)
@@ -1082,7 +1076,8 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     if (!bg_params || !pk_params || !d_k || !d_functional || !d_growth_sq || !d_out || !d_work) return cp::fail(CP_EINVAL, "cp_sigma_rz_functional: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, device, stream);
+    double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, device, stream, d_k, ln_k, nk);      // (and the table of the wavenumbers)
     if (st != CP_OK) return st;
     FunctionalArgs S{};
     {
@@ -1104,7 +1099,6 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     S.nk = nk; S.nq = nq; S.nz = nz;
     S.k = d_k;
     S.consts = reinterpret_cast<const CosmoConsts*>(coef);
-    double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
     S.ln_k = ln_k;
     S.functional = d_functional;
     S.growth_sq = d_growth_sq;
@@ -1114,7 +1108,6 @@ extern "C" int cp_sigma_rz_functional(int engine, long long ncosmo, const cp_par
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma_rz_functional: cannot select device %d", device);
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(log_wavenumbers_kernel, dim3((nk + 255) / 256), dim3(256), 0, hs, d_k, ln_k, nk);
     const unsigned grid = (unsigned)((ncosmo + 3) / 4);
     if (engine == CP_ENGINE_EH) hipLaunchKernelGGL(sigma_functional_kernel<CP_ENGINE_EH>, dim3(grid), dim3(256), 0, hs, S);
     else if (engine == CP_ENGINE_EH_NOWIGGLE) hipLaunchKernelGGL(sigma_functional_kernel<CP_ENGINE_EH_NOWIGGLE>, dim3(grid), dim3(256), 0, hs, S);
@@ -1136,7 +1129,8 @@ extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param*
     if (!bg_params || !pk_params || !d_k || !d_functional || !d_rsigma8 || !d_work) return cp::fail(CP_EINVAL, "cp_sigma8_normalise: null pointer");
     char* coef = static_cast<char*>(d_work);
     coef += (64 - (reinterpret_cast<unsigned long long>(coef) & 63u)) & 63u;
-    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, device, stream);
+    double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
+    int st = cp_power_coefficients(engine, ncosmo, bg_params, second_is_omega_m, ncdm, pk_params, coef, device, stream, d_k, ln_k, nk);      // (and the table of the wavenumbers)
     if (st != CP_OK) return st;
     FunctionalArgs S{};
     {
@@ -1158,7 +1152,6 @@ extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param*
     S.nk = nk; S.nq = 1; S.nz = 1;
     S.k = d_k;
     S.consts = reinterpret_cast<const CosmoConsts*>(coef);
-    double* ln_k = reinterpret_cast<double*>(coef + ((cp_power_workspace_bytes(ncosmo) + 63) / 64) * 64);      // behind the coefficients (cp_sigma_rz_workspace_bytes)
     S.ln_k = ln_k;
     S.functional = d_functional;
     S.pk_out = d_pk_out;
@@ -1169,7 +1162,6 @@ extern "C" int cp_sigma8_normalise(int engine, long long ncosmo, const cp_param*
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (prev != device && hipSetDevice(device) != hipSuccess) return cp::fail(CP_EDEVICE, "cp_sigma8_normalise: cannot select device %d", device);
     hipStream_t hs = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(log_wavenumbers_kernel, dim3((nk + 255) / 256), dim3(256), 0, hs, d_k, ln_k, nk);
     const unsigned grid = (unsigned)((ncosmo + 3) / 4);
     if (engine == CP_ENGINE_EH) hipLaunchKernelGGL(sigma8_normalise_kernel<CP_ENGINE_EH>, dim3(grid), dim3(256), 0, hs, S);
     else if (engine == CP_ENGINE_EH_NOWIGGLE) hipLaunchKernelGGL(sigma8_normalise_kernel<CP_ENGINE_EH_NOWIGGLE>, dim3(grid), dim3(256), 0, hs, S);
