@@ -28,6 +28,9 @@ struct TailArgs {
 #ifndef CP_TAIL_ABLATE      // diagnostic builds (wrong results): 1 no second derivatives / box, 2 no transform, 4 no exponential, 8 no splice, 16 no stores of the result
 #define CP_TAIL_ABLATE 0
 #endif
+#ifndef CP_TAIL_ROT_BATCH      // 1: the rotations of the two spectrum stages requested sixteen at a time instead of where they are used (the compiler keeps ~4
+#define CP_TAIL_ROT_BATCH 0    // in flight): measured, 9.72 against 9.63 ms per 125 000 vectors (profiles/r6_geospline_prefilter.txt) -- off
+#endif
 #ifndef CP_TAIL_KERNARG_RELOAD      // 0: the arguments as an ordinary by-value parameter, live over the whole loop (measurements)
 #define CP_TAIL_KERNARG_RELOAD 1
 #endif
@@ -248,6 +251,12 @@ __device__ __forceinline__ void tail_stages(long long p, bool has_b, int t, cplx
             const int base_b = (((tt + 255) & 255) & 1) * NS + (wb & 96), hb = (wb & 31) ^ (wb >> 5);
             const bool first = tt == 0;
             const cplx* rots = tail_args()->rot;
+#if CP_TAIL_ROT_BATCH      // the thread's sixteen rotations requested together (the compiler kept ~4 in flight: four memory round trips for the stage instead of one)
+            cplx rotv[P];
+#pragma unroll
+            for (int r = 0; r < P; ++r) rotv[r] = rots[tt + T * r];
+            CP_SCHED_FENCE();
+#endif
 #pragma unroll
             for (int r = 0; r < P; ++r) {
                 const int sa = base_a + 128 * (15 - r) + (ha ^ (4 * ((7 - r) & 7)));
@@ -257,7 +266,11 @@ __device__ __forceinline__ void tail_stages(long long p, bool has_b, int t, cplx
                 const double fa = k0 ? fl : fn;
                 const double Aa = fa * seqs[sa], Ab = fa * seqs[2 * NS + sa];
                 const double Ba = fa * seqs[sb], Bb = fa * seqs[2 * NS + sb];      // (f_{k-1} = f_n for k >= 1; k = 0 takes f_l and is real)
+#if CP_TAIL_ROT_BATCH
+                const cplx rot = rotv[r];
+#else
                 const cplx rot = rots[tt + T * r];
+#endif
                 const double cs = rot.re, sn = -rot.im;
                 cplx Ha = cplx{0.5 * (Aa * cs + Ba * sn), 0.5 * (Aa * sn - Ba * cs)};
                 cplx Hb = cplx{0.5 * (Ab * cs + Bb * sn), 0.5 * (Ab * sn - Bb * cs)};
@@ -514,11 +527,21 @@ __global__ __launch_bounds__(256, 2) void wallish_full_kernel(const FullArgs F) 
             const int e = 256 - tt, e1 = (e >> 4) & 15, ubase = 256 * (e & 15) + 16 * e1;
             const bool first = tt == 0;
             const cplx* rots = CP_GEN()->dst.rot;
+#if CP_TAIL_ROT_BATCH
+            cplx rotv[P];
+#pragma unroll
+            for (int s = 0; s < P; ++s) rotv[s] = rots[tt + T * s];
+            CP_SCHED_FENCE();
+#endif
 #pragma unroll
             for (int s = 0; s < P; ++s) {
                 const cplx v = lds[vbase + (s ^ d1)];
                 const cplx u = lds[first ? (s == 0 ? 0 : 16 - s) : ubase + ((15 - s) ^ e1)];
+#if CP_TAIL_ROT_BATCH
+                const cplx rot = rotv[s];
+#else
                 const cplx rot = rots[tt + T * s];
+#endif
                 const double f = (s == 0 && first) ? fl : fn;
                 va[s] = skip_a ? nan : f * (0.5 * (rot.re * (v.re + u.re) - rot.im * (v.im - u.im)));
                 vb[s] = skip_b ? nan : f * (0.5 * (rot.re * (v.im + u.im) - rot.im * (u.re - v.re)));
