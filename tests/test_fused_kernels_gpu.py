@@ -170,6 +170,39 @@ def test_fftlog_geospline_execute(nrows, nq, group, prefiltered, monkeypatch):
         np.testing.assert_allclose(got[keep], banded[keep], rtol=2e-11)
 
 
+@pytest.mark.parametrize('nrows,nq,group', [(20001, 256, 0), (16384, 300, 0), (12 * 1100, 256, 12), (64 * 330, 77, 64)])
+def test_prefiltered_geospline_over_many_pairs_per_workgroup(nrows, nq, group):
+    """Batches of several pairs per workgroup (the evaluation of a pair is deferred into the next one's first phase; the last pair of a workgroup is evaluated
+    behind its loop): EVERY row of the prefiltered form against the form that solves the spline on the CU from the ordinary transform -- two evaluations of an
+    FFTLog with different u, compared in tilted space --, odd batches, more than 256 radii (eight blocks of radii per workgroup), grouped layouts whose
+    tables do not fill the XCD shares evenly."""
+    torch, _lib, lib, dv, dev = _env()
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import interpolator as itp
+    k = np.geomspace(1e-7, 1e2, 1024)
+    fft = cp.TophatVariance(k, device=dev)
+    s = fft.y[0]
+    r = np.geomspace(0.8, 120., nq)
+    rng = np.random.default_rng(nrows + nq)
+    amp, tilt = (torch.as_tensor(x, device=dev) for x in (rng.uniform(0.5, 2., (nrows, 1)), rng.uniform(-2.2, -1.8, (nrows, 1))))
+    rows = (amp * 1e4 * torch.as_tensor(k / 0.05, device=dev)[None, :]**tilt).contiguous()
+    shaped = rows.reshape(nrows // group, group, 1024) if group else rows
+    results = []
+    for prefiltered in (True, False):
+        itp._GEOSPLINE_PREFILTERED = prefiltered
+        try:
+            got = itp._fftlog_then_geospline(fft, s, r, shaped, dev, sqrt=False, group=group)
+        finally:
+            itp._GEOSPLINE_PREFILTERED = True
+        assert got is not None
+        results.append(got.permute(0, 2, 1).reshape(nrows, nq) if group else got)
+    a, b = results
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    scale = (fft(rows)[1].abs() * torch.as_tensor(s**1.5, device=dev)[None, :]).max(dim=1).values      # the row's own tilted scale
+    tilted = ((a - b).abs() * torch.as_tensor(r**1.5, device=dev)[None, :]).max(dim=1).values / scale
+    assert float(tilted.max()) < 2e-13, 'row %d' % int(tilted.argmax())
+
+
 def test_geospline_plans_the_library_refuses():
     """Radii within 32 knots of either end of the grid, spans of more than 448 knots, grids that are not geometric, transforms of another size:
     no plan (the caller takes the band operator), never a wrong number."""
