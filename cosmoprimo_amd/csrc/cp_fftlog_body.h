@@ -622,7 +622,11 @@ struct Fftlog {
         if constexpr (PHN == LAST) {
             load_u(t, A, ker, w);
         } else if constexpr (PHN == NPH - 1) {
+#if defined(CP_DIAG_SKIP_TW0_RELOAD)      // diagnostic builds (wrong results): what the reload of the pass-0 twiddles in front of the last phase costs
+            (void)t0;
+#else
             load_twiddles<0>(t0, A, w);
+#endif
         }
     }
 

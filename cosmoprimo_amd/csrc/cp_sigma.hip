@@ -79,6 +79,9 @@ struct SigmaArgs {
     double* pk_out;               // (ncosmo, n) the spectra themselves, or null
 };
 
+#ifndef CP_SIGMA_DEFER      // 1: the second row of a pair's results stored behind the NEXT pair's wait for U (measurements: tools/sigma_defer.sh)
+#define CP_SIGMA_DEFER 0
+#endif
 #ifndef CP_SIGMA_RZ_TABLES
 #define CP_SIGMA_RZ_TABLES 0
 #endif
@@ -201,8 +204,8 @@ CP_HD void bspline_to_radii(int t, const cplx* lds, const int* __restrict__ qes,
     const GeoBasis B = load_uniform(basis);      // scalar loads
     for (int q = t; q < nq; q += 2 * T) {
         const int q2 = q + T < nq ? q + T : q;      // the second query of the thread (the first again when there is none: not stored)
-        const int ea = qes[q], eb = qes[q2];
-        const double xa = qxs[q], xb = qxs[q2];
+        const int ea = (CP_SIGMA_ABLATE & 32) ? 40 + (q >> 1) : qes[q], eb = (CP_SIGMA_ABLATE & 32) ? 40 + (q2 >> 1) : qes[q2];
+        const double xa = (CP_SIGMA_ABLATE & 32) ? 0.25 : qxs[q], xb = (CP_SIGMA_ABLATE & 32) ? 0.75 : qxs[q2];
         const int ja = ws + (ea < 0 ? 0 : ea) - 1, jb = ws + (eb < 0 ? 0 : eb) - 1;      // the first of the four coefficients
         cplx ca[4], cb[4];
 #pragma unroll
@@ -269,12 +272,59 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
     const double2 pw_ratio = double2{cp::wave_uniform(S.ln_k[nk_tab + T] / S.ln_k[nk_tab]), cp::wave_uniform(S.ln_k[2 * nk_tab + T] / S.ln_k[2 * nk_tab])};
     const double ln_first = cp::wave_uniform(S.ln_k[0]), ln_step = cp::wave_uniform((S.ln_k[nk_tab - 1] - S.ln_k[0]) / (double)(nk_tab - 1));
     __syncthreads();
+    // The one-off loads (twiddles, factors) are drained HERE: left in flight into the loop, the compiler's wait counts at its head had to cover this entry path
+    // too and became vmcnt(13) in phase 0 and vmcnt(0) behind its barrier of EVERY pair -- waits for the previous pair's stores (the counter retires in
+    // order), which are meant to drain under the evaluation and the first two phases (fftlog_kernel does the same: cp_fftlog_kernel.h).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
     // Every workgroup does the same work on its pairs and all start together: left alone they evaluate together and store together -- the chip alternates
     // between its vector ALUs and its memory instead of using both.  The workgroups of a CU start a fraction of a pair apart instead.
     if (S.stagger_sleeps > 0) {
         const int w = (int)((blockIdx.x / S.stagger_div) % S.stagger_mod) * S.stagger_sleeps;
         for (int i = 0; i < w; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks
     }
+    // ---- out[c, q, z] = sqrt(var[q]) sqrt(growth_sq[z]): the (nq x nz) block of a cosmology is contiguous; 16-byte stores when nz is even ----
+    auto store_rows = [&](long long first, int row_begin, int row_end) {
+        int tv = t;
+        asm volatile("" : "+v"(tv));      // (the addresses are formed here, not carried through the transform: see the loop)
+        const int nz = S.nz, block = S.nq * nz;
+        const bool even = (nz & 1) == 0;
+        const int stride = even ? 2 * T : T, e0 = even ? 2 * tv : tv;
+        const int dq = stride / nz, dz = stride - dq * nz, q_first = e0 / nz, z_first = e0 - q_first * nz;
+        for (int row = row_begin; row < ((CP_SIGMA_ABLATE & 4) ? 0 : row_end); ++row) {
+            double* dst = S.out + (first + row) * (long long)block;
+            const double* vr = roots_r + row * S.nq;
+            const double* gr = roots_g + row * nz;
+            int q = q_first, z = z_first;
+            if (even && dz == 0) {      // nz divides the stride (64 redshifts): the thread's two growth factors do not change
+                const double g0 = gr[z], g1 = gr[z + 1];
+#pragma unroll 4
+                for (int e = e0; e < block; e += stride) {
+                    cp_v2d val;
+                    val.x = vr[q] * g0;
+                    val.y = vr[q] * g1;
+                    if (CP_SIGMA_ABLATE & 64) *reinterpret_cast<cp_v2d*>(dst + e) = val;      // (diagnostic: the ordinary cache policy)
+                    else __builtin_nontemporal_store(val, reinterpret_cast<cp_v2d*>(dst + e));      // written once, read by nobody on this device soon
+                    q += dq;
+                }
+            } else if (even) {
+                for (int e = e0; e < block; e += stride) {
+                    double2 val;
+                    val.x = vr[q] * gr[z];
+                    val.y = vr[q] * gr[z + 1];
+                    *reinterpret_cast<double2*>(dst + e) = val;
+                    q += dq; z += dz;
+                    if (z >= nz) { z -= nz; ++q; }
+                }
+            } else {
+                for (int e = e0; e < block; e += stride) {
+                    dst[e] = vr[q] * gr[z];
+                    q += dq; z += dz;
+                    if (z >= nz) { z -= nz; ++q; }
+                }
+            }
+        }
+    };
+    long long pending = -1;      // CP_SIGMA_DEFER: the cosmology whose (second) row of results is still to be stored
     for (; p < npairs; p += gridDim.x) {
         const long long ia = 2 * p;
         const bool has_b = ia + 1 < S.ncosmo;
@@ -296,7 +346,20 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
                 }
             }
         }
-        if (!(CP_SIGMA_ABLATE & 8)) front_phases<F, 0>(t, A, has_b, lds, st);
+        if (CP_SIGMA_DEFER) {
+            // the phases written out: the previous pair's second row goes out right behind phase 2 -- behind the wait for U, the pair's only wait for memory
+            static_assert(F::NPH == 5, "three passes");
+            F::template phase<0>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nullptr, nullptr, 0, st);
+            __syncthreads();
+            F::template phase<1>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nullptr, nullptr, 0, st);
+            if constexpr (!F::template barrier_free_after<1>()) __syncthreads();
+            F::template phase<2>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nullptr, nullptr, 0, st);
+            if (pending >= 0) store_rows(pending, 1, 2);
+            pending = -1;
+            if constexpr (!F::template barrier_free_after<2>()) __syncthreads();
+            F::template phase<3>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nullptr, nullptr, 0, st);
+            __syncthreads();
+        } else if (!(CP_SIGMA_ABLATE & 8)) front_phases<F, 0>(t, A, has_b, lds, st);
         // ---- last phase of the FFTLog, its outputs kept on the CU ----
         cplx x[P];
         Pass<NP, P, 0>::load_lds(t0, lds, x);
@@ -307,7 +370,7 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
         asm volatile("" : "+v"(tv));
         for (int z = tv; z < 2 * S.nz; z += T) {      // (written behind the barrier: nobody is still in the previous pair's store loop)
             const long long ic = z < S.nz ? ia : ib;
-            roots_g[z] = sqrt(S.growth_sq[ic * S.nz + (z < S.nz ? z : z - S.nz)]);
+            roots_g[z] = (CP_SIGMA_ABLATE & 32) ? sqrt(1. + 1e-3 * (double)(z + ic)) : sqrt(S.growth_sq[ic * S.nz + (z < S.nz ? z : z - S.nz)]);
         }
         Pass<NP, P, 0>::twiddle_apply(st.w, x);
         Pass<NP, P, 0>::butterflies(x);
@@ -330,48 +393,16 @@ __global__ __launch_bounds__(NP / P, 2) void sigma_rz_kernel(const SigmaArgs S) 
             else spline_to_radii<T>(tv, lds, S.wb, S.j0, S.bw, S.nq, roots_r);
         }
         __syncthreads();
-        // ---- out[c, q, z] = sqrt(var[q]) sqrt(growth_sq[z]): the (nq x nz) block of a cosmology is contiguous; 16-byte stores when nz is even ----
-        {
-            const int nz = S.nz, block = S.nq * nz;
-            const bool even = (nz & 1) == 0;
-            const int stride = even ? 2 * T : T, e0 = even ? 2 * tv : tv;
-            const int dq = stride / nz, dz = stride - dq * nz, q_first = e0 / nz, z_first = e0 - q_first * nz;
-            for (int row = 0; row < ((CP_SIGMA_ABLATE & 4) ? 0 : has_b ? 2 : 1); ++row) {
-                double* dst = S.out + (ia + row) * (long long)block;
-                const double* vr = roots_r + row * S.nq;
-                const double* gr = roots_g + row * nz;
-                int q = q_first, z = z_first;
-                if (even && dz == 0) {      // nz divides the stride (64 redshifts): the thread's two growth factors do not change
-                    const double g0 = gr[z], g1 = gr[z + 1];
-#pragma unroll 4
-                    for (int e = e0; e < block; e += stride) {
-                        cp_v2d val;
-                        val.x = vr[q] * g0;
-                        val.y = vr[q] * g1;
-                        __builtin_nontemporal_store(val, reinterpret_cast<cp_v2d*>(dst + e));      // written once, read by nobody on this device soon
-                        q += dq;
-                    }
-                } else if (even) {
-                    for (int e = e0; e < block; e += stride) {
-                        double2 val;
-                        val.x = vr[q] * gr[z];
-                        val.y = vr[q] * gr[z + 1];
-                        *reinterpret_cast<double2*>(dst + e) = val;
-                        q += dq; z += dz;
-                        if (z >= nz) { z -= nz; ++q; }
-                    }
-                } else {
-                    for (int e = e0; e < block; e += stride) {
-                        dst[e] = vr[q] * gr[z];
-                        q += dq; z += dz;
-                        if (z >= nz) { z -= nz; ++q; }
-                    }
-                }
-            }
+        if (CP_SIGMA_DEFER) {      // the first row now; the second behind the NEXT pair's wait for U (see front of the loop)
+            store_rows(ia, 0, 1);
+            pending = has_b ? ia : -1;
+        } else {
+            store_rows(ia, 0, has_b ? 2 : 1);
         }
         // the next pair's phase 0 writes only the data region of the FFT, which nobody reads any more; roots_r / roots_g are rewritten behind
         // barriers of the next pair
     }
+    if (CP_SIGMA_DEFER && pending >= 0) store_rows(pending, 1, 2);
 }
 
 // ---- the same tail behind rows that come from memory: FFTLog of a batch of rows + natural spline of every output row to the radii (+ root), the
