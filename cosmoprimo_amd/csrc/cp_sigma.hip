@@ -511,6 +511,9 @@ constexpr int GEO_SMAX = 8;          // knots per lane: stretches of at most 512
 constexpr int GEO_SMIN = 4;          // (fewer knots per lane would need more than GEO_REACH lanes of carry)
 constexpr int GEO_QMAX = 8;          // queries per lane: at most 512 radii
 constexpr int GEO_HALO = 32, GEO_REACH = 9;      // GEO_REACH x GEO_SMIN >= GEO_HALO + 1
+#ifndef CP_GEO_EVAL_LAST      // 1: the deferred evaluation of a pair in the NEXT pair's last phase instead of behind its first barrier (measurements)
+#define CP_GEO_EVAL_LAST 0
+#endif
 #ifndef CP_GEO_ABLATE      // diagnostic builds (tools/geospline_ablate.sh; wrong results): 1 no carries between lanes, 2 one query per lane, 4 no root,
 #define CP_GEO_ABLATE 0    // 8 no solve at all (the tail is the barriers only), 16 no stores, 128 no reads of the coefficients, 256 the stretch not written
 #endif
@@ -693,7 +696,7 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
         {
             F::template phase<0>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
             __syncthreads();
-            if constexpr (COEF) {
+            if constexpr (COEF && !CP_GEO_EVAL_LAST) {
                 if (pending_dst && !(CP_GEO_ABLATE & 8)) evaluate(pending_dst, pending_b);
             }
             F::template phase<1>(t, A, nullptr, nullptr, nullptr, nullptr, has_b, 0, lds, nra, nrb, 0, st);
@@ -708,6 +711,10 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
             cplx x[P];
             Pass<NP, P, 0>::load_lds(t0, lds, x);
             st.info_nxt = F::screen_collect(lds);
+            if constexpr (COEF && CP_GEO_EVAL_LAST) {      // (measurements: the previous pair evaluated here, a barrier in front of this pair's coefficients)
+                if (pending_dst && !(CP_GEO_ABLATE & 8)) evaluate(pending_dst, pending_b);
+                __syncthreads();
+            }
             if constexpr (!COEF) __syncthreads();      // every thread has its inputs: the data region is free
             Pass<NP, P, 0>::twiddle_apply(st.w, x);
             Pass<NP, P, 0>::butterflies(x);
