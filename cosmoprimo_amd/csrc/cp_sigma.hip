@@ -626,6 +626,9 @@ __global__ __launch_bounds__(NP / P, 2) void fftlog_geospline_kernel(const GeoAr
             qe[j] = q < R.nq ? R.qe[q] : -1;
             qx[j] = q < R.nq ? R.qa[q] : 0.;
         }
+        // ... and landed before the loop: in flight at its head they made the compiler wait for vmcnt(0) at their first use in EVERY pair -- behind the
+        // rows phase 0 has just requested from HBM (tools/isa_waits.py)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
     auto evaluate = [&](double* dst, bool both) {
         const double* Ca = side + 1;      // Ca[-1 .. ne]: the B-spline coefficients of the stretch, first row (second: side_stride further)
