@@ -1150,24 +1150,43 @@ __global__ __launch_bounds__(256, CP_TABLES_WAVES) void tables_rows_direct_kerne
     __shared__ double exp_tab[64];
     if (threadIdx.x < 64) exp_tab[threadIdx.x] = cpmath::exp2_table[threadIdx.x];
     const int tile = (int)(blockIdx.x % nqt);
-    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
-        const int q = e >> 5, kz = e & 31;
-        wl[kz * TABLES_WSTRIDE + q] = kz < A.nz_pad ? A.wz[q * A.nz_pad + kz] : 0.;
-    }
+    // (the plan entries of the workgroup requested together, then stored / tested: entry by entry behind a test they were 8 + 16 memory round trips in a row in
+    // front of the first step of each of the 2048 workgroups -- tools/isa_waits.py)
     {
+        double wv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = (int)threadIdx.x + 256 * i, q = e >> 5, kz = e & 31;
+            wv[i] = A.wz[q * A.nz_pad + (kz < A.nz_pad ? kz : 0)];
+        }
         const int q = tile * 256 + threadIdx.x, qc = q < A.nq ? q : A.nq - 1;
         tile_w[threadIdx.x] = reinterpret_cast<const double4*>(A.qw)[qc];
         tile_j[threadIdx.x] = A.qj[qc];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = (int)threadIdx.x + 256 * i, qq = e >> 5, kz = e & 31;
+            wl[kz * TABLES_WSTRIDE + qq] = kz < A.nz_pad ? wv[i] : 0.;
+        }
     }
     __syncthreads();
     unsigned nan_z = 0u;
+    {
+        int jz[16];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int zq = 16 * mi + g + 4 * r;
-            if (zq < A.nzq && A.j0z[zq] < 0) nan_z |= 1u << (4 * mi + r);
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int zq = 16 * mi + g + 4 * r;
+                jz[4 * mi + r] = A.j0z[zq < A.nzq ? zq : 0];
+            }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int zq = 16 * mi + g + 4 * r;
+                if (zq < A.nzq && jz[4 * mi + r] < 0) nan_z |= 1u << (4 * mi + r);
+            }
+    }
     typedef double v2u __attribute__((ext_vector_type(2), aligned(8)));
     // The four waves of the workgroup take ADJACENT column tiles at every step (wave w: wavenumbers q0 + 64 jj + 16 w ...): together they walk the
     // table rows 256 bytes at a time, two whole cache lines that all four touch within the same few hundred cycles.  (Each wave walking its own
