@@ -566,8 +566,14 @@ struct Fftlog {
         const double* __restrict__ post = A.post + (long long)ker * NP;
 #pragma unroll
         for (int r = 0; r < H; ++r) {
+#if defined(CP_DIAG_CONST_FACTORS)      // diagnostic builds (wrong results): the 32 registers of the factors given back -- an upper bound on what forming them from one
+            // value per thread (they are power laws) and pinning more twiddles instead could return (tools/mb_pin_factors.sh)
+            if (WITH_PRE) st.fpre[r] = 1.25;
+            st.fpost[r] = 0.75;
+#else
             if (WITH_PRE) st.fpre[r] = ld_f64(pre, (unsigned)t * 8u, (unsigned)(T * (r + Q)) * 8u);
             st.fpost[r] = ld_f64(post, (unsigned)t * 8u, (unsigned)(T * (r + Q)) * 8u);
+#endif
         }
     }
 
