@@ -259,13 +259,15 @@ class _GeoSpline(object):
             pass
 
 
-_GEOSPLINE_MIN_ROWS = 8193      # below: the band-operator kernel of _fftlog_then_spline (launch- / latency-bound regime)
+_GEOSPLINE_MIN_ROWS = 8193      # below: the band-operator kernel of _fftlog_then_spline (launch- / latency-bound regime) ...
+_GEOSPLINE_PREFILTERED_MIN_ROWS = 513      # ... unless the prefiltered form applies: it is the faster one from ~500 rows on (tools/bench_spline_crossover.py: 1024 rows
+#                                            0.0154 against 0.0193 ms, 8192 rows 0.044 against 0.075)
 _GEOSPLINE_PREFILTERED = True      # the spline's solve folded into the transform's u (False: solved on the CU from the ordinary output; measurements)
 _SIGMA_RZ_PREFILTERED = True       # ... also in the fused sigma(r, z) kernel of the analytic engines (False: the banded operator out of L2; measurements)
 _GEOSPLINE_GROUPED = True      # sigma_rz's (..., nr, nz) layout written by the kernel itself (False: (..., nz, nr) and a transposed view; measurements)
 
 
-def _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=False, group=0):
+def _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=False, group=0, prefiltered_only=False):
     """The transform of ``rows`` (..., nk) and the natural spline of every transformed row to the radii ``rr`` as ONE kernel with the spline solved
     on the CU (``cp_fftlog_geospline_execute``), for the default transform (1024 samples).  group > 0: rows (..., group, nk) -> (..., nr, group).
     None when it does not apply."""
@@ -278,7 +280,7 @@ def _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=False, group=0):
     native = fft._get_plan(device)
     plan = _cached_operator(('geospline', id(native), _GEOSPLINE_PREFILTERED, s.tobytes(), rr.tobytes(), device.index),
                             lambda: _GeoSpline(s, rr, device, fft=fft, keep=native))
-    if plan.handle is None:
+    if plan.handle is None or (prefiltered_only and not plan.prefiltered):
         return None
     rows = rows.contiguous()
     lead = tuple(rows.shape[:-1])
@@ -343,16 +345,26 @@ def sigma_r2_of_rows(r, pk_rows, kmin=1e-7, kmax=1e2, method='fftlog', nk=None, 
         s = fft.y[0]
         op = _cached_operator(('nat', s.tobytes(), rr.tobytes(), device.index), lambda: LinearOperator.spline(s, rr, bc='natural', device=device))
         # tmp = (2 pi^2) spline(var)(r); sigma^2 = tmp / (2 pi^2)  (interpolator.py:289-291)
+        nrows = rows.numel() // max(rows.shape[-1], 1) if dv.is_torch(rows) else 0
+
+        def geospline(prefiltered_only):
+            # transform and spline in one kernel, the spline from B-spline coefficients (or solved on the CU), sigma_rz's layout written by it
+            group = int(rows.shape[-2]) if radii_before_last_axis and rows.ndim >= 2 and _TRANSPOSE_IN_STORE and _GEOSPLINE_GROUPED else 0
+            solved = _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=sqrt, group=group if group % 2 == 0 else 0, prefiltered_only=prefiltered_only)
+            if solved is not None and radii_before_last_axis and rows.ndim >= 2 and not (group and group % 2 == 0):
+                return solved.transpose(-1, -2)
+            return solved
+
+        if growth_sq is None and _GEOSPLINE_PREFILTERED and _GEOSPLINE_PREFILTERED_MIN_ROWS <= nrows < _GEOSPLINE_MIN_ROWS:
+            solved = geospline(True)      # medium batches: only the prefiltered form beats the band operator inside the transform's kernel
+            if solved is not None:
+                return solved
         fused = _fftlog_then_spline(fft, op, rows, device, sqrt=sqrt) if growth_sq is None else None
         if fused is not None:
             return fused.transpose(-1, -2) if radii_before_last_axis and fused.ndim >= 2 else fused
-        if growth_sq is None and dv.is_torch(rows) and rows.numel() // max(rows.shape[-1], 1) >= _GEOSPLINE_MIN_ROWS:
-            # many rows (config 3B: 640 000): transform and spline in one kernel, the spline solved on the CU, sigma_rz's layout written by it
-            group = int(rows.shape[-2]) if radii_before_last_axis and rows.ndim >= 2 and _TRANSPOSE_IN_STORE and _GEOSPLINE_GROUPED else 0
-            solved = _fftlog_then_geospline(fft, s, rr, rows, device, sqrt=sqrt, group=group if group % 2 == 0 else 0)
+        if growth_sq is None and nrows >= _GEOSPLINE_MIN_ROWS:      # many rows (config 3B: 640 000)
+            solved = geospline(False)
             if solved is not None:
-                if radii_before_last_axis and rows.ndim >= 2 and not (group and group % 2 == 0):
-                    return solved.transpose(-1, -2)
                 return solved
         if growth_sq is not None:
             var = fft(rows)[1]

@@ -203,6 +203,37 @@ def test_prefiltered_geospline_over_many_pairs_per_workgroup(nrows, nq, group):
     assert float(tilted.max()) < 2e-13, 'row %d' % int(tilted.argmax())
 
 
+@pytest.mark.parametrize('shape,transposed', [((1024,), False), ((16, 64), True), ((600,), False), ((9, 70), True)])
+def test_medium_batches_take_the_prefiltered_kernel(shape, transposed, monkeypatch):
+    """sigma_r2_of_rows between 513 and 8192 rows: the prefiltered FFTLog + B-spline kernel (faster than the band operator inside the transform's kernel from
+    ~500 rows on) -- same numbers as the band route to the agreement of two evaluations of an FFTLog, in both layouts; radii it refuses fall back."""
+    torch, _lib, lib, dv, dev = _env()
+    from cosmoprimo_amd import interpolator as itp
+    rng = np.random.default_rng(sum(shape))
+    r = np.geomspace(1., 120., 100)
+    amp = torch.as_tensor(rng.uniform(0.5, 2., shape + (1,)), device=dev)
+
+    def rows(k):
+        return (amp * torch.as_tensor(1e4 * (k / 0.05)**-1.9 / (1. + (k / 0.3)**2), device=dev)).contiguous()
+
+    def run(radii):
+        for key in [key for key in itp._op_cache if key[0] == 'geospline']:
+            del itp._op_cache[key]
+        out = itp.sigma_r2_of_rows(radii, rows, device=dev, sqrt=True, radii_before_last_axis=transposed)
+        return out, any(key[0] == 'geospline' and v.prefiltered for key, v in itp._op_cache.items())
+
+    new, used = run(r)
+    assert used
+    monkeypatch.setattr(itp, '_GEOSPLINE_PREFILTERED_MIN_ROWS', 1 << 40)
+    old, used = run(r)
+    assert not used and new.shape == old.shape == ((shape[0], r.size, shape[1]) if transposed else shape + (r.size,))
+    np.testing.assert_allclose(new.cpu().numpy(), old.cpu().numpy(), rtol=1e-12)
+    monkeypatch.undo()
+    near_the_end = np.array([0.012, 8.])      # within 32 knots of the first output point: the prefiltered plan is refused, the band operator answers
+    got, used = run(near_the_end)
+    assert not used and bool(torch.isfinite(got).all())
+
+
 def test_geospline_plans_the_library_refuses():
     """Radii within 32 knots of either end of the grid, spans of more than 448 knots, grids that are not geometric, transforms of another size:
     no plan (the caller takes the band operator), never a wrong number."""
