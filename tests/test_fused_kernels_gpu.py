@@ -234,6 +234,32 @@ def test_medium_batches_take_the_prefiltered_kernel(shape, transposed, monkeypat
     assert not used and bool(torch.isfinite(got).all())
 
 
+@pytest.mark.parametrize('kw', [dict(q=0.4), dict(q=-0.3, lowring=False), dict(q=0., lowring=False, xy=2.5)])
+def test_prefiltered_geospline_other_transforms(kw):
+    """The prefilter depends on the transform through the ratio of its output grid and the power law of its postfactor only: other tilts, no low-ringing
+    condition, another product x y -- against scipy's natural spline of the package's own transform; radii unsorted, repeated, some outside the grid."""
+    from scipy.interpolate import CubicSpline
+    torch, _lib, lib, dv, dev = _env()
+    import cosmoprimo_amd as cp
+    from cosmoprimo_amd import interpolator as itp
+    k = np.geomspace(1e-6, 1e2, 1024)
+    fft = cp.TophatVariance(k, device=dev, **kw)
+    s = fft.y[0]
+    rng = np.random.default_rng(7)
+    r = np.concatenate([rng.permutation(np.geomspace(s[40], s[400], 90)), [s[200], s[200], s[0] / 2., s[-1] * 3.]])
+    rows = torch.as_tensor(rng.uniform(0.5, 2., (10, 1)) * 1e4 * (k / 0.05)**-1.9 / (1. + (k / 0.3)**2), device=dev).contiguous()
+    got = itp._fftlog_then_geospline(fft, s, r, rows, dev)
+    plan = [v for key, v in itp._op_cache.items() if key[0] == 'geospline'][-1]
+    assert got is not None and plan.prefiltered
+    got, var = got.cpu().numpy(), fft(rows)[1].cpu().numpy()
+    inside = (r >= s[0]) & (r <= s[-1])
+    assert np.isnan(got[:, ~inside]).all() and np.isfinite(got[:, inside]).all()
+    tilt = 1.5 + kw['q']
+    for i in range(rows.shape[0]):
+        ref = CubicSpline(s, var[i], bc_type='natural')(r[inside])
+        assert (np.abs(got[i, inside] - ref) * r[inside]**tilt).max() < 1e-13 * np.abs(var[i] * s**tilt).max(), 'row %d' % i
+
+
 def test_geospline_plans_the_library_refuses():
     """Radii within 32 knots of either end of the grid, spans of more than 448 knots, grids that are not geometric, transforms of another size:
     no plan (the caller takes the band operator), never a wrong number."""
