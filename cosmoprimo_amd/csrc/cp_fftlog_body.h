@@ -12,6 +12,9 @@
 #include <math.h>
 
 #include "cp_fft_core.h"
+#if defined(__HIPCC__)      // (the CPU emulation of the kernel's phases, tests/host_emu, compiles this header with g++: it takes the library's pow)
+#include "cp_math.h"
+#endif
 
 namespace cpfft {
 
@@ -162,16 +165,68 @@ struct Fftlog {
     static constexpr int H = P / 2, Q = P / 4;
 
     // padded input element j of one row (reference pad(): fftlog.py:483-505); branch-free for constant / edge
+    // ratio^e of the log-log continuation of a row beyond its ends (fftlog.py:486-501): the ratio of two neighbouring samples, a whole exponent of at most the
+    // padding.  For a positive, normal ratio and |e log ratio| < 700 it is exp(e log(ratio)) with the package's own logarithm and exponential (cp_math.h: both
+    // below 1 ulp; the product carries |e log ratio| ulp, 1e-15 for the 8 of a thousand steps of a 0.8 % ratio) -- 45 instructions where the library's pow
+    // takes ~150 and the padded half of a log-extrapolated row was two thirds of its transform's time; anything else (zero, negative, Inf, NaN, overflow) is
+    // the library's.
+    static CP_HD __attribute__((noinline)) double ratio_pow(double ratio, int e) {      // (a call, like pow: 32 copies per thread cost registers the kernel does not have)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (ratio > 2.2250738585072014e-308 && ratio < 1.7976931348623157e308) {
+            const double x = (double)e * cpmath::log_pos(ratio);
+            if (fabs(x) < 700.) return cpmath::exp_mid(x);
+        }
+#endif
+        return pow(ratio, (double)e);
+    }
+
+    // The same per ROW instead of per point: log(a_1 / a_0) and log(a_{n-2} / a_{n-1}) once per thread and row (load_input), a padded point is then its end value
+    // times one exponential.  ok_* false: an end ratio that is not positive and normal (or no log extrapolation on that side) -- those points take fetch().
+    struct LogEnds {
+        double ln_l, ln_r;
+        bool ok_l, ok_r;
+    };
+    static CP_HD LogEnds log_ends(const double* __restrict__ a, const FftlogArgs& A) {
+        LogEnds E{0., 0., false, false};
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (IN_MODE == IN_LOG && A.n >= 2) {
+            const double rl = a[1] / a[0], rr = a[A.n - 2] / a[A.n - 1];
+            E.ok_l = A.ext_l == CP_EXTRAP_LOG && rl > 2.2250738585072014e-308 && rl < 1.7976931348623157e308;
+            E.ok_r = A.ext_r == CP_EXTRAP_LOG && rr > 2.2250738585072014e-308 && rr < 1.7976931348623157e308;
+            E.ln_l = E.ok_l ? log_call(rl) : 0.;
+            E.ln_r = E.ok_r ? log_call(rr) : 0.;
+        }
+#endif
+        return E;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    static __device__ __attribute__((noinline)) double log_call(double x) { return cpmath::log_pos(x); }
+    static __device__ __attribute__((noinline)) double exp_call(double x) { return cpmath::exp_mid(x); }
+#endif
+    static CP_HD double fetch_log(const double* __restrict__ a, int j, const FftlogArgs& A, const LogEnds& E) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int idx = j - A.in_left;
+        if (idx < 0 && E.ok_l) {
+            const double x = (double)idx * E.ln_l;
+            if (fabs(x) < 700.) return a[0] * exp_call(x);
+        } else if (idx >= A.n && E.ok_r) {
+            const double x = -(double)(idx - A.n + 1) * E.ln_r;
+            if (fabs(x) < 700.) return a[A.n - 1] * exp_call(x);
+        }
+#endif
+        return fetch(a, j, A);
+    }
+
     static CP_HD double fetch(const double* __restrict__ a, int j, const FftlogArgs& A) {
         const int idx = j - A.in_left;
         const int cl = idx < 0 ? 0 : (idx >= A.n ? A.n - 1 : idx);
         double v = a[cl];  // in range: the sample; out of range: the edge value
         if (idx < 0) {
             if (A.ext_l == CP_EXTRAP_CONST) v = A.val_l;
-            if (IN_MODE == IN_LOG && A.ext_l == CP_EXTRAP_LOG) v = v * pow(a[1] / v, (double)idx);
+            if (IN_MODE == IN_LOG && A.ext_l == CP_EXTRAP_LOG) v = v * ratio_pow(a[1] / v, idx);
         } else if (idx >= A.n) {
             if (A.ext_r == CP_EXTRAP_CONST) v = A.val_r;
-            if (IN_MODE == IN_LOG && A.ext_r == CP_EXTRAP_LOG) v = v / pow(a[A.n - 2] / v, (double)(idx - A.n + 1));
+            if (IN_MODE == IN_LOG && A.ext_r == CP_EXTRAP_LOG) v = v / ratio_pow(a[A.n - 2] / v, idx - A.n + 1);
         }
         return v;
     }
@@ -418,12 +473,13 @@ struct Fftlog {
     // over the workgroup in here (`info` returns the pair's exponent fields)
     static CP_HD void load_input(int t, int t_real, const FftlogArgs& A, const double* __restrict__ ra, const double* __restrict__ rb, bool has_b,
                                  const double* __restrict__ pre, cplx* lds, unsigned& info, cplx* x) {
+        const LogEnds ea = log_ends(ra, A), eb = log_ends(rb, A);
 #pragma unroll
         for (int r = 0; r < P; ++r) {
             const int j = t + T * r;
             const double f = pre[j];
-            x[r].re = fetch(ra, j, A) * f;
-            x[r].im = fetch(rb, j, A) * f;  // an incomplete pair has row b aliased to row a (never stored)
+            x[r].re = fetch_log(ra, j, A, ea) * f;
+            x[r].im = fetch_log(rb, j, A, eb) * f;  // an incomplete pair has row b aliased to row a (never stored)
         }
         if constexpr (SCREEN) screen_in_phase0<P>(t_real, A, ra, rb, pre, lds, info, x);
     }
@@ -512,7 +568,7 @@ struct Fftlog {
                 const int nidx = t + T * s;
                 const int o = nidx - A.out_off;
                 if (o >= 0 && o < A.n_out) {
-                    const double f = post[nidx];
+                    const double f = post[nidx];      // (requested point by point: all P together cost registers the log-extrapolating variant does not have -- 2.98 -> 3.10 ms, tools/bench_generic_fftlog.py)
                     double ya = x[s].re * f, yb = x[s].im * f;
                     if constexpr (SCREEN) fix_output<1>(fix, &ya, &yb);
                     oa[o] = ya;

@@ -25,6 +25,7 @@
 #include "../../include/cosmoprimo_amd.h"
 #include "cp_error.h"
 #include "cp_fft_core.h"
+#include "cp_math.h"
 #include "cp_fftlog_large.h"
 #include "cp_fftlog_tables.h"
 
@@ -44,6 +45,15 @@ struct PadSpec {
     double val_l, val_r;
 };
 
+// ratio^e of the log-log continuation (see Fftlog::ratio_pow, cp_fftlog_body.h): exp(e log ratio) for a positive, normal ratio, the library's pow otherwise
+__device__ __attribute__((noinline)) double ratio_pow(double ratio, int e) {
+    if (ratio > 2.2250738585072014e-308 && ratio < 1.7976931348623157e308) {
+        const double x = (double)e * cpmath::log_pos(ratio);
+        if (fabs(x) < 700.) return cpmath::exp_mid(x);
+    }
+    return pow(ratio, (double)e);
+}
+
 // pad(array, (L, R), extrap)[j] (fftlog.py:483-505)
 __device__ __forceinline__ double padded_sample(const double* a, int j, const PadSpec& S) {
     const int idx = j - S.in_left;
@@ -51,10 +61,10 @@ __device__ __forceinline__ double padded_sample(const double* a, int j, const Pa
     double v = a[cl];
     if (idx < 0) {
         if (S.ext_l == CP_EXTRAP_CONSTANT) v = S.val_l;
-        if (S.ext_l == CP_EXTRAP_LOGLOG) v = v * pow(a[1] / v, (double)idx);
+        if (S.ext_l == CP_EXTRAP_LOGLOG) v = v * ratio_pow(a[1] / v, idx);
     } else if (idx >= S.n) {
         if (S.ext_r == CP_EXTRAP_CONSTANT) v = S.val_r;
-        if (S.ext_r == CP_EXTRAP_LOGLOG) v = v / pow(a[S.n - 2] / v, (double)(idx - S.n + 1));
+        if (S.ext_r == CP_EXTRAP_LOGLOG) v = v / ratio_pow(a[S.n - 2] / v, idx - S.n + 1);
     }
     return v;
 }
@@ -285,12 +295,15 @@ __global__ __launch_bounds__(256) void column_direct_kernel(const ColumnArgs A) 
         double* ob = A.out + pr.rb * A.n_out;
         const double* post = A.post + (long long)pr.ker * A.S.npad;
         const double nan = __builtin_nan("");
+        double fpost[N1];      // (requested together: see fftlog_body.h, store_output)
+#pragma unroll
+        for (int m1 = 0; m1 < N1; ++m1) fpost[m1] = post[c + ROW * m1];
 #pragma unroll
         for (int m1 = 0; m1 < N1; ++m1) {
             const int m = c + ROW * m1;
             const int o = m - A.out_off;
             if (o < 0 || o >= A.n_out) continue;
-            const double f = post[m];
+            const double f = fpost[m1];
             oa[o] = sa.finite ? x[m1].re * f * sa.up : nan;
             if (pr.has_b) ob[o] = sb.finite ? x[m1].im * f * sb.up : nan;
         }
@@ -380,8 +393,13 @@ __global__ __launch_bounds__(256, 2) void row_kernel(const RowArgs A) {
             if (q) x[q] = cmul(x[q], w0[256 * q]);
         }
         Dft<16>::run(x);
+        {      // (the sixteen twiddles requested together: between the stores each one waited for the store before it -- the memory counter retires in order)
+            cplx tb[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) y[t + 256 * s] = cmul(x[s], cmul(fa, A.tw_b[(k1 * s) & mask_b]));
+            for (int s = 0; s < 16; ++s) tb[s] = A.tw_b[(k1 * s) & mask_b];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) y[t + 256 * s] = cmul(x[s], cmul(fa, tb[s]));
+        }
     }
 }
 

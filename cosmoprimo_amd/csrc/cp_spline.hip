@@ -71,9 +71,18 @@ __global__ __launch_bounds__(256) void spline_apply_kernel(const Args A) {
         const int nr = (int)((A.nrows - r0) < R ? (A.nrows - r0) : R);
         const int q0 = A.tile[4 * t], nqt = A.tile[4 * t + 1], tj0 = A.tile[4 * t + 2], span = A.tile[4 * t + 3];
         __syncthreads();
-        for (int r = 0; r < R; ++r) {
-            const double* yr = A.y + (r0 + (r < nr ? r : nr - 1)) * A.n + tj0;   // rows past the end repeat the last one (never stored)
-            for (int i = tid; i < span; i += 256) ylds[r * A.span_max + i] = yr[i];
+        // (the R rows' entries of a column requested together, then stored: row by row each load was waited for before the next was issued -- R memory round
+        // trips in a row per tile; the band weights eight at a time ahead of their multiply-adds: one by one they were a round trip per weight.  Same arithmetic,
+        // same order: tools/isa_waits.py)
+        for (int i0 = 0; i0 < span; i0 += 256) {
+            const int i = i0 + tid, ic = i < span ? i : span - 1;
+            double v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = A.y[(r0 + (r < nr ? r : nr - 1)) * A.n + tj0 + ic];   // rows past the end repeat the last one (never stored)
+            if (i < span) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ylds[r * A.span_max + i] = v[r];
+            }
         }
         __syncthreads();
         if (tid >= nqt) continue;
@@ -84,12 +93,20 @@ __global__ __launch_bounds__(256) void spline_apply_kernel(const Args A) {
         for (int r = 0; r < R; ++r) acc[r] = 0.;
         if (j0 >= 0) {
             const int base = j0 - tj0;
-            for (int jj = 0; jj < A.bw; ++jj) {
-                const double w = A.wb[(long long)jj * A.nq + q];
-                int j = base + jj;
-                j = j < span ? j : span - 1;  // padded band entries carry w = 0
+            constexpr int CHUNK = 8;
+            for (int jj0 = 0; jj0 < A.bw; jj0 += CHUNK) {
+                double w[CHUNK];
 #pragma unroll
-                for (int r = 0; r < R; ++r) acc[r] = fma(w, ylds[r * A.span_max + j], acc[r]);
+                for (int u = 0; u < CHUNK; ++u) w[u] = A.wb[(long long)(jj0 + u < A.bw ? jj0 + u : A.bw - 1) * A.nq + q];
+#pragma unroll
+                for (int u = 0; u < CHUNK; ++u) {
+                    if (jj0 + u < A.bw) {
+                        int j = base + jj0 + u;
+                        j = j < span ? j : span - 1;  // padded band entries carry w = 0
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r] = fma(w[u], ylds[r * A.span_max + j], acc[r]);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -132,12 +149,27 @@ __global__ __launch_bounds__(256) void spline_outer_kernel(const OuterArgs O) {
         const int nr = (int)((A.nrows - r0) < R ? (A.nrows - r0) : R);
         const int q0 = A.tile[4 * t], nqt = A.tile[4 * t + 1], tj0 = A.tile[4 * t + 2], span = A.tile[4 * t + 3];
         __syncthreads();   // the previous item's stores have read vlds / glds
-        for (int r = 0; r < R; ++r) {
-            const long long row = r0 + (r < nr ? r : nr - 1);
-            const double* yr = A.y + row * A.n + tj0;
-            for (int i = tid; i < span; i += 256) ylds[r * A.span_max + i] = yr[i];
-            // f = sqrt: sqrt(v g) is written as sqrt(v) sqrt(g) -- nq + nz roots per row instead of nq nz (both factors are >= 0 or the result is NaN either way)
-            for (int i = tid; i < nz; i += 256) glds[r * nz + i] = A.post_op == CP_SPLINE_POST_SQRT ? sqrt(O.g[row * nz + i]) : O.g[row * nz + i];
+        // (loads in batches, as in spline_apply_kernel: the R rows' entries of a column together, the band weights eight at a time)
+        for (int i0 = 0; i0 < span; i0 += 256) {
+            const int i = i0 + tid, ic = i < span ? i : span - 1;
+            double v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = A.y[(r0 + (r < nr ? r : nr - 1)) * A.n + tj0 + ic];
+            if (i < span) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) ylds[r * A.span_max + i] = v[r];
+            }
+        }
+        for (int i0 = 0; i0 < nz; i0 += 256) {
+            const int i = i0 + tid, ic = i < nz ? i : nz - 1;
+            double v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r] = O.g[(r0 + (r < nr ? r : nr - 1)) * nz + ic];
+            if (i < nz) {
+                // f = sqrt: sqrt(v g) is written as sqrt(v) sqrt(g) -- nq + nz roots per row instead of nq nz (both factors are >= 0 or the result is NaN either way)
+#pragma unroll
+                for (int r = 0; r < R; ++r) glds[r * nz + i] = A.post_op == CP_SPLINE_POST_SQRT ? sqrt(v[r]) : v[r];
+            }
         }
         __syncthreads();
         if (tid < nqt) {
@@ -148,12 +180,20 @@ __global__ __launch_bounds__(256) void spline_outer_kernel(const OuterArgs O) {
             for (int r = 0; r < R; ++r) acc[r] = 0.;
             if (j0 >= 0) {
                 const int base = j0 - tj0;
-                for (int jj = 0; jj < A.bw; ++jj) {
-                    const double w = A.wb[(long long)jj * A.nq + q];
-                    int j = base + jj;
-                    j = j < span ? j : span - 1;
+                constexpr int CHUNK = 8;
+                for (int jj0 = 0; jj0 < A.bw; jj0 += CHUNK) {
+                    double w[CHUNK];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r] = fma(w, ylds[r * A.span_max + j], acc[r]);
+                    for (int u = 0; u < CHUNK; ++u) w[u] = A.wb[(long long)(jj0 + u < A.bw ? jj0 + u : A.bw - 1) * A.nq + q];
+#pragma unroll
+                    for (int u = 0; u < CHUNK; ++u) {
+                        if (jj0 + u < A.bw) {
+                            int j = base + jj0 + u;
+                            j = j < span ? j : span - 1;
+#pragma unroll
+                            for (int r = 0; r < R; ++r) acc[r] = fma(w[u], ylds[r * A.span_max + j], acc[r]);
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -439,13 +479,21 @@ __global__ __launch_bounds__(256, 4) void linop_mid_mfma_kernel(const MidArgs A)
             }
         }
         double* ob = A.out + b * A.nq * A.ninner;
+        int jq[4][4];      // (the queries' band starts requested together, not one by one between the stores)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = q0 + 16 * i + g + 4 * r;
+                jq[i][r] = A.j0[q < A.nq ? q : A.nq - 1];
+            }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = q0 + 16 * i + g + 4 * r;
                 if (q >= A.nq) continue;
-                const bool nanq = A.j0[q] < 0;
+                const bool nanq = jq[i][r] < 0;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if (!colok[j]) continue;
@@ -722,8 +770,8 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
     // A dense copy (zero outside the bands) serves the matrix-core kernel, which treats the operator as a block-banded GEMM: a tile of 64
     // queries times the window of knots its bands cover.  That does (window / bandwidth) times the multiply-adds of the banded vector kernel
     // but at about five times its rate (the vector kernel reads one LDS word per multiply-add): the matrix cores are the default up to a
-    // factor 5 -- dense operators (quadrature weights, projectors: factor 1), splines between grids of similar density (factor 1.5 for 504 ->
-    // 1024 knots of a P(k) table), the wallish2018 splice from 3666 linear knots to 1024 log-spaced ones (factor 4.x: 0.98 against 1.18 ms) --
+    // factor 3.5 (5 until round 6) -- dense operators (quadrature weights, projectors: factor 1), splines between grids of similar density (factor 1.5 for 504 ->
+    // 1024 knots of a P(k) table), the wallish2018 splice from 3666 linear knots to 1024 log-spaced ones was one of them at factor 4.x (0.98 against 1.18 ms) until the vector kernel caught up --
     // and a measurement option otherwise (CP_SPLINE_PATH_MFMA).
     const size_t dense_bytes = (size_t)p->n_pad * p->nq_pad * sizeof(double);
     bool dense = keep_dense && dense_bytes <= ((size_t)256 << 20);
@@ -763,11 +811,14 @@ static int plan_from_dense(cp_spline_plan** out, int n, int nq, const double* w,
 #define CP_LINOP_SUB_FRACTION 0.67      // (tools/ab_linop_sub.sh measures 0: never)
 #endif
         p->sub_windows = work_sub <= CP_LINOP_SUB_FRACTION * work;
-        p->prefer_dense = n >= 16 && work <= 5. * (double)nq * bw;
+        // (round 6: the vector kernel requests its rows and weights in batches and runs 1.9-2.7 times faster -- tools/bench_linop.py: 8.9 -> 4.8, 2.6 -> 1.4,
+        // 1.06 -> 0.64, 1.19 -> 0.44 ms --, the matrix cores still win at factors 1 - 1.5 (3.9, 1.13, 0.45 ms) and lose at the splice's 4.x (0.50 ms): 3.5)
+        p->prefer_dense = n >= 16 && work <= 3.5 * (double)nq * bw;
         // a plan that will run on the vector route keeps no large dense copy (1024 knots -> 16 384 queries: 134 MB of device memory and a
         // blocking upload per plan); small ones stay, for the measurement option and for cp_tables_rows
         const bool valu_fits = (size_t)4 * span_max * sizeof(double) <= 160 * 1024;
-        if (!p->prefer_dense && valu_fits && dense_bytes > ((size_t)16 << 20)) dense = false;
+        const bool near_the_choice = n >= 16 && work <= 5. * (double)nq * bw;      // (the dense copy stays where the matrix cores were the choice until round 6)
+        if (!p->prefer_dense && !near_the_choice && valu_fits && dense_bytes > ((size_t)16 << 20)) dense = false;
     }
     if (dense) {
         wd.assign((size_t)p->n_pad * p->nq_pad, 0.);

@@ -151,8 +151,21 @@ __global__ __launch_bounds__(256) void spline_rows_kernel(const RowsArgs A) {
         if (A.out_m) {
             if (A.pairs) {
                 double2* dst = reinterpret_cast<double2*>(A.out_m) + row * T.n_src + T.w0;
-                if (live)
-                    for (int i = l; i < nw; i += LPR) dst[i] = double2{src[i], buf[i]};
+                if (live) {      // (the row's values four at a time ahead of their stores: one by one each load waited behind the store of the pair before it)
+                    for (int i0 = l; i0 < nw; i0 += 4 * LPR) {
+                        double y[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u * LPR;
+                            y[u] = src[i < nw ? i : nw - 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = i0 + u * LPR;
+                            if (i < nw) dst[i] = double2{y[u], buf[i]};
+                        }
+                    }
+                }
                 continue;
             }
             double* dst = A.out_m + row * T.n_src + T.w0;
