@@ -57,10 +57,14 @@ __global__ __launch_bounds__(64) void coefficients_kernel(const Args A, CosmoCon
     }
     const long long ic = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (ic >= A.ncosmo) return;
-    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
     double pw[CP_PK_NPARAMS];
 #pragma unroll
-    for (int i = 0; i < CP_PK_NPARAMS; ++i) pw[i] = with_pw ? (A.pw[i].ptr ? A.pw[i].ptr[ic] : A.pw[i].value) : 0.;
+    for (int i = 0; i < CP_PK_NPARAMS; ++i) {      // (one address per parameter -- the array's entry or the scalar among the arguments -- and the loads back to back, in
+        const double* q = A.pw[i].ptr ? A.pw[i].ptr + ic : &A.pw[i].value;      // front of the background parameters': behind a test per parameter they were a memory
+        const double raw = *q;                                                   // round trip each, a fifth of this kernel's 21 us)
+        pw[i] = with_pw ? raw : 0.;
+    }
+    const Cosmo c = load_cosmo(A.bg, ic, A.second_is_omega_m, A.ncdm_tab, A.ncdm_knots, A.nsp);
     out[ic] = cosmo_consts(c, with_pw ? pw : nullptr, A.engine);
 }
 
