@@ -118,8 +118,21 @@ __global__ __launch_bounds__(256) void interp_table_kernel(const cpit::Pair* __r
     const double x0 = xf[0].x, xn = xf[n - 1].x;
     const double xfirst = xf[first].x;
     bool outside = false;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += (long long)gridDim.x * blockDim.x)
-        out[i] = (real)cpit::interp_sample<LAW>(xf, n, first, a, b, x0, xfirst, xn, (double)x[i], &outside);      // (cp_interp_table.h)
+    constexpr int U = 4;      // samples of a thread in flight together (cp_interp_table.h: interp_samples)
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += U * stride) {
+        double v[U], r[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            live[u] = i + u * stride < nx;
+            v[u] = (double)x[live[u] ? i + u * stride : i];
+        }
+        cpit::interp_samples<LAW, U>(xf, n, first, a, b, x0, xfirst, xn, v, live, r, &outside);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (live[u]) out[i + u * stride] = (real)r[u];
+    }
     if (outside && flag) atomicOr(flag, 1);      // flag: null when the caller did not ask (cp_interp_table_apply with outside == NULL)
 }
 

@@ -110,4 +110,51 @@ CPIT_HD double interp_sample(const Pair* __restrict__ xf, long long n, long long
     return r;
 }
 
+// The same for U samples at once (the grid-stride loop of interp_table_kernel): the U guessed intervals are requested together -- one sample at a time a thread
+// waited for its sample, then for the two knots its guess pointed at, then for its store, three memory round trips in a row per sample.  The arithmetic of a
+// sample is interp_sample's, statement for statement; samples outside the law's part of the table (leading knots, outside, the last knot) go through it.
+template <int LAW, int U>
+CPIT_HD void interp_samples(const Pair* __restrict__ xf, long long n, long long first, double a, double b, double x0, double xfirst, double xn, const double* v,
+                            const bool* live, double* r, bool* outside) {
+    long long lo[U];
+    Pair k0[U], k1[U];
+    bool fast[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        fast[u] = live[u] && v[u] >= x0 && v[u] < xn && !(first > 0 && v[u] < xfirst) && n >= 2;
+        const double t = LAW == 2 ? log2_guess(fast[u] ? v[u] : xfirst) : (fast[u] ? v[u] : xfirst);
+        double g = (t - a) * b;
+        const double gmax = (double)(n - 2 - first);
+        g = g > 0. ? g : 0.;
+        g = g < gmax ? g : gmax;
+        lo[u] = n >= 2 ? first + (long long)g : 0;
+        k0[u] = xf[lo[u]];
+        k1[u] = xf[n >= 2 ? lo[u] + 1 : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        if (!fast[u]) {
+            r[u] = interp_sample<LAW>(xf, n, first, a, b, x0, xfirst, xn, v[u], outside);
+            continue;
+        }
+        const double vv = v[u];
+        long long l = lo[u];
+        Pair p0 = k0[u], p1 = k1[u];
+        while (l > first && p0.x > vv) { --l; p1 = p0; p0 = xf[l]; }
+        while (l < n - 2 && p1.x <= vv) { ++l; p0 = p1; p1 = xf[l + 1]; }
+        if (p0.x == vv) {
+            r[u] = p0.y;
+            continue;
+        }
+        const double slope = (p1.y - p0.y) / (p1.x - p0.x);
+        double res = slope * (vv - p0.x) + p0.y;
+        if (res != res) {
+            res = slope * (vv - p1.x) + p1.y;
+            if (res != res && p0.y == p1.y) res = p0.y;
+        }
+        r[u] = res;
+    }
+}
+
 }  // namespace cpit
