@@ -1043,7 +1043,10 @@ __global__ __launch_bounds__(256, 3) void sigma8_normalise_kernel(const Function
     double acc = 0.;
     __shared__ double kept[4 * PER_LANE * 64];
     double* pks = kept + (threadIdx.x >> 6) * (PER_LANE * 64) + lane;      // sample i of this lane at pks[64 i]
-#pragma unroll 2
+#ifndef CP_SIGMA8_UNROLL
+#define CP_SIGMA8_UNROLL 2
+#endif
+#pragma unroll CP_SIGMA8_UNROLL
     for (int i = 0; i < PER_LANE; ++i) {
         const int j = lane + 64 * i;
         const double kh = S.k[j], ln_kh = S.ln_k[j];
