@@ -63,6 +63,9 @@ struct Args {
 
 // TIME: the integrand carries 1 / (1 + z) and the result is (T_last - spline(z)) / h / (Gyr per Mpc): DefaultBackground.time / age
 // (cosmology.py:2000-2025), same RK4 == Simpson scan and natural spline as the distances, on the 400-knot grid.
+#ifndef CP_BG_SORT_INTERVALS      // 1: the samples of a workgroup dealt to its threads in the order of their intervals (see bg_kernel)
+#define CP_BG_SORT_INTERVALS 1
+#endif
 #ifndef CP_BG_LEAN_ORDINATE      // 0: E^2 term by term in the reference's units (cp_cosmo_common.h: inv_efunc_ln), for measurements
 #define CP_BG_LEAN_ORDINATE 1
 #endif
@@ -98,7 +101,50 @@ __global__ __launch_bounds__(256) void bg_kernel(const Args A) {
     cpmath::fill_math_tables(&mt);
     __syncthreads();
     const long long nsamp = A.ncosmo * A.nz;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+#if CP_BG_SORT_INTERVALS
+    // The quadrature walks the knots up to a sample's interval k (and a fixed number beyond): a wave is busy for the LARGEST k of its 64 samples.  The
+    // workgroup's 256 samples are dealt to its threads in the order of their intervals (a counting sort through LDS: a histogram by atomics, its prefix sum,
+    // the ranks), so that a wave holds samples of similar redshift -- for redshifts uniform in (0, 3) the four waves then walk 8, 16, 24 and 32 knots forward
+    // instead of 32 each.  A sample is computed as before, by another lane; results land at the samples' own places.
+    if (!TIME && blockDim.x == 256 && (A.kind == CP_BG_COMOVING_RADIAL || A.kind == CP_BG_ANGULAR_DIAMETER || A.kind == CP_BG_COMOVING_TRANSVERSE ||
+                                       A.kind == CP_BG_LUMINOSITY)) {
+        __shared__ int hist[128];
+        __shared__ short order[256];
+        int bin = 127;      // samples past the end of the batch, outside the knots or NaN: last (they leave the kernel at once)
+        if (i < nsamp) {
+            const double zn = A.z[A.z_shared ? i % A.nz : i];
+            if (zn >= T.zc[0] && zn <= T.zc[NK - 1]) {
+                int lo = 0, hi = NK - 1;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (zn >= T.zc[mid]) lo = mid;
+                    else hi = mid;
+                }
+                bin = lo < 126 ? lo : 126;
+            }
+        }
+        if (threadIdx.x < 128) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const int rank = atomicAdd(&hist[bin], 1);
+        __syncthreads();
+        if (threadIdx.x < 64) {      // exclusive prefix sum of the 128 counts by one wave: two bins per lane, a scan over the lanes
+            const int c0 = hist[2 * threadIdx.x], c1 = hist[2 * threadIdx.x + 1];
+            int sum = c0 + c1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(sum, off);
+                if ((int)threadIdx.x >= off) sum += up;
+            }
+            hist[2 * threadIdx.x] = sum - c0 - c1;
+            hist[2 * threadIdx.x + 1] = sum - c1;
+        }
+        __syncthreads();
+        order[hist[bin] + rank] = (short)threadIdx.x;
+        __syncthreads();
+        i = (long long)blockIdx.x * blockDim.x + order[threadIdx.x];
+    }
+#endif
     if (i >= nsamp) return;
     const long long ic = i / A.nz, iz = i - ic * A.nz;
     const Cosmo c = load_cosmo(A.p, ic, A.second_is_omega_m, A.ncdm_tab, ncdm_knots, NCDM ? A.nsp : 0);
