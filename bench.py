@@ -122,7 +122,7 @@ def eh_parameters(n, seed, torch, dev):
     return {name: torch.as_tensor(v, device=dev) for name, v in par.items()}
 
 
-def config3(cp, torch, dev, ncosmo=10000, reps=5):
+def config3(cp, torch, dev, ncosmo=10000, reps=20):
     """sigma_rz on 256 r x 64 z for a batch of EH cosmologies (method fftlog, nk = 1024): cosmologies/s, HBM fraction on the
     131 072 + 80 algorithmic bytes per cosmology (10 parameters in, 256 x 64 float64 out)."""
     import warnings
@@ -146,7 +146,7 @@ def config3(cp, torch, dev, ncosmo=10000, reps=5):
             'parity_spot_check': {'max_rel_err': err, 'tolerance': checks.TOLERANCES['config3'], 'unit_checked': 'cosmology %d, 256 r x 64 z, vs oracle' % i}}
 
 
-def config3b(cp, torch, dev, ncosmo=10000, reps=5):
+def config3b(cp, torch, dev, ncosmo=10000, reps=10):
     """sigma_rz on 256 r x 64 z for a batch of TABULATED P(k, z) (500 k x 30 z per cosmology) through
     PowerSpectrumInterpolator2D(k, z, pk=(B, nk, nz)).sigma_rz: cosmologies/s and the HBM fraction on the 120 000 + 131 072 algorithmic bytes
     per cosmology.  The tables are the reference's (tests/golden/sigma.npz: the EH98 table of its own test) times one amplitude per cosmology."""
@@ -349,7 +349,7 @@ def _config5_valu_roofline(samples_per_s, z_samples=None):
     return out
 
 
-def config5(torch, dev, om, w0, wa, zz, reps=5, spot_check=True):
+def config5(torch, dev, om, w0, wa, zz, reps=20, spot_check=True):
     from cosmoprimo_amd import background
     n = int(zz.numel())
     fn = lambda: background.distance('comoving_radial_distance', zz[:, None], dict(w0_fld=w0, wa_fld=wa), Omega_m=om, per_cosmology_z=True)      # noqa: E731
